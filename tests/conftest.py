@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """The unmodified reference (only present in the build container)."""
+    from oracle import ref_loader
+    if not ref_loader.available():
+        pytest.skip("reference tree not present")
+    r = ref_loader.load()
+    return r
