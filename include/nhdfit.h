@@ -1,0 +1,192 @@
+/*
+ * nhdfit.h - C ABI of libnhdfit.so: the MI355X (gfx950) node filter-and-score engine that
+ * replaces the per-node Python loop of the NHD scheduler's Matcher.FindNode.
+ *
+ * Boundary.  The reference has exactly one call site for this path,
+ *     match = self.matcher.FindNode(filt_nodes, top)          nhd/NHDScheduler.py:277
+ * and is pure Python, so the binding a maintainer adds is a ctypes stub; the
+ * in-tree one is nhd_amd/_lib.py and the Matcher-compatible class is nhd_amd/matcher.py.
+ *
+ * Conventions: every function returns 0 on success or a negative NHDFIT_E_* code and stores a
+ * message retrievable with nhdfit_last_error(); nothing throws across the boundary and nothing
+ * calls abort().  The caller owns every host buffer; the library copies what it needs before
+ * returning.  One context = one GPU = one caller thread at a time (the reference calls FindNode
+ * from its single scheduler thread only, nhd/NHDScheduler.py:43,277).  Multi-GPU = one process
+ * (one context) per GPU, joined by nhdfit_comm_init (RCCL all-reduce(max) of packed scores).
+ *
+ * There is deliberately no CPU implementation behind this ABI: if the HIP runtime or a gfx950
+ * device is missing, nhdfit_create fails.
+ */
+#ifndef NHDFIT_H
+#define NHDFIT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NHDFIT_ABI_VERSION        1
+#define NHDFIT_MAX_GROUPS         4      /* proc groups per pod (G)                               */
+#define NHDFIT_MAX_NUMA           2      /* NUMA nodes (= sockets, nhd/Node.py:336) per node (U)  */
+#define NHDFIT_MAX_CORES_PER_NUMA 64     /* physical cores per socket (one uint64 mask)           */
+#define NHDFIT_MAX_GPUS           32     /* GPUs per node (one uint32 mask), <= 16 per NUMA node  */
+#define NHDFIT_MAX_NICS_PER_NUMA  16
+#define NHDFIT_MAX_SWITCHES       14     /* distinct PCIe switches per node                       */
+#define NHDFIT_MAX_CLASSES        16     /* distinct NIC capacity values cluster-wide             */
+#define NHDFIT_TILE               64     /* pods per tile = wavefront width                       */
+#define NHDFIT_GLIMIT_NONE        255    /* pool without a GPU-per-switch limit (NUMA mode)       */
+
+#define NHDFIT_OK              0
+#define NHDFIT_E_INVAL        -1
+#define NHDFIT_E_NODEVICE     -2
+#define NHDFIT_E_HIP          -3
+#define NHDFIT_E_NOMEM        -4
+#define NHDFIT_E_STATE        -5
+#define NHDFIT_E_LIMIT        -6         /* a compile-time capacity above was exceeded            */
+#define NHDFIT_E_RCCL         -7
+
+/* node flags (plane2.flags) */
+#define NHDFIT_NF_MAINTENANCE  0x01u     /* Node.maintenance          nhd/Matcher.py:71           */
+#define NHDFIT_NF_ACTIVE       0x02u     /* Node.active               nhd/NHDScheduler.py:242     */
+#define NHDFIT_NF_SMT          0x04u     /* Node.smt_enabled          nhd/Node.py:225             */
+#define NHDFIT_NF_HAS_GPU      0x08u     /* len(Node.gpus) > 0        nhd/Matcher.py:411          */
+
+/* request flags */
+#define NHDFIT_RF_INITIAL_FILTER 0x01u   /* apply InitialNodeFilter (active && groups intersect), nhd/NHDScheduler.py:235-247 */
+
+/* map types = values of nhd.CfgTopology.TopologyMapType (nhd/CfgTopology.py:41-45) */
+#define NHDFIT_MAP_NUMA 1u
+#define NHDFIT_MAP_PCI  2u
+
+/* ---- packed node state: five structure-of-array planes of 16 bytes per node --------------- */
+typedef struct { uint64_t t0[NHDFIT_MAX_NUMA]; } nhdfit_plane0;   /* thread-0 "core unused" bit per physical core of socket u
+                                                                      (logical id u*cores_per_proc+i), nhd/Node.py:250-264 */
+typedef struct { uint64_t t1[NHDFIT_MAX_NUMA]; } nhdfit_plane1;   /* thread-1 (SMT sibling id + num_cores); all ones without SMT */
+typedef struct {
+    uint32_t gpu_free;      /* bit g: Node.gpus[g] unused                  nhd/Node.py:456-462 */
+    uint32_t gpu_numa1;     /* bit g: Node.gpus[g].numa_node == 1                               */
+    int32_t  hp_free;       /* Node.mem.free_hugepages_gb                  nhd/Matcher.py:78   */
+    uint32_t flags;         /* NHDFIT_NF_*                                                      */
+} nhdfit_plane2;
+typedef struct {
+    uint64_t groups;        /* interned NHD_GROUP set                      nhd/Node.py:308-321 */
+    uint16_t sig_numa[NHDFIT_MAX_NUMA];   /* NIC signature id of NUMA u, all NICs in one pool   */
+    uint16_t sig_pci[NHDFIT_MAX_NUMA];    /* ... one pool per PCIe switch with its free-GPU cap */
+} nhdfit_plane3;
+typedef struct {
+    double   busy_time;     /* Node.busy_time (monotonic seconds)          nhd/Node.py:843-850 */
+    uint64_t reserved;
+} nhdfit_plane4;
+
+/* cold per-node detail, gathered only for winners (mapping step, nhd/Matcher.py:423-452) */
+typedef struct {
+    uint8_t nic_cnt[NHDFIT_MAX_NUMA];
+    uint8_t sw_free[NHDFIT_MAX_SWITCHES];                          /* free GPUs on local switch id s, nhd/Node.py:266-273 */
+    uint8_t nic_cls[NHDFIT_MAX_NUMA][NHDFIT_MAX_NICS_PER_NUMA];    /* capacity class of NIC (numa, idx)                   */
+    uint8_t nic_sw[NHDFIT_MAX_NUMA][NHDFIT_MAX_NICS_PER_NUMA];     /* local switch id of NIC (numa, idx), nhd/Node.py:275 */
+    uint8_t numa_nodes;                                            /* Node.numa_nodes (1 or 2)                            */
+    uint8_t pad[15];
+} nhdfit_detail;                                                   /* 96 bytes */
+
+/* ---- NIC signature dictionary (cluster-wide, interned by the host packer) ----------------- */
+typedef struct { uint8_t cls; uint8_t cnt; } nhdfit_cc;           /* cnt NICs (capped at NHDFIT_MAX_GROUPS) of capacity class cls */
+
+/* ---- one pending pod: the digest of a CfgTopology (nhd/CfgTopology.py:126-232) ------------ */
+typedef struct {
+    uint32_t n_groups;                       /* len(top.proc_groups), 1..NHDFIT_MAX_GROUPS                         */
+    uint32_t map_type;                       /* TopologyMapType value; anything but NUMA/PCI never matches (Matcher.py:45-47) */
+    int32_t  hugepages_gb;                   /* top.hugepages_gb                                                   */
+    uint32_t flags;                          /* NHDFIT_RF_*                                                        */
+    uint64_t groups;                         /* interned pod node-group set (K8SMgr.py:152-165); used with RF_INITIAL_FILTER */
+    uint16_t gpus[NHDFIT_MAX_GROUPS];        /* GetTotalGpusRequested, CfgTopology.py:199                          */
+    uint16_t cpu_smt[NHDFIT_MAX_GROUPS];     /* physical cores group i needs on an SMT node   (Matcher.py:178-196) */
+    uint16_t cpu_nosmt[NHDFIT_MAX_GROUPS];   /* ... on a non-SMT node                                              */
+    uint16_t misc_smt;                       /* pod-level misc cores on an SMT node (always halved, Matcher.py:198)*/
+    uint16_t misc_nosmt;
+    uint32_t reserved;
+    double   rx[NHDFIT_MAX_GROUPS];          /* GetTotalNICsRequested, CfgTopology.py:219-232 (Gb/s, Python float) */
+    double   tx[NHDFIT_MAX_GROUPS];
+    uint64_t reserved2;
+} nhdfit_req;                                /* 128 bytes */
+
+/* ---- resource mapping of one placement = the dict FindNode returns (Matcher.py:452) ------- */
+typedef struct {
+    int8_t gpu[NHDFIT_MAX_GROUPS];           /* mapping['gpu'][i]  : NUMA node of group i       */
+    int8_t cpu[NHDFIT_MAX_GROUPS + 1];       /* mapping['cpu']     : ... plus the misc cores'   */
+    int8_t nic_numa[NHDFIT_MAX_GROUPS];      /* mapping['nic'][i][0]                            */
+    int8_t nic_idx[NHDFIT_MAX_GROUPS];       /* mapping['nic'][i][1] : per-NUMA NIC ordinal     */
+    int8_t valid;                            /* 0 = pod not placed                              */
+    int8_t pad[2];
+} nhdfit_mapping;                            /* 20 bytes */
+
+typedef struct {
+    uint64_t launches;          /* fit_score kernel launches measured so far                    */
+    double   fit_ms_total;      /* sum of their HIP-event durations (ms)                        */
+    double   fit_ms_last;
+    double   digest_ms_last;    /* request-digest kernel of the last find                       */
+    double   step_ms_last;      /* whole enqueue-to-scores-ready span of the last find          */
+    uint64_t evals_last;        /* pod x node evaluations of the last find                      */
+    uint64_t bytes_last;        /* algorithmic bytes of the last fit_score launch */
+    uint32_t nodes, nsig, ncls, lds_bytes;
+} nhdfit_stats;
+
+typedef struct nhdfit_ctx nhdfit_ctx;
+
+/* score word: 0 = no feasible node, else bit63 = preference hit (GPU-less node for a GPU-less pod,
+ * Matcher.py:401-413), low 63 bits = 0x7FFFFFFFFFFFFFFF - global node index, so that
+ * max(score) = first feasible node in candidate order with the preference applied (Matcher.py:415-421). */
+#define NHDFIT_SCORE_NONE 0ull
+#define NHDFIT_SCORE_INDEX(s) (0x7FFFFFFFFFFFFFFFull - ((s) & 0x7FFFFFFFFFFFFFFFull))
+
+int  nhdfit_abi_version(void);
+int  nhdfit_device_count(void);
+int  nhdfit_create(int device_id, nhdfit_ctx** out);
+void nhdfit_destroy(nhdfit_ctx* ctx);
+const char* nhdfit_last_error(nhdfit_ctx* ctx);            /* ctx may be NULL: last error of a failed create */
+
+/* NIC capacity classes + signature dictionary (CSR: sig -> pools -> (class,count) pairs).
+ * Signature 0 must be the empty signature.  May be called again when the dictionary grows. */
+int nhdfit_set_dictionary(nhdfit_ctx* ctx, const double* caps, uint32_t ncls,
+                          const uint32_t* sig_off, uint32_t nsig,
+                          const uint32_t* pool_off, const uint8_t* pool_glimit, uint32_t npools,
+                          const nhdfit_cc* cc, uint32_t ncc);
+
+/* (Re)size the device mirror to `capacity` nodes of which this rank's shard starts at global
+ * index `global_base` (candidate order of the whole cluster; used for the score word). */
+int nhdfit_reserve_nodes(nhdfit_ctx* ctx, uint32_t capacity, uint64_t global_base);
+/* Full or delta upload of `count` node records starting at local index `first`. */
+int nhdfit_upload_nodes(nhdfit_ctx* ctx, uint32_t first, uint32_t count,
+                        const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2,
+                        const nhdfit_plane3* p3, const nhdfit_plane4* p4, const nhdfit_detail* detail);
+int nhdfit_set_node_count(nhdfit_ctx* ctx, uint32_t n_nodes);
+
+/* Evaluate P pending pods against the mirror (mode A: every pod sees the same snapshot).
+ *   now        monotonic clock sampled once per call (IsBusy, nhd/Node.py:847-850)
+ *   cand       optional, chunk-major [ceil(n/64)][P]: restrict pod p to nodes whose bit is set
+ *              (the dict the scheduler passes to FindNode may be a filtered subset)
+ *   score_out  P score words (after the all-reduce when a communicator is attached)
+ *   bitmap_out optional, chunk-major [ceil(n/64)][P] feasibility words of THIS shard
+ *   map_out    optional, P mappings (valid only for winners owned by this shard) */
+int nhdfit_find(nhdfit_ctx* ctx, const nhdfit_req* reqs, uint32_t P, double now,
+                const uint64_t* cand, uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out);
+
+/* Benchmark / pipelined form: requests are staged once, then each step only enqueues kernels
+ * (request digest -> fit_score -> [all-reduce] -> winner mapping) on the context's stream. */
+int nhdfit_stage_requests(nhdfit_ctx* ctx, const nhdfit_req* reqs, uint32_t P);
+int nhdfit_enqueue_step(nhdfit_ctx* ctx, double now);
+int nhdfit_sync(nhdfit_ctx* ctx);
+int nhdfit_fetch(nhdfit_ctx* ctx, uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out);
+
+/* Multi-GPU: rank 0 creates the id, every rank (one process per GPU) joins. */
+int nhdfit_comm_unique_id(void* id128);
+int nhdfit_comm_init(nhdfit_ctx* ctx, int nranks, int rank, const void* id128);
+int nhdfit_comm_destroy(nhdfit_ctx* ctx);
+
+int nhdfit_get_stats(nhdfit_ctx* ctx, nhdfit_stats* out);
+int nhdfit_reset_stats(nhdfit_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NHDFIT_H */

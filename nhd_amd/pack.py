@@ -1,0 +1,434 @@
+"""Host-side packing: reference objects -> the HBM layout of include/nhdfit.h.
+
+* ``Packer.pack_nodes(nl)``   Dict[str, Node]  -> :class:`NodeTable` (five 16-byte SoA planes + the
+  cold per-node detail record).  Nodes are read purely by attribute,
+  so live ``nhd.Node.Node`` objects and the stand-ins of :mod:`nhd_amd.refmodel` both work.
+* ``Packer.digest(top, pod_groups)``   CfgTopology -> one ``nhdfit_req`` record.
+* ``Packer.planes_from_spec(spec)``    vectorised equivalent of pack_nodes for synthetic clusters.
+
+The packer also owns the cluster-wide interning dictionaries the kernels index into:
+capacity classes (distinct f64 NIC capacities, computed here with the reference's own Python
+expression ``speed * 0.9`` so the bits are identical), NIC signatures (which NIC pools a NUMA node
+offers) and node-group names (bit ids of a uint64).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+MAX_GROUPS = 4
+MAX_NUMA = 2
+MAX_CORES_PER_NUMA = 64
+MAX_GPUS = 32
+MAX_NICS_PER_NUMA = 16
+MAX_SWITCHES = 14
+MAX_CLASSES = 16
+GLIMIT_NONE = 255
+TILE = 64
+
+NF_MAINTENANCE, NF_ACTIVE, NF_SMT, NF_HAS_GPU = 1, 2, 4, 8
+RF_INITIAL_FILTER = 1
+
+NIC_BW_AVAIL_PERCENT = 0.9      # nhd/Node.py:18 (ENABLE_SHARING is False, nhd/Node.py:20)
+
+P0 = np.dtype([("t0", "<u8", (2,))])
+P1 = np.dtype([("t1", "<u8", (2,))])
+P2 = np.dtype([("gpu_free", "<u4"), ("gpu_numa1", "<u4"), ("hp_free", "<i4"), ("flags", "<u4")])
+P3 = np.dtype([("groups", "<u8"), ("sig_numa", "<u2", (2,)), ("sig_pci", "<u2", (2,))])
+P4 = np.dtype([("busy_time", "<f8"), ("reserved", "<u8")])
+DETAIL = np.dtype([("nic_cnt", "u1", (2,)), ("sw_free", "u1", (MAX_SWITCHES,)),
+                   ("nic_cls", "u1", (2, MAX_NICS_PER_NUMA)), ("nic_sw", "u1", (2, MAX_NICS_PER_NUMA)),
+                   ("numa_nodes", "u1"), ("pad", "u1", (15,))])
+REQ = np.dtype([("n_groups", "<u4"), ("map_type", "<u4"), ("hugepages_gb", "<i4"), ("flags", "<u4"),
+                ("groups", "<u8"), ("gpus", "<u2", (4,)), ("cpu_smt", "<u2", (4,)), ("cpu_nosmt", "<u2", (4,)),
+                ("misc_smt", "<u2"), ("misc_nosmt", "<u2"), ("reserved", "<u4"),
+                ("rx", "<f8", (4,)), ("tx", "<f8", (4,)), ("reserved2", "<u8")])
+MAPPING = np.dtype([("gpu", "i1", (4,)), ("cpu", "i1", (5,)), ("nic_numa", "i1", (4,)), ("nic_idx", "i1", (4,)),
+                    ("valid", "i1"), ("pad", "i1", (2,))])
+CC = np.dtype([("cls", "u1"), ("cnt", "u1")])
+assert (P0.itemsize, P1.itemsize, P2.itemsize, P3.itemsize, P4.itemsize) == (16,) * 5
+assert DETAIL.itemsize == 96 and REQ.itemsize == 128 and MAPPING.itemsize == 20
+
+ALL_ONES = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+class UnsupportedNode(ValueError):
+    """The node's topology exceeds a compile-time capacity of the device layout (include/nhdfit.h)."""
+
+
+@dataclass
+class NodeTable:
+    names: List[str]
+    p0: np.ndarray
+    p1: np.ndarray
+    p2: np.ndarray
+    p3: np.ndarray
+    p4: np.ndarray
+    detail: np.ndarray
+
+    @property
+    def n(self) -> int:
+        return len(self.p0)
+
+    def slice(self, lo: int, hi: int) -> "NodeTable":
+        return NodeTable(self.names[lo:hi] if self.names else [], self.p0[lo:hi], self.p1[lo:hi], self.p2[lo:hi],
+                         self.p3[lo:hi], self.p4[lo:hi], self.detail[lo:hi])
+
+
+def empty_table(n: int) -> NodeTable:
+    t = NodeTable([], np.zeros(n, P0), np.zeros(n, P1), np.zeros(n, P2), np.zeros(n, P3), np.zeros(n, P4),
+                  np.zeros(n, DETAIL))
+    return t
+
+
+class Packer:
+    def __init__(self):
+        self.caps: List[float] = []
+        self._cap_index: Dict[float, int] = {}
+        self.sigs: List[tuple] = [()]                  # sig 0 = no NIC pool at all
+        self._sig_index: Dict[tuple, int] = {(): 0}
+        self.group_names: List[str] = []
+        self._group_index: Dict[str, int] = {}
+        self.dict_version = 0                          # bumped whenever caps / sigs grow
+
+    # ---- interning ------------------------------------------------------------------------
+    def cap_class(self, cap) -> int:
+        cap = float(cap)
+        k = self._cap_index.get(cap)
+        if k is None:
+            if len(self.caps) >= MAX_CLASSES:
+                raise UnsupportedNode("more than %d distinct NIC capacities in the cluster" % MAX_CLASSES)
+            k = len(self.caps)
+            self.caps.append(cap)
+            self._cap_index[cap] = k
+            self.dict_version += 1
+        return k
+
+    def sig_id(self, pools: Iterable[Tuple[int, Tuple[Tuple[int, int], ...]]]) -> int:
+        key = tuple(sorted(pools))
+        k = self._sig_index.get(key)
+        if k is None:
+            if len(self.sigs) >= 0xFFFF:
+                raise UnsupportedNode("NIC signature dictionary overflow")
+            k = len(self.sigs)
+            self.sigs.append(key)
+            self._sig_index[key] = k
+            self.dict_version += 1
+        return k
+
+    def group_bits(self, names: Iterable[str]) -> int:
+        bits = 0
+        for nm in names:
+            k = self._group_index.get(nm)
+            if k is None:
+                if len(self.group_names) >= 64:
+                    raise UnsupportedNode("more than 64 distinct node-group names")
+                k = len(self.group_names)
+                self.group_names.append(nm)
+                self._group_index[nm] = k
+            bits |= 1 << k
+        return bits
+
+    def dictionary_arrays(self):
+        """CSR form for nhdfit_set_dictionary."""
+        sig_off, pool_off, glimit, cc = [0], [0], [], []
+        for sig in self.sigs:
+            for (gl, pairs) in sig:
+                glimit.append(gl)
+                cc.extend(pairs)
+                pool_off.append(len(cc))
+            sig_off.append(len(glimit))
+        caps = np.asarray(self.caps if self.caps else [0.0], dtype="<f8")
+        ccarr = np.zeros(max(1, len(cc)), CC)
+        for i, (c, n) in enumerate(cc):
+            ccarr[i] = (c, n)
+        return (caps, np.asarray(sig_off, "<u4"), np.asarray(pool_off, "<u4"),
+                np.asarray(glimit if glimit else [0], "u1"), ccarr, len(self.caps), len(self.sigs), len(glimit), len(cc))
+
+    # ---- node side ------------------------------------------------------------------------
+    def pack_node_into(self, node, t: NodeTable, i: int) -> None:
+        U = int(node.numa_nodes)
+        if U < 1 or U > MAX_NUMA:
+            raise UnsupportedNode(f"node {node.name}: {U} NUMA nodes (supported: 1..{MAX_NUMA})")
+        cpp = int(node.cores_per_proc)
+        if cpp > MAX_CORES_PER_NUMA:
+            raise UnsupportedNode(f"node {node.name}: {cpp} physical cores per socket (> {MAX_CORES_PER_NUMA})")
+        smt = bool(node.smt_enabled)
+        cores = node.cores
+        t0 = [0, 0]
+        t1 = [0, 0]
+        for u in range(U):
+            m0 = m1 = 0
+            for b in range(cpp):
+                c = cores[u * cpp + b]
+                if c.socket != u:
+                    raise UnsupportedNode(f"node {node.name}: core {u * cpp + b} is on socket {c.socket}, expected {u}")
+                if not c.used:
+                    m0 |= 1 << b
+                if smt and not cores[c.sibling].used:
+                    m1 |= 1 << b
+            t0[u] = m0
+            t1[u] = m1 if smt else 0xFFFFFFFFFFFFFFFF
+        t.p0[i]["t0"] = t0
+        t.p1[i]["t1"] = t1
+
+        gpus = node.gpus
+        if len(gpus) > MAX_GPUS:
+            raise UnsupportedNode(f"node {node.name}: {len(gpus)} GPUs (> {MAX_GPUS})")
+        sw_local: Dict[int, int] = {}
+
+        def local_sw(sw) -> int:
+            k = sw_local.get(sw)
+            if k is None:
+                if len(sw_local) >= MAX_SWITCHES:
+                    raise UnsupportedNode(f"node {node.name}: more than {MAX_SWITCHES} PCIe switches")
+                k = sw_local[sw] = len(sw_local)
+            return k
+
+        gfree = gn1 = 0
+        per_numa = [0, 0]
+        det = t.detail[i]
+        det["sw_free"] = 0
+        for g, gpu in enumerate(gpus):
+            if gpu.numa_node >= U or gpu.numa_node < 0:
+                raise UnsupportedNode(f"node {node.name}: GPU on NUMA node {gpu.numa_node}")
+            per_numa[gpu.numa_node] += 1
+            s = local_sw(gpu.pciesw)
+            if gpu.numa_node == 1:
+                gn1 |= 1 << g
+            if not gpu.used:
+                gfree |= 1 << g
+                det["sw_free"][s] += 1
+        if max(per_numa) > 16:
+            raise UnsupportedNode(f"node {node.name}: more than 16 GPUs on one NUMA node")
+
+        # NICs: capacity class + switch per (numa, idx);  nhd/Node.py:283-296, 275-281
+        cnt = [0, 0]
+        sw_numa: Dict[int, int] = {}
+        numa_pool = [dict(), dict()]                       # cls -> count
+        pci_pool = [dict(), dict()]                        # local switch -> {cls -> count}
+        det["nic_cls"] = 0
+        det["nic_sw"] = 0
+        for nic in node.nics:
+            u = nic.numa_node
+            if u >= U or u < 0:
+                continue                                   # invisible to the NIC stage (Node.py:293-294)
+            k = cnt[u]
+            if k >= MAX_NICS_PER_NUMA:
+                raise UnsupportedNode(f"node {node.name}: more than {MAX_NICS_PER_NUMA} NICs on NUMA {u}")
+            if nic.idx != k:
+                raise UnsupportedNode(f"node {node.name}: NIC ordinal {nic.idx} != position {k} on NUMA {u}")
+            cap = 0 if nic.pods_used > 0 else nic.speed * NIC_BW_AVAIL_PERCENT
+            cls = self.cap_class(cap)
+            s = local_sw(nic.pciesw)
+            if sw_numa.setdefault(s, u) != u:
+                raise UnsupportedNode(f"node {node.name}: PCIe switch {nic.pciesw:#x} has NICs on both NUMA nodes")
+            det["nic_cls"][u][k] = cls
+            det["nic_sw"][u][k] = s
+            numa_pool[u][cls] = numa_pool[u].get(cls, 0) + 1
+            d = pci_pool[u].setdefault(s, {})
+            d[cls] = d.get(cls, 0) + 1
+            cnt[u] = k + 1
+        det["nic_cnt"] = cnt
+        det["numa_nodes"] = U
+
+        def pairs(d):
+            return tuple(sorted((c, min(n, MAX_GROUPS)) for c, n in d.items()))
+
+        sig_numa, sig_pci = [0, 0], [0, 0]
+        for u in range(U):
+            if numa_pool[u]:
+                sig_numa[u] = self.sig_id([(GLIMIT_NONE, pairs(numa_pool[u]))])
+            pools = []
+            for s, d in pci_pool[u].items():
+                gl = min(int(det["sw_free"][s]), MAX_GROUPS)
+                if gl > 0:
+                    pools.append((gl, pairs(d)))
+            sig_pci[u] = self.sig_id(pools)
+
+        flags = (NF_MAINTENANCE if node.maintenance else 0) | (NF_ACTIVE if node.active else 0) | \
+                (NF_SMT if smt else 0) | (NF_HAS_GPU if len(gpus) > 0 else 0)
+        hp = int(node.mem.free_hugepages_gb)
+        t.p2[i] = (gfree, gn1, max(-2 ** 31, min(2 ** 31 - 1, hp)), flags)
+        t.p3[i]["groups"] = self.group_bits(node.groups)
+        t.p3[i]["sig_numa"] = sig_numa
+        t.p3[i]["sig_pci"] = sig_pci
+        t.p4[i]["busy_time"] = float(node.busy_time)
+
+    def pack_nodes(self, nl: Dict[str, object]) -> NodeTable:
+        t = empty_table(len(nl))
+        t.names = list(nl.keys())
+        for i, node in enumerate(nl.values()):
+            self.pack_node_into(node, t, i)
+        return t
+
+    # ---- request side ---------------------------------------------------------------------
+    def digest(self, top, pod_groups: Optional[Sequence[str]] = None) -> np.ndarray:
+        """CfgTopology -> nhdfit_req (nhd/CfgTopology.py:199-232 + nhd/Matcher.py:178-204).
+
+        pod_groups given  -> the kernel applies InitialNodeFilter (NHDScheduler.py:235-247) itself;
+        pod_groups None   -> the caller already filtered (`nl` of FindNode) and passes a candidate mask.
+        """
+        r = np.zeros((), REQ)
+        groups = top.proc_groups
+        G = len(groups)
+        mt = getattr(top.map_type, "value", top.map_type)
+        r["map_type"] = int(mt) if isinstance(mt, (int, np.integer)) else 0
+        r["n_groups"] = G
+        if G > MAX_GROUPS:
+            raise UnsupportedNode(f"pod with {G} proc groups (> {MAX_GROUPS})")
+        r["hugepages_gb"] = max(-2 ** 31, min(2 ** 31 - 1, int(top.hugepages_gb)))
+
+        def half(n):
+            return int(math.ceil(n / 2.0))
+
+        for i, pg in enumerate(groups):
+            n_proc = len(pg.proc_cores) + sum(len(g.cpu_cores) for g in pg.group_gpus)
+            n_help = len(pg.misc_cores)
+            r["gpus"][i] = len(pg.group_gpus)
+            r["cpu_nosmt"][i] = n_proc + n_help
+            r["cpu_smt"][i] = (half(n_proc) if pg.proc_smt.value else n_proc) + \
+                              (half(n_help) if pg.helper_smt.value else n_help)
+            rx = tx = 0
+            for c in pg.proc_cores:
+                d = getattr(c.nic_dir, "value", c.nic_dir)
+                if d == 1:
+                    rx += c.nic_speed
+                elif d == 2:
+                    tx += c.nic_speed
+            r["rx"][i] = float(rx)
+            r["tx"][i] = float(tx)
+        n_misc = len(top.misc_cores)
+        r["misc_nosmt"] = n_misc
+        r["misc_smt"] = half(n_misc) if top.misc_cores_smt else n_misc      # Enum truthiness, quirk Q1
+        if pod_groups is not None:
+            r["flags"] = RF_INITIAL_FILTER
+            r["groups"] = self.group_bits(pod_groups)
+        return r
+
+    def digest_many(self, tops: Sequence[object], pod_groups: Optional[Sequence[Sequence[str]]] = None) -> np.ndarray:
+        out = np.zeros(len(tops), REQ)
+        for i, top in enumerate(tops):
+            out[i] = self.digest(top, None if pod_groups is None else pod_groups[i])
+        return out
+
+    # ---- vectorised synthetic route ---------------------------------------------------------
+    def planes_from_spec(self, spec) -> NodeTable:
+        """Same planes as pack_nodes(spec.build_nodes()) without materialising objects
+        (tests/test_pack.py asserts equality).  Layout knowledge of synth.ClusterSpec.labels():
+        2 sockets, GPU g on NUMA g//2 / switch g, NIC (numa,j) on switch numa*2 + (j % 2) or, with
+        SR-IOV, on its physical function's switch numa*2 + j // (K/2); every NIC is 100 GbE."""
+        n = spec.n
+        t = empty_table(n)
+        cpp = (spec.phys // 2).astype(np.uint64)
+        valid = (np.uint64(1) << cpp) - np.uint64(1)
+        free = (~spec.core_used) & valid[:, None]
+        t.p0["t0"] = free
+        t.p1["t1"] = np.where(spec.smt[:, None], free, ALL_ONES)
+        has_gpu = spec.n_gpus > 0
+        gvalid = np.where(has_gpu, 0xF, 0).astype(np.uint32)
+        t.p2["gpu_free"] = gvalid & ~spec.gpu_used
+        t.p2["gpu_numa1"] = gvalid & np.uint32(0xC)
+        t.p2["hp_free"] = spec.hp_free
+        t.p2["flags"] = (np.where(spec.maintenance, NF_MAINTENANCE, 0) | np.where(spec.active, NF_ACTIVE, 0) |
+                         np.where(spec.smt, NF_SMT, 0) | np.where(has_gpu, NF_HAS_GPU, 0)).astype(np.uint32)
+        lut = np.array([self.group_bits([nm]) for nm in _synth_group_names()], dtype=np.uint64)
+        gb = np.zeros(n, np.uint64)
+        for k in range(16):
+            gb |= np.where((spec.group_bits >> k) & 1, lut[k], np.uint64(0)).astype(np.uint64)
+        t.p3["groups"] = gb
+        t.p4["busy_time"] = np.where(spec.busy, spec.clock_now - 5.0, spec.clock_now - 1000.0)
+
+        K = spec.nics_per_numa
+        c_used = self.cap_class(0)
+        c_free = self.cap_class(100000 / 1e3 * NIC_BW_AVAIL_PERCENT)
+        half = K // 2 if spec.sriov else None
+        det = t.detail
+        det["numa_nodes"] = 2
+        det["nic_cnt"] = K
+        # local switch ids follow first appearance: GPUs (switch g -> id g) then NICs
+        sw_of_nic = np.zeros((2, K), np.int64)
+        for numa in range(2):
+            for j in range(K):
+                sw_of_nic[numa, j] = numa * 2 + (j // half if spec.sriov else j % 2)
+        gfree_sw = np.stack([((t.p2["gpu_free"] >> g) & 1) for g in range(4)], axis=1).astype(np.uint8)   # [n,4]
+        # nodes without GPUs number their switches in NIC order instead
+        nic_order = []
+        for numa in range(2):
+            for j in range(K):
+                s = int(sw_of_nic[numa, j])
+                if s not in nic_order:
+                    nic_order.append(s)
+        local_nogpu = {s: k for k, s in enumerate(nic_order)}
+        used_bits = spec.nic_used
+        for numa in range(2):
+            for j in range(K):
+                used = ((used_bits >> (numa * K + j)) & 1).astype(bool)
+                det["nic_cls"][:, numa, j] = np.where(used, c_used, c_free)
+                s = int(sw_of_nic[numa, j])
+                det["nic_sw"][:, numa, j] = np.where(has_gpu, s, local_nogpu[s])
+        det["sw_free"][:, :4] = np.where(has_gpu[:, None], gfree_sw, 0)
+
+        # signatures: enumerate the distinct (used-count per pool, free GPUs per pool) patterns
+        for numa in range(2):
+            pool_ids = sorted(set(int(s) for s in sw_of_nic[numa]))
+            n_used_pool = {s: np.zeros(n, np.int64) for s in pool_ids}
+            n_tot_pool = {s: 0 for s in pool_ids}
+            for j in range(K):
+                s = int(sw_of_nic[numa, j])
+                n_used_pool[s] += (used_bits >> (numa * K + j)) & 1
+                n_tot_pool[s] += 1
+            n_used_all = sum(n_used_pool.values())
+            # NUMA-mode signature: one pool, all NICs
+            key_numa = n_used_all
+            sig_numa = np.zeros(n, np.uint16)
+            for v in np.unique(key_numa):
+                d = {}
+                if v:
+                    d[c_used] = int(v)
+                if K - v:
+                    d[c_free] = int(K - v)
+                pairs = tuple(sorted((c, min(m, MAX_GROUPS)) for c, m in d.items()))
+                sig_numa[key_numa == v] = self.sig_id([(GLIMIT_NONE, pairs)])
+            t.p3["sig_numa"][:, numa] = sig_numa
+            # PCI-mode signature: one pool per switch, limited by that switch's free GPUs
+            code = np.zeros(n, np.int64)
+            for s in pool_ids:
+                code = code * 64 + n_used_pool[s] * 2 + np.where(has_gpu, gfree_sw[:, s], 0)
+            sig_pci = np.zeros(n, np.uint16)
+            for v in np.unique(code):
+                sel = code == v
+                first = int(np.argmax(sel))
+                pools = []
+                for s in pool_ids:
+                    gl = int(gfree_sw[first, s]) if has_gpu[first] else 0
+                    if gl <= 0:
+                        continue
+                    nu = int(n_used_pool[s][first])
+                    d = {}
+                    if nu:
+                        d[c_used] = nu
+                    if n_tot_pool[s] - nu:
+                        d[c_free] = n_tot_pool[s] - nu
+                    pools.append((min(gl, MAX_GROUPS), tuple(sorted((c, min(m, MAX_GROUPS)) for c, m in d.items()))))
+                sig_pci[sel] = self.sig_id(pools)
+            t.p3["sig_pci"][:, numa] = sig_pci
+        t.names = []
+        return t
+
+
+def _synth_group_names():
+    from .synth import GROUP_NAMES
+    return GROUP_NAMES
+
+
+def resolve_signatures(packer: Packer, table: NodeTable):
+    """Signature ids -> their interned pool tuples (for comparing tables built by different packers)."""
+    caps = packer.caps
+
+    def res(sig):
+        return tuple(sorted((gl, tuple(sorted((caps[c], m) for c, m in pairs))) for gl, pairs in packer.sigs[sig]))
+    return [[res(int(s)) for s in row] for row in np.concatenate([table.p3["sig_numa"], table.p3["sig_pci"]], axis=1)]

@@ -1,0 +1,48 @@
+"""Host build of the kernels' shared arithmetic (TEST INFRASTRUCTURE, see host_harness.cpp)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from nhd_amd import pack
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_harness.cpp")
+SO = os.path.join(HERE, "_host_harness.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    deps = [SRC] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "winner_map.h")] + \
+           [os.path.join(HERE, "..", "..", "include", "nhdfit.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", SRC, "-o", SO])
+    _lib = ctypes.CDLL(SO)
+    _lib.hh_tuple_hash.restype = ctypes.c_uint64
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def find(packer: pack.Packer, table: pack.NodeTable, reqs: np.ndarray, now: float, cand=None, global_base=0,
+         want_bitmap=True, want_map=True):
+    L = lib()
+    caps, sig_off, pool_off, glimit, cc, ncls, nsig, npools, ncc = packer.dictionary_arrays()
+    n, P = table.n, len(reqs)
+    chunks = (n + 63) // 64
+    score = np.zeros(P, np.uint64)
+    bitmap = np.zeros((chunks, P), np.uint64) if want_bitmap else None
+    maps = np.zeros(P, pack.MAPPING) if want_map else None
+    reqs = np.ascontiguousarray(reqs)
+    L.hh_find(_p(table.p0), _p(table.p1), _p(table.p2), _p(table.p3), _p(table.p4), _p(table.detail),
+              ctypes.c_uint32(n), ctypes.c_uint64(global_base), _p(reqs), ctypes.c_uint32(P), ctypes.c_double(now),
+              _p(caps), ctypes.c_uint32(ncls), _p(sig_off), ctypes.c_uint32(nsig), _p(pool_off), _p(glimit), _p(cc),
+              _p(cand) if cand is not None else None, _p(score), _p(bitmap) if want_bitmap else None,
+              _p(maps) if want_map else None)
+    return score, bitmap, maps

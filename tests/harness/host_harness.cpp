@@ -1,0 +1,114 @@
+// host_harness.cpp - TEST INFRASTRUCTURE.  Compiles the kernels' shared arithmetic
+// (nhd_amd/csrc/fit_core.h, winner_map.h) for the host so that `pytest -m "not gpu"` can check the
+// table construction, the per-pair predicate, the selection word and the CPython set model against
+// the oracle without a GPU.  It is NOT part of libnhdfit.so and nothing in nhd_amd/ loads it.
+#include <cstring>
+#include <vector>
+#include "../../nhd_amd/csrc/winner_map.h"
+
+using namespace nhdfit;
+
+extern "C" {
+
+int hh_table_words(uint32_t nsig) { return (kRowR + (int)nsig) * kRowStride; }
+
+// Build the table image of one tile (up to 64 pods).
+void hh_build_tile(const nhdfit_req* reqs, uint32_t npods, const double* caps, uint32_t ncls,
+                   const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit,
+                   const nhdfit_cc* cc, uint32_t* tab, PodHeader* hdr) {
+    std::memset(tab, 0, sizeof(uint32_t) * hh_table_words(nsig));
+    SigDict d{sig_off, pool_off, pool_glimit, cc, nsig};
+    for (uint32_t j = 0; j < npods; ++j) {
+        const nhdfit_req& r = reqs[j];
+        hdr[j] = pod_header(r);
+        if (!(hdr[j].flags & kPodValid)) continue;
+        PodSums s;
+        pod_sums(r, s);
+        for (int e = 0; e < kRowsW; ++e) {
+            tab[(kRowW0 + e) * kRowStride + j] = entry_w0(r, s, e);
+            tab[(kRowW1 + e) * kRowStride + j] = entry_w1(r, s, e);
+        }
+        for (int f = 0; f < kFgSlots; ++f) tab[(kRowA + f) * kRowStride + j] = entry_a(s, f);
+        std::vector<uint16_t> cover(ncls * (kMaxG + 1));
+        for (uint32_t c = 0; c < ncls; ++c) class_cover(r, caps[c], s.W, s.G, &cover[c * (kMaxG + 1)]);
+        for (uint32_t g = 0; g < nsig; ++g)
+            tab[(kRowR + g) * kRowStride + j] = entry_r(sig_reach(d, g, cover.data(), s.W), s.W);
+    }
+}
+
+// CPU twin of nhdfit_find (mode A), same outputs, chunk-major bitmap [ceil(n/64)][P].
+void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
+             const nhdfit_plane4* p4, const nhdfit_detail* det, uint32_t n, uint64_t global_base,
+             const nhdfit_req* reqs, uint32_t P, double now, const double* caps, uint32_t ncls,
+             const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit,
+             const nhdfit_cc* cc, const uint64_t* cand, uint64_t* score, uint64_t* bitmap, nhdfit_mapping* maps) {
+    const uint32_t chunks = (n + 63) / 64;
+    std::vector<uint32_t> tab(hh_table_words(nsig));
+    std::vector<PodHeader> hdr(kTile);
+    for (uint32_t p = 0; p < P; ++p) score[p] = 0;
+    for (uint32_t t0 = 0; t0 < P; t0 += kTile) {
+        const uint32_t np = P - t0 < (uint32_t)kTile ? P - t0 : kTile;
+        hh_build_tile(reqs + t0, np, caps, ncls, sig_off, nsig, pool_off, pool_glimit, cc, tab.data(), hdr.data());
+        for (uint32_t c = 0; c < chunks; ++c) {
+            uint64_t nogpu = 0;
+            NodeLane lanes[64];
+            const uint32_t cnt = n - c * 64 < 64 ? n - c * 64 : 64;
+            for (uint32_t l = 0; l < cnt; ++l) {
+                const uint32_t i = c * 64 + l;
+                lanes[l] = node_lane(p0[i], p1[i], p2[i], p3[i], p4[i], now);
+                if (!(p2[i].flags & NHDFIT_NF_HAS_GPU)) nogpu |= 1ull << l;
+            }
+            for (uint32_t j = 0; j < np; ++j) {
+                uint64_t w = 0;
+                for (uint32_t l = 0; l < cnt; ++l)
+                    if (eval_pair(lanes[l], hdr[j], tab.data(), j)) w |= 1ull << l;
+                if (cand) w &= cand[(size_t)c * P + t0 + j];
+                if (bitmap) bitmap[(size_t)c * P + t0 + j] = w;
+                const uint64_t s = chunk_score(w, nogpu, hdr[j].flags & kPodNeedGpu, global_base + (uint64_t)c * 64);
+                if (s > score[t0 + j]) score[t0 + j] = s;
+            }
+        }
+    }
+    if (!maps) return;
+    for (uint32_t p = 0; p < P; ++p) {
+        std::memset(&maps[p], 0, sizeof(nhdfit_mapping));
+        if (!score[p]) continue;
+        const uint64_t gi = NHDFIT_SCORE_INDEX(score[p]);
+        if (gi < global_base || gi >= global_base + n) continue;
+        const uint32_t i = (uint32_t)(gi - global_base);
+        WinnerState w;
+        w.U = det[i].numa_nodes;
+        w.smt = p2[i].flags & NHDFIT_NF_SMT;
+        w.free_c[0] = popc64(p0[i].t0[0] & p1[i].t1[0]);
+        w.free_c[1] = popc64(p0[i].t0[1] & p1[i].t1[1]);
+        w.free_g[0] = popc32(p2[i].gpu_free & ~p2[i].gpu_numa1);
+        w.free_g[1] = popc32(p2[i].gpu_free & p2[i].gpu_numa1);
+        w.d = det[i];
+        w.caps = caps;
+        map_winner(reqs[p], w, maps[p]);
+    }
+}
+
+// list(set(codes inserted in order)) under the CPython model; tuples of length `len`, digits base `base`.
+int hh_set_list(const int16_t* codes, int n, int len, int base, int16_t* out) {
+    PySet s;
+    ps_init(s);
+    for (int i = 0; i < n; ++i) ps_add(s, codes[i], py_tuple_hash((uint32_t)codes[i], len, base));
+    return ps_list(s, out);
+}
+
+// list(set(a) & set(b) & set(c))
+int hh_set_isect3(const int16_t* a, int na, const int16_t* b, int nb, const int16_t* c, int nc, int len, int base, int16_t* out) {
+    PySet sa, sb, sc, ab, abc;
+    ps_init(sa); ps_init(sb); ps_init(sc);
+    for (int i = 0; i < na; ++i) ps_add(sa, a[i], py_tuple_hash((uint32_t)a[i], len, base));
+    for (int i = 0; i < nb; ++i) ps_add(sb, b[i], py_tuple_hash((uint32_t)b[i], len, base));
+    for (int i = 0; i < nc; ++i) ps_add(sc, c[i], py_tuple_hash((uint32_t)c[i], len, base));
+    ps_intersect(sa, sb, ab);
+    ps_intersect(ab, sc, abc);
+    return ps_list(abc, out);
+}
+
+uint64_t hh_tuple_hash(uint32_t code, int len, int base) { return py_tuple_hash(code, len, base); }
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+"""The kernels' shared arithmetic (fit_core.h / winner_map.h, host build) + the packer against the
+oracle and the golden vectors.  CPU only: this is what lets the HIP path be right first time."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nhd_amd import pack, refmodel, synth
+from oracle import nhd_oracle as O
+from tests import harness, util
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.json")))
+
+
+def decode(packer, table, reqs, score, maps, names):
+    out = []
+    for p in range(len(reqs)):
+        s = int(score[p])
+        if s == 0:
+            out.append([None])
+            continue
+        idx = 0x7FFFFFFFFFFFFFFF - (s & 0x7FFFFFFFFFFFFFFF)
+        G = int(reqs[p]["n_groups"])
+        m = maps[p]
+        assert m["valid"] == 1
+        out.append([names[idx], {"gpu": [int(x) for x in m["gpu"][:G]], "cpu": [int(x) for x in m["cpu"][:G + 1]],
+                                 "nic": [[int(a), int(b)] for a, b in zip(m["nic_numa"][:G], m["nic_idx"][:G])]}])
+    return out
+
+
+def bitmap_rows(bitmap, n, P):
+    rows = []
+    for p in range(P):
+        rows.append("".join("1" if int(bitmap[i // 64, p]) >> (i % 64) & 1 else "0" for i in range(n)))
+    return rows
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-5] for p in GOLDEN])
+def test_core_reproduces_golden(path):
+    with open(path) as f:
+        case = json.load(f)
+    nl = util.build_cluster(case["nodes"])
+    pk = pack.Packer()
+    table = pk.pack_nodes(nl)
+    tops = [refmodel.make_topology(p["spec"]) for p in case["pods"]]
+    reqs = pk.digest_many(tops, [p["groups"] for p in case["pods"]])
+    score, bitmap, maps = harness.find(pk, table, reqs, case["clock"])
+    assert bitmap_rows(bitmap, table.n, len(reqs)) == case["feasible"]
+    assert decode(pk, table, reqs, score, maps, table.names) == case["expected"]
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_core_matches_oracle_random(seed):
+    nl = util.random_cluster(31000 + seed, 40)
+    rng = np.random.default_rng(seed)
+    specs = [util.random_pod_spec(rng, max_groups=4 if seed % 4 == 0 else 3) for _ in range(30)]
+    tops = [refmodel.make_topology(s) for s in specs]
+    pk = pack.Packer()
+    table = pk.pack_nodes(nl)
+    reqs = pk.digest_many(tops)
+    score, bitmap, maps = harness.find(pk, table, reqs, util.CLOCK)
+    got = decode(pk, table, reqs, score, maps, table.names)
+    rows = bitmap_rows(bitmap, table.n, len(reqs))
+    for p, top in enumerate(tops):
+        want = O.find_node(nl, top, util.CLOCK)
+        want = [None] if want[0] is None else [want[0], {"gpu": list(want[1]["gpu"]), "cpu": list(want[1]["cpu"]),
+                                                          "nic": [list(x) for x in want[1]["nic"]]}]
+        assert got[p] == want, specs[p]
+        assert rows[p] == "".join("1" if O.feasible(v, top, util.CLOCK) else "0" for v in nl.values())
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+def test_spec_route_equals_object_route(cfg):
+    spec = synth.make_cluster(cfg, n_nodes=200)
+    pk_a, pk_b = pack.Packer(), pack.Packer()
+    ta = pk_a.pack_nodes(spec.build_nodes())
+    tb = pk_b.planes_from_spec(spec)
+    for f in ("p0", "p1", "p2", "p4"):
+        assert np.array_equal(getattr(ta, f), getattr(tb, f)), f
+    def names(pk, bits):
+        return [frozenset(pk.group_names[k] for k in range(64) if int(b) >> k & 1) for b in bits]
+    assert names(pk_a, ta.p3["groups"]) == names(pk_b, tb.p3["groups"])
+    assert pack.resolve_signatures(pk_a, ta) == pack.resolve_signatures(pk_b, tb)
+    for f in ("nic_cnt", "sw_free", "nic_sw", "numa_nodes"):
+        assert np.array_equal(ta.detail[f], tb.detail[f]), f
+    live = np.arange(pack.MAX_NICS_PER_NUMA)[None, None, :] < ta.detail["nic_cnt"][:, :, None]
+    ca = np.where(live, np.asarray(pk_a.caps)[ta.detail["nic_cls"]], -1.0)
+    cb = np.where(live, np.asarray(pk_b.caps)[tb.detail["nic_cls"]], -1.0)
+    assert np.array_equal(ca, cb)
+
+
+def test_candidate_mask_and_sharding_agree():
+    spec = synth.make_cluster(4, n_nodes=300)
+    pods, groups = synth.make_pods(4, n_pods=70)
+    pk = pack.Packer()
+    table = pk.planes_from_spec(spec)
+    reqs = pk.digest_many([refmodel.make_topology(s) for s in pods], groups)
+    full, bm, _ = harness.find(pk, table, reqs, spec.clock_now, want_map=False)
+    parts = []
+    for lo, hi in ((0, 128), (128, 300)):
+        s, _, _ = harness.find(pk, table.slice(lo, hi), reqs, spec.clock_now, global_base=lo, want_map=False)
+        parts.append(s)
+    assert np.array_equal(np.maximum(parts[0], parts[1]), full)
+    cand = np.zeros_like(bm)
+    cand[1:] = np.uint64(0xFFFFFFFFFFFFFFFF)          # forbid the first 64 nodes
+    masked, bm2, _ = harness.find(pk, table, reqs, spec.clock_now, cand=cand, want_map=False)
+    assert np.all(bm2[0] == 0) and np.array_equal(bm2[1:], bm[1:])

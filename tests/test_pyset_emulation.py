@@ -1,0 +1,92 @@
+"""The CPython set/tuple-hash model in nhd_amd/csrc/winner_map.h against the running interpreter."""
+import ctypes
+import itertools
+
+import numpy as np
+import pytest
+
+from tests import harness
+
+
+def codes_of(tuples, base):
+    out = []
+    for t in tuples:
+        c = 0
+        for d in t:
+            c = c * base + d
+        out.append(c)
+    return np.asarray(out, np.int16)
+
+
+def tuples_of(codes, length, base):
+    out = []
+    for c in codes:
+        c = int(c)
+        t = []
+        for _ in range(length):
+            t.append(c % base)
+            c //= base
+        out.append(tuple(reversed(t)))
+    return out
+
+
+def model_list(tuples, length, base):
+    L = harness.lib()
+    codes = codes_of(tuples, base)
+    out = np.zeros(64, np.int16)
+    n = L.hh_set_list(codes.ctypes.data_as(ctypes.c_void_p), len(codes), length, base, out.ctypes.data_as(ctypes.c_void_p))
+    return tuples_of(out[:n], length, base)
+
+
+@pytest.mark.parametrize("length", [1, 2, 3, 4, 5])
+def test_tuple_hash(length):
+    L = harness.lib()
+    for base in (1, 2):
+        for t in itertools.product(range(base), repeat=length):
+            assert L.hh_tuple_hash(int(codes_of([t], base)[0]), length, base) == hash(t) & (2 ** 64 - 1)
+
+
+@pytest.mark.parametrize("length", [1, 2, 3])
+def test_list_of_set_all_subsets_in_product_order(length):
+    """Every subset of U^G inserted in product order (how Matcher.py:116-141 fills `stmp`)."""
+    universe = list(itertools.product(range(2), repeat=length))
+    for mask in range(1, 1 << len(universe)):
+        sub = [t for i, t in enumerate(universe) if mask >> i & 1]
+        s = set()
+        for t in sub:
+            s.add(t)
+        assert model_list(sub, length, 2) == list(s)
+
+
+@pytest.mark.parametrize("length", [4, 5])
+def test_list_of_set_random_subsets(length):
+    rng = np.random.default_rng(length)
+    universe = list(itertools.product(range(2), repeat=length))
+    for _ in range(3000):
+        keep = rng.random(len(universe)) < rng.random()
+        sub = [t for t, k in zip(universe, keep) if k]
+        if rng.random() < 0.3:
+            rng.shuffle(sub)
+        s = set()
+        for t in sub:
+            s.add(t)
+        assert model_list(sub, length, 2) == list(s)
+
+
+@pytest.mark.parametrize("length", [1, 2, 3, 4])
+def test_three_way_intersection_order(length):
+    """list(set(a) & set(b) & set(c)) with a, b, c given as lists with duplicates (Matcher.py:342-346)."""
+    L = harness.lib()
+    rng = np.random.default_rng(100 + length)
+    universe = list(itertools.product(range(2), repeat=length))
+    for _ in range(4000):
+        lists = []
+        for _k in range(3):
+            n = int(rng.integers(1, 2 * len(universe) + 1))
+            lists.append([universe[int(i)] for i in rng.integers(0, len(universe), size=n)])
+        want = list(set(lists[0]) & set(lists[1]) & set(lists[2]))
+        arrs = [codes_of(x, 2) for x in lists]
+        out = np.zeros(64, np.int16)
+        n = L.hh_set_isect3(*(v for a in arrs for v in (a.ctypes.data_as(ctypes.c_void_p), len(a))), length, 2,
+                            out.ctypes.data_as(ctypes.c_void_p))
+        assert tuples_of(out[:n], length, 2) == want
