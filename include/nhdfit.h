@@ -153,7 +153,8 @@ int nhdfit_set_dictionary(nhdfit_ctx* ctx, const double* caps, uint32_t ncls,
                           const nhdfit_cc* cc, uint32_t ncc);
 
 /* (Re)size the device mirror to `capacity` nodes of which this rank's shard starts at global
- * index `global_base` (candidate order of the whole cluster; used for the score word). */
+ * index `global_base` (candidate order of the whole cluster; used for the score word).
+ * Growing the capacity discards the mirror's contents (node count becomes 0). */
 int nhdfit_reserve_nodes(nhdfit_ctx* ctx, uint32_t capacity, uint64_t global_base);
 /* Full or delta upload of `count` node records starting at local index `first`. */
 int nhdfit_upload_nodes(nhdfit_ctx* ctx, uint32_t first, uint32_t count,
@@ -182,6 +183,9 @@ int nhdfit_fetch(nhdfit_ctx* ctx, uint64_t* score_out, uint64_t* bitmap_out, nhd
 int nhdfit_comm_unique_id(void* id128);
 int nhdfit_comm_init(nhdfit_ctx* ctx, int nranks, int rank, const void* id128);
 int nhdfit_comm_destroy(nhdfit_ctx* ctx);
+
+/* Skip the feasibility-bitmap store / the winner-mapping kernel (both on by default). */
+int nhdfit_set_outputs(nhdfit_ctx* ctx, int want_bitmap, int want_map);
 
 int nhdfit_get_stats(nhdfit_ctx* ctx, nhdfit_stats* out);
 int nhdfit_reset_stats(nhdfit_ctx* ctx);

@@ -1,0 +1,86 @@
+"""ctypes binding of libnhdfit.so (include/nhdfit.h).  This is the stub a maintainer of the
+reference would add; there is no fallback: a missing library is an error."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from ctypes import POINTER, c_char_p, c_double, c_int, c_uint32, c_uint64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libnhdfit.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "nhdfit.h")
+
+
+class NhdFitError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libnhdfit error {code}: {msg}")
+        self.code = code
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("launches", c_uint64), ("fit_ms_total", c_double), ("fit_ms_last", c_double),
+                ("digest_ms_last", c_double), ("step_ms_last", c_double), ("evals_last", c_uint64),
+                ("bytes_last", c_uint64), ("nodes", c_uint32), ("nsig", c_uint32), ("ncls", c_uint32),
+                ("lds_bytes", c_uint32)]
+
+
+_SIGS = {
+    "nhdfit_abi_version": (c_int, []),
+    "nhdfit_device_count": (c_int, []),
+    "nhdfit_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "nhdfit_destroy": (None, [c_void_p]),
+    "nhdfit_last_error": (c_char_p, [c_void_p]),
+    "nhdfit_set_dictionary": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_uint32,
+                                      c_void_p, c_uint32]),
+    "nhdfit_reserve_nodes": (c_int, [c_void_p, c_uint32, c_uint64]),
+    "nhdfit_upload_nodes": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nhdfit_set_node_count": (c_int, [c_void_p, c_uint32]),
+    "nhdfit_find": (c_int, [c_void_p, c_void_p, c_uint32, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nhdfit_stage_requests": (c_int, [c_void_p, c_void_p, c_uint32]),
+    "nhdfit_enqueue_step": (c_int, [c_void_p, c_double]),
+    "nhdfit_sync": (c_int, [c_void_p]),
+    "nhdfit_fetch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nhdfit_comm_unique_id": (c_int, [c_void_p]),
+    "nhdfit_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "nhdfit_comm_destroy": (c_int, [c_void_p]),
+    "nhdfit_set_outputs": (c_int, [c_void_p, c_int, c_int]),
+    "nhdfit_get_stats": (c_int, [c_void_p, POINTER(Stats)]),
+    "nhdfit_reset_stats": (c_int, [c_void_p]),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    """Function names declared in include/nhdfit.h (used by the ABI test)."""
+    with open(HEADER) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\b(nhdfit_[a-z_0-9]+)\s*\(", text)))
+
+
+def load():
+    """Load the shared library.  Builds it with hipcc when it is missing (build container);
+    raises if that is impossible - the product has no CPU implementation to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build
+        try:
+            build.build_lib()
+        except Exception as e:  # noqa: BLE001
+            raise NhdFitError(-2, f"{LIB_PATH} is missing and could not be built with hipcc: {e}") from e
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx, rc):
+    if rc != 0:
+        msg = load().nhdfit_last_error(ctx)
+        raise NhdFitError(rc, msg.decode() if msg else "?")

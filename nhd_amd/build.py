@@ -1,0 +1,36 @@
+"""Build libnhdfit.so (hipcc, gfx950 only) in-tree.  `python -m nhd_amd.build [--force]`."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "nhdfit.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "fit_core.h"), os.path.join(HERE, "csrc", "winner_map.h"),
+        os.path.join(ROOT, "include", "nhdfit.h")]
+LIB = os.path.join(HERE, "libnhdfit.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def stale() -> bool:
+    return (not os.path.exists(LIB)) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
+
+
+def build_lib(force=False, verbose=False, extra=()):
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc()] + FLAGS + list(extra) + [SRC, "-o", LIB, "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=HERE)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

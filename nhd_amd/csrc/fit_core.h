@@ -217,9 +217,9 @@ NHD_HD uint32_t entry_r(uint32_t reach, uint32_t W) {
 
 // ---- node side -----------------------------------------------------------------------------------
 struct NodeLane {            // what one lane keeps for its node while it sweeps a tile of pods
-    uint32_t row_w0, row_w1; // table rows (not yet multiplied by the row stride)
-    uint32_t row_a0, row_a1;
-    uint32_t row_rn0, row_rn1, row_rp0, row_rp1;
+    uint32_t off_w0, off_w1; // word offsets of the node's table rows (row * kRowStride)
+    uint32_t off_a0, off_a1;
+    uint32_t off_rn0, off_rn1, off_rp0, off_rp1;
     int32_t  hp_free;
     uint32_t flags;
     uint64_t groups;
@@ -230,14 +230,14 @@ NHD_HD NodeLane node_lane(const nhdfit_plane0& a, const nhdfit_plane1& b, const 
                           const nhdfit_plane3& d, const nhdfit_plane4& e, double now) {
     NodeLane n;
     const uint32_t smt = (c.flags & NHDFIT_NF_SMT) ? kFcSlots : 0;
-    n.row_w0 = kRowW0 + smt + popc64(a.t0[0] & b.t1[0]);      // free physical cores, nhd/Node.py:250-264
-    n.row_w1 = kRowW1 + smt + popc64(a.t0[1] & b.t1[1]);
-    n.row_a0 = kRowA + popc32(c.gpu_free & ~c.gpu_numa1);     // free GPUs per NUMA, nhd/Node.py:456-462
-    n.row_a1 = kRowA + popc32(c.gpu_free & c.gpu_numa1);
-    n.row_rn0 = kRowR + d.sig_numa[0];
-    n.row_rn1 = kRowR + d.sig_numa[1];
-    n.row_rp0 = kRowR + d.sig_pci[0];
-    n.row_rp1 = kRowR + d.sig_pci[1];
+    n.off_w0 = (kRowW0 + smt + popc64(a.t0[0] & b.t1[0])) * kRowStride;   // free physical cores, nhd/Node.py:250-264
+    n.off_w1 = (kRowW1 + smt + popc64(a.t0[1] & b.t1[1])) * kRowStride;
+    n.off_a0 = (kRowA + popc32(c.gpu_free & ~c.gpu_numa1)) * kRowStride;  // free GPUs per NUMA, nhd/Node.py:456-462
+    n.off_a1 = (kRowA + popc32(c.gpu_free & c.gpu_numa1)) * kRowStride;
+    n.off_rn0 = (kRowR + d.sig_numa[0]) * kRowStride;
+    n.off_rn1 = (kRowR + d.sig_numa[1]) * kRowStride;
+    n.off_rp0 = (kRowR + d.sig_pci[0]) * kRowStride;
+    n.off_rp1 = (kRowR + d.sig_pci[1]) * kRowStride;
     n.hp_free = c.hp_free;
     n.flags = c.flags;
     n.groups = d.groups;
@@ -246,24 +246,26 @@ NHD_HD NodeLane node_lane(const nhdfit_plane0& a, const nhdfit_plane1& b, const 
 }
 
 // One (pod, node) evaluation against the pod's table column `col` (= pod index inside its tile).
-// `tab` is the tile's table image: word [row * kRowStride + col].
+// `tab` is the tile's table image: word [row * kRowStride + col].  Conditions on the pod header are
+// wave-uniform on the GPU (every lane of a wavefront works on the same pod), conditions on the node
+// are folded into one predicate so lanes never diverge.
 NHD_HD bool eval_pair(const NodeLane& n, const PodHeader& h, const uint32_t* tab, uint32_t col) {
-    if (!(h.flags & kPodValid)) return false;
-    if (n.flags & NHDFIT_NF_MAINTENANCE) return false;                       // Matcher.py:71
-    if (h.hp_req > n.hp_free) return false;                                  // Matcher.py:78
+    bool pass = (h.flags & kPodValid) != 0;
+    pass &= !(n.flags & NHDFIT_NF_MAINTENANCE);                              // Matcher.py:71
+    pass &= h.hp_req <= n.hp_free;                                           // Matcher.py:78
     if (h.flags & kPodFilter)                                                // NHDScheduler.py:240-242
-        if (!(n.flags & NHDFIT_NF_ACTIVE) || !(n.groups & h.groups)) return false;
-    const uint32_t x = tab[n.row_w0 * kRowStride + col] & tab[n.row_w1 * kRowStride + col];
+        pass &= ((n.flags & NHDFIT_NF_ACTIVE) != 0) & ((n.groups & h.groups) != 0);
+    const uint32_t x = tab[n.off_w0 + col] & tab[n.off_w1 + col];
     uint32_t ok = (x | (x >> 16)) & 0xFFFFu;
     if (h.flags & kPodNeedGpu) {
-        if (n.busy) return false;                                            // Matcher.py:107-111
-        ok &= tab[n.row_a0 * kRowStride + col] & (tab[n.row_a1 * kRowStride + col] >> 16);
+        pass &= !n.busy;                                                     // Matcher.py:107-111
+        ok &= tab[n.off_a0 + col] & (tab[n.off_a1 + col] >> 16);
     }
-    const bool pci = h.flags & kPodPci;
-    const uint32_t r0 = tab[(pci ? n.row_rp0 : n.row_rn0) * kRowStride + col];
-    const uint32_t r1 = tab[(pci ? n.row_rp1 : n.row_rn1) * kRowStride + col];
+    uint32_t r0, r1;
+    if (h.flags & kPodPci) { r0 = tab[n.off_rp0 + col]; r1 = tab[n.off_rp1 + col]; }
+    else                   { r0 = tab[n.off_rn0 + col]; r1 = tab[n.off_rn1 + col]; }
     ok &= (r0 >> 16) & r1;
-    return ok != 0;
+    return pass & (ok != 0);
 }
 
 // ---- selection (Matcher.py:393-421) ----------------------------------------------------------

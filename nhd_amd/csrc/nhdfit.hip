@@ -1,0 +1,680 @@
+// nhdfit.hip - gfx950 kernels and the C-ABI of libnhdfit.so (include/nhdfit.h).
+//
+// Three kernels per step, all on the context's own HIP stream:
+//   k_digest     per 64-pod tile: request records -> table image (CPU/GPU/NIC feasibility of every
+//                NUMA assignment as a function of a node's free-resource counts / NIC signature)
+//   k_fit_score  the P x N pass.  Block = (pod tile, node range).  The tile's table image is staged
+//                in LDS; a wavefront owns 64 consecutive nodes (lane = node, coalesced 16 B/lane loads
+//                of the five SoA planes, __popcll of the free-core bitmaps), sweeps the tile's 64 pods
+//                (wave-uniform request header, per-lane LDS table gathers), __ballot()s the verdict and
+//                transposes the 64 ballot words so that lane j ends up holding pod j's 64-node
+//                feasibility word: coalesced bitmap store, first-fit score via ctz, max-reduced
+//                per block and published with one atomicMax per pod.
+//   k_map        one lane per pod: the winner's resource mapping (CPython set-order model).
+// Multi-GPU: ncclAllReduce(score, P, ncclUint64, ncclMax) between k_fit_score and k_map.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "winner_map.h"
+
+using namespace nhdfit;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// device code
+// ------------------------------------------------------------------------------------------------
+struct DictView {
+    const double* caps;
+    uint32_t ncls;
+    SigDict sig;
+};
+
+// v_writelane_b32 (SGPR -> one lane of a VGPR).  This clang has no __builtin_amdgcn_writelane; the
+// asm label binds the declaration straight to the LLVM intrinsic, as the ROCm device libs do.
+extern "C" __device__ int nhd_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+constexpr int kDigestThreads = 256;
+constexpr int kDigestSlices = 8;
+
+// grid = (tiles, kDigestSlices).  Every block rebuilds the (cheap) per-pod sums / covers of its tile
+// in LDS, then fills its share of the table rows; consecutive threads write consecutive columns.
+__global__ __launch_bounds__(kDigestThreads) void k_digest(const nhdfit_req* __restrict__ reqs, uint32_t P,
+                                                           DictView d, uint32_t tab_words,
+                                                           uint32_t* __restrict__ tabs, PodHeader* __restrict__ hdr) {
+    __shared__ nhdfit_req s_req[kTile];
+    __shared__ PodSums s_sum[kTile];
+    __shared__ uint16_t s_cover[kTile][NHDFIT_MAX_CLASSES][kMaxG + 1];
+    __shared__ uint32_t s_valid[kTile];
+
+    const uint32_t tile = blockIdx.x, slice = blockIdx.y;
+    const uint32_t tid = threadIdx.x;
+    uint32_t* tab = tabs + (size_t)tile * tab_words;
+
+    if (tid < kTile) {
+        const uint32_t pod = tile * kTile + tid;
+        nhdfit_req r;
+        if (pod < P) r = reqs[pod];
+        else { memset(&r, 0, sizeof(r)); }
+        const PodHeader h = pod_header(r);
+        s_req[tid] = r;
+        s_valid[tid] = h.flags & kPodValid;
+        if (s_valid[tid]) pod_sums(r, s_sum[tid]);
+        if (slice == 0) hdr[tile * kTile + tid] = h;
+    }
+    __syncthreads();
+    for (uint32_t w = tid; w < kTile * d.ncls; w += kDigestThreads) {
+        const uint32_t j = w % kTile, c = w / kTile;
+        if (s_valid[j]) class_cover(s_req[j], d.caps[c], s_sum[j].W, s_sum[j].G, s_cover[j][c]);
+    }
+    __syncthreads();
+
+    const uint32_t rows = kRowR + d.sig.nsig;
+    for (uint32_t w = slice * kDigestThreads + tid; w < rows * kTile; w += kDigestSlices * kDigestThreads) {
+        const uint32_t j = w % kTile, row = w / kTile;
+        uint32_t v = 0;
+        if (s_valid[j]) {
+            const nhdfit_req& r = s_req[j];
+            const PodSums& s = s_sum[j];
+            if (row < (uint32_t)kRowW1) v = entry_w0(r, s, (int)row - kRowW0);
+            else if (row < (uint32_t)kRowA) v = entry_w1(r, s, (int)row - kRowW1);
+            else if (row < (uint32_t)kRowR) v = entry_a(s, (int)row - kRowA);
+            else v = entry_r(sig_reach(d.sig, row - kRowR, &s_cover[j][0][0], s.W), s.W);
+        }
+        tab[row * kRowStride + j] = v;
+    }
+}
+
+struct FitArgs {
+    const nhdfit_plane0* p0;
+    const nhdfit_plane1* p1;
+    const nhdfit_plane2* p2;
+    const nhdfit_plane3* p3;
+    const nhdfit_plane4* p4;
+    uint32_t n;                 // nodes in this shard
+    uint32_t chunks;            // ceil(n / 64)
+    uint32_t chunks_per_block;
+    uint32_t nranges;           // node ranges (blocks per tile)
+    uint64_t global_base;
+    double now;
+    const uint32_t* tabs;
+    uint32_t tab_words;         // words per tile image (multiple of 4)
+    const PodHeader* hdr;       // [tiles*64], zero flags beyond P
+    uint32_t P;
+    const uint64_t* cand;       // optional [chunks][P]
+    uint64_t* bitmap;           // optional [chunks][P]
+    unsigned long long* score;  // [P], pre-zeroed
+};
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_fit_score(FitArgs a) {
+    extern __shared__ __align__(16) uint32_t tab[];
+    __shared__ unsigned long long s_best[BLOCK / 64][64];
+    constexpr int NW = BLOCK / 64;
+
+    // blockIdx -> (tile, range): consecutive blocks (round-robin over the 8 XCDs) walk the node
+    // ranges, so one XCD keeps re-reading the same 1/8 of the node planes out of its own L2.
+    const uint32_t range = blockIdx.x % a.nranges;
+    const uint32_t tile = blockIdx.x / a.nranges;
+
+    {   // stage the tile's table image in LDS (16 B per lane, fully coalesced)
+        const uint4* src = reinterpret_cast<const uint4*>(a.tabs + (size_t)tile * a.tab_words);
+        uint4* dst = reinterpret_cast<uint4*>(tab);
+        for (uint32_t i = threadIdx.x; i < a.tab_words / 4; i += BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t pod0 = tile * kTile;
+    // lane-as-pod view of the tile's 64 request headers; inside the pod sweep they are broadcast
+    // back out of these registers with v_readlane (-> SGPRs: the header tests become scalar branches)
+    const PodHeader my_h = a.hdr[pod0 + lane];
+    const bool my_pod_live = pod0 + lane < a.P;
+    const bool my_pod_needs_gpu = (my_h.flags & kPodNeedGpu) != 0;
+    unsigned long long best = 0;
+
+    const uint32_t c_begin = range * a.chunks_per_block;
+    const uint32_t c_end = c_begin + a.chunks_per_block < a.chunks ? c_begin + a.chunks_per_block : a.chunks;
+    for (uint32_t c = c_begin + wave; c < c_end; c += NW) {
+        const uint32_t i = c * 64 + lane;
+        const bool live = i < a.n;
+        NodeLane nl;
+        if (live) {
+            nl = node_lane(a.p0[i], a.p1[i], a.p2[i], a.p3[i], a.p4[i], a.now);
+        } else {
+            nl = NodeLane{};
+            nl.flags = NHDFIT_NF_MAINTENANCE;            // never feasible
+        }
+        const uint64_t nogpu = __ballot(live && !(nl.flags & NHDFIT_NF_HAS_GPU));
+
+        uint32_t wlo = 0, whi = 0;
+#pragma unroll 8
+        for (uint32_t j = 0; j < (uint32_t)kTile; ++j) {
+            PodHeader h;                                  // wave-uniform
+            h.flags = (uint32_t)__builtin_amdgcn_readlane((int)my_h.flags, (int)j);
+            h.hp_req = __builtin_amdgcn_readlane(my_h.hp_req, (int)j);
+            h.groups = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_h.groups, (int)j) |
+                       ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_h.groups >> 32), (int)j) << 32);
+            const bool ok = eval_pair(nl, h, tab, j);
+            const uint64_t w = __ballot(ok);
+            // transpose: lane j keeps the ballot of pod j
+            wlo = (uint32_t)nhd_writelane((int)(uint32_t)w, (int)j, (int)wlo);
+            whi = (uint32_t)nhd_writelane((int)(uint32_t)(w >> 32), (int)j, (int)whi);
+        }
+        uint64_t word = ((uint64_t)whi << 32) | wlo;
+        if (my_pod_live) {
+            const size_t o = (size_t)c * a.P + pod0 + lane;
+            if (a.cand) word &= a.cand[o];
+            if (a.bitmap) a.bitmap[o] = word;
+            const unsigned long long s = chunk_score(word, nogpu, my_pod_needs_gpu, a.global_base + (uint64_t)c * 64);
+            best = s > best ? s : best;
+        }
+    }
+    s_best[wave][lane] = best;
+    __syncthreads();
+    if (wave == 0 && my_pod_live) {
+        unsigned long long m = s_best[0][lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = s_best[w][lane] > m ? s_best[w][lane] : m;
+        if (m) atomicMax(&a.score[pod0 + lane], m);
+    }
+}
+
+struct MapArgs {
+    const nhdfit_plane0* p0;
+    const nhdfit_plane1* p1;
+    const nhdfit_plane2* p2;
+    const nhdfit_detail* det;
+    uint32_t n;
+    uint64_t global_base;
+    const nhdfit_req* reqs;
+    uint32_t P;
+    const unsigned long long* score;
+    const double* caps;
+    nhdfit_mapping* out;
+};
+
+__global__ __launch_bounds__(64) void k_map(MapArgs a) {
+    const uint32_t p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= a.P) return;
+    nhdfit_mapping m;
+    memset(&m, 0, sizeof(m));
+    const unsigned long long s = a.score[p];
+    if (s) {
+        const uint64_t gi = NHDFIT_SCORE_INDEX(s);
+        if (gi >= a.global_base && gi < a.global_base + a.n) {
+            const uint32_t i = (uint32_t)(gi - a.global_base);
+            WinnerState w;
+            const nhdfit_plane0 q0 = a.p0[i];
+            const nhdfit_plane1 q1 = a.p1[i];
+            const nhdfit_plane2 q2 = a.p2[i];
+            w.d = a.det[i];
+            w.U = w.d.numa_nodes;
+            w.smt = (q2.flags & NHDFIT_NF_SMT) != 0;
+            w.free_c[0] = popc64(q0.t0[0] & q1.t1[0]);
+            w.free_c[1] = popc64(q0.t0[1] & q1.t1[1]);
+            w.free_g[0] = popc32(q2.gpu_free & ~q2.gpu_numa1);
+            w.free_g[1] = popc32(q2.gpu_free & q2.gpu_numa1);
+            w.caps = a.caps;
+            map_winner(a.reqs[p], w, m);
+        }
+    }
+    a.out[p] = m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+thread_local std::string g_create_error;
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string& err) {
+        if (handle) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (handle) break;
+        }
+        if (!handle) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+        GetUniqueId = (decltype(GetUniqueId))dlsym(handle, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(handle, "ncclCommInitRank");
+        AllReduce = (decltype(AllReduce))dlsym(handle, "ncclAllReduce");
+        CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+        GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy || !GetErrorString) {
+            err = "librccl lacks a required symbol";
+            return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;   // elements
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+constexpr int kEventRing = 256;
+
+}  // namespace
+
+struct nhdfit_ctx {
+    int dev = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipDeviceProp_t prop;
+
+    // node mirror
+    DevBuf<nhdfit_plane0> p0; DevBuf<nhdfit_plane1> p1; DevBuf<nhdfit_plane2> p2;
+    DevBuf<nhdfit_plane3> p3; DevBuf<nhdfit_plane4> p4; DevBuf<nhdfit_detail> det;
+    uint32_t n = 0, capacity = 0;
+    uint64_t global_base = 0;
+
+    // dictionary
+    DevBuf<double> caps; DevBuf<uint32_t> sig_off, pool_off; DevBuf<uint8_t> pool_glimit; DevBuf<nhdfit_cc> cc;
+    uint32_t ncls = 0, nsig = 0;
+    uint32_t tab_words = 0, lds_bytes = 0;
+
+    // requests / results
+    DevBuf<nhdfit_req> reqs; uint32_t P = 0;
+    DevBuf<PodHeader> hdr; DevBuf<uint32_t> tabs;
+    DevBuf<unsigned long long> score; DevBuf<uint64_t> bitmap; DevBuf<uint64_t> cand; DevBuf<nhdfit_mapping> maps;
+    bool use_cand = false, want_bitmap = true, want_map = true;
+
+    // timing
+    hipEvent_t ev[kEventRing][4];
+    int ev_pending = 0;
+    nhdfit_stats stats;
+
+    // collective
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+};
+
+namespace {
+
+int fail(nhdfit_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail((c), NHDFIT_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int drain_events(nhdfit_ctx* c) {
+    for (int k = 0; k < c->ev_pending; ++k) {
+        float d = 0, f = 0, s = 0;
+        HIPCHK(c, hipEventSynchronize(c->ev[k][3]));
+        HIPCHK(c, hipEventElapsedTime(&d, c->ev[k][0], c->ev[k][1]));
+        HIPCHK(c, hipEventElapsedTime(&f, c->ev[k][1], c->ev[k][2]));
+        HIPCHK(c, hipEventElapsedTime(&s, c->ev[k][0], c->ev[k][3]));
+        c->stats.launches++;
+        c->stats.fit_ms_total += f;
+        c->stats.fit_ms_last = f;
+        c->stats.digest_ms_last = d;
+        c->stats.step_ms_last = s;
+    }
+    c->ev_pending = 0;
+    return NHDFIT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nhdfit_abi_version(void) { return NHDFIT_ABI_VERSION; }
+
+int nhdfit_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* nhdfit_last_error(nhdfit_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int nhdfit_create(int device_id, nhdfit_ctx** out) {
+    if (!out) return fail(nullptr, NHDFIT_E_INVAL, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, NHDFIT_E_NODEVICE, "no HIP device available (%s); libnhdfit has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, NHDFIT_E_INVAL, "device %d out of range [0,%d)", device_id, ndev);
+    nhdfit_ctx* c = new (std::nothrow) nhdfit_ctx();
+    if (!c) return fail(nullptr, NHDFIT_E_NOMEM, "out of host memory");
+    c->dev = device_id;
+    memset(&c->stats, 0, sizeof c->stats);
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&c->prop, device_id)) != hipSuccess) {
+        int rc = fail(nullptr, NHDFIT_E_HIP, "cannot open device %d: %s", device_id, hipGetErrorString(e));
+        delete c;
+        return rc;
+    }
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        int rc = fail(nullptr, NHDFIT_E_NODEVICE, "device %d is %s; libnhdfit is built for gfx950 only", device_id, c->prop.gcnArchName);
+        delete c;
+        return rc;
+    }
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        int rc = fail(nullptr, NHDFIT_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        delete c;
+        return rc;
+    }
+    for (auto& q : c->ev)
+        for (auto& x : q)
+            if ((e = hipEventCreate(&x)) != hipSuccess) {
+                int rc = fail(nullptr, NHDFIT_E_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+                delete c;
+                return rc;
+            }
+    *out = c;
+    return NHDFIT_OK;
+}
+
+void nhdfit_destroy(nhdfit_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->dev);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
+    c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
+    c->reqs.release(); c->hdr.release(); c->tabs.release(); c->score.release(); c->bitmap.release();
+    c->cand.release(); c->maps.release();
+    for (auto& q : c->ev)
+        for (auto& x : q)
+            if (x) (void)hipEventDestroy(x);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int nhdfit_set_dictionary(nhdfit_ctx* c, const double* caps, uint32_t ncls, const uint32_t* sig_off, uint32_t nsig,
+                          const uint32_t* pool_off, const uint8_t* pool_glimit, uint32_t npools,
+                          const nhdfit_cc* cc, uint32_t ncc) {
+    if (!c) return NHDFIT_E_INVAL;
+    if (!sig_off || !pool_off || nsig < 1) return fail(c, NHDFIT_E_INVAL, "dictionary needs at least the empty signature");
+    if (ncls > NHDFIT_MAX_CLASSES) return fail(c, NHDFIT_E_LIMIT, "%u capacity classes (max %d)", ncls, NHDFIT_MAX_CLASSES);
+    if (sig_off[0] != 0 || sig_off[1] != 0) return fail(c, NHDFIT_E_INVAL, "signature 0 must be empty");
+    if (sig_off[nsig] != npools || pool_off[npools] != ncc) return fail(c, NHDFIT_E_INVAL, "inconsistent dictionary offsets");
+    for (uint32_t k = 0; k < ncc; ++k)
+        if (cc[k].cls >= ncls) return fail(c, NHDFIT_E_INVAL, "class id %u out of range", cc[k].cls);
+    const uint32_t rows = kRowR + nsig;
+    const uint32_t words = (rows * kRowStride + 3u) & ~3u;
+    const uint32_t bytes = words * 4;
+    HIPCHK(c, hipSetDevice(c->dev));
+    if (bytes + 8192 > 160 * 1024)
+        return fail(c, NHDFIT_E_LIMIT, "%u NIC signatures need %u bytes of LDS per tile (160 KiB per CU)", nsig, bytes);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, c->caps.reserve(ncls ? ncls : 1));
+    HIPCHK(c, c->sig_off.reserve(nsig + 1));
+    HIPCHK(c, c->pool_off.reserve(npools + 1));
+    HIPCHK(c, c->pool_glimit.reserve(npools ? npools : 1));
+    HIPCHK(c, c->cc.reserve(ncc ? ncc : 1));
+    if (ncls) HIPCHK(c, hipMemcpy(c->caps.p, caps, ncls * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->sig_off.p, sig_off, (nsig + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->pool_off.p, pool_off, (npools + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (npools) HIPCHK(c, hipMemcpy(c->pool_glimit.p, pool_glimit, npools, hipMemcpyHostToDevice));
+    if (ncc) HIPCHK(c, hipMemcpy(c->cc.p, cc, ncc * sizeof(nhdfit_cc), hipMemcpyHostToDevice));
+    c->ncls = ncls;
+    c->nsig = nsig;
+    c->tab_words = words;
+    c->lds_bytes = bytes;
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_score<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_score<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return NHDFIT_OK;
+}
+
+int nhdfit_reserve_nodes(nhdfit_ctx* c, uint32_t capacity, uint64_t global_base) {
+    if (!c) return NHDFIT_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (capacity > c->capacity) {
+        c->n = 0;                                   // growing drops the contents: the caller re-uploads
+        HIPCHK(c, c->p0.reserve(capacity)); HIPCHK(c, c->p1.reserve(capacity)); HIPCHK(c, c->p2.reserve(capacity));
+        HIPCHK(c, c->p3.reserve(capacity)); HIPCHK(c, c->p4.reserve(capacity)); HIPCHK(c, c->det.reserve(capacity));
+        c->capacity = capacity;
+    }
+    c->global_base = global_base;
+    return NHDFIT_OK;
+}
+
+int nhdfit_set_node_count(nhdfit_ctx* c, uint32_t n) {
+    if (!c) return NHDFIT_E_INVAL;
+    if (n > c->capacity) return fail(c, NHDFIT_E_INVAL, "node count %u exceeds reserved capacity %u", n, c->capacity);
+    c->n = n;
+    return NHDFIT_OK;
+}
+
+int nhdfit_upload_nodes(nhdfit_ctx* c, uint32_t first, uint32_t count, const nhdfit_plane0* p0, const nhdfit_plane1* p1,
+                        const nhdfit_plane2* p2, const nhdfit_plane3* p3, const nhdfit_plane4* p4, const nhdfit_detail* det) {
+    if (!c) return NHDFIT_E_INVAL;
+    if (!count) return NHDFIT_OK;
+    if (!p0 || !p1 || !p2 || !p3 || !p4 || !det) return fail(c, NHDFIT_E_INVAL, "NULL plane");
+    if ((uint64_t)first + count > c->capacity) return fail(c, NHDFIT_E_INVAL, "upload [%u,%u) exceeds capacity %u", first, first + count, c->capacity);
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // a step in flight must not see a half-written record
+    HIPCHK(c, hipMemcpy(c->p0.p + first, p0, count * sizeof *p0, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->p1.p + first, p1, count * sizeof *p1, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->p2.p + first, p2, count * sizeof *p2, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->p3.p + first, p3, count * sizeof *p3, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->p4.p + first, p4, count * sizeof *p4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->det.p + first, det, count * sizeof *det, hipMemcpyHostToDevice));
+    if (first + count > c->n) c->n = first + count;
+    return NHDFIT_OK;
+}
+
+int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
+    if (!c) return NHDFIT_E_INVAL;
+    if (!reqs || !P) return fail(c, NHDFIT_E_INVAL, "no requests");
+    if (!c->nsig) return fail(c, NHDFIT_E_STATE, "set the dictionary first");
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint32_t tiles = (P + kTile - 1) / kTile;
+    const uint32_t chunks = (c->capacity + 63) / 64;
+    HIPCHK(c, c->reqs.reserve(P));
+    HIPCHK(c, c->hdr.reserve((size_t)tiles * kTile));
+    HIPCHK(c, c->tabs.reserve((size_t)tiles * c->tab_words));
+    HIPCHK(c, c->score.reserve(P));
+    HIPCHK(c, c->maps.reserve(P));
+    HIPCHK(c, c->bitmap.reserve((size_t)chunks * P));
+    HIPCHK(c, hipMemcpy(c->reqs.p, reqs, (size_t)P * sizeof *reqs, hipMemcpyHostToDevice));
+    c->P = P;
+    c->use_cand = false;
+    return NHDFIT_OK;
+}
+
+static int stage_cand(nhdfit_ctx* c, const uint64_t* cand) {
+    const size_t words = (size_t)((c->n + 63) / 64) * c->P;
+    HIPCHK(c, c->cand.reserve(words ? words : 1));
+    HIPCHK(c, hipMemcpy(c->cand.p, cand, words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    c->use_cand = true;
+    return NHDFIT_OK;
+}
+
+int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
+    if (!c) return NHDFIT_E_INVAL;
+    if (!c->P) return fail(c, NHDFIT_E_STATE, "stage requests first");
+    if (!c->n) return fail(c, NHDFIT_E_STATE, "no nodes uploaded");
+    HIPCHK(c, hipSetDevice(c->dev));
+    if (c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc) return rc; }
+    hipEvent_t* ev = c->ev[c->ev_pending];
+    const uint32_t P = c->P, tiles = (P + kTile - 1) / kTile;
+    const uint32_t chunks = (c->n + 63) / 64;
+
+    HIPCHK(c, hipEventRecord(ev[0], c->stream));
+    HIPCHK(c, hipMemsetAsync(c->score.p, 0, (size_t)P * sizeof(unsigned long long), c->stream));
+    DictView dv{c->caps.p, c->ncls, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}};
+    hipLaunchKernelGGL(k_digest, dim3(tiles, kDigestSlices), dim3(kDigestThreads), 0, c->stream,
+                       c->reqs.p, P, dv, c->tab_words, c->tabs.p, c->hdr.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(ev[1], c->stream));
+
+    // geometry: one 1024-thread block per CU-ful of LDS; shrink blocks for small problems so that
+    // the grid still covers the chip
+    FitArgs a;
+    a.p0 = c->p0.p; a.p1 = c->p1.p; a.p2 = c->p2.p; a.p3 = c->p3.p; a.p4 = c->p4.p;
+    a.n = c->n; a.chunks = chunks; a.global_base = c->global_base; a.now = now;
+    a.tabs = c->tabs.p; a.tab_words = c->tab_words; a.hdr = c->hdr.p; a.P = P;
+    a.cand = c->use_cand ? c->cand.p : nullptr;
+    a.bitmap = c->want_bitmap ? c->bitmap.p : nullptr;
+    a.score = c->score.p;
+    const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
+    const bool big = (uint64_t)tiles * ((chunks + 63) / 64) >= cus;     // enough 16-wave blocks of 4 chunks per wave
+    const uint32_t waves = big ? 16 : 4;
+    uint32_t cpb = waves;                                                // chunks per block: >= 1 per wave
+    while ((uint64_t)tiles * ((chunks + cpb * 2 - 1) / (cpb * 2)) >= 4ull * cus && cpb < waves * 8) cpb *= 2;
+    a.chunks_per_block = cpb;
+    a.nranges = (chunks + cpb - 1) / cpb;
+    const uint32_t grid = tiles * a.nranges;
+    if (big) hipLaunchKernelGGL(k_fit_score<1024>, dim3(grid), dim3(1024), c->lds_bytes, c->stream, a);
+    else     hipLaunchKernelGGL(k_fit_score<256>, dim3(grid), dim3(256), c->lds_bytes, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(ev[2], c->stream));
+
+    if (c->comm) {
+        ncclResult_t r = g_rccl.AllReduce(c->score.p, c->score.p, P, ncclUint64, ncclMax, c->comm, c->stream);
+        if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+    }
+    if (c->want_map) {
+        MapArgs m{c->p0.p, c->p1.p, c->p2.p, c->det.p, c->n, c->global_base, c->reqs.p, P, c->score.p, c->caps.p, c->maps.p};
+        hipLaunchKernelGGL(k_map, dim3((P + 63) / 64), dim3(64), 0, c->stream, m);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(ev[3], c->stream));
+    c->ev_pending++;
+
+    c->stats.evals_last = (uint64_t)P * c->n;
+    // algorithmic bytes of the fit_score launch: every tile streams the five node
+    // planes once, every block stages its tile image once, plus the bitmap and the score words.
+    c->stats.bytes_last = (uint64_t)tiles * c->n * 80ull + (uint64_t)grid * c->lds_bytes +
+                          (c->want_bitmap ? (uint64_t)chunks * P * 8ull : 0ull) + (uint64_t)P * 8ull +
+                          (c->use_cand ? (uint64_t)chunks * P * 8ull : 0ull);
+    c->stats.nodes = c->n; c->stats.nsig = c->nsig; c->stats.ncls = c->ncls; c->stats.lds_bytes = c->lds_bytes;
+    return NHDFIT_OK;
+}
+
+int nhdfit_sync(nhdfit_ctx* c) {
+    if (!c) return NHDFIT_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return drain_events(c);
+}
+
+int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out) {
+    if (!c) return NHDFIT_E_INVAL;
+    if (!c->P) return fail(c, NHDFIT_E_STATE, "nothing staged");
+    int rc = nhdfit_sync(c);
+    if (rc) return rc;
+    if (score_out) HIPCHK(c, hipMemcpy(score_out, c->score.p, (size_t)c->P * 8, hipMemcpyDeviceToHost));
+    if (bitmap_out) {
+        if (!c->want_bitmap) return fail(c, NHDFIT_E_STATE, "bitmap output is disabled");
+        HIPCHK(c, hipMemcpy(bitmap_out, c->bitmap.p, (size_t)((c->n + 63) / 64) * c->P * 8, hipMemcpyDeviceToHost));
+    }
+    if (map_out) {
+        if (!c->want_map) return fail(c, NHDFIT_E_STATE, "mapping output is disabled");
+        HIPCHK(c, hipMemcpy(map_out, c->maps.p, (size_t)c->P * sizeof(nhdfit_mapping), hipMemcpyDeviceToHost));
+    }
+    return NHDFIT_OK;
+}
+
+int nhdfit_find(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand,
+                uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out) {
+    int rc = nhdfit_stage_requests(c, reqs, P);
+    if (rc) return rc;
+    if (cand && (rc = stage_cand(c, cand))) return rc;
+    if ((rc = nhdfit_enqueue_step(c, now))) return rc;
+    return nhdfit_fetch(c, score_out, bitmap_out, map_out);
+}
+
+int nhdfit_set_outputs(nhdfit_ctx* c, int want_bitmap, int want_map) {
+    if (!c) return NHDFIT_E_INVAL;
+    c->want_bitmap = want_bitmap != 0;
+    c->want_map = want_map != 0;
+    return NHDFIT_OK;
+}
+
+int nhdfit_comm_unique_id(void* id128) {
+    std::string err;
+    if (!id128) return NHDFIT_E_INVAL;
+    if (!g_rccl.load(err)) return fail(nullptr, NHDFIT_E_RCCL, "%s", err.c_str());
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, NHDFIT_E_RCCL, "ncclGetUniqueId: %s", g_rccl.GetErrorString(r));
+    memcpy(id128, &id, 128);
+    return NHDFIT_OK;
+}
+
+int nhdfit_comm_init(nhdfit_ctx* c, int nranks, int rank, const void* id128) {
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, NHDFIT_E_INVAL, "bad communicator arguments");
+    std::string err;
+    if (!g_rccl.load(err)) return fail(c, NHDFIT_E_RCCL, "%s", err.c_str());
+    if (c->comm) return fail(c, NHDFIT_E_STATE, "communicator already attached");
+    HIPCHK(c, hipSetDevice(c->dev));
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) { c->comm = nullptr; return fail(c, NHDFIT_E_RCCL, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
+    c->nranks = nranks;
+    c->rank = rank;
+    return NHDFIT_OK;
+}
+
+int nhdfit_comm_destroy(nhdfit_ctx* c) {
+    if (!c) return NHDFIT_E_INVAL;
+    if (c->comm) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->nranks = 1;
+    c->rank = 0;
+    return NHDFIT_OK;
+}
+
+int nhdfit_get_stats(nhdfit_ctx* c, nhdfit_stats* out) {
+    if (!c || !out) return NHDFIT_E_INVAL;
+    *out = c->stats;
+    return NHDFIT_OK;
+}
+
+int nhdfit_reset_stats(nhdfit_ctx* c) {
+    if (!c) return NHDFIT_E_INVAL;
+    int rc = nhdfit_sync(c);
+    if (rc) return rc;
+    c->stats.launches = 0;
+    c->stats.fit_ms_total = 0;
+    return NHDFIT_OK;
+}
+
+}  // extern "C"

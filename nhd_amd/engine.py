@@ -1,0 +1,128 @@
+"""Thin object wrapper over the C-ABI: one :class:`Engine` = one nhdfit_ctx = one GPU."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+
+from . import _lib, pack
+
+SCORE_MASK = 0x7FFFFFFFFFFFFFFF
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self.lib.nhdfit_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise _lib.NhdFitError(rc, (self.lib.nhdfit_last_error(None) or b"?").decode())
+        self.ctx = h
+        self.device = device
+        self.n = 0
+        self.P = 0
+        self.global_base = 0
+        self._dict_version = -1
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.nhdfit_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _chk(self, rc):
+        _lib.check(self.ctx, rc)
+
+    # ---- state ------------------------------------------------------------------------
+    def set_dictionary(self, packer: pack.Packer):
+        if self._dict_version == packer.dict_version:
+            return
+        caps, sig_off, pool_off, glimit, cc, ncls, nsig, npools, ncc = packer.dictionary_arrays()
+        self._chk(self.lib.nhdfit_set_dictionary(self.ctx, _p(caps), ncls, _p(sig_off), nsig, _p(pool_off), _p(glimit),
+                                                 npools, _p(cc), ncc))
+        self._dict_version = packer.dict_version
+
+    def upload(self, table: pack.NodeTable, global_base: int = 0, first: int = 0, capacity: Optional[int] = None):
+        """Full upload (first == 0 and nothing uploaded yet) or delta upload of `table` at `first`."""
+        cap = max(capacity or 0, first + table.n)
+        self._chk(self.lib.nhdfit_reserve_nodes(self.ctx, cap, global_base))
+        arrs = [np.ascontiguousarray(x) for x in (table.p0, table.p1, table.p2, table.p3, table.p4, table.detail)]
+        self._chk(self.lib.nhdfit_upload_nodes(self.ctx, first, table.n, *[_p(a) for a in arrs]))
+        self.n = max(self.n, first + table.n)
+        self.global_base = global_base
+
+    def reset_nodes(self):
+        self._chk(self.lib.nhdfit_set_node_count(self.ctx, 0))
+        self.n = 0
+
+    def set_outputs(self, bitmap=True, mapping=True):
+        self._chk(self.lib.nhdfit_set_outputs(self.ctx, int(bitmap), int(mapping)))
+
+    # ---- one-shot ---------------------------------------------------------------------
+    def find(self, reqs: np.ndarray, now: float, cand: Optional[np.ndarray] = None, want_bitmap=True, want_map=True):
+        reqs = np.ascontiguousarray(reqs)
+        P = len(reqs)
+        score = np.zeros(P, np.uint64)
+        bitmap = np.zeros(((self.n + 63) // 64, P), np.uint64) if want_bitmap else None
+        maps = np.zeros(P, pack.MAPPING) if want_map else None
+        if cand is not None:
+            cand = np.ascontiguousarray(cand, dtype=np.uint64)
+            assert cand.shape == ((self.n + 63) // 64, P)
+        self._chk(self.lib.nhdfit_find(self.ctx, _p(reqs), P, float(now), _p(cand), _p(score), _p(bitmap), _p(maps)))
+        self.P = P
+        return score, bitmap, maps
+
+    # ---- pipelined --------------------------------------------------------------------
+    def stage(self, reqs: np.ndarray):
+        reqs = np.ascontiguousarray(reqs)
+        self._chk(self.lib.nhdfit_stage_requests(self.ctx, _p(reqs), len(reqs)))
+        self.P = len(reqs)
+
+    def enqueue(self, now: float):
+        self._chk(self.lib.nhdfit_enqueue_step(self.ctx, float(now)))
+
+    def sync(self):
+        self._chk(self.lib.nhdfit_sync(self.ctx))
+
+    def fetch(self, want_bitmap=False, want_map=True):
+        score = np.zeros(self.P, np.uint64)
+        bitmap = np.zeros(((self.n + 63) // 64, self.P), np.uint64) if want_bitmap else None
+        maps = np.zeros(self.P, pack.MAPPING) if want_map else None
+        self._chk(self.lib.nhdfit_fetch(self.ctx, _p(score), _p(bitmap), _p(maps)))
+        return score, bitmap, maps
+
+    def stats(self) -> _lib.Stats:
+        s = _lib.Stats()
+        self._chk(self.lib.nhdfit_get_stats(self.ctx, ctypes.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._chk(self.lib.nhdfit_reset_stats(self.ctx))
+
+    # ---- collective -------------------------------------------------------------------
+    def unique_id(self) -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        rc = self.lib.nhdfit_comm_unique_id(buf)
+        if rc != 0:
+            raise _lib.NhdFitError(rc, (self.lib.nhdfit_last_error(None) or b"?").decode())
+        return buf.raw
+
+    def comm_init(self, nranks: int, rank: int, uid: bytes):
+        self._chk(self.lib.nhdfit_comm_init(self.ctx, nranks, rank, ctypes.c_char_p(uid)))
+
+    def comm_destroy(self):
+        self._chk(self.lib.nhdfit_comm_destroy(self.ctx))
+
+
+def winner_index(score: int) -> int:
+    return SCORE_MASK - (int(score) & SCORE_MASK)

@@ -1,0 +1,200 @@
+"""HipMatcher - drop-in for ``nhd.Matcher.Matcher`` (nhd/Matcher.py:21-63).
+
+    self.matcher = Matcher()                                   nhd/NHDScheduler.py:50
+    match = self.matcher.FindNode(filt_nodes, top)             nhd/NHDScheduler.py:277
+    match[0] -> node name or None,  match[1] -> {'gpu': (..), 'cpu': (..), 'nic': [(numa, idx), ..]}
+
+Same contract: ``FindNode(nl, top)`` returns ``(name, mapping)`` or the 1-tuple ``(None,)``, never
+mutates ``nl``/``top``, breaks ties by ``nl`` iteration order, is called from one thread.  The per-node
+Python loops are replaced by one pass of the gfx950 kernels over a packed mirror of the cluster
+(DESIGN.md).  If libnhdfit.so or the GPU is missing, construction raises - there is no CPU path.
+
+Two ways to keep the device mirror current:
+
+* stateless (default): every call packs ``nl`` again.  Always right, O(N) Python per call.
+* ``attach(nodes)``: ``nodes`` is the scheduler's long-lived ``self.nodes`` dict.  Nodes are packed
+  once; afterwards only nodes touched through the reference's own mutators (nhd/Node.py:144, 530,
+  587, 644, 663, 843, 308) or whose ``active`` / ``maintenance`` / ``groups`` / ``busy_time`` were
+  assigned are re-packed (dirty tracking by swapping in a thin subclass).  ``FindNode(nl, top)`` then
+  accepts any subset ``nl`` of ``nodes`` in the same relative order (what InitialNodeFilter
+  produces, nhd/NHDScheduler.py:235-247) and turns it into a candidate bitmask.
+
+``FindNodes(nl, tops, pod_groups)`` is the batch form (every pod against one snapshot).
+"""
+from __future__ import annotations
+
+import logging
+import time
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import pack
+from .engine import Engine, winner_index
+
+_MUTATORS = ("SetPhysicalIdsFromMapping", "RemoveResourcesFromTopology", "AddResourcesFromTopology",
+             "ResetResources", "ClaimPodNICResources", "SetBusy", "SetGroups", "SetHugepages", "ParseLabels")
+_WATCHED = frozenset(("active", "maintenance", "groups", "busy_time"))
+_tracked_cache: Dict[type, type] = {}
+
+
+def _tracked_class(base: type) -> type:
+    """Subclass of the node's own class that reports state changes to the matcher owning it."""
+    cls = _tracked_cache.get(base)
+    if cls is not None:
+        return cls
+
+    def __setattr__(self, key, value):
+        base.__setattr__(self, key, value)
+        if key in _WATCHED:
+            hook = self.__dict__.get("_nhdfit_dirty")
+            if hook is not None:
+                hook(self)
+
+    ns = {"__setattr__": __setattr__}
+    for name in _MUTATORS:
+        orig = getattr(base, name, None)
+        if orig is None:
+            continue
+
+        def make(orig):
+            def wrapper(self, *a, **kw):
+                try:
+                    return orig(self, *a, **kw)
+                finally:
+                    hook = self.__dict__.get("_nhdfit_dirty")
+                    if hook is not None:
+                        hook(self)
+            wrapper.__name__ = orig.__name__
+            return wrapper
+        ns[name] = make(orig)
+    cls = type("Tracked" + base.__name__, (base,), ns)
+    _tracked_cache[base] = cls
+    return cls
+
+
+class HipMatcher:
+    def __init__(self, device: int = 0, clock=time.monotonic):
+        self.logger = logging.getLogger(__name__)
+        self.engine = Engine(device)          # raises when the HIP library / a gfx950 GPU is missing
+        self.packer = pack.Packer()
+        self.clock = clock
+        self._attached: Optional[Dict[str, object]] = None
+        self._index: Dict[str, int] = {}
+        self._names: List[str] = []
+        self._table: Optional[pack.NodeTable] = None
+        self._dirty: Dict[str, object] = {}
+        self._uploaded_ids: Optional[Tuple[int, ...]] = None
+
+    # ---- mirror maintenance -------------------------------------------------------------
+    def attach(self, nodes: Dict[str, object]) -> None:
+        """Mirror `nodes` (the scheduler's self.nodes) persistently and track changes to it."""
+        self._attached = nodes
+        for node in nodes.values():
+            if type(node) not in _tracked_cache.values():
+                node.__class__ = _tracked_class(type(node))
+            node.__dict__["_nhdfit_dirty"] = self._mark
+        self._full_upload(nodes)
+        self._dirty.clear()
+
+    def detach(self) -> None:
+        if self._attached:
+            for node in self._attached.values():
+                node.__dict__.pop("_nhdfit_dirty", None)
+        self._attached = None
+
+    def _mark(self, node) -> None:
+        self._dirty[node.name] = node
+
+    def mark_dirty(self, name: str) -> None:
+        if self._attached is not None and name in self._attached:
+            self._dirty[name] = self._attached[name]
+
+    def _full_upload(self, nl: Dict[str, object]) -> None:
+        table = self.packer.pack_nodes(nl)
+        self._table = table
+        self._names = table.names
+        self._index = {nm: i for i, nm in enumerate(table.names)}
+        self.engine.reset_nodes()
+        self.engine.set_dictionary(self.packer)
+        if table.n:
+            self.engine.upload(table)
+
+    def _flush_dirty(self) -> None:
+        if not self._dirty:
+            return
+        if len(self._attached) != len(self._names) or any(nm not in self._index for nm in self._dirty):
+            self._full_upload(self._attached)          # nodes were added or removed
+            self._dirty.clear()
+            return
+        one = pack.empty_table(1)
+        for name, node in self._dirty.items():
+            i = self._index[name]
+            self.packer.pack_node_into(node, one, 0)
+            for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
+                getattr(self._table, f)[i] = getattr(one, f)[0]
+        self.engine.set_dictionary(self.packer)        # signatures may have been added
+        idx = sorted(self._index[nm] for nm in self._dirty)
+        lo = 0
+        while lo < len(idx):                           # upload contiguous runs
+            hi = lo
+            while hi + 1 < len(idx) and idx[hi + 1] == idx[hi] + 1:
+                hi += 1
+            self.engine.upload(self._table.slice(idx[lo], idx[hi] + 1), first=idx[lo], capacity=self._table.n)
+            lo = hi + 1
+        self._dirty.clear()
+
+    def _candidates(self, nl: Dict[str, object], P: int) -> Optional[np.ndarray]:
+        """Bitmask [chunks][P] of the attached nodes that are in `nl`; None when nl is everything."""
+        n = len(self._names)
+        if nl is self._attached or len(nl) == n:
+            if all(a == b for a, b in zip(nl, self._names)):
+                return None
+        idx = np.fromiter((self._index[k] for k in nl), dtype=np.int64, count=len(nl))
+        if len(idx) > 1 and not np.all(idx[1:] > idx[:-1]):
+            raise ValueError("FindNode: `nl` must keep the relative order of the attached node dict")
+        bits = np.zeros(((n + 63) // 64) * 64, dtype=bool)
+        bits[idx] = True
+        words = np.packbits(bits.reshape(-1, 64), axis=1, bitorder="little").view("<u8").reshape(-1)
+        return np.ascontiguousarray(np.repeat(words[:, None], P, axis=1))
+
+    # ---- the reference interface ----------------------------------------------------------
+    def FindNode(self, nl: Dict[str, object], top) -> Tuple:
+        return self.FindNodes(nl, [top])[0]
+
+    def FindNodes(self, nl: Dict[str, object], tops: Sequence[object],
+                  pod_groups: Optional[Sequence[Sequence[str]]] = None, now: Optional[float] = None) -> List[Tuple]:
+        """Mode-A batch: every pod of `tops` against the same snapshot of `nl`.  With `pod_groups`
+        the kernel applies InitialNodeFilter itself (nl = all nodes); without, `nl` is taken as already
+        filtered, exactly like the argument of Matcher.FindNode."""
+        if not tops:
+            return []
+        for top in tops:
+            if len(top.proc_groups) == 0 and len(nl):
+                raise IndexError("pod without processing groups (the reference fails the same way, Matcher.py:346)")
+        if len(nl) == 0:
+            return [(None,) for _ in tops]
+        now = self.clock() if now is None else now
+        cand = None
+        if self._attached is not None and all(k in self._index for k in nl):
+            self._flush_dirty()
+            cand = self._candidates(nl, len(tops))
+        else:
+            self._full_upload(nl)
+        reqs = self.packer.digest_many(tops, pod_groups)
+        score, _, maps = self.engine.find(reqs, now, cand=cand, want_bitmap=False, want_map=True)
+        out: List[Tuple] = []
+        for p in range(len(tops)):
+            s = int(score[p])
+            if s == 0:
+                out.append((None,))
+                continue
+            name = self._names[winner_index(s) - self.engine.global_base]
+            G = int(reqs[p]["n_groups"])
+            m = maps[p]
+            if not m["valid"]:
+                raise RuntimeError(f"internal error: no mapping produced for feasible node {name}")
+            out.append((name, {"gpu": tuple(int(x) for x in m["gpu"][:G]),
+                               "cpu": tuple(int(x) for x in m["cpu"][:G + 1]),
+                               "nic": [(int(a), int(b)) for a, b in zip(m["nic_numa"][:G], m["nic_idx"][:G])]}))
+        return out
