@@ -30,7 +30,8 @@ extern "C" {
 #define NHDFIT_MAX_GROUPS         4      /* proc groups per pod (G)                               */
 #define NHDFIT_MAX_NUMA           2      /* NUMA nodes (= sockets, nhd/Node.py:336) per node (U)  */
 #define NHDFIT_MAX_CORES_PER_NUMA 64     /* physical cores per socket (one uint64 mask)           */
-#define NHDFIT_MAX_GPUS           32     /* GPUs per node (one uint32 mask), <= 16 per NUMA node  */
+#define NHDFIT_MAX_GPUS           32     /* GPUs per node (one uint32 mask)                       */
+#define NHDFIT_MAX_GPUS_PER_NUMA  8      /* GPUs on one NUMA node (pair-indexed GPU table)        */
 #define NHDFIT_MAX_NICS_PER_NUMA  16
 #define NHDFIT_MAX_SWITCHES       14     /* distinct PCIe switches per node                       */
 #define NHDFIT_MAX_CLASSES        16     /* distinct NIC capacity values cluster-wide             */
@@ -145,9 +146,12 @@ int  nhdfit_create(int device_id, nhdfit_ctx** out);
 void nhdfit_destroy(nhdfit_ctx* ctx);
 const char* nhdfit_last_error(nhdfit_ctx* ctx);            /* ctx may be NULL: last error of a failed create */
 
-/* NIC capacity classes + signature dictionary (CSR: sig -> pools -> (class,count) pairs).
- * Signature 0 must be the empty signature.  May be called again when the dictionary grows. */
-int nhdfit_set_dictionary(nhdfit_ctx* ctx, const double* caps, uint32_t ncls,
+/* NIC capacity classes + signature dictionary (CSR: sig -> pools -> (class,count) pairs) and the
+ * largest number of physical cores per socket / GPUs per NUMA node anywhere in the cluster (they
+ * size the per-pod tables).  Signature 0 must be the empty signature.  May be called again when the
+ * dictionary grows. */
+int nhdfit_set_dictionary(nhdfit_ctx* ctx, uint32_t max_cores_per_numa, uint32_t max_gpus_per_numa,
+                          const double* caps, uint32_t ncls,
                           const uint32_t* sig_off, uint32_t nsig,
                           const uint32_t* pool_off, const uint8_t* pool_glimit, uint32_t npools,
                           const nhdfit_cc* cc, uint32_t ncc);

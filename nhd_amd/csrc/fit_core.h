@@ -35,14 +35,27 @@ namespace nhdfit {
 
 constexpr int kMaxG       = NHDFIT_MAX_GROUPS;
 constexpr int kTile       = NHDFIT_TILE;
-constexpr int kRowStride  = kTile + 1;               // words per table row (odd -> bank spread)
-constexpr int kFcSlots    = NHDFIT_MAX_CORES_PER_NUMA + 1;   // free cores index 0..64
-constexpr int kFgSlots    = 17;                      // free GPUs per NUMA index 0..16
-constexpr int kRowsW      = 2 * kFcSlots;            // [smt?][free cores]
-constexpr int kRowW0      = 0;
-constexpr int kRowW1      = kRowW0 + kRowsW;
-constexpr int kRowA       = kRowW1 + kRowsW;
-constexpr int kRowR       = kRowA + kFgSlots;        // + sig id
+constexpr int kRowStride  = kTile + 2;               // words per table row: even (8-byte aligned pod pairs for ds_read_b64)
+                                                     // and = 2 mod 64 so different rows land on different LDS banks
+// rows of a tile's table image: W0[2][fc_dim] W1[2][fc_dim] A[fg_dim][fg_dim] R[nsig]
+struct Layout {
+    uint32_t fc_dim;     // 1 + max physical cores on one socket anywhere in the cluster (<= 65)
+    uint32_t fg_dim;     // 1 + max GPUs installed on one NUMA node anywhere in the cluster (<= 9)
+    uint32_t row_w1;     // first row of W1   (W0 starts at row 0)
+    uint32_t row_a;      // first row of A    (+ f0 * fg_dim + f1)
+    uint32_t row_r;      // first NIC-signature row
+    uint32_t rows;
+};
+NHD_HD Layout make_layout(uint32_t max_cores_per_numa, uint32_t max_gpus_per_numa, uint32_t nsig) {
+    Layout l;
+    l.fc_dim = max_cores_per_numa + 1;
+    l.fg_dim = max_gpus_per_numa + 1;
+    l.row_w1 = 2 * l.fc_dim;
+    l.row_a = 4 * l.fc_dim;
+    l.row_r = l.row_a + l.fg_dim * l.fg_dim;
+    l.rows = l.row_r + nsig;
+    return l;
+}
 constexpr double kMinBusySecs = 30.0;                // Node.MIN_BUSY_SECS, nhd/Node.py:107
 
 // Request header consumed in the wave-uniform part of the fit kernel (one per pod).
@@ -100,13 +113,11 @@ NHD_HD PodHeader pod_header(const nhdfit_req& r) {
     return h;
 }
 
-// ---- CPU tables: row e = smt*65 + free_cores -------------------------------------------------
+// ---- CPU tables: row = smt * fc_dim + free_cores ---------------------------------------------
 //   W0[e] = C0 | C0m<<16,  C0 bit p:  sumC(S0(p))        <= f ,  C0m: sumC(S0(p)) + misc <= f
 //   W1[e] = C1m | C1<<16,  C1 bit p:  sumC(S1(p))        <= f ,  C1m: sumC(S1(p)) + misc <= f
 //   x = W0[e0] & W1[e1]  ->  cpu_ok = (x | x>>16) & 0xFFFF
-NHD_HD uint32_t entry_w0(const nhdfit_req& r, const PodSums& s, int e) {
-    const bool smt = e >= kFcSlots;
-    const uint32_t f = (uint32_t)(smt ? e - kFcSlots : e);
+NHD_HD uint32_t entry_w0(const nhdfit_req& r, const PodSums& s, bool smt, uint32_t f) {
     const uint32_t* sum = smt ? s.cpu_smt : s.cpu_nosmt;
     const uint32_t misc = smt ? r.misc_smt : r.misc_nosmt;
     uint32_t c0 = 0, c0m = 0;
@@ -118,9 +129,7 @@ NHD_HD uint32_t entry_w0(const nhdfit_req& r, const PodSums& s, int e) {
     return c0 | (c0m << 16);
 }
 
-NHD_HD uint32_t entry_w1(const nhdfit_req& r, const PodSums& s, int e) {
-    const bool smt = e >= kFcSlots;
-    const uint32_t f = (uint32_t)(smt ? e - kFcSlots : e);
+NHD_HD uint32_t entry_w1(const nhdfit_req& r, const PodSums& s, bool smt, uint32_t f) {
     const uint32_t* sum = smt ? s.cpu_smt : s.cpu_nosmt;
     const uint32_t misc = smt ? r.misc_smt : r.misc_nosmt;
     uint32_t c1 = 0, c1m = 0;
@@ -132,15 +141,12 @@ NHD_HD uint32_t entry_w1(const nhdfit_req& r, const PodSums& s, int e) {
     return c1m | (c1 << 16);
 }
 
-// ---- GPU table: row f = free GPUs on the NUMA node;  A[f] = A0 | A1<<16 ----------------------
-//   gpu_ok = (A[f0] & 0xFFFF) & (A[f1] >> 16)
-NHD_HD uint32_t entry_a(const PodSums& s, int f) {
-    uint32_t a0 = 0, a1 = 0;
-    for (uint32_t p = 0; p < s.W; ++p) {
-        if (s.gpu[~p & s.full] <= (uint32_t)f) a0 |= 1u << p;
-        if (s.gpu[p] <= (uint32_t)f) a1 |= 1u << p;
-    }
-    return a0 | (a1 << 16);
+// ---- GPU table: row (f0, f1) = free GPUs on NUMA 0 / NUMA 1;  bit p: both sums fit ---------------
+NHD_HD uint32_t entry_a(const PodSums& s, uint32_t f0, uint32_t f1) {
+    uint32_t a = 0;
+    for (uint32_t p = 0; p < s.W; ++p)
+        if (s.gpu[~p & s.full] <= f0 && s.gpu[p] <= f1) a |= 1u << p;
+    return a;
 }
 
 // ---- NIC reach families -----------------------------------------------------------------------
@@ -218,7 +224,7 @@ NHD_HD uint32_t entry_r(uint32_t reach, uint32_t W) {
 // ---- node side -----------------------------------------------------------------------------------
 struct NodeLane {            // what one lane keeps for its node while it sweeps a tile of pods
     uint32_t off_w0, off_w1; // word offsets of the node's table rows (row * kRowStride)
-    uint32_t off_a0, off_a1;
+    uint32_t off_a;
     uint32_t off_rn0, off_rn1, off_rp0, off_rp1;
     int32_t  hp_free;
     uint32_t flags;
@@ -227,17 +233,22 @@ struct NodeLane {            // what one lane keeps for its node while it sweeps
 };
 
 NHD_HD NodeLane node_lane(const nhdfit_plane0& a, const nhdfit_plane1& b, const nhdfit_plane2& c,
-                          const nhdfit_plane3& d, const nhdfit_plane4& e, double now) {
+                          const nhdfit_plane3& d, const nhdfit_plane4& e, double now, const Layout& L) {
     NodeLane n;
-    const uint32_t smt = (c.flags & NHDFIT_NF_SMT) ? kFcSlots : 0;
-    n.off_w0 = (kRowW0 + smt + popc64(a.t0[0] & b.t1[0])) * kRowStride;   // free physical cores, nhd/Node.py:250-264
-    n.off_w1 = (kRowW1 + smt + popc64(a.t0[1] & b.t1[1])) * kRowStride;
-    n.off_a0 = (kRowA + popc32(c.gpu_free & ~c.gpu_numa1)) * kRowStride;  // free GPUs per NUMA, nhd/Node.py:456-462
-    n.off_a1 = (kRowA + popc32(c.gpu_free & c.gpu_numa1)) * kRowStride;
-    n.off_rn0 = (kRowR + d.sig_numa[0]) * kRowStride;
-    n.off_rn1 = (kRowR + d.sig_numa[1]) * kRowStride;
-    n.off_rp0 = (kRowR + d.sig_pci[0]) * kRowStride;
-    n.off_rp1 = (kRowR + d.sig_pci[1]) * kRowStride;
+    const uint32_t smt = (c.flags & NHDFIT_NF_SMT) ? L.fc_dim : 0;
+    uint32_t c0 = popc64(a.t0[0] & b.t1[0]), c1 = popc64(a.t0[1] & b.t1[1]);       // free physical cores, nhd/Node.py:250-264
+    c0 = c0 < L.fc_dim ? c0 : L.fc_dim - 1;
+    c1 = c1 < L.fc_dim ? c1 : L.fc_dim - 1;
+    n.off_w0 = (smt + c0) * kRowStride;
+    n.off_w1 = (L.row_w1 + smt + c1) * kRowStride;
+    uint32_t f0 = popc32(c.gpu_free & ~c.gpu_numa1), f1 = popc32(c.gpu_free & c.gpu_numa1);   // nhd/Node.py:456-462
+    f0 = f0 < L.fg_dim ? f0 : L.fg_dim - 1;
+    f1 = f1 < L.fg_dim ? f1 : L.fg_dim - 1;
+    n.off_a = (L.row_a + f0 * L.fg_dim + f1) * kRowStride;
+    n.off_rn0 = (L.row_r + d.sig_numa[0]) * kRowStride;
+    n.off_rn1 = (L.row_r + d.sig_numa[1]) * kRowStride;
+    n.off_rp0 = (L.row_r + d.sig_pci[0]) * kRowStride;
+    n.off_rp1 = (L.row_r + d.sig_pci[1]) * kRowStride;
     n.hp_free = c.hp_free;
     n.flags = c.flags;
     n.groups = d.groups;
@@ -259,7 +270,7 @@ NHD_HD bool eval_pair(const NodeLane& n, const PodHeader& h, const uint32_t* tab
     uint32_t ok = (x | (x >> 16)) & 0xFFFFu;
     if (h.flags & kPodNeedGpu) {
         pass &= !n.busy;                                                     // Matcher.py:107-111
-        ok &= tab[n.off_a0 + col] & (tab[n.off_a1 + col] >> 16);
+        ok &= tab[n.off_a + col];
     }
     uint32_t r0, r1;
     if (h.flags & kPodPci) { r0 = tab[n.off_rp0 + col]; r1 = tab[n.off_rp1 + col]; }

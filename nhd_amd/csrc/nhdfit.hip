@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -48,7 +49,7 @@ constexpr int kDigestSlices = 8;
 // grid = (tiles, kDigestSlices).  Every block rebuilds the (cheap) per-pod sums / covers of its tile
 // in LDS, then fills its share of the table rows; consecutive threads write consecutive columns.
 __global__ __launch_bounds__(kDigestThreads) void k_digest(const nhdfit_req* __restrict__ reqs, uint32_t P,
-                                                           DictView d, uint32_t tab_words,
+                                                           DictView d, Layout L, uint32_t tab_words,
                                                            uint32_t* __restrict__ tabs, PodHeader* __restrict__ hdr) {
     __shared__ nhdfit_req s_req[kTile];
     __shared__ PodSums s_sum[kTile];
@@ -77,17 +78,17 @@ __global__ __launch_bounds__(kDigestThreads) void k_digest(const nhdfit_req* __r
     }
     __syncthreads();
 
-    const uint32_t rows = kRowR + d.sig.nsig;
-    for (uint32_t w = slice * kDigestThreads + tid; w < rows * kTile; w += kDigestSlices * kDigestThreads) {
+    for (uint32_t w = slice * kDigestThreads + tid; w < L.rows * kTile; w += kDigestSlices * kDigestThreads) {
         const uint32_t j = w % kTile, row = w / kTile;
         uint32_t v = 0;
         if (s_valid[j]) {
             const nhdfit_req& r = s_req[j];
             const PodSums& s = s_sum[j];
-            if (row < (uint32_t)kRowW1) v = entry_w0(r, s, (int)row - kRowW0);
-            else if (row < (uint32_t)kRowA) v = entry_w1(r, s, (int)row - kRowW1);
-            else if (row < (uint32_t)kRowR) v = entry_a(s, (int)row - kRowA);
-            else v = entry_r(sig_reach(d.sig, row - kRowR, &s_cover[j][0][0], s.W), s.W);
+            if (row < L.row_w1) v = entry_w0(r, s, row >= L.fc_dim, row >= L.fc_dim ? row - L.fc_dim : row);
+            else if (row < L.row_a) v = entry_w1(r, s, row - L.row_w1 >= L.fc_dim,
+                                                 row - L.row_w1 >= L.fc_dim ? row - L.row_w1 - L.fc_dim : row - L.row_w1);
+            else if (row < L.row_r) v = entry_a(s, (row - L.row_a) / L.fg_dim, (row - L.row_a) % L.fg_dim);
+            else v = entry_r(sig_reach(d.sig, row - L.row_r, &s_cover[j][0][0], s.W), s.W);
         }
         tab[row * kRowStride + j] = v;
     }
@@ -107,6 +108,7 @@ struct FitArgs {
     double now;
     const uint32_t* tabs;
     uint32_t tab_words;         // words per tile image (multiple of 4)
+    Layout layout;
     const PodHeader* hdr;       // [tiles*64], zero flags beyond P
     uint32_t P;
     const uint64_t* cand;       // optional [chunks][P]
@@ -134,11 +136,19 @@ __global__ __launch_bounds__(BLOCK) void k_fit_score(FitArgs a) {
 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t pod0 = tile * kTile;
-    // lane-as-pod view of the tile's 64 request headers; inside the pod sweep they are broadcast
-    // back out of these registers with v_readlane (-> SGPRs: the header tests become scalar branches)
+    // Lane-as-pod view of the tile's 64 request headers.  Everything the pod sweep needs from them is
+    // wave-uniform: flag tests become bit tests on 64-bit scalar masks, hp_req / groups are broadcast
+    // out of these registers with v_readlane.
     const PodHeader my_h = a.hdr[pod0 + lane];
     const bool my_pod_live = pod0 + lane < a.P;
     const bool my_pod_needs_gpu = (my_h.flags & kPodNeedGpu) != 0;
+    const uint64_t m_valid = __ballot((my_h.flags & kPodValid) != 0);
+    const uint64_t m_need = __ballot(my_pod_needs_gpu);
+    const uint64_t m_pci = __ballot((my_h.flags & kPodPci) != 0);
+    const uint64_t m_filt = __ballot((my_h.flags & kPodFilter) != 0);
+    const bool t_need = m_need != 0, t_pci = m_pci != 0, t_filt = m_filt != 0;
+    const bool homog = m_valid == ~0ull && (m_need == 0 || m_need == ~0ull) && (m_pci == 0 || m_pci == ~0ull) &&
+                       (m_filt == 0 || m_filt == ~0ull);
     unsigned long long best = 0;
 
     const uint32_t c_begin = range * a.chunks_per_block;
@@ -146,28 +156,83 @@ __global__ __launch_bounds__(BLOCK) void k_fit_score(FitArgs a) {
     for (uint32_t c = c_begin + wave; c < c_end; c += NW) {
         const uint32_t i = c * 64 + lane;
         const bool live = i < a.n;
-        NodeLane nl;
-        if (live) {
-            nl = node_lane(a.p0[i], a.p1[i], a.p2[i], a.p3[i], a.p4[i], a.now);
-        } else {
-            nl = NodeLane{};
-            nl.flags = NHDFIT_NF_MAINTENANCE;            // never feasible
-        }
+        NodeLane nl = NodeLane{};
+        if (live) nl = node_lane(a.p0[i], a.p1[i], a.p2[i], a.p3[i], a.p4[i], a.now, a.layout);
+        // node-side predicates as 64-bit lane masks (scalar registers)
+        const uint64_t n_ok = __ballot(live && !(nl.flags & NHDFIT_NF_MAINTENANCE));      // Matcher.py:71
+        const uint64_t n_active = __ballot((nl.flags & NHDFIT_NF_ACTIVE) != 0);           // NHDScheduler.py:242
+        const uint64_t n_idle = __ballot(!nl.busy);                                       // Matcher.py:107-111
         const uint64_t nogpu = __ballot(live && !(nl.flags & NHDFIT_NF_HAS_GPU));
+        const uint32_t* tw0 = tab + nl.off_w0;
+        const uint32_t* tw1 = tab + nl.off_w1;
+        const uint32_t* ta = tab + nl.off_a;
+        const uint32_t* trn0 = tab + nl.off_rn0;
+        const uint32_t* trn1 = tab + nl.off_rn1;
+        const uint32_t* trp0 = tab + nl.off_rp0;
+        const uint32_t* trp1 = tab + nl.off_rp1;
 
         uint32_t wlo = 0, whi = 0;
-#pragma unroll 8
-        for (uint32_t j = 0; j < (uint32_t)kTile; ++j) {
-            PodHeader h;                                  // wave-uniform
-            h.flags = (uint32_t)__builtin_amdgcn_readlane((int)my_h.flags, (int)j);
-            h.hp_req = __builtin_amdgcn_readlane(my_h.hp_req, (int)j);
-            h.groups = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_h.groups, (int)j) |
-                       ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_h.groups >> 32), (int)j) << 32);
-            const bool ok = eval_pair(nl, h, tab, j);
-            const uint64_t w = __ballot(ok);
-            // transpose: lane j keeps the ballot of pod j
-            wlo = (uint32_t)nhd_writelane((int)(uint32_t)w, (int)j, (int)wlo);
-            whi = (uint32_t)nhd_writelane((int)(uint32_t)(w >> 32), (int)j, (int)whi);
+        if (homog) {
+            // Fast sweep: every pod of the tile has the same (needs-GPU, PCI, filter) class - the host
+            // stages requests sorted by class - so the class tests are per-tile scalars and two pods
+            // are served by each 8-byte LDS gather (columns j, j+1 of one row are adjacent words).
+            const uint32_t* tr0 = t_pci ? trp0 : trn0;
+            const uint32_t* tr1 = t_pci ? trp1 : trn1;
+            for (uint32_t j0 = 0; j0 < (uint32_t)kTile; j0 += 8) {
+#pragma unroll
+                for (uint32_t jj = 0; jj < 8; jj += 2) {
+                    const uint32_t j = j0 + jj;
+                    const uint2 w0 = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(tw0 + j, 8));
+                    const uint2 w1 = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(tw1 + j, 8));
+                    const uint2 r0 = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(tr0 + j, 8));
+                    const uint2 r1 = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(tr1 + j, 8));
+                    uint2 ga = make_uint2(0xFFFFu, 0xFFFFu);
+                    if (t_need) ga = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(ta + j, 8));
+#pragma unroll
+                    for (uint32_t h = 0; h < 2; ++h) {
+                        const uint32_t pod = j + h;
+                        const int hp = __builtin_amdgcn_readlane(my_h.hp_req, (int)pod);
+                        uint64_t pass = n_ok & __ballot(hp <= nl.hp_free);                  // Matcher.py:78
+                        if (t_filt) {                                                         // NHDScheduler.py:240-242
+                            const uint64_t g = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_h.groups, (int)pod) |
+                                ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_h.groups >> 32), (int)pod) << 32);
+                            pass &= n_active & __ballot((nl.groups & g) != 0);
+                        }
+                        if (t_need) pass &= n_idle;                                           // Matcher.py:107-111
+                        const uint32_t x = (h ? w0.y : w0.x) & (h ? w1.y : w1.x);
+                        const uint32_t ok = (x | (x >> 16)) & (h ? ga.y : ga.x) & ((h ? r0.y : r0.x) >> 16) & (h ? r1.y : r1.x);
+                        const uint64_t w = pass & __ballot(ok != 0);
+                        wlo = (uint32_t)nhd_writelane((int)(uint32_t)w, (int)pod, (int)wlo);
+                        whi = (uint32_t)nhd_writelane((int)(uint32_t)(w >> 32), (int)pod, (int)whi);
+                    }
+                }
+            }
+        } else {
+            // Generic sweep (mixed or partly invalid tiles): per-pod class bits out of scalar masks.
+#pragma unroll 2
+            for (uint32_t j = 0; j < (uint32_t)kTile; ++j) {
+                if (!(m_valid >> j & 1)) continue;                                            // Matcher.py:45-47
+                const int hp = __builtin_amdgcn_readlane(my_h.hp_req, (int)j);
+                uint64_t pass = n_ok & __ballot(hp <= nl.hp_free);
+                if (m_filt >> j & 1) {
+                    const uint64_t g = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_h.groups, (int)j) |
+                                       ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_h.groups >> 32), (int)j) << 32);
+                    pass &= n_active & __ballot((nl.groups & g) != 0);
+                }
+                const uint32_t x = tw0[j] & tw1[j];
+                uint32_t ok = x | (x >> 16);                  // high half is cleared by the NIC term below
+                if (m_need >> j & 1) {
+                    pass &= n_idle;
+                    ok &= ta[j];
+                }
+                const bool pci = m_pci >> j & 1;
+                const uint32_t r0 = (pci ? trp0 : trn0)[j];
+                const uint32_t r1 = (pci ? trp1 : trn1)[j];
+                ok &= (r0 >> 16) & r1;
+                const uint64_t w = pass & __ballot(ok != 0);
+                wlo = (uint32_t)nhd_writelane((int)(uint32_t)w, (int)j, (int)wlo);
+                whi = (uint32_t)nhd_writelane((int)(uint32_t)(w >> 32), (int)j, (int)whi);
+            }
         }
         uint64_t word = ((uint64_t)whi << 32) | wlo;
         if (my_pod_live) {
@@ -192,7 +257,11 @@ struct MapArgs {
     const nhdfit_plane0* p0;
     const nhdfit_plane1* p1;
     const nhdfit_plane2* p2;
+    const nhdfit_plane3* p3;
     const nhdfit_detail* det;
+    const uint32_t* tabs;
+    uint32_t tab_words;
+    uint32_t row_r;
     uint32_t n;
     uint64_t global_base;
     const nhdfit_req* reqs;
@@ -202,9 +271,13 @@ struct MapArgs {
     nhdfit_mapping* out;
 };
 
+// GENERIC = false: pods with G <= 3 (register-resident set model, no scratch traffic);
+// GENERIC = true : pods with G == 4 (launched only when the batch contains such pods).
+template <bool GENERIC>
 __global__ __launch_bounds__(64) void k_map(MapArgs a) {
     const uint32_t p = blockIdx.x * 64 + threadIdx.x;
     if (p >= a.P) return;
+    if ((a.reqs[p].n_groups > 3) != GENERIC) return;
     nhdfit_mapping m;
     memset(&m, 0, sizeof(m));
     const unsigned long long s = a.score[p];
@@ -224,7 +297,14 @@ __global__ __launch_bounds__(64) void k_map(MapArgs a) {
             w.free_g[0] = popc32(q2.gpu_free & ~q2.gpu_numa1);
             w.free_g[1] = popc32(q2.gpu_free & q2.gpu_numa1);
             w.caps = a.caps;
-            map_winner(a.reqs[p], w, m);
+            const nhdfit_plane3 q3 = a.p3[i];
+            const nhdfit_req rq = a.reqs[p];
+            const uint32_t bits = nic_table_bits(a.tabs + (size_t)(p / kTile) * a.tab_words, a.row_r, p % kTile,
+                                                 rq.map_type == NHDFIT_MAP_PCI, q3.sig_numa[0], q3.sig_numa[1],
+                                                 q3.sig_pci[0], q3.sig_pci[1]);
+            const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
+            if (GENERIC) map_winner_t<GenericOps>(rq, w, codes, m);
+            else map_winner_t<SmallOps>(rq, w, codes, m);
         }
     }
     a.out[p] = m;
@@ -297,9 +377,12 @@ struct nhdfit_ctx {
     DevBuf<double> caps; DevBuf<uint32_t> sig_off, pool_off; DevBuf<uint8_t> pool_glimit; DevBuf<nhdfit_cc> cc;
     uint32_t ncls = 0, nsig = 0;
     uint32_t tab_words = 0, lds_bytes = 0;
+    Layout layout{};
+    uint32_t n_big_pods = 0;      // staged pods with more than 3 proc groups
 
     // requests / results
     DevBuf<nhdfit_req> reqs; uint32_t P = 0;
+    std::vector<uint32_t> perm;          // device (class-sorted) position -> caller's pod index
     DevBuf<PodHeader> hdr; DevBuf<uint32_t> tabs;
     DevBuf<unsigned long long> score; DevBuf<uint64_t> bitmap; DevBuf<uint64_t> cand; DevBuf<nhdfit_mapping> maps;
     bool use_cand = false, want_bitmap = true, want_map = true;
@@ -418,7 +501,9 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     delete c;
 }
 
-int nhdfit_set_dictionary(nhdfit_ctx* c, const double* caps, uint32_t ncls, const uint32_t* sig_off, uint32_t nsig,
+int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t max_gpus_per_numa,
+                          const double* caps, uint32_t ncls,
+                          const uint32_t* sig_off, uint32_t nsig,
                           const uint32_t* pool_off, const uint8_t* pool_glimit, uint32_t npools,
                           const nhdfit_cc* cc, uint32_t ncc) {
     if (!c) return NHDFIT_E_INVAL;
@@ -428,8 +513,12 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, const double* caps, uint32_t ncls, cons
     if (sig_off[nsig] != npools || pool_off[npools] != ncc) return fail(c, NHDFIT_E_INVAL, "inconsistent dictionary offsets");
     for (uint32_t k = 0; k < ncc; ++k)
         if (cc[k].cls >= ncls) return fail(c, NHDFIT_E_INVAL, "class id %u out of range", cc[k].cls);
-    const uint32_t rows = kRowR + nsig;
-    const uint32_t words = (rows * kRowStride + 3u) & ~3u;
+    if (max_gpus_per_numa > NHDFIT_MAX_GPUS_PER_NUMA)
+        return fail(c, NHDFIT_E_LIMIT, "%u GPUs per NUMA node (max %d)", max_gpus_per_numa, NHDFIT_MAX_GPUS_PER_NUMA);
+    if (max_cores_per_numa < 1 || max_cores_per_numa > NHDFIT_MAX_CORES_PER_NUMA)
+        return fail(c, NHDFIT_E_LIMIT, "%u cores per socket (supported: 1..%d)", max_cores_per_numa, NHDFIT_MAX_CORES_PER_NUMA);
+    const Layout L = make_layout(max_cores_per_numa, max_gpus_per_numa, nsig);
+    const uint32_t words = (L.rows * kRowStride + 3u) & ~3u;
     const uint32_t bytes = words * 4;
     HIPCHK(c, hipSetDevice(c->dev));
     if (bytes + 8192 > 160 * 1024)
@@ -449,6 +538,7 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, const double* caps, uint32_t ncls, cons
     c->nsig = nsig;
     c->tab_words = words;
     c->lds_bytes = bytes;
+    c->layout = L;
     HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_score<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_score<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return NHDFIT_OK;
@@ -507,16 +597,34 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     HIPCHK(c, c->score.reserve(P));
     HIPCHK(c, c->maps.reserve(P));
     HIPCHK(c, c->bitmap.reserve((size_t)chunks * P));
-    HIPCHK(c, hipMemcpy(c->reqs.p, reqs, (size_t)P * sizeof *reqs, hipMemcpyHostToDevice));
+    // Pods are staged sorted by request class so that 64-pod tiles are homogeneous (fast sweep of
+    // k_fit_score) and the lanes of k_map have similar group counts; results are un-permuted in fetch.
+    c->perm.resize(P);
+    std::vector<uint32_t> key(P);
+    c->n_big_pods = 0;
+    for (uint32_t p = 0; p < P; ++p) {
+        const PodHeader h = pod_header(reqs[p]);
+        c->perm[p] = p;
+        key[p] = ((h.flags & kPodValid) ? 0u : 1u << 12) | ((reqs[p].n_groups > 3 ? 1u : 0u) << 11) |
+                 ((h.flags & (kPodNeedGpu | kPodPci | kPodFilter)) << 4) | (reqs[p].n_groups & 15u);
+        c->n_big_pods += reqs[p].n_groups > 3;
+    }
+    std::stable_sort(c->perm.begin(), c->perm.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
+    std::vector<nhdfit_req> sorted(P);
+    for (uint32_t i = 0; i < P; ++i) sorted[i] = reqs[c->perm[i]];
+    HIPCHK(c, hipMemcpy(c->reqs.p, sorted.data(), (size_t)P * sizeof *reqs, hipMemcpyHostToDevice));
     c->P = P;
     c->use_cand = false;
     return NHDFIT_OK;
 }
 
 static int stage_cand(nhdfit_ctx* c, const uint64_t* cand) {
-    const size_t words = (size_t)((c->n + 63) / 64) * c->P;
+    const size_t chunks = (c->n + 63) / 64, words = chunks * c->P;
     HIPCHK(c, c->cand.reserve(words ? words : 1));
-    HIPCHK(c, hipMemcpy(c->cand.p, cand, words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    std::vector<uint64_t> tmp(words);
+    for (size_t ch = 0; ch < chunks; ++ch)
+        for (uint32_t i = 0; i < c->P; ++i) tmp[ch * c->P + i] = cand[ch * c->P + c->perm[i]];
+    HIPCHK(c, hipMemcpy(c->cand.p, tmp.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice));
     c->use_cand = true;
     return NHDFIT_OK;
 }
@@ -535,7 +643,7 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     HIPCHK(c, hipMemsetAsync(c->score.p, 0, (size_t)P * sizeof(unsigned long long), c->stream));
     DictView dv{c->caps.p, c->ncls, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}};
     hipLaunchKernelGGL(k_digest, dim3(tiles, kDigestSlices), dim3(kDigestThreads), 0, c->stream,
-                       c->reqs.p, P, dv, c->tab_words, c->tabs.p, c->hdr.p);
+                       c->reqs.p, P, dv, c->layout, c->tab_words, c->tabs.p, c->hdr.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(ev[1], c->stream));
 
@@ -544,7 +652,7 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     FitArgs a;
     a.p0 = c->p0.p; a.p1 = c->p1.p; a.p2 = c->p2.p; a.p3 = c->p3.p; a.p4 = c->p4.p;
     a.n = c->n; a.chunks = chunks; a.global_base = c->global_base; a.now = now;
-    a.tabs = c->tabs.p; a.tab_words = c->tab_words; a.hdr = c->hdr.p; a.P = P;
+    a.tabs = c->tabs.p; a.tab_words = c->tab_words; a.layout = c->layout; a.hdr = c->hdr.p; a.P = P;
     a.cand = c->use_cand ? c->cand.p : nullptr;
     a.bitmap = c->want_bitmap ? c->bitmap.p : nullptr;
     a.score = c->score.p;
@@ -566,8 +674,10 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
         if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
     }
     if (c->want_map) {
-        MapArgs m{c->p0.p, c->p1.p, c->p2.p, c->det.p, c->n, c->global_base, c->reqs.p, P, c->score.p, c->caps.p, c->maps.p};
-        hipLaunchKernelGGL(k_map, dim3((P + 63) / 64), dim3(64), 0, c->stream, m);
+        MapArgs m{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->det.p, c->tabs.p, c->tab_words, c->layout.row_r, c->n,
+                  c->global_base, c->reqs.p, P, c->score.p, c->caps.p, c->maps.p};
+        if (c->n_big_pods < P) hipLaunchKernelGGL(k_map<false>, dim3((P + 63) / 64), dim3(64), 0, c->stream, m);
+        if (c->n_big_pods) hipLaunchKernelGGL(k_map<true>, dim3((P + 63) / 64), dim3(64), 0, c->stream, m);
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(ev[3], c->stream));
@@ -595,14 +705,25 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
     if (!c->P) return fail(c, NHDFIT_E_STATE, "nothing staged");
     int rc = nhdfit_sync(c);
     if (rc) return rc;
-    if (score_out) HIPCHK(c, hipMemcpy(score_out, c->score.p, (size_t)c->P * 8, hipMemcpyDeviceToHost));
+    const uint32_t P = c->P;
+    if (score_out) {
+        std::vector<uint64_t> tmp(P);
+        HIPCHK(c, hipMemcpy(tmp.data(), c->score.p, (size_t)P * 8, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < P; ++i) score_out[c->perm[i]] = tmp[i];
+    }
     if (bitmap_out) {
         if (!c->want_bitmap) return fail(c, NHDFIT_E_STATE, "bitmap output is disabled");
-        HIPCHK(c, hipMemcpy(bitmap_out, c->bitmap.p, (size_t)((c->n + 63) / 64) * c->P * 8, hipMemcpyDeviceToHost));
+        const size_t chunks = (c->n + 63) / 64;
+        std::vector<uint64_t> tmp(chunks * P);
+        HIPCHK(c, hipMemcpy(tmp.data(), c->bitmap.p, chunks * P * 8, hipMemcpyDeviceToHost));
+        for (size_t ch = 0; ch < chunks; ++ch)
+            for (uint32_t i = 0; i < P; ++i) bitmap_out[ch * P + c->perm[i]] = tmp[ch * P + i];
     }
     if (map_out) {
         if (!c->want_map) return fail(c, NHDFIT_E_STATE, "mapping output is disabled");
-        HIPCHK(c, hipMemcpy(map_out, c->maps.p, (size_t)c->P * sizeof(nhdfit_mapping), hipMemcpyDeviceToHost));
+        std::vector<nhdfit_mapping> tmp(P);
+        HIPCHK(c, hipMemcpy(tmp.data(), c->maps.p, (size_t)P * sizeof(nhdfit_mapping), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < P; ++i) map_out[c->perm[i]] = tmp[i];
     }
     return NHDFIT_OK;
 }

@@ -23,6 +23,7 @@ MAX_GROUPS = 4
 MAX_NUMA = 2
 MAX_CORES_PER_NUMA = 64
 MAX_GPUS = 32
+MAX_GPUS_PER_NUMA = 8
 MAX_NICS_PER_NUMA = 16
 MAX_SWITCHES = 14
 MAX_CLASSES = 16
@@ -92,7 +93,9 @@ class Packer:
         self._sig_index: Dict[tuple, int] = {(): 0}
         self.group_names: List[str] = []
         self._group_index: Dict[str, int] = {}
-        self.dict_version = 0                          # bumped whenever caps / sigs grow
+        self.max_gpus_per_numa = 0                     # table dimensions (fit_core.h Layout)
+        self.max_cores_per_numa = 1
+        self.dict_version = 0                          # bumped whenever caps / sigs / that maximum grow
 
     # ---- interning ------------------------------------------------------------------------
     def cap_class(self, cap) -> int:
@@ -156,6 +159,9 @@ class Packer:
         cpp = int(node.cores_per_proc)
         if cpp > MAX_CORES_PER_NUMA:
             raise UnsupportedNode(f"node {node.name}: {cpp} physical cores per socket (> {MAX_CORES_PER_NUMA})")
+        if cpp > self.max_cores_per_numa:
+            self.max_cores_per_numa = cpp
+            self.dict_version += 1
         smt = bool(node.smt_enabled)
         cores = node.cores
         t0 = [0, 0]
@@ -202,8 +208,11 @@ class Packer:
             if not gpu.used:
                 gfree |= 1 << g
                 det["sw_free"][s] += 1
-        if max(per_numa) > 16:
-            raise UnsupportedNode(f"node {node.name}: more than 16 GPUs on one NUMA node")
+        if max(per_numa) > MAX_GPUS_PER_NUMA:
+            raise UnsupportedNode(f"node {node.name}: more than {MAX_GPUS_PER_NUMA} GPUs on one NUMA node")
+        if max(per_numa) > self.max_gpus_per_numa:
+            self.max_gpus_per_numa = max(per_numa)
+            self.dict_version += 1
 
         # NICs: capacity class + switch per (numa, idx);  nhd/Node.py:283-296, 275-281
         cnt = [0, 0]
@@ -324,11 +333,17 @@ class Packer:
         n = spec.n
         t = empty_table(n)
         cpp = (spec.phys // 2).astype(np.uint64)
+        if int(cpp.max()) > self.max_cores_per_numa:
+            self.max_cores_per_numa = int(cpp.max())
+            self.dict_version += 1
         valid = (np.uint64(1) << cpp) - np.uint64(1)
         free = (~spec.core_used) & valid[:, None]
         t.p0["t0"] = free
         t.p1["t1"] = np.where(spec.smt[:, None], free, ALL_ONES)
         has_gpu = spec.n_gpus > 0
+        if has_gpu.any() and self.max_gpus_per_numa < 2:
+            self.max_gpus_per_numa = 2
+            self.dict_version += 1
         gvalid = np.where(has_gpu, 0xF, 0).astype(np.uint32)
         t.p2["gpu_free"] = gvalid & ~spec.gpu_used
         t.p2["gpu_numa1"] = gvalid & np.uint32(0xC)

@@ -31,9 +31,10 @@ def _p(a):
 
 
 def find(packer: pack.Packer, table: pack.NodeTable, reqs: np.ndarray, now: float, cand=None, global_base=0,
-         want_bitmap=True, want_map=True):
+         want_bitmap=True, want_map=True, force_generic=False):
     L = lib()
     caps, sig_off, pool_off, glimit, cc, ncls, nsig, npools, ncc = packer.dictionary_arrays()
+    fgmax = packer.max_gpus_per_numa
     n, P = table.n, len(reqs)
     chunks = (n + 63) // 64
     score = np.zeros(P, np.uint64)
@@ -42,7 +43,7 @@ def find(packer: pack.Packer, table: pack.NodeTable, reqs: np.ndarray, now: floa
     reqs = np.ascontiguousarray(reqs)
     L.hh_find(_p(table.p0), _p(table.p1), _p(table.p2), _p(table.p3), _p(table.p4), _p(table.detail),
               ctypes.c_uint32(n), ctypes.c_uint64(global_base), _p(reqs), ctypes.c_uint32(P), ctypes.c_double(now),
-              _p(caps), ctypes.c_uint32(ncls), _p(sig_off), ctypes.c_uint32(nsig), _p(pool_off), _p(glimit), _p(cc),
+              ctypes.c_uint32(packer.max_cores_per_numa), ctypes.c_uint32(fgmax), _p(caps), ctypes.c_uint32(ncls), _p(sig_off), ctypes.c_uint32(nsig), _p(pool_off), _p(glimit), _p(cc),
               _p(cand) if cand is not None else None, _p(score), _p(bitmap) if want_bitmap else None,
-              _p(maps) if want_map else None)
+              _p(maps) if want_map else None, ctypes.c_int(int(force_generic)))
     return score, bitmap, maps

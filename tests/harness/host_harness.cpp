@@ -10,13 +10,14 @@ using namespace nhdfit;
 
 extern "C" {
 
-int hh_table_words(uint32_t nsig) { return (kRowR + (int)nsig) * kRowStride; }
+int hh_table_words(uint32_t fcmax, uint32_t fgmax, uint32_t nsig) { return (int)(make_layout(fcmax, fgmax, nsig).rows * kRowStride); }
 
 // Build the table image of one tile (up to 64 pods).
-void hh_build_tile(const nhdfit_req* reqs, uint32_t npods, const double* caps, uint32_t ncls,
+void hh_build_tile(const nhdfit_req* reqs, uint32_t npods, uint32_t fcmax, uint32_t fgmax, const double* caps, uint32_t ncls,
                    const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit,
                    const nhdfit_cc* cc, uint32_t* tab, PodHeader* hdr) {
-    std::memset(tab, 0, sizeof(uint32_t) * hh_table_words(nsig));
+    const Layout L = make_layout(fcmax, fgmax, nsig);
+    std::memset(tab, 0, sizeof(uint32_t) * hh_table_words(fcmax, fgmax, nsig));
     SigDict d{sig_off, pool_off, pool_glimit, cc, nsig};
     for (uint32_t j = 0; j < npods; ++j) {
         const nhdfit_req& r = reqs[j];
@@ -24,38 +25,42 @@ void hh_build_tile(const nhdfit_req* reqs, uint32_t npods, const double* caps, u
         if (!(hdr[j].flags & kPodValid)) continue;
         PodSums s;
         pod_sums(r, s);
-        for (int e = 0; e < kRowsW; ++e) {
-            tab[(kRowW0 + e) * kRowStride + j] = entry_w0(r, s, e);
-            tab[(kRowW1 + e) * kRowStride + j] = entry_w1(r, s, e);
+        for (uint32_t e = 0; e < 2 * L.fc_dim; ++e) {
+            tab[e * kRowStride + j] = entry_w0(r, s, e >= L.fc_dim, e % L.fc_dim);
+            tab[(L.row_w1 + e) * kRowStride + j] = entry_w1(r, s, e >= L.fc_dim, e % L.fc_dim);
         }
-        for (int f = 0; f < kFgSlots; ++f) tab[(kRowA + f) * kRowStride + j] = entry_a(s, f);
+        for (uint32_t f0 = 0; f0 < L.fg_dim; ++f0)
+            for (uint32_t f1 = 0; f1 < L.fg_dim; ++f1)
+                tab[(L.row_a + f0 * L.fg_dim + f1) * kRowStride + j] = entry_a(s, f0, f1);
         std::vector<uint16_t> cover(ncls * (kMaxG + 1));
         for (uint32_t c = 0; c < ncls; ++c) class_cover(r, caps[c], s.W, s.G, &cover[c * (kMaxG + 1)]);
         for (uint32_t g = 0; g < nsig; ++g)
-            tab[(kRowR + g) * kRowStride + j] = entry_r(sig_reach(d, g, cover.data(), s.W), s.W);
+            tab[(L.row_r + g) * kRowStride + j] = entry_r(sig_reach(d, g, cover.data(), s.W), s.W);
     }
 }
 
 // CPU twin of nhdfit_find (mode A), same outputs, chunk-major bitmap [ceil(n/64)][P].
 void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
              const nhdfit_plane4* p4, const nhdfit_detail* det, uint32_t n, uint64_t global_base,
-             const nhdfit_req* reqs, uint32_t P, double now, const double* caps, uint32_t ncls,
+             const nhdfit_req* reqs, uint32_t P, double now, uint32_t fcmax, uint32_t fgmax, const double* caps, uint32_t ncls,
              const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit,
-             const nhdfit_cc* cc, const uint64_t* cand, uint64_t* score, uint64_t* bitmap, nhdfit_mapping* maps) {
+             const nhdfit_cc* cc, const uint64_t* cand, uint64_t* score, uint64_t* bitmap, nhdfit_mapping* maps,
+             int force_generic) {
     const uint32_t chunks = (n + 63) / 64;
-    std::vector<uint32_t> tab(hh_table_words(nsig));
+    const Layout L = make_layout(fcmax, fgmax, nsig);
+    std::vector<uint32_t> tab(hh_table_words(fcmax, fgmax, nsig));
     std::vector<PodHeader> hdr(kTile);
     for (uint32_t p = 0; p < P; ++p) score[p] = 0;
     for (uint32_t t0 = 0; t0 < P; t0 += kTile) {
         const uint32_t np = P - t0 < (uint32_t)kTile ? P - t0 : kTile;
-        hh_build_tile(reqs + t0, np, caps, ncls, sig_off, nsig, pool_off, pool_glimit, cc, tab.data(), hdr.data());
+        hh_build_tile(reqs + t0, np, fcmax, fgmax, caps, ncls, sig_off, nsig, pool_off, pool_glimit, cc, tab.data(), hdr.data());
         for (uint32_t c = 0; c < chunks; ++c) {
             uint64_t nogpu = 0;
             NodeLane lanes[64];
             const uint32_t cnt = n - c * 64 < 64 ? n - c * 64 : 64;
             for (uint32_t l = 0; l < cnt; ++l) {
                 const uint32_t i = c * 64 + l;
-                lanes[l] = node_lane(p0[i], p1[i], p2[i], p3[i], p4[i], now);
+                lanes[l] = node_lane(p0[i], p1[i], p2[i], p3[i], p4[i], now, L);
                 if (!(p2[i].flags & NHDFIT_NF_HAS_GPU)) nogpu |= 1ull << l;
             }
             for (uint32_t j = 0; j < np; ++j) {
@@ -73,6 +78,10 @@ void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plan
     for (uint32_t p = 0; p < P; ++p) {
         std::memset(&maps[p], 0, sizeof(nhdfit_mapping));
         if (!score[p]) continue;
+        if (p % kTile == 0) {
+            const uint32_t np = P - p < (uint32_t)kTile ? P - p : kTile;
+            hh_build_tile(reqs + p, np, fcmax, fgmax, caps, ncls, sig_off, nsig, pool_off, pool_glimit, cc, tab.data(), hdr.data());
+        }
         const uint64_t gi = NHDFIT_SCORE_INDEX(score[p]);
         if (gi < global_base || gi >= global_base + n) continue;
         const uint32_t i = (uint32_t)(gi - global_base);
@@ -85,7 +94,11 @@ void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plan
         w.free_g[1] = popc32(p2[i].gpu_free & p2[i].gpu_numa1);
         w.d = det[i];
         w.caps = caps;
-        map_winner(reqs[p], w, maps[p]);
+        const uint32_t bits = nic_table_bits(tab.data(), L.row_r, p % kTile, reqs[p].map_type == NHDFIT_MAP_PCI,
+                                             p3[i].sig_numa[0], p3[i].sig_numa[1], p3[i].sig_pci[0], p3[i].sig_pci[1]);
+        const uint32_t codes = nic_codes_from_table_bits(bits, (int)reqs[p].n_groups, w.U);
+        if (force_generic) map_winner_t<GenericOps>(reqs[p], w, codes, maps[p]);
+        else map_winner(reqs[p], w, codes, maps[p]);
     }
 }
 
@@ -107,6 +120,25 @@ int hh_set_isect3(const int16_t* a, int na, const int16_t* b, int nb, const int1
     ps_intersect(sa, sb, ab);
     ps_intersect(ab, sc, abc);
     return ps_list(abc, out);
+}
+
+// the register-resident model
+int hh_small_set_list(const int16_t* codes, int n, int len, int base, int16_t* out) {
+    SmallSet s;
+    ss_init(s, len, base);
+    for (int i = 0; i < n; ++i) ss_add(s, codes[i]);
+    return ss_list(s, out);
+}
+
+int hh_small_isect3(const int16_t* a, int na, const int16_t* b, int nb, const int16_t* c, int nc, int len, int base, int16_t* out) {
+    SmallSet sa, sb, sc, ab, abc;
+    ss_init(sa, len, base); ss_init(sb, len, base); ss_init(sc, len, base);
+    for (int i = 0; i < na; ++i) ss_add(sa, a[i]);
+    for (int i = 0; i < nb; ++i) ss_add(sb, b[i]);
+    for (int i = 0; i < nc; ++i) ss_add(sc, c[i]);
+    ss_intersect(sa, sb, ab);
+    ss_intersect(ab, sc, abc);
+    return ss_list(abc, out);
 }
 
 uint64_t hh_tuple_hash(uint32_t code, int len, int base) { return py_tuple_hash(code, len, base); }

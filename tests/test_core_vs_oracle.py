@@ -107,3 +107,14 @@ def test_candidate_mask_and_sharding_agree():
     cand[1:] = np.uint64(0xFFFFFFFFFFFFFFFF)          # forbid the first 64 nodes
     masked, bm2, _ = harness.find(pk, table, reqs, spec.clock_now, cand=cand, want_map=False)
     assert np.all(bm2[0] == 0) and np.array_equal(bm2[1:], bm[1:])
+
+
+def test_register_and_generic_set_models_agree():
+    spec = synth.make_cluster(4, n_nodes=400)
+    pods, groups = synth.make_pods(4, n_pods=128)
+    pk = pack.Packer()
+    table = pk.planes_from_spec(spec)
+    reqs = pk.digest_many([refmodel.make_topology(s) for s in pods], groups)
+    a = harness.find(pk, table, reqs, spec.clock_now, force_generic=False)
+    b = harness.find(pk, table, reqs, spec.clock_now, force_generic=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and a[2]["valid"].sum() > 100

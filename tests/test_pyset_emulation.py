@@ -90,3 +90,39 @@ def test_three_way_intersection_order(length):
         n = L.hh_set_isect3(*(v for a in arrs for v in (a.ctypes.data_as(ctypes.c_void_p), len(a))), length, 2,
                             out.ctypes.data_as(ctypes.c_void_p))
         assert tuples_of(out[:n], length, 2) == want
+
+
+def small_list(tuples, length, base):
+    L = harness.lib()
+    codes = codes_of(tuples, base)
+    out = np.zeros(64, np.int16)
+    n = L.hh_small_set_list(codes.ctypes.data_as(ctypes.c_void_p), len(codes), length, base, out.ctypes.data_as(ctypes.c_void_p))
+    return tuples_of(out[:n], length, base)
+
+
+@pytest.mark.parametrize("length", [1, 2, 3, 4])
+def test_register_model_matches_python(length):
+    """SmallSet (the register-resident model used for G <= 3, up to 16 keys) == CPython."""
+    L = harness.lib()
+    rng = np.random.default_rng(7 + length)
+    universe = list(itertools.product(range(2), repeat=length))
+    masks = range(1, 1 << len(universe)) if length <= 3 else [int(x) for x in rng.integers(1, 1 << 16, size=6000)]
+    for mask in masks:
+        sub = [t for i, t in enumerate(universe) if mask >> i & 1]
+        if length == 4 and rng.random() < 0.3:
+            rng.shuffle(sub)
+        s = set()
+        for t in sub:
+            s.add(t)
+        assert small_list(sub, length, 2) == list(s)
+    for _ in range(3000):
+        lists = []
+        for _k in range(3):
+            n = int(rng.integers(1, 2 * len(universe) + 1))
+            lists.append([universe[int(i)] for i in rng.integers(0, len(universe), size=n)])
+        want = list(set(lists[0]) & set(lists[1]) & set(lists[2]))
+        arrs = [codes_of(x, 2) for x in lists]
+        out = np.zeros(64, np.int16)
+        n = L.hh_small_isect3(*(v for a in arrs for v in (a.ctypes.data_as(ctypes.c_void_p), len(a))), length, 2,
+                              out.ctypes.data_as(ctypes.c_void_p))
+        assert tuples_of(out[:n], length, 2) == want
