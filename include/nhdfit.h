@@ -77,7 +77,8 @@ typedef struct {
 } nhdfit_plane3;
 typedef struct {
     double   busy_time;     /* Node.busy_time (monotonic seconds)          nhd/Node.py:843-850 */
-    uint64_t reserved;
+    uint32_t group_set;     /* id of the node's interned NHD_GROUP set (row of the per-tile group table) */
+    uint32_t reserved;
 } nhdfit_plane4;
 
 /* cold per-node detail, gathered only for winners (mapping step, nhd/Matcher.py:423-452) */
@@ -151,6 +152,7 @@ const char* nhdfit_last_error(nhdfit_ctx* ctx);            /* ctx may be NULL: l
  * size the per-pod tables).  Signature 0 must be the empty signature.  May be called again when the
  * dictionary grows. */
 int nhdfit_set_dictionary(nhdfit_ctx* ctx, uint32_t max_cores_per_numa, uint32_t max_gpus_per_numa,
+                          const uint64_t* group_sets, uint32_t n_group_sets,   /* distinct node-group bit sets, id = index */
                           const double* caps, uint32_t ncls,
                           const uint32_t* sig_off, uint32_t nsig,
                           const uint32_t* pool_off, const uint8_t* pool_glimit, uint32_t npools,

@@ -31,7 +31,7 @@ _SIGS = {
     "nhdfit_create": (c_int, [c_int, POINTER(c_void_p)]),
     "nhdfit_destroy": (None, [c_void_p]),
     "nhdfit_last_error": (c_char_p, [c_void_p]),
-    "nhdfit_set_dictionary": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_uint32,
+    "nhdfit_set_dictionary": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_uint32,
                                       c_void_p, c_uint32]),
     "nhdfit_reserve_nodes": (c_int, [c_void_p, c_uint32, c_uint64]),
     "nhdfit_upload_nodes": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

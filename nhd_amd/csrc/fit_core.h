@@ -20,45 +20,74 @@
 // look-ups only and every f64 operation is performed exactly as the reference performs it.
 //
 // A node is feasible for a pod iff some p passes all three (this is the set intersection of
-// Matcher.py:346) plus the scalar predicates (maintenance, hugepages, busy, node groups).
+// Matcher.py:346) plus the scalar predicates (maintenance, hugepages, busy, node groups), which are
+// tabulated too: one 64-bit word per node-side value holds the verdict for all 64 pods of a tile.
+//
+// ---- table image of one 64-pod tile (staged in LDS by the fit kernel) ---------------------------
+//   16-bit rows: 64 pods x uint16 (bit p = assignment p passes), kRowBytes apart; pod j sits in halfword
+//   slot16(j): the two halves of 32-bit word w hold pods (w, w+16) resp. (16+w, 32+w..) so that a packed
+//   per-half "non-zero" test lands the verdicts of 32 pods in pod order inside one 32-bit register
+//     W0[smt][c][m]  c free cores on socket 0:  m=0: sumC(S0) <= c      m=1: sumC(S0)+misc <= c
+//     W1[smt][c][m]  c free cores on socket 1:  m=0: sumC(S1) <= c      m=1: sumC(S1)+misc <= c
+//                    cpu_ok = (W0[.][1] & W1[.][0]) | (W0[.][0] & W1[.][1])
+//     A[f0][f1]      free GPUs on NUMA 0 / 1:   sumG(S0) <= f0 && sumG(S1) <= f1
+//     R0[sig]        NIC signature of NUMA 0:   S0(p) in reach(sig)
+//     R1[sig]        NIC signature of NUMA 1:   S1(p) in reach(sig)
+//   64-bit rows: bit j = verdict for pod j of the tile
+//     HP[k]          k = clamp(free hugepages, -1, hp_max) + 1:  pod valid && hp_req <= free
+//     GF[gs]         node-group set id: pod does not filter || sets intersect  (NHDScheduler.py:240)
 #pragma once
 #include <stdint.h>
 #include "../../include/nhdfit.h"
 
 #if defined(__HIPCC__)
-#define NHD_HD __host__ __device__ inline
+#define NHD_HD __host__ __device__ __forceinline__
 #else
 #define NHD_HD inline
 #endif
 
 namespace nhdfit {
 
-constexpr int kMaxG       = NHDFIT_MAX_GROUPS;
-constexpr int kTile       = NHDFIT_TILE;
-constexpr int kRowStride  = kTile + 2;               // words per table row: even (8-byte aligned pod pairs for ds_read_b64)
-                                                     // and = 2 mod 64 so different rows land on different LDS banks
-// rows of a tile's table image: W0[2][fc_dim] W1[2][fc_dim] A[fg_dim][fg_dim] R[nsig]
+constexpr int kMaxG      = NHDFIT_MAX_GROUPS;
+constexpr int kTile      = NHDFIT_TILE;
+constexpr int kRowBytes  = kTile * 2 + 16;           // 144: 16-byte aligned rows (ds_read_b128 = 8 pods); row r starts at
+                                                     // 16-byte slot 9r mod 16, so 16 different rows never share LDS banks
+constexpr int kMaxHpRows = 1024;                     // hugepage table rows (larger requests are clamped, see hp_bit)
+constexpr double kMinBusySecs = 30.0;                // Node.MIN_BUSY_SECS, nhd/Node.py:107
+
+// halfword index of pod j (0..63) inside a 16-bit row: word w = (j & 15) + 16 * (j >> 5), half = (j >> 4) & 1
+NHD_HD uint32_t slot16(uint32_t j) { return 2 * ((j & 15u) + 16u * (j >> 5)) + ((j >> 4) & 1u); }
+
 struct Layout {
     uint32_t fc_dim;     // 1 + max physical cores on one socket anywhere in the cluster (<= 65)
     uint32_t fg_dim;     // 1 + max GPUs installed on one NUMA node anywhere in the cluster (<= 9)
-    uint32_t row_w1;     // first row of W1   (W0 starts at row 0)
-    uint32_t row_a;      // first row of A    (+ f0 * fg_dim + f1)
-    uint32_t row_r;      // first NIC-signature row
-    uint32_t rows;
+    uint32_t nsig, ngs;  // NIC signatures, node-group sets
+    uint32_t hp_rows;    // 2 + largest hugepage request of the staged batch (capped at kMaxHpRows)
+    uint32_t row_w1, row_a, row_r0, row_r1, rows16;   // first 16-bit row of each table (W0 starts at 0)
+    uint32_t off_hp, off_gf;                           // byte offsets of the 64-bit tables
+    uint32_t bytes;                                    // image size, multiple of 16
 };
-NHD_HD Layout make_layout(uint32_t max_cores_per_numa, uint32_t max_gpus_per_numa, uint32_t nsig) {
+
+NHD_HD Layout make_layout(uint32_t max_cores_per_numa, uint32_t max_gpus_per_numa, uint32_t nsig, uint32_t ngs,
+                          uint32_t hp_rows) {
     Layout l;
     l.fc_dim = max_cores_per_numa + 1;
     l.fg_dim = max_gpus_per_numa + 1;
-    l.row_w1 = 2 * l.fc_dim;
-    l.row_a = 4 * l.fc_dim;
-    l.row_r = l.row_a + l.fg_dim * l.fg_dim;
-    l.rows = l.row_r + nsig;
+    l.nsig = nsig;
+    l.ngs = ngs;
+    l.hp_rows = hp_rows;
+    l.row_w1 = 4 * l.fc_dim;                         // W0: rows [m][smt][c] = m*2*fc_dim + smt*fc_dim + c
+    l.row_a = 8 * l.fc_dim;
+    l.row_r0 = l.row_a + l.fg_dim * l.fg_dim;
+    l.row_r1 = l.row_r0 + nsig;
+    l.rows16 = l.row_r1 + nsig;
+    l.off_hp = l.rows16 * kRowBytes;
+    l.off_gf = l.off_hp + hp_rows * 8;
+    l.bytes = (l.off_gf + ngs * 8 + 15u) & ~15u;
     return l;
 }
-constexpr double kMinBusySecs = 30.0;                // Node.MIN_BUSY_SECS, nhd/Node.py:107
 
-// Request header consumed in the wave-uniform part of the fit kernel (one per pod).
+// Request header (one per pod), kept for the lane-as-pod view of the fit kernel.
 struct PodHeader {
     int32_t  hp_req;
     uint32_t flags;      // kPod*
@@ -75,6 +104,7 @@ NHD_HD int popc32(uint32_t x) { return __builtin_popcount(x); }
 // ---- subset sums of the per-group integer demands -------------------------------------------
 struct PodSums {
     uint32_t G, W, full;                 // W = 2^G assignments, full = W-1
+    uint32_t misc_smt, misc_nosmt;
     uint32_t gpu[1 << kMaxG];            // sum of gpus[i], i in S
     uint32_t cpu_smt[1 << kMaxG];        // sum of cpu_smt[i]
     uint32_t cpu_nosmt[1 << kMaxG];
@@ -89,6 +119,8 @@ NHD_HD void pod_sums(const nhdfit_req& r, PodSums& s) {
     s.G = r.n_groups;
     s.W = 1u << s.G;
     s.full = s.W - 1;
+    s.misc_smt = r.misc_smt;
+    s.misc_nosmt = r.misc_nosmt;
     for (uint32_t S = 0; S < s.W; ++S) {
         uint32_t g = 0, a = 0, b = 0;
         for (uint32_t i = 0; i < s.G; ++i)
@@ -113,35 +145,17 @@ NHD_HD PodHeader pod_header(const nhdfit_req& r) {
     return h;
 }
 
-// ---- CPU tables: row = smt * fc_dim + free_cores ---------------------------------------------
-//   W0[e] = C0 | C0m<<16,  C0 bit p:  sumC(S0(p))        <= f ,  C0m: sumC(S0(p)) + misc <= f
-//   W1[e] = C1m | C1<<16,  C1 bit p:  sumC(S1(p))        <= f ,  C1m: sumC(S1(p)) + misc <= f
-//   x = W0[e0] & W1[e1]  ->  cpu_ok = (x | x>>16) & 0xFFFF
-NHD_HD uint32_t entry_w0(const nhdfit_req& r, const PodSums& s, bool smt, uint32_t f) {
+// ---- 16-bit table entries ---------------------------------------------------------------------
+// socket u in {0,1}; c free physical cores; m: 1 = the pod-level misc cores also land on this socket
+NHD_HD uint32_t entry_w(const PodSums& s, uint32_t u, bool smt, uint32_t c, uint32_t m) {
     const uint32_t* sum = smt ? s.cpu_smt : s.cpu_nosmt;
-    const uint32_t misc = smt ? r.misc_smt : r.misc_nosmt;
-    uint32_t c0 = 0, c0m = 0;
-    for (uint32_t p = 0; p < s.W; ++p) {
-        const uint32_t d = sum[~p & s.full];
-        if (d <= f) c0 |= 1u << p;
-        if (d + misc <= f) c0m |= 1u << p;
-    }
-    return c0 | (c0m << 16);
+    const uint32_t extra = m ? (smt ? s.misc_smt : s.misc_nosmt) : 0;
+    uint32_t out = 0;
+    for (uint32_t p = 0; p < s.W; ++p)
+        if (sum[u ? p : (~p & s.full)] + extra <= c) out |= 1u << p;
+    return out;
 }
 
-NHD_HD uint32_t entry_w1(const nhdfit_req& r, const PodSums& s, bool smt, uint32_t f) {
-    const uint32_t* sum = smt ? s.cpu_smt : s.cpu_nosmt;
-    const uint32_t misc = smt ? r.misc_smt : r.misc_nosmt;
-    uint32_t c1 = 0, c1m = 0;
-    for (uint32_t p = 0; p < s.W; ++p) {
-        const uint32_t d = sum[p];
-        if (d <= f) c1 |= 1u << p;
-        if (d + misc <= f) c1m |= 1u << p;
-    }
-    return c1m | (c1 << 16);
-}
-
-// ---- GPU table: row (f0, f1) = free GPUs on NUMA 0 / NUMA 1;  bit p: both sums fit ---------------
 NHD_HD uint32_t entry_a(const PodSums& s, uint32_t f0, uint32_t f1) {
     uint32_t a = 0;
     for (uint32_t p = 0; p < s.W; ++p)
@@ -212,23 +226,48 @@ NHD_HD uint32_t sig_reach(const SigDict& d, uint32_t sig, const uint16_t* cover,
     return reach;
 }
 
-// R[sig] = reach | rev_W(reach)<<16, rev_W(x) bit p = x bit (W-1-p) = x bit S0(p)
-//   nic_ok = (R[sig0] >> 16) & R[sig1] & 0xFFFF
-NHD_HD uint32_t entry_r(uint32_t reach, uint32_t W) {
+// R1[sig] bit p = reach bit S1(p) = reach bit p;  R0[sig] bit p = reach bit S0(p) = reach bit (W-1-p)
+NHD_HD uint32_t entry_r(uint32_t reach, uint32_t W, uint32_t u) {
+    if (u) return reach & 0xFFFFu;
     uint32_t rev = 0;
     for (uint32_t p = 0; p < W; ++p)
         if (reach >> (W - 1 - p) & 1) rev |= 1u << p;
-    return (reach & 0xFFFFu) | (rev << 16);
+    return rev;
+}
+
+// value of 16-bit row `row` for one pod
+NHD_HD uint32_t row16_entry(const Layout& L, const PodSums& s, const SigDict& d, const uint16_t* cover, uint32_t row) {
+    if (row < L.row_a) {
+        const uint32_t u = row >= L.row_w1, k = u ? row - L.row_w1 : row;      // k = m*2*fc_dim + smt*fc_dim + c
+        const uint32_t m = k >= 2 * L.fc_dim, sc = m ? k - 2 * L.fc_dim : k;
+        return entry_w(s, u, sc >= L.fc_dim, sc >= L.fc_dim ? sc - L.fc_dim : sc, m);
+    }
+    if (row < L.row_r0) return entry_a(s, (row - L.row_a) / L.fg_dim, (row - L.row_a) % L.fg_dim);
+    if (row < L.row_r1) return entry_r(sig_reach(d, row - L.row_r0, cover, s.W), s.W, 0);
+    return entry_r(sig_reach(d, row - L.row_r1, cover, s.W), s.W, 1);
+}
+
+// 64-bit rows: one bit per pod of the tile.
+// HP row k stands for "free hugepages = k-1"; the last row for "free >= hp_rows-2".  Requests are
+// non-negative; requests above the cap are compared against the cap row exactly as hp_req <= free would
+// fail for every free < request as long as free is below the cap, and the cap (1022 GiB of 1 GiB pages
+// per pod) is documented in DESIGN.md.
+NHD_HD bool hp_bit(const PodHeader& h, const Layout& L, uint32_t k) {
+    if (!(h.flags & kPodValid)) return false;
+    return h.hp_req <= (int32_t)k - 1;                                         // Matcher.py:78
+}
+NHD_HD bool gf_bit(const PodHeader& h, uint64_t node_groups) {
+    return !(h.flags & kPodFilter) || (node_groups & h.groups) != 0;           // NHDScheduler.py:240
 }
 
 // ---- node side -----------------------------------------------------------------------------------
 struct NodeLane {            // what one lane keeps for its node while it sweeps a tile of pods
-    uint32_t off_w0, off_w1; // word offsets of the node's table rows (row * kRowStride)
+    uint32_t off_w0, off_w1; // byte offsets of the node's rows in the tile image (the m=1 rows follow at +w_misc)
+    uint32_t w_misc;
     uint32_t off_a;
-    uint32_t off_rn0, off_rn1, off_rp0, off_rp1;
-    int32_t  hp_free;
+    uint32_t off_r0n, off_r1n, off_r0p, off_r1p;   // NUMA-mode / PCI-mode NIC rows
+    uint32_t off_hp, off_gf;
     uint32_t flags;
-    uint64_t groups;
     bool     busy;
 };
 
@@ -239,44 +278,58 @@ NHD_HD NodeLane node_lane(const nhdfit_plane0& a, const nhdfit_plane1& b, const 
     uint32_t c0 = popc64(a.t0[0] & b.t1[0]), c1 = popc64(a.t0[1] & b.t1[1]);       // free physical cores, nhd/Node.py:250-264
     c0 = c0 < L.fc_dim ? c0 : L.fc_dim - 1;
     c1 = c1 < L.fc_dim ? c1 : L.fc_dim - 1;
-    n.off_w0 = (smt + c0) * kRowStride;
-    n.off_w1 = (L.row_w1 + smt + c1) * kRowStride;
+    n.off_w0 = (smt + c0) * kRowBytes;
+    n.off_w1 = (L.row_w1 + smt + c1) * kRowBytes;
+    n.w_misc = 2 * L.fc_dim * kRowBytes;
     uint32_t f0 = popc32(c.gpu_free & ~c.gpu_numa1), f1 = popc32(c.gpu_free & c.gpu_numa1);   // nhd/Node.py:456-462
     f0 = f0 < L.fg_dim ? f0 : L.fg_dim - 1;
     f1 = f1 < L.fg_dim ? f1 : L.fg_dim - 1;
-    n.off_a = (L.row_a + f0 * L.fg_dim + f1) * kRowStride;
-    n.off_rn0 = (L.row_r + d.sig_numa[0]) * kRowStride;
-    n.off_rn1 = (L.row_r + d.sig_numa[1]) * kRowStride;
-    n.off_rp0 = (L.row_r + d.sig_pci[0]) * kRowStride;
-    n.off_rp1 = (L.row_r + d.sig_pci[1]) * kRowStride;
-    n.hp_free = c.hp_free;
+    n.off_a = (L.row_a + f0 * L.fg_dim + f1) * kRowBytes;
+    n.off_r0n = (L.row_r0 + d.sig_numa[0]) * kRowBytes;
+    n.off_r1n = (L.row_r1 + d.sig_numa[1]) * kRowBytes;
+    n.off_r0p = (L.row_r0 + d.sig_pci[0]) * kRowBytes;
+    n.off_r1p = (L.row_r1 + d.sig_pci[1]) * kRowBytes;
+    int32_t hp = c.hp_free;
+    hp = hp < -1 ? -1 : hp;
+    hp = hp > (int32_t)L.hp_rows - 2 ? (int32_t)L.hp_rows - 2 : hp;
+    n.off_hp = L.off_hp + (uint32_t)(hp + 1) * 8;
+    const uint32_t gs = e.group_set < L.ngs ? e.group_set : 0;
+    n.off_gf = L.off_gf + gs * 8;
     n.flags = c.flags;
-    n.groups = d.groups;
     n.busy = (now - e.busy_time) < kMinBusySecs;              // Node.IsBusy, nhd/Node.py:847-850
     return n;
 }
 
-// One (pod, node) evaluation against the pod's table column `col` (= pod index inside its tile).
-// `tab` is the tile's table image: word [row * kRowStride + col].  Conditions on the pod header are
-// wave-uniform on the GPU (every lane of a wavefront works on the same pod), conditions on the node
-// are folded into one predicate so lanes never diverge.
-NHD_HD bool eval_pair(const NodeLane& n, const PodHeader& h, const uint32_t* tab, uint32_t col) {
-    bool pass = (h.flags & kPodValid) != 0;
-    pass &= !(n.flags & NHDFIT_NF_MAINTENANCE);                              // Matcher.py:71
-    pass &= h.hp_req <= n.hp_free;                                           // Matcher.py:78
-    if (h.flags & kPodFilter)                                                // NHDScheduler.py:240-242
-        pass &= ((n.flags & NHDFIT_NF_ACTIVE) != 0) & ((n.groups & h.groups) != 0);
-    const uint32_t x = tab[n.off_w0 + col] & tab[n.off_w1 + col];
-    uint32_t ok = (x | (x >> 16)) & 0xFFFFu;
-    if (h.flags & kPodNeedGpu) {
-        pass &= !n.busy;                                                     // Matcher.py:107-111
-        ok &= tab[n.off_a + col];
-    }
-    uint32_t r0, r1;
-    if (h.flags & kPodPci) { r0 = tab[n.off_rp0 + col]; r1 = tab[n.off_rp1 + col]; }
-    else                   { r0 = tab[n.off_rn0 + col]; r1 = tab[n.off_rn1 + col]; }
-    ok &= (r0 >> 16) & r1;
-    return pass & (ok != 0);
+NHD_HD uint32_t ld16(const uint8_t* img, uint32_t off, uint32_t col) {
+    return reinterpret_cast<const uint16_t*>(img + off)[slot16(col)];
+}
+NHD_HD uint64_t ld64(const uint8_t* img, uint32_t off) { return *reinterpret_cast<const uint64_t*>(img + off); }
+
+// Scalar predicates of one node against all 64 pods of the tile (bit j = pod j may consider the node).
+// m_filt / m_need: tile masks of pods that apply InitialNodeFilter / request GPUs.
+NHD_HD uint64_t node_pod_mask(const NodeLane& n, const uint8_t* img, uint64_t m_filt, uint64_t m_need) {
+    if (n.flags & NHDFIT_NF_MAINTENANCE) return 0;                       // Matcher.py:71
+    uint64_t m = ld64(img, n.off_hp);                                    // Matcher.py:78 (+ request validity)
+    m &= ld64(img, n.off_gf);                                            // NHDScheduler.py:240
+    if (!(n.flags & NHDFIT_NF_ACTIVE)) m &= ~m_filt;                     // NHDScheduler.py:241-242
+    if (n.busy) m &= ~m_need;                                            // Matcher.py:107-111
+    return m;
+}
+
+// NUMA-assignment feasibility of one (pod, node) pair: pod = column `col` of the tile image.
+NHD_HD bool eval_assignments(const NodeLane& n, const uint8_t* img, uint32_t col, bool pci) {
+    const uint32_t cpu = (ld16(img, n.off_w0 + n.w_misc, col) & ld16(img, n.off_w1, col)) |
+                         (ld16(img, n.off_w0, col) & ld16(img, n.off_w1 + n.w_misc, col));
+    const uint32_t ok = cpu & ld16(img, n.off_a, col) &
+                        ld16(img, pci ? n.off_r0p : n.off_r0n, col) & ld16(img, pci ? n.off_r1p : n.off_r1n, col);
+    return ok != 0;
+}
+
+// NIC-feasible assignment bits (bit p) of one (pod, node) pair, for the winner mapping
+NHD_HD uint32_t nic_assignment_bits(const uint8_t* img, const Layout& L, uint32_t col, bool pci, const nhdfit_plane3& q3) {
+    const uint32_t r0 = ld16(img, (L.row_r0 + (pci ? q3.sig_pci[0] : q3.sig_numa[0])) * kRowBytes, col);
+    const uint32_t r1 = ld16(img, (L.row_r1 + (pci ? q3.sig_pci[1] : q3.sig_numa[1])) * kRowBytes, col);
+    return r0 & r1;
 }
 
 // ---- selection (Matcher.py:393-421) ----------------------------------------------------------

@@ -36,6 +36,7 @@ namespace {
 struct DictView {
     const double* caps;
     uint32_t ncls;
+    const uint64_t* group_sets;
     SigDict sig;
 };
 
@@ -44,21 +45,22 @@ struct DictView {
 extern "C" __device__ int nhd_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
 constexpr int kDigestThreads = 256;
-constexpr int kDigestSlices = 8;
+constexpr int kDigestSlices = 16;
 
 // grid = (tiles, kDigestSlices).  Every block rebuilds the (cheap) per-pod sums / covers of its tile
 // in LDS, then fills its share of the table rows; consecutive threads write consecutive columns.
 __global__ __launch_bounds__(kDigestThreads) void k_digest(const nhdfit_req* __restrict__ reqs, uint32_t P,
-                                                           DictView d, Layout L, uint32_t tab_words,
-                                                           uint32_t* __restrict__ tabs, PodHeader* __restrict__ hdr) {
-    __shared__ nhdfit_req s_req[kTile];
+                                                           DictView d, Layout L, uint8_t* __restrict__ tabs,
+                                                           PodHeader* __restrict__ hdr) {
+    struct PaddedReq { nhdfit_req r; uint32_t pad; };          // 33-word stride: lane j -> bank j
+    __shared__ PaddedReq s_req[kTile];
     __shared__ PodSums s_sum[kTile];
     __shared__ uint16_t s_cover[kTile][NHDFIT_MAX_CLASSES][kMaxG + 1];
-    __shared__ uint32_t s_valid[kTile];
+    __shared__ PodHeader s_hdr[kTile];
 
     const uint32_t tile = blockIdx.x, slice = blockIdx.y;
     const uint32_t tid = threadIdx.x;
-    uint32_t* tab = tabs + (size_t)tile * tab_words;
+    uint8_t* img = tabs + (size_t)tile * L.bytes;
 
     if (tid < kTile) {
         const uint32_t pod = tile * kTile + tid;
@@ -66,31 +68,33 @@ __global__ __launch_bounds__(kDigestThreads) void k_digest(const nhdfit_req* __r
         if (pod < P) r = reqs[pod];
         else { memset(&r, 0, sizeof(r)); }
         const PodHeader h = pod_header(r);
-        s_req[tid] = r;
-        s_valid[tid] = h.flags & kPodValid;
-        if (s_valid[tid]) pod_sums(r, s_sum[tid]);
+        s_req[tid].r = r;
+        s_hdr[tid] = h;
+        if (h.flags & kPodValid) pod_sums(r, s_sum[tid]);
         if (slice == 0) hdr[tile * kTile + tid] = h;
     }
     __syncthreads();
     for (uint32_t w = tid; w < kTile * d.ncls; w += kDigestThreads) {
         const uint32_t j = w % kTile, c = w / kTile;
-        if (s_valid[j]) class_cover(s_req[j], d.caps[c], s_sum[j].W, s_sum[j].G, s_cover[j][c]);
+        if (s_hdr[j].flags & kPodValid) class_cover(s_req[j].r, d.caps[c], s_sum[j].W, s_sum[j].G, s_cover[j][c]);
     }
     __syncthreads();
 
-    for (uint32_t w = slice * kDigestThreads + tid; w < L.rows * kTile; w += kDigestSlices * kDigestThreads) {
+    // 16-bit rows: one thread per (row, pod)
+    for (uint32_t w = slice * kDigestThreads + tid; w < L.rows16 * kTile; w += kDigestSlices * kDigestThreads) {
         const uint32_t j = w % kTile, row = w / kTile;
         uint32_t v = 0;
-        if (s_valid[j]) {
-            const nhdfit_req& r = s_req[j];
-            const PodSums& s = s_sum[j];
-            if (row < L.row_w1) v = entry_w0(r, s, row >= L.fc_dim, row >= L.fc_dim ? row - L.fc_dim : row);
-            else if (row < L.row_a) v = entry_w1(r, s, row - L.row_w1 >= L.fc_dim,
-                                                 row - L.row_w1 >= L.fc_dim ? row - L.row_w1 - L.fc_dim : row - L.row_w1);
-            else if (row < L.row_r) v = entry_a(s, (row - L.row_a) / L.fg_dim, (row - L.row_a) % L.fg_dim);
-            else v = entry_r(sig_reach(d.sig, row - L.row_r, &s_cover[j][0][0], s.W), s.W);
-        }
-        tab[row * kRowStride + j] = v;
+        if (s_hdr[j].flags & kPodValid) v = row16_entry(L, s_sum[j], d.sig, &s_cover[j][0][0], row);
+        reinterpret_cast<uint16_t*>(img + row * kRowBytes)[slot16(j)] = (uint16_t)v;
+    }
+    // 64-bit rows: one wavefront per row, ballot over the 64 pods
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const uint32_t nrows64 = L.hp_rows + L.ngs;
+    for (uint32_t k = slice * (kDigestThreads / 64) + wave; k < nrows64; k += kDigestSlices * (kDigestThreads / 64)) {
+        const bool bit = k < L.hp_rows ? hp_bit(s_hdr[lane], L, k) : gf_bit(s_hdr[lane], d.group_sets[k - L.hp_rows]);
+        const uint64_t word = __ballot(bit);
+        if (lane == 0)
+            *reinterpret_cast<uint64_t*>(img + (k < L.hp_rows ? L.off_hp + 8 * k : L.off_gf + 8 * (k - L.hp_rows))) = word;
     }
 }
 
@@ -106,8 +110,7 @@ struct FitArgs {
     uint32_t nranges;           // node ranges (blocks per tile)
     uint64_t global_base;
     double now;
-    const uint32_t* tabs;
-    uint32_t tab_words;         // words per tile image (multiple of 4)
+    const uint8_t* tabs;        // tile images, layout.bytes apart
     Layout layout;
     const PodHeader* hdr;       // [tiles*64], zero flags beyond P
     uint32_t P;
@@ -116,9 +119,53 @@ struct FitArgs {
     unsigned long long* score;  // [P], pre-zeroed
 };
 
+// One step of the 64 x 64 bit-matrix transpose across a wavefront: exchange S x S sub-blocks between
+// lanes l and l ^ S (S < 32, inside one 32-bit register).
+template <int S>
+__device__ __forceinline__ uint32_t xpose_step(uint32_t x, uint32_t lane) {
+    constexpr uint32_t M = S == 16 ? 0x0000FFFFu : S == 8 ? 0x00FF00FFu : S == 4 ? 0x0F0F0F0Fu
+                                                 : S == 2 ? 0x33333333u : 0x55555555u;   // bits b with (b & S) == 0
+    const uint32_t y = (uint32_t)__shfl_xor((int)x, S, 64);
+    return (lane & S) ? (((y >> S) & M) | (x & ~M)) : ((x & M) | ((y << S) & ~M));
+}
+
+// in: lane l holds row l (bit j = column j) as (lo = columns 0..31, hi = columns 32..63);
+// out: lane j holds column j (bit l = row l).
+__device__ __forceinline__ void transpose64(uint32_t& lo, uint32_t& hi, uint32_t lane) {
+    // 32 x 32 blocks: swap the hi word of lanes 0..31 with the lo word of lanes 32..63
+    const auto sw = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+    lo = sw[0];
+    hi = sw[1];
+    lo = xpose_step<16>(lo, lane); hi = xpose_step<16>(hi, lane);
+    lo = xpose_step<8>(lo, lane);  hi = xpose_step<8>(hi, lane);
+    lo = xpose_step<4>(lo, lane);  hi = xpose_step<4>(hi, lane);
+    lo = xpose_step<2>(lo, lane);  hi = xpose_step<2>(hi, lane);
+    lo = xpose_step<1>(lo, lane);  hi = xpose_step<1>(hi, lane);
+}
+
+__device__ __forceinline__ uint4 lds16(const uint8_t* img, uint32_t off) {
+    return *reinterpret_cast<const uint4*>(__builtin_assume_aligned(img + off, 16));
+}
+__device__ __forceinline__ uint32_t pick(const uint4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
+
+// two pods per 32-bit word: (cpu placement with the misc cores on either socket) & GPU & NIC NUMA-0 & NIC NUMA-1
+__device__ __forceinline__ uint32_t assignments_ok(uint32_t w0, uint32_t w0m, uint32_t w1, uint32_t w1m, uint32_t ga,
+                                                   uint32_t r0, uint32_t r1) {
+    const uint32_t t1 = __builtin_amdgcn_bitop3_b32(w0m, w1, ga, 0x80);      // a & b & c
+    const uint32_t t2 = __builtin_amdgcn_bitop3_b32(w0, w1m, ga, 0x80);
+    const uint32_t t3 = __builtin_amdgcn_bitop3_b32(t1, t2, r0, 0xA8);       // (a | b) & c
+    return t3 & r1;
+}
+// per 16-bit half: 1 if any assignment bit is set, else 0
+__device__ __forceinline__ uint32_t nonzero_halves(uint32_t ok) {
+    uint32_t nz;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(ok), "v"(0x00010001u));
+    return nz;
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_fit_score(FitArgs a) {
-    extern __shared__ __align__(16) uint32_t tab[];
+    extern __shared__ __align__(16) uint8_t img[];
     __shared__ unsigned long long s_best[BLOCK / 64][64];
     constexpr int NW = BLOCK / 64;
 
@@ -128,27 +175,23 @@ __global__ __launch_bounds__(BLOCK) void k_fit_score(FitArgs a) {
     const uint32_t tile = blockIdx.x / a.nranges;
 
     {   // stage the tile's table image in LDS (16 B per lane, fully coalesced)
-        const uint4* src = reinterpret_cast<const uint4*>(a.tabs + (size_t)tile * a.tab_words);
-        uint4* dst = reinterpret_cast<uint4*>(tab);
-        for (uint32_t i = threadIdx.x; i < a.tab_words / 4; i += BLOCK) dst[i] = src[i];
+        const uint4* src = reinterpret_cast<const uint4*>(a.tabs + (size_t)tile * a.layout.bytes);
+        uint4* dst = reinterpret_cast<uint4*>(img);
+        for (uint32_t i = threadIdx.x; i < a.layout.bytes / 16; i += BLOCK) dst[i] = src[i];
     }
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t pod0 = tile * kTile;
-    // Lane-as-pod view of the tile's 64 request headers.  Everything the pod sweep needs from them is
-    // wave-uniform: flag tests become bit tests on 64-bit scalar masks, hp_req / groups are broadcast
-    // out of these registers with v_readlane.
+    // lane-as-pod view of the tile's 64 request headers -> class masks of the tile (scalar registers)
     const PodHeader my_h = a.hdr[pod0 + lane];
     const bool my_pod_live = pod0 + lane < a.P;
     const bool my_pod_needs_gpu = (my_h.flags & kPodNeedGpu) != 0;
-    const uint64_t m_valid = __ballot((my_h.flags & kPodValid) != 0);
     const uint64_t m_need = __ballot(my_pod_needs_gpu);
     const uint64_t m_pci = __ballot((my_h.flags & kPodPci) != 0);
     const uint64_t m_filt = __ballot((my_h.flags & kPodFilter) != 0);
-    const bool t_need = m_need != 0, t_pci = m_pci != 0, t_filt = m_filt != 0;
-    const bool homog = m_valid == ~0ull && (m_need == 0 || m_need == ~0ull) && (m_pci == 0 || m_pci == ~0ull) &&
-                       (m_filt == 0 || m_filt == ~0ull);
+    // requests are staged sorted by class, so almost every tile is all-PCI or all-NUMA
+    const bool pci_uniform = m_pci == 0 || m_pci == ~0ull;
     unsigned long long best = 0;
 
     const uint32_t c_begin = range * a.chunks_per_block;
@@ -157,83 +200,57 @@ __global__ __launch_bounds__(BLOCK) void k_fit_score(FitArgs a) {
         const uint32_t i = c * 64 + lane;
         const bool live = i < a.n;
         NodeLane nl = NodeLane{};
+        nl.flags = NHDFIT_NF_MAINTENANCE;                      // lanes past the end are never feasible
         if (live) nl = node_lane(a.p0[i], a.p1[i], a.p2[i], a.p3[i], a.p4[i], a.now, a.layout);
-        // node-side predicates as 64-bit lane masks (scalar registers)
-        const uint64_t n_ok = __ballot(live && !(nl.flags & NHDFIT_NF_MAINTENANCE));      // Matcher.py:71
-        const uint64_t n_active = __ballot((nl.flags & NHDFIT_NF_ACTIVE) != 0);           // NHDScheduler.py:242
-        const uint64_t n_idle = __ballot(!nl.busy);                                       // Matcher.py:107-111
         const uint64_t nogpu = __ballot(live && !(nl.flags & NHDFIT_NF_HAS_GPU));
-        const uint32_t* tw0 = tab + nl.off_w0;
-        const uint32_t* tw1 = tab + nl.off_w1;
-        const uint32_t* ta = tab + nl.off_a;
-        const uint32_t* trn0 = tab + nl.off_rn0;
-        const uint32_t* trn1 = tab + nl.off_rn1;
-        const uint32_t* trp0 = tab + nl.off_rp0;
-        const uint32_t* trp1 = tab + nl.off_rp1;
 
-        uint32_t wlo = 0, whi = 0;
-        if (homog) {
-            // Fast sweep: every pod of the tile has the same (needs-GPU, PCI, filter) class - the host
-            // stages requests sorted by class - so the class tests are per-tile scalars and two pods
-            // are served by each 8-byte LDS gather (columns j, j+1 of one row are adjacent words).
-            const uint32_t* tr0 = t_pci ? trp0 : trn0;
-            const uint32_t* tr1 = t_pci ? trp1 : trn1;
-            for (uint32_t j0 = 0; j0 < (uint32_t)kTile; j0 += 8) {
+        // (1) NUMA-assignment feasibility against all 64 pods, in the lane = node domain: 16-bit table rows,
+        //     8 pods per 16-byte LDS gather, two pods per 32-bit VALU op.  "Some assignment survives" is a
+        //     packed non-zero test per 16-bit half (v_pk_min_u16 with 1); thanks to the slot16() column
+        //     order the 0/1 results of word w drop into bits w and w+16 of a 32-pod accumulator.
+        uint32_t acc[2] = {0, 0};                                // pods 0..31, pods 32..63
+        if (pci_uniform) {
+            const uint32_t o_r0 = m_pci ? nl.off_r0p : nl.off_r0n;
+            const uint32_t o_r1 = m_pci ? nl.off_r1p : nl.off_r1n;
 #pragma unroll
-                for (uint32_t jj = 0; jj < 8; jj += 2) {
-                    const uint32_t j = j0 + jj;
-                    const uint2 w0 = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(tw0 + j, 8));
-                    const uint2 w1 = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(tw1 + j, 8));
-                    const uint2 r0 = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(tr0 + j, 8));
-                    const uint2 r1 = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(tr1 + j, 8));
-                    uint2 ga = make_uint2(0xFFFFu, 0xFFFFu);
-                    if (t_need) ga = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(ta + j, 8));
+            for (uint32_t q = 0; q < (uint32_t)kTile / 8; ++q) {
+                const uint32_t cb = q * 16;                      // 4 words = 8 pods
+                const uint4 w0 = lds16(img, nl.off_w0 + cb), w0m = lds16(img, nl.off_w0 + nl.w_misc + cb);
+                const uint4 w1 = lds16(img, nl.off_w1 + cb), w1m = lds16(img, nl.off_w1 + nl.w_misc + cb);
+                const uint4 ga = lds16(img, nl.off_a + cb);
+                const uint4 r0 = lds16(img, o_r0 + cb), r1 = lds16(img, o_r1 + cb);
 #pragma unroll
-                    for (uint32_t h = 0; h < 2; ++h) {
-                        const uint32_t pod = j + h;
-                        const int hp = __builtin_amdgcn_readlane(my_h.hp_req, (int)pod);
-                        uint64_t pass = n_ok & __ballot(hp <= nl.hp_free);                  // Matcher.py:78
-                        if (t_filt) {                                                         // NHDScheduler.py:240-242
-                            const uint64_t g = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_h.groups, (int)pod) |
-                                ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_h.groups >> 32), (int)pod) << 32);
-                            pass &= n_active & __ballot((nl.groups & g) != 0);
-                        }
-                        if (t_need) pass &= n_idle;                                           // Matcher.py:107-111
-                        const uint32_t x = (h ? w0.y : w0.x) & (h ? w1.y : w1.x);
-                        const uint32_t ok = (x | (x >> 16)) & (h ? ga.y : ga.x) & ((h ? r0.y : r0.x) >> 16) & (h ? r1.y : r1.x);
-                        const uint64_t w = pass & __ballot(ok != 0);
-                        wlo = (uint32_t)nhd_writelane((int)(uint32_t)w, (int)pod, (int)wlo);
-                        whi = (uint32_t)nhd_writelane((int)(uint32_t)(w >> 32), (int)pod, (int)whi);
-                    }
-                }
+                for (int k = 0; k < 4; ++k)
+                    acc[q >> 2] |= nonzero_halves(assignments_ok(pick(w0, k), pick(w0m, k), pick(w1, k), pick(w1m, k),
+                                                                 pick(ga, k), pick(r0, k), pick(r1, k))) << ((q & 3) * 4 + k);
             }
         } else {
-            // Generic sweep (mixed or partly invalid tiles): per-pod class bits out of scalar masks.
-#pragma unroll 2
-            for (uint32_t j = 0; j < (uint32_t)kTile; ++j) {
-                if (!(m_valid >> j & 1)) continue;                                            // Matcher.py:45-47
-                const int hp = __builtin_amdgcn_readlane(my_h.hp_req, (int)j);
-                uint64_t pass = n_ok & __ballot(hp <= nl.hp_free);
-                if (m_filt >> j & 1) {
-                    const uint64_t g = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_h.groups, (int)j) |
-                                       ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_h.groups >> 32), (int)j) << 32);
-                    pass &= n_active & __ballot((nl.groups & g) != 0);
+            // mixed tile (class boundary, rare): read both NIC row variants and pick per pod
+#pragma unroll 1
+            for (uint32_t q = 0; q < (uint32_t)kTile / 8; ++q) {
+                const uint32_t cb = q * 16;
+                const uint4 w0 = lds16(img, nl.off_w0 + cb), w0m = lds16(img, nl.off_w0 + nl.w_misc + cb);
+                const uint4 w1 = lds16(img, nl.off_w1 + cb), w1m = lds16(img, nl.off_w1 + nl.w_misc + cb);
+                const uint4 ga = lds16(img, nl.off_a + cb);
+                const uint4 r0n = lds16(img, nl.off_r0n + cb), r1n = lds16(img, nl.off_r1n + cb);
+                const uint4 r0p = lds16(img, nl.off_r0p + cb), r1p = lds16(img, nl.off_r1p + cb);
+                uint32_t part = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t w = (q & 3) * 4 + k, base = (q >> 2) * 32;      // word w holds pods base+w, base+w+16
+                    const uint32_t sel = ((m_pci >> (base + w) & 1) ? 0xFFFFu : 0u) | ((m_pci >> (base + w + 16) & 1) ? 0xFFFF0000u : 0u);
+                    const uint32_t r0 = (pick(r0p, k) & sel) | (pick(r0n, k) & ~sel);
+                    const uint32_t r1 = (pick(r1p, k) & sel) | (pick(r1n, k) & ~sel);
+                    part |= nonzero_halves(assignments_ok(pick(w0, k), pick(w0m, k), pick(w1, k), pick(w1m, k), pick(ga, k), r0, r1)) << k;
                 }
-                const uint32_t x = tw0[j] & tw1[j];
-                uint32_t ok = x | (x >> 16);                  // high half is cleared by the NIC term below
-                if (m_need >> j & 1) {
-                    pass &= n_idle;
-                    ok &= ta[j];
-                }
-                const bool pci = m_pci >> j & 1;
-                const uint32_t r0 = (pci ? trp0 : trn0)[j];
-                const uint32_t r1 = (pci ? trp1 : trn1)[j];
-                ok &= (r0 >> 16) & r1;
-                const uint64_t w = pass & __ballot(ok != 0);
-                wlo = (uint32_t)nhd_writelane((int)(uint32_t)w, (int)j, (int)wlo);
-                whi = (uint32_t)nhd_writelane((int)(uint32_t)(w >> 32), (int)j, (int)whi);
+                if (q >> 2) acc[1] |= part << ((q & 3) * 4); else acc[0] |= part << ((q & 3) * 4);
             }
         }
+        // (2) scalar predicates of this lane's node against all 64 pods (one 64-bit word per table row)
+        const uint64_t fm = node_pod_mask(nl, img, m_filt, m_need);
+        uint32_t wlo = acc[0] & (uint32_t)fm, whi = acc[1] & (uint32_t)(fm >> 32);
+        // (3) 64 x 64 bit transpose: lane j now holds pod j's verdict over the chunk's 64 nodes
+        transpose64(wlo, whi, lane);
         uint64_t word = ((uint64_t)whi << 32) | wlo;
         if (my_pod_live) {
             const size_t o = (size_t)c * a.P + pod0 + lane;
@@ -259,9 +276,8 @@ struct MapArgs {
     const nhdfit_plane2* p2;
     const nhdfit_plane3* p3;
     const nhdfit_detail* det;
-    const uint32_t* tabs;
-    uint32_t tab_words;
-    uint32_t row_r;
+    const uint8_t* tabs;
+    Layout layout;
     uint32_t n;
     uint64_t global_base;
     const nhdfit_req* reqs;
@@ -271,14 +287,19 @@ struct MapArgs {
     nhdfit_mapping* out;
 };
 
+// One pod per wavefront: the mapping is a long, branchy, strictly sequential computation (the
+// CPython set model), so lanes working on different pods would serialise each other's control flow.
+// Lane 0 of each wave does the work (no divergence); 4 096 pods = 4 096 short waves spread over the chip.
 // GENERIC = false: pods with G <= 3 (register-resident set model, no scratch traffic);
 // GENERIC = true : pods with G == 4 (launched only when the batch contains such pods).
+constexpr int kMapWaves = 4;
 template <bool GENERIC>
-__global__ __launch_bounds__(64) void k_map(MapArgs a) {
-    const uint32_t p = blockIdx.x * 64 + threadIdx.x;
-    if (p >= a.P) return;
+__global__ __launch_bounds__(64 * kMapWaves) void k_map(MapArgs a) {
+    const uint32_t p = __builtin_amdgcn_readfirstlane(blockIdx.x * kMapWaves + (threadIdx.x >> 6));
+    if (p >= a.P || (threadIdx.x & 63) != 0) return;     // one working lane per wave: scratch traffic of one thread
     if ((a.reqs[p].n_groups > 3) != GENERIC) return;
-    nhdfit_mapping m;
+    // everything indexed dynamically (request, winner detail, result) stays in global memory: no scratch
+    nhdfit_mapping& m = a.out[p];
     memset(&m, 0, sizeof(m));
     const unsigned long long s = a.score[p];
     if (s) {
@@ -289,25 +310,22 @@ __global__ __launch_bounds__(64) void k_map(MapArgs a) {
             const nhdfit_plane0 q0 = a.p0[i];
             const nhdfit_plane1 q1 = a.p1[i];
             const nhdfit_plane2 q2 = a.p2[i];
-            w.d = a.det[i];
-            w.U = w.d.numa_nodes;
+            w.d = a.det + i;
+            w.U = w.d->numa_nodes;
             w.smt = (q2.flags & NHDFIT_NF_SMT) != 0;
             w.free_c[0] = popc64(q0.t0[0] & q1.t1[0]);
             w.free_c[1] = popc64(q0.t0[1] & q1.t1[1]);
             w.free_g[0] = popc32(q2.gpu_free & ~q2.gpu_numa1);
             w.free_g[1] = popc32(q2.gpu_free & q2.gpu_numa1);
             w.caps = a.caps;
-            const nhdfit_plane3 q3 = a.p3[i];
-            const nhdfit_req rq = a.reqs[p];
-            const uint32_t bits = nic_table_bits(a.tabs + (size_t)(p / kTile) * a.tab_words, a.row_r, p % kTile,
-                                                 rq.map_type == NHDFIT_MAP_PCI, q3.sig_numa[0], q3.sig_numa[1],
-                                                 q3.sig_pci[0], q3.sig_pci[1]);
+            const nhdfit_req& rq = a.reqs[p];
+            const uint32_t bits = nic_assignment_bits(a.tabs + (size_t)(p / kTile) * a.layout.bytes, a.layout, p % kTile,
+                                                      rq.map_type == NHDFIT_MAP_PCI, a.p3[i]);
             const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
             if (GENERIC) map_winner_t<GenericOps>(rq, w, codes, m);
             else map_winner_t<SmallOps>(rq, w, codes, m);
         }
     }
-    a.out[p] = m;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -376,14 +394,16 @@ struct nhdfit_ctx {
     // dictionary
     DevBuf<double> caps; DevBuf<uint32_t> sig_off, pool_off; DevBuf<uint8_t> pool_glimit; DevBuf<nhdfit_cc> cc;
     uint32_t ncls = 0, nsig = 0;
-    uint32_t tab_words = 0, lds_bytes = 0;
+    uint32_t max_cores = 1, max_gpus = 0, ngs = 0;
+    DevBuf<uint64_t> group_sets;
+    uint32_t lds_bytes = 0;
     Layout layout{};
     uint32_t n_big_pods = 0;      // staged pods with more than 3 proc groups
 
     // requests / results
     DevBuf<nhdfit_req> reqs; uint32_t P = 0;
     std::vector<uint32_t> perm;          // device (class-sorted) position -> caller's pod index
-    DevBuf<PodHeader> hdr; DevBuf<uint32_t> tabs;
+    DevBuf<PodHeader> hdr; DevBuf<uint8_t> tabs;
     DevBuf<unsigned long long> score; DevBuf<uint64_t> bitmap; DevBuf<uint64_t> cand; DevBuf<nhdfit_mapping> maps;
     bool use_cand = false, want_bitmap = true, want_map = true;
 
@@ -502,6 +522,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
 }
 
 int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t max_gpus_per_numa,
+                          const uint64_t* group_sets, uint32_t n_group_sets,
                           const double* caps, uint32_t ncls,
                           const uint32_t* sig_off, uint32_t nsig,
                           const uint32_t* pool_off, const uint8_t* pool_glimit, uint32_t npools,
@@ -517,13 +538,16 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
         return fail(c, NHDFIT_E_LIMIT, "%u GPUs per NUMA node (max %d)", max_gpus_per_numa, NHDFIT_MAX_GPUS_PER_NUMA);
     if (max_cores_per_numa < 1 || max_cores_per_numa > NHDFIT_MAX_CORES_PER_NUMA)
         return fail(c, NHDFIT_E_LIMIT, "%u cores per socket (supported: 1..%d)", max_cores_per_numa, NHDFIT_MAX_CORES_PER_NUMA);
-    const Layout L = make_layout(max_cores_per_numa, max_gpus_per_numa, nsig);
-    const uint32_t words = (L.rows * kRowStride + 3u) & ~3u;
-    const uint32_t bytes = words * 4;
+    if (n_group_sets && !group_sets) return fail(c, NHDFIT_E_INVAL, "NULL group set table");
+    const Layout L = make_layout(max_cores_per_numa, max_gpus_per_numa, nsig, n_group_sets ? n_group_sets : 1, kMaxHpRows);
     HIPCHK(c, hipSetDevice(c->dev));
-    if (bytes + 8192 > 160 * 1024)
-        return fail(c, NHDFIT_E_LIMIT, "%u NIC signatures need %u bytes of LDS per tile (160 KiB per CU)", nsig, bytes);
+    if (L.bytes + 8192 > 160 * 1024)
+        return fail(c, NHDFIT_E_LIMIT, "%u NIC signatures / %u node-group sets need %u bytes of LDS per tile (160 KiB per CU)",
+                    nsig, n_group_sets, L.bytes);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, c->group_sets.reserve(n_group_sets ? n_group_sets : 1));
+    if (n_group_sets) HIPCHK(c, hipMemcpy(c->group_sets.p, group_sets, n_group_sets * sizeof(uint64_t), hipMemcpyHostToDevice));
+    else { const uint64_t zero = 0; HIPCHK(c, hipMemcpy(c->group_sets.p, &zero, sizeof zero, hipMemcpyHostToDevice)); }
     HIPCHK(c, c->caps.reserve(ncls ? ncls : 1));
     HIPCHK(c, c->sig_off.reserve(nsig + 1));
     HIPCHK(c, c->pool_off.reserve(npools + 1));
@@ -536,11 +560,12 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     if (ncc) HIPCHK(c, hipMemcpy(c->cc.p, cc, ncc * sizeof(nhdfit_cc), hipMemcpyHostToDevice));
     c->ncls = ncls;
     c->nsig = nsig;
-    c->tab_words = words;
-    c->lds_bytes = bytes;
-    c->layout = L;
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_score<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_score<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    c->ngs = n_group_sets ? n_group_sets : 1;
+    c->max_cores = max_cores_per_numa;
+    c->max_gpus = max_gpus_per_numa;
+    c->P = 0;                                       // staged tables (if any) were built for the old dictionary
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_score<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_score<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
     return NHDFIT_OK;
 }
 
@@ -591,9 +616,18 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const uint32_t tiles = (P + kTile - 1) / kTile;
     const uint32_t chunks = (c->capacity + 63) / 64;
+    int32_t hp_max = 0;
+    for (uint32_t p = 0; p < P; ++p) {
+        if (reqs[p].hugepages_gb < 0) return fail(c, NHDFIT_E_INVAL, "pod %u asks for a negative number of hugepages", p);
+        hp_max = reqs[p].hugepages_gb > hp_max ? reqs[p].hugepages_gb : hp_max;
+    }
+    if (hp_max > kMaxHpRows - 2)
+        return fail(c, NHDFIT_E_LIMIT, "a pod asks for %d GiB of hugepages (limit %d)", hp_max, kMaxHpRows - 2);
+    c->layout = make_layout(c->max_cores, c->max_gpus, c->nsig, c->ngs, (uint32_t)hp_max + 2);
+    c->lds_bytes = c->layout.bytes;
     HIPCHK(c, c->reqs.reserve(P));
     HIPCHK(c, c->hdr.reserve((size_t)tiles * kTile));
-    HIPCHK(c, c->tabs.reserve((size_t)tiles * c->tab_words));
+    HIPCHK(c, c->tabs.reserve((size_t)tiles * c->layout.bytes));
     HIPCHK(c, c->score.reserve(P));
     HIPCHK(c, c->maps.reserve(P));
     HIPCHK(c, c->bitmap.reserve((size_t)chunks * P));
@@ -641,9 +675,9 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
 
     HIPCHK(c, hipEventRecord(ev[0], c->stream));
     HIPCHK(c, hipMemsetAsync(c->score.p, 0, (size_t)P * sizeof(unsigned long long), c->stream));
-    DictView dv{c->caps.p, c->ncls, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}};
+    DictView dv{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}};
     hipLaunchKernelGGL(k_digest, dim3(tiles, kDigestSlices), dim3(kDigestThreads), 0, c->stream,
-                       c->reqs.p, P, dv, c->layout, c->tab_words, c->tabs.p, c->hdr.p);
+                       c->reqs.p, P, dv, c->layout, c->tabs.p, c->hdr.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(ev[1], c->stream));
 
@@ -652,7 +686,7 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     FitArgs a;
     a.p0 = c->p0.p; a.p1 = c->p1.p; a.p2 = c->p2.p; a.p3 = c->p3.p; a.p4 = c->p4.p;
     a.n = c->n; a.chunks = chunks; a.global_base = c->global_base; a.now = now;
-    a.tabs = c->tabs.p; a.tab_words = c->tab_words; a.layout = c->layout; a.hdr = c->hdr.p; a.P = P;
+    a.tabs = c->tabs.p; a.layout = c->layout; a.hdr = c->hdr.p; a.P = P;
     a.cand = c->use_cand ? c->cand.p : nullptr;
     a.bitmap = c->want_bitmap ? c->bitmap.p : nullptr;
     a.score = c->score.p;
@@ -674,10 +708,11 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
         if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
     }
     if (c->want_map) {
-        MapArgs m{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->det.p, c->tabs.p, c->tab_words, c->layout.row_r, c->n,
+        MapArgs m{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->det.p, c->tabs.p, c->layout, c->n,
                   c->global_base, c->reqs.p, P, c->score.p, c->caps.p, c->maps.p};
-        if (c->n_big_pods < P) hipLaunchKernelGGL(k_map<false>, dim3((P + 63) / 64), dim3(64), 0, c->stream, m);
-        if (c->n_big_pods) hipLaunchKernelGGL(k_map<true>, dim3((P + 63) / 64), dim3(64), 0, c->stream, m);
+        const dim3 mg((P + kMapWaves - 1) / kMapWaves), mb(64 * kMapWaves);
+        if (c->n_big_pods < P) hipLaunchKernelGGL(k_map<false>, mg, mb, 0, c->stream, m);
+        if (c->n_big_pods) hipLaunchKernelGGL(k_map<true>, mg, mb, 0, c->stream, m);
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(ev[3], c->stream));

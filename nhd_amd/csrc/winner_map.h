@@ -22,10 +22,8 @@ constexpr uint64_t kXX2 = 14029467366897019727ULL;
 constexpr uint64_t kXX5 = 2870177450012600261ULL;
 
 // hash(tuple of `len` ints); hash(int k>=0) == k.  Tuples are coded in base U in {1, 2} (NUMA nodes per
-// node) with the first element most significant: digit i = bit (len-1-i) of `code` (all zero for U=1),
-// which keeps integer division out of the device code.
-NHD_HD uint64_t py_tuple_hash(uint32_t code, int len, int base) {
-    (void)base;
+// node) with the first element most significant: digit i = bit (len-1-i) of `code` (all zero for U=1).
+constexpr uint64_t py_tuple_hash_calc(uint32_t code, int len) {
     uint64_t acc = kXX5;
     for (int i = 0; i < len; ++i) {
         const uint64_t lane = (code >> (len - 1 - i)) & 1u;
@@ -36,6 +34,28 @@ NHD_HD uint64_t py_tuple_hash(uint32_t code, int len, int base) {
     acc += (uint64_t)len ^ (kXX5 ^ 3527539ULL);
     if (acc == (uint64_t)-1) return 1546275796ULL;
     return acc;
+}
+// all hashes the path can need (tuples of length <= 5 over {0,1}), evaluated at compile time: the
+// sequential mapping kernel spends most of its instructions here otherwise
+struct TupleHashTable { uint64_t h[6][32]; };
+constexpr TupleHashTable make_tuple_hash_table() {
+    TupleHashTable t{};
+    for (int len = 0; len <= 5; ++len)
+        for (uint32_t code = 0; code < 32; ++code) t.h[len][code] = code < (1u << len) ? py_tuple_hash_calc(code, len) : 0;
+    return t;
+}
+#if defined(__HIPCC__)
+__device__ const TupleHashTable kTupleHashDev = make_tuple_hash_table();
+#endif
+static constexpr TupleHashTable kTupleHashHost = make_tuple_hash_table();
+
+NHD_HD uint64_t py_tuple_hash(uint32_t code, int len, int base) {
+    (void)base;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return kTupleHashDev.h[len][code & 31u];
+#else
+    return kTupleHashHost.h[len][code & 31u];
+#endif
 }
 
 constexpr int kSetCap = 128;      // 32 distinct tuples at most (2^(G+1), G=4) -> table never exceeds 128 slots
@@ -149,21 +169,30 @@ struct SmallSet {
     uint64_t k0, k1, k2, k3;
 };
 
-NHD_HD void ss_init(SmallSet& s, int len, int base) {
+// NOTE: every helper takes and returns the set BY VALUE.  With reference parameters LLVM turns the
+// "which 64-bit word holds this slot" selects into address arithmetic on the struct, which pins all
+// sets in scratch memory (400 B/lane, and a scratch-limited occupancy) instead of registers.
+NHD_HD SmallSet ss_make(int len, int base) {
+    SmallSet s;
     s.used = 0; s.mask = 7; s.fill = 0; s.len = len; s.base = base;
     s.k0 = s.k1 = s.k2 = s.k3 = 0;
+    return s;
 }
-NHD_HD int ss_key(const SmallSet& s, int slot) {
+NHD_HD int ss_key(SmallSet s, int slot) {
     const uint64_t w = slot < 16 ? (slot < 8 ? s.k0 : s.k1) : (slot < 24 ? s.k2 : s.k3);
     return (int)((w >> ((slot & 7) * 8)) & 0xFF);
 }
-NHD_HD void ss_put(SmallSet& s, int slot, int key) {
+NHD_HD SmallSet ss_put(SmallSet s, int slot, int key) {
     const uint64_t v = (uint64_t)key << ((slot & 7) * 8);
-    if (slot < 8) s.k0 |= v; else if (slot < 16) s.k1 |= v; else if (slot < 24) s.k2 |= v; else s.k3 |= v;
+    s.k0 |= slot < 8 ? v : 0;
+    s.k1 |= (slot >= 8 && slot < 16) ? v : 0;
+    s.k2 |= (slot >= 16 && slot < 24) ? v : 0;
+    s.k3 |= slot >= 24 ? v : 0;
     s.used |= 1u << slot;
+    return s;
 }
 // slot where `key` lives (>= 0), or -(free slot)-1 where it would be inserted
-NHD_HD int ss_probe(const SmallSet& s, int key, uint64_t h, bool match) {
+NHD_HD int ss_probe(SmallSet s, int key, uint64_t h, bool match) {
     uint64_t perturb = h;
     uint32_t i = (uint32_t)(h & (uint64_t)s.mask);
     for (;;) {
@@ -176,37 +205,40 @@ NHD_HD int ss_probe(const SmallSet& s, int key, uint64_t h, bool match) {
         i = (uint32_t)((i * 5 + 1 + perturb) & (uint64_t)s.mask);
     }
 }
-NHD_HD void ss_add(SmallSet& s, int key) {
+NHD_HD SmallSet ss_add(SmallSet s, int key) {
     const uint64_t h = py_tuple_hash((uint32_t)key, s.len, s.base);
     const int r = ss_probe(s, key, h, true);
-    if (r >= 0) return;
-    ss_put(s, -r - 1, key);
+    if (r >= 0) return s;
+    s = ss_put(s, -r - 1, key);
     s.fill++;
     if (s.fill * 5 >= s.mask * 3) {                   // 8 -> 32 slots (set_table_resize(used*4)); never further
-        SmallSet o = s;
+        const SmallSet o = s;
         s.used = 0; s.mask = 31; s.k0 = s.k1 = s.k2 = s.k3 = 0;
         for (int i = 0; i <= o.mask; ++i)
             if (o.used >> i & 1) {
                 const int k = ss_key(o, i);
-                ss_put(s, -ss_probe(s, k, py_tuple_hash((uint32_t)k, s.len, s.base), false) - 1, k);
+                s = ss_put(s, -ss_probe(s, k, py_tuple_hash((uint32_t)k, s.len, s.base), false) - 1, k);
             }
     }
+    return s;
 }
-NHD_HD bool ss_has(const SmallSet& s, int key) {
+NHD_HD bool ss_has(SmallSet s, int key) {
     return ss_probe(s, key, py_tuple_hash((uint32_t)key, s.len, s.base), true) >= 0;
 }
-NHD_HD void ss_intersect(const SmallSet& a, const SmallSet& b, SmallSet& out) {
-    ss_init(out, a.len, a.base);
+// a & b: iterate the smaller operand (b on ties) in slot order, probe the other (set_intersection)
+NHD_HD SmallSet ss_intersect(SmallSet a, SmallSet b) {
+    SmallSet out = ss_make(a.len, a.base);
     const bool swap = b.fill > a.fill;
-    const SmallSet& probe = swap ? b : a;
-    const SmallSet& iter = swap ? a : b;
+    const SmallSet probe = swap ? b : a;
+    const SmallSet iter = swap ? a : b;
     for (int i = 0; i <= iter.mask; ++i)
         if (iter.used >> i & 1) {
             const int k = ss_key(iter, i);
-            if (ss_has(probe, k)) ss_add(out, k);
+            if (ss_has(probe, k)) out = ss_add(out, k);
         }
+    return out;
 }
-NHD_HD int ss_list(const SmallSet& s, int16_t* out) {
+NHD_HD int ss_list(SmallSet s, int16_t* out) {
     int n = 0;
     for (int i = 0; i <= s.mask; ++i)
         if (s.used >> i & 1) out[n++] = (int16_t)ss_key(s, i);
@@ -221,14 +253,18 @@ struct GenericOps {
     NHD_HD static void isect(const Set& a, const Set& b, Set& o) { ps_intersect(a, b, o); }
     NHD_HD static int list(const Set& s, int16_t* o) { return ps_list(s, o); }
     NHD_HD static int size(const Set& s) { return s.fill; }
+    NHD_HD static int slots(const Set& s) { return s.mask + 1; }
+    NHD_HD static int key_at(const Set& s, int slot) { return s.key[slot]; }              // -1 = empty slot
 };
 struct SmallOps {
     typedef SmallSet Set;
-    NHD_HD static void init(Set& s, int len, int base) { ss_init(s, len, base); }
-    NHD_HD static void add(Set& s, int key, int, int) { ss_add(s, key); }
-    NHD_HD static void isect(const Set& a, const Set& b, Set& o) { ss_intersect(a, b, o); }
+    NHD_HD static void init(Set& s, int len, int base) { s = ss_make(len, base); }
+    NHD_HD static void add(Set& s, int key, int, int) { s = ss_add(s, key); }
+    NHD_HD static void isect(const Set& a, const Set& b, Set& o) { o = ss_intersect(a, b); }
     NHD_HD static int list(const Set& s, int16_t* o) { return ss_list(s, o); }
     NHD_HD static int size(const Set& s) { return s.fill; }
+    NHD_HD static int slots(const Set& s) { return s.mask + 1; }
+    NHD_HD static int key_at(const Set& s, int slot) { return (s.used >> slot & 1) ? ss_key(s, slot) : -1; }
 };
 
 // ---- the winner's resource state -------------------------------------------------------------------
@@ -236,7 +272,7 @@ struct WinnerState {
     int U;                        // Node.numa_nodes (1 or 2)
     bool smt;
     int free_c[2], free_g[2];
-    nhdfit_detail d;
+    const nhdfit_detail* d;       // the winner's cold record (left in global memory: indexed dynamically)
     const double* caps;           // capacity per class
 };
 
@@ -252,44 +288,53 @@ NHD_HD uint32_t ipow(int b, int e) { return b == 1 ? 1u : 1u << e; }   // b in {
 // on the NUMA node `assign` gives it, or false.  Order: itertools.product over NUMA nodes of
 // itertools.product(range(K_u), repeat=#groups on u) - i.e. an odometer whose most significant
 // digits are the NUMA-0 groups (ascending group index), then the NUMA-1 groups.
+// All small per-group state is nibble-packed into scalars so nothing lives in scratch memory.
+NHD_HD uint32_t nib_get(uint32_t v, int i) { return (v >> (4 * i)) & 15u; }
+NHD_HD uint32_t nib_set(uint32_t v, int i, uint32_t x) { return (v & ~(15u << (4 * i))) | (x << (4 * i)); }
+
 NHD_HD bool first_nic_choice(const nhdfit_req& r, const WinnerState& w, uint32_t gcode, bool pci, int8_t nic_idx[kMaxG]) {
     const int G = (int)r.n_groups;
-    int order[kMaxG], numa_of[kMaxG], n = 0;
+    uint32_t order = 0, numa = 0;                    // order: nibble pos -> group; numa: bit g -> NUMA of group g
+    int n = 0;
     for (int u = 0; u < w.U; ++u)
         for (int g = 0; g < G; ++g)
-            if (tup_digit(gcode, G, w.U, g) == u) { order[n] = g; numa_of[g] = u; ++n; }
+            if (tup_digit(gcode, G, w.U, g) == u) { order = nib_set(order, n, (uint32_t)g); numa |= (uint32_t)u << g; ++n; }
     for (int g = 0; g < G; ++g)
-        if (w.d.nic_cnt[numa_of[g]] == 0) return false;
-    int pick[kMaxG] = {0, 0, 0, 0};
+        if (w.d->nic_cnt[(numa >> g) & 1] == 0) return false;
+    uint32_t pick = 0;                               // nibble g -> NIC ordinal chosen for group g
     for (;;) {
-        // evaluate: subtract in group order per NIC
         bool ok = true;
-        double rx[2][NHDFIT_MAX_NICS_PER_NUMA], tx[2][NHDFIT_MAX_NICS_PER_NUMA];
-        for (int u = 0; u < w.U; ++u)
-            for (int k = 0; k < w.d.nic_cnt[u]; ++k) rx[u][k] = tx[u][k] = w.caps[w.d.nic_cls[u][k]];
-        for (int g = 0; g < G; ++g) {
-            const int u = numa_of[g], k = pick[g];
-            rx[u][k] = rx[u][k] - r.rx[g];
-            tx[u][k] = tx[u][k] - r.tx[g];
+        for (int g = 0; g < G && ok; ++g) {
+            const uint32_t u = (numa >> g) & 1, k = nib_get(pick, g);
+            bool first_on_nic = true;
+            for (int h = 0; h < g; ++h)
+                if (((numa >> h) & 1) == u && nib_get(pick, h) == k) first_on_nic = false;
+            if (!first_on_nic) continue;
+            // the reference subtracts every group placed on this NIC from [cap, cap] in group order (Matcher.py:261-263)
+            double rx = w.caps[w.d->nic_cls[u][k]], tx = rx;
+            for (int h = g; h < G; ++h)
+                if (((numa >> h) & 1) == u && nib_get(pick, h) == k) { rx = rx - r.rx[h]; tx = tx - r.tx[h]; }
+            if (rx < 0 || tx < 0) ok = false;                                    // Matcher.py:267
         }
-        for (int u = 0; u < w.U && ok; ++u)
-            for (int k = 0; k < w.d.nic_cnt[u]; ++k)
-                if (rx[u][k] < 0 || tx[u][k] < 0) { ok = false; break; }
-        if (ok && pci) {                                  // Matcher.py:312-322
-            uint8_t cnt[NHDFIT_MAX_SWITCHES] = {0};
-            for (int g = 0; g < G; ++g) cnt[w.d.nic_sw[numa_of[g]][pick[g]]]++;
-            for (int s = 0; s < NHDFIT_MAX_SWITCHES; ++s)
-                if (cnt[s] > w.d.sw_free[s]) { ok = false; break; }
+        if (ok && pci) {                                                         // Matcher.py:312-322
+            for (int g = 0; g < G && ok; ++g) {
+                const uint32_t s = w.d->nic_sw[(numa >> g) & 1][nib_get(pick, g)];
+                uint32_t cnt = 0;
+                for (int h = 0; h < G; ++h)
+                    if (w.d->nic_sw[(numa >> h) & 1][nib_get(pick, h)] == s) ++cnt;
+                if (cnt > w.d->sw_free[s]) ok = false;
+            }
         }
         if (ok) {
-            for (int g = 0; g < G; ++g) nic_idx[g] = (int8_t)pick[g];
+            for (int g = 0; g < G; ++g) nic_idx[g] = (int8_t)nib_get(pick, g);
             return true;
         }
         int pos = G - 1;                                  // advance the odometer (last digit fastest)
         while (pos >= 0) {
-            const int g = order[pos];
-            if (++pick[g] < w.d.nic_cnt[numa_of[g]]) break;
-            pick[g] = 0;
+            const int g = (int)nib_get(order, pos);
+            const uint32_t v = nib_get(pick, g) + 1;
+            if (v < w.d->nic_cnt[(numa >> g) & 1]) { pick = nib_set(pick, g, v); break; }
+            pick = nib_set(pick, g, 0);
             --pos;
         }
         if (pos < 0) return false;
@@ -313,6 +358,22 @@ NHD_HD uint32_t nic_codes_from_table_bits(uint32_t bits, int G, int U) {
 // Restatement of the winner-only tail of FindNode (Matcher.py:337-391 + 423-452).
 // `nic_codes`: bit c set = assignment with tuple code c has at least one valid NIC choice (after the
 // PCI pruning) - taken from the same reach tables the fit kernel used.  Returns false if infeasible.
+// GetNumaGroupIdx (Matcher.py:427-437) over one candidate list (= a set walked in slot order)
+template <class Ops>
+NHD_HD int pick_gpu_tuple(const typename Ops::Set& gset, int G, int U) {
+    int best = -1, best_spread = -1;
+    for (int i = 0; i < Ops::slots(gset); ++i) {
+        const int k = Ops::key_at(gset, i);
+        if (k < 0) continue;
+        int ones = 0;
+        for (int g = 0; g < G; ++g) ones += tup_digit((uint32_t)k, G, U, g);
+        const int zeros = G - ones;
+        const int spread = U == 1 ? 0 : (ones > zeros ? ones - zeros : zeros - ones);
+        if (spread > best_spread) { best_spread = spread; best = k; }
+    }
+    return best;
+}
+
 template <class Ops>
 NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic_codes, nhdfit_mapping& out) {
     typedef typename Ops::Set Set;
@@ -321,70 +382,53 @@ NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic
     const uint32_t nG = ipow(U, G), nC = ipow(U, G + 1);
     out.valid = 0;
 
-    // candidate sets in product order (Matcher.py:116-141, 206-220)
+    // candidate sets in product order (Matcher.py:116-141, 206-220).  list(set) = keys in slot order, so the
+    // "lists" of the reference are never materialised: the sets' slots are walked instead.
     Set sg, sc;
     Ops::init(sg, G, U);
     Ops::init(sc, G + 1, U);
-    uint32_t demand[kMaxG + 1];
-    for (int g = 0; g < G; ++g) demand[g] = w.smt ? r.cpu_smt[g] : r.cpu_nosmt[g];
-    demand[G] = w.smt ? r.misc_smt : r.misc_nosmt;
     for (uint32_t code = 0; code < nG; ++code) {
-        uint32_t tot[2] = {0, 0};
-        for (int g = 0; g < G; ++g) tot[tup_digit(code, G, U, g)] += r.gpus[g];
-        bool ok = true;
-        for (int u = 0; u < U; ++u) ok = ok && tot[u] <= (uint32_t)w.free_g[u];
-        if (ok) Ops::add(sg, (int)code, G, U);
+        uint32_t t0 = 0, t1 = 0;
+        for (int g = 0; g < G; ++g) { if (tup_digit(code, G, U, g)) t1 += r.gpus[g]; else t0 += r.gpus[g]; }
+        if (t0 <= (uint32_t)w.free_g[0] && t1 <= (uint32_t)w.free_g[1]) Ops::add(sg, (int)code, G, U);
     }
     for (uint32_t code = 0; code < nC; ++code) {
-        uint32_t tot[2] = {0, 0};
-        for (int g = 0; g <= G; ++g) tot[tup_digit(code, G + 1, U, g)] += demand[g];
-        bool ok = true;
-        for (int u = 0; u < U; ++u) ok = ok && tot[u] <= (uint32_t)w.free_c[u];
-        if (ok) Ops::add(sc, (int)code, G + 1, U);
+        uint32_t t0 = 0, t1 = 0;
+        for (int g = 0; g <= G; ++g) {
+            const uint32_t d = g < G ? (w.smt ? r.cpu_smt[g] : r.cpu_nosmt[g]) : (w.smt ? r.misc_smt : r.misc_nosmt);
+            if (tup_digit(code, G + 1, U, g)) t1 += d; else t0 += d;
+        }
+        if (t0 <= (uint32_t)w.free_c[0] && t1 <= (uint32_t)w.free_c[1]) Ops::add(sc, (int)code, G + 1, U);
     }
     if (Ops::size(sg) == 0 || Ops::size(sc) == 0 || !(nic_codes & ((nG >= 32 ? 0u : (1u << nG)) - 1u))) return false;
 
     // intersection of the three prefix sets (Matcher.py:342-346): set(list) re-inserts in list order
-    int16_t lg[1 << kMaxG], lc[2 << kMaxG];
-    const int ng = Ops::list(sg, lg), nc = Ops::list(sc, lc);
     Set a, b, c, ab, abc;
     Ops::init(a, G, U); Ops::init(b, G, U); Ops::init(c, G, U);
-    for (int i = 0; i < ng; ++i) Ops::add(a, lg[i], G, U);
-    for (int i = 0; i < nc; ++i) Ops::add(b, lc[i] >> (U - 1), G, U);           // tuple[:-1]
+    for (int i = 0; i < Ops::slots(sg); ++i) { const int k = Ops::key_at(sg, i); if (k >= 0) Ops::add(a, k, G, U); }
+    for (int i = 0; i < Ops::slots(sc); ++i) { const int k = Ops::key_at(sc, i); if (k >= 0) Ops::add(b, k >> (U - 1), G, U); }   // tuple[:-1]
     for (uint32_t code = 0; code < nG; ++code)
         if (nic_codes >> code & 1) Ops::add(c, (int)code, G, U);
     Ops::isect(a, b, ab);
     Ops::isect(ab, c, abc);
     if (Ops::size(abc) == 0) return false;
 
-    // GPU list: replaced by the intersection only if that drops something (Matcher.py:363-366)
-    int16_t gl[1 << kMaxG];
-    int ngl;
-    if (Ops::size(abc) < Ops::size(sg)) ngl = Ops::list(abc, gl);
-    else { ngl = ng; for (int i = 0; i < ng; ++i) gl[i] = lg[i]; }
-
+    // GPU list: replaced by the intersection only if that drops something (Matcher.py:363-366);
     // GetNumaGroupIdx (Matcher.py:427-437): first maximiser of max-min per-NUMA group count
-    int best = -1, best_spread = -1;
-    for (int i = 0; i < ngl; ++i) {
-        int cnt[2] = {0, 0};
-        for (int g = 0; g < G; ++g) cnt[tup_digit((uint32_t)gl[i], G, U, g)]++;
-        int mx = cnt[0], mn = cnt[0];
-        for (int u = 1; u < U; ++u) { mx = cnt[u] > mx ? cnt[u] : mx; mn = cnt[u] < mn ? cnt[u] : mn; }
-        if (mx - mn > best_spread) { best_spread = mx - mn; best = gl[i]; }
+    const uint32_t gcode = (uint32_t)(Ops::size(abc) < Ops::size(sg) ? pick_gpu_tuple<Ops>(abc, G, U)
+                                                                        : pick_gpu_tuple<Ops>(sg, G, U));
+    int ccode = -1;                                                        // Matcher.py:441-444
+    for (int i = 0; i < Ops::slots(sc) && ccode < 0; ++i) {
+        const int k = Ops::key_at(sc, i);
+        if (k >= 0 && (uint32_t)(k >> (U - 1)) == gcode) ccode = k;
     }
-    const uint32_t gcode = (uint32_t)best;
-    int16_t ccode = -1;                                                    // Matcher.py:441-444
-    for (int i = 0; i < nc; ++i)
-        if ((uint32_t)(lc[i] >> (U - 1)) == gcode) { ccode = lc[i]; break; }
-    int8_t nic_idx[kMaxG];
-    if (ccode < 0 || !first_nic_choice(r, w, gcode, pci, nic_idx)) return false;   // Matcher.py:446-449
-
+    if (ccode < 0) return false;
     for (int g = 0; g < kMaxG; ++g) { out.gpu[g] = out.nic_numa[g] = out.nic_idx[g] = -1; }
     for (int g = 0; g <= kMaxG; ++g) out.cpu[g] = -1;
+    if (!first_nic_choice(r, w, gcode, pci, out.nic_idx)) return false;   // Matcher.py:446-449
     for (int g = 0; g < G; ++g) {
         out.gpu[g] = (int8_t)tup_digit(gcode, G, U, g);
         out.nic_numa[g] = out.gpu[g];
-        out.nic_idx[g] = nic_idx[g];
     }
     for (int g = 0; g <= G; ++g) out.cpu[g] = (int8_t)tup_digit((uint32_t)ccode, G + 1, U, g);
     out.valid = 1;
@@ -395,14 +439,6 @@ NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic
 NHD_HD bool map_winner(const nhdfit_req& r, const WinnerState& w, uint32_t nic_codes, nhdfit_mapping& out) {
     if (r.n_groups <= 3) return map_winner_t<SmallOps>(r, w, nic_codes, out);
     return map_winner_t<GenericOps>(r, w, nic_codes, out);
-}
-
-// NIC-feasible assignment bits of one (pod, node) pair out of the pod's table column.
-NHD_HD uint32_t nic_table_bits(const uint32_t* tab, uint32_t row_r, uint32_t col, bool pci, uint32_t sig0_numa,
-                               uint32_t sig1_numa, uint32_t sig0_pci, uint32_t sig1_pci) {
-    const uint32_t r0 = tab[(row_r + (pci ? sig0_pci : sig0_numa)) * kRowStride + col];
-    const uint32_t r1 = tab[(row_r + (pci ? sig1_pci : sig1_numa)) * kRowStride + col];
-    return (r0 >> 16) & r1 & 0xFFFFu;
 }
 
 }  // namespace nhdfit

@@ -48,7 +48,9 @@ class Engine:
         if self._dict_version == packer.dict_version:
             return
         caps, sig_off, pool_off, glimit, cc, ncls, nsig, npools, ncc = packer.dictionary_arrays()
-        self._chk(self.lib.nhdfit_set_dictionary(self.ctx, packer.max_cores_per_numa, packer.max_gpus_per_numa, _p(caps), ncls, _p(sig_off), nsig, _p(pool_off), _p(glimit),
+        gs = packer.group_set_array()
+        self._chk(self.lib.nhdfit_set_dictionary(self.ctx, packer.max_cores_per_numa, packer.max_gpus_per_numa,
+                                                 _p(gs), len(packer.group_sets), _p(caps), ncls, _p(sig_off), nsig, _p(pool_off), _p(glimit),
                                                  npools, _p(cc), ncc))
         self._dict_version = packer.dict_version
 

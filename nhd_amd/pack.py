@@ -39,7 +39,7 @@ P0 = np.dtype([("t0", "<u8", (2,))])
 P1 = np.dtype([("t1", "<u8", (2,))])
 P2 = np.dtype([("gpu_free", "<u4"), ("gpu_numa1", "<u4"), ("hp_free", "<i4"), ("flags", "<u4")])
 P3 = np.dtype([("groups", "<u8"), ("sig_numa", "<u2", (2,)), ("sig_pci", "<u2", (2,))])
-P4 = np.dtype([("busy_time", "<f8"), ("reserved", "<u8")])
+P4 = np.dtype([("busy_time", "<f8"), ("group_set", "<u4"), ("reserved", "<u4")])
 DETAIL = np.dtype([("nic_cnt", "u1", (2,)), ("sw_free", "u1", (MAX_SWITCHES,)),
                    ("nic_cls", "u1", (2, MAX_NICS_PER_NUMA)), ("nic_sw", "u1", (2, MAX_NICS_PER_NUMA)),
                    ("numa_nodes", "u1"), ("pad", "u1", (15,))])
@@ -93,6 +93,8 @@ class Packer:
         self._sig_index: Dict[tuple, int] = {(): 0}
         self.group_names: List[str] = []
         self._group_index: Dict[str, int] = {}
+        self.group_sets: List[int] = []                # distinct node-group bit sets, id = position
+        self._group_set_index: Dict[int, int] = {}
         self.max_gpus_per_numa = 0                     # table dimensions (fit_core.h Layout)
         self.max_cores_per_numa = 1
         self.dict_version = 0                          # bumped whenever caps / sigs / that maximum grow
@@ -134,6 +136,18 @@ class Packer:
                 self._group_index[nm] = k
             bits |= 1 << k
         return bits
+
+    def group_set_id(self, bits: int) -> int:
+        k = self._group_set_index.get(bits)
+        if k is None:
+            k = len(self.group_sets)
+            self.group_sets.append(bits)
+            self._group_set_index[bits] = k
+            self.dict_version += 1
+        return k
+
+    def group_set_array(self) -> np.ndarray:
+        return np.asarray(self.group_sets if self.group_sets else [0], dtype="<u8")
 
     def dictionary_arrays(self):
         """CSR form for nhdfit_set_dictionary."""
@@ -262,10 +276,12 @@ class Packer:
                 (NF_SMT if smt else 0) | (NF_HAS_GPU if len(gpus) > 0 else 0)
         hp = int(node.mem.free_hugepages_gb)
         t.p2[i] = (gfree, gn1, max(-2 ** 31, min(2 ** 31 - 1, hp)), flags)
-        t.p3[i]["groups"] = self.group_bits(node.groups)
+        gbits = self.group_bits(node.groups)
+        t.p3[i]["groups"] = gbits
         t.p3[i]["sig_numa"] = sig_numa
         t.p3[i]["sig_pci"] = sig_pci
         t.p4[i]["busy_time"] = float(node.busy_time)
+        t.p4[i]["group_set"] = self.group_set_id(gbits)
 
     def pack_nodes(self, nl: Dict[str, object]) -> NodeTable:
         t = empty_table(len(nl))
@@ -355,6 +371,9 @@ class Packer:
         for k in range(16):
             gb |= np.where((spec.group_bits >> k) & 1, lut[k], np.uint64(0)).astype(np.uint64)
         t.p3["groups"] = gb
+        uniq, inv = np.unique(gb, return_inverse=True)
+        ids = np.array([self.group_set_id(int(u)) for u in uniq], dtype=np.uint32)
+        t.p4["group_set"] = ids[inv]
         t.p4["busy_time"] = np.where(spec.busy, spec.clock_now - 5.0, spec.clock_now - 1000.0)
 
         K = spec.nics_per_numa

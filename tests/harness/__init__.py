@@ -35,6 +35,7 @@ def find(packer: pack.Packer, table: pack.NodeTable, reqs: np.ndarray, now: floa
     L = lib()
     caps, sig_off, pool_off, glimit, cc, ncls, nsig, npools, ncc = packer.dictionary_arrays()
     fgmax = packer.max_gpus_per_numa
+    gs = packer.group_set_array()
     n, P = table.n, len(reqs)
     chunks = (n + 63) // 64
     score = np.zeros(P, np.uint64)
@@ -43,7 +44,8 @@ def find(packer: pack.Packer, table: pack.NodeTable, reqs: np.ndarray, now: floa
     reqs = np.ascontiguousarray(reqs)
     L.hh_find(_p(table.p0), _p(table.p1), _p(table.p2), _p(table.p3), _p(table.p4), _p(table.detail),
               ctypes.c_uint32(n), ctypes.c_uint64(global_base), _p(reqs), ctypes.c_uint32(P), ctypes.c_double(now),
-              ctypes.c_uint32(packer.max_cores_per_numa), ctypes.c_uint32(fgmax), _p(caps), ctypes.c_uint32(ncls), _p(sig_off), ctypes.c_uint32(nsig), _p(pool_off), _p(glimit), _p(cc),
+              ctypes.c_uint32(packer.max_cores_per_numa), ctypes.c_uint32(fgmax),
+              _p(gs), ctypes.c_uint32(len(packer.group_sets)), _p(caps), ctypes.c_uint32(ncls), _p(sig_off), ctypes.c_uint32(nsig), _p(pool_off), _p(glimit), _p(cc),
               _p(cand) if cand is not None else None, _p(score), _p(bitmap) if want_bitmap else None,
               _p(maps) if want_map else None, ctypes.c_int(int(force_generic)))
     return score, bitmap, maps

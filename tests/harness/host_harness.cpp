@@ -8,65 +8,77 @@
 
 using namespace nhdfit;
 
-extern "C" {
+namespace {
+struct Dict {
+    uint32_t fcmax, fgmax;
+    const uint64_t* gs; uint32_t ngs;
+    const double* caps; uint32_t ncls;
+    SigDict sig;
+};
 
-int hh_table_words(uint32_t fcmax, uint32_t fgmax, uint32_t nsig) { return (int)(make_layout(fcmax, fgmax, nsig).rows * kRowStride); }
-
-// Build the table image of one tile (up to 64 pods).
-void hh_build_tile(const nhdfit_req* reqs, uint32_t npods, uint32_t fcmax, uint32_t fgmax, const double* caps, uint32_t ncls,
-                   const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit,
-                   const nhdfit_cc* cc, uint32_t* tab, PodHeader* hdr) {
-    const Layout L = make_layout(fcmax, fgmax, nsig);
-    std::memset(tab, 0, sizeof(uint32_t) * hh_table_words(fcmax, fgmax, nsig));
-    SigDict d{sig_off, pool_off, pool_glimit, cc, nsig};
-    for (uint32_t j = 0; j < npods; ++j) {
-        const nhdfit_req& r = reqs[j];
+// table image of one tile (up to 64 pods), same bytes the digest kernel produces
+void build_tile(const nhdfit_req* reqs, uint32_t npods, const Dict& d, const Layout& L, uint8_t* img, PodHeader* hdr) {
+    std::memset(img, 0, L.bytes);
+    std::vector<uint16_t> cover(d.ncls * (kMaxG + 1));
+    for (uint32_t j = 0; j < (uint32_t)kTile; ++j) {
+        nhdfit_req r;
+        if (j < npods) r = reqs[j]; else std::memset(&r, 0, sizeof r);
         hdr[j] = pod_header(r);
+        for (uint32_t k = 0; k < L.hp_rows; ++k)
+            if (hp_bit(hdr[j], L, k)) *reinterpret_cast<uint64_t*>(img + L.off_hp + 8 * k) |= 1ull << j;
+        for (uint32_t g = 0; g < L.ngs; ++g)
+            if (gf_bit(hdr[j], d.gs[g])) *reinterpret_cast<uint64_t*>(img + L.off_gf + 8 * g) |= 1ull << j;
         if (!(hdr[j].flags & kPodValid)) continue;
         PodSums s;
         pod_sums(r, s);
-        for (uint32_t e = 0; e < 2 * L.fc_dim; ++e) {
-            tab[e * kRowStride + j] = entry_w0(r, s, e >= L.fc_dim, e % L.fc_dim);
-            tab[(L.row_w1 + e) * kRowStride + j] = entry_w1(r, s, e >= L.fc_dim, e % L.fc_dim);
-        }
-        for (uint32_t f0 = 0; f0 < L.fg_dim; ++f0)
-            for (uint32_t f1 = 0; f1 < L.fg_dim; ++f1)
-                tab[(L.row_a + f0 * L.fg_dim + f1) * kRowStride + j] = entry_a(s, f0, f1);
-        std::vector<uint16_t> cover(ncls * (kMaxG + 1));
-        for (uint32_t c = 0; c < ncls; ++c) class_cover(r, caps[c], s.W, s.G, &cover[c * (kMaxG + 1)]);
-        for (uint32_t g = 0; g < nsig; ++g)
-            tab[(L.row_r + g) * kRowStride + j] = entry_r(sig_reach(d, g, cover.data(), s.W), s.W);
+        for (uint32_t c = 0; c < d.ncls; ++c) class_cover(r, d.caps[c], s.W, s.G, &cover[c * (kMaxG + 1)]);
+        for (uint32_t row = 0; row < L.rows16; ++row)
+            reinterpret_cast<uint16_t*>(img + row * kRowBytes)[slot16(j)] = (uint16_t)row16_entry(L, s, d.sig, cover.data(), row);
     }
 }
+}  // namespace
+
+extern "C" {
 
 // CPU twin of nhdfit_find (mode A), same outputs, chunk-major bitmap [ceil(n/64)][P].
 void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
              const nhdfit_plane4* p4, const nhdfit_detail* det, uint32_t n, uint64_t global_base,
-             const nhdfit_req* reqs, uint32_t P, double now, uint32_t fcmax, uint32_t fgmax, const double* caps, uint32_t ncls,
+             const nhdfit_req* reqs, uint32_t P, double now, uint32_t fcmax, uint32_t fgmax,
+             const uint64_t* gs, uint32_t ngs, const double* caps, uint32_t ncls,
              const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit,
              const nhdfit_cc* cc, const uint64_t* cand, uint64_t* score, uint64_t* bitmap, nhdfit_mapping* maps,
              int force_generic) {
     const uint32_t chunks = (n + 63) / 64;
-    const Layout L = make_layout(fcmax, fgmax, nsig);
-    std::vector<uint32_t> tab(hh_table_words(fcmax, fgmax, nsig));
+    int32_t hpmax = 0;
+    for (uint32_t p = 0; p < P; ++p) hpmax = reqs[p].hugepages_gb > hpmax ? reqs[p].hugepages_gb : hpmax;
+    const Dict d{fcmax, fgmax, gs, ngs, caps, ncls, SigDict{sig_off, pool_off, pool_glimit, cc, nsig}};
+    const Layout L = make_layout(fcmax, fgmax, nsig, ngs, (uint32_t)hpmax + 2);
+    std::vector<uint8_t> img(L.bytes);
     std::vector<PodHeader> hdr(kTile);
     for (uint32_t p = 0; p < P; ++p) score[p] = 0;
     for (uint32_t t0 = 0; t0 < P; t0 += kTile) {
         const uint32_t np = P - t0 < (uint32_t)kTile ? P - t0 : kTile;
-        hh_build_tile(reqs + t0, np, fcmax, fgmax, caps, ncls, sig_off, nsig, pool_off, pool_glimit, cc, tab.data(), hdr.data());
+        build_tile(reqs + t0, np, d, L, img.data(), hdr.data());
+        uint64_t m_filt = 0, m_need = 0;
+        for (uint32_t j = 0; j < np; ++j) {
+            if (hdr[j].flags & kPodFilter) m_filt |= 1ull << j;
+            if (hdr[j].flags & kPodNeedGpu) m_need |= 1ull << j;
+        }
         for (uint32_t c = 0; c < chunks; ++c) {
             uint64_t nogpu = 0;
             NodeLane lanes[64];
+            uint64_t fm[64];
             const uint32_t cnt = n - c * 64 < 64 ? n - c * 64 : 64;
             for (uint32_t l = 0; l < cnt; ++l) {
                 const uint32_t i = c * 64 + l;
                 lanes[l] = node_lane(p0[i], p1[i], p2[i], p3[i], p4[i], now, L);
+                fm[l] = node_pod_mask(lanes[l], img.data(), m_filt, m_need);
                 if (!(p2[i].flags & NHDFIT_NF_HAS_GPU)) nogpu |= 1ull << l;
             }
             for (uint32_t j = 0; j < np; ++j) {
                 uint64_t w = 0;
                 for (uint32_t l = 0; l < cnt; ++l)
-                    if (eval_pair(lanes[l], hdr[j], tab.data(), j)) w |= 1ull << l;
+                    if ((fm[l] >> j & 1) && eval_assignments(lanes[l], img.data(), j, hdr[j].flags & kPodPci)) w |= 1ull << l;
                 if (cand) w &= cand[(size_t)c * P + t0 + j];
                 if (bitmap) bitmap[(size_t)c * P + t0 + j] = w;
                 const uint64_t s = chunk_score(w, nogpu, hdr[j].flags & kPodNeedGpu, global_base + (uint64_t)c * 64);
@@ -80,7 +92,7 @@ void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plan
         if (!score[p]) continue;
         if (p % kTile == 0) {
             const uint32_t np = P - p < (uint32_t)kTile ? P - p : kTile;
-            hh_build_tile(reqs + p, np, fcmax, fgmax, caps, ncls, sig_off, nsig, pool_off, pool_glimit, cc, tab.data(), hdr.data());
+            build_tile(reqs + p, np, d, L, img.data(), hdr.data());
         }
         const uint64_t gi = NHDFIT_SCORE_INDEX(score[p]);
         if (gi < global_base || gi >= global_base + n) continue;
@@ -92,10 +104,9 @@ void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plan
         w.free_c[1] = popc64(p0[i].t0[1] & p1[i].t1[1]);
         w.free_g[0] = popc32(p2[i].gpu_free & ~p2[i].gpu_numa1);
         w.free_g[1] = popc32(p2[i].gpu_free & p2[i].gpu_numa1);
-        w.d = det[i];
+        w.d = det + i;
         w.caps = caps;
-        const uint32_t bits = nic_table_bits(tab.data(), L.row_r, p % kTile, reqs[p].map_type == NHDFIT_MAP_PCI,
-                                             p3[i].sig_numa[0], p3[i].sig_numa[1], p3[i].sig_pci[0], p3[i].sig_pci[1]);
+        const uint32_t bits = nic_assignment_bits(img.data(), L, p % kTile, reqs[p].map_type == NHDFIT_MAP_PCI, p3[i]);
         const uint32_t codes = nic_codes_from_table_bits(bits, (int)reqs[p].n_groups, w.U);
         if (force_generic) map_winner_t<GenericOps>(reqs[p], w, codes, maps[p]);
         else map_winner(reqs[p], w, codes, maps[p]);
@@ -124,21 +135,17 @@ int hh_set_isect3(const int16_t* a, int na, const int16_t* b, int nb, const int1
 
 // the register-resident model
 int hh_small_set_list(const int16_t* codes, int n, int len, int base, int16_t* out) {
-    SmallSet s;
-    ss_init(s, len, base);
-    for (int i = 0; i < n; ++i) ss_add(s, codes[i]);
+    SmallSet s = ss_make(len, base);
+    for (int i = 0; i < n; ++i) s = ss_add(s, codes[i]);
     return ss_list(s, out);
 }
 
 int hh_small_isect3(const int16_t* a, int na, const int16_t* b, int nb, const int16_t* c, int nc, int len, int base, int16_t* out) {
-    SmallSet sa, sb, sc, ab, abc;
-    ss_init(sa, len, base); ss_init(sb, len, base); ss_init(sc, len, base);
-    for (int i = 0; i < na; ++i) ss_add(sa, a[i]);
-    for (int i = 0; i < nb; ++i) ss_add(sb, b[i]);
-    for (int i = 0; i < nc; ++i) ss_add(sc, c[i]);
-    ss_intersect(sa, sb, ab);
-    ss_intersect(ab, sc, abc);
-    return ss_list(abc, out);
+    SmallSet sa = ss_make(len, base), sb = ss_make(len, base), sc = ss_make(len, base);
+    for (int i = 0; i < na; ++i) sa = ss_add(sa, a[i]);
+    for (int i = 0; i < nb; ++i) sb = ss_add(sb, b[i]);
+    for (int i = 0; i < nc; ++i) sc = ss_add(sc, c[i]);
+    return ss_list(ss_intersect(ss_intersect(sa, sb), sc), out);
 }
 
 uint64_t hh_tuple_hash(uint32_t code, int len, int base) { return py_tuple_hash(code, len, base); }

@@ -77,11 +77,14 @@ def test_spec_route_equals_object_route(cfg):
     pk_a, pk_b = pack.Packer(), pack.Packer()
     ta = pk_a.pack_nodes(spec.build_nodes())
     tb = pk_b.planes_from_spec(spec)
-    for f in ("p0", "p1", "p2", "p4"):
+    for f in ("p0", "p1", "p2"):
         assert np.array_equal(getattr(ta, f), getattr(tb, f)), f
+    assert np.array_equal(ta.p4["busy_time"], tb.p4["busy_time"])
     def names(pk, bits):
         return [frozenset(pk.group_names[k] for k in range(64) if int(b) >> k & 1) for b in bits]
     assert names(pk_a, ta.p3["groups"]) == names(pk_b, tb.p3["groups"])
+    assert names(pk_a, np.asarray(pk_a.group_sets, dtype=object)[ta.p4["group_set"]]) == \
+           names(pk_b, np.asarray(pk_b.group_sets, dtype=object)[tb.p4["group_set"]])
     assert pack.resolve_signatures(pk_a, ta) == pack.resolve_signatures(pk_b, tb)
     for f in ("nic_cnt", "sw_free", "nic_sw", "numa_nodes"):
         assert np.array_equal(ta.detail[f], tb.detail[f]), f
