@@ -74,9 +74,12 @@ def _tracked_class(base: type) -> type:
 
 
 class HipMatcher:
-    def __init__(self, device: int = 0, clock=time.monotonic):
+    def __init__(self, device: int = 0, clock=time.monotonic, engine_factory=None):
+        """`engine_factory(device)` exists for the test-suite only (it injects the host build of the
+        kernels' arithmetic so the host logic of this class can be exercised without a GPU); the
+        default is the HIP engine, which raises when the library or a gfx950 GPU is missing."""
         self.logger = logging.getLogger(__name__)
-        self.engine = Engine(device)          # raises when the HIP library / a gfx950 GPU is missing
+        self.engine = (engine_factory or Engine)(device)
         self.packer = pack.Packer()
         self.clock = clock
         self._attached: Optional[Dict[str, object]] = None

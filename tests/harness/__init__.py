@@ -49,3 +49,39 @@ def find(packer: pack.Packer, table: pack.NodeTable, reqs: np.ndarray, now: floa
               _p(cand) if cand is not None else None, _p(score), _p(bitmap) if want_bitmap else None,
               _p(maps) if want_map else None, ctypes.c_int(int(force_generic)))
     return score, bitmap, maps
+
+
+class HarnessEngine:
+    """Engine-compatible front-end of the host build (TEST ONLY): lets HipMatcher's host logic (packing,
+    dirty tracking, candidate masks, result decoding) and the sharding helpers run on CPU."""
+
+    def __init__(self, device=0):
+        self.device = device
+        self.n = 0
+        self.global_base = 0
+        self.packer = None
+        self.table = None
+
+    def close(self):
+        pass
+
+    def set_dictionary(self, packer):
+        self.packer = packer
+
+    def reset_nodes(self):
+        self.n = 0
+        self.table = None
+
+    def upload(self, table, global_base=0, first=0, capacity=None):
+        if first == 0 and (self.table is None or table.n >= self.n):
+            self.table = pack.NodeTable(list(table.names), *[np.array(getattr(table, f)) for f in
+                                                            ("p0", "p1", "p2", "p3", "p4", "detail")])
+        else:
+            for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
+                getattr(self.table, f)[first:first + table.n] = getattr(table, f)
+        self.n = self.table.n
+        self.global_base = global_base
+
+    def find(self, reqs, now, cand=None, want_bitmap=True, want_map=True):
+        return find(self.packer, self.table, reqs, now, cand=cand, global_base=self.global_base,
+                    want_bitmap=want_bitmap, want_map=want_map)

@@ -1,0 +1,66 @@
+"""HipMatcher's HOST logic (packing, persistent mirror + dirty tracking, candidate masks, decoding) on CPU,
+with the host build of the kernel arithmetic injected as the engine (tests/harness.HarnessEngine)."""
+import numpy as np
+import pytest
+
+from nhd_amd import refmodel, synth
+from nhd_amd.matcher import HipMatcher
+from oracle import nhd_oracle as O
+from tests import harness, util
+
+
+def norm(res):
+    return (None,) if res[0] is None else (res[0], {"gpu": tuple(res[1]["gpu"]), "cpu": tuple(res[1]["cpu"]),
+                                                    "nic": [tuple(x) for x in res[1]["nic"]]})
+
+
+def test_stateless_findnode_matches_oracle():
+    nl = util.random_cluster(99, 60)
+    m = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)
+    rng = np.random.default_rng(1)
+    for _ in range(40):
+        top = refmodel.make_topology(util.random_pod_spec(rng))
+        assert m.FindNode(nl, top) == norm(O.find_node(nl, top, util.CLOCK))
+    assert m.FindNode({}, top) == (None,)
+
+
+def test_attach_mode_dirty_tracking_and_candidate_subsets():
+    spec = synth.make_cluster(4, n_nodes=200)
+    nl = spec.build_nodes()
+    pods, groups = synth.make_pods(4, n_pods=30)
+    tops = [refmodel.make_topology(s) for s in pods]
+    m = HipMatcher(clock=lambda: spec.clock_now, engine_factory=harness.HarnessEngine)
+    m.attach(nl)
+    first = m.FindNodes(nl, tops)
+    assert [norm(r) for r in first] == [norm(O.find_node(nl, t, spec.clock_now)) for t in tops]
+    winners = list(dict.fromkeys(r[0] for r in first if r[0] is not None))
+    others = [k for k in nl if k not in winners]
+    a, b, c = (winners + others)[:3]
+    nl[a].maintenance = True                          # watched attribute -> tracked automatically
+    nl[b].busy_time = spec.clock_now
+    for g in nl[c].gpus:
+        g.used = True
+    for k in nl[c].cores:
+        k.used = True
+    m.mark_dirty(c)                                   # inner object write -> explicit mark
+    assert len(m._dirty) == 3
+    second = m.FindNodes(nl, tops)
+    assert not m._dirty
+    assert [norm(r) for r in second] == [norm(O.find_node(nl, t, spec.clock_now)) for t in tops]
+    sub = {k: v for i, (k, v) in enumerate(nl.items()) if i % 4 != 1}
+    for t in tops[:12]:
+        assert m.FindNode(sub, t) == norm(O.find_node(sub, t, spec.clock_now))
+    with pytest.raises(ValueError):
+        m.FindNode(dict(reversed(list(nl.items()))), tops[0])       # order differs from the attached dict
+
+
+def test_pod_groups_filter_equals_scheduler_side_filter():
+    spec = synth.make_cluster(5, n_nodes=300)
+    nl = spec.build_nodes()
+    pods, groups = synth.make_pods(5, n_pods=25)
+    tops = [refmodel.make_topology(s) for s in pods]
+    m = HipMatcher(clock=lambda: spec.clock_now, engine_factory=harness.HarnessEngine)
+    got = m.FindNodes(nl, tops, pod_groups=groups)
+    for top, grp, res in zip(tops, groups, got):
+        sub = O.initial_node_filter(nl, grp)
+        assert norm(res) == norm(O.find_node(sub, top, spec.clock_now))

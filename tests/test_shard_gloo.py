@@ -1,0 +1,82 @@
+"""The N > 1 path on CPU: two processes (gloo), each owning a contiguous node shard, max-reduction of the
+packed scores, merge of the owner's mappings - must equal the single-shard result exactly.
+Per-shard evaluation runs on the host build of the kernel arithmetic (tests/harness); on the GPU the same
+reduction is RCCL inside libnhdfit (`ncclAllReduce(uint64, max)`)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nhd_amd import pack, refmodel, shard, synth
+from tests import harness
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _problem(cfg, n, P):
+    spec = synth.make_cluster(cfg, n_nodes=n)
+    pods, groups = synth.make_pods(cfg, n_pods=P)
+    tops = [refmodel.make_topology(s) for s in pods]
+    return spec, tops, groups
+
+
+def _worker(rank, world, port, cfg, n, P, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec, tops, groups = _problem(cfg, n, P)
+    lo, hi = shard.shard_bounds(n, world, rank)
+    pk = pack.Packer()
+    table = pk.planes_from_spec(spec.shard(lo, hi))
+    reqs = pk.digest_many(tops, groups)
+    score, _, maps = harness.find(pk, table, reqs, spec.clock_now, global_base=lo, want_bitmap=False)
+    red = shard.allreduce_max_scores(score)
+    # a rank keeps a mapping only if it owns the global winner
+    owner = np.array([lo <= (0x7FFFFFFFFFFFFFFF - (int(s) & 0x7FFFFFFFFFFFFFFF)) < hi if s else False for s in red])
+    maps[~owner] = np.zeros((), pack.MAPPING)
+    merged = shard.merge_mappings(maps)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "score.npy"), red)
+        np.save(os.path.join(out_dir, "maps.npy"), merged.view(np.int8))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg,n,P", [(4, 1000, 96), (5, 777, 70)])
+def test_two_rank_sharding_equals_single_shard(tmp_path, cfg, n, P):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, cfg, n, P, str(tmp_path)), nprocs=2, join=True)
+    spec, tops, groups = _problem(cfg, n, P)
+    pk = pack.Packer()
+    table = pk.planes_from_spec(spec)
+    want_score, _, want_maps = harness.find(pk, table, pk.digest_many(tops, groups), spec.clock_now, want_bitmap=False)
+    assert np.array_equal(np.load(tmp_path / "score.npy"), want_score)
+    assert np.array_equal(np.load(tmp_path / "maps.npy"), want_maps.view(np.int8))
+    assert np.count_nonzero(want_score) > 0
+
+
+def test_order_preserving_score_encoding():
+    rng = np.random.default_rng(0)
+    s = rng.integers(0, 2 ** 64, size=1000, dtype=np.uint64)
+    s[:3] = [0, 2 ** 63, 2 ** 64 - 1]
+    i = shard.to_ordered_int64(s)
+    assert np.array_equal(shard.from_ordered_int64(i), s)
+    assert np.array_equal(np.argsort(i, kind="stable"), np.argsort(s, kind="stable"))
+
+
+def test_shard_bounds_cover_and_align():
+    for n in (1, 63, 64, 65, 1000, 65536):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard.shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and (b % 64 == 0 or b == n)
