@@ -1,6 +1,7 @@
 // nhdfit.hip - gfx950 kernels and the C-ABI of libnhdfit.so (include/nhdfit.h).
 //
-// Three kernels per step, all on the context's own HIP stream:
+// Three kernels per step, software-pipelined over three HIP streams with triple-buffered request-side
+// state (digest of step i+1 and winner mapping of step i-1 overlap the fit kernel of step i):
 //   k_digest     per 64-pod tile: request records -> table image (CPU/GPU/NIC feasibility of every
 //                NUMA assignment as a function of a node's free-resource counts / NIC signature)
 //   k_fit_score  the P x N pass.  Block = (pod tile, node range).  The tile's table image is staged
@@ -19,6 +20,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -376,12 +378,17 @@ struct DevBuf {
 };
 
 constexpr int kEventRing = 256;
+constexpr int kBufs = 3;          // pipeline depth: digest(i+1) | fit(i) | map(i-1)
 
 }  // namespace
 
 struct nhdfit_ctx {
     int dev = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // fit_score (+ all-reduce): the stage that owns the chip
+    hipStream_t s_digest = nullptr;      // request digest of the next step
+    hipStream_t s_map = nullptr;         // winner mapping of the previous step
+    hipEvent_t ev_digest[kBufs] = {}, ev_fit[kBufs] = {}, ev_map[kBufs] = {};
+    uint64_t step = 0;                   // steps enqueued since the last stage_requests
     std::string err;
     hipDeviceProp_t prop;
 
@@ -403,12 +410,13 @@ struct nhdfit_ctx {
     // requests / results
     DevBuf<nhdfit_req> reqs; uint32_t P = 0;
     std::vector<uint32_t> perm;          // device (class-sorted) position -> caller's pod index
-    DevBuf<PodHeader> hdr; DevBuf<uint8_t> tabs;
-    DevBuf<unsigned long long> score; DevBuf<uint64_t> bitmap; DevBuf<uint64_t> cand; DevBuf<nhdfit_mapping> maps;
+    DevBuf<PodHeader> hdr[kBufs]; DevBuf<uint8_t> tabs[kBufs];
+    DevBuf<unsigned long long> score[kBufs]; DevBuf<nhdfit_mapping> maps[kBufs];
+    DevBuf<uint64_t> bitmap; DevBuf<uint64_t> cand;
     bool use_cand = false, want_bitmap = true, want_map = true;
 
     // timing
-    hipEvent_t ev[kEventRing][4];
+    hipEvent_t ev[kEventRing][5];        // digest start / digest end / fit start / fit end / map end
     int ev_pending = 0;
     nhdfit_stats stats;
 
@@ -438,10 +446,10 @@ int fail(nhdfit_ctx* c, int code, const char* fmt, ...) {
 int drain_events(nhdfit_ctx* c) {
     for (int k = 0; k < c->ev_pending; ++k) {
         float d = 0, f = 0, s = 0;
-        HIPCHK(c, hipEventSynchronize(c->ev[k][3]));
+        HIPCHK(c, hipEventSynchronize(c->ev[k][4]));
         HIPCHK(c, hipEventElapsedTime(&d, c->ev[k][0], c->ev[k][1]));
-        HIPCHK(c, hipEventElapsedTime(&f, c->ev[k][1], c->ev[k][2]));
-        HIPCHK(c, hipEventElapsedTime(&s, c->ev[k][0], c->ev[k][3]));
+        HIPCHK(c, hipEventElapsedTime(&f, c->ev[k][2], c->ev[k][3]));
+        HIPCHK(c, hipEventElapsedTime(&s, c->ev[k][0], c->ev[k][4]));
         c->stats.launches++;
         c->stats.fit_ms_total += f;
         c->stats.fit_ms_last = f;
@@ -449,6 +457,13 @@ int drain_events(nhdfit_ctx* c) {
         c->stats.step_ms_last = s;
     }
     c->ev_pending = 0;
+    return NHDFIT_OK;
+}
+
+int sync_all(nhdfit_ctx* c) {
+    HIPCHK(c, hipStreamSynchronize(c->s_digest));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->s_map));
     return NHDFIT_OK;
 }
 
@@ -489,11 +504,21 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
         delete c;
         return rc;
     }
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->s_digest, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->s_map, hipStreamNonBlocking)) != hipSuccess) {
         int rc = fail(nullptr, NHDFIT_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
         delete c;
         return rc;
     }
+    for (int b = 0; b < kBufs; ++b)
+        if ((e = hipEventCreateWithFlags(&c->ev_digest[b], hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&c->ev_fit[b], hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&c->ev_map[b], hipEventDisableTiming)) != hipSuccess) {
+            int rc = fail(nullptr, NHDFIT_E_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+            delete c;
+            return rc;
+        }
     for (auto& q : c->ev)
         for (auto& x : q)
             if ((e = hipEventCreate(&x)) != hipSuccess) {
@@ -508,16 +533,23 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
 void nhdfit_destroy(nhdfit_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->dev);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream && c->s_digest && c->s_map) (void)sync_all(c);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
-    c->reqs.release(); c->hdr.release(); c->tabs.release(); c->score.release(); c->bitmap.release();
-    c->cand.release(); c->maps.release();
+    c->reqs.release(); c->bitmap.release(); c->cand.release(); c->group_sets.release();
+    for (int b = 0; b < kBufs; ++b) {
+        c->hdr[b].release(); c->tabs[b].release(); c->score[b].release(); c->maps[b].release();
+        if (c->ev_digest[b]) (void)hipEventDestroy(c->ev_digest[b]);
+        if (c->ev_fit[b]) (void)hipEventDestroy(c->ev_fit[b]);
+        if (c->ev_map[b]) (void)hipEventDestroy(c->ev_map[b]);
+    }
     for (auto& q : c->ev)
         for (auto& x : q)
             if (x) (void)hipEventDestroy(x);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->s_digest) (void)hipStreamDestroy(c->s_digest);
+    if (c->s_map) (void)hipStreamDestroy(c->s_map);
     delete c;
 }
 
@@ -541,10 +573,10 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     if (n_group_sets && !group_sets) return fail(c, NHDFIT_E_INVAL, "NULL group set table");
     const Layout L = make_layout(max_cores_per_numa, max_gpus_per_numa, nsig, n_group_sets ? n_group_sets : 1, kMaxHpRows);
     HIPCHK(c, hipSetDevice(c->dev));
-    if (L.bytes + 8192 > 160 * 1024)
+    if (L.bytes + 4096 > 160 * 1024)
         return fail(c, NHDFIT_E_LIMIT, "%u NIC signatures / %u node-group sets need %u bytes of LDS per tile (160 KiB per CU)",
                     nsig, n_group_sets, L.bytes);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc_ = sync_all(c); if (rc_) return rc_; }
     HIPCHK(c, c->group_sets.reserve(n_group_sets ? n_group_sets : 1));
     if (n_group_sets) HIPCHK(c, hipMemcpy(c->group_sets.p, group_sets, n_group_sets * sizeof(uint64_t), hipMemcpyHostToDevice));
     else { const uint64_t zero = 0; HIPCHK(c, hipMemcpy(c->group_sets.p, &zero, sizeof zero, hipMemcpyHostToDevice)); }
@@ -564,7 +596,7 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     c->max_cores = max_cores_per_numa;
     c->max_gpus = max_gpus_per_numa;
     c->P = 0;                                       // staged tables (if any) were built for the old dictionary
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_score<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_score<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_score<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
     return NHDFIT_OK;
 }
@@ -572,7 +604,7 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
 int nhdfit_reserve_nodes(nhdfit_ctx* c, uint32_t capacity, uint64_t global_base) {
     if (!c) return NHDFIT_E_INVAL;
     HIPCHK(c, hipSetDevice(c->dev));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc_ = sync_all(c); if (rc_) return rc_; }
     if (capacity > c->capacity) {
         c->n = 0;                                   // growing drops the contents: the caller re-uploads
         HIPCHK(c, c->p0.reserve(capacity)); HIPCHK(c, c->p1.reserve(capacity)); HIPCHK(c, c->p2.reserve(capacity));
@@ -597,7 +629,7 @@ int nhdfit_upload_nodes(nhdfit_ctx* c, uint32_t first, uint32_t count, const nhd
     if (!p0 || !p1 || !p2 || !p3 || !p4 || !det) return fail(c, NHDFIT_E_INVAL, "NULL plane");
     if ((uint64_t)first + count > c->capacity) return fail(c, NHDFIT_E_INVAL, "upload [%u,%u) exceeds capacity %u", first, first + count, c->capacity);
     HIPCHK(c, hipSetDevice(c->dev));
-    HIPCHK(c, hipStreamSynchronize(c->stream));     // a step in flight must not see a half-written record
+    { int rc_ = sync_all(c); if (rc_) return rc_; }     // a step in flight must not see a half-written record
     HIPCHK(c, hipMemcpy(c->p0.p + first, p0, count * sizeof *p0, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->p1.p + first, p1, count * sizeof *p1, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->p2.p + first, p2, count * sizeof *p2, hipMemcpyHostToDevice));
@@ -613,7 +645,9 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     if (!reqs || !P) return fail(c, NHDFIT_E_INVAL, "no requests");
     if (!c->nsig) return fail(c, NHDFIT_E_STATE, "set the dictionary first");
     HIPCHK(c, hipSetDevice(c->dev));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc_ = sync_all(c); if (rc_) return rc_; }
+    { int rc_ = drain_events(c); if (rc_) return rc_; }
+    c->step = 0;
     const uint32_t tiles = (P + kTile - 1) / kTile;
     const uint32_t chunks = (c->capacity + 63) / 64;
     int32_t hp_max = 0;
@@ -626,10 +660,12 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     c->layout = make_layout(c->max_cores, c->max_gpus, c->nsig, c->ngs, (uint32_t)hp_max + 2);
     c->lds_bytes = c->layout.bytes;
     HIPCHK(c, c->reqs.reserve(P));
-    HIPCHK(c, c->hdr.reserve((size_t)tiles * kTile));
-    HIPCHK(c, c->tabs.reserve((size_t)tiles * c->layout.bytes));
-    HIPCHK(c, c->score.reserve(P));
-    HIPCHK(c, c->maps.reserve(P));
+    for (int b = 0; b < kBufs; ++b) {
+        HIPCHK(c, c->hdr[b].reserve((size_t)tiles * kTile));
+        HIPCHK(c, c->tabs[b].reserve((size_t)tiles * c->layout.bytes));
+        HIPCHK(c, c->score[b].reserve(P));
+        HIPCHK(c, c->maps[b].reserve(P));
+    }
     HIPCHK(c, c->bitmap.reserve((size_t)chunks * P));
     // Pods are staged sorted by request class so that 64-pod tiles are homogeneous (fast sweep of
     // k_fit_score) and the lanes of k_map have similar group counts; results are un-permuted in fetch.
@@ -673,50 +709,65 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     const uint32_t P = c->P, tiles = (P + kTile - 1) / kTile;
     const uint32_t chunks = (c->n + 63) / 64;
 
-    HIPCHK(c, hipEventRecord(ev[0], c->stream));
-    HIPCHK(c, hipMemsetAsync(c->score.p, 0, (size_t)P * sizeof(unsigned long long), c->stream));
-    DictView dv{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}};
-    hipLaunchKernelGGL(k_digest, dim3(tiles, kDigestSlices), dim3(kDigestThreads), 0, c->stream,
-                       c->reqs.p, P, dv, c->layout, c->tabs.p, c->hdr.p);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(ev[1], c->stream));
+    const int b = (int)(c->step % kBufs);
 
-    // geometry: one 1024-thread block per CU-ful of LDS; shrink blocks for small problems so that
+    // stage 1 (s_digest): request digest into buffer set b - once the mapping of step i-3 has let go of it
+    if (c->step >= (uint64_t)kBufs) HIPCHK(c, hipStreamWaitEvent(c->s_digest, c->ev_map[b], 0));
+    HIPCHK(c, hipEventRecord(ev[0], c->s_digest));
+    HIPCHK(c, hipMemsetAsync(c->score[b].p, 0, (size_t)P * sizeof(unsigned long long), c->s_digest));
+    DictView dv{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}};
+    hipLaunchKernelGGL(k_digest, dim3(tiles, kDigestSlices), dim3(kDigestThreads), 0, c->s_digest,
+                       c->reqs.p, P, dv, c->layout, c->tabs[b].p, c->hdr[b].p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(ev[1], c->s_digest));
+    HIPCHK(c, hipEventRecord(c->ev_digest[b], c->s_digest));
+
+    // stage 2 (stream): fit + score + select over every (pod, node) pair, then the all-reduce
+    // geometry: one 1024-thread block per half CU of LDS; shrink blocks for small problems so that
     // the grid still covers the chip
     FitArgs a;
     a.p0 = c->p0.p; a.p1 = c->p1.p; a.p2 = c->p2.p; a.p3 = c->p3.p; a.p4 = c->p4.p;
     a.n = c->n; a.chunks = chunks; a.global_base = c->global_base; a.now = now;
-    a.tabs = c->tabs.p; a.layout = c->layout; a.hdr = c->hdr.p; a.P = P;
+    a.tabs = c->tabs[b].p; a.layout = c->layout; a.hdr = c->hdr[b].p; a.P = P;
     a.cand = c->use_cand ? c->cand.p : nullptr;
     a.bitmap = c->want_bitmap ? c->bitmap.p : nullptr;
-    a.score = c->score.p;
+    a.score = c->score[b].p;
     const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
-    const bool big = (uint64_t)tiles * ((chunks + 63) / 64) >= cus;     // enough 16-wave blocks of 4 chunks per wave
-    const uint32_t waves = big ? 16 : 4;
+    // 512-thread blocks (8 waves, 2 co-resident blocks per CU at 84 VGPRs: one block's LDS fill overlaps the
+    // other's sweep; measured 6 % faster than 1024-thread blocks), 256-thread blocks for small problems
+    const bool big = (uint64_t)tiles * ((chunks + 31) / 32) >= cus;
+    const uint32_t waves = big ? 8 : 4;
     uint32_t cpb = waves;                                                // chunks per block: >= 1 per wave
-    while ((uint64_t)tiles * ((chunks + cpb * 2 - 1) / (cpb * 2)) >= 4ull * cus && cpb < waves * 8) cpb *= 2;
+    while ((uint64_t)tiles * ((chunks + cpb * 2 - 1) / (cpb * 2)) >= 8ull * cus && cpb < waves * 8) cpb *= 2;
     a.chunks_per_block = cpb;
     a.nranges = (chunks + cpb - 1) / cpb;
     const uint32_t grid = tiles * a.nranges;
-    if (big) hipLaunchKernelGGL(k_fit_score<1024>, dim3(grid), dim3(1024), c->lds_bytes, c->stream, a);
-    else     hipLaunchKernelGGL(k_fit_score<256>, dim3(grid), dim3(256), c->lds_bytes, c->stream, a);
-    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_digest[b], 0));
     HIPCHK(c, hipEventRecord(ev[2], c->stream));
-
+    if (big) hipLaunchKernelGGL((k_fit_score<512>), dim3(grid), dim3(512), c->lds_bytes, c->stream, a);
+    else     hipLaunchKernelGGL((k_fit_score<256>), dim3(grid), dim3(256), c->lds_bytes, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(ev[3], c->stream));
     if (c->comm) {
-        ncclResult_t r = g_rccl.AllReduce(c->score.p, c->score.p, P, ncclUint64, ncclMax, c->comm, c->stream);
+        ncclResult_t r = g_rccl.AllReduce(c->score[b].p, c->score[b].p, P, ncclUint64, ncclMax, c->comm, c->stream);
         if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
     }
+    HIPCHK(c, hipEventRecord(c->ev_fit[b], c->stream));
+
+    // stage 3 (s_map): the winners' resource mappings
+    HIPCHK(c, hipStreamWaitEvent(c->s_map, c->ev_fit[b], 0));
     if (c->want_map) {
-        MapArgs m{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->det.p, c->tabs.p, c->layout, c->n,
-                  c->global_base, c->reqs.p, P, c->score.p, c->caps.p, c->maps.p};
+        MapArgs m{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->det.p, c->tabs[b].p, c->layout, c->n,
+                  c->global_base, c->reqs.p, P, c->score[b].p, c->caps.p, c->maps[b].p};
         const dim3 mg((P + kMapWaves - 1) / kMapWaves), mb(64 * kMapWaves);
-        if (c->n_big_pods < P) hipLaunchKernelGGL(k_map<false>, mg, mb, 0, c->stream, m);
-        if (c->n_big_pods) hipLaunchKernelGGL(k_map<true>, mg, mb, 0, c->stream, m);
+        if (c->n_big_pods < P) hipLaunchKernelGGL(k_map<false>, mg, mb, 0, c->s_map, m);
+        if (c->n_big_pods) hipLaunchKernelGGL(k_map<true>, mg, mb, 0, c->s_map, m);
         HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipEventRecord(ev[3], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_map[b], c->s_map));
+    HIPCHK(c, hipEventRecord(ev[4], c->s_map));
     c->ev_pending++;
+    c->step++;
 
     c->stats.evals_last = (uint64_t)P * c->n;
     // algorithmic bytes of the fit_score launch: every tile streams the five node
@@ -731,19 +782,20 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
 int nhdfit_sync(nhdfit_ctx* c) {
     if (!c) return NHDFIT_E_INVAL;
     HIPCHK(c, hipSetDevice(c->dev));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc_ = sync_all(c); if (rc_) return rc_; }
     return drain_events(c);
 }
 
 int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out) {
     if (!c) return NHDFIT_E_INVAL;
-    if (!c->P) return fail(c, NHDFIT_E_STATE, "nothing staged");
+    if (!c->P || !c->step) return fail(c, NHDFIT_E_STATE, "nothing staged / no step enqueued");
     int rc = nhdfit_sync(c);
     if (rc) return rc;
     const uint32_t P = c->P;
+    const int b = (int)((c->step - 1) % kBufs);             // results of the most recent step
     if (score_out) {
         std::vector<uint64_t> tmp(P);
-        HIPCHK(c, hipMemcpy(tmp.data(), c->score.p, (size_t)P * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(tmp.data(), c->score[b].p, (size_t)P * 8, hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < P; ++i) score_out[c->perm[i]] = tmp[i];
     }
     if (bitmap_out) {
@@ -757,7 +809,7 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
     if (map_out) {
         if (!c->want_map) return fail(c, NHDFIT_E_STATE, "mapping output is disabled");
         std::vector<nhdfit_mapping> tmp(P);
-        HIPCHK(c, hipMemcpy(tmp.data(), c->maps.p, (size_t)P * sizeof(nhdfit_mapping), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(tmp.data(), c->maps[b].p, (size_t)P * sizeof(nhdfit_mapping), hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < P; ++i) map_out[c->perm[i]] = tmp[i];
     }
     return NHDFIT_OK;
@@ -809,7 +861,7 @@ int nhdfit_comm_init(nhdfit_ctx* c, int nranks, int rank, const void* id128) {
 int nhdfit_comm_destroy(nhdfit_ctx* c) {
     if (!c) return NHDFIT_E_INVAL;
     if (c->comm) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        { int rc_ = sync_all(c); if (rc_) return rc_; }
         g_rccl.CommDestroy(c->comm);
         c->comm = nullptr;
     }

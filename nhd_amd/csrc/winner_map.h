@@ -178,6 +178,12 @@ NHD_HD SmallSet ss_make(int len, int base) {
     s.k0 = s.k1 = s.k2 = s.k3 = 0;
     return s;
 }
+// next occupied slot >= from, or -1 (sets are walked in slot order = CPython iteration order)
+NHD_HD int ss_next(SmallSet s, int from) {
+    if (from > s.mask) return -1;
+    const uint32_t m = s.used >> from;
+    return m ? from + __builtin_ctz(m) : -1;
+}
 NHD_HD int ss_key(SmallSet s, int slot) {
     const uint64_t w = slot < 16 ? (slot < 8 ? s.k0 : s.k1) : (slot < 24 ? s.k2 : s.k3);
     return (int)((w >> ((slot & 7) * 8)) & 0xFF);
@@ -214,11 +220,10 @@ NHD_HD SmallSet ss_add(SmallSet s, int key) {
     if (s.fill * 5 >= s.mask * 3) {                   // 8 -> 32 slots (set_table_resize(used*4)); never further
         const SmallSet o = s;
         s.used = 0; s.mask = 31; s.k0 = s.k1 = s.k2 = s.k3 = 0;
-        for (int i = 0; i <= o.mask; ++i)
-            if (o.used >> i & 1) {
-                const int k = ss_key(o, i);
-                s = ss_put(s, -ss_probe(s, k, py_tuple_hash((uint32_t)k, s.len, s.base), false) - 1, k);
-            }
+        for (int i = ss_next(o, 0); i >= 0; i = ss_next(o, i + 1)) {
+            const int k = ss_key(o, i);
+            s = ss_put(s, -ss_probe(s, k, py_tuple_hash((uint32_t)k, s.len, s.base), false) - 1, k);
+        }
     }
     return s;
 }
@@ -231,11 +236,10 @@ NHD_HD SmallSet ss_intersect(SmallSet a, SmallSet b) {
     const bool swap = b.fill > a.fill;
     const SmallSet probe = swap ? b : a;
     const SmallSet iter = swap ? a : b;
-    for (int i = 0; i <= iter.mask; ++i)
-        if (iter.used >> i & 1) {
-            const int k = ss_key(iter, i);
-            if (ss_has(probe, k)) out = ss_add(out, k);
-        }
+    for (int i = ss_next(iter, 0); i >= 0; i = ss_next(iter, i + 1)) {
+        const int k = ss_key(iter, i);
+        if (ss_has(probe, k)) out = ss_add(out, k);
+    }
     return out;
 }
 NHD_HD int ss_list(SmallSet s, int16_t* out) {
@@ -253,8 +257,8 @@ struct GenericOps {
     NHD_HD static void isect(const Set& a, const Set& b, Set& o) { ps_intersect(a, b, o); }
     NHD_HD static int list(const Set& s, int16_t* o) { return ps_list(s, o); }
     NHD_HD static int size(const Set& s) { return s.fill; }
-    NHD_HD static int slots(const Set& s) { return s.mask + 1; }
-    NHD_HD static int key_at(const Set& s, int slot) { return s.key[slot]; }              // -1 = empty slot
+    NHD_HD static int next(const Set& s, int from) { for (int i = from; i <= s.mask; ++i) if (s.key[i] >= 0) return i; return -1; }
+    NHD_HD static int key_at(const Set& s, int slot) { return s.key[slot]; }
 };
 struct SmallOps {
     typedef SmallSet Set;
@@ -263,8 +267,8 @@ struct SmallOps {
     NHD_HD static void isect(const Set& a, const Set& b, Set& o) { o = ss_intersect(a, b); }
     NHD_HD static int list(const Set& s, int16_t* o) { return ss_list(s, o); }
     NHD_HD static int size(const Set& s) { return s.fill; }
-    NHD_HD static int slots(const Set& s) { return s.mask + 1; }
-    NHD_HD static int key_at(const Set& s, int slot) { return (s.used >> slot & 1) ? ss_key(s, slot) : -1; }
+    NHD_HD static int next(const Set& s, int from) { return ss_next(s, from); }
+    NHD_HD static int key_at(const Set& s, int slot) { return ss_key(s, slot); }
 };
 
 // ---- the winner's resource state -------------------------------------------------------------------
@@ -362,9 +366,8 @@ NHD_HD uint32_t nic_codes_from_table_bits(uint32_t bits, int G, int U) {
 template <class Ops>
 NHD_HD int pick_gpu_tuple(const typename Ops::Set& gset, int G, int U) {
     int best = -1, best_spread = -1;
-    for (int i = 0; i < Ops::slots(gset); ++i) {
+    for (int i = Ops::next(gset, 0); i >= 0; i = Ops::next(gset, i + 1)) {
         const int k = Ops::key_at(gset, i);
-        if (k < 0) continue;
         int ones = 0;
         for (int g = 0; g < G; ++g) ones += tup_digit((uint32_t)k, G, U, g);
         const int zeros = G - ones;
@@ -405,8 +408,8 @@ NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic
     // intersection of the three prefix sets (Matcher.py:342-346): set(list) re-inserts in list order
     Set a, b, c, ab, abc;
     Ops::init(a, G, U); Ops::init(b, G, U); Ops::init(c, G, U);
-    for (int i = 0; i < Ops::slots(sg); ++i) { const int k = Ops::key_at(sg, i); if (k >= 0) Ops::add(a, k, G, U); }
-    for (int i = 0; i < Ops::slots(sc); ++i) { const int k = Ops::key_at(sc, i); if (k >= 0) Ops::add(b, k >> (U - 1), G, U); }   // tuple[:-1]
+    for (int i = Ops::next(sg, 0); i >= 0; i = Ops::next(sg, i + 1)) Ops::add(a, Ops::key_at(sg, i), G, U);
+    for (int i = Ops::next(sc, 0); i >= 0; i = Ops::next(sc, i + 1)) Ops::add(b, Ops::key_at(sc, i) >> (U - 1), G, U);   // tuple[:-1]
     for (uint32_t code = 0; code < nG; ++code)
         if (nic_codes >> code & 1) Ops::add(c, (int)code, G, U);
     Ops::isect(a, b, ab);
@@ -418,9 +421,9 @@ NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic
     const uint32_t gcode = (uint32_t)(Ops::size(abc) < Ops::size(sg) ? pick_gpu_tuple<Ops>(abc, G, U)
                                                                         : pick_gpu_tuple<Ops>(sg, G, U));
     int ccode = -1;                                                        // Matcher.py:441-444
-    for (int i = 0; i < Ops::slots(sc) && ccode < 0; ++i) {
+    for (int i = Ops::next(sc, 0); i >= 0 && ccode < 0; i = Ops::next(sc, i + 1)) {
         const int k = Ops::key_at(sc, i);
-        if (k >= 0 && (uint32_t)(k >> (U - 1)) == gcode) ccode = k;
+        if ((uint32_t)(k >> (U - 1)) == gcode) ccode = k;
     }
     if (ccode < 0) return false;
     for (int g = 0; g < kMaxG; ++g) { out.gpu[g] = out.nic_numa[g] = out.nic_idx[g] = -1; }
