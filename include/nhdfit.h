@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NHDFIT_ABI_VERSION        1
+#define NHDFIT_ABI_VERSION        2
 #define NHDFIT_MAX_GROUPS         4      /* proc groups per pod (G)                               */
 #define NHDFIT_MAX_NUMA           2      /* NUMA nodes (= sockets, nhd/Node.py:336) per node (U)  */
 #define NHDFIT_MAX_CORES_PER_NUMA 64     /* physical cores per socket (one uint64 mask)           */
@@ -88,8 +88,10 @@ typedef struct {
     uint8_t nic_cls[NHDFIT_MAX_NUMA][NHDFIT_MAX_NICS_PER_NUMA];    /* capacity class of NIC (numa, idx)                   */
     uint8_t nic_sw[NHDFIT_MAX_NUMA][NHDFIT_MAX_NICS_PER_NUMA];     /* local switch id of NIC (numa, idx), nhd/Node.py:275 */
     uint8_t numa_nodes;                                            /* Node.numa_nodes (1 or 2)                            */
-    uint8_t pad[15];
-} nhdfit_detail;                                                   /* 96 bytes */
+    uint8_t n_gpus;                                                /* len(Node.gpus)                                      */
+    uint8_t pad[14];
+    uint8_t gpu_sw[NHDFIT_MAX_GPUS];                               /* local switch id of Node.gpus[g] (commit step, nhd/Node.py:648-655) */
+} nhdfit_detail;                                                   /* 128 bytes */
 
 /* ---- NIC signature dictionary (cluster-wide, interned by the host packer) ----------------- */
 typedef struct { uint8_t cls; uint8_t cnt; } nhdfit_cc;           /* cnt NICs (capped at NHDFIT_MAX_GROUPS) of capacity class cls */
@@ -106,10 +108,15 @@ typedef struct {
     uint16_t cpu_nosmt[NHDFIT_MAX_GROUPS];   /* ... on a non-SMT node                                              */
     uint16_t misc_smt;                       /* pod-level misc cores on an SMT node (always halved, Matcher.py:198)*/
     uint16_t misc_nosmt;
-    uint32_t reserved;
+    /* raw counts for the commit step (Node.SetPhysicalIdsFromMapping, nhd/Node.py:663-841) */
+    uint8_t  n_proc[NHDFIT_MAX_GROUPS];      /* len(proc_cores) + sum(len(gpu.cpu_cores)): one GetFreeCpuBatch with proc_smt */
     double   rx[NHDFIT_MAX_GROUPS];          /* GetTotalNICsRequested, CfgTopology.py:219-232 (Gb/s, Python float) */
     double   tx[NHDFIT_MAX_GROUPS];
-    uint64_t reserved2;
+    uint8_t  n_help[NHDFIT_MAX_GROUPS];      /* len(group.misc_cores): second batch with helper_smt                  */
+    uint8_t  n_misc;                         /* len(top.misc_cores): last batch with the real misc_cores_smt flag     */
+    uint8_t  smt_bits;                       /* bit g: group g proc_smt enabled; bit 4+g: helper_smt enabled           */
+    uint8_t  misc_smt_enabled;               /* top.misc_cores_smt == SMT_ENABLED (Node.py:799)                        */
+    uint8_t  nic_use;                        /* bit g: group g has RX/TX cores -> its NIC is claimed (Node.py:744-764, 644) */
 } nhdfit_req;                                /* 128 bytes */
 
 /* ---- resource mapping of one placement = the dict FindNode returns (Matcher.py:452) ------- */
@@ -177,6 +184,15 @@ int nhdfit_set_node_count(nhdfit_ctx* ctx, uint32_t n_nodes);
  *   map_out    optional, P mappings (valid only for winners owned by this shard) */
 int nhdfit_find(nhdfit_ctx* ctx, const nhdfit_req* reqs, uint32_t P, double now,
                 const uint64_t* cand, uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out);
+
+/* Mode B: like nhdfit_find, but pod k is matched against the cluster as left by the placements of pods
+ * 0..k-1 of the same batch - the scheduler loop commits every winner (SetBusy, SetPhysicalIdsFromMapping,
+ * ClaimPodNICResources; nhd/NHDScheduler.py:289-304) before it matches the next pending pod (:425-437).
+ * The device mirror itself is not modified: the caller applies the placements to its Node objects and
+ * re-uploads those nodes.  node_out[p] = global node index or -1; status_out[p] != 0 where the reference's
+ * own commit step would have raised (parity undefined from there on).  Single shard only. */
+int nhdfit_find_sequential(nhdfit_ctx* ctx, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand,
+                           int64_t* node_out, nhdfit_mapping* map_out, int32_t* status_out);
 
 /* Benchmark / pipelined form: requests are staged once, then each step only enqueues kernels
  * (request digest -> fit_score -> [all-reduce] -> winner mapping) on the context's stream. */

@@ -26,7 +26,7 @@
 #include <string>
 #include <vector>
 
-#include "winner_map.h"
+#include "seq_core.h"
 
 using namespace nhdfit;
 
@@ -330,6 +330,67 @@ __global__ __launch_bounds__(64 * kMapWaves) void k_map(MapArgs a) {
     }
 }
 
+// ---- mode B: sequential resolver ------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_nogpu(const nhdfit_plane2* __restrict__ p2, uint32_t n, uint64_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    const uint64_t w = __ballot(i < n && !(p2[i].flags & NHDFIT_NF_HAS_GPU));
+    if (threadIdx.x == 0) out[blockIdx.x] = w;
+}
+
+struct ResolveArgs {
+    SeqStatic s;
+    const nhdfit_req* reqs;          // class-sorted order (as staged)
+    const PodHeader* hdr;
+    const unsigned long long* score;
+    const nhdfit_mapping* maps;
+    const uint64_t* bitmap;          // [chunks][P] snapshot feasibility
+    const uint64_t* nogpu;           // [chunks]
+    const uint32_t* order;           // caller's pod i -> staged position
+    uint32_t P, chunks;
+    int32_t* slot_of;                // [n], -1
+    OverlayNode* overlay;            // [P]
+    SeqResult* out;                  // [P], caller's order
+};
+
+// first candidate >= from in pod `pos`'s bitmap row: 64 chunk words per step (one per lane), ballot, ctz
+struct WaveScan {
+    const uint64_t* bitmap;
+    const uint64_t* nogpu;
+    uint32_t chunks, P, pos, lane;
+    __device__ int64_t next(bool pref, int64_t from) const {
+        const uint32_t c0 = (uint32_t)(from >> 6);
+        for (uint32_t base = c0; base < chunks; base += 64) {
+            const uint32_t c = base + lane;
+            uint64_t w = c < chunks ? bitmap[(size_t)c * P + pos] : 0;
+            if (pref && c < chunks) w &= nogpu[c];
+            if (c == c0) w &= ~0ull << (from & 63);
+            const uint64_t any = __ballot(w != 0);
+            if (any) {
+                const int l = __builtin_ctzll(any);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, l);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
+                const uint64_t word = ((uint64_t)hi << 32) | lo;
+                return (int64_t)(base + l) * 64 + __builtin_ctzll(word);
+            }
+        }
+        return -1;
+    }
+};
+
+// One wavefront walks the batch in the caller's order (the chain of decisions is inherently sequential);
+// all lanes carry the same scalar state, the bitmap row scans use the whole wave.
+__global__ __launch_bounds__(64) void k_resolve(ResolveArgs a) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t n_overlay = 0;
+    for (uint32_t i = 0; i < a.P; ++i) {
+        const uint32_t pos = a.order[i];
+        WaveScan scan{a.bitmap, a.nogpu, a.chunks, a.P, pos, lane};
+        SeqResult res;
+        resolve_pod(a.s, a.reqs[pos], a.hdr[pos], a.score[pos], a.maps[pos], scan, a.slot_of, a.overlay, &n_overlay, res);
+        if (lane == 0) a.out[i] = res;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -413,6 +474,8 @@ struct nhdfit_ctx {
     DevBuf<PodHeader> hdr[kBufs]; DevBuf<uint8_t> tabs[kBufs];
     DevBuf<unsigned long long> score[kBufs]; DevBuf<nhdfit_mapping> maps[kBufs];
     DevBuf<uint64_t> bitmap; DevBuf<uint64_t> cand;
+    // mode B
+    DevBuf<uint64_t> nogpu; DevBuf<int32_t> slot_of; DevBuf<OverlayNode> overlay; DevBuf<SeqResult> seq_out; DevBuf<uint32_t> order;
     bool use_cand = false, want_bitmap = true, want_map = true;
 
     // timing
@@ -538,6 +601,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
     c->reqs.release(); c->bitmap.release(); c->cand.release(); c->group_sets.release();
+    c->nogpu.release(); c->slot_of.release(); c->overlay.release(); c->seq_out.release(); c->order.release();
     for (int b = 0; b < kBufs; ++b) {
         c->hdr[b].release(); c->tabs[b].release(); c->score[b].release(); c->maps[b].release();
         if (c->ev_digest[b]) (void)hipEventDestroy(c->ev_digest[b]);
@@ -822,6 +886,47 @@ int nhdfit_find(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, c
     if (cand && (rc = stage_cand(c, cand))) return rc;
     if ((rc = nhdfit_enqueue_step(c, now))) return rc;
     return nhdfit_fetch(c, score_out, bitmap_out, map_out);
+}
+
+int nhdfit_find_sequential(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand,
+                           int64_t* node_out, nhdfit_mapping* map_out, int32_t* status_out) {
+    if (!c) return NHDFIT_E_INVAL;
+    if (c->comm) return fail(c, NHDFIT_E_STATE, "sequential (mode B) batches are single-shard: detach the communicator");
+    if (!node_out) return fail(c, NHDFIT_E_INVAL, "node_out is NULL");
+    const bool wb = c->want_bitmap, wm = c->want_map;
+    c->want_bitmap = c->want_map = true;
+    int rc = nhdfit_stage_requests(c, reqs, P);
+    if (!rc && cand) rc = stage_cand(c, cand);
+    if (!rc) rc = nhdfit_enqueue_step(c, now);
+    c->want_bitmap = wb; c->want_map = wm;
+    if (rc) return rc;
+    const int b = (int)((c->step - 1) % kBufs);
+    const uint32_t chunks = (c->n + 63) / 64;
+    HIPCHK(c, c->nogpu.reserve(chunks));
+    HIPCHK(c, c->slot_of.reserve(c->n));
+    HIPCHK(c, c->overlay.reserve(P));
+    HIPCHK(c, c->seq_out.reserve(P));
+    HIPCHK(c, c->order.reserve(P));
+    std::vector<uint32_t> order(P);                       // caller's pod -> staged (class-sorted) position
+    for (uint32_t i = 0; i < P; ++i) order[c->perm[i]] = i;
+    HIPCHK(c, hipMemcpyAsync(c->order.p, order.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, c->s_map));
+    HIPCHK(c, hipMemsetAsync(c->slot_of.p, 0xFF, (size_t)c->n * sizeof(int32_t), c->s_map));
+    hipLaunchKernelGGL(k_nogpu, dim3(chunks), dim3(64), 0, c->s_map, c->p2.p, c->n, c->nogpu.p);
+    ResolveArgs ra{SeqStatic{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->p4.p, c->det.p, c->caps.p, c->n, c->global_base, now},
+                   c->reqs.p, c->hdr[b].p, c->score[b].p, c->maps[b].p, c->bitmap.p, c->nogpu.p, c->order.p, P, chunks,
+                   c->slot_of.p, c->overlay.p, c->seq_out.p};
+    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, c->s_map, ra);       // after k_map on the same stream
+    HIPCHK(c, hipGetLastError());
+    std::vector<SeqResult> out(P);
+    HIPCHK(c, hipMemcpyAsync(out.data(), c->seq_out.p, P * sizeof(SeqResult), hipMemcpyDeviceToHost, c->s_map));
+    rc = nhdfit_sync(c);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < P; ++i) {
+        node_out[i] = out[i].node;
+        if (map_out) map_out[i] = out[i].map;
+        if (status_out) status_out[i] = out[i].status;
+    }
+    return NHDFIT_OK;
 }
 
 int nhdfit_set_outputs(nhdfit_ctx* c, int want_bitmap, int want_map) {

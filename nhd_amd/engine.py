@@ -84,6 +84,19 @@ class Engine:
         self.P = P
         return score, bitmap, maps
 
+    def find_sequential(self, reqs: np.ndarray, now: float, cand: Optional[np.ndarray] = None):
+        """Mode B (sequential commit inside the batch): (node index or -1, mappings, status) per pod."""
+        reqs = np.ascontiguousarray(reqs)
+        P = len(reqs)
+        node = np.zeros(P, np.int64)
+        maps = np.zeros(P, pack.MAPPING)
+        status = np.zeros(P, np.int32)
+        if cand is not None:
+            cand = np.ascontiguousarray(cand, dtype=np.uint64)
+        self._chk(self.lib.nhdfit_find_sequential(self.ctx, _p(reqs), P, float(now), _p(cand), _p(node), _p(maps), _p(status)))
+        self.P = P
+        return node, maps, status
+
     # ---- pipelined --------------------------------------------------------------------
     def stage(self, reqs: np.ndarray):
         reqs = np.ascontiguousarray(reqs)

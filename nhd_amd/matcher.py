@@ -165,11 +165,22 @@ class HipMatcher:
     def FindNode(self, nl: Dict[str, object], top) -> Tuple:
         return self.FindNodes(nl, [top])[0]
 
+    def ScheduleBatch(self, nl: Dict[str, object], tops: Sequence[object],
+                      pod_groups: Optional[Sequence[Sequence[str]]] = None, now: Optional[float] = None) -> List[Tuple]:
+        """Mode B: the result list the scheduler loop would produce by calling FindNode and committing each
+        winner before the next pod (nhd/NHDScheduler.py:289-304, 425-437) - decided in one device pass.
+        The node objects are NOT modified; apply each placement with the node's own SetBusy /
+        SetPhysicalIdsFromMapping / ClaimPodNICResources, exactly as AttemptScheduling does."""
+        return self._run(nl, tops, pod_groups, now, sequential=True)
+
     def FindNodes(self, nl: Dict[str, object], tops: Sequence[object],
                   pod_groups: Optional[Sequence[Sequence[str]]] = None, now: Optional[float] = None) -> List[Tuple]:
         """Mode-A batch: every pod of `tops` against the same snapshot of `nl`.  With `pod_groups`
         the kernel applies InitialNodeFilter itself (nl = all nodes); without, `nl` is taken as already
         filtered, exactly like the argument of Matcher.FindNode."""
+        return self._run(nl, tops, pod_groups, now, sequential=False)
+
+    def _run(self, nl, tops, pod_groups, now, sequential):
         if not tops:
             return []
         for top in tops:
@@ -185,14 +196,20 @@ class HipMatcher:
         else:
             self._full_upload(nl)
         reqs = self.packer.digest_many(tops, pod_groups)
-        score, _, maps = self.engine.find(reqs, now, cand=cand, want_bitmap=False, want_map=True)
+        if sequential:
+            node, maps, status = self.engine.find_sequential(reqs, now, cand=cand)
+            if status.any():
+                self.logger.warning("mode B: the reference's commit step would have failed for pod %d", int(np.flatnonzero(status)[0]))
+            index = node - self.engine.global_base
+        else:
+            score, _, maps = self.engine.find(reqs, now, cand=cand, want_bitmap=False, want_map=True)
+            index = np.array([winner_index(int(s)) - self.engine.global_base if s else -1 for s in score], dtype=np.int64)
         out: List[Tuple] = []
         for p in range(len(tops)):
-            s = int(score[p])
-            if s == 0:
+            if index[p] < 0:
                 out.append((None,))
                 continue
-            name = self._names[winner_index(s) - self.engine.global_base]
+            name = self._names[int(index[p])]
             G = int(reqs[p]["n_groups"])
             m = maps[p]
             if not m["valid"]:

@@ -42,16 +42,17 @@ P3 = np.dtype([("groups", "<u8"), ("sig_numa", "<u2", (2,)), ("sig_pci", "<u2", 
 P4 = np.dtype([("busy_time", "<f8"), ("group_set", "<u4"), ("reserved", "<u4")])
 DETAIL = np.dtype([("nic_cnt", "u1", (2,)), ("sw_free", "u1", (MAX_SWITCHES,)),
                    ("nic_cls", "u1", (2, MAX_NICS_PER_NUMA)), ("nic_sw", "u1", (2, MAX_NICS_PER_NUMA)),
-                   ("numa_nodes", "u1"), ("pad", "u1", (15,))])
+                   ("numa_nodes", "u1"), ("n_gpus", "u1"), ("pad", "u1", (14,)), ("gpu_sw", "u1", (MAX_GPUS,))])
 REQ = np.dtype([("n_groups", "<u4"), ("map_type", "<u4"), ("hugepages_gb", "<i4"), ("flags", "<u4"),
                 ("groups", "<u8"), ("gpus", "<u2", (4,)), ("cpu_smt", "<u2", (4,)), ("cpu_nosmt", "<u2", (4,)),
-                ("misc_smt", "<u2"), ("misc_nosmt", "<u2"), ("reserved", "<u4"),
-                ("rx", "<f8", (4,)), ("tx", "<f8", (4,)), ("reserved2", "<u8")])
+                ("misc_smt", "<u2"), ("misc_nosmt", "<u2"), ("n_proc", "u1", (4,)),
+                ("rx", "<f8", (4,)), ("tx", "<f8", (4,)), ("n_help", "u1", (4,)), ("n_misc", "u1"), ("smt_bits", "u1"),
+                ("misc_smt_enabled", "u1"), ("nic_use", "u1")])
 MAPPING = np.dtype([("gpu", "i1", (4,)), ("cpu", "i1", (5,)), ("nic_numa", "i1", (4,)), ("nic_idx", "i1", (4,)),
                     ("valid", "i1"), ("pad", "i1", (2,))])
 CC = np.dtype([("cls", "u1"), ("cnt", "u1")])
 assert (P0.itemsize, P1.itemsize, P2.itemsize, P3.itemsize, P4.itemsize) == (16,) * 5
-assert DETAIL.itemsize == 96 and REQ.itemsize == 128 and MAPPING.itemsize == 20
+assert DETAIL.itemsize == 128 and REQ.itemsize == 128 and MAPPING.itemsize == 20
 
 ALL_ONES = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -87,8 +88,8 @@ def empty_table(n: int) -> NodeTable:
 
 class Packer:
     def __init__(self):
-        self.caps: List[float] = []
-        self._cap_index: Dict[float, int] = {}
+        self.caps: List[float] = [0.0]                 # class 0 = a claimed NIC (capacity 0, nhd/Node.py:292)
+        self._cap_index: Dict[float, int] = {0.0: 0}
         self.sigs: List[tuple] = [()]                  # sig 0 = no NIC pool at all
         self._sig_index: Dict[tuple, int] = {(): 0}
         self.group_names: List[str] = []
@@ -212,11 +213,14 @@ class Packer:
         per_numa = [0, 0]
         det = t.detail[i]
         det["sw_free"] = 0
+        det["gpu_sw"] = 0
+        det["n_gpus"] = len(gpus)
         for g, gpu in enumerate(gpus):
             if gpu.numa_node >= U or gpu.numa_node < 0:
                 raise UnsupportedNode(f"node {node.name}: GPU on NUMA node {gpu.numa_node}")
             per_numa[gpu.numa_node] += 1
             s = local_sw(gpu.pciesw)
+            det["gpu_sw"][g] = s
             if gpu.numa_node == 1:
                 gn1 |= 1 << g
             if not gpu.used:
@@ -314,6 +318,14 @@ class Packer:
             n_proc = len(pg.proc_cores) + sum(len(g.cpu_cores) for g in pg.group_gpus)
             n_help = len(pg.misc_cores)
             r["gpus"][i] = len(pg.group_gpus)
+            if n_proc > 255 or n_help > 255:
+                raise UnsupportedNode("a proc group asks for more than 255 cores")
+            r["n_proc"][i] = n_proc
+            r["n_help"][i] = n_help
+            if pg.proc_smt.value:
+                r["smt_bits"] |= 1 << i
+            if pg.helper_smt.value:
+                r["smt_bits"] |= 1 << (4 + i)
             r["cpu_nosmt"][i] = n_proc + n_help
             r["cpu_smt"][i] = (half(n_proc) if pg.proc_smt.value else n_proc) + \
                               (half(n_help) if pg.helper_smt.value else n_help)
@@ -324,10 +336,14 @@ class Packer:
                     rx += c.nic_speed
                 elif d == 2:
                     tx += c.nic_speed
+                if d in (1, 2):
+                    r["nic_use"] |= 1 << i
             r["rx"][i] = float(rx)
             r["tx"][i] = float(tx)
         n_misc = len(top.misc_cores)
         r["misc_nosmt"] = n_misc
+        r["n_misc"] = min(n_misc, 255)
+        r["misc_smt_enabled"] = 1 if getattr(top.misc_cores_smt, "value", top.misc_cores_smt) == 1 else 0
         r["misc_smt"] = half(n_misc) if top.misc_cores_smt else n_misc      # Enum truthiness, quirk Q1
         if pod_groups is not None:
             r["flags"] = RF_INITIAL_FILTER
@@ -383,6 +399,8 @@ class Packer:
         det = t.detail
         det["numa_nodes"] = 2
         det["nic_cnt"] = K
+        det["n_gpus"] = np.where(has_gpu, 4, 0)
+        det["gpu_sw"][:, :4] = np.where(has_gpu[:, None], np.arange(4)[None, :], 0)
         # local switch ids follow first appearance: GPUs (switch g -> id g) then NICs
         sw_of_nic = np.zeros((2, K), np.int64)
         for numa in range(2):

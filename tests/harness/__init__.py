@@ -51,6 +51,22 @@ def find(packer: pack.Packer, table: pack.NodeTable, reqs: np.ndarray, now: floa
     return score, bitmap, maps
 
 
+def resolve(packer, table, reqs, now, global_base=0, cand=None):
+    """Mode B on the host build: snapshot pass + sequential resolver.  Returns (node index or -1, maps, status)."""
+    L = lib()
+    score, bitmap, maps = find(packer, table, reqs, now, global_base=global_base, cand=cand)
+    caps = np.asarray(packer.caps, dtype="<f8")
+    P = len(reqs)
+    node = np.zeros(P, np.int64)
+    out_maps = np.zeros(P, pack.MAPPING)
+    status = np.zeros(P, np.int32)
+    reqs = np.ascontiguousarray(reqs)
+    L.hh_resolve(_p(table.p0), _p(table.p1), _p(table.p2), _p(table.p3), _p(table.p4), _p(table.detail),
+                 ctypes.c_uint32(table.n), ctypes.c_uint64(global_base), _p(reqs), ctypes.c_uint32(P), ctypes.c_double(now),
+                 _p(caps), _p(score), _p(bitmap), _p(maps), _p(node), _p(out_maps), _p(status))
+    return node, out_maps, status
+
+
 class HarnessEngine:
     """Engine-compatible front-end of the host build (TEST ONLY): lets HipMatcher's host logic (packing,
     dirty tracking, candidate masks, result decoding) and the sharding helpers run on CPU."""
@@ -85,3 +101,6 @@ class HarnessEngine:
     def find(self, reqs, now, cand=None, want_bitmap=True, want_map=True):
         return find(self.packer, self.table, reqs, now, cand=cand, global_base=self.global_base,
                     want_bitmap=want_bitmap, want_map=want_map)
+
+    def find_sequential(self, reqs, now, cand=None):
+        return resolve(self.packer, self.table, reqs, now, global_base=self.global_base, cand=cand)

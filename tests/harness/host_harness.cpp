@@ -4,7 +4,7 @@
 // the oracle without a GPU.  It is NOT part of libnhdfit.so and nothing in nhd_amd/ loads it.
 #include <cstring>
 #include <vector>
-#include "../../nhd_amd/csrc/winner_map.h"
+#include "../../nhd_amd/csrc/seq_core.h"
 
 using namespace nhdfit;
 
@@ -89,11 +89,11 @@ void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plan
     if (!maps) return;
     for (uint32_t p = 0; p < P; ++p) {
         std::memset(&maps[p], 0, sizeof(nhdfit_mapping));
-        if (!score[p]) continue;
         if (p % kTile == 0) {
             const uint32_t np = P - p < (uint32_t)kTile ? P - p : kTile;
             build_tile(reqs + p, np, d, L, img.data(), hdr.data());
         }
+        if (!score[p]) continue;
         const uint64_t gi = NHDFIT_SCORE_INDEX(score[p]);
         if (gi < global_base || gi >= global_base + n) continue;
         const uint32_t i = (uint32_t)(gi - global_base);
@@ -110,6 +110,43 @@ void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plan
         const uint32_t codes = nic_codes_from_table_bits(bits, (int)reqs[p].n_groups, w.U);
         if (force_generic) map_winner_t<GenericOps>(reqs[p], w, codes, maps[p]);
         else map_winner(reqs[p], w, codes, maps[p]);
+    }
+}
+
+// CPU twin of the sequential (mode B) resolver: inputs are the snapshot outputs of hh_find.
+void hh_resolve(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
+                const nhdfit_plane4* p4, const nhdfit_detail* det, uint32_t n, uint64_t global_base,
+                const nhdfit_req* reqs, uint32_t P, double now, const double* caps,
+                const uint64_t* score_a, const uint64_t* bitmap_a, const nhdfit_mapping* maps_a,
+                int64_t* node_out, nhdfit_mapping* map_out, int32_t* status_out) {
+    const uint32_t chunks = (n + 63) / 64;
+    const SeqStatic s{p0, p1, p2, p3, p4, det, caps, n, global_base, now};
+    std::vector<int32_t> slot_of(n, -1);
+    std::vector<OverlayNode> overlay(P);
+    uint32_t n_overlay = 0;
+    struct HostScan {
+        const uint64_t* bm; const nhdfit_plane2* p2; uint32_t chunks, P, pod, n;
+        int64_t next(bool pref, int64_t from) {
+            for (uint32_t c = (uint32_t)(from / 64); c < chunks; ++c) {
+                uint64_t w = bm[(size_t)c * P + pod];
+                if (c == (uint32_t)(from / 64)) w &= ~0ull << (from % 64);
+                while (w) {
+                    const int b = __builtin_ctzll(w);
+                    const uint32_t nd = c * 64 + b;
+                    if (!pref || !(p2[nd].flags & NHDFIT_NF_HAS_GPU)) return nd;
+                    w &= w - 1;
+                }
+            }
+            return -1;
+        }
+    };
+    for (uint32_t p = 0; p < P; ++p) {
+        HostScan scan{bitmap_a, p2, chunks, P, p, n};
+        SeqResult res;
+        resolve_pod(s, reqs[p], pod_header(reqs[p]), score_a[p], maps_a[p], scan, slot_of.data(), overlay.data(), &n_overlay, res);
+        node_out[p] = res.node;
+        map_out[p] = res.map;
+        status_out[p] = res.status;
     }
 }
 

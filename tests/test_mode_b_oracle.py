@@ -1,0 +1,45 @@
+"""Pins the oracle's commit step / sequential batch (mode B) to the unmodified reference: the reference's own
+SetBusy + SetPhysicalIdsFromMapping + ClaimPodNICResources applied between FindNode calls."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from nhd_amd import refmodel, synth
+from oracle import nhd_oracle as O
+
+
+def node_state(n):
+    return ([c.used for c in n.cores], [g.used for g in n.gpus], [(k.pods_used, tuple(k.speed_used)) for k in n.nics],
+            n.mem.free_hugepages_gb, n.busy_time)
+
+
+@pytest.mark.parametrize("cfg", [2, 3, 4, 5])
+def test_sequential_commit_matches_reference(ref, cfg):
+    from oracle import ref_loader
+    clock = ref_loader.VirtualClock(1.0e6).install()
+    spec = synth.make_cluster(cfg, n_nodes=30)
+    pods, groups = synth.make_pods(cfg, n_pods=80)
+    for p in pods:
+        p["misc_smt"] = True                  # stay out of the reference's buggy unwind path
+    ref_nodes = spec.build_nodes(ref)
+    ora_nodes = spec.build_nodes()            # stand-ins
+    tops_r = [refmodel.make_topology(p, ref) for p in pods]
+    tops_o = [refmodel.make_topology(p) for p in pods]
+    want = []
+    for top, grp in zip(tops_r, groups):
+        sub = O.initial_node_filter(ref_nodes, grp)
+        res = ref_loader.find_node(sub, top)
+        want.append(res)
+        if res[0] is not None:
+            n = ref_nodes[res[0]]
+            n.SetBusy()
+            with contextlib.redirect_stdout(io.StringIO()):
+                nic_list = n.SetPhysicalIdsFromMapping(res[1], top)
+            n.ClaimPodNICResources(list({x[0] for x in nic_list}))
+    got = O.schedule_sequence(ora_nodes, tops_o, groups, clock.t)
+    assert got == want
+    assert sum(r[0] is not None for r in want) >= 10
+    for k in ref_nodes:
+        assert node_state(ref_nodes[k]) == node_state(ora_nodes[k]), k
