@@ -287,6 +287,7 @@ struct MapArgs {
     const unsigned long long* score;
     const double* caps;
     nhdfit_mapping* out;
+    uint64_t* memo;             // choose_tuples memo (kMemoSlots words, cleared every step)
 };
 
 // One pod per wavefront: the mapping is a long, branchy, strictly sequential computation (the
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(64 * kMapWaves) void k_map(MapArgs a) {
                                                       rq.map_type == NHDFIT_MAP_PCI, a.p3[i]);
             const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
             if (GENERIC) map_winner_t<GenericOps>(rq, w, codes, m);
-            else map_winner_t<SmallOps>(rq, w, codes, m);
+            else map_winner_t<SmallOps>(rq, w, codes, m, a.memo);
         }
     }
 }
@@ -352,25 +353,32 @@ struct ResolveArgs {
     SeqResult* out;                  // [P], caller's order
 };
 
-// first candidate >= from in pod `pos`'s bitmap row: 64 chunk words per step (one per lane), ballot, ctz
+// First still-feasible candidate >= from in pod `pos`'s snapshot bitmap row.  Each lane takes one 64-node
+// chunk word and tests ITS candidates (lanes run in parallel: 4 096 nodes per step); the earliest lane with
+// a hit wins.  Candidates on nodes no earlier pod touched pass immediately; dirty ones are re-evaluated.
 struct WaveScan {
     const uint64_t* bitmap;
     const uint64_t* nogpu;
     uint32_t chunks, P, pos, lane;
-    __device__ int64_t next(bool pref, int64_t from) const {
+    __device__ int64_t find_first(bool pref, int64_t from, const StillFeasible& ok) const {
         const uint32_t c0 = (uint32_t)(from >> 6);
         for (uint32_t base = c0; base < chunks; base += 64) {
             const uint32_t c = base + lane;
             uint64_t w = c < chunks ? bitmap[(size_t)c * P + pos] : 0;
             if (pref && c < chunks) w &= nogpu[c];
             if (c == c0) w &= ~0ull << (from & 63);
-            const uint64_t any = __ballot(w != 0);
+            int64_t mine = -1;
+            while (w) {
+                const int64_t nd = (int64_t)c * 64 + __builtin_ctzll(w);
+                if (ok(nd)) { mine = nd; break; }
+                w &= w - 1;
+            }
+            const uint64_t any = __ballot(mine >= 0);
             if (any) {
                 const int l = __builtin_ctzll(any);
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, l);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
-                const uint64_t word = ((uint64_t)hi << 32) | lo;
-                return (int64_t)(base + l) * 64 + __builtin_ctzll(word);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, l);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)mine >> 32), l);
+                return (int64_t)(((uint64_t)hi << 32) | lo);
             }
         }
         return -1;
@@ -379,6 +387,7 @@ struct WaveScan {
 
 // One wavefront walks the batch in the caller's order (the chain of decisions is inherently sequential);
 // all lanes carry the same scalar state, the bitmap row scans use the whole wave.
+template <bool SMALL_ONLY>
 __global__ __launch_bounds__(64) void k_resolve(ResolveArgs a) {
     const uint32_t lane = threadIdx.x;
     uint32_t n_overlay = 0;
@@ -386,7 +395,8 @@ __global__ __launch_bounds__(64) void k_resolve(ResolveArgs a) {
         const uint32_t pos = a.order[i];
         WaveScan scan{a.bitmap, a.nogpu, a.chunks, a.P, pos, lane};
         SeqResult res;
-        resolve_pod(a.s, a.reqs[pos], a.hdr[pos], a.score[pos], a.maps[pos], scan, a.slot_of, a.overlay, &n_overlay, res);
+        resolve_pod<WaveScan, SMALL_ONLY>(a.s, a.reqs[pos], a.hdr[pos], a.score[pos], a.maps[pos], scan, a.slot_of,
+                                          a.overlay, &n_overlay, res);
         if (lane == 0) a.out[i] = res;
     }
 }
@@ -473,7 +483,7 @@ struct nhdfit_ctx {
     std::vector<uint32_t> perm;          // device (class-sorted) position -> caller's pod index
     DevBuf<PodHeader> hdr[kBufs]; DevBuf<uint8_t> tabs[kBufs];
     DevBuf<unsigned long long> score[kBufs]; DevBuf<nhdfit_mapping> maps[kBufs];
-    DevBuf<uint64_t> bitmap; DevBuf<uint64_t> cand;
+    DevBuf<uint64_t> bitmap; DevBuf<uint64_t> cand; DevBuf<uint64_t> memo;
     // mode B
     DevBuf<uint64_t> nogpu; DevBuf<int32_t> slot_of; DevBuf<OverlayNode> overlay; DevBuf<SeqResult> seq_out; DevBuf<uint32_t> order;
     bool use_cand = false, want_bitmap = true, want_map = true;
@@ -601,7 +611,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
     c->reqs.release(); c->bitmap.release(); c->cand.release(); c->group_sets.release();
-    c->nogpu.release(); c->slot_of.release(); c->overlay.release(); c->seq_out.release(); c->order.release();
+    c->memo.release(); c->nogpu.release(); c->slot_of.release(); c->overlay.release(); c->seq_out.release(); c->order.release();
     for (int b = 0; b < kBufs; ++b) {
         c->hdr[b].release(); c->tabs[b].release(); c->score[b].release(); c->maps[b].release();
         if (c->ev_digest[b]) (void)hipEventDestroy(c->ev_digest[b]);
@@ -821,8 +831,10 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     // stage 3 (s_map): the winners' resource mappings
     HIPCHK(c, hipStreamWaitEvent(c->s_map, c->ev_fit[b], 0));
     if (c->want_map) {
+        HIPCHK(c, c->memo.reserve(kMemoSlots));
+        HIPCHK(c, hipMemsetAsync(c->memo.p, 0, kMemoSlots * sizeof(uint64_t), c->s_map));   // every step pays its own misses
         MapArgs m{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->det.p, c->tabs[b].p, c->layout, c->n,
-                  c->global_base, c->reqs.p, P, c->score[b].p, c->caps.p, c->maps[b].p};
+                  c->global_base, c->reqs.p, P, c->score[b].p, c->caps.p, c->maps[b].p, c->memo.p};
         const dim3 mg((P + kMapWaves - 1) / kMapWaves), mb(64 * kMapWaves);
         if (c->n_big_pods < P) hipLaunchKernelGGL(k_map<false>, mg, mb, 0, c->s_map, m);
         if (c->n_big_pods) hipLaunchKernelGGL(k_map<true>, mg, mb, 0, c->s_map, m);
@@ -915,7 +927,8 @@ int nhdfit_find_sequential(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, do
     ResolveArgs ra{SeqStatic{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->p4.p, c->det.p, c->caps.p, c->n, c->global_base, now},
                    c->reqs.p, c->hdr[b].p, c->score[b].p, c->maps[b].p, c->bitmap.p, c->nogpu.p, c->order.p, P, chunks,
                    c->slot_of.p, c->overlay.p, c->seq_out.p};
-    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, c->s_map, ra);       // after k_map on the same stream
+    if (c->n_big_pods) hipLaunchKernelGGL(k_resolve<false>, dim3(1), dim3(64), 0, c->s_map, ra);   // after k_map, same stream
+    else hipLaunchKernelGGL(k_resolve<true>, dim3(1), dim3(64), 0, c->s_map, ra);
     HIPCHK(c, hipGetLastError());
     std::vector<SeqResult> out(P);
     HIPCHK(c, hipMemcpyAsync(out.data(), c->seq_out.p, P * sizeof(SeqResult), hipMemcpyDeviceToHost, c->s_map));

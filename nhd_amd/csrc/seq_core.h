@@ -36,6 +36,7 @@ struct OverlayNode {             // a node some earlier pod of the batch was com
     uint32_t gpu_free;
     int32_t  hp_free;
     uint32_t busy;
+    uint32_t unclaimed;          // NICs whose capacity class is not 0 (not yet claimed by a pod)
     nhdfit_detail d;             // nic_cls / sw_free are kept current
 };
 
@@ -47,6 +48,9 @@ NHD_HD void overlay_init(OverlayNode& o, const SeqStatic& s, uint32_t node) {
     o.hp_free = s.p2[node].hp_free;
     o.busy = (s.now - s.p4[node].busy_time) < kMinBusySecs;
     o.d = s.det[node];
+    o.unclaimed = 0;
+    for (int u = 0; u < 2; ++u)
+        for (int k = 0; k < o.d.nic_cnt[u]; ++k) o.unclaimed += o.d.nic_cls[u][k] != 0;
 }
 
 NHD_HD WinnerState overlay_state(const OverlayNode& o, const SeqStatic& s) {
@@ -105,6 +109,28 @@ NHD_HD bool eval_direct(const OverlayNode& o, const SeqStatic& s, const nhdfit_r
     return false;
 }
 
+// Cheap necessary conditions (no enumeration): prunes the typical "an earlier pod of the batch filled this
+// node" case before eval_direct is tried.  Never rejects a feasible pair.
+NHD_HD bool quick_maybe(const OverlayNode& o, const SeqStatic& s, const nhdfit_req& r, const PodHeader& h) {
+    const nhdfit_plane2& q2 = s.p2[o.node];
+    if (!(h.flags & kPodValid) || (q2.flags & NHDFIT_NF_MAINTENANCE) || h.hp_req > o.hp_free) return false;
+    if ((h.flags & kPodNeedGpu) && o.busy) return false;
+    const bool smt = (q2.flags & NHDFIT_NF_SMT) != 0;
+    uint32_t cores = smt ? r.misc_smt : r.misc_nosmt, gpus = 0, need_bw = 0, biggest = 0;
+    for (uint32_t g = 0; g < r.n_groups; ++g) {
+        const uint32_t d = smt ? r.cpu_smt[g] : r.cpu_nosmt[g];
+        cores += d;
+        biggest = d > biggest ? d : biggest;
+        gpus += r.gpus[g];
+        need_bw |= (r.rx[g] > 0 || r.tx[g] > 0) ? 1u : 0u;
+    }
+    const int32_t f0 = o.free_c[0], f1 = o.free_c[1];
+    if ((int32_t)cores > f0 + f1 || (int32_t)biggest > (f0 > f1 ? f0 : f1)) return false;
+    if ((int32_t)gpus > popc32(o.gpu_free)) return false;
+    if (need_bw && !o.unclaimed) return false;               // every NIC left has capacity 0
+    return true;
+}
+
 NHD_HD uint32_t phys_cores(uint32_t n, bool smt_requested, bool smt_node) {
     return (smt_node && smt_requested) ? (n + 1) / 2 : n;     // GetFreeCpuBatch, nhd/Node.py:502-519
 }
@@ -144,6 +170,9 @@ NHD_HD int apply_commit(OverlayNode& o, const SeqStatic& s, const nhdfit_req& r,
         if (claimed0 >> k & 1) o.d.nic_cls[0][k] = 0;                               // capacity class 0 = 0.0
         if (claimed1 >> k & 1) o.d.nic_cls[1][k] = 0;
     }
+    o.unclaimed = 0;
+    for (int u = 0; u < 2; ++u)
+        for (int k = 0; k < o.d.nic_cnt[u]; ++k) o.unclaimed += o.d.nic_cls[u][k] != 0;
     return bad;
 }
 
@@ -154,13 +183,28 @@ struct SeqResult {
     int32_t status;              // 0 ok / not placed, 1 = the reference's commit step would have failed
 };
 
+// Is the snapshot candidate `nd` still feasible for this pod after the commits so far?
+struct StillFeasible {
+    const SeqStatic& s;
+    const nhdfit_req& r;
+    const PodHeader& h;
+    const int32_t* slot_of;
+    const OverlayNode* overlay;
+    NHD_HD bool operator()(int64_t nd) const {
+        const int32_t slot = slot_of[nd];
+        if (slot < 0) return true;                            // untouched: the snapshot verdict stands
+        uint32_t codes;
+        return quick_maybe(overlay[slot], s, r, h) && eval_direct(overlay[slot], s, r, h, &codes);
+    }
+};
+
 // One pod of the sequential batch.
 //   score_a / map_a : the snapshot (mode A) result of this pod
-//   scan.next(pref, from) : first node >= from whose snapshot feasibility bit is set for this pod (and, if
-//                           `pref`, that has no GPU installed), or -1
+//   scan.find_first(pref, from, ok) : first node >= from whose snapshot feasibility bit is set for this pod
+//                           (and, if `pref`, that has no GPU installed) and for which ok(node) holds, or -1
 //   slot_of[node]   : overlay slot of a dirty node, -1 if no earlier pod of the batch touched it
 // Selection rule = SelectNode (nhd/Matcher.py:393-421) over the up-to-date candidate list.
-template <class Scan>
+template <class Scan, bool SMALL_ONLY = false>
 NHD_HD void resolve_pod(const SeqStatic& s, const nhdfit_req& r, const PodHeader& h, unsigned long long score_a,
                         const nhdfit_mapping& map_a, Scan& scan, int32_t* slot_of, OverlayNode* overlay,
                         uint32_t* n_overlay, SeqResult& out) {
@@ -169,44 +213,35 @@ NHD_HD void resolve_pod(const SeqStatic& s, const nhdfit_req& r, const PodHeader
     out.map = nhdfit_mapping{};
     if (!score_a) return;                                     // infeasible everywhere even before any commit
     const int64_t winner_a = (int64_t)(NHDFIT_SCORE_INDEX(score_a) - s.global_base);
-    bool pref = (score_a >> 63) != 0;                         // a GPU-less node was available for this GPU-less pod
-    int64_t from = winner_a;
-    for (;;) {
-        const int64_t nd = scan.next(pref, from);
-        if (nd < 0) {
-            if (!pref) return;
-            pref = false;                                     // no preferred node left: fall back to any candidate
-            from = 0;
-            continue;
-        }
-        const int32_t slot = slot_of[nd];
-        nhdfit_mapping m = nhdfit_mapping{};
-        if (slot < 0 && nd == winner_a) {
-            m = map_a;                                        // untouched snapshot winner: its mapping is already known
-        } else {
-            OverlayNode tmp;
-            if (slot < 0) overlay_init(tmp, s, (uint32_t)nd);
-            const OverlayNode& o = slot < 0 ? tmp : overlay[slot];
-            uint32_t codes = 0;
-            if (slot >= 0) {
-                if (!eval_direct(o, s, r, h, &codes)) { from = nd + 1; continue; }   // an earlier pod used it up
-            } else {
-                codes = nic_codes_direct(r, overlay_state(o, s));
-            }
-            map_winner(r, overlay_state(o, s), codes, m);
-        }
-        int32_t use = slot;
-        if (use < 0) {
-            use = (int32_t)(*n_overlay);
-            *n_overlay = (uint32_t)use + 1;
-            overlay_init(overlay[use], s, (uint32_t)nd);
-            slot_of[nd] = use;
-        }
-        out.status = m.valid ? apply_commit(overlay[use], s, r, m) : 1;
-        out.map = m;
-        out.node = (int64_t)s.global_base + nd;
-        return;
+    const StillFeasible ok{s, r, h, slot_of, overlay};
+    int64_t nd = -1;
+    if ((score_a >> 63) != 0) nd = scan.find_first(true, winner_a, ok);    // GPU-less nodes first for a GPU-less pod
+    if (nd < 0) nd = scan.find_first(false, (score_a >> 63) ? 0 : winner_a, ok);
+    if (nd < 0) return;
+
+    const int32_t slot = slot_of[nd];
+    nhdfit_mapping m = nhdfit_mapping{};
+    if (slot < 0 && nd == winner_a) {
+        m = map_a;                                            // untouched snapshot winner: its mapping is already known
+    } else {
+        OverlayNode tmp;
+        if (slot < 0) overlay_init(tmp, s, (uint32_t)nd);
+        const OverlayNode& o = slot < 0 ? tmp : overlay[slot];
+        // SMALL_ONLY: the batch holds no pod with more than 3 groups -> only the register-resident set model
+        // is instantiated and the resolver kernel needs no scratch memory
+        if (SMALL_ONLY) map_winner_t<SmallOps>(r, overlay_state(o, s), nic_codes_direct(r, overlay_state(o, s)), m);
+        else map_winner(r, overlay_state(o, s), nic_codes_direct(r, overlay_state(o, s)), m);
     }
+    int32_t use = slot;
+    if (use < 0) {
+        use = (int32_t)(*n_overlay);
+        *n_overlay = (uint32_t)use + 1;
+        overlay_init(overlay[use], s, (uint32_t)nd);
+        slot_of[nd] = use;
+    }
+    out.status = m.valid ? apply_commit(overlay[use], s, r, m) : 1;
+    out.map = m;
+    out.node = (int64_t)s.global_base + nd;
 }
 
 }  // namespace nhdfit

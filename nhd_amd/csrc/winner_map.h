@@ -377,34 +377,22 @@ NHD_HD int pick_gpu_tuple(const typename Ops::Set& gset, int G, int U) {
     return best;
 }
 
+// The order-dependent core of the mapping as a pure function of three small bit sets:
+//   sg_mask / sc_mask / nic_codes : bit c = tuple code c is a valid GPU / CPU(+misc) / NIC assignment
+// Returns false if the three prefix sets do not intersect, else the chosen GPU tuple and CPU tuple codes.
 template <class Ops>
-NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic_codes, nhdfit_mapping& out) {
+NHD_HD bool choose_tuples(int G, int U, uint32_t sg_mask, uint32_t sc_mask, uint32_t nic_codes, uint32_t& gcode, int& ccode) {
     typedef typename Ops::Set Set;
-    const int G = (int)r.n_groups, U = w.U;
-    const bool pci = r.map_type == NHDFIT_MAP_PCI;
     const uint32_t nG = ipow(U, G), nC = ipow(U, G + 1);
-    out.valid = 0;
-
     // candidate sets in product order (Matcher.py:116-141, 206-220).  list(set) = keys in slot order, so the
     // "lists" of the reference are never materialised: the sets' slots are walked instead.
     Set sg, sc;
     Ops::init(sg, G, U);
     Ops::init(sc, G + 1, U);
-    for (uint32_t code = 0; code < nG; ++code) {
-        uint32_t t0 = 0, t1 = 0;
-        for (int g = 0; g < G; ++g) { if (tup_digit(code, G, U, g)) t1 += r.gpus[g]; else t0 += r.gpus[g]; }
-        if (t0 <= (uint32_t)w.free_g[0] && t1 <= (uint32_t)w.free_g[1]) Ops::add(sg, (int)code, G, U);
-    }
-    for (uint32_t code = 0; code < nC; ++code) {
-        uint32_t t0 = 0, t1 = 0;
-        for (int g = 0; g <= G; ++g) {
-            const uint32_t d = g < G ? (w.smt ? r.cpu_smt[g] : r.cpu_nosmt[g]) : (w.smt ? r.misc_smt : r.misc_nosmt);
-            if (tup_digit(code, G + 1, U, g)) t1 += d; else t0 += d;
-        }
-        if (t0 <= (uint32_t)w.free_c[0] && t1 <= (uint32_t)w.free_c[1]) Ops::add(sc, (int)code, G + 1, U);
-    }
-    if (Ops::size(sg) == 0 || Ops::size(sc) == 0 || !(nic_codes & ((nG >= 32 ? 0u : (1u << nG)) - 1u))) return false;
-
+    for (uint32_t code = 0; code < nG; ++code)
+        if (sg_mask >> code & 1) Ops::add(sg, (int)code, G, U);
+    for (uint32_t code = 0; code < nC; ++code)
+        if (sc_mask >> code & 1) Ops::add(sc, (int)code, G + 1, U);
     // intersection of the three prefix sets (Matcher.py:342-346): set(list) re-inserts in list order
     Set a, b, c, ab, abc;
     Ops::init(a, G, U); Ops::init(b, G, U); Ops::init(c, G, U);
@@ -415,17 +403,70 @@ NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic
     Ops::isect(a, b, ab);
     Ops::isect(ab, c, abc);
     if (Ops::size(abc) == 0) return false;
-
     // GPU list: replaced by the intersection only if that drops something (Matcher.py:363-366);
     // GetNumaGroupIdx (Matcher.py:427-437): first maximiser of max-min per-NUMA group count
-    const uint32_t gcode = (uint32_t)(Ops::size(abc) < Ops::size(sg) ? pick_gpu_tuple<Ops>(abc, G, U)
-                                                                        : pick_gpu_tuple<Ops>(sg, G, U));
-    int ccode = -1;                                                        // Matcher.py:441-444
+    gcode = (uint32_t)(Ops::size(abc) < Ops::size(sg) ? pick_gpu_tuple<Ops>(abc, G, U) : pick_gpu_tuple<Ops>(sg, G, U));
+    ccode = -1;                                                            // Matcher.py:441-444
     for (int i = Ops::next(sc, 0); i >= 0 && ccode < 0; i = Ops::next(sc, i + 1)) {
         const int k = Ops::key_at(sc, i);
         if ((uint32_t)(k >> (U - 1)) == gcode) ccode = k;
     }
-    if (ccode < 0) return false;
+    return ccode >= 0;
+}
+
+// Memo of choose_tuples for G <= 3 (its whole input is 35 bits): one 64-bit word per slot =
+// key << 16 | 1 << 15 | ok << 14 | gcode << 4 | ccode.  Lossy direct-mapped table; a stale or foreign slot
+// is just a miss.  Keeps the sequential CPython-set model off the critical path of the mapping kernel.
+constexpr uint32_t kMemoSlots = 4096;
+NHD_HD uint64_t memo_key(int G, int U, uint32_t sg_mask, uint32_t sc_mask, uint32_t nic_codes) {
+    return (uint64_t)(G & 3) | ((uint64_t)(U - 1) << 2) | ((uint64_t)(sg_mask & 0xFF) << 3) |
+           ((uint64_t)(nic_codes & 0xFF) << 11) | ((uint64_t)(sc_mask & 0xFFFF) << 19);
+}
+
+// Restatement of the winner-only tail of FindNode (Matcher.py:337-391 + 423-452).
+// `nic_codes`: bit c set = assignment with tuple code c has at least one valid NIC choice (after the
+// PCI pruning) - taken from the same reach tables the fit kernel used.  Returns false if infeasible.
+template <class Ops>
+NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic_codes, nhdfit_mapping& out,
+                         uint64_t* memo = nullptr) {
+    const int G = (int)r.n_groups, U = w.U;
+    const bool pci = r.map_type == NHDFIT_MAP_PCI;
+    const uint32_t nG = ipow(U, G), nC = ipow(U, G + 1);
+    out.valid = 0;
+    nic_codes &= (nG >= 32 ? 0u : (1u << nG)) - 1u;
+
+    uint32_t sg_mask = 0, sc_mask = 0;
+    for (uint32_t code = 0; code < nG; ++code) {
+        uint32_t t0 = 0, t1 = 0;
+        for (int g = 0; g < G; ++g) { if (tup_digit(code, G, U, g)) t1 += r.gpus[g]; else t0 += r.gpus[g]; }
+        if (t0 <= (uint32_t)w.free_g[0] && t1 <= (uint32_t)w.free_g[1]) sg_mask |= 1u << code;
+    }
+    for (uint32_t code = 0; code < nC; ++code) {
+        uint32_t t0 = 0, t1 = 0;
+        for (int g = 0; g <= G; ++g) {
+            const uint32_t d = g < G ? (w.smt ? r.cpu_smt[g] : r.cpu_nosmt[g]) : (w.smt ? r.misc_smt : r.misc_nosmt);
+            if (tup_digit(code, G + 1, U, g)) t1 += d; else t0 += d;
+        }
+        if (t0 <= (uint32_t)w.free_c[0] && t1 <= (uint32_t)w.free_c[1]) sc_mask |= 1u << code;
+    }
+    if (!sg_mask || !sc_mask || !nic_codes) return false;
+
+    uint32_t gcode = 0;
+    int ccode = -1;
+    bool ok;
+    const bool use_memo = memo != nullptr && G <= 3;
+    const uint64_t key = memo_key(G, U, sg_mask, sc_mask, nic_codes);
+    const uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 52) & (kMemoSlots - 1);
+    uint64_t e = use_memo ? memo[slot] : 0;
+    if (use_memo && (e >> 16) == key && (e >> 15 & 1)) {
+        ok = (e >> 14 & 1) != 0;
+        gcode = (uint32_t)(e >> 4) & 7u;
+        ccode = (int)(e & 15u);
+    } else {
+        ok = choose_tuples<Ops>(G, U, sg_mask, sc_mask, nic_codes, gcode, ccode);
+        if (use_memo) memo[slot] = (key << 16) | (1ull << 15) | ((uint64_t)ok << 14) | ((uint64_t)(gcode & 7u) << 4) | (uint64_t)(ccode & 15);
+    }
+    if (!ok) return false;
     for (int g = 0; g < kMaxG; ++g) { out.gpu[g] = out.nic_numa[g] = out.nic_idx[g] = -1; }
     for (int g = 0; g <= kMaxG; ++g) out.cpu[g] = -1;
     if (!first_nic_choice(r, w, gcode, pci, out.nic_idx)) return false;   // Matcher.py:446-449
@@ -439,8 +480,9 @@ NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic
 }
 
 // G <= 3: every set stays within 32 slots -> register-resident model; G == 4: generic model.
-NHD_HD bool map_winner(const nhdfit_req& r, const WinnerState& w, uint32_t nic_codes, nhdfit_mapping& out) {
-    if (r.n_groups <= 3) return map_winner_t<SmallOps>(r, w, nic_codes, out);
+NHD_HD bool map_winner(const nhdfit_req& r, const WinnerState& w, uint32_t nic_codes, nhdfit_mapping& out,
+                       uint64_t* memo = nullptr) {
+    if (r.n_groups <= 3) return map_winner_t<SmallOps>(r, w, nic_codes, out, memo);
     return map_winner_t<GenericOps>(r, w, nic_codes, out);
 }
 

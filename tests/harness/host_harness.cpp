@@ -87,6 +87,7 @@ void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plan
         }
     }
     if (!maps) return;
+    std::vector<uint64_t> memo(kMemoSlots, 0);       // same memo as the mapping kernel (exercised on the host too)
     for (uint32_t p = 0; p < P; ++p) {
         std::memset(&maps[p], 0, sizeof(nhdfit_mapping));
         if (p % kTile == 0) {
@@ -109,7 +110,7 @@ void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plan
         const uint32_t bits = nic_assignment_bits(img.data(), L, p % kTile, reqs[p].map_type == NHDFIT_MAP_PCI, p3[i]);
         const uint32_t codes = nic_codes_from_table_bits(bits, (int)reqs[p].n_groups, w.U);
         if (force_generic) map_winner_t<GenericOps>(reqs[p], w, codes, maps[p]);
-        else map_winner(reqs[p], w, codes, maps[p]);
+        else map_winner(reqs[p], w, codes, maps[p], memo.data());
     }
 }
 
@@ -126,14 +127,14 @@ void hh_resolve(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_p
     uint32_t n_overlay = 0;
     struct HostScan {
         const uint64_t* bm; const nhdfit_plane2* p2; uint32_t chunks, P, pod, n;
-        int64_t next(bool pref, int64_t from) {
+        int64_t find_first(bool pref, int64_t from, const StillFeasible& ok) {
             for (uint32_t c = (uint32_t)(from / 64); c < chunks; ++c) {
                 uint64_t w = bm[(size_t)c * P + pod];
                 if (c == (uint32_t)(from / 64)) w &= ~0ull << (from % 64);
                 while (w) {
                     const int b = __builtin_ctzll(w);
                     const uint32_t nd = c * 64 + b;
-                    if (!pref || !(p2[nd].flags & NHDFIT_NF_HAS_GPU)) return nd;
+                    if ((!pref || !(p2[nd].flags & NHDFIT_NF_HAS_GPU)) && ok(nd)) return nd;
                     w &= w - 1;
                 }
             }
