@@ -287,7 +287,6 @@ struct MapArgs {
     const unsigned long long* score;
     const double* caps;
     nhdfit_mapping* out;
-    uint64_t* memo;             // choose_tuples memo (kMemoSlots words, cleared every step)
 };
 
 // One pod per wavefront: the mapping is a long, branchy, strictly sequential computation (the
@@ -326,7 +325,7 @@ __global__ __launch_bounds__(64 * kMapWaves) void k_map(MapArgs a) {
                                                       rq.map_type == NHDFIT_MAP_PCI, a.p3[i]);
             const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
             if (GENERIC) map_winner_t<GenericOps>(rq, w, codes, m);
-            else map_winner_t<SmallOps>(rq, w, codes, m, a.memo);
+            else map_winner_t<SmallOps>(rq, w, codes, m);
         }
     }
 }
@@ -483,7 +482,7 @@ struct nhdfit_ctx {
     std::vector<uint32_t> perm;          // device (class-sorted) position -> caller's pod index
     DevBuf<PodHeader> hdr[kBufs]; DevBuf<uint8_t> tabs[kBufs];
     DevBuf<unsigned long long> score[kBufs]; DevBuf<nhdfit_mapping> maps[kBufs];
-    DevBuf<uint64_t> bitmap; DevBuf<uint64_t> cand; DevBuf<uint64_t> memo;
+    DevBuf<uint64_t> bitmap; DevBuf<uint64_t> cand;
     // mode B
     DevBuf<uint64_t> nogpu; DevBuf<int32_t> slot_of; DevBuf<OverlayNode> overlay; DevBuf<SeqResult> seq_out; DevBuf<uint32_t> order;
     bool use_cand = false, want_bitmap = true, want_map = true;
@@ -611,7 +610,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
     c->reqs.release(); c->bitmap.release(); c->cand.release(); c->group_sets.release();
-    c->memo.release(); c->nogpu.release(); c->slot_of.release(); c->overlay.release(); c->seq_out.release(); c->order.release();
+    c->nogpu.release(); c->slot_of.release(); c->overlay.release(); c->seq_out.release(); c->order.release();
     for (int b = 0; b < kBufs; ++b) {
         c->hdr[b].release(); c->tabs[b].release(); c->score[b].release(); c->maps[b].release();
         if (c->ev_digest[b]) (void)hipEventDestroy(c->ev_digest[b]);
@@ -831,10 +830,8 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     // stage 3 (s_map): the winners' resource mappings
     HIPCHK(c, hipStreamWaitEvent(c->s_map, c->ev_fit[b], 0));
     if (c->want_map) {
-        HIPCHK(c, c->memo.reserve(kMemoSlots));
-        HIPCHK(c, hipMemsetAsync(c->memo.p, 0, kMemoSlots * sizeof(uint64_t), c->s_map));   // every step pays its own misses
         MapArgs m{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->det.p, c->tabs[b].p, c->layout, c->n,
-                  c->global_base, c->reqs.p, P, c->score[b].p, c->caps.p, c->maps[b].p, c->memo.p};
+                  c->global_base, c->reqs.p, P, c->score[b].p, c->caps.p, c->maps[b].p};
         const dim3 mg((P + kMapWaves - 1) / kMapWaves), mb(64 * kMapWaves);
         if (c->n_big_pods < P) hipLaunchKernelGGL(k_map<false>, mg, mb, 0, c->s_map, m);
         if (c->n_big_pods) hipLaunchKernelGGL(k_map<true>, mg, mb, 0, c->s_map, m);

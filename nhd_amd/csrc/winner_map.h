@@ -414,21 +414,11 @@ NHD_HD bool choose_tuples(int G, int U, uint32_t sg_mask, uint32_t sc_mask, uint
     return ccode >= 0;
 }
 
-// Memo of choose_tuples for G <= 3 (its whole input is 35 bits): one 64-bit word per slot =
-// key << 16 | 1 << 15 | ok << 14 | gcode << 4 | ccode.  Lossy direct-mapped table; a stale or foreign slot
-// is just a miss.  Keeps the sequential CPython-set model off the critical path of the mapping kernel.
-constexpr uint32_t kMemoSlots = 4096;
-NHD_HD uint64_t memo_key(int G, int U, uint32_t sg_mask, uint32_t sc_mask, uint32_t nic_codes) {
-    return (uint64_t)(G & 3) | ((uint64_t)(U - 1) << 2) | ((uint64_t)(sg_mask & 0xFF) << 3) |
-           ((uint64_t)(nic_codes & 0xFF) << 11) | ((uint64_t)(sc_mask & 0xFFFF) << 19);
-}
-
 // Restatement of the winner-only tail of FindNode (Matcher.py:337-391 + 423-452).
 // `nic_codes`: bit c set = assignment with tuple code c has at least one valid NIC choice (after the
 // PCI pruning) - taken from the same reach tables the fit kernel used.  Returns false if infeasible.
 template <class Ops>
-NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic_codes, nhdfit_mapping& out,
-                         uint64_t* memo = nullptr) {
+NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic_codes, nhdfit_mapping& out) {
     const int G = (int)r.n_groups, U = w.U;
     const bool pci = r.map_type == NHDFIT_MAP_PCI;
     const uint32_t nG = ipow(U, G), nC = ipow(U, G + 1);
@@ -453,19 +443,7 @@ NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic
 
     uint32_t gcode = 0;
     int ccode = -1;
-    bool ok;
-    const bool use_memo = memo != nullptr && G <= 3;
-    const uint64_t key = memo_key(G, U, sg_mask, sc_mask, nic_codes);
-    const uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 52) & (kMemoSlots - 1);
-    uint64_t e = use_memo ? memo[slot] : 0;
-    if (use_memo && (e >> 16) == key && (e >> 15 & 1)) {
-        ok = (e >> 14 & 1) != 0;
-        gcode = (uint32_t)(e >> 4) & 7u;
-        ccode = (int)(e & 15u);
-    } else {
-        ok = choose_tuples<Ops>(G, U, sg_mask, sc_mask, nic_codes, gcode, ccode);
-        if (use_memo) memo[slot] = (key << 16) | (1ull << 15) | ((uint64_t)ok << 14) | ((uint64_t)(gcode & 7u) << 4) | (uint64_t)(ccode & 15);
-    }
+    const bool ok = choose_tuples<Ops>(G, U, sg_mask, sc_mask, nic_codes, gcode, ccode);
     if (!ok) return false;
     for (int g = 0; g < kMaxG; ++g) { out.gpu[g] = out.nic_numa[g] = out.nic_idx[g] = -1; }
     for (int g = 0; g <= kMaxG; ++g) out.cpu[g] = -1;
@@ -480,9 +458,8 @@ NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic
 }
 
 // G <= 3: every set stays within 32 slots -> register-resident model; G == 4: generic model.
-NHD_HD bool map_winner(const nhdfit_req& r, const WinnerState& w, uint32_t nic_codes, nhdfit_mapping& out,
-                       uint64_t* memo = nullptr) {
-    if (r.n_groups <= 3) return map_winner_t<SmallOps>(r, w, nic_codes, out, memo);
+NHD_HD bool map_winner(const nhdfit_req& r, const WinnerState& w, uint32_t nic_codes, nhdfit_mapping& out) {
+    if (r.n_groups <= 3) return map_winner_t<SmallOps>(r, w, nic_codes, out);
     return map_winner_t<GenericOps>(r, w, nic_codes, out);
 }
 

@@ -87,7 +87,6 @@ void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plan
         }
     }
     if (!maps) return;
-    std::vector<uint64_t> memo(kMemoSlots, 0);       // same memo as the mapping kernel (exercised on the host too)
     for (uint32_t p = 0; p < P; ++p) {
         std::memset(&maps[p], 0, sizeof(nhdfit_mapping));
         if (p % kTile == 0) {
@@ -110,7 +109,7 @@ void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plan
         const uint32_t bits = nic_assignment_bits(img.data(), L, p % kTile, reqs[p].map_type == NHDFIT_MAP_PCI, p3[i]);
         const uint32_t codes = nic_codes_from_table_bits(bits, (int)reqs[p].n_groups, w.U);
         if (force_generic) map_winner_t<GenericOps>(reqs[p], w, codes, maps[p]);
-        else map_winner(reqs[p], w, codes, maps[p], memo.data());
+        else map_winner(reqs[p], w, codes, maps[p]);
     }
 }
 
