@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the node filter-and-score hot path (contract: see the task statement / DESIGN.md section 4).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -32,12 +32,12 @@ HBM_PEAK_GBS = 8000.0       # MI355X spec (guides/MI355X_MICROARCH.md, "Chip-lev
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=4, help="BASELINE config whose cluster/pod mix is generated")
     ap.add_argument("--nodes-per-gpu", type=int, default=65536)
     ap.add_argument("--pods", type=int, default=4096)
-    ap.add_argument("--cpu-sample-pods", type=int, default=192, help="pods timed on the CPU port (rank 0, N=1 only)")
+    ap.add_argument("--cpu-sample-pods", type=int, default=1024, help="pods timed on the CPU port (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -108,6 +108,15 @@ def main():
     fit_ms = st.fit_ms_total / max(1, st.launches)
     achieved = st.bytes_last / (fit_ms * 1e-3) / 1e9 if fit_ms > 0 else 0.0
 
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        w = tj["workload"]
+        if (w["config"], w["nodes_per_gpu"], w["pods"]) == (args.config, args.nodes_per_gpu, args.pods):
+            traffic = tj["hbm_bytes_per_launch"]      # PMC pass of the same command, committed under profiles/
+
     out = {
         "metric": "pod-placement filter-and-score throughput (pod x node fit-and-score evaluations/s; decisions/s in decisions_per_s)",
         "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -121,10 +130,14 @@ def main():
                    "parallelism": f"node-shard x{world}, RCCL all-reduce(max) of {args.pods} u64 scores" if world > 1 else "single GPU",
                    "nic_signatures": st.nsig, "lds_bytes_per_block": st.lds_bytes},
         "roofline": {"bound": "hbm", "kernel": "k_fit_score", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(st.bytes_last), "kernel_ms": fit_ms,
                      "digest_kernel_ms": st.digest_ms_last, "device_step_ms": st.step_ms_last,
-                     "note": "integer table look-ups: the kernel is LDS/VALU-issue bound, see DESIGN.md section 4"},
+                     "note": "achieved = algorithmic bytes / mean HIP-event duration of k_fit_score on its own stream while the "
+                             "digest of the next step and the winner mapping of the previous one overlap it (3-stream "
+                             "pipeline); traffic = HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE): the node "
+                             "planes and table images are served from L2 / Infinity Cache, the kernel is VALU-issue + LDS bound "
+                             "(DESIGN.md section 4)"},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
