@@ -53,7 +53,9 @@ constexpr int kDigestSlices = 16;
 // in LDS, then fills its share of the table rows; consecutive threads write consecutive columns.
 __global__ __launch_bounds__(kDigestThreads) void k_digest(const nhdfit_req* __restrict__ reqs, uint32_t P,
                                                            DictView d, Layout L, uint8_t* __restrict__ tabs,
-                                                           PodHeader* __restrict__ hdr) {
+                                                           PodHeader* __restrict__ hdr,
+                                                           unsigned long long* __restrict__ score,
+                                                           unsigned long long* __restrict__ shape_keys, uint32_t shape_slots) {
     struct PaddedReq { nhdfit_req r; uint32_t pad; };          // 33-word stride: lane j -> bank j
     __shared__ PaddedReq s_req[kTile];
     __shared__ PodSums s_sum[kTile];
@@ -73,8 +75,15 @@ __global__ __launch_bounds__(kDigestThreads) void k_digest(const nhdfit_req* __r
         s_req[tid].r = r;
         s_hdr[tid] = h;
         if (h.flags & kPodValid) pod_sums(r, s_sum[tid]);
-        if (slice == 0) hdr[tile * kTile + tid] = h;
+        if (slice == 0) {
+            hdr[tile * kTile + tid] = h;
+            if (pod < P) score[pod] = 0;                   // the fit kernel accumulates with atomicMax
+        }
     }
+    // clear this step's shape table of the mapping kernels (saves two memset launches per step)
+    if (shape_keys)
+        for (uint32_t k = (blockIdx.y * gridDim.x + blockIdx.x) * kDigestThreads + tid; k < shape_slots;
+             k += gridDim.x * gridDim.y * kDigestThreads) shape_keys[k] = 0;
     __syncthreads();
     for (uint32_t w = tid; w < kTile * d.ncls; w += kDigestThreads) {
         const uint32_t j = w % kTile, c = w / kTile;
@@ -330,6 +339,94 @@ __global__ __launch_bounds__(64 * kMapWaves) void k_map(MapArgs a) {
     }
 }
 
+// ---- winner mapping for G <= 3 pods, de-duplicated by candidate-set shape --------------------------
+// The sequential CPython-set model (choose_tuples) is a pure function of 35 bits (shape_key).  Thousands of
+// pods share a few hundred shapes, so: (1) every pod derives its shape in parallel and interns it in a
+// per-step hash table, (2) one wavefront per distinct shape runs the set model, (3) every pod finishes its
+// mapping (first valid NIC choice) in parallel.  Nothing survives the step.
+__device__ __forceinline__ bool load_winner(const MapArgs& a, uint32_t p, WinnerState& w, uint32_t& i) {
+    const unsigned long long s = a.score[p];
+    if (!s) return false;
+    const uint64_t gi = NHDFIT_SCORE_INDEX(s);
+    if (gi < a.global_base || gi >= a.global_base + a.n) return false;
+    i = (uint32_t)(gi - a.global_base);
+    const nhdfit_plane0 q0 = a.p0[i];
+    const nhdfit_plane1 q1 = a.p1[i];
+    const nhdfit_plane2 q2 = a.p2[i];
+    w.d = a.det + i;
+    w.U = w.d->numa_nodes;
+    w.smt = (q2.flags & NHDFIT_NF_SMT) != 0;
+    w.free_c[0] = popc64(q0.t0[0] & q1.t1[0]);
+    w.free_c[1] = popc64(q0.t0[1] & q1.t1[1]);
+    w.free_g[0] = popc32(q2.gpu_free & ~q2.gpu_numa1);
+    w.free_g[1] = popc32(q2.gpu_free & q2.gpu_numa1);
+    w.caps = a.caps;
+    return true;
+}
+
+struct ShapeArgs {
+    unsigned long long* keys;    // [slots] 0 = empty
+    uint32_t* result;            // [slots] ok << 8 | gcode << 4 | ccode
+    int32_t* slot_of_pod;        // [P] hash slot, < 0: nothing to map
+    uint32_t slots;              // power of two >= 2 P
+};
+
+__global__ __launch_bounds__(64) void k_map_shapes(MapArgs a, ShapeArgs h) {
+    const uint32_t p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= a.P) return;
+    int32_t slot = -1;
+    WinnerState w;
+    uint32_t i;
+    const nhdfit_req& rq = a.reqs[p];
+    if (rq.n_groups <= 3 && load_winner(a, p, w, i)) {
+        const uint32_t bits = nic_assignment_bits(a.tabs + (size_t)(p / kTile) * a.layout.bytes, a.layout, p % kTile,
+                                                  rq.map_type == NHDFIT_MAP_PCI, a.p3[i]);
+        const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
+        uint32_t sg, sc;
+        candidate_masks(rq, w, sg, sc);
+        if (sg && sc && codes) {
+            const unsigned long long key = shape_key((int)rq.n_groups, w.U, sg, sc, codes);
+            uint32_t x = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (h.slots - 1);
+            for (;;) {
+                const unsigned long long old = atomicCAS(&h.keys[x], 0ull, key);
+                if (old == 0ull || old == key) break;
+                x = (x + 1) & (h.slots - 1);
+            }
+            slot = (int32_t)x;
+        }
+    }
+    h.slot_of_pod[p] = slot;
+}
+
+__global__ __launch_bounds__(256) void k_map_choose(ShapeArgs h) {
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (slot >= h.slots || (threadIdx.x & 63) != 0) return;
+    const unsigned long long key = h.keys[slot];
+    if (!key) return;
+    const int G = (int)(key & 3), U = (int)((key >> 2) & 1) + 1;
+    uint32_t gcode = 0;
+    int ccode = -1;
+    const bool ok = choose_tuples<SmallOps>(G, U, (uint32_t)(key >> 3) & 0xFF, (uint32_t)(key >> 19) & 0xFFFF,
+                                            (uint32_t)(key >> 11) & 0xFF, gcode, ccode);
+    h.result[slot] = ((uint32_t)ok << 8) | ((gcode & 7u) << 4) | ((uint32_t)ccode & 15u);
+}
+
+__global__ __launch_bounds__(64) void k_map_finish(MapArgs a, ShapeArgs h) {
+    const uint32_t p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= a.P) return;
+    const nhdfit_req& rq = a.reqs[p];
+    if (rq.n_groups > 3) return;                      // handled by k_map<true>
+    nhdfit_mapping& m = a.out[p];
+    memset(&m, 0, sizeof(m));
+    const int32_t slot = h.slot_of_pod[p];
+    if (slot < 0) return;
+    const uint32_t res = h.result[slot];
+    WinnerState w;
+    uint32_t i;
+    if (!(res >> 8 & 1) || !load_winner(a, p, w, i)) return;
+    finish_mapping(rq, w, (res >> 4) & 7u, (int)(res & 15u), m);
+}
+
 // ---- mode B: sequential resolver ------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_nogpu(const nhdfit_plane2* __restrict__ p2, uint32_t n, uint64_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
@@ -456,7 +553,8 @@ struct nhdfit_ctx {
     int dev = -1;
     hipStream_t stream = nullptr;        // fit_score (+ all-reduce): the stage that owns the chip
     hipStream_t s_digest = nullptr;      // request digest of the next step
-    hipStream_t s_map = nullptr;         // winner mapping of the previous step
+    hipStream_t s_map[kBufs] = {};       // winner mapping of earlier steps (one stream per buffer set: the mapping
+                                         // stage is latency-bound, consecutive steps' mappings may overlap each other)
     hipEvent_t ev_digest[kBufs] = {}, ev_fit[kBufs] = {}, ev_map[kBufs] = {};
     uint64_t step = 0;                   // steps enqueued since the last stage_requests
     std::string err;
@@ -483,6 +581,7 @@ struct nhdfit_ctx {
     DevBuf<PodHeader> hdr[kBufs]; DevBuf<uint8_t> tabs[kBufs];
     DevBuf<unsigned long long> score[kBufs]; DevBuf<nhdfit_mapping> maps[kBufs];
     DevBuf<uint64_t> bitmap; DevBuf<uint64_t> cand;
+    DevBuf<unsigned long long> shape_keys[kBufs]; DevBuf<uint32_t> shape_res[kBufs]; DevBuf<int32_t> shape_slot[kBufs];   // k_map_* dedup tables
     // mode B
     DevBuf<uint64_t> nogpu; DevBuf<int32_t> slot_of; DevBuf<OverlayNode> overlay; DevBuf<SeqResult> seq_out; DevBuf<uint32_t> order;
     bool use_cand = false, want_bitmap = true, want_map = true;
@@ -535,7 +634,7 @@ int drain_events(nhdfit_ctx* c) {
 int sync_all(nhdfit_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->s_digest));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->s_map));
+    for (int b = 0; b < kBufs; ++b) HIPCHK(c, hipStreamSynchronize(c->s_map[b]));
     return NHDFIT_OK;
 }
 
@@ -578,7 +677,9 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
     }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->s_digest, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&c->s_map, hipStreamNonBlocking)) != hipSuccess) {
+        (e = hipStreamCreateWithFlags(&c->s_map[0], hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->s_map[1], hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->s_map[2], hipStreamNonBlocking)) != hipSuccess) {
         int rc = fail(nullptr, NHDFIT_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
         delete c;
         return rc;
@@ -605,11 +706,12 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
 void nhdfit_destroy(nhdfit_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->dev);
-    if (c->stream && c->s_digest && c->s_map) (void)sync_all(c);
+    if (c->stream && c->s_digest && c->s_map[0] && c->s_map[1] && c->s_map[2]) (void)sync_all(c);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
     c->reqs.release(); c->bitmap.release(); c->cand.release(); c->group_sets.release();
+    for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); }
     c->nogpu.release(); c->slot_of.release(); c->overlay.release(); c->seq_out.release(); c->order.release();
     for (int b = 0; b < kBufs; ++b) {
         c->hdr[b].release(); c->tabs[b].release(); c->score[b].release(); c->maps[b].release();
@@ -622,7 +724,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
             if (x) (void)hipEventDestroy(x);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->s_digest) (void)hipStreamDestroy(c->s_digest);
-    if (c->s_map) (void)hipStreamDestroy(c->s_map);
+    for (int b = 0; b < kBufs; ++b) if (c->s_map[b]) (void)hipStreamDestroy(c->s_map[b]);
     delete c;
 }
 
@@ -785,14 +887,24 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     const int b = (int)(c->step % kBufs);
 
     // stage 1 (s_digest): request digest into buffer set b - once the mapping of step i-3 has let go of it
+    // HIP-event timing is sampled (every 8th step): at ~100 us per step the host is the bottleneck otherwise
+    const bool timed = c->step < 2 || (c->step & 7) == 0;
+    uint32_t shape_slots = 1024;
+    while (shape_slots < 2 * P) shape_slots <<= 1;
+    const bool small_map = c->want_map && c->n_big_pods < P;
+    if (small_map) {
+        HIPCHK(c, c->shape_keys[b].reserve(shape_slots));
+        HIPCHK(c, c->shape_res[b].reserve(shape_slots));
+        HIPCHK(c, c->shape_slot[b].reserve(P));
+    }
     if (c->step >= (uint64_t)kBufs) HIPCHK(c, hipStreamWaitEvent(c->s_digest, c->ev_map[b], 0));
-    HIPCHK(c, hipEventRecord(ev[0], c->s_digest));
-    HIPCHK(c, hipMemsetAsync(c->score[b].p, 0, (size_t)P * sizeof(unsigned long long), c->s_digest));
+    if (timed) HIPCHK(c, hipEventRecord(ev[0], c->s_digest));
     DictView dv{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}};
     hipLaunchKernelGGL(k_digest, dim3(tiles, kDigestSlices), dim3(kDigestThreads), 0, c->s_digest,
-                       c->reqs.p, P, dv, c->layout, c->tabs[b].p, c->hdr[b].p);
+                       c->reqs.p, P, dv, c->layout, c->tabs[b].p, c->hdr[b].p, c->score[b].p,
+                       small_map ? c->shape_keys[b].p : nullptr, shape_slots);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(ev[1], c->s_digest));
+    if (timed) HIPCHK(c, hipEventRecord(ev[1], c->s_digest));
     HIPCHK(c, hipEventRecord(c->ev_digest[b], c->s_digest));
 
     // stage 2 (stream): fit + score + select over every (pod, node) pair, then the all-reduce
@@ -816,11 +928,11 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     a.nranges = (chunks + cpb - 1) / cpb;
     const uint32_t grid = tiles * a.nranges;
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_digest[b], 0));
-    HIPCHK(c, hipEventRecord(ev[2], c->stream));
+    if (timed) HIPCHK(c, hipEventRecord(ev[2], c->stream));
     if (big) hipLaunchKernelGGL((k_fit_score<512>), dim3(grid), dim3(512), c->lds_bytes, c->stream, a);
     else     hipLaunchKernelGGL((k_fit_score<256>), dim3(grid), dim3(256), c->lds_bytes, c->stream, a);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(ev[3], c->stream));
+    if (timed) HIPCHK(c, hipEventRecord(ev[3], c->stream));
     if (c->comm) {
         ncclResult_t r = g_rccl.AllReduce(c->score[b].p, c->score[b].p, P, ncclUint64, ncclMax, c->comm, c->stream);
         if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
@@ -828,18 +940,26 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     HIPCHK(c, hipEventRecord(c->ev_fit[b], c->stream));
 
     // stage 3 (s_map): the winners' resource mappings
-    HIPCHK(c, hipStreamWaitEvent(c->s_map, c->ev_fit[b], 0));
+    hipStream_t sm = c->s_map[b];
+    HIPCHK(c, hipStreamWaitEvent(sm, c->ev_fit[b], 0));
     if (c->want_map) {
         MapArgs m{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->det.p, c->tabs[b].p, c->layout, c->n,
                   c->global_base, c->reqs.p, P, c->score[b].p, c->caps.p, c->maps[b].p};
         const dim3 mg((P + kMapWaves - 1) / kMapWaves), mb(64 * kMapWaves);
-        if (c->n_big_pods < P) hipLaunchKernelGGL(k_map<false>, mg, mb, 0, c->s_map, m);
-        if (c->n_big_pods) hipLaunchKernelGGL(k_map<true>, mg, mb, 0, c->s_map, m);
+        if (small_map) {
+            ShapeArgs h{c->shape_keys[b].p, c->shape_res[b].p, c->shape_slot[b].p, shape_slots};
+            hipLaunchKernelGGL(k_map_shapes, dim3((P + 63) / 64), dim3(64), 0, sm, m, h);
+            hipLaunchKernelGGL(k_map_choose, dim3(shape_slots / 4), dim3(256), 0, sm, h);
+            hipLaunchKernelGGL(k_map_finish, dim3((P + 63) / 64), dim3(64), 0, sm, m, h);
+        }
+        if (c->n_big_pods) hipLaunchKernelGGL(k_map<true>, mg, mb, 0, sm, m);
         HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipEventRecord(c->ev_map[b], c->s_map));
-    HIPCHK(c, hipEventRecord(ev[4], c->s_map));
-    c->ev_pending++;
+    HIPCHK(c, hipEventRecord(c->ev_map[b], sm));
+    if (timed) {
+        HIPCHK(c, hipEventRecord(ev[4], sm));
+        c->ev_pending++;
+    }
     c->step++;
 
     c->stats.evals_last = (uint64_t)P * c->n;
@@ -918,17 +1038,18 @@ int nhdfit_find_sequential(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, do
     HIPCHK(c, c->order.reserve(P));
     std::vector<uint32_t> order(P);                       // caller's pod -> staged (class-sorted) position
     for (uint32_t i = 0; i < P; ++i) order[c->perm[i]] = i;
-    HIPCHK(c, hipMemcpyAsync(c->order.p, order.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, c->s_map));
-    HIPCHK(c, hipMemsetAsync(c->slot_of.p, 0xFF, (size_t)c->n * sizeof(int32_t), c->s_map));
-    hipLaunchKernelGGL(k_nogpu, dim3(chunks), dim3(64), 0, c->s_map, c->p2.p, c->n, c->nogpu.p);
+    hipStream_t sm = c->s_map[b];
+    HIPCHK(c, hipMemcpyAsync(c->order.p, order.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
+    HIPCHK(c, hipMemsetAsync(c->slot_of.p, 0xFF, (size_t)c->n * sizeof(int32_t), sm));
+    hipLaunchKernelGGL(k_nogpu, dim3(chunks), dim3(64), 0, sm, c->p2.p, c->n, c->nogpu.p);
     ResolveArgs ra{SeqStatic{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->p4.p, c->det.p, c->caps.p, c->n, c->global_base, now},
                    c->reqs.p, c->hdr[b].p, c->score[b].p, c->maps[b].p, c->bitmap.p, c->nogpu.p, c->order.p, P, chunks,
                    c->slot_of.p, c->overlay.p, c->seq_out.p};
-    if (c->n_big_pods) hipLaunchKernelGGL(k_resolve<false>, dim3(1), dim3(64), 0, c->s_map, ra);   // after k_map, same stream
-    else hipLaunchKernelGGL(k_resolve<true>, dim3(1), dim3(64), 0, c->s_map, ra);
+    if (c->n_big_pods) hipLaunchKernelGGL(k_resolve<false>, dim3(1), dim3(64), 0, sm, ra);   // after the mapping, same stream
+    else hipLaunchKernelGGL(k_resolve<true>, dim3(1), dim3(64), 0, sm, ra);
     HIPCHK(c, hipGetLastError());
     std::vector<SeqResult> out(P);
-    HIPCHK(c, hipMemcpyAsync(out.data(), c->seq_out.p, P * sizeof(SeqResult), hipMemcpyDeviceToHost, c->s_map));
+    HIPCHK(c, hipMemcpyAsync(out.data(), c->seq_out.p, P * sizeof(SeqResult), hipMemcpyDeviceToHost, sm));
     rc = nhdfit_sync(c);
     if (rc) return rc;
     for (uint32_t i = 0; i < P; ++i) {

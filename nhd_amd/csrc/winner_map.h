@@ -359,9 +359,6 @@ NHD_HD uint32_t nic_codes_from_table_bits(uint32_t bits, int G, int U) {
     return out;
 }
 
-// Restatement of the winner-only tail of FindNode (Matcher.py:337-391 + 423-452).
-// `nic_codes`: bit c set = assignment with tuple code c has at least one valid NIC choice (after the
-// PCI pruning) - taken from the same reach tables the fit kernel used.  Returns false if infeasible.
 // GetNumaGroupIdx (Matcher.py:427-437) over one candidate list (= a set walked in slot order)
 template <class Ops>
 NHD_HD int pick_gpu_tuple(const typename Ops::Set& gset, int G, int U) {
@@ -414,18 +411,12 @@ NHD_HD bool choose_tuples(int G, int U, uint32_t sg_mask, uint32_t sc_mask, uint
     return ccode >= 0;
 }
 
-// Restatement of the winner-only tail of FindNode (Matcher.py:337-391 + 423-452).
-// `nic_codes`: bit c set = assignment with tuple code c has at least one valid NIC choice (after the
-// PCI pruning) - taken from the same reach tables the fit kernel used.  Returns false if infeasible.
-template <class Ops>
-NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic_codes, nhdfit_mapping& out) {
+// Valid GPU / CPU(+misc) assignments of a pod on the winner as bit sets over tuple codes
+// (Matcher.py:116-141, 206-220: the sets `stmp` before they are turned into lists).
+NHD_HD void candidate_masks(const nhdfit_req& r, const WinnerState& w, uint32_t& sg_mask, uint32_t& sc_mask) {
     const int G = (int)r.n_groups, U = w.U;
-    const bool pci = r.map_type == NHDFIT_MAP_PCI;
     const uint32_t nG = ipow(U, G), nC = ipow(U, G + 1);
-    out.valid = 0;
-    nic_codes &= (nG >= 32 ? 0u : (1u << nG)) - 1u;
-
-    uint32_t sg_mask = 0, sc_mask = 0;
+    sg_mask = sc_mask = 0;
     for (uint32_t code = 0; code < nG; ++code) {
         uint32_t t0 = 0, t1 = 0;
         for (int g = 0; g < G; ++g) { if (tup_digit(code, G, U, g)) t1 += r.gpus[g]; else t0 += r.gpus[g]; }
@@ -439,15 +430,21 @@ NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic
         }
         if (t0 <= (uint32_t)w.free_c[0] && t1 <= (uint32_t)w.free_c[1]) sc_mask |= 1u << code;
     }
-    if (!sg_mask || !sc_mask || !nic_codes) return false;
+}
 
-    uint32_t gcode = 0;
-    int ccode = -1;
-    const bool ok = choose_tuples<Ops>(G, U, sg_mask, sc_mask, nic_codes, gcode, ccode);
-    if (!ok) return false;
+// choose_tuples' whole input for G <= 3 in 35 bits (bit 63 marks "occupied" in the dedup table of the mapping
+// kernels): pods whose winners offer the same candidate sets share one run of the sequential set model.
+NHD_HD uint64_t shape_key(int G, int U, uint32_t sg_mask, uint32_t sc_mask, uint32_t nic_codes) {
+    return (1ull << 63) | (uint64_t)(G & 3) | ((uint64_t)(U - 1) << 2) | ((uint64_t)(sg_mask & 0xFF) << 3) |
+           ((uint64_t)(nic_codes & 0xFF) << 11) | ((uint64_t)(sc_mask & 0xFFFF) << 19);
+}
+
+// Fills the mapping once the GPU and CPU tuples are chosen (Matcher.py:446-452).
+NHD_HD bool finish_mapping(const nhdfit_req& r, const WinnerState& w, uint32_t gcode, int ccode, nhdfit_mapping& out) {
+    const int G = (int)r.n_groups, U = w.U;
     for (int g = 0; g < kMaxG; ++g) { out.gpu[g] = out.nic_numa[g] = out.nic_idx[g] = -1; }
     for (int g = 0; g <= kMaxG; ++g) out.cpu[g] = -1;
-    if (!first_nic_choice(r, w, gcode, pci, out.nic_idx)) return false;   // Matcher.py:446-449
+    if (!first_nic_choice(r, w, gcode, r.map_type == NHDFIT_MAP_PCI, out.nic_idx)) return false;
     for (int g = 0; g < G; ++g) {
         out.gpu[g] = (int8_t)tup_digit(gcode, G, U, g);
         out.nic_numa[g] = out.gpu[g];
@@ -455,6 +452,24 @@ NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic
     for (int g = 0; g <= G; ++g) out.cpu[g] = (int8_t)tup_digit((uint32_t)ccode, G + 1, U, g);
     out.valid = 1;
     return true;
+}
+
+// Restatement of the winner-only tail of FindNode (Matcher.py:337-391 + 423-452).
+// `nic_codes`: bit c set = assignment with tuple code c has at least one valid NIC choice (after the
+// PCI pruning) - taken from the same reach tables the fit kernel used.  Returns false if infeasible.
+template <class Ops>
+NHD_HD bool map_winner_t(const nhdfit_req& r, const WinnerState& w, uint32_t nic_codes, nhdfit_mapping& out) {
+    const int G = (int)r.n_groups, U = w.U;
+    const uint32_t nG = ipow(U, G);
+    out.valid = 0;
+    nic_codes &= (nG >= 32 ? 0u : (1u << nG)) - 1u;
+    uint32_t sg_mask, sc_mask;
+    candidate_masks(r, w, sg_mask, sc_mask);
+    if (!sg_mask || !sc_mask || !nic_codes) return false;
+    uint32_t gcode = 0;
+    int ccode = -1;
+    if (!choose_tuples<Ops>(G, U, sg_mask, sc_mask, nic_codes, gcode, ccode)) return false;
+    return finish_mapping(r, w, gcode, ccode, out);
 }
 
 // G <= 3: every set stays within 32 slots -> register-resident model; G == 4: generic model.
