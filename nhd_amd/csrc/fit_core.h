@@ -24,16 +24,17 @@
 // tabulated too: one 64-bit word per node-side value holds the verdict for all 64 pods of a tile.
 //
 // ---- table image of one 64-pod tile (staged in LDS by the fit kernel) ---------------------------
-//   16-bit rows: 64 pods x uint16 (bit p = assignment p passes), kRowBytes apart; pod j sits in halfword
-//   slot16(j): the two halves of 32-bit word w hold pods (w, w+16) resp. (16+w, 32+w..) so that a packed
-//   per-half "non-zero" test lands the verdicts of 32 pods in pod order inside one 32-bit register
-//     W0[smt][c][m]  c free cores on socket 0:  m=0: sumC(S0) <= c      m=1: sumC(S0)+misc <= c
-//     W1[smt][c][m]  c free cores on socket 1:  m=0: sumC(S1) <= c      m=1: sumC(S1)+misc <= c
-//                    cpu_ok = (W0[.][1] & W1[.][0]) | (W0[.][0] & W1[.][1])
+//   Bit-sliced: every table row holds, for each NUMA assignment p, ONE 64-bit word whose bit j says
+//   "assignment p of pod j passes this test".  Row = W words (W = 2^maxG of the batch) + 8 B pad.
+//     W0[m][smt][c]  c free cores on socket 0:  m=0: sumC(S0) <= c      m=1: sumC(S0)+misc <= c
+//     W1[m][smt][c]  c free cores on socket 1:  m=0: sumC(S1) <= c      m=1: sumC(S1)+misc <= c
+//                    cpu_ok = (W0[1] & W1[0]) | (W0[0] & W1[1])
 //     A[f0][f1]      free GPUs on NUMA 0 / 1:   sumG(S0) <= f0 && sumG(S1) <= f1
 //     R0[sig]        NIC signature of NUMA 0:   S0(p) in reach(sig)
 //     R1[sig]        NIC signature of NUMA 1:   S1(p) in reach(sig)
-//   64-bit rows: bit j = verdict for pod j of the tile
+//   so  feasible pods of a node = OR over p of (cpu_ok & A & R0 & R1)[p]  -  five/seven 64-bit ANDs per
+//   assignment serve all 64 pods at once, and no per-pod "any assignment left?" test is needed.
+//   64-bit scalar-predicate rows (bit j = verdict for pod j):
 //     HP[k]          k = clamp(free hugepages, -1, hp_max) + 1:  pod valid && hp_req <= free
 //     GF[gs]         node-group set id: pod does not filter || sets intersect  (NHDScheduler.py:240)
 #pragma once
@@ -50,27 +51,26 @@ namespace nhdfit {
 
 constexpr int kMaxG      = NHDFIT_MAX_GROUPS;
 constexpr int kTile      = NHDFIT_TILE;
-constexpr int kRowBytes  = kTile * 2 + 16;           // 144: 16-byte aligned rows (ds_read_b128 = 8 pods); row r starts at
-                                                     // 16-byte slot 9r mod 16, so 16 different rows never share LDS banks
 constexpr int kMaxHpRows = 1024;                     // hugepage table rows (larger requests are clamped, see hp_bit)
 constexpr double kMinBusySecs = 30.0;                // Node.MIN_BUSY_SECS, nhd/Node.py:107
-
-// halfword index of pod j (0..63) inside a 16-bit row: word w = (j & 15) + 16 * (j >> 5), half = (j >> 4) & 1
-NHD_HD uint32_t slot16(uint32_t j) { return 2 * ((j & 15u) + 16u * (j >> 5)) + ((j >> 4) & 1u); }
 
 struct Layout {
     uint32_t fc_dim;     // 1 + max physical cores on one socket anywhere in the cluster (<= 65)
     uint32_t fg_dim;     // 1 + max GPUs installed on one NUMA node anywhere in the cluster (<= 9)
     uint32_t nsig, ngs;  // NIC signatures, node-group sets
     uint32_t hp_rows;    // 2 + largest hugepage request of the staged batch (capped at kMaxHpRows)
-    uint32_t row_w1, row_a, row_r0, row_r1, rows16;   // first 16-bit row of each table (W0 starts at 0)
+    uint32_t W;          // assignments per pod the rows provide for: 2^(largest group count of the staged batch)
+    uint32_t row_bytes;  // W * 8 + 8: 8-byte aligned, and 18 r mod 64 banks: 32 different rows never collide
+    uint32_t row_w1, row_a, row_r0, row_r1, rows16;   // first row of each assignment table (W0 starts at 0)
     uint32_t off_hp, off_gf;                           // byte offsets of the 64-bit tables
     uint32_t bytes;                                    // image size, multiple of 16
 };
 
 NHD_HD Layout make_layout(uint32_t max_cores_per_numa, uint32_t max_gpus_per_numa, uint32_t nsig, uint32_t ngs,
-                          uint32_t hp_rows) {
+                          uint32_t hp_rows, uint32_t max_groups) {
     Layout l;
+    l.W = 1u << max_groups;
+    l.row_bytes = l.W * 8 + 8;
     l.fc_dim = max_cores_per_numa + 1;
     l.fg_dim = max_gpus_per_numa + 1;
     l.nsig = nsig;
@@ -81,7 +81,7 @@ NHD_HD Layout make_layout(uint32_t max_cores_per_numa, uint32_t max_gpus_per_num
     l.row_r0 = l.row_a + l.fg_dim * l.fg_dim;
     l.row_r1 = l.row_r0 + nsig;
     l.rows16 = l.row_r1 + nsig;
-    l.off_hp = l.rows16 * kRowBytes;
+    l.off_hp = l.rows16 * l.row_bytes;
     l.off_gf = l.off_hp + hp_rows * 8;
     l.bytes = (l.off_gf + ngs * 8 + 15u) & ~15u;
     return l;
@@ -97,6 +97,7 @@ constexpr uint32_t kPodValid   = 1u;   // map type NUMA or PCI, 1 <= G <= kMaxG
 constexpr uint32_t kPodNeedGpu = 2u;   // sum(gpus) > 0  (== any group has GPUs, Matcher.py:403-407)
 constexpr uint32_t kPodPci     = 4u;
 constexpr uint32_t kPodFilter  = 8u;   // apply InitialNodeFilter
+constexpr uint32_t kPodGroupsShift = 4;   // bits 4..6: n_groups (lets the fit kernel skip assignments no pod of a tile has)
 
 NHD_HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
 NHD_HD int popc32(uint32_t x) { return __builtin_popcount(x); }
@@ -141,6 +142,7 @@ NHD_HD PodHeader pod_header(const nhdfit_req& r) {
         if (g) h.flags |= kPodNeedGpu;
         if (r.map_type == NHDFIT_MAP_PCI) h.flags |= kPodPci;
         if (r.flags & NHDFIT_RF_INITIAL_FILTER) h.flags |= kPodFilter;
+        h.flags |= r.n_groups << kPodGroupsShift;
     }
     return h;
 }
@@ -278,17 +280,17 @@ NHD_HD NodeLane node_lane(const nhdfit_plane0& a, const nhdfit_plane1& b, const 
     uint32_t c0 = popc64(a.t0[0] & b.t1[0]), c1 = popc64(a.t0[1] & b.t1[1]);       // free physical cores, nhd/Node.py:250-264
     c0 = c0 < L.fc_dim ? c0 : L.fc_dim - 1;
     c1 = c1 < L.fc_dim ? c1 : L.fc_dim - 1;
-    n.off_w0 = (smt + c0) * kRowBytes;
-    n.off_w1 = (L.row_w1 + smt + c1) * kRowBytes;
-    n.w_misc = 2 * L.fc_dim * kRowBytes;
+    n.off_w0 = (smt + c0) * L.row_bytes;
+    n.off_w1 = (L.row_w1 + smt + c1) * L.row_bytes;
+    n.w_misc = 2 * L.fc_dim * L.row_bytes;
     uint32_t f0 = popc32(c.gpu_free & ~c.gpu_numa1), f1 = popc32(c.gpu_free & c.gpu_numa1);   // nhd/Node.py:456-462
     f0 = f0 < L.fg_dim ? f0 : L.fg_dim - 1;
     f1 = f1 < L.fg_dim ? f1 : L.fg_dim - 1;
-    n.off_a = (L.row_a + f0 * L.fg_dim + f1) * kRowBytes;
-    n.off_r0n = (L.row_r0 + d.sig_numa[0]) * kRowBytes;
-    n.off_r1n = (L.row_r1 + d.sig_numa[1]) * kRowBytes;
-    n.off_r0p = (L.row_r0 + d.sig_pci[0]) * kRowBytes;
-    n.off_r1p = (L.row_r1 + d.sig_pci[1]) * kRowBytes;
+    n.off_a = (L.row_a + f0 * L.fg_dim + f1) * L.row_bytes;
+    n.off_r0n = (L.row_r0 + d.sig_numa[0]) * L.row_bytes;
+    n.off_r1n = (L.row_r1 + d.sig_numa[1]) * L.row_bytes;
+    n.off_r0p = (L.row_r0 + d.sig_pci[0]) * L.row_bytes;
+    n.off_r1p = (L.row_r1 + d.sig_pci[1]) * L.row_bytes;
     int32_t hp = c.hp_free;
     hp = hp < -1 ? -1 : hp;
     hp = hp > (int32_t)L.hp_rows - 2 ? (int32_t)L.hp_rows - 2 : hp;
@@ -300,9 +302,6 @@ NHD_HD NodeLane node_lane(const nhdfit_plane0& a, const nhdfit_plane1& b, const 
     return n;
 }
 
-NHD_HD uint32_t ld16(const uint8_t* img, uint32_t off, uint32_t col) {
-    return reinterpret_cast<const uint16_t*>(img + off)[slot16(col)];
-}
 NHD_HD uint64_t ld64(const uint8_t* img, uint32_t off) { return *reinterpret_cast<const uint64_t*>(img + off); }
 
 // Scalar predicates of one node against all 64 pods of the tile (bit j = pod j may consider the node).
@@ -316,20 +315,29 @@ NHD_HD uint64_t node_pod_mask(const NodeLane& n, const uint8_t* img, uint64_t m_
     return m;
 }
 
-// NUMA-assignment feasibility of one (pod, node) pair: pod = column `col` of the tile image.
-NHD_HD bool eval_assignments(const NodeLane& n, const uint8_t* img, uint32_t col, bool pci) {
-    const uint32_t cpu = (ld16(img, n.off_w0 + n.w_misc, col) & ld16(img, n.off_w1, col)) |
-                         (ld16(img, n.off_w0, col) & ld16(img, n.off_w1 + n.w_misc, col));
-    const uint32_t ok = cpu & ld16(img, n.off_a, col) &
-                        ld16(img, pci ? n.off_r0p : n.off_r0n, col) & ld16(img, pci ? n.off_r1p : n.off_r1n, col);
-    return ok != 0;
+// Pods of the tile (bit j) for which SOME NUMA assignment passes the CPU, GPU and NIC tests on this node.
+// m_pci: tile mask of pods in PCI mode (they read the PCI-mode NIC rows).
+NHD_HD uint64_t node_assignment_mask(const NodeLane& n, const uint8_t* img, uint32_t W, uint64_t m_pci) {
+    uint64_t acc = 0;
+    for (uint32_t p = 0; p < W; ++p) {
+        const uint32_t o = p * 8;
+        const uint64_t cpu = (ld64(img, n.off_w0 + n.w_misc + o) & ld64(img, n.off_w1 + o)) |
+                             (ld64(img, n.off_w0 + o) & ld64(img, n.off_w1 + n.w_misc + o));
+        const uint64_t r0 = (ld64(img, n.off_r0p + o) & m_pci) | (ld64(img, n.off_r0n + o) & ~m_pci);
+        const uint64_t r1 = (ld64(img, n.off_r1p + o) & m_pci) | (ld64(img, n.off_r1n + o) & ~m_pci);
+        acc |= cpu & ld64(img, n.off_a + o) & r0 & r1;
+    }
+    return acc;
 }
 
 // NIC-feasible assignment bits (bit p) of one (pod, node) pair, for the winner mapping
 NHD_HD uint32_t nic_assignment_bits(const uint8_t* img, const Layout& L, uint32_t col, bool pci, const nhdfit_plane3& q3) {
-    const uint32_t r0 = ld16(img, (L.row_r0 + (pci ? q3.sig_pci[0] : q3.sig_numa[0])) * kRowBytes, col);
-    const uint32_t r1 = ld16(img, (L.row_r1 + (pci ? q3.sig_pci[1] : q3.sig_numa[1])) * kRowBytes, col);
-    return r0 & r1;
+    const uint32_t o0 = (L.row_r0 + (pci ? q3.sig_pci[0] : q3.sig_numa[0])) * L.row_bytes;
+    const uint32_t o1 = (L.row_r1 + (pci ? q3.sig_pci[1] : q3.sig_numa[1])) * L.row_bytes;
+    uint32_t bits = 0;
+    for (uint32_t p = 0; p < L.W; ++p)
+        if ((ld64(img, o0 + p * 8) & ld64(img, o1 + p * 8)) >> col & 1) bits |= 1u << p;
+    return bits;
 }
 
 // ---- selection (Matcher.py:393-421) ----------------------------------------------------------

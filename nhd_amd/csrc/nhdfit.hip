@@ -91,15 +91,20 @@ __global__ __launch_bounds__(kDigestThreads) void k_digest(const nhdfit_req* __r
     }
     __syncthreads();
 
-    // 16-bit rows: one thread per (row, pod)
-    for (uint32_t w = slice * kDigestThreads + tid; w < L.rows16 * kTile; w += kDigestSlices * kDigestThreads) {
-        const uint32_t j = w % kTile, row = w / kTile;
-        uint32_t v = 0;
-        if (s_hdr[j].flags & kPodValid) v = row16_entry(L, s_sum[j], d.sig, &s_cover[j][0][0], row);
-        reinterpret_cast<uint16_t*>(img + row * kRowBytes)[slot16(j)] = (uint16_t)v;
-    }
-    // 64-bit rows: one wavefront per row, ballot over the 64 pods
+    // assignment rows, bit-sliced: one wavefront per row, lane = pod computes its 16-bit entry, one ballot per
+    // assignment gives the row's W words (bit j of word p = assignment p of pod j passes)
     const uint32_t wave = tid >> 6, lane = tid & 63;
+    for (uint32_t row = slice * (kDigestThreads / 64) + wave; row < L.rows16; row += kDigestSlices * (kDigestThreads / 64)) {
+        uint32_t v = 0;
+        if (s_hdr[lane].flags & kPodValid) v = row16_entry(L, s_sum[lane], d.sig, &s_cover[lane][0][0], row);
+        unsigned long long mine = 0;
+        for (uint32_t p = 0; p < L.W; ++p) {
+            const unsigned long long word = __ballot(v >> p & 1);
+            if (lane == p) mine = word;
+        }
+        if (lane < L.W) *reinterpret_cast<unsigned long long*>(img + row * L.row_bytes + lane * 8) = mine;
+    }
+    // 64-bit scalar-predicate rows: one wavefront per row, ballot over the 64 pods
     const uint32_t nrows64 = L.hp_rows + L.ngs;
     for (uint32_t k = slice * (kDigestThreads / 64) + wave; k < nrows64; k += kDigestSlices * (kDigestThreads / 64)) {
         const bool bit = k < L.hp_rows ? hp_bit(s_hdr[lane], L, k) : gf_bit(s_hdr[lane], d.group_sets[k - L.hp_rows]);
@@ -154,24 +159,53 @@ __device__ __forceinline__ void transpose64(uint32_t& lo, uint32_t& hi, uint32_t
     lo = xpose_step<1>(lo, lane);  hi = xpose_step<1>(hi, lane);
 }
 
-__device__ __forceinline__ uint4 lds16(const uint8_t* img, uint32_t off) {
-    return *reinterpret_cast<const uint4*>(__builtin_assume_aligned(img + off, 16));
-}
-__device__ __forceinline__ uint32_t pick(const uint4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 
-// two pods per 32-bit word: (cpu placement with the misc cores on either socket) & GPU & NIC NUMA-0 & NIC NUMA-1
-__device__ __forceinline__ uint32_t assignments_ok(uint32_t w0, uint32_t w0m, uint32_t w1, uint32_t w1m, uint32_t ga,
-                                                   uint32_t r0, uint32_t r1) {
-    const uint32_t t1 = __builtin_amdgcn_bitop3_b32(w0m, w1, ga, 0x80);      // a & b & c
-    const uint32_t t2 = __builtin_amdgcn_bitop3_b32(w0, w1m, ga, 0x80);
-    const uint32_t t3 = __builtin_amdgcn_bitop3_b32(t1, t2, r0, 0xA8);       // (a | b) & c
-    return t3 & r1;
+__device__ __forceinline__ uint2 lds8(const uint8_t* img, uint32_t off) {
+    return *reinterpret_cast<const uint2*>(__builtin_assume_aligned(img + off, 8));
 }
-// per 16-bit half: 1 if any assignment bit is set, else 0
-__device__ __forceinline__ uint32_t nonzero_halves(uint32_t ok) {
-    uint32_t nz;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(ok), "v"(0x00010001u));
-    return nz;
+
+// Pods of the tile (bit j) for which some NUMA assignment passes CPU & GPU & NIC on this lane's node.
+// One 64-bit word per (table row, assignment) serves all 64 pods: per assignment 7 LDS words, 8 VALU ops.
+template <int W, bool MIXED>
+__device__ __forceinline__ uint64_t sweep_assignments(const uint8_t* img, const NodeLane& nl, uint32_t o_r0, uint32_t o_r1,
+                                                      uint64_t m_pci) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int p = 0; p < W; ++p) {
+        const uint32_t o = p * 8;
+        const uint2 w0 = lds8(img, nl.off_w0 + o), w0m = lds8(img, nl.off_w0 + nl.w_misc + o);
+        const uint2 w1 = lds8(img, nl.off_w1 + o), w1m = lds8(img, nl.off_w1 + nl.w_misc + o);
+        const uint2 ga = lds8(img, nl.off_a + o);
+        uint2 r0 = lds8(img, o_r0 + o), r1 = lds8(img, o_r1 + o);
+        if (MIXED) {             // tile with NUMA- and PCI-mode pods: per-pod choice of the NIC rows
+            const uint2 q0 = lds8(img, nl.off_r0p + o), q1 = lds8(img, nl.off_r1p + o);
+            const uint32_t ml = (uint32_t)m_pci, mh = (uint32_t)(m_pci >> 32);
+            r0.x = (q0.x & ml) | (r0.x & ~ml); r0.y = (q0.y & mh) | (r0.y & ~mh);
+            r1.x = (q1.x & ml) | (r1.x & ~ml); r1.y = (q1.y & mh) | (r1.y & ~mh);
+        }
+        {   // low 32 pods
+            const uint32_t cpu = (w0m.x & w1.x) | (w0.x & w1m.x);
+            const uint32_t t = __builtin_amdgcn_bitop3_b32(cpu, ga.x, r0.x, 0x80);          // a & b & c
+            lo = __builtin_amdgcn_bitop3_b32(t, r1.x, lo, 0xEA);                             // (a & b) | c
+        }
+        {   // high 32 pods
+            const uint32_t cpu = (w0m.y & w1.y) | (w0.y & w1m.y);
+            const uint32_t t = __builtin_amdgcn_bitop3_b32(cpu, ga.y, r0.y, 0x80);
+            hi = __builtin_amdgcn_bitop3_b32(t, r1.y, hi, 0xEA);
+        }
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <bool MIXED>
+__device__ __forceinline__ uint64_t sweep_dispatch(uint32_t W, const uint8_t* img, const NodeLane& nl, uint32_t o_r0,
+                                                   uint32_t o_r1, uint64_t m_pci) {
+    switch (W) {                                    // wave-uniform
+        case 2: return sweep_assignments<2, MIXED>(img, nl, o_r0, o_r1, m_pci);
+        case 4: return sweep_assignments<4, MIXED>(img, nl, o_r0, o_r1, m_pci);
+        case 8: return sweep_assignments<8, MIXED>(img, nl, o_r0, o_r1, m_pci);
+        default: return sweep_assignments<16, MIXED>(img, nl, o_r0, o_r1, m_pci);
+    }
 }
 
 template <int BLOCK>
@@ -203,6 +237,9 @@ __global__ __launch_bounds__(BLOCK) void k_fit_score(FitArgs a) {
     const uint64_t m_filt = __ballot((my_h.flags & kPodFilter) != 0);
     // requests are staged sorted by class, so almost every tile is all-PCI or all-NUMA
     const bool pci_uniform = m_pci == 0 || m_pci == ~0ull;
+    // assignments the tile needs: 2^(largest group count among its pods) - tiles are sorted by class and size
+    const uint32_t my_g = (my_h.flags >> kPodGroupsShift) & 7u;
+    const uint32_t Wt = __ballot(my_g >= 4) ? 16u : __ballot(my_g == 3) ? 8u : __ballot(my_g == 2) ? 4u : 2u;
     unsigned long long best = 0;
 
     const uint32_t c_begin = range * a.chunks_per_block;
@@ -215,51 +252,13 @@ __global__ __launch_bounds__(BLOCK) void k_fit_score(FitArgs a) {
         if (live) nl = node_lane(a.p0[i], a.p1[i], a.p2[i], a.p3[i], a.p4[i], a.now, a.layout);
         const uint64_t nogpu = __ballot(live && !(nl.flags & NHDFIT_NF_HAS_GPU));
 
-        // (1) NUMA-assignment feasibility against all 64 pods, in the lane = node domain: 16-bit table rows,
-        //     8 pods per 16-byte LDS gather, two pods per 32-bit VALU op.  "Some assignment survives" is a
-        //     packed non-zero test per 16-bit half (v_pk_min_u16 with 1); thanks to the slot16() column
-        //     order the 0/1 results of word w drop into bits w and w+16 of a 32-pod accumulator.
-        uint32_t acc[2] = {0, 0};                                // pods 0..31, pods 32..63
-        if (pci_uniform) {
-            const uint32_t o_r0 = m_pci ? nl.off_r0p : nl.off_r0n;
-            const uint32_t o_r1 = m_pci ? nl.off_r1p : nl.off_r1n;
-#pragma unroll
-            for (uint32_t q = 0; q < (uint32_t)kTile / 8; ++q) {
-                const uint32_t cb = q * 16;                      // 4 words = 8 pods
-                const uint4 w0 = lds16(img, nl.off_w0 + cb), w0m = lds16(img, nl.off_w0 + nl.w_misc + cb);
-                const uint4 w1 = lds16(img, nl.off_w1 + cb), w1m = lds16(img, nl.off_w1 + nl.w_misc + cb);
-                const uint4 ga = lds16(img, nl.off_a + cb);
-                const uint4 r0 = lds16(img, o_r0 + cb), r1 = lds16(img, o_r1 + cb);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    acc[q >> 2] |= nonzero_halves(assignments_ok(pick(w0, k), pick(w0m, k), pick(w1, k), pick(w1m, k),
-                                                                 pick(ga, k), pick(r0, k), pick(r1, k))) << ((q & 3) * 4 + k);
-            }
-        } else {
-            // mixed tile (class boundary, rare): read both NIC row variants and pick per pod
-#pragma unroll 1
-            for (uint32_t q = 0; q < (uint32_t)kTile / 8; ++q) {
-                const uint32_t cb = q * 16;
-                const uint4 w0 = lds16(img, nl.off_w0 + cb), w0m = lds16(img, nl.off_w0 + nl.w_misc + cb);
-                const uint4 w1 = lds16(img, nl.off_w1 + cb), w1m = lds16(img, nl.off_w1 + nl.w_misc + cb);
-                const uint4 ga = lds16(img, nl.off_a + cb);
-                const uint4 r0n = lds16(img, nl.off_r0n + cb), r1n = lds16(img, nl.off_r1n + cb);
-                const uint4 r0p = lds16(img, nl.off_r0p + cb), r1p = lds16(img, nl.off_r1p + cb);
-                uint32_t part = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t w = (q & 3) * 4 + k, base = (q >> 2) * 32;      // word w holds pods base+w, base+w+16
-                    const uint32_t sel = ((m_pci >> (base + w) & 1) ? 0xFFFFu : 0u) | ((m_pci >> (base + w + 16) & 1) ? 0xFFFF0000u : 0u);
-                    const uint32_t r0 = (pick(r0p, k) & sel) | (pick(r0n, k) & ~sel);
-                    const uint32_t r1 = (pick(r1p, k) & sel) | (pick(r1n, k) & ~sel);
-                    part |= nonzero_halves(assignments_ok(pick(w0, k), pick(w0m, k), pick(w1, k), pick(w1m, k), pick(ga, k), r0, r1)) << k;
-                }
-                if (q >> 2) acc[1] |= part << ((q & 3) * 4); else acc[0] |= part << ((q & 3) * 4);
-            }
-        }
+        // (1) NUMA-assignment feasibility against all 64 pods, in the lane = node domain (bit-sliced tables)
+        uint64_t okm;
+        if (pci_uniform) okm = sweep_dispatch<false>(Wt, img, nl, m_pci ? nl.off_r0p : nl.off_r0n, m_pci ? nl.off_r1p : nl.off_r1n, m_pci);
+        else okm = sweep_dispatch<true>(Wt, img, nl, nl.off_r0n, nl.off_r1n, m_pci);
         // (2) scalar predicates of this lane's node against all 64 pods (one 64-bit word per table row)
         const uint64_t fm = node_pod_mask(nl, img, m_filt, m_need);
-        uint32_t wlo = acc[0] & (uint32_t)fm, whi = acc[1] & (uint32_t)(fm >> 32);
+        uint32_t wlo = (uint32_t)(okm & fm), whi = (uint32_t)((okm & fm) >> 32);
         // (3) 64 x 64 bit transpose: lane j now holds pod j's verdict over the chunk's 64 nodes
         transpose64(wlo, whi, lane);
         uint64_t word = ((uint64_t)whi << 32) | wlo;
@@ -746,7 +745,7 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     if (max_cores_per_numa < 1 || max_cores_per_numa > NHDFIT_MAX_CORES_PER_NUMA)
         return fail(c, NHDFIT_E_LIMIT, "%u cores per socket (supported: 1..%d)", max_cores_per_numa, NHDFIT_MAX_CORES_PER_NUMA);
     if (n_group_sets && !group_sets) return fail(c, NHDFIT_E_INVAL, "NULL group set table");
-    const Layout L = make_layout(max_cores_per_numa, max_gpus_per_numa, nsig, n_group_sets ? n_group_sets : 1, kMaxHpRows);
+    const Layout L = make_layout(max_cores_per_numa, max_gpus_per_numa, nsig, n_group_sets ? n_group_sets : 1, kMaxHpRows, kMaxG);
     HIPCHK(c, hipSetDevice(c->dev));
     if (L.bytes + 4096 > 160 * 1024)
         return fail(c, NHDFIT_E_LIMIT, "%u NIC signatures / %u node-group sets need %u bytes of LDS per tile (160 KiB per CU)",
@@ -826,13 +825,15 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     const uint32_t tiles = (P + kTile - 1) / kTile;
     const uint32_t chunks = (c->capacity + 63) / 64;
     int32_t hp_max = 0;
+    uint32_t g_max = 1;
     for (uint32_t p = 0; p < P; ++p) {
         if (reqs[p].hugepages_gb < 0) return fail(c, NHDFIT_E_INVAL, "pod %u asks for a negative number of hugepages", p);
         hp_max = reqs[p].hugepages_gb > hp_max ? reqs[p].hugepages_gb : hp_max;
+        if (req_valid(reqs[p]) && reqs[p].n_groups > g_max) g_max = reqs[p].n_groups;
     }
     if (hp_max > kMaxHpRows - 2)
         return fail(c, NHDFIT_E_LIMIT, "a pod asks for %d GiB of hugepages (limit %d)", hp_max, kMaxHpRows - 2);
-    c->layout = make_layout(c->max_cores, c->max_gpus, c->nsig, c->ngs, (uint32_t)hp_max + 2);
+    c->layout = make_layout(c->max_cores, c->max_gpus, c->nsig, c->ngs, (uint32_t)hp_max + 2, g_max);
     c->lds_bytes = c->layout.bytes;
     HIPCHK(c, c->reqs.reserve(P));
     for (int b = 0; b < kBufs; ++b) {

@@ -32,8 +32,11 @@ void build_tile(const nhdfit_req* reqs, uint32_t npods, const Dict& d, const Lay
         PodSums s;
         pod_sums(r, s);
         for (uint32_t c = 0; c < d.ncls; ++c) class_cover(r, d.caps[c], s.W, s.G, &cover[c * (kMaxG + 1)]);
-        for (uint32_t row = 0; row < L.rows16; ++row)
-            reinterpret_cast<uint16_t*>(img + row * kRowBytes)[slot16(j)] = (uint16_t)row16_entry(L, s, d.sig, cover.data(), row);
+        for (uint32_t row = 0; row < L.rows16; ++row) {
+            const uint32_t v = row16_entry(L, s, d.sig, cover.data(), row);
+            for (uint32_t p = 0; p < L.W; ++p)
+                if (v >> p & 1) *reinterpret_cast<uint64_t*>(img + row * L.row_bytes + p * 8) |= 1ull << j;
+        }
     }
 }
 }  // namespace
@@ -50,19 +53,24 @@ void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plan
              int force_generic) {
     const uint32_t chunks = (n + 63) / 64;
     int32_t hpmax = 0;
-    for (uint32_t p = 0; p < P; ++p) hpmax = reqs[p].hugepages_gb > hpmax ? reqs[p].hugepages_gb : hpmax;
+    uint32_t gmax = 1;
+    for (uint32_t p = 0; p < P; ++p) {
+        hpmax = reqs[p].hugepages_gb > hpmax ? reqs[p].hugepages_gb : hpmax;
+        if (req_valid(reqs[p]) && reqs[p].n_groups > gmax) gmax = reqs[p].n_groups;
+    }
     const Dict d{fcmax, fgmax, gs, ngs, caps, ncls, SigDict{sig_off, pool_off, pool_glimit, cc, nsig}};
-    const Layout L = make_layout(fcmax, fgmax, nsig, ngs, (uint32_t)hpmax + 2);
+    const Layout L = make_layout(fcmax, fgmax, nsig, ngs, (uint32_t)hpmax + 2, gmax);
     std::vector<uint8_t> img(L.bytes);
     std::vector<PodHeader> hdr(kTile);
     for (uint32_t p = 0; p < P; ++p) score[p] = 0;
     for (uint32_t t0 = 0; t0 < P; t0 += kTile) {
         const uint32_t np = P - t0 < (uint32_t)kTile ? P - t0 : kTile;
         build_tile(reqs + t0, np, d, L, img.data(), hdr.data());
-        uint64_t m_filt = 0, m_need = 0;
+        uint64_t m_filt = 0, m_need = 0, m_pci = 0;
         for (uint32_t j = 0; j < np; ++j) {
             if (hdr[j].flags & kPodFilter) m_filt |= 1ull << j;
             if (hdr[j].flags & kPodNeedGpu) m_need |= 1ull << j;
+            if (hdr[j].flags & kPodPci) m_pci |= 1ull << j;
         }
         for (uint32_t c = 0; c < chunks; ++c) {
             uint64_t nogpu = 0;
@@ -72,13 +80,14 @@ void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plan
             for (uint32_t l = 0; l < cnt; ++l) {
                 const uint32_t i = c * 64 + l;
                 lanes[l] = node_lane(p0[i], p1[i], p2[i], p3[i], p4[i], now, L);
-                fm[l] = node_pod_mask(lanes[l], img.data(), m_filt, m_need);
+                fm[l] = node_pod_mask(lanes[l], img.data(), m_filt, m_need) &
+                        node_assignment_mask(lanes[l], img.data(), L.W, m_pci);
                 if (!(p2[i].flags & NHDFIT_NF_HAS_GPU)) nogpu |= 1ull << l;
             }
             for (uint32_t j = 0; j < np; ++j) {
                 uint64_t w = 0;
                 for (uint32_t l = 0; l < cnt; ++l)
-                    if ((fm[l] >> j & 1) && eval_assignments(lanes[l], img.data(), j, hdr[j].flags & kPodPci)) w |= 1ull << l;
+                    if (fm[l] >> j & 1) w |= 1ull << l;
                 if (cand) w &= cand[(size_t)c * P + t0 + j];
                 if (bitmap) bitmap[(size_t)c * P + t0 + j] = w;
                 const uint64_t s = chunk_score(w, nogpu, hdr[j].flags & kPodNeedGpu, global_base + (uint64_t)c * 64);
