@@ -47,7 +47,7 @@ struct DictView {
 extern "C" __device__ int nhd_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
 constexpr int kDigestThreads = 256;
-constexpr int kDigestSlices = 16;
+constexpr int kDigestSlices = 8;
 
 // grid = (tiles, kDigestSlices).  Every block rebuilds the (cheap) per-pod sums / covers of its tile
 // in LDS, then fills its share of the table rows; consecutive threads write consecutive columns.
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kDigestThreads) void k_digest(const nhdfit_req* __r
     // assignment rows, bit-sliced: one wavefront per row, lane = pod computes its 16-bit entry, one ballot per
     // assignment gives the row's W words (bit j of word p = assignment p of pod j passes)
     const uint32_t wave = tid >> 6, lane = tid & 63;
-    for (uint32_t row = slice * (kDigestThreads / 64) + wave; row < L.rows16; row += kDigestSlices * (kDigestThreads / 64)) {
+    for (uint32_t row = slice * (kDigestThreads / 64) + wave; row < L.rows16; row += gridDim.y * (kDigestThreads / 64)) {
         uint32_t v = 0;
         if (s_hdr[lane].flags & kPodValid) v = row16_entry(L, s_sum[lane], d.sig, &s_cover[lane][0][0], row);
         unsigned long long mine = 0;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kDigestThreads) void k_digest(const nhdfit_req* __r
     }
     // 64-bit scalar-predicate rows: one wavefront per row, ballot over the 64 pods
     const uint32_t nrows64 = L.hp_rows + L.ngs;
-    for (uint32_t k = slice * (kDigestThreads / 64) + wave; k < nrows64; k += kDigestSlices * (kDigestThreads / 64)) {
+    for (uint32_t k = slice * (kDigestThreads / 64) + wave; k < nrows64; k += gridDim.y * (kDigestThreads / 64)) {
         const bool bit = k < L.hp_rows ? hp_bit(s_hdr[lane], L, k) : gf_bit(s_hdr[lane], d.group_sets[k - L.hp_rows]);
         const uint64_t word = __ballot(bit);
         if (lane == 0)
@@ -137,26 +137,57 @@ struct FitArgs {
 
 // One step of the 64 x 64 bit-matrix transpose across a wavefront: exchange S x S sub-blocks between
 // lanes l and l ^ S (S < 32, inside one 32-bit register).
+// Value of x in lane (l ^ S), S in {1, 2, 4}: DPP moves inside a row of 16 lanes - no LDS crossbar
+// (ds_bpermute), no address registers.
 template <int S>
-__device__ __forceinline__ uint32_t xpose_step(uint32_t x, uint32_t lane) {
-    constexpr uint32_t M = S == 16 ? 0x0000FFFFu : S == 8 ? 0x00FF00FFu : S == 4 ? 0x0F0F0F0Fu
-                                                 : S == 2 ? 0x33333333u : 0x55555555u;   // bits b with (b & S) == 0
-    const uint32_t y = (uint32_t)__shfl_xor((int)x, S, 64);
-    return (lane & S) ? (((y >> S) & M) | (x & ~M)) : ((x & M) | ((y << S) & ~M));
+__device__ __forceinline__ uint32_t from_lane_xor(uint32_t x) {
+    const int v = (int)x;
+    if constexpr (S == 1) return (uint32_t)__builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    else if constexpr (S == 2) return (uint32_t)__builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else {
+        const int y = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);     // row_shl:4 -> banks 0,2 read lane+4
+        return (uint32_t)__builtin_amdgcn_update_dpp(y, v, 0x114, 0xF, 0xA, false);  // row_shr:4 -> banks 1,3 read lane-4
+    }
+}
+
+// One butterfly stage (S = 4, 2, 1) of the bit transpose on both words: lanes l and l^S exchange the off-diagonal
+// S-bit blocks.  Branch-free: the partner's word rotated by +-S is merged under a per-lane mask (v_alignbit +
+// v_bfi).  The rotate amount and the mask are rebuilt from a constant SGPR lane mask in 3 instructions per stage
+// (volatile: kept out of the loop pre-header - as loop invariants they would pin 2 VGPRs per stage).
+template <int S>
+__device__ __forceinline__ void xpose_stage(uint32_t& lo, uint32_t& hi) {
+    constexpr uint32_t M = S == 4 ? 0x0F0F0F0Fu : S == 2 ? 0x33333333u : 0x55555555u;   // bits b with (b & S) == 0
+    constexpr uint64_t UP = S == 4 ? 0xF0F0F0F0F0F0F0F0ull : S == 2 ? 0xCCCCCCCCCCCCCCCCull : 0xAAAAAAAAAAAAAAAAull;   // lanes l with (l & S) != 0
+    uint32_t amt, sgn;
+    asm volatile("v_cndmask_b32_e64 %0, %2, %3, %4\n\tv_cndmask_b32_e64 %1, 0, -1, %4"
+                 : "=&v"(amt), "=v"(sgn) : "n"(32 - S), "n"(S), "s"(UP));
+    const uint32_t keep = M ^ sgn;                  // "up" lanes keep their high blocks, the others their low blocks
+    const uint32_t ylo = from_lane_xor<S>(lo), yhi = from_lane_xor<S>(hi);
+    const uint32_t rlo = __builtin_amdgcn_alignbit(ylo, ylo, amt), rhi = __builtin_amdgcn_alignbit(yhi, yhi, amt);
+    lo = (lo & keep) | (rlo & ~keep);
+    hi = (hi & keep) | (rhi & ~keep);
 }
 
 // in: lane l holds row l (bit j = column j) as (lo = columns 0..31, hi = columns 32..63);
-// out: lane j holds column j (bit l = row l).
-__device__ __forceinline__ void transpose64(uint32_t& lo, uint32_t& hi, uint32_t lane) {
+// out: lane j holds column j (bit l = row l).  ~45 VALU instructions, no LDS traffic.
+__device__ __forceinline__ void transpose64(uint32_t& lo, uint32_t& hi) {
     // 32 x 32 blocks: swap the hi word of lanes 0..31 with the lo word of lanes 32..63
-    const auto sw = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
-    lo = sw[0];
-    hi = sw[1];
-    lo = xpose_step<16>(lo, lane); hi = xpose_step<16>(hi, lane);
-    lo = xpose_step<8>(lo, lane);  hi = xpose_step<8>(hi, lane);
-    lo = xpose_step<4>(lo, lane);  hi = xpose_step<4>(hi, lane);
-    lo = xpose_step<2>(lo, lane);  hi = xpose_step<2>(hi, lane);
-    lo = xpose_step<1>(lo, lane);  hi = xpose_step<1>(hi, lane);
+    const auto s32 = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+    // 16 x 16 blocks of both words with one v_permlane16_swap: gather the low halves of (lo, hi) in one register and
+    // the high halves in another, swap [high halves of lanes l] with [low halves of lanes l + 16]
+    const uint32_t l16 = __builtin_amdgcn_perm(s32[1], s32[0], 0x05040100u), h16 = __builtin_amdgcn_perm(s32[1], s32[0], 0x07060302u);
+    const auto s16 = __builtin_amdgcn_permlane16_swap(l16, h16, false, false);
+    // 8 x 8 blocks: the same with bytes (the scatter of the previous stage folded into this gather); the swap is two
+    // DPP moves whose bank masks pick the receiving lanes: lanes 0-7 of a row get the partner's even bytes as their odd
+    // bytes, lanes 8-15 the partner's odd bytes as their even bytes
+    const uint32_t l8 = __builtin_amdgcn_perm(s16[1], s16[0], 0x06020400u), h8 = __builtin_amdgcn_perm(s16[1], s16[0], 0x07030501u);
+    const uint32_t h8x = (uint32_t)__builtin_amdgcn_update_dpp((int)h8, (int)l8, 0x128, 0xF, 0x3, false);   // row_ror:8
+    const uint32_t l8x = (uint32_t)__builtin_amdgcn_update_dpp((int)l8, (int)h8, 0x128, 0xF, 0xC, false);
+    lo = __builtin_amdgcn_perm(h8x, l8x, 0x05010400u);
+    hi = __builtin_amdgcn_perm(h8x, l8x, 0x07030602u);
+    xpose_stage<4>(lo, hi);
+    xpose_stage<2>(lo, hi);
+    xpose_stage<1>(lo, hi);
 }
 
 
@@ -260,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void k_fit_score(FitArgs a) {
         const uint64_t fm = node_pod_mask(nl, img, m_filt, m_need);
         uint32_t wlo = (uint32_t)(okm & fm), whi = (uint32_t)((okm & fm) >> 32);
         // (3) 64 x 64 bit transpose: lane j now holds pod j's verdict over the chunk's 64 nodes
-        transpose64(wlo, whi, lane);
+        transpose64(wlo, whi);
         uint64_t word = ((uint64_t)whi << 32) | wlo;
         if (my_pod_live) {
             const size_t o = (size_t)c * a.P + pod0 + lane;
@@ -544,7 +575,8 @@ struct DevBuf {
 };
 
 constexpr int kEventRing = 256;
-constexpr int kBufs = 3;          // pipeline depth: digest(i+1) | fit(i) | map(i-1)
+constexpr int kBufs = 8;          // buffer sets allocated; ctx->depth of them are cycled (pipeline depth)
+static int depth_env() { const char* e = getenv("NHDFIT_DEPTH"); int d = e ? atoi(e) : 5; return d < 1 ? 1 : d > kBufs ? kBufs : d; }
 
 }  // namespace
 
@@ -552,6 +584,7 @@ struct nhdfit_ctx {
     int dev = -1;
     hipStream_t stream = nullptr;        // fit_score (+ all-reduce): the stage that owns the chip
     hipStream_t s_digest = nullptr;      // request digest of the next step
+    int depth = depth_env();
     hipStream_t s_map[kBufs] = {};       // winner mapping of earlier steps (one stream per buffer set: the mapping
                                          // stage is latency-bound, consecutive steps' mappings may overlap each other)
     hipEvent_t ev_digest[kBufs] = {}, ev_fit[kBufs] = {}, ev_map[kBufs] = {};
@@ -851,8 +884,10 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     for (uint32_t p = 0; p < P; ++p) {
         const PodHeader h = pod_header(reqs[p]);
         c->perm[p] = p;
-        key[p] = ((h.flags & kPodValid) ? 0u : 1u << 12) | ((reqs[p].n_groups > 3 ? 1u : 0u) << 11) |
-                 ((h.flags & (kPodNeedGpu | kPodPci | kPodFilter)) << 4) | (reqs[p].n_groups & 15u);
+        // group count is the major key, descending: the tiles with the most assignments to sweep are the
+        // first blocks of the fit grid (longest-first keeps the tail of the launch short)
+        key[p] = ((h.flags & kPodValid) ? 0u : 1u << 16) | ((reqs[p].n_groups > 3 ? 1u : 0u) << 15) |
+                 ((15u - (reqs[p].n_groups & 15u)) << 8) | (h.flags & (kPodNeedGpu | kPodPci | kPodFilter));
         c->n_big_pods += reqs[p].n_groups > 3;
     }
     std::stable_sort(c->perm.begin(), c->perm.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
@@ -885,7 +920,7 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     const uint32_t P = c->P, tiles = (P + kTile - 1) / kTile;
     const uint32_t chunks = (c->n + 63) / 64;
 
-    const int b = (int)(c->step % kBufs);
+    const int b = (int)(c->step % c->depth);
 
     // stage 1 (s_digest): request digest into buffer set b - once the mapping of step i-3 has let go of it
     // HIP-event timing is sampled (every 8th step): at ~100 us per step the host is the bottleneck otherwise
@@ -898,10 +933,11 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
         HIPCHK(c, c->shape_res[b].reserve(shape_slots));
         HIPCHK(c, c->shape_slot[b].reserve(P));
     }
-    if (c->step >= (uint64_t)kBufs) HIPCHK(c, hipStreamWaitEvent(c->s_digest, c->ev_map[b], 0));
+    if (c->step >= (uint64_t)c->depth) HIPCHK(c, hipStreamWaitEvent(c->s_digest, c->ev_map[b], 0));
     if (timed) HIPCHK(c, hipEventRecord(ev[0], c->s_digest));
     DictView dv{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}};
-    hipLaunchKernelGGL(k_digest, dim3(tiles, kDigestSlices), dim3(kDigestThreads), 0, c->s_digest,
+    static const int sl_env = getenv("NHDFIT_SLICES") ? atoi(getenv("NHDFIT_SLICES")) : kDigestSlices;
+    hipLaunchKernelGGL(k_digest, dim3(tiles, sl_env), dim3(kDigestThreads), 0, c->s_digest,
                        c->reqs.p, P, dv, c->layout, c->tabs[b].p, c->hdr[b].p, c->score[b].p,
                        small_map ? c->shape_keys[b].p : nullptr, shape_slots);
     HIPCHK(c, hipGetLastError());
@@ -923,8 +959,10 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     // other's sweep; measured 6 % faster than 1024-thread blocks), 256-thread blocks for small problems
     const bool big = (uint64_t)tiles * ((chunks + 31) / 32) >= cus;
     const uint32_t waves = big ? 8 : 4;
+    static const int cpb_env = getenv("NHDFIT_CPB") ? atoi(getenv("NHDFIT_CPB")) : 0;
     uint32_t cpb = waves;                                                // chunks per block: >= 1 per wave
     while ((uint64_t)tiles * ((chunks + cpb * 2 - 1) / (cpb * 2)) >= 8ull * cus && cpb < waves * 8) cpb *= 2;
+    if (cpb_env) cpb = (uint32_t)cpb_env;
     a.chunks_per_block = cpb;
     a.nranges = (chunks + cpb - 1) / cpb;
     const uint32_t grid = tiles * a.nranges;
@@ -986,7 +1024,7 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
     int rc = nhdfit_sync(c);
     if (rc) return rc;
     const uint32_t P = c->P;
-    const int b = (int)((c->step - 1) % kBufs);             // results of the most recent step
+    const int b = (int)((c->step - 1) % c->depth);             // results of the most recent step
     if (score_out) {
         std::vector<uint64_t> tmp(P);
         HIPCHK(c, hipMemcpy(tmp.data(), c->score[b].p, (size_t)P * 8, hipMemcpyDeviceToHost));
@@ -1030,7 +1068,7 @@ int nhdfit_find_sequential(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, do
     if (!rc) rc = nhdfit_enqueue_step(c, now);
     c->want_bitmap = wb; c->want_map = wm;
     if (rc) return rc;
-    const int b = (int)((c->step - 1) % kBufs);
+    const int b = (int)((c->step - 1) % c->depth);
     const uint32_t chunks = (c->n + 63) / 64;
     HIPCHK(c, c->nogpu.reserve(chunks));
     HIPCHK(c, c->slot_of.reserve(c->n));
