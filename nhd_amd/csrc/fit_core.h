@@ -168,12 +168,19 @@ NHD_HD uint32_t entry_a(const PodSums& s, uint32_t f0, uint32_t f1) {
 // ---- NIC reach families -----------------------------------------------------------------------
 // A family is a bitmask over group-subsets S (bit S set = "these groups can be hosted together").
 // dunion(A,B) = { R|S : R in A, S in B, R&S == 0 }.
+// For disjoint R, S the union R|S equals R+S, so "every R of a that is disjoint from S, united with S" is
+// (a & disj(S)) << S with disj(S) = the subsets of {0..3} that avoid S: 16 shift-and-mask terms, no inner loop.
+static_assert(kMaxG == 4, "the disj() masks below enumerate subsets of four groups");
 NHD_HD uint32_t dunion(uint32_t a, uint32_t b, uint32_t W) {
+    (void)W;                                   // members of a and b are < W, and so is every R|S
     uint32_t out = 0;
-    for (uint32_t S = 0; S < W; ++S) {
-        if (!(b >> S & 1)) continue;
-        for (uint32_t R = 0; R < W; ++R)
-            if ((a >> R & 1) && !(R & S)) out |= 1u << (R | S);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t S = 0; S < (1u << kMaxG); ++S) {
+        const uint32_t disj = ((S & 1) ? 0x5555u : 0xFFFFu) & ((S & 2) ? 0x3333u : 0xFFFFu) &
+                              ((S & 4) ? 0x0F0Fu : 0xFFFFu) & ((S & 8) ? 0x00FFu : 0xFFFFu);
+        if (b >> S & 1) out |= (a & disj) << S;
     }
     return out;
 }
@@ -198,11 +205,9 @@ NHD_HD void class_cover(const nhdfit_req& r, double cap, uint32_t W, uint32_t G,
         cover[n] = (n <= G) ? (uint16_t)dunion(cover[n - 1], fit, W) : cover[G];
 }
 
-NHD_HD uint32_t size_le_mask(uint32_t W, uint32_t limit) {       // subsets with at most `limit` groups
-    uint32_t m = 0;
-    for (uint32_t S = 0; S < W; ++S)
-        if ((uint32_t)popc32(S) <= limit) m |= 1u << S;
-    return m;
+NHD_HD uint32_t size_le_mask(uint32_t W, uint32_t limit) {       // subsets of {0..3} below W with at most `limit` groups
+    const uint32_t by_size = limit == 0 ? 0x0001u : limit == 1 ? 0x0117u : limit == 2 ? 0x177Fu : limit == 3 ? 0x7FFFu : 0xFFFFu;
+    return by_size & ((1u << W) - 1u);
 }
 
 struct SigDict {
@@ -231,10 +236,12 @@ NHD_HD uint32_t sig_reach(const SigDict& d, uint32_t sig, const uint16_t* cover,
 // R1[sig] bit p = reach bit S1(p) = reach bit p;  R0[sig] bit p = reach bit S0(p) = reach bit (W-1-p)
 NHD_HD uint32_t entry_r(uint32_t reach, uint32_t W, uint32_t u) {
     if (u) return reach & 0xFFFFu;
-    uint32_t rev = 0;
-    for (uint32_t p = 0; p < W; ++p)
-        if (reach >> (W - 1 - p) & 1) rev |= 1u << p;
-    return rev;
+    uint32_t r = reach & 0xFFFFu;                       // reverse the low 16 bits, then keep the top W of them
+    r = (r & 0x5555u) << 1 | (r >> 1 & 0x5555u);
+    r = (r & 0x3333u) << 2 | (r >> 2 & 0x3333u);
+    r = (r & 0x0F0Fu) << 4 | (r >> 4 & 0x0F0Fu);
+    r = (r & 0x00FFu) << 8 | (r >> 8 & 0x00FFu);
+    return r >> (16 - W);
 }
 
 // value of 16-bit row `row` for one pod

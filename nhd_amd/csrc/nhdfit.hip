@@ -46,6 +46,23 @@ struct DictView {
 // asm label binds the declaration straight to the LLVM intrinsic, as the ROCm device libs do.
 extern "C" __device__ int nhd_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
+struct PaddedReq { nhdfit_req r; uint32_t pad; };             // LDS copies, 33-word stride: lane j -> bank j
+struct PaddedDetail { nhdfit_detail d; uint32_t pad; };
+
+// Coalesced copy of up to 64 consecutive request records (from pod0) into LDS, zero (= invalid) past P.
+template <int THREADS>
+__device__ __forceinline__ void stage_requests_lds(const nhdfit_req* __restrict__ reqs, uint32_t pod0, uint32_t P, PaddedReq* s_req) {
+    constexpr uint32_t kParts = sizeof(nhdfit_req) / 16;
+    const uint32_t live = pod0 < P ? (P - pod0 < (uint32_t)kTile ? P - pod0 : (uint32_t)kTile) : 0u;
+    const uint4* src = reinterpret_cast<const uint4*>(reqs + pod0);
+    for (uint32_t c = threadIdx.x; c < kTile * kParts; c += THREADS) {
+        const uint32_t j = c / kParts;
+        const uint4 v = j < live ? src[c] : make_uint4(0u, 0u, 0u, 0u);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&s_req[j]) + (c % kParts) * 4;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+}
+
 constexpr int kDigestThreads = 256;
 constexpr int kDigestSlices = 8;
 
@@ -56,7 +73,6 @@ __global__ __launch_bounds__(kDigestThreads) void k_digest(const nhdfit_req* __r
                                                            PodHeader* __restrict__ hdr,
                                                            unsigned long long* __restrict__ score,
                                                            unsigned long long* __restrict__ shape_keys, uint32_t shape_slots) {
-    struct PaddedReq { nhdfit_req r; uint32_t pad; };          // 33-word stride: lane j -> bank j
     __shared__ PaddedReq s_req[kTile];
     __shared__ PodSums s_sum[kTile];
     __shared__ uint16_t s_cover[kTile][NHDFIT_MAX_CLASSES][kMaxG + 1];
@@ -66,17 +82,16 @@ __global__ __launch_bounds__(kDigestThreads) void k_digest(const nhdfit_req* __r
     const uint32_t tid = threadIdx.x;
     uint8_t* img = tabs + (size_t)tile * L.bytes;
 
+    stage_requests_lds<kDigestThreads>(reqs, tile * kTile, P, s_req);
+    __syncthreads();
     if (tid < kTile) {
-        const uint32_t pod = tile * kTile + tid;
-        nhdfit_req r;
-        if (pod < P) r = reqs[pod];
-        else { memset(&r, 0, sizeof(r)); }
+        const nhdfit_req& r = s_req[tid].r;
         const PodHeader h = pod_header(r);
-        s_req[tid].r = r;
         s_hdr[tid] = h;
         if (h.flags & kPodValid) pod_sums(r, s_sum[tid]);
         if (slice == 0) {
-            hdr[tile * kTile + tid] = h;
+            const uint32_t pod = tile * kTile + tid;
+            hdr[pod] = h;
             if (pod < P) score[pod] = 0;                   // the fit kernel accumulates with atomicMax
         }
     }
@@ -402,12 +417,15 @@ struct ShapeArgs {
 };
 
 __global__ __launch_bounds__(64) void k_map_shapes(MapArgs a, ShapeArgs h) {
+    __shared__ PaddedReq s_req[kTile];                 // the request is read field by field, many times: keep it in LDS
+    stage_requests_lds<64>(a.reqs, blockIdx.x * 64, a.P, s_req);
+    __syncthreads();
     const uint32_t p = blockIdx.x * 64 + threadIdx.x;
     if (p >= a.P) return;
     int32_t slot = -1;
     WinnerState w;
     uint32_t i;
-    const nhdfit_req& rq = a.reqs[p];
+    const nhdfit_req& rq = s_req[threadIdx.x].r;
     if (rq.n_groups <= 3 && load_winner(a, p, w, i)) {
         const uint32_t bits = nic_assignment_bits(a.tabs + (size_t)(p / kTile) * a.layout.bytes, a.layout, p % kTile,
                                                   rq.map_type == NHDFIT_MAP_PCI, a.p3[i]);
@@ -442,19 +460,33 @@ __global__ __launch_bounds__(256) void k_map_choose(ShapeArgs h) {
 }
 
 __global__ __launch_bounds__(64) void k_map_finish(MapArgs a, ShapeArgs h) {
+    __shared__ PaddedReq s_req[kTile];                 // request and winner detail are read field by field: LDS copies
+    __shared__ PaddedDetail s_det[kTile];
+    __shared__ nhdfit_mapping s_out[kTile];            // written slot by slot (dynamic indices): LDS, not scratch
+    stage_requests_lds<64>(a.reqs, blockIdx.x * 64, a.P, s_req);
+    __syncthreads();
     const uint32_t p = blockIdx.x * 64 + threadIdx.x;
     if (p >= a.P) return;
-    const nhdfit_req& rq = a.reqs[p];
+    const nhdfit_req& rq = s_req[threadIdx.x].r;
     if (rq.n_groups > 3) return;                      // handled by k_map<true>
-    nhdfit_mapping& m = a.out[p];
+    nhdfit_mapping& m = s_out[threadIdx.x];
     memset(&m, 0, sizeof(m));
     const int32_t slot = h.slot_of_pod[p];
-    if (slot < 0) return;
-    const uint32_t res = h.result[slot];
+    const uint32_t res = slot >= 0 ? h.result[slot] : 0u;
     WinnerState w;
     uint32_t i;
-    if (!(res >> 8 & 1) || !load_winner(a, p, w, i)) return;
-    finish_mapping(rq, w, (res >> 4) & 7u, (int)(res & 15u), m);
+    if ((res >> 8 & 1) && load_winner(a, p, w, i)) {
+        const uint4* src = reinterpret_cast<const uint4*>(w.d);
+        uint4 v[sizeof(nhdfit_detail) / 16];
+#pragma unroll
+        for (uint32_t k = 0; k < sizeof(nhdfit_detail) / 16; ++k) v[k] = src[k];
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&s_det[threadIdx.x]);
+#pragma unroll
+        for (uint32_t k = 0; k < sizeof(nhdfit_detail) / 16; ++k) { dst[4 * k] = v[k].x; dst[4 * k + 1] = v[k].y; dst[4 * k + 2] = v[k].z; dst[4 * k + 3] = v[k].w; }
+        w.d = &s_det[threadIdx.x].d;
+        finish_mapping(rq, w, (res >> 4) & 7u, (int)(res & 15u), m);
+    }
+    a.out[p] = m;
 }
 
 // ---- mode B: sequential resolver ------------------------------------------------------------------
@@ -582,12 +614,11 @@ static int depth_env() { const char* e = getenv("NHDFIT_DEPTH"); int d = e ? ato
 
 struct nhdfit_ctx {
     int dev = -1;
-    hipStream_t stream = nullptr;        // fit_score (+ all-reduce): the stage that owns the chip
-    hipStream_t s_digest = nullptr;      // request digest of the next step
-    int depth = depth_env();
-    hipStream_t s_map[kBufs] = {};       // winner mapping of earlier steps (one stream per buffer set: the mapping
-                                         // stage is latency-bound, consecutive steps' mappings may overlap each other)
-    hipEvent_t ev_digest[kBufs] = {}, ev_fit[kBufs] = {}, ev_map[kBufs] = {};
+    hipStream_t stream = nullptr;        // the all-reduce of sharded runs (one communicator -> one stream)
+    int depth = depth_env();             // steps in flight
+    hipStream_t lane[kBufs] = {};        // step i runs digest -> fit -> mapping in order on lane[i % depth] with buffer
+                                         // set i % depth: stream order is the only dependency, steps overlap across lanes
+    hipEvent_t ev_fit[kBufs] = {}, ev_red[kBufs] = {};   // lane <-> all-reduce stream hand-over (sharded runs only)
     uint64_t step = 0;                   // steps enqueued since the last stage_requests
     std::string err;
     hipDeviceProp_t prop;
@@ -612,7 +643,7 @@ struct nhdfit_ctx {
     std::vector<uint32_t> perm;          // device (class-sorted) position -> caller's pod index
     DevBuf<PodHeader> hdr[kBufs]; DevBuf<uint8_t> tabs[kBufs];
     DevBuf<unsigned long long> score[kBufs]; DevBuf<nhdfit_mapping> maps[kBufs];
-    DevBuf<uint64_t> bitmap; DevBuf<uint64_t> cand;
+    DevBuf<uint64_t> bitmap[kBufs]; DevBuf<uint64_t> cand;
     DevBuf<unsigned long long> shape_keys[kBufs]; DevBuf<uint32_t> shape_res[kBufs]; DevBuf<int32_t> shape_slot[kBufs];   // k_map_* dedup tables
     // mode B
     DevBuf<uint64_t> nogpu; DevBuf<int32_t> slot_of; DevBuf<OverlayNode> overlay; DevBuf<SeqResult> seq_out; DevBuf<uint32_t> order;
@@ -664,9 +695,8 @@ int drain_events(nhdfit_ctx* c) {
 }
 
 int sync_all(nhdfit_ctx* c) {
-    HIPCHK(c, hipStreamSynchronize(c->s_digest));
+    for (int b = 0; b < c->depth; ++b) HIPCHK(c, hipStreamSynchronize(c->lane[b]));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int b = 0; b < kBufs; ++b) HIPCHK(c, hipStreamSynchronize(c->s_map[b]));
     return NHDFIT_OK;
 }
 
@@ -683,6 +713,8 @@ int nhdfit_device_count(void) {
 }
 
 const char* nhdfit_last_error(nhdfit_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void nhdfit_destroy(nhdfit_ctx* c);
 
 int nhdfit_create(int device_id, nhdfit_ctx** out) {
     if (!out) return fail(nullptr, NHDFIT_E_INVAL, "out is NULL");
@@ -707,30 +739,20 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
         delete c;
         return rc;
     }
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&c->s_digest, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&c->s_map[0], hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&c->s_map[1], hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&c->s_map[2], hipStreamNonBlocking)) != hipSuccess) {
-        int rc = fail(nullptr, NHDFIT_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
-        delete c;
-        return rc;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int b = 0; b < kBufs && e == hipSuccess; ++b) e = hipStreamCreateWithFlags(&c->lane[b], hipStreamNonBlocking);
+    for (int b = 0; b < kBufs && e == hipSuccess; ++b) {
+        e = hipEventCreateWithFlags(&c->ev_fit[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_red[b], hipEventDisableTiming);
     }
-    for (int b = 0; b < kBufs; ++b)
-        if ((e = hipEventCreateWithFlags(&c->ev_digest[b], hipEventDisableTiming)) != hipSuccess ||
-            (e = hipEventCreateWithFlags(&c->ev_fit[b], hipEventDisableTiming)) != hipSuccess ||
-            (e = hipEventCreateWithFlags(&c->ev_map[b], hipEventDisableTiming)) != hipSuccess) {
-            int rc = fail(nullptr, NHDFIT_E_HIP, "hipEventCreate: %s", hipGetErrorString(e));
-            delete c;
-            return rc;
-        }
     for (auto& q : c->ev)
         for (auto& x : q)
-            if ((e = hipEventCreate(&x)) != hipSuccess) {
-                int rc = fail(nullptr, NHDFIT_E_HIP, "hipEventCreate: %s", hipGetErrorString(e));
-                delete c;
-                return rc;
-            }
+            if (e == hipSuccess) e = hipEventCreate(&x);
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, NHDFIT_E_HIP, "stream / event creation: %s", hipGetErrorString(e));
+        nhdfit_destroy(c);
+        return rc;
+    }
     *out = c;
     return NHDFIT_OK;
 }
@@ -738,25 +760,23 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
 void nhdfit_destroy(nhdfit_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->dev);
-    if (c->stream && c->s_digest && c->s_map[0] && c->s_map[1] && c->s_map[2]) (void)sync_all(c);
+    (void)hipDeviceSynchronize();
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
-    c->reqs.release(); c->bitmap.release(); c->cand.release(); c->group_sets.release();
+    c->reqs.release(); c->cand.release(); c->group_sets.release();
     for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); }
     c->nogpu.release(); c->slot_of.release(); c->overlay.release(); c->seq_out.release(); c->order.release();
     for (int b = 0; b < kBufs; ++b) {
-        c->hdr[b].release(); c->tabs[b].release(); c->score[b].release(); c->maps[b].release();
-        if (c->ev_digest[b]) (void)hipEventDestroy(c->ev_digest[b]);
+        c->hdr[b].release(); c->tabs[b].release(); c->score[b].release(); c->maps[b].release(); c->bitmap[b].release();
         if (c->ev_fit[b]) (void)hipEventDestroy(c->ev_fit[b]);
-        if (c->ev_map[b]) (void)hipEventDestroy(c->ev_map[b]);
+        if (c->ev_red[b]) (void)hipEventDestroy(c->ev_red[b]);
+        if (c->lane[b]) (void)hipStreamDestroy(c->lane[b]);
     }
     for (auto& q : c->ev)
         for (auto& x : q)
             if (x) (void)hipEventDestroy(x);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->s_digest) (void)hipStreamDestroy(c->s_digest);
-    for (int b = 0; b < kBufs; ++b) if (c->s_map[b]) (void)hipStreamDestroy(c->s_map[b]);
     delete c;
 }
 
@@ -875,7 +895,6 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
         HIPCHK(c, c->score[b].reserve(P));
         HIPCHK(c, c->maps[b].reserve(P));
     }
-    HIPCHK(c, c->bitmap.reserve((size_t)chunks * P));
     // Pods are staged sorted by request class so that 64-pod tiles are homogeneous (fast sweep of
     // k_fit_score) and the lanes of k_map have similar group counts; results are un-permuted in fetch.
     c->perm.resize(P);
@@ -922,8 +941,10 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
 
     const int b = (int)(c->step % c->depth);
 
-    // stage 1 (s_digest): request digest into buffer set b - once the mapping of step i-3 has let go of it
-    // HIP-event timing is sampled (every 8th step): at ~100 us per step the host is the bottleneck otherwise
+    // step i = digest -> fit(+score+select) -> [all-reduce] -> winner mapping, all on lane[i % depth] with buffer set
+    // i % depth: no events between the stages, and a lane is free again exactly when its previous step is done.
+    // HIP-event timing is sampled (every 8th step): the host is the bottleneck otherwise (~5 us per API call)
+    hipStream_t sb = c->lane[b];
     const bool timed = c->step < 2 || (c->step & 7) == 0;
     uint32_t shape_slots = 1024;
     while (shape_slots < 2 * P) shape_slots <<= 1;
@@ -933,70 +954,58 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
         HIPCHK(c, c->shape_res[b].reserve(shape_slots));
         HIPCHK(c, c->shape_slot[b].reserve(P));
     }
-    if (c->step >= (uint64_t)c->depth) HIPCHK(c, hipStreamWaitEvent(c->s_digest, c->ev_map[b], 0));
-    if (timed) HIPCHK(c, hipEventRecord(ev[0], c->s_digest));
+    if (c->want_bitmap) HIPCHK(c, c->bitmap[b].reserve((size_t)chunks * P));
+    if (timed) HIPCHK(c, hipEventRecord(ev[0], sb));
     DictView dv{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}};
-    static const int sl_env = getenv("NHDFIT_SLICES") ? atoi(getenv("NHDFIT_SLICES")) : kDigestSlices;
-    hipLaunchKernelGGL(k_digest, dim3(tiles, sl_env), dim3(kDigestThreads), 0, c->s_digest,
+    hipLaunchKernelGGL(k_digest, dim3(tiles, kDigestSlices), dim3(kDigestThreads), 0, sb,
                        c->reqs.p, P, dv, c->layout, c->tabs[b].p, c->hdr[b].p, c->score[b].p,
                        small_map ? c->shape_keys[b].p : nullptr, shape_slots);
-    HIPCHK(c, hipGetLastError());
-    if (timed) HIPCHK(c, hipEventRecord(ev[1], c->s_digest));
-    HIPCHK(c, hipEventRecord(c->ev_digest[b], c->s_digest));
+    if (timed) HIPCHK(c, hipEventRecord(ev[1], sb));
 
-    // stage 2 (stream): fit + score + select over every (pod, node) pair, then the all-reduce
-    // geometry: one 1024-thread block per half CU of LDS; shrink blocks for small problems so that
-    // the grid still covers the chip
     FitArgs a;
     a.p0 = c->p0.p; a.p1 = c->p1.p; a.p2 = c->p2.p; a.p3 = c->p3.p; a.p4 = c->p4.p;
     a.n = c->n; a.chunks = chunks; a.global_base = c->global_base; a.now = now;
     a.tabs = c->tabs[b].p; a.layout = c->layout; a.hdr = c->hdr[b].p; a.P = P;
     a.cand = c->use_cand ? c->cand.p : nullptr;
-    a.bitmap = c->want_bitmap ? c->bitmap.p : nullptr;
+    a.bitmap = c->want_bitmap ? c->bitmap[b].p : nullptr;
     a.score = c->score[b].p;
     const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
-    // 512-thread blocks (8 waves, 2 co-resident blocks per CU at 84 VGPRs: one block's LDS fill overlaps the
-    // other's sweep; measured 6 % faster than 1024-thread blocks), 256-thread blocks for small problems
+    // 512-thread blocks (8 waves; 3 co-resident blocks per CU at 70 VGPRs: one block's LDS fill overlaps the others'
+    // sweep), 256-thread blocks for small problems so that the grid still covers the chip
     const bool big = (uint64_t)tiles * ((chunks + 31) / 32) >= cus;
     const uint32_t waves = big ? 8 : 4;
-    static const int cpb_env = getenv("NHDFIT_CPB") ? atoi(getenv("NHDFIT_CPB")) : 0;
     uint32_t cpb = waves;                                                // chunks per block: >= 1 per wave
     while ((uint64_t)tiles * ((chunks + cpb * 2 - 1) / (cpb * 2)) >= 8ull * cus && cpb < waves * 8) cpb *= 2;
-    if (cpb_env) cpb = (uint32_t)cpb_env;
     a.chunks_per_block = cpb;
     a.nranges = (chunks + cpb - 1) / cpb;
     const uint32_t grid = tiles * a.nranges;
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_digest[b], 0));
-    if (timed) HIPCHK(c, hipEventRecord(ev[2], c->stream));
-    if (big) hipLaunchKernelGGL((k_fit_score<512>), dim3(grid), dim3(512), c->lds_bytes, c->stream, a);
-    else     hipLaunchKernelGGL((k_fit_score<256>), dim3(grid), dim3(256), c->lds_bytes, c->stream, a);
-    HIPCHK(c, hipGetLastError());
-    if (timed) HIPCHK(c, hipEventRecord(ev[3], c->stream));
-    if (c->comm) {
+    if (timed) HIPCHK(c, hipEventRecord(ev[2], sb));
+    if (big) hipLaunchKernelGGL((k_fit_score<512>), dim3(grid), dim3(512), c->lds_bytes, sb, a);
+    else     hipLaunchKernelGGL((k_fit_score<256>), dim3(grid), dim3(256), c->lds_bytes, sb, a);
+    if (timed) HIPCHK(c, hipEventRecord(ev[3], sb));
+    if (c->comm) {      // one communicator -> its collectives stay on one stream, in step order
+        HIPCHK(c, hipEventRecord(c->ev_fit[b], sb));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fit[b], 0));
         ncclResult_t r = g_rccl.AllReduce(c->score[b].p, c->score[b].p, P, ncclUint64, ncclMax, c->comm, c->stream);
         if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+        HIPCHK(c, hipEventRecord(c->ev_red[b], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(sb, c->ev_red[b], 0));
     }
-    HIPCHK(c, hipEventRecord(c->ev_fit[b], c->stream));
-
-    // stage 3 (s_map): the winners' resource mappings
-    hipStream_t sm = c->s_map[b];
-    HIPCHK(c, hipStreamWaitEvent(sm, c->ev_fit[b], 0));
     if (c->want_map) {
         MapArgs m{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->det.p, c->tabs[b].p, c->layout, c->n,
                   c->global_base, c->reqs.p, P, c->score[b].p, c->caps.p, c->maps[b].p};
         const dim3 mg((P + kMapWaves - 1) / kMapWaves), mb(64 * kMapWaves);
         if (small_map) {
             ShapeArgs h{c->shape_keys[b].p, c->shape_res[b].p, c->shape_slot[b].p, shape_slots};
-            hipLaunchKernelGGL(k_map_shapes, dim3((P + 63) / 64), dim3(64), 0, sm, m, h);
-            hipLaunchKernelGGL(k_map_choose, dim3(shape_slots / 4), dim3(256), 0, sm, h);
-            hipLaunchKernelGGL(k_map_finish, dim3((P + 63) / 64), dim3(64), 0, sm, m, h);
+            hipLaunchKernelGGL(k_map_shapes, dim3((P + 63) / 64), dim3(64), 0, sb, m, h);
+            hipLaunchKernelGGL(k_map_choose, dim3(shape_slots / 4), dim3(256), 0, sb, h);
+            hipLaunchKernelGGL(k_map_finish, dim3((P + 63) / 64), dim3(64), 0, sb, m, h);
         }
-        if (c->n_big_pods) hipLaunchKernelGGL(k_map<true>, mg, mb, 0, sm, m);
-        HIPCHK(c, hipGetLastError());
+        if (c->n_big_pods) hipLaunchKernelGGL(k_map<true>, mg, mb, 0, sb, m);
     }
-    HIPCHK(c, hipEventRecord(c->ev_map[b], sm));
+    HIPCHK(c, hipGetLastError());
     if (timed) {
-        HIPCHK(c, hipEventRecord(ev[4], sm));
+        HIPCHK(c, hipEventRecord(ev[4], sb));
         c->ev_pending++;
     }
     c->step++;
@@ -1034,7 +1043,7 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
         if (!c->want_bitmap) return fail(c, NHDFIT_E_STATE, "bitmap output is disabled");
         const size_t chunks = (c->n + 63) / 64;
         std::vector<uint64_t> tmp(chunks * P);
-        HIPCHK(c, hipMemcpy(tmp.data(), c->bitmap.p, chunks * P * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(tmp.data(), c->bitmap[b].p, chunks * P * 8, hipMemcpyDeviceToHost));
         for (size_t ch = 0; ch < chunks; ++ch)
             for (uint32_t i = 0; i < P; ++i) bitmap_out[ch * P + c->perm[i]] = tmp[ch * P + i];
     }
@@ -1077,12 +1086,12 @@ int nhdfit_find_sequential(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, do
     HIPCHK(c, c->order.reserve(P));
     std::vector<uint32_t> order(P);                       // caller's pod -> staged (class-sorted) position
     for (uint32_t i = 0; i < P; ++i) order[c->perm[i]] = i;
-    hipStream_t sm = c->s_map[b];
+    hipStream_t sm = c->lane[b];
     HIPCHK(c, hipMemcpyAsync(c->order.p, order.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
     HIPCHK(c, hipMemsetAsync(c->slot_of.p, 0xFF, (size_t)c->n * sizeof(int32_t), sm));
     hipLaunchKernelGGL(k_nogpu, dim3(chunks), dim3(64), 0, sm, c->p2.p, c->n, c->nogpu.p);
     ResolveArgs ra{SeqStatic{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->p4.p, c->det.p, c->caps.p, c->n, c->global_base, now},
-                   c->reqs.p, c->hdr[b].p, c->score[b].p, c->maps[b].p, c->bitmap.p, c->nogpu.p, c->order.p, P, chunks,
+                   c->reqs.p, c->hdr[b].p, c->score[b].p, c->maps[b].p, c->bitmap[b].p, c->nogpu.p, c->order.p, P, chunks,
                    c->slot_of.p, c->overlay.p, c->seq_out.p};
     if (c->n_big_pods) hipLaunchKernelGGL(k_resolve<false>, dim3(1), dim3(64), 0, sm, ra);   // after the mapping, same stream
     else hipLaunchKernelGGL(k_resolve<true>, dim3(1), dim3(64), 0, sm, ra);
