@@ -1,18 +1,20 @@
 // nhdfit.hip - gfx950 kernels and the C-ABI of libnhdfit.so (include/nhdfit.h).
 //
-// Three kernels per step, software-pipelined over three HIP streams with triple-buffered request-side
-// state (digest of step i+1 and winner mapping of step i-1 overlap the fit kernel of step i):
-//   k_digest     per 64-pod tile: request records -> table image (CPU/GPU/NIC feasibility of every
-//                NUMA assignment as a function of a node's free-resource counts / NIC signature)
-//   k_fit_score  the P x N pass.  Block = (pod tile, node range).  The tile's table image is staged
-//                in LDS; a wavefront owns 64 consecutive nodes (lane = node, coalesced 16 B/lane loads
-//                of the five SoA planes, __popcll of the free-core bitmaps), sweeps the tile's 64 pods
-//                (wave-uniform request header, per-lane LDS table gathers), __ballot()s the verdict and
-//                transposes the 64 ballot words so that lane j ends up holding pod j's 64-node
-//                feasibility word: coalesced bitmap store, first-fit score via ctz, max-reduced
-//                per block and published with one atomicMax per pod.
-//   k_map        one lane per pod: the winner's resource mapping (CPython set-order model).
-// Multi-GPU: ncclAllReduce(score, P, ncclUint64, ncclMax) between k_fit_score and k_map.
+// ONE kernel launch per step (k_step).  Its grid is the union of five block ranges ("roles"), each working on a
+// different step of a software pipeline over eight request-side buffer sets:
+//   digest (step i+1)  per 64-pod tile: request records -> bit-sliced table image (CPU/GPU/NIC feasibility of every
+//                      NUMA assignment as a function of a node's free-resource counts / NIC signature)
+//   fit    (step i)    the P x N pass.  Block = (pod tile, node range).  The tile's table image is staged in LDS; a
+//                      wavefront owns 64 consecutive nodes (lane = node, coalesced 16 B/lane loads of the five SoA
+//                      planes, __popcll of the free-core bitmaps), ANDs the table rows of its node for all 64 pods
+//                      at once, transposes the 64 x 64 verdict bits so that lane j holds pod j's 64-node word:
+//                      coalesced bitmap store, first-fit score via ctz, max-reduced per block, one atomicMax per pod
+//   shapes (step i-1), choose (step i-2), finish (step i-3)
+//                      the winners' resource mappings (CPython set-order model): per-pod shape, the sequential
+//                      set model once per distinct shape of a tile, per-pod NIC choice
+// The side roles are long on latency and short on work; inside the fit role's launch they cost no stream time and
+// no extra launches (the host does one launch per step).  Multi-GPU: ncclAllReduce(score, P, ncclUint64, ncclMax)
+// on a second stream between the fit of step i and the shapes role of step i (one launch later).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -47,7 +49,6 @@ struct DictView {
 extern "C" __device__ int nhd_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
 struct PaddedReq { nhdfit_req r; uint32_t pad; };             // LDS copies, 33-word stride: lane j -> bank j
-struct PaddedDetail { nhdfit_detail d; uint32_t pad; };
 
 // Coalesced copy of up to 64 consecutive request records (from pod0) into LDS, zero (= invalid) past P.
 template <int THREADS>
@@ -63,66 +64,112 @@ __device__ __forceinline__ void stage_requests_lds(const nhdfit_req* __restrict_
     }
 }
 
-constexpr int kDigestThreads = 256;
-constexpr int kDigestSlices = 8;
+template <class T>
+__device__ __forceinline__ T* carve(uint8_t*& p, size_t count) {      // 16-byte aligned slices of a block's LDS
+    T* r = reinterpret_cast<T*>(p);
+    p += (count * sizeof(T) + 15) & ~size_t(15);
+    return r;
+}
+constexpr size_t lds_slice(size_t bytes) { return (bytes + 15) & ~size_t(15); }
 
-// grid = (tiles, kDigestSlices).  Every block rebuilds the (cheap) per-pod sums / covers of its tile
-// in LDS, then fills its share of the table rows; consecutive threads write consecutive columns.
-__global__ __launch_bounds__(kDigestThreads) void k_digest(const nhdfit_req* __restrict__ reqs, uint32_t P,
-                                                           DictView d, Layout L, uint8_t* __restrict__ tabs,
-                                                           PodHeader* __restrict__ hdr,
-                                                           unsigned long long* __restrict__ score,
-                                                           unsigned long long* __restrict__ shape_keys, uint32_t shape_slots) {
-    __shared__ PaddedReq s_req[kTile];
-    __shared__ PodSums s_sum[kTile];
-    __shared__ uint16_t s_cover[kTile][NHDFIT_MAX_CLASSES][kMaxG + 1];
-    __shared__ PodHeader s_hdr[kTile];
+struct DigestArgs {
+    const nhdfit_req* reqs;          // class-sorted order (as staged)
+    uint32_t P;
+    DictView d;
+    Layout L;
+    uint8_t* tabs;                   // out: tile images, L.bytes apart
+    PodHeader* hdr;                  // out: [tiles*64]
+    unsigned long long* score;       // out: zeroed (the fit role accumulates with atomicMax)
+    uint32_t parts;                  // blocks per tile (each sweeps 1/parts of the rows)
+};
+constexpr size_t kDigestLds = lds_slice(kTile * sizeof(PaddedReq)) + lds_slice(kTile * sizeof(PodSums)) +
+                              lds_slice(kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1) * sizeof(uint16_t)) + lds_slice(kTile * sizeof(PodHeader));
 
-    const uint32_t tile = blockIdx.x, slice = blockIdx.y;
+// Request digest, one block per 64-pod tile: per-pod subset sums / NIC covers in LDS, then the table rows
+// (lane = pod, one ballot per assignment).  Few, busy blocks: in the step kernel every resident side block
+// displaces a block of the fit role.
+template <int THREADS>
+__device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, uint8_t* lds) {
+    PaddedReq* s_req = carve<PaddedReq>(lds, kTile);
+    PodSums* s_sum = carve<PodSums>(lds, kTile);
+    uint16_t (*s_cover)[NHDFIT_MAX_CLASSES][kMaxG + 1] =
+        reinterpret_cast<uint16_t (*)[NHDFIT_MAX_CLASSES][kMaxG + 1]>(carve<uint16_t>(lds, kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1)));
+    PodHeader* s_hdr = carve<PodHeader>(lds, kTile);
+
+    const uint32_t tile = blk / a.parts, part = blk % a.parts;   // `parts` blocks share a tile's rows
     const uint32_t tid = threadIdx.x;
-    uint8_t* img = tabs + (size_t)tile * L.bytes;
+    const Layout& L = a.L;
+    uint8_t* img = a.tabs + (size_t)tile * L.bytes;
 
-    stage_requests_lds<kDigestThreads>(reqs, tile * kTile, P, s_req);
+    stage_requests_lds<THREADS>(a.reqs, tile * kTile, a.P, s_req);
     __syncthreads();
     if (tid < kTile) {
         const nhdfit_req& r = s_req[tid].r;
         const PodHeader h = pod_header(r);
         s_hdr[tid] = h;
         if (h.flags & kPodValid) pod_sums(r, s_sum[tid]);
-        if (slice == 0) {
+        if (part == 0) {
             const uint32_t pod = tile * kTile + tid;
-            hdr[pod] = h;
-            if (pod < P) score[pod] = 0;                   // the fit kernel accumulates with atomicMax
+            a.hdr[pod] = h;
+            if (pod < a.P) a.score[pod] = 0;
         }
     }
-    // clear this step's shape table of the mapping kernels (saves two memset launches per step)
-    if (shape_keys)
-        for (uint32_t k = (blockIdx.y * gridDim.x + blockIdx.x) * kDigestThreads + tid; k < shape_slots;
-             k += gridDim.x * gridDim.y * kDigestThreads) shape_keys[k] = 0;
     __syncthreads();
-    for (uint32_t w = tid; w < kTile * d.ncls; w += kDigestThreads) {
+    for (uint32_t w = tid; w < kTile * a.d.ncls; w += THREADS) {
         const uint32_t j = w % kTile, c = w / kTile;
-        if (s_hdr[j].flags & kPodValid) class_cover(s_req[j].r, d.caps[c], s_sum[j].W, s_sum[j].G, s_cover[j][c]);
+        if (s_hdr[j].flags & kPodValid) class_cover(s_req[j].r, a.d.caps[c], s_sum[j].W, s_sum[j].G, s_cover[j][c]);
     }
     __syncthreads();
 
-    // assignment rows, bit-sliced: one wavefront per row, lane = pod computes its 16-bit entry, one ballot per
-    // assignment gives the row's W words (bit j of word p = assignment p of pod j passes)
+    // assignment rows, bit-sliced: lane = pod computes its 16-bit entry (bit p = assignment p passes), one ballot
+    // per assignment turns 64 entries into the row's W words (bit j of word p = assignment p of pod j passes)
+    constexpr uint32_t NW = THREADS / 64;
     const uint32_t wave = tid >> 6, lane = tid & 63;
-    for (uint32_t row = slice * (kDigestThreads / 64) + wave; row < L.rows16; row += gridDim.y * (kDigestThreads / 64)) {
-        uint32_t v = 0;
-        if (s_hdr[lane].flags & kPodValid) v = row16_entry(L, s_sum[lane], d.sig, &s_cover[lane][0][0], row);
+    const bool valid = (s_hdr[lane].flags & kPodValid) != 0;
+    auto emit_row = [&](uint32_t row, uint32_t v) {
         unsigned long long mine = 0;
         for (uint32_t p = 0; p < L.W; ++p) {
             const unsigned long long word = __ballot(v >> p & 1);
             if (lane == p) mine = word;
         }
         if (lane < L.W) *reinterpret_cast<unsigned long long*>(img + row * L.row_bytes + lane * 8) = mine;
+    };
+    // CPU rows W0/W1[misc here?][smt][free cores c]: for a pod, socket, SMT mode and misc placement the entry is
+    // { p : demand_p <= c } - the demands are read once per (socket, misc, smt) group and swept over c in registers
+    // (one group per wavefront) instead of being re-read from LDS for each of the 4 * fc_dim rows of the group
+    for (uint32_t g = wave; g < 8; g += NW) {
+        const uint32_t u = g >> 2, m = (g >> 1) & 1, smt = g & 1;
+        uint32_t t[1 << kMaxG];
+#pragma unroll
+        for (uint32_t p = 0; p < (1u << kMaxG); ++p) {
+            t[p] = 0xFFFFFFFFu;
+            if (valid && p < s_sum[lane].W) {
+                const uint32_t* sum = smt ? s_sum[lane].cpu_smt : s_sum[lane].cpu_nosmt;
+                const uint32_t extra = m ? (smt ? s_sum[lane].misc_smt : s_sum[lane].misc_nosmt) : 0;
+                t[p] = sum[u ? p : (~p & s_sum[lane].full)] + extra;
+            }
+        }
+        const uint32_t row0 = (u ? L.row_w1 : 0u) + m * 2 * L.fc_dim + smt * L.fc_dim;
+        for (uint32_t c = part; c < L.fc_dim; c += a.parts) {
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t p = 0; p < (1u << kMaxG); ++p) v |= (t[p] <= c ? 1u : 0u) << p;
+            emit_row(row0 + c, v);
+        }
+    }
+    // GPU rows A[f0][f1]
+    for (uint32_t k = wave * a.parts + part; k < L.fg_dim * L.fg_dim; k += NW * a.parts)
+        emit_row(L.row_a + k, valid ? entry_a(s_sum[lane], k / L.fg_dim, k % L.fg_dim) : 0u);
+    // NIC rows R0/R1[signature]: one reach family per (signature, pod), both sockets' rows from it
+    for (uint32_t sig = wave * a.parts + part; sig < L.nsig; sig += NW * a.parts) {
+        const uint32_t reach = valid ? sig_reach(a.d.sig, sig, &s_cover[lane][0][0], s_sum[lane].W) : 0u;
+        emit_row(L.row_r0 + sig, valid ? entry_r(reach, s_sum[lane].W, 0) : 0u);
+        emit_row(L.row_r1 + sig, valid ? entry_r(reach, s_sum[lane].W, 1) : 0u);
     }
     // 64-bit scalar-predicate rows: one wavefront per row, ballot over the 64 pods
     const uint32_t nrows64 = L.hp_rows + L.ngs;
-    for (uint32_t k = slice * (kDigestThreads / 64) + wave; k < nrows64; k += gridDim.y * (kDigestThreads / 64)) {
-        const bool bit = k < L.hp_rows ? hp_bit(s_hdr[lane], L, k) : gf_bit(s_hdr[lane], d.group_sets[k - L.hp_rows]);
+    for (uint32_t k = wave * a.parts + part; k < nrows64; k += NW * a.parts) {
+        const bool bit = k < L.hp_rows ? hp_bit(s_hdr[lane], L, k) : gf_bit(s_hdr[lane], a.d.group_sets[k - L.hp_rows]);
         const uint64_t word = __ballot(bit);
         if (lane == 0)
             *reinterpret_cast<uint64_t*>(img + (k < L.hp_rows ? L.off_hp + 8 * k : L.off_gf + 8 * (k - L.hp_rows))) = word;
@@ -254,16 +301,19 @@ __device__ __forceinline__ uint64_t sweep_dispatch(uint32_t W, const uint8_t* im
     }
 }
 
+// The P x N pass.  Block = (pod tile, node range): the tile's table image is staged in LDS, every wavefront
+// sweeps 64-node chunks of the range (lane = node), transposes the verdicts (lane = pod), writes the bitmap word
+// and keeps the best score; one atomicMax per pod and block.
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_fit_score(FitArgs a) {
-    extern __shared__ __align__(16) uint8_t img[];
-    __shared__ unsigned long long s_best[BLOCK / 64][64];
+__device__ __forceinline__ void role_fit(const FitArgs& a, uint32_t blk, uint8_t* lds) {
     constexpr int NW = BLOCK / 64;
+    uint8_t* img = lds;
+    unsigned long long (*s_best)[64] = reinterpret_cast<unsigned long long (*)[64]>(lds + lds_slice(a.layout.bytes));
 
     // blockIdx -> (tile, range): consecutive blocks (round-robin over the 8 XCDs) walk the node
     // ranges, so one XCD keeps re-reading the same 1/8 of the node planes out of its own L2.
-    const uint32_t range = blockIdx.x % a.nranges;
-    const uint32_t tile = blockIdx.x / a.nranges;
+    const uint32_t range = blk % a.nranges;
+    const uint32_t tile = blk / a.nranges;
 
     {   // stage the tile's table image in LDS (16 B per lane, fully coalesced)
         const uint4* src = reinterpret_cast<const uint4*>(a.tabs + (size_t)tile * a.layout.bytes);
@@ -385,10 +435,10 @@ __global__ __launch_bounds__(64 * kMapWaves) void k_map(MapArgs a) {
 }
 
 // ---- winner mapping for G <= 3 pods, de-duplicated by candidate-set shape --------------------------
-// The sequential CPython-set model (choose_tuples) is a pure function of 35 bits (shape_key).  Thousands of
-// pods share a few hundred shapes, so: (1) every pod derives its shape in parallel and interns it in a
-// per-step hash table, (2) one wavefront per distinct shape runs the set model, (3) every pod finishes its
-// mapping (first valid NIC choice) in parallel.  Nothing survives the step.
+// The sequential CPython-set model (choose_tuples) is a pure function of 35 bits (shape_key).  So: (1) every pod
+// derives its shape in parallel, the distinct shapes of each 64-pod tile are collected (wave ballots, no atomics),
+// (2) one wavefront per distinct shape runs the set model, (3) every pod finishes its mapping (first valid NIC
+// choice) in parallel.  Nothing survives the step.
 __device__ __forceinline__ bool load_winner(const MapArgs& a, uint32_t p, WinnerState& w, uint32_t& i) {
     const unsigned long long s = a.score[p];
     if (!s) return false;
@@ -410,83 +460,160 @@ __device__ __forceinline__ bool load_winner(const MapArgs& a, uint32_t p, Winner
 }
 
 struct ShapeArgs {
-    unsigned long long* keys;    // [slots] 0 = empty
-    uint32_t* result;            // [slots] ok << 8 | gcode << 4 | ccode
-    int32_t* slot_of_pod;        // [P] hash slot, < 0: nothing to map
-    uint32_t slots;              // power of two >= 2 P
+    unsigned long long* keys;    // [tiles*64] distinct shapes of tile t at [64 t, 64 t + count[t])
+    uint32_t* result;            // [tiles*64] ok << 8 | gcode << 4 | ccode of the shape in the same slot
+    int32_t* slot_of_pod;        // [P] slot of the pod's shape, < 0: nothing to map
+    uint32_t* count;             // [tiles]
+    const AscEntry* asc;         // layouts of ascending-filled sets (winner_map.h), built once per context
 };
 
-__global__ __launch_bounds__(64) void k_map_shapes(MapArgs a, ShapeArgs h) {
-    __shared__ PaddedReq s_req[kTile];                 // the request is read field by field, many times: keep it in LDS
-    stage_requests_lds<64>(a.reqs, blockIdx.x * 64, a.P, s_req);
-    __syncthreads();
-    const uint32_t p = blockIdx.x * 64 + threadIdx.x;
-    if (p >= a.P) return;
+// one thread per (tuple length, subset): the set model itself fills the table
+__global__ __launch_bounds__(256) void k_build_asc(AscEntry* table) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= kAscEntries) return;
+    const int len = e >= kAscOffset[4] ? 4 : e >= kAscOffset[3] ? 3 : e >= kAscOffset[2] ? 2 : 1;
+    table[e] = asc_entry_build(len, e - kAscOffset[len]);
+}
+
+
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int lane) {
+    return ((unsigned long long)(uint32_t)__shfl((int)(v >> 32), lane, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, lane, 64);
+}
+
+// (1) lane = pod, wavefront = tile: derive the shape, de-duplicate within the tile
+template <int THREADS>
+__device__ __forceinline__ void role_shapes(const MapArgs& a, const ShapeArgs& h, uint32_t blk) {
+    const uint32_t p = blk * THREADS + threadIdx.x, tile = p >> 6, lane = threadIdx.x & 63;
+    if (tile * 64 >= a.P) return;                      // whole wavefront past the end
     int32_t slot = -1;
+    unsigned long long key = 0;
     WinnerState w;
     uint32_t i;
-    const nhdfit_req& rq = s_req[threadIdx.x].r;
-    if (rq.n_groups <= 3 && load_winner(a, p, w, i)) {
-        const uint32_t bits = nic_assignment_bits(a.tabs + (size_t)(p / kTile) * a.layout.bytes, a.layout, p % kTile,
+    const nhdfit_req& rq = a.reqs[p < a.P ? p : 0];
+    if (p < a.P && rq.n_groups <= 3 && load_winner(a, p, w, i)) {
+        const uint32_t bits = nic_assignment_bits(a.tabs + (size_t)tile * a.layout.bytes, a.layout, lane,
                                                   rq.map_type == NHDFIT_MAP_PCI, a.p3[i]);
         const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
         uint32_t sg, sc;
         candidate_masks(rq, w, sg, sc);
-        if (sg && sc && codes) {
-            const unsigned long long key = shape_key((int)rq.n_groups, w.U, sg, sc, codes);
-            uint32_t x = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (h.slots - 1);
-            for (;;) {
-                const unsigned long long old = atomicCAS(&h.keys[x], 0ull, key);
-                if (old == 0ull || old == key) break;
-                x = (x + 1) & (h.slots - 1);
-            }
-            slot = (int32_t)x;
-        }
+        if (sg && sc && codes) key = shape_key((int)rq.n_groups, w.U, sg, sc, codes);
     }
-    h.slot_of_pod[p] = slot;
+    // distinct shapes of the tile (pods of a tile mostly share a handful): slot 64 tile + j for the j-th one.
+    // No cross-tile interning: it needs a hash table in global memory, and its atomics cost the concurrently
+    // running fit role more than the extra runs of the set model cost the choose role.
+    unsigned long long todo = __ballot(key != 0ull);
+    uint32_t nd = 0;
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const unsigned long long k = shfl64(key, leader);
+        if ((int)lane == leader) h.keys[tile * 64 + nd] = k;
+        if (key == k) slot = (int32_t)(tile * 64 + nd);
+        todo &= ~__ballot(key == k);
+        ++nd;
+    }
+    if (lane == 0) h.count[tile] = nd;
+    if (p < a.P) h.slot_of_pod[p] = slot;
 }
 
-__global__ __launch_bounds__(256) void k_map_choose(ShapeArgs h) {
-    const uint32_t slot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (slot >= h.slots || (threadIdx.x & 63) != 0) return;
-    const unsigned long long key = h.keys[slot];
-    if (!key) return;
-    const int G = (int)(key & 3), U = (int)((key >> 2) & 1) + 1;
-    uint32_t gcode = 0;
-    int ccode = -1;
-    const bool ok = choose_tuples<SmallOps>(G, U, (uint32_t)(key >> 3) & 0xFF, (uint32_t)(key >> 19) & 0xFFFF,
-                                            (uint32_t)(key >> 11) & 0xFF, gcode, ccode);
-    h.result[slot] = ((uint32_t)ok << 8) | ((gcode & 7u) << 4) | ((uint32_t)ccode & 15u);
+// (2) one wavefront (its lane 0: the model is strictly sequential) per distinct shape.  The model lives in
+// scalar registers (it is wave-uniform); not inlined into k_step so that its SGPR spill slots do not become
+// VGPRs of every role - the fit role's occupancy is set by the kernel's VGPR count.
+__device__ __forceinline__ void role_choose(const ShapeArgs& h, uint32_t w, uint32_t waves, uint32_t tiles) {
+    // wavefront w of the role takes the shapes j = sub, sub + S, ... of tile (w mod tiles): a few shapes per wave
+    // keeps the role on few CUs (its scalar code competes with the fit role for the scalar unit and the I-cache)
+    const uint32_t S = waves / tiles ? waves / tiles : 1u;
+    if (w >= S * tiles) return;
+    const uint32_t tile = w % tiles, sub = w / tiles;
+    const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.count[tile]);
+    for (uint32_t j = sub; j < count; j += S) {
+        const uint32_t k = tile * 64 + j;
+        const unsigned long long kv = h.keys[k];
+        const unsigned long long key = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(kv >> 32)) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kv);
+        const int G = (int)(key & 3), U = (int)((key >> 2) & 1) + 1;
+        uint32_t gcode = 0;
+        int ccode = -1;
+        const bool ok = choose_tuples<SmallOps>(G, U, (uint32_t)(key >> 3) & 0xFF, (uint32_t)(key >> 19) & 0xFFFF,
+                                                (uint32_t)(key >> 11) & 0xFF, gcode, ccode, h.asc);
+        h.result[k] = ((uint32_t)ok << 8) | ((gcode & 7u) << 4) | ((uint32_t)ccode & 15u);
+    }
 }
 
-__global__ __launch_bounds__(64) void k_map_finish(MapArgs a, ShapeArgs h) {
-    __shared__ PaddedReq s_req[kTile];                 // request and winner detail are read field by field: LDS copies
-    __shared__ PaddedDetail s_det[kTile];
-    __shared__ nhdfit_mapping s_out[kTile];            // written slot by slot (dynamic indices): LDS, not scratch
-    stage_requests_lds<64>(a.reqs, blockIdx.x * 64, a.P, s_req);
-    __syncthreads();
-    const uint32_t p = blockIdx.x * 64 + threadIdx.x;
+// (3) lane = pod: first valid NIC choice under the chosen tuples.  Request, winner detail and result are accessed
+// field by field with dynamic indices: they stay in global memory (L2-resident), not in scratch.
+template <int THREADS>
+__device__ __forceinline__ void role_finish(const MapArgs& a, const ShapeArgs& h, uint32_t blk) {
+    const uint32_t p = blk * THREADS + threadIdx.x;
     if (p >= a.P) return;
-    const nhdfit_req& rq = s_req[threadIdx.x].r;
+    const nhdfit_req& rq = a.reqs[p];
     if (rq.n_groups > 3) return;                      // handled by k_map<true>
-    nhdfit_mapping& m = s_out[threadIdx.x];
+    nhdfit_mapping& m = a.out[p];
     memset(&m, 0, sizeof(m));
     const int32_t slot = h.slot_of_pod[p];
-    const uint32_t res = slot >= 0 ? h.result[slot] : 0u;
+    if (slot < 0) return;
+    const uint32_t res = h.result[slot];
     WinnerState w;
     uint32_t i;
-    if ((res >> 8 & 1) && load_winner(a, p, w, i)) {
-        const uint4* src = reinterpret_cast<const uint4*>(w.d);
-        uint4 v[sizeof(nhdfit_detail) / 16];
-#pragma unroll
-        for (uint32_t k = 0; k < sizeof(nhdfit_detail) / 16; ++k) v[k] = src[k];
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&s_det[threadIdx.x]);
-#pragma unroll
-        for (uint32_t k = 0; k < sizeof(nhdfit_detail) / 16; ++k) { dst[4 * k] = v[k].x; dst[4 * k + 1] = v[k].y; dst[4 * k + 2] = v[k].z; dst[4 * k + 3] = v[k].w; }
-        w.d = &s_det[threadIdx.x].d;
-        finish_mapping(rq, w, (res >> 4) & 7u, (int)(res & 15u), m);
+    if (!(res >> 8 & 1) || !load_winner(a, p, w, i)) return;
+    finish_mapping(rq, w, (res >> 4) & 7u, (int)(res & 15u), m);
+}
+
+// ---- the step kernel ---------------------------------------------------------------------------------
+// ONE launch per step.  The grid is the union of five block ranges ("roles") that work on five different steps of
+// the software pipeline:  [choose(i-2) | shapes(i-1) | finish(i-3) | digest(i+1) | fit(i)].  The four side roles
+// are short on work and long on latency (sequential set model, dependent look-ups); scheduled first, they run in
+// the shadow of the chip-filling fit role instead of serialising the stream with ~20-40 us kernels of their own.
+// Dependencies only cross launches (stream order).  A role with zero blocks is simply absent: the same kernel
+// serves a single find (five launches, one role each) and the pipeline flush.
+struct StepArgs {
+    uint32_t nb_choose, nb_shapes, nb_finish, nb_digest;     // blocks per side role, in grid order; fit takes the rest
+    uint32_t shapes_P;                                       // pods (= upper bound of the choose role's shape slots)
+    uint32_t side_prio;                                      // raise the side roles' issue priority
+    ShapeArgs choose;
+    MapArgs shapes_m; ShapeArgs shapes_h;
+    MapArgs finish_m; ShapeArgs finish_h;
+    DigestArgs digest;
+    FitArgs fit;
+    unsigned long long* role_clock;      // profiling aid (NHDFIT_ROLE_TIMES): [5][2] first start / last end per role, 100 MHz ticks
+};
+
+__device__ __forceinline__ void stamp(unsigned long long* role_clock, int role, unsigned long long t0) {
+    if (role_clock && threadIdx.x == 0) {
+        atomicMin(&role_clock[2 * role], t0);
+        atomicMax(&role_clock[2 * role + 1], (unsigned long long)wall_clock64());
     }
-    a.out[p] = m;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_fit_only(FitArgs a) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    role_fit<BLOCK>(a, blockIdx.x, lds);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 7) void k_step(StepArgs a) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    uint32_t blk = blockIdx.x;
+    const unsigned long long t0 = a.role_clock ? (unsigned long long)wall_clock64() : 0ull;
+    // the side roles are latency chains on a few wavefronts: with issue priority over the chip-filling fit role they
+    // finish (and free their block slots) sooner, at no cost in total work
+    if (blk < a.nb_choose + a.nb_shapes + a.nb_finish + a.nb_digest) { if (a.side_prio) __builtin_amdgcn_s_setprio(3); }
+    if (blk < a.nb_choose) {
+        if ((threadIdx.x & 63) == 0)
+            role_choose(a.choose, (uint32_t)__builtin_amdgcn_readfirstlane((int)(blk * (BLOCK / 64) + (threadIdx.x >> 6))),
+                        a.nb_choose * (BLOCK / 64), (a.shapes_P + kTile - 1) / kTile);
+        stamp(a.role_clock, 0, t0);
+        return;
+    }
+    blk -= a.nb_choose;
+    if (blk < a.nb_shapes) { role_shapes<BLOCK>(a.shapes_m, a.shapes_h, blk); stamp(a.role_clock, 1, t0); return; }
+    blk -= a.nb_shapes;
+    if (blk < a.nb_finish) { role_finish<BLOCK>(a.finish_m, a.finish_h, blk); stamp(a.role_clock, 2, t0); return; }
+    blk -= a.nb_finish;
+    if (blk < a.nb_digest) { role_digest<BLOCK>(a.digest, blk, lds); stamp(a.role_clock, 3, t0); return; }
+    blk -= a.nb_digest;
+    role_fit<BLOCK>(a.fit, blk, lds);
+    stamp(a.role_clock, 4, t0);
 }
 
 // ---- mode B: sequential resolver ------------------------------------------------------------------
@@ -607,19 +734,25 @@ struct DevBuf {
 };
 
 constexpr int kEventRing = 256;
-constexpr int kBufs = 8;          // buffer sets allocated; ctx->depth of them are cycled (pipeline depth)
-static int depth_env() { const char* e = getenv("NHDFIT_DEPTH"); int d = e ? atoi(e) : 5; return d < 1 ? 1 : d > kBufs ? kBufs : d; }
+constexpr int kBufs = 8;          // buffer sets: step s owns set s % kBufs from its digest (one launch before its fit)
+                                  // to the end of its mapping (four launches after it, five when sharded)
 
 }  // namespace
 
 struct nhdfit_ctx {
     int dev = -1;
-    hipStream_t stream = nullptr;        // the all-reduce of sharded runs (one communicator -> one stream)
-    int depth = depth_env();             // steps in flight
-    hipStream_t lane[kBufs] = {};        // step i runs digest -> fit -> mapping in order on lane[i % depth] with buffer
-                                         // set i % depth: stream order is the only dependency, steps overlap across lanes
-    hipEvent_t ev_fit[kBufs] = {}, ev_red[kBufs] = {};   // lane <-> all-reduce stream hand-over (sharded runs only)
-    uint64_t step = 0;                   // steps enqueued since the last stage_requests
+    hipStream_t stream = nullptr;        // the step launches, in order
+    hipStream_t s_red = nullptr;         // the all-reduce of sharded runs, overlapping the next step launch
+    hipEvent_t ev_fit[kBufs] = {}, ev_red[kBufs] = {};   // stream <-> s_red hand-over (sharded runs only)
+    // software pipeline: number of steps (since the last stage_requests) whose phase has been launched
+    uint64_t n_dig = 0, n_fit = 0, n_shaped = 0, n_chosen = 0, n_finished = 0;
+    bool geom_big = true;                // 512-thread step blocks (256 for small problems)
+    uint32_t digest_parts = getenv("NHDFIT_DIGEST_PARTS") ? (uint32_t)atoi(getenv("NHDFIT_DIGEST_PARTS")) : 2;   // tuning aid
+    uint32_t side_prio = getenv("NHDFIT_SIDE_PRIO") ? (uint32_t)atoi(getenv("NHDFIT_SIDE_PRIO")) : 1;   // tuning aid
+    uint32_t choose_split = getenv("NHDFIT_CHOOSE_SPLIT") ? (uint32_t)atoi(getenv("NHDFIT_CHOOSE_SPLIT")) : 64;   // tuning aid: wavefronts per tile
+    bool split = getenv("NHDFIT_SPLIT") != nullptr;
+    DevBuf<unsigned long long> role_clock;            // profiling aid: NHDFIT_ROLE_TIMES=<step> prints the role windows of that step
+    int64_t role_step = getenv("NHDFIT_ROLE_TIMES") ? atoll(getenv("NHDFIT_ROLE_TIMES")) : -1;   // profiling aid: launch the side roles apart from the fit role
     std::string err;
     hipDeviceProp_t prop;
 
@@ -643,14 +776,18 @@ struct nhdfit_ctx {
     std::vector<uint32_t> perm;          // device (class-sorted) position -> caller's pod index
     DevBuf<PodHeader> hdr[kBufs]; DevBuf<uint8_t> tabs[kBufs];
     DevBuf<unsigned long long> score[kBufs]; DevBuf<nhdfit_mapping> maps[kBufs];
-    DevBuf<uint64_t> bitmap[kBufs]; DevBuf<uint64_t> cand;
-    DevBuf<unsigned long long> shape_keys[kBufs]; DevBuf<uint32_t> shape_res[kBufs]; DevBuf<int32_t> shape_slot[kBufs];   // k_map_* dedup tables
+    DevBuf<uint64_t> bitmap;             // one buffer: the fit roles of consecutive steps run in stream order
+    DevBuf<uint64_t> cand;
+    DevBuf<unsigned long long> shape_keys[kBufs]; DevBuf<uint32_t> shape_res[kBufs]; DevBuf<int32_t> shape_slot[kBufs];   // mapping dedup tables
+    DevBuf<uint32_t> shape_list[kBufs];  // distinct shapes per tile
+    DevBuf<AscEntry> asc;                // layouts of ascending-filled CPython sets (static table, built at creation)
     // mode B
     DevBuf<uint64_t> nogpu; DevBuf<int32_t> slot_of; DevBuf<OverlayNode> overlay; DevBuf<SeqResult> seq_out; DevBuf<uint32_t> order;
     bool use_cand = false, want_bitmap = true, want_map = true;
 
     // timing
-    hipEvent_t ev[kEventRing][5];        // digest start / digest end / fit start / fit end / map end
+    hipEvent_t ev[kEventRing][2];        // start / end of sampled step launches
+    uint8_t ev_kind[kEventRing] = {};    // 0 = step launch with a fit role, 1 = digest-only launch
     int ev_pending = 0;
     nhdfit_stats stats;
 
@@ -679,24 +816,25 @@ int fail(nhdfit_ctx* c, int code, const char* fmt, ...) {
 
 int drain_events(nhdfit_ctx* c) {
     for (int k = 0; k < c->ev_pending; ++k) {
-        float d = 0, f = 0, s = 0;
-        HIPCHK(c, hipEventSynchronize(c->ev[k][4]));
-        HIPCHK(c, hipEventElapsedTime(&d, c->ev[k][0], c->ev[k][1]));
-        HIPCHK(c, hipEventElapsedTime(&f, c->ev[k][2], c->ev[k][3]));
-        HIPCHK(c, hipEventElapsedTime(&s, c->ev[k][0], c->ev[k][4]));
+        float f = 0;
+        HIPCHK(c, hipEventSynchronize(c->ev[k][1]));
+        HIPCHK(c, hipEventElapsedTime(&f, c->ev[k][0], c->ev[k][1]));
+        if (c->ev_kind[k]) { c->stats.digest_ms_last = f; continue; }
         c->stats.launches++;
         c->stats.fit_ms_total += f;
         c->stats.fit_ms_last = f;
-        c->stats.digest_ms_last = d;
-        c->stats.step_ms_last = s;
+        c->stats.step_ms_last = f;
     }
     c->ev_pending = 0;
     return NHDFIT_OK;
 }
 
+int flush_pipeline(nhdfit_ctx* c);
+
 int sync_all(nhdfit_ctx* c) {
-    for (int b = 0; b < c->depth; ++b) HIPCHK(c, hipStreamSynchronize(c->lane[b]));
+    { int rc_ = flush_pipeline(c); if (rc_) return rc_; }      // pending mapping phases of the last steps
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->s_red));
     return NHDFIT_OK;
 }
 
@@ -740,7 +878,7 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
         return rc;
     }
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    for (int b = 0; b < kBufs && e == hipSuccess; ++b) e = hipStreamCreateWithFlags(&c->lane[b], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_red, hipStreamNonBlocking);
     for (int b = 0; b < kBufs && e == hipSuccess; ++b) {
         e = hipEventCreateWithFlags(&c->ev_fit[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_red[b], hipEventDisableTiming);
@@ -748,8 +886,14 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
     for (auto& q : c->ev)
         for (auto& x : q)
             if (e == hipSuccess) e = hipEventCreate(&x);
+    if (e == hipSuccess) e = c->asc.reserve(kAscEntries);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_build_asc, dim3((kAscEntries + 255) / 256), dim3(256), 0, c->stream, c->asc.p);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
     if (e != hipSuccess) {
-        int rc = fail(nullptr, NHDFIT_E_HIP, "stream / event creation: %s", hipGetErrorString(e));
+        int rc = fail(nullptr, NHDFIT_E_HIP, "stream / event / table creation: %s", hipGetErrorString(e));
         nhdfit_destroy(c);
         return rc;
     }
@@ -764,19 +908,19 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
-    c->reqs.release(); c->cand.release(); c->group_sets.release();
-    for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); }
+    c->reqs.release(); c->bitmap.release(); c->cand.release(); c->role_clock.release(); c->asc.release(); c->group_sets.release();
+    for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); c->shape_list[b].release(); }
     c->nogpu.release(); c->slot_of.release(); c->overlay.release(); c->seq_out.release(); c->order.release();
     for (int b = 0; b < kBufs; ++b) {
-        c->hdr[b].release(); c->tabs[b].release(); c->score[b].release(); c->maps[b].release(); c->bitmap[b].release();
+        c->hdr[b].release(); c->tabs[b].release(); c->score[b].release(); c->maps[b].release();
         if (c->ev_fit[b]) (void)hipEventDestroy(c->ev_fit[b]);
         if (c->ev_red[b]) (void)hipEventDestroy(c->ev_red[b]);
-        if (c->lane[b]) (void)hipStreamDestroy(c->lane[b]);
     }
     for (auto& q : c->ev)
         for (auto& x : q)
             if (x) (void)hipEventDestroy(x);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->s_red) (void)hipStreamDestroy(c->s_red);
     delete c;
 }
 
@@ -823,8 +967,10 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     c->max_cores = max_cores_per_numa;
     c->max_gpus = max_gpus_per_numa;
     c->P = 0;                                       // staged tables (if any) were built for the old dictionary
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_score<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_score<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_only<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_only<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return NHDFIT_OK;
 }
 
@@ -874,9 +1020,8 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     HIPCHK(c, hipSetDevice(c->dev));
     { int rc_ = sync_all(c); if (rc_) return rc_; }
     { int rc_ = drain_events(c); if (rc_) return rc_; }
-    c->step = 0;
+    c->n_dig = c->n_fit = c->n_shaped = c->n_chosen = c->n_finished = 0;
     const uint32_t tiles = (P + kTile - 1) / kTile;
-    const uint32_t chunks = (c->capacity + 63) / 64;
     int32_t hp_max = 0;
     uint32_t g_max = 1;
     for (uint32_t p = 0; p < P; ++p) {
@@ -929,95 +1074,181 @@ static int stage_cand(nhdfit_ctx* c, const uint64_t* cand) {
     return NHDFIT_OK;
 }
 
+namespace {
+
+// One launch of the step kernel with every role that has work (see k_step).  `with_fit`: the fit role for step
+// n_fit plus the digest of step n_fit + 1; `flushing`: nothing new will follow, drain the mapping phases.
+int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool flushing) {
+    const uint32_t P = c->P, tiles = (P + kTile - 1) / kTile;
+    const uint32_t chunks = (c->n + 63) / 64;
+    const bool big = c->geom_big;
+    const uint32_t block = big ? 512 : 256, nw = block / 64;
+    const bool small_map = c->want_map && c->n_big_pods < P;
+
+    StepArgs a;
+    memset(&a, 0, sizeof a);
+    a.shapes_P = P;
+    a.side_prio = c->side_prio;
+    auto map_args = [&](int b) {
+        return MapArgs{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->det.p, c->tabs[b].p, c->layout, c->n,
+                       c->global_base, c->reqs.p, P, c->score[b].p, c->caps.p, c->maps[b].p};
+    };
+    auto shape_args = [&](int b) {
+        return ShapeArgs{c->shape_keys[b].p, c->shape_res[b].p, c->shape_slot[b].p, c->shape_list[b].p, c->asc.p};
+    };
+    // mapping phases of earlier steps: each advances by at most one step per launch
+    bool did_shapes = false, did_choose = false, did_finish = false;
+    if (small_map) {
+        if (c->n_finished < c->n_chosen) {
+            const int b = (int)(c->n_finished % kBufs);
+            a.finish_m = map_args(b); a.finish_h = shape_args(b); a.nb_finish = (P + block - 1) / block; did_finish = true;
+        }
+        if (c->n_chosen < c->n_shaped) {
+            a.choose = shape_args((int)(c->n_chosen % kBufs));
+            a.nb_choose = (tiles * c->choose_split + nw - 1) / nw; did_choose = true;
+        }
+        // scores of step s are final once its fit launch (and, sharded, its all-reduce) is done; sharded runs give
+        // the all-reduce one launch of slack so that it overlaps the next fit instead of stalling the stream
+        const uint64_t ready = c->comm && !flushing && c->n_fit ? c->n_fit - 1 : c->n_fit;
+        if (c->n_shaped < ready) {
+            const int b = (int)(c->n_shaped % kBufs);
+            if (c->comm) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_red[b], 0));
+            HIPCHK(c, c->shape_keys[b].reserve((size_t)tiles * kTile));
+            HIPCHK(c, c->shape_res[b].reserve((size_t)tiles * kTile));
+            HIPCHK(c, c->shape_slot[b].reserve(P));
+            HIPCHK(c, c->shape_list[b].reserve(tiles));
+            a.shapes_m = map_args(b); a.shapes_h = shape_args(b); a.nb_shapes = (P + block - 1) / block; did_shapes = true;
+        }
+    }
+    with_digest = with_digest && c->n_dig <= c->n_fit + (with_fit ? 1 : 0) + (c->split ? 1 : 0);   // at most one step ahead of the fit
+    if (with_digest) {
+        const int b = (int)(c->n_dig % kBufs);                              // the next undigested step
+        a.digest = DigestArgs{c->reqs.p, P,
+                              DictView{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}},
+                              c->layout, c->tabs[b].p, c->hdr[b].p, c->score[b].p,
+                              c->digest_parts};
+        a.nb_digest = tiles * c->digest_parts;
+    }
+    uint32_t nb_fit = 0;
+    int bf = -1;
+    if (with_fit) {
+        bf = (int)(c->n_fit % kBufs);
+        if (c->want_bitmap) HIPCHK(c, c->bitmap.reserve((size_t)chunks * P));
+        FitArgs& f = a.fit;
+        f.p0 = c->p0.p; f.p1 = c->p1.p; f.p2 = c->p2.p; f.p3 = c->p3.p; f.p4 = c->p4.p;
+        f.n = c->n; f.chunks = chunks; f.global_base = c->global_base; f.now = now;
+        f.tabs = c->tabs[bf].p; f.layout = c->layout; f.hdr = c->hdr[bf].p; f.P = P;
+        f.cand = c->use_cand ? c->cand.p : nullptr;
+        f.bitmap = c->want_bitmap ? c->bitmap.p : nullptr;
+        f.score = c->score[bf].p;
+        const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
+        uint32_t cpb = nw;                                                   // chunks per block: >= 1 per wave
+        while ((uint64_t)tiles * ((chunks + cpb * 2 - 1) / (cpb * 2)) >= 8ull * cus && cpb < nw * 8) cpb *= 2;
+        f.chunks_per_block = cpb;
+        f.nranges = (chunks + cpb - 1) / cpb;
+        nb_fit = tiles * f.nranges;
+    }
+    const uint32_t grid = a.nb_choose + a.nb_shapes + a.nb_finish + a.nb_digest + nb_fit;
+    if (!grid) return NHDFIT_OK;
+    // dynamic LDS of the launch: the largest need among the roles present
+    size_t lds = nb_fit ? lds_slice(c->layout.bytes) + (size_t)nw * 64 * sizeof(unsigned long long) : 0;
+    if (a.nb_digest && kDigestLds > lds) lds = kDigestLds;
+
+    // HIP-event timing is sampled (every 8th fit launch; every digest-only launch)
+    if (with_fit && (int64_t)c->n_fit == c->role_step) {
+        HIPCHK(c, c->role_clock.reserve(10));
+        unsigned long long init[10];
+        for (int k = 0; k < 5; ++k) { init[2 * k] = ~0ull; init[2 * k + 1] = 0; }
+        HIPCHK(c, hipMemcpyAsync(c->role_clock.p, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        a.role_clock = c->role_clock.p;
+    }
+    const bool timed = (with_fit && (c->n_fit < 2 || (c->n_fit & 7) == 0)) || (!with_fit && with_digest);
+    if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc) return rc; }
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][0], c->stream));
+    if (grid == nb_fit && c->split) {
+        if (big) hipLaunchKernelGGL((k_fit_only<512>), dim3(grid), dim3(512), lds, c->stream, a.fit);
+        else     hipLaunchKernelGGL((k_fit_only<256>), dim3(grid), dim3(256), lds, c->stream, a.fit);
+    } else
+    if (big) hipLaunchKernelGGL((k_step<512>), dim3(grid), dim3(512), lds, c->stream, a);
+    else     hipLaunchKernelGGL((k_step<256>), dim3(grid), dim3(256), lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    if (timed) {
+        HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
+        c->ev_kind[c->ev_pending++] = with_fit ? 0 : 1;
+    }
+    if (a.role_clock) {
+        unsigned long long t[10];
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
+        unsigned long long first = ~0ull;
+        for (int k = 0; k < 5; ++k) first = t[2 * k] < first ? t[2 * k] : first;
+        static const char* names[5] = {"choose", "shapes", "finish", "digest", "fit"};
+        for (int k = 0; k < 5; ++k)
+            if (t[2 * k + 1]) fprintf(stderr, "[nhdfit] step %lld role %-6s: first block starts +%.2f us, last block ends +%.2f us\n",
+                                      (long long)c->role_step, names[k], (t[2 * k] - first) * 0.01, (t[2 * k + 1] - first) * 0.01);
+    }
+    c->n_finished += did_finish; c->n_chosen += did_choose; c->n_shaped += did_shapes;
+    if (with_digest) c->n_dig++;
+    if (with_fit) {
+        hipStream_t after = c->stream;           // where the scores of this step become final
+        if (c->comm) {      // one communicator -> its collectives stay on one stream (s_red), in step order
+            HIPCHK(c, hipEventRecord(c->ev_fit[bf], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->s_red, c->ev_fit[bf], 0));
+            ncclResult_t r = g_rccl.AllReduce(c->score[bf].p, c->score[bf].p, P, ncclUint64, ncclMax, c->comm, c->s_red);
+            if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+            after = c->s_red;
+        }
+        if (c->want_map && c->n_big_pods) {      // pods with 4 proc groups: generic set model (scratch-heavy, kept out of k_step)
+            const dim3 mg((P + kMapWaves - 1) / kMapWaves), mb(64 * kMapWaves);
+            hipLaunchKernelGGL(k_map<true>, mg, mb, 0, after, map_args(bf));
+            HIPCHK(c, hipGetLastError());
+        }
+        if (c->comm) HIPCHK(c, hipEventRecord(c->ev_red[bf], c->s_red));
+        c->n_fit++;
+        c->stats.evals_last = (uint64_t)P * c->n;
+        // algorithmic bytes of the fit role: every tile streams the five node planes once,
+        // every block stages its tile image once, plus the bitmap and the score words.
+        c->stats.bytes_last = (uint64_t)tiles * c->n * 80ull + (uint64_t)nb_fit * c->lds_bytes +
+                              (c->want_bitmap ? (uint64_t)chunks * P * 8ull : 0ull) + (uint64_t)P * 8ull +
+                              (c->use_cand ? (uint64_t)chunks * P * 8ull : 0ull);
+        c->stats.nodes = c->n; c->stats.nsig = c->nsig; c->stats.ncls = c->ncls; c->stats.lds_bytes = c->lds_bytes;
+    }
+    return NHDFIT_OK;
+}
+
+int flush_pipeline(nhdfit_ctx* c) {
+    if (!c->P || !c->want_map || c->n_big_pods >= c->P) return NHDFIT_OK;
+    while (c->n_finished < c->n_fit) {
+        int rc = launch_step(c, false, false, 0.0, true);
+        if (rc) return rc;
+    }
+    return NHDFIT_OK;
+}
+
+}  // namespace
+
 int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     if (!c) return NHDFIT_E_INVAL;
     if (!c->P) return fail(c, NHDFIT_E_STATE, "stage requests first");
     if (!c->n) return fail(c, NHDFIT_E_STATE, "no nodes uploaded");
     HIPCHK(c, hipSetDevice(c->dev));
-    if (c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc) return rc; }
-    hipEvent_t* ev = c->ev[c->ev_pending];
-    const uint32_t P = c->P, tiles = (P + kTile - 1) / kTile;
-    const uint32_t chunks = (c->n + 63) / 64;
-
-    const int b = (int)(c->step % c->depth);
-
-    // step i = digest -> fit(+score+select) -> [all-reduce] -> winner mapping, all on lane[i % depth] with buffer set
-    // i % depth: no events between the stages, and a lane is free again exactly when its previous step is done.
-    // HIP-event timing is sampled (every 8th step): the host is the bottleneck otherwise (~5 us per API call)
-    hipStream_t sb = c->lane[b];
-    const bool timed = c->step < 2 || (c->step & 7) == 0;
-    uint32_t shape_slots = 1024;
-    while (shape_slots < 2 * P) shape_slots <<= 1;
-    const bool small_map = c->want_map && c->n_big_pods < P;
-    if (small_map) {
-        HIPCHK(c, c->shape_keys[b].reserve(shape_slots));
-        HIPCHK(c, c->shape_res[b].reserve(shape_slots));
-        HIPCHK(c, c->shape_slot[b].reserve(P));
+    if (c->n_fit == 0) {
+        // 512-thread blocks (8 waves; 3 co-resident blocks per CU at 70 VGPRs: one block's LDS fill overlaps the
+        // others' sweep), 256-thread blocks for small problems so that the grid still covers the chip
+        const uint32_t tiles = (c->P + kTile - 1) / kTile, chunks = (c->n + 63) / 64;
+        c->geom_big = (uint64_t)tiles * ((chunks + 31) / 32) >= (uint32_t)c->prop.multiProcessorCount;
     }
-    if (c->want_bitmap) HIPCHK(c, c->bitmap[b].reserve((size_t)chunks * P));
-    if (timed) HIPCHK(c, hipEventRecord(ev[0], sb));
-    DictView dv{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}};
-    hipLaunchKernelGGL(k_digest, dim3(tiles, kDigestSlices), dim3(kDigestThreads), 0, sb,
-                       c->reqs.p, P, dv, c->layout, c->tabs[b].p, c->hdr[b].p, c->score[b].p,
-                       small_map ? c->shape_keys[b].p : nullptr, shape_slots);
-    if (timed) HIPCHK(c, hipEventRecord(ev[1], sb));
-
-    FitArgs a;
-    a.p0 = c->p0.p; a.p1 = c->p1.p; a.p2 = c->p2.p; a.p3 = c->p3.p; a.p4 = c->p4.p;
-    a.n = c->n; a.chunks = chunks; a.global_base = c->global_base; a.now = now;
-    a.tabs = c->tabs[b].p; a.layout = c->layout; a.hdr = c->hdr[b].p; a.P = P;
-    a.cand = c->use_cand ? c->cand.p : nullptr;
-    a.bitmap = c->want_bitmap ? c->bitmap[b].p : nullptr;
-    a.score = c->score[b].p;
-    const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
-    // 512-thread blocks (8 waves; 3 co-resident blocks per CU at 70 VGPRs: one block's LDS fill overlaps the others'
-    // sweep), 256-thread blocks for small problems so that the grid still covers the chip
-    const bool big = (uint64_t)tiles * ((chunks + 31) / 32) >= cus;
-    const uint32_t waves = big ? 8 : 4;
-    uint32_t cpb = waves;                                                // chunks per block: >= 1 per wave
-    while ((uint64_t)tiles * ((chunks + cpb * 2 - 1) / (cpb * 2)) >= 8ull * cus && cpb < waves * 8) cpb *= 2;
-    a.chunks_per_block = cpb;
-    a.nranges = (chunks + cpb - 1) / cpb;
-    const uint32_t grid = tiles * a.nranges;
-    if (timed) HIPCHK(c, hipEventRecord(ev[2], sb));
-    if (big) hipLaunchKernelGGL((k_fit_score<512>), dim3(grid), dim3(512), c->lds_bytes, sb, a);
-    else     hipLaunchKernelGGL((k_fit_score<256>), dim3(grid), dim3(256), c->lds_bytes, sb, a);
-    if (timed) HIPCHK(c, hipEventRecord(ev[3], sb));
-    if (c->comm) {      // one communicator -> its collectives stay on one stream, in step order
-        HIPCHK(c, hipEventRecord(c->ev_fit[b], sb));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fit[b], 0));
-        ncclResult_t r = g_rccl.AllReduce(c->score[b].p, c->score[b].p, P, ncclUint64, ncclMax, c->comm, c->stream);
-        if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
-        HIPCHK(c, hipEventRecord(c->ev_red[b], c->stream));
-        HIPCHK(c, hipStreamWaitEvent(sb, c->ev_red[b], 0));
+    if (c->n_dig <= c->n_fit) {                      // first step after staging: its digest has not run yet
+        int rc = launch_step(c, false, true, now, false);
+        if (rc) return rc;
     }
-    if (c->want_map) {
-        MapArgs m{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->det.p, c->tabs[b].p, c->layout, c->n,
-                  c->global_base, c->reqs.p, P, c->score[b].p, c->caps.p, c->maps[b].p};
-        const dim3 mg((P + kMapWaves - 1) / kMapWaves), mb(64 * kMapWaves);
-        if (small_map) {
-            ShapeArgs h{c->shape_keys[b].p, c->shape_res[b].p, c->shape_slot[b].p, shape_slots};
-            hipLaunchKernelGGL(k_map_shapes, dim3((P + 63) / 64), dim3(64), 0, sb, m, h);
-            hipLaunchKernelGGL(k_map_choose, dim3(shape_slots / 4), dim3(256), 0, sb, h);
-            hipLaunchKernelGGL(k_map_finish, dim3((P + 63) / 64), dim3(64), 0, sb, m, h);
-        }
-        if (c->n_big_pods) hipLaunchKernelGGL(k_map<true>, mg, mb, 0, sb, m);
+    if (c->split) {                                  // profiling aid: side roles and fit role as two launches
+        int rc = launch_step(c, false, true, now, false);
+        if (rc) return rc;
+        return launch_step(c, true, false, now, false);
     }
-    HIPCHK(c, hipGetLastError());
-    if (timed) {
-        HIPCHK(c, hipEventRecord(ev[4], sb));
-        c->ev_pending++;
-    }
-    c->step++;
-
-    c->stats.evals_last = (uint64_t)P * c->n;
-    // algorithmic bytes of the fit_score launch: every tile streams the five node
-    // planes once, every block stages its tile image once, plus the bitmap and the score words.
-    c->stats.bytes_last = (uint64_t)tiles * c->n * 80ull + (uint64_t)grid * c->lds_bytes +
-                          (c->want_bitmap ? (uint64_t)chunks * P * 8ull : 0ull) + (uint64_t)P * 8ull +
-                          (c->use_cand ? (uint64_t)chunks * P * 8ull : 0ull);
-    c->stats.nodes = c->n; c->stats.nsig = c->nsig; c->stats.ncls = c->ncls; c->stats.lds_bytes = c->lds_bytes;
-    return NHDFIT_OK;
+    return launch_step(c, true, true, now, false);
 }
 
 int nhdfit_sync(nhdfit_ctx* c) {
@@ -1029,11 +1260,11 @@ int nhdfit_sync(nhdfit_ctx* c) {
 
 int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out) {
     if (!c) return NHDFIT_E_INVAL;
-    if (!c->P || !c->step) return fail(c, NHDFIT_E_STATE, "nothing staged / no step enqueued");
+    if (!c->P || !c->n_fit) return fail(c, NHDFIT_E_STATE, "nothing staged / no step enqueued");
     int rc = nhdfit_sync(c);
     if (rc) return rc;
     const uint32_t P = c->P;
-    const int b = (int)((c->step - 1) % c->depth);             // results of the most recent step
+    const int b = (int)((c->n_fit - 1) % kBufs);               // results of the most recent step
     if (score_out) {
         std::vector<uint64_t> tmp(P);
         HIPCHK(c, hipMemcpy(tmp.data(), c->score[b].p, (size_t)P * 8, hipMemcpyDeviceToHost));
@@ -1043,7 +1274,7 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
         if (!c->want_bitmap) return fail(c, NHDFIT_E_STATE, "bitmap output is disabled");
         const size_t chunks = (c->n + 63) / 64;
         std::vector<uint64_t> tmp(chunks * P);
-        HIPCHK(c, hipMemcpy(tmp.data(), c->bitmap[b].p, chunks * P * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(tmp.data(), c->bitmap.p, chunks * P * 8, hipMemcpyDeviceToHost));
         for (size_t ch = 0; ch < chunks; ++ch)
             for (uint32_t i = 0; i < P; ++i) bitmap_out[ch * P + c->perm[i]] = tmp[ch * P + i];
     }
@@ -1077,7 +1308,8 @@ int nhdfit_find_sequential(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, do
     if (!rc) rc = nhdfit_enqueue_step(c, now);
     c->want_bitmap = wb; c->want_map = wm;
     if (rc) return rc;
-    const int b = (int)((c->step - 1) % c->depth);
+    if ((rc = flush_pipeline(c))) return rc;                  // the resolver starts from the snapshot mappings
+    const int b = (int)((c->n_fit - 1) % kBufs);
     const uint32_t chunks = (c->n + 63) / 64;
     HIPCHK(c, c->nogpu.reserve(chunks));
     HIPCHK(c, c->slot_of.reserve(c->n));
@@ -1086,12 +1318,12 @@ int nhdfit_find_sequential(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, do
     HIPCHK(c, c->order.reserve(P));
     std::vector<uint32_t> order(P);                       // caller's pod -> staged (class-sorted) position
     for (uint32_t i = 0; i < P; ++i) order[c->perm[i]] = i;
-    hipStream_t sm = c->lane[b];
+    hipStream_t sm = c->stream;
     HIPCHK(c, hipMemcpyAsync(c->order.p, order.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
     HIPCHK(c, hipMemsetAsync(c->slot_of.p, 0xFF, (size_t)c->n * sizeof(int32_t), sm));
     hipLaunchKernelGGL(k_nogpu, dim3(chunks), dim3(64), 0, sm, c->p2.p, c->n, c->nogpu.p);
     ResolveArgs ra{SeqStatic{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->p4.p, c->det.p, c->caps.p, c->n, c->global_base, now},
-                   c->reqs.p, c->hdr[b].p, c->score[b].p, c->maps[b].p, c->bitmap[b].p, c->nogpu.p, c->order.p, P, chunks,
+                   c->reqs.p, c->hdr[b].p, c->score[b].p, c->maps[b].p, c->bitmap.p, c->nogpu.p, c->order.p, P, chunks,
                    c->slot_of.p, c->overlay.p, c->seq_out.p};
     if (c->n_big_pods) hipLaunchKernelGGL(k_resolve<false>, dim3(1), dim3(64), 0, sm, ra);   // after the mapping, same stream
     else hipLaunchKernelGGL(k_resolve<true>, dim3(1), dim3(64), 0, sm, ra);
@@ -1110,6 +1342,11 @@ int nhdfit_find_sequential(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, do
 
 int nhdfit_set_outputs(nhdfit_ctx* c, int want_bitmap, int want_map) {
     if (!c) return NHDFIT_E_INVAL;
+    if ((want_bitmap != 0) != c->want_bitmap || (want_map != 0) != c->want_map) {   // steps in flight keep the old setting
+        HIPCHK(c, hipSetDevice(c->dev));
+        int rc_ = sync_all(c);
+        if (rc_) return rc_;
+    }
     c->want_bitmap = want_bitmap != 0;
     c->want_map = want_map != 0;
     return NHDFIT_OK;

@@ -158,24 +158,88 @@ NHD_HD int ps_list(const PySet& s, int16_t* out) {
 }
 
 
-// ---- register-resident variant for tables that never outgrow 32 slots (<= 18 keys) -----------------
-// Same insertion / growth / intersection rules as PySet above.  Keys live in four 64-bit registers
-// (8 bits per slot) and occupancy in a 32-bit mask, so the winner-mapping kernel does not touch
-// scratch memory for pods with G <= 3 (at most 2^(G+1) = 16 distinct tuples).  Hashes are recomputed
-// from the key (hash(tuple) is a pure function of its digits).
+// ---- register-resident variant for tables that never outgrow 32 slots (<= 16 keys < 16) ------------
+// Same insertion / growth / intersection rules as PySet above.  Keys live in two 64-bit registers (4 bits per
+// slot) and occupancy in a 32-bit mask, so the winner-mapping code does not touch scratch memory for pods with
+// G <= 3 (tuples of length <= 4: at most 16 distinct tuple codes).
 struct SmallSet {
-    uint32_t used;
+    uint32_t used;                // occupied slots
+    uint32_t present;             // keys in the set (bit = tuple code): membership without probing
     int mask, fill, len, base;
-    uint64_t k0, k1, k2, k3;
+    uint64_t k0, k1;              // key of slot i: 4 bits each
 };
+
+// The slots CPython examines for a key, in order (set_add_entry: the home slot, its LINEAR_PROBES successors when
+// they exist, then the perturbed recurrence), depend only on (tuple length, key, table size).
+//  * home slots: compile-time constants per tuple length (3 / 5 bits per key) - the common case costs no memory access;
+//  * the rest of the probe order: tabulated at compile time, 24 probes of 5 bits per (length, table size, key), read
+//    only after a collision.  Rows that run out (never observed: a 32-slot table holds at most 16 keys here) fall
+//    back to the live recurrence.
+constexpr uint64_t home_slots(int len, uint64_t mask, int bits, uint32_t first, uint32_t count) {
+    uint64_t w = 0;
+    for (uint32_t k = 0; k < count; ++k)
+        if (first + k < (1u << len)) w |= (py_tuple_hash_calc(first + k, len) & mask) << (bits * k);
+    return w;
+}
+template <int LEN> struct HomeSlots {
+    static constexpr uint64_t h7 = home_slots(LEN, 7, 3, 0, 16);        // keys 0..15, 3 bits each
+    static constexpr uint64_t h31lo = home_slots(LEN, 31, 5, 0, 12);    // keys 0..11, 5 bits each
+    static constexpr uint64_t h31hi = home_slots(LEN, 31, 5, 12, 4);    // keys 12..15
+};
+NHD_HD int home_slot(int len, int mask, int key) {
+    if (mask == 7) {
+        const uint64_t w = len == 1 ? HomeSlots<1>::h7 : len == 2 ? HomeSlots<2>::h7 : len == 3 ? HomeSlots<3>::h7 : HomeSlots<4>::h7;
+        return (int)((w >> (3 * key)) & 7u);
+    }
+    const uint64_t lo = len == 1 ? HomeSlots<1>::h31lo : len == 2 ? HomeSlots<2>::h31lo : len == 3 ? HomeSlots<3>::h31lo : HomeSlots<4>::h31lo;
+    const uint64_t hi = len == 1 ? HomeSlots<1>::h31hi : len == 2 ? HomeSlots<2>::h31hi : len == 3 ? HomeSlots<3>::h31hi : HomeSlots<4>::h31hi;
+    return (int)(((key < 12 ? lo >> (5 * key) : hi >> (5 * (key - 12)))) & 31u);
+}
+
+constexpr int kProbeLen = 24;
+struct ProbeRow { uint64_t lo, hi; };                     // probes 0..11 / 12..23
+struct ProbeTable { ProbeRow row[5][2][16]; };            // [tuple length][0: 8 slots, 1: 32 slots][key]
+constexpr ProbeTable make_probe_table() {
+    ProbeTable t{};
+    for (int len = 0; len <= 4; ++len)
+        for (int mi = 0; mi < 2; ++mi)
+            for (uint32_t key = 0; key < 16; ++key) {
+                if (key >= (1u << len)) continue;
+                const uint64_t mask = mi ? 31 : 7;
+                const uint64_t h = py_tuple_hash_calc(key, len);
+                uint64_t perturb = h, i = h & mask, lo = 0, hi = 0;
+                int n = 0;
+                while (n < kProbeLen) {
+                    const int probes = (i + 9 <= mask) ? 9 : 0;
+                    for (int j = 0; j <= probes && n < kProbeLen; ++j, ++n) {
+                        if (n < 12) lo |= (i + j) << (5 * n); else hi |= (i + j) << (5 * (n - 12));
+                    }
+                    perturb >>= 5;
+                    i = (i * 5 + 1 + perturb) & mask;
+                }
+                t.row[len][mi][key] = ProbeRow{lo, hi};
+            }
+    return t;
+}
+#if defined(__HIPCC__)
+__device__ const ProbeTable kProbeDev = make_probe_table();
+#endif
+static constexpr ProbeTable kProbeHost = make_probe_table();
+NHD_HD ProbeRow probe_row(int len, int mask, uint32_t key) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return kProbeDev.row[len][mask > 7][key & 15u];
+#else
+    return kProbeHost.row[len][mask > 7][key & 15u];
+#endif
+}
 
 // NOTE: every helper takes and returns the set BY VALUE.  With reference parameters LLVM turns the
 // "which 64-bit word holds this slot" selects into address arithmetic on the struct, which pins all
-// sets in scratch memory (400 B/lane, and a scratch-limited occupancy) instead of registers.
+// sets in scratch memory instead of registers.
 NHD_HD SmallSet ss_make(int len, int base) {
     SmallSet s;
-    s.used = 0; s.mask = 7; s.fill = 0; s.len = len; s.base = base;
-    s.k0 = s.k1 = s.k2 = s.k3 = 0;
+    s.used = 0; s.present = 0; s.mask = 7; s.fill = 0; s.len = len; s.base = base;
+    s.k0 = s.k1 = 0;
     return s;
 }
 // next occupied slot >= from, or -1 (sets are walked in slot order = CPython iteration order)
@@ -185,50 +249,75 @@ NHD_HD int ss_next(SmallSet s, int from) {
     return m ? from + __builtin_ctz(m) : -1;
 }
 NHD_HD int ss_key(SmallSet s, int slot) {
-    const uint64_t w = slot < 16 ? (slot < 8 ? s.k0 : s.k1) : (slot < 24 ? s.k2 : s.k3);
-    return (int)((w >> ((slot & 7) * 8)) & 0xFF);
+    return (int)(((slot < 16 ? s.k0 : s.k1) >> ((slot & 15) * 4)) & 15u);
 }
 NHD_HD SmallSet ss_put(SmallSet s, int slot, int key) {
-    const uint64_t v = (uint64_t)key << ((slot & 7) * 8);
-    s.k0 |= slot < 8 ? v : 0;
-    s.k1 |= (slot >= 8 && slot < 16) ? v : 0;
-    s.k2 |= (slot >= 16 && slot < 24) ? v : 0;
-    s.k3 |= slot >= 24 ? v : 0;
+    const uint64_t v = (uint64_t)key << ((slot & 15) * 4);
+    s.k0 |= slot < 16 ? v : 0;
+    s.k1 |= slot >= 16 ? v : 0;
     s.used |= 1u << slot;
     return s;
 }
-// slot where `key` lives (>= 0), or -(free slot)-1 where it would be inserted
-NHD_HD int ss_probe(SmallSet s, int key, uint64_t h, bool match) {
+// first free slot in the order CPython examines them for `key` (the key is known to be absent)
+NHD_HD int ss_free_slot(uint32_t used, int mask, int len, int key) {
+    const int home = home_slot(len, mask, key);
+    if (!(used >> home & 1)) return home;
+    const ProbeRow r = probe_row(len, mask, (uint32_t)key);
+    uint64_t w = r.lo;
+    for (int n = 0; n < kProbeLen; ++n) {
+        if (n == 12) w = r.hi;
+        const int slot = (int)(w & 31u);
+        if (!(used >> slot & 1)) return slot;
+        w >>= 5;
+    }
+    // beyond the tabulated prefix: the live recurrence, from the start
+    const uint64_t h = py_tuple_hash((uint32_t)key, len, 2);
     uint64_t perturb = h;
-    uint32_t i = (uint32_t)(h & (uint64_t)s.mask);
+    uint32_t i = (uint32_t)(h & (uint64_t)mask);
     for (;;) {
-        const int probes = (i + 9 <= (uint32_t)s.mask) ? 9 : 0;
-        for (int j = 0; j <= probes; ++j) {
-            if (!(s.used >> (i + j) & 1)) return -(int)(i + j) - 1;
-            if (match && ss_key(s, (int)(i + j)) == key) return (int)(i + j);
-        }
+        const int probes = (i + 9 <= (uint32_t)mask) ? 9 : 0;
+        for (int j = 0; j <= probes; ++j)
+            if (!(used >> (i + j) & 1)) return (int)(i + j);
         perturb >>= 5;
-        i = (uint32_t)((i * 5 + 1 + perturb) & (uint64_t)s.mask);
+        i = (uint32_t)((i * 5 + 1 + perturb) & (uint64_t)mask);
     }
 }
 NHD_HD SmallSet ss_add(SmallSet s, int key) {
-    const uint64_t h = py_tuple_hash((uint32_t)key, s.len, s.base);
-    const int r = ss_probe(s, key, h, true);
-    if (r >= 0) return s;
-    s = ss_put(s, -r - 1, key);
+    if (s.present >> key & 1) return s;
+    s = ss_put(s, ss_free_slot(s.used, s.mask, s.len, key), key);
+    s.present |= 1u << key;
     s.fill++;
     if (s.fill * 5 >= s.mask * 3) {                   // 8 -> 32 slots (set_table_resize(used*4)); never further
         const SmallSet o = s;
-        s.used = 0; s.mask = 31; s.k0 = s.k1 = s.k2 = s.k3 = 0;
+        s.used = 0; s.mask = 31; s.k0 = s.k1 = 0;
         for (int i = ss_next(o, 0); i >= 0; i = ss_next(o, i + 1)) {
             const int k = ss_key(o, i);
-            s = ss_put(s, -ss_probe(s, k, py_tuple_hash((uint32_t)k, s.len, s.base), false) - 1, k);
+            s = ss_put(s, ss_free_slot(s.used, 31, s.len, k), k);
         }
     }
     return s;
 }
-NHD_HD bool ss_has(SmallSet s, int key) {
-    return ss_probe(s, key, py_tuple_hash((uint32_t)key, s.len, s.base), true) >= 0;
+NHD_HD bool ss_has(SmallSet s, int key) { return (s.present >> key & 1) != 0; }
+
+// A set filled in ascending code order (how the reference builds its candidate sets, Matcher.py:116-141, 206-220)
+// is a pure function of (tuple length, which codes): its final layout is tabulated once per process - by this very
+// model (asc_entry_build below, on the device at context creation / on the host on first use) - for all
+// 4 + 16 + 256 + 65536 subsets of the 2, 4, 8 or 16 tuples of length 1..4.
+struct AscEntry { uint32_t used, pad; uint64_t k0, k1; };                  // 24 bytes
+constexpr uint32_t kAscOffset[5] = {0, 0, 4, 20, 276};                    // first entry of tuple length 1..4
+constexpr uint32_t kAscEntries = 276 + 65536;
+NHD_HD AscEntry asc_entry_build(int len, uint32_t subset) {
+    SmallSet s = ss_make(len, 2);
+    for (uint32_t code = 0; code < (1u << len); ++code)
+        if (subset >> code & 1) s = ss_add(s, (int)code);
+    return AscEntry{s.used, 0u, s.k0, s.k1};
+}
+NHD_HD SmallSet ss_from_asc(const AscEntry* table, int len, int base, uint32_t subset) {
+    const AscEntry e = table[kAscOffset[len] + subset];
+    SmallSet s;
+    s.used = e.used; s.present = subset; s.fill = popc32(subset); s.mask = s.fill >= 5 ? 31 : 7;
+    s.len = len; s.base = base; s.k0 = e.k0; s.k1 = e.k1;
+    return s;
 }
 // a & b: iterate the smaller operand (b on ties) in slot order, probe the other (set_intersection)
 NHD_HD SmallSet ss_intersect(SmallSet a, SmallSet b) {
@@ -253,6 +342,12 @@ NHD_HD int ss_list(SmallSet s, int16_t* out) {
 struct GenericOps {
     typedef PySet Set;
     NHD_HD static void init(Set& s, int, int) { ps_init(s); }
+    // set filled with the codes of `subset` in ascending order
+    NHD_HD static void from_subset(Set& s, const AscEntry*, int len, int base, uint32_t subset) {
+        ps_init(s);
+        for (uint32_t code = 0; code < 32; ++code)
+            if (subset >> code & 1) ps_add(s, (int16_t)code, py_tuple_hash(code, len, base));
+    }
     NHD_HD static void add(Set& s, int key, int len, int base) { ps_add(s, (int16_t)key, py_tuple_hash((uint32_t)key, len, base)); }
     NHD_HD static void isect(const Set& a, const Set& b, Set& o) { ps_intersect(a, b, o); }
     NHD_HD static int list(const Set& s, int16_t* o) { return ps_list(s, o); }
@@ -263,6 +358,12 @@ struct GenericOps {
 struct SmallOps {
     typedef SmallSet Set;
     NHD_HD static void init(Set& s, int len, int base) { s = ss_make(len, base); }
+    NHD_HD static void from_subset(Set& s, const AscEntry* table, int len, int base, uint32_t subset) {
+        if (table) { s = ss_from_asc(table, len, base, subset); return; }
+        s = ss_make(len, base);
+        for (uint32_t code = 0; code < (1u << len); ++code)
+            if (subset >> code & 1) s = ss_add(s, (int)code);
+    }
     NHD_HD static void add(Set& s, int key, int, int) { s = ss_add(s, key); }
     NHD_HD static void isect(const Set& a, const Set& b, Set& o) { o = ss_intersect(a, b); }
     NHD_HD static int list(const Set& s, int16_t* o) { return ss_list(s, o); }
@@ -378,25 +479,22 @@ NHD_HD int pick_gpu_tuple(const typename Ops::Set& gset, int G, int U) {
 //   sg_mask / sc_mask / nic_codes : bit c = tuple code c is a valid GPU / CPU(+misc) / NIC assignment
 // Returns false if the three prefix sets do not intersect, else the chosen GPU tuple and CPU tuple codes.
 template <class Ops>
-NHD_HD bool choose_tuples(int G, int U, uint32_t sg_mask, uint32_t sc_mask, uint32_t nic_codes, uint32_t& gcode, int& ccode) {
+NHD_HD bool choose_tuples(int G, int U, uint32_t sg_mask, uint32_t sc_mask, uint32_t nic_codes, uint32_t& gcode, int& ccode,
+                          const AscEntry* asc = nullptr) {
     typedef typename Ops::Set Set;
     const uint32_t nG = ipow(U, G), nC = ipow(U, G + 1);
     // candidate sets in product order (Matcher.py:116-141, 206-220).  list(set) = keys in slot order, so the
-    // "lists" of the reference are never materialised: the sets' slots are walked instead.
+    // "lists" of the reference are never materialised: the sets' slots are walked instead.  `asc`: the table of
+    // ascending-filled sets (AscEntry), or null to build them insertion by insertion.
     Set sg, sc;
-    Ops::init(sg, G, U);
-    Ops::init(sc, G + 1, U);
-    for (uint32_t code = 0; code < nG; ++code)
-        if (sg_mask >> code & 1) Ops::add(sg, (int)code, G, U);
-    for (uint32_t code = 0; code < nC; ++code)
-        if (sc_mask >> code & 1) Ops::add(sc, (int)code, G + 1, U);
+    Ops::from_subset(sg, asc, G, U, sg_mask & ((1u << nG) - 1u));
+    Ops::from_subset(sc, asc, G + 1, U, sc_mask & (nC >= 32 ? ~0u : (1u << nC) - 1u));
     // intersection of the three prefix sets (Matcher.py:342-346): set(list) re-inserts in list order
     Set a, b, c, ab, abc;
-    Ops::init(a, G, U); Ops::init(b, G, U); Ops::init(c, G, U);
+    Ops::init(a, G, U); Ops::init(b, G, U);
     for (int i = Ops::next(sg, 0); i >= 0; i = Ops::next(sg, i + 1)) Ops::add(a, Ops::key_at(sg, i), G, U);
     for (int i = Ops::next(sc, 0); i >= 0; i = Ops::next(sc, i + 1)) Ops::add(b, Ops::key_at(sc, i) >> (U - 1), G, U);   // tuple[:-1]
-    for (uint32_t code = 0; code < nG; ++code)
-        if (nic_codes >> code & 1) Ops::add(c, (int)code, G, U);
+    Ops::from_subset(c, asc, G, U, nic_codes & ((1u << nG) - 1u));
     Ops::isect(a, b, ab);
     Ops::isect(ab, c, abc);
     if (Ops::size(abc) == 0) return false;

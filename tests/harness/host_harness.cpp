@@ -196,4 +196,36 @@ int hh_small_isect3(const int16_t* a, int na, const int16_t* b, int nb, const in
 
 uint64_t hh_tuple_hash(uint32_t code, int len, int base) { return py_tuple_hash(code, len, base); }
 
+// the table of ascending-filled sets (AscEntry), built by the model itself exactly as k_build_asc does on the device
+static const AscEntry* host_asc_table() {
+    static std::vector<AscEntry> t;
+    if (t.empty()) {
+        t.resize(kAscEntries);
+        for (int len = 1; len <= 4; ++len)
+            for (uint32_t sub = 0; sub < (1u << (1u << len)); ++sub) t[kAscOffset[len] + sub] = asc_entry_build(len, sub);
+    }
+    return t.data();
+}
+
+// list(set filled with `subset` in ascending order) read back from the table
+int hh_asc_set_list(uint32_t subset, int len, int base, int16_t* out) {
+    return ss_list(ss_from_asc(host_asc_table(), len, base, subset), out);
+}
+
+// choose_tuples (register model) with / without the table; returns ok, writes gcode / ccode
+int hh_choose(int G, int U, uint32_t sg, uint32_t sc, uint32_t nic, int use_table, uint32_t* gcode, int* ccode) {
+    uint32_t g = 0; int c = -1;
+    const bool ok = choose_tuples<SmallOps>(G, U, sg, sc, nic, g, c, use_table ? host_asc_table() : nullptr);
+    *gcode = g; *ccode = c;
+    return ok ? 1 : 0;
+}
+
+// the same through the generic (PySet) model
+int hh_choose_generic(int G, int U, uint32_t sg, uint32_t sc, uint32_t nic, uint32_t* gcode, int* ccode) {
+    uint32_t g = 0; int c = -1;
+    const bool ok = choose_tuples<GenericOps>(G, U, sg, sc, nic, g, c);
+    *gcode = g; *ccode = c;
+    return ok ? 1 : 0;
+}
+
 }  // extern "C"

@@ -126,3 +126,36 @@ def test_register_model_matches_python(length):
         n = L.hh_small_isect3(*(v for a in arrs for v in (a.ctypes.data_as(ctypes.c_void_p), len(a))), length, 2,
                               out.ctypes.data_as(ctypes.c_void_p))
         assert tuples_of(out[:n], length, 2) == want
+
+
+@pytest.mark.parametrize("length", [1, 2, 3, 4])
+def test_ascending_table_matches_python(length):
+    """The static table of ascending-filled sets (AscEntry; what the choose role reads instead of inserting
+    code by code) == list(set) of CPython for every subset (length 4: all 65 536 of them)."""
+    L = harness.lib()
+    universe = list(itertools.product(range(2), repeat=length))
+    out = np.zeros(64, np.int16)
+    for subset in range(1 << len(universe)):
+        s = set()
+        for i, t in enumerate(universe):
+            if subset >> i & 1:
+                s.add(t)
+        n = L.hh_asc_set_list(subset, length, 2, out.ctypes.data_as(ctypes.c_void_p))
+        assert tuples_of(out[:n], length, 2) == list(s), (length, subset)
+
+
+def test_choose_tuples_table_vs_insertion_vs_generic():
+    """choose_tuples: table-backed register model == insertion-built register model == generic PySet model."""
+    L = harness.lib()
+    rng = np.random.default_rng(99)
+    g1, c1, g2, c2, g3, c3 = (ctypes.c_uint32(), ctypes.c_int(), ctypes.c_uint32(), ctypes.c_int(), ctypes.c_uint32(), ctypes.c_int())
+    for _ in range(40000):
+        G = int(rng.integers(1, 4)); U = int(rng.integers(1, 3))
+        nG, nC = (1 << G, 1 << (G + 1)) if U == 2 else (1, 1)
+        sg = int(rng.integers(1, 1 << nG)); sc = int(rng.integers(1, 1 << nC)); nic = int(rng.integers(1, 1 << nG))
+        a = L.hh_choose(G, U, sg, sc, nic, 1, ctypes.byref(g1), ctypes.byref(c1))
+        b = L.hh_choose(G, U, sg, sc, nic, 0, ctypes.byref(g2), ctypes.byref(c2))
+        c = L.hh_choose_generic(G, U, sg, sc, nic, ctypes.byref(g3), ctypes.byref(c3))
+        assert a == b == c, (G, U, sg, sc, nic)
+        if a:
+            assert (g1.value, c1.value) == (g2.value, c2.value) == (g3.value, c3.value), (G, U, sg, sc, nic)
