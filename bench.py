@@ -7,7 +7,9 @@
 
 One step = one pass of the whole path over one batch of pending pods with the cluster mirror and the
 request records already resident in HBM: request digest -> fit+score over every (pod, node) pair of
-this rank's node shard -> [RCCL all-reduce(max) of the packed scores] -> winner mapping.
+this rank's node shard -> [RCCL all-reduce(max) of the packed scores] -> winner mapping.  The library issues
+ONE kernel launch per step (k_step): its grid carries the fit role of this step together with the digest of
+the next step and the mapping roles of the previous three (software pipeline, nhd_amd/csrc/nhdfit.hip).
 
 Workload (config.workload): BASELINE.json's 64k-node case - config 4's cluster (CPU+GPU+NIC, PCI
 locality for half the pods) with 65 536 nodes PER GPU and 4 096 pending pods; with N GPUs the node axis
@@ -129,15 +131,15 @@ def main():
                    "nodes_total": n_total, "nodes_per_gpu": args.nodes_per_gpu, "pods": args.pods,
                    "parallelism": f"node-shard x{world}, RCCL all-reduce(max) of {args.pods} u64 scores" if world > 1 else "single GPU",
                    "nic_signatures": st.nsig, "lds_bytes_per_block": st.lds_bytes},
-        "roofline": {"bound": "hbm", "kernel": "k_fit_score", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(st.bytes_last), "kernel_ms": fit_ms,
                      "digest_kernel_ms": st.digest_ms_last, "device_step_ms": st.step_ms_last,
-                     "note": "achieved = algorithmic bytes / mean HIP-event duration of k_fit_score on its own stream while the "
-                             "digest of the next step and the winner mapping of the previous one overlap it (3-stream "
-                             "pipeline); traffic = HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE): the node "
-                             "planes and table images are served from L2 / Infinity Cache, the kernel is VALU-issue + LDS bound "
-                             "(DESIGN.md section 4)"},
+                     "note": "achieved = algorithmic bytes of the fit role / mean HIP-event duration of the whole fused step "
+                             "kernel (fit role + next step's digest + earlier steps' mapping roles in the same launch, "
+                             "sampled every 8th step on the launch stream); traffic = HBM bytes/launch from rocprofv3 PMC "
+                             "(2*FETCH_SIZE + WRITE_SIZE): the node planes and table images are served from L2 / Infinity "
+                             "Cache, the kernel is VALU-issue bound (DESIGN.md section 4)"},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -130,13 +130,14 @@ typedef struct {
 } nhdfit_mapping;                            /* 20 bytes */
 
 typedef struct {
-    uint64_t launches;          /* fit_score kernel launches measured so far                    */
-    double   fit_ms_total;      /* sum of their HIP-event durations (ms)                        */
+    uint64_t launches;          /* step-kernel launches carrying a fit role that were timed (every 8th step)   */
+    double   fit_ms_total;      /* sum of their HIP-event durations (ms): the whole fused launch - fit role plus
+                                   the digest / mapping roles of neighbouring steps that share it              */
     double   fit_ms_last;
-    double   digest_ms_last;    /* request-digest kernel of the last find                       */
-    double   step_ms_last;      /* whole enqueue-to-scores-ready span of the last find          */
-    uint64_t evals_last;        /* pod x node evaluations of the last find                      */
-    uint64_t bytes_last;        /* algorithmic bytes of the last fit_score launch */
+    double   digest_ms_last;    /* last digest-only launch (the first step after staging has nothing to share) */
+    double   step_ms_last;      /* = fit_ms_last (one launch per step)                                         */
+    uint64_t evals_last;        /* pod x node evaluations of the last step                                      */
+    uint64_t bytes_last;        /* algorithmic bytes of the last fit role                 */
     uint32_t nodes, nsig, ncls, lds_bytes;
 } nhdfit_stats;
 
