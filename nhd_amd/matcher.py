@@ -150,10 +150,9 @@ class HipMatcher:
     def _candidates(self, nl: Dict[str, object], P: int) -> Optional[np.ndarray]:
         """Bitmask [chunks][P] of the attached nodes that are in `nl`; None when nl is everything."""
         n = len(self._names)
-        if nl is self._attached or len(nl) == n:
-            if all(a == b for a, b in zip(nl, self._names)):
-                return None
-        idx = np.fromiter((self._index[k] for k in nl), dtype=np.int64, count=len(nl))
+        if len(nl) == n and list(nl) == self._names:          # C-speed comparison (identical str objects short-cut)
+            return None
+        idx = np.fromiter(map(self._index.__getitem__, nl), dtype=np.int64, count=len(nl))
         if len(idx) > 1 and not np.all(idx[1:] > idx[:-1]):
             raise ValueError("FindNode: `nl` must keep the relative order of the attached node dict")
         bits = np.zeros(((n + 63) // 64) * 64, dtype=bool)
