@@ -20,6 +20,7 @@
 #ifndef NHDFIT_H
 #define NHDFIT_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -57,6 +58,7 @@ extern "C" {
 #define NHDFIT_RF_INITIAL_FILTER 0x01u   /* apply InitialNodeFilter (active && groups intersect), nhd/NHDScheduler.py:235-247 */
 
 /* map types = values of nhd.CfgTopology.TopologyMapType (nhd/CfgTopology.py:41-45) */
+#define NHDFIT_MAP_INVALID 0u    /* never matches (Matcher.py:45-47) */
 #define NHDFIT_MAP_NUMA 1u
 #define NHDFIT_MAP_PCI  2u
 
@@ -212,6 +214,17 @@ int nhdfit_set_outputs(nhdfit_ctx* ctx, int want_bitmap, int want_map);
 
 int nhdfit_get_stats(nhdfit_ctx* ctx, nhdfit_stats* out);
 int nhdfit_reset_stats(nhdfit_ctx* ctx);
+
+/* ---- request digest straight from the wire format (host code, no GPU needed) -------------------------
+ * The pod's Triad libconfig text -> nhdfit_req, replacing TriadCfgParser(text, False).CfgToTopology(False)
+ * (nhd/TriadCfgParser.py:337-380, called from nhd/NHDScheduler.py:262-270) followed by the getters FindNode
+ * applies to the resulting CfgTopology (nhd/CfgTopology.py:199-232).  `flags` / `groups` (the pod's NHD_GROUP
+ * annotation, nhd/K8SMgr.py:152-165) are not part of the text: the caller fills them in.
+ * Returns 0, or one of the codes below with a message in err[errlen]. */
+#define NHDFIT_WIRE_NONE   1   /* the reference's CfgToTopology returns None for this text (pod not scheduled) */
+#define NHDFIT_WIRE_RAISE  2   /* the reference would raise (malformed text, value of the wrong type)           */
+#define NHDFIT_WIRE_LIMIT  3   /* more than NHDFIT_MAX_GROUPS proc groups or 255 cores in a group               */
+int nhdfit_digest_triad_config(const char* text, size_t len, nhdfit_req* out, char* err, size_t errlen);
 
 #ifdef __cplusplus
 }

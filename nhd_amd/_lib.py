@@ -48,6 +48,7 @@ _SIGS = {
     "nhdfit_set_outputs": (c_int, [c_void_p, c_int, c_int]),
     "nhdfit_get_stats": (c_int, [c_void_p, POINTER(Stats)]),
     "nhdfit_reset_stats": (c_int, [c_void_p]),
+    "nhdfit_digest_triad_config": (c_int, [c_char_p, ctypes.c_size_t, c_void_p, c_char_p, ctypes.c_size_t]),
 }
 
 _lib = None

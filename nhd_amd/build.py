@@ -7,8 +7,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "nhdfit.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "fit_core.h"), os.path.join(HERE, "csrc", "winner_map.h"),
-        os.path.join(ROOT, "include", "nhdfit.h")]
+WIRE = os.path.join(HERE, "csrc", "wire_digest.cpp")          # host-only translation unit (libconfig reader)
+DEPS = [SRC, WIRE, os.path.join(HERE, "csrc", "fit_core.h"), os.path.join(HERE, "csrc", "winner_map.h"),
+        os.path.join(HERE, "csrc", "seq_core.h"), os.path.join(ROOT, "include", "nhdfit.h")]
 LIB = os.path.join(HERE, "libnhdfit.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
@@ -25,7 +26,7 @@ def stale() -> bool:
 def build_lib(force=False, verbose=False, extra=()):
     if not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + list(extra) + [SRC, "-o", LIB, "-ldl"]
+    cmd = [hipcc()] + FLAGS + list(extra) + [SRC, WIRE, "-o", LIB, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=HERE)

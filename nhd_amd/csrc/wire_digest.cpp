@@ -1,0 +1,599 @@
+// wire_digest.cpp - pod request digest straight from the wire format.
+//
+// The reference turns the pod's libconfig text into a CfgTopology object graph
+// (nhd/TriadCfgParser.py:337-380 CfgToTopology, 134-309 ParseModGroups, 106-132 ParseMiscCores, 92-104
+// ParseHugePages) and FindNode then re-derives a handful of integers from it (nhd/CfgTopology.py:199-232).
+// This file goes from the text to the fixed 128-byte nhdfit_req in one pass: an own reader for the libconfig
+// grammar (the reference uses the third-party `libconf` package) and a walk of the Triad topology section that
+// follows the reference's parser statement by statement - including what it does NOT check (chained `!=` length
+// tests, cores added before a later failure, map types other than NUMA / PCI left INVALID).
+//
+// Host-only C++ (no HIP): part of libnhdfit.so, callable without a GPU.
+//   0                 request written
+//   NHDFIT_WIRE_NONE  the reference's CfgToTopology returns None for this text (logged error, pod not scheduled)
+//   NHDFIT_WIRE_RAISE the reference would raise (malformed text, wrong value types) - the scheduler thread would die
+//   NHDFIT_WIRE_LIMIT more than NHDFIT_MAX_GROUPS groups / 255 cores per group (same limit as Packer.digest)
+#include <cctype>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/nhdfit.h"
+
+namespace {
+
+struct Reject { std::string why; };      // reference returns None
+struct Raise { std::string why; };       // reference raises
+struct AttrMissing { std::string why; }; // AttributeError inside a path look-up (caught or not depends on the call site)
+struct Limit { std::string why; };
+
+struct Value;
+using ValuePtr = std::shared_ptr<Value>;
+struct Value {
+    enum Kind { Int, Float, Bool, Str, Array, List, Group } kind = Int;
+    long long i = 0;
+    double f = 0;
+    bool b = false;
+    std::string s;
+    std::vector<ValuePtr> items;                                  // Array [..] / List (..)
+    std::vector<std::pair<std::string, ValuePtr>> fields;         // Group {..}, in file order
+
+    const Value* find(const std::string& key) const {
+        for (const auto& kv : fields)
+            if (kv.first == key) return kv.second.get();
+        return nullptr;
+    }
+    bool has(const std::string& key) const { return find(key) != nullptr; }
+    bool is_seq() const { return kind == Array || kind == List; }
+};
+
+// ---- libconfig reader (grammar of libconfig 1.7 as the `libconf` package accepts it) -------------------------
+class Reader {
+public:
+    Reader(const char* p, size_t n) : p_(p), end_(p + n) {}
+
+    ValuePtr parse_document() {
+        auto root = std::make_shared<Value>();
+        root->kind = Value::Group;
+        parse_settings(*root, /*top=*/true);
+        skip_ws();
+        if (p_ != end_) fail("unexpected character");
+        return root;
+    }
+
+private:
+    const char* p_;
+    const char* end_;
+
+    [[noreturn]] void fail(const char* what) const { throw Raise{std::string("libconfig syntax: ") + what}; }
+
+    void skip_ws() {
+        for (;;) {
+            while (p_ < end_ && std::isspace((unsigned char)*p_)) ++p_;
+            if (p_ < end_ && *p_ == '#') { while (p_ < end_ && *p_ != '\n') ++p_; continue; }
+            if (p_ + 1 < end_ && p_[0] == '/' && p_[1] == '/') { while (p_ < end_ && *p_ != '\n') ++p_; continue; }
+            if (p_ + 1 < end_ && p_[0] == '/' && p_[1] == '*') {
+                p_ += 2;
+                while (p_ + 1 < end_ && !(p_[0] == '*' && p_[1] == '/')) ++p_;
+                if (p_ + 1 >= end_) fail("unterminated comment");
+                p_ += 2;
+                continue;
+            }
+            return;
+        }
+    }
+    bool peek(char c) { skip_ws(); return p_ < end_ && *p_ == c; }
+    bool accept(char c) { if (peek(c)) { ++p_; return true; } return false; }
+
+    static bool name_start(char c) { return std::isalpha((unsigned char)c) || c == '*'; }
+    static bool name_char(char c) { return std::isalnum((unsigned char)c) || c == '_' || c == '-' || c == '*'; }
+
+    void parse_settings(Value& group, bool top) {
+        for (;;) {
+            skip_ws();
+            if (p_ == end_) { if (!top) fail("unterminated group"); return; }
+            if (*p_ == '}') { if (top) fail("unbalanced '}'"); return; }
+            if (*p_ == '@') fail("@include is not supported");
+            if (!name_start(*p_)) fail("setting name expected");
+            const char* b = p_;
+            while (p_ < end_ && name_char(*p_)) ++p_;
+            std::string name(b, p_);
+            skip_ws();
+            if (p_ == end_ || (*p_ != '=' && *p_ != ':')) fail("'=' or ':' expected");
+            ++p_;
+            ValuePtr v = parse_value();
+            bool replaced = false;                                               // libconf: a repeated name overwrites (dict assignment)
+            for (auto& kv : group.fields)
+                if (kv.first == name) { kv.second = v; replaced = true; break; }
+            if (!replaced) group.fields.emplace_back(std::move(name), std::move(v));
+            skip_ws();
+            if (p_ < end_ && (*p_ == ';' || *p_ == ',')) ++p_;
+        }
+    }
+
+    ValuePtr parse_value() {
+        skip_ws();
+        if (p_ == end_) fail("value expected");
+        auto v = std::make_shared<Value>();
+        if (*p_ == '{') {
+            ++p_;
+            v->kind = Value::Group;
+            parse_settings(*v, false);
+            if (!accept('}')) fail("'}' expected");
+            return v;
+        }
+        if (*p_ == '[' || *p_ == '(') {
+            const bool array = *p_ == '[';
+            const char close = array ? ']' : ')';
+            ++p_;
+            v->kind = array ? Value::Array : Value::List;
+            if (accept(close)) return v;
+            for (;;) {
+                ValuePtr e = parse_value();
+                if (array && (e->kind == Value::Array || e->kind == Value::List || e->kind == Value::Group))
+                    fail("arrays hold scalars only");
+                v->items.push_back(std::move(e));
+                if (accept(',')) { if (accept(close)) return v; continue; }      // trailing comma is accepted
+                if (accept(close)) return v;
+                fail("',' or closing bracket expected");
+            }
+        }
+        return parse_scalar();
+    }
+
+    ValuePtr parse_scalar() {
+        auto v = std::make_shared<Value>();
+        if (*p_ == '"') {
+            v->kind = Value::Str;
+            while (peek('"')) parse_string_piece(v->s);                           // adjacent strings concatenate
+            return v;
+        }
+        const char* b = p_;
+        while (p_ < end_ && (std::isalnum((unsigned char)*p_) || *p_ == '.' || *p_ == '+' || *p_ == '-')) ++p_;
+        // "1e-5": the sign after an exponent was consumed above; "1-2" is not a token libconfig knows anyway
+        std::string t(b, p_);
+        if (t.empty()) fail("value expected");
+        std::string lower;
+        for (char c : t) lower.push_back((char)std::tolower((unsigned char)c));
+        if (lower == "true" || lower == "false") { v->kind = Value::Bool; v->b = lower == "true"; return v; }
+        size_t k = 0;
+        if (k < t.size() && (t[k] == '+' || t[k] == '-')) ++k;
+        const bool hex = t.size() > k + 2 && t[k] == '0' && (t[k + 1] == 'x' || t[k + 1] == 'X') && k == 0;
+        if (hex) {
+            size_t e = 2;
+            while (e < t.size() && std::isxdigit((unsigned char)t[e])) ++e;
+            std::string suffix = t.substr(e);
+            if (e == 2 || !(suffix.empty() || suffix == "L" || suffix == "LL")) fail("bad hexadecimal integer");
+            v->kind = Value::Int;
+            v->i = (long long)std::strtoull(t.substr(2, e - 2).c_str(), nullptr, 16);
+            return v;
+        }
+        bool digits = false, dot = false, exp = false, ok = true;
+        size_t j = k;
+        while (j < t.size() && std::isdigit((unsigned char)t[j])) { ++j; digits = true; }
+        if (j < t.size() && t[j] == '.') { dot = true; ++j; while (j < t.size() && std::isdigit((unsigned char)t[j])) { ++j; digits = true; } }
+        if (j < t.size() && (t[j] == 'e' || t[j] == 'E')) {
+            exp = true; ++j;
+            if (j < t.size() && (t[j] == '+' || t[j] == '-')) ++j;
+            size_t d0 = j;
+            while (j < t.size() && std::isdigit((unsigned char)t[j])) ++j;
+            if (j == d0) ok = false;
+        }
+        if (!digits) ok = false;
+        if (ok && (dot || exp)) {
+            if (j != t.size()) fail("bad floating point value");
+            v->kind = Value::Float;
+            v->f = std::strtod(t.c_str(), nullptr);
+            return v;
+        }
+        if (ok) {
+            std::string suffix = t.substr(j);
+            if (!(suffix.empty() || suffix == "L" || suffix == "LL")) fail("bad integer");
+            v->kind = Value::Int;
+            v->i = std::strtoll(t.substr(0, j).c_str(), nullptr, 10);
+            return v;
+        }
+        fail("unknown token");
+    }
+
+    void parse_string_piece(std::string& out) {
+        ++p_;                                                                     // opening quote
+        for (;;) {
+            if (p_ == end_) fail("unterminated string");
+            char c = *p_++;
+            if (c == '"') return;
+            if (c != '\\') { out.push_back(c); continue; }
+            if (p_ == end_) fail("unterminated string");
+            c = *p_++;
+            switch (c) {
+                case 'n': out.push_back('\n'); break;
+                case 'r': out.push_back('\r'); break;
+                case 't': out.push_back('\t'); break;
+                case 'f': out.push_back('\f'); break;
+                case '\\': out.push_back('\\'); break;
+                case '"': out.push_back('"'); break;
+                case 'x': {
+                    if (p_ + 1 >= end_ || !std::isxdigit((unsigned char)p_[0]) || !std::isxdigit((unsigned char)p_[1])) fail("bad \\x escape");
+                    out.push_back((char)std::strtol(std::string(p_, p_ + 2).c_str(), nullptr, 16));
+                    p_ += 2;
+                    break;
+                }
+                default: fail("unknown escape");
+            }
+        }
+    }
+};
+
+// ---- the Python operations the reference applies to the parsed values ------------------------------------------
+// magicattr.get(cfg, "a.b[0].c"): attribute = group member, [k] = k-th element of an array / list
+const Value& lookup(const Value& root, const std::string& path) {
+    const Value* cur = &root;
+    size_t k = 0;
+    bool first = true;
+    while (k < path.size()) {
+        if (path[k] == '[') {
+            size_t e = path.find(']', k);
+            if (e == std::string::npos || e == k + 1) throw Raise{"bad attribute path '" + path + "'"};
+            for (size_t d = k + 1; d < e; ++d)
+                if (!std::isdigit((unsigned char)path[d])) throw Raise{"bad index in attribute path '" + path + "'"};
+            const unsigned long idx = std::strtoul(path.substr(k + 1, e - k - 1).c_str(), nullptr, 10);
+            if (cur->is_seq()) {
+                if (idx >= cur->items.size()) throw Raise{"index out of range in '" + path + "'"};
+                cur = cur->items[idx].get();
+            } else {
+                throw Raise{"subscript of a non-sequence in '" + path + "'"};     // KeyError / TypeError
+            }
+            k = e + 1;
+            continue;
+        }
+        if (path[k] == '.') {
+            if (first) throw Raise{"bad attribute path '" + path + "'"};
+            ++k;
+        } else if (!first) {
+            throw Raise{"bad attribute path '" + path + "'"};
+        }
+        size_t e = k;
+        while (e < path.size() && path[e] != '.' && path[e] != '[') ++e;
+        if (e == k) throw Raise{"bad attribute path '" + path + "'"};
+        const std::string name = path.substr(k, e - k);
+        const Value* next = cur->kind == Value::Group ? cur->find(name) : nullptr;
+        if (!next) throw AttrMissing{"no attribute '" + name + "' in '" + path + "'"};
+        cur = next;
+        k = e;
+        first = false;
+    }
+    if (first) throw Raise{"empty attribute path"};
+    return *cur;
+}
+
+const Value& attr(const Value& g, const char* name) {                       // obj.name on an AttrDict
+    const Value* v = g.kind == Value::Group ? g.find(name) : nullptr;
+    if (!v) throw AttrMissing{std::string("no attribute '") + name + "'"};
+    return *v;
+}
+
+long long py_int(const Value& v) {                                         // int(x)
+    switch (v.kind) {
+        case Value::Int: return v.i;
+        case Value::Bool: return v.b ? 1 : 0;
+        case Value::Float:
+            if (!std::isfinite(v.f)) throw Raise{"int() of a non-finite float"};
+            return (long long)std::trunc(v.f);
+        case Value::Str: {
+            size_t a = 0, b = v.s.size();
+            while (a < b && std::isspace((unsigned char)v.s[a])) ++a;
+            while (b > a && std::isspace((unsigned char)v.s[b - 1])) --b;
+            std::string t = v.s.substr(a, b - a), digits;
+            size_t k = 0;
+            bool neg = false;
+            if (k < t.size() && (t[k] == '+' || t[k] == '-')) { neg = t[k] == '-'; ++k; }
+            bool prev_digit = false;
+            for (; k < t.size(); ++k) {
+                if (std::isdigit((unsigned char)t[k])) { digits.push_back(t[k]); prev_digit = true; }
+                else if (t[k] == '_' && prev_digit && k + 1 < t.size() && std::isdigit((unsigned char)t[k + 1])) prev_digit = false;
+                else throw Raise{"int() of a non-numeric string"};
+            }
+            if (digits.empty()) throw Raise{"int() of a non-numeric string"};
+            const long long m = std::strtoll(digits.c_str(), nullptr, 10);
+            return neg ? -m : m;
+        }
+        default: throw Raise{"int() of a group / list"};
+    }
+}
+
+bool truthy(const Value& v) {                                              // bool(x)
+    switch (v.kind) {
+        case Value::Int: return v.i != 0;
+        case Value::Float: return v.f != 0.0;
+        case Value::Bool: return v.b;
+        case Value::Str: return !v.s.empty();
+        case Value::Group: return !v.fields.empty();
+        default: return !v.items.empty();
+    }
+}
+
+size_t py_len(const Value& v) {                                            // len(x)
+    switch (v.kind) {
+        case Value::Str: return v.s.size();
+        case Value::Group: return v.fields.size();
+        case Value::Array: case Value::List: return v.items.size();
+        default: throw Raise{"len() of a scalar"};
+    }
+}
+
+// NIC speeds are stored as they come (TriadCfgParser.py:205, 210) and only added up in FindNode
+// (CfgTopology.py:219-232: 0 + s1 + s2 ...): a non-number parses fine there and raises later.  Here: remembered,
+// reported as NHDFIT_WIRE_RAISE once the parse itself has succeeded.
+double speed_of(const Value& v, bool& bad) {
+    switch (v.kind) {
+        case Value::Int: return (double)v.i;
+        case Value::Float: return v.f;
+        case Value::Bool: return v.b ? 1.0 : 0.0;
+        default: bad = true; return 0.0;
+    }
+}
+
+const std::string& str_of(const Value& v, const char* what) {
+    if (v.kind != Value::Str) throw Raise{std::string(what) + " is not a string"};
+    return v.s;
+}
+
+// key of the reference's gpumap dict (TriadCfgParser.py:231-240): Python equality / hashing of scalars
+struct GpuKey {
+    bool is_str; double num; std::string s;
+    bool operator==(const GpuKey& o) const { return is_str == o.is_str && (is_str ? s == o.s : num == o.num); }
+};
+GpuKey gpu_key(const Value& v) {
+    switch (v.kind) {
+        case Value::Int: return {false, (double)v.i, {}};
+        case Value::Float: return {false, v.f, {}};
+        case Value::Bool: return {false, v.b ? 1.0 : 0.0, {}};
+        case Value::Str: return {true, 0, v.s};
+        default: throw Raise{"GPU device id is not a scalar"};
+    }
+}
+
+struct GroupTotals {
+    unsigned proc = 0, help = 0, gpus = 0;
+    bool proc_smt = false, helper_smt = false, nic_use = false;
+    double rx = 0, tx = 0;
+};
+
+// nhd/TriadCfgParser.py:134-309
+void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTotals>& groups, uint32_t& map_type, bool& bad_speed) {
+    if (!topo.has("mod_defs")) throw Reject{"no mod_defs in TopologyCfg"};
+    if (!topo.has("map_type")) throw Reject{"no map_type in TopologyCfg"};
+    const Value& mt = attr(topo, "map_type");
+    map_type = NHDFIT_MAP_INVALID;                                           // SetTopMapType: anything else stays INVALID
+    if (mt.kind == Value::Str && mt.s == "NUMA") map_type = NHDFIT_MAP_NUMA;
+    else if (mt.kind == Value::Str && mt.s == "PCI") map_type = NHDFIT_MAP_PCI;
+
+    const Value& mod_defs = attr(topo, "mod_defs");
+    if (!mod_defs.is_seq()) throw Raise{"mod_defs is not a list"};
+    for (const auto& mdp : mod_defs.items) {
+        const Value& md = *mdp;
+        const Value& module = attr(md, "module");
+        if (module.kind != Value::Str || !cfg.has(module.s)) throw Reject{"module not found at top level"};
+        const Value& instances = *cfg.find(module.s);
+        if (!instances.is_seq()) throw Raise{"module section is not a list of instances"};
+        for (size_t idx = 0; idx < instances.items.size(); ++idx) {
+            const Value& mi = *instances.items[idx];
+            (void)attr(mi, "module");                                       // the reference formats mi.module into its log line
+            GroupTotals pg;
+            const std::string mattr = module.s + "[" + std::to_string(idx) + "]";
+
+            if (md.has("helper_cores")) {
+                if (!md.has("helper_cores_smt")) throw Reject{"helper_cores_smt not defined"};
+                pg.helper_smt = truthy(attr(md, "helper_cores_smt"));
+                const Value& hcs = attr(md, "helper_cores");
+                if (!hcs.is_seq()) throw Raise{"helper_cores is not a list"};
+                for (const auto& hc : hcs.items) {
+                    const std::string name = mattr + "." + str_of(*hc, "helper core name");
+                    const Value& a = lookup(cfg, name);
+                    if (a.kind == Value::Array) {                           // libconf: [..] -> list, (..) -> tuple
+                        for (const auto& c : a.items) { (void)py_int(*c); pg.help++; }
+                    } else {
+                        (void)py_int(a);
+                        pg.help++;
+                    }
+                }
+            }
+
+            if (md.has("dp_group")) {
+                const Value& dpg = attr(md, "dp_group");
+                const Value* dp = nullptr;
+                try {
+                    dp = &lookup(cfg, mattr + "." + str_of(attr(dpg, "name"), "dp_group.name"));
+                } catch (const AttrMissing&) { throw Reject{"dp group attribute not found"}; }
+                  catch (const Raise&) { throw Reject{"dp group attribute not found"}; }
+                if (py_len(*dp) != 1) throw Reject{"DP groups of multiple NUMA nodes not supported"};
+                if (!dp->is_seq()) throw Raise{"dp group is not a list"};
+                const Value& d0 = *dp->items[0];
+                // chained comparison of the reference (TriadCfgParser.py:193): `a != b != c != d` is
+                // (a != b) and (b != c) and (c != d), evaluated left to right and short-circuited - the speed lists
+                // are not even looked up when the two core lists have equal length
+                const Value &rxc = attr(d0, "rx_cores"), &txc = attr(d0, "tx_cores");
+                if (py_len(rxc) != py_len(txc)) {
+                    const Value& rxs0 = attr(d0, "rx_speeds");
+                    if (py_len(txc) != py_len(rxs0) && py_len(rxs0) != py_len(attr(d0, "tx_speeds")))
+                        throw Reject{"core / speed list lengths differ"};
+                }
+                pg.proc_smt = truthy(attr(dpg, "proc_cores_smt"));
+                try {
+                    const size_t n = py_len(rxc);
+                    for (size_t g = 0; g < n; ++g) {
+                        const Value& rxs = attr(d0, "rx_speeds");                 // looked up per core, inside the try
+                        if (!rxs.is_seq() || g >= rxs.items.size() || !rxc.is_seq()) throw Raise{"rx index"};
+                        const double rs = speed_of(*rxs.items[g], bad_speed);
+                        (void)py_int(*rxc.items[g]);
+                        pg.proc++; pg.rx += rs; pg.nic_use = true;
+                        if (!txc.is_seq() || g >= txc.items.size()) throw Raise{"tx index"};
+                        const Value& txs = attr(d0, "tx_speeds");
+                        if (!txs.is_seq() || g >= txs.items.size()) throw Raise{"tx index"};
+                        const double ts = speed_of(*txs.items[g], bad_speed);
+                        (void)py_int(*txc.items[g]);
+                        pg.proc++; pg.tx += ts;
+                    }
+                } catch (const Raise&) { throw Reject{"error when parsing NIC fields"}; }
+                  catch (const AttrMissing&) { throw Reject{"error when parsing NIC fields"}; }
+                try {                                                        // CPU workers: optional, errors are swallowed
+                    const Value& cw = attr(d0, "cpu_workers");
+                    const size_t n = py_len(cw);
+                    for (size_t c = 0; c < n; ++c) {
+                        if (!cw.is_seq()) throw Raise{"cpu_workers"};
+                        (void)py_int(*cw.items[c]);
+                        pg.proc++;
+                    }
+                } catch (const Raise&) {} catch (const AttrMissing&) {}
+                const Value& gm = attr(d0, "gpu_map");
+                const size_t ng = py_len(gm);
+                if (ng && !gm.is_seq()) throw Raise{"gpu_map is not a list"};
+                std::vector<GpuKey> keys;
+                std::vector<std::vector<const Value*>> cores;
+                for (size_t g = 0; g < ng; ++g) {
+                    const Value& e = *gm.items[g];
+                    if (py_len(e) != 2) continue;                            // logged, not processed
+                    if (!e.is_seq()) throw Raise{"gpu_map entry is not a pair"};
+                    const GpuKey key = gpu_key(*e.items[1]);
+                    size_t k = 0;
+                    while (k < keys.size() && !(keys[k] == key)) ++k;
+                    if (k == keys.size()) { keys.push_back(key); cores.emplace_back(); }
+                    cores[k].push_back(e.items[0].get());
+                }
+                for (const auto& cl : cores) {
+                    for (const Value* c : cl) { (void)py_int(*c); pg.proc++; }    // the GPU's feeder cores count as proc cores
+                    pg.gpus++;
+                }
+            }
+
+            if (md.has("nic_cores")) {
+                const Value& nc = attr(md, "nic_cores");
+                if (py_len(nc) != 5) throw Reject{"wrong number of parameters for nic_cores"};
+                if (!nc.is_seq()) throw Raise{"nic_cores is not a list"};
+                const Value *rxc, *rxs, *txc, *txs;
+                try {
+                    auto get = [&](size_t k) -> const Value* {
+                        const Value& nm = *nc.items[k];
+                        if (nm.kind != Value::Str) throw Raise{"nic_cores name"};
+                        return &lookup(cfg, mattr + "." + nm.s);
+                    };
+                    rxc = get(0); rxs = get(1); txc = get(2); txs = get(3);
+                } catch (const Raise&) { throw Reject{"could not find NIC attributes"}; }
+                  catch (const AttrMissing&) { throw Reject{"could not find NIC attributes"}; }
+                if (py_len(*rxc) != py_len(*rxs) && py_len(*rxs) != py_len(*txc) && py_len(*txc) != py_len(*txs))   // && short-circuits like the chain
+                    throw Reject{"speed and core lengths differ"};
+                pg.proc_smt = truthy(*nc.items[4]);
+                const size_t n = py_len(*rxc);
+                for (size_t g = 0; g < n; ++g) {
+                    if (!rxc->is_seq() || !rxs->is_seq() || g >= rxs->items.size()) throw Raise{"rx speed index"};
+                    const double rs = speed_of(*rxs->items[g], bad_speed);
+                    (void)py_int(*rxc->items[g]);
+                    pg.proc++; pg.rx += rs; pg.nic_use = true;
+                    if (!txc->is_seq() || g >= txc->items.size() || !txs->is_seq() || g >= txs->items.size()) throw Raise{"tx index"};
+                    const double ts = speed_of(*txs->items[g], bad_speed);
+                    (void)py_int(*txc->items[g]);
+                    pg.proc++; pg.tx += ts;
+                }
+            }
+            groups.push_back(pg);
+        }
+    }
+}
+
+unsigned half_up(unsigned n) { return (n + 1) / 2; }                        // math.ceil(n / 2.0)
+
+void digest(const char* text, size_t len, nhdfit_req& r) {
+    Reader reader(text, len);
+    const ValuePtr rootp = reader.parse_document();
+    const Value& cfg = *rootp;
+    // CfgToTopology, nhd/TriadCfgParser.py:337-380
+    if (!cfg.has("TopologyCfg")) throw Reject{"no TopologyCfg section"};
+    const Value& topo = *cfg.find("TopologyCfg");
+    if (topo.kind != Value::Group) throw Raise{"TopologyCfg is not a group"};
+    for (const char* f : {"cpu_arch", "ext_cores", "kni_vlan"})
+        if (!topo.has(f)) throw Reject{std::string("mandatory field ") + f + " missing"};
+    {
+        const Value& arch = attr(topo, "cpu_arch");
+        static const char* known[] = {"ANY", "HASWELL", "BROADWELL", "SKYLAKE", "COOPER_LAKE", "ICE_LAKE"};
+        bool ok = false;
+        for (const char* k : known) ok = ok || (arch.kind == Value::Str && arch.s == k);
+        if (!ok) throw Reject{"unknown cpu_arch"};
+    }
+    // ParseMiscCores, :106-132
+    if (!topo.has("ext_cores_smt")) throw Reject{"no ext_cores_smt"};
+    const bool misc_smt = truthy(attr(topo, "ext_cores_smt"));
+    unsigned n_misc = 0;
+    {
+        const Value& ext = attr(topo, "ext_cores");
+        if (!ext.is_seq()) throw Raise{"ext_cores is not a list"};
+        for (const auto& e : ext.items) {
+            try {
+                (void)py_int(lookup(cfg, str_of(*e, "ext core name")));
+            } catch (const AttrMissing&) { throw Reject{"ext core not found"}; }     // the one exception type the reference catches here
+            n_misc++;
+        }
+    }
+    // ParseKniDataVlan (:80-90) only stores a name.  ParseModGroups:
+    std::vector<GroupTotals> groups;
+    uint32_t map_type = NHDFIT_MAP_INVALID;
+    bool bad_speed = false;
+    try {
+        parse_mod_groups(cfg, topo, groups, map_type, bad_speed);
+    } catch (const AttrMissing& e) { throw Raise{e.why}; }                     // uncaught AttributeError in the reference
+    // ParseHugePages, :92-104
+    if (!cfg.has("Hugepages_GB")) throw Reject{"no Hugepages_GB"};
+    const long long hp = py_int(*cfg.find("Hugepages_GB"));
+    if (bad_speed) throw Raise{"a NIC speed is not a number (the reference fails when FindNode adds the speeds up)"};
+
+    // the integers FindNode derives from the object graph (nhd/CfgTopology.py:199-232, nhd/Matcher.py:178-204)
+    if (groups.size() > NHDFIT_MAX_GROUPS) throw Limit{"more proc groups than NHDFIT_MAX_GROUPS"};
+    std::memset(&r, 0, sizeof r);
+    r.n_groups = (uint32_t)groups.size();
+    r.map_type = map_type;
+    r.hugepages_gb = (int32_t)(hp < INT32_MIN ? INT32_MIN : hp > INT32_MAX ? INT32_MAX : hp);
+    for (size_t i = 0; i < groups.size(); ++i) {
+        const GroupTotals& g = groups[i];
+        if (g.proc > 255 || g.help > 255) throw Limit{"a proc group asks for more than 255 cores"};
+        r.gpus[i] = (uint16_t)g.gpus;
+        r.n_proc[i] = (uint8_t)g.proc;
+        r.n_help[i] = (uint8_t)g.help;
+        if (g.proc_smt) r.smt_bits |= (uint8_t)(1u << i);
+        if (g.helper_smt) r.smt_bits |= (uint8_t)(1u << (4 + i));
+        r.cpu_nosmt[i] = (uint16_t)(g.proc + g.help);
+        r.cpu_smt[i] = (uint16_t)((g.proc_smt ? half_up(g.proc) : g.proc) + (g.helper_smt ? half_up(g.help) : g.help));
+        r.rx[i] = g.rx;
+        r.tx[i] = g.tx;
+        if (g.nic_use) r.nic_use |= (uint8_t)(1u << i);
+    }
+    if (n_misc > 65535) throw Limit{"too many misc cores"};
+    r.misc_nosmt = (uint16_t)n_misc;
+    r.n_misc = (uint8_t)(n_misc > 255 ? 255 : n_misc);
+    r.misc_smt_enabled = misc_smt ? 1 : 0;
+    // Matcher.py:198 tests the truthiness of the SMTSetting enum member, which is always true (quirk Q1)
+    r.misc_smt = (uint16_t)half_up(n_misc);
+}
+
+void set_err(char* err, size_t errlen, const std::string& msg) {
+    if (err && errlen) std::snprintf(err, errlen, "%s", msg.c_str());
+}
+
+}  // namespace
+
+extern "C" int nhdfit_digest_triad_config(const char* text, size_t len, nhdfit_req* out, char* err, size_t errlen) {
+    if (!text || !out) { set_err(err, errlen, "null argument"); return NHDFIT_E_INVAL; }
+    try {
+        digest(text, len, *out);
+        set_err(err, errlen, "");
+        return NHDFIT_OK;
+    } catch (const Reject& e) { set_err(err, errlen, e.why); return NHDFIT_WIRE_NONE; }
+      catch (const Raise& e) { set_err(err, errlen, e.why); return NHDFIT_WIRE_RAISE; }
+      catch (const AttrMissing& e) { set_err(err, errlen, e.why); return NHDFIT_WIRE_RAISE; }
+      catch (const Limit& e) { set_err(err, errlen, e.why); return NHDFIT_WIRE_LIMIT; }
+      catch (const std::exception& e) { set_err(err, errlen, e.what()); return NHDFIT_E_INVAL; }
+      catch (...) { set_err(err, errlen, "unknown failure"); return NHDFIT_E_INVAL; }
+}

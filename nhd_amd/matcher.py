@@ -179,22 +179,50 @@ class HipMatcher:
         filtered, exactly like the argument of Matcher.FindNode."""
         return self._run(nl, tops, pod_groups, now, sequential=False)
 
-    def _run(self, nl, tops, pod_groups, now, sequential):
-        if not tops:
+    def FindNodesFromConfigs(self, nl: Dict[str, object], cfg_texts: Sequence[str],
+                             pod_groups: Optional[Sequence[Sequence[str]]] = None, now: Optional[float] = None,
+                             sequential: bool = False) -> List[Tuple]:
+        """Batch matching straight from the pods' Triad libconfig texts: no
+        TriadCfgParser / CfgTopology object graph per pending pod (nhd/NHDScheduler.py:262-277) - the texts are
+        digested by host C++ in libnhdfit.so (nhd_amd/wire.py).  A text for which the reference's CfgToTopology
+        returns None yields `(None,)`, like the scheduler skipping that pod.  The caller parses the config of a
+        pod it actually binds (the commit step needs the CfgTopology, nhd/NHDScheduler.py:289-304)."""
+        from . import wire
+        if not cfg_texts:
             return []
-        for top in tops:
-            if len(top.proc_groups) == 0 and len(nl):
+        reqs = np.zeros(len(cfg_texts), pack.REQ)
+        skip = np.zeros(len(cfg_texts), bool)
+        for i, text in enumerate(cfg_texts):
+            r = wire.digest_config(text, None if pod_groups is None else pod_groups[i], self.packer)
+            if r is None:
+                skip[i] = True                              # stays an all-zero (= never matching) request
+            else:
+                reqs[i] = r
+        for i in np.flatnonzero(~skip):
+            if reqs[i]["n_groups"] == 0 and len(nl):
                 raise IndexError("pod without processing groups (the reference fails the same way, Matcher.py:346)")
+        out = self._run(nl, None, pod_groups, now, sequential, reqs=reqs)
+        return [(None,) if skip[i] else out[i] for i in range(len(cfg_texts))]
+
+    def _run(self, nl, tops, pod_groups, now, sequential, reqs=None):
+        if reqs is None:
+            if not tops:
+                return []
+            for top in tops:
+                if len(top.proc_groups) == 0 and len(nl):
+                    raise IndexError("pod without processing groups (the reference fails the same way, Matcher.py:346)")
+        n_pods = len(tops) if reqs is None else len(reqs)
         if len(nl) == 0:
-            return [(None,) for _ in tops]
+            return [(None,) for _ in range(n_pods)]
         now = self.clock() if now is None else now
         cand = None
         if self._attached is not None and all(k in self._index for k in nl):
             self._flush_dirty()
-            cand = self._candidates(nl, len(tops))
+            cand = self._candidates(nl, n_pods)
         else:
             self._full_upload(nl)
-        reqs = self.packer.digest_many(tops, pod_groups)
+        if reqs is None:
+            reqs = self.packer.digest_many(tops, pod_groups)
         if sequential:
             node, maps, status = self.engine.find_sequential(reqs, now, cand=cand)
             if status.any():
@@ -204,7 +232,7 @@ class HipMatcher:
             score, _, maps = self.engine.find(reqs, now, cand=cand, want_bitmap=False, want_map=True)
             index = np.array([winner_index(int(s)) - self.engine.global_base if s else -1 for s in score], dtype=np.int64)
         out: List[Tuple] = []
-        for p in range(len(tops)):
+        for p in range(n_pods):
             if index[p] < 0:
                 out.append((None,))
                 continue

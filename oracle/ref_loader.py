@@ -58,6 +58,34 @@ def load():
     return ns
 
 
+_parser_cls = None
+
+
+def triad_parser():
+    """The unmodified reference nhd.TriadCfgParser.TriadCfgParser (row f3 of SURVEY.md section 8).  Its two absent
+    third-party imports, `libconf` and `magicattr`, are satisfied by the restatements under oracle/_shim."""
+    global _parser_cls
+    if _parser_cls is None:
+        load()
+        for name in ("nhd.TriadCfgParser", "nhd.CfgParser"):
+            lg = logging.getLogger(name)
+            lg.addHandler(logging.NullHandler())
+            lg.setLevel(logging.CRITICAL + 1)
+            lg.propagate = False
+        for name in ("libconf", "magicattr"):              # an empty placeholder module left by another test
+            if name in sys.modules and not hasattr(sys.modules[name], "loads" if name == "libconf" else "get"):
+                del sys.modules[name]
+                sys.modules.pop("nhd.TriadCfgParser", None)
+        import nhd.TriadCfgParser as tp
+        _parser_cls = tp.TriadCfgParser
+    return _parser_cls
+
+
+def config_to_topology(text):
+    """TriadCfgParser(text, False).CfgToTopology(False) as the scheduler calls it (nhd/NHDScheduler.py:262-270)."""
+    return triad_parser()(text, False).CfgToTopology(False)
+
+
 class VirtualClock:
     """Replaces `time` inside nhd.Node so IsBusy (Node.py:847-850) is deterministic."""
 

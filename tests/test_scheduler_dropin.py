@@ -47,8 +47,8 @@ class FakeParser:
 @pytest.fixture(scope="module")
 def sched_mod(ref):
     """Import nhd.NHDScheduler with its K8s-side third-party imports stubbed out."""
-    for name in ("kubernetes", "kubernetes.client", "kubernetes.config", "kubernetes.watch", "kubernetes.client.rest",
-                 "magicattr", "libconf"):
+    # libconf / magicattr (imported by nhd.TriadCfgParser) resolve to the stand-ins under oracle/_shim
+    for name in ("kubernetes", "kubernetes.client", "kubernetes.config", "kubernetes.watch", "kubernetes.client.rest"):
         if name not in sys.modules:
             sys.modules[name] = types.ModuleType(name)
     sys.modules["kubernetes"].client = sys.modules["kubernetes.client"]

@@ -1,0 +1,119 @@
+"""Row f3 (request digest straight from the wire format): nhdfit_digest_triad_config (host C++ in libnhdfit.so)
+against the UNMODIFIED reference parser nhd/TriadCfgParser.py (run on the libconf / magicattr stand-ins of
+oracle/_shim, the two third-party packages being absent) followed by Packer.digest - the path the scheduler takes
+today (nhd/NHDScheduler.py:262-277).  Needs the reference tree (build container only); the committed fixtures of
+tests/golden/wire/wire_configs.json carry the same check to the GPU box (tests/test_wire_golden.py)."""
+import numpy as np
+import pytest
+
+from nhd_amd import pack, wire
+from oracle import ref_loader
+from tests import wire_gen
+
+pytestmark = pytest.mark.skipif(not ref_loader.available(), reason="reference tree not present")
+
+
+def reference_outcome(text):
+    """('ok', req) | ('none',) | ('raise',) | ('limit',) - what the scheduler would see with the reference."""
+    try:
+        top = ref_loader.config_to_topology(text)
+    except Exception:  # noqa: BLE001 - any exception kills the scheduler thread the same way
+        return ("raise",)
+    if top is None:
+        return ("none",)
+    try:
+        req = pack.Packer().digest(top)
+    except pack.UnsupportedNode:
+        return ("limit",)
+    except Exception:  # noqa: BLE001 - e.g. a string NIC speed: FindNode's getters raise on it
+        return ("raise",)
+    return ("ok", req)
+
+
+def product_outcome(text):
+    try:
+        req = wire.digest_config(text)
+    except wire.ConfigError:
+        return ("raise",)
+    except pack.UnsupportedNode:
+        return ("limit",)
+    return ("none",) if req is None else ("ok", req)
+
+
+def assert_same(text, tag):
+    want, got = reference_outcome(text), product_outcome(text)
+    assert want[0] == got[0], (tag, want[0], got[0], text)
+    if want[0] == "ok":
+        assert want[1].tobytes() == got[1].tobytes(), (tag, want[1], got[1], text)
+    return want[0]
+
+
+def test_random_well_formed_configs():
+    seen = set()
+    for seed in range(1500):
+        seen.add(assert_same(wire_gen.make_config(seed), seed))
+    assert "ok" in seen
+
+
+@pytest.mark.parametrize("defect", [d for d in wire_gen.DEFECTS if d])
+def test_defective_configs(defect):
+    outcomes = set()
+    for seed in range(120):
+        outcomes.add(assert_same(wire_gen.make_config(10_000 + seed, defect), (defect, seed)))
+    if defect not in ("helper_missing", "int_of_string", "speed_index", "two_numa_dp", "nic_cores_len", "helper_smt_missing"):
+        assert outcomes <= {"none", "raise"}, (defect, outcomes)      # these defects always bite
+
+
+def test_hand_written_edge_cases():
+    base = wire_gen.make_config(3)
+    cases = {
+        "empty": "",
+        "only comment": "# nothing\n",
+        "scalar topology": 'TopologyCfg = 5; Hugepages_GB = 1;',
+        "unterminated": 'TopologyCfg = { cpu_arch = "ANY";',
+        "string speed": base.replace("rx_speeds", "rx_speeds_old", 1) + 'Extra = 1;',
+        "duplicate setting": base + "\nHugepages_GB = 7;\n",
+        "huge pages float": base.replace("Hugepages_GB", "Hugepages_GB_x", 1) + "\nHugepages_GB = 3.9;\n",
+        "hugepages string": base.replace("Hugepages_GB", "Hugepages_GB_x", 1) + '\nHugepages_GB = " 12 ";\n',
+    }
+    for tag, text in cases.items():
+        assert_same(text, tag)
+
+
+def test_pod_groups_annotation():
+    pk = pack.Packer()
+    text = next(t for t in (wire_gen.make_config(s) for s in range(50)) if product_outcome(t)[0] == "ok")
+    req = wire.digest_config(text, pod_groups=["default", "edge"], packer=pk)
+    top = ref_loader.config_to_topology(text)
+    assert req.tobytes() == pk.digest(top, ["default", "edge"]).tobytes()
+
+
+def test_matcher_from_config_texts_equals_matcher_from_topologies():
+    """HipMatcher.FindNodesFromConfigs(texts) == HipMatcher.FindNodes(reference-parsed topologies) == the reference
+    Matcher on those topologies; texts the reference rejects give (None,).  Host build of the kernel arithmetic."""
+    from nhd_amd.matcher import HipMatcher
+    from oracle import nhd_oracle as O
+    from tests import harness, util
+    nl = util.random_cluster(31, 80)
+    texts, tops = [], []
+    for seed in range(400):
+        t = wire_gen.make_config(seed, "no_hugepages" if seed % 9 == 0 else None)
+        if reference_outcome(t)[0] in ("ok", "none"):
+            texts.append(t)
+            tops.append(ref_loader.config_to_topology(t))
+        if len(texts) == 60:
+            break
+    assert any(t is None for t in tops) and sum(t is not None for t in tops) > 30
+    m = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)
+    got = m.FindNodesFromConfigs(nl, texts)
+    live = [t for t in tops if t is not None]
+    want_live = iter(m.FindNodes(nl, live))
+    want = [(None,) if t is None else next(want_live) for t in tops]
+    assert got == want
+    placed = 0
+    for t, g in zip(tops, got):
+        if t is not None and len(t.proc_groups):
+            ref = O.find_node(nl, t, util.CLOCK)
+            assert (g[0], g[1:] and g[1]["gpu"]) == (ref[0], ref[1:] and tuple(ref[1]["gpu"]))
+            placed += g[0] is not None
+    assert placed > 0
