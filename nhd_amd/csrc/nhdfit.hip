@@ -1041,7 +1041,7 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
         HIPCHK(c, c->maps[b].reserve(P));
     }
     // Pods are staged sorted by request class so that 64-pod tiles are homogeneous (fast sweep of
-    // k_fit_score) and the lanes of k_map have similar group counts; results are un-permuted in fetch.
+    // the fit role) and the lanes of the mapping roles have similar group counts; results are un-permuted in fetch.
     c->perm.resize(P);
     std::vector<uint32_t> key(P);
     c->n_big_pods = 0;

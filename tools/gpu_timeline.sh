@@ -18,7 +18,7 @@ with open(sys.argv[2], "w") as o:
     o.write("kernel,queue,start_us,end_us,dur_us\n")
     for r in rows:
         n = r["Kernel_Name"]
-        for k in ("k_digest", "k_fit_score", "k_map_shapes", "k_map_choose", "k_map_finish", "k_map", "k_resolve", "k_nogpu"):
+        for k in ("k_step", "k_fit_only", "k_build_asc", "k_map", "k_resolve", "k_nogpu"):
             if k in n: n = k; break
         s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
         o.write(f"{n[:24]},{r.get('Queue_Id','')},{s/1e3:.1f},{e/1e3:.1f},{(e-s)/1e3:.1f}\n")
