@@ -465,7 +465,15 @@ struct ShapeArgs {
     int32_t* slot_of_pod;        // [P] slot of the pod's shape, < 0: nothing to map
     uint32_t* count;             // [tiles]
     const AscEntry* asc;         // layouts of ascending-filled sets (winner_map.h), built once per context
+    const uint8_t* choose_tab;   // tabulated choose_tuples for U = 2, G <= 2 (winner_map.h), or null
 };
+// slot_of_pod encodings: >= 0 slot of the pod's shape; -1 nothing to map; <= -2: the result word itself, -2 - word
+// (shapes answered from choose_tab never reach the choose role)
+
+__global__ __launch_bounds__(256) void k_build_choose(const AscEntry* asc, uint8_t* table) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e < kChooseEntries) table[e] = choose_entry_build(asc, e);
+}
 
 // one thread per (tuple length, subset): the set model itself fills the table
 __global__ __launch_bounds__(256) void k_build_asc(AscEntry* table) {
@@ -496,7 +504,12 @@ __device__ __forceinline__ void role_shapes(const MapArgs& a, const ShapeArgs& h
         const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
         uint32_t sg, sc;
         candidate_masks(rq, w, sg, sc);
-        if (sg && sc && codes) key = shape_key((int)rq.n_groups, w.U, sg, sc, codes);
+        if (sg && sc && codes) {
+            if (h.choose_tab && choose_tabulated((int)rq.n_groups, w.U))
+                slot = -2 - (int32_t)choose_from_table(h.choose_tab, (int)rq.n_groups, sg, sc, codes);
+            else
+                key = shape_key((int)rq.n_groups, w.U, sg, sc, codes);
+        }
     }
     // distinct shapes of the tile (pods of a tile mostly share a handful): slot 64 tile + j for the j-th one.
     // No cross-tile interning: it needs a hash table in global memory, and its atomics cost the concurrently
@@ -550,8 +563,8 @@ __device__ __forceinline__ void role_finish(const MapArgs& a, const ShapeArgs& h
     nhdfit_mapping& m = a.out[p];
     memset(&m, 0, sizeof(m));
     const int32_t slot = h.slot_of_pod[p];
-    if (slot < 0) return;
-    const uint32_t res = h.result[slot];
+    if (slot == -1) return;
+    const uint32_t res = slot >= 0 ? h.result[slot] : (uint32_t)(-2 - slot);
     WinnerState w;
     uint32_t i;
     if (!(res >> 8 & 1) || !load_winner(a, p, w, i)) return;
@@ -781,6 +794,8 @@ struct nhdfit_ctx {
     DevBuf<unsigned long long> shape_keys[kBufs]; DevBuf<uint32_t> shape_res[kBufs]; DevBuf<int32_t> shape_slot[kBufs];   // mapping dedup tables
     DevBuf<uint32_t> shape_list[kBufs];  // distinct shapes per tile
     DevBuf<AscEntry> asc;                // layouts of ascending-filled CPython sets (static table, built at creation)
+    DevBuf<uint8_t> choose_tab;          // choose_tuples tabulated for U = 2, G <= 2 (static table, built at creation)
+    bool use_choose_tab = getenv("NHDFIT_NO_CHOOSE_TABLE") == nullptr;   // tuning aid: run the set model for every shape
     // mode B
     DevBuf<uint64_t> nogpu; DevBuf<int32_t> slot_of; DevBuf<OverlayNode> overlay; DevBuf<SeqResult> seq_out; DevBuf<uint32_t> order;
     bool use_cand = false, want_bitmap = true, want_map = true;
@@ -890,6 +905,11 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_build_asc, dim3((kAscEntries + 255) / 256), dim3(256), 0, c->stream, c->asc.p);
         e = hipGetLastError();
+        if (e == hipSuccess) e = c->choose_tab.reserve(kChooseEntries);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_build_choose, dim3((kChooseEntries + 255) / 256), dim3(256), 0, c->stream, c->asc.p, c->choose_tab.p);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     }
     if (e != hipSuccess) {
@@ -908,7 +928,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
-    c->reqs.release(); c->bitmap.release(); c->cand.release(); c->role_clock.release(); c->asc.release(); c->group_sets.release();
+    c->reqs.release(); c->bitmap.release(); c->cand.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->group_sets.release();
     for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); c->shape_list[b].release(); }
     c->nogpu.release(); c->slot_of.release(); c->overlay.release(); c->seq_out.release(); c->order.release();
     for (int b = 0; b < kBufs; ++b) {
@@ -1094,7 +1114,8 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
                        c->global_base, c->reqs.p, P, c->score[b].p, c->caps.p, c->maps[b].p};
     };
     auto shape_args = [&](int b) {
-        return ShapeArgs{c->shape_keys[b].p, c->shape_res[b].p, c->shape_slot[b].p, c->shape_list[b].p, c->asc.p};
+        return ShapeArgs{c->shape_keys[b].p, c->shape_res[b].p, c->shape_slot[b].p, c->shape_list[b].p, c->asc.p,
+                         c->use_choose_tab ? c->choose_tab.p : nullptr};
     };
     // mapping phases of earlier steps: each advances by at most one step per launch
     bool did_shapes = false, did_choose = false, did_finish = false;

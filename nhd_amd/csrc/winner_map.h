@@ -509,6 +509,36 @@ NHD_HD bool choose_tuples(int G, int U, uint32_t sg_mask, uint32_t sc_mask, uint
     return ccode >= 0;
 }
 
+// ---- the whole of choose_tuples, tabulated for the small shapes ------------------------------------------
+// With two NUMA nodes and G <= 2 proc groups the order-dependent core has only 2+4+2 resp. 4+8+4 input bits:
+// 256 + 65 536 one-byte answers, filled once per context by choose_tuples itself (k_build_choose) - pods of these
+// shapes (90 % of the BASELINE mix) need no run of the sequential model at all, only the G = 3 shapes do.
+constexpr uint32_t kChooseOffset[3] = {0, 0, 256};                        // first entry of G = 1, 2
+constexpr uint32_t kChooseEntries = 256 + 65536;
+NHD_HD bool choose_tabulated(int G, int U) { return U == 2 && G >= 1 && G <= 2; }
+NHD_HD uint32_t choose_index(int G, uint32_t sg_mask, uint32_t sc_mask, uint32_t nic_codes) {
+    const uint32_t nG = 1u << G, nC = 2u << G;                            // tuple codes per set (U = 2)
+    return kChooseOffset[G] + ((sg_mask & ((1u << nG) - 1u)) | (sc_mask & ((1u << nC) - 1u)) << nG |
+                               (nic_codes & ((1u << nG) - 1u)) << (nG + nC));
+}
+// result word as the choose role writes it: ok << 8 | gcode << 4 | ccode
+NHD_HD uint32_t choose_result_word(bool ok, uint32_t gcode, int ccode) {
+    return ((uint32_t)ok << 8) | ((gcode & 7u) << 4) | ((uint32_t)ccode & 15u);
+}
+NHD_HD uint8_t choose_entry_build(const AscEntry* asc, uint32_t entry) {
+    const int G = entry >= kChooseOffset[2] ? 2 : 1;
+    const uint32_t nG = 1u << G, nC = 2u << G, x = entry - kChooseOffset[G];
+    const uint32_t sg = x & ((1u << nG) - 1u), sc = (x >> nG) & ((1u << nC) - 1u), nic = x >> (nG + nC);
+    uint32_t gcode = 0;
+    int ccode = -1;
+    const bool ok = sg && sc && nic && choose_tuples<SmallOps>(G, 2, sg, sc, nic, gcode, ccode, asc);
+    return (uint8_t)(ok ? 0x80u | ((gcode & 7u) << 4) | ((uint32_t)ccode & 15u) : 0u);   // G <= 2: gcode < 4, ccode < 8
+}
+NHD_HD uint32_t choose_from_table(const uint8_t* table, int G, uint32_t sg_mask, uint32_t sc_mask, uint32_t nic_codes) {
+    const uint32_t e = table[choose_index(G, sg_mask, sc_mask, nic_codes)];
+    return choose_result_word((e & 0x80u) != 0, (e >> 4) & 7u, (int)(e & 15u));
+}
+
 // Valid GPU / CPU(+misc) assignments of a pod on the winner as bit sets over tuple codes
 // (Matcher.py:116-141, 206-220: the sets `stmp` before they are turned into lists).
 NHD_HD void candidate_masks(const nhdfit_req& r, const WinnerState& w, uint32_t& sg_mask, uint32_t& sc_mask) {

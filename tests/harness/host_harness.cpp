@@ -220,6 +220,18 @@ int hh_choose(int G, int U, uint32_t sg, uint32_t sc, uint32_t nic, int use_tabl
     return ok ? 1 : 0;
 }
 
+// tabulated choose_tuples (U = 2, G <= 2): table built exactly as k_build_choose does; returns the result word
+static const uint8_t* host_choose_table() {
+    static std::vector<uint8_t> t;
+    if (t.empty()) {
+        t.resize(kChooseEntries);
+        for (uint32_t e = 0; e < kChooseEntries; ++e) t[e] = choose_entry_build(host_asc_table(), e);
+    }
+    return t.data();
+}
+int hh_choose_tabulated(int G, int U) { return choose_tabulated(G, U) ? 1 : 0; }
+uint32_t hh_choose_from_table(int G, uint32_t sg, uint32_t sc, uint32_t nic) { return choose_from_table(host_choose_table(), G, sg, sc, nic); }
+
 // the same through the generic (PySet) model
 int hh_choose_generic(int G, int U, uint32_t sg, uint32_t sc, uint32_t nic, uint32_t* gcode, int* ccode) {
     uint32_t g = 0; int c = -1;

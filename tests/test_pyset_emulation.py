@@ -159,3 +159,30 @@ def test_choose_tuples_table_vs_insertion_vs_generic():
         assert a == b == c, (G, U, sg, sc, nic)
         if a:
             assert (g1.value, c1.value) == (g2.value, c2.value) == (g3.value, c3.value), (G, U, sg, sc, nic)
+
+
+def test_tabulated_choose_equals_the_model_everywhere():
+    """The 256 + 65 536-entry table the shapes role answers from (U = 2, G <= 2) against the insertion-built
+    register model and the generic PySet model, for EVERY input (index / encode / decode plumbing included)."""
+    L = harness.lib()
+    L.hh_choose_from_table.restype = ctypes.c_uint32
+    g, c = ctypes.c_uint32(), ctypes.c_int()
+    assert L.hh_choose_tabulated(1, 2) and L.hh_choose_tabulated(2, 2)
+    assert not L.hh_choose_tabulated(3, 2) and not L.hh_choose_tabulated(1, 1) and not L.hh_choose_tabulated(4, 2)
+    rng = np.random.default_rng(5)
+    for G in (1, 2):
+        nG, nC = 1 << G, 2 << G
+        total = 1 << (2 * nG + nC)
+        picks = range(total) if G == 1 else [int(x) for x in rng.integers(0, total, size=20000)]
+        for x in picks:
+            sg, sc, nic = x & ((1 << nG) - 1), (x >> nG) & ((1 << nC) - 1), x >> (nG + nC)
+            word = L.hh_choose_from_table(G, sg, sc, nic)
+            if sg and sc and nic:
+                ok = L.hh_choose(G, 2, sg, sc, nic, 0, ctypes.byref(g), ctypes.byref(c))
+                ok2 = L.hh_choose_generic(G, 2, sg, sc, nic, ctypes.byref(g), ctypes.byref(c)) if ok else 0
+                assert ok == ok2
+            else:
+                ok = 0
+            assert (word >> 8 & 1) == ok, (G, sg, sc, nic)
+            if ok:
+                assert ((word >> 4) & 7, word & 15) == (g.value, c.value), (G, sg, sc, nic)
