@@ -153,52 +153,71 @@ private:
             while (peek('"')) parse_string_piece(v->s);                           // adjacent strings concatenate
             return v;
         }
-        const char* b = p_;
-        while (p_ < end_ && (std::isalnum((unsigned char)*p_) || *p_ == '.' || *p_ == '+' || *p_ == '-')) ++p_;
-        // "1e-5": the sign after an exponent was consumed above; "1-2" is not a token libconfig knows anyway
-        std::string t(b, p_);
-        if (t.empty()) fail("value expected");
-        std::string lower;
-        for (char c : t) lower.push_back((char)std::tolower((unsigned char)c));
-        if (lower == "true" || lower == "false") { v->kind = Value::Bool; v->b = lower == "true"; return v; }
-        size_t k = 0;
-        if (k < t.size() && (t[k] == '+' || t[k] == '-')) ++k;
-        const bool hex = t.size() > k + 2 && t[k] == '0' && (t[k + 1] == 'x' || t[k + 1] == 'X') && k == 0;
-        if (hex) {
-            size_t e = 2;
-            while (e < t.size() && std::isxdigit((unsigned char)t[e])) ++e;
-            std::string suffix = t.substr(e);
-            if (e == 2 || !(suffix.empty() || suffix == "L" || suffix == "LL")) fail("bad hexadecimal integer");
+        // token classes in libconf's order, first match wins: float, hex, integer, boolean
+        const char* q = p_;
+        auto digits = [&](const char* c) { while (c < end_ && std::isdigit((unsigned char)*c)) ++c; return c; };
+        {   // float: [-+]?(\d+)?\.\d*([eE][-+]?\d+)?  |  [-+]?\d+(\.\d*)?[eE][-+]?\d+
+            const char* c = q;
+            if (c < end_ && (*c == '+' || *c == '-')) ++c;
+            const char* d = digits(c);
+            const char* e = nullptr;
+            if (d < end_ && *d == '.') {
+                e = digits(d + 1);
+                if (e < end_ && (*e == 'e' || *e == 'E')) {
+                    const char* x = e + 1;
+                    if (x < end_ && (*x == '+' || *x == '-')) ++x;
+                    const char* y = digits(x);
+                    if (y > x) e = y;
+                }
+            } else if (d > c && d < end_ && (*d == 'e' || *d == 'E')) {
+                const char* x = d + 1;
+                if (x < end_ && (*x == '+' || *x == '-')) ++x;
+                const char* y = digits(x);
+                if (y > x) e = y;
+            }
+            if (e) {
+                bool any_digit = false;
+                for (const char* z = q; z < e; ++z) any_digit = any_digit || std::isdigit((unsigned char)*z);
+                if (!any_digit) fail("'.' is matched as a float and is not one");    // libconf: float('.') raises
+                v->kind = Value::Float;
+                v->f = std::strtod(std::string(q, e).c_str(), nullptr);
+                p_ = e;
+                return v;
+            }
+        }
+        auto long_suffix = [&](const char* c) { if (c < end_ && *c == 'L') { ++c; if (c < end_ && *c == 'L') ++c; } return c; };
+        if (q + 2 < end_ && q[0] == '0' && (q[1] == 'x' || q[1] == 'X') && std::isxdigit((unsigned char)q[2])) {
+            const char* c = q + 2;
+            while (c < end_ && std::isxdigit((unsigned char)*c)) ++c;
             v->kind = Value::Int;
-            v->i = (long long)std::strtoull(t.substr(2, e - 2).c_str(), nullptr, 16);
+            v->i = (long long)std::strtoull(std::string(q + 2, c).c_str(), nullptr, 16);
+            p_ = long_suffix(c);
             return v;
         }
-        bool digits = false, dot = false, exp = false, ok = true;
-        size_t j = k;
-        while (j < t.size() && std::isdigit((unsigned char)t[j])) { ++j; digits = true; }
-        if (j < t.size() && t[j] == '.') { dot = true; ++j; while (j < t.size() && std::isdigit((unsigned char)t[j])) { ++j; digits = true; } }
-        if (j < t.size() && (t[j] == 'e' || t[j] == 'E')) {
-            exp = true; ++j;
-            if (j < t.size() && (t[j] == '+' || t[j] == '-')) ++j;
-            size_t d0 = j;
-            while (j < t.size() && std::isdigit((unsigned char)t[j])) ++j;
-            if (j == d0) ok = false;
+        {
+            const char* c = q;
+            if (c < end_ && (*c == '+' || *c == '-')) ++c;
+            const char* d = digits(c);
+            if (d > c) {
+                v->kind = Value::Int;
+                v->i = std::strtoll(std::string(q, d).c_str(), nullptr, 10);
+                p_ = long_suffix(d);
+                return v;
+            }
         }
-        if (!digits) ok = false;
-        if (ok && (dot || exp)) {
-            if (j != t.size()) fail("bad floating point value");
-            v->kind = Value::Float;
-            v->f = std::strtod(t.c_str(), nullptr);
-            return v;
+        for (const char* word : {"true", "false"}) {
+            const size_t len = std::strlen(word);
+            if ((size_t)(end_ - q) < len) continue;
+            bool same = true;
+            for (size_t k = 0; k < len; ++k) same = same && std::tolower((unsigned char)q[k]) == word[k];
+            if (same && (q + len == end_ || !(std::isalnum((unsigned char)q[len]) || q[len] == '_'))) {      // \b
+                v->kind = Value::Bool;
+                v->b = word[0] == 't';
+                p_ = q + len;
+                return v;
+            }
         }
-        if (ok) {
-            std::string suffix = t.substr(j);
-            if (!(suffix.empty() || suffix == "L" || suffix == "LL")) fail("bad integer");
-            v->kind = Value::Int;
-            v->i = std::strtoll(t.substr(0, j).c_str(), nullptr, 10);
-            return v;
-        }
-        fail("unknown token");
+        fail("value expected");
     }
 
     void parse_string_piece(std::string& out) {
@@ -230,44 +249,114 @@ private:
 };
 
 // ---- the Python operations the reference applies to the parsed values ------------------------------------------
-// magicattr.get(cfg, "a.b[0].c"): attribute = group member, [k] = k-th element of an array / list
-const Value& lookup(const Value& root, const std::string& path) {
-    const Value* cur = &root;
+// magicattr.get(cfg, "a.b[0].c"): the path is parsed as a Python expression (names, attributes, constant
+// subscripts) and walked with getattr / subscription.  What is not such an expression (or is another kind of
+// expression: "a-b", "f(x)", a keyword) raises; a missing attribute is an AttributeError (AttrMissing here - some call
+// sites of the reference catch exactly that), a bad subscript an IndexError / KeyError / TypeError (Raise).
+bool py_keyword(const std::string& w) {
+    static const char* kw[] = {"False", "None", "True", "and", "as", "assert", "async", "await", "break", "class", "continue",
+                               "def", "del", "elif", "else", "except", "finally", "for", "from", "global", "if", "import", "in",
+                               "is", "lambda", "nonlocal", "not", "or", "pass", "raise", "return", "try", "while", "with", "yield"};
+    for (const char* k : kw)
+        if (w == k) return true;
+    return false;
+}
+
+thread_local std::vector<ValuePtr> g_temps;      // one-character strings made by string subscripts; cleared per digest
+
+struct PathStep { enum { Attr, Index, Key } kind; std::string name; unsigned long idx; };
+
+// phase 1: the whole path must be a valid expression before anything is looked up (ast.parse comes first)
+std::vector<PathStep> parse_path(const std::string& path) {
+    std::vector<PathStep> steps;
     size_t k = 0;
-    bool first = true;
-    while (k < path.size()) {
-        if (path[k] == '[') {
-            size_t e = path.find(']', k);
-            if (e == std::string::npos || e == k + 1) throw Raise{"bad attribute path '" + path + "'"};
-            for (size_t d = k + 1; d < e; ++d)
-                if (!std::isdigit((unsigned char)path[d])) throw Raise{"bad index in attribute path '" + path + "'"};
-            const unsigned long idx = std::strtoul(path.substr(k + 1, e - k - 1).c_str(), nullptr, 10);
-            if (cur->is_seq()) {
-                if (idx >= cur->items.size()) throw Raise{"index out of range in '" + path + "'"};
-                cur = cur->items[idx].get();
-            } else {
-                throw Raise{"subscript of a non-sequence in '" + path + "'"};     // KeyError / TypeError
-            }
-            k = e + 1;
-            continue;
+    const size_t n = path.size();
+    auto bad = [&](const char* why) -> Raise { return Raise{std::string(why) + " in attribute path '" + path + "'"}; };
+    auto skip = [&] { while (k < n && (path[k] == ' ' || path[k] == '\t')) ++k; };
+    auto ident = [&]() -> std::string {
+        const size_t b = k;
+        if (k < n && (std::isalpha((unsigned char)path[k]) || path[k] == '_')) {
+            ++k;
+            while (k < n && (std::isalnum((unsigned char)path[k]) || path[k] == '_')) ++k;
+        }
+        if (k == b) throw bad("name expected");
+        std::string w = path.substr(b, k - b);
+        if (py_keyword(w)) throw bad("keyword");
+        return w;
+    };
+    if (n == 0 || path[0] == ' ' || path[0] == '\t' || path[0] == '\n') throw bad("empty or indented expression");
+    steps.push_back({PathStep::Attr, ident(), 0});
+    for (;;) {
+        skip();
+        if (k == n) break;
+        if (path[k] == '#') break;                                          // a Python comment: the rest is not looked at
+        if (path[k] == ';' || path[k] == '\n') {                            // end of the statement: only blanks / a comment may follow
+            while (k < n && (path[k] == ';' || path[k] == '\n' || path[k] == ' ' || path[k] == '\t')) ++k;
+            if (k < n && path[k] != '#') throw bad("more than one statement");
+            break;
         }
         if (path[k] == '.') {
-            if (first) throw Raise{"bad attribute path '" + path + "'"};
-            ++k;
-        } else if (!first) {
-            throw Raise{"bad attribute path '" + path + "'"};
+            ++k; skip();
+            steps.push_back({PathStep::Attr, ident(), 0});
+            continue;
         }
-        size_t e = k;
-        while (e < path.size() && path[e] != '.' && path[e] != '[') ++e;
-        if (e == k) throw Raise{"bad attribute path '" + path + "'"};
-        const std::string name = path.substr(k, e - k);
-        const Value* next = cur->kind == Value::Group ? cur->find(name) : nullptr;
-        if (!next) throw AttrMissing{"no attribute '" + name + "' in '" + path + "'"};
-        cur = next;
-        k = e;
-        first = false;
+        if (path[k] != '[') throw bad("unexpected character");
+        ++k; skip();
+        if (k < n && (path[k] == '\'' || path[k] == '"')) {                 // string subscript: dict key
+            const char q = path[k++];
+            const size_t b = k;
+            while (k < n && path[k] != q) { if (path[k] == '\\' || path[k] == '\n') throw bad("escape in subscript"); ++k; }
+            if (k == n) throw bad("unterminated string");
+            steps.push_back({PathStep::Key, path.substr(b, k - b), 0});
+            ++k; skip();
+            if (k == n || path[k] != ']') throw bad("']' expected");
+            ++k;
+            continue;
+        }
+        std::string digits;
+        bool prev_digit = false;
+        while (k < n && (std::isdigit((unsigned char)path[k]) || path[k] == '_')) {
+            if (path[k] == '_') { if (!prev_digit || k + 1 >= n || !std::isdigit((unsigned char)path[k + 1])) throw bad("bad integer"); prev_digit = false; }
+            else { digits.push_back(path[k]); prev_digit = true; }
+            ++k;
+        }
+        if (digits.empty()) throw bad("constant subscript expected");
+        if (digits.size() > 1 && digits[0] == '0' && digits.find_first_not_of('0') != std::string::npos) throw bad("leading zeros");
+        skip();
+        if (k == n || path[k] != ']') throw bad("']' expected");
+        ++k;
+        steps.push_back({PathStep::Index, {}, digits.size() > 9 ? 999999999ul : std::strtoul(digits.c_str(), nullptr, 10)});
     }
-    if (first) throw Raise{"empty attribute path"};
+    return steps;
+}
+
+// phase 2: getattr / subscription, left to right
+const Value& lookup(const Value& root, const std::string& path, std::vector<ValuePtr>& temps = g_temps) {
+    const std::vector<PathStep> steps = parse_path(path);
+    const Value* cur = &root;
+    for (const PathStep& st : steps) {
+        if (st.kind == PathStep::Attr) {
+            const Value* next = cur->kind == Value::Group ? cur->find(st.name) : nullptr;
+            if (!next) throw AttrMissing{"no attribute '" + st.name + "' in '" + path + "'"};
+            cur = next;
+        } else if (st.kind == PathStep::Key) {
+            const Value* next = cur->kind == Value::Group ? cur->find(st.name) : nullptr;
+            if (!next) throw Raise{"bad string subscript in '" + path + "'"};      // KeyError / TypeError
+            cur = next;
+        } else if (cur->is_seq()) {
+            if (st.idx >= cur->items.size()) throw Raise{"index out of range in '" + path + "'"};
+            cur = cur->items[st.idx].get();
+        } else if (cur->kind == Value::Str) {                                    // 'abc'[1] is a one-character string
+            if (st.idx >= cur->s.size()) throw Raise{"index out of range in '" + path + "'"};
+            auto ch = std::make_shared<Value>();
+            ch->kind = Value::Str;
+            ch->s = cur->s.substr(st.idx, 1);
+            temps.push_back(ch);
+            cur = ch.get();
+        } else {
+            throw Raise{"subscript of a group or number in '" + path + "'"};     // KeyError / TypeError
+        }
+    }
     return *cur;
 }
 
@@ -338,6 +427,15 @@ double speed_of(const Value& v, bool& bad) {
     }
 }
 
+std::string py_format(const Value& v) {                                    // f"{x}" for the values that can name something
+    switch (v.kind) {
+        case Value::Str: return v.s;
+        case Value::Int: return std::to_string(v.i);
+        case Value::Bool: return v.b ? "True" : "False";
+        default: return "<unnamed>";                                        // floats / containers: never a valid path element
+    }
+}
+
 const std::string& str_of(const Value& v, const char* what) {
     if (v.kind != Value::Str) throw Raise{std::string(what) + " is not a string"};
     return v.s;
@@ -396,7 +494,10 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
                     const std::string name = mattr + "." + str_of(*hc, "helper core name");
                     const Value& a = lookup(cfg, name);
                     if (a.kind == Value::Array) {                           // libconf: [..] -> list, (..) -> tuple
-                        for (const auto& c : a.items) { (void)py_int(*c); pg.help++; }
+                        for (size_t e = 0; e < a.items.size(); ++e) {       // the reference looks every element up by its own path
+                            (void)py_int(lookup(cfg, name + "[" + std::to_string(e) + "]"));
+                            pg.help++;
+                        }
                     } else {
                         (void)py_int(a);
                         pg.help++;
@@ -407,8 +508,11 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
             if (md.has("dp_group")) {
                 const Value& dpg = attr(md, "dp_group");
                 const Value* dp = nullptr;
+                // the bare `except:` around this look-up logs md.dp_group.name again (TriadCfgParser.py:195): without a
+                // name the handler itself raises; with one, any failure of the look-up is a logged error -> None
+                const Value& dp_name = attr(dpg, "name");
                 try {
-                    dp = &lookup(cfg, mattr + "." + str_of(attr(dpg, "name"), "dp_group.name"));
+                    dp = &lookup(cfg, mattr + "." + py_format(dp_name));
                 } catch (const AttrMissing&) { throw Reject{"dp group attribute not found"}; }
                   catch (const Raise&) { throw Reject{"dp group attribute not found"}; }
                 if (py_len(*dp) != 1) throw Reject{"DP groups of multiple NUMA nodes not supported"};
@@ -489,14 +593,15 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
                     throw Reject{"speed and core lengths differ"};
                 pg.proc_smt = truthy(*nc.items[4]);
                 const size_t n = py_len(*rxc);
+                auto elem = [&](size_t which, size_t g) -> const Value& {     // f'{mattr}.{md.nic_cores[which]}[{g}]', looked up afresh
+                    return lookup(cfg, mattr + "." + nc.items[which]->s + "[" + std::to_string(g) + "]");
+                };
                 for (size_t g = 0; g < n; ++g) {
-                    if (!rxc->is_seq() || !rxs->is_seq() || g >= rxs->items.size()) throw Raise{"rx speed index"};
-                    const double rs = speed_of(*rxs->items[g], bad_speed);
-                    (void)py_int(*rxc->items[g]);
+                    const double rs = speed_of(elem(1, g), bad_speed);
+                    (void)py_int(elem(0, g));
                     pg.proc++; pg.rx += rs; pg.nic_use = true;
-                    if (!txc->is_seq() || g >= txc->items.size() || !txs->is_seq() || g >= txs->items.size()) throw Raise{"tx index"};
-                    const double ts = speed_of(*txs->items[g], bad_speed);
-                    (void)py_int(*txc->items[g]);
+                    const double ts = speed_of(elem(3, g), bad_speed);
+                    (void)py_int(elem(2, g));
                     pg.proc++; pg.tx += ts;
                 }
             }
@@ -508,6 +613,7 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
 unsigned half_up(unsigned n) { return (n + 1) / 2; }                        // math.ceil(n / 2.0)
 
 void digest(const char* text, size_t len, nhdfit_req& r) {
+    g_temps.clear();
     Reader reader(text, len);
     const ValuePtr rootp = reader.parse_document();
     const Value& cfg = *rootp;

@@ -117,3 +117,24 @@ def test_matcher_from_config_texts_equals_matcher_from_topologies():
             assert (g[0], g[1:] and g[1]["gpu"]) == (ref[0], ref[1:] and tuple(ref[1]["gpu"]))
             placed += g[0] is not None
     assert placed > 0
+
+
+def test_mutated_configs_agree():
+    """Fuzz: 1-3 random character edits (delete / insert / replace, biased to libconfig punctuation) of generated
+    configs - outcome (request bytes, None, raise, limit) must stay identical to the reference parser's."""
+    rng = np.random.default_rng(20260921)
+    alphabet = list('{}[]()=:;,."\\\\#/* -+eExL0123456789abtrue\\n')
+    outcomes = set()
+    for _ in range(1200):
+        t = list(wire_gen.make_config(int(rng.integers(0, 500))))
+        for _e in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, len(t)))
+            op = rng.random()
+            if op < 0.4:
+                del t[pos]
+            elif op < 0.8:
+                t.insert(pos, alphabet[int(rng.integers(0, len(alphabet)))])
+            else:
+                t[pos] = alphabet[int(rng.integers(0, len(alphabet)))]
+        outcomes.add(assert_same("".join(t), "fuzz"))
+    assert outcomes == {"ok", "none", "raise", "limit"}
