@@ -225,6 +225,8 @@ int nhdfit_reset_stats(nhdfit_ctx* ctx);
 #define NHDFIT_WIRE_RAISE  2   /* the reference would raise (malformed text, value of the wrong type)           */
 #define NHDFIT_WIRE_LIMIT  3   /* more than NHDFIT_MAX_GROUPS proc groups or 255 cores in a group               */
 int nhdfit_digest_triad_config(const char* text, size_t len, nhdfit_req* out, char* err, size_t errlen);
+/* n texts in one call: codes[i] as above, out[i] zeroed unless codes[i] == 0; returns how many codes are non-zero */
+int nhdfit_digest_triad_configs(const char* const* texts, const size_t* lens, uint32_t n, nhdfit_req* out, int32_t* codes);
 
 #ifdef __cplusplus
 }

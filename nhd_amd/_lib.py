@@ -49,6 +49,7 @@ _SIGS = {
     "nhdfit_get_stats": (c_int, [c_void_p, POINTER(Stats)]),
     "nhdfit_reset_stats": (c_int, [c_void_p]),
     "nhdfit_digest_triad_config": (c_int, [c_char_p, ctypes.c_size_t, c_void_p, c_char_p, ctypes.c_size_t]),
+    "nhdfit_digest_triad_configs": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_void_p]),
 }
 
 _lib = None

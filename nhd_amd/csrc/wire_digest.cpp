@@ -33,7 +33,7 @@ struct AttrMissing { std::string why; }; // AttributeError inside a path look-up
 struct Limit { std::string why; };
 
 struct Value;
-using ValuePtr = std::shared_ptr<Value>;
+using ValuePtr = Value*;                                              // owned by the Arena of the current digest
 struct Value {
     enum Kind { Int, Float, Bool, Str, Array, List, Group } kind = Int;
     long long i = 0;
@@ -43,14 +43,35 @@ struct Value {
     std::vector<ValuePtr> items;                                  // Array [..] / List (..)
     std::vector<std::pair<std::string, ValuePtr>> fields;         // Group {..}, in file order
 
-    const Value* find(const std::string& key) const {
+    const Value* find(const std::string& key) const { return find(key.data(), key.size()); }
+    const Value* find(const char* key, size_t len) const {
         for (const auto& kv : fields)
-            if (kv.first == key) return kv.second.get();
+            if (kv.first.size() == len && std::memcmp(kv.first.data(), key, len) == 0) return kv.second;
         return nullptr;
     }
     bool has(const std::string& key) const { return find(key) != nullptr; }
     bool is_seq() const { return kind == Array || kind == List; }
 };
+
+// Values live in chunks that are recycled from one digest to the next (one allocation per 256 values instead of one
+// per value: the reader was allocation-bound)
+class Arena {
+public:
+    Value* make() {
+        if (used_ == chunks_.size() * kChunk) chunks_.emplace_back(new Value[kChunk]);
+        Value* v = &chunks_[used_ / kChunk][used_ % kChunk];
+        ++used_;
+        v->kind = Value::Int; v->i = 0; v->f = 0; v->b = false;
+        v->s.clear(); v->items.clear(); v->fields.clear();
+        return v;
+    }
+    void reset() { used_ = 0; }
+private:
+    static constexpr size_t kChunk = 256;
+    std::vector<std::unique_ptr<Value[]>> chunks_;
+    size_t used_ = 0;
+};
+thread_local Arena g_arena;
 
 // ---- libconfig reader (grammar of libconfig 1.7 as the `libconf` package accepts it) -------------------------
 class Reader {
@@ -58,7 +79,7 @@ public:
     Reader(const char* p, size_t n) : p_(p), end_(p + n) {}
 
     ValuePtr parse_document() {
-        auto root = std::make_shared<Value>();
+        Value* root = g_arena.make();
         root->kind = Value::Group;
         parse_settings(*root, /*top=*/true);
         skip_ws();
@@ -119,7 +140,7 @@ private:
     ValuePtr parse_value() {
         skip_ws();
         if (p_ == end_) fail("value expected");
-        auto v = std::make_shared<Value>();
+        Value* v = g_arena.make();
         if (*p_ == '{') {
             ++p_;
             v->kind = Value::Group;
@@ -147,7 +168,7 @@ private:
     }
 
     ValuePtr parse_scalar() {
-        auto v = std::make_shared<Value>();
+        Value* v = g_arena.make();
         if (*p_ == '"') {
             v->kind = Value::Str;
             while (peek('"')) parse_string_piece(v->s);                           // adjacent strings concatenate
@@ -253,39 +274,37 @@ private:
 // subscripts) and walked with getattr / subscription.  What is not such an expression (or is another kind of
 // expression: "a-b", "f(x)", a keyword) raises; a missing attribute is an AttributeError (AttrMissing here - some call
 // sites of the reference catch exactly that), a bad subscript an IndexError / KeyError / TypeError (Raise).
-bool py_keyword(const std::string& w) {
+bool py_keyword(const char* w, size_t len) {
     static const char* kw[] = {"False", "None", "True", "and", "as", "assert", "async", "await", "break", "class", "continue",
                                "def", "del", "elif", "else", "except", "finally", "for", "from", "global", "if", "import", "in",
                                "is", "lambda", "nonlocal", "not", "or", "pass", "raise", "return", "try", "while", "with", "yield"};
     for (const char* k : kw)
-        if (w == k) return true;
+        if (std::strlen(k) == len && std::memcmp(k, w, len) == 0) return true;
     return false;
 }
 
-thread_local std::vector<ValuePtr> g_temps;      // one-character strings made by string subscripts; cleared per digest
-
-struct PathStep { enum { Attr, Index, Key } kind; std::string name; unsigned long idx; };
+struct PathStep { enum { Attr, Index, Key } kind; const char* name; size_t len; unsigned long idx; };   // name points into the path
 
 // phase 1: the whole path must be a valid expression before anything is looked up (ast.parse comes first)
-std::vector<PathStep> parse_path(const std::string& path) {
-    std::vector<PathStep> steps;
+const std::vector<PathStep>& parse_path(const std::string& path) {
+    thread_local std::vector<PathStep> steps;                               // recycled: no allocation per look-up
+    steps.clear();
     size_t k = 0;
     const size_t n = path.size();
     auto bad = [&](const char* why) -> Raise { return Raise{std::string(why) + " in attribute path '" + path + "'"}; };
     auto skip = [&] { while (k < n && (path[k] == ' ' || path[k] == '\t')) ++k; };
-    auto ident = [&]() -> std::string {
+    auto ident = [&]() -> PathStep {
         const size_t b = k;
         if (k < n && (std::isalpha((unsigned char)path[k]) || path[k] == '_')) {
             ++k;
             while (k < n && (std::isalnum((unsigned char)path[k]) || path[k] == '_')) ++k;
         }
         if (k == b) throw bad("name expected");
-        std::string w = path.substr(b, k - b);
-        if (py_keyword(w)) throw bad("keyword");
-        return w;
+        if (py_keyword(path.data() + b, k - b)) throw bad("keyword");
+        return PathStep{PathStep::Attr, path.data() + b, k - b, 0};
     };
     if (n == 0 || path[0] == ' ' || path[0] == '\t' || path[0] == '\n') throw bad("empty or indented expression");
-    steps.push_back({PathStep::Attr, ident(), 0});
+    steps.push_back(ident());
     for (;;) {
         skip();
         if (k == n) break;
@@ -297,7 +316,7 @@ std::vector<PathStep> parse_path(const std::string& path) {
         }
         if (path[k] == '.') {
             ++k; skip();
-            steps.push_back({PathStep::Attr, ident(), 0});
+            steps.push_back(ident());
             continue;
         }
         if (path[k] != '[') throw bad("unexpected character");
@@ -307,7 +326,7 @@ std::vector<PathStep> parse_path(const std::string& path) {
             const size_t b = k;
             while (k < n && path[k] != q) { if (path[k] == '\\' || path[k] == '\n') throw bad("escape in subscript"); ++k; }
             if (k == n) throw bad("unterminated string");
-            steps.push_back({PathStep::Key, path.substr(b, k - b), 0});
+            steps.push_back({PathStep::Key, path.data() + b, k - b, 0});
             ++k; skip();
             if (k == n || path[k] != ']') throw bad("']' expected");
             ++k;
@@ -325,34 +344,33 @@ std::vector<PathStep> parse_path(const std::string& path) {
         skip();
         if (k == n || path[k] != ']') throw bad("']' expected");
         ++k;
-        steps.push_back({PathStep::Index, {}, digits.size() > 9 ? 999999999ul : std::strtoul(digits.c_str(), nullptr, 10)});
+        steps.push_back({PathStep::Index, nullptr, 0, digits.size() > 9 ? 999999999ul : std::strtoul(digits.c_str(), nullptr, 10)});
     }
     return steps;
 }
 
 // phase 2: getattr / subscription, left to right
-const Value& lookup(const Value& root, const std::string& path, std::vector<ValuePtr>& temps = g_temps) {
-    const std::vector<PathStep> steps = parse_path(path);
+const Value& lookup(const Value& root, const std::string& path) {
+    const std::vector<PathStep>& steps = parse_path(path);
     const Value* cur = &root;
     for (const PathStep& st : steps) {
         if (st.kind == PathStep::Attr) {
-            const Value* next = cur->kind == Value::Group ? cur->find(st.name) : nullptr;
-            if (!next) throw AttrMissing{"no attribute '" + st.name + "' in '" + path + "'"};
+            const Value* next = cur->kind == Value::Group ? cur->find(st.name, st.len) : nullptr;
+            if (!next) throw AttrMissing{"no attribute '" + std::string(st.name, st.len) + "' in '" + path + "'"};
             cur = next;
         } else if (st.kind == PathStep::Key) {
-            const Value* next = cur->kind == Value::Group ? cur->find(st.name) : nullptr;
+            const Value* next = cur->kind == Value::Group ? cur->find(st.name, st.len) : nullptr;
             if (!next) throw Raise{"bad string subscript in '" + path + "'"};      // KeyError / TypeError
             cur = next;
         } else if (cur->is_seq()) {
             if (st.idx >= cur->items.size()) throw Raise{"index out of range in '" + path + "'"};
-            cur = cur->items[st.idx].get();
+            cur = cur->items[st.idx];
         } else if (cur->kind == Value::Str) {                                    // 'abc'[1] is a one-character string
             if (st.idx >= cur->s.size()) throw Raise{"index out of range in '" + path + "'"};
-            auto ch = std::make_shared<Value>();
+            Value* ch = g_arena.make();
             ch->kind = Value::Str;
             ch->s = cur->s.substr(st.idx, 1);
-            temps.push_back(ch);
-            cur = ch.get();
+            cur = ch;
         } else {
             throw Raise{"subscript of a group or number in '" + path + "'"};     // KeyError / TypeError
         }
@@ -545,7 +563,7 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
                     }
                 } catch (const Raise&) { throw Reject{"error when parsing NIC fields"}; }
                   catch (const AttrMissing&) { throw Reject{"error when parsing NIC fields"}; }
-                try {                                                        // CPU workers: optional, errors are swallowed
+                if (d0.kind == Value::Group && d0.has("cpu_workers")) try {    // CPU workers: optional, errors are swallowed
                     const Value& cw = attr(d0, "cpu_workers");
                     const size_t n = py_len(cw);
                     for (size_t c = 0; c < n; ++c) {
@@ -567,7 +585,7 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
                     size_t k = 0;
                     while (k < keys.size() && !(keys[k] == key)) ++k;
                     if (k == keys.size()) { keys.push_back(key); cores.emplace_back(); }
-                    cores[k].push_back(e.items[0].get());
+                    cores[k].push_back(e.items[0]);
                 }
                 for (const auto& cl : cores) {
                     for (const Value* c : cl) { (void)py_int(*c); pg.proc++; }    // the GPU's feeder cores count as proc cores
@@ -613,7 +631,7 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
 unsigned half_up(unsigned n) { return (n + 1) / 2; }                        // math.ceil(n / 2.0)
 
 void digest(const char* text, size_t len, nhdfit_req& r) {
-    g_temps.clear();
+    g_arena.reset();
     Reader reader(text, len);
     const ValuePtr rootp = reader.parse_document();
     const Value& cfg = *rootp;
@@ -702,4 +720,18 @@ extern "C" int nhdfit_digest_triad_config(const char* text, size_t len, nhdfit_r
       catch (const Limit& e) { set_err(err, errlen, e.why); return NHDFIT_WIRE_LIMIT; }
       catch (const std::exception& e) { set_err(err, errlen, e.what()); return NHDFIT_E_INVAL; }
       catch (...) { set_err(err, errlen, "unknown failure"); return NHDFIT_E_INVAL; }
+}
+
+// n texts at once (one FFI crossing per batch of pending pods): codes[i] = what nhdfit_digest_triad_config returns
+// for text i; out[i] is written (zeroed unless the code is 0).  Returns the number of texts with a non-zero code.
+extern "C" int nhdfit_digest_triad_configs(const char* const* texts, const size_t* lens, uint32_t n, nhdfit_req* out, int32_t* codes) {
+    if (!texts || !lens || !out || !codes) return NHDFIT_E_INVAL;
+    int bad = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        std::memset(&out[i], 0, sizeof out[i]);
+        nhdfit_req r;
+        codes[i] = nhdfit_digest_triad_config(texts[i], lens[i], &r, nullptr, 0);
+        if (codes[i] == NHDFIT_OK) out[i] = r; else ++bad;
+    }
+    return bad;
 }

@@ -190,14 +190,14 @@ class HipMatcher:
         from . import wire
         if not cfg_texts:
             return []
-        reqs = np.zeros(len(cfg_texts), pack.REQ)
-        skip = np.zeros(len(cfg_texts), bool)
-        for i, text in enumerate(cfg_texts):
-            r = wire.digest_config(text, None if pod_groups is None else pod_groups[i], self.packer)
-            if r is None:
-                skip[i] = True                              # stays an all-zero (= never matching) request
-            else:
-                reqs[i] = r
+        reqs, codes = wire.digest_configs(cfg_texts)
+        for i in np.flatnonzero(codes > wire.WIRE_NONE):     # what the reference would raise on: report it properly
+            wire.digest_config(cfg_texts[int(i)])
+        skip = codes == wire.WIRE_NONE                       # all-zero (= never matching) requests
+        if pod_groups is not None:
+            for i in np.flatnonzero(~skip):
+                reqs[i]["flags"] = pack.RF_INITIAL_FILTER
+                reqs[i]["groups"] = self.packer.group_bits(pod_groups[int(i)])
         for i in np.flatnonzero(~skip):
             if reqs[i]["n_groups"] == 0 and len(nl):
                 raise IndexError("pod without processing groups (the reference fails the same way, Matcher.py:346)")

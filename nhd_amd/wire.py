@@ -47,3 +47,18 @@ def digest_config(text, pod_groups: Optional[Sequence[str]] = None, packer: Opti
         req["flags"] = pack.RF_INITIAL_FILTER
         req["groups"] = packer.group_bits(pod_groups)
     return req
+
+
+def digest_configs(texts: Sequence) -> "tuple[np.ndarray, np.ndarray]":
+    """Many texts in one library call: (requests [n] of dtype pack.REQ, codes [n] int32).  codes[i] is 0, WIRE_NONE,
+    WIRE_RAISE or WIRE_LIMIT; requests of non-zero codes are all-zero records (= never matching)."""
+    lib = _lib.load()
+    raws = [t.encode("utf-8") if isinstance(t, str) else bytes(t) for t in texts]
+    n = len(raws)
+    reqs = np.zeros(n, pack.REQ)
+    codes = np.zeros(n, np.int32)
+    if n:
+        ptrs = (ctypes.c_char_p * n)(*raws)
+        lens = (ctypes.c_size_t * n)(*[len(r) for r in raws])
+        lib.nhdfit_digest_triad_configs(ptrs, lens, n, reqs.ctypes.data_as(ctypes.c_void_p), codes.ctypes.data_as(ctypes.c_void_p))
+    return reqs, codes
