@@ -293,6 +293,7 @@ const std::vector<PathStep>& parse_path(const std::string& path) {
     const size_t n = path.size();
     auto bad = [&](const char* why) -> Raise { return Raise{std::string(why) + " in attribute path '" + path + "'"}; };
     auto skip = [&] { while (k < n && (path[k] == ' ' || path[k] == '\t')) ++k; };
+    auto skip_in = [&] { while (k < n && (path[k] == ' ' || path[k] == '\t' || path[k] == '\n')) ++k; };   // inside [ ]: lines join
     auto ident = [&]() -> PathStep {
         const size_t b = k;
         if (k < n && (std::isalpha((unsigned char)path[k]) || path[k] == '_')) {
@@ -320,14 +321,14 @@ const std::vector<PathStep>& parse_path(const std::string& path) {
             continue;
         }
         if (path[k] != '[') throw bad("unexpected character");
-        ++k; skip();
+        ++k; skip_in();
         if (k < n && (path[k] == '\'' || path[k] == '"')) {                 // string subscript: dict key
             const char q = path[k++];
             const size_t b = k;
             while (k < n && path[k] != q) { if (path[k] == '\\' || path[k] == '\n') throw bad("escape in subscript"); ++k; }
             if (k == n) throw bad("unterminated string");
             steps.push_back({PathStep::Key, path.data() + b, k - b, 0});
-            ++k; skip();
+            ++k; skip_in();
             if (k == n || path[k] != ']') throw bad("']' expected");
             ++k;
             continue;
@@ -341,7 +342,7 @@ const std::vector<PathStep>& parse_path(const std::string& path) {
         }
         if (digits.empty()) throw bad("constant subscript expected");
         if (digits.size() > 1 && digits[0] == '0' && digits.find_first_not_of('0') != std::string::npos) throw bad("leading zeros");
-        skip();
+        skip_in();
         if (k == n || path[k] != ']') throw bad("']' expected");
         ++k;
         steps.push_back({PathStep::Index, nullptr, 0, digits.size() > 9 ? 999999999ul : std::strtoul(digits.c_str(), nullptr, 10)});
