@@ -165,7 +165,18 @@ def cpu_baseline(spec, tops, pod_groups, sample, gpu_score, base, winner_index):
     gpu_winner = np.array([winner_index(s) - base if s else -1 for s in gpu_score[:sample]], dtype=np.int64)
     if not np.array_equal(gpu_winner, winner):
         raise SystemExit("PARITY FAILURE: GPU winners differ from the CPU port on the sampled pods")
+    # the same sample on every host core (OpenMP over pods), for scale: the primary figure stays the 1-core one
+    ncores = os.cpu_count() or 1
+    many = None
+    if ncores > 1:
+        t0 = time.perf_counter()
+        winner_mt, _ = cl.find(op, spec.clock_now, want_feas=False, threads=ncores)
+        dt_mt = time.perf_counter() - t0
+        if not np.array_equal(winner_mt, winner):
+            raise SystemExit("PARITY FAILURE: the multi-threaded CPU port disagrees with the single-threaded one")
+        many = {"value": sample * spec.n / dt_mt, "cores": ncores, "seconds": dt_mt}
     return {"value": sample * spec.n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+            "all_host_cores": many,
             "sample": f"first {sample} pods x {spec.n} nodes, oracle/nhd_oracle.c (gcc -O2), {dt:.1f} s; "
                       f"winners identical to the GPU's on all {sample} pods",
             "reference_python_note": "the reference itself is Python and absent on the GPU box; measured in the build "
