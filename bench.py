@@ -43,6 +43,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly one line: the result.  Native libraries are chatty on it (gloo's "[Gloo] Rank 0 is
+    # connected ...", librccl's version banner at communicator creation), so file descriptor 1 is pointed at
+    # stderr for the duration of the run and the JSON line goes to a private duplicate of the real stdout.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -145,7 +152,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(spec, tops, pod_groups, args.cpu_sample_pods, score, lo, winner_index)
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         eng.comm_destroy()

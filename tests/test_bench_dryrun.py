@@ -1,11 +1,8 @@
 """bench.py's control flow (argument handling, JSON contract, CPU-baseline leg with its parity assert) on CPU: the
 Engine is replaced by the host harness, so the numbers mean nothing - the keys and the parity check do."""
-import io
 import json
 import os
-import runpy
 import sys
-from contextlib import redirect_stdout
 
 from tests import harness
 
@@ -27,17 +24,26 @@ class DryEngine(harness.HarnessEngine):
         return self.find(self._reqs, self._now, want_bitmap=want_bitmap, want_map=want_map)
 
 
-def test_bench_json_contract(monkeypatch):
-    import nhd_amd.engine as eng_mod
-    monkeypatch.setattr(eng_mod, "Engine", DryEngine)
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3", "--warmup", "1", "--nodes-per-gpu", "1024",
-                                      "--pods", "96", "--cpu-sample-pods", "32"])
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
-        monkeypatch.delenv(k, raising=False)
-    buf = io.StringIO()
-    with redirect_stdout(buf):
-        runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
-    lines = [ln for ln in buf.getvalue().splitlines() if ln.strip()]
+_SINGLE_SCRIPT = r"""
+import runpy, sys
+sys.path.insert(0, {root!r})
+from tests.test_bench_dryrun import DryEngine
+import nhd_amd.engine as eng_mod
+eng_mod.Engine = DryEngine
+sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--nodes-per-gpu", "1024", "--pods", "96", "--cpu-sample-pods", "32"]
+print("library chatter that must not reach the result stream", file=sys.stderr)
+runpy.run_path({bench!r}, run_name="__main__")
+"""
+
+
+def test_bench_json_contract(tmp_path):
+    import subprocess
+    script = tmp_path / "single.py"
+    script.write_text(_SINGLE_SCRIPT.format(root=ROOT, bench=os.path.join(ROOT, "bench.py")))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1                                   # exactly one JSON line
     out = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -48,3 +54,40 @@ def test_bench_json_contract(monkeypatch):
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+
+
+_RANK_SCRIPT = r"""
+import runpy, sys
+sys.path.insert(0, {root!r})
+from tests.test_bench_dryrun import DryEngine
+import nhd_amd.engine as eng_mod
+
+class ShardedDry(DryEngine):
+    def unique_id(self): return b"\0" * 128
+    def comm_init(self, nranks, rank, uid): self.nranks = nranks
+    def comm_destroy(self): pass
+
+eng_mod.Engine = ShardedDry
+sys.argv = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--nodes-per-gpu", "512", "--pods", "40"]
+runpy.run_path({bench!r}, run_name="__main__")
+"""
+
+
+def test_bench_two_ranks_control_plane(tmp_path):
+    """`--gpus 2` as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* in the env, gloo
+    control plane): rank 0 prints the one JSON line with n_gpus = 2 and both shards' nodes, rank 1 prints nothing."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT.format(root=ROOT, bench=os.path.join(ROOT, "bench.py")))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    lines0 = [ln for ln in outs[0][0].splitlines() if ln.strip()]
+    assert len(lines0) == 1 and not outs[1][0].strip()
+    out = json.loads(lines0[0])
+    assert out["n_gpus"] == 2 and out["config"]["nodes_total"] == 1024 and "cpu_baseline" not in out
