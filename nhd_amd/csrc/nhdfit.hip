@@ -1227,6 +1227,8 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         }
         if (c->comm) HIPCHK(c, hipEventRecord(c->ev_red[bf], c->s_red));
         c->n_fit++;
+        // no mapping roles for this step (output switched off, or only 4-group pods): nothing to catch up on later
+        if (!small_map) c->n_shaped = c->n_chosen = c->n_finished = c->n_fit;
         c->stats.evals_last = (uint64_t)P * c->n;
         // algorithmic bytes of the fit role: every tile streams the five node planes once,
         // every block stages its tile image once, plus the bitmap and the score words.

@@ -655,12 +655,21 @@ void digest(const char* text, size_t len, nhdfit_req& r) {
     unsigned n_misc = 0;
     {
         const Value& ext = attr(topo, "ext_cores");
-        if (!ext.is_seq()) throw Raise{"ext_cores is not a list"};
-        for (const auto& e : ext.items) {
+        // `for i in ext_cores`: a list / array yields its elements, a string its characters, a group its setting names
+        auto one = [&](const std::string& name) {
             try {
-                (void)py_int(lookup(cfg, str_of(*e, "ext core name")));
+                (void)py_int(lookup(cfg, name));
             } catch (const AttrMissing&) { throw Reject{"ext core not found"}; }     // the one exception type the reference catches here
             n_misc++;
+        };
+        if (ext.is_seq()) {
+            for (const auto& e : ext.items) one(str_of(*e, "ext core name"));        // in order: an earlier failure wins
+        } else if (ext.kind == Value::Str) {
+            for (char ch : ext.s) one(std::string(1, ch));
+        } else if (ext.kind == Value::Group) {
+            for (const auto& kv : ext.fields) one(kv.first);
+        } else {
+            throw Raise{"ext_cores is not iterable"};
         }
     }
     // ParseKniDataVlan (:80-90) only stores a name.  ParseModGroups:
