@@ -547,29 +547,28 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
                         throw Reject{"core / speed list lengths differ"};
                 }
                 pg.proc_smt = truthy(attr(dpg, "proc_cores_smt"));
+                // every core and speed is looked up afresh by its composed path, as the reference does
+                // (f'{mattr}.{md.dp_group.name}[0].rx_cores[{gidx}]', TriadCfgParser.py:203-215)
+                const std::string dpath = mattr + "." + py_format(dp_name) + "[0].";
+                auto elem = [&](const char* field, size_t g) -> const Value& {
+                    return lookup(cfg, dpath + field + "[" + std::to_string(g) + "]");
+                };
                 try {
                     const size_t n = py_len(rxc);
                     for (size_t g = 0; g < n; ++g) {
-                        const Value& rxs = attr(d0, "rx_speeds");                 // looked up per core, inside the try
-                        if (!rxs.is_seq() || g >= rxs.items.size() || !rxc.is_seq()) throw Raise{"rx index"};
-                        const double rs = speed_of(*rxs.items[g], bad_speed);
-                        (void)py_int(*rxc.items[g]);
+                        const double rs = speed_of(elem("rx_speeds", g), bad_speed);
+                        (void)py_int(elem("rx_cores", g));
                         pg.proc++; pg.rx += rs; pg.nic_use = true;
-                        if (!txc.is_seq() || g >= txc.items.size()) throw Raise{"tx index"};
-                        const Value& txs = attr(d0, "tx_speeds");
-                        if (!txs.is_seq() || g >= txs.items.size()) throw Raise{"tx index"};
-                        const double ts = speed_of(*txs.items[g], bad_speed);
-                        (void)py_int(*txc.items[g]);
+                        const double ts = speed_of(elem("tx_speeds", g), bad_speed);
+                        (void)py_int(elem("tx_cores", g));
                         pg.proc++; pg.tx += ts;
                     }
                 } catch (const Raise&) { throw Reject{"error when parsing NIC fields"}; }
                   catch (const AttrMissing&) { throw Reject{"error when parsing NIC fields"}; }
                 if (d0.kind == Value::Group && d0.has("cpu_workers")) try {    // CPU workers: optional, errors are swallowed
-                    const Value& cw = attr(d0, "cpu_workers");
-                    const size_t n = py_len(cw);
+                    const size_t n = py_len(attr(d0, "cpu_workers"));
                     for (size_t c = 0; c < n; ++c) {
-                        if (!cw.is_seq()) throw Raise{"cpu_workers"};
-                        (void)py_int(*cw.items[c]);
+                        (void)py_int(elem("cpu_workers", c));
                         pg.proc++;
                     }
                 } catch (const Raise&) {} catch (const AttrMissing&) {}
@@ -577,7 +576,7 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
                 const size_t ng = py_len(gm);
                 if (ng && !gm.is_seq()) throw Raise{"gpu_map is not a list"};
                 std::vector<GpuKey> keys;
-                std::vector<std::vector<const Value*>> cores;
+                std::vector<std::vector<size_t>> cores;                      // gpu_map entries (by index) of each device
                 for (size_t g = 0; g < ng; ++g) {
                     const Value& e = *gm.items[g];
                     if (py_len(e) != 2) continue;                            // logged, not processed
@@ -586,10 +585,13 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
                     size_t k = 0;
                     while (k < keys.size() && !(keys[k] == key)) ++k;
                     if (k == keys.size()) { keys.push_back(key); cores.emplace_back(); }
-                    cores[k].push_back(e.items[0]);
+                    cores[k].push_back(g);
                 }
                 for (const auto& cl : cores) {
-                    for (const Value* c : cl) { (void)py_int(*c); pg.proc++; }    // the GPU's feeder cores count as proc cores
+                    for (size_t g : cl) {                                     // the GPU's feeder cores count as proc cores
+                        (void)py_int(lookup(cfg, dpath + "gpu_map[" + std::to_string(g) + "][0]"));
+                        pg.proc++;
+                    }
                     pg.gpus++;
                 }
             }
