@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "seq_core.h"
+#include "set_states.h"
 
 using namespace nhdfit;
 
@@ -466,6 +467,7 @@ struct ShapeArgs {
     uint32_t* count;             // [tiles]
     const AscEntry* asc;         // layouts of ascending-filled sets (winner_map.h), built once per context
     const uint8_t* choose_tab;   // tabulated choose_tuples for U = 2, G <= 2 (winner_map.h), or null
+    SetStates st;                // set-layout state machine for U = 2, G = 3 (set_states.h); info == null: not used
 };
 // slot_of_pod encodings: >= 0 slot of the pod's shape; -1 nothing to map; <= -2: the result word itself, -2 - word
 // (shapes answered from choose_tab never reach the choose role)
@@ -546,6 +548,10 @@ __device__ __forceinline__ void role_choose(const ShapeArgs& h, uint32_t w, uint
         const int G = (int)(key & 3), U = (int)((key >> 2) & 1) + 1;
         uint32_t gcode = 0;
         int ccode = -1;
+        if (h.st.info && G == 3 && U == 2) {         // ~40 table look-ups instead of the insertion-by-insertion model
+            h.result[k] = choose_g3(h.st, h.asc, (uint32_t)(key >> 3) & 0xFF, (uint32_t)(key >> 19) & 0xFFFF, (uint32_t)(key >> 11) & 0xFF);
+            continue;
+        }
         const bool ok = choose_tuples<SmallOps>(G, U, (uint32_t)(key >> 3) & 0xFF, (uint32_t)(key >> 19) & 0xFFFF,
                                                 (uint32_t)(key >> 11) & 0xFF, gcode, ccode, h.asc);
         h.result[k] = ((uint32_t)ok << 8) | ((gcode & 7u) << 4) | ((uint32_t)ccode & 15u);
@@ -796,6 +802,10 @@ struct nhdfit_ctx {
     DevBuf<AscEntry> asc;                // layouts of ascending-filled CPython sets (static table, built at creation)
     DevBuf<uint8_t> choose_tab;          // choose_tuples tabulated for U = 2, G <= 2 (static table, built at creation)
     bool use_choose_tab = getenv("NHDFIT_NO_CHOOSE_TABLE") == nullptr;   // tuning aid: run the set model for every shape
+    // set-layout state machine for three-group pods (set_states.h): verified against the model on the host
+    // (tests/test_pyset_emulation.py), not yet measured on the GPU - opt-in until it is (NHDFIT_SET_STATES=1)
+    DevBuf<uint64_t> st_info; DevBuf<uint32_t> st_next, st_asc; uint32_t st_n = 0;
+    bool use_set_states = getenv("NHDFIT_SET_STATES") != nullptr;
     // mode B
     DevBuf<uint64_t> nogpu; DevBuf<int32_t> slot_of; DevBuf<OverlayNode> overlay; DevBuf<SeqResult> seq_out; DevBuf<uint32_t> order;
     bool use_cand = false, want_bitmap = true, want_map = true;
@@ -905,6 +915,18 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_build_asc, dim3((kAscEntries + 255) / 256), dim3(256), 0, c->stream, c->asc.p);
         e = hipGetLastError();
+        if (e == hipSuccess && c->use_set_states) {
+            std::vector<uint64_t> info;
+            std::vector<uint32_t> next, asc;
+            build_set_states(info, next, asc);
+            c->st_n = (uint32_t)info.size();
+            e = c->st_info.reserve(info.size());
+            if (e == hipSuccess) e = c->st_next.reserve(next.size());
+            if (e == hipSuccess) e = c->st_asc.reserve(asc.size());
+            if (e == hipSuccess) e = hipMemcpy(c->st_info.p, info.data(), info.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(c->st_next.p, next.data(), next.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(c->st_asc.p, asc.data(), asc.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        }
         if (e == hipSuccess) e = c->choose_tab.reserve(kChooseEntries);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_build_choose, dim3((kChooseEntries + 255) / 256), dim3(256), 0, c->stream, c->asc.p, c->choose_tab.p);
@@ -928,7 +950,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
-    c->reqs.release(); c->bitmap.release(); c->cand.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->group_sets.release();
+    c->reqs.release(); c->bitmap.release(); c->cand.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); c->shape_list[b].release(); }
     c->nogpu.release(); c->slot_of.release(); c->overlay.release(); c->seq_out.release(); c->order.release();
     for (int b = 0; b < kBufs; ++b) {
@@ -1115,7 +1137,8 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
     };
     auto shape_args = [&](int b) {
         return ShapeArgs{c->shape_keys[b].p, c->shape_res[b].p, c->shape_slot[b].p, c->shape_list[b].p, c->asc.p,
-                         c->use_choose_tab ? c->choose_tab.p : nullptr};
+                         c->use_choose_tab ? c->choose_tab.p : nullptr,
+                         c->use_set_states ? SetStates{c->st_info.p, c->st_next.p, c->st_asc.p, c->st_n} : SetStates{nullptr, nullptr, nullptr, 0}};
     };
     // mapping phases of earlier steps: each advances by at most one step per launch
     bool did_shapes = false, did_choose = false, did_finish = false;

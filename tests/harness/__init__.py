@@ -17,7 +17,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    deps = [SRC] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "winner_map.h")] + \
+    deps = [SRC] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "winner_map.h", "seq_core.h", "set_states.h")] + \
            [os.path.join(HERE, "..", "..", "include", "nhdfit.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", SRC, "-o", SO])

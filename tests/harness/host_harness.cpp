@@ -5,6 +5,7 @@
 #include <cstring>
 #include <vector>
 #include "../../nhd_amd/csrc/seq_core.h"
+#include "../../nhd_amd/csrc/set_states.h"
 
 using namespace nhdfit;
 
@@ -231,6 +232,20 @@ static const uint8_t* host_choose_table() {
 }
 int hh_choose_tabulated(int G, int U) { return choose_tabulated(G, U) ? 1 : 0; }
 uint32_t hh_choose_from_table(int G, uint32_t sg, uint32_t sc, uint32_t nic) { return choose_from_table(host_choose_table(), G, sg, sc, nic); }
+
+// choose_tuples for G = 3, U = 2 through the set-layout state machine (set_states.h)
+static const SetStates& host_set_states() {
+    static std::vector<uint64_t> info;
+    static std::vector<uint32_t> next, asc;
+    static SetStates t{};
+    if (info.empty()) {
+        build_set_states(info, next, asc);
+        t = SetStates{info.data(), next.data(), asc.data(), (uint32_t)info.size()};
+    }
+    return t;
+}
+uint32_t hh_set_state_count() { return host_set_states().n; }
+uint32_t hh_choose_g3(uint32_t sg, uint32_t sc, uint32_t nic) { return choose_g3(host_set_states(), host_asc_table(), sg, sc, nic); }
 
 // the same through the generic (PySet) model
 int hh_choose_generic(int G, int U, uint32_t sg, uint32_t sc, uint32_t nic, uint32_t* gcode, int* ccode) {

@@ -186,3 +186,36 @@ def test_tabulated_choose_equals_the_model_everywhere():
             assert (word >> 8 & 1) == ok, (G, sg, sc, nic)
             if ok:
                 assert ((word >> 4) & 7, word & 15) == (g.value, c.value), (G, sg, sc, nic)
+
+
+def test_set_layout_state_machine_equals_the_model():
+    """choose_tuples for three proc groups on two NUMA nodes through the set-layout state machine
+    (nhd_amd/csrc/set_states.h: enumerated layouts + transition table) == the insertion-by-insertion register model
+    == the generic PySet model, on 200 000 random inputs plus structured sweeps (all GPU / NIC subsets for sampled CPU
+    subsets, all CPU subsets for sampled GPU / NIC subsets)."""
+    L = harness.lib()
+    L.hh_choose_g3.restype = ctypes.c_uint32
+    L.hh_set_state_count.restype = ctypes.c_uint32
+    assert 100 < L.hh_set_state_count() < 5000          # 338 layouts for keys 0..7
+    g, c = ctypes.c_uint32(), ctypes.c_int()
+    rng = np.random.default_rng(11)
+
+    def check(sg, sc, nic, generic=False):
+        word = L.hh_choose_g3(sg, sc, nic)
+        ok = L.hh_choose(3, 2, sg, sc, nic, 0, ctypes.byref(g), ctypes.byref(c)) if (sg and sc and nic) else 0
+        assert (word >> 8 & 1) == ok, (sg, sc, nic)
+        if ok:
+            assert ((word >> 4) & 7, word & 15) == (g.value, c.value), (sg, sc, nic)
+            if generic:
+                assert L.hh_choose_generic(3, 2, sg, sc, nic, ctypes.byref(g), ctypes.byref(c)) == 1
+                assert ((word >> 4) & 7, word & 15) == (g.value, c.value)
+
+    for k in range(200000):
+        check(int(rng.integers(0, 256)), int(rng.integers(0, 65536)), int(rng.integers(0, 256)), generic=k % 50 == 0)
+    for sc in [int(x) for x in rng.integers(1, 65536, size=4)] + [0xFFFF, 0x5555, 0x0F0F]:
+        for sg in range(1, 256, 3):
+            for nic in range(1, 256, 5):
+                check(sg, sc, nic)
+    for sg, nic in [(0xFF, 0xFF), (0x81, 0xFF), (0x7E, 0x7E), (0x18, 0xFF), (0xFF, 0x01)]:
+        for sc in range(1, 65536, 7):
+            check(sg, sc, nic)
