@@ -803,7 +803,8 @@ struct nhdfit_ctx {
     DevBuf<uint8_t> choose_tab;          // choose_tuples tabulated for U = 2, G <= 2 (static table, built at creation)
     bool use_choose_tab = getenv("NHDFIT_NO_CHOOSE_TABLE") == nullptr;   // tuning aid: run the set model for every shape
     // set-layout state machine for three-group pods (set_states.h): verified against the model on the host
-    // (tests/test_pyset_emulation.py), not yet measured on the GPU - opt-in until it is (NHDFIT_SET_STATES=1)
+    // (tests/test_pyset_emulation.py) and parity-green on the GPU, but not yet timed there - opt-in until it is
+    // (NHDFIT_SET_STATES=1)
     DevBuf<uint64_t> st_info; DevBuf<uint32_t> st_next, st_asc; uint32_t st_n = 0;
     bool use_set_states = getenv("NHDFIT_SET_STATES") != nullptr;
     // mode B
