@@ -138,3 +138,14 @@ def test_mutated_configs_agree():
                 t[pos] = alphabet[int(rng.integers(0, len(alphabet)))]
         outcomes.add(assert_same("".join(t), "fuzz"))
     assert outcomes == {"ok", "none", "raise", "limit"}
+
+
+def test_sequential_batch_from_config_texts():
+    """Mode B (commit after every pod) fed with config texts == mode B fed with the reference-parsed topologies."""
+    from nhd_amd.matcher import HipMatcher
+    from tests import harness, util
+    nl = util.random_cluster(44, 50)
+    texts = [t for t in (wire_gen.make_config(s) for s in range(200)) if reference_outcome(t)[0] == "ok"][:40]
+    tops = [ref_loader.config_to_topology(t) for t in texts]
+    m = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)
+    assert m.FindNodesFromConfigs(nl, texts, sequential=True) == m.ScheduleBatch(nl, tops)
