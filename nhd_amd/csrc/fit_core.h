@@ -309,6 +309,45 @@ NHD_HD NodeLane node_lane(const nhdfit_plane0& a, const nhdfit_plane1& b, const 
     return n;
 }
 
+// ---- node records: node_lane() minus the clock, precomputed -----------------------------------------------
+// Everything node_lane derives from the five planes depends only on the mirror and the table layout, not on the
+// pod tile or the step: a 32-byte record per node (row offsets in units of 8 bytes - rows are 8-byte aligned and an
+// image is far below 512 KB) replaces five 16-byte plane loads and ~100 VALU instructions per (node chunk, pod
+// tile) pair by two loads and a few unpacks.  Rebuilt when nodes are uploaded or the layout changes.
+struct alignas(16) NodeRec {
+    uint16_t off_w0, off_w1, off_a, off_r0n, off_r1n, off_r0p, off_r1p, off_hp;    // first 16 bytes
+    uint16_t off_gf, flags;
+    uint32_t reserved;
+    double busy_time;                                                               // second 16 bytes
+};
+static_assert(sizeof(NodeRec) == 32, "two 16-byte loads per node");
+
+NHD_HD NodeRec make_node_record(const nhdfit_plane0& a, const nhdfit_plane1& b, const nhdfit_plane2& c,
+                                const nhdfit_plane3& d, const nhdfit_plane4& e, const Layout& L) {
+    const NodeLane n = node_lane(a, b, c, d, e, 0.0, L);
+    NodeRec r;
+    r.off_w0 = (uint16_t)(n.off_w0 >> 3); r.off_w1 = (uint16_t)(n.off_w1 >> 3); r.off_a = (uint16_t)(n.off_a >> 3);
+    r.off_r0n = (uint16_t)(n.off_r0n >> 3); r.off_r1n = (uint16_t)(n.off_r1n >> 3);
+    r.off_r0p = (uint16_t)(n.off_r0p >> 3); r.off_r1p = (uint16_t)(n.off_r1p >> 3);
+    r.off_hp = (uint16_t)(n.off_hp >> 3); r.off_gf = (uint16_t)(n.off_gf >> 3);
+    r.flags = (uint16_t)n.flags;
+    r.reserved = 0;
+    r.busy_time = e.busy_time;
+    return r;
+}
+
+NHD_HD NodeLane node_lane_from_record(const NodeRec& r, double now, const Layout& L) {
+    NodeLane n;
+    n.off_w0 = (uint32_t)r.off_w0 << 3; n.off_w1 = (uint32_t)r.off_w1 << 3; n.off_a = (uint32_t)r.off_a << 3;
+    n.off_r0n = (uint32_t)r.off_r0n << 3; n.off_r1n = (uint32_t)r.off_r1n << 3;
+    n.off_r0p = (uint32_t)r.off_r0p << 3; n.off_r1p = (uint32_t)r.off_r1p << 3;
+    n.off_hp = (uint32_t)r.off_hp << 3; n.off_gf = (uint32_t)r.off_gf << 3;
+    n.w_misc = 2 * L.fc_dim * L.row_bytes;
+    n.flags = r.flags;
+    n.busy = (now - r.busy_time) < kMinBusySecs;
+    return n;
+}
+
 NHD_HD uint64_t ld64(const uint8_t* img, uint32_t off) { return *reinterpret_cast<const uint64_t*>(img + off); }
 
 // Scalar predicates of one node against all 64 pods of the tile (bit j = pod j may consider the node).

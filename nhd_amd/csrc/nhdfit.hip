@@ -183,6 +183,7 @@ struct FitArgs {
     const nhdfit_plane2* p2;
     const nhdfit_plane3* p3;
     const nhdfit_plane4* p4;
+    const NodeRec* rec;         // precomputed node records (role_fit<.., true>), or null
     uint32_t n;                 // nodes in this shard
     uint32_t chunks;            // ceil(n / 64)
     uint32_t chunks_per_block;
@@ -305,7 +306,7 @@ __device__ __forceinline__ uint64_t sweep_dispatch(uint32_t W, const uint8_t* im
 // The P x N pass.  Block = (pod tile, node range): the tile's table image is staged in LDS, every wavefront
 // sweeps 64-node chunks of the range (lane = node), transposes the verdicts (lane = pod), writes the bitmap word
 // and keeps the best score; one atomicMax per pod and block.
-template <int BLOCK>
+template <int BLOCK, bool REC>
 __device__ __forceinline__ void role_fit(const FitArgs& a, uint32_t blk, uint8_t* lds) {
     constexpr int NW = BLOCK / 64;
     uint8_t* img = lds;
@@ -346,7 +347,11 @@ __device__ __forceinline__ void role_fit(const FitArgs& a, uint32_t blk, uint8_t
         const bool live = i < a.n;
         NodeLane nl = NodeLane{};
         nl.flags = NHDFIT_NF_MAINTENANCE;                      // lanes past the end are never feasible
-        if (live) nl = node_lane(a.p0[i], a.p1[i], a.p2[i], a.p3[i], a.p4[i], a.now, a.layout);
+        if constexpr (REC) {
+            if (live) nl = node_lane_from_record(a.rec[i], a.now, a.layout);      // two 16-byte loads, no popcounts / multiplies
+        } else {
+            if (live) nl = node_lane(a.p0[i], a.p1[i], a.p2[i], a.p3[i], a.p4[i], a.now, a.layout);
+        }
         const uint64_t nogpu = __ballot(live && !(nl.flags & NHDFIT_NF_HAS_GPU));
 
         // (1) NUMA-assignment feasibility against all 64 pods, in the lane = node domain (bit-sliced tables)
@@ -606,10 +611,16 @@ __device__ __forceinline__ void stamp(unsigned long long* role_clock, int role, 
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_fit_only(FitArgs a) {
     extern __shared__ __align__(16) uint8_t lds[];
-    role_fit<BLOCK>(a, blockIdx.x, lds);
+    role_fit<BLOCK, false>(a, blockIdx.x, lds);
 }
 
-template <int BLOCK>
+// node records of the whole mirror for the current table layout (one thread per node; only after uploads / re-staging)
+__global__ __launch_bounds__(256) void k_node_records(FitArgs a, NodeRec* out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.n) out[i] = make_node_record(a.p0[i], a.p1[i], a.p2[i], a.p3[i], a.p4[i], a.layout);
+}
+
+template <int BLOCK, bool REC>
 __global__ __launch_bounds__(BLOCK, 7) void k_step(StepArgs a) {
     extern __shared__ __align__(16) uint8_t lds[];
     uint32_t blk = blockIdx.x;
@@ -631,7 +642,7 @@ __global__ __launch_bounds__(BLOCK, 7) void k_step(StepArgs a) {
     blk -= a.nb_finish;
     if (blk < a.nb_digest) { role_digest<BLOCK>(a.digest, blk, lds); stamp(a.role_clock, 3, t0); return; }
     blk -= a.nb_digest;
-    role_fit<BLOCK>(a.fit, blk, lds);
+    role_fit<BLOCK, REC>(a.fit, blk, lds);
     stamp(a.role_clock, 4, t0);
 }
 
@@ -801,6 +812,10 @@ struct nhdfit_ctx {
     DevBuf<uint32_t> shape_list[kBufs];  // distinct shapes per tile
     DevBuf<AscEntry> asc;                // layouts of ascending-filled CPython sets (static table, built at creation)
     DevBuf<uint8_t> choose_tab;          // choose_tuples tabulated for U = 2, G <= 2 (static table, built at creation)
+    // node records (fit_core.h NodeRec): arithmetic checked on the host against node_lane(); the kernel variant has not
+    // run on a GPU yet - opt-in (NHDFIT_NODE_RECORDS=1) until it has been measured
+    DevBuf<NodeRec> rec; bool rec_valid = false;
+    bool use_node_records = getenv("NHDFIT_NODE_RECORDS") != nullptr;
     bool use_choose_tab = getenv("NHDFIT_NO_CHOOSE_TABLE") == nullptr;   // tuning aid: run the set model for every shape
     // set-layout state machine for three-group pods (set_states.h): verified against the model on the host
     // (tests/test_pyset_emulation.py) and parity-green on the GPU, but not yet timed there - opt-in until it is
@@ -951,7 +966,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
-    c->reqs.release(); c->bitmap.release(); c->cand.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
+    c->reqs.release(); c->bitmap.release(); c->cand.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->rec.release(); c->group_sets.release();
     for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); c->shape_list[b].release(); }
     c->nogpu.release(); c->slot_of.release(); c->overlay.release(); c->seq_out.release(); c->order.release();
     for (int b = 0; b < kBufs; ++b) {
@@ -991,6 +1006,7 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
         return fail(c, NHDFIT_E_LIMIT, "%u NIC signatures / %u node-group sets need %u bytes of LDS per tile (160 KiB per CU)",
                     nsig, n_group_sets, L.bytes);
     { int rc_ = sync_all(c); if (rc_) return rc_; }
+    c->rec_valid = false;                               // node records depend on the mirror and on the table layout
     HIPCHK(c, c->group_sets.reserve(n_group_sets ? n_group_sets : 1));
     if (n_group_sets) HIPCHK(c, hipMemcpy(c->group_sets.p, group_sets, n_group_sets * sizeof(uint64_t), hipMemcpyHostToDevice));
     else { const uint64_t zero = 0; HIPCHK(c, hipMemcpy(c->group_sets.p, &zero, sizeof zero, hipMemcpyHostToDevice)); }
@@ -1012,8 +1028,10 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     c->P = 0;                                       // staged tables (if any) were built for the old dictionary
     HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_only<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_only<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return NHDFIT_OK;
 }
 
@@ -1021,6 +1039,7 @@ int nhdfit_reserve_nodes(nhdfit_ctx* c, uint32_t capacity, uint64_t global_base)
     if (!c) return NHDFIT_E_INVAL;
     HIPCHK(c, hipSetDevice(c->dev));
     { int rc_ = sync_all(c); if (rc_) return rc_; }
+    c->rec_valid = false;                               // node records depend on the mirror and on the table layout
     if (capacity > c->capacity) {
         c->n = 0;                                   // growing drops the contents: the caller re-uploads
         HIPCHK(c, c->p0.reserve(capacity)); HIPCHK(c, c->p1.reserve(capacity)); HIPCHK(c, c->p2.reserve(capacity));
@@ -1034,7 +1053,12 @@ int nhdfit_reserve_nodes(nhdfit_ctx* c, uint32_t capacity, uint64_t global_base)
 int nhdfit_set_node_count(nhdfit_ctx* c, uint32_t n) {
     if (!c) return NHDFIT_E_INVAL;
     if (n > c->capacity) return fail(c, NHDFIT_E_INVAL, "node count %u exceeds reserved capacity %u", n, c->capacity);
-    c->n = n;
+    if (n != c->n) {
+        HIPCHK(c, hipSetDevice(c->dev));
+        { int rc_ = sync_all(c); if (rc_) return rc_; }     // mapping phases of steps in flight still read the old count
+        c->rec_valid = false;
+        c->n = n;
+    }
     return NHDFIT_OK;
 }
 
@@ -1046,6 +1070,7 @@ int nhdfit_upload_nodes(nhdfit_ctx* c, uint32_t first, uint32_t count, const nhd
     if ((uint64_t)first + count > c->capacity) return fail(c, NHDFIT_E_INVAL, "upload [%u,%u) exceeds capacity %u", first, first + count, c->capacity);
     HIPCHK(c, hipSetDevice(c->dev));
     { int rc_ = sync_all(c); if (rc_) return rc_; }     // a step in flight must not see a half-written record
+    c->rec_valid = false;                               // node records depend on the mirror and on the table layout
     HIPCHK(c, hipMemcpy(c->p0.p + first, p0, count * sizeof *p0, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->p1.p + first, p1, count * sizeof *p1, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->p2.p + first, p2, count * sizeof *p2, hipMemcpyHostToDevice));
@@ -1062,6 +1087,7 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     if (!c->nsig) return fail(c, NHDFIT_E_STATE, "set the dictionary first");
     HIPCHK(c, hipSetDevice(c->dev));
     { int rc_ = sync_all(c); if (rc_) return rc_; }
+    c->rec_valid = false;                               // node records depend on the mirror and on the table layout
     { int rc_ = drain_events(c); if (rc_) return rc_; }
     c->n_dig = c->n_fit = c->n_shaped = c->n_chosen = c->n_finished = 0;
     const uint32_t tiles = (P + kTile - 1) / kTile;
@@ -1181,6 +1207,7 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         if (c->want_bitmap) HIPCHK(c, c->bitmap.reserve((size_t)chunks * P));
         FitArgs& f = a.fit;
         f.p0 = c->p0.p; f.p1 = c->p1.p; f.p2 = c->p2.p; f.p3 = c->p3.p; f.p4 = c->p4.p;
+        f.rec = nullptr;
         f.n = c->n; f.chunks = chunks; f.global_base = c->global_base; f.now = now;
         f.tabs = c->tabs[bf].p; f.layout = c->layout; f.hdr = c->hdr[bf].p; f.P = P;
         f.cand = c->use_cand ? c->cand.p : nullptr;
@@ -1192,6 +1219,15 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         f.chunks_per_block = cpb;
         f.nranges = (chunks + cpb - 1) / cpb;
         nb_fit = tiles * f.nranges;
+        if (c->use_node_records) {
+            if (!c->rec_valid) {                                   // mirror or layout changed since the records were built
+                HIPCHK(c, c->rec.reserve(c->capacity ? c->capacity : c->n));
+                hipLaunchKernelGGL(k_node_records, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, f, c->rec.p);
+                HIPCHK(c, hipGetLastError());
+                c->rec_valid = true;
+            }
+            f.rec = c->rec.p;
+        }
     }
     const uint32_t grid = a.nb_choose + a.nb_shapes + a.nb_finish + a.nb_digest + nb_fit;
     if (!grid) return NHDFIT_OK;
@@ -1215,8 +1251,12 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         if (big) hipLaunchKernelGGL((k_fit_only<512>), dim3(grid), dim3(512), lds, c->stream, a.fit);
         else     hipLaunchKernelGGL((k_fit_only<256>), dim3(grid), dim3(256), lds, c->stream, a.fit);
     } else
-    if (big) hipLaunchKernelGGL((k_step<512>), dim3(grid), dim3(512), lds, c->stream, a);
-    else     hipLaunchKernelGGL((k_step<256>), dim3(grid), dim3(256), lds, c->stream, a);
+    if (a.fit.rec) {
+        if (big) hipLaunchKernelGGL((k_step<512, true>), dim3(grid), dim3(512), lds, c->stream, a);
+        else     hipLaunchKernelGGL((k_step<256, true>), dim3(grid), dim3(256), lds, c->stream, a);
+    } else
+    if (big) hipLaunchKernelGGL((k_step<512, false>), dim3(grid), dim3(512), lds, c->stream, a);
+    else     hipLaunchKernelGGL((k_step<256, false>), dim3(grid), dim3(256), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));

@@ -180,6 +180,24 @@ int hh_set_isect3(const int16_t* a, int na, const int16_t* b, int nb, const int1
     return ps_list(abc, out);
 }
 
+// node records (fit_core.h): node_lane() recomputed from the precomputed record must give the same lane state
+// for every node, layout and clock.  Returns the number of nodes that differ.
+int hh_node_record_mismatches(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
+                              const nhdfit_plane4* p4, uint32_t n, uint32_t fcmax, uint32_t fgmax, uint32_t nsig, uint32_t ngs,
+                              uint32_t hp_rows, uint32_t gmax, double now) {
+    const Layout L = make_layout(fcmax, fgmax, nsig, ngs, hp_rows, gmax);
+    int bad = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const NodeLane a = node_lane(p0[i], p1[i], p2[i], p3[i], p4[i], now, L);
+        const NodeLane b = node_lane_from_record(make_node_record(p0[i], p1[i], p2[i], p3[i], p4[i], L), now, L);
+        const bool same = a.off_w0 == b.off_w0 && a.off_w1 == b.off_w1 && a.w_misc == b.w_misc && a.off_a == b.off_a &&
+                          a.off_r0n == b.off_r0n && a.off_r1n == b.off_r1n && a.off_r0p == b.off_r0p && a.off_r1p == b.off_r1p &&
+                          a.off_hp == b.off_hp && a.off_gf == b.off_gf && a.flags == b.flags && a.busy == b.busy;
+        bad += !same;
+    }
+    return bad;
+}
+
 // the register-resident model
 int hh_small_set_list(const int16_t* codes, int n, int len, int base, int16_t* out) {
     SmallSet s = ss_make(len, base);

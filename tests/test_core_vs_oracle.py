@@ -121,3 +121,36 @@ def test_register_and_generic_set_models_agree():
     a = harness.find(pk, table, reqs, spec.clock_now, force_generic=False)
     b = harness.find(pk, table, reqs, spec.clock_now, force_generic=True)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and a[2]["valid"].sum() > 100
+
+
+def test_node_records_reproduce_node_lane():
+    """The precomputed 32-byte node record (fit_core.h NodeRec, the opt-in NHDFIT_NODE_RECORDS path of the fit role)
+    expands to exactly the lane state node_lane() derives from the five planes - for heterogeneous clusters, every
+    layout size the batch can force (group count, hugepage rows) and clocks on both sides of the busy window."""
+    import ctypes
+    from nhd_amd import pack, synth
+    from tests import harness
+    L = harness.lib()
+    for cfg, n in ((3, 3000), (5, 2000), (2, 1000)):
+        spec = synth.make_cluster(cfg, n_nodes=n)
+        pk = pack.Packer()
+        t = pk.planes_from_spec(spec)
+        _caps, _so, _po, _gl, _cc, _ncls, nsig, _np, _ncc = pk.dictionary_arrays()
+        for gmax in (1, 2, 3, 4):
+            for hp_rows in (2, 10, 66):
+                for now in (spec.clock_now, spec.clock_now + 24.9, spec.clock_now + 25.1, spec.clock_now + 1e6):
+                    bad = L.hh_node_record_mismatches(
+                        harness._p(t.p0), harness._p(t.p1), harness._p(t.p2), harness._p(t.p3), harness._p(t.p4),
+                        ctypes.c_uint32(n), ctypes.c_uint32(pk.max_cores_per_numa), ctypes.c_uint32(pk.max_gpus_per_numa),
+                        ctypes.c_uint32(nsig), ctypes.c_uint32(len(pk.group_sets)), ctypes.c_uint32(hp_rows),
+                        ctypes.c_uint32(gmax), ctypes.c_double(now))
+                    assert bad == 0, (cfg, gmax, hp_rows, now, bad)
+    nl = util.random_cluster(77, 300)
+    pk = pack.Packer()
+    t = pk.pack_nodes(nl)
+    nsig = pk.dictionary_arrays()[6]
+    bad = L.hh_node_record_mismatches(harness._p(t.p0), harness._p(t.p1), harness._p(t.p2), harness._p(t.p3), harness._p(t.p4),
+                                      ctypes.c_uint32(t.n), ctypes.c_uint32(pk.max_cores_per_numa), ctypes.c_uint32(pk.max_gpus_per_numa),
+                                      ctypes.c_uint32(nsig), ctypes.c_uint32(len(pk.group_sets)), ctypes.c_uint32(18),
+                                      ctypes.c_uint32(4), ctypes.c_double(util.CLOCK))
+    assert bad == 0
