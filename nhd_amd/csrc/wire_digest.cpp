@@ -27,6 +27,14 @@
 
 namespace {
 
+// ASCII classification without the locale-aware <cctype> calls (they were 13 % of the profile)
+inline bool is_digit(char c) { return c >= '0' && c <= '9'; }
+inline bool is_alpha(char c) { return (unsigned char)((c | 32) - 'a') < 26; }
+inline bool is_alnum(char c) { return is_digit(c) || is_alpha(c); }
+inline bool is_space(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+inline bool is_xdigit(char c) { return is_digit(c) || (unsigned char)((c | 32) - 'a') < 6; }
+inline char to_lower(char c) { return (c >= 'A' && c <= 'Z') ? (char)(c | 32) : c; }
+
 struct Reject { std::string why; };      // reference returns None
 struct Raise { std::string why; };       // reference raises
 struct AttrMissing { std::string why; }; // AttributeError inside a path look-up (caught or not depends on the call site)
@@ -41,12 +49,14 @@ struct Value {
     bool b = false;
     std::string s;
     std::vector<ValuePtr> items;                                  // Array [..] / List (..)
-    std::vector<std::pair<std::string, ValuePtr>> fields;         // Group {..}, in file order
+    struct Name { const char* p; size_t n; std::string str() const { return std::string(p, n); } };   // points into the input text
+    std::vector<std::pair<Name, ValuePtr>> fields;                // Group {..}, in file order
 
     const Value* find(const std::string& key) const { return find(key.data(), key.size()); }
+    const Value* find(const char* key) const { return find(key, std::strlen(key)); }
     const Value* find(const char* key, size_t len) const {
         for (const auto& kv : fields)
-            if (kv.first.size() == len && std::memcmp(kv.first.data(), key, len) == 0) return kv.second;
+            if (kv.first.n == len && std::memcmp(kv.first.p, key, len) == 0) return kv.second;
         return nullptr;
     }
     bool has(const std::string& key) const { return find(key) != nullptr; }
@@ -95,7 +105,7 @@ private:
 
     void skip_ws() {
         for (;;) {
-            while (p_ < end_ && std::isspace((unsigned char)*p_)) ++p_;
+            while (p_ < end_ && is_space(*p_)) ++p_;
             if (p_ < end_ && *p_ == '#') { while (p_ < end_ && *p_ != '\n') ++p_; continue; }
             if (p_ + 1 < end_ && p_[0] == '/' && p_[1] == '/') { while (p_ < end_ && *p_ != '\n') ++p_; continue; }
             if (p_ + 1 < end_ && p_[0] == '/' && p_[1] == '*') {
@@ -111,8 +121,8 @@ private:
     bool peek(char c) { skip_ws(); return p_ < end_ && *p_ == c; }
     bool accept(char c) { if (peek(c)) { ++p_; return true; } return false; }
 
-    static bool name_start(char c) { return std::isalpha((unsigned char)c) || c == '*'; }
-    static bool name_char(char c) { return std::isalnum((unsigned char)c) || c == '_' || c == '-' || c == '*'; }
+    static bool name_start(char c) { return is_alpha(c) || c == '*'; }
+    static bool name_char(char c) { return is_alnum(c) || c == '_' || c == '-' || c == '*'; }
 
     void parse_settings(Value& group, bool top) {
         for (;;) {
@@ -123,15 +133,15 @@ private:
             if (!name_start(*p_)) fail("setting name expected");
             const char* b = p_;
             while (p_ < end_ && name_char(*p_)) ++p_;
-            std::string name(b, p_);
+            const Value::Name name{b, (size_t)(p_ - b)};
             skip_ws();
             if (p_ == end_ || (*p_ != '=' && *p_ != ':')) fail("'=' or ':' expected");
             ++p_;
             ValuePtr v = parse_value();
             bool replaced = false;                                               // libconf: a repeated name overwrites (dict assignment)
             for (auto& kv : group.fields)
-                if (kv.first == name) { kv.second = v; replaced = true; break; }
-            if (!replaced) group.fields.emplace_back(std::move(name), std::move(v));
+                if (kv.first.n == name.n && std::memcmp(kv.first.p, name.p, name.n) == 0) { kv.second = v; replaced = true; break; }
+            if (!replaced) group.fields.emplace_back(name, v);
             skip_ws();
             if (p_ < end_ && (*p_ == ';' || *p_ == ',')) ++p_;
         }
@@ -176,7 +186,7 @@ private:
         }
         // token classes in libconf's order, first match wins: float, hex, integer, boolean
         const char* q = p_;
-        auto digits = [&](const char* c) { while (c < end_ && std::isdigit((unsigned char)*c)) ++c; return c; };
+        auto digits = [&](const char* c) { while (c < end_ && is_digit(*c)) ++c; return c; };
         {   // float: [-+]?(\d+)?\.\d*([eE][-+]?\d+)?  |  [-+]?\d+(\.\d*)?[eE][-+]?\d+
             const char* c = q;
             if (c < end_ && (*c == '+' || *c == '-')) ++c;
@@ -198,7 +208,7 @@ private:
             }
             if (e) {
                 bool any_digit = false;
-                for (const char* z = q; z < e; ++z) any_digit = any_digit || std::isdigit((unsigned char)*z);
+                for (const char* z = q; z < e; ++z) any_digit = any_digit || is_digit(*z);
                 if (!any_digit) fail("'.' is matched as a float and is not one");    // libconf: float('.') raises
                 v->kind = Value::Float;
                 v->f = std::strtod(std::string(q, e).c_str(), nullptr);
@@ -207,9 +217,9 @@ private:
             }
         }
         auto long_suffix = [&](const char* c) { if (c < end_ && *c == 'L') { ++c; if (c < end_ && *c == 'L') ++c; } return c; };
-        if (q + 2 < end_ && q[0] == '0' && (q[1] == 'x' || q[1] == 'X') && std::isxdigit((unsigned char)q[2])) {
+        if (q + 2 < end_ && q[0] == '0' && (q[1] == 'x' || q[1] == 'X') && is_xdigit(q[2])) {
             const char* c = q + 2;
-            while (c < end_ && std::isxdigit((unsigned char)*c)) ++c;
+            while (c < end_ && is_xdigit(*c)) ++c;
             v->kind = Value::Int;
             v->i = (long long)std::strtoull(std::string(q + 2, c).c_str(), nullptr, 16);
             p_ = long_suffix(c);
@@ -230,8 +240,8 @@ private:
             const size_t len = std::strlen(word);
             if ((size_t)(end_ - q) < len) continue;
             bool same = true;
-            for (size_t k = 0; k < len; ++k) same = same && std::tolower((unsigned char)q[k]) == word[k];
-            if (same && (q + len == end_ || !(std::isalnum((unsigned char)q[len]) || q[len] == '_'))) {      // \b
+            for (size_t k = 0; k < len; ++k) same = same && to_lower(q[k]) == word[k];
+            if (same && (q + len == end_ || !(is_alnum(q[len]) || q[len] == '_'))) {      // \b
                 v->kind = Value::Bool;
                 v->b = word[0] == 't';
                 p_ = q + len;
@@ -258,7 +268,7 @@ private:
                 case '\\': out.push_back('\\'); break;
                 case '"': out.push_back('"'); break;
                 case 'x': {
-                    if (p_ + 1 >= end_ || !std::isxdigit((unsigned char)p_[0]) || !std::isxdigit((unsigned char)p_[1])) fail("bad \\x escape");
+                    if (p_ + 1 >= end_ || !is_xdigit(p_[0]) || !is_xdigit(p_[1])) fail("bad \\x escape");
                     out.push_back((char)std::strtol(std::string(p_, p_ + 2).c_str(), nullptr, 16));
                     p_ += 2;
                     break;
@@ -278,10 +288,32 @@ bool py_keyword(const char* w, size_t len) {
     static const char* kw[] = {"False", "None", "True", "and", "as", "assert", "async", "await", "break", "class", "continue",
                                "def", "del", "elif", "else", "except", "finally", "for", "from", "global", "if", "import", "in",
                                "is", "lambda", "nonlocal", "not", "or", "pass", "raise", "return", "try", "while", "with", "yield"};
+    if (len < 2 || len > 8) return false;
     for (const char* k : kw)
-        if (std::strlen(k) == len && std::memcmp(k, w, len) == 0) return true;
+        if (k[0] == w[0] && std::strncmp(k, w, len) == 0 && k[len] == 0) return true;
     return false;
 }
+
+// Paths are composed in one recycled buffer (no temporaries per look-up); valid until the next compose().
+class PathBuf {
+public:
+    PathBuf& start(const std::string& prefix) { s_.assign(prefix); return *this; }
+    PathBuf& add(const char* t) { s_.append(t); return *this; }
+    PathBuf& add(const std::string& t) { s_.append(t); return *this; }
+    PathBuf& index(size_t k) {
+        char tmp[24];
+        int n = 0;
+        do { tmp[n++] = (char)('0' + k % 10); k /= 10; } while (k);
+        s_.push_back('[');
+        while (n) s_.push_back(tmp[--n]);
+        s_.push_back(']');
+        return *this;
+    }
+    const std::string& str() const { return s_; }
+private:
+    std::string s_;
+};
+thread_local PathBuf g_path;
 
 struct PathStep { enum { Attr, Index, Key } kind; const char* name; size_t len; unsigned long idx; };   // name points into the path
 
@@ -296,9 +328,9 @@ const std::vector<PathStep>& parse_path(const std::string& path) {
     auto skip_in = [&] { while (k < n && (path[k] == ' ' || path[k] == '\t' || path[k] == '\n')) ++k; };   // inside [ ]: lines join
     auto ident = [&]() -> PathStep {
         const size_t b = k;
-        if (k < n && (std::isalpha((unsigned char)path[k]) || path[k] == '_')) {
+        if (k < n && (is_alpha(path[k]) || path[k] == '_')) {
             ++k;
-            while (k < n && (std::isalnum((unsigned char)path[k]) || path[k] == '_')) ++k;
+            while (k < n && (is_alnum(path[k]) || path[k] == '_')) ++k;
         }
         if (k == b) throw bad("name expected");
         if (py_keyword(path.data() + b, k - b)) throw bad("keyword");
@@ -335,8 +367,8 @@ const std::vector<PathStep>& parse_path(const std::string& path) {
         }
         std::string digits;
         bool prev_digit = false;
-        while (k < n && (std::isdigit((unsigned char)path[k]) || path[k] == '_')) {
-            if (path[k] == '_') { if (!prev_digit || k + 1 >= n || !std::isdigit((unsigned char)path[k + 1])) throw bad("bad integer"); prev_digit = false; }
+        while (k < n && (is_digit(path[k]) || path[k] == '_')) {
+            if (path[k] == '_') { if (!prev_digit || k + 1 >= n || !is_digit(path[k + 1])) throw bad("bad integer"); prev_digit = false; }
             else { digits.push_back(path[k]); prev_digit = true; }
             ++k;
         }
@@ -394,16 +426,16 @@ long long py_int(const Value& v) {                                         // in
             return (long long)std::trunc(v.f);
         case Value::Str: {
             size_t a = 0, b = v.s.size();
-            while (a < b && std::isspace((unsigned char)v.s[a])) ++a;
-            while (b > a && std::isspace((unsigned char)v.s[b - 1])) --b;
+            while (a < b && is_space(v.s[a])) ++a;
+            while (b > a && is_space(v.s[b - 1])) --b;
             std::string t = v.s.substr(a, b - a), digits;
             size_t k = 0;
             bool neg = false;
             if (k < t.size() && (t[k] == '+' || t[k] == '-')) { neg = t[k] == '-'; ++k; }
             bool prev_digit = false;
             for (; k < t.size(); ++k) {
-                if (std::isdigit((unsigned char)t[k])) { digits.push_back(t[k]); prev_digit = true; }
-                else if (t[k] == '_' && prev_digit && k + 1 < t.size() && std::isdigit((unsigned char)t[k + 1])) prev_digit = false;
+                if (is_digit(t[k])) { digits.push_back(t[k]); prev_digit = true; }
+                else if (t[k] == '_' && prev_digit && k + 1 < t.size() && is_digit(t[k + 1])) prev_digit = false;
                 else throw Raise{"int() of a non-numeric string"};
             }
             if (digits.empty()) throw Raise{"int() of a non-numeric string"};
@@ -514,7 +546,7 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
                     const Value& a = lookup(cfg, name);
                     if (a.kind == Value::Array) {                           // libconf: [..] -> list, (..) -> tuple
                         for (size_t e = 0; e < a.items.size(); ++e) {       // the reference looks every element up by its own path
-                            (void)py_int(lookup(cfg, name + "[" + std::to_string(e) + "]"));
+                            (void)py_int(lookup(cfg, g_path.start(name).index(e).str()));
                             pg.help++;
                         }
                     } else {
@@ -551,7 +583,7 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
                 // (f'{mattr}.{md.dp_group.name}[0].rx_cores[{gidx}]', TriadCfgParser.py:203-215)
                 const std::string dpath = mattr + "." + py_format(dp_name) + "[0].";
                 auto elem = [&](const char* field, size_t g) -> const Value& {
-                    return lookup(cfg, dpath + field + "[" + std::to_string(g) + "]");
+                    return lookup(cfg, g_path.start(dpath).add(field).index(g).str());
                 };
                 try {
                     const size_t n = py_len(rxc);
@@ -589,7 +621,7 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
                 }
                 for (const auto& cl : cores) {
                     for (size_t g : cl) {                                     // the GPU's feeder cores count as proc cores
-                        (void)py_int(lookup(cfg, dpath + "gpu_map[" + std::to_string(g) + "][0]"));
+                        (void)py_int(lookup(cfg, g_path.start(dpath).add("gpu_map").index(g).add("[0]").str()));
                         pg.proc++;
                     }
                     pg.gpus++;
@@ -615,7 +647,7 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
                 pg.proc_smt = truthy(*nc.items[4]);
                 const size_t n = py_len(*rxc);
                 auto elem = [&](size_t which, size_t g) -> const Value& {     // f'{mattr}.{md.nic_cores[which]}[{g}]', looked up afresh
-                    return lookup(cfg, mattr + "." + nc.items[which]->s + "[" + std::to_string(g) + "]");
+                    return lookup(cfg, g_path.start(mattr).add(".").add(nc.items[which]->s).index(g).str());
                 };
                 for (size_t g = 0; g < n; ++g) {
                     const double rs = speed_of(elem(1, g), bad_speed);
@@ -669,7 +701,7 @@ void digest(const char* text, size_t len, nhdfit_req& r) {
         } else if (ext.kind == Value::Str) {
             for (char ch : ext.s) one(std::string(1, ch));
         } else if (ext.kind == Value::Group) {
-            for (const auto& kv : ext.fields) one(kv.first);
+            for (const auto& kv : ext.fields) one(kv.first.str());
         } else {
             throw Raise{"ext_cores is not iterable"};
         }
