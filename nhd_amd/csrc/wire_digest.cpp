@@ -336,7 +336,21 @@ const std::vector<PathStep>& parse_path(const std::string& path) {
         if (py_keyword(path.data() + b, k - b)) throw bad("keyword");
         return PathStep{PathStep::Attr, path.data() + b, k - b, 0};
     };
-    if (n == 0 || path[0] == ' ' || path[0] == '\t' || path[0] == '\n') throw bad("empty or indented expression");
+    // blank lines (also whitespace-only ones) before the expression are fine; an indented first line is not
+    for (;;) {
+        size_t e = k;
+        while (e < n && (path[e] == ' ' || path[e] == '\t')) ++e;
+        if (e < n && path[e] == '\n') { k = e + 1; continue; }
+        if (e < n && path[e] == '#') {                                       // a comment line, indented or not
+            while (e < n && path[e] != '\n') ++e;
+            if (e == n) throw bad("empty expression");
+            k = e + 1;
+            continue;
+        }
+        if (e == n) throw bad("empty expression");
+        if (e != k) throw bad("indented expression");
+        break;
+    }
     steps.push_back(ident());
     for (;;) {
         skip();
