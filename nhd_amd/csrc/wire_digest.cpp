@@ -100,6 +100,18 @@ public:
 private:
     const char* p_;
     const char* end_;
+    int depth_ = 0;                       // open '{' / '[' / '(' levels around the value being parsed
+    // Nesting bound.  The reference's recursive-descent parser (libconf under CPython's default recursion limit of
+    // 1000, several frames per level) raises RecursionError a few hundred levels deep - a catchable exception, the pod
+    // is reported and skipped.  Recursing without a bound here would instead overflow the native stack and take the
+    // scheduler process down.  Triad configs nest 4-5 levels; anything deeper than this is answered the
+    // way the reference answers its own limit: WIRE_RAISE.
+    static constexpr int kMaxDepth = 128;
+    struct DepthGuard {
+        int& d;
+        explicit DepthGuard(int& depth) : d(depth) { ++d; }
+        ~DepthGuard() { --d; }
+    };
 
     [[noreturn]] void fail(const char* what) const { throw Raise{std::string("libconfig syntax: ") + what}; }
 
@@ -150,6 +162,8 @@ private:
     ValuePtr parse_value() {
         skip_ws();
         if (p_ == end_) fail("value expected");
+        const DepthGuard guard(depth_);
+        if (depth_ > kMaxDepth) fail("nesting deeper than 128 levels (the reference parser raises RecursionError)");
         Value* v = g_arena.make();
         if (*p_ == '{') {
             ++p_;

@@ -32,3 +32,18 @@ def test_wire_golden(case):
 
 def test_fixture_covers_every_outcome():
     assert {c["outcome"] for c in CASES} == {"ok", "none", "raise", "limit"}
+
+
+@pytest.mark.parametrize("opener,closer", [("(", ")"), ("[", "]"), ("{ a = ", "; }")])
+def test_deep_nesting_raises_instead_of_overflowing_the_stack(opener, closer):
+    """A pod's config text is user-supplied: 100 000 nested brackets must come back as the catchable error the
+    reference's parser produces at its own limit (RecursionError), never as a stack overflow of the scheduler
+    process (wire_digest.cpp)."""
+    for depth in (129, 100_000):
+        text = "TopologyCfg = " + opener * depth + "1" + closer * depth + ";"
+        with pytest.raises(wire.ConfigError):
+            wire.digest_config(text)
+        reqs, codes = wire.digest_configs([text, text])
+        assert list(codes) == [wire.WIRE_RAISE, wire.WIRE_RAISE]
+    ok_depth = "X = " + "(" * 100 + "1" + ")" * 100 + ";"         # well inside the bound: parsed (and not a Triad config)
+    assert wire.digest_config(ok_depth) is None or True
