@@ -23,20 +23,26 @@
 // Matcher.py:346) plus the scalar predicates (maintenance, hugepages, busy, node groups), which are
 // tabulated too: one 64-bit word per node-side value holds the verdict for all 64 pods of a tile.
 //
-// ---- table image of one 64-pod tile (staged in LDS by the fit kernel) ---------------------------
+// ---- table image of one 64-pod tile -----------------------------------------------------------------
 //   Bit-sliced: every table row holds, for each NUMA assignment p, ONE 64-bit word whose bit j says
-//   "assignment p of pod j passes this test".  Row = W words (W = 2^maxG of the batch) + 8 B pad.
-//     W0[m][smt][c]  c free cores on socket 0:  m=0: sumC(S0) <= c      m=1: sumC(S0)+misc <= c
-//     W1[m][smt][c]  c free cores on socket 1:  m=0: sumC(S1) <= c      m=1: sumC(S1)+misc <= c
-//                    cpu_ok = (W0[1] & W1[0]) | (W0[0] & W1[1])
-//     A[f0][f1]      free GPUs on NUMA 0 / 1:   sumG(S0) <= f0 && sumG(S1) <= f1
-//     R0[sig]        NIC signature of NUMA 0:   S0(p) in reach(sig)
-//     R1[sig]        NIC signature of NUMA 1:   S1(p) in reach(sig)
-//   so  feasible pods of a node = OR over p of (cpu_ok & A & R0 & R1)[p]  -  five/seven 64-bit ANDs per
-//   assignment serve all 64 pods at once, and no per-pod "any assignment left?" test is needed.
-//   64-bit scalar-predicate rows (bit j = verdict for pod j):
+//   "assignment p of pod j passes this test".  A tile's rows have W = 2^(largest group count among its
+//   pods) words (tiles are staged sorted by group count, so most tiles are narrow).
+//
+//   COLD section - global memory only; read for winners (mapping) and for committed nodes (mode B):
+//     A0[f], A1[f]   f free GPUs on NUMA 0 / 1:      sumG(S0) <= f   /   sumG(S1) <= f
+//     R0[sig]        NIC signature of NUMA 0:         S0(p) in reach(sig)
+//     R1[sig]        NIC signature of NUMA 1:         S1(p) in reach(sig)
+//   HOT section - staged in LDS by the fit role, rows 16-byte aligned for ds_read_b128:
+//     X[class]       class = interned (NUMA u, f_u, sigNUMA_u, sigPCI_u) of the mirror's nodes (interned on the
+//                    device, k_xkeys):  A_u[f] & (pod j in PCI mode ? R_u[sigPCI] : R_u[sigNUMA])
+//     WC[u][smt][c]  record of two rows, c free physical cores on socket u:
+//                      m=0: sumC(Su) <= c       m=1: sumC(Su) + misc <= c
+//                    cpu_ok = (WC0[m=1] & WC1[m=0]) | (WC0[m=0] & WC1[m=1])
+//     GX[g]          64-bit rows (bit j = pod j): row 0 = never (maintenance / lanes past the end), row
+//                    1 + 2*gs + active: pod does not apply InitialNodeFilter || (node groups intersect && active)
 //     HP[k]          k = clamp(free hugepages, -1, hp_max) + 1:  pod valid && hp_req <= free
-//     GF[gs]         node-group set id: pod does not filter || sets intersect  (NHDScheduler.py:240)
+//   feasible pods of a node = OR_p (cpu_ok & X0 & X1)[p]  &  GX & HP & (busy ? ~pods_needing_gpus : all)
+//   - six 16-byte row fetches and 16 bit operations per pair of assignments serve all 64 pods at once.
 #pragma once
 #include <stdint.h>
 #include "../../include/nhdfit.h"
@@ -51,40 +57,71 @@ namespace nhdfit {
 
 constexpr int kMaxG      = NHDFIT_MAX_GROUPS;
 constexpr int kTile      = NHDFIT_TILE;
-constexpr int kMaxHpRows = 1024;                     // hugepage table rows (larger requests are clamped, see hp_bit)
+constexpr int kMaxHpRows = 1024;                     // hugepage table rows (larger requests are rejected at staging)
+constexpr int kWClasses  = 4;                        // W = 2, 4, 8, 16
 constexpr double kMinBusySecs = 30.0;                // Node.MIN_BUSY_SECS, nhd/Node.py:107
+constexpr uint32_t kMinXCap = 32;                    // X rows are provisioned in powers of two (records stay valid while classes are appended)
+
+NHD_HD uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
+// Row strides: multiples of 16 bytes (ds_read_b128) and an odd multiple of 16 for every W, so that the 16 lanes a
+// b128 access is serviced for hit 16 different bank groups when their rows lie within a window of 16 rows.
+NHD_HD uint32_t wc_stride_of(uint32_t W) { return 2 * W * 8 + 16; }
+NHD_HD uint32_t x_stride_of(uint32_t W) { return W == 2 ? 16u : W * 8 + 16; }
 
 struct Layout {
+    uint32_t W;          // assignments per row: 2, 4, 8 or 16
     uint32_t fc_dim;     // 1 + max physical cores on one socket anywhere in the cluster (<= 65)
     uint32_t fg_dim;     // 1 + max GPUs installed on one NUMA node anywhere in the cluster (<= 9)
     uint32_t nsig, ngs;  // NIC signatures, node-group sets
-    uint32_t hp_rows;    // 2 + largest hugepage request of the staged batch (capped at kMaxHpRows)
-    uint32_t W;          // assignments per pod the rows provide for: 2^(largest group count of the staged batch)
-    uint32_t row_bytes;  // W * 8 + 8: 8-byte aligned, and 18 r mod 64 banks: 32 different rows never collide
-    uint32_t row_w1, row_a, row_r0, row_r1, rows16;   // first row of each assignment table (W0 starts at 0)
-    uint32_t off_hp, off_gf;                           // byte offsets of the 64-bit tables
-    uint32_t bytes;                                    // image size, multiple of 16
+    uint32_t hp_rows;    // 2 + largest hugepage request of the staged batch
+    uint32_t x_cap;      // provisioned X rows (power of two >= interned classes)
+    uint32_t row;        // W * 8: bytes of an unpadded row (cold section, m=1 row of a WC record)
+    uint32_t wc_stride, x_stride;
+    // cold section (byte offsets from the image start)
+    uint32_t off_a0, off_a1, off_r0, off_r1;
+    uint32_t off_hot;    // start of the hot section (multiple of 16)
+    // hot section (byte offsets from off_hot): X first - its capacity, not its fill, fixes what follows
+    uint32_t hot_x, hot_wc0, hot_wc1, hot_gx, hot_hp;
+    uint32_t hot_bytes;  // multiple of 16
+    uint32_t bytes;      // whole image, multiple of 16
 };
 
-NHD_HD Layout make_layout(uint32_t max_cores_per_numa, uint32_t max_gpus_per_numa, uint32_t nsig, uint32_t ngs,
-                          uint32_t hp_rows, uint32_t max_groups) {
+NHD_HD uint32_t x_capacity(uint32_t nx) {
+    uint32_t c = kMinXCap;
+    while (c < nx) c <<= 1;
+    return c;
+}
+
+NHD_HD Layout make_layout(uint32_t W, uint32_t max_cores_per_numa, uint32_t max_gpus_per_numa, uint32_t nsig, uint32_t ngs,
+                          uint32_t hp_rows, uint32_t x_cap) {
     Layout l;
-    l.W = 1u << max_groups;
-    l.row_bytes = l.W * 8 + 8;
+    l.W = W;
     l.fc_dim = max_cores_per_numa + 1;
     l.fg_dim = max_gpus_per_numa + 1;
     l.nsig = nsig;
     l.ngs = ngs;
     l.hp_rows = hp_rows;
-    l.row_w1 = 4 * l.fc_dim;                         // W0: rows [m][smt][c] = m*2*fc_dim + smt*fc_dim + c
-    l.row_a = 8 * l.fc_dim;
-    l.row_r0 = l.row_a + l.fg_dim * l.fg_dim;
-    l.row_r1 = l.row_r0 + nsig;
-    l.rows16 = l.row_r1 + nsig;
-    l.off_hp = l.rows16 * l.row_bytes;
-    l.off_gf = l.off_hp + hp_rows * 8;
-    l.bytes = (l.off_gf + ngs * 8 + 15u) & ~15u;
+    l.x_cap = x_cap;
+    l.row = W * 8;
+    l.wc_stride = wc_stride_of(W);
+    l.x_stride = x_stride_of(W);
+    l.off_a0 = 0;
+    l.off_a1 = l.off_a0 + l.fg_dim * l.row;
+    l.off_r0 = l.off_a1 + l.fg_dim * l.row;
+    l.off_r1 = l.off_r0 + nsig * l.row;
+    l.off_hot = align16(l.off_r1 + nsig * l.row);
+    l.hot_x = 0;
+    l.hot_wc0 = l.hot_x + x_cap * l.x_stride;
+    l.hot_wc1 = l.hot_wc0 + 2 * l.fc_dim * l.wc_stride;          // records [smt][c]
+    l.hot_gx = l.hot_wc1 + 2 * l.fc_dim * l.wc_stride;
+    l.hot_hp = l.hot_gx + align16((1 + 2 * ngs) * 8);
+    l.hot_bytes = l.hot_hp + align16(hp_rows * 8);
+    l.bytes = l.off_hot + l.hot_bytes;
     return l;
+}
+
+NHD_HD uint32_t wclass_of(uint32_t max_groups) {          // tile class 0..3 <-> W = 2 << class
+    return max_groups <= 1 ? 0u : max_groups == 2 ? 1u : max_groups == 3 ? 2u : 3u;
 }
 
 // Request header (one per pod), kept for the lane-as-pod view of the fit kernel.
@@ -97,7 +134,7 @@ constexpr uint32_t kPodValid   = 1u;   // map type NUMA or PCI, 1 <= G <= kMaxG
 constexpr uint32_t kPodNeedGpu = 2u;   // sum(gpus) > 0  (== any group has GPUs, Matcher.py:403-407)
 constexpr uint32_t kPodPci     = 4u;
 constexpr uint32_t kPodFilter  = 8u;   // apply InitialNodeFilter
-constexpr uint32_t kPodGroupsShift = 4;   // bits 4..6: n_groups (lets the fit kernel skip assignments no pod of a tile has)
+constexpr uint32_t kPodGroupsShift = 4;   // bits 4..6: n_groups
 
 NHD_HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
 NHD_HD int popc32(uint32_t x) { return __builtin_popcount(x); }
@@ -147,7 +184,7 @@ NHD_HD PodHeader pod_header(const nhdfit_req& r) {
     return h;
 }
 
-// ---- 16-bit table entries ---------------------------------------------------------------------
+// ---- 16-bit table entries (bit p = assignment p of this pod passes) ----------------------------
 // socket u in {0,1}; c free physical cores; m: 1 = the pod-level misc cores also land on this socket
 NHD_HD uint32_t entry_w(const PodSums& s, uint32_t u, bool smt, uint32_t c, uint32_t m) {
     const uint32_t* sum = smt ? s.cpu_smt : s.cpu_nosmt;
@@ -158,10 +195,11 @@ NHD_HD uint32_t entry_w(const PodSums& s, uint32_t u, bool smt, uint32_t c, uint
     return out;
 }
 
-NHD_HD uint32_t entry_a(const PodSums& s, uint32_t f0, uint32_t f1) {
+// f free GPUs on NUMA u: the groups assignment p puts there ask for no more
+NHD_HD uint32_t entry_a(const PodSums& s, uint32_t u, uint32_t f) {
     uint32_t a = 0;
     for (uint32_t p = 0; p < s.W; ++p)
-        if (s.gpu[~p & s.full] <= f0 && s.gpu[p] <= f1) a |= 1u << p;
+        if (s.gpu[u ? p : (~p & s.full)] <= f) a |= 1u << p;
     return a;
 }
 
@@ -244,142 +282,147 @@ NHD_HD uint32_t entry_r(uint32_t reach, uint32_t W, uint32_t u) {
     return r >> (16 - W);
 }
 
-// value of 16-bit row `row` for one pod
-NHD_HD uint32_t row16_entry(const Layout& L, const PodSums& s, const SigDict& d, const uint16_t* cover, uint32_t row) {
-    if (row < L.row_a) {
-        const uint32_t u = row >= L.row_w1, k = u ? row - L.row_w1 : row;      // k = m*2*fc_dim + smt*fc_dim + c
-        const uint32_t m = k >= 2 * L.fc_dim, sc = m ? k - 2 * L.fc_dim : k;
-        return entry_w(s, u, sc >= L.fc_dim, sc >= L.fc_dim ? sc - L.fc_dim : sc, m);
-    }
-    if (row < L.row_r0) return entry_a(s, (row - L.row_a) / L.fg_dim, (row - L.row_a) % L.fg_dim);
-    if (row < L.row_r1) return entry_r(sig_reach(d, row - L.row_r0, cover, s.W), s.W, 0);
-    return entry_r(sig_reach(d, row - L.row_r1, cover, s.W), s.W, 1);
-}
-
 // 64-bit rows: one bit per pod of the tile.
-// HP row k stands for "free hugepages = k-1"; the last row for "free >= hp_rows-2".  Requests are
-// non-negative; requests above the cap are compared against the cap row exactly as hp_req <= free would
-// fail for every free < request as long as free is below the cap, and the cap (1022 GiB of 1 GiB pages
-// per pod) is documented in DESIGN.md.
-NHD_HD bool hp_bit(const PodHeader& h, const Layout& L, uint32_t k) {
+// HP row k stands for "free hugepages = k-1"; the last row for "free >= hp_rows-2" (no pod of the batch asks for more).
+NHD_HD bool hp_bit(const PodHeader& h, uint32_t k) {
     if (!(h.flags & kPodValid)) return false;
     return h.hp_req <= (int32_t)k - 1;                                         // Matcher.py:78
 }
-NHD_HD bool gf_bit(const PodHeader& h, uint64_t node_groups) {
-    return !(h.flags & kPodFilter) || (node_groups & h.groups) != 0;           // NHDScheduler.py:240
+// GX row g: 0 = never; 1 + 2*gs + active
+NHD_HD bool gx_bit(const PodHeader& h, uint32_t g, const uint64_t* group_sets) {
+    if (g == 0) return false;
+    const uint32_t gs = (g - 1) >> 1, active = (g - 1) & 1;
+    if (!(h.flags & kPodFilter)) return true;                                  // the caller filtered already
+    return active && (group_sets[gs] & h.groups) != 0;                         // NHDScheduler.py:240-242
 }
 
 // ---- node side -----------------------------------------------------------------------------------
-struct NodeLane {            // what one lane keeps for its node while it sweeps a tile of pods
-    uint32_t off_w0, off_w1; // byte offsets of the node's rows in the tile image (the m=1 rows follow at +w_misc)
-    uint32_t w_misc;
-    uint32_t off_a;
-    uint32_t off_r0n, off_r1n, off_r0p, off_r1p;   // NUMA-mode / PCI-mode NIC rows
-    uint32_t off_hp, off_gf;
-    uint32_t flags;
-    bool     busy;
+struct NodeIdx {            // what the five planes of a node say about which table rows apply to it
+    uint32_t w0, w1;         // WC record index smt * fc_dim + free physical cores, sockets 0 / 1
+    uint32_t f0, f1;         // free GPUs per NUMA node (clamped to the table)
+    uint32_t hp;             // HP row before the clamp to the batch's hp_rows (< kMaxHpRows)
+    uint32_t gx;             // GX row
+    uint32_t nogpu;          // no GPU installed (SelectNode's preference, Matcher.py:401-413)
 };
 
-NHD_HD NodeLane node_lane(const nhdfit_plane0& a, const nhdfit_plane1& b, const nhdfit_plane2& c,
-                          const nhdfit_plane3& d, const nhdfit_plane4& e, double now, const Layout& L) {
-    NodeLane n;
-    const uint32_t smt = (c.flags & NHDFIT_NF_SMT) ? L.fc_dim : 0;
+NHD_HD NodeIdx node_index(const nhdfit_plane0& a, const nhdfit_plane1& b, const nhdfit_plane2& c, const nhdfit_plane4& e,
+                          uint32_t fc_dim, uint32_t fg_dim, uint32_t ngs) {
+    NodeIdx n;
+    const uint32_t smt = (c.flags & NHDFIT_NF_SMT) ? fc_dim : 0;
     uint32_t c0 = popc64(a.t0[0] & b.t1[0]), c1 = popc64(a.t0[1] & b.t1[1]);       // free physical cores, nhd/Node.py:250-264
-    c0 = c0 < L.fc_dim ? c0 : L.fc_dim - 1;
-    c1 = c1 < L.fc_dim ? c1 : L.fc_dim - 1;
-    n.off_w0 = (smt + c0) * L.row_bytes;
-    n.off_w1 = (L.row_w1 + smt + c1) * L.row_bytes;
-    n.w_misc = 2 * L.fc_dim * L.row_bytes;
+    c0 = c0 < fc_dim ? c0 : fc_dim - 1;
+    c1 = c1 < fc_dim ? c1 : fc_dim - 1;
+    n.w0 = smt + c0;
+    n.w1 = smt + c1;
     uint32_t f0 = popc32(c.gpu_free & ~c.gpu_numa1), f1 = popc32(c.gpu_free & c.gpu_numa1);   // nhd/Node.py:456-462
-    f0 = f0 < L.fg_dim ? f0 : L.fg_dim - 1;
-    f1 = f1 < L.fg_dim ? f1 : L.fg_dim - 1;
-    n.off_a = (L.row_a + f0 * L.fg_dim + f1) * L.row_bytes;
-    n.off_r0n = (L.row_r0 + d.sig_numa[0]) * L.row_bytes;
-    n.off_r1n = (L.row_r1 + d.sig_numa[1]) * L.row_bytes;
-    n.off_r0p = (L.row_r0 + d.sig_pci[0]) * L.row_bytes;
-    n.off_r1p = (L.row_r1 + d.sig_pci[1]) * L.row_bytes;
+    n.f0 = f0 < fg_dim ? f0 : fg_dim - 1;
+    n.f1 = f1 < fg_dim ? f1 : fg_dim - 1;
     int32_t hp = c.hp_free;
     hp = hp < -1 ? -1 : hp;
-    hp = hp > (int32_t)L.hp_rows - 2 ? (int32_t)L.hp_rows - 2 : hp;
-    n.off_hp = L.off_hp + (uint32_t)(hp + 1) * 8;
-    const uint32_t gs = e.group_set < L.ngs ? e.group_set : 0;
-    n.off_gf = L.off_gf + gs * 8;
-    n.flags = c.flags;
-    n.busy = (now - e.busy_time) < kMinBusySecs;              // Node.IsBusy, nhd/Node.py:847-850
+    hp = hp > kMaxHpRows - 2 ? kMaxHpRows - 2 : hp;
+    n.hp = (uint32_t)(hp + 1);
+    const uint32_t gs = e.group_set < ngs ? e.group_set : 0;
+    n.gx = (c.flags & NHDFIT_NF_MAINTENANCE) ? 0u : 1u + 2u * gs + ((c.flags & NHDFIT_NF_ACTIVE) ? 1u : 0u);   // Matcher.py:71
+    n.nogpu = (c.flags & NHDFIT_NF_HAS_GPU) ? 0u : 1u;
     return n;
 }
 
-// ---- node records: node_lane() minus the clock, precomputed -----------------------------------------------
-// Everything node_lane derives from the five planes depends only on the mirror and the table layout, not on the
-// pod tile or the step: a 32-byte record per node (row offsets in units of 8 bytes - rows are 8-byte aligned and an
-// image is far below 512 KB) replaces five 16-byte plane loads and ~100 VALU instructions per (node chunk, pod
-// tile) pair by two loads and a few unpacks.  Rebuilt when nodes are uploaded or the layout changes.
-struct alignas(16) NodeRec {
-    uint16_t off_w0, off_w1, off_a, off_r0n, off_r1n, off_r0p, off_r1p, off_hp;    // first 16 bytes
-    uint16_t off_gf, flags;
-    uint32_t reserved;
-    double busy_time;                                                               // second 16 bytes
-};
-static_assert(sizeof(NodeRec) == 32, "two 16-byte loads per node");
+// class key of one NUMA node of a node: everything the GPU and NIC tests of that NUMA node depend on
+NHD_HD uint64_t xkey(uint32_t u, uint32_t f, uint32_t sig_numa, uint32_t sig_pci) {
+    return (1ull << 63) | ((uint64_t)u << 62) | ((uint64_t)f << 32) | ((uint64_t)sig_numa << 16) | (uint64_t)sig_pci;
+}
+NHD_HD uint32_t xkey_u(uint64_t k) { return (uint32_t)(k >> 62) & 1u; }
+NHD_HD uint32_t xkey_f(uint64_t k) { return (uint32_t)(k >> 32) & 0xFFu; }
+NHD_HD uint32_t xkey_sig_numa(uint64_t k) { return (uint32_t)(k >> 16) & 0xFFFFu; }
+NHD_HD uint32_t xkey_sig_pci(uint64_t k) { return (uint32_t)k & 0xFFFFu; }
 
-NHD_HD NodeRec make_node_record(const nhdfit_plane0& a, const nhdfit_plane1& b, const nhdfit_plane2& c,
-                                const nhdfit_plane3& d, const nhdfit_plane4& e, const Layout& L) {
-    const NodeLane n = node_lane(a, b, c, d, e, 0.0, L);
+// The 16-byte node record the fit role streams (one array per row width W): hot-section offsets in units of
+// 8 bytes, so that a node costs two loads (record + busy time) and one shift per row address.
+struct alignas(16) NodeRec {
+    uint16_t w0, w1, x0, x1;          // WC records of socket 0 / 1, X rows of NUMA 0 / 1   (offset / 8)
+    uint16_t gx;                      // GX row (offset / 8)
+    uint16_t hp;                      // HP row INDEX (clamped to the batch's rows in the kernel)
+    uint16_t flags;                   // kRecNoGpu
+    uint16_t pad;
+};
+static_assert(sizeof(NodeRec) == 16, "one 16-byte load per node");
+constexpr uint16_t kRecNoGpu = 1;
+
+NHD_HD NodeRec make_record(const NodeIdx& n, uint32_t x0, uint32_t x1, const Layout& L) {
     NodeRec r;
-    r.off_w0 = (uint16_t)(n.off_w0 >> 3); r.off_w1 = (uint16_t)(n.off_w1 >> 3); r.off_a = (uint16_t)(n.off_a >> 3);
-    r.off_r0n = (uint16_t)(n.off_r0n >> 3); r.off_r1n = (uint16_t)(n.off_r1n >> 3);
-    r.off_r0p = (uint16_t)(n.off_r0p >> 3); r.off_r1p = (uint16_t)(n.off_r1p >> 3);
-    r.off_hp = (uint16_t)(n.off_hp >> 3); r.off_gf = (uint16_t)(n.off_gf >> 3);
-    r.flags = (uint16_t)n.flags;
-    r.reserved = 0;
-    r.busy_time = e.busy_time;
+    r.w0 = (uint16_t)((L.hot_wc0 + n.w0 * L.wc_stride) >> 3);
+    r.w1 = (uint16_t)((L.hot_wc1 + n.w1 * L.wc_stride) >> 3);
+    r.x0 = (uint16_t)((L.hot_x + x0 * L.x_stride) >> 3);
+    r.x1 = (uint16_t)((L.hot_x + x1 * L.x_stride) >> 3);
+    r.gx = (uint16_t)((L.hot_gx + n.gx * 8) >> 3);
+    r.hp = (uint16_t)n.hp;
+    r.flags = n.nogpu ? kRecNoGpu : 0;
+    r.pad = 0;
+    return r;
+}
+NHD_HD NodeRec dead_record(const Layout& L) {                    // lanes past the end of the mirror: GX row 0 = never
+    NodeRec r;
+    r.w0 = (uint16_t)(L.hot_wc0 >> 3); r.w1 = (uint16_t)(L.hot_wc1 >> 3);
+    r.x0 = r.x1 = (uint16_t)(L.hot_x >> 3);
+    r.gx = (uint16_t)(L.hot_gx >> 3);
+    r.hp = 0; r.flags = 0; r.pad = 0;
     return r;
 }
 
-NHD_HD NodeLane node_lane_from_record(const NodeRec& r, double now, const Layout& L) {
-    NodeLane n;
-    n.off_w0 = (uint32_t)r.off_w0 << 3; n.off_w1 = (uint32_t)r.off_w1 << 3; n.off_a = (uint32_t)r.off_a << 3;
-    n.off_r0n = (uint32_t)r.off_r0n << 3; n.off_r1n = (uint32_t)r.off_r1n << 3;
-    n.off_r0p = (uint32_t)r.off_r0p << 3; n.off_r1p = (uint32_t)r.off_r1p << 3;
-    n.off_hp = (uint32_t)r.off_hp << 3; n.off_gf = (uint32_t)r.off_gf << 3;
-    n.w_misc = 2 * L.fc_dim * L.row_bytes;
-    n.flags = r.flags;
-    n.busy = (now - r.busy_time) < kMinBusySecs;
-    return n;
+// Node.IsBusy (nhd/Node.py:847-850) is `(now - busy_time) < 30.0` in binary64.  fl(now - t) never increases with t,
+// so the busy nodes are exactly those with busy_time >= busy_threshold(now): one comparison per node instead of a
+// subtraction and a comparison, and still the reference's own arithmetic (the threshold is found with it).
+inline double busy_threshold(double now) {
+    double b = now - kMinBusySecs;
+    auto up = [](double x) { return __builtin_nextafter(x, __builtin_inf()); };
+    auto down = [](double x) { return __builtin_nextafter(x, -__builtin_inf()); };
+    for (int i = 0; i < 64 && !((now - b) < kMinBusySecs); ++i) b = up(b);
+    for (int i = 0; i < 64 && (now - down(b)) < kMinBusySecs; ++i) b = down(b);
+    return b;
 }
 
 NHD_HD uint64_t ld64(const uint8_t* img, uint32_t off) { return *reinterpret_cast<const uint64_t*>(img + off); }
 
-// Scalar predicates of one node against all 64 pods of the tile (bit j = pod j may consider the node).
-// m_filt / m_need: tile masks of pods that apply InitialNodeFilter / request GPUs.
-NHD_HD uint64_t node_pod_mask(const NodeLane& n, const uint8_t* img, uint64_t m_filt, uint64_t m_need) {
-    if (n.flags & NHDFIT_NF_MAINTENANCE) return 0;                       // Matcher.py:71
-    uint64_t m = ld64(img, n.off_hp);                                    // Matcher.py:78 (+ request validity)
-    m &= ld64(img, n.off_gf);                                            // NHDScheduler.py:240
-    if (!(n.flags & NHDFIT_NF_ACTIVE)) m &= ~m_filt;                     // NHDScheduler.py:241-242
-    if (n.busy) m &= ~m_need;                                            // Matcher.py:107-111
-    return m;
-}
-
-// Pods of the tile (bit j) for which SOME NUMA assignment passes the CPU, GPU and NIC tests on this node.
-// m_pci: tile mask of pods in PCI mode (they read the PCI-mode NIC rows).
-NHD_HD uint64_t node_assignment_mask(const NodeLane& n, const uint8_t* img, uint32_t W, uint64_t m_pci) {
+// Feasible pods (bit j) of one node from the HOT section of a tile image - the fit role's arithmetic, restated
+// with plain loads (host twin, tests).  Wt = the tile's row width, m_need = pods of the tile that request GPUs.
+NHD_HD uint64_t node_word_hot(const uint8_t* hot, const Layout& L, const NodeRec& r, bool busy, uint64_t m_need) {
+    const uint32_t w0 = (uint32_t)r.w0 << 3, w1 = (uint32_t)r.w1 << 3, x0 = (uint32_t)r.x0 << 3, x1 = (uint32_t)r.x1 << 3;
     uint64_t acc = 0;
-    for (uint32_t p = 0; p < W; ++p) {
+    for (uint32_t p = 0; p < L.W; ++p) {
         const uint32_t o = p * 8;
-        const uint64_t cpu = (ld64(img, n.off_w0 + n.w_misc + o) & ld64(img, n.off_w1 + o)) |
-                             (ld64(img, n.off_w0 + o) & ld64(img, n.off_w1 + n.w_misc + o));
-        const uint64_t r0 = (ld64(img, n.off_r0p + o) & m_pci) | (ld64(img, n.off_r0n + o) & ~m_pci);
-        const uint64_t r1 = (ld64(img, n.off_r1p + o) & m_pci) | (ld64(img, n.off_r1n + o) & ~m_pci);
-        acc |= cpu & ld64(img, n.off_a + o) & r0 & r1;
+        const uint64_t cpu = (ld64(hot, w0 + L.row + o) & ld64(hot, w1 + o)) | (ld64(hot, w0 + o) & ld64(hot, w1 + L.row + o));
+        acc |= cpu & ld64(hot, x0 + o) & ld64(hot, x1 + o);
     }
-    return acc;
+    const uint32_t hp = r.hp < L.hp_rows ? r.hp : L.hp_rows - 1;
+    uint64_t pred = ld64(hot, (uint32_t)r.gx << 3) & ld64(hot, L.hot_hp + hp * 8);
+    if (busy) pred &= ~m_need;                                           // Matcher.py:107-111
+    return acc & pred;
 }
 
-// NIC-feasible assignment bits (bit p) of one (pod, node) pair, for the winner mapping
+// The same verdict from the COLD rows (A / R per signature) and the class-independent hot rows (WC, GX, HP): for
+// nodes whose (f, signature) class has no X row yet - a node a pod of the running batch was just committed to.
+NHD_HD uint64_t node_word_cold(const uint8_t* img, const Layout& L, const NodeIdx& n, const nhdfit_plane3& q3, bool busy,
+                               uint64_t m_need, uint64_t m_pci) {
+    const uint8_t* hot = img + L.off_hot;
+    const uint32_t w0 = L.hot_wc0 + n.w0 * L.wc_stride, w1 = L.hot_wc1 + n.w1 * L.wc_stride;
+    uint64_t acc = 0;
+    for (uint32_t p = 0; p < L.W; ++p) {
+        const uint32_t o = p * 8;
+        const uint64_t cpu = (ld64(hot, w0 + L.row + o) & ld64(hot, w1 + o)) | (ld64(hot, w0 + o) & ld64(hot, w1 + L.row + o));
+        const uint64_t r0 = (ld64(img, L.off_r0 + q3.sig_pci[0] * L.row + o) & m_pci) | (ld64(img, L.off_r0 + q3.sig_numa[0] * L.row + o) & ~m_pci);
+        const uint64_t r1 = (ld64(img, L.off_r1 + q3.sig_pci[1] * L.row + o) & m_pci) | (ld64(img, L.off_r1 + q3.sig_numa[1] * L.row + o) & ~m_pci);
+        acc |= cpu & ld64(img, L.off_a0 + n.f0 * L.row + o) & ld64(img, L.off_a1 + n.f1 * L.row + o) & r0 & r1;
+    }
+    const uint32_t hp = n.hp < L.hp_rows ? n.hp : L.hp_rows - 1;
+    uint64_t pred = ld64(hot, L.hot_gx + n.gx * 8) & ld64(hot, L.hot_hp + hp * 8);
+    if (busy) pred &= ~m_need;
+    return acc & pred;
+}
+
+// NIC-feasible assignment bits (bit p) of one (pod, node) pair, for the winner mapping (cold R rows)
 NHD_HD uint32_t nic_assignment_bits(const uint8_t* img, const Layout& L, uint32_t col, bool pci, const nhdfit_plane3& q3) {
-    const uint32_t o0 = (L.row_r0 + (pci ? q3.sig_pci[0] : q3.sig_numa[0])) * L.row_bytes;
-    const uint32_t o1 = (L.row_r1 + (pci ? q3.sig_pci[1] : q3.sig_numa[1])) * L.row_bytes;
+    const uint32_t o0 = L.off_r0 + (pci ? q3.sig_pci[0] : q3.sig_numa[0]) * L.row;
+    const uint32_t o1 = L.off_r1 + (pci ? q3.sig_pci[1] : q3.sig_numa[1]) * L.row;
     uint32_t bits = 0;
     for (uint32_t p = 0; p < L.W; ++p)
         if ((ld64(img, o0 + p * 8) & ld64(img, o1 + p * 8)) >> col & 1) bits |= 1u << p;
@@ -394,6 +437,9 @@ NHD_HD uint64_t chunk_score(uint64_t word, uint64_t nogpu, bool pod_needs_gpu, u
     const uint64_t pick = pref ? pref : word;
     const uint64_t idx = first_global_index + (uint64_t)__builtin_ctzll(pick);
     return (pref ? (1ull << 63) : 0ull) | (0x7FFFFFFFFFFFFFFFull - idx);
+}
+NHD_HD uint64_t score_of(bool pref, uint64_t global_index) {
+    return (pref ? (1ull << 63) : 0ull) | (0x7FFFFFFFFFFFFFFFull - global_index);
 }
 
 }  // namespace nhdfit

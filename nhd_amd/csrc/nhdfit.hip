@@ -77,16 +77,19 @@ struct DigestArgs {
     const nhdfit_req* reqs;          // class-sorted order (as staged)
     uint32_t P;
     DictView d;
-    Layout L;
-    uint8_t* tabs;                   // out: tile images, L.bytes apart
+    Layout L[kWClasses];             // image layout per row width W = 2 << class
+    uint32_t pitch;                  // bytes between tile images
+    uint8_t* tabs;                   // out: tile images
     PodHeader* hdr;                  // out: [tiles*64]
     unsigned long long* score;       // out: zeroed (the fit role accumulates with atomicMax)
-    uint32_t parts;                  // blocks per tile (each sweeps 1/parts of the rows)
+    const uint64_t* xcls;            // interned (NUMA, free GPUs, signature) classes of the mirror: key of X row k
+    const uint32_t* nx;              // number of classes
 };
 constexpr size_t kDigestLds = lds_slice(kTile * sizeof(PaddedReq)) + lds_slice(kTile * sizeof(PodSums)) +
                               lds_slice(kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1) * sizeof(uint16_t)) + lds_slice(kTile * sizeof(PodHeader));
+constexpr uint32_t kDigestParts = 2;      // blocks per tile: part 0 = CPU / scalar-predicate rows, part 1 = GPU / NIC rows
 
-// Request digest, one block per 64-pod tile: per-pod subset sums / NIC covers in LDS, then the table rows
+// Request digest, two blocks per 64-pod tile: per-pod subset sums / NIC covers in LDS, then the table rows
 // (lane = pod, one ballot per assignment).  Few, busy blocks: in the step kernel every resident side block
 // displaces a block of the fit role.
 template <int THREADS>
@@ -97,10 +100,9 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
         reinterpret_cast<uint16_t (*)[NHDFIT_MAX_CLASSES][kMaxG + 1]>(carve<uint16_t>(lds, kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1)));
     PodHeader* s_hdr = carve<PodHeader>(lds, kTile);
 
-    const uint32_t tile = blk / a.parts, part = blk % a.parts;   // `parts` blocks share a tile's rows
+    const uint32_t tile = blk / kDigestParts, part = blk % kDigestParts;
     const uint32_t tid = threadIdx.x;
-    const Layout& L = a.L;
-    uint8_t* img = a.tabs + (size_t)tile * L.bytes;
+    uint8_t* img = a.tabs + (size_t)tile * a.pitch;
 
     stage_requests_lds<THREADS>(a.reqs, tile * kTile, a.P, s_req);
     __syncthreads();
@@ -116,87 +118,112 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
         }
     }
     __syncthreads();
+
+    constexpr uint32_t NW = THREADS / 64;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const bool valid = (s_hdr[lane].flags & kPodValid) != 0;
+    // the tile's row width: 2^(largest group count among its pods) - the same rule the host applies when it
+    // builds the fit role's work items (tile_wclass)
+    const uint32_t my_g = valid ? (s_hdr[lane].flags >> kPodGroupsShift) & 7u : 0u;
+    const uint32_t wcls = __ballot(my_g >= 4) ? 3u : __ballot(my_g == 3) ? 2u : __ballot(my_g == 2) ? 1u : 0u;
+    const Layout& L = a.L[wcls];
+    const uint32_t W = L.W;
+    uint8_t* hot = img + L.off_hot;
+    // bit-sliced row: lane = pod holds its 16-bit entry (bit p = assignment p passes), one ballot per assignment
+    // turns the 64 entries into the row's W words (bit j of word p = assignment p of pod j passes)
+    auto emit_row = [&](uint8_t* row, uint32_t v) {
+        unsigned long long mine = 0;
+        for (uint32_t p = 0; p < W; ++p) {
+            const unsigned long long word = __ballot(v >> p & 1);
+            if (lane == p) mine = word;
+        }
+        if (lane < W) *reinterpret_cast<unsigned long long*>(row + lane * 8) = mine;
+    };
+
+    if (part == 0) {
+        // CPU records WC[u][smt][c] = {m=0 row, m=1 row}: for a pod, socket, SMT mode and misc placement the entry is
+        // { p : demand_p <= c } - the demands are read once per (socket, misc, smt) group and swept over c in
+        // registers (one group per wavefront) instead of being re-read from LDS for each of the rows of the group
+        for (uint32_t g = wave; g < 8; g += NW) {
+            const uint32_t u = g >> 2, m = (g >> 1) & 1, smt = g & 1;
+            uint32_t t[1 << kMaxG];
+#pragma unroll
+            for (uint32_t p = 0; p < (1u << kMaxG); ++p) {
+                t[p] = 0xFFFFFFFFu;
+                if (valid && p < s_sum[lane].W) {
+                    const uint32_t* sum = smt ? s_sum[lane].cpu_smt : s_sum[lane].cpu_nosmt;
+                    const uint32_t extra = m ? (smt ? s_sum[lane].misc_smt : s_sum[lane].misc_nosmt) : 0;
+                    t[p] = sum[u ? p : (~p & s_sum[lane].full)] + extra;
+                }
+            }
+            uint8_t* base = hot + (u ? L.hot_wc1 : L.hot_wc0) + smt * L.fc_dim * L.wc_stride + m * L.row;
+            for (uint32_t c = 0; c < L.fc_dim; ++c) {
+                uint32_t v = 0;
+#pragma unroll
+                for (uint32_t p = 0; p < (1u << kMaxG); ++p) v |= (t[p] <= c ? 1u : 0u) << p;
+                emit_row(base + c * L.wc_stride, v);
+            }
+        }
+        // 64-bit scalar-predicate rows: one wavefront per row, ballot over the 64 pods
+        const uint32_t ngx = 1 + 2 * L.ngs, nrows64 = ngx + L.hp_rows;
+        for (uint32_t k = wave; k < nrows64; k += NW) {
+            const bool bit = k < ngx ? gx_bit(s_hdr[lane], k, a.d.group_sets) : hp_bit(s_hdr[lane], k - ngx);
+            const uint64_t word = __ballot(bit);
+            if (lane == 0)
+                *reinterpret_cast<uint64_t*>(hot + (k < ngx ? L.hot_gx + 8 * k : L.hot_hp + 8 * (k - ngx))) = word;
+        }
+        return;
+    }
+
+    // part 1: NIC covers per (pod, capacity class), then the cold rows A0/A1[f], R0/R1[sig]
     for (uint32_t w = tid; w < kTile * a.d.ncls; w += THREADS) {
         const uint32_t j = w % kTile, c = w / kTile;
         if (s_hdr[j].flags & kPodValid) class_cover(s_req[j].r, a.d.caps[c], s_sum[j].W, s_sum[j].G, s_cover[j][c]);
     }
     __syncthreads();
-
-    // assignment rows, bit-sliced: lane = pod computes its 16-bit entry (bit p = assignment p passes), one ballot
-    // per assignment turns 64 entries into the row's W words (bit j of word p = assignment p of pod j passes)
-    constexpr uint32_t NW = THREADS / 64;
-    const uint32_t wave = tid >> 6, lane = tid & 63;
-    const bool valid = (s_hdr[lane].flags & kPodValid) != 0;
-    auto emit_row = [&](uint32_t row, uint32_t v) {
-        unsigned long long mine = 0;
-        for (uint32_t p = 0; p < L.W; ++p) {
-            const unsigned long long word = __ballot(v >> p & 1);
-            if (lane == p) mine = word;
-        }
-        if (lane < L.W) *reinterpret_cast<unsigned long long*>(img + row * L.row_bytes + lane * 8) = mine;
-    };
-    // CPU rows W0/W1[misc here?][smt][free cores c]: for a pod, socket, SMT mode and misc placement the entry is
-    // { p : demand_p <= c } - the demands are read once per (socket, misc, smt) group and swept over c in registers
-    // (one group per wavefront) instead of being re-read from LDS for each of the 4 * fc_dim rows of the group
-    for (uint32_t g = wave; g < 8; g += NW) {
-        const uint32_t u = g >> 2, m = (g >> 1) & 1, smt = g & 1;
-        uint32_t t[1 << kMaxG];
-#pragma unroll
-        for (uint32_t p = 0; p < (1u << kMaxG); ++p) {
-            t[p] = 0xFFFFFFFFu;
-            if (valid && p < s_sum[lane].W) {
-                const uint32_t* sum = smt ? s_sum[lane].cpu_smt : s_sum[lane].cpu_nosmt;
-                const uint32_t extra = m ? (smt ? s_sum[lane].misc_smt : s_sum[lane].misc_nosmt) : 0;
-                t[p] = sum[u ? p : (~p & s_sum[lane].full)] + extra;
-            }
-        }
-        const uint32_t row0 = (u ? L.row_w1 : 0u) + m * 2 * L.fc_dim + smt * L.fc_dim;
-        for (uint32_t c = part; c < L.fc_dim; c += a.parts) {
-            uint32_t v = 0;
-#pragma unroll
-            for (uint32_t p = 0; p < (1u << kMaxG); ++p) v |= (t[p] <= c ? 1u : 0u) << p;
-            emit_row(row0 + c, v);
-        }
+    for (uint32_t k = wave; k < 2 * L.fg_dim; k += NW) {
+        const uint32_t u = k >= L.fg_dim, f = u ? k - L.fg_dim : k;
+        emit_row(img + (u ? L.off_a1 : L.off_a0) + f * L.row, valid ? entry_a(s_sum[lane], u, f) : 0u);
     }
-    // GPU rows A[f0][f1]
-    for (uint32_t k = wave * a.parts + part; k < L.fg_dim * L.fg_dim; k += NW * a.parts)
-        emit_row(L.row_a + k, valid ? entry_a(s_sum[lane], k / L.fg_dim, k % L.fg_dim) : 0u);
-    // NIC rows R0/R1[signature]: one reach family per (signature, pod), both sockets' rows from it
-    for (uint32_t sig = wave * a.parts + part; sig < L.nsig; sig += NW * a.parts) {
+    for (uint32_t sig = wave; sig < L.nsig; sig += NW) {        // one reach family per (signature, pod), both sockets' rows from it
         const uint32_t reach = valid ? sig_reach(a.d.sig, sig, &s_cover[lane][0][0], s_sum[lane].W) : 0u;
-        emit_row(L.row_r0 + sig, valid ? entry_r(reach, s_sum[lane].W, 0) : 0u);
-        emit_row(L.row_r1 + sig, valid ? entry_r(reach, s_sum[lane].W, 1) : 0u);
+        emit_row(img + L.off_r0 + sig * L.row, valid ? entry_r(reach, s_sum[lane].W, 0) : 0u);
+        emit_row(img + L.off_r1 + sig * L.row, valid ? entry_r(reach, s_sum[lane].W, 1) : 0u);
     }
-    // 64-bit scalar-predicate rows: one wavefront per row, ballot over the 64 pods
-    const uint32_t nrows64 = L.hp_rows + L.ngs;
-    for (uint32_t k = wave * a.parts + part; k < nrows64; k += NW * a.parts) {
-        const bool bit = k < L.hp_rows ? hp_bit(s_hdr[lane], L, k) : gf_bit(s_hdr[lane], a.d.group_sets[k - L.hp_rows]);
-        const uint64_t word = __ballot(bit);
-        if (lane == 0)
-            *reinterpret_cast<uint64_t*>(img + (k < L.hp_rows ? L.off_hp + 8 * k : L.off_gf + 8 * (k - L.hp_rows))) = word;
+    __syncthreads();                                            // the block reads back the cold rows it just wrote
+    // hot rows X[class] = A_u[f] & (PCI-mode pods: R_u[sigPCI], NUMA-mode pods: R_u[sigNUMA]) - pure word
+    // operations on the cold rows, one lane per (class, assignment)
+    const uint64_t m_pci = __ballot((s_hdr[lane].flags & kPodPci) != 0);
+    const uint32_t nx = a.nx[0] < L.x_cap ? a.nx[0] : L.x_cap;
+    for (uint32_t i = tid; i < nx * W; i += THREADS) {
+        const uint32_t k = i / W, p = i % W;
+        const uint64_t key = a.xcls[k];
+        const uint32_t u = xkey_u(key);
+        const uint8_t* rbase = img + (u ? L.off_r1 : L.off_r0) + p * 8;
+        const uint64_t av = ld64(img, (u ? L.off_a1 : L.off_a0) + xkey_f(key) * L.row + p * 8);
+        const uint64_t rn = ld64(rbase, xkey_sig_numa(key) * L.row), rp = ld64(rbase, xkey_sig_pci(key) * L.row);
+        *reinterpret_cast<uint64_t*>(hot + L.hot_x + k * L.x_stride + p * 8) = av & ((rp & m_pci) | (rn & ~m_pci));
     }
 }
 
+struct FitItem { uint32_t tile, wcls, c_begin, c_end; };       // one block of the fit role: chunks [c_begin, c_end) of a tile
+
 struct FitArgs {
-    const nhdfit_plane0* p0;
-    const nhdfit_plane1* p1;
-    const nhdfit_plane2* p2;
-    const nhdfit_plane3* p3;
-    const nhdfit_plane4* p4;
-    const NodeRec* rec;         // precomputed node records (role_fit<.., true>), or null
+    const NodeRec* rec[kWClasses];   // node records per row width (k_xrecords), padded to a multiple of 64 nodes
+    const nhdfit_plane4* p4;         // busy times (padded likewise)
     uint32_t n;                 // nodes in this shard
     uint32_t chunks;            // ceil(n / 64)
-    uint32_t chunks_per_block;
-    uint32_t nranges;           // node ranges (blocks per tile)
     uint64_t global_base;
-    double now;
-    const uint8_t* tabs;        // tile images, layout.bytes apart
-    Layout layout;
+    double busy_from;           // busy_threshold(now): a node is busy iff busy_time >= busy_from
+    const uint8_t* tabs;        // tile images
+    uint32_t pitch;
+    Layout L[kWClasses];
     const PodHeader* hdr;       // [tiles*64], zero flags beyond P
     uint32_t P;
-    const uint64_t* cand;       // optional [chunks][P]
-    uint64_t* bitmap;           // optional [chunks][P]
+    const uint64_t* cand;       // optional [chunks]: candidate nodes (bit = node) common to all pods of the call
+    uint64_t* nm;               // optional node-major feasibility words [tiles][chunks*64]: bit j = pod 64*tile+j
     unsigned long long* score;  // [P], pre-zeroed
+    const FitItem* items;
 };
 
 // One step of the 64 x 64 bit-matrix transpose across a wavefront: exchange S x S sub-blocks between
@@ -254,124 +281,131 @@ __device__ __forceinline__ void transpose64(uint32_t& lo, uint32_t& hi) {
     xpose_stage<1>(lo, hi);
 }
 
-
+__device__ __forceinline__ uint4 lds16(const uint8_t* img, uint32_t off) {
+    return *reinterpret_cast<const uint4*>(__builtin_assume_aligned(img + off, 16));
+}
 __device__ __forceinline__ uint2 lds8(const uint8_t* img, uint32_t off) {
     return *reinterpret_cast<const uint2*>(__builtin_assume_aligned(img + off, 8));
 }
 
-// Pods of the tile (bit j) for which some NUMA assignment passes CPU & GPU & NIC on this lane's node.
-// One 64-bit word per (table row, assignment) serves all 64 pods: per assignment 7 LDS words, 8 VALU ops.
-template <int W, bool MIXED>
-__device__ __forceinline__ uint64_t sweep_assignments(const uint8_t* img, const NodeLane& nl, uint32_t o_r0, uint32_t o_r1,
-                                                      uint64_t m_pci) {
+// Pods of the tile (bit j) for which some NUMA assignment passes CPU & GPU & NIC on this lane's node: per PAIR of
+// assignments six 16-byte row fetches (ds_read_b128) and 16 three-input bit operations serve all 64 pods.
+// a_* = byte addresses of the node's rows in the staged hot section; the m=1 row of a WC record follows its m=0 row.
+template <int W>
+__device__ __forceinline__ uint64_t sweep_assignments(const uint8_t* hot, uint32_t a_w0, uint32_t a_w1, uint32_t a_x0, uint32_t a_x1) {
     uint32_t lo = 0, hi = 0;
 #pragma unroll
-    for (int p = 0; p < W; ++p) {
-        const uint32_t o = p * 8;
-        const uint2 w0 = lds8(img, nl.off_w0 + o), w0m = lds8(img, nl.off_w0 + nl.w_misc + o);
-        const uint2 w1 = lds8(img, nl.off_w1 + o), w1m = lds8(img, nl.off_w1 + nl.w_misc + o);
-        const uint2 ga = lds8(img, nl.off_a + o);
-        uint2 r0 = lds8(img, o_r0 + o), r1 = lds8(img, o_r1 + o);
-        if (MIXED) {             // tile with NUMA- and PCI-mode pods: per-pod choice of the NIC rows
-            const uint2 q0 = lds8(img, nl.off_r0p + o), q1 = lds8(img, nl.off_r1p + o);
-            const uint32_t ml = (uint32_t)m_pci, mh = (uint32_t)(m_pci >> 32);
-            r0.x = (q0.x & ml) | (r0.x & ~ml); r0.y = (q0.y & mh) | (r0.y & ~mh);
-            r1.x = (q1.x & ml) | (r1.x & ~ml); r1.y = (q1.y & mh) | (r1.y & ~mh);
-        }
-        {   // low 32 pods
-            const uint32_t cpu = (w0m.x & w1.x) | (w0.x & w1m.x);
-            const uint32_t t = __builtin_amdgcn_bitop3_b32(cpu, ga.x, r0.x, 0x80);          // a & b & c
-            lo = __builtin_amdgcn_bitop3_b32(t, r1.x, lo, 0xEA);                             // (a & b) | c
-        }
-        {   // high 32 pods
-            const uint32_t cpu = (w0m.y & w1.y) | (w0.y & w1m.y);
-            const uint32_t t = __builtin_amdgcn_bitop3_b32(cpu, ga.y, r0.y, 0x80);
-            hi = __builtin_amdgcn_bitop3_b32(t, r1.y, hi, 0xEA);
-        }
+    for (int q = 0; q < W / 2; ++q) {
+        const uint32_t o = q * 16;
+        const uint4 w0 = lds16(hot, a_w0 + o), w0m = lds16(hot, a_w0 + W * 8 + o);
+        const uint4 w1 = lds16(hot, a_w1 + o), w1m = lds16(hot, a_w1 + W * 8 + o);
+        const uint4 x0 = lds16(hot, a_x0 + o), x1 = lds16(hot, a_x1 + o);
+        // words .x/.y = assignment 2q (pods 0-31 / 32-63), .z/.w = assignment 2q+1
+        const uint32_t c0 = __builtin_amdgcn_bitop3_b32(w0.x, w1m.x, w0m.x & w1.x, 0xEA);     // (a & b) | c
+        const uint32_t c1 = __builtin_amdgcn_bitop3_b32(w0.y, w1m.y, w0m.y & w1.y, 0xEA);
+        const uint32_t c2 = __builtin_amdgcn_bitop3_b32(w0.z, w1m.z, w0m.z & w1.z, 0xEA);
+        const uint32_t c3 = __builtin_amdgcn_bitop3_b32(w0.w, w1m.w, w0m.w & w1.w, 0xEA);
+        lo |= __builtin_amdgcn_bitop3_b32(c0, x0.x, x1.x, 0x80) | __builtin_amdgcn_bitop3_b32(c2, x0.z, x1.z, 0x80);   // a & b & c
+        hi |= __builtin_amdgcn_bitop3_b32(c1, x0.y, x1.y, 0x80) | __builtin_amdgcn_bitop3_b32(c3, x0.w, x1.w, 0x80);
     }
     return ((uint64_t)hi << 32) | lo;
 }
 
-template <bool MIXED>
-__device__ __forceinline__ uint64_t sweep_dispatch(uint32_t W, const uint8_t* img, const NodeLane& nl, uint32_t o_r0,
-                                                   uint32_t o_r1, uint64_t m_pci) {
-    switch (W) {                                    // wave-uniform
-        case 2: return sweep_assignments<2, MIXED>(img, nl, o_r0, o_r1, m_pci);
-        case 4: return sweep_assignments<4, MIXED>(img, nl, o_r0, o_r1, m_pci);
-        case 8: return sweep_assignments<8, MIXED>(img, nl, o_r0, o_r1, m_pci);
-        default: return sweep_assignments<16, MIXED>(img, nl, o_r0, o_r1, m_pci);
-    }
-}
-
-// The P x N pass.  Block = (pod tile, node range): the tile's table image is staged in LDS, every wavefront
-// sweeps 64-node chunks of the range (lane = node), transposes the verdicts (lane = pod), writes the bitmap word
-// and keeps the best score; one atomicMax per pod and block.
-template <int BLOCK, bool REC>
-__device__ __forceinline__ void role_fit(const FitArgs& a, uint32_t blk, uint8_t* lds) {
+// The P x N pass.  Block = chunks [c_begin, c_end) of one pod tile: the hot section of the tile's table image is
+// staged in LDS, every wavefront sweeps a contiguous run of 64-node chunks (lane = node: one 16-byte record and
+// the busy time per node), writes the node-major verdict word and tracks the tile's first-fit winners.
+//
+// Winner tracking without transposing every chunk: a wavefront walks its chunks in ascending node order, so a
+// pod's first hit is its best node of that run.  The pods still without a hit (and the GPU-less pods still without
+// a GPU-less node, SelectNode's preference) are two wave-uniform 64-bit masks; a chunk whose verdict words do
+// not touch them - all but the first one or two of a run - costs four instructions.  Only a chunk with news is
+// transposed (lane = pod) and scored.
+template <int BLOCK, int W>
+__device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, uint8_t* lds) {
     constexpr int NW = BLOCK / 64;
-    uint8_t* img = lds;
-    unsigned long long (*s_best)[64] = reinterpret_cast<unsigned long long (*)[64]>(lds + lds_slice(a.layout.bytes));
+    const Layout& L = a.L[W == 2 ? 0 : W == 4 ? 1 : W == 8 ? 2 : 3];
+    uint8_t* hot = lds;
+    unsigned long long (*s_best)[64] = reinterpret_cast<unsigned long long (*)[64]>(lds + lds_slice(L.hot_bytes));
+    const uint32_t tile = it.tile;
 
-    // blockIdx -> (tile, range): consecutive blocks (round-robin over the 8 XCDs) walk the node
-    // ranges, so one XCD keeps re-reading the same 1/8 of the node planes out of its own L2.
-    const uint32_t range = blk % a.nranges;
-    const uint32_t tile = blk / a.nranges;
-
-    {   // stage the tile's table image in LDS (16 B per lane, fully coalesced)
-        const uint4* src = reinterpret_cast<const uint4*>(a.tabs + (size_t)tile * a.layout.bytes);
-        uint4* dst = reinterpret_cast<uint4*>(img);
-        for (uint32_t i = threadIdx.x; i < a.layout.bytes / 16; i += BLOCK) dst[i] = src[i];
+    {   // stage the hot section of the tile's table image in LDS (16 B per lane, fully coalesced)
+        const uint4* src = reinterpret_cast<const uint4*>(a.tabs + (size_t)tile * a.pitch + L.off_hot);
+        uint4* dst = reinterpret_cast<uint4*>(hot);
+        for (uint32_t i = threadIdx.x; i < L.hot_bytes / 16; i += BLOCK) dst[i] = src[i];
     }
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t pod0 = tile * kTile;
     // lane-as-pod view of the tile's 64 request headers -> class masks of the tile (scalar registers)
     const PodHeader my_h = a.hdr[pod0 + lane];
     const bool my_pod_live = pod0 + lane < a.P;
     const bool my_pod_needs_gpu = (my_h.flags & kPodNeedGpu) != 0;
     const uint64_t m_need = __ballot(my_pod_needs_gpu);
-    const uint64_t m_pci = __ballot((my_h.flags & kPodPci) != 0);
-    const uint64_t m_filt = __ballot((my_h.flags & kPodFilter) != 0);
-    // requests are staged sorted by class, so almost every tile is all-PCI or all-NUMA
-    const bool pci_uniform = m_pci == 0 || m_pci == ~0ull;
-    // assignments the tile needs: 2^(largest group count among its pods) - tiles are sorted by class and size
-    const uint32_t my_g = (my_h.flags >> kPodGroupsShift) & 7u;
-    const uint32_t Wt = __ballot(my_g >= 4) ? 16u : __ballot(my_g == 3) ? 8u : __ballot(my_g == 2) ? 4u : 2u;
-    unsigned long long best = 0;
+    uint64_t need_any = __ballot(my_pod_live);                               // pods without a feasible node so far
+    uint64_t need_pref = __ballot(my_pod_live && !my_pod_needs_gpu);         // GPU-less pods without a GPU-less node so far
+    uint32_t best_any = ~0u, best_pref = ~0u;                                // lane = pod: local node index
 
-    const uint32_t c_begin = range * a.chunks_per_block;
-    const uint32_t c_end = c_begin + a.chunks_per_block < a.chunks ? c_begin + a.chunks_per_block : a.chunks;
-    for (uint32_t c = c_begin + wave; c < c_end; c += NW) {
-        const uint32_t i = c * 64 + lane;
-        const bool live = i < a.n;
-        NodeLane nl = NodeLane{};
-        nl.flags = NHDFIT_NF_MAINTENANCE;                      // lanes past the end are never feasible
-        if constexpr (REC) {
-            if (live) nl = node_lane_from_record(a.rec[i], a.now, a.layout);      // two 16-byte loads, no popcounts / multiplies
-        } else {
-            if (live) nl = node_lane(a.p0[i], a.p1[i], a.p2[i], a.p3[i], a.p4[i], a.now, a.layout);
-        }
-        const uint64_t nogpu = __ballot(live && !(nl.flags & NHDFIT_NF_HAS_GPU));
-
-        // (1) NUMA-assignment feasibility against all 64 pods, in the lane = node domain (bit-sliced tables)
-        uint64_t okm;
-        if (pci_uniform) okm = sweep_dispatch<false>(Wt, img, nl, m_pci ? nl.off_r0p : nl.off_r0n, m_pci ? nl.off_r1p : nl.off_r1n, m_pci);
-        else okm = sweep_dispatch<true>(Wt, img, nl, nl.off_r0n, nl.off_r1n, m_pci);
-        // (2) scalar predicates of this lane's node against all 64 pods (one 64-bit word per table row)
-        const uint64_t fm = node_pod_mask(nl, img, m_filt, m_need);
-        uint32_t wlo = (uint32_t)(okm & fm), whi = (uint32_t)((okm & fm) >> 32);
-        // (3) 64 x 64 bit transpose: lane j now holds pod j's verdict over the chunk's 64 nodes
-        transpose64(wlo, whi);
-        uint64_t word = ((uint64_t)whi << 32) | wlo;
-        if (my_pod_live) {
-            const size_t o = (size_t)c * a.P + pod0 + lane;
-            if (a.cand) word &= a.cand[o];
-            if (a.bitmap) a.bitmap[o] = word;
-            const unsigned long long s = chunk_score(word, nogpu, my_pod_needs_gpu, a.global_base + (uint64_t)c * 64);
-            best = s > best ? s : best;
-        }
+    const NodeRec* __restrict__ recs = a.rec[W == 2 ? 0 : W == 4 ? 1 : W == 8 ? 2 : 3];
+    const uint32_t hp_last = L.hp_rows - 1;
+    const uint32_t len = it.c_end - it.c_begin, per = (len + NW - 1) / NW;
+    const uint32_t c_first = it.c_begin + wave * per;
+    const uint32_t c_last = c_first + per < it.c_end ? c_first + per : it.c_end;
+    const size_t npad = (size_t)a.chunks * 64;
+    // the next chunk's record and busy time are requested before this chunk is worked on: a wavefront's chunks are
+    // one dependent chain of L2 round trips otherwise
+    uint4 rv = make_uint4(0u, 0u, 0u, 0u);
+    double bt = 0.0;
+    if (c_first < c_last) {
+        rv = *reinterpret_cast<const uint4*>(recs + c_first * 64 + lane);           // {w0,w1}, {x0,x1}, {gx,hp}, {flags,pad}
+        bt = a.p4[c_first * 64 + lane].busy_time;
     }
+    for (uint32_t c = c_first; c < c_last; ++c) {
+        const uint32_t i = c * 64 + lane;
+        uint4 rv_next = rv;
+        double bt_next = bt;
+        if (c + 1 < c_last) {
+            rv_next = *reinterpret_cast<const uint4*>(recs + i + 64);
+            bt_next = a.p4[i + 64].busy_time;
+        }
+        const uint32_t a_w0 = (rv.x & 0xFFFFu) << 3, a_w1 = (rv.x >> 16) << 3;
+        const uint32_t a_x0 = (rv.y & 0xFFFFu) << 3, a_x1 = (rv.y >> 16) << 3;
+        const uint32_t a_gx = (rv.z & 0xFFFFu) << 3;
+        const uint32_t hp = rv.z >> 16;
+        const uint32_t a_hp = L.hot_hp + (hp < hp_last ? hp : hp_last) * 8;
+        const bool nogpu = (rv.w & kRecNoGpu) != 0;
+
+        // (1) NUMA-assignment feasibility against all 64 pods (bit-sliced tables), (2) scalar predicates
+        const uint64_t okm = sweep_assignments<W>(hot, a_w0, a_w1, a_x0, a_x1);
+        const uint2 gx = lds8(hot, a_gx), hpw = lds8(hot, a_hp);
+        const bool busy = bt >= a.busy_from;                                  // Node.IsBusy, nhd/Node.py:847-850
+        uint32_t wlo = (uint32_t)okm & gx.x & hpw.x, whi = (uint32_t)(okm >> 32) & gx.y & hpw.y;
+        if (busy) { wlo &= ~(uint32_t)m_need; whi &= ~(uint32_t)(m_need >> 32); }      // Matcher.py:107-111
+        if (a.cand) {                                                         // candidate dict of the call (FindNode's nl)
+            const uint64_t cw = a.cand[c];
+            if (!(cw >> lane & 1)) wlo = whi = 0;
+        }
+        if (a.nm) a.nm[(size_t)tile * npad + i] = ((uint64_t)whi << 32) | wlo;
+
+        // (3) does this chunk change any pod's winner?
+        const uint32_t nlo = (uint32_t)need_any | (nogpu ? (uint32_t)need_pref : 0u);
+        const uint32_t nhi = (uint32_t)(need_any >> 32) | (nogpu ? (uint32_t)(need_pref >> 32) : 0u);
+        if (__ballot(((wlo & nlo) | (whi & nhi)) != 0)) {
+            const uint64_t nogpu_mask = __ballot(nogpu);
+            transpose64(wlo, whi);                                            // lane j: pod j's verdict over the chunk's 64 nodes
+            const uint64_t word = ((uint64_t)whi << 32) | wlo;
+            const uint64_t pref = my_pod_needs_gpu ? 0ull : word & nogpu_mask;
+            if (word && best_any == ~0u) best_any = c * 64 + (uint32_t)__builtin_ctzll(word);
+            if (pref && best_pref == ~0u) best_pref = c * 64 + (uint32_t)__builtin_ctzll(pref);
+            need_any &= ~__ballot(word != 0);
+            need_pref &= ~__ballot(pref != 0);
+        }
+        rv = rv_next;
+        bt = bt_next;
+    }
+    unsigned long long best = 0;
+    if (best_pref != ~0u) best = score_of(true, a.global_base + best_pref);
+    else if (best_any != ~0u) best = score_of(false, a.global_base + best_any);
     s_best[wave][lane] = best;
     __syncthreads();
     if (wave == 0 && my_pod_live) {
@@ -382,14 +416,31 @@ __device__ __forceinline__ void role_fit(const FitArgs& a, uint32_t blk, uint8_t
     }
 }
 
+template <int BLOCK>
+__device__ __forceinline__ void role_fit(const FitArgs& a, uint32_t blk, uint8_t* lds) {
+    FitItem it = a.items[blk];                      // block-uniform: keep it in scalar registers
+    it.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.tile);
+    it.wcls = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.wcls);
+    it.c_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_begin);
+    it.c_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_end);
+    switch (it.wcls) {
+        case 0: role_fit_w<BLOCK, 2>(a, it, lds); break;
+        case 1: role_fit_w<BLOCK, 4>(a, it, lds); break;
+        case 2: role_fit_w<BLOCK, 8>(a, it, lds); break;
+        default: role_fit_w<BLOCK, 16>(a, it, lds); break;
+    }
+}
+
 struct MapArgs {
     const nhdfit_plane0* p0;
     const nhdfit_plane1* p1;
     const nhdfit_plane2* p2;
     const nhdfit_plane3* p3;
     const nhdfit_detail* det;
-    const uint8_t* tabs;
-    Layout layout;
+    const uint8_t* tabs;             // tile images (their cold R rows: NIC-feasible assignments of a winner)
+    uint32_t pitch;
+    const uint8_t* tile_wcls;        // row width class of every tile
+    Layout L[kWClasses];
     uint32_t n;
     uint64_t global_base;
     const nhdfit_req* reqs;
@@ -431,7 +482,7 @@ __global__ __launch_bounds__(64 * kMapWaves) void k_map(MapArgs a) {
             w.free_g[1] = popc32(q2.gpu_free & q2.gpu_numa1);
             w.caps = a.caps;
             const nhdfit_req& rq = a.reqs[p];
-            const uint32_t bits = nic_assignment_bits(a.tabs + (size_t)(p / kTile) * a.layout.bytes, a.layout, p % kTile,
+            const uint32_t bits = nic_assignment_bits(a.tabs + (size_t)(p / kTile) * a.pitch, a.L[a.tile_wcls[p / kTile]], p % kTile,
                                                       rq.map_type == NHDFIT_MAP_PCI, a.p3[i]);
             const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
             if (GENERIC) map_winner_t<GenericOps>(rq, w, codes, m);
@@ -506,7 +557,7 @@ __device__ __forceinline__ void role_shapes(const MapArgs& a, const ShapeArgs& h
     uint32_t i;
     const nhdfit_req& rq = a.reqs[p < a.P ? p : 0];
     if (p < a.P && rq.n_groups <= 3 && load_winner(a, p, w, i)) {
-        const uint32_t bits = nic_assignment_bits(a.tabs + (size_t)tile * a.layout.bytes, a.layout, lane,
+        const uint32_t bits = nic_assignment_bits(a.tabs + (size_t)tile * a.pitch, a.L[a.tile_wcls[tile]], lane,
                                                   rq.map_type == NHDFIT_MAP_PCI, a.p3[i]);
         const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
         uint32_t sg, sc;
@@ -611,17 +662,97 @@ __device__ __forceinline__ void stamp(unsigned long long* role_clock, int role, 
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_fit_only(FitArgs a) {
     extern __shared__ __align__(16) uint8_t lds[];
-    role_fit<BLOCK, false>(a, blockIdx.x, lds);
+    role_fit<BLOCK>(a, blockIdx.x, lds);
 }
 
-// node records of the whole mirror for the current table layout (one thread per node; only after uploads / re-staging)
-__global__ __launch_bounds__(256) void k_node_records(FitArgs a, NodeRec* out) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < a.n) out[i] = make_node_record(a.p0[i], a.p1[i], a.p2[i], a.p3[i], a.p4[i], a.layout);
+// ---- node records ------------------------------------------------------------------------------------
+// Everything the fit role needs from a node's five planes depends only on the mirror and the dictionary, not on the
+// pod tile or the step.  After nodes change: (1) k_xkeys interns the (NUMA, free GPUs, NUMA-mode signature,
+// PCI-mode signature) class of both NUMA nodes of every touched node in a device hash table, (2) k_xassign gives new
+// classes the next X row, (3) k_xrecords writes the 16-byte records (one array per row width).  Classes are never
+// removed, rows are provisioned in powers of two: records stay valid while classes are appended.
+constexpr uint32_t kXSlots = 1u << 15;          // open-addressing table; the host grows nothing: > kXSlots / 2 classes is NHDFIT_E_LIMIT
+struct XTable {
+    unsigned long long* key;                    // [kXSlots], 0 = empty
+    uint32_t* id;                               // [kXSlots], ~0u = not assigned yet
+    uint64_t* cls;                              // [kXSlots / 2]: key of X row k
+    uint32_t* nx;                               // [0] = classes, [1] = overflow flag
+};
+struct RecArgs {
+    const nhdfit_plane0* p0; const nhdfit_plane1* p1; const nhdfit_plane2* p2; const nhdfit_plane3* p3; const nhdfit_plane4* p4;
+    uint32_t n, npad;                           // nodes / nodes rounded up to whole chunks
+    uint32_t first, count;                      // nodes to (re)do
+    uint32_t fc_dim, fg_dim, ngs;
+    XTable x;
+    Layout L[kWClasses];
+    NodeRec* rec[kWClasses];
+};
+__device__ __forceinline__ uint32_t xhash(uint64_t k) {
+    k ^= k >> 33; k *= 0xFF51AFD7ED558CCDull; k ^= k >> 29;
+    return (uint32_t)k & (kXSlots - 1);
+}
+__device__ __forceinline__ uint32_t xslot_find(const XTable& x, uint64_t key) {        // the key is present
+    uint32_t s = xhash(key);
+    while (x.key[s] != key) s = (s + 1) & (kXSlots - 1);
+    return s;
+}
+__global__ __launch_bounds__(256) void k_xkeys(RecArgs a) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.count) return;
+    const uint32_t i = a.first + t;
+    if (i >= a.n) return;
+    const NodeIdx n = node_index(a.p0[i], a.p1[i], a.p2[i], a.p4[i], a.fc_dim, a.fg_dim, a.ngs);
+    const nhdfit_plane3 q3 = a.p3[i];
+    for (uint32_t u = 0; u < 2; ++u) {
+        const unsigned long long key = xkey(u, u ? n.f1 : n.f0, q3.sig_numa[u], q3.sig_pci[u]);
+        uint32_t s = xhash(key);
+        for (uint32_t probes = 0; probes < kXSlots; ++probes, s = (s + 1) & (kXSlots - 1)) {
+            const unsigned long long prev = atomicCAS(&a.x.key[s], 0ull, key);
+            if (prev == 0ull || prev == key) break;
+        }
+    }
+}
+__global__ __launch_bounds__(1024) void k_xassign(XTable x) {      // one block: new classes get rows in slot order
+    for (uint32_t s = threadIdx.x; s < kXSlots; s += 1024)
+        if (x.key[s] != 0ull && x.id[s] == ~0u) {
+            const uint32_t k = atomicAdd(&x.nx[0], 1u);
+            if (k < kXSlots / 2) { x.id[s] = k; x.cls[k] = x.key[s]; }
+            else { x.id[s] = 0; x.nx[1] = 1; }
+        }
+}
+__global__ __launch_bounds__(256) void k_xrecords(RecArgs a) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.count) return;
+    const uint32_t i = a.first + t;
+    if (i >= a.npad) return;
+    if (i >= a.n) {                                                // padding of the last chunk
+        for (int w = 0; w < kWClasses; ++w) a.rec[w][i] = dead_record(a.L[w]);
+        return;
+    }
+    const NodeIdx n = node_index(a.p0[i], a.p1[i], a.p2[i], a.p4[i], a.fc_dim, a.fg_dim, a.ngs);
+    const nhdfit_plane3 q3 = a.p3[i];
+    const uint32_t x0 = a.x.id[xslot_find(a.x, xkey(0, n.f0, q3.sig_numa[0], q3.sig_pci[0]))];
+    const uint32_t x1 = a.x.id[xslot_find(a.x, xkey(1, n.f1, q3.sig_numa[1], q3.sig_pci[1]))];
+    for (int w = 0; w < kWClasses; ++w) a.rec[w][i] = make_record(n, x0, x1, a.L[w]);
 }
 
-template <int BLOCK, bool REC>
-__global__ __launch_bounds__(BLOCK, 7) void k_step(StepArgs a) {
+// node-major verdict words [tiles][chunks*64] -> pod-major rows [chunks][P] (the layout of nhdfit_find's
+// bitmap_out and of the sequential resolver): one wavefront per (tile, chunk), 64 x 64 bit transpose in registers
+__global__ __launch_bounds__(256) void k_rows(const uint64_t* __restrict__ nm, uint64_t* __restrict__ rows, uint32_t chunks, uint32_t P) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t tiles = (P + kTile - 1) / kTile;
+    if (w >= tiles * chunks) return;
+    const uint32_t tile = w / chunks, c = w % chunks;
+    const uint64_t v = nm[((size_t)tile * chunks + c) * 64 + lane];
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    transpose64(lo, hi);
+    const uint32_t pod = tile * kTile + lane;
+    if (pod < P) rows[(size_t)c * P + pod] = ((uint64_t)hi << 32) | lo;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : 7) void k_step(StepArgs a) {   // 512 threads = 2 waves per SIMD: 3 blocks per CU either way
     extern __shared__ __align__(16) uint8_t lds[];
     uint32_t blk = blockIdx.x;
     const unsigned long long t0 = a.role_clock ? (unsigned long long)wall_clock64() : 0ull;
@@ -642,8 +773,23 @@ __global__ __launch_bounds__(BLOCK, 7) void k_step(StepArgs a) {
     blk -= a.nb_finish;
     if (blk < a.nb_digest) { role_digest<BLOCK>(a.digest, blk, lds); stamp(a.role_clock, 3, t0); return; }
     blk -= a.nb_digest;
-    role_fit<BLOCK, REC>(a.fit, blk, lds);
+    role_fit<BLOCK>(a.fit, blk, lds);
     stamp(a.role_clock, 4, t0);
+}
+
+// Profiling aid (NHDFIT_ROLE_KERNELS=1): one role per launch, so that rocprofv3 --stats names each role's stand-alone time.
+template <int BLOCK, int ROLE>
+__global__ __launch_bounds__(BLOCK, 6) void k_role(StepArgs a) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const uint32_t blk = blockIdx.x;
+    if constexpr (ROLE == 0) {
+        if ((threadIdx.x & 63) == 0)
+            role_choose(a.choose, (uint32_t)__builtin_amdgcn_readfirstlane((int)(blk * (BLOCK / 64) + (threadIdx.x >> 6))),
+                        a.nb_choose * (BLOCK / 64), (a.shapes_P + kTile - 1) / kTile);
+    } else if constexpr (ROLE == 1) role_shapes<BLOCK>(a.shapes_m, a.shapes_h, blk);
+    else if constexpr (ROLE == 2) role_finish<BLOCK>(a.finish_m, a.finish_h, blk);
+    else if constexpr (ROLE == 3) role_digest<BLOCK>(a.digest, blk, lds);
+    else role_fit<BLOCK>(a.fit, blk, lds);
 }
 
 // ---- mode B: sequential resolver ------------------------------------------------------------------
@@ -781,6 +927,7 @@ struct nhdfit_ctx {
     uint32_t side_prio = getenv("NHDFIT_SIDE_PRIO") ? (uint32_t)atoi(getenv("NHDFIT_SIDE_PRIO")) : 1;   // tuning aid
     uint32_t choose_split = getenv("NHDFIT_CHOOSE_SPLIT") ? (uint32_t)atoi(getenv("NHDFIT_CHOOSE_SPLIT")) : 64;   // tuning aid: wavefronts per tile
     bool split = getenv("NHDFIT_SPLIT") != nullptr;
+    bool role_kernels = getenv("NHDFIT_ROLE_KERNELS") != nullptr;   // profiling aid: every role as a kernel of its own (512-thread geometry only)
     DevBuf<unsigned long long> role_clock;            // profiling aid: NHDFIT_ROLE_TIMES=<step> prints the role windows of that step
     int64_t role_step = getenv("NHDFIT_ROLE_TIMES") ? atoll(getenv("NHDFIT_ROLE_TIMES")) : -1;   // profiling aid: launch the side roles apart from the fit role
     std::string err;
@@ -797,31 +944,41 @@ struct nhdfit_ctx {
     uint32_t ncls = 0, nsig = 0;
     uint32_t max_cores = 1, max_gpus = 0, ngs = 0;
     DevBuf<uint64_t> group_sets;
-    uint32_t lds_bytes = 0;
-    Layout layout{};
+    uint32_t lds_bytes = 0;       // largest hot section among the staged tiles (what a fit block stages in LDS)
+    Layout L[kWClasses] = {};     // tile-image layout per row width (dictionary, staged batch, provisioned X rows)
+    uint32_t pitch = 0;           // bytes between tile images
+    uint32_t hp_rows = 2;
     uint32_t n_big_pods = 0;      // staged pods with more than 3 proc groups
+    uint32_t max_wcls = 0;        // widest tile class of the staged batch
 
     // requests / results
     DevBuf<nhdfit_req> reqs; uint32_t P = 0;
     std::vector<uint32_t> perm;          // device (class-sorted) position -> caller's pod index
     DevBuf<PodHeader> hdr[kBufs]; DevBuf<uint8_t> tabs[kBufs];
     DevBuf<unsigned long long> score[kBufs]; DevBuf<nhdfit_mapping> maps[kBufs];
-    DevBuf<uint64_t> bitmap;             // one buffer: the fit roles of consecutive steps run in stream order
-    DevBuf<uint64_t> cand;
+    DevBuf<uint64_t> nm;                 // node-major verdict words [tiles][chunks*64] (one buffer: the fit roles of consecutive steps run in stream order)
+    DevBuf<uint64_t> bitmap;             // pod-major rows [chunks][P], converted from `nm` on demand (fetch, mode B)
+    DevBuf<uint64_t> cand;               // [chunks] candidate nodes of the call
+    DevBuf<uint8_t> tile_wcls;           // row width class per staged tile
+    DevBuf<FitItem> items; uint32_t n_items = 0;   // work items of the fit role (blocks), heaviest tiles first
+    std::vector<uint8_t> h_tile_wcls;
     DevBuf<unsigned long long> shape_keys[kBufs]; DevBuf<uint32_t> shape_res[kBufs]; DevBuf<int32_t> shape_slot[kBufs];   // mapping dedup tables
     DevBuf<uint32_t> shape_list[kBufs];  // distinct shapes per tile
     DevBuf<AscEntry> asc;                // layouts of ascending-filled CPython sets (static table, built at creation)
     DevBuf<uint8_t> choose_tab;          // choose_tuples tabulated for U = 2, G <= 2 (static table, built at creation)
-    // node records (fit_core.h NodeRec): arithmetic checked on the host against node_lane(); the kernel variant has not
-    // run on a GPU yet - opt-in (NHDFIT_NODE_RECORDS=1) until it has been measured
-    DevBuf<NodeRec> rec; bool rec_valid = false;
-    bool use_node_records = getenv("NHDFIT_NODE_RECORDS") != nullptr;
+    // node records (fit_core.h NodeRec) + the class table behind their X rows; [rec_lo, rec_hi) = nodes whose records
+    // are stale (uploads, commits), rec_all = every record (dictionary / capacity / node count changed)
+    DevBuf<NodeRec> rec[kWClasses];
+    DevBuf<unsigned long long> xkeys; DevBuf<uint32_t> xids; DevBuf<uint64_t> xcls; DevBuf<uint32_t> xnx;
+    uint32_t rec_lo = 0, rec_hi = 0; bool rec_all = true;
+    uint32_t nx = 0, x_cap = kMinXCap;   // interned classes (as of the last record update) / provisioned X rows
+    uint32_t cpw[kWClasses] = {8, 6, 4, 2};   // chunks per wavefront of a fit block, per row width (NHDFIT_CPW="a,b,c,d")
     bool use_choose_tab = getenv("NHDFIT_NO_CHOOSE_TABLE") == nullptr;   // tuning aid: run the set model for every shape
     // set-layout state machine for three-group pods (set_states.h): verified against the model on the host
-    // (tests/test_pyset_emulation.py) and parity-green on the GPU, but not yet timed there - opt-in until it is
-    // (NHDFIT_SET_STATES=1)
+    // (tests/test_pyset_emulation.py), parity-green and 10 % faster per step on the GPU (profiles/r02):
+    // on by default, NHDFIT_NO_SET_STATES=1 runs the insertion-by-insertion model instead
     DevBuf<uint64_t> st_info; DevBuf<uint32_t> st_next, st_asc; uint32_t st_n = 0;
-    bool use_set_states = getenv("NHDFIT_SET_STATES") != nullptr;
+    bool use_set_states = getenv("NHDFIT_NO_SET_STATES") == nullptr;
     // mode B
     DevBuf<uint64_t> nogpu; DevBuf<int32_t> slot_of; DevBuf<OverlayNode> overlay; DevBuf<SeqResult> seq_out; DevBuf<uint32_t> order;
     bool use_cand = false, want_bitmap = true, want_map = true;
@@ -871,6 +1028,7 @@ int drain_events(nhdfit_ctx* c) {
 }
 
 int flush_pipeline(nhdfit_ctx* c);
+int refresh_layouts(nhdfit_ctx* c);
 
 int sync_all(nhdfit_ctx* c) {
     { int rc_ = flush_pipeline(c); if (rc_) return rc_; }      // pending mapping phases of the last steps
@@ -927,6 +1085,18 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
     for (auto& q : c->ev)
         for (auto& x : q)
             if (e == hipSuccess) e = hipEventCreate(&x);
+    if (e == hipSuccess) e = c->xkeys.reserve(kXSlots);
+    if (e == hipSuccess) e = c->xids.reserve(kXSlots);
+    if (e == hipSuccess) e = c->xcls.reserve(kXSlots / 2);
+    if (e == hipSuccess) e = c->xnx.reserve(2);
+    if (e == hipSuccess) e = hipMemsetAsync(c->xkeys.p, 0, kXSlots * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->xids.p, 0xFF, kXSlots * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->xnx.p, 0, 2 * sizeof(uint32_t), c->stream);
+    if (const char* cpw = getenv("NHDFIT_CPW")) {            // tuning aid
+        unsigned v[kWClasses];
+        if (sscanf(cpw, "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]) == 4)
+            for (int k = 0; k < kWClasses; ++k) c->cpw[k] = v[k] ? v[k] : 1;
+    }
     if (e == hipSuccess) e = c->asc.reserve(kAscEntries);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_build_asc, dim3((kAscEntries + 255) / 256), dim3(256), 0, c->stream, c->asc.p);
@@ -966,7 +1136,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
-    c->reqs.release(); c->bitmap.release(); c->cand.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->rec.release(); c->group_sets.release();
+    c->reqs.release(); c->bitmap.release(); c->nm.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); c->shape_list[b].release(); }
     c->nogpu.release(); c->slot_of.release(); c->overlay.release(); c->seq_out.release(); c->order.release();
     for (int b = 0; b < kBufs; ++b) {
@@ -1000,13 +1170,10 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     if (max_cores_per_numa < 1 || max_cores_per_numa > NHDFIT_MAX_CORES_PER_NUMA)
         return fail(c, NHDFIT_E_LIMIT, "%u cores per socket (supported: 1..%d)", max_cores_per_numa, NHDFIT_MAX_CORES_PER_NUMA);
     if (n_group_sets && !group_sets) return fail(c, NHDFIT_E_INVAL, "NULL group set table");
-    const Layout L = make_layout(max_cores_per_numa, max_gpus_per_numa, nsig, n_group_sets ? n_group_sets : 1, kMaxHpRows, kMaxG);
+    if (nsig > 0xFFFF) return fail(c, NHDFIT_E_LIMIT, "%u NIC signatures (max 65535)", nsig);
     HIPCHK(c, hipSetDevice(c->dev));
-    if (L.bytes + 4096 > 160 * 1024)
-        return fail(c, NHDFIT_E_LIMIT, "%u NIC signatures / %u node-group sets need %u bytes of LDS per tile (160 KiB per CU)",
-                    nsig, n_group_sets, L.bytes);
     { int rc_ = sync_all(c); if (rc_) return rc_; }
-    c->rec_valid = false;                               // node records depend on the mirror and on the table layout
+    c->rec_all = true;                                  // node records depend on the mirror and on the table layout
     HIPCHK(c, c->group_sets.reserve(n_group_sets ? n_group_sets : 1));
     if (n_group_sets) HIPCHK(c, hipMemcpy(c->group_sets.p, group_sets, n_group_sets * sizeof(uint64_t), hipMemcpyHostToDevice));
     else { const uint64_t zero = 0; HIPCHK(c, hipMemcpy(c->group_sets.p, &zero, sizeof zero, hipMemcpyHostToDevice)); }
@@ -1028,10 +1195,10 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     c->P = 0;                                       // staged tables (if any) were built for the old dictionary
     HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_only<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_only<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_role<512, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_role<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return NHDFIT_OK;
 }
 
@@ -1039,11 +1206,14 @@ int nhdfit_reserve_nodes(nhdfit_ctx* c, uint32_t capacity, uint64_t global_base)
     if (!c) return NHDFIT_E_INVAL;
     HIPCHK(c, hipSetDevice(c->dev));
     { int rc_ = sync_all(c); if (rc_) return rc_; }
-    c->rec_valid = false;                               // node records depend on the mirror and on the table layout
     if (capacity > c->capacity) {
         c->n = 0;                                   // growing drops the contents: the caller re-uploads
-        HIPCHK(c, c->p0.reserve(capacity)); HIPCHK(c, c->p1.reserve(capacity)); HIPCHK(c, c->p2.reserve(capacity));
-        HIPCHK(c, c->p3.reserve(capacity)); HIPCHK(c, c->p4.reserve(capacity)); HIPCHK(c, c->det.reserve(capacity));
+        c->rec_all = true;
+        const size_t padded = ((size_t)capacity + 63) & ~size_t(63);       // the fit role reads whole 64-node chunks
+        HIPCHK(c, c->p0.reserve(padded)); HIPCHK(c, c->p1.reserve(padded)); HIPCHK(c, c->p2.reserve(padded));
+        HIPCHK(c, c->p3.reserve(padded)); HIPCHK(c, c->p4.reserve(padded)); HIPCHK(c, c->det.reserve(capacity));
+        for (auto& r : c->rec) HIPCHK(c, r.reserve(padded));
+        HIPCHK(c, hipMemset(c->p4.p, 0, padded * sizeof(nhdfit_plane4)));   // busy times of the padding lanes: any finite value
         c->capacity = capacity;
     }
     c->global_base = global_base;
@@ -1056,7 +1226,8 @@ int nhdfit_set_node_count(nhdfit_ctx* c, uint32_t n) {
     if (n != c->n) {
         HIPCHK(c, hipSetDevice(c->dev));
         { int rc_ = sync_all(c); if (rc_) return rc_; }     // mapping phases of steps in flight still read the old count
-        c->rec_valid = false;
+        c->rec_all = true;                                  // the padding records of the last chunk move
+        c->n_items = 0;
         c->n = n;
     }
     return NHDFIT_OK;
@@ -1070,7 +1241,9 @@ int nhdfit_upload_nodes(nhdfit_ctx* c, uint32_t first, uint32_t count, const nhd
     if ((uint64_t)first + count > c->capacity) return fail(c, NHDFIT_E_INVAL, "upload [%u,%u) exceeds capacity %u", first, first + count, c->capacity);
     HIPCHK(c, hipSetDevice(c->dev));
     { int rc_ = sync_all(c); if (rc_) return rc_; }     // a step in flight must not see a half-written record
-    c->rec_valid = false;                               // node records depend on the mirror and on the table layout
+    if (first + count > c->n) { c->rec_all = true; c->n_items = 0; }   // the node count changes: the last chunk's padding moves
+    else if (c->rec_lo == c->rec_hi) { c->rec_lo = first; c->rec_hi = first + count; }
+    else { c->rec_lo = std::min(c->rec_lo, first); c->rec_hi = std::max(c->rec_hi, first + count); }
     HIPCHK(c, hipMemcpy(c->p0.p + first, p0, count * sizeof *p0, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->p1.p + first, p1, count * sizeof *p1, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->p2.p + first, p2, count * sizeof *p2, hipMemcpyHostToDevice));
@@ -1081,35 +1254,50 @@ int nhdfit_upload_nodes(nhdfit_ctx* c, uint32_t first, uint32_t count, const nhd
     return NHDFIT_OK;
 }
 
+namespace {
+// Tile-image layouts for the current dictionary, staged batch and provisioned X rows; (re)sizes the image buffers.
+int refresh_layouts(nhdfit_ctx* c) {
+    uint32_t pitch = 0, hot = 0;
+    for (uint32_t w = 0; w < (uint32_t)kWClasses; ++w) {
+        c->L[w] = make_layout(2u << w, c->max_cores, c->max_gpus, c->nsig, c->ngs, c->hp_rows, c->x_cap);
+        if (w <= c->max_wcls) { pitch = std::max(pitch, c->L[w].bytes); hot = std::max(hot, c->L[w].hot_bytes); }
+    }
+    if ((size_t)hot + 8 * 64 * sizeof(unsigned long long) > 160 * 1024)
+        return fail(c, NHDFIT_E_LIMIT, "the hot table section of a pod tile needs %u bytes of LDS (160 KiB per CU): %u node classes, "
+                    "%u node-group sets, %u hugepage rows", hot, c->nx, c->ngs, c->hp_rows);
+    c->pitch = pitch;
+    c->lds_bytes = hot;
+    if (c->P) {
+        const uint32_t tiles = (c->P + kTile - 1) / kTile;
+        for (int b = 0; b < kBufs; ++b) HIPCHK(c, c->tabs[b].reserve((size_t)tiles * pitch));
+    }
+    return NHDFIT_OK;
+}
+}  // namespace
+
 int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     if (!c) return NHDFIT_E_INVAL;
     if (!reqs || !P) return fail(c, NHDFIT_E_INVAL, "no requests");
     if (!c->nsig) return fail(c, NHDFIT_E_STATE, "set the dictionary first");
     HIPCHK(c, hipSetDevice(c->dev));
     { int rc_ = sync_all(c); if (rc_) return rc_; }
-    c->rec_valid = false;                               // node records depend on the mirror and on the table layout
     { int rc_ = drain_events(c); if (rc_) return rc_; }
     c->n_dig = c->n_fit = c->n_shaped = c->n_chosen = c->n_finished = 0;
     const uint32_t tiles = (P + kTile - 1) / kTile;
     int32_t hp_max = 0;
-    uint32_t g_max = 1;
     for (uint32_t p = 0; p < P; ++p) {
         if (reqs[p].hugepages_gb < 0) return fail(c, NHDFIT_E_INVAL, "pod %u asks for a negative number of hugepages", p);
         hp_max = reqs[p].hugepages_gb > hp_max ? reqs[p].hugepages_gb : hp_max;
-        if (req_valid(reqs[p]) && reqs[p].n_groups > g_max) g_max = reqs[p].n_groups;
     }
     if (hp_max > kMaxHpRows - 2)
         return fail(c, NHDFIT_E_LIMIT, "a pod asks for %d GiB of hugepages (limit %d)", hp_max, kMaxHpRows - 2);
-    c->layout = make_layout(c->max_cores, c->max_gpus, c->nsig, c->ngs, (uint32_t)hp_max + 2, g_max);
-    c->lds_bytes = c->layout.bytes;
     HIPCHK(c, c->reqs.reserve(P));
     for (int b = 0; b < kBufs; ++b) {
         HIPCHK(c, c->hdr[b].reserve((size_t)tiles * kTile));
-        HIPCHK(c, c->tabs[b].reserve((size_t)tiles * c->layout.bytes));
         HIPCHK(c, c->score[b].reserve(P));
         HIPCHK(c, c->maps[b].reserve(P));
     }
-    // Pods are staged sorted by request class so that 64-pod tiles are homogeneous (fast sweep of
+    // Pods are staged sorted by request class so that 64-pod tiles are homogeneous (narrow table rows, fast sweep of
     // the fit role) and the lanes of the mapping roles have similar group counts; results are un-permuted in fetch.
     c->perm.resize(P);
     std::vector<uint32_t> key(P);
@@ -1127,23 +1315,109 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     std::vector<nhdfit_req> sorted(P);
     for (uint32_t i = 0; i < P; ++i) sorted[i] = reqs[c->perm[i]];
     HIPCHK(c, hipMemcpy(c->reqs.p, sorted.data(), (size_t)P * sizeof *reqs, hipMemcpyHostToDevice));
+    // row width class of every tile: 2^(largest group count among its valid pods) assignments - the digest role
+    // derives the same class from the same records
+    c->h_tile_wcls.assign(tiles, 0);
+    c->max_wcls = 0;
+    for (uint32_t i = 0; i < P; ++i)
+        if (req_valid(sorted[i])) {
+            const uint8_t w = (uint8_t)wclass_of(sorted[i].n_groups);
+            if (w > c->h_tile_wcls[i / kTile]) c->h_tile_wcls[i / kTile] = w;
+            if (w > c->max_wcls) c->max_wcls = w;
+        }
+    HIPCHK(c, c->tile_wcls.reserve(tiles));
+    HIPCHK(c, hipMemcpy(c->tile_wcls.p, c->h_tile_wcls.data(), tiles, hipMemcpyHostToDevice));
     c->P = P;
+    c->hp_rows = (uint32_t)hp_max + 2;
+    c->n_items = 0;                                 // the fit role's work items are rebuilt at the next step
     c->use_cand = false;
-    return NHDFIT_OK;
+    return refresh_layouts(c);
 }
 
 static int stage_cand(nhdfit_ctx* c, const uint64_t* cand) {
-    const size_t chunks = (c->n + 63) / 64, words = chunks * c->P;
-    HIPCHK(c, c->cand.reserve(words ? words : 1));
-    std::vector<uint64_t> tmp(words);
-    for (size_t ch = 0; ch < chunks; ++ch)
-        for (uint32_t i = 0; i < c->P; ++i) tmp[ch * c->P + i] = cand[ch * c->P + c->perm[i]];
-    HIPCHK(c, hipMemcpy(c->cand.p, tmp.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    const size_t chunks = (c->n + 63) / 64;
+    HIPCHK(c, c->cand.reserve(chunks ? chunks : 1));
+    HIPCHK(c, hipMemcpy(c->cand.p, cand, chunks * sizeof(uint64_t), hipMemcpyHostToDevice));
     c->use_cand = true;
     return NHDFIT_OK;
 }
 
 namespace {
+
+// Bring the node records (and the class table behind their X rows) up to date with the mirror.  Cheap no-op when
+// nothing changed; otherwise three small kernels over the touched nodes and one 8-byte read-back (the host sizes the
+// tile images by the class count).  A grown class count or a changed dictionary re-does every record.
+int ensure_records(nhdfit_ctx* c) {
+    if (!c->rec_all && c->rec_lo == c->rec_hi) return NHDFIT_OK;
+    if (!c->n) { c->rec_all = false; c->rec_lo = c->rec_hi = 0; return NHDFIT_OK; }
+    const uint32_t npad = (c->n + 63) & ~63u;
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint32_t first = c->rec_all ? 0 : c->rec_lo, count = c->rec_all ? npad : c->rec_hi - c->rec_lo;
+        RecArgs r;
+        memset(&r, 0, sizeof r);
+        r.p0 = c->p0.p; r.p1 = c->p1.p; r.p2 = c->p2.p; r.p3 = c->p3.p; r.p4 = c->p4.p;
+        r.n = c->n; r.npad = npad; r.first = first; r.count = count;
+        r.fc_dim = c->max_cores + 1; r.fg_dim = c->max_gpus + 1; r.ngs = c->ngs;
+        r.x = XTable{c->xkeys.p, c->xids.p, c->xcls.p, c->xnx.p};
+        for (int w = 0; w < kWClasses; ++w) {
+            // records hold hot-section offsets: they depend on the dictionary and the provisioned X rows, not on the batch
+            r.L[w] = make_layout(2u << w, c->max_cores, c->max_gpus, c->nsig, c->ngs, 2, c->x_cap);
+            r.rec[w] = c->rec[w].p;
+        }
+        const dim3 grid((count + 255) / 256), block(256);
+        if (pass == 0) {
+            hipLaunchKernelGGL(k_xkeys, grid, block, 0, c->stream, r);
+            hipLaunchKernelGGL(k_xassign, dim3(1), dim3(1024), 0, c->stream, r.x);
+        }
+        hipLaunchKernelGGL(k_xrecords, grid, block, 0, c->stream, r);
+        HIPCHK(c, hipGetLastError());
+        if (pass == 1) break;
+        uint32_t nx[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(nx, c->xnx.p, sizeof nx, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (nx[1] || nx[0] > kXSlots / 2) return fail(c, NHDFIT_E_LIMIT, "more than %u distinct (free GPUs, NIC signature) node classes", kXSlots / 2);
+        c->nx = nx[0];
+        if (nx[0] <= c->x_cap) break;
+        // more classes than provisioned rows: every hot-section offset moves -> staged tables and all records are redone
+        { int rc_ = sync_all(c); if (rc_) return rc_; }
+        c->x_cap = x_capacity(nx[0]);
+        c->rec_all = true;
+        c->n_dig = c->n_fit;
+        int rc = refresh_layouts(c);
+        if (rc) return rc;
+    }
+    c->rec_all = false;
+    c->rec_lo = c->rec_hi = 0;
+    return NHDFIT_OK;
+}
+
+// Work items of the fit role: every tile's chunks cut into runs of (waves per block) x (chunks per wavefront of its
+// row width); wide tiles first (longest-first keeps the tail of the launch short).  Small problems get shorter
+// runs so that the grid still covers the chip.
+int build_items(nhdfit_ctx* c, uint32_t nw) {
+    const uint32_t tiles = (c->P + kTile - 1) / kTile, chunks = (c->n + 63) / 64;
+    const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
+    uint32_t shrink = 1;
+    for (;;) {
+        uint64_t blocks = 0;
+        for (uint32_t t = 0; t < tiles; ++t) {
+            const uint32_t run = nw * std::max(1u, c->cpw[c->h_tile_wcls[t]] / shrink);
+            blocks += (chunks + run - 1) / run;
+        }
+        if (blocks >= 2ull * cus || shrink >= 8) break;
+        shrink *= 2;
+    }
+    std::vector<FitItem> items;
+    for (uint32_t t = 0; t < tiles; ++t) {           // staged order = widest tiles first
+        const uint32_t w = c->h_tile_wcls[t], run = nw * std::max(1u, c->cpw[w] / shrink);
+        for (uint32_t b = 0; b < chunks; b += run) items.push_back(FitItem{t, w, b, std::min(chunks, b + run)});
+    }
+    HIPCHK(c, c->items.reserve(items.size() ? items.size() : 1));
+    HIPCHK(c, hipMemcpyAsync(c->items.p, items.data(), items.size() * sizeof(FitItem), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // `items` is a local
+    c->n_items = (uint32_t)items.size();
+    return NHDFIT_OK;
+}
 
 // One launch of the step kernel with every role that has work (see k_step).  `with_fit`: the fit role for step
 // n_fit plus the digest of step n_fit + 1; `flushing`: nothing new will follow, drain the mapping phases.
@@ -1153,14 +1427,21 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
     const bool big = c->geom_big;
     const uint32_t block = big ? 512 : 256, nw = block / 64;
     const bool small_map = c->want_map && c->n_big_pods < P;
+    if (with_fit || with_digest) { int rc_ = ensure_records(c); if (rc_) return rc_; }
 
     StepArgs a;
     memset(&a, 0, sizeof a);
     a.shapes_P = P;
     a.side_prio = c->side_prio;
     auto map_args = [&](int b) {
-        return MapArgs{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->det.p, c->tabs[b].p, c->layout, c->n,
-                       c->global_base, c->reqs.p, P, c->score[b].p, c->caps.p, c->maps[b].p};
+        MapArgs m;
+        memset(&m, 0, sizeof m);
+        m.p0 = c->p0.p; m.p1 = c->p1.p; m.p2 = c->p2.p; m.p3 = c->p3.p; m.det = c->det.p;
+        m.tabs = c->tabs[b].p; m.pitch = c->pitch; m.tile_wcls = c->tile_wcls.p;
+        for (int w = 0; w < kWClasses; ++w) m.L[w] = c->L[w];
+        m.n = c->n; m.global_base = c->global_base; m.reqs = c->reqs.p; m.P = P;
+        m.score = c->score[b].p; m.caps = c->caps.p; m.out = c->maps[b].p;
+        return m;
     };
     auto shape_args = [&](int b) {
         return ShapeArgs{c->shape_keys[b].p, c->shape_res[b].p, c->shape_slot[b].p, c->shape_list[b].p, c->asc.p,
@@ -1194,45 +1475,35 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
     with_digest = with_digest && c->n_dig <= c->n_fit + (with_fit ? 1 : 0) + (c->split ? 1 : 0);   // at most one step ahead of the fit
     if (with_digest) {
         const int b = (int)(c->n_dig % kBufs);                              // the next undigested step
-        a.digest = DigestArgs{c->reqs.p, P,
-                              DictView{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}},
-                              c->layout, c->tabs[b].p, c->hdr[b].p, c->score[b].p,
-                              c->digest_parts};
-        a.nb_digest = tiles * c->digest_parts;
+        DigestArgs& d = a.digest;
+        d.reqs = c->reqs.p; d.P = P;
+        d.d = DictView{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}};
+        for (int w = 0; w < kWClasses; ++w) d.L[w] = c->L[w];
+        d.pitch = c->pitch; d.tabs = c->tabs[b].p; d.hdr = c->hdr[b].p; d.score = c->score[b].p;
+        d.xcls = c->xcls.p; d.nx = c->xnx.p;
+        a.nb_digest = tiles * kDigestParts;
     }
     uint32_t nb_fit = 0;
     int bf = -1;
     if (with_fit) {
         bf = (int)(c->n_fit % kBufs);
-        if (c->want_bitmap) HIPCHK(c, c->bitmap.reserve((size_t)chunks * P));
+        if (c->want_bitmap) HIPCHK(c, c->nm.reserve((size_t)tiles * chunks * 64));
+        if (!c->n_items) { int rc_ = build_items(c, nw); if (rc_) return rc_; }
         FitArgs& f = a.fit;
-        f.p0 = c->p0.p; f.p1 = c->p1.p; f.p2 = c->p2.p; f.p3 = c->p3.p; f.p4 = c->p4.p;
-        f.rec = nullptr;
-        f.n = c->n; f.chunks = chunks; f.global_base = c->global_base; f.now = now;
-        f.tabs = c->tabs[bf].p; f.layout = c->layout; f.hdr = c->hdr[bf].p; f.P = P;
+        for (int w = 0; w < kWClasses; ++w) { f.rec[w] = c->rec[w].p; f.L[w] = c->L[w]; }
+        f.p4 = c->p4.p;
+        f.n = c->n; f.chunks = chunks; f.global_base = c->global_base; f.busy_from = busy_threshold(now);
+        f.tabs = c->tabs[bf].p; f.pitch = c->pitch; f.hdr = c->hdr[bf].p; f.P = P;
         f.cand = c->use_cand ? c->cand.p : nullptr;
-        f.bitmap = c->want_bitmap ? c->bitmap.p : nullptr;
+        f.nm = c->want_bitmap ? c->nm.p : nullptr;
         f.score = c->score[bf].p;
-        const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
-        uint32_t cpb = nw;                                                   // chunks per block: >= 1 per wave
-        while ((uint64_t)tiles * ((chunks + cpb * 2 - 1) / (cpb * 2)) >= 8ull * cus && cpb < nw * 8) cpb *= 2;
-        f.chunks_per_block = cpb;
-        f.nranges = (chunks + cpb - 1) / cpb;
-        nb_fit = tiles * f.nranges;
-        if (c->use_node_records) {
-            if (!c->rec_valid) {                                   // mirror or layout changed since the records were built
-                HIPCHK(c, c->rec.reserve(c->capacity ? c->capacity : c->n));
-                hipLaunchKernelGGL(k_node_records, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, f, c->rec.p);
-                HIPCHK(c, hipGetLastError());
-                c->rec_valid = true;
-            }
-            f.rec = c->rec.p;
-        }
+        f.items = c->items.p;
+        nb_fit = c->n_items;
     }
     const uint32_t grid = a.nb_choose + a.nb_shapes + a.nb_finish + a.nb_digest + nb_fit;
     if (!grid) return NHDFIT_OK;
     // dynamic LDS of the launch: the largest need among the roles present
-    size_t lds = nb_fit ? lds_slice(c->layout.bytes) + (size_t)nw * 64 * sizeof(unsigned long long) : 0;
+    size_t lds = nb_fit ? lds_slice(c->lds_bytes) + (size_t)nw * 64 * sizeof(unsigned long long) : 0;
     if (a.nb_digest && kDigestLds > lds) lds = kDigestLds;
 
     // HIP-event timing is sampled (every 8th fit launch; every digest-only launch)
@@ -1247,16 +1518,20 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
     const bool timed = (with_fit && (c->n_fit < 2 || (c->n_fit & 7) == 0)) || (!with_fit && with_digest);
     if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc) return rc; }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][0], c->stream));
+    if (c->role_kernels) {
+        const uint32_t nb[5] = {a.nb_choose, a.nb_shapes, a.nb_finish, a.nb_digest, nb_fit};
+        if (nb[0]) hipLaunchKernelGGL((k_role<512, 0>), dim3(nb[0]), dim3(512), 0, c->stream, a);
+        if (nb[1]) hipLaunchKernelGGL((k_role<512, 1>), dim3(nb[1]), dim3(512), 0, c->stream, a);
+        if (nb[2]) hipLaunchKernelGGL((k_role<512, 2>), dim3(nb[2]), dim3(512), 0, c->stream, a);
+        if (nb[3]) hipLaunchKernelGGL((k_role<512, 3>), dim3(nb[3]), dim3(512), kDigestLds, c->stream, a);
+        if (nb[4]) hipLaunchKernelGGL((k_role<512, 4>), dim3(nb[4]), dim3(512), lds, c->stream, a);
+    } else
     if (grid == nb_fit && c->split) {
         if (big) hipLaunchKernelGGL((k_fit_only<512>), dim3(grid), dim3(512), lds, c->stream, a.fit);
         else     hipLaunchKernelGGL((k_fit_only<256>), dim3(grid), dim3(256), lds, c->stream, a.fit);
     } else
-    if (a.fit.rec) {
-        if (big) hipLaunchKernelGGL((k_step<512, true>), dim3(grid), dim3(512), lds, c->stream, a);
-        else     hipLaunchKernelGGL((k_step<256, true>), dim3(grid), dim3(256), lds, c->stream, a);
-    } else
-    if (big) hipLaunchKernelGGL((k_step<512, false>), dim3(grid), dim3(512), lds, c->stream, a);
-    else     hipLaunchKernelGGL((k_step<256, false>), dim3(grid), dim3(256), lds, c->stream, a);
+    if (big) hipLaunchKernelGGL((k_step<512>), dim3(grid), dim3(512), lds, c->stream, a);
+    else     hipLaunchKernelGGL((k_step<256>), dim3(grid), dim3(256), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
@@ -1294,13 +1569,23 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         // no mapping roles for this step (output switched off, or only 4-group pods): nothing to catch up on later
         if (!small_map) c->n_shaped = c->n_chosen = c->n_finished = c->n_fit;
         c->stats.evals_last = (uint64_t)P * c->n;
-        // algorithmic bytes of the fit role: every tile streams the five node planes once,
-        // every block stages its tile image once, plus the bitmap and the score words.
-        c->stats.bytes_last = (uint64_t)tiles * c->n * 80ull + (uint64_t)nb_fit * c->lds_bytes +
-                              (c->want_bitmap ? (uint64_t)chunks * P * 8ull : 0ull) + (uint64_t)P * 8ull +
-                              (c->use_cand ? (uint64_t)chunks * P * 8ull : 0ull);
+        // algorithmic bytes of the step, SURVEY.md section 8(d): ceil(P/T) * N * B_node + P * B_req + P * N / 8 + 8 * P
+        // with T = 64 pods per tile, B_node = 24 (the 16-byte node record + the 8-byte busy time every tile streams),
+        // B_req = 128; the P * N / 8 term is the node-major verdict matrix (dropped when that output is switched off)
+        c->stats.bytes_last = (uint64_t)tiles * c->n * 24ull + (uint64_t)P * sizeof(nhdfit_req) +
+                              (c->want_bitmap ? (uint64_t)tiles * chunks * 64ull * 8ull : 0ull) + (uint64_t)P * 8ull;
         c->stats.nodes = c->n; c->stats.nsig = c->nsig; c->stats.ncls = c->ncls; c->stats.lds_bytes = c->lds_bytes;
     }
+    return NHDFIT_OK;
+}
+
+// pod-major rows [chunks][P] of the last step's verdict matrix (stream-ordered after the step that produced it)
+int convert_rows(nhdfit_ctx* c) {
+    const uint32_t chunks = (c->n + 63) / 64, tiles = (c->P + kTile - 1) / kTile;
+    HIPCHK(c, c->bitmap.reserve((size_t)chunks * c->P));
+    hipLaunchKernelGGL(k_rows, dim3((tiles * chunks + 3) / 4), dim3(256), 0, c->stream, c->nm.p, c->bitmap.p, chunks, c->P);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return NHDFIT_OK;
 }
 
@@ -1325,6 +1610,8 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
         // others' sweep), 256-thread blocks for small problems so that the grid still covers the chip
         const uint32_t tiles = (c->P + kTile - 1) / kTile, chunks = (c->n + 63) / 64;
         c->geom_big = (uint64_t)tiles * ((chunks + 31) / 32) >= (uint32_t)c->prop.multiProcessorCount;
+        if (const char* b = getenv("NHDFIT_BLOCK")) c->geom_big = atoi(b) >= 512;      // tuning aid
+        if (c->role_kernels) c->geom_big = true;
     }
     if (c->n_dig <= c->n_fit) {                      // first step after staging: its digest has not run yet
         int rc = launch_step(c, false, true, now, false);
@@ -1360,6 +1647,7 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
     if (bitmap_out) {
         if (!c->want_bitmap) return fail(c, NHDFIT_E_STATE, "bitmap output is disabled");
         const size_t chunks = (c->n + 63) / 64;
+        { int rc_ = convert_rows(c); if (rc_) return rc_; }
         std::vector<uint64_t> tmp(chunks * P);
         HIPCHK(c, hipMemcpy(tmp.data(), c->bitmap.p, chunks * P * 8, hipMemcpyDeviceToHost));
         for (size_t ch = 0; ch < chunks; ++ch)
@@ -1396,6 +1684,7 @@ int nhdfit_find_sequential(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, do
     c->want_bitmap = wb; c->want_map = wm;
     if (rc) return rc;
     if ((rc = flush_pipeline(c))) return rc;                  // the resolver starts from the snapshot mappings
+    if ((rc = convert_rows(c))) return rc;                    // ... and walks pod-major rows of the snapshot verdicts
     const int b = (int)((c->n_fit - 1) % kBufs);
     const uint32_t chunks = (c->n + 63) / 64;
     HIPCHK(c, c->nogpu.reserve(chunks));

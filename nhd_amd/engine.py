@@ -79,7 +79,7 @@ class Engine:
         maps = np.zeros(P, pack.MAPPING) if want_map else None
         if cand is not None:
             cand = np.ascontiguousarray(cand, dtype=np.uint64)
-            assert cand.shape == ((self.n + 63) // 64, P)
+            assert cand.shape == ((self.n + 63) // 64,)
         self._chk(self.lib.nhdfit_find(self.ctx, _p(reqs), P, float(now), _p(cand), _p(score), _p(bitmap), _p(maps)))
         self.P = P
         return score, bitmap, maps

@@ -147,8 +147,8 @@ class HipMatcher:
             lo = hi + 1
         self._dirty.clear()
 
-    def _candidates(self, nl: Dict[str, object], P: int) -> Optional[np.ndarray]:
-        """Bitmask [chunks][P] of the attached nodes that are in `nl`; None when nl is everything."""
+    def _candidates(self, nl: Dict[str, object]) -> Optional[np.ndarray]:
+        """Bitmask [chunks] (bit = node) of the attached nodes that are in `nl`; None when nl is everything."""
         n = len(self._names)
         if len(nl) == n and list(nl) == self._names:          # C-speed comparison (identical str objects short-cut)
             return None
@@ -157,8 +157,7 @@ class HipMatcher:
             raise ValueError("FindNode: `nl` must keep the relative order of the attached node dict")
         bits = np.zeros(((n + 63) // 64) * 64, dtype=bool)
         bits[idx] = True
-        words = np.packbits(bits.reshape(-1, 64), axis=1, bitorder="little").view("<u8").reshape(-1)
-        return np.ascontiguousarray(np.repeat(words[:, None], P, axis=1))
+        return np.ascontiguousarray(np.packbits(bits.reshape(-1, 64), axis=1, bitorder="little").view("<u8").reshape(-1))
 
     # ---- the reference interface ----------------------------------------------------------
     def FindNode(self, nl: Dict[str, object], top) -> Tuple:
@@ -218,7 +217,7 @@ class HipMatcher:
         cand = None
         if self._attached is not None and all(k in self._index for k in nl):
             self._flush_dirty()
-            cand = self._candidates(nl, n_pods)
+            cand = self._candidates(nl)
         else:
             self._full_upload(nl)
         if reqs is None:

@@ -42,12 +42,14 @@ def find(packer: pack.Packer, table: pack.NodeTable, reqs: np.ndarray, now: floa
     bitmap = np.zeros((chunks, P), np.uint64) if want_bitmap else None
     maps = np.zeros(P, pack.MAPPING) if want_map else None
     reqs = np.ascontiguousarray(reqs)
-    L.hh_find(_p(table.p0), _p(table.p1), _p(table.p2), _p(table.p3), _p(table.p4), _p(table.detail),
+    L.hh_find.restype = ctypes.c_int
+    bad = L.hh_find(_p(table.p0), _p(table.p1), _p(table.p2), _p(table.p3), _p(table.p4), _p(table.detail),
               ctypes.c_uint32(n), ctypes.c_uint64(global_base), _p(reqs), ctypes.c_uint32(P), ctypes.c_double(now),
               ctypes.c_uint32(packer.max_cores_per_numa), ctypes.c_uint32(fgmax),
               _p(gs), ctypes.c_uint32(len(packer.group_sets)), _p(caps), ctypes.c_uint32(ncls), _p(sig_off), ctypes.c_uint32(nsig), _p(pool_off), _p(glimit), _p(cc),
               _p(cand) if cand is not None else None, _p(score), _p(bitmap) if want_bitmap else None,
               _p(maps) if want_map else None, ctypes.c_int(int(force_generic)))
+    assert bad == 0, f"{bad} (node, tile) verdicts differ between the hot and the cold table section / the two forms of IsBusy"
     return score, bitmap, maps
 
 

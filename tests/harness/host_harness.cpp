@@ -2,12 +2,15 @@
 // (nhd_amd/csrc/fit_core.h, winner_map.h) for the host so that `pytest -m "not gpu"` can check the
 // table construction, the per-pair predicate, the selection word and the CPython set model against
 // the oracle without a GPU.  It is NOT part of libnhdfit.so and nothing in nhd_amd/ loads it.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 #include "../../nhd_amd/csrc/seq_core.h"
 #include "../../nhd_amd/csrc/set_states.h"
 
 using namespace nhdfit;
+
+#include <map>
 
 namespace {
 struct Dict {
@@ -17,91 +20,137 @@ struct Dict {
     SigDict sig;
 };
 
-// table image of one tile (up to 64 pods), same bytes the digest kernel produces
-void build_tile(const nhdfit_req* reqs, uint32_t npods, const Dict& d, const Layout& L, uint8_t* img, PodHeader* hdr) {
+// table image of one tile (up to 64 pods): the bytes the digest role produces, built pod by pod
+void build_tile(const nhdfit_req* reqs, uint32_t npods, const Dict& d, const Layout& L, const std::vector<uint64_t>& xcls,
+                uint8_t* img, PodHeader* hdr) {
     std::memset(img, 0, L.bytes);
     std::vector<uint16_t> cover(d.ncls * (kMaxG + 1));
+    uint8_t* hot = img + L.off_hot;
+    auto set_bits = [&](uint8_t* row, uint32_t v, uint32_t j) {
+        for (uint32_t p = 0; p < L.W; ++p)
+            if (v >> p & 1) *reinterpret_cast<uint64_t*>(row + p * 8) |= 1ull << j;
+    };
+    uint64_t m_pci = 0;
     for (uint32_t j = 0; j < (uint32_t)kTile; ++j) {
         nhdfit_req r;
         if (j < npods) r = reqs[j]; else std::memset(&r, 0, sizeof r);
         hdr[j] = pod_header(r);
+        if (hdr[j].flags & kPodPci) m_pci |= 1ull << j;
         for (uint32_t k = 0; k < L.hp_rows; ++k)
-            if (hp_bit(hdr[j], L, k)) *reinterpret_cast<uint64_t*>(img + L.off_hp + 8 * k) |= 1ull << j;
-        for (uint32_t g = 0; g < L.ngs; ++g)
-            if (gf_bit(hdr[j], d.gs[g])) *reinterpret_cast<uint64_t*>(img + L.off_gf + 8 * g) |= 1ull << j;
+            if (hp_bit(hdr[j], k)) *reinterpret_cast<uint64_t*>(hot + L.hot_hp + 8 * k) |= 1ull << j;
+        for (uint32_t g = 0; g < 1 + 2 * L.ngs; ++g)
+            if (gx_bit(hdr[j], g, d.gs)) *reinterpret_cast<uint64_t*>(hot + L.hot_gx + 8 * g) |= 1ull << j;
         if (!(hdr[j].flags & kPodValid)) continue;
         PodSums s;
         pod_sums(r, s);
         for (uint32_t c = 0; c < d.ncls; ++c) class_cover(r, d.caps[c], s.W, s.G, &cover[c * (kMaxG + 1)]);
-        for (uint32_t row = 0; row < L.rows16; ++row) {
-            const uint32_t v = row16_entry(L, s, d.sig, cover.data(), row);
-            for (uint32_t p = 0; p < L.W; ++p)
-                if (v >> p & 1) *reinterpret_cast<uint64_t*>(img + row * L.row_bytes + p * 8) |= 1ull << j;
+        for (uint32_t u = 0; u < 2; ++u)
+            for (uint32_t smt = 0; smt < 2; ++smt)
+                for (uint32_t c = 0; c < L.fc_dim; ++c)
+                    for (uint32_t m = 0; m < 2; ++m)
+                        set_bits(hot + (u ? L.hot_wc1 : L.hot_wc0) + (smt * L.fc_dim + c) * L.wc_stride + m * L.row, entry_w(s, u, smt, c, m), j);
+        for (uint32_t u = 0; u < 2; ++u)
+            for (uint32_t f = 0; f < L.fg_dim; ++f) set_bits(img + (u ? L.off_a1 : L.off_a0) + f * L.row, entry_a(s, u, f), j);
+        for (uint32_t sig = 0; sig < L.nsig; ++sig) {
+            const uint32_t reach = sig_reach(d.sig, sig, cover.data(), s.W);
+            set_bits(img + L.off_r0 + sig * L.row, entry_r(reach, s.W, 0), j);
+            set_bits(img + L.off_r1 + sig * L.row, entry_r(reach, s.W, 1), j);
         }
     }
+    for (uint32_t k = 0; k < xcls.size(); ++k)
+        for (uint32_t p = 0; p < L.W; ++p) {
+            const uint64_t key = xcls[k];
+            const uint32_t u = xkey_u(key);
+            const uint64_t av = ld64(img, (u ? L.off_a1 : L.off_a0) + xkey_f(key) * L.row + p * 8);
+            const uint64_t rn = ld64(img, (u ? L.off_r1 : L.off_r0) + xkey_sig_numa(key) * L.row + p * 8);
+            const uint64_t rp = ld64(img, (u ? L.off_r1 : L.off_r0) + xkey_sig_pci(key) * L.row + p * 8);
+            *reinterpret_cast<uint64_t*>(hot + L.hot_x + k * L.x_stride + p * 8) = av & ((rp & m_pci) | (rn & ~m_pci));
+        }
 }
 }  // namespace
 
 extern "C" {
 
-// CPU twin of nhdfit_find (mode A), same outputs, chunk-major bitmap [ceil(n/64)][P].
-void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
-             const nhdfit_plane4* p4, const nhdfit_detail* det, uint32_t n, uint64_t global_base,
-             const nhdfit_req* reqs, uint32_t P, double now, uint32_t fcmax, uint32_t fgmax,
-             const uint64_t* gs, uint32_t ngs, const double* caps, uint32_t ncls,
-             const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit,
-             const nhdfit_cc* cc, const uint64_t* cand, uint64_t* score, uint64_t* bitmap, nhdfit_mapping* maps,
-             int force_generic) {
+// CPU twin of nhdfit_find (mode A), same outputs, chunk-major bitmap [ceil(n/64)][P].  cand: [chunks] node mask.
+// Returns the number of (node, tile) pairs whose hot-section verdict differs from the cold-section one (must be 0).
+int hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
+            const nhdfit_plane4* p4, const nhdfit_detail* det, uint32_t n, uint64_t global_base,
+            const nhdfit_req* reqs, uint32_t P, double now, uint32_t fcmax, uint32_t fgmax,
+            const uint64_t* gs, uint32_t ngs, const double* caps, uint32_t ncls,
+            const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit,
+            const nhdfit_cc* cc, const uint64_t* cand, uint64_t* score, uint64_t* bitmap, nhdfit_mapping* maps,
+            int force_generic) {
     const uint32_t chunks = (n + 63) / 64;
     int32_t hpmax = 0;
-    uint32_t gmax = 1;
-    for (uint32_t p = 0; p < P; ++p) {
-        hpmax = reqs[p].hugepages_gb > hpmax ? reqs[p].hugepages_gb : hpmax;
-        if (req_valid(reqs[p]) && reqs[p].n_groups > gmax) gmax = reqs[p].n_groups;
-    }
+    for (uint32_t p = 0; p < P; ++p) hpmax = reqs[p].hugepages_gb > hpmax ? reqs[p].hugepages_gb : hpmax;
     const Dict d{fcmax, fgmax, gs, ngs, caps, ncls, SigDict{sig_off, pool_off, pool_glimit, cc, nsig}};
-    const Layout L = make_layout(fcmax, fgmax, nsig, ngs, (uint32_t)hpmax + 2, gmax);
-    std::vector<uint8_t> img(L.bytes);
+    // node classes, interned in node order (the device interns them in a hash table: the ids differ, the rows do not)
+    std::map<uint64_t, uint32_t> xid;
+    std::vector<uint64_t> xcls;
+    std::vector<NodeIdx> nidx(n);
+    std::vector<uint32_t> x0(n), x1(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        nidx[i] = node_index(p0[i], p1[i], p2[i], p4[i], fcmax + 1, fgmax + 1, ngs);
+        for (uint32_t u = 0; u < 2; ++u) {
+            const uint64_t key = xkey(u, u ? nidx[i].f1 : nidx[i].f0, p3[i].sig_numa[u], p3[i].sig_pci[u]);
+            auto it = xid.find(key);
+            if (it == xid.end()) { it = xid.emplace(key, (uint32_t)xcls.size()).first; xcls.push_back(key); }
+            (u ? x1 : x0)[i] = it->second;
+        }
+    }
+    const uint32_t x_cap = x_capacity((uint32_t)xcls.size());
+    const double busy_from = busy_threshold(now);
+    int mismatches = 0;
+    std::vector<uint8_t> img;
     std::vector<PodHeader> hdr(kTile);
-    for (uint32_t p = 0; p < P; ++p) score[p] = 0;
+    std::vector<uint8_t> tile_wcls((P + kTile - 1) / kTile, 0);
+    for (uint32_t p = 0; p < P; ++p) {
+        score[p] = 0;
+        if (req_valid(reqs[p])) tile_wcls[p / kTile] = std::max<uint8_t>(tile_wcls[p / kTile], (uint8_t)wclass_of(reqs[p].n_groups));
+    }
     for (uint32_t t0 = 0; t0 < P; t0 += kTile) {
         const uint32_t np = P - t0 < (uint32_t)kTile ? P - t0 : kTile;
-        build_tile(reqs + t0, np, d, L, img.data(), hdr.data());
-        uint64_t m_filt = 0, m_need = 0, m_pci = 0;
+        const Layout L = make_layout(2u << tile_wcls[t0 / kTile], fcmax, fgmax, nsig, ngs, (uint32_t)hpmax + 2, x_cap);
+        img.assign(L.bytes, 0);
+        build_tile(reqs + t0, np, d, L, xcls, img.data(), hdr.data());
+        uint64_t m_need = 0, m_pci = 0;
         for (uint32_t j = 0; j < np; ++j) {
-            if (hdr[j].flags & kPodFilter) m_filt |= 1ull << j;
             if (hdr[j].flags & kPodNeedGpu) m_need |= 1ull << j;
             if (hdr[j].flags & kPodPci) m_pci |= 1ull << j;
         }
         for (uint32_t c = 0; c < chunks; ++c) {
             uint64_t nogpu = 0;
-            NodeLane lanes[64];
             uint64_t fm[64];
             const uint32_t cnt = n - c * 64 < 64 ? n - c * 64 : 64;
             for (uint32_t l = 0; l < cnt; ++l) {
                 const uint32_t i = c * 64 + l;
-                lanes[l] = node_lane(p0[i], p1[i], p2[i], p3[i], p4[i], now, L);
-                fm[l] = node_pod_mask(lanes[l], img.data(), m_filt, m_need) &
-                        node_assignment_mask(lanes[l], img.data(), L.W, m_pci);
-                if (!(p2[i].flags & NHDFIT_NF_HAS_GPU)) nogpu |= 1ull << l;
+                const bool busy = p4[i].busy_time >= busy_from;
+                if (busy != ((now - p4[i].busy_time) < kMinBusySecs)) ++mismatches;      // the threshold form of IsBusy
+                const NodeRec rec = make_record(nidx[i], x0[i], x1[i], L);
+                fm[l] = node_word_hot(img.data() + L.off_hot, L, rec, busy, m_need);
+                if (fm[l] != node_word_cold(img.data(), L, nidx[i], p3[i], busy, m_need, m_pci)) ++mismatches;
+                if (cand && !(cand[c] >> l & 1)) fm[l] = 0;
+                if (nidx[i].nogpu) nogpu |= 1ull << l;
             }
             for (uint32_t j = 0; j < np; ++j) {
                 uint64_t w = 0;
                 for (uint32_t l = 0; l < cnt; ++l)
                     if (fm[l] >> j & 1) w |= 1ull << l;
-                if (cand) w &= cand[(size_t)c * P + t0 + j];
                 if (bitmap) bitmap[(size_t)c * P + t0 + j] = w;
                 const uint64_t s = chunk_score(w, nogpu, hdr[j].flags & kPodNeedGpu, global_base + (uint64_t)c * 64);
                 if (s > score[t0 + j]) score[t0 + j] = s;
             }
         }
     }
-    if (!maps) return;
+    if (!maps) return mismatches;
+    Layout L{};
     for (uint32_t p = 0; p < P; ++p) {
         std::memset(&maps[p], 0, sizeof(nhdfit_mapping));
         if (p % kTile == 0) {
             const uint32_t np = P - p < (uint32_t)kTile ? P - p : kTile;
-            build_tile(reqs + p, np, d, L, img.data(), hdr.data());
+            L = make_layout(2u << tile_wcls[p / kTile], fcmax, fgmax, nsig, ngs, (uint32_t)hpmax + 2, x_cap);
+            img.assign(L.bytes, 0);
+            build_tile(reqs + p, np, d, L, xcls, img.data(), hdr.data());
         }
         if (!score[p]) continue;
         const uint64_t gi = NHDFIT_SCORE_INDEX(score[p]);
@@ -121,6 +170,7 @@ void hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plan
         if (force_generic) map_winner_t<GenericOps>(reqs[p], w, codes, maps[p]);
         else map_winner(reqs[p], w, codes, maps[p]);
     }
+    return mismatches;
 }
 
 // CPU twin of the sequential (mode B) resolver: inputs are the snapshot outputs of hh_find.
@@ -178,24 +228,6 @@ int hh_set_isect3(const int16_t* a, int na, const int16_t* b, int nb, const int1
     ps_intersect(sa, sb, ab);
     ps_intersect(ab, sc, abc);
     return ps_list(abc, out);
-}
-
-// node records (fit_core.h): node_lane() recomputed from the precomputed record must give the same lane state
-// for every node, layout and clock.  Returns the number of nodes that differ.
-int hh_node_record_mismatches(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
-                              const nhdfit_plane4* p4, uint32_t n, uint32_t fcmax, uint32_t fgmax, uint32_t nsig, uint32_t ngs,
-                              uint32_t hp_rows, uint32_t gmax, double now) {
-    const Layout L = make_layout(fcmax, fgmax, nsig, ngs, hp_rows, gmax);
-    int bad = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        const NodeLane a = node_lane(p0[i], p1[i], p2[i], p3[i], p4[i], now, L);
-        const NodeLane b = node_lane_from_record(make_node_record(p0[i], p1[i], p2[i], p3[i], p4[i], L), now, L);
-        const bool same = a.off_w0 == b.off_w0 && a.off_w1 == b.off_w1 && a.w_misc == b.w_misc && a.off_a == b.off_a &&
-                          a.off_r0n == b.off_r0n && a.off_r1n == b.off_r1n && a.off_r0p == b.off_r0p && a.off_r1p == b.off_r1p &&
-                          a.off_hp == b.off_hp && a.off_gf == b.off_gf && a.flags == b.flags && a.busy == b.busy;
-        bad += !same;
-    }
-    return bad;
 }
 
 // the register-resident model

@@ -106,7 +106,7 @@ def test_candidate_mask_and_sharding_agree():
         s, _, _ = harness.find(pk, table.slice(lo, hi), reqs, spec.clock_now, global_base=lo, want_map=False)
         parts.append(s)
     assert np.array_equal(np.maximum(parts[0], parts[1]), full)
-    cand = np.zeros_like(bm)
+    cand = np.zeros(bm.shape[0], np.uint64)
     cand[1:] = np.uint64(0xFFFFFFFFFFFFFFFF)          # forbid the first 64 nodes
     masked, bm2, _ = harness.find(pk, table, reqs, spec.clock_now, cand=cand, want_map=False)
     assert np.all(bm2[0] == 0) and np.array_equal(bm2[1:], bm[1:])
@@ -123,34 +123,22 @@ def test_register_and_generic_set_models_agree():
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and a[2]["valid"].sum() > 100
 
 
-def test_node_records_reproduce_node_lane():
-    """The precomputed 32-byte node record (fit_core.h NodeRec, the opt-in NHDFIT_NODE_RECORDS path of the fit role)
-    expands to exactly the lane state node_lane() derives from the five planes - for heterogeneous clusters, every
-    layout size the batch can force (group count, hugepage rows) and clocks on both sides of the busy window."""
-    import ctypes
-    from nhd_amd import pack, synth
-    from tests import harness
-    L = harness.lib()
-    for cfg, n in ((3, 3000), (5, 2000), (2, 1000)):
+def test_hot_and_cold_table_sections_agree_on_heterogeneous_clusters():
+    """The fit role reads a node's GPU / NIC verdict from the X row of its interned (free GPUs, signatures) class; the
+    mapping roles and mode B read the per-signature cold rows.  harness.find() asserts, for every (node, tile) pair it
+    evaluates, that both give the same word and that the threshold form of Node.IsBusy equals the subtraction form
+    (clocks on both sides of the busy window)."""
+    for cfg, n in ((3, 1500), (5, 1000), (2, 500)):
         spec = synth.make_cluster(cfg, n_nodes=n)
+        pods, groups = synth.make_pods(cfg, n_pods=96)
         pk = pack.Packer()
         t = pk.planes_from_spec(spec)
-        _caps, _so, _po, _gl, _cc, _ncls, nsig, _np, _ncc = pk.dictionary_arrays()
-        for gmax in (1, 2, 3, 4):
-            for hp_rows in (2, 10, 66):
-                for now in (spec.clock_now, spec.clock_now + 24.9, spec.clock_now + 25.1, spec.clock_now + 1e6):
-                    bad = L.hh_node_record_mismatches(
-                        harness._p(t.p0), harness._p(t.p1), harness._p(t.p2), harness._p(t.p3), harness._p(t.p4),
-                        ctypes.c_uint32(n), ctypes.c_uint32(pk.max_cores_per_numa), ctypes.c_uint32(pk.max_gpus_per_numa),
-                        ctypes.c_uint32(nsig), ctypes.c_uint32(len(pk.group_sets)), ctypes.c_uint32(hp_rows),
-                        ctypes.c_uint32(gmax), ctypes.c_double(now))
-                    assert bad == 0, (cfg, gmax, hp_rows, now, bad)
+        reqs = pk.digest_many([refmodel.make_topology(s) for s in pods], groups)
+        for now in (spec.clock_now, spec.clock_now + 24.9, spec.clock_now + 25.1, spec.clock_now + 1e6):
+            harness.find(pk, t, reqs, now, want_map=False)
     nl = util.random_cluster(77, 300)
     pk = pack.Packer()
     t = pk.pack_nodes(nl)
-    nsig = pk.dictionary_arrays()[6]
-    bad = L.hh_node_record_mismatches(harness._p(t.p0), harness._p(t.p1), harness._p(t.p2), harness._p(t.p3), harness._p(t.p4),
-                                      ctypes.c_uint32(t.n), ctypes.c_uint32(pk.max_cores_per_numa), ctypes.c_uint32(pk.max_gpus_per_numa),
-                                      ctypes.c_uint32(nsig), ctypes.c_uint32(len(pk.group_sets)), ctypes.c_uint32(18),
-                                      ctypes.c_uint32(4), ctypes.c_double(util.CLOCK))
-    assert bad == 0
+    rng = np.random.default_rng(5)
+    reqs = pk.digest_many([refmodel.make_topology(util.random_pod_spec(rng, max_groups=4)) for _ in range(70)])
+    harness.find(pk, t, reqs, util.CLOCK, want_map=False)
