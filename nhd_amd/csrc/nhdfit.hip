@@ -87,11 +87,12 @@ struct DigestArgs {
 };
 constexpr size_t kDigestLds = lds_slice(kTile * sizeof(PaddedReq)) + lds_slice(kTile * sizeof(PodSums)) +
                               lds_slice(kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1) * sizeof(uint16_t)) + lds_slice(kTile * sizeof(PodHeader));
-constexpr uint32_t kDigestParts = 2;      // blocks per tile: part 0 = CPU / scalar-predicate rows, part 1 = GPU / NIC rows
+constexpr uint32_t kWcParts = 4;                     // blocks per tile that share its CPU rows (free-core count c = part mod 4)
+constexpr uint32_t kDigestParts = 1 + kWcParts;      // part 0 = GPU / NIC rows (cold section + X), parts 1..4 = CPU rows, the last one also HP / GX
 
-// Request digest, two blocks per 64-pod tile: per-pod subset sums / NIC covers in LDS, then the table rows
-// (lane = pod, one ballot per assignment).  Few, busy blocks: in the step kernel every resident side block
-// displaces a block of the fit role.
+// Request digest, kDigestParts blocks per 64-pod tile: per-pod subset sums / NIC covers in LDS, then the table rows
+// (lane = pod, one ballot per assignment).  The role is a chain of dependent phases, not a lot of work: it is cut
+// into parts by table so that the chain of each block stays short.
 template <int THREADS>
 __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, uint8_t* lds) {
     PaddedReq* s_req = carve<PaddedReq>(lds, kTile);
@@ -106,21 +107,34 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
 
     stage_requests_lds<THREADS>(a.reqs, tile * kTile, a.P, s_req);
     __syncthreads();
+    constexpr uint32_t NW = THREADS / 64;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
     if (tid < kTile) {
         const nhdfit_req& r = s_req[tid].r;
         const PodHeader h = pod_header(r);
         s_hdr[tid] = h;
-        if (h.flags & kPodValid) pod_sums(r, s_sum[tid]);
+        PodSums& ps = s_sum[tid];
+        ps.G = r.n_groups; ps.W = 1u << (r.n_groups & 7u); ps.full = ps.W - 1;
+        ps.misc_smt = r.misc_smt; ps.misc_nosmt = r.misc_nosmt;
         if (part == 0) {
             const uint32_t pod = tile * kTile + tid;
             a.hdr[pod] = h;
             if (pod < a.P) a.score[pod] = 0;
         }
     }
+    {   // subset sums (pod_sums), one subset per (wavefront, lane = pod) instead of 16 in a row on one wavefront
+        const nhdfit_req& r = s_req[lane].r;
+        const bool ok = req_valid(r);
+        for (uint32_t S = wave; S < (1u << kMaxG); S += NW) {
+            if (!ok || S >= (1u << r.n_groups)) continue;
+            uint32_t g = 0, x = 0, y = 0;
+            for (uint32_t i = 0; i < r.n_groups; ++i)
+                if (S >> i & 1) { g += r.gpus[i]; x += r.cpu_smt[i]; y += r.cpu_nosmt[i]; }
+            s_sum[lane].gpu[S] = g; s_sum[lane].cpu_smt[S] = x; s_sum[lane].cpu_nosmt[S] = y;
+        }
+    }
     __syncthreads();
 
-    constexpr uint32_t NW = THREADS / 64;
-    const uint32_t wave = tid >> 6, lane = tid & 63;
     const bool valid = (s_hdr[lane].flags & kPodValid) != 0;
     // the tile's row width: 2^(largest group count among its pods) - the same rule the host applies when it
     // builds the fit role's work items (tile_wclass)
@@ -140,7 +154,7 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
         if (lane < W) *reinterpret_cast<unsigned long long*>(row + lane * 8) = mine;
     };
 
-    if (part == 0) {
+    if (part != 0) {
         // CPU records WC[u][smt][c] = {m=0 row, m=1 row}: for a pod, socket, SMT mode and misc placement the entry is
         // { p : demand_p <= c } - the demands are read once per (socket, misc, smt) group and swept over c in
         // registers (one group per wavefront) instead of being re-read from LDS for each of the rows of the group
@@ -157,13 +171,14 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
                 }
             }
             uint8_t* base = hot + (u ? L.hot_wc1 : L.hot_wc0) + smt * L.fc_dim * L.wc_stride + m * L.row;
-            for (uint32_t c = 0; c < L.fc_dim; ++c) {
+            for (uint32_t c = part - 1; c < L.fc_dim; c += kWcParts) {
                 uint32_t v = 0;
 #pragma unroll
                 for (uint32_t p = 0; p < (1u << kMaxG); ++p) v |= (t[p] <= c ? 1u : 0u) << p;
                 emit_row(base + c * L.wc_stride, v);
             }
         }
+        if (part != kWcParts) return;
         // 64-bit scalar-predicate rows: one wavefront per row, ballot over the 64 pods
         const uint32_t ngx = 1 + 2 * L.ngs, nrows64 = ngx + L.hp_rows;
         for (uint32_t k = wave; k < nrows64; k += NW) {
@@ -175,7 +190,7 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
         return;
     }
 
-    // part 1: NIC covers per (pod, capacity class), then the cold rows A0/A1[f], R0/R1[sig]
+    // part 0: NIC covers per (pod, capacity class), then the cold rows A0/A1[f], R0/R1[sig]
     for (uint32_t w = tid; w < kTile * a.d.ncls; w += THREADS) {
         const uint32_t j = w % kTile, c = w / kTile;
         if (s_hdr[j].flags & kPodValid) class_cover(s_req[j].r, a.d.caps[c], s_sum[j].W, s_sum[j].G, s_cover[j][c]);
@@ -224,6 +239,7 @@ struct FitArgs {
     uint64_t* nm;               // optional node-major feasibility words [tiles][chunks*64]: bit j = pod 64*tile+j
     unsigned long long* score;  // [P], pre-zeroed
     const FitItem* items;
+    uint32_t dbg_skip;          // tuning aid (NHDFIT_FIT_SKIP): 1 no table sweep, 2 no winner tracking, 4 constant record, 8 no predicate rows
 };
 
 // One step of the 64 x 64 bit-matrix transpose across a wavefront: exchange S x S sub-blocks between
@@ -331,7 +347,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
     {   // stage the hot section of the tile's table image in LDS (16 B per lane, fully coalesced)
         const uint4* src = reinterpret_cast<const uint4*>(a.tabs + (size_t)tile * a.pitch + L.off_hot);
         uint4* dst = reinterpret_cast<uint4*>(hot);
-        for (uint32_t i = threadIdx.x; i < L.hot_bytes / 16; i += BLOCK) dst[i] = src[i];
+        if (!(a.dbg_skip & 16)) for (uint32_t i = threadIdx.x; i < L.hot_bytes / 16; i += BLOCK) dst[i] = src[i];
     }
     __syncthreads();
 
@@ -350,7 +366,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
     const uint32_t hp_last = L.hp_rows - 1;
     const uint32_t len = it.c_end - it.c_begin, per = (len + NW - 1) / NW;
     const uint32_t c_first = it.c_begin + wave * per;
-    const uint32_t c_last = c_first + per < it.c_end ? c_first + per : it.c_end;
+    const uint32_t c_last = (a.dbg_skip & 64) ? c_first : c_first + per < it.c_end ? c_first + per : it.c_end;
     const size_t npad = (size_t)a.chunks * 64;
     // the next chunk's record and busy time are requested before this chunk is worked on: a wavefront's chunks are
     // one dependent chain of L2 round trips otherwise
@@ -364,7 +380,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
         const uint32_t i = c * 64 + lane;
         uint4 rv_next = rv;
         double bt_next = bt;
-        if (c + 1 < c_last) {
+        if (c + 1 < c_last && !(a.dbg_skip & 4)) {
             rv_next = *reinterpret_cast<const uint4*>(recs + i + 64);
             bt_next = a.p4[i + 64].busy_time;
         }
@@ -376,8 +392,8 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
         const bool nogpu = (rv.w & kRecNoGpu) != 0;
 
         // (1) NUMA-assignment feasibility against all 64 pods (bit-sliced tables), (2) scalar predicates
-        const uint64_t okm = sweep_assignments<W>(hot, a_w0, a_w1, a_x0, a_x1);
-        const uint2 gx = lds8(hot, a_gx), hpw = lds8(hot, a_hp);
+        const uint64_t okm = (a.dbg_skip & 1) ? ((uint64_t)rv.y << 32 | rv.x) : sweep_assignments<W>(hot, a_w0, a_w1, a_x0, a_x1);
+        const uint2 gx = (a.dbg_skip & 8) ? make_uint2(rv.z, rv.w) : lds8(hot, a_gx), hpw = (a.dbg_skip & 8) ? make_uint2(~0u, ~0u) : lds8(hot, a_hp);
         const bool busy = bt >= a.busy_from;                                  // Node.IsBusy, nhd/Node.py:847-850
         uint32_t wlo = (uint32_t)okm & gx.x & hpw.x, whi = (uint32_t)(okm >> 32) & gx.y & hpw.y;
         if (busy) { wlo &= ~(uint32_t)m_need; whi &= ~(uint32_t)(m_need >> 32); }      // Matcher.py:107-111
@@ -390,7 +406,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
         // (3) does this chunk change any pod's winner?
         const uint32_t nlo = (uint32_t)need_any | (nogpu ? (uint32_t)need_pref : 0u);
         const uint32_t nhi = (uint32_t)(need_any >> 32) | (nogpu ? (uint32_t)(need_pref >> 32) : 0u);
-        if (__ballot(((wlo & nlo) | (whi & nhi)) != 0)) {
+        if (!(a.dbg_skip & 2) && __ballot(((wlo & nlo) | (whi & nhi)) != 0)) {
             const uint64_t nogpu_mask = __ballot(nogpu);
             transpose64(wlo, whi);                                            // lane j: pod j's verdict over the chunk's 64 nodes
             const uint64_t word = ((uint64_t)whi << 32) | wlo;
@@ -406,6 +422,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
     unsigned long long best = 0;
     if (best_pref != ~0u) best = score_of(true, a.global_base + best_pref);
     else if (best_any != ~0u) best = score_of(false, a.global_base + best_any);
+    if (a.dbg_skip & 32) return;
     s_best[wave][lane] = best;
     __syncthreads();
     if (wave == 0 && my_pod_live) {
@@ -546,19 +563,118 @@ __device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int l
     return ((unsigned long long)(uint32_t)__shfl((int)(v >> 32), lane, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, lane, 64);
 }
 
+// Staging for the lane = pod mapping roles.  The mapping arithmetic (candidate masks, first NIC choice) indexes the
+// request record and the winner's detail record dynamically inside nested loops; against global memory every such
+// access is a dependent L2 round trip and a role becomes a 25-30 us latency chain.  So a block first copies the
+// records of its pods (THREADS / 4 of them: the copies are cooperative, the arithmetic runs on a quarter of the
+// threads) into LDS with wide coalesced loads - three round trips in all (score, node records, table rows).
+struct PaddedDet { nhdfit_detail d; uint32_t pad; };           // 33-word stride: lane j -> bank j
+struct StagedNode {                                            // 9 words
+    int32_t node;                                              // local index of the pod's winner, -1: none on this shard
+    uint32_t free_c[2], free_g[2];
+    uint16_t sig_numa[2], sig_pci[2];
+    uint32_t smt, U;
+};
+struct MapStage {
+    PaddedReq* req; PaddedDet* det; StagedNode* w; nhdfit_mapping* map; double* caps;
+};
+template <int THREADS>
+constexpr size_t map_lds_bytes() {
+    constexpr size_t pods = THREADS / 4;
+    return lds_slice(pods * sizeof(PaddedReq)) + lds_slice(pods * sizeof(PaddedDet)) + lds_slice(pods * sizeof(StagedNode)) +
+           lds_slice(pods * sizeof(nhdfit_mapping)) + lds_slice(NHDFIT_MAX_CLASSES * sizeof(double));
+}
+template <int THREADS>
+__device__ __forceinline__ MapStage stage_winners(const MapArgs& a, uint32_t pod0, uint8_t* lds) {
+    constexpr uint32_t PODS = THREADS / 4;
+    MapStage s;
+    s.req = carve<PaddedReq>(lds, PODS);
+    s.det = carve<PaddedDet>(lds, PODS);
+    s.w = carve<StagedNode>(lds, PODS);
+    s.map = carve<nhdfit_mapping>(lds, PODS);
+    s.caps = carve<double>(lds, NHDFIT_MAX_CLASSES);
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t kParts = sizeof(nhdfit_req) / 16;
+    const uint32_t live = pod0 < a.P ? (a.P - pod0 < PODS ? a.P - pod0 : PODS) : 0u;
+    {   // request records, coalesced
+        const uint4* src = reinterpret_cast<const uint4*>(a.reqs + pod0);
+        for (uint32_t c = tid; c < PODS * kParts; c += THREADS) {
+            const uint32_t j = c / kParts;
+            const uint4 v = j < live ? src[c] : make_uint4(0u, 0u, 0u, 0u);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(&s.req[j]) + (c % kParts) * 4;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    }
+    if (tid < NHDFIT_MAX_CLASSES) s.caps[tid] = a.caps[tid];                // the dictionary buffer holds >= 16 entries
+    if (tid < PODS) {                                                       // winners and their plane-derived counts
+        StagedNode n;
+        n.node = -1;
+        n.free_c[0] = n.free_c[1] = n.free_g[0] = n.free_g[1] = 0; n.smt = 0; n.U = 1;
+        n.sig_numa[0] = n.sig_numa[1] = n.sig_pci[0] = n.sig_pci[1] = 0;
+        const unsigned long long sc = tid < live ? a.score[pod0 + tid] : 0ull;
+        if (sc) {
+            const uint64_t gi = NHDFIT_SCORE_INDEX(sc);
+            if (gi >= a.global_base && gi < a.global_base + a.n) {
+                const uint32_t i = (uint32_t)(gi - a.global_base);
+                const nhdfit_plane0 q0 = a.p0[i];
+                const nhdfit_plane1 q1 = a.p1[i];
+                const nhdfit_plane2 q2 = a.p2[i];
+                const nhdfit_plane3 q3 = a.p3[i];
+                n.node = (int32_t)i;
+                n.smt = (q2.flags & NHDFIT_NF_SMT) != 0;
+                n.free_c[0] = popc64(q0.t0[0] & q1.t1[0]); n.free_c[1] = popc64(q0.t0[1] & q1.t1[1]);
+                n.free_g[0] = popc32(q2.gpu_free & ~q2.gpu_numa1); n.free_g[1] = popc32(q2.gpu_free & q2.gpu_numa1);
+                n.sig_numa[0] = q3.sig_numa[0]; n.sig_numa[1] = q3.sig_numa[1];
+                n.sig_pci[0] = q3.sig_pci[0]; n.sig_pci[1] = q3.sig_pci[1];
+            }
+        }
+        s.w[tid] = n;
+    }
+    __syncthreads();
+    constexpr uint32_t kDetParts = sizeof(nhdfit_detail) / 16;              // detail records of the winners: 8 lanes x 16 B per pod
+    for (uint32_t c = tid; c < PODS * kDetParts; c += THREADS) {
+        const uint32_t j = c / kDetParts, part = c % kDetParts;
+        const int32_t i = s.w[j].node;
+        if (i >= 0) {
+            const uint4 v = reinterpret_cast<const uint4*>(a.det + i)[part];
+            uint32_t* dst = reinterpret_cast<uint32_t*>(&s.det[j]) + part * 4;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    }
+    __syncthreads();
+    return s;
+}
+__device__ __forceinline__ WinnerState staged_state(const MapStage& s, uint32_t j) {
+    WinnerState w;
+    w.d = &s.det[j].d;
+    w.U = s.det[j].d.numa_nodes;
+    w.smt = s.w[j].smt != 0;
+    w.free_c[0] = (int)s.w[j].free_c[0]; w.free_c[1] = (int)s.w[j].free_c[1];
+    w.free_g[0] = (int)s.w[j].free_g[0]; w.free_g[1] = (int)s.w[j].free_g[1];
+    w.caps = s.caps;
+    return w;
+}
+
 // (1) lane = pod, wavefront = tile: derive the shape, de-duplicate within the tile
 template <int THREADS>
-__device__ __forceinline__ void role_shapes(const MapArgs& a, const ShapeArgs& h, uint32_t blk) {
-    const uint32_t p = blk * THREADS + threadIdx.x, tile = p >> 6, lane = threadIdx.x & 63;
+__device__ __forceinline__ void role_shapes(const MapArgs& a, const ShapeArgs& h, uint32_t blk, uint8_t* lds) {
+    constexpr uint32_t PODS = THREADS / 4;
+    const uint32_t pod0 = blk * PODS;
+    const MapStage st = stage_winners<THREADS>(a, pod0, lds);
+    if (threadIdx.x >= PODS) return;
+    const uint32_t j = threadIdx.x, p = pod0 + j, tile = p >> 6, lane = threadIdx.x & 63;
     if (tile * 64 >= a.P) return;                      // whole wavefront past the end
     int32_t slot = -1;
     unsigned long long key = 0;
-    WinnerState w;
-    uint32_t i;
-    const nhdfit_req& rq = a.reqs[p < a.P ? p : 0];
-    if (p < a.P && rq.n_groups <= 3 && load_winner(a, p, w, i)) {
+    const nhdfit_req& rq = st.req[j].r;
+    if (p < a.P && rq.n_groups <= 3 && st.w[j].node >= 0) {
+        const WinnerState w = staged_state(st, j);
+        nhdfit_plane3 q3;
+        q3.groups = 0;
+        q3.sig_numa[0] = st.w[j].sig_numa[0]; q3.sig_numa[1] = st.w[j].sig_numa[1];
+        q3.sig_pci[0] = st.w[j].sig_pci[0]; q3.sig_pci[1] = st.w[j].sig_pci[1];
         const uint32_t bits = nic_assignment_bits(a.tabs + (size_t)tile * a.pitch, a.L[a.tile_wcls[tile]], lane,
-                                                  rq.map_type == NHDFIT_MAP_PCI, a.p3[i]);
+                                                  rq.map_type == NHDFIT_MAP_PCI, q3);
         const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
         uint32_t sg, sc;
         candidate_masks(rq, w, sg, sc);
@@ -614,23 +730,34 @@ __device__ __forceinline__ void role_choose(const ShapeArgs& h, uint32_t w, uint
     }
 }
 
-// (3) lane = pod: first valid NIC choice under the chosen tuples.  Request, winner detail and result are accessed
-// field by field with dynamic indices: they stay in global memory (L2-resident), not in scratch.
+// (3) lane = pod: first valid NIC choice under the chosen tuples, from the staged copies; the mappings leave the
+// block as one coalesced store.
 template <int THREADS>
-__device__ __forceinline__ void role_finish(const MapArgs& a, const ShapeArgs& h, uint32_t blk) {
-    const uint32_t p = blk * THREADS + threadIdx.x;
-    if (p >= a.P) return;
-    const nhdfit_req& rq = a.reqs[p];
-    if (rq.n_groups > 3) return;                      // handled by k_map<true>
-    nhdfit_mapping& m = a.out[p];
-    memset(&m, 0, sizeof(m));
-    const int32_t slot = h.slot_of_pod[p];
-    if (slot == -1) return;
-    const uint32_t res = slot >= 0 ? h.result[slot] : (uint32_t)(-2 - slot);
-    WinnerState w;
-    uint32_t i;
-    if (!(res >> 8 & 1) || !load_winner(a, p, w, i)) return;
-    finish_mapping(rq, w, (res >> 4) & 7u, (int)(res & 15u), m);
+__device__ __forceinline__ void role_finish(const MapArgs& a, const ShapeArgs& h, uint32_t blk, uint8_t* lds) {
+    constexpr uint32_t PODS = THREADS / 4;
+    const uint32_t pod0 = blk * PODS;
+    const MapStage st = stage_winners<THREADS>(a, pod0, lds);
+    const uint32_t j = threadIdx.x, p = pod0 + j;
+    if (j < PODS) {
+        nhdfit_mapping& m = st.map[j];
+        memset(&m, 0, sizeof(m));
+        const nhdfit_req& rq = st.req[j].r;
+        if (p < a.P && rq.n_groups <= 3) {
+            const int32_t slot = h.slot_of_pod[p];
+            if (slot != -1) {
+                const uint32_t res = slot >= 0 ? h.result[slot] : (uint32_t)(-2 - slot);
+                if ((res >> 8 & 1) && st.w[j].node >= 0) finish_mapping(rq, staged_state(st, j), (res >> 4) & 7u, (int)(res & 15u), m);
+            }
+        }
+    }
+    __syncthreads();
+    // 20-byte records, PODS of them: copied out as words; pods with more than 3 groups belong to k_map<true>
+    const uint32_t live = pod0 < a.P ? (a.P - pod0 < PODS ? a.P - pod0 : PODS) : 0u;
+    constexpr uint32_t kWords = sizeof(nhdfit_mapping) / 4;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(st.map);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(a.out + pod0);
+    for (uint32_t c = threadIdx.x; c < live * kWords; c += THREADS)
+        if (st.req[c / kWords].r.n_groups <= 3) dst[c] = src[c];
 }
 
 // ---- the step kernel ---------------------------------------------------------------------------------
@@ -767,9 +894,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : 7) void k_step(StepArgs a
         return;
     }
     blk -= a.nb_choose;
-    if (blk < a.nb_shapes) { role_shapes<BLOCK>(a.shapes_m, a.shapes_h, blk); stamp(a.role_clock, 1, t0); return; }
+    if (blk < a.nb_shapes) { role_shapes<BLOCK>(a.shapes_m, a.shapes_h, blk, lds); stamp(a.role_clock, 1, t0); return; }
     blk -= a.nb_shapes;
-    if (blk < a.nb_finish) { role_finish<BLOCK>(a.finish_m, a.finish_h, blk); stamp(a.role_clock, 2, t0); return; }
+    if (blk < a.nb_finish) { role_finish<BLOCK>(a.finish_m, a.finish_h, blk, lds); stamp(a.role_clock, 2, t0); return; }
     blk -= a.nb_finish;
     if (blk < a.nb_digest) { role_digest<BLOCK>(a.digest, blk, lds); stamp(a.role_clock, 3, t0); return; }
     blk -= a.nb_digest;
@@ -786,8 +913,8 @@ __global__ __launch_bounds__(BLOCK, 6) void k_role(StepArgs a) {
         if ((threadIdx.x & 63) == 0)
             role_choose(a.choose, (uint32_t)__builtin_amdgcn_readfirstlane((int)(blk * (BLOCK / 64) + (threadIdx.x >> 6))),
                         a.nb_choose * (BLOCK / 64), (a.shapes_P + kTile - 1) / kTile);
-    } else if constexpr (ROLE == 1) role_shapes<BLOCK>(a.shapes_m, a.shapes_h, blk);
-    else if constexpr (ROLE == 2) role_finish<BLOCK>(a.finish_m, a.finish_h, blk);
+    } else if constexpr (ROLE == 1) role_shapes<BLOCK>(a.shapes_m, a.shapes_h, blk, lds);
+    else if constexpr (ROLE == 2) role_finish<BLOCK>(a.finish_m, a.finish_h, blk, lds);
     else if constexpr (ROLE == 3) role_digest<BLOCK>(a.digest, blk, lds);
     else role_fit<BLOCK>(a.fit, blk, lds);
 }
@@ -925,7 +1052,7 @@ struct nhdfit_ctx {
     bool geom_big = true;                // 512-thread step blocks (256 for small problems)
     uint32_t digest_parts = getenv("NHDFIT_DIGEST_PARTS") ? (uint32_t)atoi(getenv("NHDFIT_DIGEST_PARTS")) : 2;   // tuning aid
     uint32_t side_prio = getenv("NHDFIT_SIDE_PRIO") ? (uint32_t)atoi(getenv("NHDFIT_SIDE_PRIO")) : 1;   // tuning aid
-    uint32_t choose_split = getenv("NHDFIT_CHOOSE_SPLIT") ? (uint32_t)atoi(getenv("NHDFIT_CHOOSE_SPLIT")) : 64;   // tuning aid: wavefronts per tile
+    uint32_t choose_split = getenv("NHDFIT_CHOOSE_SPLIT") ? (uint32_t)atoi(getenv("NHDFIT_CHOOSE_SPLIT")) : 16;   // tuning aid: wavefronts per tile
     bool split = getenv("NHDFIT_SPLIT") != nullptr;
     bool role_kernels = getenv("NHDFIT_ROLE_KERNELS") != nullptr;   // profiling aid: every role as a kernel of its own (512-thread geometry only)
     DevBuf<unsigned long long> role_clock;            // profiling aid: NHDFIT_ROLE_TIMES=<step> prints the role windows of that step
@@ -972,7 +1099,7 @@ struct nhdfit_ctx {
     DevBuf<unsigned long long> xkeys; DevBuf<uint32_t> xids; DevBuf<uint64_t> xcls; DevBuf<uint32_t> xnx;
     uint32_t rec_lo = 0, rec_hi = 0; bool rec_all = true;
     uint32_t nx = 0, x_cap = kMinXCap;   // interned classes (as of the last record update) / provisioned X rows
-    uint32_t cpw[kWClasses] = {8, 6, 4, 2};   // chunks per wavefront of a fit block, per row width (NHDFIT_CPW="a,b,c,d")
+    uint32_t fit_blocks = getenv("NHDFIT_FIT_BLOCKS") ? (uint32_t)atoi(getenv("NHDFIT_FIT_BLOCKS")) : 0;   // tuning aid: blocks of the fit role
     bool use_choose_tab = getenv("NHDFIT_NO_CHOOSE_TABLE") == nullptr;   // tuning aid: run the set model for every shape
     // set-layout state machine for three-group pods (set_states.h): verified against the model on the host
     // (tests/test_pyset_emulation.py), parity-green and 10 % faster per step on the GPU (profiles/r02):
@@ -1092,11 +1219,6 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
     if (e == hipSuccess) e = hipMemsetAsync(c->xkeys.p, 0, kXSlots * sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->xids.p, 0xFF, kXSlots * sizeof(uint32_t), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->xnx.p, 0, 2 * sizeof(uint32_t), c->stream);
-    if (const char* cpw = getenv("NHDFIT_CPW")) {            // tuning aid
-        unsigned v[kWClasses];
-        if (sscanf(cpw, "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]) == 4)
-            for (int k = 0; k < kWClasses; ++k) c->cpw[k] = v[k] ? v[k] : 1;
-    }
     if (e == hipSuccess) e = c->asc.reserve(kAscEntries);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_build_asc, dim3((kAscEntries + 255) / 256), dim3(256), 0, c->stream, c->asc.p);
@@ -1177,7 +1299,7 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     HIPCHK(c, c->group_sets.reserve(n_group_sets ? n_group_sets : 1));
     if (n_group_sets) HIPCHK(c, hipMemcpy(c->group_sets.p, group_sets, n_group_sets * sizeof(uint64_t), hipMemcpyHostToDevice));
     else { const uint64_t zero = 0; HIPCHK(c, hipMemcpy(c->group_sets.p, &zero, sizeof zero, hipMemcpyHostToDevice)); }
-    HIPCHK(c, c->caps.reserve(ncls ? ncls : 1));
+    HIPCHK(c, c->caps.reserve(NHDFIT_MAX_CLASSES));           // the mapping roles stage all 16 entries
     HIPCHK(c, c->sig_off.reserve(nsig + 1));
     HIPCHK(c, c->pool_off.reserve(npools + 1));
     HIPCHK(c, c->pool_glimit.reserve(npools ? npools : 1));
@@ -1391,26 +1513,27 @@ int ensure_records(nhdfit_ctx* c) {
     return NHDFIT_OK;
 }
 
-// Work items of the fit role: every tile's chunks cut into runs of (waves per block) x (chunks per wavefront of its
-// row width); wide tiles first (longest-first keeps the tail of the launch short).  Small problems get shorter
-// runs so that the grid still covers the chip.
+// Work items of the fit role (one block each): the tiles' chunk ranges cut so that every block carries about the
+// same cost - a chunk of a tile with W assignments costs ~(6 + W) - and the block count is a fixed multiple of what
+// the chip holds at once (NHDFIT_FIT_BLOCKS overrides the target).  Wide tiles first: longest-first keeps the tail
+// of the launch short.  Small problems simply get one wavefront-run per chunk.
 int build_items(nhdfit_ctx* c, uint32_t nw) {
     const uint32_t tiles = (c->P + kTile - 1) / kTile, chunks = (c->n + 63) / 64;
     const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
-    uint32_t shrink = 1;
-    for (;;) {
-        uint64_t blocks = 0;
-        for (uint32_t t = 0; t < tiles; ++t) {
-            const uint32_t run = nw * std::max(1u, c->cpw[c->h_tile_wcls[t]] / shrink);
-            blocks += (chunks + run - 1) / run;
-        }
-        if (blocks >= 2ull * cus || shrink >= 8) break;
-        shrink *= 2;
-    }
+    // two of the three 512-thread blocks a CU holds (the side roles of the same launch live in the third slot)
+    uint32_t target = c->fit_blocks ? c->fit_blocks : cus * (nw == 8 ? 2u : 5u);
+    uint64_t total = 0;
+    for (uint32_t t = 0; t < tiles; ++t) total += (uint64_t)chunks * (6u + (2u << c->h_tile_wcls[t]));
     std::vector<FitItem> items;
     for (uint32_t t = 0; t < tiles; ++t) {           // staged order = widest tiles first
-        const uint32_t w = c->h_tile_wcls[t], run = nw * std::max(1u, c->cpw[w] / shrink);
-        for (uint32_t b = 0; b < chunks; b += run) items.push_back(FitItem{t, w, b, std::min(chunks, b + run)});
+        const uint32_t w = c->h_tile_wcls[t];
+        const uint64_t cost = (uint64_t)chunks * (6u + (2u << w));
+        uint32_t nb = (uint32_t)((cost * target + total / 2) / total);
+        nb = std::max(1u, std::min(nb, (chunks + nw - 1) / nw));          // at least one chunk per wavefront
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t lo = (uint32_t)((uint64_t)chunks * b / nb), hi = (uint32_t)((uint64_t)chunks * (b + 1) / nb);
+            if (hi > lo) items.push_back(FitItem{t, w, lo, hi});
+        }
     }
     HIPCHK(c, c->items.reserve(items.size() ? items.size() : 1));
     HIPCHK(c, hipMemcpyAsync(c->items.p, items.data(), items.size() * sizeof(FitItem), hipMemcpyHostToDevice, c->stream));
@@ -1453,7 +1576,7 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
     if (small_map) {
         if (c->n_finished < c->n_chosen) {
             const int b = (int)(c->n_finished % kBufs);
-            a.finish_m = map_args(b); a.finish_h = shape_args(b); a.nb_finish = (P + block - 1) / block; did_finish = true;
+            a.finish_m = map_args(b); a.finish_h = shape_args(b); a.nb_finish = (P + block / 4 - 1) / (block / 4); did_finish = true;
         }
         if (c->n_chosen < c->n_shaped) {
             a.choose = shape_args((int)(c->n_chosen % kBufs));
@@ -1469,7 +1592,7 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
             HIPCHK(c, c->shape_res[b].reserve((size_t)tiles * kTile));
             HIPCHK(c, c->shape_slot[b].reserve(P));
             HIPCHK(c, c->shape_list[b].reserve(tiles));
-            a.shapes_m = map_args(b); a.shapes_h = shape_args(b); a.nb_shapes = (P + block - 1) / block; did_shapes = true;
+            a.shapes_m = map_args(b); a.shapes_h = shape_args(b); a.nb_shapes = (P + block / 4 - 1) / (block / 4); did_shapes = true;
         }
     }
     with_digest = with_digest && c->n_dig <= c->n_fit + (with_fit ? 1 : 0) + (c->split ? 1 : 0);   // at most one step ahead of the fit
@@ -1498,6 +1621,7 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         f.nm = c->want_bitmap ? c->nm.p : nullptr;
         f.score = c->score[bf].p;
         f.items = c->items.p;
+        f.dbg_skip = getenv("NHDFIT_FIT_SKIP") ? (uint32_t)atoi(getenv("NHDFIT_FIT_SKIP")) : 0;
         nb_fit = c->n_items;
     }
     const uint32_t grid = a.nb_choose + a.nb_shapes + a.nb_finish + a.nb_digest + nb_fit;
@@ -1505,6 +1629,8 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
     // dynamic LDS of the launch: the largest need among the roles present
     size_t lds = nb_fit ? lds_slice(c->lds_bytes) + (size_t)nw * 64 * sizeof(unsigned long long) : 0;
     if (a.nb_digest && kDigestLds > lds) lds = kDigestLds;
+    const size_t map_lds = big ? map_lds_bytes<512>() : map_lds_bytes<256>();
+    if ((a.nb_shapes || a.nb_finish) && map_lds > lds) lds = map_lds;
 
     // HIP-event timing is sampled (every 8th fit launch; every digest-only launch)
     if (with_fit && (int64_t)c->n_fit == c->role_step) {
@@ -1521,8 +1647,8 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
     if (c->role_kernels) {
         const uint32_t nb[5] = {a.nb_choose, a.nb_shapes, a.nb_finish, a.nb_digest, nb_fit};
         if (nb[0]) hipLaunchKernelGGL((k_role<512, 0>), dim3(nb[0]), dim3(512), 0, c->stream, a);
-        if (nb[1]) hipLaunchKernelGGL((k_role<512, 1>), dim3(nb[1]), dim3(512), 0, c->stream, a);
-        if (nb[2]) hipLaunchKernelGGL((k_role<512, 2>), dim3(nb[2]), dim3(512), 0, c->stream, a);
+        if (nb[1]) hipLaunchKernelGGL((k_role<512, 1>), dim3(nb[1]), dim3(512), map_lds_bytes<512>(), c->stream, a);
+        if (nb[2]) hipLaunchKernelGGL((k_role<512, 2>), dim3(nb[2]), dim3(512), map_lds_bytes<512>(), c->stream, a);
         if (nb[3]) hipLaunchKernelGGL((k_role<512, 3>), dim3(nb[3]), dim3(512), kDigestLds, c->stream, a);
         if (nb[4]) hipLaunchKernelGGL((k_role<512, 4>), dim3(nb[4]), dim3(512), lds, c->stream, a);
     } else
