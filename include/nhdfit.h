@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NHDFIT_ABI_VERSION        2
+#define NHDFIT_ABI_VERSION        3
 #define NHDFIT_MAX_GROUPS         4      /* proc groups per pod (G)                               */
 #define NHDFIT_MAX_NUMA           2      /* NUMA nodes (= sockets, nhd/Node.py:336) per node (U)  */
 #define NHDFIT_MAX_CORES_PER_NUMA 64     /* physical cores per socket (one uint64 mask)           */
@@ -131,6 +131,27 @@ typedef struct {
     int8_t pad[2];
 } nhdfit_mapping;                            /* 20 bytes */
 
+/* ---- physical ids of one committed placement = what Node.SetPhysicalIdsFromMapping writes into the pod's
+ * CfgTopology (nhd/Node.py:663-841).  A core batch (one GetFreeCpuBatch call, nhd/Node.py:502-519) is two masks
+ * over the physical cores of its socket: `take` = cores whose thread 0 was handed out, `pair` = those whose SMT
+ * sibling was handed out with it.  The reference's list is, for ascending core b in `take`: logical id
+ * numa * cores_per_proc + b, then - if b is in `pair` - its sibling (id + num_cores).  It assigns that list to the
+ * group's GPU cpu_cores first, then to its proc_cores (nhd/Node.py:729-742). */
+#define NHDFIT_PLACEMENT_GPUS 8
+typedef struct {
+    uint64_t proc_take[NHDFIT_MAX_GROUPS], proc_pair[NHDFIT_MAX_GROUPS];   /* batch of len(proc_cores) + GPU cores, proc_smt   */
+    uint64_t help_take[NHDFIT_MAX_GROUPS], help_pair[NHDFIT_MAX_GROUPS];   /* batch of the group's helper cores, helper_smt    */
+    uint64_t misc_take, misc_pair;                                         /* pod-level misc cores, misc_cores_smt (Node.py:799) */
+    uint8_t  gpu[NHDFIT_MAX_GROUPS][NHDFIT_PLACEMENT_GPUS];                /* position in Node.gpus of the k-th GPU of group g, 0xFF = none */
+    int8_t   numa[NHDFIT_MAX_GROUPS + 1];                                  /* NUMA node of group g / of the misc cores          */
+    uint8_t  status;                                                       /* NHDFIT_COMMIT_*                                   */
+    uint8_t  pad[2];
+} nhdfit_placement;                                                        /* 184 bytes */
+#define NHDFIT_COMMIT_OK          0
+#define NHDFIT_COMMIT_WOULD_RAISE 1   /* the reference's commit would raise (or hand a core out twice): parity undefined        */
+#define NHDFIT_COMMIT_NEW_SIG     2   /* committed, but the node's new NIC state has no signature in the dictionary yet: intern
+                                         it (download the node, re-derive its signatures) and upload its plane 3           */
+
 typedef struct {
     uint64_t launches;          /* step-kernel launches carrying a fit role that were timed (every 8th step)   */
     double   fit_ms_total;      /* sum of their HIP-event durations (ms): the whole fused launch - fit role plus
@@ -178,10 +199,15 @@ int nhdfit_upload_nodes(nhdfit_ctx* ctx, uint32_t first, uint32_t count,
                         const nhdfit_plane3* p3, const nhdfit_plane4* p4, const nhdfit_detail* detail);
 int nhdfit_set_node_count(nhdfit_ctx* ctx, uint32_t n_nodes);
 
+/* Read node records back (after device-side commits). */
+int nhdfit_download_nodes(nhdfit_ctx* ctx, uint32_t first, uint32_t count,
+                          nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plane2* p2,
+                          nhdfit_plane3* p3, nhdfit_plane4* p4, nhdfit_detail* detail);
+
 /* Evaluate P pending pods against the mirror (mode A: every pod sees the same snapshot).
  *   now        monotonic clock sampled once per call (IsBusy, nhd/Node.py:847-850)
- *   cand       optional, chunk-major [ceil(n/64)][P]: restrict pod p to nodes whose bit is set
- *              (the dict the scheduler passes to FindNode may be a filtered subset)
+ *   cand       optional, [ceil(n/64)] words, bit = node: restrict the call to these nodes
+ *              (the dict the scheduler passes to FindNode may be a filtered subset of the mirror)
  *   score_out  P score words (after the all-reduce when a communicator is attached)
  *   bitmap_out optional, chunk-major [ceil(n/64)][P] feasibility words of THIS shard
  *   map_out    optional, P mappings (valid only for winners owned by this shard) */
@@ -196,6 +222,27 @@ int nhdfit_find(nhdfit_ctx* ctx, const nhdfit_req* reqs, uint32_t P, double now,
  * own commit step would have raised (parity undefined from there on).  Single shard only. */
 int nhdfit_find_sequential(nhdfit_ctx* ctx, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand,
                            int64_t* node_out, nhdfit_mapping* map_out, int32_t* status_out);
+
+/* Mode B with the commit step on the device: every winner is committed to the packed node
+ * state exactly as SetBusy / SetPhysicalIdsFromMapping / ClaimPodNICResources would (nhd/NHDScheduler.py:289-304,
+ * nhd/Node.py:663-841, 644-646) before the next pod of the batch is matched, and the physical ids come back.
+ *   apply      != 0: the commits stay in the device mirror (the scheduler's Node objects are updated by the caller
+ *              with the reference's own mutators, nothing is re-packed or re-uploaded); 0: the mirror is restored
+ *   place_out  optional, P records
+ *   n_done     pods decided.  n_done < P only when a commit produced a NIC state the dictionary has no signature for
+ *              (status NHDFIT_COMMIT_NEW_SIG on one or more pods of [first_pod, n_done)): intern it, patch those nodes
+ *              (nhdfit_download_nodes / nhdfit_upload_nodes) and call again with first_pod = n_done; first_pod > 0
+ *              continues the batch staged by the previous call and re-evaluates the `n_resume` (<= 8) patched nodes
+ *              `resume_nodes` (local indices) against the remaining pods first. */
+int nhdfit_schedule_batch(nhdfit_ctx* ctx, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand, int apply,
+                          uint32_t first_pod, const int64_t* resume_nodes, uint32_t n_resume,
+                          int64_t* node_out, nhdfit_mapping* map_out, nhdfit_placement* place_out, int32_t* status_out,
+                          uint32_t* n_done);
+
+/* The commit step for ONE placement the caller obtained from nhdfit_find (the scheduler's pod-at-a-time loop):
+ * updates the mirror in place and returns the physical ids.  busy_time = the node's Node.busy_time after SetBusy(). */
+int nhdfit_commit(nhdfit_ctx* ctx, uint32_t node, const nhdfit_req* req, const nhdfit_mapping* map, double busy_time,
+                  nhdfit_placement* place_out);
 
 /* Benchmark / pipelined form: requests are staged once, then each step only enqueues kernels
  * (request digest -> fit_score -> [all-reduce] -> winner mapping) on the context's stream. */

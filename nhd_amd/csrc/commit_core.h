@@ -1,0 +1,178 @@
+// commit_core.h - the commit step on the packed node state.
+//
+// After FindNode has picked a node and a mapping, the scheduler turns the mapping into physical ids and marks the
+// resources used (nhd/NHDScheduler.py:289-304):
+//     SetBusy()                                   nhd/Node.py:843-845
+//     SetPhysicalIdsFromMapping(mapping, top)      nhd/Node.py:663-841  (GetFreeCpuBatch 502-519, GetNicObjFromIndex
+//                                                  657-661, GetFreePciGpuFromNic 648-655, GetNextGpuFree 495-500)
+//     ClaimPodNICResources(nidx)                   nhd/Node.py:644-646
+// The same on the five planes + detail record of the device mirror, written once for the gfx950 kernels and the host
+// twin of the tests.  What is picked, in the reference's order:
+//   * per group g on NUMA node u = mapping['gpu'][g]: one GetFreeCpuBatch(u, n_proc[g], proc_smt): the scan walks
+//     Node.cores in index order, i.e. the thread-0 cores of socket u ascending (they precede every sibling), and takes
+//     a core when both of its threads are unused - [core, sibling] while the request is SMT and >= 2 cores are still
+//     wanted, else [core].  On the bitmaps: the lowest set bits of t0[u] & t1[u].
+//   * each GPU of the group: first unused GPU on the NIC's PCIe switch, else (NUMA mode) first unused GPU of NUMA u
+//   * a second batch for the group's helper cores (helper_smt), a last one for the pod's misc cores on NUMA
+//     mapping['cpu'][-1] with the REAL misc_cores_smt flag
+//   * hugepages, busy time, and pods_used += 1 on every NIC that carries an RX / TX core: its capacity becomes 0
+// A batch that cannot be filled from thread-0 cores makes the reference scan on into the sibling range and hand out
+// cores twice or raise: status 1, parity undefined from there on, as in the reference.
+//
+// The NIC signatures of the node change with claims and GPU picks; their ids are looked up in a table the host
+// derives from the dictionary (sig_key below is the canonical key of a NUMA node's pool set).  A state the dictionary
+// does not hold yet is reported (status kCommitNewSig): the host interns it and patches the node.
+#pragma once
+#include "fit_core.h"
+
+namespace nhdfit {
+
+constexpr int kCommitOk = 0, kCommitWouldRaise = 1, kCommitNewSig = 2;
+
+struct NodeState {                   // registers / LDS copy of one node while it is modified
+    nhdfit_plane0 p0; nhdfit_plane1 p1; nhdfit_plane2 p2; nhdfit_plane3 p3; nhdfit_plane4 p4;
+};
+
+// lowest k set bits of x
+NHD_HD uint64_t lowest_bits(uint64_t x, uint32_t k) {
+    uint64_t out = 0;
+    for (uint32_t i = 0; i < k && x; ++i) { const uint64_t b = x & (0 - x); out |= b; x ^= b; }
+    return out;
+}
+
+// GetFreeCpuBatch(numa, num, smt) on the bitmaps of socket u.  Returns false if the socket cannot fill the batch
+// from cores whose both threads are free.
+NHD_HD bool take_batch(NodeState& s, uint32_t u, uint32_t num, bool smt_requested, uint64_t& take, uint64_t& pair) {
+    const bool smt_node = (s.p2.flags & NHDFIT_NF_SMT) != 0;
+    const uint64_t free = s.p0.t0[u] & s.p1.t1[u];
+    const bool pairs = smt_node && smt_requested;
+    const uint32_t n_take = pairs ? (num + 1) / 2 : num, n_pair = pairs ? num / 2 : 0;
+    take = lowest_bits(free, n_take);
+    pair = lowest_bits(free, n_pair);
+    s.p0.t0[u] &= ~take;
+    if (smt_node) s.p1.t1[u] &= ~pair;
+    return (uint32_t)popc64(take) == n_take;
+}
+
+// canonical key of one NIC pool: free-GPU limit (NHDFIT_GLIMIT_NONE for the NUMA-mode pool) and the number of NICs
+// per capacity class, both capped at NHDFIT_MAX_GROUPS exactly as the host packer caps them (more never matters).
+// Counts travel as sixteen 4-bit saturating counters in one 64-bit word: no local arrays (dynamically indexed local
+// arrays live in scratch memory on the GPU - a dependent memory round trip per access).
+NHD_HD uint64_t count_add(uint64_t counts, uint32_t cls) {
+    const uint32_t sh = 4 * (cls & 15u);
+    return ((counts >> sh) & 15u) < 15u ? counts + (1ull << sh) : counts;
+}
+NHD_HD uint64_t pool_key_packed(uint32_t glimit, uint64_t counts) {
+    uint64_t k = (uint64_t)(glimit & 0xFFu) << 48;
+    for (uint32_t c = 0; c < NHDFIT_MAX_CLASSES; ++c) {
+        const uint64_t n = (counts >> (4 * c)) & 15u;
+        k |= (n > (uint64_t)kMaxG ? (uint64_t)kMaxG : n) << (3 * c);
+    }
+    return k;
+}
+NHD_HD uint64_t pool_key(uint32_t glimit, const uint8_t cnt[NHDFIT_MAX_CLASSES]) {       // host side: dictionary entries
+    uint64_t k = (uint64_t)(glimit & 0xFFu) << 48;
+    for (uint32_t c = 0; c < NHDFIT_MAX_CLASSES; ++c) k |= (uint64_t)(cnt[c] > kMaxG ? kMaxG : cnt[c]) << (3 * c);
+    return k;
+}
+NHD_HD uint64_t mix64(uint64_t k) { k ^= k >> 33; k *= 0xFF51AFD7ED558CCDull; k ^= k >> 33; k *= 0xC4CEB9FE1A85EC53ull; k ^= k >> 33; return k; }
+// key of a pool SET (order-free): sum of mixed pool keys, tagged with the pool count
+NHD_HD uint64_t sig_key_add(uint64_t acc, uint64_t pk) { return acc + mix64(pk) + 0x9E3779B97F4A7C15ull; }
+
+// keys of the NUMA-mode and PCI-mode signature of NUMA node u from a detail record (host packer: pack_node_into)
+NHD_HD void sig_keys_of(const nhdfit_detail& d, uint32_t u, uint64_t& key_numa, uint64_t& key_pci) {
+    key_numa = key_pci = 0;
+    const uint32_t n = d.nic_cnt[u];
+    uint64_t all = 0;
+    for (uint32_t k = 0; k < n; ++k) all = count_add(all, d.nic_cls[u][k]);
+    if (n) key_numa = sig_key_add(0, pool_key_packed(NHDFIT_GLIMIT_NONE, all));
+    uint32_t seen = 0;                                           // local switch ids already turned into a pool
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t sw = d.nic_sw[u][k];
+        if (seen >> sw & 1) continue;
+        seen |= 1u << sw;
+        const uint32_t gl = d.sw_free[sw] > kMaxG ? kMaxG : d.sw_free[sw];
+        if (!gl) continue;                                       // no free GPU behind it: the pool hosts nothing
+        uint64_t cnt = 0;
+        for (uint32_t j = k; j < n; ++j)
+            if (d.nic_sw[u][j] == sw) cnt = count_add(cnt, d.nic_cls[u][j]);
+        key_pci = sig_key_add(key_pci, pool_key_packed(gl, cnt));
+    }
+}
+
+struct SigTable {                    // open addressing, built by the host from the dictionary (nhdfit_set_dictionary)
+    const uint64_t* key;             // [slots]: 0 = empty (the empty signature, key 0, is id 0 by convention)
+    const uint32_t* id;
+    uint32_t mask;                   // slots - 1
+};
+NHD_HD bool sig_lookup(const SigTable& t, uint64_t key, uint32_t& id) {
+    if (key == 0) { id = 0; return true; }
+    for (uint32_t s = (uint32_t)mix64(key) & t.mask, probes = 0; probes <= t.mask; ++probes, s = (s + 1) & t.mask) {
+        if (t.key[s] == key) { id = t.id[s]; return true; }
+        if (t.key[s] == 0) return false;
+    }
+    return false;
+}
+
+// One placement on one node.  `s` / `d` are modified in place; `out` receives the physical ids.
+NHD_HD int commit_node(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, const nhdfit_mapping& m, double busy_time,
+                       const SigTable& sigs, nhdfit_placement& out) {
+    const int G = (int)r.n_groups;
+    int status = kCommitOk;
+    for (int g = 0; g < kMaxG; ++g) {
+        out.proc_take[g] = out.proc_pair[g] = out.help_take[g] = out.help_pair[g] = 0;
+        for (int k = 0; k < NHDFIT_PLACEMENT_GPUS; ++k) out.gpu[g][k] = 0xFF;
+        out.numa[g] = -1;
+    }
+    out.misc_take = out.misc_pair = 0;
+    out.numa[kMaxG] = -1;
+    out.pad[0] = out.pad[1] = 0;
+    s.p4.busy_time = busy_time;                                                     // SetBusy, nhd/Node.py:843-845
+    uint32_t claimed0 = 0, claimed1 = 0;                                            // NIC ordinals to claim, per NUMA node
+    bool gpu_taken = false;
+    for (int g = 0; g < G; ++g) {
+        const uint32_t u = (uint32_t)m.gpu[g] & 1u;
+        out.numa[g] = (int8_t)u;
+        if (!take_batch(s, u, r.n_proc[g], (r.smt_bits >> g & 1) != 0, out.proc_take[g], out.proc_pair[g])) status = kCommitWouldRaise;
+        const uint32_t nu = (uint32_t)m.nic_numa[g] & 1u, nk = (uint32_t)m.nic_idx[g] & 15u;
+        const uint32_t sw = d.nic_sw[nu][nk];
+        for (uint32_t k = 0; k < r.gpus[g]; ++k) {
+            int pick = -1;
+            for (int x = 0; x < d.n_gpus && pick < 0; ++x)                          // GetFreePciGpuFromNic, Node.py:648-655
+                if ((s.p2.gpu_free >> x & 1) && d.gpu_sw[x] == sw) pick = x;
+            if (pick < 0 && r.map_type != NHDFIT_MAP_PCI)
+                for (int x = 0; x < d.n_gpus && pick < 0; ++x)                      // GetNextGpuFree, Node.py:495-500
+                    if ((s.p2.gpu_free >> x & 1) && (s.p2.gpu_numa1 >> x & 1) == u) pick = x;
+            if (pick < 0) { status = kCommitWouldRaise; continue; }
+            s.p2.gpu_free &= ~(1u << pick);
+            if (d.sw_free[d.gpu_sw[pick]]) d.sw_free[d.gpu_sw[pick]]--;
+            gpu_taken = true;
+            if (k < (uint32_t)NHDFIT_PLACEMENT_GPUS) out.gpu[g][k] = (uint8_t)pick;
+        }
+        if (!take_batch(s, u, r.n_help[g], (r.smt_bits >> (4 + g) & 1) != 0, out.help_take[g], out.help_pair[g])) status = kCommitWouldRaise;
+        if (r.nic_use >> g & 1) { if (nu) claimed1 |= 1u << nk; else claimed0 |= 1u << nk; }
+    }
+    if (r.hugepages_gb > 0) s.p2.hp_free -= r.hugepages_gb;                        // Node.py:794-796
+    const uint32_t mu = (uint32_t)m.cpu[G] & 1u;
+    out.numa[kMaxG] = (int8_t)mu;
+    if (!take_batch(s, mu, r.n_misc, r.misc_smt_enabled != 0, out.misc_take, out.misc_pair)) status = kCommitWouldRaise;   // Node.py:799
+    for (uint32_t k = 0; k < (uint32_t)NHDFIT_MAX_NICS_PER_NUMA; ++k) {                 // ClaimPodNICResources: capacity class 0 = 0.0
+        if (claimed0 >> k & 1) d.nic_cls[0][k] = 0;
+        if (claimed1 >> k & 1) d.nic_cls[1][k] = 0;
+    }
+    // the node's NIC signatures under the new NIC / GPU state (a NUMA node without a claim keeps its ids unless a GPU
+    // was taken: the free-GPU count behind a switch enters the PCI-mode pools)
+    for (uint32_t u = 0; u < 2; ++u) {
+        if (!(u ? claimed1 : claimed0) && !gpu_taken) continue;
+        uint64_t kn, kp;
+        uint32_t idn = 0, idp = 0;
+        sig_keys_of(d, u, kn, kp);
+        if (!sig_lookup(sigs, kn, idn) || !sig_lookup(sigs, kp, idp)) { if (status == kCommitOk) status = kCommitNewSig; }
+        s.p3.sig_numa[u] = (uint16_t)idn;
+        s.p3.sig_pci[u] = (uint16_t)idp;
+    }
+    out.status = (uint8_t)status;
+    return status;
+}
+
+}  // namespace nhdfit

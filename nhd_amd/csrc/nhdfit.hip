@@ -29,7 +29,6 @@
 #include <vector>
 
 #include "seq_core.h"
-#include "set_states.h"
 
 using namespace nhdfit;
 
@@ -919,74 +918,453 @@ __global__ __launch_bounds__(BLOCK, 6) void k_role(StepArgs a) {
     else role_fit<BLOCK>(a.fit, blk, lds);
 }
 
-// ---- mode B: sequential resolver ------------------------------------------------------------------
+// ---- mode B: sequential commit on the device (seq_core.h) ---------------------------------------------
 __global__ __launch_bounds__(64) void k_nogpu(const nhdfit_plane2* __restrict__ p2, uint32_t n, uint64_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     const uint64_t w = __ballot(i < n && !(p2[i].flags & NHDFIT_NF_HAS_GPU));
     if (threadIdx.x == 0) out[blockIdx.x] = w;
 }
 
-struct ResolveArgs {
-    SeqStatic s;
-    const nhdfit_req* reqs;          // class-sorted order (as staged)
-    const PodHeader* hdr;
-    const unsigned long long* score;
-    const nhdfit_mapping* maps;
-    const uint64_t* bitmap;          // [chunks][P] snapshot feasibility
-    const uint64_t* nogpu;           // [chunks]
-    const uint32_t* order;           // caller's pod i -> staged position
-    uint32_t P, chunks;
-    int32_t* slot_of;                // [n], -1
-    OverlayNode* overlay;            // [P]
-    SeqResult* out;                  // [P], caller's order
+// per tile: pods that request GPUs / are in PCI mode (node_word_cold's masks)
+__global__ __launch_bounds__(64) void k_tile_masks(const PodHeader* __restrict__ hdr, uint32_t tiles, uint64_t* __restrict__ out) {
+    const PodHeader h = hdr[blockIdx.x * 64 + threadIdx.x];
+    const uint64_t need = __ballot((h.flags & kPodNeedGpu) != 0), pci = __ballot((h.flags & kPodPci) != 0);
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = need; out[2 * blockIdx.x + 1] = pci; }
+}
+
+struct UndoRec { uint32_t node, pad[3]; NodeState st; nhdfit_detail d; };
+
+struct SeqArgs {
+    nhdfit_plane0* p0; nhdfit_plane1* p1; nhdfit_plane2* p2; nhdfit_plane3* p3; nhdfit_plane4* p4; nhdfit_detail* det;   // the mirror (modified)
+    uint32_t n, chunks; uint64_t global_base; double now;
+    const nhdfit_req* reqs; const PodHeader* hdr; const unsigned long long* score; uint32_t P;
+    const uint32_t* order;           // caller's pod i -> staged (class-sorted) position
+    const uint8_t* tabs; uint32_t pitch; const uint8_t* tile_wcls; Layout L[kWClasses];
+    uint64_t* rows;                  // [chunks][P] verdict rows of the snapshot, kept current
+    uint64_t* nm;                    // [tiles][chunks*64] the same matrix node-major, kept current
+    const uint64_t* nogpu;           // [chunks] nodes without a GPU installed
+    const uint64_t* tile_masks;      // [tiles][2]
+    const double* caps; SigTable sigs; uint32_t fc_dim, fg_dim, ngs;
+    MapTables mt;
+    UndoRec* undo; int32_t* touched; uint32_t* counters;     // first-touch copies (apply = 0), [n] -1 / slot, [0] = undo records
+    SeqResult* out; nhdfit_placement* place;                  // [P], caller's order
+    uint32_t first_pod; int64_t resume_nodes[8]; uint32_t* n_done;     // resume_nodes: -1 terminated
+    uint32_t lds_tables;
+    unsigned long long* prof;        // tuning aid (NHDFIT_SEQ_PROF): ticks (100 MHz) per phase, rounds, pods kept
+    uint32_t keep_undo;
 };
 
-// First still-feasible candidate >= from in pod `pos`'s snapshot bitmap row.  Each lane takes one 64-node
-// chunk word and tests ITS candidates (lanes run in parallel: 4 096 nodes per step); the earliest lane with
-// a hit wins.  Candidates on nodes no earlier pod touched pass immediately; dirty ones are re-evaluated.
-struct WaveScan {
-    const uint64_t* bitmap;
-    const uint64_t* nogpu;
-    uint32_t chunks, P, pos, lane;
-    __device__ int64_t find_first(bool pref, int64_t from, const StillFeasible& ok) const {
-        const uint32_t c0 = (uint32_t)(from >> 6);
-        for (uint32_t base = c0; base < chunks; base += 64) {
-            const uint32_t c = base + lane;
-            uint64_t w = c < chunks ? bitmap[(size_t)c * P + pos] : 0;
-            if (pref && c < chunks) w &= nogpu[c];
-            if (c == c0) w &= ~0ull << (from & 63);
-            int64_t mine = -1;
-            while (w) {
-                const int64_t nd = (int64_t)c * 64 + __builtin_ctzll(w);
-                if (ok(nd)) { mine = nd; break; }
-                w &= w - 1;
-            }
-            const uint64_t any = __ballot(mine >= 0);
-            if (any) {
-                const int l = __builtin_ctzll(any);
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, l);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)mine >> 32), l);
-                return (int64_t)(((uint64_t)hi << 32) | lo);
+// ---- wave-cooperative forms of the mapping arithmetic (winner_map.h), for the sequential kernel ---------------
+// One lane working through candidate_masks / first_nic_choice / nic_assignment_bits costs ~15 us per pod - the whole
+// wavefront is there, so every tuple code / NIC choice / table row gets a lane.  Same arithmetic, same order of the
+// f64 subtractions; the host twin and the mode-A roles keep the scalar forms (tests compare both).
+__device__ __forceinline__ uint32_t nic_assignment_bits_wave(const uint8_t* img, const Layout& L, uint32_t col, bool pci, const nhdfit_plane3& q3, uint32_t lane) {
+    const uint32_t o0 = L.off_r0 + (pci ? q3.sig_pci[0] : q3.sig_numa[0]) * L.row;
+    const uint32_t o1 = L.off_r1 + (pci ? q3.sig_pci[1] : q3.sig_numa[1]) * L.row;
+    const bool ok = lane < L.W && ((ld64(img, o0 + lane * 8) & ld64(img, o1 + lane * 8)) >> col & 1);
+    return (uint32_t)__ballot(ok);
+}
+__device__ __forceinline__ void candidate_masks_wave(const nhdfit_req& r, const WinnerState& w, uint32_t lane, uint32_t& sg_mask, uint32_t& sc_mask) {
+    const int G = (int)r.n_groups, U = w.U;
+    const uint32_t nG = ipow(U, G), nC = ipow(U, G + 1);
+    bool okg = false, okc = false;
+    if (lane < nG) {
+        uint32_t t0 = 0, t1 = 0;
+        for (int g = 0; g < G; ++g) { if (tup_digit(lane, G, U, g)) t1 += r.gpus[g]; else t0 += r.gpus[g]; }
+        okg = t0 <= (uint32_t)w.free_g[0] && t1 <= (uint32_t)w.free_g[1];
+    }
+    if (lane >= 32 && lane - 32 < nC) {
+        const uint32_t code = lane - 32;
+        uint32_t t0 = 0, t1 = 0;
+        for (int g = 0; g <= G; ++g) {
+            const uint32_t d = g < G ? (w.smt ? r.cpu_smt[g] : r.cpu_nosmt[g]) : (w.smt ? r.misc_smt : r.misc_nosmt);
+            if (tup_digit(code, G + 1, U, g)) t1 += d; else t0 += d;
+        }
+        okc = t0 <= (uint32_t)w.free_c[0] && t1 <= (uint32_t)w.free_c[1];
+    }
+    sg_mask = (uint32_t)__ballot(okg);
+    sc_mask = (uint32_t)(__ballot(okc) >> 32);
+}
+// first_nic_choice: lane = position in the reference's enumeration order (an odometer whose most significant digits are
+// the NUMA-0 groups in ascending order, then the NUMA-1 groups; last digit fastest), 64 positions per pass
+__device__ __forceinline__ bool first_nic_choice_wave(const nhdfit_req& r, const WinnerState& w, uint32_t gcode, bool pci, uint32_t lane, int8_t nic_idx[kMaxG]) {
+    const int G = (int)r.n_groups;
+    uint32_t order = 0, numa = 0;
+    int n = 0;
+    for (int u = 0; u < w.U; ++u)
+        for (int g = 0; g < G; ++g)
+            if (tup_digit(gcode, G, w.U, g) == u) { order = nib_set(order, n, (uint32_t)g); numa |= (uint32_t)u << g; ++n; }
+    uint32_t total = 1;
+    for (int g = 0; g < G; ++g) {
+        const uint32_t k = w.d->nic_cnt[(numa >> g) & 1];
+        if (k == 0) return false;
+        total *= k;
+    }
+    for (uint32_t base = 0; base < total; base += 64) {
+        uint32_t rem = base + lane, pick = 0;
+        const bool live = rem < total;
+        for (int pos = G - 1; pos >= 0; --pos) {
+            const int g = (int)nib_get(order, pos);
+            const uint32_t k = w.d->nic_cnt[(numa >> g) & 1];
+            pick = nib_set(pick, g, rem % k);
+            rem /= k;
+        }
+        bool ok = live;
+        for (int g = 0; g < G && ok; ++g) {
+            const uint32_t u = (numa >> g) & 1, k = nib_get(pick, g);
+            bool first_on_nic = true;
+            for (int h = 0; h < g; ++h)
+                if (((numa >> h) & 1) == u && nib_get(pick, h) == k) first_on_nic = false;
+            if (!first_on_nic) continue;
+            double rx = w.caps[w.d->nic_cls[u][k]], tx = rx;                     // Matcher.py:261-263, group order
+            for (int h = g; h < G; ++h)
+                if (((numa >> h) & 1) == u && nib_get(pick, h) == k) { rx = rx - r.rx[h]; tx = tx - r.tx[h]; }
+            if (rx < 0 || tx < 0) ok = false;                                    // Matcher.py:267
+        }
+        if (ok && pci) {                                                         // Matcher.py:312-322
+            for (int g = 0; g < G && ok; ++g) {
+                const uint32_t sw = w.d->nic_sw[(numa >> g) & 1][nib_get(pick, g)];
+                uint32_t cnt = 0;
+                for (int h = 0; h < G; ++h)
+                    if (w.d->nic_sw[(numa >> h) & 1][nib_get(pick, h)] == sw) ++cnt;
+                if (cnt > w.d->sw_free[sw]) ok = false;
             }
         }
-        return -1;
+        const uint64_t any = __ballot(ok);
+        if (any) {
+            const uint32_t best = (uint32_t)__builtin_amdgcn_readlane((int)pick, __builtin_ctzll(any));
+            for (int g = 0; g < G; ++g) nic_idx[g] = (int8_t)nib_get(best, g);
+            return true;
+        }
     }
-};
+    return false;
+}
+// rare paths of the mapping, kept out of line: inlined, their scratch arrays (generic set model) and scalar-register
+// spills (insertion-by-insertion model) would be paid by every pod of the sequential kernel
+__device__ __noinline__ bool map_generic_cold(const nhdfit_req* r, const WinnerState* w, uint32_t codes, nhdfit_mapping* m) {
+    return map_winner_t<GenericOps>(*r, *w, codes, *m);
+}
+__device__ __noinline__ uint32_t choose_model_cold(int G, int U, uint32_t sg, uint32_t sc, uint32_t cd, const AscEntry* asc) {
+    uint32_t gcode = 0;
+    int ccode = -1;
+    const bool ok = choose_tuples<SmallOps>(G, U, sg, sc, cd, gcode, ccode, asc);
+    return choose_result_word(ok, gcode, ccode);
+}
+// map_on_state (seq_core.h) with the parallel pieces; every lane returns the same mapping
+__device__ __forceinline__ bool map_on_state_wave(const nhdfit_req& r, const NodeState& s, const nhdfit_detail& d, const double* caps, uint32_t nic_bits,
+                                                  const MapTables& t, uint32_t lane, nhdfit_mapping& m) {
+    const WinnerState w = state_view(s, d, caps);
+    const int G = (int)r.n_groups, U = w.U;
+    m = nhdfit_mapping{};
+    const uint32_t codes = nic_codes_from_table_bits(nic_bits, G, U);
+    if (G > 3) return map_generic_cold(&r, &w, codes, &m);
+    uint32_t sg, sc;
+    candidate_masks_wave(r, w, lane, sg, sc);
+    const uint32_t cd = codes & ((1u << ipow(U, G)) - 1u);
+    if (!sg || !sc || !cd) return false;
+    uint32_t res;
+    if (t.choose_tab && choose_tabulated(G, U)) res = choose_from_table(t.choose_tab, G, sg, sc, cd);
+    else if (t.st.info && G == 3 && U == 2) res = choose_g3(t.st, t.asc, sg, sc, cd);
+    else res = choose_model_cold(G, U, sg, sc, cd, t.asc);
+    if (!(res >> 8 & 1)) return false;
+    const uint32_t gcode = (res >> 4) & 7u;
+    const int ccode = (int)(res & 15u);
+    for (int g = 0; g < kMaxG; ++g) { m.gpu[g] = m.nic_numa[g] = m.nic_idx[g] = -1; }
+    for (int g = 0; g <= kMaxG; ++g) m.cpu[g] = -1;
+    if (!first_nic_choice_wave(r, w, gcode, r.map_type == NHDFIT_MAP_PCI, lane, m.nic_idx)) return false;
+    for (int g = 0; g < G; ++g) { m.gpu[g] = (int8_t)tup_digit(gcode, G, U, g); m.nic_numa[g] = m.gpu[g]; }
+    for (int g = 0; g <= G; ++g) m.cpu[g] = (int8_t)tup_digit((uint32_t)ccode, G + 1, U, g);
+    m.valid = 1;
+    return true;
+}
 
-// One wavefront walks the batch in the caller's order (the chain of decisions is inherently sequential);
-// all lanes carry the same scalar state, the bitmap row scans use the whole wave.
-template <bool SMALL_ONLY>
-__global__ __launch_bounds__(64) void k_resolve(ResolveArgs a) {
-    const uint32_t lane = threadIdx.x;
-    uint32_t n_overlay = 0;
-    for (uint32_t i = 0; i < a.P; ++i) {
-        const uint32_t pos = a.order[i];
-        WaveScan scan{a.bitmap, a.nogpu, a.chunks, a.P, pos, lane};
-        SeqResult res;
-        resolve_pod<WaveScan, SMALL_ONLY>(a.s, a.reqs[pos], a.hdr[pos], a.score[pos], a.maps[pos], scan, a.slot_of,
-                                          a.overlay, &n_overlay, res);
-        if (lane == 0) a.out[i] = res;
+// One block walks the batch in the caller's order, kSeqPods pods per round (one per wavefront):
+//   (1) every wavefront finds its pod's node in the pod's row (all rows are current at this point);
+//   (2) the round keeps the longest prefix of pods whose nodes are pairwise different.  A commit only clears bits of
+//       ITS node's column, and a pod's node is the first set bit of its row: committing another node first cannot
+//       change that choice - so the pods of the prefix are independent and exactly what the one-by-one loop decides;
+//   (3) one lane per kept pod maps it against the node's current state and commits (commit_core.h);
+//   (4) all threads re-evaluate the committed nodes' columns against every tile (cold rows) and patch the rows.
+// The next round starts at the first pod that was not kept.
+constexpr int kSeqPods = 8;
+constexpr int kSeqThreads = 64 * kSeqPods;
+__global__ __launch_bounds__(kSeqThreads) void k_seq(SeqArgs a) {
+    __shared__ PaddedReq s_req[kSeqPods];
+    __shared__ nhdfit_detail s_det[kSeqPods];
+    __shared__ NodeState s_st[kSeqPods];
+    __shared__ int64_t s_node[kSeqPods];
+    __shared__ uint32_t s_pos[kSeqPods];
+    __shared__ int32_t s_status[kSeqPods];
+    __shared__ nhdfit_placement s_place[kSeqPods];
+    __shared__ SeqResult s_res[kSeqPods];
+    __shared__ int32_t s_stop;
+    __shared__ uint64_t s_changed[kSeqThreads];
+    __shared__ double s_caps[NHDFIT_MAX_CLASSES];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tiles = (a.P + kTile - 1) / kTile;
+    const size_t npad = (size_t)a.chunks * 64;
+    if (tid == 0) s_stop = 0;
+    if (tid < NHDFIT_MAX_CLASSES) s_caps[tid] = a.caps[tid];
+    // small per-batch look-up data the chain would otherwise fetch from L2 pod after pod: staged in LDS once
+    // (a.lds_tables = 0: the batch is too large, they stay in global memory)
+    extern __shared__ __align__(16) uint8_t s_dyn[];
+    const uint32_t* order = a.order;
+    const uint64_t* tile_masks = a.tile_masks;
+    const uint8_t* tile_wcls = a.tile_wcls;
+    SigTable sigs = a.sigs;
+    if (a.lds_tables) {
+        uint8_t* q = s_dyn;
+        uint64_t* l_masks = carve<uint64_t>(q, (size_t)tiles * 2);
+        uint64_t* l_skey = carve<uint64_t>(q, (size_t)a.sigs.mask + 1);
+        uint32_t* l_sid = carve<uint32_t>(q, (size_t)a.sigs.mask + 1);
+        uint32_t* l_order = carve<uint32_t>(q, a.P);
+        uint8_t* l_wcls = carve<uint8_t>(q, tiles);
+        for (uint32_t k = tid; k < tiles * 2; k += kSeqThreads) l_masks[k] = a.tile_masks[k];
+        for (uint32_t k = tid; k <= a.sigs.mask; k += kSeqThreads) { l_skey[k] = a.sigs.key[k]; l_sid[k] = a.sigs.id[k]; }
+        for (uint32_t k = tid; k < a.P; k += kSeqThreads) l_order[k] = a.order[k];
+        for (uint32_t k = tid; k < tiles; k += kSeqThreads) l_wcls[k] = a.tile_wcls[k];
+        order = l_order; tile_masks = l_masks; tile_wcls = l_wcls;
+        sigs = SigTable{l_skey, l_sid, a.sigs.mask};
     }
+
+    auto load_node = [&](uint32_t slot, uint32_t v) {             // planes + detail of node v -> LDS slot (one wavefront)
+        uint32_t* st = reinterpret_cast<uint32_t*>(&s_st[slot]);
+        if (lane < 5) {
+            const uint4 q = lane == 0 ? *reinterpret_cast<const uint4*>(a.p0 + v) : lane == 1 ? *reinterpret_cast<const uint4*>(a.p1 + v) :
+                            lane == 2 ? *reinterpret_cast<const uint4*>(a.p2 + v) : lane == 3 ? *reinterpret_cast<const uint4*>(a.p3 + v) :
+                                        *reinterpret_cast<const uint4*>(a.p4 + v);
+            st[lane * 4 + 0] = q.x; st[lane * 4 + 1] = q.y; st[lane * 4 + 2] = q.z; st[lane * 4 + 3] = q.w;
+        }
+        if (lane >= 8 && lane < 16) {
+            const uint4 q = reinterpret_cast<const uint4*>(a.det + v)[lane - 8];
+            uint32_t* dd = reinterpret_cast<uint32_t*>(&s_det[slot]) + (lane - 8) * 4;
+            dd[0] = q.x; dd[1] = q.y; dd[2] = q.z; dd[3] = q.w;
+        }
+    };
+    auto store_node = [&](uint32_t slot, uint32_t v) {
+        const uint32_t* st = reinterpret_cast<const uint32_t*>(&s_st[slot]);
+        if (lane < 5) {
+            const uint4 q = make_uint4(st[lane * 4], st[lane * 4 + 1], st[lane * 4 + 2], st[lane * 4 + 3]);
+            if (lane == 0) *reinterpret_cast<uint4*>(a.p0 + v) = q;
+            else if (lane == 1) *reinterpret_cast<uint4*>(a.p1 + v) = q;
+            else if (lane == 2) *reinterpret_cast<uint4*>(a.p2 + v) = q;
+            else if (lane == 3) *reinterpret_cast<uint4*>(a.p3 + v) = q;
+            else *reinterpret_cast<uint4*>(a.p4 + v) = q;
+        }
+        if (lane >= 8 && lane < 16) {
+            const uint32_t* dd = reinterpret_cast<const uint32_t*>(&s_det[slot]) + (lane - 8) * 4;
+            reinterpret_cast<uint4*>(a.det + v)[lane - 8] = make_uint4(dd[0], dd[1], dd[2], dd[3]);
+        }
+    };
+    // columns of the nodes in slots [0, cnt) flagged in `mask` against every tile (cold rows); rows patched where a
+    // pod lost a node.  All threads; ends with a barrier.
+    auto refresh_columns = [&](uint32_t cnt, uint32_t mask) {
+        for (uint32_t k0 = 0; k0 < cnt * tiles; k0 += kSeqThreads) {
+            const uint32_t k = k0 + tid;
+            uint64_t changed = 0;
+            uint32_t slot = 0, t = 0;
+            if (k < cnt * tiles) {
+                slot = k / tiles; t = k % tiles;
+                if (mask >> slot & 1) {
+                    const uint32_t v = (uint32_t)s_node[slot];
+                    const NodeState& st = s_st[slot];
+                    const NodeIdx ni = node_index(st.p0, st.p1, st.p2, st.p4, a.fc_dim, a.fg_dim, a.ngs);
+                    const bool busy = (a.now - st.p4.busy_time) < kMinBusySecs;
+                    const uint64_t old = a.nm[(size_t)t * npad + v];
+                    const uint64_t word = node_word_cold(a.tabs + (size_t)t * a.pitch, a.L[tile_wcls[t]], ni, st.p3, busy,
+                                                         tile_masks[2 * t], tile_masks[2 * t + 1]);
+                    changed = old & ~word;
+                    if (changed) a.nm[(size_t)t * npad + v] = old & word;
+                }
+            }
+            s_changed[tid] = changed;
+            __syncthreads();
+            const uint32_t span = cnt * tiles - k0 < (uint32_t)kSeqThreads ? cnt * tiles - k0 : kSeqThreads;
+            for (uint32_t q = tid; q < span * 64; q += kSeqThreads) {
+                const uint32_t e = q >> 6, j = q & 63;
+                if (s_changed[e] >> j & 1) {
+                    const uint32_t kk = k0 + e, sl = kk / tiles, tt = kk % tiles, v = (uint32_t)s_node[sl];
+                    // two nodes of one 64-node chunk may lose the same pod in the same round: atomic
+                    atomicAnd(reinterpret_cast<unsigned long long*>(&a.rows[(size_t)(v >> 6) * a.P + (size_t)tt * 64 + j]), ~(1ull << (v & 63)));
+                }
+            }
+            __syncthreads();
+        }
+    };
+    __syncthreads();
+    {   // nodes the host patched after a NEW_SIG stop: their columns are refreshed before the batch continues
+        uint32_t cnt = 0;
+        for (; cnt < (uint32_t)kSeqPods && a.resume_nodes[cnt] >= 0; ++cnt) {
+            if (wave == cnt) { load_node(cnt, (uint32_t)a.resume_nodes[cnt]); if (lane == 0) s_node[cnt] = a.resume_nodes[cnt]; }
+        }
+        __syncthreads();
+        if (cnt) refresh_columns(cnt, (1u << cnt) - 1u);
+    }
+
+    uint32_t i = a.first_pod;
+    unsigned long long t_find = 0, t_map = 0, t_col = 0, n_rounds = 0, tick = a.prof ? wall_clock64() : 0;
+    unsigned long long t_sub[5] = {0, 0, 0, 0, 0}, sub = 0;
+    auto sublap = [&](int k) { if (a.prof && wave == 0) { const unsigned long long t = wall_clock64(); t_sub[k] += t - sub; sub = t; } };
+    auto lap = [&](unsigned long long& acc) { if (a.prof) { const unsigned long long t = wall_clock64(); acc += t - tick; tick = t; } };
+    while (i < a.P) {
+        if (s_stop) break;
+        // (1) wavefront w: pod i + w
+        const uint32_t mine = i + wave;
+        int64_t nd = -1;
+        if (mine < a.P) {
+            const uint32_t pos = order[mine];
+            if (lane < sizeof(nhdfit_req) / 16) {
+                const uint4 v = reinterpret_cast<const uint4*>(a.reqs + pos)[lane];
+                uint32_t* dst = reinterpret_cast<uint32_t*>(&s_req[wave]) + lane * 4;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+            const unsigned long long score_a = a.score[pos];
+            if (score_a) {      // first feasible node of the pod's row, GPU-less nodes first for a GPU-less pod
+                const int64_t winner_a = (int64_t)(NHDFIT_SCORE_INDEX(score_a) - a.global_base);
+                for (int pass = (score_a >> 63) ? 0 : 1; pass < 2 && nd < 0; ++pass) {
+                    const bool pref = pass == 0;
+                    const int64_t from = pref ? winner_a : ((score_a >> 63) ? 0 : winner_a);
+                    for (uint32_t base = (uint32_t)(from >> 6); base < a.chunks && nd < 0; base += 64) {
+                        const uint32_t c = base + lane;
+                        uint64_t w = c < a.chunks ? a.rows[(size_t)c * a.P + pos] : 0;
+                        if (pref && c < a.chunks) w &= a.nogpu[c];
+                        if (c == (uint32_t)(from >> 6)) w &= ~0ull << (from & 63);
+                        const uint64_t any = __ballot(w != 0);
+                        if (any) {
+                            const int l = __builtin_ctzll(any);
+                            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, l);
+                            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
+                            nd = (int64_t)(base + l) * 64 + __builtin_ctzll(((uint64_t)hi << 32) | lo);
+                        }
+                    }
+                }
+            }
+            if (lane == 0) { s_node[wave] = nd; s_pos[wave] = pos; s_status[wave] = 0; }
+        } else if (lane == 0) { s_node[wave] = -2; s_status[wave] = 0; }          // past the end of the batch
+        __syncthreads();
+        lap(t_find);
+        // (2) longest prefix of pods with pairwise different nodes
+        uint32_t keep = 0;
+        for (; keep < (uint32_t)kSeqPods && s_node[keep] != -2; ++keep) {
+            bool clash = false;
+            for (uint32_t e = 0; e < keep; ++e) clash = clash || (s_node[keep] >= 0 && s_node[e] == s_node[keep]);
+            if (clash) break;
+        }
+        // (3) map + commit: one wavefront per kept pod
+        if (wave < keep) {
+            if (nd < 0) {
+                if (lane == 0) { SeqResult r; r.node = -1; r.map = nhdfit_mapping{}; r.status = 0; a.out[mine] = r; }
+            } else {
+                const uint32_t v = (uint32_t)nd;
+                if (a.prof && wave == 0) sub = wall_clock64();
+                const int32_t seen = lane == 0 ? a.touched[v] : 0;       // requested together with the node record
+                load_node(wave, v);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const nhdfit_req& rq = s_req[wave].r;
+                    NodeState& st = s_st[wave];
+                    nhdfit_detail& dd = s_det[wave];
+                    sublap(0);
+                    const uint32_t pos = s_pos[wave], tile = pos >> 6;
+                    const uint32_t bits = nic_assignment_bits_wave(a.tabs + (size_t)tile * a.pitch, a.L[tile_wcls[tile]], pos & 63,
+                                                                   rq.map_type == NHDFIT_MAP_PCI, st.p3, lane);
+                    sublap(1);
+                    nhdfit_mapping mp;
+                    const bool mapped = map_on_state_wave(rq, st, dd, s_caps, bits, a.mt, lane, mp);      // all lanes, same result
+                    __builtin_amdgcn_wave_barrier();
+                    sublap(2);
+                    const int32_t first_touch = __builtin_amdgcn_readfirstlane(seen) < 0;
+                    if (first_touch) {                                   // first touch of this batch: keep the original (whole wavefront copies)
+                        uint32_t slot = 0;
+                        if (lane == 0) { slot = atomicAdd(&a.counters[0], 1u); a.touched[v] = (int32_t)slot; }
+                        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+                        if (a.keep_undo) {
+                            uint32_t* dst = reinterpret_cast<uint32_t*>(&a.undo[slot]);
+                            if (lane == 0) dst[0] = v;
+                            if (lane < sizeof(NodeState) / 4) dst[4 + lane] = reinterpret_cast<const uint32_t*>(&st)[lane];
+                            if (lane < sizeof(nhdfit_detail) / 4) dst[4 + sizeof(NodeState) / 4 + lane] = reinterpret_cast<const uint32_t*>(&dd)[lane];
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) {
+                        SeqResult& res = s_res[wave];
+                        nhdfit_placement& pl = s_place[wave];
+                        res.node = (int64_t)a.global_base + nd;
+                        res.map = mp;
+                        if (mapped) {
+                            res.status = commit_node(st, dd, rq, res.map, a.now, sigs, pl);
+                        } else {
+                            memset(&pl, 0, sizeof pl);
+                            res.map = nhdfit_mapping{};
+                            res.status = kCommitWouldRaise;              // the row said feasible, the mapping disagrees: cannot happen
+                            pl.status = kCommitWouldRaise;
+                        }
+                        s_status[wave] = res.status;
+                        if (res.status == kCommitNewSig) s_stop = 1;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    sublap(3);
+                    if (lane < sizeof(SeqResult) / 4) reinterpret_cast<uint32_t*>(&a.out[mine])[lane] = reinterpret_cast<const uint32_t*>(&s_res[wave])[lane];
+                    if (a.place && lane < sizeof(nhdfit_placement) / 4)
+                        reinterpret_cast<uint32_t*>(&a.place[mine])[lane] = reinterpret_cast<const uint32_t*>(&s_place[wave])[lane];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                store_node(wave, v);
+                sublap(4);
+            }
+        }
+        __syncthreads();
+        lap(t_map);
+        // (4) columns of the committed nodes (not of those the host has to patch first)
+        uint32_t mask = 0;
+        for (uint32_t e = 0; e < keep; ++e)
+            if (s_node[e] >= 0 && s_status[e] != kCommitNewSig) mask |= 1u << e;
+        if (mask) refresh_columns(keep, mask);
+        lap(t_col);
+        ++n_rounds;
+        i += keep;
+    }
+    if (tid == 0) *a.n_done = i;
+    if (tid == 0 && a.prof) { a.prof[0] = t_find; a.prof[1] = t_map; a.prof[2] = t_col; a.prof[3] = n_rounds; a.prof[4] = i - a.first_pod;
+                              for (int k = 0; k < 5; ++k) a.prof[5 + k] = t_sub[k]; }
+}
+
+// apply = 0: put the touched nodes back
+__global__ __launch_bounds__(64) void k_undo(SeqArgs a) {
+    const uint32_t k = blockIdx.x;
+    if (k >= a.counters[0]) return;
+    const UndoRec& u = a.undo[k];
+    const uint32_t lane = threadIdx.x, v = u.node;
+    const uint32_t* st = reinterpret_cast<const uint32_t*>(&u.st);
+    if (lane < 5) {
+        const uint4 q = make_uint4(st[lane * 4], st[lane * 4 + 1], st[lane * 4 + 2], st[lane * 4 + 3]);
+        if (lane == 0) *reinterpret_cast<uint4*>(a.p0 + v) = q;
+        else if (lane == 1) *reinterpret_cast<uint4*>(a.p1 + v) = q;
+        else if (lane == 2) *reinterpret_cast<uint4*>(a.p2 + v) = q;
+        else if (lane == 3) *reinterpret_cast<uint4*>(a.p3 + v) = q;
+        else *reinterpret_cast<uint4*>(a.p4 + v) = q;
+    }
+    if (lane >= 8 && lane < 16) reinterpret_cast<uint4*>(a.det + v)[lane - 8] = reinterpret_cast<const uint4*>(&u.d)[lane - 8];
+}
+
+// the commit step for one placement (nhdfit_commit)
+struct CommitArgs {
+    nhdfit_plane0* p0; nhdfit_plane1* p1; nhdfit_plane2* p2; nhdfit_plane3* p3; nhdfit_plane4* p4; nhdfit_detail* det;
+    uint32_t node; nhdfit_req req; nhdfit_mapping map; double busy_time; SigTable sigs; nhdfit_placement* out;
+};
+__global__ __launch_bounds__(64) void k_commit(CommitArgs a) {
+    if (threadIdx.x != 0) return;
+    NodeState s;
+    s.p0 = a.p0[a.node]; s.p1 = a.p1[a.node]; s.p2 = a.p2[a.node]; s.p3 = a.p3[a.node]; s.p4 = a.p4[a.node];
+    nhdfit_detail d = a.det[a.node];
+    nhdfit_placement pl;
+    memset(&pl, 0, sizeof pl);
+    commit_node(s, d, a.req, a.map, a.busy_time, a.sigs, pl);
+    a.p0[a.node] = s.p0; a.p1[a.node] = s.p1; a.p2[a.node] = s.p2; a.p3[a.node] = s.p3; a.p4[a.node] = s.p4;
+    a.det[a.node] = d;
+    *a.out = pl;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1107,7 +1485,9 @@ struct nhdfit_ctx {
     DevBuf<uint64_t> st_info; DevBuf<uint32_t> st_next, st_asc; uint32_t st_n = 0;
     bool use_set_states = getenv("NHDFIT_NO_SET_STATES") == nullptr;
     // mode B
-    DevBuf<uint64_t> nogpu; DevBuf<int32_t> slot_of; DevBuf<OverlayNode> overlay; DevBuf<SeqResult> seq_out; DevBuf<uint32_t> order;
+    DevBuf<uint64_t> nogpu, tile_masks; DevBuf<int32_t> touched; DevBuf<UndoRec> undo; DevBuf<SeqResult> seq_out; DevBuf<nhdfit_placement> seq_place;
+    DevBuf<uint32_t> order, seq_counters;
+    DevBuf<uint64_t> sig_keys; DevBuf<uint32_t> sig_ids; uint32_t sig_mask = 0;   // canonical NIC-state key -> signature id (commit_core.h)
     bool use_cand = false, want_bitmap = true, want_map = true;
 
     // timing
@@ -1260,7 +1640,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
     c->reqs.release(); c->bitmap.release(); c->nm.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); c->shape_list[b].release(); }
-    c->nogpu.release(); c->slot_of.release(); c->overlay.release(); c->seq_out.release(); c->order.release();
+    c->nogpu.release(); c->tile_masks.release(); c->touched.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_counters.release(); c->sig_keys.release(); c->sig_ids.release();
     for (int b = 0; b < kBufs; ++b) {
         c->hdr[b].release(); c->tabs[b].release(); c->score[b].release(); c->maps[b].release();
         if (c->ev_fit[b]) (void)hipEventDestroy(c->ev_fit[b]);
@@ -1309,6 +1689,31 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     HIPCHK(c, hipMemcpy(c->pool_off.p, pool_off, (npools + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
     if (npools) HIPCHK(c, hipMemcpy(c->pool_glimit.p, pool_glimit, npools, hipMemcpyHostToDevice));
     if (ncc) HIPCHK(c, hipMemcpy(c->cc.p, cc, ncc * sizeof(nhdfit_cc), hipMemcpyHostToDevice));
+    {   // canonical key of every signature's pool set -> id, for the device-side commit (commit_core.h sig_keys_of)
+        uint32_t slots = 64;
+        while (slots < 4 * nsig) slots <<= 1;
+        std::vector<uint64_t> keys(slots, 0);
+        std::vector<uint32_t> ids(slots, 0);
+        for (uint32_t sg = 1; sg < nsig; ++sg) {
+            uint64_t key = 0;
+            for (uint32_t pl = sig_off[sg]; pl < sig_off[sg + 1]; ++pl) {
+                uint8_t cnt[NHDFIT_MAX_CLASSES] = {0};
+                for (uint32_t k = pool_off[pl]; k < pool_off[pl + 1]; ++k) cnt[cc[k].cls & 15u] = cc[k].cnt;
+                key = sig_key_add(key, pool_key(pool_glimit[pl], cnt));
+            }
+            if (key == 0) continue;                                   // a signature made of no pool is the empty one
+            uint32_t sl = (uint32_t)mix64(key) & (slots - 1);
+            while (keys[sl] != 0 && keys[sl] != key) sl = (sl + 1) & (slots - 1);
+            if (keys[sl] == key && ids[sl] != sg)
+                return fail(c, NHDFIT_E_INVAL, "signatures %u and %u describe the same NIC pools", ids[sl], sg);
+            keys[sl] = key; ids[sl] = sg;
+        }
+        HIPCHK(c, c->sig_keys.reserve(slots));
+        HIPCHK(c, c->sig_ids.reserve(slots));
+        HIPCHK(c, hipMemcpy(c->sig_keys.p, keys.data(), slots * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->sig_ids.p, ids.data(), slots * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->sig_mask = slots - 1;
+    }
     c->ncls = ncls;
     c->nsig = nsig;
     c->ngs = n_group_sets ? n_group_sets : 1;
@@ -1797,48 +2202,167 @@ int nhdfit_find(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, c
     return nhdfit_fetch(c, score_out, bitmap_out, map_out);
 }
 
-int nhdfit_find_sequential(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand,
-                           int64_t* node_out, nhdfit_mapping* map_out, int32_t* status_out) {
+namespace {
+MapTables map_tables(nhdfit_ctx* c) {
+    return MapTables{c->asc.p, c->use_choose_tab ? c->choose_tab.p : nullptr,
+                     c->use_set_states ? SetStates{c->st_info.p, c->st_next.p, c->st_asc.p, c->st_n} : SetStates{nullptr, nullptr, nullptr, 0}};
+}
+SigTable sig_table(nhdfit_ctx* c) { return SigTable{c->sig_keys.p, c->sig_ids.p, c->sig_mask}; }
+}  // namespace
+
+int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand, int apply,
+                          uint32_t first_pod, const int64_t* resume_nodes, uint32_t n_resume,
+                          int64_t* node_out, nhdfit_mapping* map_out, nhdfit_placement* place_out, int32_t* status_out,
+                          uint32_t* n_done) {
     if (!c) return NHDFIT_E_INVAL;
     if (c->comm) return fail(c, NHDFIT_E_STATE, "sequential (mode B) batches are single-shard: detach the communicator");
-    if (!node_out) return fail(c, NHDFIT_E_INVAL, "node_out is NULL");
-    const bool wb = c->want_bitmap, wm = c->want_map;
-    c->want_bitmap = c->want_map = true;
-    int rc = nhdfit_stage_requests(c, reqs, P);
-    if (!rc && cand) rc = stage_cand(c, cand);
-    if (!rc) rc = nhdfit_enqueue_step(c, now);
-    c->want_bitmap = wb; c->want_map = wm;
-    if (rc) return rc;
-    if ((rc = flush_pipeline(c))) return rc;                  // the resolver starts from the snapshot mappings
-    if ((rc = convert_rows(c))) return rc;                    // ... and walks pod-major rows of the snapshot verdicts
-    const int b = (int)((c->n_fit - 1) % kBufs);
-    const uint32_t chunks = (c->n + 63) / 64;
-    HIPCHK(c, c->nogpu.reserve(chunks));
-    HIPCHK(c, c->slot_of.reserve(c->n));
-    HIPCHK(c, c->overlay.reserve(P));
-    HIPCHK(c, c->seq_out.reserve(P));
-    HIPCHK(c, c->order.reserve(P));
-    std::vector<uint32_t> order(P);                       // caller's pod -> staged (class-sorted) position
-    for (uint32_t i = 0; i < P; ++i) order[c->perm[i]] = i;
+    if (!node_out || !n_done) return fail(c, NHDFIT_E_INVAL, "node_out / n_done is NULL");
+    if (first_pod > P) return fail(c, NHDFIT_E_INVAL, "first_pod %u beyond the batch (%u pods)", first_pod, P);
+    if (first_pod && !apply) return fail(c, NHDFIT_E_INVAL, "a batch can only be continued with apply != 0");
+    HIPCHK(c, hipSetDevice(c->dev));
     hipStream_t sm = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->order.p, order.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
-    HIPCHK(c, hipMemsetAsync(c->slot_of.p, 0xFF, (size_t)c->n * sizeof(int32_t), sm));
-    hipLaunchKernelGGL(k_nogpu, dim3(chunks), dim3(64), 0, sm, c->p2.p, c->n, c->nogpu.p);
-    ResolveArgs ra{SeqStatic{c->p0.p, c->p1.p, c->p2.p, c->p3.p, c->p4.p, c->det.p, c->caps.p, c->n, c->global_base, now},
-                   c->reqs.p, c->hdr[b].p, c->score[b].p, c->maps[b].p, c->bitmap.p, c->nogpu.p, c->order.p, P, chunks,
-                   c->slot_of.p, c->overlay.p, c->seq_out.p};
-    if (c->n_big_pods) hipLaunchKernelGGL(k_resolve<false>, dim3(1), dim3(64), 0, sm, ra);   // after the mapping, same stream
-    else hipLaunchKernelGGL(k_resolve<true>, dim3(1), dim3(64), 0, sm, ra);
+    const uint32_t chunks = (c->n + 63) / 64;
+    int rc;
+    if (first_pod == 0) {
+        // snapshot pass: digest + fit (verdict matrix and first-fit scores; the mapping roles are not needed - every
+        // placement of the batch is mapped against the node's state at ITS turn)
+        const bool wb = c->want_bitmap, wm = c->want_map;
+        c->want_bitmap = true; c->want_map = false;
+        rc = nhdfit_stage_requests(c, reqs, P);
+        if (!rc && cand) rc = stage_cand(c, cand);
+        if (!rc) rc = nhdfit_enqueue_step(c, now);
+        c->want_bitmap = wb; c->want_map = wm;
+        if (rc) return rc;
+        if ((rc = convert_rows(c))) return rc;
+        const uint32_t tiles = (P + kTile - 1) / kTile;
+        HIPCHK(c, c->nogpu.reserve(chunks ? chunks : 1));
+        HIPCHK(c, c->tile_masks.reserve((size_t)tiles * 2));
+        HIPCHK(c, c->touched.reserve(c->n ? c->n : 1));
+        HIPCHK(c, c->undo.reserve(apply ? 1 : P));
+        HIPCHK(c, c->seq_out.reserve(P));
+        HIPCHK(c, c->seq_place.reserve(P));
+        HIPCHK(c, c->order.reserve(P));
+        HIPCHK(c, c->seq_counters.reserve(4));
+        std::vector<uint32_t> order(P);                       // caller's pod -> staged (class-sorted) position
+        for (uint32_t i = 0; i < P; ++i) order[c->perm[i]] = i;
+        HIPCHK(c, hipMemcpyAsync(c->order.p, order.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
+        HIPCHK(c, hipStreamSynchronize(sm));                  // `order` is a local
+        HIPCHK(c, hipMemsetAsync(c->touched.p, 0xFF, (size_t)c->n * sizeof(int32_t), sm));
+        HIPCHK(c, hipMemsetAsync(c->seq_counters.p, 0, 4 * sizeof(uint32_t), sm));
+        hipLaunchKernelGGL(k_nogpu, dim3(chunks), dim3(64), 0, sm, c->p2.p, c->n, c->nogpu.p);
+        const int b0 = (int)((c->n_fit - 1) % kBufs);
+        hipLaunchKernelGGL(k_tile_masks, dim3(tiles), dim3(64), 0, sm, c->hdr[b0].p, tiles, c->tile_masks.p);
+        HIPCHK(c, hipGetLastError());
+    } else if (!c->P || P != c->P || !c->n_fit) {
+        return fail(c, NHDFIT_E_STATE, "no batch of %u pods to continue", P);
+    }
+    const int b = (int)((c->n_fit - 1) % kBufs);
+    SeqArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.p0 = c->p0.p; sa.p1 = c->p1.p; sa.p2 = c->p2.p; sa.p3 = c->p3.p; sa.p4 = c->p4.p; sa.det = c->det.p;
+    sa.n = c->n; sa.chunks = chunks; sa.global_base = c->global_base; sa.now = now;
+    sa.reqs = c->reqs.p; sa.hdr = c->hdr[b].p; sa.score = c->score[b].p; sa.P = P; sa.order = c->order.p;
+    sa.tabs = c->tabs[b].p; sa.pitch = c->pitch; sa.tile_wcls = c->tile_wcls.p;
+    for (int w = 0; w < kWClasses; ++w) sa.L[w] = c->L[w];
+    sa.rows = c->bitmap.p; sa.nm = c->nm.p; sa.nogpu = c->nogpu.p; sa.tile_masks = c->tile_masks.p;
+    sa.caps = c->caps.p; sa.sigs = sig_table(c); sa.fc_dim = c->max_cores + 1; sa.fg_dim = c->max_gpus + 1; sa.ngs = c->ngs;
+    sa.mt = map_tables(c);
+    sa.undo = c->undo.p; sa.touched = c->touched.p; sa.counters = c->seq_counters.p; sa.keep_undo = apply ? 0 : 1;
+    sa.out = c->seq_out.p; sa.place = c->seq_place.p;
+    if (n_resume > 8 || (n_resume && !resume_nodes)) return fail(c, NHDFIT_E_INVAL, "at most 8 resume nodes");
+    for (uint32_t k = 0; k < 8; ++k) sa.resume_nodes[k] = k < n_resume ? resume_nodes[k] : -1;
+    sa.first_pod = first_pod; sa.n_done = c->seq_counters.p + 1;
+    const uint32_t tiles_b = (P + kTile - 1) / kTile;
+    size_t seq_lds = lds_slice((size_t)tiles_b * 16) + lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4) +
+                     lds_slice((size_t)P * 4) + lds_slice(tiles_b);
+    sa.lds_tables = seq_lds <= 96 * 1024;
+    if (!sa.lds_tables) seq_lds = 0;
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_seq, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    const bool seq_prof = getenv("NHDFIT_SEQ_PROF") != nullptr;
+    if (seq_prof) { HIPCHK(c, c->role_clock.reserve(10)); sa.prof = c->role_clock.p; }
+    hipLaunchKernelGGL(k_seq, dim3(1), dim3(kSeqThreads), seq_lds, sm, sa);
+    if (seq_prof) {
+        unsigned long long t[10];
+        HIPCHK(c, hipStreamSynchronize(sm));
+        HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[nhdfit] k_seq wave 0 per round: node load %.1f, NIC bits %.1f, mapping %.1f, commit %.1f, write-back %.1f us\n",
+                t[5] * 0.01 / (double)(t[3] ? t[3] : 1), t[6] * 0.01 / (double)(t[3] ? t[3] : 1), t[7] * 0.01 / (double)(t[3] ? t[3] : 1),
+                t[8] * 0.01 / (double)(t[3] ? t[3] : 1), t[9] * 0.01 / (double)(t[3] ? t[3] : 1));
+        fprintf(stderr, "[nhdfit] k_seq: %llu pods in %llu rounds; find %.1f us, map+commit %.1f us, columns %.1f us per round\n", t[4], t[3],
+                t[0] * 0.01 / (double)(t[3] ? t[3] : 1), t[1] * 0.01 / (double)(t[3] ? t[3] : 1), t[2] * 0.01 / (double)(t[3] ? t[3] : 1));
+    }
+    if (!apply) hipLaunchKernelGGL(k_undo, dim3(P), dim3(64), 0, sm, sa);
     HIPCHK(c, hipGetLastError());
     std::vector<SeqResult> out(P);
+    uint32_t counters[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(out.data(), c->seq_out.p, P * sizeof(SeqResult), hipMemcpyDeviceToHost, sm));
+    HIPCHK(c, hipMemcpyAsync(counters, c->seq_counters.p, sizeof counters, hipMemcpyDeviceToHost, sm));
+    if (place_out) HIPCHK(c, hipMemcpyAsync(place_out, c->seq_place.p, (size_t)P * sizeof(nhdfit_placement), hipMemcpyDeviceToHost, sm));
     rc = nhdfit_sync(c);
     if (rc) return rc;
-    for (uint32_t i = 0; i < P; ++i) {
+    *n_done = counters[1];
+    int64_t lo = -1, hi = -1;
+    for (uint32_t i = first_pod; i < counters[1]; ++i) {
         node_out[i] = out[i].node;
         if (map_out) map_out[i] = out[i].map;
         if (status_out) status_out[i] = out[i].status;
+        if (out[i].node >= 0) {
+            const int64_t v = out[i].node - (int64_t)c->global_base;
+            lo = lo < 0 || v < lo ? v : lo;
+            hi = v + 1 > hi ? v + 1 : hi;
+        }
     }
+    if (apply && lo >= 0) {                                     // records of the committed nodes are stale
+        if (c->rec_lo == c->rec_hi) { c->rec_lo = (uint32_t)lo; c->rec_hi = (uint32_t)hi; }
+        else { c->rec_lo = std::min(c->rec_lo, (uint32_t)lo); c->rec_hi = std::max(c->rec_hi, (uint32_t)hi); }
+    }
+    return NHDFIT_OK;
+}
+
+int nhdfit_find_sequential(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand,
+                           int64_t* node_out, nhdfit_mapping* map_out, int32_t* status_out) {
+    // the mirror is left as it was; a NIC state without a signature cannot stop the batch here (nothing could be
+    // patched): the remaining pods simply see that node with the empty signature, which the caller is told about
+    uint32_t done = 0;
+    int rc = nhdfit_schedule_batch(c, reqs, P, now, cand, 0, 0, nullptr, 0, node_out, map_out, nullptr, status_out, &done);
+    if (rc) return rc;
+    if (done < P) return fail(c, NHDFIT_E_STATE, "pod %u left its node in a NIC state the dictionary has no signature for: "
+                              "use nhdfit_schedule_batch (apply) and intern it", done - 1);
+    return NHDFIT_OK;
+}
+
+int nhdfit_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_req* req, const nhdfit_mapping* map, double busy_time,
+                  nhdfit_placement* place_out) {
+    if (!c || !req || !map || !place_out) return NHDFIT_E_INVAL;
+    if (node >= c->n) return fail(c, NHDFIT_E_INVAL, "node %u out of range (%u nodes)", node, c->n);
+    if (!map->valid) return fail(c, NHDFIT_E_INVAL, "the mapping is not valid");
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, c->seq_place.reserve(1));
+    CommitArgs ca;
+    memset(&ca, 0, sizeof ca);
+    ca.p0 = c->p0.p; ca.p1 = c->p1.p; ca.p2 = c->p2.p; ca.p3 = c->p3.p; ca.p4 = c->p4.p; ca.det = c->det.p;
+    ca.node = node; ca.req = *req; ca.map = *map; ca.busy_time = busy_time; ca.sigs = sig_table(c); ca.out = c->seq_place.p;
+    hipLaunchKernelGGL(k_commit, dim3(1), dim3(64), 0, c->stream, ca);       // stream order: after every step in flight
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(place_out, c->seq_place.p, sizeof(nhdfit_placement), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->rec_lo == c->rec_hi) { c->rec_lo = node; c->rec_hi = node + 1; }
+    else { c->rec_lo = std::min(c->rec_lo, node); c->rec_hi = std::max(c->rec_hi, node + 1); }
+    return NHDFIT_OK;
+}
+
+int nhdfit_download_nodes(nhdfit_ctx* c, uint32_t first, uint32_t count, nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plane2* p2,
+                          nhdfit_plane3* p3, nhdfit_plane4* p4, nhdfit_detail* det) {
+    if (!c) return NHDFIT_E_INVAL;
+    if ((uint64_t)first + count > c->n) return fail(c, NHDFIT_E_INVAL, "download [%u,%u) exceeds the %u nodes of the mirror", first, first + count, c->n);
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (p0) HIPCHK(c, hipMemcpy(p0, c->p0.p + first, count * sizeof *p0, hipMemcpyDeviceToHost));
+    if (p1) HIPCHK(c, hipMemcpy(p1, c->p1.p + first, count * sizeof *p1, hipMemcpyDeviceToHost));
+    if (p2) HIPCHK(c, hipMemcpy(p2, c->p2.p + first, count * sizeof *p2, hipMemcpyDeviceToHost));
+    if (p3) HIPCHK(c, hipMemcpy(p3, c->p3.p + first, count * sizeof *p3, hipMemcpyDeviceToHost));
+    if (p4) HIPCHK(c, hipMemcpy(p4, c->p4.p + first, count * sizeof *p4, hipMemcpyDeviceToHost));
+    if (det) HIPCHK(c, hipMemcpy(det, c->det.p + first, count * sizeof *det, hipMemcpyDeviceToHost));
     return NHDFIT_OK;
 }
 

@@ -97,6 +97,58 @@ class Engine:
         self.P = P
         return node, maps, status
 
+    def schedule_batch(self, reqs: np.ndarray, now: float, packer: pack.Packer, cand: Optional[np.ndarray] = None, apply: bool = True):
+        """Mode B with the commit step on the device (nhdfit_schedule_batch): (node index or -1, mappings, placements,
+        status) per pod.  apply=True leaves the commits in the device mirror.  A commit that puts a node into a NIC
+        state the dictionary has no signature for stops the device pass; the state is interned here (`packer`), the
+        node's plane 3 patched, and the batch continues - with Packer.close_signatures() up front this never happens."""
+        reqs = np.ascontiguousarray(reqs)
+        P = len(reqs)
+        node = np.zeros(P, np.int64)
+        maps = np.zeros(P, pack.MAPPING)
+        places = np.zeros(P, pack.PLACEMENT)
+        status = np.zeros(P, np.int32)
+        if cand is not None:
+            cand = np.ascontiguousarray(cand, dtype=np.uint64)
+        done = ctypes.c_uint32(0)
+        first, resume = 0, np.zeros(0, np.int64)
+        while True:
+            self._chk(self.lib.nhdfit_schedule_batch(self.ctx, _p(reqs), P, float(now), _p(cand), int(apply), first,
+                                                     _p(resume) if len(resume) else None, len(resume),
+                                                     _p(node), _p(maps), _p(places), _p(status), ctypes.byref(done)))
+            if done.value >= P or not apply:
+                break
+            stuck = [int(node[i] - self.global_base) for i in range(first, done.value) if status[i] == pack.COMMIT_NEW_SIG]
+            assert stuck, "the device stopped a batch without reporting a new NIC state"
+            patched = []
+            for v in stuck:
+                one = self.download(v, 1)
+                sn, sp = packer.sigs_from_detail(one.detail[0])
+                one.p3[0]["sig_numa"] = sn
+                one.p3[0]["sig_pci"] = sp
+                patched.append((v, one))
+            self.set_dictionary(packer)
+            for v, one in patched:
+                self.upload(one, global_base=self.global_base, first=v, capacity=self.n)
+            first, resume = done.value, np.asarray(stuck, np.int64)
+        self.P = P
+        self.n_done = done.value
+        return node, maps, places, status
+
+    def commit(self, node: int, req: np.ndarray, mapping: np.ndarray, busy_time: float) -> np.ndarray:
+        """The commit step for one placement (nhdfit_commit): updates the device mirror, returns the placement record."""
+        out = np.zeros((), pack.PLACEMENT)
+        req = np.ascontiguousarray(req)
+        mapping = np.ascontiguousarray(mapping)
+        self._chk(self.lib.nhdfit_commit(self.ctx, int(node), _p(req), _p(mapping), float(busy_time), _p(out)))
+        return out
+
+    def download(self, first: int = 0, count: Optional[int] = None) -> pack.NodeTable:
+        count = self.n - first if count is None else count
+        t = pack.empty_table(count)
+        self._chk(self.lib.nhdfit_download_nodes(self.ctx, first, count, _p(t.p0), _p(t.p1), _p(t.p2), _p(t.p3), _p(t.p4), _p(t.detail)))
+        return t
+
     # ---- pipelined --------------------------------------------------------------------
     def stage(self, reqs: np.ndarray):
         reqs = np.ascontiguousarray(reqs)

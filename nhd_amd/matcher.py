@@ -49,7 +49,7 @@ def _tracked_class(base: type) -> type:
         if key in _WATCHED:
             hook = self.__dict__.get("_nhdfit_dirty")
             if hook is not None:
-                hook(self)
+                hook(self, key)
 
     ns = {"__setattr__": __setattr__}
     for name in _MUTATORS:
@@ -57,17 +57,28 @@ def _tracked_class(base: type) -> type:
         if orig is None:
             continue
 
-        def make(orig):
+        def make(orig, name):
             def wrapper(self, *a, **kw):
+                ok = False
                 try:
-                    return orig(self, *a, **kw)
+                    out = orig(self, *a, **kw)
+                    ok = True
+                    return out
                 finally:
                     hook = self.__dict__.get("_nhdfit_dirty")
                     if hook is not None:
-                        hook(self)
+                        # the commit step of AttemptScheduling (nhd/NHDScheduler.py:289-304) is mirrored on the device
+                        # instead of re-packing the node: see HipMatcher._on_commit / _on_claim
+                        done = False
+                        if ok and name == "SetPhysicalIdsFromMapping":
+                            done = self.__dict__["_nhdfit_owner"]._on_commit(self, *a, **kw)
+                        elif ok and name == "ClaimPodNICResources":
+                            done = self.__dict__["_nhdfit_owner"]._on_claim(self, *a, **kw)
+                        if not done:
+                            hook(self, name)
             wrapper.__name__ = orig.__name__
             return wrapper
-        ns[name] = make(orig)
+        ns[name] = make(orig, name)
     cls = type("Tracked" + base.__name__, (base,), ns)
     _tracked_cache[base] = cls
     return cls
@@ -87,6 +98,8 @@ class HipMatcher:
         self._names: List[str] = []
         self._table: Optional[pack.NodeTable] = None
         self._dirty: Dict[str, object] = {}
+        self._reasons: Dict[str, set] = {}
+        self._claims: Dict[str, frozenset] = {}
         self._uploaded_ids: Optional[Tuple[int, ...]] = None
 
     # ---- mirror maintenance -------------------------------------------------------------
@@ -97,21 +110,94 @@ class HipMatcher:
             if type(node) not in _tracked_cache.values():
                 node.__class__ = _tracked_class(type(node))
             node.__dict__["_nhdfit_dirty"] = self._mark
+            node.__dict__["_nhdfit_owner"] = self
         self._full_upload(nodes)
+        self.packer.close_signatures()                 # every NIC state a commit can produce gets its signature now
+        self.engine.set_dictionary(self.packer)
         self._dirty.clear()
+        self._reasons.clear()
+        self._claims = {}
 
     def detach(self) -> None:
         if self._attached:
             for node in self._attached.values():
                 node.__dict__.pop("_nhdfit_dirty", None)
+                node.__dict__.pop("_nhdfit_owner", None)
         self._attached = None
 
-    def _mark(self, node) -> None:
+    # ---- commit step mirrored on the device (row f1) ---------------------------------------
+    def _mapping_record(self, mapping) -> np.ndarray:
+        m = np.zeros((), pack.MAPPING)
+        G = len(mapping["gpu"])
+        m["gpu"][:G] = mapping["gpu"]
+        m["cpu"][:G + 1] = mapping["cpu"]
+        m["nic_numa"][:G] = [x[0] for x in mapping["nic"]]
+        m["nic_idx"][:G] = [x[1] for x in mapping["nic"]]
+        m["valid"] = 1
+        return m
+
+    def CommitPlacement(self, name: str, top, mapping, busy_time: Optional[float] = None) -> dict:
+        """The commit step of AttemptScheduling (SetBusy / SetPhysicalIdsFromMapping / ClaimPodNICResources,
+        nhd/NHDScheduler.py:289-304) applied to the DEVICE mirror of attached node `name` (nhdfit_commit); returns
+        the physical ids the reference would write into `top` (pack.expand_placement).  The Node object itself is
+        not touched."""
+        i = self._index[name]
+        node = self._attached[name] if self._attached is not None else None
+        req = self.packer.digest(top)
+        bt = float(node.busy_time if busy_time is None and node is not None else busy_time)
+        place = self.engine.commit(i, req, self._mapping_record(mapping), bt)
+        if int(place["status"]) == pack.COMMIT_NEW_SIG:        # cannot happen after close_signatures(); handled anyway
+            one = self.engine.download(i, 1)
+            sn, sp = self.packer.sigs_from_detail(one.detail[0])
+            one.p3[0]["sig_numa"], one.p3[0]["sig_pci"] = sn, sp
+            self.engine.set_dictionary(self.packer)
+            self.engine.upload(one, first=i, capacity=len(self._names))
+        cpp = int(node.cores_per_proc) if node is not None else 0
+        G = int(req["n_groups"])
+        return pack.expand_placement(place, G, cpp, cpp * int(node.sockets) if node is not None else 0,
+                                     [int(req["gpus"][g]) for g in range(G)])
+
+    def _on_commit(self, node, mapping, top) -> bool:
+        """After the reference's own SetPhysicalIdsFromMapping succeeded on an attached node: the same commit on the
+        device mirror, checked against what the reference just wrote into `top`.  True = the mirror is current."""
+        if self._attached is None or node.name not in self._index or node.name in self._dirty_strict:
+            return False
+        try:
+            ids = self.CommitPlacement(node.name, top, mapping)
+        except Exception:  # noqa: BLE001 - any doubt: fall back to re-packing the node
+            return False
+        pos = {g.device_id: k for k, g in enumerate(node.gpus)}
+        want = {"groups": [{"cores": [c.core for g in pg.group_gpus for c in g.cpu_cores] + [c.core for c in pg.proc_cores],
+                            "helpers": [c.core for c in pg.misc_cores], "gpus": [pos[g.device_id] for g in pg.group_gpus]}
+                           for pg in top.proc_groups], "misc": [c.core for c in top.misc_cores]}
+        if ids != want:
+            return False
+        claim = set()
+        for gi, pg in enumerate(top.proc_groups):
+            if any(getattr(c.nic_dir, "value", c.nic_dir) in (1, 2) for c in pg.proc_cores):
+                numa, idx = mapping["nic"][gi]
+                claim.add(next(k for k, n in enumerate(node.nics) if n.idx == idx and n.numa_node == numa))
+        self._claims[node.name] = frozenset(claim)             # the device already zeroed these NICs' capacities
+        self._dirty.pop(node.name, None)                       # SetBusy marked it: the commit carried the busy time
+        self._reasons.pop(node.name, None)
+        return True
+
+    def _on_claim(self, node, nidx) -> bool:
+        want = self._claims.pop(node.name, None) if hasattr(self, "_claims") else None
+        return want is not None and frozenset(nidx) == want
+
+    def _mark(self, node, reason: str = "") -> None:
         self._dirty[node.name] = node
+        self._reasons.setdefault(node.name, set()).add(reason)
+
+    @property
+    def _dirty_strict(self):
+        """Nodes whose pending change is more than a SetBusy() (the only mutator that precedes a commit)."""
+        return {nm for nm in self._dirty if not self._reasons.get(nm, {""}) <= {"busy_time", "SetBusy"}}
 
     def mark_dirty(self, name: str) -> None:
         if self._attached is not None and name in self._attached:
-            self._dirty[name] = self._attached[name]
+            self._mark(self._attached[name], "explicit")
 
     def _full_upload(self, nl: Dict[str, object]) -> None:
         table = self.packer.pack_nodes(nl)
@@ -129,6 +215,7 @@ class HipMatcher:
         if len(self._attached) != len(self._names) or any(nm not in self._index for nm in self._dirty):
             self._full_upload(self._attached)          # nodes were added or removed
             self._dirty.clear()
+            self._reasons.clear()
             return
         one = pack.empty_table(1)
         for name, node in self._dirty.items():
@@ -146,6 +233,7 @@ class HipMatcher:
             self.engine.upload(self._table.slice(idx[lo], idx[hi] + 1), first=idx[lo], capacity=self._table.n)
             lo = hi + 1
         self._dirty.clear()
+        self._reasons.clear()
 
     def _candidates(self, nl: Dict[str, object]) -> Optional[np.ndarray]:
         """Bitmask [chunks] (bit = node) of the attached nodes that are in `nl`; None when nl is everything."""
@@ -164,12 +252,17 @@ class HipMatcher:
         return self.FindNodes(nl, [top])[0]
 
     def ScheduleBatch(self, nl: Dict[str, object], tops: Sequence[object],
-                      pod_groups: Optional[Sequence[Sequence[str]]] = None, now: Optional[float] = None) -> List[Tuple]:
+                      pod_groups: Optional[Sequence[Sequence[str]]] = None, now: Optional[float] = None,
+                      apply: bool = False) -> List[Tuple]:
         """Mode B: the result list the scheduler loop would produce by calling FindNode and committing each
-        winner before the next pod (nhd/NHDScheduler.py:289-304, 425-437) - decided in one device pass.
-        The node objects are NOT modified; apply each placement with the node's own SetBusy /
-        SetPhysicalIdsFromMapping / ClaimPodNICResources, exactly as AttemptScheduling does."""
-        return self._run(nl, tops, pod_groups, now, sequential=True)
+        winner before the next pod (nhd/NHDScheduler.py:289-304, 425-437) - decided AND committed on the device in
+        one pass (nhdfit_schedule_batch).  `self.last_placements[i]` holds pod i's physical ids (the lists
+        SetPhysicalIdsFromMapping would write into its topology, pack.expand_placement) or None.
+        The node objects are NOT modified: apply each placement with the node's own SetBusy /
+        SetPhysicalIdsFromMapping / ClaimPodNICResources, exactly as AttemptScheduling does.  apply=True keeps the
+        commits in the device mirror (attached mode: the reference mutators that follow are then recognised as
+        already mirrored); apply=False restores it."""
+        return self._run(nl, tops, pod_groups, now, sequential=True, apply=apply)
 
     def FindNodes(self, nl: Dict[str, object], tops: Sequence[object],
                   pod_groups: Optional[Sequence[Sequence[str]]] = None, now: Optional[float] = None) -> List[Tuple]:
@@ -203,7 +296,7 @@ class HipMatcher:
         out = self._run(nl, None, pod_groups, now, sequential, reqs=reqs)
         return [(None,) if skip[i] else out[i] for i in range(len(cfg_texts))]
 
-    def _run(self, nl, tops, pod_groups, now, sequential, reqs=None):
+    def _run(self, nl, tops, pod_groups, now, sequential, reqs=None, apply=False):
         if reqs is None:
             if not tops:
                 return []
@@ -222,19 +315,30 @@ class HipMatcher:
             self._full_upload(nl)
         if reqs is None:
             reqs = self.packer.digest_many(tops, pod_groups)
+        places = None
         if sequential:
-            node, maps, status = self.engine.find_sequential(reqs, now, cand=cand)
-            if status.any():
-                self.logger.warning("mode B: the reference's commit step would have failed for pod %d", int(np.flatnonzero(status)[0]))
+            self.packer.close_signatures()                 # every NIC state a commit can produce has a signature
+            self.engine.set_dictionary(self.packer)
+            node, maps, places, status = self.engine.schedule_batch(reqs, now, self.packer, cand=cand, apply=apply)
+            if (status == pack.COMMIT_WOULD_RAISE).any():
+                self.logger.warning("mode B: the reference's commit step would have failed for pod %d",
+                                    int(np.flatnonzero(status == pack.COMMIT_WOULD_RAISE)[0]))
             index = node - self.engine.global_base
         else:
             score, _, maps = self.engine.find(reqs, now, cand=cand, want_bitmap=False, want_map=True)
             index = np.array([winner_index(int(s)) - self.engine.global_base if s else -1 for s in score], dtype=np.int64)
         out: List[Tuple] = []
+        self.last_placements = [None] * n_pods
         for p in range(n_pods):
             if index[p] < 0:
                 out.append((None,))
                 continue
+            if places is not None and self._attached is not None:
+                nd = self._attached.get(self._names[int(index[p])])
+                if nd is not None:
+                    Gp = int(reqs[p]["n_groups"])
+                    self.last_placements[p] = pack.expand_placement(places[p], Gp, int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets),
+                                                                    [int(reqs[p]["gpus"][g]) for g in range(Gp)])
             name = self._names[int(index[p])]
             G = int(reqs[p]["n_groups"])
             m = maps[p]

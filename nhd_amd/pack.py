@@ -50,9 +50,13 @@ REQ = np.dtype([("n_groups", "<u4"), ("map_type", "<u4"), ("hugepages_gb", "<i4"
                 ("misc_smt_enabled", "u1"), ("nic_use", "u1")])
 MAPPING = np.dtype([("gpu", "i1", (4,)), ("cpu", "i1", (5,)), ("nic_numa", "i1", (4,)), ("nic_idx", "i1", (4,)),
                     ("valid", "i1"), ("pad", "i1", (2,))])
+PLACEMENT = np.dtype([("proc_take", "<u8", (4,)), ("proc_pair", "<u8", (4,)), ("help_take", "<u8", (4,)), ("help_pair", "<u8", (4,)),
+                      ("misc_take", "<u8"), ("misc_pair", "<u8"), ("gpu", "u1", (4, 8)), ("numa", "i1", (5,)), ("status", "u1"),
+                      ("pad", "u1", (2,))])
+COMMIT_OK, COMMIT_WOULD_RAISE, COMMIT_NEW_SIG = 0, 1, 2
 CC = np.dtype([("cls", "u1"), ("cnt", "u1")])
 assert (P0.itemsize, P1.itemsize, P2.itemsize, P3.itemsize, P4.itemsize) == (16,) * 5
-assert DETAIL.itemsize == 128 and REQ.itemsize == 128 and MAPPING.itemsize == 20
+assert DETAIL.itemsize == 128 and REQ.itemsize == 128 and MAPPING.itemsize == 20 and PLACEMENT.itemsize == 184
 
 ALL_ONES = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -165,6 +169,69 @@ class Packer:
             ccarr[i] = (c, n)
         return (caps, np.asarray(sig_off, "<u4"), np.asarray(pool_off, "<u4"),
                 np.asarray(glimit if glimit else [0], "u1"), ccarr, len(self.caps), len(self.sigs), len(glimit), len(cc))
+
+    def sigs_from_detail(self, det) -> Tuple[List[int], List[int]]:
+        """(sig_numa[2], sig_pci[2]) of a node from its detail record alone (NIC classes / switches, free GPUs per
+        switch) - interning what is new.  Used after a device-side commit left a node in a NIC state the dictionary
+        did not hold yet (NHDFIT_COMMIT_NEW_SIG); same construction as pack_node_into."""
+        sig_numa, sig_pci = [0, 0], [0, 0]
+        for u in range(MAX_NUMA):
+            n = int(det["nic_cnt"][u])
+            numa_pool: Dict[int, int] = {}
+            pci_pool: Dict[int, Dict[int, int]] = {}
+            for k in range(n):
+                cls, sw = int(det["nic_cls"][u][k]), int(det["nic_sw"][u][k])
+                numa_pool[cls] = numa_pool.get(cls, 0) + 1
+                d = pci_pool.setdefault(sw, {})
+                d[cls] = d.get(cls, 0) + 1
+            pairs = lambda d: tuple(sorted((c, min(m, MAX_GROUPS)) for c, m in d.items()))   # noqa: E731
+            if numa_pool:
+                sig_numa[u] = self.sig_id([(GLIMIT_NONE, pairs(numa_pool))])
+            pools = []
+            for sw, d in pci_pool.items():
+                gl = min(int(det["sw_free"][sw]), MAX_GROUPS)
+                if gl > 0:
+                    pools.append((gl, pairs(d)))
+            sig_pci[u] = self.sig_id(pools)
+        return sig_numa, sig_pci
+
+    def close_signatures(self, max_new: int = 4096) -> int:
+        """Interns every NIC signature a commit can turn an interned one into: one NIC of a pool claimed (its capacity
+        class becomes 0, nhd/Node.py:644-646) or one GPU behind a PCI-mode pool taken (nhd/Node.py:648-655).  Counts are
+        capped at MAX_GROUPS in a signature, so a capped count yields both "still capped" and "one less".  With the
+        closure interned up front, device-side commits (nhdfit_schedule_batch / nhdfit_commit) never meet a NIC state
+        without a signature.  Returns the number of signatures added."""
+        added = 0
+        todo = list(self.sigs)
+        seen = set(self.sigs)
+        while todo and added < max_new:
+            sig = todo.pop()
+            for pi, (gl, pairs) in enumerate(sig):
+                succ_pools = []
+                counts = dict(pairs)
+                for cls, cnt in pairs:                                  # claim one NIC of class cls
+                    if cls == 0 or cnt == 0:
+                        continue
+                    for new_cnt in ({cnt - 1, cnt} if cnt >= MAX_GROUPS else {cnt - 1}):
+                        c2 = dict(counts)
+                        if new_cnt:
+                            c2[cls] = new_cnt
+                        else:
+                            c2.pop(cls)
+                        c2[0] = min(c2.get(0, 0) + 1, MAX_GROUPS)
+                        succ_pools.append((gl, tuple(sorted(c2.items()))))
+                if gl != GLIMIT_NONE:                                   # one GPU behind this switch taken
+                    for new_gl in ({gl - 1, gl} if gl >= MAX_GROUPS else {gl - 1}):
+                        succ_pools.append((new_gl, pairs) if new_gl > 0 else None)
+                for sp in succ_pools:
+                    pools = [p for k, p in enumerate(sig) if k != pi] + ([sp] if sp is not None else [])
+                    key = tuple(sorted(pools))
+                    if key not in seen:
+                        seen.add(key)
+                        self.sig_id(pools)
+                        todo.append(key)
+                        added += 1
+        return added
 
     # ---- node side ------------------------------------------------------------------------
     def pack_node_into(self, node, t: NodeTable, i: int) -> None:
@@ -470,6 +537,38 @@ class Packer:
             t.p3["sig_pci"][:, numa] = sig_pci
         t.names = []
         return t
+
+
+def expand_batch(take: int, pair: int, numa: int, cores_per_proc: int, num_cores: int) -> List[int]:
+    """The list one GetFreeCpuBatch call returns (nhd/Node.py:502-519) from the two masks of a placement record:
+    ascending physical core b of socket `numa` -> logical id numa * cores_per_proc + b, followed by its SMT
+    sibling (id + num_cores, nhd/Node.py:343-350) when the pair bit is set."""
+    out: List[int] = []
+    take, pair = int(take), int(pair)
+    b = 0
+    while take >> b:
+        if take >> b & 1:
+            core = numa * cores_per_proc + b
+            out.append(core)
+            if pair >> b & 1:
+                out.append(core + num_cores)
+        b += 1
+    return out
+
+
+def expand_placement(place, n_groups: int, cores_per_proc: int, num_cores: int, gpus_per_group: Sequence[int]) -> dict:
+    """nhdfit_placement -> the physical ids Node.SetPhysicalIdsFromMapping hands out, in its order:
+    {'groups': [{'cores': [...], 'helpers': [...], 'gpus': [positions in Node.gpus]}], 'misc': [...]}.
+    `cores` is the group's whole batch: the reference gives its first entries to the GPUs' cpu_cores (in GPU order),
+    the rest to proc_cores (nhd/Node.py:729-742)."""
+    groups = []
+    for g in range(n_groups):
+        u = int(place["numa"][g])
+        groups.append({"cores": expand_batch(place["proc_take"][g], place["proc_pair"][g], u, cores_per_proc, num_cores),
+                       "helpers": expand_batch(place["help_take"][g], place["help_pair"][g], u, cores_per_proc, num_cores),
+                       "gpus": [int(x) for x in place["gpu"][g][:gpus_per_group[g]]]})
+    misc = expand_batch(place["misc_take"], place["misc_pair"], int(place["numa"][MAX_GROUPS]), cores_per_proc, num_cores)
+    return {"groups": groups, "misc": misc}
 
 
 def _synth_group_names():

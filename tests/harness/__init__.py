@@ -17,7 +17,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    deps = [SRC] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "winner_map.h", "seq_core.h", "set_states.h")] + \
+    deps = [SRC] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "winner_map.h", "seq_core.h", "set_states.h", "commit_core.h")] + \
            [os.path.join(HERE, "..", "..", "include", "nhdfit.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", SRC, "-o", SO])
@@ -53,20 +53,59 @@ def find(packer: pack.Packer, table: pack.NodeTable, reqs: np.ndarray, now: floa
     return score, bitmap, maps
 
 
-def resolve(packer, table, reqs, now, global_base=0, cand=None):
-    """Mode B on the host build: snapshot pass + sequential resolver.  Returns (node index or -1, maps, status)."""
+def _dict_args(packer):
+    caps, sig_off, pool_off, glimit, cc, ncls, nsig, npools, ncc = packer.dictionary_arrays()
+    return caps, sig_off, pool_off, glimit, cc, ncls, nsig
+
+
+def schedule(packer, table, reqs, now, global_base=0, cand=None, apply=False, close=False):
+    """Mode B on the host build: snapshot pass + sequential commit on host copies of the planes.
+    Returns (node index or -1, maps, placements, status, n_done); apply=True writes the committed state into `table`."""
     L = lib()
-    score, bitmap, maps = find(packer, table, reqs, now, global_base=global_base, cand=cand)
-    caps = np.asarray(packer.caps, dtype="<f8")
+    if close:
+        packer.close_signatures()
+    score, bitmap, _ = find(packer, table, reqs, now, global_base=global_base, cand=cand, want_map=False)
+    caps, sig_off, pool_off, glimit, cc, ncls, nsig = _dict_args(packer)
+    gs = packer.group_set_array()
     P = len(reqs)
     node = np.zeros(P, np.int64)
-    out_maps = np.zeros(P, pack.MAPPING)
+    maps = np.zeros(P, pack.MAPPING)
+    places = np.zeros(P, pack.PLACEMENT)
     status = np.zeros(P, np.int32)
     reqs = np.ascontiguousarray(reqs)
-    L.hh_resolve(_p(table.p0), _p(table.p1), _p(table.p2), _p(table.p3), _p(table.p4), _p(table.detail),
-                 ctypes.c_uint32(table.n), ctypes.c_uint64(global_base), _p(reqs), ctypes.c_uint32(P), ctypes.c_double(now),
-                 _p(caps), _p(score), _p(bitmap), _p(maps), _p(node), _p(out_maps), _p(status))
-    return node, out_maps, status
+    planes = [np.array(getattr(table, f)) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
+    L.hh_schedule.restype = ctypes.c_uint32
+    done = L.hh_schedule(*[_p(x) for x in planes], ctypes.c_uint32(table.n), ctypes.c_uint64(global_base), _p(reqs), ctypes.c_uint32(P),
+                         ctypes.c_double(now), ctypes.c_uint32(packer.max_cores_per_numa), ctypes.c_uint32(packer.max_gpus_per_numa),
+                         _p(gs), ctypes.c_uint32(len(packer.group_sets)), _p(caps), ctypes.c_uint32(ncls), _p(sig_off), ctypes.c_uint32(nsig),
+                         _p(pool_off), _p(glimit), _p(cc), _p(score), _p(bitmap), _p(node), _p(maps), _p(places), _p(status))
+    if apply:
+        for f, arr in zip(("p0", "p1", "p2", "p3", "p4", "detail"), planes):
+            getattr(table, f)[...] = arr
+    return node, maps, places, status, int(done)
+
+
+def resolve(packer, table, reqs, now, global_base=0, cand=None):
+    """Mode B, mirror untouched: (node index or -1, maps, status) - the nhdfit_find_sequential contract."""
+    node, maps, _, status, done = schedule(packer, table, reqs, now, global_base=global_base, cand=cand, close=True)
+    assert done == len(reqs), "a commit left a node in a NIC state the dictionary has no signature for"
+    return node, maps, status
+
+
+def commit(packer, table, i, req, mapping, busy_time):
+    """The commit step alone on node i of `table` (modified in place).  Returns (status, placement)."""
+    L = lib()
+    _, sig_off, pool_off, glimit, cc, _, nsig = _dict_args(packer)
+    out = np.zeros((), pack.PLACEMENT)
+    req = np.ascontiguousarray(req)
+    mapping = np.ascontiguousarray(mapping)
+    rows = [np.ascontiguousarray(getattr(table, f)[i:i + 1]) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
+    L.hh_commit.restype = ctypes.c_int
+    rc = L.hh_commit(*[_p(x) for x in rows], _p(req), _p(mapping), ctypes.c_double(busy_time), _p(sig_off), ctypes.c_uint32(nsig),
+                     _p(pool_off), _p(glimit), _p(cc), _p(out))
+    for f, r in zip(("p0", "p1", "p2", "p3", "p4", "detail"), rows):
+        getattr(table, f)[i] = r[0]
+    return int(rc), out
 
 
 class HarnessEngine:
@@ -106,3 +145,16 @@ class HarnessEngine:
 
     def find_sequential(self, reqs, now, cand=None):
         return resolve(self.packer, self.table, reqs, now, global_base=self.global_base, cand=cand)
+
+    def schedule_batch(self, reqs, now, packer, cand=None, apply=True):
+        node, maps, places, status, done = schedule(packer, self.table, reqs, now, global_base=self.global_base, cand=cand, apply=apply)
+        assert done == len(reqs)
+        self.n_done = done
+        return node, maps, places, status
+
+    def commit(self, node, req, mapping, busy_time):
+        return commit(self.packer, self.table, node, req, mapping, busy_time)[1]
+
+    def download(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        return self.table.slice(first, first + count)

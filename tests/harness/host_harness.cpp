@@ -173,41 +173,129 @@ int hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane
     return mismatches;
 }
 
-// CPU twin of the sequential (mode B) resolver: inputs are the snapshot outputs of hh_find.
-void hh_resolve(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
-                const nhdfit_plane4* p4, const nhdfit_detail* det, uint32_t n, uint64_t global_base,
-                const nhdfit_req* reqs, uint32_t P, double now, const double* caps,
-                const uint64_t* score_a, const uint64_t* bitmap_a, const nhdfit_mapping* maps_a,
-                int64_t* node_out, nhdfit_mapping* map_out, int32_t* status_out) {
-    const uint32_t chunks = (n + 63) / 64;
-    const SeqStatic s{p0, p1, p2, p3, p4, det, caps, n, global_base, now};
-    std::vector<int32_t> slot_of(n, -1);
-    std::vector<OverlayNode> overlay(P);
-    uint32_t n_overlay = 0;
-    struct HostScan {
-        const uint64_t* bm; const nhdfit_plane2* p2; uint32_t chunks, P, pod, n;
-        int64_t find_first(bool pref, int64_t from, const StillFeasible& ok) {
-            for (uint32_t c = (uint32_t)(from / 64); c < chunks; ++c) {
-                uint64_t w = bm[(size_t)c * P + pod];
-                if (c == (uint32_t)(from / 64)) w &= ~0ull << (from % 64);
-                while (w) {
-                    const int b = __builtin_ctzll(w);
-                    const uint32_t nd = c * 64 + b;
-                    if ((!pref || !(p2[nd].flags & NHDFIT_NF_HAS_GPU)) && ok(nd)) return nd;
+// CPU twin of nhdfit_schedule_batch (mode B with the commit step on the packed state): the algorithm of seq_core.h /
+// k_seq, pod by pod, on host copies of the planes (modified in place = apply).  Inputs as hh_find plus the snapshot
+// rows / scores hh_find produced.  Returns the number of pods decided (< P: a commit produced an unknown NIC state).
+uint32_t hh_schedule(nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plane2* p2, nhdfit_plane3* p3, nhdfit_plane4* p4, nhdfit_detail* det,
+                     uint32_t n, uint64_t global_base, const nhdfit_req* reqs, uint32_t P, double now, uint32_t fcmax, uint32_t fgmax,
+                     const uint64_t* gs, uint32_t ngs, const double* caps, uint32_t ncls,
+                     const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit, const nhdfit_cc* cc,
+                     const uint64_t* score_a, uint64_t* rows, int64_t* node_out, nhdfit_mapping* map_out, nhdfit_placement* place_out,
+                     int32_t* status_out) {
+    const uint32_t chunks = (n + 63) / 64, tiles = (P + kTile - 1) / kTile;
+    int32_t hpmax = 0;
+    for (uint32_t p = 0; p < P; ++p) hpmax = reqs[p].hugepages_gb > hpmax ? reqs[p].hugepages_gb : hpmax;
+    const Dict d{fcmax, fgmax, gs, ngs, caps, ncls, SigDict{sig_off, pool_off, pool_glimit, cc, nsig}};
+    // signature key table, as nhdfit_set_dictionary builds it
+    uint32_t slots = 64;
+    while (slots < 4 * nsig) slots <<= 1;
+    std::vector<uint64_t> skeys(slots, 0);
+    std::vector<uint32_t> sids(slots, 0);
+    for (uint32_t sg = 1; sg < nsig; ++sg) {
+        uint64_t key = 0;
+        for (uint32_t pl = sig_off[sg]; pl < sig_off[sg + 1]; ++pl) {
+            uint8_t cnt[NHDFIT_MAX_CLASSES] = {0};
+            for (uint32_t k = pool_off[pl]; k < pool_off[pl + 1]; ++k) cnt[cc[k].cls & 15u] = cc[k].cnt;
+            key = sig_key_add(key, pool_key(pool_glimit[pl], cnt));
+        }
+        if (!key) continue;
+        uint32_t sl = (uint32_t)mix64(key) & (slots - 1);
+        while (skeys[sl] != 0 && skeys[sl] != key) sl = (sl + 1) & (slots - 1);
+        skeys[sl] = key; sids[sl] = sg;
+    }
+    const SigTable sigs{skeys.data(), sids.data(), slots - 1};
+    // tile images (cold rows are all the column refresh needs; X rows are left empty)
+    std::vector<uint8_t> tile_wcls(tiles, 0);
+    for (uint32_t p = 0; p < P; ++p)
+        if (req_valid(reqs[p])) tile_wcls[p / kTile] = std::max<uint8_t>(tile_wcls[p / kTile], (uint8_t)wclass_of(reqs[p].n_groups));
+    std::vector<Layout> L(tiles);
+    std::vector<std::vector<uint8_t>> img(tiles);
+    std::vector<uint64_t> m_need(tiles, 0), m_pci(tiles, 0);
+    std::vector<PodHeader> hdr(kTile);
+    const std::vector<uint64_t> no_classes;
+    for (uint32_t t = 0; t < tiles; ++t) {
+        const uint32_t np = P - t * kTile < (uint32_t)kTile ? P - t * kTile : kTile;
+        L[t] = make_layout(2u << tile_wcls[t], fcmax, fgmax, nsig, ngs, (uint32_t)hpmax + 2, kMinXCap);
+        img[t].assign(L[t].bytes, 0);
+        build_tile(reqs + t * kTile, np, d, L[t], no_classes, img[t].data(), hdr.data());
+        for (uint32_t j = 0; j < np; ++j) {
+            if (hdr[j].flags & kPodNeedGpu) m_need[t] |= 1ull << j;
+            if (hdr[j].flags & kPodPci) m_pci[t] |= 1ull << j;
+        }
+    }
+    const MapTables mt{nullptr, nullptr, SetStates{nullptr, nullptr, nullptr, 0}};
+    uint32_t i = 0;
+    for (; i < P; ++i) {
+        node_out[i] = -1;
+        std::memset(&map_out[i], 0, sizeof(nhdfit_mapping));
+        if (place_out) std::memset(&place_out[i], 0, sizeof(nhdfit_placement));
+        status_out[i] = 0;
+        const uint64_t sa = score_a[i];
+        if (!sa) continue;
+        const int64_t winner_a = (int64_t)(NHDFIT_SCORE_INDEX(sa) - global_base);
+        int64_t nd = -1;
+        for (int pass = (sa >> 63) ? 0 : 1; pass < 2 && nd < 0; ++pass) {
+            const bool pref = pass == 0;
+            const int64_t from = pref ? winner_a : ((sa >> 63) ? 0 : winner_a);
+            for (uint32_t c = (uint32_t)(from >> 6); c < chunks && nd < 0; ++c) {
+                uint64_t w = rows[(size_t)c * P + i];
+                if (c == (uint32_t)(from >> 6)) w &= ~0ull << (from & 63);
+                while (w && nd < 0) {
+                    const uint32_t v = c * 64 + (uint32_t)__builtin_ctzll(w);
+                    if (!pref || !(p2[v].flags & NHDFIT_NF_HAS_GPU)) nd = v;
                     w &= w - 1;
                 }
             }
-            return -1;
         }
-    };
-    for (uint32_t p = 0; p < P; ++p) {
-        HostScan scan{bitmap_a, p2, chunks, P, p, n};
-        SeqResult res;
-        resolve_pod(s, reqs[p], pod_header(reqs[p]), score_a[p], maps_a[p], scan, slot_of.data(), overlay.data(), &n_overlay, res);
-        node_out[p] = res.node;
-        map_out[p] = res.map;
-        status_out[p] = res.status;
+        if (nd < 0) continue;
+        const uint32_t v = (uint32_t)nd, t = i / kTile;
+        NodeState st{p0[v], p1[v], p2[v], p3[v], p4[v]};
+        nhdfit_detail dd = det[v];
+        const uint32_t bits = nic_assignment_bits(img[t].data(), L[t], i % kTile, reqs[i].map_type == NHDFIT_MAP_PCI, st.p3);
+        nhdfit_placement pl;
+        std::memset(&pl, 0, sizeof pl);
+        node_out[i] = (int64_t)global_base + nd;
+        if (map_on_state(reqs[i], st, dd, caps, bits, mt, map_out[i])) status_out[i] = commit_node(st, dd, reqs[i], map_out[i], now, sigs, pl);
+        else { status_out[i] = kCommitWouldRaise; pl.status = kCommitWouldRaise; }
+        if (place_out) place_out[i] = pl;
+        p0[v] = st.p0; p1[v] = st.p1; p2[v] = st.p2; p3[v] = st.p3; p4[v] = st.p4; det[v] = dd;
+        if (status_out[i] == kCommitNewSig) { ++i; break; }
+        const NodeIdx ni = node_index(st.p0, st.p1, st.p2, st.p4, fcmax + 1, fgmax + 1, ngs);
+        const bool busy = (now - st.p4.busy_time) < kMinBusySecs;
+        for (uint32_t tt = 0; tt < tiles; ++tt) {
+            const uint64_t word = node_word_cold(img[tt].data(), L[tt], ni, st.p3, busy, m_need[tt], m_pci[tt]);
+            for (uint32_t j = 0; j < (uint32_t)kTile && tt * kTile + j < P; ++j)
+                if (!(word >> j & 1)) rows[(size_t)(v >> 6) * P + tt * kTile + j] &= ~(1ull << (v & 63));
+        }
     }
+    return i;
+}
+
+// the commit step alone (nhdfit_commit) on one node record
+int hh_commit(nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plane2* p2, nhdfit_plane3* p3, nhdfit_plane4* p4, nhdfit_detail* det,
+              const nhdfit_req* req, const nhdfit_mapping* map, double busy_time,
+              const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit, const nhdfit_cc* cc,
+              nhdfit_placement* out) {
+    uint32_t slots = 64;
+    while (slots < 4 * nsig) slots <<= 1;
+    std::vector<uint64_t> skeys(slots, 0);
+    std::vector<uint32_t> sids(slots, 0);
+    for (uint32_t sg = 1; sg < nsig; ++sg) {
+        uint64_t key = 0;
+        for (uint32_t pl = sig_off[sg]; pl < sig_off[sg + 1]; ++pl) {
+            uint8_t cnt[NHDFIT_MAX_CLASSES] = {0};
+            for (uint32_t k = pool_off[pl]; k < pool_off[pl + 1]; ++k) cnt[cc[k].cls & 15u] = cc[k].cnt;
+            key = sig_key_add(key, pool_key(pool_glimit[pl], cnt));
+        }
+        if (!key) continue;
+        uint32_t sl = (uint32_t)mix64(key) & (slots - 1);
+        while (skeys[sl] != 0 && skeys[sl] != key) sl = (sl + 1) & (slots - 1);
+        skeys[sl] = key; sids[sl] = sg;
+    }
+    NodeState st{*p0, *p1, *p2, *p3, *p4};
+    const int rc = commit_node(st, *det, *req, *map, busy_time, SigTable{skeys.data(), sids.data(), slots - 1}, *out);
+    *p0 = st.p0; *p1 = st.p1; *p2 = st.p2; *p3 = st.p3; *p4 = st.p4;
+    return rc;
 }
 
 // list(set(codes inserted in order)) under the CPython model; tuples of length `len`, digits base `base`.

@@ -15,12 +15,12 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_lib._SIGS)
-    assert lib.nhdfit_abi_version() == 2
+    assert lib.nhdfit_abi_version() == 3
 
 
 def test_struct_sizes_match_header():
     # sizes asserted on the C side by the struct comments; here: numpy mirrors
-    assert pack.REQ.itemsize == 128 and pack.DETAIL.itemsize == 128 and pack.MAPPING.itemsize == 20
+    assert pack.REQ.itemsize == 128 and pack.DETAIL.itemsize == 128 and pack.MAPPING.itemsize == 20 and pack.PLACEMENT.itemsize == 184
     assert ctypes.sizeof(_lib.Stats) == 72
 
 

@@ -1,0 +1,126 @@
+"""Row f1 (commit step on packed state, nhd_amd/csrc/commit_core.h + seq_core.h), host build: against the fixtures the
+unmodified reference produced (tests/golden/commit) and against the oracle's sequential batch.  CPU only."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from nhd_amd import pack, refmodel, synth
+from oracle import nhd_oracle as O
+from tests import commit_check, harness
+
+
+@pytest.mark.parametrize("path", commit_check.FIXTURES, ids=[os.path.basename(p)[:-5] for p in commit_check.FIXTURES])
+def test_host_twin_reproduces_reference_commits(path):
+    case = commit_check.load(path)
+    spec, nodes, tops, pk, table, reqs = commit_check.build(case)
+    dict_before = pk.dict_version
+    node, maps, places, status, done = harness.schedule(pk, table, reqs, case["clock"], apply=True)
+    assert done == len(reqs)
+    commit_check.check(case, nodes, tops, table, reqs, node, maps, places, status, table)
+    commit_check.check_signatures(pk, table)
+    assert pk.dict_version == dict_before        # the closure held every NIC state the commits produced
+
+
+@pytest.mark.parametrize("cfg,n,P", [(3, 40, 120), (4, 16, 150), (5, 120, 300), (2, 20, 80)])
+def test_placements_match_oracle_ids(cfg, n, P):
+    """Physical ids and decisions of the host twin against the oracle's sequential batch (pinned to the reference in
+    tests/test_mode_b_oracle.py) on more shapes than the committed fixtures cover."""
+    spec = synth.make_cluster(cfg, n_nodes=n)
+    pods, groups = synth.make_pods(cfg, n_pods=P)
+    for p in pods:
+        p["misc_smt"] = True
+    nodes = spec.build_nodes()
+    tops = [refmodel.make_topology(s) for s in pods]
+    pk = pack.Packer()
+    table = pk.pack_nodes(nodes)
+    reqs = pk.digest_many(tops, groups)
+    pk.close_signatures()
+    node, maps, places, status, done = harness.schedule(pk, table, reqs, spec.clock_now, apply=True)
+    assert done == P
+    ids = []
+    want = O.schedule_sequence(nodes, tops, groups, spec.clock_now, ids_out=ids)       # mutates `nodes`
+    for i, (w, wid) in enumerate(zip(want, ids)):
+        if w[0] is None:
+            assert node[i] < 0
+            continue
+        assert table.names[int(node[i])] == w[0]
+        nd = nodes[w[0]]
+        G = int(reqs[i]["n_groups"])
+        got = pack.expand_placement(places[i], G, int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets),
+                                    [int(reqs[i]["gpus"][g]) for g in range(G)])
+        assert got == wid, (i, got, wid)
+    # the packed state after the batch == the packed form of the oracle's mutated nodes
+    after = pack.Packer()
+    t2 = after.pack_nodes(nodes)
+    for f in ("p0", "p1"):
+        assert np.array_equal(getattr(table, f), getattr(t2, f)), f
+    for f in ("gpu_free", "hp_free"):
+        assert np.array_equal(table.p2[f], t2.p2[f]), f
+    assert np.array_equal(table.p4["busy_time"], t2.p4["busy_time"])
+    assert pack.resolve_signatures(pk, table) == pack.resolve_signatures(after, t2)
+
+
+def test_unknown_nic_state_is_reported_not_guessed():
+    """Without the signature closure a commit can leave a node in a NIC state the dictionary has no id for: the batch
+    stops right after that pod (n_done), the node's record says so, and interning + patching lets it continue."""
+    spec = synth.make_cluster(3, n_nodes=6)
+    pods, groups = synth.make_pods(3, n_pods=60)
+    for p in pods:
+        p["misc_smt"] = True
+    nodes = spec.build_nodes()
+    pk = pack.Packer()
+    table = pk.pack_nodes(nodes)
+    reqs = pk.digest_many([refmodel.make_topology(s) for s in pods], groups)
+    node, maps, places, status, done = harness.schedule(pk, table, reqs, spec.clock_now, apply=True)
+    if done < len(reqs):
+        assert status[done - 1] == pack.COMMIT_NEW_SIG
+        v = int(node[done - 1])
+        before = pk.dict_version
+        pk.sigs_from_detail(table.detail[v])
+        assert pk.dict_version > before                      # it really was a new signature
+    else:
+        assert not (status == pack.COMMIT_NEW_SIG).any()
+
+
+def test_single_commit_matches_oracle():
+    """nhdfit_commit's arithmetic (one placement) on heterogeneous random nodes."""
+    from tests import util
+    nl = util.random_cluster(4242, 60)
+    rng = np.random.default_rng(11)
+    pk = pack.Packer()
+    table = pk.pack_nodes(nl)
+    pk.close_signatures()
+    placed = 0
+    for k in range(120):
+        spec = util.random_pod_spec(rng, max_groups=3)
+        spec["misc_smt"] = True
+        top = refmodel.make_topology(spec)
+        res = O.find_node(nl, top, util.CLOCK)
+        if res[0] is None:
+            continue
+        i = table.names.index(res[0])
+        req = pk.digest(top)
+        m = np.zeros((), pack.MAPPING)
+        G = len(res[1]["gpu"])
+        m["gpu"][:G] = res[1]["gpu"]; m["cpu"][:G + 1] = res[1]["cpu"]
+        m["nic_numa"][:G] = [x[0] for x in res[1]["nic"]]; m["nic_idx"][:G] = [x[1] for x in res[1]["nic"]]
+        m["valid"] = 1
+        ids = {}
+        try:
+            O.commit(nl[res[0]], top, res[1], util.CLOCK + k, ids)
+        except O.CommitFailure:
+            break                                            # parity undefined from here on (the reference unwinds, badly)
+        rc, place = harness.commit(pk, table, i, req, m, util.CLOCK + k)
+        assert rc in (pack.COMMIT_OK, pack.COMMIT_NEW_SIG)
+        nd = nl[res[0]]
+        got = pack.expand_placement(place, G, int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets),
+                                    [int(req["gpus"][g]) for g in range(G)])
+        assert got == ids, (k, got, ids)
+        one = pack.empty_table(1)
+        pack.Packer().pack_node_into(nd, one, 0)
+        assert np.array_equal(one.p0[0], table.p0[i]) and np.array_equal(one.p1[0], table.p1[i])
+        assert one.p2[0]["gpu_free"] == table.p2[i]["gpu_free"] and one.p2[0]["hp_free"] == table.p2[i]["hp_free"]
+        placed += 1
+    assert placed >= 20
