@@ -15,11 +15,20 @@ Workload (config.workload): BASELINE.json's 64k-node case - config 4's cluster (
 locality for half the pods) with 65 536 nodes PER GPU and 4 096 pending pods; with N GPUs the node axis
 is sharded (weak scaling: N x 65 536 nodes in total), pods are replicated, one all-reduce picks the winners.
 value = pod x node evaluations per second over the whole job.
+
+BASELINE.json's own multi-GPU shapes (strong scaling: the cluster is fixed, the shards shrink):
+    ... bench.py --gpus 4 --config 4 --total-nodes 65536   --pods 4096      (config 4: 16 384 nodes per GPU)
+    ... bench.py --gpus 8 --config 5 --total-nodes 262144  --pods 16384     (config 5: 32 768 nodes per GPU)
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -29,6 +38,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X spec (guides/MI355X_MICROARCH.md, "Chip-level parameters"); ~6300 achievable
+VALU_NS_PER_WAVE_INST = 1.2  # measured full-rate wave64 VALU issue per SIMD (tools/valu_calib.hip, profiles/r02/valu_calib.jsonl)
+SIMDS = 1024
 
 
 def main():
@@ -38,9 +49,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=4, help="BASELINE config whose cluster/pod mix is generated")
     ap.add_argument("--nodes-per-gpu", type=int, default=65536)
+    ap.add_argument("--total-nodes", type=int, default=0, help="strong scaling: fixed cluster size, shards of total/N nodes")
     ap.add_argument("--pods", type=int, default=4096)
     ap.add_argument("--cpu-sample-pods", type=int, default=1024, help="pods timed on the CPU port (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (HBM traffic of the step kernel)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the mode-B and end-to-end legs after the timed region")
     args = ap.parse_args()
 
     # stdout carries exactly one line: the result.  Native libraries are chatty on it (gloo's "[Gloo] Rank 0 is
@@ -57,6 +71,9 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    strong = args.total_nodes > 0
+    if strong:
+        args.nodes_per_gpu = (args.total_nodes + world - 1) // world
 
     dist = None
     if world > 1:
@@ -64,11 +81,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
-    from nhd_amd import pack, refmodel, synth
+    from nhd_amd import pack
     from nhd_amd.engine import Engine, winner_index
+    from workload import refmodel, synth
 
-    n_total = args.nodes_per_gpu * world
-    lo, hi = rank * args.nodes_per_gpu, (rank + 1) * args.nodes_per_gpu
+    n_total = args.total_nodes if strong else args.nodes_per_gpu * world
+    lo, hi = rank * args.nodes_per_gpu, min(n_total, (rank + 1) * args.nodes_per_gpu)
     spec_all = synth.make_cluster(args.config, n_nodes=n_total)
     spec = spec_all.shard(lo, hi)
     pods, pod_groups = synth.make_pods(args.config, n_pods=args.pods)
@@ -77,11 +95,11 @@ def main():
     pk = pack.Packer()
     table = pk.planes_from_spec(spec)
     reqs = pk.digest_many(tops, pod_groups)
+    pk.close_signatures()
     eng = Engine(local_rank)
     eng.set_dictionary(pk)
     eng.upload(table, global_base=lo)
     if world > 1:
-        import torch
         uid = [eng.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         eng.comm_init(world, rank, uid[0])
@@ -116,22 +134,35 @@ def main():
     ms_per_step = dt * 1e3 / args.steps
     fit_ms = st.fit_ms_total / max(1, st.launches)
     achieved = st.bytes_last / (fit_ms * 1e-3) / 1e9 if fit_ms > 0 else 0.0
+    inner = bool(os.environ.get("NHD_BENCH_INNER"))
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            tj = json.load(f)
-        w = tj["workload"]
-        if (w["config"], w["nodes_per_gpu"], w["pods"]) == (args.config, args.nodes_per_gpu, args.pods):
-            traffic = tj["hbm_bytes_per_launch"]      # PMC pass of the same command, committed under profiles/
+    # HBM traffic of the step kernel from hardware counters: short rocprofv3 passes of this very script (FETCH_SIZE,
+    # WRITE_SIZE, SQ_INSTS_VALU; one counter set per pass, never combined with tracing), rank 0 at N = 1.  Falls back
+    # to the committed profile of the same workload, and says which of the two it is.
+    counters = None
+    if rank == 0 and world == 1 and not args.no_pmc and not inner:
+        counters = measure_counters(args)
+    traffic, traffic_source = None, None
+    if counters and counters.get("hbm_bytes_per_launch"):
+        traffic = counters["hbm_bytes_per_launch"]
+        traffic_source = "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this script (2 x FETCH_SIZE + WRITE_SIZE, mean over the k_step launches)"
+    else:
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+            with open(tpath) as f:
+                tj = json.load(f)
+            w = tj["workload"]
+            if (w["config"], w["nodes_per_gpu"], w["pods"]) == (args.config, args.nodes_per_gpu, args.pods):
+                traffic = tj["hbm_bytes_per_launch"]
+                traffic_source = "from " + os.path.relpath(tpath, ROOT) + " (committed profile of the same command, not this run)"
+                break
+    valu = counters.get("valu_insts_per_launch") if counters else None
 
     out = {
-        "metric": "pod-placement filter-and-score throughput (pod x node fit-and-score evaluations/s; decisions/s in decisions_per_s)",
+        "metric": "pod-placement filter-and-score throughput (pod x node fit-and-score evaluations/s; placement decisions/s under commit semantics in mode_b)",
         "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u64 bitmaps + int32 table look-ups (f64 NIC arithmetic in the request digest)", "data": "synthetic",
-        "decisions_per_s": args.pods * args.steps / dt,
+        "snapshot_decisions_per_s": args.pods * args.steps / dt,
         "placed_pods": int(np.count_nonzero(score)),
         "config": {"workload": f"BASELINE config {args.config} cluster: {args.nodes_per_gpu} nodes/GPU x {args.pods} pods, "
                                f"CPU+GPU+NIC predicate, PCI locality for ~half the pods, node axis sharded over {world} GPU(s)",
@@ -139,18 +170,28 @@ def main():
                    "parallelism": f"node-shard x{world}, RCCL all-reduce(max) of {args.pods} u64 scores" if world > 1 else "single GPU",
                    "nic_signatures": st.nsig, "lds_bytes_per_block": st.lds_bytes},
         "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": int(st.bytes_last), "kernel_ms": fit_ms,
-                     "digest_kernel_ms": st.digest_ms_last, "device_step_ms": st.step_ms_last,
-                     "note": "achieved = algorithmic bytes of the fit role / mean HIP-event duration of the whole fused step "
-                             "kernel (fit role + next step's digest + earlier steps' mapping roles in the same launch, "
-                             "sampled every 8th step on the launch stream); traffic = HBM bytes/launch from rocprofv3 PMC "
-                             "(2*FETCH_SIZE + WRITE_SIZE): the node planes and table images are served from L2 / Infinity "
-                             "Cache, the kernel is VALU-issue bound (DESIGN.md section 4)"},
+                     "bytes_formula": "SURVEY.md 8(d): ceil(P/64) * N * 24 (16-byte node record + 8-byte busy time per node and tile) "
+                                      "+ P * 128 (requests) + P * N / 8 (verdict matrix) + 8 * P (scores)",
+                     "hbm_counter": None if not traffic or fit_ms <= 0 else {
+                         "achieved": traffic / (fit_ms * 1e-3) / 1e9, "frac": traffic / (fit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "bytes the counters saw per launch / the same kernel time: what HBM really moved"},
+                     "issue": None if not valu or fit_ms <= 0 else {
+                         "valu_wave_insts_per_launch": valu,
+                         "valu_issue_frac": valu * VALU_NS_PER_WAVE_INST * 1e-9 / SIMDS / (fit_ms * 1e-3),
+                         "note": "wave64 VALU instructions x 1.2 ns (measured full-rate issue per SIMD, profiles/r02/valu_calib.jsonl) / 1024 SIMDs / kernel time"},
+                     "limited_by": "latency of dependent L2 / LDS round trips inside short roles; neither HBM, VALU issue nor LDS bandwidth is "
+                                   "saturated (DESIGN.md section 4).  `achieved` counts algorithmic bytes: the node records are re-read per pod "
+                                   "tile out of L2 / Infinity Cache, only the verdict matrix and the first touch of the tables reach HBM",
+                     "digest_kernel_ms": st.digest_ms_last, "device_step_ms": st.step_ms_last},
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(spec, tops, pod_groups, args.cpu_sample_pods, score, lo, winner_index)
+    if rank == 0 and world == 1 and not args.no_extras and not inner:
+        out["end_to_end"] = end_to_end(eng, reqs, now, args.pods, n_total)
+        out["mode_b"] = mode_b(eng, pk, reqs, now, args.pods)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not inner:
+        out["cpu_baseline"] = cpu_baseline(spec, tops, pod_groups, args.cpu_sample_pods, score, lo, winner_index, args)
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
@@ -160,9 +201,77 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(spec, tops, pod_groups, sample, gpu_score, base, winner_index):
+def end_to_end(eng, reqs, now, P, n_total):
+    """The whole call as a scheduler makes it: host request records in, winners + mappings out (nhdfit_find: host sort
+    into tiles, H2D of the requests, digest / fit / mapping launches, D2H) - host buffers on both sides, so PCIe and the
+    launch latencies are inside.  Never the headline `value`."""
+    eng.find(reqs, now, want_bitmap=False, want_map=True)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        eng.find(reqs, now, want_bitmap=False, want_map=True)
+        ts.append(time.perf_counter() - t0)
+    t = min(ts)
+    return {"call": "nhdfit_find (stage + H2D + 5 launches + D2H of scores and mappings)", "ms_per_call": t * 1e3,
+            "evals_per_s": P * n_total / t, "decisions_per_s": P / t}
+
+
+def mode_b(eng, pk, reqs, now, P):
+    """Placement decisions under the scheduler's commit semantics (nhdfit_schedule_batch): every winner is committed to
+    the packed node state on the device (physical core / GPU ids out) before the next pod is matched."""
+    eng.schedule_batch(reqs, now, pk, apply=False)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        node, _, _, status = eng.schedule_batch(reqs, now, pk, apply=False)
+        ts.append(time.perf_counter() - t0)
+    t = min(ts)
+    return {"call": "nhdfit_schedule_batch (snapshot pass + sequential commit on the device, mirror restored)", "decisions_per_s": P / t,
+            "ms_per_batch": t * 1e3, "placed": int((node >= 0).sum()), "distinct_nodes": int(len(set(node[node >= 0].tolist()))),
+            "commits_that_would_raise": int((status == 1).sum())}
+
+
+def measure_counters(args):
+    """HBM bytes and VALU instructions per k_step launch: this script under rocprofv3, one counter set per pass."""
+    rocprof = shutil.which("rocprofv3")
+    if not rocprof:
+        return None
+    base = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "60", "--warmup", "5", "--config", str(args.config),
+            "--nodes-per-gpu", str(args.nodes_per_gpu), "--pods", str(args.pods), "--no-cpu-baseline", "--no-pmc", "--no-extras"]
+    env = dict(os.environ, NHD_BENCH_INNER="1", TMPDIR="/tmp")
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="nhdbench_", dir="/tmp")
+    try:
+        for name, ctrs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("valu", ["SQ_INSTS_VALU"])):
+            d = os.path.join(tmp, name)
+            cmd = [rocprof, "--pmc"] + ctrs + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + base
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+            except Exception:  # noqa: BLE001 - counters are optional: no profiler, no counters
+                return got or None
+            vals = {}
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if "k_step" in row["Kernel_Name"]:
+                            vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for k, v in vals.items():
+                got[k] = sum(v) / len(v)
+        if "FETCH_SIZE" in got and "WRITE_SIZE" in got:
+            # gfx950: FETCH_SIZE counts the 128-byte requests of wide coalesced reads as 64 bytes -> x 2
+            # (guides/MI355X_MICROARCH.md, HBM); both counters are in KiB
+            got["hbm_bytes_per_launch"] = int((2 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024)
+        if "SQ_INSTS_VALU" in got:
+            got["valu_insts_per_launch"] = got["SQ_INSTS_VALU"]
+        return got
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cpu_baseline(spec, tops, pod_groups, sample, gpu_score, base, winner_index, args):
     """The C port of the reference path (oracle/nhd_oracle.c) on the same inputs, 1 host core, on the
-    first `sample` pods x all of this GPU's nodes; also asserts the GPU picked the same nodes."""
+    first `sample` pods x all of this GPU's nodes; also asserts the GPU picked the same nodes.  The reference itself is
+    Python and absent on this box: its figures, measured in the build container on this workload's inputs, ride along."""
     from oracle import coracle
     cl = coracle.Cluster.from_spec(spec)
     sample = min(sample, len(tops))
@@ -183,12 +292,23 @@ def cpu_baseline(spec, tops, pod_groups, sample, gpu_score, base, winner_index):
         if not np.array_equal(winner_mt, winner):
             raise SystemExit("PARITY FAILURE: the multi-threaded CPU port disagrees with the single-threaded one")
         many = {"value": sample * spec.n / dt_mt, "cores": ncores, "seconds": dt_mt}
+    reference = None
+    for rpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "cpu_reference.json")), reverse=True):
+        with open(rpath) as f:
+            rj = json.load(f)
+        if (rj.get("config"), rj.get("nodes"), rj.get("pods_in_batch")) == (args.config, spec.n, args.pods):
+            reference = {"source": os.path.relpath(rpath, ROOT) + " (unmodified reference Matcher.FindNode on this workload's inputs, measured in the "
+                                   "build container - the reference is Python and not present on the GPU box)",
+                         "one_core": {"value": rj["one_core"]["evals_per_s"], "decisions_per_s": rj["one_core"]["decisions_per_s"], "cores": 1},
+                         "all_cores": {"value": rj["all_cores"]["evals_per_s"], "decisions_per_s": rj["all_cores"]["decisions_per_s"],
+                                       "cores": rj["all_cores"]["cores"]},
+                         "host": rj.get("host"), "sampled_pods": rj.get("sampled_pods"), "parity": rj.get("parity")}
+            break
     return {"value": sample * spec.n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
             "all_host_cores": many,
             "sample": f"first {sample} pods x {spec.n} nodes, oracle/nhd_oracle.c (gcc -O2), {dt:.1f} s; "
                       f"winners identical to the GPU's on all {sample} pods",
-            "reference_python_note": "the reference itself is Python and absent on the GPU box; measured in the build "
-                                     "container it runs ~3-9 k evals/s/core (BASELINE.md section 2)"}
+            "reference": reference}
 
 
 if __name__ == "__main__":

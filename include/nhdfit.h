@@ -256,6 +256,21 @@ int nhdfit_comm_unique_id(void* id128);
 int nhdfit_comm_init(nhdfit_ctx* ctx, int nranks, int rank, const void* id128);
 int nhdfit_comm_destroy(nhdfit_ctx* ctx);
 
+/* One process, several GPUs (the reference calls FindNode from its one scheduler thread, nhd/NHDScheduler.py:43,277):
+ * a group owns one context per device; the caller shards the node axis contiguously over them (nhdfit_group_ctx(g, k) +
+ * nhdfit_reserve_nodes(global_base) / nhdfit_upload_nodes / nhdfit_set_dictionary per shard, as for a single context).
+ * nhdfit_group_find replicates the requests, runs digest + fit on every device, max-reduces the P packed scores with ONE
+ * all-reduce over xGMI (ncclCommInitAll communicators, grouped ncclAllReduce(ncclUint64, ncclMax)), lets the owner of
+ * each winner map it and returns scores, mappings and owners.  cand: NULL or one [chunks] mask (or NULL) per shard. */
+typedef struct nhdfit_group nhdfit_group;
+int  nhdfit_group_create(const int* devices, int n, nhdfit_group** out);
+void nhdfit_group_destroy(nhdfit_group* g);
+int  nhdfit_group_size(nhdfit_group* g);
+nhdfit_ctx* nhdfit_group_ctx(nhdfit_group* g, int k);
+const char* nhdfit_group_last_error(nhdfit_group* g);
+int  nhdfit_group_find(nhdfit_group* g, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* const* cand,
+                       uint64_t* score_out, nhdfit_mapping* map_out, int32_t* owner_out);
+
 /* Skip the feasibility-bitmap store / the winner-mapping kernel (both on by default). */
 int nhdfit_set_outputs(nhdfit_ctx* ctx, int want_bitmap, int want_map);
 

@@ -52,6 +52,12 @@ _SIGS = {
     "nhdfit_set_outputs": (c_int, [c_void_p, c_int, c_int]),
     "nhdfit_get_stats": (c_int, [c_void_p, POINTER(Stats)]),
     "nhdfit_reset_stats": (c_int, [c_void_p]),
+    "nhdfit_group_create": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
+    "nhdfit_group_destroy": (None, [c_void_p]),
+    "nhdfit_group_size": (c_int, [c_void_p]),
+    "nhdfit_group_ctx": (c_void_p, [c_void_p, c_int]),
+    "nhdfit_group_last_error": (c_char_p, [c_void_p]),
+    "nhdfit_group_find": (c_int, [c_void_p, c_void_p, c_uint32, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nhdfit_digest_triad_config": (c_int, [c_char_p, ctypes.c_size_t, c_void_p, c_char_p, ctypes.c_size_t]),
     "nhdfit_digest_triad_configs": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_void_p]),
 }

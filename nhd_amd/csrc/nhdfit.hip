@@ -1378,6 +1378,9 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool load(std::string& err) {
         if (handle) return true;
@@ -1390,8 +1393,11 @@ struct Rccl {
         CommInitRank = (decltype(CommInitRank))dlsym(handle, "ncclCommInitRank");
         AllReduce = (decltype(AllReduce))dlsym(handle, "ncclAllReduce");
         CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+        CommInitAll = (decltype(CommInitAll))dlsym(handle, "ncclCommInitAll");
+        GroupStart = (decltype(GroupStart))dlsym(handle, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(handle, "ncclGroupEnd");
         GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
-        if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy || !GetErrorString) {
+        if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy || !GetErrorString || !CommInitAll || !GroupStart || !GroupEnd) {
             err = "librccl lacks a required symbol";
             return false;
         }
@@ -2414,6 +2420,129 @@ int nhdfit_comm_destroy(nhdfit_ctx* c) {
     }
     c->nranks = 1;
     c->rank = 0;
+    return NHDFIT_OK;
+}
+
+// ---- one process, several GPUs: the reference's single scheduler thread behind FindNode on all devices ------------
+struct nhdfit_group {
+    std::vector<nhdfit_ctx*> ctx;
+    std::vector<ncclComm_t> comm;        // empty: scores are max-reduced on the host (NHDFIT_GROUP_REDUCE=host, or one device)
+    std::string err;
+};
+
+int nhdfit_group_create(const int* devices, int n, nhdfit_group** out) {
+    if (!devices || n < 1 || !out) return fail(nullptr, NHDFIT_E_INVAL, "bad device list");
+    *out = nullptr;
+    nhdfit_group* g = new (std::nothrow) nhdfit_group();
+    if (!g) return fail(nullptr, NHDFIT_E_NOMEM, "out of host memory");
+    for (int k = 0; k < n; ++k) {
+        nhdfit_ctx* c = nullptr;
+        int rc = nhdfit_create(devices[k], &c);
+        if (rc) { for (auto* x : g->ctx) nhdfit_destroy(x); delete g; return rc; }
+        g->ctx.push_back(c);
+    }
+    const char* mode = getenv("NHDFIT_GROUP_REDUCE");
+    if (n > 1 && !(mode && !strcmp(mode, "host"))) {
+        std::string err;
+        if (!g_rccl.load(err)) { for (auto* x : g->ctx) nhdfit_destroy(x); delete g; return fail(nullptr, NHDFIT_E_RCCL, "%s", err.c_str()); }
+        g->comm.resize(n);
+        ncclResult_t r = g_rccl.CommInitAll(g->comm.data(), n, devices);      // one communicator per device, one process
+        if (r != ncclSuccess) {
+            for (auto* x : g->ctx) nhdfit_destroy(x);
+            delete g;
+            return fail(nullptr, NHDFIT_E_RCCL, "ncclCommInitAll: %s", g_rccl.GetErrorString(r));
+        }
+    }
+    *out = g;
+    return NHDFIT_OK;
+}
+
+void nhdfit_group_destroy(nhdfit_group* g) {
+    if (!g) return;
+    for (size_t k = 0; k < g->ctx.size(); ++k) {
+        (void)hipSetDevice(g->ctx[k]->dev);
+        (void)hipDeviceSynchronize();
+        if (k < g->comm.size() && g->comm[k]) g_rccl.CommDestroy(g->comm[k]);
+    }
+    for (auto* c : g->ctx) nhdfit_destroy(c);
+    delete g;
+}
+
+int nhdfit_group_size(nhdfit_group* g) { return g ? (int)g->ctx.size() : 0; }
+nhdfit_ctx* nhdfit_group_ctx(nhdfit_group* g, int k) { return g && k >= 0 && k < (int)g->ctx.size() ? g->ctx[k] : nullptr; }
+const char* nhdfit_group_last_error(nhdfit_group* g) { return g ? g->err.c_str() : ""; }
+
+// Mode A over every shard of the group: requests replicated, digest + fit per device, ONE all-reduce(max) of the P packed
+// scores over xGMI (ncclGroupStart / ncclAllReduce per device / ncclGroupEnd), then the owner of each winner maps it.
+// cand[k]: optional candidate mask of shard k.  map_out[p] is taken from the owner; owner_out[p] = its shard or -1.
+int nhdfit_group_find(nhdfit_group* g, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* const* cand,
+                      uint64_t* score_out, nhdfit_mapping* map_out, int32_t* owner_out) {
+    if (!g || !reqs || !P || !score_out) return NHDFIT_E_INVAL;
+    const size_t n = g->ctx.size();
+    auto gfail = [&](nhdfit_ctx* c, int rc) { g->err = c ? c->err : std::string("group error"); return rc; };
+    for (size_t k = 0; k < n; ++k) {                                     // digest + fit on every device, no host wait in between
+        nhdfit_ctx* c = g->ctx[k];
+        int rc = nhdfit_stage_requests(c, reqs, P);
+        if (!rc && cand && cand[k]) rc = stage_cand(c, cand[k]);
+        if (!rc && c->n) rc = nhdfit_enqueue_step(c, now);
+        if (rc) return gfail(c, rc);
+    }
+    std::vector<std::vector<uint64_t>> host_scores;
+    if (!g->comm.empty()) {
+        ncclResult_t r = g_rccl.GroupStart();
+        for (size_t k = 0; k < n && r == ncclSuccess; ++k) {
+            nhdfit_ctx* c = g->ctx[k];
+            if (hipSetDevice(c->dev) != hipSuccess) { r = ncclSystemError; break; }
+            const int b = c->n_fit ? (int)((c->n_fit - 1) % kBufs) : 0;
+            if (!c->n) {                                                 // a shard without nodes contributes "no feasible node"
+                if (c->score[b].reserve(P) != hipSuccess || hipMemsetAsync(c->score[b].p, 0, (size_t)P * 8, c->stream) != hipSuccess) { r = ncclSystemError; break; }
+            }
+            r = g_rccl.AllReduce(c->score[b].p, c->score[b].p, P, ncclUint64, ncclMax, g->comm[k], c->stream);
+        }
+        ncclResult_t r2 = g_rccl.GroupEnd();
+        if (r != ncclSuccess || r2 != ncclSuccess) { g->err = std::string("ncclAllReduce (group): ") + g_rccl.GetErrorString(r != ncclSuccess ? r : r2); return NHDFIT_E_RCCL; }
+    } else if (n > 1) {                                                  // host max-reduce (debug / test path): D2H, max, H2D
+        host_scores.resize(n);
+        std::vector<uint64_t> best(P, 0), tmp(P);
+        for (size_t k = 0; k < n; ++k) {
+            nhdfit_ctx* c = g->ctx[k];
+            if (!c->n) continue;
+            HIPCHK(c, hipSetDevice(c->dev));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const int b = (int)((c->n_fit - 1) % kBufs);
+            HIPCHK(c, hipMemcpy(tmp.data(), c->score[b].p, (size_t)P * 8, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < P; ++i) best[i] = std::max(best[i], tmp[i]);
+        }
+        for (size_t k = 0; k < n; ++k) {
+            nhdfit_ctx* c = g->ctx[k];
+            if (!c->n) continue;
+            HIPCHK(c, hipSetDevice(c->dev));
+            const int b = (int)((c->n_fit - 1) % kBufs);
+            HIPCHK(c, hipMemcpy(c->score[b].p, best.data(), (size_t)P * 8, hipMemcpyHostToDevice));
+        }
+    }
+    // mapping roles per device (each maps the winners it owns), then collect
+    std::vector<nhdfit_mapping> maps(P);
+    std::vector<uint64_t> sc(P);
+    bool have_score = false;
+    if (map_out) memset(map_out, 0, (size_t)P * sizeof(nhdfit_mapping));
+    if (owner_out) for (uint32_t i = 0; i < P; ++i) owner_out[i] = -1;
+    for (size_t k = 0; k < n; ++k) {
+        nhdfit_ctx* c = g->ctx[k];
+        if (!c->n) continue;
+        int rc = nhdfit_fetch(c, sc.data(), nullptr, map_out ? maps.data() : nullptr);
+        if (rc) return gfail(c, rc);
+        if (!have_score) { memcpy(score_out, sc.data(), (size_t)P * 8); have_score = true; }
+        for (uint32_t i = 0; i < P; ++i) {
+            if (!sc[i]) continue;
+            const uint64_t gi = NHDFIT_SCORE_INDEX(sc[i]);
+            if (gi >= c->global_base && gi < c->global_base + c->n) {
+                if (map_out) map_out[i] = maps[i];
+                if (owner_out) owner_out[i] = (int32_t)k;
+            }
+        }
+    }
+    if (!have_score) memset(score_out, 0, (size_t)P * 8);
     return NHDFIT_OK;
 }
 

@@ -191,5 +191,169 @@ class Engine:
         self._chk(self.lib.nhdfit_comm_destroy(self.ctx))
 
 
+class _ShardView(Engine):
+    """An Engine whose context belongs to a group (the group destroys it)."""
+
+    def __init__(self, lib, ctx, device):  # noqa: D401 - no nhdfit_create here
+        self.lib = lib
+        self.ctx = ctypes.c_void_p(ctx)
+        self.device = device
+        self.n = 0
+        self.P = 0
+        self.global_base = 0
+        self._dict_version = -1
+
+    def close(self):
+        self.ctx = None
+
+
+class GroupEngine:
+    """One process, several GPUs: the node axis of the mirror cut into contiguous shards (multiples of 64 nodes), one
+    context per device, winners picked by ONE all-reduce(max) of the packed scores over xGMI inside libnhdfit
+    (nhdfit_group_find).  Presents the Engine interface HipMatcher uses, so `HipMatcher(devices=[0, 1, ...])` lets the
+    reference's unmodified one-thread scheduler (nhd/NHDScheduler.py:43,50,277) drive all GPUs of the node.
+    `engine_factory` (tests only): build the shards from host-twin engines and reduce on the host instead."""
+
+    def __init__(self, devices, engine_factory=None):
+        self.devices = list(devices)
+        if not self.devices:
+            raise ValueError("GroupEngine needs at least one device")
+        self.n = 0
+        self.P = 0
+        self.global_base = 0
+        self.group = None
+        self._bounds = []
+        if engine_factory is not None:
+            self.lib = None
+            self.shards = [engine_factory(d) for d in self.devices]
+        else:
+            self.lib = _lib.load()
+            g = ctypes.c_void_p()
+            devs = (ctypes.c_int * len(self.devices))(*self.devices)
+            rc = self.lib.nhdfit_group_create(devs, len(self.devices), ctypes.byref(g))
+            if rc != 0:
+                raise _lib.NhdFitError(rc, (self.lib.nhdfit_last_error(None) or b"?").decode())
+            self.group = g
+            self.shards = [_ShardView(self.lib, self.lib.nhdfit_group_ctx(g, k), d) for k, d in enumerate(self.devices)]
+
+    def close(self):
+        if self.group is not None:
+            self.lib.nhdfit_group_destroy(self.group)
+            self.group = None
+        for s in self.shards:
+            s.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ---- state ------------------------------------------------------------------------
+    def set_dictionary(self, packer: pack.Packer):
+        for s in self.shards:
+            s.set_dictionary(packer)
+
+    def reset_nodes(self):
+        for s in self.shards:
+            s.reset_nodes()
+        self.n = 0
+        self._bounds = []
+
+    def _shard_of(self, i: int) -> int:
+        for k, (lo, hi) in enumerate(self._bounds):
+            if lo <= i < hi:
+                return k
+        raise IndexError(i)
+
+    def upload(self, table: pack.NodeTable, global_base: int = 0, first: int = 0, capacity: Optional[int] = None):
+        """Full upload (first == 0: defines the shard bounds) or delta upload of a run of nodes at `first`."""
+        from .sharding import shard_bounds
+        if first == 0 and (not self._bounds or table.n >= self.n):
+            n = table.n
+            self._bounds = [shard_bounds(n, len(self.shards), r) for r in range(len(self.shards))]
+            for s, (lo, hi) in zip(self.shards, self._bounds):
+                s.reset_nodes()
+                if hi > lo:
+                    s.upload(table.slice(lo, hi), global_base=lo)
+                else:
+                    s.global_base = lo
+            self.n = n
+            return
+        lo_i = first
+        while lo_i < first + table.n:                               # a run may straddle shards
+            k = self._shard_of(lo_i)
+            lo, hi = self._bounds[k]
+            hi_i = min(first + table.n, hi)
+            self.shards[k].upload(table.slice(lo_i - first, hi_i - first), global_base=lo, first=lo_i - lo, capacity=hi - lo)
+            lo_i = hi_i
+
+    def set_outputs(self, bitmap=True, mapping=True):
+        for s in self.shards:
+            s.set_outputs(bitmap, mapping)
+
+    # ---- one-shot ---------------------------------------------------------------------
+    def find(self, reqs: np.ndarray, now: float, cand: Optional[np.ndarray] = None, want_bitmap=False, want_map=True):
+        reqs = np.ascontiguousarray(reqs)
+        P = len(reqs)
+        cands = None
+        if cand is not None:
+            cand = np.ascontiguousarray(cand, dtype=np.uint64)
+            cands = [np.ascontiguousarray(cand[lo // 64:(hi + 63) // 64]) if hi > lo else None for lo, hi in self._bounds]
+        self.P = P
+        if self.group is None:                                      # host twin shards: reduce here
+            score = np.zeros(P, np.uint64)
+            maps = np.zeros(P, pack.MAPPING)
+            parts = []
+            for k, s in enumerate(self.shards):
+                if self._bounds[k][1] > self._bounds[k][0]:
+                    parts.append((k, s.find(reqs, now, cand=None if cands is None else cands[k], want_bitmap=False, want_map=want_map)))
+            for k, (sc, _, mp) in parts:
+                score = np.maximum(score, sc)
+            for k, (sc, _, mp) in parts:
+                lo, hi = self._bounds[k]
+                idx = np.where(score == 0, -1, (SCORE_MASK - (score & np.uint64(SCORE_MASK))).astype(np.int64))
+                own = (sc == score) & (idx >= lo) & (idx < hi)
+                if want_map:
+                    maps[own] = mp[own]
+            return score, None, (maps if want_map else None)
+        score = np.zeros(P, np.uint64)
+        maps = np.zeros(P, pack.MAPPING) if want_map else None
+        owner = np.zeros(P, np.int32)
+        cptr = None
+        if cands is not None:
+            cptr = (ctypes.c_void_p * len(self.shards))(*[None if c is None else c.ctypes.data for c in cands])
+        rc = self.lib.nhdfit_group_find(self.group, _p(reqs), P, float(now), cptr, _p(score), _p(maps), _p(owner))
+        if rc != 0:
+            raise _lib.NhdFitError(rc, (self.lib.nhdfit_group_last_error(self.group) or b"?").decode())
+        return score, None, maps
+
+    def schedule_batch(self, *a, **kw):
+        raise NotImplementedError("sequential (mode B) batches run on one shard: use HipMatcher(device=...) for ScheduleBatch")
+
+    find_sequential = schedule_batch
+
+    def commit(self, node: int, req, mapping, busy_time):
+        k = self._shard_of(node)
+        return self.shards[k].commit(node - self._bounds[k][0], req, mapping, busy_time)
+
+    def download(self, first: int = 0, count: Optional[int] = None) -> pack.NodeTable:
+        count = self.n - first if count is None else count
+        out = pack.empty_table(count)
+        i = first
+        while i < first + count:
+            k = self._shard_of(i)
+            lo, hi = self._bounds[k]
+            j = min(first + count, hi)
+            part = self.shards[k].download(i - lo, j - i)
+            for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
+                getattr(out, f)[i - first:j - first] = getattr(part, f)
+            i = j
+        return out
+
+    def stats(self):
+        return self.shards[0].stats()
+
+
 def winner_index(score: int) -> int:
     return SCORE_MASK - (int(score) & SCORE_MASK)

@@ -30,7 +30,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import pack
-from .engine import Engine, winner_index
+from .engine import Engine, GroupEngine, winner_index
 
 _MUTATORS = ("SetPhysicalIdsFromMapping", "RemoveResourcesFromTopology", "AddResourcesFromTopology",
              "ResetResources", "ClaimPodNICResources", "SetBusy", "SetGroups", "SetHugepages", "ParseLabels")
@@ -85,12 +85,18 @@ def _tracked_class(base: type) -> type:
 
 
 class HipMatcher:
-    def __init__(self, device: int = 0, clock=time.monotonic, engine_factory=None):
-        """`engine_factory(device)` exists for the test-suite only (it injects the host build of the
+    def __init__(self, device: int = 0, clock=time.monotonic, engine_factory=None, devices: Optional[Sequence[int]] = None):
+        """`devices=[0, 1, ...]`: shard the mirror over several GPUs of this process (engine.GroupEngine: node axis
+        cut into contiguous shards, one RCCL all-reduce(max) of the packed scores per call picks the winners) - the
+        reference's one-thread scheduler keeps calling FindNode exactly as before.
+        `engine_factory(device)` exists for the test-suite only (it injects the host build of the
         kernels' arithmetic so the host logic of this class can be exercised without a GPU); the
         default is the HIP engine, which raises when the library or a gfx950 GPU is missing."""
         self.logger = logging.getLogger(__name__)
-        self.engine = (engine_factory or Engine)(device)
+        if devices is not None:
+            self.engine = GroupEngine(devices, engine_factory)
+        else:
+            self.engine = (engine_factory or Engine)(device)
         self.packer = pack.Packer()
         self.clock = clock
         self._attached: Optional[Dict[str, object]] = None

@@ -2,7 +2,7 @@
 
 * ``Packer.pack_nodes(nl)``   Dict[str, Node]  -> :class:`NodeTable` (five 16-byte SoA planes + the
   cold per-node detail record).  Nodes are read purely by attribute,
-  so live ``nhd.Node.Node`` objects and the stand-ins of :mod:`nhd_amd.refmodel` both work.
+  so live ``nhd.Node.Node`` objects and the stand-ins of :mod:`workload.refmodel` both work.
 * ``Packer.digest(top, pod_groups)``   CfgTopology -> one ``nhdfit_req`` record.
 * ``Packer.planes_from_spec(spec)``    vectorised equivalent of pack_nodes for synthetic clusters.
 
@@ -572,7 +572,7 @@ def expand_placement(place, n_groups: int, cores_per_proc: int, num_cores: int, 
 
 
 def _synth_group_names():
-    from .synth import GROUP_NAMES
+    from workload.synth import GROUP_NAMES
     return GROUP_NAMES
 
 

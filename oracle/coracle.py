@@ -88,8 +88,8 @@ class Cluster:
 
     @staticmethod
     def from_spec(spec, group_ids=None):
-        """Vectorised flattening of nhd_amd.synth.ClusterSpec (layout facts: see ClusterSpec.labels)."""
-        from nhd_amd import synth
+        """Vectorised flattening of workload.synth.ClusterSpec (layout facts: see ClusterSpec.labels)."""
+        from workload import synth
         gid = group_ids or GroupIds()
         n, K = spec.n, spec.nics_per_numa
         phys = spec.phys.astype(np.int64)

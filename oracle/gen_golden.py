@@ -20,8 +20,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from nhd_amd import refmodel, synth          # noqa: E402
-from nhd_amd.refmodel import NFD             # noqa: E402
+from workload import refmodel, synth# noqa: E402
+from workload.refmodel import NFD             # noqa: E402
 from oracle import ref_loader                # noqa: E402
 from oracle import nhd_oracle                # noqa: E402
 from tests import util                       # noqa: E402

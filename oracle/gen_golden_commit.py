@@ -4,7 +4,7 @@ TEST INFRASTRUCTURE; run in the build container only:
 
     python oracle/gen_golden_commit.py
 
-For a seeded synthetic cluster and pod list (nhd_amd.synth), the scheduler loop of nhd/NHDScheduler.py:274-304 is
+For a seeded synthetic cluster and pod list (workload.synth), the scheduler loop of nhd/NHDScheduler.py:274-304 is
 replayed with the reference's own objects under a virtual clock: InitialNodeFilter -> Matcher.FindNode -> SetBusy ->
 SetPhysicalIdsFromMapping -> ClaimPodNICResources, pod after pod.  Each fixture holds
   expected[i] = [node name, mapping, ids]   ids = the physical ids the reference wrote into the pod's CfgTopology:
@@ -25,7 +25,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from nhd_amd import pack, refmodel, synth    # noqa: E402
+from nhd_amd import pack
+from workload import refmodel, synth# noqa: E402
 from oracle import nhd_oracle, ref_loader    # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden", "commit")

@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from nhd_amd import pack                              # noqa: E402
+from nhd_amd import pack# noqa: E402
 from tests import wire_gen                            # noqa: E402
 from tests.test_wire_digest import reference_outcome  # noqa: E402
 

@@ -8,7 +8,8 @@ import os
 
 import numpy as np
 
-from nhd_amd import pack, refmodel, synth
+from nhd_amd import pack
+from workload import refmodel, synth
 
 FIXTURES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "commit", "*.json")))
 

@@ -30,7 +30,7 @@ sys.path.insert(0, {root!r})
 from tests.test_bench_dryrun import DryEngine
 import nhd_amd.engine as eng_mod
 eng_mod.Engine = DryEngine
-sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--nodes-per-gpu", "1024", "--pods", "96", "--cpu-sample-pods", "32"]
+sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--nodes-per-gpu", "1024", "--pods", "96", "--cpu-sample-pods", "32", "--no-pmc"]
 print("library chatter that must not reach the result stream", file=sys.stderr)
 runpy.run_path({bench!r}, run_name="__main__")
 """
@@ -54,6 +54,9 @@ def test_bench_json_contract(tmp_path):
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    assert out["mode_b"]["decisions_per_s"] > 0 and out["mode_b"]["placed"] > 0       # decisions under commit semantics
+    assert out["end_to_end"]["evals_per_s"] > 0
+    assert out["roofline"]["bound"] == "hbm" and "limited_by" in out["roofline"] and "traffic_source" in out["roofline"]
 
 
 _RANK_SCRIPT = r"""
@@ -91,3 +94,25 @@ def test_bench_two_ranks_control_plane(tmp_path):
     assert len(lines0) == 1 and not outs[1][0].strip()
     out = json.loads(lines0[0])
     assert out["n_gpus"] == 2 and out["config"]["nodes_total"] == 1024 and "cpu_baseline" not in out
+
+
+_STRONG_SCRIPT = _RANK_SCRIPT.replace('"--nodes-per-gpu", "512", "--pods", "40"', '"--config", "5", "--total-nodes", "1500", "--pods", "70"')
+
+
+def test_bench_strong_scaling_shape(tmp_path):
+    """BASELINE.json's own multi-GPU shapes are strong scaling (fixed cluster, node axis cut over the ranks):
+    `--total-nodes` at two ranks - uneven last shard included."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "strong.py"
+    script.write_text(_STRONG_SCRIPT.format(root=ROOT, bench=os.path.join(ROOT, "bench.py")))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    out = json.loads([ln for ln in outs[0][0].splitlines() if ln.strip()][0])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2
+    assert out["config"]["nodes_total"] == 1500 and out["config"]["nodes_per_gpu"] == 750

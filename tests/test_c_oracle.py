@@ -7,7 +7,7 @@ import time
 import numpy as np
 import pytest
 
-from nhd_amd import refmodel, synth
+from workload import refmodel, synth
 from oracle import coracle
 from oracle import nhd_oracle as O
 from tests import util

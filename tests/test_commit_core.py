@@ -6,7 +6,8 @@ import os
 import numpy as np
 import pytest
 
-from nhd_amd import pack, refmodel, synth
+from nhd_amd import pack
+from workload import refmodel, synth
 from oracle import nhd_oracle as O
 from tests import commit_check, harness
 

@@ -3,7 +3,7 @@ with the host build of the kernel arithmetic injected as the engine (tests/harne
 import numpy as np
 import pytest
 
-from nhd_amd import refmodel, synth
+from workload import refmodel, synth
 from nhd_amd.matcher import HipMatcher
 from oracle import nhd_oracle as O
 from tests import harness, util

@@ -3,7 +3,8 @@ sequential batch (itself pinned to the reference in tests/test_mode_b_oracle.py)
 import numpy as np
 import pytest
 
-from nhd_amd import pack, refmodel, synth
+from nhd_amd import pack
+from workload import refmodel, synth
 from oracle import nhd_oracle as O
 from tests import harness, util
 

@@ -6,7 +6,7 @@ import io
 import numpy as np
 import pytest
 
-from nhd_amd import refmodel, synth
+from workload import refmodel, synth
 from oracle import nhd_oracle as O
 
 

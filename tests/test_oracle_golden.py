@@ -6,7 +6,7 @@ import os
 
 import pytest
 
-from nhd_amd import refmodel
+from workload import refmodel
 from oracle import nhd_oracle as O
 from tests import util
 

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from nhd_amd import refmodel, synth
+from workload import refmodel, synth
 from oracle import nhd_oracle as O
 from tests import util
 

@@ -13,7 +13,7 @@ import types
 import numpy as np
 import pytest
 
-from nhd_amd import refmodel, synth
+from workload import refmodel, synth
 from nhd_amd.matcher import HipMatcher
 from tests import harness
 

@@ -11,8 +11,11 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from nhd_amd import pack, refmodel, shard, synth
+from nhd_amd import pack
+from workload import refmodel, synth
+from nhd_amd import sharding as shard
 from tests import harness
+from workload import dist as dist_util
 
 
 def _free_port():
@@ -39,11 +42,11 @@ def _worker(rank, world, port, cfg, n, P, out_dir):
     table = pk.planes_from_spec(spec.shard(lo, hi))
     reqs = pk.digest_many(tops, groups)
     score, _, maps = harness.find(pk, table, reqs, spec.clock_now, global_base=lo, want_bitmap=False)
-    red = shard.allreduce_max_scores(score)
+    red = dist_util.allreduce_max_scores(score)
     # a rank keeps a mapping only if it owns the global winner
     owner = np.array([lo <= (0x7FFFFFFFFFFFFFFF - (int(s) & 0x7FFFFFFFFFFFFFFF)) < hi if s else False for s in red])
     maps[~owner] = np.zeros((), pack.MAPPING)
-    merged = shard.merge_mappings(maps)
+    merged = dist_util.merge_mappings(maps)
     if rank == 0:
         np.save(os.path.join(out_dir, "score.npy"), red)
         np.save(os.path.join(out_dir, "maps.npy"), merged.view(np.int8))

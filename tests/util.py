@@ -2,8 +2,8 @@
 BASELINE configs: 1- and 2-socket nodes, mixed NIC speeds, slow NICs, odd switch layouts)."""
 import numpy as np
 
-from nhd_amd import refmodel
-from nhd_amd.refmodel import NFD
+from workload import refmodel
+from workload.refmodel import NFD
 
 CLOCK = 1.0e6
 

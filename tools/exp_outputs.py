@@ -4,7 +4,8 @@
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from nhd_amd import pack, refmodel, synth
+from nhd_amd import pack
+from workload import refmodel, synth
 from nhd_amd.engine import Engine
 
 n, P, steps = 65536, 4096, 400

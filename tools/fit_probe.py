@@ -4,7 +4,8 @@ Run under rocprofv3 with NHDFIT_ROLE_KERNELS=1 to get the stand-alone time of ea
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from nhd_amd import pack, refmodel, synth
+from nhd_amd import pack
+from workload import refmodel, synth
 from nhd_amd.engine import Engine
 
 cfg = int(os.environ.get("PROBE_CFG", "4"))

@@ -3,7 +3,7 @@
 BASELINE config 1 (32 nodes) and config 2 (4 096 nodes), stateless and with the persistent mirror (attach)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from nhd_amd import refmodel, synth
+from workload import refmodel, synth
 from nhd_amd.matcher import HipMatcher
 
 out = []

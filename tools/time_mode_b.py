@@ -4,7 +4,8 @@ sequential commit inside the batch.  Prints one JSON line."""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from nhd_amd import pack, refmodel, synth
+from nhd_amd import pack
+from workload import refmodel, synth
 from nhd_amd.engine import Engine
 
 n, P = int(sys.argv[1]) if len(sys.argv) > 1 else 65536, int(sys.argv[2]) if len(sys.argv) > 2 else 4096

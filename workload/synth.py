@@ -6,7 +6,7 @@ machine.  A cluster is held as a :class:`ClusterSpec` (plain numpy columns).  It
 can be turned into
 
 * NFD label dicts + occupancy, to be parsed by the reference's own
-  ``Node.ParseLabels`` (nhd/Node.py:468) or by :mod:`nhd_amd.refmodel` when the
+  ``Node.ParseLabels`` (nhd/Node.py:468) or by :mod:`workload.refmodel` when the
   reference is not installed  ->  ``spec.build_nodes(...)``; these objects feed
   ``pack.pack_nodes`` exactly like live scheduler state would;
 * packed device planes directly (``pack.planes_from_spec``), for cluster sizes at
