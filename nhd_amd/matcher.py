@@ -104,14 +104,17 @@ class HipMatcher:
         self._names: List[str] = []
         self._table: Optional[pack.NodeTable] = None
         self._dirty: Dict[str, object] = {}
+        self._mirror_foreign = False                       # the mirror holds a dict other than the attached one
         self._reasons: Dict[str, set] = {}
         self._claims: Dict[str, frozenset] = {}
+        self._batch_ids: Dict[str, list] = {}              # ScheduleBatch(apply=True): ids the device already committed, per node, in order
         self._uploaded_ids: Optional[Tuple[int, ...]] = None
 
     # ---- mirror maintenance -------------------------------------------------------------
     def attach(self, nodes: Dict[str, object]) -> None:
         """Mirror `nodes` (the scheduler's self.nodes) persistently and track changes to it."""
         self._attached = nodes
+        self._mirror_foreign = False
         for node in nodes.values():
             if type(node) not in _tracked_cache.values():
                 node.__class__ = _tracked_class(type(node))
@@ -167,16 +170,24 @@ class HipMatcher:
         """After the reference's own SetPhysicalIdsFromMapping succeeded on an attached node: the same commit on the
         device mirror, checked against what the reference just wrote into `top`.  True = the mirror is current."""
         if self._attached is None or node.name not in self._index or node.name in self._dirty_strict:
+            self._batch_ids.pop(node.name, None)
             return False
-        try:
-            ids = self.CommitPlacement(node.name, top, mapping)
-        except Exception:  # noqa: BLE001 - any doubt: fall back to re-packing the node
-            return False
+        pending = self._batch_ids.get(node.name)
+        if pending:                                            # ScheduleBatch(apply=True) committed this placement on the device already
+            ids = pending.pop(0)
+            if not pending:
+                del self._batch_ids[node.name]
+        else:
+            try:
+                ids = self.CommitPlacement(node.name, top, mapping)
+            except Exception:  # noqa: BLE001 - any doubt: fall back to re-packing the node
+                return False
         pos = {g.device_id: k for k, g in enumerate(node.gpus)}
         want = {"groups": [{"cores": [c.core for g in pg.group_gpus for c in g.cpu_cores] + [c.core for c in pg.proc_cores],
                             "helpers": [c.core for c in pg.misc_cores], "gpus": [pos[g.device_id] for g in pg.group_gpus]}
                            for pg in top.proc_groups], "misc": [c.core for c in top.misc_cores]}
         if ids != want:
+            self._batch_ids.pop(node.name, None)
             return False
         claim = set()
         for gi, pg in enumerate(top.proc_groups):
@@ -218,7 +229,7 @@ class HipMatcher:
     def _flush_dirty(self) -> None:
         if not self._dirty:
             return
-        if len(self._attached) != len(self._names) or any(nm not in self._index for nm in self._dirty):
+        if any(nm not in self._index for nm in self._dirty):
             self._full_upload(self._attached)          # nodes were added or removed
             self._dirty.clear()
             self._reasons.clear()
@@ -314,11 +325,23 @@ class HipMatcher:
             return [(None,) for _ in range(n_pods)]
         now = self.clock() if now is None else now
         cand = None
-        if self._attached is not None and all(k in self._index for k in nl):
+        known = False
+        if self._attached is not None:
+            if len(self._attached) != len(self._names) or self._mirror_foreign:
+                self.attach(self._attached)                # nodes were added / removed, or a foreign dict was matched in between
+            if nl is self._attached:                       # the scheduler's own dict: nothing to look up, O(1) in the node count
+                known = True
+            else:
+                try:
+                    cand = self._candidates(nl)
+                    known = True
+                except KeyError:                           # names the attached dict does not hold: stateless for this call
+                    known = False
+        if known:
             self._flush_dirty()
-            cand = self._candidates(nl)
         else:
             self._full_upload(nl)
+            self._mirror_foreign = self._attached is not None
         if reqs is None:
             reqs = self.packer.digest_many(tops, pod_groups)
         places = None
@@ -345,6 +368,8 @@ class HipMatcher:
                     Gp = int(reqs[p]["n_groups"])
                     self.last_placements[p] = pack.expand_placement(places[p], Gp, int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets),
                                                                     [int(reqs[p]["gpus"][g]) for g in range(Gp)])
+                    if apply:                                  # the reference mutators that follow find their work mirrored already
+                        self._batch_ids.setdefault(nd.name, []).append(self.last_placements[p])
             name = self._names[int(index[p])]
             G = int(reqs[p]["n_groups"])
             m = maps[p]

@@ -64,3 +64,29 @@ def test_pod_groups_filter_equals_scheduler_side_filter():
     for top, grp, res in zip(tops, groups, got):
         sub = O.initial_node_filter(nl, grp)
         assert norm(res) == norm(O.find_node(sub, top, spec.clock_now))
+
+
+def test_attached_dict_grows_and_foreign_dicts_do_not_corrupt_the_mirror():
+    """a node added to the attached dict must be hooked and mirrored; a call with a dict the mirror does
+    not know (names outside the attached dict) runs stateless and must not leave a subset behind as 'the mirror'."""
+    spec = synth.make_cluster(3, n_nodes=120)
+    every = spec.build_nodes()
+    names = list(every)
+    nl = {k: every[k] for k in names[:100]}
+    pods, _ = synth.make_pods(3, n_pods=20)
+    tops = [refmodel.make_topology(s) for s in pods]
+    m = HipMatcher(clock=lambda: spec.clock_now, engine_factory=harness.HarnessEngine)
+    m.attach(nl)
+    m.FindNodes(nl, tops)
+    for k in names[100:110]:                           # the scheduler learns about new nodes (BuildInitialNodeList again)
+        nl[k] = every[k]
+    assert [norm(r) for r in m.FindNodes(nl, tops)] == [norm(O.find_node(nl, t, spec.clock_now)) for t in tops]
+    nl[names[105]].maintenance = True                  # a node that joined later is tracked like the others
+    assert names[105] in m._dirty
+    assert [norm(r) for r in m.FindNodes(nl, tops)] == [norm(O.find_node(nl, t, spec.clock_now)) for t in tops]
+    foreign = {k: every[k] for k in names[110:]}       # not part of the attached dict at all
+    for t in tops[:5]:
+        assert norm(m.FindNode(foreign, t)) == norm(O.find_node(foreign, t, spec.clock_now))
+    assert [norm(r) for r in m.FindNodes(nl, tops)] == [norm(O.find_node(nl, t, spec.clock_now)) for t in tops]
+    nl[names[3]].maintenance = True
+    assert [norm(r) for r in m.FindNodes(nl, tops)] == [norm(O.find_node(nl, t, spec.clock_now)) for t in tops]
