@@ -78,12 +78,17 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    from . import build
     if not os.path.exists(LIB_PATH):
-        from . import build
         try:
             build.build_lib()
         except Exception as e:  # noqa: BLE001
             raise NhdFitError(-2, f"{LIB_PATH} is missing and could not be built with hipcc: {e}") from e
+    elif build.stale() and os.path.exists(build.hipcc()):      # a source is newer than the library (development tree)
+        try:
+            build.build_lib()
+        except Exception:  # noqa: BLE001 - keep the library that is there
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)

@@ -419,14 +419,20 @@ NHD_HD uint64_t node_word_cold(const uint8_t* img, const Layout& L, const NodeId
     return acc & pred;
 }
 
-// NIC-feasible assignment bits (bit p) of one (pod, node) pair, for the winner mapping (cold R rows)
-NHD_HD uint32_t nic_assignment_bits(const uint8_t* img, const Layout& L, uint32_t col, bool pci, const nhdfit_plane3& q3) {
+// NIC-feasible assignment bits (bit p) of one (pod, node) pair, for the winner mapping (cold R rows).
+// ColdView: the four layout words that addressing needs (kernel arguments carry these instead of whole Layouts).
+struct ColdView { uint32_t off_r0, off_r1, row, W; };
+NHD_HD ColdView cold_view(const Layout& L) { return ColdView{L.off_r0, L.off_r1, L.row, L.W}; }
+NHD_HD uint32_t nic_assignment_bits(const uint8_t* img, const ColdView& L, uint32_t col, bool pci, const nhdfit_plane3& q3) {
     const uint32_t o0 = L.off_r0 + (pci ? q3.sig_pci[0] : q3.sig_numa[0]) * L.row;
     const uint32_t o1 = L.off_r1 + (pci ? q3.sig_pci[1] : q3.sig_numa[1]) * L.row;
     uint32_t bits = 0;
     for (uint32_t p = 0; p < L.W; ++p)
         if ((ld64(img, o0 + p * 8) & ld64(img, o1 + p * 8)) >> col & 1) bits |= 1u << p;
     return bits;
+}
+NHD_HD uint32_t nic_assignment_bits(const uint8_t* img, const Layout& L, uint32_t col, bool pci, const nhdfit_plane3& q3) {
+    return nic_assignment_bits(img, cold_view(L), col, pci, q3);
 }
 
 // ---- selection (Matcher.py:393-421) ----------------------------------------------------------

@@ -231,7 +231,8 @@ struct FitArgs {
     double busy_from;           // busy_threshold(now): a node is busy iff busy_time >= busy_from
     const uint8_t* tabs;        // tile images
     uint32_t pitch;
-    Layout L[kWClasses];
+    uint32_t off_hot[kWClasses], hot_bytes[kWClasses], hot_hp[kWClasses];   // per row width: where the hot section starts, its size, its HP rows
+    uint32_t hp_last;           // last HP row of the staged batch (hp_rows - 1)
     const PodHeader* hdr;       // [tiles*64], zero flags beyond P
     uint32_t P;
     const uint64_t* cand;       // optional [chunks]: candidate nodes (bit = node) common to all pods of the call
@@ -338,22 +339,36 @@ __device__ __forceinline__ uint64_t sweep_assignments(const uint8_t* hot, uint32
 template <int BLOCK, int W>
 __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, uint8_t* lds) {
     constexpr int NW = BLOCK / 64;
-    const Layout& L = a.L[W == 2 ? 0 : W == 4 ? 1 : W == 8 ? 2 : 3];
+    constexpr int WC = W == 2 ? 0 : W == 4 ? 1 : W == 8 ? 2 : 3;
+    const uint32_t hot_bytes = a.hot_bytes[WC];
     uint8_t* hot = lds;
-    unsigned long long (*s_best)[64] = reinterpret_cast<unsigned long long (*)[64]>(lds + lds_slice(L.hot_bytes));
+    unsigned long long (*s_best)[64] = reinterpret_cast<unsigned long long (*)[64]>(lds + lds_slice(hot_bytes));
     const uint32_t tile = it.tile;
+    const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t pod0 = tile * kTile;
+    const NodeRec* __restrict__ recs = a.rec[WC];
+    const uint32_t len = it.c_end - it.c_begin, per = (len + NW - 1) / NW;
+    const uint32_t c_first = it.c_begin + wave * per;
+    const uint32_t c_last = (a.dbg_skip & 64) ? c_first : c_first + per < it.c_end ? c_first + per : it.c_end;
 
+    // Everything the block needs first is requested before anything is waited for: the tile's request headers, the
+    // wavefront's first node records and the hot section of the table image are independent L2 round trips - issued one
+    // after the other behind a barrier they would add up.
+    const PodHeader my_h = a.hdr[pod0 + lane];
+    uint4 rv = make_uint4(0u, 0u, 0u, 0u);
+    double bt = 0.0;
+    if (c_first < c_last) {
+        rv = *reinterpret_cast<const uint4*>(recs + c_first * 64 + lane);           // {w0,w1}, {x0,x1}, {gx,hp}, {flags,pad}
+        bt = a.p4[c_first * 64 + lane].busy_time;
+    }
     {   // stage the hot section of the tile's table image in LDS (16 B per lane, fully coalesced)
-        const uint4* src = reinterpret_cast<const uint4*>(a.tabs + (size_t)tile * a.pitch + L.off_hot);
+        const uint4* src = reinterpret_cast<const uint4*>(a.tabs + (size_t)tile * a.pitch + a.off_hot[WC]);
         uint4* dst = reinterpret_cast<uint4*>(hot);
-        if (!(a.dbg_skip & 16)) for (uint32_t i = threadIdx.x; i < L.hot_bytes / 16; i += BLOCK) dst[i] = src[i];
+        if (!(a.dbg_skip & 16)) for (uint32_t i = threadIdx.x; i < hot_bytes / 16; i += BLOCK) dst[i] = src[i];
     }
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t pod0 = tile * kTile;
     // lane-as-pod view of the tile's 64 request headers -> class masks of the tile (scalar registers)
-    const PodHeader my_h = a.hdr[pod0 + lane];
     const bool my_pod_live = pod0 + lane < a.P;
     const bool my_pod_needs_gpu = (my_h.flags & kPodNeedGpu) != 0;
     const uint64_t m_need = __ballot(my_pod_needs_gpu);
@@ -361,20 +376,10 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
     uint64_t need_pref = __ballot(my_pod_live && !my_pod_needs_gpu);         // GPU-less pods without a GPU-less node so far
     uint32_t best_any = ~0u, best_pref = ~0u;                                // lane = pod: local node index
 
-    const NodeRec* __restrict__ recs = a.rec[W == 2 ? 0 : W == 4 ? 1 : W == 8 ? 2 : 3];
-    const uint32_t hp_last = L.hp_rows - 1;
-    const uint32_t len = it.c_end - it.c_begin, per = (len + NW - 1) / NW;
-    const uint32_t c_first = it.c_begin + wave * per;
-    const uint32_t c_last = (a.dbg_skip & 64) ? c_first : c_first + per < it.c_end ? c_first + per : it.c_end;
+    const uint32_t hp_last = a.hp_last, hot_hp = a.hot_hp[WC];
     const size_t npad = (size_t)a.chunks * 64;
     // the next chunk's record and busy time are requested before this chunk is worked on: a wavefront's chunks are
     // one dependent chain of L2 round trips otherwise
-    uint4 rv = make_uint4(0u, 0u, 0u, 0u);
-    double bt = 0.0;
-    if (c_first < c_last) {
-        rv = *reinterpret_cast<const uint4*>(recs + c_first * 64 + lane);           // {w0,w1}, {x0,x1}, {gx,hp}, {flags,pad}
-        bt = a.p4[c_first * 64 + lane].busy_time;
-    }
     for (uint32_t c = c_first; c < c_last; ++c) {
         const uint32_t i = c * 64 + lane;
         uint4 rv_next = rv;
@@ -387,7 +392,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
         const uint32_t a_x0 = (rv.y & 0xFFFFu) << 3, a_x1 = (rv.y >> 16) << 3;
         const uint32_t a_gx = (rv.z & 0xFFFFu) << 3;
         const uint32_t hp = rv.z >> 16;
-        const uint32_t a_hp = L.hot_hp + (hp < hp_last ? hp : hp_last) * 8;
+        const uint32_t a_hp = hot_hp + (hp < hp_last ? hp : hp_last) * 8;
         const bool nogpu = (rv.w & kRecNoGpu) != 0;
 
         // (1) NUMA-assignment feasibility against all 64 pods (bit-sliced tables), (2) scalar predicates
@@ -456,7 +461,7 @@ struct MapArgs {
     const uint8_t* tabs;             // tile images (their cold R rows: NIC-feasible assignments of a winner)
     uint32_t pitch;
     const uint8_t* tile_wcls;        // row width class of every tile
-    Layout L[kWClasses];
+    ColdView L[kWClasses];
     uint32_t n;
     uint64_t global_base;
     const nhdfit_req* reqs;
@@ -767,7 +772,7 @@ __device__ __forceinline__ void role_finish(const MapArgs& a, const ShapeArgs& h
 // Dependencies only cross launches (stream order).  A role with zero blocks is simply absent: the same kernel
 // serves a single find (five launches, one role each) and the pipeline flush.
 struct StepArgs {
-    uint32_t nb_choose, nb_shapes, nb_finish, nb_digest;     // blocks per side role, in grid order; fit takes the rest
+    uint32_t nb_fit, nb_choose, nb_shapes, nb_finish, nb_digest;     // blocks per role, in grid order
     uint32_t shapes_P;                                       // pods (= upper bound of the choose role's shape slots)
     uint32_t side_prio;                                      // raise the side roles' issue priority
     ShapeArgs choose;
@@ -882,9 +887,16 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : 7) void k_step(StepArgs a
     extern __shared__ __align__(16) uint8_t lds[];
     uint32_t blk = blockIdx.x;
     const unsigned long long t0 = a.role_clock ? (unsigned long long)wall_clock64() : 0ull;
-    // the side roles are latency chains on a few wavefronts: with issue priority over the chip-filling fit role they
-    // finish (and free their block slots) sooner, at no cost in total work
-    if (blk < a.nb_choose + a.nb_shapes + a.nb_finish + a.nb_digest) { if (a.side_prio) __builtin_amdgcn_s_setprio(3); }
+    // Grid order: the fit role first.  Its blocks are sized to fill two of the three block slots of every CU, so all of
+    // them start at once; the side roles (short latency chains on few wavefronts) take the third slot, with issue
+    // priority so that they finish - and hand the slot on - sooner.
+    if (blk < a.nb_fit) {
+        role_fit<BLOCK>(a.fit, blk, lds);
+        stamp(a.role_clock, 4, t0);
+        return;
+    }
+    blk -= a.nb_fit;
+    if (a.side_prio) __builtin_amdgcn_s_setprio(3);
     if (blk < a.nb_choose) {
         if ((threadIdx.x & 63) == 0)
             role_choose(a.choose, (uint32_t)__builtin_amdgcn_readfirstlane((int)(blk * (BLOCK / 64) + (threadIdx.x >> 6))),
@@ -897,10 +909,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : 7) void k_step(StepArgs a
     blk -= a.nb_shapes;
     if (blk < a.nb_finish) { role_finish<BLOCK>(a.finish_m, a.finish_h, blk, lds); stamp(a.role_clock, 2, t0); return; }
     blk -= a.nb_finish;
-    if (blk < a.nb_digest) { role_digest<BLOCK>(a.digest, blk, lds); stamp(a.role_clock, 3, t0); return; }
-    blk -= a.nb_digest;
-    role_fit<BLOCK>(a.fit, blk, lds);
-    stamp(a.role_clock, 4, t0);
+    role_digest<BLOCK>(a.digest, blk, lds);
+    stamp(a.role_clock, 3, t0);
 }
 
 // Profiling aid (NHDFIT_ROLE_KERNELS=1): one role per launch, so that rocprofv3 --stats names each role's stand-alone time.
@@ -1932,7 +1942,7 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
     const uint32_t tiles = (c->P + kTile - 1) / kTile, chunks = (c->n + 63) / 64;
     const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
     // two of the three 512-thread blocks a CU holds (the side roles of the same launch live in the third slot)
-    uint32_t target = c->fit_blocks ? c->fit_blocks : cus * (nw == 8 ? 2u : 5u);
+    uint32_t target = c->fit_blocks ? c->fit_blocks : cus * (nw == 8 ? 2u : 5u);          // see k_step: the fit role leads the grid
     uint64_t total = 0;
     for (uint32_t t = 0; t < tiles; ++t) total += (uint64_t)chunks * (6u + (2u << c->h_tile_wcls[t]));
     std::vector<FitItem> items;
@@ -1972,7 +1982,7 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         memset(&m, 0, sizeof m);
         m.p0 = c->p0.p; m.p1 = c->p1.p; m.p2 = c->p2.p; m.p3 = c->p3.p; m.det = c->det.p;
         m.tabs = c->tabs[b].p; m.pitch = c->pitch; m.tile_wcls = c->tile_wcls.p;
-        for (int w = 0; w < kWClasses; ++w) m.L[w] = c->L[w];
+        for (int w = 0; w < kWClasses; ++w) m.L[w] = cold_view(c->L[w]);
         m.n = c->n; m.global_base = c->global_base; m.reqs = c->reqs.p; m.P = P;
         m.score = c->score[b].p; m.caps = c->caps.p; m.out = c->maps[b].p;
         return m;
@@ -2024,7 +2034,10 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         if (c->want_bitmap) HIPCHK(c, c->nm.reserve((size_t)tiles * chunks * 64));
         if (!c->n_items) { int rc_ = build_items(c, nw); if (rc_) return rc_; }
         FitArgs& f = a.fit;
-        for (int w = 0; w < kWClasses; ++w) { f.rec[w] = c->rec[w].p; f.L[w] = c->L[w]; }
+        for (int w = 0; w < kWClasses; ++w) {
+            f.rec[w] = c->rec[w].p; f.off_hot[w] = c->L[w].off_hot; f.hot_bytes[w] = c->L[w].hot_bytes; f.hot_hp[w] = c->L[w].hot_hp;
+        }
+        f.hp_last = c->hp_rows - 1;
         f.p4 = c->p4.p;
         f.n = c->n; f.chunks = chunks; f.global_base = c->global_base; f.busy_from = busy_threshold(now);
         f.tabs = c->tabs[bf].p; f.pitch = c->pitch; f.hdr = c->hdr[bf].p; f.P = P;
@@ -2035,6 +2048,7 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         f.dbg_skip = getenv("NHDFIT_FIT_SKIP") ? (uint32_t)atoi(getenv("NHDFIT_FIT_SKIP")) : 0;
         nb_fit = c->n_items;
     }
+    a.nb_fit = nb_fit;
     const uint32_t grid = a.nb_choose + a.nb_shapes + a.nb_finish + a.nb_digest + nb_fit;
     if (!grid) return NHDFIT_OK;
     // dynamic LDS of the launch: the largest need among the roles present

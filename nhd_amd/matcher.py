@@ -84,6 +84,34 @@ def _tracked_class(base: type) -> type:
     return cls
 
 
+# What list(set(itertools.product(range(2), repeat=k))) gives under the CPython set / tuple-hash behaviour the device-side
+# model (nhd_amd/csrc/winner_map.h) reproduces (CPython 3.8 - 3.12, 64-bit).  FindNode's mapping is "bit-identical to the
+# reference" relative to the interpreter that would run the reference - i.e. this one: if it orders sets differently
+# (another Python implementation, a future change of tuple hashing) the model no longer speaks for it and HipMatcher
+# refuses to start instead of returning mappings the reference would not.
+_SET_ORDER_PROBES = {
+    1: [(0,), (1,)],
+    2: [(0, 1), (1, 0), (1, 1), (0, 0)],
+    3: [(1, 0, 1), (1, 1, 0), (0, 1, 0), (0, 0, 0), (1, 0, 0), (0, 0, 1), (1, 1, 1), (0, 1, 1)],
+    4: [(0, 0, 0, 1), (0, 0, 1, 0), (0, 1, 0, 1), (0, 1, 1, 1), (1, 0, 1, 1), (1, 1, 0, 0), (0, 1, 0, 0), (1, 1, 1, 0),
+        (0, 1, 1, 0), (0, 0, 0, 0), (1, 0, 1, 0), (1, 0, 0, 1), (1, 1, 0, 1), (1, 0, 0, 0), (0, 0, 1, 1), (1, 1, 1, 1)],
+}
+_SET_INTERSECTION_PROBE = [(1, 0, 1), (1, 1, 1), (0, 0, 0), (0, 1, 1)]
+
+
+def check_interpreter_set_model() -> None:
+    import itertools
+    for k, want in _SET_ORDER_PROBES.items():
+        if list(set(itertools.product(range(2), repeat=k))) != want:
+            raise RuntimeError("this Python interpreter iterates sets of int tuples in a different order than the set model of "
+                               "libnhdfit (CPython 3.8-3.12): FindNode's NUMA mapping would differ from the reference Matcher's")
+    a = set(itertools.product(range(2), repeat=3))
+    b = {t for t in a if sum(t) != 1}
+    c = {t for t in a if t[0] == 0 or t[2] == 1}
+    if list(a & b & c) != _SET_INTERSECTION_PROBE:
+        raise RuntimeError("this Python interpreter intersects sets in a different order than the set model of libnhdfit")
+
+
 class HipMatcher:
     def __init__(self, device: int = 0, clock=time.monotonic, engine_factory=None, devices: Optional[Sequence[int]] = None):
         """`devices=[0, 1, ...]`: shard the mirror over several GPUs of this process (engine.GroupEngine: node axis
@@ -93,6 +121,7 @@ class HipMatcher:
         kernels' arithmetic so the host logic of this class can be exercised without a GPU); the
         default is the HIP engine, which raises when the library or a gfx950 GPU is missing."""
         self.logger = logging.getLogger(__name__)
+        check_interpreter_set_model()
         if devices is not None:
             self.engine = GroupEngine(devices, engine_factory)
         else:
@@ -306,7 +335,7 @@ class HipMatcher:
         if pod_groups is not None:
             for i in np.flatnonzero(~skip):
                 reqs[i]["flags"] = pack.RF_INITIAL_FILTER
-                reqs[i]["groups"] = self.packer.group_bits(pod_groups[int(i)])
+                reqs[i]["groups"] = self.packer.group_bits_known(pod_groups[int(i)])
         for i in np.flatnonzero(~skip):
             if reqs[i]["n_groups"] == 0 and len(nl):
                 raise IndexError("pod without processing groups (the reference fails the same way, Matcher.py:346)")

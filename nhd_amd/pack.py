@@ -142,6 +142,17 @@ class Packer:
             bits |= 1 << k
         return bits
 
+    def group_bits_known(self, names: Iterable[str]) -> int:
+        """Bit set of the names the NODES of the cluster carry; a pod's group name no node has contributes no bit (it can
+        match nothing) and - unlike group_bits - is not interned: pod annotations are user input and must not be able
+        to use up the 64 ids."""
+        bits = 0
+        for nm in names:
+            k = self._group_index.get(nm)
+            if k is not None:
+                bits |= 1 << k
+        return bits
+
     def group_set_id(self, bits: int) -> int:
         k = self._group_set_index.get(bits)
         if k is None:
@@ -414,7 +425,7 @@ class Packer:
         r["misc_smt"] = half(n_misc) if top.misc_cores_smt else n_misc      # Enum truthiness, quirk Q1
         if pod_groups is not None:
             r["flags"] = RF_INITIAL_FILTER
-            r["groups"] = self.group_bits(pod_groups)
+            r["groups"] = self.group_bits_known(pod_groups)
         return r
 
     def digest_many(self, tops: Sequence[object], pod_groups: Optional[Sequence[Sequence[str]]] = None) -> np.ndarray:

@@ -219,3 +219,19 @@ def test_set_layout_state_machine_equals_the_model():
     for sg, nic in [(0xFF, 0xFF), (0x81, 0xFF), (0x7E, 0x7E), (0x18, 0xFF), (0xFF, 0x01)]:
         for sc in range(1, 65536, 7):
             check(sg, sc, nic)
+
+
+def test_matcher_start_up_probes_agree_with_interpreter_and_model():
+    """HipMatcher() checks at construction that the running interpreter orders sets the way the device model assumes
+    (nhd_amd.matcher.check_interpreter_set_model): the literals it compares with must be what this interpreter AND the
+    model produce."""
+    import itertools
+    from nhd_amd import matcher
+    matcher.check_interpreter_set_model()
+    L = harness.lib()
+    for k, want in matcher._SET_ORDER_PROBES.items():
+        codes = np.arange(1 << k, dtype=np.int16)                      # product order = ascending tuple code
+        out = np.zeros(1 << k, np.int16)
+        n = L.hh_set_list(codes.ctypes.data_as(ctypes.c_void_p), len(codes), k, 2, out.ctypes.data_as(ctypes.c_void_p))
+        got = [tuple((int(c) >> (k - 1 - i)) & 1 for i in range(k)) for c in out[:n]]
+        assert got == want == list(set(itertools.product(range(2), repeat=k)))
