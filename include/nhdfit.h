@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NHDFIT_ABI_VERSION        3
+#define NHDFIT_ABI_VERSION        4
 #define NHDFIT_MAX_GROUPS         4      /* proc groups per pod (G)                               */
 #define NHDFIT_MAX_NUMA           2      /* NUMA nodes (= sockets, nhd/Node.py:336) per node (U)  */
 #define NHDFIT_MAX_CORES_PER_NUMA 64     /* physical cores per socket (one uint64 mask)           */
@@ -229,13 +229,12 @@ int nhdfit_find_sequential(nhdfit_ctx* ctx, const nhdfit_req* reqs, uint32_t P, 
  *   apply      != 0: the commits stay in the device mirror (the scheduler's Node objects are updated by the caller
  *              with the reference's own mutators, nothing is re-packed or re-uploaded); 0: the mirror is restored
  *   place_out  optional, P records
- *   n_done     pods decided.  n_done < P only when a commit produced a NIC state the dictionary has no signature for
- *              (status NHDFIT_COMMIT_NEW_SIG on one or more pods of [first_pod, n_done)): intern it, patch those nodes
- *              (nhdfit_download_nodes / nhdfit_upload_nodes) and call again with first_pod = n_done; first_pod > 0
- *              continues the batch staged by the previous call and re-evaluates the `n_resume` (<= 8) patched nodes
- *              `resume_nodes` (local indices) against the remaining pods first. */
+ *   n_done     pods decided.  n_done < P only when a commit left a node in a NIC state the dictionary has no signature
+ *              id for (status NHDFIT_COMMIT_NEW_SIG on one or more pods of [0, n_done)): intern the state, patch those
+ *              nodes (nhdfit_download_nodes / nhdfit_set_dictionary / nhdfit_upload_nodes) and submit the remaining pods
+ *              as a new batch - with apply != 0 the mirror already holds the placements made so far.  With the
+ *              signature closure interned up front (nhd_amd.pack.Packer.close_signatures) this never happens. */
 int nhdfit_schedule_batch(nhdfit_ctx* ctx, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand, int apply,
-                          uint32_t first_pod, const int64_t* resume_nodes, uint32_t n_resume,
                           int64_t* node_out, nhdfit_mapping* map_out, nhdfit_placement* place_out, int32_t* status_out,
                           uint32_t* n_done);
 

@@ -38,8 +38,8 @@ _SIGS = {
     "nhdfit_set_node_count": (c_int, [c_void_p, c_uint32]),
     "nhdfit_find": (c_int, [c_void_p, c_void_p, c_uint32, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nhdfit_find_sequential": (c_int, [c_void_p, c_void_p, c_uint32, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "nhdfit_schedule_batch": (c_int, [c_void_p, c_void_p, c_uint32, c_double, c_void_p, c_int, c_uint32, c_void_p, c_uint32,
-                                      c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_uint32)]),
+    "nhdfit_schedule_batch": (c_int, [c_void_p, c_void_p, c_uint32, c_double, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      POINTER(c_uint32)]),
     "nhdfit_commit": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_double, c_void_p]),
     "nhdfit_download_nodes": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nhdfit_stage_requests": (c_int, [c_void_p, c_void_p, c_uint32]),

@@ -947,20 +947,21 @@ struct UndoRec { uint32_t node, pad[3]; NodeState st; nhdfit_detail d; };
 struct SeqArgs {
     nhdfit_plane0* p0; nhdfit_plane1* p1; nhdfit_plane2* p2; nhdfit_plane3* p3; nhdfit_plane4* p4; nhdfit_detail* det;   // the mirror (modified)
     uint32_t n, chunks; uint64_t global_base; double now;
-    const nhdfit_req* reqs; const PodHeader* hdr; const unsigned long long* score; uint32_t P;
+    const nhdfit_req* reqs; const unsigned long long* score; uint32_t P;
     const uint32_t* order;           // caller's pod i -> staged (class-sorted) position
     const uint8_t* tabs; uint32_t pitch; const uint8_t* tile_wcls; Layout L[kWClasses];
-    uint64_t* rows;                  // [chunks][P] verdict rows of the snapshot, kept current
-    uint64_t* nm;                    // [tiles][chunks*64] the same matrix node-major, kept current
+    uint64_t* rows;                  // [chunks][P] verdict rows of the snapshot; kept current for the pods without GPUs
+    uint64_t* nm;                    // [tiles][chunks*64] the same matrix node-major, kept current likewise
+    uint64_t* taken;                 // [chunks] nodes that received a pod of this batch: busy, i.e. gone for every pod with GPUs
     const uint64_t* nogpu;           // [chunks] nodes without a GPU installed
-    const uint64_t* tile_masks;      // [tiles][2]
+    const uint64_t* tile_masks;      // [tiles][2]: pods that request GPUs / are in PCI mode
     const double* caps; SigTable sigs; uint32_t fc_dim, fg_dim, ngs;
     MapTables mt;
     UndoRec* undo; int32_t* touched; uint32_t* counters;     // first-touch copies (apply = 0), [n] -1 / slot, [0] = undo records
     SeqResult* out; nhdfit_placement* place;                  // [P], caller's order
-    uint32_t first_pod; int64_t resume_nodes[8]; uint32_t* n_done;     // resume_nodes: -1 terminated
+    uint32_t* n_done; uint16_t* gl_tiles;          // scratch: [tiles] the tiles that hold pods without GPUs
     uint32_t lds_tables;
-    unsigned long long* prof;        // tuning aid (NHDFIT_SEQ_PROF): ticks (100 MHz) per phase, rounds, pods kept
+    unsigned long long* prof;        // tuning aid (NHDFIT_SEQ_PROF): ticks (100 MHz) per phase, rounds, pods
     uint32_t keep_undo;
 };
 
@@ -1088,32 +1089,46 @@ __device__ __forceinline__ bool map_on_state_wave(const nhdfit_req& r, const Nod
     return true;
 }
 
-// One block walks the batch in the caller's order, kSeqPods pods per round (one per wavefront):
-//   (1) every wavefront finds its pod's node in the pod's row (all rows are current at this point);
-//   (2) the round keeps the longest prefix of pods whose nodes are pairwise different.  A commit only clears bits of
-//       ITS node's column, and a pod's node is the first set bit of its row: committing another node first cannot
-//       change that choice - so the pods of the prefix are independent and exactly what the one-by-one loop decides;
-//   (3) one lane per kept pod maps it against the node's current state and commits (commit_core.h);
-//   (4) all threads re-evaluate the committed nodes' columns against every tile (cold rows) and patch the rows.
-// The next round starts at the first pod that was not kept.
-constexpr int kSeqPods = 8;
-constexpr int kSeqThreads = 64 * kSeqPods;
-__global__ __launch_bounds__(kSeqThreads) void k_seq(SeqArgs a) {
+// One block walks the batch in the caller's order, kSeqPods pods per round (one per wavefront).
+// What a commit changes for the pods that follow (nhd/NHDScheduler.py:289-304):
+//   * SetBusy: the node is busy until now + 30 s, and a busy node is dropped for every pod that requests GPUs
+//     (nhd/Matcher.py:107-111, nhd/Node.py:843-850) - for those pods the kernel keeps ONE bit per node ("taken") next
+//     to the snapshot's verdict rows;
+//   * for the pods without GPUs the node stays a candidate as far as its resources go: the committed nodes' columns
+//     are re-evaluated against the tiles that hold such pods (cold rows) and their rows patched.
+// Per round:
+//   (1) every wavefront scans its pod's row (minus the taken nodes if the pod wants GPUs) up to the first window of 64
+//       chunks with a candidate and parks the window's 64 words in LDS;
+//   (2) wavefront 0 walks the round's pods in order.  A pod with GPUs gets the first bit of its window that no earlier
+//       pod of the round took (those nodes are busy by the time it is the pod's turn, nothing else changed for it).  A
+//       pod without GPUs gets the first bit of its window; if an earlier pod of the round took that very node, what
+//       is left of the node decides - the round ends before this pod.  So does a pod whose window ran dry;
+//   (3) one wavefront per kept pod: node record -> LDS, mapping against the node's state at this turn, commit
+//       (commit_core.h), record and placement written back;
+//   (4) all threads: columns of the committed nodes for the tiles with GPU-less pods.
+template <int kSeqPods>
+__global__ __launch_bounds__(64 * kSeqPods) void k_seq(SeqArgs a) {
+    constexpr int kSeqThreads = 64 * kSeqPods;
     __shared__ PaddedReq s_req[kSeqPods];
     __shared__ nhdfit_detail s_det[kSeqPods];
     __shared__ NodeState s_st[kSeqPods];
+    __shared__ uint64_t s_win[kSeqPods][64];
+    __shared__ uint32_t s_base[kSeqPods];
+    __shared__ int32_t s_have[kSeqPods];             // -2: past the end of the batch, 0: no candidate, 1: window parked, +2: pod wants GPUs
     __shared__ int64_t s_node[kSeqPods];
     __shared__ uint32_t s_pos[kSeqPods];
     __shared__ int32_t s_status[kSeqPods];
     __shared__ nhdfit_placement s_place[kSeqPods];
     __shared__ SeqResult s_res[kSeqPods];
+    __shared__ uint32_t s_keep;
     __shared__ int32_t s_stop;
+    __shared__ uint32_t s_ngl;                       // tiles that hold pods without GPUs
     __shared__ uint64_t s_changed[kSeqThreads];
     __shared__ double s_caps[NHDFIT_MAX_CLASSES];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tiles = (a.P + kTile - 1) / kTile;
     const size_t npad = (size_t)a.chunks * 64;
-    if (tid == 0) s_stop = 0;
+    if (tid == 0) { s_stop = 0; s_ngl = 0; }
     if (tid < NHDFIT_MAX_CLASSES) s_caps[tid] = a.caps[tid];
     // small per-batch look-up data the chain would otherwise fetch from L2 pod after pod: staged in LDS once
     // (a.lds_tables = 0: the batch is too large, they stay in global memory)
@@ -1121,7 +1136,14 @@ __global__ __launch_bounds__(kSeqThreads) void k_seq(SeqArgs a) {
     const uint32_t* order = a.order;
     const uint64_t* tile_masks = a.tile_masks;
     const uint8_t* tile_wcls = a.tile_wcls;
+    const uint16_t* gl_tiles = a.gl_tiles;
     SigTable sigs = a.sigs;
+    __syncthreads();
+    for (uint32_t t = tid; t < tiles; t += kSeqThreads) {         // order of the list does not matter
+        const uint32_t live = a.P - t * kTile < (uint32_t)kTile ? a.P - t * kTile : (uint32_t)kTile;
+        const uint64_t lm = live == 64 ? ~0ull : (1ull << live) - 1;
+        if (~a.tile_masks[2 * t] & lm) a.gl_tiles[atomicAdd(&s_ngl, 1u)] = (uint16_t)t;
+    }
     if (a.lds_tables) {
         uint8_t* q = s_dyn;
         uint64_t* l_masks = carve<uint64_t>(q, (size_t)tiles * 2);
@@ -1136,6 +1158,9 @@ __global__ __launch_bounds__(kSeqThreads) void k_seq(SeqArgs a) {
         order = l_order; tile_masks = l_masks; tile_wcls = l_wcls;
         sigs = SigTable{l_skey, l_sid, a.sigs.mask};
     }
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t ngl = s_ngl;
 
     auto load_node = [&](uint32_t slot, uint32_t v) {             // planes + detail of node v -> LDS slot (one wavefront)
         uint32_t* st = reinterpret_cast<uint32_t*>(&s_st[slot]);
@@ -1166,34 +1191,33 @@ __global__ __launch_bounds__(kSeqThreads) void k_seq(SeqArgs a) {
             reinterpret_cast<uint4*>(a.det + v)[lane - 8] = make_uint4(dd[0], dd[1], dd[2], dd[3]);
         }
     };
-    // columns of the nodes in slots [0, cnt) flagged in `mask` against every tile (cold rows); rows patched where a
-    // pod lost a node.  All threads; ends with a barrier.
+    // columns of the nodes in slots [0, cnt) flagged in `mask` against the tiles with GPU-less pods (cold rows); the
+    // rows of those pods patched where one lost a node.  All threads; ends with a barrier.
     auto refresh_columns = [&](uint32_t cnt, uint32_t mask) {
-        for (uint32_t k0 = 0; k0 < cnt * tiles; k0 += kSeqThreads) {
+        for (uint32_t k0 = 0; k0 < cnt * ngl; k0 += kSeqThreads) {
             const uint32_t k = k0 + tid;
             uint64_t changed = 0;
-            uint32_t slot = 0, t = 0;
-            if (k < cnt * tiles) {
-                slot = k / tiles; t = k % tiles;
+            if (k < cnt * ngl) {
+                const uint32_t slot = k / ngl, t = gl_tiles[k % ngl];
                 if (mask >> slot & 1) {
                     const uint32_t v = (uint32_t)s_node[slot];
                     const NodeState& st = s_st[slot];
                     const NodeIdx ni = node_index(st.p0, st.p1, st.p2, st.p4, a.fc_dim, a.fg_dim, a.ngs);
                     const bool busy = (a.now - st.p4.busy_time) < kMinBusySecs;
+                    const uint64_t need = tile_masks[2 * t];
                     const uint64_t old = a.nm[(size_t)t * npad + v];
-                    const uint64_t word = node_word_cold(a.tabs + (size_t)t * a.pitch, a.L[tile_wcls[t]], ni, st.p3, busy,
-                                                         tile_masks[2 * t], tile_masks[2 * t + 1]);
-                    changed = old & ~word;
-                    if (changed) a.nm[(size_t)t * npad + v] = old & word;
+                    const uint64_t word = node_word_cold(a.tabs + (size_t)t * a.pitch, a.L[tile_wcls[t]], ni, st.p3, busy, need, tile_masks[2 * t + 1]);
+                    changed = old & ~word & ~need;               // pods with GPUs go by the taken bits
+                    if (changed) a.nm[(size_t)t * npad + v] = old & ~changed;
                 }
             }
             s_changed[tid] = changed;
             __syncthreads();
-            const uint32_t span = cnt * tiles - k0 < (uint32_t)kSeqThreads ? cnt * tiles - k0 : kSeqThreads;
+            const uint32_t span = cnt * ngl - k0 < (uint32_t)kSeqThreads ? cnt * ngl - k0 : kSeqThreads;
             for (uint32_t q = tid; q < span * 64; q += kSeqThreads) {
                 const uint32_t e = q >> 6, j = q & 63;
                 if (s_changed[e] >> j & 1) {
-                    const uint32_t kk = k0 + e, sl = kk / tiles, tt = kk % tiles, v = (uint32_t)s_node[sl];
+                    const uint32_t kk = k0 + e, sl = kk / ngl, tt = gl_tiles[kk % ngl], v = (uint32_t)s_node[sl];
                     // two nodes of one 64-node chunk may lose the same pod in the same round: atomic
                     atomicAnd(reinterpret_cast<unsigned long long*>(&a.rows[(size_t)(v >> 6) * a.P + (size_t)tt * 64 + j]), ~(1ull << (v & 63)));
                 }
@@ -1201,18 +1225,9 @@ __global__ __launch_bounds__(kSeqThreads) void k_seq(SeqArgs a) {
             __syncthreads();
         }
     };
-    __syncthreads();
-    {   // nodes the host patched after a NEW_SIG stop: their columns are refreshed before the batch continues
-        uint32_t cnt = 0;
-        for (; cnt < (uint32_t)kSeqPods && a.resume_nodes[cnt] >= 0; ++cnt) {
-            if (wave == cnt) { load_node(cnt, (uint32_t)a.resume_nodes[cnt]); if (lane == 0) s_node[cnt] = a.resume_nodes[cnt]; }
-        }
-        __syncthreads();
-        if (cnt) refresh_columns(cnt, (1u << cnt) - 1u);
-    }
 
-    uint32_t i = a.first_pod;
-    unsigned long long t_find = 0, t_map = 0, t_col = 0, n_rounds = 0, tick = a.prof ? wall_clock64() : 0;
+    uint32_t i = 0;
+    unsigned long long t_find = 0, t_pick = 0, t_map = 0, t_col = 0, n_rounds = 0, tick = a.prof ? wall_clock64() : 0;
     unsigned long long t_sub[5] = {0, 0, 0, 0, 0}, sub = 0;
     auto sublap = [&](int k) { if (a.prof && wave == 0) { const unsigned long long t = wall_clock64(); t_sub[k] += t - sub; sub = t; } };
     auto lap = [&](unsigned long long& acc) { if (a.prof) { const unsigned long long t = wall_clock64(); acc += t - tick; tick = t; } };
@@ -1220,53 +1235,89 @@ __global__ __launch_bounds__(kSeqThreads) void k_seq(SeqArgs a) {
         if (s_stop) break;
         // (1) wavefront w: pod i + w
         const uint32_t mine = i + wave;
-        int64_t nd = -1;
+        int32_t have = -2;
         if (mine < a.P) {
+            have = 0;
             const uint32_t pos = order[mine];
             if (lane < sizeof(nhdfit_req) / 16) {
                 const uint4 v = reinterpret_cast<const uint4*>(a.reqs + pos)[lane];
                 uint32_t* dst = reinterpret_cast<uint32_t*>(&s_req[wave]) + lane * 4;
                 dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
             }
+            const bool wants_gpu = (tile_masks[2 * (pos >> 6)] >> (pos & 63) & 1) != 0;
             const unsigned long long score_a = a.score[pos];
-            if (score_a) {      // first feasible node of the pod's row, GPU-less nodes first for a GPU-less pod
+            if (score_a) {      // first window with a candidate, GPU-less nodes first for a GPU-less pod
                 const int64_t winner_a = (int64_t)(NHDFIT_SCORE_INDEX(score_a) - a.global_base);
-                for (int pass = (score_a >> 63) ? 0 : 1; pass < 2 && nd < 0; ++pass) {
+                for (int pass = (score_a >> 63) ? 0 : 1; pass < 2 && !have; ++pass) {
                     const bool pref = pass == 0;
                     const int64_t from = pref ? winner_a : ((score_a >> 63) ? 0 : winner_a);
-                    for (uint32_t base = (uint32_t)(from >> 6); base < a.chunks && nd < 0; base += 64) {
+                    for (uint32_t base = (uint32_t)(from >> 6); base < a.chunks && !have; base += 64) {
                         const uint32_t c = base + lane;
-                        uint64_t w = c < a.chunks ? a.rows[(size_t)c * a.P + pos] : 0;
-                        if (pref && c < a.chunks) w &= a.nogpu[c];
+                        uint64_t w = 0;
+                        if (c < a.chunks) {
+                            // rows / taken: patched with atomics by the other wavefronts, read past the CU's vector cache
+                            w = __hip_atomic_load(&a.rows[(size_t)c * a.P + pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (wants_gpu) w &= ~__hip_atomic_load(&a.taken[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (pref) w &= a.nogpu[c];
+                        }
                         if (c == (uint32_t)(from >> 6)) w &= ~0ull << (from & 63);
-                        const uint64_t any = __ballot(w != 0);
-                        if (any) {
-                            const int l = __builtin_ctzll(any);
-                            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, l);
-                            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
-                            nd = (int64_t)(base + l) * 64 + __builtin_ctzll(((uint64_t)hi << 32) | lo);
+                        if (__ballot(w != 0)) {
+                            s_win[wave][lane] = w;
+                            if (lane == 0) s_base[wave] = base;
+                            have = 1;
                         }
                     }
                 }
             }
-            if (lane == 0) { s_node[wave] = nd; s_pos[wave] = pos; s_status[wave] = 0; }
-        } else if (lane == 0) { s_node[wave] = -2; s_status[wave] = 0; }          // past the end of the batch
+            if (wants_gpu) have += 2;
+            if (lane == 0) s_pos[wave] = pos;
+        }
+        if (lane == 0) { s_have[wave] = have; s_status[wave] = 0; }
         __syncthreads();
         lap(t_find);
-        // (2) longest prefix of pods with pairwise different nodes
-        uint32_t keep = 0;
-        for (; keep < (uint32_t)kSeqPods && s_node[keep] != -2; ++keep) {
-            bool clash = false;
-            for (uint32_t e = 0; e < keep; ++e) clash = clash || (s_node[keep] >= 0 && s_node[e] == s_node[keep]);
-            if (clash) break;
+        // (2) the round's pods in order
+        if (wave == 0) {
+            uint32_t chosen = 0xFFFFFFFFu;                        // lane e: node of the round's pod e
+            uint32_t keep = 0;
+            for (; keep < (uint32_t)kSeqPods; ++keep) {
+                const int32_t hv = s_have[keep];
+                if (hv == -2) break;
+                int64_t nd = -1;
+                if (hv & 1) {
+                    const bool wants_gpu = (hv & 2) != 0;
+                    uint64_t w = s_win[keep][lane];
+                    const uint32_t base = s_base[keep], c = base + lane;
+                    if (wants_gpu)
+                        for (uint32_t e = 0; e < keep; ++e) {
+                            const uint32_t ch = (uint32_t)__builtin_amdgcn_readlane((int)chosen, (int)e);
+                            if (ch != 0xFFFFFFFFu && (ch >> 6) == c) w &= ~(1ull << (ch & 63));
+                        }
+                    const uint64_t any = __ballot(w != 0);
+                    if (!any) break;                              // window ran dry (never pod 0: nothing is excluded for it)
+                    const int l = __builtin_ctzll(any);
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, l);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
+                    nd = (int64_t)(base + l) * 64 + __builtin_ctzll(((uint64_t)hi << 32) | lo);
+                    if (!wants_gpu && __ballot(lane < keep && chosen == (uint32_t)nd)) break;   // the node's state after that commit decides
+                    if (lane == keep) chosen = (uint32_t)nd;
+                }
+                if (lane == 0) s_node[keep] = nd;
+            }
+            if (lane == 0) s_keep = keep;
         }
+        __syncthreads();
+        lap(t_pick);
+        const uint32_t keep = s_keep;
         // (3) map + commit: one wavefront per kept pod
         if (wave < keep) {
+            const int64_t nd = s_node[wave];
             if (nd < 0) {
                 if (lane == 0) { SeqResult r; r.node = -1; r.map = nhdfit_mapping{}; r.status = 0; a.out[mine] = r; }
             } else {
                 const uint32_t v = (uint32_t)nd;
                 if (a.prof && wave == 0) sub = wall_clock64();
+                unsigned long long was = 0;
+                if (lane == 0) was = atomicOr(reinterpret_cast<unsigned long long*>(&a.taken[v >> 6]), 1ull << (v & 63));
                 const int32_t seen = lane == 0 ? a.touched[v] : 0;       // requested together with the node record
                 load_node(wave, v);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1322,23 +1373,27 @@ __global__ __launch_bounds__(kSeqThreads) void k_seq(SeqArgs a) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 store_node(wave, v);
+                asm volatile("" :: "v"(was));                            // the taken bit has reached L2 before the round ends
                 sublap(4);
             }
         }
         __syncthreads();
         lap(t_map);
-        // (4) columns of the committed nodes (not of those the host has to patch first)
-        uint32_t mask = 0;
-        for (uint32_t e = 0; e < keep; ++e)
-            if (s_node[e] >= 0 && s_status[e] != kCommitNewSig) mask |= 1u << e;
-        if (mask) refresh_columns(keep, mask);
+        // (4) columns of the committed nodes, for the pods without GPUs (not after a stop: the host patches those nodes
+        // and starts over with the pods that are left)
+        if (ngl && !s_stop) {
+            uint32_t mask = 0;
+            for (uint32_t e = 0; e < keep; ++e)
+                if (s_node[e] >= 0) mask |= 1u << e;
+            if (mask) refresh_columns(keep, mask);
+        }
         lap(t_col);
         ++n_rounds;
         i += keep;
     }
     if (tid == 0) *a.n_done = i;
-    if (tid == 0 && a.prof) { a.prof[0] = t_find; a.prof[1] = t_map; a.prof[2] = t_col; a.prof[3] = n_rounds; a.prof[4] = i - a.first_pod;
-                              for (int k = 0; k < 5; ++k) a.prof[5 + k] = t_sub[k]; }
+    if (tid == 0 && a.prof) { a.prof[0] = t_find; a.prof[1] = t_map; a.prof[2] = t_pick; a.prof[3] = n_rounds; a.prof[4] = i;
+                              for (int k = 0; k < 5; ++k) a.prof[5 + k] = t_sub[k]; a.prof[10] = t_col; }
 }
 
 // apply = 0: put the touched nodes back
@@ -1446,6 +1501,7 @@ struct nhdfit_ctx {
     bool geom_big = true;                // 512-thread step blocks (256 for small problems)
     uint32_t digest_parts = getenv("NHDFIT_DIGEST_PARTS") ? (uint32_t)atoi(getenv("NHDFIT_DIGEST_PARTS")) : 2;   // tuning aid
     uint32_t side_prio = getenv("NHDFIT_SIDE_PRIO") ? (uint32_t)atoi(getenv("NHDFIT_SIDE_PRIO")) : 1;   // tuning aid
+    int seq_pods = getenv("NHDFIT_SEQ_PODS") && atoi(getenv("NHDFIT_SEQ_PODS")) == 8 ? 8 : 16;   // tuning aid: pods per round of the sequential kernel
     uint32_t choose_split = getenv("NHDFIT_CHOOSE_SPLIT") ? (uint32_t)atoi(getenv("NHDFIT_CHOOSE_SPLIT")) : 16;   // tuning aid: wavefronts per tile
     bool split = getenv("NHDFIT_SPLIT") != nullptr;
     bool role_kernels = getenv("NHDFIT_ROLE_KERNELS") != nullptr;   // profiling aid: every role as a kernel of its own (512-thread geometry only)
@@ -1501,7 +1557,7 @@ struct nhdfit_ctx {
     DevBuf<uint64_t> st_info; DevBuf<uint32_t> st_next, st_asc; uint32_t st_n = 0;
     bool use_set_states = getenv("NHDFIT_NO_SET_STATES") == nullptr;
     // mode B
-    DevBuf<uint64_t> nogpu, tile_masks; DevBuf<int32_t> touched; DevBuf<UndoRec> undo; DevBuf<SeqResult> seq_out; DevBuf<nhdfit_placement> seq_place;
+    DevBuf<uint64_t> nogpu, taken, tile_masks; DevBuf<int32_t> touched; DevBuf<uint16_t> gl_tiles; std::vector<uint32_t> order_host; std::vector<SeqResult> seq_host; DevBuf<UndoRec> undo; DevBuf<SeqResult> seq_out; DevBuf<nhdfit_placement> seq_place;
     DevBuf<uint32_t> order, seq_counters;
     DevBuf<uint64_t> sig_keys; DevBuf<uint32_t> sig_ids; uint32_t sig_mask = 0;   // canonical NIC-state key -> signature id (commit_core.h)
     bool use_cand = false, want_bitmap = true, want_map = true;
@@ -1656,7 +1712,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
     c->reqs.release(); c->bitmap.release(); c->nm.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); c->shape_list[b].release(); }
-    c->nogpu.release(); c->tile_masks.release(); c->touched.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_counters.release(); c->sig_keys.release(); c->sig_ids.release();
+    c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->sig_keys.release(); c->sig_ids.release();
     for (int b = 0; b < kBufs; ++b) {
         c->hdr[b].release(); c->tabs[b].release(); c->score[b].release(); c->maps[b].release();
         if (c->ev_fit[b]) (void)hipEventDestroy(c->ev_fit[b]);
@@ -2089,7 +2145,7 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         c->ev_kind[c->ev_pending++] = with_fit ? 0 : 1;
     }
     if (a.role_clock) {
-        unsigned long long t[10];
+        unsigned long long t[12];
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
         unsigned long long first = ~0ull;
@@ -2231,19 +2287,17 @@ SigTable sig_table(nhdfit_ctx* c) { return SigTable{c->sig_keys.p, c->sig_ids.p,
 }  // namespace
 
 int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand, int apply,
-                          uint32_t first_pod, const int64_t* resume_nodes, uint32_t n_resume,
                           int64_t* node_out, nhdfit_mapping* map_out, nhdfit_placement* place_out, int32_t* status_out,
                           uint32_t* n_done) {
     if (!c) return NHDFIT_E_INVAL;
     if (c->comm) return fail(c, NHDFIT_E_STATE, "sequential (mode B) batches are single-shard: detach the communicator");
     if (!node_out || !n_done) return fail(c, NHDFIT_E_INVAL, "node_out / n_done is NULL");
-    if (first_pod > P) return fail(c, NHDFIT_E_INVAL, "first_pod %u beyond the batch (%u pods)", first_pod, P);
-    if (first_pod && !apply) return fail(c, NHDFIT_E_INVAL, "a batch can only be continued with apply != 0");
+    if (!std::isfinite(now)) return fail(c, NHDFIT_E_INVAL, "now must be finite (a placed node is busy at `now`)");
     HIPCHK(c, hipSetDevice(c->dev));
     hipStream_t sm = c->stream;
     const uint32_t chunks = (c->n + 63) / 64;
     int rc;
-    if (first_pod == 0) {
+    {
         // snapshot pass: digest + fit (verdict matrix and first-fit scores; the mapping roles are not needed - every
         // placement of the batch is mapped against the node's state at ITS turn)
         const bool wb = c->want_bitmap, wm = c->want_map;
@@ -2256,78 +2310,77 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         if ((rc = convert_rows(c))) return rc;
         const uint32_t tiles = (P + kTile - 1) / kTile;
         HIPCHK(c, c->nogpu.reserve(chunks ? chunks : 1));
+        HIPCHK(c, c->taken.reserve(chunks ? chunks : 1));
         HIPCHK(c, c->tile_masks.reserve((size_t)tiles * 2));
+        HIPCHK(c, c->gl_tiles.reserve(tiles));
         HIPCHK(c, c->touched.reserve(c->n ? c->n : 1));
+        HIPCHK(c, c->seq_counters.reserve(4));
         HIPCHK(c, c->undo.reserve(apply ? 1 : P));
         HIPCHK(c, c->seq_out.reserve(P));
         HIPCHK(c, c->seq_place.reserve(P));
         HIPCHK(c, c->order.reserve(P));
-        HIPCHK(c, c->seq_counters.reserve(4));
-        std::vector<uint32_t> order(P);                       // caller's pod -> staged (class-sorted) position
-        for (uint32_t i = 0; i < P; ++i) order[c->perm[i]] = i;
-        HIPCHK(c, hipMemcpyAsync(c->order.p, order.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
-        HIPCHK(c, hipStreamSynchronize(sm));                  // `order` is a local
+        c->order_host.resize(P);                              // caller's pod -> staged (class-sorted) position
+        for (uint32_t i = 0; i < P; ++i) c->order_host[c->perm[i]] = i;
+        HIPCHK(c, hipMemcpyAsync(c->order.p, c->order_host.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
+        HIPCHK(c, hipMemsetAsync(c->taken.p, 0, (size_t)(chunks ? chunks : 1) * sizeof(uint64_t), sm));
         HIPCHK(c, hipMemsetAsync(c->touched.p, 0xFF, (size_t)c->n * sizeof(int32_t), sm));
         HIPCHK(c, hipMemsetAsync(c->seq_counters.p, 0, 4 * sizeof(uint32_t), sm));
         hipLaunchKernelGGL(k_nogpu, dim3(chunks), dim3(64), 0, sm, c->p2.p, c->n, c->nogpu.p);
         const int b0 = (int)((c->n_fit - 1) % kBufs);
         hipLaunchKernelGGL(k_tile_masks, dim3(tiles), dim3(64), 0, sm, c->hdr[b0].p, tiles, c->tile_masks.p);
         HIPCHK(c, hipGetLastError());
-    } else if (!c->P || P != c->P || !c->n_fit) {
-        return fail(c, NHDFIT_E_STATE, "no batch of %u pods to continue", P);
     }
     const int b = (int)((c->n_fit - 1) % kBufs);
     SeqArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.p0 = c->p0.p; sa.p1 = c->p1.p; sa.p2 = c->p2.p; sa.p3 = c->p3.p; sa.p4 = c->p4.p; sa.det = c->det.p;
     sa.n = c->n; sa.chunks = chunks; sa.global_base = c->global_base; sa.now = now;
-    sa.reqs = c->reqs.p; sa.hdr = c->hdr[b].p; sa.score = c->score[b].p; sa.P = P; sa.order = c->order.p;
+    sa.reqs = c->reqs.p; sa.score = c->score[b].p; sa.P = P; sa.order = c->order.p;
     sa.tabs = c->tabs[b].p; sa.pitch = c->pitch; sa.tile_wcls = c->tile_wcls.p;
     for (int w = 0; w < kWClasses; ++w) sa.L[w] = c->L[w];
-    sa.rows = c->bitmap.p; sa.nm = c->nm.p; sa.nogpu = c->nogpu.p; sa.tile_masks = c->tile_masks.p;
+    sa.rows = c->bitmap.p; sa.nm = c->nm.p; sa.taken = c->taken.p; sa.nogpu = c->nogpu.p; sa.tile_masks = c->tile_masks.p;
     sa.caps = c->caps.p; sa.sigs = sig_table(c); sa.fc_dim = c->max_cores + 1; sa.fg_dim = c->max_gpus + 1; sa.ngs = c->ngs;
     sa.mt = map_tables(c);
     sa.undo = c->undo.p; sa.touched = c->touched.p; sa.counters = c->seq_counters.p; sa.keep_undo = apply ? 0 : 1;
-    sa.out = c->seq_out.p; sa.place = c->seq_place.p;
-    if (n_resume > 8 || (n_resume && !resume_nodes)) return fail(c, NHDFIT_E_INVAL, "at most 8 resume nodes");
-    for (uint32_t k = 0; k < 8; ++k) sa.resume_nodes[k] = k < n_resume ? resume_nodes[k] : -1;
-    sa.first_pod = first_pod; sa.n_done = c->seq_counters.p + 1;
+    sa.out = c->seq_out.p; sa.place = c->seq_place.p; sa.n_done = c->seq_counters.p + 1; sa.gl_tiles = c->gl_tiles.p;
     const uint32_t tiles_b = (P + kTile - 1) / kTile;
-    size_t seq_lds = lds_slice((size_t)tiles_b * 16) + lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4) +
-                     lds_slice((size_t)P * 4) + lds_slice(tiles_b);
+    size_t seq_lds = lds_slice((size_t)tiles_b * 16) + lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4) + lds_slice((size_t)P * 4) + lds_slice(tiles_b);
     sa.lds_tables = seq_lds <= 96 * 1024;
     if (!sa.lds_tables) seq_lds = 0;
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_seq, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    const int seq_pods = c->seq_pods;
+    HIPCHK(c, hipFuncSetAttribute(seq_pods == 16 ? (const void*)k_seq<16> : (const void*)k_seq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     const bool seq_prof = getenv("NHDFIT_SEQ_PROF") != nullptr;
-    if (seq_prof) { HIPCHK(c, c->role_clock.reserve(10)); sa.prof = c->role_clock.p; }
-    hipLaunchKernelGGL(k_seq, dim3(1), dim3(kSeqThreads), seq_lds, sm, sa);
+    if (seq_prof) { HIPCHK(c, c->role_clock.reserve(12)); sa.prof = c->role_clock.p; }
+    if (seq_pods == 16) hipLaunchKernelGGL(k_seq<16>, dim3(1), dim3(1024), seq_lds, sm, sa);
+    else hipLaunchKernelGGL(k_seq<8>, dim3(1), dim3(512), seq_lds, sm, sa);
     if (seq_prof) {
-        unsigned long long t[10];
+        unsigned long long t[12];
         HIPCHK(c, hipStreamSynchronize(sm));
         HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
+        const double per = 0.01 / (double)(t[3] ? t[3] : 1);
         fprintf(stderr, "[nhdfit] k_seq wave 0 per round: node load %.1f, NIC bits %.1f, mapping %.1f, commit %.1f, write-back %.1f us\n",
-                t[5] * 0.01 / (double)(t[3] ? t[3] : 1), t[6] * 0.01 / (double)(t[3] ? t[3] : 1), t[7] * 0.01 / (double)(t[3] ? t[3] : 1),
-                t[8] * 0.01 / (double)(t[3] ? t[3] : 1), t[9] * 0.01 / (double)(t[3] ? t[3] : 1));
-        fprintf(stderr, "[nhdfit] k_seq: %llu pods in %llu rounds; find %.1f us, map+commit %.1f us, columns %.1f us per round\n", t[4], t[3],
-                t[0] * 0.01 / (double)(t[3] ? t[3] : 1), t[1] * 0.01 / (double)(t[3] ? t[3] : 1), t[2] * 0.01 / (double)(t[3] ? t[3] : 1));
+                t[5] * per, t[6] * per, t[7] * per, t[8] * per, t[9] * per);
+        fprintf(stderr, "[nhdfit] k_seq: %llu pods in %llu rounds; scan %.1f us, pick %.1f us, map+commit %.1f us, columns %.1f us per round\n", t[4], t[3],
+                t[0] * per, t[2] * per, t[1] * per, t[10] * per);
     }
     if (!apply) hipLaunchKernelGGL(k_undo, dim3(P), dim3(64), 0, sm, sa);
     HIPCHK(c, hipGetLastError());
-    std::vector<SeqResult> out(P);
+    c->seq_host.resize(P);
     uint32_t counters[4] = {0, 0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(out.data(), c->seq_out.p, P * sizeof(SeqResult), hipMemcpyDeviceToHost, sm));
+    HIPCHK(c, hipMemcpyAsync(c->seq_host.data(), c->seq_out.p, P * sizeof(SeqResult), hipMemcpyDeviceToHost, sm));
     HIPCHK(c, hipMemcpyAsync(counters, c->seq_counters.p, sizeof counters, hipMemcpyDeviceToHost, sm));
     if (place_out) HIPCHK(c, hipMemcpyAsync(place_out, c->seq_place.p, (size_t)P * sizeof(nhdfit_placement), hipMemcpyDeviceToHost, sm));
     rc = nhdfit_sync(c);
     if (rc) return rc;
     *n_done = counters[1];
     int64_t lo = -1, hi = -1;
-    for (uint32_t i = first_pod; i < counters[1]; ++i) {
-        node_out[i] = out[i].node;
-        if (map_out) map_out[i] = out[i].map;
-        if (status_out) status_out[i] = out[i].status;
-        if (out[i].node >= 0) {
-            const int64_t v = out[i].node - (int64_t)c->global_base;
+    for (uint32_t i = 0; i < counters[1]; ++i) {
+        const SeqResult& o = c->seq_host[i];
+        node_out[i] = o.node;
+        if (map_out) map_out[i] = o.map;
+        if (status_out) status_out[i] = o.status;
+        if (o.node >= 0) {
+            const int64_t v = o.node - (int64_t)c->global_base;
             lo = lo < 0 || v < lo ? v : lo;
             hi = v + 1 > hi ? v + 1 : hi;
         }
@@ -2341,10 +2394,9 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
 
 int nhdfit_find_sequential(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand,
                            int64_t* node_out, nhdfit_mapping* map_out, int32_t* status_out) {
-    // the mirror is left as it was; a NIC state without a signature cannot stop the batch here (nothing could be
-    // patched): the remaining pods simply see that node with the empty signature, which the caller is told about
+    // the mirror is left as it was (k_undo): a NIC state without a signature cannot be patched in, the batch fails
     uint32_t done = 0;
-    int rc = nhdfit_schedule_batch(c, reqs, P, now, cand, 0, 0, nullptr, 0, node_out, map_out, nullptr, status_out, &done);
+    int rc = nhdfit_schedule_batch(c, reqs, P, now, cand, 0, node_out, map_out, nullptr, status_out, &done);
     if (rc) return rc;
     if (done < P) return fail(c, NHDFIT_E_STATE, "pod %u left its node in a NIC state the dictionary has no signature for: "
                               "use nhdfit_schedule_batch (apply) and intern it", done - 1);

@@ -101,7 +101,8 @@ class Engine:
         """Mode B with the commit step on the device (nhdfit_schedule_batch): (node index or -1, mappings, placements,
         status) per pod.  apply=True leaves the commits in the device mirror.  A commit that puts a node into a NIC
         state the dictionary has no signature for stops the device pass; the state is interned here (`packer`), the
-        node's plane 3 patched, and the batch continues - with Packer.close_signatures() up front this never happens."""
+        node's plane 3 patched, and the pods that are left go out as a new batch (the mirror holds the placements made
+        so far) - with Packer.close_signatures() up front this never happens."""
         reqs = np.ascontiguousarray(reqs)
         P = len(reqs)
         node = np.zeros(P, np.int64)
@@ -110,29 +111,29 @@ class Engine:
         status = np.zeros(P, np.int32)
         if cand is not None:
             cand = np.ascontiguousarray(cand, dtype=np.uint64)
-        done = ctypes.c_uint32(0)
-        first, resume = 0, np.zeros(0, np.int64)
-        while True:
-            self._chk(self.lib.nhdfit_schedule_batch(self.ctx, _p(reqs), P, float(now), _p(cand), int(apply), first,
-                                                     _p(resume) if len(resume) else None, len(resume),
-                                                     _p(node), _p(maps), _p(places), _p(status), ctypes.byref(done)))
-            if done.value >= P or not apply:
-                break
-            stuck = [int(node[i] - self.global_base) for i in range(first, done.value) if status[i] == pack.COMMIT_NEW_SIG]
-            assert stuck, "the device stopped a batch without reporting a new NIC state"
+        first = 0
+        while first < P:
+            done = ctypes.c_uint32(0)
+            self._chk(self.lib.nhdfit_schedule_batch(self.ctx, _p(reqs[first:]), P - first, float(now), _p(cand), int(apply),
+                                                     _p(node[first:]), _p(maps[first:]), _p(places[first:]), _p(status[first:]),
+                                                     ctypes.byref(done)))
+            last = first + done.value
+            stuck = [int(node[i] - self.global_base) for i in range(first, last) if status[i] == pack.COMMIT_NEW_SIG]
+            if last < P and not (apply and stuck):
+                raise _lib.NhdFitError(-5, "the device stopped a sequential batch early without a NIC state to intern")
             patched = []
-            for v in stuck:
+            for v in stuck if apply else []:
                 one = self.download(v, 1)
                 sn, sp = packer.sigs_from_detail(one.detail[0])
                 one.p3[0]["sig_numa"] = sn
                 one.p3[0]["sig_pci"] = sp
                 patched.append((v, one))
-            self.set_dictionary(packer)
-            for v, one in patched:
-                self.upload(one, global_base=self.global_base, first=v, capacity=self.n)
-            first, resume = done.value, np.asarray(stuck, np.int64)
+            if patched:
+                self.set_dictionary(packer)
+                for v, one in patched:
+                    self.upload(one, global_base=self.global_base, first=v, capacity=self.n)
+            first = last
         self.P = P
-        self.n_done = done.value
         return node, maps, places, status
 
     def commit(self, node: int, req: np.ndarray, mapping: np.ndarray, busy_time: float) -> np.ndarray:
