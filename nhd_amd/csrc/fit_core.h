@@ -401,22 +401,29 @@ NHD_HD uint64_t node_word_hot(const uint8_t* hot, const Layout& L, const NodeRec
 
 // The same verdict from the COLD rows (A / R per signature) and the class-independent hot rows (WC, GX, HP): for
 // nodes whose (f, signature) class has no X row yet - a node a pod of the running batch was just committed to.
-NHD_HD uint64_t node_word_cold(const uint8_t* img, const Layout& L, const NodeIdx& n, const nhdfit_plane3& q3, bool busy,
-                               uint64_t m_need, uint64_t m_pci) {
+// one assignment word p of the W the verdict ORs together / the node-wide predicates - split out so that the sequential
+// kernel can give every p a lane
+NHD_HD uint64_t node_term_cold(const uint8_t* img, const Layout& L, const NodeIdx& n, const nhdfit_plane3& q3, uint64_t m_pci, uint32_t p) {
     const uint8_t* hot = img + L.off_hot;
     const uint32_t w0 = L.hot_wc0 + n.w0 * L.wc_stride, w1 = L.hot_wc1 + n.w1 * L.wc_stride;
-    uint64_t acc = 0;
-    for (uint32_t p = 0; p < L.W; ++p) {
-        const uint32_t o = p * 8;
-        const uint64_t cpu = (ld64(hot, w0 + L.row + o) & ld64(hot, w1 + o)) | (ld64(hot, w0 + o) & ld64(hot, w1 + L.row + o));
-        const uint64_t r0 = (ld64(img, L.off_r0 + q3.sig_pci[0] * L.row + o) & m_pci) | (ld64(img, L.off_r0 + q3.sig_numa[0] * L.row + o) & ~m_pci);
-        const uint64_t r1 = (ld64(img, L.off_r1 + q3.sig_pci[1] * L.row + o) & m_pci) | (ld64(img, L.off_r1 + q3.sig_numa[1] * L.row + o) & ~m_pci);
-        acc |= cpu & ld64(img, L.off_a0 + n.f0 * L.row + o) & ld64(img, L.off_a1 + n.f1 * L.row + o) & r0 & r1;
-    }
+    const uint32_t o = p * 8;
+    const uint64_t cpu = (ld64(hot, w0 + L.row + o) & ld64(hot, w1 + o)) | (ld64(hot, w0 + o) & ld64(hot, w1 + L.row + o));
+    const uint64_t r0 = (ld64(img, L.off_r0 + q3.sig_pci[0] * L.row + o) & m_pci) | (ld64(img, L.off_r0 + q3.sig_numa[0] * L.row + o) & ~m_pci);
+    const uint64_t r1 = (ld64(img, L.off_r1 + q3.sig_pci[1] * L.row + o) & m_pci) | (ld64(img, L.off_r1 + q3.sig_numa[1] * L.row + o) & ~m_pci);
+    return cpu & ld64(img, L.off_a0 + n.f0 * L.row + o) & ld64(img, L.off_a1 + n.f1 * L.row + o) & r0 & r1;
+}
+NHD_HD uint64_t node_pred_cold(const uint8_t* img, const Layout& L, const NodeIdx& n, bool busy, uint64_t m_need) {
+    const uint8_t* hot = img + L.off_hot;
     const uint32_t hp = n.hp < L.hp_rows ? n.hp : L.hp_rows - 1;
     uint64_t pred = ld64(hot, L.hot_gx + n.gx * 8) & ld64(hot, L.hot_hp + hp * 8);
     if (busy) pred &= ~m_need;
-    return acc & pred;
+    return pred;
+}
+NHD_HD uint64_t node_word_cold(const uint8_t* img, const Layout& L, const NodeIdx& n, const nhdfit_plane3& q3, bool busy,
+                               uint64_t m_need, uint64_t m_pci) {
+    uint64_t acc = 0;
+    for (uint32_t p = 0; p < L.W; ++p) acc |= node_term_cold(img, L, n, q3, m_pci, p);
+    return acc & node_pred_cold(img, L, n, busy, m_need);
 }
 
 // NIC-feasible assignment bits (bit p) of one (pod, node) pair, for the winner mapping (cold R rows).

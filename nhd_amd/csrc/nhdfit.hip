@@ -951,7 +951,6 @@ struct SeqArgs {
     const uint32_t* order;           // caller's pod i -> staged (class-sorted) position
     const uint8_t* tabs; uint32_t pitch; const uint8_t* tile_wcls; Layout L[kWClasses];
     uint64_t* rows;                  // [chunks][P] verdict rows of the snapshot; kept current for the pods without GPUs
-    uint64_t* nm;                    // [tiles][chunks*64] the same matrix node-major, kept current likewise
     uint64_t* taken;                 // [chunks] nodes that received a pod of this batch: busy, i.e. gone for every pod with GPUs
     const uint64_t* nogpu;           // [chunks] nodes without a GPU installed
     const uint64_t* tile_masks;      // [tiles][2]: pods that request GPUs / are in PCI mode
@@ -1094,8 +1093,8 @@ __device__ __forceinline__ bool map_on_state_wave(const nhdfit_req& r, const Nod
 //   * SetBusy: the node is busy until now + 30 s, and a busy node is dropped for every pod that requests GPUs
 //     (nhd/Matcher.py:107-111, nhd/Node.py:843-850) - for those pods the kernel keeps ONE bit per node ("taken") next
 //     to the snapshot's verdict rows;
-//   * for the pods without GPUs the node stays a candidate as far as its resources go: the committed nodes' columns
-//     are re-evaluated against the tiles that hold such pods (cold rows) and their rows patched.
+//   * for the pods without GPUs the node stays a candidate as far as its resources go: the committed nodes are
+//     re-evaluated against the tiles that hold such pods (cold rows) and those pods' rows patched.
 // Per round:
 //   (1) every wavefront scans its pod's row (minus the taken nodes if the pod wants GPUs) up to the first window of 64
 //       chunks with a candidate and parks the window's 64 words in LDS;
@@ -1105,7 +1104,8 @@ __device__ __forceinline__ bool map_on_state_wave(const nhdfit_req& r, const Nod
 //       is left of the node decides - the round ends before this pod.  So does a pod whose window ran dry;
 //   (3) one wavefront per kept pod: node record -> LDS, mapping against the node's state at this turn, commit
 //       (commit_core.h), record and placement written back;
-//   (4) all threads: columns of the committed nodes for the tiles with GPU-less pods.
+//   (4) all threads: the committed nodes against the tiles with GPU-less pods, sixteen lanes per (node, tile), which
+//       then clear the node's bit in the rows of the pods that lost it.
 template <int kSeqPods>
 __global__ __launch_bounds__(64 * kSeqPods) void k_seq(SeqArgs a) {
     constexpr int kSeqThreads = 64 * kSeqPods;
@@ -1123,12 +1123,14 @@ __global__ __launch_bounds__(64 * kSeqPods) void k_seq(SeqArgs a) {
     __shared__ uint32_t s_keep;
     __shared__ int32_t s_stop;
     __shared__ uint32_t s_ngl;                       // tiles that hold pods without GPUs
-    __shared__ uint64_t s_changed[kSeqThreads];
+    constexpr uint32_t kGlLds = 256;
+    __shared__ uint16_t s_gl[kGlLds];                // their list (a.gl_tiles when it is longer)
+    __shared__ Layout s_L[kWClasses];                // kernel-argument arrays indexed at run time would live in scratch memory
     __shared__ double s_caps[NHDFIT_MAX_CLASSES];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tiles = (a.P + kTile - 1) / kTile;
-    const size_t npad = (size_t)a.chunks * 64;
     if (tid == 0) { s_stop = 0; s_ngl = 0; }
+    if (tid < (uint32_t)kWClasses) s_L[tid] = a.L[tid];
     if (tid < NHDFIT_MAX_CLASSES) s_caps[tid] = a.caps[tid];
     // small per-batch look-up data the chain would otherwise fetch from L2 pod after pod: staged in LDS once
     // (a.lds_tables = 0: the batch is too large, they stay in global memory)
@@ -1136,13 +1138,16 @@ __global__ __launch_bounds__(64 * kSeqPods) void k_seq(SeqArgs a) {
     const uint32_t* order = a.order;
     const uint64_t* tile_masks = a.tile_masks;
     const uint8_t* tile_wcls = a.tile_wcls;
-    const uint16_t* gl_tiles = a.gl_tiles;
     SigTable sigs = a.sigs;
     __syncthreads();
-    for (uint32_t t = tid; t < tiles; t += kSeqThreads) {         // order of the list does not matter
+    for (uint32_t t = tid; t < tiles; t += kSeqThreads) {         // the order of the list does not matter
         const uint32_t live = a.P - t * kTile < (uint32_t)kTile ? a.P - t * kTile : (uint32_t)kTile;
         const uint64_t lm = live == 64 ? ~0ull : (1ull << live) - 1;
-        if (~a.tile_masks[2 * t] & lm) a.gl_tiles[atomicAdd(&s_ngl, 1u)] = (uint16_t)t;
+        if (~a.tile_masks[2 * t] & lm) {
+            const uint32_t at = atomicAdd(&s_ngl, 1u);
+            a.gl_tiles[at] = (uint16_t)t;
+            if (at < kGlLds) s_gl[at] = (uint16_t)t;
+        }
     }
     if (a.lds_tables) {
         uint8_t* q = s_dyn;
@@ -1161,6 +1166,7 @@ __global__ __launch_bounds__(64 * kSeqPods) void k_seq(SeqArgs a) {
     __threadfence_block();
     __syncthreads();
     const uint32_t ngl = s_ngl;
+    const uint16_t* gl_tiles = ngl <= kGlLds ? s_gl : a.gl_tiles;
 
     auto load_node = [&](uint32_t slot, uint32_t v) {             // planes + detail of node v -> LDS slot (one wavefront)
         uint32_t* st = reinterpret_cast<uint32_t*>(&s_st[slot]);
@@ -1191,44 +1197,9 @@ __global__ __launch_bounds__(64 * kSeqPods) void k_seq(SeqArgs a) {
             reinterpret_cast<uint4*>(a.det + v)[lane - 8] = make_uint4(dd[0], dd[1], dd[2], dd[3]);
         }
     };
-    // columns of the nodes in slots [0, cnt) flagged in `mask` against the tiles with GPU-less pods (cold rows); the
-    // rows of those pods patched where one lost a node.  All threads; ends with a barrier.
-    auto refresh_columns = [&](uint32_t cnt, uint32_t mask) {
-        for (uint32_t k0 = 0; k0 < cnt * ngl; k0 += kSeqThreads) {
-            const uint32_t k = k0 + tid;
-            uint64_t changed = 0;
-            if (k < cnt * ngl) {
-                const uint32_t slot = k / ngl, t = gl_tiles[k % ngl];
-                if (mask >> slot & 1) {
-                    const uint32_t v = (uint32_t)s_node[slot];
-                    const NodeState& st = s_st[slot];
-                    const NodeIdx ni = node_index(st.p0, st.p1, st.p2, st.p4, a.fc_dim, a.fg_dim, a.ngs);
-                    const bool busy = (a.now - st.p4.busy_time) < kMinBusySecs;
-                    const uint64_t need = tile_masks[2 * t];
-                    const uint64_t old = a.nm[(size_t)t * npad + v];
-                    const uint64_t word = node_word_cold(a.tabs + (size_t)t * a.pitch, a.L[tile_wcls[t]], ni, st.p3, busy, need, tile_masks[2 * t + 1]);
-                    changed = old & ~word & ~need;               // pods with GPUs go by the taken bits
-                    if (changed) a.nm[(size_t)t * npad + v] = old & ~changed;
-                }
-            }
-            s_changed[tid] = changed;
-            __syncthreads();
-            const uint32_t span = cnt * ngl - k0 < (uint32_t)kSeqThreads ? cnt * ngl - k0 : kSeqThreads;
-            for (uint32_t q = tid; q < span * 64; q += kSeqThreads) {
-                const uint32_t e = q >> 6, j = q & 63;
-                if (s_changed[e] >> j & 1) {
-                    const uint32_t kk = k0 + e, sl = kk / ngl, tt = gl_tiles[kk % ngl], v = (uint32_t)s_node[sl];
-                    // two nodes of one 64-node chunk may lose the same pod in the same round: atomic
-                    atomicAnd(reinterpret_cast<unsigned long long*>(&a.rows[(size_t)(v >> 6) * a.P + (size_t)tt * 64 + j]), ~(1ull << (v & 63)));
-                }
-            }
-            __syncthreads();
-        }
-    };
-
     uint32_t i = 0;
-    unsigned long long t_find = 0, t_pick = 0, t_map = 0, t_col = 0, n_rounds = 0, tick = a.prof ? wall_clock64() : 0;
-    unsigned long long t_sub[5] = {0, 0, 0, 0, 0}, sub = 0;
+    unsigned long long t_find = 0, t_pick = 0, t_map = 0, n_rounds = 0, tick = a.prof ? wall_clock64() : 0;
+    unsigned long long t_sub[5] = {0, 0, 0, 0, 0}, sub = 0, t_c[5] = {0, 0, 0, 0, 0};
     auto sublap = [&](int k) { if (a.prof && wave == 0) { const unsigned long long t = wall_clock64(); t_sub[k] += t - sub; sub = t; } };
     auto lap = [&](unsigned long long& acc) { if (a.prof) { const unsigned long long t = wall_clock64(); acc += t - tick; tick = t; } };
     while (i < a.P) {
@@ -1277,29 +1248,31 @@ __global__ __launch_bounds__(64 * kSeqPods) void k_seq(SeqArgs a) {
         lap(t_find);
         // (2) the round's pods in order
         if (wave == 0) {
-            uint32_t chosen = 0xFFFFFFFFu;                        // lane e: node of the round's pod e
+            const int32_t my_hv = lane < (uint32_t)kSeqPods ? s_have[lane] : -2;       // lane e: the round's pod e
+            const uint32_t my_base = lane < (uint32_t)kSeqPods ? s_base[lane] : 0u;
+            uint32_t chosen = 0xFFFFFFFFu;
             uint32_t keep = 0;
             for (; keep < (uint32_t)kSeqPods; ++keep) {
-                const int32_t hv = s_have[keep];
+                const int32_t hv = __builtin_amdgcn_readlane(my_hv, (int)keep);
                 if (hv == -2) break;
                 int64_t nd = -1;
                 if (hv & 1) {
-                    const bool wants_gpu = (hv & 2) != 0;
-                    uint64_t w = s_win[keep][lane];
-                    const uint32_t base = s_base[keep], c = base + lane;
-                    if (wants_gpu)
-                        for (uint32_t e = 0; e < keep; ++e) {
-                            const uint32_t ch = (uint32_t)__builtin_amdgcn_readlane((int)chosen, (int)e);
-                            if (ch != 0xFFFFFFFFu && (ch >> 6) == c) w &= ~(1ull << (ch & 63));
-                        }
+                    const uint64_t w = s_win[keep][lane];             // earlier pods' nodes are already knocked out (below)
+                    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)my_base, (int)keep);
                     const uint64_t any = __ballot(w != 0);
                     if (!any) break;                              // window ran dry (never pod 0: nothing is excluded for it)
                     const int l = __builtin_ctzll(any);
                     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, l);
                     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
                     nd = (int64_t)(base + l) * 64 + __builtin_ctzll(((uint64_t)hi << 32) | lo);
-                    if (!wants_gpu && __ballot(lane < keep && chosen == (uint32_t)nd)) break;   // the node's state after that commit decides
+                    if (!(hv & 2) && __ballot(lane < keep && chosen == (uint32_t)nd)) break;   // the node's state after that commit decides
                     if (lane == keep) chosen = (uint32_t)nd;
+                    if (lane > keep && (my_hv & 3) == 3) {        // busy for the later pods with GPUs
+                        const uint32_t idx = ((uint32_t)nd >> 6) - my_base;
+                        if (idx < 64u) s_win[lane][idx] &= ~(1ull << (nd & 63));
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
                 if (lane == 0) s_node[keep] = nd;
             }
@@ -1313,6 +1286,7 @@ __global__ __launch_bounds__(64 * kSeqPods) void k_seq(SeqArgs a) {
             const int64_t nd = s_node[wave];
             if (nd < 0) {
                 if (lane == 0) { SeqResult r; r.node = -1; r.map = nhdfit_mapping{}; r.status = 0; a.out[mine] = r; }
+                if (a.place && lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&a.place[mine])[lane] = 0u;
             } else {
                 const uint32_t v = (uint32_t)nd;
                 if (a.prof && wave == 0) sub = wall_clock64();
@@ -1328,7 +1302,7 @@ __global__ __launch_bounds__(64 * kSeqPods) void k_seq(SeqArgs a) {
                     nhdfit_detail& dd = s_det[wave];
                     sublap(0);
                     const uint32_t pos = s_pos[wave], tile = pos >> 6;
-                    const uint32_t bits = nic_assignment_bits_wave(a.tabs + (size_t)tile * a.pitch, a.L[tile_wcls[tile]], pos & 63,
+                    const uint32_t bits = nic_assignment_bits_wave(a.tabs + (size_t)tile * a.pitch, s_L[tile_wcls[tile]], pos & 63,
                                                                    rq.map_type == NHDFIT_MAP_PCI, st.p3, lane);
                     sublap(1);
                     nhdfit_mapping mp;
@@ -1379,21 +1353,57 @@ __global__ __launch_bounds__(64 * kSeqPods) void k_seq(SeqArgs a) {
         }
         __syncthreads();
         lap(t_map);
-        // (4) columns of the committed nodes, for the pods without GPUs (not after a stop: the host patches those nodes
-        // and starts over with the pods that are left)
+        // (4) what is left of the committed nodes, for the pods without GPUs (not after a stop: the host patches those
+        // nodes and starts over with the pods that are left)
         if (ngl && !s_stop) {
-            uint32_t mask = 0;
-            for (uint32_t e = 0; e < keep; ++e)
-                if (s_node[e] >= 0) mask |= 1u << e;
-            if (mask) refresh_columns(keep, mask);
+            // sixteen lanes per (node, tile): lane p evaluates assignment word p (W <= 16; the W words of a table row are
+            // contiguous), the group ORs them together and clears the node's bit in the rows of the pods that lost it
+            const uint32_t items = keep * ngl, p = lane & 15u, grp = tid >> 4;
+            constexpr uint32_t kGroups = kSeqThreads / 16, kDepth = 4;       // kDepth items per group in flight: one memory round trip
+            for (uint32_t k0 = 0; k0 < items; k0 += kGroups * kDepth) {
+                uint64_t lost[kDepth];
+                uint32_t vv[kDepth], tt[kDepth];
+#pragma unroll
+                for (uint32_t u = 0; u < kDepth; ++u) {
+                    const uint32_t k = k0 + u * kGroups + grp;
+                    lost[u] = 0; vv[u] = 0; tt[u] = 0;
+                    if (k >= items) continue;                         // group-uniform
+                    const uint32_t slot = k / ngl, t = gl_tiles[k % ngl];
+                    if (s_node[slot] < 0) continue;
+                    const NodeState& st = s_st[slot];
+                    const NodeIdx ni = node_index(st.p0, st.p1, st.p2, st.p4, a.fc_dim, a.fg_dim, a.ngs);
+                    const bool busy = (a.now - st.p4.busy_time) < kMinBusySecs;
+                    const uint64_t need = tile_masks[2 * t];
+                    const uint8_t* img = a.tabs + (size_t)t * a.pitch;
+                    const Layout& L = s_L[tile_wcls[t]];
+                    uint64_t term = p < L.W ? node_term_cold(img, L, ni, st.p3, tile_masks[2 * t + 1], p) : 0ull;
+                    for (int m = 1; m < 16; m <<= 1) term |= __shfl_xor(term, m, 16);
+                    lost[u] = ~(term & node_pred_cold(img, L, ni, busy, need)) & ~need;     // pods with GPUs go by the taken bits
+                    vv[u] = (uint32_t)s_node[slot]; tt[u] = t;
+                }
+                if (a.prof && tid == 0) { const unsigned long long tq = wall_clock64(); t_c[0] += tq - tick; tick = tq; }
+#pragma unroll
+                for (uint32_t u = 0; u < kDepth; ++u)
+                    for (uint32_t q = 0; q < 4; ++q) {
+                        const uint32_t j = q * 16 + p;
+                        // already clear for most: no harm; two nodes of one 64-node chunk may hit the same word: atomic
+                        if ((lost[u] >> j & 1) && (size_t)tt[u] * 64 + j < a.P)
+                            atomicAnd(reinterpret_cast<unsigned long long*>(&a.rows[(size_t)(vv[u] >> 6) * a.P + (size_t)tt[u] * 64 + j]), ~(1ull << (vv[u] & 63)));
+                    }
+            }
+            if (a.prof && tid == 0) { const unsigned long long tq = wall_clock64(); t_c[1] += tq - tick; tick = tq; }
+            __threadfence();                                      // the patches are in L2 before the next scan
+            if (a.prof && tid == 0) { const unsigned long long tq = wall_clock64(); t_c[2] += tq - tick; tick = tq; }
+            __syncthreads();
+            if (a.prof && tid == 0) { const unsigned long long tq = wall_clock64(); t_c[3] += tq - tick; tick = tq; t_c[4] += items; }
         }
-        lap(t_col);
+        if (a.prof) { const unsigned long long t = wall_clock64(); tick = t; }
         ++n_rounds;
         i += keep;
     }
     if (tid == 0) *a.n_done = i;
     if (tid == 0 && a.prof) { a.prof[0] = t_find; a.prof[1] = t_map; a.prof[2] = t_pick; a.prof[3] = n_rounds; a.prof[4] = i;
-                              for (int k = 0; k < 5; ++k) a.prof[5 + k] = t_sub[k]; a.prof[10] = t_col; }
+                              for (int k = 0; k < 5; ++k) a.prof[5 + k] = t_sub[k]; a.prof[10] = t_c[0] + t_c[1] + t_c[2] + t_c[3]; for (int k = 0; k < 5; ++k) a.prof[11 + k] = t_c[k]; }
 }
 
 // apply = 0: put the touched nodes back
@@ -2145,7 +2155,7 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         c->ev_kind[c->ev_pending++] = with_fit ? 0 : 1;
     }
     if (a.role_clock) {
-        unsigned long long t[12];
+        unsigned long long t[16];
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
         unsigned long long first = ~0ull;
@@ -2312,8 +2322,8 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, c->nogpu.reserve(chunks ? chunks : 1));
         HIPCHK(c, c->taken.reserve(chunks ? chunks : 1));
         HIPCHK(c, c->tile_masks.reserve((size_t)tiles * 2));
-        HIPCHK(c, c->gl_tiles.reserve(tiles));
         HIPCHK(c, c->touched.reserve(c->n ? c->n : 1));
+        HIPCHK(c, c->gl_tiles.reserve(tiles));
         HIPCHK(c, c->seq_counters.reserve(4));
         HIPCHK(c, c->undo.reserve(apply ? 1 : P));
         HIPCHK(c, c->seq_out.reserve(P));
@@ -2338,7 +2348,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     sa.reqs = c->reqs.p; sa.score = c->score[b].p; sa.P = P; sa.order = c->order.p;
     sa.tabs = c->tabs[b].p; sa.pitch = c->pitch; sa.tile_wcls = c->tile_wcls.p;
     for (int w = 0; w < kWClasses; ++w) sa.L[w] = c->L[w];
-    sa.rows = c->bitmap.p; sa.nm = c->nm.p; sa.taken = c->taken.p; sa.nogpu = c->nogpu.p; sa.tile_masks = c->tile_masks.p;
+    sa.rows = c->bitmap.p; sa.taken = c->taken.p; sa.nogpu = c->nogpu.p; sa.tile_masks = c->tile_masks.p;
     sa.caps = c->caps.p; sa.sigs = sig_table(c); sa.fc_dim = c->max_cores + 1; sa.fg_dim = c->max_gpus + 1; sa.ngs = c->ngs;
     sa.mt = map_tables(c);
     sa.undo = c->undo.p; sa.touched = c->touched.p; sa.counters = c->seq_counters.p; sa.keep_undo = apply ? 0 : 1;
@@ -2350,11 +2360,11 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     const int seq_pods = c->seq_pods;
     HIPCHK(c, hipFuncSetAttribute(seq_pods == 16 ? (const void*)k_seq<16> : (const void*)k_seq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     const bool seq_prof = getenv("NHDFIT_SEQ_PROF") != nullptr;
-    if (seq_prof) { HIPCHK(c, c->role_clock.reserve(12)); sa.prof = c->role_clock.p; }
+    if (seq_prof) { HIPCHK(c, c->role_clock.reserve(16)); sa.prof = c->role_clock.p; }
     if (seq_pods == 16) hipLaunchKernelGGL(k_seq<16>, dim3(1), dim3(1024), seq_lds, sm, sa);
     else hipLaunchKernelGGL(k_seq<8>, dim3(1), dim3(512), seq_lds, sm, sa);
     if (seq_prof) {
-        unsigned long long t[12];
+        unsigned long long t[16];
         HIPCHK(c, hipStreamSynchronize(sm));
         HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
         const double per = 0.01 / (double)(t[3] ? t[3] : 1);
@@ -2362,6 +2372,8 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
                 t[5] * per, t[6] * per, t[7] * per, t[8] * per, t[9] * per);
         fprintf(stderr, "[nhdfit] k_seq: %llu pods in %llu rounds; scan %.1f us, pick %.1f us, map+commit %.1f us, columns %.1f us per round\n", t[4], t[3],
                 t[0] * per, t[2] * per, t[1] * per, t[10] * per);
+        fprintf(stderr, "[nhdfit] k_seq columns: evaluate %.1f, patch %.1f, fence %.1f, barrier %.1f us per round; %.1f (node, tile) pairs per round\n",
+                t[11] * per, t[12] * per, t[13] * per, t[14] * per, (double)t[15] / (double)(t[3] ? t[3] : 1));
     }
     if (!apply) hipLaunchKernelGGL(k_undo, dim3(P), dim3(64), 0, sm, sa);
     HIPCHK(c, hipGetLastError());

@@ -280,7 +280,9 @@ class GroupEngine:
                 else:
                     s.global_base = lo
             self.n = n
+            self._has_gpu = np.array((table.p2["flags"] & pack.NF_HAS_GPU) != 0)
             return
+        self._has_gpu[first:first + table.n] = (table.p2["flags"] & pack.NF_HAS_GPU) != 0
         lo_i = first
         while lo_i < first + table.n:                               # a run may straddle shards
             k = self._shard_of(lo_i)
@@ -292,6 +294,13 @@ class GroupEngine:
     def set_outputs(self, bitmap=True, mapping=True):
         for s in self.shards:
             s.set_outputs(bitmap, mapping)
+
+    def _nogpu_words(self, k: int) -> np.ndarray:
+        """Shard k's nodes without a GPU installed, one bit per node (static per node: the hardware)."""
+        lo, hi = self._bounds[k]
+        bits = np.zeros(((hi - lo + 63) // 64) * 64, np.uint8)
+        bits[:hi - lo] = ~self._has_gpu[lo:hi]
+        return np.packbits(bits, bitorder="little").view(np.uint64).copy()
 
     # ---- one-shot ---------------------------------------------------------------------
     def find(self, reqs: np.ndarray, now: float, cand: Optional[np.ndarray] = None, want_bitmap=False, want_map=True):
@@ -329,10 +338,69 @@ class GroupEngine:
             raise _lib.NhdFitError(rc, (self.lib.nhdfit_group_last_error(self.group) or b"?").decode())
         return score, None, maps
 
-    def schedule_batch(self, *a, **kw):
-        raise NotImplementedError("sequential (mode B) batches run on one shard: use HipMatcher(device=...) for ScheduleBatch")
+    def schedule_batch(self, reqs: np.ndarray, now: float, packer: pack.Packer, cand: Optional[np.ndarray] = None, apply: bool = True):
+        """Mode B over all shards, exactly the one-by-one loop's decisions (nhd/NHDScheduler.py:425-437 with
+        Matcher.SelectNode's order, nhd/Matcher.py:401-413): a pod takes the first feasible node of the cluster, a pod
+        without GPUs the first feasible GPU-less node if there is one.  Two facts make that separable by shard:
+          * nodes without GPUs only ever receive pods without GPUs, so their state evolves under that subsequence alone:
+            the GPU-less pods walk the shards' GPU-less nodes in shard order, each shard's sequential pass
+            (nhdfit_schedule_batch, candidates = its GPU-less nodes) handing the pods it could not place to the next;
+          * whatever is left of them and the pods with GPUs then walk the shards in the same manner over all nodes:
+            a pod reaches shard s iff no node of shards < s could take it at its turn, and shard s's state depends
+            only on the pods placed there before.  (A GPU-less node that refused a pod only lost resources since.)
+        Each pass runs on ONE device; a pod costs a pass only on the shards it is offered to.  apply=False restores the
+        shards from copies taken up front."""
+        reqs = np.ascontiguousarray(reqs)
+        P = len(reqs)
+        node = np.full(P, -1, np.int64)
+        maps = np.zeros(P, pack.MAPPING)
+        places = np.zeros(P, pack.PLACEMENT)
+        status = np.zeros(P, np.int32)
+        if cand is not None:
+            cand = np.ascontiguousarray(cand, dtype=np.uint64)
+        live = [k for k, (lo, hi) in enumerate(self._bounds) if hi > lo]
+        saved = {} if apply else {k: self.shards[k].download(0, self._bounds[k][1] - self._bounds[k][0]) for k in live}
+        nogpu = {k: self._nogpu_words(k) for k in live}
+        wants_gpu = reqs["gpus"].sum(axis=1) > 0
+        touched = {}
 
-    find_sequential = schedule_batch
+        def offer(pods: np.ndarray, gpu_less_nodes_only: bool) -> np.ndarray:
+            for k in live:
+                if len(pods) == 0:
+                    break
+                lo, hi = self._bounds[k]
+                mask = None if cand is None else np.ascontiguousarray(cand[lo // 64:(hi + 63) // 64])
+                if gpu_less_nodes_only:
+                    mask = nogpu[k] if mask is None else mask & nogpu[k]
+                    if not mask.any():
+                        continue
+                nd, mp, pl, st = self.shards[k].schedule_batch(reqs[pods], now, packer, cand=mask, apply=True)
+                got = nd >= 0
+                node[pods[got]] = nd[got]
+                maps[pods[got]] = mp[got]
+                places[pods[got]] = pl[got]
+                status[pods[got]] = st[got]
+                if got.any():
+                    a, b = int(nd[got].min()) - lo, int(nd[got].max()) - lo + 1
+                    touched[k] = (min(a, touched[k][0]), max(b, touched[k][1])) if k in touched else (a, b)
+                pods = pods[~got]
+            return pods
+
+        left = offer(np.flatnonzero(~wants_gpu), True)
+        rest = np.sort(np.concatenate([np.flatnonzero(wants_gpu), left]))
+        offer(rest, False)
+        if not apply:
+            for k, (a, b) in touched.items():
+                lo, hi = self._bounds[k]
+                self.shards[k].upload(saved[k].slice(a, b), global_base=lo, first=a, capacity=hi - lo)
+        self.P = P
+        return node, maps, places, status
+
+    def find_sequential(self, reqs: np.ndarray, now: float, cand: Optional[np.ndarray] = None, packer: Optional[pack.Packer] = None):
+        if packer is None:
+            raise ValueError("GroupEngine.find_sequential needs the packer (NIC states are interned on the way)")
+        node, maps, _, status = self.schedule_batch(reqs, now, packer, cand=cand, apply=False)
+        return node, maps, status
 
     def commit(self, node: int, req, mapping, busy_time):
         k = self._shard_of(node)

@@ -157,4 +157,5 @@ class HarnessEngine:
 
     def download(self, first=0, count=None):
         count = self.n - first if count is None else count
-        return self.table.slice(first, first + count)
+        t = self.table.slice(first, first + count)
+        return pack.NodeTable(list(t.names), *[np.array(getattr(t, f)) for f in ("p0", "p1", "p2", "p3", "p4", "detail")])   # a copy, as a device read-back is

@@ -67,3 +67,46 @@ def test_more_devices_than_chunks():
     m = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine, devices=list(range(8)))
     for top in tops:
         assert jsonable(m.FindNode(nl, top)) == jsonable(O.find_node(nl, top, util.CLOCK))
+
+
+@pytest.mark.parametrize("ndev", [2, 3, 5])
+@pytest.mark.parametrize("cfg,n,P", [(3, 200, 260), (4, 150, 220), (5, 130, 200)])
+def test_sharded_sequential_batch_equals_the_one_by_one_loop(cfg, n, P, ndev):
+    """Mode B across shards (GroupEngine.schedule_batch): GPU-less pods first walk the shards' GPU-less nodes, the rest
+    walks all nodes shard by shard - node, mapping and physical ids per pod equal the oracle's pod-by-pod loop over the
+    whole cluster (pinned to the reference), and so does the mirror afterwards (apply) / nothing changed (no apply)."""
+    spec = synth.make_cluster(cfg, n_nodes=n)
+    pods, groups = synth.make_pods(cfg, n_pods=P)
+    for p in pods:
+        p["misc_smt"] = True
+    nl = spec.build_nodes()
+    tops = [refmodel.make_topology(s) for s in pods]
+    many = HipMatcher(clock=lambda: spec.clock_now, engine_factory=harness.HarnessEngine, devices=list(range(ndev)))
+    many.attach(nl)
+    before = many.engine.download()
+    got = many.ScheduleBatch(nl, tops, pod_groups=groups)                   # apply=False: the shards are put back
+    after = many.engine.download()
+    for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
+        assert np.array_equal(getattr(before, f), getattr(after, f)), f
+    ids = []
+    ora = spec.build_nodes()
+    want = O.schedule_sequence(ora, tops, groups, spec.clock_now, ids_out=ids)
+    assert [jsonable(r) for r in got] == [jsonable(w) for w in want]
+    assert [p for p in many.last_placements] == ids
+    placed = [w for w in want if w[0] is not None]
+    assert len(placed) > 40 and len({w[0] for w in placed}) > 10
+    # pods that went past the first shard: the hand-over between shards is exercised
+    names = list(nl)
+    cut = many.engine._bounds[0][1]
+    assert any(names.index(w[0]) >= cut for w in placed)
+    # apply=True: the mirror holds the committed state of the oracle's node objects
+    got2 = many.ScheduleBatch(nl, tops, pod_groups=groups, apply=True)
+    assert [jsonable(r) for r in got2] == [jsonable(w) for w in want]
+    final = many.engine.download()
+    pk = many.packer
+    ref = pk.pack_nodes(ora)
+    for f in ("p0", "p1"):
+        assert np.array_equal(getattr(final, f), getattr(ref, f)), f
+    for f in ("gpu_free", "hp_free"):
+        assert np.array_equal(final.p2[f], ref.p2[f]), f
+    assert np.array_equal(final.p4["busy_time"], ref.p4["busy_time"])
