@@ -80,8 +80,11 @@ struct Layout {
     // cold section (byte offsets from the image start)
     uint32_t off_a0, off_a1, off_r0, off_r1;
     uint32_t off_hot;    // start of the hot section (multiple of 16)
-    // hot section (byte offsets from off_hot): X first - its capacity, not its fill, fixes what follows
-    uint32_t hot_x, hot_wc0, hot_wc1, hot_gx, hot_hp;
+    // hot section (byte offsets from off_hot): WC, GX, then X, then HP.  Everything up to the end of X depends on the
+    // dictionary and the provisioned X rows only (node records hold these offsets); HP depends on the staged batch.
+    // A fit block stages the section in LDS; when the node classes of a large heterogeneous cluster outgrow LDS it
+    // stages a prefix (plus HP) and the X rows beyond it are read from global memory (L2).
+    uint32_t hot_wc0, hot_wc1, hot_gx, hot_x, hot_hp;
     uint32_t hot_bytes;  // multiple of 16
     uint32_t bytes;      // whole image, multiple of 16
 };
@@ -110,11 +113,11 @@ NHD_HD Layout make_layout(uint32_t W, uint32_t max_cores_per_numa, uint32_t max_
     l.off_r0 = l.off_a1 + l.fg_dim * l.row;
     l.off_r1 = l.off_r0 + nsig * l.row;
     l.off_hot = align16(l.off_r1 + nsig * l.row);
-    l.hot_x = 0;
-    l.hot_wc0 = l.hot_x + x_cap * l.x_stride;
+    l.hot_wc0 = 0;
     l.hot_wc1 = l.hot_wc0 + 2 * l.fc_dim * l.wc_stride;          // records [smt][c]
     l.hot_gx = l.hot_wc1 + 2 * l.fc_dim * l.wc_stride;
-    l.hot_hp = l.hot_gx + align16((1 + 2 * ngs) * 8);
+    l.hot_x = l.hot_gx + align16((1 + 2 * ngs) * 8);
+    l.hot_hp = l.hot_x + x_cap * l.x_stride;
     l.hot_bytes = l.hot_hp + align16(hp_rows * 8);
     l.bytes = l.off_hot + l.hot_bytes;
     return l;

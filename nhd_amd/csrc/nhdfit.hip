@@ -232,6 +232,9 @@ struct FitArgs {
     const uint8_t* tabs;        // tile images
     uint32_t pitch;
     uint32_t off_hot[kWClasses], hot_bytes[kWClasses], hot_hp[kWClasses];   // per row width: where the hot section starts, its size, its HP rows
+    uint32_t hot_staged[kWClasses];   // == hot_bytes: the whole section is staged in LDS.  Smaller: only this prefix (it ends inside X) and the
+                                      // HP rows behind it; X rows past the prefix are read from global memory
+    uint32_t hp_bytes;
     uint32_t hp_last;           // last HP row of the staged batch (hp_rows - 1)
     const PodHeader* hdr;       // [tiles*64], zero flags beyond P
     uint32_t P;
@@ -327,6 +330,30 @@ __device__ __forceinline__ uint64_t sweep_assignments(const uint8_t* hot, uint32
     return ((uint64_t)hi << 32) | lo;
 }
 
+// The same with the lanes whose X rows lie beyond the staged prefix of the hot section reading them from the image in
+// global memory (the cluster holds more node classes than LDS has room for: slower, not wrong).
+template <int W>
+__device__ __forceinline__ uint64_t sweep_assignments_spill(const uint8_t* hot, const uint8_t* hot_global, uint32_t staged,
+                                                            uint32_t a_w0, uint32_t a_w1, uint32_t a_x0, uint32_t a_x1) {
+    const bool far0 = a_x0 + W * 8 > staged, far1 = a_x1 + W * 8 > staged;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll 1
+    for (int q = 0; q < W / 2; ++q) {
+        const uint32_t o = q * 16;
+        const uint4 w0 = lds16(hot, a_w0 + o), w0m = lds16(hot, a_w0 + W * 8 + o);
+        const uint4 w1 = lds16(hot, a_w1 + o), w1m = lds16(hot, a_w1 + W * 8 + o);
+        const uint4 x0 = far0 ? *reinterpret_cast<const uint4*>(hot_global + a_x0 + o) : lds16(hot, a_x0 + o);
+        const uint4 x1 = far1 ? *reinterpret_cast<const uint4*>(hot_global + a_x1 + o) : lds16(hot, a_x1 + o);
+        const uint32_t c0 = __builtin_amdgcn_bitop3_b32(w0.x, w1m.x, w0m.x & w1.x, 0xEA);
+        const uint32_t c1 = __builtin_amdgcn_bitop3_b32(w0.y, w1m.y, w0m.y & w1.y, 0xEA);
+        const uint32_t c2 = __builtin_amdgcn_bitop3_b32(w0.z, w1m.z, w0m.z & w1.z, 0xEA);
+        const uint32_t c3 = __builtin_amdgcn_bitop3_b32(w0.w, w1m.w, w0m.w & w1.w, 0xEA);
+        lo |= __builtin_amdgcn_bitop3_b32(c0, x0.x, x1.x, 0x80) | __builtin_amdgcn_bitop3_b32(c2, x0.z, x1.z, 0x80);
+        hi |= __builtin_amdgcn_bitop3_b32(c1, x0.y, x1.y, 0x80) | __builtin_amdgcn_bitop3_b32(c3, x0.w, x1.w, 0x80);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // The P x N pass.  Block = chunks [c_begin, c_end) of one pod tile: the hot section of the tile's table image is
 // staged in LDS, every wavefront sweeps a contiguous run of 64-node chunks (lane = node: one 16-byte record and
 // the busy time per node), writes the node-major verdict word and tracks the tile's first-fit winners.
@@ -336,13 +363,15 @@ __device__ __forceinline__ uint64_t sweep_assignments(const uint8_t* hot, uint32
 // a GPU-less node, SelectNode's preference) are two wave-uniform 64-bit masks; a chunk whose verdict words do
 // not touch them - all but the first one or two of a run - costs four instructions.  Only a chunk with news is
 // transposed (lane = pod) and scored.
-template <int BLOCK, int W>
+template <int BLOCK, int W, bool SPILL>
 __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, uint8_t* lds) {
     constexpr int NW = BLOCK / 64;
     constexpr int WC = W == 2 ? 0 : W == 4 ? 1 : W == 8 ? 2 : 3;
     const uint32_t hot_bytes = a.hot_bytes[WC];
     uint8_t* hot = lds;
-    unsigned long long (*s_best)[64] = reinterpret_cast<unsigned long long (*)[64]>(lds + lds_slice(hot_bytes));
+    const uint32_t staged = a.hot_staged[WC];
+    const bool spill = SPILL && staged < hot_bytes;                                 // block-uniform; SPILL: the launch was told to expect it
+    unsigned long long (*s_best)[64] = reinterpret_cast<unsigned long long (*)[64]>(lds + lds_slice(spill ? staged + a.hp_bytes : hot_bytes));
     const uint32_t tile = it.tile;
     const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t pod0 = tile * kTile;
@@ -361,10 +390,15 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
         rv = *reinterpret_cast<const uint4*>(recs + c_first * 64 + lane);           // {w0,w1}, {x0,x1}, {gx,hp}, {flags,pad}
         bt = a.p4[c_first * 64 + lane].busy_time;
     }
+    const uint8_t* hot_global = a.tabs + (size_t)tile * a.pitch + a.off_hot[WC];
     {   // stage the hot section of the tile's table image in LDS (16 B per lane, fully coalesced)
-        const uint4* src = reinterpret_cast<const uint4*>(a.tabs + (size_t)tile * a.pitch + a.off_hot[WC]);
+        const uint4* src = reinterpret_cast<const uint4*>(hot_global);
         uint4* dst = reinterpret_cast<uint4*>(hot);
-        if (!(a.dbg_skip & 16)) for (uint32_t i = threadIdx.x; i < hot_bytes / 16; i += BLOCK) dst[i] = src[i];
+        if (!(a.dbg_skip & 16)) for (uint32_t i = threadIdx.x; i < staged / 16; i += BLOCK) dst[i] = src[i];
+        if (spill) {                                                                 // the HP rows go right behind the prefix
+            const uint4* hsrc = reinterpret_cast<const uint4*>(hot_global + a.hot_hp[WC]);
+            for (uint32_t i = threadIdx.x; i < a.hp_bytes / 16; i += BLOCK) dst[staged / 16 + i] = hsrc[i];
+        }
     }
     __syncthreads();
 
@@ -376,7 +410,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
     uint64_t need_pref = __ballot(my_pod_live && !my_pod_needs_gpu);         // GPU-less pods without a GPU-less node so far
     uint32_t best_any = ~0u, best_pref = ~0u;                                // lane = pod: local node index
 
-    const uint32_t hp_last = a.hp_last, hot_hp = a.hot_hp[WC];
+    const uint32_t hp_last = a.hp_last, hot_hp = spill ? staged : a.hot_hp[WC];
     const size_t npad = (size_t)a.chunks * 64;
     // the next chunk's record and busy time are requested before this chunk is worked on: a wavefront's chunks are
     // one dependent chain of L2 round trips otherwise
@@ -396,7 +430,11 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
         const bool nogpu = (rv.w & kRecNoGpu) != 0;
 
         // (1) NUMA-assignment feasibility against all 64 pods (bit-sliced tables), (2) scalar predicates
-        const uint64_t okm = (a.dbg_skip & 1) ? ((uint64_t)rv.y << 32 | rv.x) : sweep_assignments<W>(hot, a_w0, a_w1, a_x0, a_x1);
+        uint64_t okm;
+        if (SPILL && spill && __ballot(a_x0 + W * 8 > staged || a_x1 + W * 8 > staged))
+            okm = sweep_assignments_spill<W>(hot, hot_global, staged, a_w0, a_w1, a_x0, a_x1);
+        else
+            okm = (a.dbg_skip & 1) ? ((uint64_t)rv.y << 32 | rv.x) : sweep_assignments<W>(hot, a_w0, a_w1, a_x0, a_x1);
         const uint2 gx = (a.dbg_skip & 8) ? make_uint2(rv.z, rv.w) : lds8(hot, a_gx), hpw = (a.dbg_skip & 8) ? make_uint2(~0u, ~0u) : lds8(hot, a_hp);
         const bool busy = bt >= a.busy_from;                                  // Node.IsBusy, nhd/Node.py:847-850
         uint32_t wlo = (uint32_t)okm & gx.x & hpw.x, whi = (uint32_t)(okm >> 32) & gx.y & hpw.y;
@@ -437,7 +475,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
     }
 }
 
-template <int BLOCK>
+template <int BLOCK, bool SPILL = false>
 __device__ __forceinline__ void role_fit(const FitArgs& a, uint32_t blk, uint8_t* lds) {
     FitItem it = a.items[blk];                      // block-uniform: keep it in scalar registers
     it.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.tile);
@@ -445,10 +483,10 @@ __device__ __forceinline__ void role_fit(const FitArgs& a, uint32_t blk, uint8_t
     it.c_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_begin);
     it.c_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_end);
     switch (it.wcls) {
-        case 0: role_fit_w<BLOCK, 2>(a, it, lds); break;
-        case 1: role_fit_w<BLOCK, 4>(a, it, lds); break;
-        case 2: role_fit_w<BLOCK, 8>(a, it, lds); break;
-        default: role_fit_w<BLOCK, 16>(a, it, lds); break;
+        case 0: role_fit_w<BLOCK, 2, SPILL>(a, it, lds); break;
+        case 1: role_fit_w<BLOCK, 4, SPILL>(a, it, lds); break;
+        case 2: role_fit_w<BLOCK, 8, SPILL>(a, it, lds); break;
+        default: role_fit_w<BLOCK, 16, SPILL>(a, it, lds); break;
     }
 }
 
@@ -882,8 +920,8 @@ __global__ __launch_bounds__(256) void k_rows(const uint64_t* __restrict__ nm, u
     if (pod < P) rows[(size_t)c * P + pod] = ((uint64_t)hi << 32) | lo;
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : 7) void k_step(StepArgs a) {   // 512 threads = 2 waves per SIMD: 3 blocks per CU either way
+template <int BLOCK, bool SPILL = false>      // SPILL: some tiles stage only a prefix of their hot section (refresh_layouts)
+__global__ __launch_bounds__(BLOCK, SPILL ? (BLOCK == 512 ? 4 : 5) : (BLOCK == 512 ? 6 : 7)) void k_step(StepArgs a) {   // SPILL: two blocks per CU (LDS)   // 512 threads = 2 waves per SIMD: 3 blocks per CU either way
     extern __shared__ __align__(16) uint8_t lds[];
     uint32_t blk = blockIdx.x;
     const unsigned long long t0 = a.role_clock ? (unsigned long long)wall_clock64() : 0ull;
@@ -891,7 +929,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : 7) void k_step(StepArgs a
     // them start at once; the side roles (short latency chains on few wavefronts) take the third slot, with issue
     // priority so that they finish - and hand the slot on - sooner.
     if (blk < a.nb_fit) {
-        role_fit<BLOCK>(a.fit, blk, lds);
+        role_fit<BLOCK, SPILL>(a.fit, blk, lds);
         stamp(a.role_clock, 4, t0);
         return;
     }
@@ -1532,6 +1570,8 @@ struct nhdfit_ctx {
     uint32_t max_cores = 1, max_gpus = 0, ngs = 0;
     DevBuf<uint64_t> group_sets;
     uint32_t lds_bytes = 0;       // largest hot section among the staged tiles (what a fit block stages in LDS)
+    bool x_spill = false;
+    uint32_t hot_staged[kWClasses] = {0, 0, 0, 0};   // per row width: bytes of the hot section staged in LDS (== hot_bytes unless the X rows outgrow LDS)
     Layout L[kWClasses] = {};     // tile-image layout per row width (dictionary, staged batch, provisioned X rows)
     uint32_t pitch = 0;           // bytes between tile images
     uint32_t hp_rows = 2;
@@ -1616,6 +1656,7 @@ int drain_events(nhdfit_ctx* c) {
     return NHDFIT_OK;
 }
 
+constexpr size_t kLdsPerCu = 160 * 1024;      // gfx950
 int flush_pipeline(nhdfit_ctx* c);
 int refresh_layouts(nhdfit_ctx* c);
 
@@ -1808,6 +1849,8 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     HIPCHK(c, hipFuncSetAttribute((const void*)k_role<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return NHDFIT_OK;
 }
 
@@ -1871,11 +1914,30 @@ int refresh_layouts(nhdfit_ctx* c) {
         c->L[w] = make_layout(2u << w, c->max_cores, c->max_gpus, c->nsig, c->ngs, c->hp_rows, c->x_cap);
         if (w <= c->max_wcls) { pitch = std::max(pitch, c->L[w].bytes); hot = std::max(hot, c->L[w].hot_bytes); }
     }
-    if ((size_t)hot + 8 * 64 * sizeof(unsigned long long) > 160 * 1024)
-        return fail(c, NHDFIT_E_LIMIT, "the hot table section of a pod tile needs %u bytes of LDS (160 KiB per CU): %u node classes, "
-                    "%u node-group sets, %u hugepage rows", hot, c->nx, c->ngs, c->hp_rows);
+    // What a fit block stages in LDS: the whole hot section if it fits next to the winner scratch (8 wavefronts x 64
+    // pods x 8 B); otherwise - more node classes than LDS has rows for - a prefix that leaves room for a second block
+    // per CU, plus the HP rows; the X rows beyond the prefix are read from global memory (L2): slower, not wrong.
+    const uint32_t scratch = 8 * 64 * sizeof(unsigned long long), hp_bytes = align16(c->hp_rows * 8);
+    const bool spill = (size_t)hot + scratch > kLdsPerCu;
+    uint32_t lds = 0;
+    for (uint32_t w = 0; w < (uint32_t)kWClasses; ++w) {
+        const Layout& L = c->L[w];
+        if (w <= c->max_wcls && L.hot_hp + hp_bytes > 0xFFFFu * 8u)
+            return fail(c, NHDFIT_E_LIMIT, "%u node classes: the table rows of a pod tile no longer fit 16-bit row offsets (512 KiB)", c->nx);
+        uint32_t staged = L.hot_bytes;
+        if (spill && w <= c->max_wcls && (size_t)L.hot_bytes + scratch > kLdsPerCu / 2) {
+            staged = (uint32_t)(kLdsPerCu / 2 - scratch - hp_bytes) & ~15u;
+            if (staged < L.hot_x + L.x_stride)
+                return fail(c, NHDFIT_E_LIMIT, "the fixed table rows of a pod tile need %u bytes of LDS: %u node-group sets, %u hugepage rows, "
+                            "%u cores per socket", L.hot_x + hp_bytes, c->ngs, c->hp_rows, c->max_cores);
+            staged = std::min(staged, L.hot_hp);
+        }
+        c->hot_staged[w] = staged;
+        if (w <= c->max_wcls) lds = std::max(lds, staged < L.hot_bytes ? staged + hp_bytes : L.hot_bytes);
+    }
     c->pitch = pitch;
-    c->lds_bytes = hot;
+    c->lds_bytes = lds;
+    c->x_spill = spill;
     if (c->P) {
         const uint32_t tiles = (c->P + kTile - 1) / kTile;
         for (int b = 0; b < kBufs; ++b) HIPCHK(c, c->tabs[b].reserve((size_t)tiles * pitch));
@@ -2101,9 +2163,9 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         if (!c->n_items) { int rc_ = build_items(c, nw); if (rc_) return rc_; }
         FitArgs& f = a.fit;
         for (int w = 0; w < kWClasses; ++w) {
-            f.rec[w] = c->rec[w].p; f.off_hot[w] = c->L[w].off_hot; f.hot_bytes[w] = c->L[w].hot_bytes; f.hot_hp[w] = c->L[w].hot_hp;
+            f.rec[w] = c->rec[w].p; f.off_hot[w] = c->L[w].off_hot; f.hot_bytes[w] = c->L[w].hot_bytes; f.hot_hp[w] = c->L[w].hot_hp; f.hot_staged[w] = c->hot_staged[w];
         }
-        f.hp_last = c->hp_rows - 1;
+        f.hp_last = c->hp_rows - 1; f.hp_bytes = align16(c->hp_rows * 8);
         f.p4 = c->p4.p;
         f.n = c->n; f.chunks = chunks; f.global_base = c->global_base; f.busy_from = busy_threshold(now);
         f.tabs = c->tabs[bf].p; f.pitch = c->pitch; f.hdr = c->hdr[bf].p; f.P = P;
@@ -2135,6 +2197,10 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
     const bool timed = (with_fit && (c->n_fit < 2 || (c->n_fit & 7) == 0)) || (!with_fit && with_digest);
     if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc) return rc; }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][0], c->stream));
+    if (c->x_spill) {               // more node classes than LDS rows: the variant whose fit role reads the rest from global memory
+        if (big) hipLaunchKernelGGL((k_step<512, true>), dim3(grid), dim3(512), lds, c->stream, a);
+        else     hipLaunchKernelGGL((k_step<256, true>), dim3(grid), dim3(256), lds, c->stream, a);
+    } else
     if (c->role_kernels) {
         const uint32_t nb[5] = {a.nb_choose, a.nb_shapes, a.nb_finish, a.nb_digest, nb_fit};
         if (nb[0]) hipLaunchKernelGGL((k_role<512, 0>), dim3(nb[0]), dim3(512), 0, c->stream, a);
