@@ -190,6 +190,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras and not inner:
         out["end_to_end"] = end_to_end(eng, reqs, now, args.pods, n_total)
         out["mode_b"] = mode_b(eng, pk, reqs, now, args.pods)
+        out["other_configs"] = other_configs(args, local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not inner:
         out["cpu_baseline"] = cpu_baseline(spec, tops, pod_groups, args.cpu_sample_pods, score, lo, winner_index, args)
     if rank == 0:
@@ -214,6 +215,46 @@ def end_to_end(eng, reqs, now, P, n_total):
     t = min(ts)
     return {"call": "nhdfit_find (stage + H2D + 5 launches + D2H of scores and mappings)", "ms_per_call": t * 1e3,
             "evals_per_s": P * n_total / t, "decisions_per_s": P / t}
+
+
+def other_configs(args, device):
+    """BASELINE.json's other shapes on one GPU, same step, same clock (not the headline; 60 steps each): config 2 whole
+    (4 096 nodes x 256 pods), config 3 whole (16 384 x 1 024), one config-5 shard (32 768 x 2 048: an eighth of its nodes, an
+    eighth of its pods).  Mode A step rate and the mode-B decision rate of each."""
+    from nhd_amd import pack
+    from nhd_amd.engine import Engine
+    from workload import refmodel, synth
+    rows = []
+    for cfg, n, P in ((2, 4096, 256), (3, 16384, 1024), (5, 32768, 2048)):
+        if (cfg, n, P) == (args.config, args.nodes_per_gpu, args.pods):
+            continue
+        spec = synth.make_cluster(cfg, n_nodes=n)
+        pods, groups = synth.make_pods(cfg, n_pods=P)
+        tops = [refmodel.make_topology(s) for s in pods]
+        pk = pack.Packer()
+        table = pk.planes_from_spec(spec)
+        reqs = pk.digest_many(tops, groups)
+        pk.close_signatures()
+        eng = Engine(device)
+        eng.set_dictionary(pk)
+        eng.upload(table)
+        eng.stage(reqs)
+        for _ in range(5):
+            eng.enqueue(spec.clock_now)
+        eng.sync()
+        steps = 60
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.enqueue(spec.clock_now)
+        eng.sync()
+        dt = time.perf_counter() - t0
+        score, _, _ = eng.fetch(want_bitmap=False, want_map=True)
+        mb = mode_b(eng, pk, reqs, spec.clock_now, P)
+        rows.append({"config": cfg, "nodes": n, "pods": P, "ms_per_step": dt * 1e3 / steps, "evals_per_s": float(P) * n * steps / dt,
+                     "placed_pods": int(np.count_nonzero(score)), "nic_signatures": len(pk.sigs),
+                     "mode_b_decisions_per_s": mb["decisions_per_s"], "mode_b_placed": mb["placed"]})
+        eng.close()
+    return rows
 
 
 def mode_b(eng, pk, reqs, now, P):
