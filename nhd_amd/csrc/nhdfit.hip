@@ -2221,7 +2221,7 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         c->ev_kind[c->ev_pending++] = with_fit ? 0 : 1;
     }
     if (a.role_clock) {
-        unsigned long long t[16];
+        unsigned long long t[10];
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
         unsigned long long first = ~0ull;

@@ -397,7 +397,9 @@ NHD_HD uint32_t ipow(int b, int e) { return b == 1 ? 1u : 1u << e; }   // b in {
 NHD_HD uint32_t nib_get(uint32_t v, int i) { return (v >> (4 * i)) & 15u; }
 NHD_HD uint32_t nib_set(uint32_t v, int i, uint32_t x) { return (v & ~(15u << (4 * i))) | (x << (4 * i)); }
 
-NHD_HD bool first_nic_choice(const nhdfit_req& r, const WinnerState& w, uint32_t gcode, bool pci, int8_t nic_idx[kMaxG]) {
+// the enumeration as the reference writes it: every combination until one passes (kept for requests the pruning of
+// first_nic_choice is not valid for)
+NHD_HD bool first_nic_choice_plain(const nhdfit_req& r, const WinnerState& w, uint32_t gcode, bool pci, int8_t nic_idx[kMaxG]) {
     const int G = (int)r.n_groups;
     uint32_t order = 0, numa = 0;                    // order: nibble pos -> group; numa: bit g -> NUMA of group g
     int n = 0;
@@ -443,6 +445,64 @@ NHD_HD bool first_nic_choice(const nhdfit_req& r, const WinnerState& w, uint32_t
             --pos;
         }
         if (pos < 0) return false;
+    }
+}
+
+NHD_HD bool first_nic_choice(const nhdfit_req& r, const WinnerState& w, uint32_t gcode, bool pci, int8_t nic_idx[kMaxG]) {
+    const int G = (int)r.n_groups;
+    uint32_t order = 0, numa = 0;                    // order: nibble pos -> group; numa: bit g -> NUMA of group g
+    int n = 0;
+    for (int u = 0; u < w.U; ++u)
+        for (int g = 0; g < G; ++g)
+            if (tup_digit(gcode, G, w.U, g) == u) { order = nib_set(order, n, (uint32_t)g); numa |= (uint32_t)u << g; ++n; }
+    for (int g = 0; g < G; ++g)
+        if (w.d->nic_cnt[(numa >> g) & 1] == 0) return false;
+    for (int g = 0; g < G; ++g)
+        if (!(r.rx[g] >= 0) || !(r.tx[g] >= 0)) return first_nic_choice_plain(r, w, gcode, pci, nic_idx);   // negative / NaN speeds: no pruning
+    // The reference walks itertools.product over the groups' NIC lists (groups ordered by NUMA node, then index; last
+    // group fastest) and takes the first combination that passes (Matcher.py:261-267, 312-322).  Both tests only get
+    // harder as groups are added - a NIC's head-room goes down with every subtraction (requests are >= 0; the groups of a
+    // NIC are subtracted in group order, which is the order they are assigned here), a switch's group count goes up - so
+    // a prefix that already fails has no valid completion: depth-first in the same order with that pruning returns the
+    // same first combination without visiting n^G of them when the leading NICs are claimed.
+    uint32_t pick = 0;                               // nibble g -> NIC ordinal chosen for group g
+    auto prefix_ok = [&](int pos) {                  // groups order[0..pos] assigned: does the newest one still fit?
+        const int g = (int)nib_get(order, pos);
+        const uint32_t u = (numa >> g) & 1, k = nib_get(pick, g);
+        double rx = w.caps[w.d->nic_cls[u][k]], tx = rx;
+        for (int q = 0; q <= pos; ++q) {             // same NUMA node => ascending group index along `order`
+            const int h = (int)nib_get(order, q);
+            if (((numa >> h) & 1) == u && nib_get(pick, h) == k) { rx = rx - r.rx[h]; tx = tx - r.tx[h]; }
+        }
+        if (rx < 0 || tx < 0) return false;                                      // Matcher.py:267
+        if (pci) {                                                               // Matcher.py:312-322
+            const uint32_t sw = w.d->nic_sw[u][k];
+            uint32_t cnt = 0;
+            for (int q = 0; q <= pos; ++q) {
+                const int h = (int)nib_get(order, q);
+                if (w.d->nic_sw[(numa >> h) & 1][nib_get(pick, h)] == sw) ++cnt;
+            }
+            if (cnt > w.d->sw_free[sw]) return false;
+        }
+        return true;
+    };
+    int pos = 0;
+    for (;;) {
+        if (prefix_ok(pos)) {
+            if (pos == G - 1) {
+                for (int g = 0; g < G; ++g) nic_idx[g] = (int8_t)nib_get(pick, g);
+                return true;
+            }
+            ++pos;                                    // next group starts at its first NIC (its nibble is 0)
+            continue;
+        }
+        for (;;) {                                    // next candidate: advance this digit, or back up
+            const int g = (int)nib_get(order, pos);
+            const uint32_t v = nib_get(pick, g) + 1;
+            if (v < w.d->nic_cnt[(numa >> g) & 1]) { pick = nib_set(pick, g, v); break; }
+            pick = nib_set(pick, g, 0);
+            if (--pos < 0) return false;
+        }
     }
 }
 

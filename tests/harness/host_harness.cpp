@@ -394,3 +394,17 @@ int hh_choose_generic(int G, int U, uint32_t sg, uint32_t sc, uint32_t nic, uint
 }
 
 }  // extern "C"
+
+// first_nic_choice (depth-first with prefix pruning) next to the plain enumeration it replaces, on one fabricated
+// winner: returns (found_pruned) | (found_plain << 1); the picks go to out_pruned / out_plain.
+extern "C" int hh_first_nic_choice(const nhdfit_req* r, const nhdfit_detail* d, const double* caps, uint32_t gcode, int pci,
+                                   int8_t* out_pruned, int8_t* out_plain) {
+    WinnerState w{};
+    w.U = d->numa_nodes;
+    w.d = d;
+    w.caps = caps;
+    for (int g = 0; g < kMaxG; ++g) out_pruned[g] = out_plain[g] = -1;
+    const bool a = first_nic_choice(*r, w, gcode, pci != 0, out_pruned);
+    const bool b = first_nic_choice_plain(*r, w, gcode, pci != 0, out_plain);
+    return (a ? 1 : 0) | (b ? 2 : 0);
+}
