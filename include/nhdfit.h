@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NHDFIT_ABI_VERSION        4
+#define NHDFIT_ABI_VERSION        5
 #define NHDFIT_MAX_GROUPS         4      /* proc groups per pod (G)                               */
 #define NHDFIT_MAX_NUMA           2      /* NUMA nodes (= sockets, nhd/Node.py:336) per node (U)  */
 #define NHDFIT_MAX_CORES_PER_NUMA 64     /* physical cores per socket (one uint64 mask)           */
@@ -91,9 +91,53 @@ typedef struct {
     uint8_t nic_sw[NHDFIT_MAX_NUMA][NHDFIT_MAX_NICS_PER_NUMA];     /* local switch id of NIC (numa, idx), nhd/Node.py:275 */
     uint8_t numa_nodes;                                            /* Node.numa_nodes (1 or 2)                            */
     uint8_t n_gpus;                                                /* len(Node.gpus)                                      */
-    uint8_t pad[14];
+    uint8_t nic_pods[12];                                          /* Node.nics[].pods_used as 32 three-bit counters, NIC (numa, idx)
+                                                                      = counter numa*16+idx, two's complement -3 .. 3; the pattern
+                                                                      4 = out of range, sticky: the host re-packs the node
+                                                                      (NHDFIT_DELTA_REPACK).  nhd/Node.py:292,644-646            */
+    uint8_t pad[2];
     uint8_t gpu_sw[NHDFIT_MAX_GPUS];                               /* local switch id of Node.gpus[g] (commit step, nhd/Node.py:648-655) */
 } nhdfit_detail;                                                   /* 128 bytes */
+
+/* cold per-node record no commit changes: what ResetResources goes back to (nhd/Node.py:144-161) and each NIC's own
+ * capacity class (its class whenever pods_used <= 0, nhd/Node.py:292) */
+typedef struct {
+    uint64_t t0[NHDFIT_MAX_NUMA], t1[NHDFIT_MAX_NUMA];             /* planes 0 / 1 with every core outside reserved_cores unused */
+    uint8_t  nic_base[NHDFIT_MAX_NUMA][NHDFIT_MAX_NICS_PER_NUMA];  /* capacity class of speed * 0.9 of NIC (numa, idx)           */
+    int32_t  hp_total;                                             /* Node.mem.ttl_hugepages_gb                                   */
+    uint8_t  pad[12];
+} nhdfit_origin;                                                   /* 80 bytes */
+
+/* ---- one change of a node outside the commit step ("K3 delta update"): the scheduler's
+ * release / reclaim paths and its writes to scalar node fields, applied to the device mirror in place of re-packing
+ * and re-uploading the node.  The host turns the ids a CfgTopology holds into masks over the planes. */
+#define NHDFIT_DELTA_TAKE          1u   /* Node.RemoveResourcesFromTopology  nhd/Node.py:530-585 (start-up replay, NHDScheduler.py:135) */
+#define NHDFIT_DELTA_GIVE          2u   /* Node.AddResourcesFromTopology     nhd/Node.py:587-636 (pod deleted, NHDScheduler.py:203)     */
+#define NHDFIT_DELTA_RESET         3u   /* Node.ResetResources               nhd/Node.py:144-161                                        */
+#define NHDFIT_DELTA_SET_FLAGS     4u   /* node.active / node.maintenance    nhd/NHDScheduler.py:533-566                                */
+#define NHDFIT_DELTA_SET_GROUPS    5u   /* Node.SetGroups                    nhd/Node.py:308-310, NHDScheduler.py:570                   */
+#define NHDFIT_DELTA_SET_BUSY      6u   /* Node.SetBusy / busy_time          nhd/Node.py:843-845                                        */
+#define NHDFIT_DELTA_SET_HUGEPAGES 7u   /* Node.SetHugepages(alloc, free)    nhd/Node.py:489-493                                        */
+#define NHDFIT_DELTA_MAX_NICS      15
+typedef struct {
+    uint32_t node;                           /* local index in the mirror                                                     */
+    uint32_t op;                             /* NHDFIT_DELTA_*                                                                 */
+    uint64_t t0[NHDFIT_MAX_NUMA], t1[NHDFIT_MAX_NUMA];   /* TAKE / GIVE: the cores the topology names, as bits of planes 0 / 1   */
+    uint32_t gpus;                           /* TAKE / GIVE: bit x = Node.gpus[x] named by a group_gpus entry (by device id)      */
+    int32_t  hugepages_gb;                   /* TAKE / GIVE: top.hugepages_gb (applied when > 0); SET_HUGEPAGES: the new free count */
+    int32_t  hp_total;                       /* SET_HUGEPAGES: alloc                                                           */
+    uint32_t flags_mask, flags_value;        /* SET_FLAGS: which of NHDFIT_NF_MAINTENANCE / NHDFIT_NF_ACTIVE, and their values   */
+    uint32_t group_set;                      /* SET_GROUPS: id of the interned set                                             */
+    uint64_t groups;                         /* SET_GROUPS: interned bits                                                      */
+    double   busy_time;                      /* SET_BUSY                                                                       */
+    uint8_t  nic_n;                          /* TAKE / GIVE: nic_core_pairing entries whose MAC is one of the node's NICs       */
+    uint8_t  nic[NHDFIT_DELTA_MAX_NICS];     /* (numa << 4) | idx per entry: pods_used +1 / -1 each (a NIC may repeat)          */
+} nhdfit_delta;                              /* 96 bytes */
+#define NHDFIT_DELTA_OK      0
+#define NHDFIT_DELTA_REPACK  1   /* a pods_used counter left the range the packed form tracks: only the Node object knows the
+                                    NIC's state now - re-pack and upload the node                                            */
+#define NHDFIT_DELTA_NEW_SIG 2   /* applied, but the node's new NIC state has no signature in the dictionary yet: intern it
+                                    (download the node, re-derive its signatures - or re-pack it) and upload its plane 3     */
 
 /* ---- NIC signature dictionary (cluster-wide, interned by the host packer) ----------------- */
 typedef struct { uint8_t cls; uint8_t cnt; } nhdfit_cc;           /* cnt NICs (capped at NHDFIT_MAX_GROUPS) of capacity class cls */
@@ -198,6 +242,13 @@ int nhdfit_upload_nodes(nhdfit_ctx* ctx, uint32_t first, uint32_t count,
                         const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2,
                         const nhdfit_plane3* p3, const nhdfit_plane4* p4, const nhdfit_detail* detail);
 int nhdfit_set_node_count(nhdfit_ctx* ctx, uint32_t n_nodes);
+
+/* The nhdfit_origin records of nodes [first, first+count) (needed by nhdfit_apply_deltas; uploaded next to the planes). */
+int nhdfit_upload_origin(nhdfit_ctx* ctx, uint32_t first, uint32_t count, const nhdfit_origin* origin);
+
+/* K3: apply `n` deltas to the mirror, in array order (deltas of one node keep their order; different nodes are independent).
+ * Runs on the context's stream behind every step in flight; blocks until status_out (n bytes, NHDFIT_DELTA_*) is on the host. */
+int nhdfit_apply_deltas(nhdfit_ctx* ctx, const nhdfit_delta* deltas, uint32_t n, uint8_t* status_out);
 
 /* Read node records back (after device-side commits). */
 int nhdfit_download_nodes(nhdfit_ctx* ctx, uint32_t first, uint32_t count,

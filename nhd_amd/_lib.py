@@ -36,6 +36,8 @@ _SIGS = {
     "nhdfit_reserve_nodes": (c_int, [c_void_p, c_uint32, c_uint64]),
     "nhdfit_upload_nodes": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nhdfit_set_node_count": (c_int, [c_void_p, c_uint32]),
+    "nhdfit_upload_origin": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p]),
+    "nhdfit_apply_deltas": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p]),
     "nhdfit_find": (c_int, [c_void_p, c_void_p, c_uint32, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nhdfit_find_sequential": (c_int, [c_void_p, c_void_p, c_uint32, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nhdfit_schedule_batch": (c_int, [c_void_p, c_void_p, c_uint32, c_double, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -28,6 +28,7 @@
 namespace nhdfit {
 
 constexpr int kCommitOk = 0, kCommitWouldRaise = 1, kCommitNewSig = 2;
+static_assert(sizeof(nhdfit_detail) == 128 && sizeof(nhdfit_origin) == 80 && sizeof(nhdfit_delta) == 96, "record sizes of include/nhdfit.h");
 
 struct NodeState {                   // registers / LDS copy of one node while it is modified
     nhdfit_plane0 p0; nhdfit_plane1 p1; nhdfit_plane2 p2; nhdfit_plane3 p3; nhdfit_plane4 p4;
@@ -114,6 +115,32 @@ NHD_HD bool sig_lookup(const SigTable& t, uint64_t key, uint32_t& id) {
     return false;
 }
 
+// Node.nics[].pods_used next to the capacity classes: 32 three-bit counters in the detail record (include/nhdfit.h),
+// two's complement -3 .. 3 (an all-zero record = no pod on any NIC), the bit pattern 4 = out of range (sticky).
+// pods_add returns +1 (pods_used > 0 afterwards: capacity 0), 0 (pods_used <= 0: the NIC's own capacity, nhd/Node.py:292)
+// or -1 (out of range: only the Node object knows - treated as used here; the delta path reports NHDFIT_DELTA_REPACK
+// and the host re-packs the node).
+constexpr uint32_t kPodsLost = 4;
+NHD_HD uint32_t pods_get(const nhdfit_detail& d, uint32_t u, uint32_t k) {
+    const uint32_t bit = 3 * (u * NHDFIT_MAX_NICS_PER_NUMA + k), by = bit >> 3, sh = bit & 7;
+    const uint32_t w = (uint32_t)d.nic_pods[by] | (by + 1 < sizeof d.nic_pods ? (uint32_t)d.nic_pods[by + 1] << 8 : 0u);
+    return (w >> sh) & 7u;
+}
+NHD_HD void pods_set(nhdfit_detail& d, uint32_t u, uint32_t k, uint32_t v) {
+    const uint32_t bit = 3 * (u * NHDFIT_MAX_NICS_PER_NUMA + k), by = bit >> 3, sh = bit & 7;
+    const uint32_t m = 7u << sh, x = (v & 7u) << sh;
+    d.nic_pods[by] = (uint8_t)((d.nic_pods[by] & ~m) | x);
+    if (sh > 5 && by + 1 < sizeof d.nic_pods) d.nic_pods[by + 1] = (uint8_t)((d.nic_pods[by + 1] & ~(m >> 8)) | (x >> 8));
+}
+NHD_HD int pods_add(nhdfit_detail& d, uint32_t u, uint32_t k, int delta) {
+    const uint32_t cur = pods_get(d, u, k);
+    if (cur == kPodsLost) return -1;
+    const int nv = (cur < 4 ? (int)cur : (int)cur - 8) + delta;
+    if (nv < -3 || nv > 3) { pods_set(d, u, k, kPodsLost); return -1; }
+    pods_set(d, u, k, (uint32_t)nv & 7u);
+    return nv > 0 ? 1 : 0;
+}
+
 // One placement on one node.  `s` / `d` are modified in place; `out` receives the physical ids.
 NHD_HD int commit_node(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, const nhdfit_mapping& m, double busy_time,
                        const SigTable& sigs, nhdfit_placement& out) {
@@ -156,9 +183,9 @@ NHD_HD int commit_node(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, cons
     const uint32_t mu = (uint32_t)m.cpu[G] & 1u;
     out.numa[kMaxG] = (int8_t)mu;
     if (!take_batch(s, mu, r.n_misc, r.misc_smt_enabled != 0, out.misc_take, out.misc_pair)) status = kCommitWouldRaise;   // Node.py:799
-    for (uint32_t k = 0; k < (uint32_t)NHDFIT_MAX_NICS_PER_NUMA; ++k) {                 // ClaimPodNICResources: capacity class 0 = 0.0
-        if (claimed0 >> k & 1) d.nic_cls[0][k] = 0;
-        if (claimed1 >> k & 1) d.nic_cls[1][k] = 0;
+    for (uint32_t k = 0; k < (uint32_t)NHDFIT_MAX_NICS_PER_NUMA; ++k) {                 // ClaimPodNICResources: pods_used += 1; capacity
+        if (claimed0 >> k & 1) { if (pods_add(d, 0, k, 1) != 0) d.nic_cls[0][k] = 0; }  // class 0 = 0.0 while pods_used > 0 (Node.py:292)
+        if (claimed1 >> k & 1) { if (pods_add(d, 1, k, 1) != 0) d.nic_cls[1][k] = 0; }
     }
     // the node's NIC signatures under the new NIC / GPU state (a NUMA node without a claim keeps its ids unless a GPU
     // was taken: the free-GPU count behind a switch enters the PCI-mode pools)
@@ -172,6 +199,84 @@ NHD_HD int commit_node(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, cons
         s.p3.sig_pci[u] = (uint16_t)idp;
     }
     out.status = (uint8_t)status;
+    return status;
+}
+
+// ---- K3: one delta on one node ---------------------------------------------------------
+// free GPUs behind every local switch, from the free mask (what pack_node_into counts, nhd/Node.py:266-273)
+NHD_HD void recount_sw_free(const NodeState& s, nhdfit_detail& d) {
+    for (uint32_t k = 0; k < (uint32_t)NHDFIT_MAX_SWITCHES; ++k) d.sw_free[k] = 0;
+    for (uint32_t x = 0; x < d.n_gpus && x < (uint32_t)NHDFIT_MAX_GPUS; ++x)
+        if (s.p2.gpu_free >> x & 1) d.sw_free[d.gpu_sw[x]]++;
+}
+// signature ids of both NUMA nodes from the detail record; false = a state the dictionary does not hold
+NHD_HD bool resign(NodeState& s, const nhdfit_detail& d, const SigTable& sigs) {
+    bool ok = true;
+    for (uint32_t u = 0; u < 2; ++u) {
+        uint64_t kn, kp;
+        uint32_t idn = 0, idp = 0;
+        sig_keys_of(d, u, kn, kp);
+        if (!sig_lookup(sigs, kn, idn) || !sig_lookup(sigs, kp, idp)) ok = false;
+        s.p3.sig_numa[u] = (uint16_t)idn;
+        s.p3.sig_pci[u] = (uint16_t)idp;
+    }
+    return ok;
+}
+// RemoveResourcesFromTopology / AddResourcesFromTopology / ResetResources / the scalar setters on the packed state
+// (nhd/Node.py:530-636, 144-161, 308-310, 489-493, 843-845; nhd/NHDScheduler.py:533-570).  `o` may be written by
+// SET_HUGEPAGES (ttl_hugepages_gb).  Returns NHDFIT_DELTA_*.
+NHD_HD int apply_delta(NodeState& s, nhdfit_detail& d, nhdfit_origin& o, const nhdfit_delta& q, const SigTable& sigs) {
+    int status = NHDFIT_DELTA_OK;
+    bool nic_or_gpu = false;
+    switch (q.op) {
+    case NHDFIT_DELTA_TAKE:
+    case NHDFIT_DELTA_GIVE: {
+        const bool take = q.op == NHDFIT_DELTA_TAKE;
+        const bool smt = (s.p2.flags & NHDFIT_NF_SMT) != 0;
+        for (uint32_t u = 0; u < 2; ++u) {                           // cores[..].used = True / False
+            if (take) { s.p0.t0[u] &= ~q.t0[u]; if (smt) s.p1.t1[u] &= ~q.t1[u]; }
+            else      { s.p0.t0[u] |= q.t0[u];  if (smt) s.p1.t1[u] |= q.t1[u]; }
+        }
+        const uint32_t all = d.n_gpus >= 32 ? 0xFFFFFFFFu : (1u << d.n_gpus) - 1u;
+        const uint32_t g = q.gpus & all;
+        if (g) {                                                     // GetGPU(device_id).used = True / False
+            s.p2.gpu_free = take ? s.p2.gpu_free & ~g : s.p2.gpu_free | g;
+            recount_sw_free(s, d);
+            nic_or_gpu = true;
+        }
+        for (uint32_t i = 0; i < q.nic_n && i < (uint32_t)NHDFIT_DELTA_MAX_NICS; ++i) {   // nic_core_pairing: pods_used +- 1
+            const uint32_t u = q.nic[i] >> 4 & 1u, k = q.nic[i] & 15u;
+            if (k >= d.nic_cnt[u]) continue;
+            const int r = pods_add(d, u, k, take ? 1 : -1);
+            if (r < 0) status = NHDFIT_DELTA_REPACK;
+            d.nic_cls[u][k] = r == 0 ? o.nic_base[u][k] : 0;
+            nic_or_gpu = true;
+        }
+        if (q.hugepages_gb > 0) s.p2.hp_free = take ? s.p2.hp_free - q.hugepages_gb : s.p2.hp_free + q.hugepages_gb;
+        break;
+    }
+    case NHDFIT_DELTA_RESET: {
+        const bool smt = (s.p2.flags & NHDFIT_NF_SMT) != 0;
+        for (uint32_t u = 0; u < 2; ++u) { s.p0.t0[u] = o.t0[u]; if (smt) s.p1.t1[u] = o.t1[u]; }
+        s.p2.gpu_free = d.n_gpus >= 32 ? 0xFFFFFFFFu : (1u << d.n_gpus) - 1u;
+        recount_sw_free(s, d);
+        for (uint32_t u = 0; u < 2; ++u)
+            for (uint32_t k = 0; k < d.nic_cnt[u]; ++k) { pods_set(d, u, k, 0); d.nic_cls[u][k] = o.nic_base[u][k]; }
+        s.p2.hp_free = o.hp_total;
+        nic_or_gpu = true;
+        break;
+    }
+    case NHDFIT_DELTA_SET_FLAGS: {
+        const uint32_t m = q.flags_mask & (NHDFIT_NF_MAINTENANCE | NHDFIT_NF_ACTIVE);
+        s.p2.flags = (s.p2.flags & ~m) | (q.flags_value & m);
+        break;
+    }
+    case NHDFIT_DELTA_SET_GROUPS: s.p3.groups = q.groups; s.p4.group_set = q.group_set; break;
+    case NHDFIT_DELTA_SET_BUSY: s.p4.busy_time = q.busy_time; break;
+    case NHDFIT_DELTA_SET_HUGEPAGES: s.p2.hp_free = q.hugepages_gb; o.hp_total = q.hp_total; break;
+    default: status = NHDFIT_DELTA_REPACK; break;
+    }
+    if (nic_or_gpu && !resign(s, d, sigs) && status == NHDFIT_DELTA_OK) status = NHDFIT_DELTA_NEW_SIG;
     return status;
 }
 

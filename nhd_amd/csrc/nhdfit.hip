@@ -1462,6 +1462,28 @@ __global__ __launch_bounds__(64) void k_undo(SeqArgs a) {
     if (lane >= 8 && lane < 16) reinterpret_cast<uint4*>(a.det + v)[lane - 8] = reinterpret_cast<const uint4*>(&u.d)[lane - 8];
 }
 
+// K3 (nhdfit_apply_deltas): one lane per run of deltas that name the same node (the host sorts the array by node,
+// keeping the order inside a node): load the node, apply the run in order, store it.  Runs are independent.
+struct DeltaArgs {
+    nhdfit_plane0* p0; nhdfit_plane1* p1; nhdfit_plane2* p2; nhdfit_plane3* p3; nhdfit_plane4* p4; nhdfit_detail* det;
+    nhdfit_origin* origin;
+    const nhdfit_delta* deltas; const uint32_t* run; uint32_t n_runs;     // run[r] .. run[r+1]: deltas of one node
+    SigTable sigs; uint8_t* status;
+};
+__global__ __launch_bounds__(64) void k_delta(DeltaArgs a) {
+    const uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= a.n_runs) return;
+    const uint32_t lo = a.run[r], hi = a.run[r + 1], v = a.deltas[lo].node;
+    NodeState s;
+    s.p0 = a.p0[v]; s.p1 = a.p1[v]; s.p2 = a.p2[v]; s.p3 = a.p3[v]; s.p4 = a.p4[v];
+    nhdfit_detail d = a.det[v];
+    nhdfit_origin o = a.origin[v];
+    for (uint32_t k = lo; k < hi; ++k) a.status[k] = (uint8_t)apply_delta(s, d, o, a.deltas[k], a.sigs);
+    a.p0[v] = s.p0; a.p1[v] = s.p1; a.p2[v] = s.p2; a.p3[v] = s.p3; a.p4[v] = s.p4;
+    a.det[v] = d;
+    a.origin[v] = o;
+}
+
 // the commit step for one placement (nhdfit_commit)
 struct CommitArgs {
     nhdfit_plane0* p0; nhdfit_plane1* p1; nhdfit_plane2* p2; nhdfit_plane3* p3; nhdfit_plane4* p4; nhdfit_detail* det;
@@ -1561,6 +1583,8 @@ struct nhdfit_ctx {
     // node mirror
     DevBuf<nhdfit_plane0> p0; DevBuf<nhdfit_plane1> p1; DevBuf<nhdfit_plane2> p2;
     DevBuf<nhdfit_plane3> p3; DevBuf<nhdfit_plane4> p4; DevBuf<nhdfit_detail> det;
+    DevBuf<nhdfit_origin> origin; uint32_t origin_hi = 0;   // nhdfit_upload_origin: records [0, origin_hi) are there
+    DevBuf<nhdfit_delta> deltas; DevBuf<uint32_t> delta_run; DevBuf<uint8_t> delta_status;
     uint32_t n = 0, capacity = 0;
     uint64_t global_base = 0;
 
@@ -1760,6 +1784,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     (void)hipDeviceSynchronize();
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
+    c->origin.release(); c->deltas.release(); c->delta_run.release(); c->delta_status.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
     c->reqs.release(); c->bitmap.release(); c->nm.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); c->shape_list[b].release(); }
@@ -1864,6 +1889,7 @@ int nhdfit_reserve_nodes(nhdfit_ctx* c, uint32_t capacity, uint64_t global_base)
         const size_t padded = ((size_t)capacity + 63) & ~size_t(63);       // the fit role reads whole 64-node chunks
         HIPCHK(c, c->p0.reserve(padded)); HIPCHK(c, c->p1.reserve(padded)); HIPCHK(c, c->p2.reserve(padded));
         HIPCHK(c, c->p3.reserve(padded)); HIPCHK(c, c->p4.reserve(padded)); HIPCHK(c, c->det.reserve(capacity));
+        HIPCHK(c, c->origin.reserve(capacity)); c->origin_hi = 0;
         for (auto& r : c->rec) HIPCHK(c, r.reserve(padded));
         HIPCHK(c, hipMemset(c->p4.p, 0, padded * sizeof(nhdfit_plane4)));   // busy times of the padding lanes: any finite value
         c->capacity = capacity;
@@ -2498,6 +2524,63 @@ int nhdfit_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_req* req, const nhd
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->rec_lo == c->rec_hi) { c->rec_lo = node; c->rec_hi = node + 1; }
     else { c->rec_lo = std::min(c->rec_lo, node); c->rec_hi = std::max(c->rec_hi, node + 1); }
+    return NHDFIT_OK;
+}
+
+int nhdfit_upload_origin(nhdfit_ctx* c, uint32_t first, uint32_t count, const nhdfit_origin* origin) {
+    if (!c) return NHDFIT_E_INVAL;
+    if (!count) return NHDFIT_OK;
+    if (!origin) return fail(c, NHDFIT_E_INVAL, "NULL origin");
+    if ((uint64_t)first + count > c->capacity) return fail(c, NHDFIT_E_INVAL, "upload [%u,%u) exceeds capacity %u", first, first + count, c->capacity);
+    if (first > c->origin_hi) return fail(c, NHDFIT_E_INVAL, "origin records [%u,%u) are missing", c->origin_hi, first);
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                  // a delta kernel in flight may still write its records
+    HIPCHK(c, hipMemcpy(c->origin.p + first, origin, count * sizeof *origin, hipMemcpyHostToDevice));
+    c->origin_hi = std::max(c->origin_hi, first + count);
+    return NHDFIT_OK;
+}
+
+int nhdfit_apply_deltas(nhdfit_ctx* c, const nhdfit_delta* deltas, uint32_t n, uint8_t* status_out) {
+    if (!c) return NHDFIT_E_INVAL;
+    if (!n) return NHDFIT_OK;
+    if (!deltas || !status_out) return fail(c, NHDFIT_E_INVAL, "deltas / status_out is NULL");
+    if (c->origin_hi < c->n) return fail(c, NHDFIT_E_STATE, "upload the origin records first (nhdfit_upload_origin)");
+    // runs of one node, in array order inside a node (stable sort by node)
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (deltas[i].node >= c->n) return fail(c, NHDFIT_E_INVAL, "delta %u: node %u out of range (%u nodes)", i, deltas[i].node, c->n);
+        if (deltas[i].op < NHDFIT_DELTA_TAKE || deltas[i].op > NHDFIT_DELTA_SET_HUGEPAGES) return fail(c, NHDFIT_E_INVAL, "delta %u: unknown op %u", i, deltas[i].op);
+        if (deltas[i].nic_n > NHDFIT_DELTA_MAX_NICS) return fail(c, NHDFIT_E_INVAL, "delta %u: %u NIC entries", i, (unsigned)deltas[i].nic_n);
+        order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return deltas[x].node < deltas[y].node; });
+    std::vector<nhdfit_delta> sorted(n);
+    std::vector<uint32_t> run;
+    uint32_t lo = ~0u, hi = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        sorted[i] = deltas[order[i]];
+        if (i == 0 || sorted[i].node != sorted[i - 1].node) run.push_back(i);
+        lo = std::min(lo, sorted[i].node); hi = std::max(hi, sorted[i].node + 1);
+    }
+    const uint32_t n_runs = (uint32_t)run.size();
+    run.push_back(n);
+    HIPCHK(c, hipSetDevice(c->dev));
+    { int rc_ = flush_pipeline(c); if (rc_) return rc_; }       // mapping phases of steps in flight read the nodes as they were matched
+    HIPCHK(c, c->deltas.reserve(n)); HIPCHK(c, c->delta_run.reserve(run.size())); HIPCHK(c, c->delta_status.reserve(n));
+    HIPCHK(c, hipMemcpyAsync(c->deltas.p, sorted.data(), n * sizeof(nhdfit_delta), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->delta_run.p, run.data(), run.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    DeltaArgs da;
+    memset(&da, 0, sizeof da);
+    da.p0 = c->p0.p; da.p1 = c->p1.p; da.p2 = c->p2.p; da.p3 = c->p3.p; da.p4 = c->p4.p; da.det = c->det.p; da.origin = c->origin.p;
+    da.deltas = c->deltas.p; da.run = c->delta_run.p; da.n_runs = n_runs; da.sigs = sig_table(c); da.status = c->delta_status.p;
+    hipLaunchKernelGGL(k_delta, dim3((n_runs + 63) / 64), dim3(64), 0, c->stream, da);
+    HIPCHK(c, hipGetLastError());
+    std::vector<uint8_t> st(n);
+    HIPCHK(c, hipMemcpyAsync(st.data(), c->delta_status.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                  // (also keeps `sorted` / `run` alive until the copies are done)
+    for (uint32_t i = 0; i < n; ++i) status_out[order[i]] = st[i];
+    if (c->rec_lo == c->rec_hi) { c->rec_lo = lo; c->rec_hi = hi; }
+    else { c->rec_lo = std::min(c->rec_lo, lo); c->rec_hi = std::max(c->rec_hi, hi); }
     return NHDFIT_OK;
 }
 

@@ -60,8 +60,19 @@ class Engine:
         self._chk(self.lib.nhdfit_reserve_nodes(self.ctx, cap, global_base))
         arrs = [np.ascontiguousarray(x) for x in (table.p0, table.p1, table.p2, table.p3, table.p4, table.detail)]
         self._chk(self.lib.nhdfit_upload_nodes(self.ctx, first, table.n, *[_p(a) for a in arrs]))
+        if table.origin is not None and table.n:
+            self._chk(self.lib.nhdfit_upload_origin(self.ctx, first, table.n, _p(np.ascontiguousarray(table.origin))))
         self.n = max(self.n, first + table.n)
         self.global_base = global_base
+
+    def apply_deltas(self, deltas: np.ndarray) -> np.ndarray:
+        """K3 (nhdfit_apply_deltas): release / reclaim / reset / scalar writes applied to the device mirror in array order.
+        `deltas["node"]` = local index.  Returns the per-delta status (pack.DELTA_OK / DELTA_REPACK)."""
+        deltas = np.ascontiguousarray(deltas, dtype=pack.DELTA).reshape(-1)
+        status = np.zeros(len(deltas), np.uint8)
+        if len(deltas):
+            self._chk(self.lib.nhdfit_apply_deltas(self.ctx, _p(deltas), len(deltas), _p(status)))
+        return status
 
     def reset_nodes(self):
         self._chk(self.lib.nhdfit_set_node_count(self.ctx, 0))
@@ -405,6 +416,18 @@ class GroupEngine:
     def commit(self, node: int, req, mapping, busy_time):
         k = self._shard_of(node)
         return self.shards[k].commit(node - self._bounds[k][0], req, mapping, busy_time)
+
+    def apply_deltas(self, deltas: np.ndarray) -> np.ndarray:
+        """Deltas with GLOBAL node indices, routed to the shards that own the nodes (order kept per shard)."""
+        deltas = np.ascontiguousarray(deltas, dtype=pack.DELTA).reshape(-1)
+        status = np.zeros(len(deltas), np.uint8)
+        owner = np.array([self._shard_of(int(v)) for v in deltas["node"]], dtype=np.int64)
+        for k in np.unique(owner):
+            sel = np.flatnonzero(owner == k)
+            part = deltas[sel].copy()
+            part["node"] -= self._bounds[int(k)][0]
+            status[sel] = self.shards[int(k)].apply_deltas(part)
+        return status
 
     def download(self, first: int = 0, count: Optional[int] = None) -> pack.NodeTable:
         count = self.n - first if count is None else count

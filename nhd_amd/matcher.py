@@ -69,11 +69,21 @@ def _tracked_class(base: type) -> type:
                     if hook is not None:
                         # the commit step of AttemptScheduling (nhd/NHDScheduler.py:289-304) is mirrored on the device
                         # instead of re-packing the node: see HipMatcher._on_commit / _on_claim
+                        # and so are the release / reclaim / reset paths and SetHugepages (row f2: nhdfit_apply_deltas)
                         done = False
+                        owner = self.__dict__["_nhdfit_owner"]
                         if ok and name == "SetPhysicalIdsFromMapping":
-                            done = self.__dict__["_nhdfit_owner"]._on_commit(self, *a, **kw)
+                            done = owner._on_commit(self, *a, **kw)
                         elif ok and name == "ClaimPodNICResources":
-                            done = self.__dict__["_nhdfit_owner"]._on_claim(self, *a, **kw)
+                            done = owner._on_claim(self, *a, **kw)
+                        elif ok and name in ("RemoveResourcesFromTopology", "AddResourcesFromTopology"):
+                            done = owner._on_topology(self, name, *a, **kw)
+                        elif ok and name == "ResetResources":
+                            done = owner._on_queued_scalar(self, "reset")
+                        elif ok and name == "SetHugepages":
+                            done = owner._on_queued_scalar(self, "hugepages")
+                        elif ok and name == "SetGroups":
+                            done = True                              # the assignment to .groups inside it was seen by __setattr__
                         if not done:
                             hook(self, name)
             wrapper.__name__ = orig.__name__
@@ -137,6 +147,8 @@ class HipMatcher:
         self._reasons: Dict[str, set] = {}
         self._claims: Dict[str, frozenset] = {}
         self._batch_ids: Dict[str, list] = {}              # ScheduleBatch(apply=True): ids the device already committed, per node, in order
+        self._deltas: List[np.ndarray] = []                # release / reclaim / reset / SetHugepages waiting for the device, in call order
+        self.delta_stats = {"applied": 0, "repacked": 0}
         self._uploaded_ids: Optional[Tuple[int, ...]] = None
 
     # ---- mirror maintenance -------------------------------------------------------------
@@ -154,6 +166,7 @@ class HipMatcher:
         self.engine.set_dictionary(self.packer)
         self._dirty.clear()
         self._reasons.clear()
+        self._deltas = []
         self._claims = {}
 
     def detach(self) -> None:
@@ -202,6 +215,10 @@ class HipMatcher:
             self._batch_ids.pop(node.name, None)
             return False
         pending = self._batch_ids.get(node.name)
+        if not pending and self._deltas:
+            self._flush_deltas()                               # releases queued before this commit reach the device first
+            if node.name in self._dirty_strict:
+                return False
         if pending:                                            # ScheduleBatch(apply=True) committed this placement on the device already
             ids = pending.pop(0)
             if not pending:
@@ -224,13 +241,58 @@ class HipMatcher:
                 numa, idx = mapping["nic"][gi]
                 claim.add(next(k for k, n in enumerate(node.nics) if n.idx == idx and n.numa_node == numa))
         self._claims[node.name] = frozenset(claim)             # the device already zeroed these NICs' capacities
-        self._dirty.pop(node.name, None)                       # SetBusy marked it: the commit carried the busy time
-        self._reasons.pop(node.name, None)
+        left = self._reasons.get(node.name, set()) - {"busy_time", "SetBusy"}    # SetBusy marked it: the commit carried the busy time
+        if left:
+            self._reasons[node.name] = left                    # cordon / maintenance / groups written earlier still go out as deltas
+        else:
+            self._dirty.pop(node.name, None)
+            self._reasons.pop(node.name, None)
         return True
 
     def _on_claim(self, node, nidx) -> bool:
         want = self._claims.pop(node.name, None) if hasattr(self, "_claims") else None
         return want is not None and frozenset(nidx) == want
+
+    # ---- release / reclaim / reset mirrored on the device (row f2, "K3") ---------------------
+    _SCALAR_REASONS = frozenset(("active", "maintenance", "groups", "busy_time", "SetBusy", "SetGroups"))
+
+    def _on_topology(self, node, name, top) -> bool:
+        """After the reference's RemoveResourcesFromTopology / AddResourcesFromTopology ran on an attached node: the same
+        change as a delta record for nhdfit_apply_deltas (sent with the next flush).  True = no re-pack needed."""
+        if self._attached is None or node.name not in self._index or node.name in self._dirty_strict:
+            return False
+        try:
+            op = pack.DELTA_TAKE if name == "RemoveResourcesFromTopology" else pack.DELTA_GIVE
+            self._deltas.append(self.packer.delta_from_topology(self._index[node.name], node, top, op))
+        except Exception:  # noqa: BLE001 - any doubt (ids outside the node ...): re-pack
+            return False
+        return True
+
+    def _on_queued_scalar(self, node, what: str) -> bool:
+        if self._attached is None or node.name not in self._index or node.name in self._dirty_strict:
+            return False
+        self._deltas.append(self.packer.delta_scalar(self._index[node.name], node, what))
+        return True
+
+    def _flush_deltas(self) -> None:
+        """Queued deltas -> device.  A node whose delta comes back with a status (pods_used out of the tracked range, NIC
+        state without a signature) is re-packed from its object like any other dirty node."""
+        if not self._deltas:
+            return
+        strict = self._dirty_strict
+        q = [d for d in self._deltas if self._names[int(d["node"])] not in strict]
+        self._deltas = []
+        if not q:
+            return
+        self.engine.set_dictionary(self.packer)            # a SetGroups may have interned a new group set
+        status = self.engine.apply_deltas(np.array(q, dtype=pack.DELTA))
+        self.delta_stats["applied"] += len(q)
+        for d, st in zip(q, status):
+            if st != pack.DELTA_OK:
+                name = self._names[int(d["node"])]
+                if name not in self._dirty_strict:
+                    self.delta_stats["repacked"] += 1
+                self._mark(self._attached[name], "delta-status")
 
     def _mark(self, node, reason: str = "") -> None:
         self._dirty[node.name] = node
@@ -238,8 +300,9 @@ class HipMatcher:
 
     @property
     def _dirty_strict(self):
-        """Nodes whose pending change is more than a SetBusy() (the only mutator that precedes a commit)."""
-        return {nm for nm in self._dirty if not self._reasons.get(nm, {""}) <= {"busy_time", "SetBusy"}}
+        """Nodes that wait for a re-pack: their pending change is more than writes to scalar fields (those travel as deltas
+        of their own and commute with commits and releases)."""
+        return {nm for nm in self._dirty if not self._reasons.get(nm, {""}) <= self._SCALAR_REASONS}
 
     def mark_dirty(self, name: str) -> None:
         if self._attached is not None and name in self._attached:
@@ -256,12 +319,24 @@ class HipMatcher:
             self.engine.upload(table)
 
     def _flush_dirty(self) -> None:
-        if not self._dirty:
-            return
         if any(nm not in self._index for nm in self._dirty):
             self._full_upload(self._attached)          # nodes were added or removed
             self._dirty.clear()
             self._reasons.clear()
+            self._deltas = []
+            return
+        # writes to scalar fields (cordon / maintenance / groups / busy time, nhd/NHDScheduler.py:533-570) travel as deltas too
+        for name in [nm for nm in self._dirty if self._reasons.get(nm, {""}) <= self._SCALAR_REASONS]:
+            node, why = self._dirty.pop(name), self._reasons.pop(name)
+            i = self._index[name]
+            if why & {"active", "maintenance"}:
+                self._deltas.append(self.packer.delta_scalar(i, node, "active"))
+            if why & {"groups", "SetGroups"}:
+                self._deltas.append(self.packer.delta_scalar(i, node, "groups"))
+            if why & {"busy_time", "SetBusy"}:
+                self._deltas.append(self.packer.delta_scalar(i, node, "busy_time"))
+        self._flush_deltas()
+        if not self._dirty:
             return
         one = pack.empty_table(1)
         for name, node in self._dirty.items():

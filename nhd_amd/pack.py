@@ -42,7 +42,17 @@ P3 = np.dtype([("groups", "<u8"), ("sig_numa", "<u2", (2,)), ("sig_pci", "<u2", 
 P4 = np.dtype([("busy_time", "<f8"), ("group_set", "<u4"), ("reserved", "<u4")])
 DETAIL = np.dtype([("nic_cnt", "u1", (2,)), ("sw_free", "u1", (MAX_SWITCHES,)),
                    ("nic_cls", "u1", (2, MAX_NICS_PER_NUMA)), ("nic_sw", "u1", (2, MAX_NICS_PER_NUMA)),
-                   ("numa_nodes", "u1"), ("n_gpus", "u1"), ("pad", "u1", (14,)), ("gpu_sw", "u1", (MAX_GPUS,))])
+                   ("numa_nodes", "u1"), ("n_gpus", "u1"), ("nic_pods", "u1", (12,)), ("pad", "u1", (2,)),
+                   ("gpu_sw", "u1", (MAX_GPUS,))])
+ORIGIN = np.dtype([("t0", "<u8", (2,)), ("t1", "<u8", (2,)), ("nic_base", "u1", (2, MAX_NICS_PER_NUMA)), ("hp_total", "<i4"),
+                   ("pad", "u1", (12,))])
+DELTA_MAX_NICS = 15
+DELTA = np.dtype([("node", "<u4"), ("op", "<u4"), ("t0", "<u8", (2,)), ("t1", "<u8", (2,)), ("gpus", "<u4"), ("hugepages_gb", "<i4"),
+                  ("hp_total", "<i4"), ("flags_mask", "<u4"), ("flags_value", "<u4"), ("group_set", "<u4"), ("groups", "<u8"),
+                  ("busy_time", "<f8"), ("nic_n", "u1"), ("nic", "u1", (DELTA_MAX_NICS,))])
+DELTA_TAKE, DELTA_GIVE, DELTA_RESET, DELTA_SET_FLAGS, DELTA_SET_GROUPS, DELTA_SET_BUSY, DELTA_SET_HUGEPAGES = 1, 2, 3, 4, 5, 6, 7
+DELTA_OK, DELTA_REPACK, DELTA_NEW_SIG = 0, 1, 2
+PODS_LOST = 4                    # nic_pods bit pattern "out of range" (include/nhdfit.h)
 REQ = np.dtype([("n_groups", "<u4"), ("map_type", "<u4"), ("hugepages_gb", "<i4"), ("flags", "<u4"),
                 ("groups", "<u8"), ("gpus", "<u2", (4,)), ("cpu_smt", "<u2", (4,)), ("cpu_nosmt", "<u2", (4,)),
                 ("misc_smt", "<u2"), ("misc_nosmt", "<u2"), ("n_proc", "u1", (4,)),
@@ -57,6 +67,7 @@ COMMIT_OK, COMMIT_WOULD_RAISE, COMMIT_NEW_SIG = 0, 1, 2
 CC = np.dtype([("cls", "u1"), ("cnt", "u1")])
 assert (P0.itemsize, P1.itemsize, P2.itemsize, P3.itemsize, P4.itemsize) == (16,) * 5
 assert DETAIL.itemsize == 128 and REQ.itemsize == 128 and MAPPING.itemsize == 20 and PLACEMENT.itemsize == 184
+assert ORIGIN.itemsize == 80 and DELTA.itemsize == 96
 
 ALL_ONES = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -74,6 +85,7 @@ class NodeTable:
     p3: np.ndarray
     p4: np.ndarray
     detail: np.ndarray
+    origin: Optional[np.ndarray] = None          # nhdfit_origin records (what ResetResources / a released NIC go back to)
 
     @property
     def n(self) -> int:
@@ -81,13 +93,30 @@ class NodeTable:
 
     def slice(self, lo: int, hi: int) -> "NodeTable":
         return NodeTable(self.names[lo:hi] if self.names else [], self.p0[lo:hi], self.p1[lo:hi], self.p2[lo:hi],
-                         self.p3[lo:hi], self.p4[lo:hi], self.detail[lo:hi])
+                         self.p3[lo:hi], self.p4[lo:hi], self.detail[lo:hi],
+                         None if self.origin is None else self.origin[lo:hi])
 
 
 def empty_table(n: int) -> NodeTable:
     t = NodeTable([], np.zeros(n, P0), np.zeros(n, P1), np.zeros(n, P2), np.zeros(n, P3), np.zeros(n, P4),
-                  np.zeros(n, DETAIL))
+                  np.zeros(n, DETAIL), np.zeros(n, ORIGIN))
     return t
+
+
+def pods_code(pods_used: int) -> int:
+    """Three-bit counter of Node.nics[].pods_used in the detail record (include/nhdfit.h: two's complement, 4 = out of range)."""
+    return int(pods_used) & 7 if -3 <= pods_used <= 3 else PODS_LOST
+
+
+def set_pods(det, u: int, k: int, code: int) -> None:
+    bit = 3 * (u * MAX_NICS_PER_NUMA + k)
+    word = int.from_bytes(bytes(det["nic_pods"]), "little")
+    word = (word & ~(7 << bit)) | ((code & 7) << bit)
+    det["nic_pods"] = np.frombuffer(word.to_bytes(12, "little"), np.uint8)
+
+
+def get_pods(det, u: int, k: int) -> int:
+    return (int.from_bytes(bytes(det["nic_pods"]), "little") >> (3 * (u * MAX_NICS_PER_NUMA + k))) & 7
 
 
 class Packer:
@@ -273,6 +302,22 @@ class Packer:
             t1[u] = m1 if smt else 0xFFFFFFFFFFFFFFFF
         t.p0[i]["t0"] = t0
         t.p1[i]["t1"] = t1
+        if t.origin is not None:                           # ResetResources: every core outside reserved_cores unused (Node.py:147-149)
+            reserved = set(getattr(node, "reserved_cores", ()))
+            o0, o1 = [0, 0], [0, 0]
+            for u in range(U):
+                for b in range(cpp):
+                    c = cores[u * cpp + b]
+                    if c.core not in reserved:
+                        o0[u] |= 1 << b
+                    if smt and cores[c.sibling].core not in reserved:
+                        o1[u] |= 1 << b
+                if not smt:
+                    o1[u] = 0xFFFFFFFFFFFFFFFF
+            t.origin[i]["t0"] = o0
+            t.origin[i]["t1"] = o1
+            t.origin[i]["hp_total"] = max(-2 ** 31, min(2 ** 31 - 1, int(getattr(node.mem, "ttl_hugepages_gb", 0))))
+            t.origin[i]["nic_base"] = 0
 
         gpus = node.gpus
         if len(gpus) > MAX_GPUS:
@@ -317,6 +362,7 @@ class Packer:
         pci_pool = [dict(), dict()]                        # local switch -> {cls -> count}
         det["nic_cls"] = 0
         det["nic_sw"] = 0
+        det["nic_pods"] = 0
         for nic in node.nics:
             u = nic.numa_node
             if u >= U or u < 0:
@@ -333,6 +379,10 @@ class Packer:
                 raise UnsupportedNode(f"node {node.name}: PCIe switch {nic.pciesw:#x} has NICs on both NUMA nodes")
             det["nic_cls"][u][k] = cls
             det["nic_sw"][u][k] = s
+            if nic.pods_used:
+                set_pods(det, u, k, pods_code(nic.pods_used))
+            if t.origin is not None:
+                t.origin[i]["nic_base"][u][k] = self.cap_class(nic.speed * NIC_BW_AVAIL_PERCENT)
             numa_pool[u][cls] = numa_pool[u].get(cls, 0) + 1
             d = pci_pool[u].setdefault(s, {})
             d[cls] = d.get(cls, 0) + 1
@@ -371,6 +421,83 @@ class Packer:
         for i, node in enumerate(nl.values()):
             self.pack_node_into(node, t, i)
         return t
+
+    # ---- K3 deltas ------------------------------------------------
+    @staticmethod
+    def core_masks(node, core_ids) -> Tuple[List[int], List[int]]:
+        """Logical core ids -> bits of planes 0 / 1 (pack_node_into: thread-0 core u*cpp+b = bit b of t0[u]; an id in the
+        sibling range is the t1 bit of the thread-0 core it belongs to, nhd/Node.py:343-350)."""
+        U, cpp = int(node.sockets), int(node.cores_per_proc)
+        t0, t1 = [0, 0], [0, 0]
+        for c in core_ids:
+            c = int(c)
+            if 0 <= c < U * cpp:
+                t0[c // cpp] |= 1 << (c % cpp)
+            elif node.smt_enabled and U * cpp <= c < 2 * U * cpp:
+                h = int(node.cores[c].sibling)
+                t1[h // cpp] |= 1 << (h % cpp)
+            else:
+                raise UnsupportedNode(f"node {node.name}: core id {c} outside the node")
+        return t0, t1
+
+    def delta_from_topology(self, index: int, node, top, op: int) -> np.ndarray:
+        """The nhdfit_delta of Node.RemoveResourcesFromTopology (DELTA_TAKE) / AddResourcesFromTopology (DELTA_GIVE) for
+        a topology with physical ids (nhd/Node.py:530-636): cores, GPUs by device id, one pods_used step per
+        nic_core_pairing entry whose MAC is on the node, hugepages."""
+        d = np.zeros((), DELTA)
+        d["node"], d["op"] = index, op
+        ids = []
+        gmask = 0
+        pos = {g.device_id: k for k, g in enumerate(node.gpus)}
+        for pg in top.proc_groups:
+            ids += [c.core for c in pg.misc_cores] + [c.core for c in pg.proc_cores]
+            for g in pg.group_gpus:
+                k = pos.get(g.device_id)
+                if k is not None:                            # "Cannot find GPU device ID": logged, skipped (Node.py:549-551)
+                    gmask |= 1 << k
+                ids += [c.core for c in g.cpu_cores]
+        ids += [c.core for c in top.misc_cores]
+        d["t0"], d["t1"] = self.core_masks(node, ids)
+        d["gpus"] = gmask
+        d["hugepages_gb"] = max(-2 ** 31, min(2 ** 31 - 1, int(top.hugepages_gb)))
+        by_mac = {n.mac: n for n in node.nics}
+        U = int(node.sockets)
+        k = 0
+        for p in getattr(top, "nic_core_pairing", ()):
+            nic = by_mac.get(p.mac)
+            if nic is None or not (0 <= nic.numa_node < U):   # not on this node / invisible to the NIC stage
+                continue
+            if k >= DELTA_MAX_NICS:
+                raise UnsupportedNode("more than %d NIC pairings in one topology" % DELTA_MAX_NICS)
+            d["nic"][k] = (int(nic.numa_node) << 4) | int(nic.idx)
+            k += 1
+        d["nic_n"] = k
+        return d
+
+    def delta_scalar(self, index: int, node, what: str) -> np.ndarray:
+        """Deltas of the scheduler's writes to scalar node fields, from the node's state AFTER the write."""
+        d = np.zeros((), DELTA)
+        d["node"] = index
+        if what in ("active", "maintenance"):
+            d["op"] = DELTA_SET_FLAGS
+            d["flags_mask"] = NF_MAINTENANCE | NF_ACTIVE
+            d["flags_value"] = (NF_MAINTENANCE if node.maintenance else 0) | (NF_ACTIVE if node.active else 0)
+        elif what == "groups":
+            d["op"] = DELTA_SET_GROUPS
+            gb = self.group_bits(node.groups)
+            d["groups"], d["group_set"] = gb, self.group_set_id(gb)
+        elif what == "busy_time":
+            d["op"] = DELTA_SET_BUSY
+            d["busy_time"] = float(node.busy_time)
+        elif what == "hugepages":
+            d["op"] = DELTA_SET_HUGEPAGES
+            d["hugepages_gb"] = max(-2 ** 31, min(2 ** 31 - 1, int(node.mem.free_hugepages_gb)))
+            d["hp_total"] = max(-2 ** 31, min(2 ** 31 - 1, int(node.mem.ttl_hugepages_gb)))
+        elif what == "reset":
+            d["op"] = DELTA_RESET
+        else:
+            raise ValueError(what)
+        return d
 
     # ---- request side ---------------------------------------------------------------------
     def digest(self, top, pod_groups: Optional[Sequence[str]] = None) -> np.ndarray:
@@ -494,13 +621,21 @@ class Packer:
                     nic_order.append(s)
         local_nogpu = {s: k for k, s in enumerate(nic_order)}
         used_bits = spec.nic_used
+        pods_word = np.zeros((2, n), np.uint64)                  # 16 three-bit counters per NUMA node = 48 bits each
         for numa in range(2):
             for j in range(K):
                 used = ((used_bits >> (numa * K + j)) & 1).astype(bool)
                 det["nic_cls"][:, numa, j] = np.where(used, c_used, c_free)
+                pods_word[numa] |= used.astype(np.uint64) << np.uint64(3 * j)                   # pods_used = 1 on a used NIC
+                t.origin["nic_base"][:, numa, j] = c_free
                 s = int(sw_of_nic[numa, j])
                 det["nic_sw"][:, numa, j] = np.where(has_gpu, s, local_nogpu[s])
         det["sw_free"][:, :4] = np.where(has_gpu[:, None], gfree_sw, 0)
+        for b in range(12):
+            det["nic_pods"][:, b] = ((pods_word[b // 6] >> np.uint64(8 * (b % 6))) & np.uint64(0xFF)).astype(np.uint8)
+        t.origin["t0"] = valid[:, None] & ~np.uint64(3)          # cores 0, 1 of each socket are reserved (synth.ClusterSpec.labels)
+        t.origin["t1"] = np.where(spec.smt[:, None], valid[:, None] & ~np.uint64(3), ALL_ONES)
+        t.origin["hp_total"] = getattr(spec, "hp_total", 64)
 
         # signatures: enumerate the distinct (used-count per pool, free GPUs per pool) patterns
         for numa in range(2):

@@ -108,6 +108,22 @@ def commit(packer, table, i, req, mapping, busy_time):
     return int(rc), out
 
 
+def apply_deltas(packer, table, deltas):
+    """K3 on the host build: `deltas` (pack.DELTA, local node indices) applied in order to `table` (in place)."""
+    L = lib()
+    _, sig_off, pool_off, glimit, cc, _, nsig = _dict_args(packer)
+    deltas = np.ascontiguousarray(deltas, dtype=pack.DELTA).reshape(-1)
+    status = np.zeros(len(deltas), np.uint8)
+    planes = [np.ascontiguousarray(getattr(table, f)) for f in ("p0", "p1", "p2", "p3", "p4", "detail", "origin")]
+    L.hh_apply_deltas.restype = ctypes.c_int
+    rc = L.hh_apply_deltas(*[_p(x) for x in planes], ctypes.c_uint32(table.n), _p(deltas), ctypes.c_uint32(len(deltas)),
+                           _p(sig_off), ctypes.c_uint32(nsig), _p(pool_off), _p(glimit), _p(cc), _p(status))
+    assert rc == 0
+    for f, arr in zip(("p0", "p1", "p2", "p3", "p4", "detail", "origin"), planes):
+        getattr(table, f)[...] = arr
+    return status
+
+
 class HarnessEngine:
     """Engine-compatible front-end of the host build (TEST ONLY): lets HipMatcher's host logic (packing,
     dirty tracking, candidate masks, result decoding) and the sharding helpers run on CPU."""
@@ -132,9 +148,10 @@ class HarnessEngine:
     def upload(self, table, global_base=0, first=0, capacity=None):
         if first == 0 and (self.table is None or table.n >= self.n):
             self.table = pack.NodeTable(list(table.names), *[np.array(getattr(table, f)) for f in
-                                                            ("p0", "p1", "p2", "p3", "p4", "detail")])
+                                                            ("p0", "p1", "p2", "p3", "p4", "detail")],
+                                        np.zeros(table.n, pack.ORIGIN) if table.origin is None else np.array(table.origin))
         else:
-            for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
+            for f in ("p0", "p1", "p2", "p3", "p4", "detail") + (("origin",) if table.origin is not None else ()):
                 getattr(self.table, f)[first:first + table.n] = getattr(table, f)
         self.n = self.table.n
         self.global_base = global_base
@@ -154,6 +171,9 @@ class HarnessEngine:
 
     def commit(self, node, req, mapping, busy_time):
         return commit(self.packer, self.table, node, req, mapping, busy_time)[1]
+
+    def apply_deltas(self, deltas):
+        return apply_deltas(self.packer, self.table, deltas)
 
     def download(self, first=0, count=None):
         count = self.n - first if count is None else count

@@ -408,3 +408,36 @@ extern "C" int hh_first_nic_choice(const nhdfit_req* r, const nhdfit_detail* d, 
     const bool b = first_nic_choice_plain(*r, w, gcode, pci != 0, out_plain);
     return (a ? 1 : 0) | (b ? 2 : 0);
 }
+
+// CPU twin of nhdfit_apply_deltas (K3): the deltas in array order on host copies of the planes.
+extern "C" int hh_apply_deltas(nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plane2* p2, nhdfit_plane3* p3, nhdfit_plane4* p4, nhdfit_detail* det,
+                               nhdfit_origin* origin, uint32_t n_nodes, const nhdfit_delta* deltas, uint32_t n,
+                               const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit, const nhdfit_cc* cc,
+                               uint8_t* status_out) {
+    uint32_t slots = 64;
+    while (slots < 4 * nsig) slots <<= 1;
+    std::vector<uint64_t> skeys(slots, 0);
+    std::vector<uint32_t> sids(slots, 0);
+    for (uint32_t sg = 1; sg < nsig; ++sg) {
+        uint64_t key = 0;
+        for (uint32_t pl = sig_off[sg]; pl < sig_off[sg + 1]; ++pl) {
+            uint8_t cnt[NHDFIT_MAX_CLASSES] = {0};
+            for (uint32_t k = pool_off[pl]; k < pool_off[pl + 1]; ++k) cnt[cc[k].cls & 15u] = cc[k].cnt;
+            key = sig_key_add(key, pool_key(pool_glimit[pl], cnt));
+        }
+        if (!key) continue;
+        uint32_t sl = (uint32_t)mix64(key) & (slots - 1);
+        while (skeys[sl] != 0 && skeys[sl] != key) sl = (sl + 1) & (slots - 1);
+        skeys[sl] = key; sids[sl] = sg;
+    }
+    const SigTable sigs{skeys.data(), sids.data(), slots - 1};
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t v = deltas[i].node;
+        if (v >= n_nodes) return -1;
+        NodeState s;
+        s.p0 = p0[v]; s.p1 = p1[v]; s.p2 = p2[v]; s.p3 = p3[v]; s.p4 = p4[v];
+        status_out[i] = (uint8_t)apply_delta(s, det[v], origin[v], deltas[i], sigs);
+        p0[v] = s.p0; p1[v] = s.p1; p2[v] = s.p2; p3[v] = s.p3; p4[v] = s.p4;
+    }
+    return 0;
+}

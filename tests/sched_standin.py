@@ -35,11 +35,70 @@ class SchedNode(refmodel.StandInNode):
                 c.core = k
         for c, k in zip(top.misc_cores, ids["misc"]):
             c.core = k
+        for pair in top.nic_core_pairing:                            # NICGroup.AddInterface(mac), nhd/Node.py:758-764
+            gi = next(i for i, pg in enumerate(top.proc_groups) if pair.rx_core in pg.proc_cores)
+            numa, idx = mapping["nic"][gi]
+            pair.mac = next(n.mac for n in self.nics if n.numa_node == numa and n.idx == idx)
         return [(i, 0, 0) for i in self._claim]
 
     def ClaimPodNICResources(self, nidx):                            # nhd/Node.py:644-646
         for i in nidx:
             self.nics[i].pods_used += 1
+
+    # release / reclaim / reset and the scalar setters (row f2): restated for the stand-in objects, pinned to the
+    # reference by tests/test_delta_core.py::test_standin_mutators_match_reference
+    def _topology_cores(self, top):
+        for pg in top.proc_groups:
+            yield from (c.core for c in pg.misc_cores)
+            yield from (c.core for c in pg.proc_cores)
+            for g in pg.group_gpus:
+                yield from (c.core for c in g.cpu_cores)
+        yield from (c.core for c in top.misc_cores)
+
+    def _set_topology(self, top, used: bool):
+        for c in self._topology_cores(top):
+            self.cores[c].used = used
+        for pg in top.proc_groups:
+            for g in pg.group_gpus:
+                dev = next((d for d in self.gpus if d.device_id == g.device_id), None)
+                if dev is not None:
+                    dev.used = used
+        for p in top.nic_core_pairing:
+            nic = next((n for n in self.nics if n.mac == p.mac), None)
+            if nic is None:
+                continue
+            sign = 1 if used else -1
+            nic.speed_used[0] += sign * p.rx_core.nic_speed
+            nic.speed_used[1] += sign * p.tx_core.nic_speed
+            nic.pods_used += sign
+        if top.hugepages_gb > 0:
+            self.mem.free_hugepages_gb += -top.hugepages_gb if used else top.hugepages_gb
+
+    def RemoveResourcesFromTopology(self, top):                      # nhd/Node.py:530-585
+        self._set_topology(top, True)
+        return True
+
+    def AddResourcesFromTopology(self, top):                         # nhd/Node.py:587-636
+        self._set_topology(top, False)
+
+    def ResetResources(self):                                        # nhd/Node.py:144-161
+        for c in self.cores:
+            if c.core not in self.reserved_cores:
+                c.used = False
+        for g in self.gpus:
+            g.used = False
+        for n in self.nics:
+            n.pods_used = 0
+            n.speed_used = [0, 0]
+        self.mem.free_hugepages_gb = self.mem.ttl_hugepages_gb
+
+    def SetGroups(self, groups: str):                                # nhd/Node.py:308-310
+        self.groups = groups.split('.')
+
+    def SetHugepages(self, alloc: int, free: int):                   # nhd/Node.py:489-493
+        self.mem.ttl_hugepages_gb = alloc
+        self.mem.free_hugepages_gb = free - self.mem.res_hugepages_gb
+        return True
 
 
 def adopt(nodes: Dict[str, object], clock) -> Dict[str, object]:

@@ -87,12 +87,17 @@ def test_spec_route_equals_object_route(cfg):
     assert names(pk_a, np.asarray(pk_a.group_sets, dtype=object)[ta.p4["group_set"]]) == \
            names(pk_b, np.asarray(pk_b.group_sets, dtype=object)[tb.p4["group_set"]])
     assert pack.resolve_signatures(pk_a, ta) == pack.resolve_signatures(pk_b, tb)
-    for f in ("nic_cnt", "sw_free", "nic_sw", "numa_nodes"):
+    for f in ("nic_cnt", "sw_free", "nic_sw", "numa_nodes", "nic_pods"):
         assert np.array_equal(ta.detail[f], tb.detail[f]), f
+    for f in ("t0", "t1", "hp_total"):                        # what ResetResources goes back to
+        assert np.array_equal(ta.origin[f], tb.origin[f]), f
     live = np.arange(pack.MAX_NICS_PER_NUMA)[None, None, :] < ta.detail["nic_cnt"][:, :, None]
     ca = np.where(live, np.asarray(pk_a.caps)[ta.detail["nic_cls"]], -1.0)
     cb = np.where(live, np.asarray(pk_b.caps)[tb.detail["nic_cls"]], -1.0)
     assert np.array_equal(ca, cb)
+    live = np.arange(pack.MAX_NICS_PER_NUMA)[None, None, :] < ta.detail["nic_cnt"][:, :, None]
+    assert np.array_equal(np.where(live, np.asarray(pk_a.caps)[ta.origin["nic_base"]], -1.0),
+                          np.where(live, np.asarray(pk_b.caps)[tb.origin["nic_base"]], -1.0))
 
 
 def test_candidate_mask_and_sharding_agree():
