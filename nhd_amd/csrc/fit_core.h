@@ -212,18 +212,22 @@ NHD_HD uint32_t entry_a(const PodSums& s, uint32_t u, uint32_t f) {
 // For disjoint R, S the union R|S equals R+S, so "every R of a that is disjoint from S, united with S" is
 // (a & disj(S)) << S with disj(S) = the subsets of {0..3} that avoid S: 16 shift-and-mask terms, no inner loop.
 static_assert(kMaxG == 4, "the disj() masks below enumerate subsets of four groups");
-NHD_HD uint32_t dunion(uint32_t a, uint32_t b, uint32_t W) {
-    (void)W;                                   // members of a and b are < W, and so is every R|S
+template <uint32_t TERMS>
+NHD_HD uint32_t dunion_n(uint32_t a, uint32_t b) {       // members of b below TERMS only
     uint32_t out = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (uint32_t S = 0; S < (1u << kMaxG); ++S) {
+    for (uint32_t S = 0; S < TERMS; ++S) {
         const uint32_t disj = ((S & 1) ? 0x5555u : 0xFFFFu) & ((S & 2) ? 0x3333u : 0xFFFFu) &
                               ((S & 4) ? 0x0F0Fu : 0xFFFFu) & ((S & 8) ? 0x00FFu : 0xFFFFu);
         if (b >> S & 1) out |= (a & disj) << S;
     }
     return out;
+}
+NHD_HD uint32_t dunion(uint32_t a, uint32_t b, uint32_t W) {
+    (void)W;                                   // members of a and b are < W, and so is every R|S
+    return dunion_n<1u << kMaxG>(a, b);
 }
 
 // Block S of groups sharing one NIC of capacity `cap`: the reference subtracts each group's rx / tx
@@ -237,13 +241,19 @@ NHD_HD bool block_fits(const nhdfit_req& r, double cap, uint32_t S) {
 }
 
 // cover[n] = group-sets that n NICs of this capacity can host (n = 0..G)
-NHD_HD void class_cover(const nhdfit_req& r, double cap, uint32_t W, uint32_t G, uint16_t cover[kMaxG + 1]) {
+// WW: compile-time bound >= W for the unions (the device instantiates the row width of the pod's tile: a two-group tile
+// pays 4 terms per union, not 16)
+template <uint32_t WW>
+NHD_HD void class_cover_w(const nhdfit_req& r, double cap, uint32_t W, uint32_t G, uint16_t cover[kMaxG + 1]) {
     uint32_t fit = 1;                       // the empty block always "fits"
     for (uint32_t S = 1; S < W; ++S)
         if (block_fits(r, cap, S)) fit |= 1u << S;
     cover[0] = 1;
     for (uint32_t n = 1; n <= (uint32_t)kMaxG; ++n)
-        cover[n] = (n <= G) ? (uint16_t)dunion(cover[n - 1], fit, W) : cover[G];
+        cover[n] = (n <= G) ? (uint16_t)dunion_n<WW>(cover[n - 1], fit) : cover[G];
+}
+NHD_HD void class_cover(const nhdfit_req& r, double cap, uint32_t W, uint32_t G, uint16_t cover[kMaxG + 1]) {
+    class_cover_w<1u << kMaxG>(r, cap, W, G, cover);
 }
 
 NHD_HD uint32_t size_le_mask(uint32_t W, uint32_t limit) {       // subsets of {0..3} below W with at most `limit` groups
@@ -260,18 +270,22 @@ struct SigDict {
 };
 
 // reach family of one signature for one pod; cover = [ncls][kMaxG+1]
-NHD_HD uint32_t sig_reach(const SigDict& d, uint32_t sig, const uint16_t* cover, uint32_t W) {
+template <uint32_t WW>
+NHD_HD uint32_t sig_reach_w(const SigDict& d, uint32_t sig, const uint16_t* cover, uint32_t W) {
     uint32_t reach = 1;
     for (uint32_t pl = d.sig_off[sig]; pl < d.sig_off[sig + 1]; ++pl) {
         uint32_t pool = 1;
         for (uint32_t k = d.pool_off[pl]; k < d.pool_off[pl + 1]; ++k) {
             uint32_t n = d.cc[k].cnt > kMaxG ? kMaxG : d.cc[k].cnt;
-            pool = dunion(pool, cover[d.cc[k].cls * (kMaxG + 1) + n], W);
+            pool = dunion_n<WW>(pool, cover[d.cc[k].cls * (kMaxG + 1) + n]);
         }
         if (d.pool_glimit[pl] != NHDFIT_GLIMIT_NONE) pool &= size_le_mask(W, d.pool_glimit[pl]);
-        reach = dunion(reach, pool, W);
+        reach = dunion_n<WW>(reach, pool);
     }
     return reach;
+}
+NHD_HD uint32_t sig_reach(const SigDict& d, uint32_t sig, const uint16_t* cover, uint32_t W) {
+    return sig_reach_w<1u << kMaxG>(d, sig, cover, W);
 }
 
 // R1[sig] bit p = reach bit S1(p) = reach bit p;  R0[sig] bit p = reach bit S0(p) = reach bit (W-1-p)

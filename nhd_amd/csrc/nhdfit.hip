@@ -26,6 +26,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "seq_core.h"
@@ -42,6 +43,12 @@ struct DictView {
     uint32_t ncls;
     const uint64_t* group_sets;
     SigDict sig;
+    // the same dictionary as ONE stream of 16-bit words the digest role stages in LDS (walking the three CSR levels in
+    // global memory costs a dependent scalar load per level, pool and class - 2-3 us per signature):
+    // [0, nsig]: word offset of each signature's record behind the table; record = { #pools, per pool: glimit << 8 | #cc,
+    // then #cc x (cls << 8 | cnt) }
+    const uint16_t* flat;
+    uint32_t flat_words;             // 0: not available (the stream would not fit 16-bit offsets)
 };
 
 // v_writelane_b32 (SGPR -> one lane of a VGPR).  This clang has no __builtin_amdgcn_writelane; the
@@ -84,8 +91,10 @@ struct DigestArgs {
     const uint64_t* xcls;            // interned (NUMA, free GPUs, signature) classes of the mirror: key of X row k
     const uint32_t* nx;              // number of classes
 };
+constexpr uint32_t kDictLdsWords = 6144;             // 12 KB for the staged signature stream (c5: 151 signatures = 1.5 K words)
 constexpr size_t kDigestLds = lds_slice(kTile * sizeof(PaddedReq)) + lds_slice(kTile * sizeof(PodSums)) +
-                              lds_slice(kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1) * sizeof(uint16_t)) + lds_slice(kTile * sizeof(PodHeader));
+                              lds_slice(kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1) * sizeof(uint16_t)) + lds_slice(kTile * sizeof(PodHeader)) +
+                              lds_slice(kDictLdsWords * sizeof(uint16_t));
 constexpr uint32_t kWcParts = 4;                     // blocks per tile that share its CPU rows (free-core count c = part mod 4)
 constexpr uint32_t kDigestParts = 1 + kWcParts;      // part 0 = GPU / NIC rows (cold section + X), parts 1..4 = CPU rows, the last one also HP / GX
 
@@ -99,6 +108,7 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
     uint16_t (*s_cover)[NHDFIT_MAX_CLASSES][kMaxG + 1] =
         reinterpret_cast<uint16_t (*)[NHDFIT_MAX_CLASSES][kMaxG + 1]>(carve<uint16_t>(lds, kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1)));
     PodHeader* s_hdr = carve<PodHeader>(lds, kTile);
+    uint16_t* s_flat = carve<uint16_t>(lds, kDictLdsWords);
 
     const uint32_t tile = blk / kDigestParts, part = blk % kDigestParts;
     const uint32_t tid = threadIdx.x;
@@ -178,31 +188,84 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
             }
         }
         if (part != kWcParts) return;
-        // 64-bit scalar-predicate rows: one wavefront per row, ballot over the 64 pods
-        const uint32_t ngx = 1 + 2 * L.ngs, nrows64 = ngx + L.hp_rows;
-        for (uint32_t k = wave; k < nrows64; k += NW) {
-            const bool bit = k < ngx ? gx_bit(s_hdr[lane], k, a.d.group_sets) : hp_bit(s_hdr[lane], k - ngx);
-            const uint64_t word = __ballot(bit);
-            if (lane == 0)
-                *reinterpret_cast<uint64_t*>(hot + (k < ngx ? L.hot_gx + 8 * k : L.hot_hp + 8 * (k - ngx))) = word;
+        // 64-bit scalar-predicate rows: ballots over the 64 pods (lane = pod).  HP: one wavefront per row.  GX: there can
+        // be hundreds of node-group sets (c5: every 1-3 name combination of 16 names) - a wavefront takes 64 sets at a time,
+        // one coalesced load, and hands them round with v_readlane (a scalar load per row costs a memory round trip each);
+        // lane i keeps the word of set i and stores its two rows (inactive, active: NHDScheduler.py:240-242, gx_bit).
+        for (uint32_t k = wave; k < L.hp_rows; k += NW) {
+            const uint64_t word = __ballot(hp_bit(s_hdr[lane], k));
+            if (lane == 0) *reinterpret_cast<uint64_t*>(hot + L.hot_hp + 8 * k) = word;
+        }
+        const bool filtered = (s_hdr[lane].flags & kPodFilter) != 0;       // else: the caller filtered already - every row passes
+        const uint64_t my_groups = s_hdr[lane].groups;
+        const uint64_t unfiltered = __ballot(!filtered);
+        if (tid == 0) *reinterpret_cast<uint64_t*>(hot + L.hot_gx) = 0;     // row 0: never
+        for (uint32_t g0 = wave * 64; g0 < L.ngs; g0 += NW * 64) {
+            const uint32_t cnt = L.ngs - g0 < 64u ? L.ngs - g0 : 64u;
+            const uint64_t my_set = lane < cnt ? a.d.group_sets[g0 + lane] : 0ull;
+            uint64_t mine = 0;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint64_t set = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_set, (int)i) |
+                                     (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_set >> 32), (int)i) << 32;
+                const uint64_t word = unfiltered | __ballot(filtered && (set & my_groups) != 0);
+                if (lane == i) mine = word;
+            }
+            if (lane < cnt) {
+                uint64_t* rows = reinterpret_cast<uint64_t*>(hot + L.hot_gx + 8 * (1 + 2 * (g0 + lane)));
+                rows[0] = unfiltered;                                        // node not active
+                rows[1] = mine;
+            }
         }
         return;
     }
 
-    // part 0: NIC covers per (pod, capacity class), then the cold rows A0/A1[f], R0/R1[sig]
-    for (uint32_t w = tid; w < kTile * a.d.ncls; w += THREADS) {
-        const uint32_t j = w % kTile, c = w / kTile;
-        if (s_hdr[j].flags & kPodValid) class_cover(s_req[j].r, a.d.caps[c], s_sum[j].W, s_sum[j].G, s_cover[j][c]);
-    }
-    __syncthreads();
+    // part 0: NIC covers per (pod, capacity class), then the cold rows A0/A1[f], R0/R1[sig].  The unions behind both are
+    // instantiated per row width (uniform over the block): a two-group tile pays 4 terms per union, not 16.
+    const bool staged = a.d.flat_words != 0 && a.d.flat_words <= kDictLdsWords;
+    if (staged)
+        for (uint32_t w = tid; w < a.d.flat_words / 2; w += THREADS)        // (the stream is padded to an even word count)
+            reinterpret_cast<uint32_t*>(s_flat)[w] = reinterpret_cast<const uint32_t*>(a.d.flat)[w];
+    auto covers_and_sig_rows = [&](auto width) {
+        constexpr uint32_t WW = decltype(width)::value;
+        for (uint32_t w = tid; w < kTile * a.d.ncls; w += THREADS) {
+            const uint32_t j = w % kTile, c = w / kTile;
+            if (s_hdr[j].flags & kPodValid) class_cover_w<WW>(s_req[j].r, a.d.caps[c], s_sum[j].W, s_sum[j].G, s_cover[j][c]);
+        }
+        __syncthreads();
+        for (uint32_t sig = wave; sig < L.nsig; sig += NW) {    // one reach family per (signature, pod), both sockets' rows from it
+            uint32_t reach = 0;
+            if (staged) {
+                // the record is read with the same address in every lane (LDS broadcast); readfirstlane hands the loop
+                // bounds to the scalar unit so the walk stays wave-uniform
+                auto word = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flat[i]); };
+                uint32_t at = a.d.sig.nsig + 1 + word(sig);
+                const uint32_t npools = word(at++);
+                reach = 1;
+                for (uint32_t pl = 0; pl < npools; ++pl) {
+                    const uint32_t head = word(at++), ncc = head & 0xFFu, glimit = head >> 8;
+                    uint32_t pool = 1;
+                    for (uint32_t k = 0; k < ncc; ++k) {
+                        const uint32_t e = word(at++), cnt = e & 0xFFu, cls = e >> 8;
+                        pool = dunion_n<WW>(pool, s_cover[lane][cls][cnt > (uint32_t)kMaxG ? kMaxG : cnt]);
+                    }
+                    if (glimit != NHDFIT_GLIMIT_NONE) pool &= size_le_mask(s_sum[lane].W, glimit);
+                    reach = dunion_n<WW>(reach, pool);
+                }
+                if (!valid) reach = 0;
+            } else {
+                reach = valid ? sig_reach_w<WW>(a.d.sig, sig, &s_cover[lane][0][0], s_sum[lane].W) : 0u;
+            }
+            emit_row(img + L.off_r0 + sig * L.row, valid ? entry_r(reach, s_sum[lane].W, 0) : 0u);
+            emit_row(img + L.off_r1 + sig * L.row, valid ? entry_r(reach, s_sum[lane].W, 1) : 0u);
+        }
+    };
+    if (W == 2) covers_and_sig_rows(std::integral_constant<uint32_t, 2>{});
+    else if (W == 4) covers_and_sig_rows(std::integral_constant<uint32_t, 4>{});
+    else if (W == 8) covers_and_sig_rows(std::integral_constant<uint32_t, 8>{});
+    else covers_and_sig_rows(std::integral_constant<uint32_t, 16>{});
     for (uint32_t k = wave; k < 2 * L.fg_dim; k += NW) {
         const uint32_t u = k >= L.fg_dim, f = u ? k - L.fg_dim : k;
         emit_row(img + (u ? L.off_a1 : L.off_a0) + f * L.row, valid ? entry_a(s_sum[lane], u, f) : 0u);
-    }
-    for (uint32_t sig = wave; sig < L.nsig; sig += NW) {        // one reach family per (signature, pod), both sockets' rows from it
-        const uint32_t reach = valid ? sig_reach(a.d.sig, sig, &s_cover[lane][0][0], s_sum[lane].W) : 0u;
-        emit_row(img + L.off_r0 + sig * L.row, valid ? entry_r(reach, s_sum[lane].W, 0) : 0u);
-        emit_row(img + L.off_r1 + sig * L.row, valid ? entry_r(reach, s_sum[lane].W, 1) : 0u);
     }
     __syncthreads();                                            // the block reads back the cold rows it just wrote
     // hot rows X[class] = A_u[f] & (PCI-mode pods: R_u[sigPCI], NUMA-mode pods: R_u[sigNUMA]) - pure word
@@ -1590,6 +1653,7 @@ struct nhdfit_ctx {
 
     // dictionary
     DevBuf<double> caps; DevBuf<uint32_t> sig_off, pool_off; DevBuf<uint8_t> pool_glimit; DevBuf<nhdfit_cc> cc;
+    DevBuf<uint16_t> sig_flat; uint32_t flat_words = 0;
     uint32_t ncls = 0, nsig = 0;
     uint32_t max_cores = 1, max_gpus = 0, ngs = 0;
     DevBuf<uint64_t> group_sets;
@@ -1785,7 +1849,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->origin.release(); c->deltas.release(); c->delta_run.release(); c->delta_status.release();
-    c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release();
+    c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release();
     c->reqs.release(); c->bitmap.release(); c->nm.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); c->shape_list[b].release(); }
     c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->sig_keys.release(); c->sig_ids.release();
@@ -1861,6 +1925,28 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
         HIPCHK(c, hipMemcpy(c->sig_keys.p, keys.data(), slots * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->sig_ids.p, ids.data(), slots * sizeof(uint32_t), hipMemcpyHostToDevice));
         c->sig_mask = slots - 1;
+    }
+    {   // the dictionary as one stream of 16-bit words (DictView::flat)
+        std::vector<uint16_t> flat(nsig + 1, 0);
+        bool fits = true;
+        for (uint32_t sg = 0; sg < nsig && fits; ++sg) {
+            const size_t at = flat.size() - (nsig + 1);
+            if (at > 0xFFFFu) { fits = false; break; }
+            flat[sg] = (uint16_t)at;
+            flat.push_back((uint16_t)(sig_off[sg + 1] - sig_off[sg]));
+            for (uint32_t pl = sig_off[sg]; pl < sig_off[sg + 1]; ++pl) {
+                const uint32_t ncc_pl = pool_off[pl + 1] - pool_off[pl];
+                if (ncc_pl > 255u) { fits = false; break; }
+                flat.push_back((uint16_t)(pool_glimit[pl] << 8 | ncc_pl));
+                for (uint32_t k = pool_off[pl]; k < pool_off[pl + 1]; ++k) flat.push_back((uint16_t)((cc[k].cls & 0xFFu) << 8 | cc[k].cnt));
+            }
+        }
+        if (flat.size() & 1) flat.push_back(0);
+        c->flat_words = fits ? (uint32_t)flat.size() : 0;
+        if (fits) {
+            HIPCHK(c, c->sig_flat.reserve(flat.size()));
+            HIPCHK(c, hipMemcpy(c->sig_flat.p, flat.data(), flat.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
     }
     c->ncls = ncls;
     c->nsig = nsig;
@@ -2175,7 +2261,7 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         const int b = (int)(c->n_dig % kBufs);                              // the next undigested step
         DigestArgs& d = a.digest;
         d.reqs = c->reqs.p; d.P = P;
-        d.d = DictView{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}};
+        d.d = DictView{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}, c->sig_flat.p, c->flat_words};
         for (int w = 0; w < kWClasses; ++w) d.L[w] = c->L[w];
         d.pitch = c->pitch; d.tabs = c->tabs[b].p; d.hdr = c->hdr[b].p; d.score = c->score[b].p;
         d.xcls = c->xcls.p; d.nx = c->xnx.p;
