@@ -83,7 +83,7 @@ def main():
 
     from nhd_amd import pack
     from nhd_amd.engine import Engine, winner_index
-    from workload import refmodel, synth
+    from workload import planes, refmodel, synth
 
     n_total = args.total_nodes if strong else args.nodes_per_gpu * world
     lo, hi = rank * args.nodes_per_gpu, min(n_total, (rank + 1) * args.nodes_per_gpu)
@@ -93,7 +93,7 @@ def main():
     tops = [refmodel.make_topology(s) for s in pods]
 
     pk = pack.Packer()
-    table = pk.planes_from_spec(spec)
+    table = planes.planes_from_spec(pk, spec)
     reqs = pk.digest_many(tops, pod_groups)
     pk.close_signatures()
     eng = Engine(local_rank)
@@ -191,6 +191,8 @@ def main():
         out["end_to_end"] = end_to_end(eng, reqs, now, args.pods, n_total)
         out["mode_b"] = mode_b(eng, pk, reqs, now, args.pods)
         out["other_configs"] = other_configs(args, local_rank)
+        out["deltas"] = delta_rate(eng, table)
+        out["score_only"] = score_only(eng, reqs, now, args.pods, n_total)     # last: it changes the context's outputs
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not inner:
         out["cpu_baseline"] = cpu_baseline(spec, tops, pod_groups, args.cpu_sample_pods, score, lo, winner_index, args)
     if rank == 0:
@@ -217,13 +219,69 @@ def end_to_end(eng, reqs, now, P, n_total):
             "evals_per_s": P * n_total / t, "decisions_per_s": P / t}
 
 
+def score_only(eng, reqs, now, P, n_total, steps=100):
+    """The same step without the verdict matrix: what Matcher.FindNode (mode A) needs is the winners and their mappings;
+    the P x N feasibility bits are an extra output (bitmap_out, mode B's scan rows).  SURVEY.md 8(d): "drop any output
+    term the build does not materialise and say so" - the headline `value` keeps materialising it."""
+    eng.set_outputs(bitmap=False, mapping=True)
+    eng.stage(reqs)
+    for _ in range(10):
+        eng.enqueue(now)
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.enqueue(now)
+    eng.sync()
+    dt = time.perf_counter() - t0
+    score, _, _ = eng.fetch(want_bitmap=False, want_map=True)
+    return {"ms_per_step": dt * 1e3 / steps, "evals_per_s": float(P) * n_total * steps / dt, "placed_pods": int(np.count_nonzero(score)),
+            "note": "verdict matrix (P x N / 8 bytes per step) not written; winners and mappings only"}
+
+
+def delta_rate(eng, table, n=4096):
+    """Row f2 (nhdfit_apply_deltas): n pods' worth of resources taken from n different nodes in one call, then given back
+    in a second one (RemoveResourcesFromTopology / AddResourcesFromTopology as delta records: 4 cores, a NIC claim, 2 GB
+    of hugepages each); the mirror must come back bit for bit.  Time per call includes the H2D of the records, the
+    kernel, the D2H of the statuses and the host-side grouping by node."""
+    from nhd_amd import pack
+    n = min(n, table.n)
+    before = eng.download()
+    d = np.zeros(n, pack.DELTA)
+    d["node"] = np.arange(n, dtype=np.uint32) * (table.n // n)
+    free = before.p0["t0"][d["node"]] & before.p1["t1"][d["node"]]
+    pick = np.zeros_like(free)
+    for _ in range(4):                                     # the four lowest free cores of socket 0
+        low = free[:, 0] & (~free[:, 0] + np.uint64(1))
+        pick[:, 0] |= low
+        free[:, 0] &= ~low
+    d["t0"] = pick
+    d["t1"] = pick
+    d["hugepages_gb"] = 2
+    d["nic_n"] = 1                                         # NIC (0, 0)
+    ts = {}
+    for name, op in (("take", pack.DELTA_TAKE), ("give", pack.DELTA_GIVE)):
+        d["op"] = op
+        t0 = time.perf_counter()
+        st = eng.apply_deltas(d)
+        ts[name] = time.perf_counter() - t0
+        if (st != pack.DELTA_OK).any():
+            raise SystemExit("delta leg: a delta came back with a status")
+    after = eng.download()
+    for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
+        if not np.array_equal(getattr(before, f), getattr(after, f)):
+            raise SystemExit("delta leg: take + give did not restore plane " + f)
+    t = max(ts.values())
+    return {"call": "nhdfit_apply_deltas (one call per direction, %d nodes each)" % n, "ms_per_call": t * 1e3, "deltas_per_s": n / t,
+            "mirror_restored": True}
+
+
 def other_configs(args, device):
     """BASELINE.json's other shapes on one GPU, same step, same clock (not the headline; 60 steps each): config 2 whole
     (4 096 nodes x 256 pods), config 3 whole (16 384 x 1 024), one config-5 shard (32 768 x 2 048: an eighth of its nodes, an
     eighth of its pods).  Mode A step rate and the mode-B decision rate of each."""
     from nhd_amd import pack
     from nhd_amd.engine import Engine
-    from workload import refmodel, synth
+    from workload import planes, refmodel, synth
     rows = []
     for cfg, n, P in ((2, 4096, 256), (3, 16384, 1024), (5, 32768, 2048)):
         if (cfg, n, P) == (args.config, args.nodes_per_gpu, args.pods):
@@ -232,7 +290,7 @@ def other_configs(args, device):
         pods, groups = synth.make_pods(cfg, n_pods=P)
         tops = [refmodel.make_topology(s) for s in pods]
         pk = pack.Packer()
-        table = pk.planes_from_spec(spec)
+        table = planes.planes_from_spec(pk, spec)
         reqs = pk.digest_many(tops, groups)
         pk.close_signatures()
         eng = Engine(device)

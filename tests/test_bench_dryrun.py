@@ -18,6 +18,7 @@ class DryEngine(harness.HarnessEngine):
     def enqueue(self, now): self._now = now
     def sync(self): pass
     def reset_stats(self): pass
+    def set_outputs(self, bitmap=True, mapping=True): pass
     def stats(self): return _Stats()
 
     def fetch(self, want_bitmap=False, want_map=True):
@@ -56,6 +57,7 @@ def test_bench_json_contract(tmp_path):
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert out["mode_b"]["decisions_per_s"] > 0 and out["mode_b"]["placed"] > 0       # decisions under commit semantics
     assert out["end_to_end"]["evals_per_s"] > 0
+    assert out["score_only"]["evals_per_s"] > 0 and out["deltas"]["mirror_restored"] and out["deltas"]["deltas_per_s"] > 0
     assert out["roofline"]["bound"] == "hbm" and "limited_by" in out["roofline"] and "traffic_source" in out["roofline"]
 
 

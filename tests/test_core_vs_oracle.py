@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from nhd_amd import pack
-from workload import refmodel, synth
+from workload import planes, refmodel, synth
 from oracle import nhd_oracle as O
 from tests import harness, util
 
@@ -77,7 +77,7 @@ def test_spec_route_equals_object_route(cfg):
     spec = synth.make_cluster(cfg, n_nodes=200)
     pk_a, pk_b = pack.Packer(), pack.Packer()
     ta = pk_a.pack_nodes(spec.build_nodes())
-    tb = pk_b.planes_from_spec(spec)
+    tb = planes.planes_from_spec(pk_b, spec)
     for f in ("p0", "p1", "p2"):
         assert np.array_equal(getattr(ta, f), getattr(tb, f)), f
     assert np.array_equal(ta.p4["busy_time"], tb.p4["busy_time"])
@@ -104,7 +104,7 @@ def test_candidate_mask_and_sharding_agree():
     spec = synth.make_cluster(4, n_nodes=300)
     pods, groups = synth.make_pods(4, n_pods=70)
     pk = pack.Packer()
-    table = pk.planes_from_spec(spec)
+    table = planes.planes_from_spec(pk, spec)
     reqs = pk.digest_many([refmodel.make_topology(s) for s in pods], groups)
     full, bm, _ = harness.find(pk, table, reqs, spec.clock_now, want_map=False)
     parts = []
@@ -122,7 +122,7 @@ def test_register_and_generic_set_models_agree():
     spec = synth.make_cluster(4, n_nodes=400)
     pods, groups = synth.make_pods(4, n_pods=128)
     pk = pack.Packer()
-    table = pk.planes_from_spec(spec)
+    table = planes.planes_from_spec(pk, spec)
     reqs = pk.digest_many([refmodel.make_topology(s) for s in pods], groups)
     a = harness.find(pk, table, reqs, spec.clock_now, force_generic=False)
     b = harness.find(pk, table, reqs, spec.clock_now, force_generic=True)
@@ -138,7 +138,7 @@ def test_hot_and_cold_table_sections_agree_on_heterogeneous_clusters():
         spec = synth.make_cluster(cfg, n_nodes=n)
         pods, groups = synth.make_pods(cfg, n_pods=96)
         pk = pack.Packer()
-        t = pk.planes_from_spec(spec)
+        t = planes.planes_from_spec(pk, spec)
         reqs = pk.digest_many([refmodel.make_topology(s) for s in pods], groups)
         for now in (spec.clock_now, spec.clock_now + 24.9, spec.clock_now + 25.1, spec.clock_now + 1e6):
             harness.find(pk, t, reqs, now, want_map=False)

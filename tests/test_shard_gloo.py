@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from nhd_amd import pack
-from workload import refmodel, synth
+from workload import planes, refmodel, synth
 from nhd_amd import sharding as shard
 from tests import harness
 from workload import dist as dist_util
@@ -39,7 +39,7 @@ def _worker(rank, world, port, cfg, n, P, out_dir):
     spec, tops, groups = _problem(cfg, n, P)
     lo, hi = shard.shard_bounds(n, world, rank)
     pk = pack.Packer()
-    table = pk.planes_from_spec(spec.shard(lo, hi))
+    table = planes.planes_from_spec(pk, spec.shard(lo, hi))
     reqs = pk.digest_many(tops, groups)
     score, _, maps = harness.find(pk, table, reqs, spec.clock_now, global_base=lo, want_bitmap=False)
     red = dist_util.allreduce_max_scores(score)
@@ -60,7 +60,7 @@ def test_two_rank_sharding_equals_single_shard(tmp_path, cfg, n, P):
     mp.spawn(_worker, args=(2, port, cfg, n, P, str(tmp_path)), nprocs=2, join=True)
     spec, tops, groups = _problem(cfg, n, P)
     pk = pack.Packer()
-    table = pk.planes_from_spec(spec)
+    table = planes.planes_from_spec(pk, spec)
     want_score, _, want_maps = harness.find(pk, table, pk.digest_many(tops, groups), spec.clock_now, want_bitmap=False)
     assert np.array_equal(np.load(tmp_path / "score.npy"), want_score)
     assert np.array_equal(np.load(tmp_path / "maps.npy"), want_maps.view(np.int8))

@@ -5,7 +5,7 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from nhd_amd import pack
-from workload import refmodel, synth
+from workload import planes, refmodel, synth
 from nhd_amd.engine import Engine
 
 cfg = int(os.environ.get("PROBE_CFG", "4"))
@@ -15,7 +15,7 @@ spec = synth.make_cluster(cfg, n_nodes=n)
 pods, groups = synth.make_pods(cfg, n_pods=P)
 tops = [refmodel.make_topology(s) for s in pods]
 pk = pack.Packer()
-table = pk.planes_from_spec(spec)
+table = planes.planes_from_spec(pk, spec)
 reqs = pk.digest_many(tops, groups)
 eng = Engine(0)
 eng.set_dictionary(pk)

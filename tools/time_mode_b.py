@@ -5,7 +5,7 @@ import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from nhd_amd import pack
-from workload import refmodel, synth
+from workload import planes, refmodel, synth
 from nhd_amd.engine import Engine
 
 n, P = int(sys.argv[1]) if len(sys.argv) > 1 else 65536, int(sys.argv[2]) if len(sys.argv) > 2 else 4096
@@ -15,7 +15,7 @@ pods, groups = synth.make_pods(cfg, n_pods=P)
 for p in pods:
     p["misc_smt"] = True
 tops = [refmodel.make_topology(s) for s in pods]
-pk = pack.Packer(); table = pk.planes_from_spec(spec); reqs = pk.digest_many(tops, groups)
+pk = pack.Packer(); table = planes.planes_from_spec(pk, spec); reqs = pk.digest_many(tops, groups)
 added = pk.close_signatures()
 eng = Engine(0); eng.set_dictionary(pk); eng.upload(table)
 eng.schedule_batch(reqs, spec.clock_now, pk, apply=False)

@@ -9,7 +9,7 @@ can be turned into
   ``Node.ParseLabels`` (nhd/Node.py:468) or by :mod:`workload.refmodel` when the
   reference is not installed  ->  ``spec.build_nodes(...)``; these objects feed
   ``pack.pack_nodes`` exactly like live scheduler state would;
-* packed device planes directly (``pack.planes_from_spec``), for cluster sizes at
+* packed device planes directly (``workload.planes.planes_from_spec``), for cluster sizes at
   which building ~100 Python objects per node would dominate the benchmark.
   tests/test_pack.py asserts both routes give bit-identical planes.
 """
