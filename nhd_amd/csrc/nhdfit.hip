@@ -2186,11 +2186,26 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
     uint64_t total = 0;
     for (uint32_t t = 0; t < tiles; ++t) total += (uint64_t)chunks * (6u + (2u << c->h_tile_wcls[t]));
     std::vector<FitItem> items;
+    // XCD-aware form (big problems): the fit role leads the grid and block b runs on XCD b % 8 (observed placement, used
+    // for speed only), so every tile gets a multiple of 8 blocks and block j of a tile works inside eighth j % 8 of the
+    // node axis: an XCD's L2 then only ever sees its eighth of the node records (0.7 MB at 65 536 nodes instead of all
+    // 5.5 MB of the three row widths + busy times - more than the 4 MB an XCD has), re-read once per pod tile.
+    static const bool xcd_items = !(getenv("NHDFIT_XCD_ITEMS") && atoi(getenv("NHDFIT_XCD_ITEMS")) == 0);
+    const bool by_xcd = xcd_items && !c->fit_blocks && chunks >= 8u * 4u * nw && nw == 8;
     for (uint32_t t = 0; t < tiles; ++t) {           // staged order = widest tiles first
         const uint32_t w = c->h_tile_wcls[t];
         const uint64_t cost = (uint64_t)chunks * (6u + (2u << w));
         uint32_t nb = (uint32_t)((cost * target + total / 2) / total);
         nb = std::max(1u, std::min(nb, (chunks + nw - 1) / nw));          // at least one chunk per wavefront
+        if (by_xcd) {
+            const uint32_t k = nb <= 11 ? 1u : nb <= 23 ? 2u : 4u;         // 8, 16 or 32 blocks
+            for (uint32_t j = 0; j < 8 * k; ++j) {
+                const uint32_t r = (j % 8) * k + j / 8;                     // range r of 8k: the (j / 8)-th piece of eighth j % 8
+                const uint32_t lo = (uint32_t)((uint64_t)chunks * r / (8 * k)), hi = (uint32_t)((uint64_t)chunks * (r + 1) / (8 * k));
+                items.push_back(FitItem{t, w, lo, hi});                     // (never empty: chunks >= 256; keeps b % 8 aligned)
+            }
+            continue;
+        }
         for (uint32_t b = 0; b < nb; ++b) {
             const uint32_t lo = (uint32_t)((uint64_t)chunks * b / nb), hi = (uint32_t)((uint64_t)chunks * (b + 1) / nb);
             if (hi > lo) items.push_back(FitItem{t, w, lo, hi});
