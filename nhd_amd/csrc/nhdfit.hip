@@ -20,6 +20,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1618,6 +1619,20 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+template <class T>
+struct PinBuf {                   // page-locked host staging: async copies in both directions, no bounce buffer inside the runtime
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 constexpr int kEventRing = 256;
 constexpr int kBufs = 8;          // buffer sets: step s owns set s % kBufs from its digest (one launch before its fit)
                                   // to the end of its mapping (four launches after it, five when sharded)
@@ -1669,6 +1684,8 @@ struct nhdfit_ctx {
     // requests / results
     DevBuf<nhdfit_req> reqs; uint32_t P = 0;
     std::vector<uint32_t> perm;          // device (class-sorted) position -> caller's pod index
+    PinBuf<nhdfit_req> pin_reqs; PinBuf<uint8_t> pin_wcls; PinBuf<uint64_t> pin_score; PinBuf<nhdfit_mapping> pin_maps;   // host staging of one call
+    PinBuf<uint8_t> pin_items;           // the fit role's work items on their way to the device
     DevBuf<PodHeader> hdr[kBufs]; DevBuf<uint8_t> tabs[kBufs];
     DevBuf<unsigned long long> score[kBufs]; DevBuf<nhdfit_mapping> maps[kBufs];
     DevBuf<uint64_t> nm;                 // node-major verdict words [tiles][chunks*64] (one buffer: the fit roles of consecutive steps run in stream order)
@@ -1849,6 +1866,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->origin.release(); c->deltas.release(); c->delta_run.release(); c->delta_status.release();
+    c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release();
     c->reqs.release(); c->bitmap.release(); c->nm.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); c->shape_list[b].release(); }
@@ -2083,21 +2101,24 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     // Pods are staged sorted by request class so that 64-pod tiles are homogeneous (narrow table rows, fast sweep of
     // the fit role) and the lanes of the mapping roles have similar group counts; results are un-permuted in fetch.
     c->perm.resize(P);
-    std::vector<uint32_t> key(P);
+    std::vector<uint16_t> key(P);
     c->n_big_pods = 0;
+    uint32_t start[512 + 1] = {0};
     for (uint32_t p = 0; p < P; ++p) {
         const PodHeader h = pod_header(reqs[p]);
-        c->perm[p] = p;
         // group count is the major key, descending: the tiles with the most assignments to sweep are the
         // first blocks of the fit grid (longest-first keeps the tail of the launch short)
-        key[p] = ((h.flags & kPodValid) ? 0u : 1u << 16) | ((reqs[p].n_groups > 3 ? 1u : 0u) << 15) |
-                 ((15u - (reqs[p].n_groups & 15u)) << 8) | (h.flags & (kPodNeedGpu | kPodPci | kPodFilter));
+        key[p] = (uint16_t)(((h.flags & kPodValid) ? 0u : 1u << 8) | ((reqs[p].n_groups > 3 ? 1u : 0u) << 7) |
+                            ((15u - (reqs[p].n_groups & 15u)) << 3) | ((h.flags & (kPodNeedGpu | kPodPci | kPodFilter)) >> 1));
         c->n_big_pods += reqs[p].n_groups > 3;
+        start[key[p] + 1]++;
     }
-    std::stable_sort(c->perm.begin(), c->perm.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
-    std::vector<nhdfit_req> sorted(P);
+    for (uint32_t k = 0; k < 512; ++k) start[k + 1] += start[k];          // stable counting sort: 9-bit keys
+    for (uint32_t p = 0; p < P; ++p) c->perm[start[key[p]]++] = p;
+    HIPCHK(c, c->pin_reqs.reserve(P));
+    nhdfit_req* sorted = c->pin_reqs.p;                                   // (free again: sync_all above waited for the last copy out of it)
     for (uint32_t i = 0; i < P; ++i) sorted[i] = reqs[c->perm[i]];
-    HIPCHK(c, hipMemcpy(c->reqs.p, sorted.data(), (size_t)P * sizeof *reqs, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpyAsync(c->reqs.p, sorted, (size_t)P * sizeof *reqs, hipMemcpyHostToDevice, c->stream));
     // row width class of every tile: 2^(largest group count among its valid pods) assignments - the digest role
     // derives the same class from the same records
     c->h_tile_wcls.assign(tiles, 0);
@@ -2109,7 +2130,9 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
             if (w > c->max_wcls) c->max_wcls = w;
         }
     HIPCHK(c, c->tile_wcls.reserve(tiles));
-    HIPCHK(c, hipMemcpy(c->tile_wcls.p, c->h_tile_wcls.data(), tiles, hipMemcpyHostToDevice));
+    HIPCHK(c, c->pin_wcls.reserve(tiles));
+    memcpy(c->pin_wcls.p, c->h_tile_wcls.data(), tiles);
+    HIPCHK(c, hipMemcpyAsync(c->tile_wcls.p, c->pin_wcls.p, tiles, hipMemcpyHostToDevice, c->stream));
     c->P = P;
     c->hp_rows = (uint32_t)hp_max + 2;
     c->n_items = 0;                                 // the fit role's work items are rebuilt at the next step
@@ -2212,8 +2235,11 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
         }
     }
     HIPCHK(c, c->items.reserve(items.size() ? items.size() : 1));
-    HIPCHK(c, hipMemcpyAsync(c->items.p, items.data(), items.size() * sizeof(FitItem), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));      // `items` is a local
+    // page-locked staging, no wait: the list is only rebuilt after something drained the stream (stage_requests,
+    // upload_nodes, set_node_count all sync first), so the previous copy out of this buffer is long done
+    HIPCHK(c, c->pin_items.reserve(items.size() * sizeof(FitItem) + 1));
+    memcpy(c->pin_items.p, items.data(), items.size() * sizeof(FitItem));
+    HIPCHK(c, hipMemcpyAsync(c->items.p, c->pin_items.p, items.size() * sizeof(FitItem), hipMemcpyHostToDevice, c->stream));
     c->n_items = (uint32_t)items.size();
     return NHDFIT_OK;
 }
@@ -2445,15 +2471,27 @@ int nhdfit_sync(nhdfit_ctx* c) {
 int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out) {
     if (!c) return NHDFIT_E_INVAL;
     if (!c->P || !c->n_fit) return fail(c, NHDFIT_E_STATE, "nothing staged / no step enqueued");
-    int rc = nhdfit_sync(c);
-    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->dev));
+    if (map_out && !c->want_map) return fail(c, NHDFIT_E_STATE, "mapping output is disabled");
     const uint32_t P = c->P;
     const int b = (int)((c->n_fit - 1) % kBufs);               // results of the most recent step
+    // the launches that finish the mappings still in flight, the copies behind them on the same stream, ONE wait
+    { int rc_ = flush_pipeline(c); if (rc_) return rc_; }
+    if (c->comm) HIPCHK(c, hipStreamSynchronize(c->s_red));
     if (score_out) {
-        std::vector<uint64_t> tmp(P);
-        HIPCHK(c, hipMemcpy(tmp.data(), c->score[b].p, (size_t)P * 8, hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < P; ++i) score_out[c->perm[i]] = tmp[i];
+        HIPCHK(c, c->pin_score.reserve(P));
+        HIPCHK(c, hipMemcpyAsync(c->pin_score.p, c->score[b].p, (size_t)P * 8, hipMemcpyDeviceToHost, c->stream));
     }
+    if (map_out) {
+        HIPCHK(c, c->pin_maps.reserve(P));
+        HIPCHK(c, hipMemcpyAsync(c->pin_maps.p, c->maps[b].p, (size_t)P * sizeof(nhdfit_mapping), hipMemcpyDeviceToHost, c->stream));
+    }
+    int rc = nhdfit_sync(c);
+    if (rc) return rc;
+    if (score_out)
+        for (uint32_t i = 0; i < P; ++i) score_out[c->perm[i]] = c->pin_score.p[i];
+    if (map_out)
+        for (uint32_t i = 0; i < P; ++i) map_out[c->perm[i]] = c->pin_maps.p[i];
     if (bitmap_out) {
         if (!c->want_bitmap) return fail(c, NHDFIT_E_STATE, "bitmap output is disabled");
         const size_t chunks = (c->n + 63) / 64;
@@ -2463,22 +2501,29 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
         for (size_t ch = 0; ch < chunks; ++ch)
             for (uint32_t i = 0; i < P; ++i) bitmap_out[ch * P + c->perm[i]] = tmp[ch * P + i];
     }
-    if (map_out) {
-        if (!c->want_map) return fail(c, NHDFIT_E_STATE, "mapping output is disabled");
-        std::vector<nhdfit_mapping> tmp(P);
-        HIPCHK(c, hipMemcpy(tmp.data(), c->maps[b].p, (size_t)P * sizeof(nhdfit_mapping), hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < P; ++i) map_out[c->perm[i]] = tmp[i];
-    }
     return NHDFIT_OK;
 }
 
 int nhdfit_find(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand,
                 uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out) {
+    static const bool prof = getenv("NHDFIT_FIND_PROF") != nullptr;      // tuning aid: host-side phase times of the call
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!prof) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[nhdfit] find P=%u %s %.1f us\n", P, what, std::chrono::duration<double, std::micro>(t1 - t0).count());
+        t0 = t1;
+    };
     int rc = nhdfit_stage_requests(c, reqs, P);
     if (rc) return rc;
+    lap("stage");
     if (cand && (rc = stage_cand(c, cand))) return rc;
     if ((rc = nhdfit_enqueue_step(c, now))) return rc;
-    return nhdfit_fetch(c, score_out, bitmap_out, map_out);
+    lap("enqueue");
+    if (prof) { if ((rc = flush_pipeline(c))) return rc; lap("flush-launches"); if ((rc = nhdfit_sync(c))) return rc; lap("sync"); }
+    rc = nhdfit_fetch(c, score_out, bitmap_out, map_out);
+    lap("fetch");
+    return rc;
 }
 
 namespace {
