@@ -158,6 +158,7 @@ class Engine:
     def download(self, first: int = 0, count: Optional[int] = None) -> pack.NodeTable:
         count = self.n - first if count is None else count
         t = pack.empty_table(count)
+        t.origin = None                                     # not read back: uploading this table leaves the origin records alone
         self._chk(self.lib.nhdfit_download_nodes(self.ctx, first, count, _p(t.p0), _p(t.p1), _p(t.p2), _p(t.p3), _p(t.p4), _p(t.detail)))
         return t
 
@@ -432,6 +433,7 @@ class GroupEngine:
     def download(self, first: int = 0, count: Optional[int] = None) -> pack.NodeTable:
         count = self.n - first if count is None else count
         out = pack.empty_table(count)
+        out.origin = None
         i = first
         while i < first + count:
             k = self._shard_of(i)

@@ -342,7 +342,7 @@ class HipMatcher:
         for name, node in self._dirty.items():
             i = self._index[name]
             self.packer.pack_node_into(node, one, 0)
-            for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
+            for f in ("p0", "p1", "p2", "p3", "p4", "detail", "origin"):
                 getattr(self._table, f)[i] = getattr(one, f)[0]
         self.engine.set_dictionary(self.packer)        # signatures may have been added
         idx = sorted(self._index[nm] for nm in self._dirty)
