@@ -60,6 +60,7 @@ def _tracked_class(base: type) -> type:
         def make(orig, name):
             def wrapper(self, *a, **kw):
                 ok = False
+                out = None
                 try:
                     out = orig(self, *a, **kw)
                     ok = True
@@ -76,8 +77,8 @@ def _tracked_class(base: type) -> type:
                             done = owner._on_commit(self, *a, **kw)
                         elif ok and name == "ClaimPodNICResources":
                             done = owner._on_claim(self, *a, **kw)
-                        elif ok and name in ("RemoveResourcesFromTopology", "AddResourcesFromTopology"):
-                            done = owner._on_topology(self, name, *a, **kw)
+                        elif ok and name in ("RemoveResourcesFromTopology", "AddResourcesFromTopology") and out is not False:
+                            done = owner._on_topology(self, name, *a, **kw)    # (False: the reference gave up half-way, Node.py:543-545 - re-pack)
                         elif ok and name == "ResetResources":
                             done = owner._on_queued_scalar(self, "reset")
                         elif ok and name == "SetHugepages":
