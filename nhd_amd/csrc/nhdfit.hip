@@ -2221,7 +2221,8 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
         uint32_t nb = (uint32_t)((cost * target + total / 2) / total);
         nb = std::max(1u, std::min(nb, (chunks + nw - 1) / nw));          // at least one chunk per wavefront
         if (by_xcd) {
-            const uint32_t k = nb <= 11 ? 1u : nb <= 23 ? 2u : 4u;         // 8, 16 or 32 blocks
+            static const uint32_t force_k = getenv("NHDFIT_XCD_K") ? (uint32_t)atoi(getenv("NHDFIT_XCD_K")) : 0u;   // tuning aid
+            const uint32_t k = force_k ? force_k : nb <= 11 ? 1u : nb <= 23 ? 2u : 4u;         // 8, 16 or 32 blocks
             for (uint32_t j = 0; j < 8 * k; ++j) {
                 const uint32_t r = (j % 8) * k + j / 8;                     // range r of 8k: the (j / 8)-th piece of eighth j % 8
                 const uint32_t lo = (uint32_t)((uint64_t)chunks * r / (8 * k)), hi = (uint32_t)((uint64_t)chunks * (r + 1) / (8 * k));
