@@ -116,13 +116,15 @@ def test_standin_mutators_match_reference(cfg):
     assert D.state_of(snodes) == D.state_of(rnodes)
 
 
+@pytest.mark.parametrize("devices", [None, [0, 1, 2]], ids=["one-engine", "three-shards"])
 @pytest.mark.parametrize("path", D.FIXTURES, ids=[os.path.basename(p)[:-5] for p in D.FIXTURES])
-def test_attached_matcher_mirrors_mutators_as_deltas(path):
-    """Reference-generated fixture through HipMatcher (attached, host-twin engine): binds, FindNode results in between,
-    node objects and mirror at every checkpoint; the mutators travel as deltas - a node is re-packed only where a
-    delta came back with a status."""
+def test_attached_matcher_mirrors_mutators_as_deltas(path, devices):
+    """Reference-generated fixture through HipMatcher (attached, host-twin engine; also sharded over three of them -
+    GroupEngine routes every delta to the shard that owns its node): binds, FindNode results in between, node objects and
+    mirror at every checkpoint; the mutators travel as deltas - a node is re-packed only where a delta came back with a
+    status."""
     case = D.load(path)
-    m, nodes, binds, finds, uploads = D.replay(case, engine_factory=harness.HarnessEngine)
+    m, nodes, binds, finds, uploads = D.replay(case, engine_factory=harness.HarnessEngine, devices=devices)
     assert binds == case["binds"]
     assert finds == case["finds"]
     assert m.delta_stats["applied"] > case["n_ops"] // 2
