@@ -126,3 +126,90 @@ def test_attempt_scheduling_same_binds_and_state(ref, sched_mod, cfg):
     assert a.failed_schedule_count == b.failed_schedule_count
     for k in a.nodes:
         assert node_state(a.nodes[k]) == node_state(b.nodes[k]), k
+
+
+class LifecycleK8S(FakeK8S):
+    """The fake K8s with the pod-side calls of the release / restart paths (nhd/NHDScheduler.py:107-204)."""
+    def __init__(self, pod_groups):
+        super().__init__(pod_groups)
+        self.gone = set()
+
+    def GetCfgAnnotations(self, pod, ns): return False if pod in self.gone else pod       # the "config string" is the pod's name
+    def GetPodNode(self, pod, ns): return self.binds.get(pod)
+    def GetScheduledPods(self, sched_name): return [(p, "ns", "uid-" + p, "Running") for p in self.binds if p not in self.gone]
+
+
+@pytest.mark.parametrize("cfg", [3, 4, 5])
+def test_pod_lifecycle_through_the_unmodified_scheduler(ref, sched_mod, cfg):
+    """Schedule, delete, schedule again, lose track (ResetResources + LoadDeployedConfigs reclaiming every running pod) -
+    all through the UNMODIFIED scheduler methods (AttemptScheduling, ReleasePodResources, ResetResources: NHDScheduler.py:
+    249-353, 185-204, 146-157, 107-144), once with the reference Matcher and once with HipMatcher attached.  Binds and node
+    states must agree step by step; on the HipMatcher side the release / reset / reclaim calls reach the mirror as delta
+    records (row f2) - the mirror equals a fresh pack of the scheduler's nodes at the end and no node was re-uploaded."""
+    import contextlib, io
+    from oracle import ref_loader
+    from nhd_amd import pack
+    S = sched_mod
+    clock = ref_loader.VirtualClock(1.0e6).install()
+    spec = synth.make_cluster(cfg, n_nodes=32)
+    descs = [spec.describe(i) for i in range(spec.n)]
+    pods, groups = synth.make_pods(cfg, n_pods=90)
+    for p in pods:
+        p["misc_smt"] = True
+    names = [f"pod{i}" for i in range(len(pods))]
+    pg = dict(zip(names, groups))
+
+    def make():
+        fake = LifecycleK8S(pg)
+        S.K8SMgr.GetInstance = staticmethod(lambda: fake)
+        import queue
+        sched = S.NHDScheduler(queue.Queue())
+        sched.nodes = {d["name"]: refmodel.build_node(d, ref) for d in descs}
+        tops = {nm: refmodel.make_topology(sp, ref) for nm, sp in zip(names, pods)}
+        sched.GetCfgParser = lambda t, s, _tops=tops: FakeParser(_tops[s] if s in _tops else _tops[s[1]])   # cfgstr: name, or ("cfg", name)
+        return sched, fake
+
+    a, ka = make()
+    b, kb = make()
+    m = HipMatcher(clock=lambda: clock.t, engine_factory=harness.HarnessEngine)
+    b.matcher = m
+    uploads = []
+    m.attach(b.nodes)
+    orig_upload = m.engine.upload
+    m.engine.upload = lambda *x, **k: (uploads.append(x[0].n), orig_upload(*x, **k))[1]
+
+    def both(fn):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ra = fn(a)
+        rb = fn(b)
+        assert ra == rb
+        assert ka.binds == kb.binds
+        for k in a.nodes:
+            assert node_state(a.nodes[k]) == node_state(b.nodes[k]), k
+        return ra
+
+    def schedule(lo, hi):
+        n = 0
+        for name in names[lo:hi]:
+            clock.t += 1.0
+            n += bool(both(lambda s: s.AttemptScheduling(name, "ns")))
+        return n
+
+    assert schedule(0, 50) >= 10
+    bound = [nm for nm in names[:50] if nm in ka.binds]
+    for name in bound[::2]:                                  # pods complete: their resources go back (ReleasePodResources)
+        clock.t += 1.0
+        both(lambda s: s.ReleasePodResources(name, "ns"))
+        ka.gone.add(name); kb.gone.add(name)
+    assert schedule(50, 75) >= 3                             # the freed resources are handed out again
+    clock.t += 1.0
+    both(lambda s: s.ReleasePodResources("pod-nobody-knows", "ns") if not (ka.gone.add("pod-nobody-knows") or kb.gone.add("pod-nobody-knows")) else None)
+    # ^ a pod the API server no longer has: the scheduler resets every node and reclaims what is still running (:190-193)
+    assert schedule(75, 90) >= 1
+    assert m.delta_stats["applied"] >= len(bound) // 2 + len(b.nodes)
+    assert len(uploads) == m.delta_stats["repacked"]
+    m.FindNode(b.nodes, refmodel.make_topology(pods[0], ref))               # flush
+    got = m.engine.download()
+    want = m.packer.pack_nodes(b.nodes)
+    for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
+        assert np.array_equal(getattr(got, f), getattr(want, f)), f
