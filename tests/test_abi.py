@@ -35,3 +35,29 @@ def test_create_without_gpu_fails_loudly():
     from nhd_amd.matcher import HipMatcher
     with pytest.raises(_lib.NhdFitError):
         HipMatcher()
+
+
+def test_null_context_is_an_error_code_not_a_crash():
+    """Every entry point that takes a context answers NHDFIT_E_INVAL to a NULL one (nothing aborts across the boundary)."""
+    lib = _lib.load()
+    buf = (ctypes.c_uint8 * 256)()
+    assert lib.nhdfit_apply_deltas(None, buf, 1, buf) == -1
+    assert lib.nhdfit_upload_origin(None, 0, 1, buf) == -1
+    assert lib.nhdfit_upload_nodes(None, 0, 1, buf, buf, buf, buf, buf, buf) == -1
+    assert lib.nhdfit_download_nodes(None, 0, 1, buf, buf, buf, buf, buf, buf) == -1
+    assert lib.nhdfit_find(None, buf, 1, 0.0, None, buf, None, None) == -1
+    assert lib.nhdfit_commit(None, 0, buf, buf, 0.0, buf) == -1
+    assert lib.nhdfit_stage_requests(None, buf, 1) == -1
+    assert lib.nhdfit_enqueue_step(None, 0.0) == -1
+    assert lib.nhdfit_sync(None) == -1
+    assert lib.nhdfit_set_node_count(None, 0) == -1
+    assert lib.nhdfit_reserve_nodes(None, 1, 0) == -1
+
+
+def test_delta_and_origin_records_match_header():
+    assert pack.ORIGIN.itemsize == 80 and pack.DELTA.itemsize == 96
+    # field offsets the device code relies on (include/nhdfit.h)
+    assert pack.DELTA.fields["t0"][1] == 8 and pack.DELTA.fields["gpus"][1] == 40 and pack.DELTA.fields["groups"][1] == 64
+    assert pack.DELTA.fields["busy_time"][1] == 72 and pack.DELTA.fields["nic_n"][1] == 80
+    assert pack.DETAIL.fields["nic_pods"][1] == 82 and pack.DETAIL.fields["gpu_sw"][1] == 96
+    assert pack.ORIGIN.fields["nic_base"][1] == 32 and pack.ORIGIN.fields["hp_total"][1] == 64
