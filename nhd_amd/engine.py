@@ -54,6 +54,10 @@ class Engine:
                                                  npools, _p(cc), ncc))
         self._dict_version = packer.dict_version
 
+    def forget_dictionary(self):
+        """The next set_dictionary uploads whatever packer it is given (a NEW Packer restarts its version count)."""
+        self._dict_version = -1
+
     def upload(self, table: pack.NodeTable, global_base: int = 0, first: int = 0, capacity: Optional[int] = None):
         """Full upload (first == 0 and nothing uploaded yet) or delta upload of `table` at `first`."""
         cap = max(capacity or 0, first + table.n)
@@ -266,6 +270,10 @@ class GroupEngine:
     def set_dictionary(self, packer: pack.Packer):
         for s in self.shards:
             s.set_dictionary(packer)
+
+    def forget_dictionary(self):
+        for s in self.shards:
+            s.forget_dictionary()
 
     def reset_nodes(self):
         for s in self.shards:

@@ -157,6 +157,10 @@ class HipMatcher:
         """Mirror `nodes` (the scheduler's self.nodes) persistently and track changes to it."""
         self._attached = nodes
         self._mirror_foreign = False
+        # a fresh dictionary: NIC signatures, capacity classes and group sets of nodes that left the cluster (or of states
+        # nothing is in any more) do not pile up over the life of a scheduler that re-attaches after node churn
+        self.packer = pack.Packer()
+        self.engine.forget_dictionary()
         for node in nodes.values():
             if type(node) not in _tracked_cache.values():
                 node.__class__ = _tracked_class(type(node))
@@ -408,10 +412,7 @@ class HipMatcher:
         for i in np.flatnonzero(codes > wire.WIRE_NONE):     # what the reference would raise on: report it properly
             wire.digest_config(cfg_texts[int(i)])
         skip = codes == wire.WIRE_NONE                       # all-zero (= never matching) requests
-        if pod_groups is not None:
-            for i in np.flatnonzero(~skip):
-                reqs[i]["flags"] = pack.RF_INITIAL_FILTER
-                reqs[i]["groups"] = self.packer.group_bits_known(pod_groups[int(i)])
+        # (the pods' group bits are filled in by _run, after the mirror - and with it the dictionary - is current)
         for i in np.flatnonzero(~skip):
             if reqs[i]["n_groups"] == 0 and len(nl):
                 raise IndexError("pod without processing groups (the reference fails the same way, Matcher.py:346)")
@@ -449,6 +450,10 @@ class HipMatcher:
             self._mirror_foreign = self._attached is not None
         if reqs is None:
             reqs = self.packer.digest_many(tops, pod_groups)
+        elif pod_groups is not None:                       # requests digested from config texts: InitialNodeFilter in the kernel
+            for i in range(n_pods):
+                reqs[i]["flags"] = pack.RF_INITIAL_FILTER
+                reqs[i]["groups"] = self.packer.group_bits_known(pod_groups[i])
         places = None
         if sequential:
             self.packer.close_signatures()                 # every NIC state a commit can produce has a signature

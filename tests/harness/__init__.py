@@ -141,6 +141,9 @@ class HarnessEngine:
     def set_dictionary(self, packer):
         self.packer = packer
 
+    def forget_dictionary(self):
+        pass
+
     def reset_nodes(self):
         self.n = 0
         self.table = None

@@ -90,3 +90,28 @@ def test_attached_dict_grows_and_foreign_dicts_do_not_corrupt_the_mirror():
     assert [norm(r) for r in m.FindNodes(nl, tops)] == [norm(O.find_node(nl, t, spec.clock_now)) for t in tops]
     nl[names[3]].maintenance = True
     assert [norm(r) for r in m.FindNodes(nl, tops)] == [norm(O.find_node(nl, t, spec.clock_now)) for t in tops]
+
+
+def test_reattach_after_node_churn_compacts_the_dictionary():
+    """Nodes leave and join the attached dict: the matcher re-attaches with a FRESH packer - signatures / group sets only
+    the departed nodes had are gone, results stay the oracle's, and pods given as config-less requests with groups (the
+    in-kernel InitialNodeFilter) use the new group ids."""
+    spec = synth.make_cluster(5, n_nodes=160)
+    nl = spec.build_nodes()
+    pods, groups = synth.make_pods(5, n_pods=40)
+    tops = [refmodel.make_topology(s) for s in pods]
+    m = HipMatcher(clock=lambda: spec.clock_now, engine_factory=harness.HarnessEngine)
+    m.attach(nl)
+    want = [norm(O.find_node(O.initial_node_filter(nl, g), t, spec.clock_now)) for t, g in zip(tops, groups)]
+    assert [norm(r) for r in m.FindNodes(nl, tops, pod_groups=groups)] == want
+    sigs_before, sets_before, packer_before = len(m.packer.sigs), len(m.packer.group_sets), m.packer
+    for name in list(nl)[:120]:                      # three quarters of the cluster go away ...
+        del nl[name]
+    extra = synth.make_cluster(5, n_nodes=200).build_nodes()
+    for name in list(extra)[160:170]:                # ... ten new nodes join
+        nl[name] = extra[name]
+    want = [norm(O.find_node(O.initial_node_filter(nl, g), t, spec.clock_now)) for t, g in zip(tops, groups)]
+    assert [norm(r) for r in m.FindNodes(nl, tops, pod_groups=groups)] == want
+    assert m.packer is not packer_before
+    assert len(m.packer.sigs) <= sigs_before and len(m.packer.group_sets) < sets_before
+    assert len(m._names) == 50
