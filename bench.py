@@ -277,13 +277,14 @@ def delta_rate(eng, table, n=4096):
 
 def other_configs(args, device):
     """BASELINE.json's other shapes on one GPU, same step, same clock (not the headline; 60 steps each): config 2 whole
-    (4 096 nodes x 256 pods), config 3 whole (16 384 x 1 024), one config-5 shard (32 768 x 2 048: an eighth of its nodes, an
-    eighth of its pods).  Mode A step rate and the mode-B decision rate of each."""
+    (4 096 nodes x 256 pods), config 3 whole (16 384 x 1 024), a config-5 shard cut both ways (32 768 x 2 048: an eighth of
+    its nodes, an eighth of its pods) and as one GPU of the 8-GPU run has it (32 768 nodes x all 16 384 pods).  Mode A step rate
+    and the mode-B decision rate of each."""
     from nhd_amd import pack
     from nhd_amd.engine import Engine
     from workload import planes, refmodel, synth
     rows = []
-    for cfg, n, P in ((2, 4096, 256), (3, 16384, 1024), (5, 32768, 2048)):
+    for cfg, n, P in ((2, 4096, 256), (3, 16384, 1024), (5, 32768, 2048), (5, 32768, 16384)):
         if (cfg, n, P) == (args.config, args.nodes_per_gpu, args.pods):
             continue
         spec = synth.make_cluster(cfg, n_nodes=n)
