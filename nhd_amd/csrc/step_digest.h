@@ -1,0 +1,248 @@
+// step_digest.h - request digest role of the step kernel (k_step): pod requests -> bit-sliced tile image.
+// Device code of libnhdfit.so; included by nhdfit.hip inside its anonymous namespace, in this order: step_digest.h,
+// step_fit.h, step_map.h, step_kernel.h, seq_kernel.h (one translation unit: the roles are fused into one kernel).
+// gfx950 only.
+struct DictView {
+    const double* caps;
+    uint32_t ncls;
+    const uint64_t* group_sets;
+    SigDict sig;
+    // the same dictionary as ONE stream of 16-bit words the digest role stages in LDS (walking the three CSR levels in
+    // global memory costs a dependent scalar load per level, pool and class - 2-3 us per signature):
+    // [0, nsig]: word offset of each signature's record behind the table; record = { #pools, per pool: glimit << 8 | #cc,
+    // then #cc x (cls << 8 | cnt) }
+    const uint16_t* flat;
+    uint32_t flat_words;             // 0: not available (the stream would not fit 16-bit offsets)
+};
+
+// v_writelane_b32 (SGPR -> one lane of a VGPR).  This clang has no __builtin_amdgcn_writelane; the
+// asm label binds the declaration straight to the LLVM intrinsic, as the ROCm device libs do.
+extern "C" __device__ int nhd_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+struct PaddedReq { nhdfit_req r; uint32_t pad; };             // LDS copies, 33-word stride: lane j -> bank j
+
+// Coalesced copy of up to 64 consecutive request records (from pod0) into LDS, zero (= invalid) past P.
+template <int THREADS>
+__device__ __forceinline__ void stage_requests_lds(const nhdfit_req* __restrict__ reqs, uint32_t pod0, uint32_t P, PaddedReq* s_req) {
+    constexpr uint32_t kParts = sizeof(nhdfit_req) / 16;
+    const uint32_t live = pod0 < P ? (P - pod0 < (uint32_t)kTile ? P - pod0 : (uint32_t)kTile) : 0u;
+    const uint4* src = reinterpret_cast<const uint4*>(reqs + pod0);
+    for (uint32_t c = threadIdx.x; c < kTile * kParts; c += THREADS) {
+        const uint32_t j = c / kParts;
+        const uint4 v = j < live ? src[c] : make_uint4(0u, 0u, 0u, 0u);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&s_req[j]) + (c % kParts) * 4;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+}
+
+template <class T>
+__device__ __forceinline__ T* carve(uint8_t*& p, size_t count) {      // 16-byte aligned slices of a block's LDS
+    T* r = reinterpret_cast<T*>(p);
+    p += (count * sizeof(T) + 15) & ~size_t(15);
+    return r;
+}
+constexpr size_t lds_slice(size_t bytes) { return (bytes + 15) & ~size_t(15); }
+
+struct DigestArgs {
+    const nhdfit_req* reqs;          // class-sorted order (as staged)
+    uint32_t P;
+    DictView d;
+    Layout L[kWClasses];             // image layout per row width W = 2 << class
+    uint32_t pitch;                  // bytes between tile images
+    uint8_t* tabs;                   // out: tile images
+    PodHeader* hdr;                  // out: [tiles*64]
+    unsigned long long* score;       // out: zeroed (the fit role accumulates with atomicMax)
+    const uint64_t* xcls;            // interned (NUMA, free GPUs, signature) classes of the mirror: key of X row k
+    const uint32_t* nx;              // number of classes
+};
+constexpr uint32_t kDictLdsWords = 6144;             // 12 KB for the staged signature stream (c5: 151 signatures = 1.5 K words)
+constexpr size_t kDigestLds = lds_slice(kTile * sizeof(PaddedReq)) + lds_slice(kTile * sizeof(PodSums)) +
+                              lds_slice(kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1) * sizeof(uint16_t)) + lds_slice(kTile * sizeof(PodHeader)) +
+                              lds_slice(kDictLdsWords * sizeof(uint16_t));
+constexpr uint32_t kWcParts = 4;                     // blocks per tile that share its CPU rows (free-core count c = part mod 4)
+constexpr uint32_t kDigestParts = 1 + kWcParts;      // part 0 = GPU / NIC rows (cold section + X), parts 1..4 = CPU rows, the last one also HP / GX
+
+// Request digest, kDigestParts blocks per 64-pod tile: per-pod subset sums / NIC covers in LDS, then the table rows
+// (lane = pod, one ballot per assignment).  The role is a chain of dependent phases, not a lot of work: it is cut
+// into parts by table so that the chain of each block stays short.
+template <int THREADS>
+__device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, uint8_t* lds) {
+    PaddedReq* s_req = carve<PaddedReq>(lds, kTile);
+    PodSums* s_sum = carve<PodSums>(lds, kTile);
+    uint16_t (*s_cover)[NHDFIT_MAX_CLASSES][kMaxG + 1] =
+        reinterpret_cast<uint16_t (*)[NHDFIT_MAX_CLASSES][kMaxG + 1]>(carve<uint16_t>(lds, kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1)));
+    PodHeader* s_hdr = carve<PodHeader>(lds, kTile);
+    uint16_t* s_flat = carve<uint16_t>(lds, kDictLdsWords);
+
+    const uint32_t tile = blk / kDigestParts, part = blk % kDigestParts;
+    const uint32_t tid = threadIdx.x;
+    uint8_t* img = a.tabs + (size_t)tile * a.pitch;
+
+    stage_requests_lds<THREADS>(a.reqs, tile * kTile, a.P, s_req);
+    __syncthreads();
+    constexpr uint32_t NW = THREADS / 64;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    if (tid < kTile) {
+        const nhdfit_req& r = s_req[tid].r;
+        const PodHeader h = pod_header(r);
+        s_hdr[tid] = h;
+        PodSums& ps = s_sum[tid];
+        ps.G = r.n_groups; ps.W = 1u << (r.n_groups & 7u); ps.full = ps.W - 1;
+        ps.misc_smt = r.misc_smt; ps.misc_nosmt = r.misc_nosmt;
+        if (part == 0) {
+            const uint32_t pod = tile * kTile + tid;
+            a.hdr[pod] = h;
+            if (pod < a.P) a.score[pod] = 0;
+        }
+    }
+    {   // subset sums (pod_sums), one subset per (wavefront, lane = pod) instead of 16 in a row on one wavefront
+        const nhdfit_req& r = s_req[lane].r;
+        const bool ok = req_valid(r);
+        for (uint32_t S = wave; S < (1u << kMaxG); S += NW) {
+            if (!ok || S >= (1u << r.n_groups)) continue;
+            uint32_t g = 0, x = 0, y = 0;
+            for (uint32_t i = 0; i < r.n_groups; ++i)
+                if (S >> i & 1) { g += r.gpus[i]; x += r.cpu_smt[i]; y += r.cpu_nosmt[i]; }
+            s_sum[lane].gpu[S] = g; s_sum[lane].cpu_smt[S] = x; s_sum[lane].cpu_nosmt[S] = y;
+        }
+    }
+    __syncthreads();
+
+    const bool valid = (s_hdr[lane].flags & kPodValid) != 0;
+    // the tile's row width: 2^(largest group count among its pods) - the same rule the host applies when it
+    // builds the fit role's work items (tile_wclass)
+    const uint32_t my_g = valid ? (s_hdr[lane].flags >> kPodGroupsShift) & 7u : 0u;
+    const uint32_t wcls = __ballot(my_g >= 4) ? 3u : __ballot(my_g == 3) ? 2u : __ballot(my_g == 2) ? 1u : 0u;
+    const Layout& L = a.L[wcls];
+    const uint32_t W = L.W;
+    uint8_t* hot = img + L.off_hot;
+    // bit-sliced row: lane = pod holds its 16-bit entry (bit p = assignment p passes), one ballot per assignment
+    // turns the 64 entries into the row's W words (bit j of word p = assignment p of pod j passes)
+    auto emit_row = [&](uint8_t* row, uint32_t v) {
+        unsigned long long mine = 0;
+        for (uint32_t p = 0; p < W; ++p) {
+            const unsigned long long word = __ballot(v >> p & 1);
+            if (lane == p) mine = word;
+        }
+        if (lane < W) *reinterpret_cast<unsigned long long*>(row + lane * 8) = mine;
+    };
+
+    if (part != 0) {
+        // CPU records WC[u][smt][c] = {m=0 row, m=1 row}: for a pod, socket, SMT mode and misc placement the entry is
+        // { p : demand_p <= c } - the demands are read once per (socket, misc, smt) group and swept over c in
+        // registers (one group per wavefront) instead of being re-read from LDS for each of the rows of the group
+        for (uint32_t g = wave; g < 8; g += NW) {
+            const uint32_t u = g >> 2, m = (g >> 1) & 1, smt = g & 1;
+            uint32_t t[1 << kMaxG];
+#pragma unroll
+            for (uint32_t p = 0; p < (1u << kMaxG); ++p) {
+                t[p] = 0xFFFFFFFFu;
+                if (valid && p < s_sum[lane].W) {
+                    const uint32_t* sum = smt ? s_sum[lane].cpu_smt : s_sum[lane].cpu_nosmt;
+                    const uint32_t extra = m ? (smt ? s_sum[lane].misc_smt : s_sum[lane].misc_nosmt) : 0;
+                    t[p] = sum[u ? p : (~p & s_sum[lane].full)] + extra;
+                }
+            }
+            uint8_t* base = hot + (u ? L.hot_wc1 : L.hot_wc0) + smt * L.fc_dim * L.wc_stride + m * L.row;
+            for (uint32_t c = part - 1; c < L.fc_dim; c += kWcParts) {
+                uint32_t v = 0;
+#pragma unroll
+                for (uint32_t p = 0; p < (1u << kMaxG); ++p) v |= (t[p] <= c ? 1u : 0u) << p;
+                emit_row(base + c * L.wc_stride, v);
+            }
+        }
+        if (part != kWcParts) return;
+        // 64-bit scalar-predicate rows: ballots over the 64 pods (lane = pod).  HP: one wavefront per row.  GX: there can
+        // be hundreds of node-group sets (c5: every 1-3 name combination of 16 names) - a wavefront takes 64 sets at a time,
+        // one coalesced load, and hands them round with v_readlane (a scalar load per row costs a memory round trip each);
+        // lane i keeps the word of set i and stores its two rows (inactive, active: NHDScheduler.py:240-242, gx_bit).
+        for (uint32_t k = wave; k < L.hp_rows; k += NW) {
+            const uint64_t word = __ballot(hp_bit(s_hdr[lane], k));
+            if (lane == 0) *reinterpret_cast<uint64_t*>(hot + L.hot_hp + 8 * k) = word;
+        }
+        const bool filtered = (s_hdr[lane].flags & kPodFilter) != 0;       // else: the caller filtered already - every row passes
+        const uint64_t my_groups = s_hdr[lane].groups;
+        const uint64_t unfiltered = __ballot(!filtered);
+        if (tid == 0) *reinterpret_cast<uint64_t*>(hot + L.hot_gx) = 0;     // row 0: never
+        for (uint32_t g0 = wave * 64; g0 < L.ngs; g0 += NW * 64) {
+            const uint32_t cnt = L.ngs - g0 < 64u ? L.ngs - g0 : 64u;
+            const uint64_t my_set = lane < cnt ? a.d.group_sets[g0 + lane] : 0ull;
+            uint64_t mine = 0;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint64_t set = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_set, (int)i) |
+                                     (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_set >> 32), (int)i) << 32;
+                const uint64_t word = unfiltered | __ballot(filtered && (set & my_groups) != 0);
+                if (lane == i) mine = word;
+            }
+            if (lane < cnt) {
+                uint64_t* rows = reinterpret_cast<uint64_t*>(hot + L.hot_gx + 8 * (1 + 2 * (g0 + lane)));
+                rows[0] = unfiltered;                                        // node not active
+                rows[1] = mine;
+            }
+        }
+        return;
+    }
+
+    // part 0: NIC covers per (pod, capacity class), then the cold rows A0/A1[f], R0/R1[sig].  The unions behind both are
+    // instantiated per row width (uniform over the block): a two-group tile pays 4 terms per union, not 16.
+    const bool staged = a.d.flat_words != 0 && a.d.flat_words <= kDictLdsWords;
+    if (staged)
+        for (uint32_t w = tid; w < a.d.flat_words / 2; w += THREADS)        // (the stream is padded to an even word count)
+            reinterpret_cast<uint32_t*>(s_flat)[w] = reinterpret_cast<const uint32_t*>(a.d.flat)[w];
+    auto covers_and_sig_rows = [&](auto width) {
+        constexpr uint32_t WW = decltype(width)::value;
+        for (uint32_t w = tid; w < kTile * a.d.ncls; w += THREADS) {
+            const uint32_t j = w % kTile, c = w / kTile;
+            if (s_hdr[j].flags & kPodValid) class_cover_w<WW>(s_req[j].r, a.d.caps[c], s_sum[j].W, s_sum[j].G, s_cover[j][c]);
+        }
+        __syncthreads();
+        for (uint32_t sig = wave; sig < L.nsig; sig += NW) {    // one reach family per (signature, pod), both sockets' rows from it
+            uint32_t reach = 0;
+            if (staged) {
+                // the record is read with the same address in every lane (LDS broadcast); readfirstlane hands the loop
+                // bounds to the scalar unit so the walk stays wave-uniform
+                auto word = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flat[i]); };
+                uint32_t at = a.d.sig.nsig + 1 + word(sig);
+                const uint32_t npools = word(at++);
+                reach = 1;
+                for (uint32_t pl = 0; pl < npools; ++pl) {
+                    const uint32_t head = word(at++), ncc = head & 0xFFu, glimit = head >> 8;
+                    uint32_t pool = 1;
+                    for (uint32_t k = 0; k < ncc; ++k) {
+                        const uint32_t e = word(at++), cnt = e & 0xFFu, cls = e >> 8;
+                        pool = dunion_n<WW>(pool, s_cover[lane][cls][cnt > (uint32_t)kMaxG ? kMaxG : cnt]);
+                    }
+                    if (glimit != NHDFIT_GLIMIT_NONE) pool &= size_le_mask(s_sum[lane].W, glimit);
+                    reach = dunion_n<WW>(reach, pool);
+                }
+                if (!valid) reach = 0;
+            } else {
+                reach = valid ? sig_reach_w<WW>(a.d.sig, sig, &s_cover[lane][0][0], s_sum[lane].W) : 0u;
+            }
+            emit_row(img + L.off_r0 + sig * L.row, valid ? entry_r(reach, s_sum[lane].W, 0) : 0u);
+            emit_row(img + L.off_r1 + sig * L.row, valid ? entry_r(reach, s_sum[lane].W, 1) : 0u);
+        }
+    };
+    if (W == 2) covers_and_sig_rows(std::integral_constant<uint32_t, 2>{});
+    else if (W == 4) covers_and_sig_rows(std::integral_constant<uint32_t, 4>{});
+    else if (W == 8) covers_and_sig_rows(std::integral_constant<uint32_t, 8>{});
+    else covers_and_sig_rows(std::integral_constant<uint32_t, 16>{});
+    for (uint32_t k = wave; k < 2 * L.fg_dim; k += NW) {
+        const uint32_t u = k >= L.fg_dim, f = u ? k - L.fg_dim : k;
+        emit_row(img + (u ? L.off_a1 : L.off_a0) + f * L.row, valid ? entry_a(s_sum[lane], u, f) : 0u);
+    }
+    __syncthreads();                                            // the block reads back the cold rows it just wrote
+    // hot rows X[class] = A_u[f] & (PCI-mode pods: R_u[sigPCI], NUMA-mode pods: R_u[sigNUMA]) - pure word
+    // operations on the cold rows, one lane per (class, assignment)
+    const uint64_t m_pci = __ballot((s_hdr[lane].flags & kPodPci) != 0);
+    const uint32_t nx = a.nx[0] < L.x_cap ? a.nx[0] : L.x_cap;
+    for (uint32_t i = tid; i < nx * W; i += THREADS) {
+        const uint32_t k = i / W, p = i % W;
+        const uint64_t key = a.xcls[k];
+        const uint32_t u = xkey_u(key);
+        const uint8_t* rbase = img + (u ? L.off_r1 : L.off_r0) + p * 8;
+        const uint64_t av = ld64(img, (u ? L.off_a1 : L.off_a0) + xkey_f(key) * L.row + p * 8);
+        const uint64_t rn = ld64(rbase, xkey_sig_numa(key) * L.row), rp = ld64(rbase, xkey_sig_pci(key) * L.row);
+        *reinterpret_cast<uint64_t*>(hot + L.hot_x + k * L.x_stride + p * 8) = av & ((rp & m_pci) | (rn & ~m_pci));
+    }
+}

@@ -1,0 +1,333 @@
+// step_fit.h - fit role of the step kernel: the P x N pass over node records against the staged tile image.
+// Device code of libnhdfit.so; included by nhdfit.hip inside its anonymous namespace, in this order: step_digest.h,
+// step_fit.h, step_map.h, step_kernel.h, seq_kernel.h (one translation unit: the roles are fused into one kernel).
+// gfx950 only.
+struct FitItem { uint32_t tile, wcls, c_begin, c_end; };       // one block of the fit role: chunks [c_begin, c_end) of a tile
+
+struct FitArgs {
+    const NodeRec* rec[kWClasses];   // node records per row width (k_xrecords), padded to a multiple of 64 nodes
+    const nhdfit_plane4* p4;         // busy times (padded likewise)
+    uint32_t n;                 // nodes in this shard
+    uint32_t chunks;            // ceil(n / 64)
+    uint64_t global_base;
+    double busy_from;           // busy_threshold(now): a node is busy iff busy_time >= busy_from
+    const uint8_t* tabs;        // tile images
+    uint32_t pitch;
+    uint32_t off_hot[kWClasses], hot_bytes[kWClasses], hot_hp[kWClasses];   // per row width: where the hot section starts, its size, its HP rows
+    uint32_t hot_staged[kWClasses];   // == hot_bytes: the whole section is staged in LDS.  Smaller: only this prefix (it ends inside X) and the
+                                      // HP rows behind it; X rows past the prefix are read from global memory
+    uint32_t hp_bytes;
+    uint32_t hp_last;           // last HP row of the staged batch (hp_rows - 1)
+    const PodHeader* hdr;       // [tiles*64], zero flags beyond P
+    uint32_t P;
+    const uint64_t* cand;       // optional [chunks]: candidate nodes (bit = node) common to all pods of the call
+    uint64_t* nm;               // optional node-major feasibility words [tiles][chunks*64]: bit j = pod 64*tile+j
+    unsigned long long* score;  // [P], pre-zeroed
+    const FitItem* items;
+    uint32_t dbg_skip;          // tuning aid (NHDFIT_FIT_SKIP): 1 no table sweep, 2 no winner tracking, 4 constant record, 8 no predicate rows
+};
+
+// One step of the 64 x 64 bit-matrix transpose across a wavefront: exchange S x S sub-blocks between
+// lanes l and l ^ S (S < 32, inside one 32-bit register).
+// Value of x in lane (l ^ S), S in {1, 2, 4}: DPP moves inside a row of 16 lanes - no LDS crossbar
+// (ds_bpermute), no address registers.
+template <int S>
+__device__ __forceinline__ uint32_t from_lane_xor(uint32_t x) {
+    const int v = (int)x;
+    if constexpr (S == 1) return (uint32_t)__builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    else if constexpr (S == 2) return (uint32_t)__builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else {
+        const int y = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);     // row_shl:4 -> banks 0,2 read lane+4
+        return (uint32_t)__builtin_amdgcn_update_dpp(y, v, 0x114, 0xF, 0xA, false);  // row_shr:4 -> banks 1,3 read lane-4
+    }
+}
+
+// One butterfly stage (S = 4, 2, 1) of the bit transpose on both words: lanes l and l^S exchange the off-diagonal
+// S-bit blocks.  Branch-free: the partner's word rotated by +-S is merged under a per-lane mask (v_alignbit +
+// v_bfi).  The rotate amount and the mask are rebuilt from a constant SGPR lane mask in 3 instructions per stage
+// (volatile: kept out of the loop pre-header - as loop invariants they would pin 2 VGPRs per stage).
+template <int S>
+__device__ __forceinline__ void xpose_stage(uint32_t& lo, uint32_t& hi) {
+    constexpr uint32_t M = S == 4 ? 0x0F0F0F0Fu : S == 2 ? 0x33333333u : 0x55555555u;   // bits b with (b & S) == 0
+    constexpr uint64_t UP = S == 4 ? 0xF0F0F0F0F0F0F0F0ull : S == 2 ? 0xCCCCCCCCCCCCCCCCull : 0xAAAAAAAAAAAAAAAAull;   // lanes l with (l & S) != 0
+    uint32_t amt, sgn;
+    asm volatile("v_cndmask_b32_e64 %0, %2, %3, %4\n\tv_cndmask_b32_e64 %1, 0, -1, %4"
+                 : "=&v"(amt), "=v"(sgn) : "n"(32 - S), "n"(S), "s"(UP));
+    const uint32_t keep = M ^ sgn;                  // "up" lanes keep their high blocks, the others their low blocks
+    const uint32_t ylo = from_lane_xor<S>(lo), yhi = from_lane_xor<S>(hi);
+    const uint32_t rlo = __builtin_amdgcn_alignbit(ylo, ylo, amt), rhi = __builtin_amdgcn_alignbit(yhi, yhi, amt);
+    lo = (lo & keep) | (rlo & ~keep);
+    hi = (hi & keep) | (rhi & ~keep);
+}
+
+// in: lane l holds row l (bit j = column j) as (lo = columns 0..31, hi = columns 32..63);
+// out: lane j holds column j (bit l = row l).  ~45 VALU instructions, no LDS traffic.
+__device__ __forceinline__ void transpose64(uint32_t& lo, uint32_t& hi) {
+    // 32 x 32 blocks: swap the hi word of lanes 0..31 with the lo word of lanes 32..63
+    const auto s32 = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+    // 16 x 16 blocks of both words with one v_permlane16_swap: gather the low halves of (lo, hi) in one register and
+    // the high halves in another, swap [high halves of lanes l] with [low halves of lanes l + 16]
+    const uint32_t l16 = __builtin_amdgcn_perm(s32[1], s32[0], 0x05040100u), h16 = __builtin_amdgcn_perm(s32[1], s32[0], 0x07060302u);
+    const auto s16 = __builtin_amdgcn_permlane16_swap(l16, h16, false, false);
+    // 8 x 8 blocks: the same with bytes (the scatter of the previous stage folded into this gather); the swap is two
+    // DPP moves whose bank masks pick the receiving lanes: lanes 0-7 of a row get the partner's even bytes as their odd
+    // bytes, lanes 8-15 the partner's odd bytes as their even bytes
+    const uint32_t l8 = __builtin_amdgcn_perm(s16[1], s16[0], 0x06020400u), h8 = __builtin_amdgcn_perm(s16[1], s16[0], 0x07030501u);
+    const uint32_t h8x = (uint32_t)__builtin_amdgcn_update_dpp((int)h8, (int)l8, 0x128, 0xF, 0x3, false);   // row_ror:8
+    const uint32_t l8x = (uint32_t)__builtin_amdgcn_update_dpp((int)l8, (int)h8, 0x128, 0xF, 0xC, false);
+    lo = __builtin_amdgcn_perm(h8x, l8x, 0x05010400u);
+    hi = __builtin_amdgcn_perm(h8x, l8x, 0x07030602u);
+    xpose_stage<4>(lo, hi);
+    xpose_stage<2>(lo, hi);
+    xpose_stage<1>(lo, hi);
+}
+
+__device__ __forceinline__ uint4 lds16(const uint8_t* img, uint32_t off) {
+    return *reinterpret_cast<const uint4*>(__builtin_assume_aligned(img + off, 16));
+}
+__device__ __forceinline__ uint2 lds8(const uint8_t* img, uint32_t off) {
+    return *reinterpret_cast<const uint2*>(__builtin_assume_aligned(img + off, 8));
+}
+
+// Pods of the tile (bit j) for which some NUMA assignment passes CPU & GPU & NIC on this lane's node: per PAIR of
+// assignments six 16-byte row fetches (ds_read_b128) and 16 three-input bit operations serve all 64 pods.
+// a_* = byte addresses of the node's rows in the staged hot section; the m=1 row of a WC record follows its m=0 row.
+template <int W>
+__device__ __forceinline__ uint64_t sweep_assignments(const uint8_t* hot, uint32_t a_w0, uint32_t a_w1, uint32_t a_x0, uint32_t a_x1) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int q = 0; q < W / 2; ++q) {
+        const uint32_t o = q * 16;
+        const uint4 w0 = lds16(hot, a_w0 + o), w0m = lds16(hot, a_w0 + W * 8 + o);
+        const uint4 w1 = lds16(hot, a_w1 + o), w1m = lds16(hot, a_w1 + W * 8 + o);
+        const uint4 x0 = lds16(hot, a_x0 + o), x1 = lds16(hot, a_x1 + o);
+        // words .x/.y = assignment 2q (pods 0-31 / 32-63), .z/.w = assignment 2q+1
+        const uint32_t c0 = __builtin_amdgcn_bitop3_b32(w0.x, w1m.x, w0m.x & w1.x, 0xEA);     // (a & b) | c
+        const uint32_t c1 = __builtin_amdgcn_bitop3_b32(w0.y, w1m.y, w0m.y & w1.y, 0xEA);
+        const uint32_t c2 = __builtin_amdgcn_bitop3_b32(w0.z, w1m.z, w0m.z & w1.z, 0xEA);
+        const uint32_t c3 = __builtin_amdgcn_bitop3_b32(w0.w, w1m.w, w0m.w & w1.w, 0xEA);
+        lo |= __builtin_amdgcn_bitop3_b32(c0, x0.x, x1.x, 0x80) | __builtin_amdgcn_bitop3_b32(c2, x0.z, x1.z, 0x80);   // a & b & c
+        hi |= __builtin_amdgcn_bitop3_b32(c1, x0.y, x1.y, 0x80) | __builtin_amdgcn_bitop3_b32(c3, x0.w, x1.w, 0x80);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// The same with the lanes whose X rows lie beyond the staged prefix of the hot section reading them from the image in
+// global memory (the cluster holds more node classes than LDS has room for: slower, not wrong).
+template <int W>
+__device__ __forceinline__ uint64_t sweep_assignments_spill(const uint8_t* hot, const uint8_t* hot_global, uint32_t staged,
+                                                            uint32_t a_w0, uint32_t a_w1, uint32_t a_x0, uint32_t a_x1) {
+    const bool far0 = a_x0 + W * 8 > staged, far1 = a_x1 + W * 8 > staged;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll 1
+    for (int q = 0; q < W / 2; ++q) {
+        const uint32_t o = q * 16;
+        const uint4 w0 = lds16(hot, a_w0 + o), w0m = lds16(hot, a_w0 + W * 8 + o);
+        const uint4 w1 = lds16(hot, a_w1 + o), w1m = lds16(hot, a_w1 + W * 8 + o);
+        const uint4 x0 = far0 ? *reinterpret_cast<const uint4*>(hot_global + a_x0 + o) : lds16(hot, a_x0 + o);
+        const uint4 x1 = far1 ? *reinterpret_cast<const uint4*>(hot_global + a_x1 + o) : lds16(hot, a_x1 + o);
+        const uint32_t c0 = __builtin_amdgcn_bitop3_b32(w0.x, w1m.x, w0m.x & w1.x, 0xEA);
+        const uint32_t c1 = __builtin_amdgcn_bitop3_b32(w0.y, w1m.y, w0m.y & w1.y, 0xEA);
+        const uint32_t c2 = __builtin_amdgcn_bitop3_b32(w0.z, w1m.z, w0m.z & w1.z, 0xEA);
+        const uint32_t c3 = __builtin_amdgcn_bitop3_b32(w0.w, w1m.w, w0m.w & w1.w, 0xEA);
+        lo |= __builtin_amdgcn_bitop3_b32(c0, x0.x, x1.x, 0x80) | __builtin_amdgcn_bitop3_b32(c2, x0.z, x1.z, 0x80);
+        hi |= __builtin_amdgcn_bitop3_b32(c1, x0.y, x1.y, 0x80) | __builtin_amdgcn_bitop3_b32(c3, x0.w, x1.w, 0x80);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// The P x N pass.  Block = chunks [c_begin, c_end) of one pod tile: the hot section of the tile's table image is
+// staged in LDS, every wavefront sweeps a contiguous run of 64-node chunks (lane = node: one 16-byte record and
+// the busy time per node), writes the node-major verdict word and tracks the tile's first-fit winners.
+//
+// Winner tracking without transposing every chunk: a wavefront walks its chunks in ascending node order, so a
+// pod's first hit is its best node of that run.  The pods still without a hit (and the GPU-less pods still without
+// a GPU-less node, SelectNode's preference) are two wave-uniform 64-bit masks; a chunk whose verdict words do
+// not touch them - all but the first one or two of a run - costs four instructions.  Only a chunk with news is
+// transposed (lane = pod) and scored.
+template <int BLOCK, int W, bool SPILL>
+__device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, uint8_t* lds) {
+    constexpr int NW = BLOCK / 64;
+    constexpr int WC = W == 2 ? 0 : W == 4 ? 1 : W == 8 ? 2 : 3;
+    const uint32_t hot_bytes = a.hot_bytes[WC];
+    uint8_t* hot = lds;
+    const uint32_t staged = a.hot_staged[WC];
+    const bool spill = SPILL && staged < hot_bytes;                                 // block-uniform; SPILL: the launch was told to expect it
+    unsigned long long (*s_best)[64] = reinterpret_cast<unsigned long long (*)[64]>(lds + lds_slice(spill ? staged + a.hp_bytes : hot_bytes));
+    const uint32_t tile = it.tile;
+    const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t pod0 = tile * kTile;
+    const NodeRec* __restrict__ recs = a.rec[WC];
+    const uint32_t len = it.c_end - it.c_begin, per = (len + NW - 1) / NW;
+    const uint32_t c_first = it.c_begin + wave * per;
+    const uint32_t c_last = (a.dbg_skip & 64) ? c_first : c_first + per < it.c_end ? c_first + per : it.c_end;
+
+    // Everything the block needs first is requested before anything is waited for: the tile's request headers, the
+    // wavefront's first node records and the hot section of the table image are independent L2 round trips - issued one
+    // after the other behind a barrier they would add up.
+    const PodHeader my_h = a.hdr[pod0 + lane];
+    uint4 rv = make_uint4(0u, 0u, 0u, 0u);
+    double bt = 0.0;
+    if (c_first < c_last) {
+        rv = *reinterpret_cast<const uint4*>(recs + c_first * 64 + lane);           // {w0,w1}, {x0,x1}, {gx,hp}, {flags,pad}
+        bt = a.p4[c_first * 64 + lane].busy_time;
+    }
+    const uint8_t* hot_global = a.tabs + (size_t)tile * a.pitch + a.off_hot[WC];
+    {   // stage the hot section of the tile's table image in LDS (16 B per lane, fully coalesced)
+        const uint4* src = reinterpret_cast<const uint4*>(hot_global);
+        uint4* dst = reinterpret_cast<uint4*>(hot);
+        if (!(a.dbg_skip & 16)) for (uint32_t i = threadIdx.x; i < staged / 16; i += BLOCK) dst[i] = src[i];
+        if (spill) {                                                                 // the HP rows go right behind the prefix
+            const uint4* hsrc = reinterpret_cast<const uint4*>(hot_global + a.hot_hp[WC]);
+            for (uint32_t i = threadIdx.x; i < a.hp_bytes / 16; i += BLOCK) dst[staged / 16 + i] = hsrc[i];
+        }
+    }
+    __syncthreads();
+
+    // lane-as-pod view of the tile's 64 request headers -> class masks of the tile (scalar registers)
+    const bool my_pod_live = pod0 + lane < a.P;
+    const bool my_pod_needs_gpu = (my_h.flags & kPodNeedGpu) != 0;
+    const uint64_t m_need = __ballot(my_pod_needs_gpu);
+    uint64_t need_any = __ballot(my_pod_live);                               // pods without a feasible node so far
+    uint64_t need_pref = __ballot(my_pod_live && !my_pod_needs_gpu);         // GPU-less pods without a GPU-less node so far
+    uint32_t best_any = ~0u, best_pref = ~0u;                                // lane = pod: local node index
+
+    const uint32_t hp_last = a.hp_last, hot_hp = spill ? staged : a.hot_hp[WC];
+    const size_t npad = (size_t)a.chunks * 64;
+    // the next chunk's record and busy time are requested before this chunk is worked on: a wavefront's chunks are
+    // one dependent chain of L2 round trips otherwise
+    for (uint32_t c = c_first; c < c_last; ++c) {
+        const uint32_t i = c * 64 + lane;
+        uint4 rv_next = rv;
+        double bt_next = bt;
+        if (c + 1 < c_last && !(a.dbg_skip & 4)) {
+            rv_next = *reinterpret_cast<const uint4*>(recs + i + 64);
+            bt_next = a.p4[i + 64].busy_time;
+        }
+        const uint32_t a_w0 = (rv.x & 0xFFFFu) << 3, a_w1 = (rv.x >> 16) << 3;
+        const uint32_t a_x0 = (rv.y & 0xFFFFu) << 3, a_x1 = (rv.y >> 16) << 3;
+        const uint32_t a_gx = (rv.z & 0xFFFFu) << 3;
+        const uint32_t hp = rv.z >> 16;
+        const uint32_t a_hp = hot_hp + (hp < hp_last ? hp : hp_last) * 8;
+        const bool nogpu = (rv.w & kRecNoGpu) != 0;
+
+        // (1) NUMA-assignment feasibility against all 64 pods (bit-sliced tables), (2) scalar predicates
+        uint64_t okm;
+        if (SPILL && spill && __ballot(a_x0 + W * 8 > staged || a_x1 + W * 8 > staged))
+            okm = sweep_assignments_spill<W>(hot, hot_global, staged, a_w0, a_w1, a_x0, a_x1);
+        else
+            okm = (a.dbg_skip & 1) ? ((uint64_t)rv.y << 32 | rv.x) : sweep_assignments<W>(hot, a_w0, a_w1, a_x0, a_x1);
+        const uint2 gx = (a.dbg_skip & 8) ? make_uint2(rv.z, rv.w) : lds8(hot, a_gx), hpw = (a.dbg_skip & 8) ? make_uint2(~0u, ~0u) : lds8(hot, a_hp);
+        const bool busy = bt >= a.busy_from;                                  // Node.IsBusy, nhd/Node.py:847-850
+        uint32_t wlo = (uint32_t)okm & gx.x & hpw.x, whi = (uint32_t)(okm >> 32) & gx.y & hpw.y;
+        if (busy) { wlo &= ~(uint32_t)m_need; whi &= ~(uint32_t)(m_need >> 32); }      // Matcher.py:107-111
+        if (a.cand) {                                                         // candidate dict of the call (FindNode's nl)
+            const uint64_t cw = a.cand[c];
+            if (!(cw >> lane & 1)) wlo = whi = 0;
+        }
+        if (a.nm) a.nm[(size_t)tile * npad + i] = ((uint64_t)whi << 32) | wlo;
+
+        // (3) does this chunk change any pod's winner?
+        const uint32_t nlo = (uint32_t)need_any | (nogpu ? (uint32_t)need_pref : 0u);
+        const uint32_t nhi = (uint32_t)(need_any >> 32) | (nogpu ? (uint32_t)(need_pref >> 32) : 0u);
+        if (!(a.dbg_skip & 2) && __ballot(((wlo & nlo) | (whi & nhi)) != 0)) {
+            const uint64_t nogpu_mask = __ballot(nogpu);
+            transpose64(wlo, whi);                                            // lane j: pod j's verdict over the chunk's 64 nodes
+            const uint64_t word = ((uint64_t)whi << 32) | wlo;
+            const uint64_t pref = my_pod_needs_gpu ? 0ull : word & nogpu_mask;
+            if (word && best_any == ~0u) best_any = c * 64 + (uint32_t)__builtin_ctzll(word);
+            if (pref && best_pref == ~0u) best_pref = c * 64 + (uint32_t)__builtin_ctzll(pref);
+            need_any &= ~__ballot(word != 0);
+            need_pref &= ~__ballot(pref != 0);
+        }
+        rv = rv_next;
+        bt = bt_next;
+    }
+    unsigned long long best = 0;
+    if (best_pref != ~0u) best = score_of(true, a.global_base + best_pref);
+    else if (best_any != ~0u) best = score_of(false, a.global_base + best_any);
+    if (a.dbg_skip & 32) return;
+    s_best[wave][lane] = best;
+    __syncthreads();
+    if (wave == 0 && my_pod_live) {
+        unsigned long long m = s_best[0][lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = s_best[w][lane] > m ? s_best[w][lane] : m;
+        if (m) atomicMax(&a.score[pod0 + lane], m);
+    }
+}
+
+template <int BLOCK, bool SPILL = false>
+__device__ __forceinline__ void role_fit(const FitArgs& a, uint32_t blk, uint8_t* lds) {
+    FitItem it = a.items[blk];                      // block-uniform: keep it in scalar registers
+    it.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.tile);
+    it.wcls = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.wcls);
+    it.c_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_begin);
+    it.c_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_end);
+    switch (it.wcls) {
+        case 0: role_fit_w<BLOCK, 2, SPILL>(a, it, lds); break;
+        case 1: role_fit_w<BLOCK, 4, SPILL>(a, it, lds); break;
+        case 2: role_fit_w<BLOCK, 8, SPILL>(a, it, lds); break;
+        default: role_fit_w<BLOCK, 16, SPILL>(a, it, lds); break;
+    }
+}
+
+struct MapArgs {
+    const nhdfit_plane0* p0;
+    const nhdfit_plane1* p1;
+    const nhdfit_plane2* p2;
+    const nhdfit_plane3* p3;
+    const nhdfit_detail* det;
+    const uint8_t* tabs;             // tile images (their cold R rows: NIC-feasible assignments of a winner)
+    uint32_t pitch;
+    const uint8_t* tile_wcls;        // row width class of every tile
+    ColdView L[kWClasses];
+    uint32_t n;
+    uint64_t global_base;
+    const nhdfit_req* reqs;
+    uint32_t P;
+    const unsigned long long* score;
+    const double* caps;
+    nhdfit_mapping* out;
+};
+
+// One pod per wavefront: the mapping is a long, branchy, strictly sequential computation (the
+// CPython set model), so lanes working on different pods would serialise each other's control flow.
+// Lane 0 of each wave does the work (no divergence); 4 096 pods = 4 096 short waves spread over the chip.
+// GENERIC = false: pods with G <= 3 (register-resident set model, no scratch traffic);
+// GENERIC = true : pods with G == 4 (launched only when the batch contains such pods).
+constexpr int kMapWaves = 4;
+template <bool GENERIC>
+__global__ __launch_bounds__(64 * kMapWaves) void k_map(MapArgs a) {
+    const uint32_t p = __builtin_amdgcn_readfirstlane(blockIdx.x * kMapWaves + (threadIdx.x >> 6));
+    if (p >= a.P || (threadIdx.x & 63) != 0) return;     // one working lane per wave: scratch traffic of one thread
+    if ((a.reqs[p].n_groups > 3) != GENERIC) return;
+    // everything indexed dynamically (request, winner detail, result) stays in global memory: no scratch
+    nhdfit_mapping& m = a.out[p];
+    memset(&m, 0, sizeof(m));
+    const unsigned long long s = a.score[p];
+    if (s) {
+        const uint64_t gi = NHDFIT_SCORE_INDEX(s);
+        if (gi >= a.global_base && gi < a.global_base + a.n) {
+            const uint32_t i = (uint32_t)(gi - a.global_base);
+            WinnerState w;
+            const nhdfit_plane0 q0 = a.p0[i];
+            const nhdfit_plane1 q1 = a.p1[i];
+            const nhdfit_plane2 q2 = a.p2[i];
+            w.d = a.det + i;
+            w.U = w.d->numa_nodes;
+            w.smt = (q2.flags & NHDFIT_NF_SMT) != 0;
+            w.free_c[0] = popc64(q0.t0[0] & q1.t1[0]);
+            w.free_c[1] = popc64(q0.t0[1] & q1.t1[1]);
+            w.free_g[0] = popc32(q2.gpu_free & ~q2.gpu_numa1);
+            w.free_g[1] = popc32(q2.gpu_free & q2.gpu_numa1);
+            w.caps = a.caps;
+            const nhdfit_req& rq = a.reqs[p];
+            const uint32_t bits = nic_assignment_bits(a.tabs + (size_t)(p / kTile) * a.pitch, a.L[a.tile_wcls[p / kTile]], p % kTile,
+                                                      rq.map_type == NHDFIT_MAP_PCI, a.p3[i]);
+            const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
+            if (GENERIC) map_winner_t<GenericOps>(rq, w, codes, m);
+            else map_winner_t<SmallOps>(rq, w, codes, m);
+        }
+    }
+}

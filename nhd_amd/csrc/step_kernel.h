@@ -1,0 +1,167 @@
+// step_kernel.h - k_step itself (five roles, one launch), its per-role stand-alone form and the node-record kernels.
+// Device code of libnhdfit.so; included by nhdfit.hip inside its anonymous namespace, in this order: step_digest.h,
+// step_fit.h, step_map.h, step_kernel.h, seq_kernel.h (one translation unit: the roles are fused into one kernel).
+// gfx950 only.
+// ---- the step kernel ---------------------------------------------------------------------------------
+// ONE launch per step.  The grid is the union of five block ranges ("roles") that work on five different steps of
+// the software pipeline:  [choose(i-2) | shapes(i-1) | finish(i-3) | digest(i+1) | fit(i)].  The four side roles
+// are short on work and long on latency (sequential set model, dependent look-ups); scheduled first, they run in
+// the shadow of the chip-filling fit role instead of serialising the stream with ~20-40 us kernels of their own.
+// Dependencies only cross launches (stream order).  A role with zero blocks is simply absent: the same kernel
+// serves a single find (five launches, one role each) and the pipeline flush.
+struct StepArgs {
+    uint32_t nb_fit, nb_choose, nb_shapes, nb_finish, nb_digest;     // blocks per role, in grid order
+    uint32_t shapes_P;                                       // pods (= upper bound of the choose role's shape slots)
+    uint32_t side_prio;                                      // raise the side roles' issue priority
+    ShapeArgs choose;
+    MapArgs shapes_m; ShapeArgs shapes_h;
+    MapArgs finish_m; ShapeArgs finish_h;
+    DigestArgs digest;
+    FitArgs fit;
+    unsigned long long* role_clock;      // profiling aid (NHDFIT_ROLE_TIMES): [5][2] first start / last end per role, 100 MHz ticks
+};
+
+__device__ __forceinline__ void stamp(unsigned long long* role_clock, int role, unsigned long long t0) {
+    if (role_clock && threadIdx.x == 0) {
+        atomicMin(&role_clock[2 * role], t0);
+        atomicMax(&role_clock[2 * role + 1], (unsigned long long)wall_clock64());
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_fit_only(FitArgs a) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    role_fit<BLOCK>(a, blockIdx.x, lds);
+}
+
+// ---- node records ------------------------------------------------------------------------------------
+// Everything the fit role needs from a node's five planes depends only on the mirror and the dictionary, not on the
+// pod tile or the step.  After nodes change: (1) k_xkeys interns the (NUMA, free GPUs, NUMA-mode signature,
+// PCI-mode signature) class of both NUMA nodes of every touched node in a device hash table, (2) k_xassign gives new
+// classes the next X row, (3) k_xrecords writes the 16-byte records (one array per row width).  Classes are never
+// removed, rows are provisioned in powers of two: records stay valid while classes are appended.
+constexpr uint32_t kXSlots = 1u << 15;          // open-addressing table; the host grows nothing: > kXSlots / 2 classes is NHDFIT_E_LIMIT
+struct XTable {
+    unsigned long long* key;                    // [kXSlots], 0 = empty
+    uint32_t* id;                               // [kXSlots], ~0u = not assigned yet
+    uint64_t* cls;                              // [kXSlots / 2]: key of X row k
+    uint32_t* nx;                               // [0] = classes, [1] = overflow flag
+};
+struct RecArgs {
+    const nhdfit_plane0* p0; const nhdfit_plane1* p1; const nhdfit_plane2* p2; const nhdfit_plane3* p3; const nhdfit_plane4* p4;
+    uint32_t n, npad;                           // nodes / nodes rounded up to whole chunks
+    uint32_t first, count;                      // nodes to (re)do
+    uint32_t fc_dim, fg_dim, ngs;
+    XTable x;
+    Layout L[kWClasses];
+    NodeRec* rec[kWClasses];
+};
+__device__ __forceinline__ uint32_t xhash(uint64_t k) {
+    k ^= k >> 33; k *= 0xFF51AFD7ED558CCDull; k ^= k >> 29;
+    return (uint32_t)k & (kXSlots - 1);
+}
+__device__ __forceinline__ uint32_t xslot_find(const XTable& x, uint64_t key) {        // the key is present
+    uint32_t s = xhash(key);
+    while (x.key[s] != key) s = (s + 1) & (kXSlots - 1);
+    return s;
+}
+__global__ __launch_bounds__(256) void k_xkeys(RecArgs a) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.count) return;
+    const uint32_t i = a.first + t;
+    if (i >= a.n) return;
+    const NodeIdx n = node_index(a.p0[i], a.p1[i], a.p2[i], a.p4[i], a.fc_dim, a.fg_dim, a.ngs);
+    const nhdfit_plane3 q3 = a.p3[i];
+    for (uint32_t u = 0; u < 2; ++u) {
+        const unsigned long long key = xkey(u, u ? n.f1 : n.f0, q3.sig_numa[u], q3.sig_pci[u]);
+        uint32_t s = xhash(key);
+        for (uint32_t probes = 0; probes < kXSlots; ++probes, s = (s + 1) & (kXSlots - 1)) {
+            const unsigned long long prev = atomicCAS(&a.x.key[s], 0ull, key);
+            if (prev == 0ull || prev == key) break;
+        }
+    }
+}
+__global__ __launch_bounds__(1024) void k_xassign(XTable x) {      // one block: new classes get rows in slot order
+    for (uint32_t s = threadIdx.x; s < kXSlots; s += 1024)
+        if (x.key[s] != 0ull && x.id[s] == ~0u) {
+            const uint32_t k = atomicAdd(&x.nx[0], 1u);
+            if (k < kXSlots / 2) { x.id[s] = k; x.cls[k] = x.key[s]; }
+            else { x.id[s] = 0; x.nx[1] = 1; }
+        }
+}
+__global__ __launch_bounds__(256) void k_xrecords(RecArgs a) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.count) return;
+    const uint32_t i = a.first + t;
+    if (i >= a.npad) return;
+    if (i >= a.n) {                                                // padding of the last chunk
+        for (int w = 0; w < kWClasses; ++w) a.rec[w][i] = dead_record(a.L[w]);
+        return;
+    }
+    const NodeIdx n = node_index(a.p0[i], a.p1[i], a.p2[i], a.p4[i], a.fc_dim, a.fg_dim, a.ngs);
+    const nhdfit_plane3 q3 = a.p3[i];
+    const uint32_t x0 = a.x.id[xslot_find(a.x, xkey(0, n.f0, q3.sig_numa[0], q3.sig_pci[0]))];
+    const uint32_t x1 = a.x.id[xslot_find(a.x, xkey(1, n.f1, q3.sig_numa[1], q3.sig_pci[1]))];
+    for (int w = 0; w < kWClasses; ++w) a.rec[w][i] = make_record(n, x0, x1, a.L[w]);
+}
+
+// node-major verdict words [tiles][chunks*64] -> pod-major rows [chunks][P] (the layout of nhdfit_find's
+// bitmap_out and of the sequential resolver): one wavefront per (tile, chunk), 64 x 64 bit transpose in registers
+__global__ __launch_bounds__(256) void k_rows(const uint64_t* __restrict__ nm, uint64_t* __restrict__ rows, uint32_t chunks, uint32_t P) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t tiles = (P + kTile - 1) / kTile;
+    if (w >= tiles * chunks) return;
+    const uint32_t tile = w / chunks, c = w % chunks;
+    const uint64_t v = nm[((size_t)tile * chunks + c) * 64 + lane];
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    transpose64(lo, hi);
+    const uint32_t pod = tile * kTile + lane;
+    if (pod < P) rows[(size_t)c * P + pod] = ((uint64_t)hi << 32) | lo;
+}
+
+template <int BLOCK, bool SPILL = false>      // SPILL: some tiles stage only a prefix of their hot section (refresh_layouts)
+__global__ __launch_bounds__(BLOCK, SPILL ? (BLOCK == 512 ? 4 : 5) : (BLOCK == 512 ? 6 : 7)) void k_step(StepArgs a) {   // SPILL: two blocks per CU (LDS)   // 512 threads = 2 waves per SIMD: 3 blocks per CU either way
+    extern __shared__ __align__(16) uint8_t lds[];
+    uint32_t blk = blockIdx.x;
+    const unsigned long long t0 = a.role_clock ? (unsigned long long)wall_clock64() : 0ull;
+    // Grid order: the fit role first.  Its blocks are sized to fill two of the three block slots of every CU, so all of
+    // them start at once; the side roles (short latency chains on few wavefronts) take the third slot, with issue
+    // priority so that they finish - and hand the slot on - sooner.
+    if (blk < a.nb_fit) {
+        role_fit<BLOCK, SPILL>(a.fit, blk, lds);
+        stamp(a.role_clock, 4, t0);
+        return;
+    }
+    blk -= a.nb_fit;
+    if (a.side_prio) __builtin_amdgcn_s_setprio(3);
+    if (blk < a.nb_choose) {
+        if ((threadIdx.x & 63) == 0)
+            role_choose(a.choose, (uint32_t)__builtin_amdgcn_readfirstlane((int)(blk * (BLOCK / 64) + (threadIdx.x >> 6))),
+                        a.nb_choose * (BLOCK / 64), (a.shapes_P + kTile - 1) / kTile);
+        stamp(a.role_clock, 0, t0);
+        return;
+    }
+    blk -= a.nb_choose;
+    if (blk < a.nb_shapes) { role_shapes<BLOCK>(a.shapes_m, a.shapes_h, blk, lds); stamp(a.role_clock, 1, t0); return; }
+    blk -= a.nb_shapes;
+    if (blk < a.nb_finish) { role_finish<BLOCK>(a.finish_m, a.finish_h, blk, lds); stamp(a.role_clock, 2, t0); return; }
+    blk -= a.nb_finish;
+    role_digest<BLOCK>(a.digest, blk, lds);
+    stamp(a.role_clock, 3, t0);
+}
+
+// Profiling aid (NHDFIT_ROLE_KERNELS=1): one role per launch, so that rocprofv3 --stats names each role's stand-alone time.
+template <int BLOCK, int ROLE>
+__global__ __launch_bounds__(BLOCK, 6) void k_role(StepArgs a) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const uint32_t blk = blockIdx.x;
+    if constexpr (ROLE == 0) {
+        if ((threadIdx.x & 63) == 0)
+            role_choose(a.choose, (uint32_t)__builtin_amdgcn_readfirstlane((int)(blk * (BLOCK / 64) + (threadIdx.x >> 6))),
+                        a.nb_choose * (BLOCK / 64), (a.shapes_P + kTile - 1) / kTile);
+    } else if constexpr (ROLE == 1) role_shapes<BLOCK>(a.shapes_m, a.shapes_h, blk, lds);
+    else if constexpr (ROLE == 2) role_finish<BLOCK>(a.finish_m, a.finish_h, blk, lds);
+    else if constexpr (ROLE == 3) role_digest<BLOCK>(a.digest, blk, lds);
+    else role_fit<BLOCK>(a.fit, blk, lds);
+}

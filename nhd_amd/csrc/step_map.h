@@ -1,0 +1,255 @@
+// step_map.h - mapping roles of the step kernel (shapes / choose / finish) and the generic G = 4 mapping kernel.
+// Device code of libnhdfit.so; included by nhdfit.hip inside its anonymous namespace, in this order: step_digest.h,
+// step_fit.h, step_map.h, step_kernel.h, seq_kernel.h (one translation unit: the roles are fused into one kernel).
+// gfx950 only.
+// ---- winner mapping for G <= 3 pods, de-duplicated by candidate-set shape --------------------------
+// The sequential CPython-set model (choose_tuples) is a pure function of 35 bits (shape_key).  So: (1) every pod
+// derives its shape in parallel, the distinct shapes of each 64-pod tile are collected (wave ballots, no atomics),
+// (2) one wavefront per distinct shape runs the set model, (3) every pod finishes its mapping (first valid NIC
+// choice) in parallel.  Nothing survives the step.
+__device__ __forceinline__ bool load_winner(const MapArgs& a, uint32_t p, WinnerState& w, uint32_t& i) {
+    const unsigned long long s = a.score[p];
+    if (!s) return false;
+    const uint64_t gi = NHDFIT_SCORE_INDEX(s);
+    if (gi < a.global_base || gi >= a.global_base + a.n) return false;
+    i = (uint32_t)(gi - a.global_base);
+    const nhdfit_plane0 q0 = a.p0[i];
+    const nhdfit_plane1 q1 = a.p1[i];
+    const nhdfit_plane2 q2 = a.p2[i];
+    w.d = a.det + i;
+    w.U = w.d->numa_nodes;
+    w.smt = (q2.flags & NHDFIT_NF_SMT) != 0;
+    w.free_c[0] = popc64(q0.t0[0] & q1.t1[0]);
+    w.free_c[1] = popc64(q0.t0[1] & q1.t1[1]);
+    w.free_g[0] = popc32(q2.gpu_free & ~q2.gpu_numa1);
+    w.free_g[1] = popc32(q2.gpu_free & q2.gpu_numa1);
+    w.caps = a.caps;
+    return true;
+}
+
+struct ShapeArgs {
+    unsigned long long* keys;    // [tiles*64] distinct shapes of tile t at [64 t, 64 t + count[t])
+    uint32_t* result;            // [tiles*64] ok << 8 | gcode << 4 | ccode of the shape in the same slot
+    int32_t* slot_of_pod;        // [P] slot of the pod's shape, < 0: nothing to map
+    uint32_t* count;             // [tiles]
+    const AscEntry* asc;         // layouts of ascending-filled sets (winner_map.h), built once per context
+    const uint8_t* choose_tab;   // tabulated choose_tuples for U = 2, G <= 2 (winner_map.h), or null
+    SetStates st;                // set-layout state machine for U = 2, G = 3 (set_states.h); info == null: not used
+};
+// slot_of_pod encodings: >= 0 slot of the pod's shape; -1 nothing to map; <= -2: the result word itself, -2 - word
+// (shapes answered from choose_tab never reach the choose role)
+
+__global__ __launch_bounds__(256) void k_build_choose(const AscEntry* asc, uint8_t* table) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e < kChooseEntries) table[e] = choose_entry_build(asc, e);
+}
+
+// one thread per (tuple length, subset): the set model itself fills the table
+__global__ __launch_bounds__(256) void k_build_asc(AscEntry* table) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= kAscEntries) return;
+    const int len = e >= kAscOffset[4] ? 4 : e >= kAscOffset[3] ? 3 : e >= kAscOffset[2] ? 2 : 1;
+    table[e] = asc_entry_build(len, e - kAscOffset[len]);
+}
+
+
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int lane) {
+    return ((unsigned long long)(uint32_t)__shfl((int)(v >> 32), lane, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, lane, 64);
+}
+
+// Staging for the lane = pod mapping roles.  The mapping arithmetic (candidate masks, first NIC choice) indexes the
+// request record and the winner's detail record dynamically inside nested loops; against global memory every such
+// access is a dependent L2 round trip and a role becomes a 25-30 us latency chain.  So a block first copies the
+// records of its pods (THREADS / 4 of them: the copies are cooperative, the arithmetic runs on a quarter of the
+// threads) into LDS with wide coalesced loads - three round trips in all (score, node records, table rows).
+struct PaddedDet { nhdfit_detail d; uint32_t pad; };           // 33-word stride: lane j -> bank j
+struct StagedNode {                                            // 9 words
+    int32_t node;                                              // local index of the pod's winner, -1: none on this shard
+    uint32_t free_c[2], free_g[2];
+    uint16_t sig_numa[2], sig_pci[2];
+    uint32_t smt, U;
+};
+struct MapStage {
+    PaddedReq* req; PaddedDet* det; StagedNode* w; nhdfit_mapping* map; double* caps;
+};
+template <int THREADS>
+constexpr size_t map_lds_bytes() {
+    constexpr size_t pods = THREADS / 4;
+    return lds_slice(pods * sizeof(PaddedReq)) + lds_slice(pods * sizeof(PaddedDet)) + lds_slice(pods * sizeof(StagedNode)) +
+           lds_slice(pods * sizeof(nhdfit_mapping)) + lds_slice(NHDFIT_MAX_CLASSES * sizeof(double));
+}
+template <int THREADS>
+__device__ __forceinline__ MapStage stage_winners(const MapArgs& a, uint32_t pod0, uint8_t* lds) {
+    constexpr uint32_t PODS = THREADS / 4;
+    MapStage s;
+    s.req = carve<PaddedReq>(lds, PODS);
+    s.det = carve<PaddedDet>(lds, PODS);
+    s.w = carve<StagedNode>(lds, PODS);
+    s.map = carve<nhdfit_mapping>(lds, PODS);
+    s.caps = carve<double>(lds, NHDFIT_MAX_CLASSES);
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t kParts = sizeof(nhdfit_req) / 16;
+    const uint32_t live = pod0 < a.P ? (a.P - pod0 < PODS ? a.P - pod0 : PODS) : 0u;
+    {   // request records, coalesced
+        const uint4* src = reinterpret_cast<const uint4*>(a.reqs + pod0);
+        for (uint32_t c = tid; c < PODS * kParts; c += THREADS) {
+            const uint32_t j = c / kParts;
+            const uint4 v = j < live ? src[c] : make_uint4(0u, 0u, 0u, 0u);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(&s.req[j]) + (c % kParts) * 4;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    }
+    if (tid < NHDFIT_MAX_CLASSES) s.caps[tid] = a.caps[tid];                // the dictionary buffer holds >= 16 entries
+    if (tid < PODS) {                                                       // winners and their plane-derived counts
+        StagedNode n;
+        n.node = -1;
+        n.free_c[0] = n.free_c[1] = n.free_g[0] = n.free_g[1] = 0; n.smt = 0; n.U = 1;
+        n.sig_numa[0] = n.sig_numa[1] = n.sig_pci[0] = n.sig_pci[1] = 0;
+        const unsigned long long sc = tid < live ? a.score[pod0 + tid] : 0ull;
+        if (sc) {
+            const uint64_t gi = NHDFIT_SCORE_INDEX(sc);
+            if (gi >= a.global_base && gi < a.global_base + a.n) {
+                const uint32_t i = (uint32_t)(gi - a.global_base);
+                const nhdfit_plane0 q0 = a.p0[i];
+                const nhdfit_plane1 q1 = a.p1[i];
+                const nhdfit_plane2 q2 = a.p2[i];
+                const nhdfit_plane3 q3 = a.p3[i];
+                n.node = (int32_t)i;
+                n.smt = (q2.flags & NHDFIT_NF_SMT) != 0;
+                n.free_c[0] = popc64(q0.t0[0] & q1.t1[0]); n.free_c[1] = popc64(q0.t0[1] & q1.t1[1]);
+                n.free_g[0] = popc32(q2.gpu_free & ~q2.gpu_numa1); n.free_g[1] = popc32(q2.gpu_free & q2.gpu_numa1);
+                n.sig_numa[0] = q3.sig_numa[0]; n.sig_numa[1] = q3.sig_numa[1];
+                n.sig_pci[0] = q3.sig_pci[0]; n.sig_pci[1] = q3.sig_pci[1];
+            }
+        }
+        s.w[tid] = n;
+    }
+    __syncthreads();
+    constexpr uint32_t kDetParts = sizeof(nhdfit_detail) / 16;              // detail records of the winners: 8 lanes x 16 B per pod
+    for (uint32_t c = tid; c < PODS * kDetParts; c += THREADS) {
+        const uint32_t j = c / kDetParts, part = c % kDetParts;
+        const int32_t i = s.w[j].node;
+        if (i >= 0) {
+            const uint4 v = reinterpret_cast<const uint4*>(a.det + i)[part];
+            uint32_t* dst = reinterpret_cast<uint32_t*>(&s.det[j]) + part * 4;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    }
+    __syncthreads();
+    return s;
+}
+__device__ __forceinline__ WinnerState staged_state(const MapStage& s, uint32_t j) {
+    WinnerState w;
+    w.d = &s.det[j].d;
+    w.U = s.det[j].d.numa_nodes;
+    w.smt = s.w[j].smt != 0;
+    w.free_c[0] = (int)s.w[j].free_c[0]; w.free_c[1] = (int)s.w[j].free_c[1];
+    w.free_g[0] = (int)s.w[j].free_g[0]; w.free_g[1] = (int)s.w[j].free_g[1];
+    w.caps = s.caps;
+    return w;
+}
+
+// (1) lane = pod, wavefront = tile: derive the shape, de-duplicate within the tile
+template <int THREADS>
+__device__ __forceinline__ void role_shapes(const MapArgs& a, const ShapeArgs& h, uint32_t blk, uint8_t* lds) {
+    constexpr uint32_t PODS = THREADS / 4;
+    const uint32_t pod0 = blk * PODS;
+    const MapStage st = stage_winners<THREADS>(a, pod0, lds);
+    if (threadIdx.x >= PODS) return;
+    const uint32_t j = threadIdx.x, p = pod0 + j, tile = p >> 6, lane = threadIdx.x & 63;
+    if (tile * 64 >= a.P) return;                      // whole wavefront past the end
+    int32_t slot = -1;
+    unsigned long long key = 0;
+    const nhdfit_req& rq = st.req[j].r;
+    if (p < a.P && rq.n_groups <= 3 && st.w[j].node >= 0) {
+        const WinnerState w = staged_state(st, j);
+        nhdfit_plane3 q3;
+        q3.groups = 0;
+        q3.sig_numa[0] = st.w[j].sig_numa[0]; q3.sig_numa[1] = st.w[j].sig_numa[1];
+        q3.sig_pci[0] = st.w[j].sig_pci[0]; q3.sig_pci[1] = st.w[j].sig_pci[1];
+        const uint32_t bits = nic_assignment_bits(a.tabs + (size_t)tile * a.pitch, a.L[a.tile_wcls[tile]], lane,
+                                                  rq.map_type == NHDFIT_MAP_PCI, q3);
+        const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
+        uint32_t sg, sc;
+        candidate_masks(rq, w, sg, sc);
+        if (sg && sc && codes) {
+            if (h.choose_tab && choose_tabulated((int)rq.n_groups, w.U))
+                slot = -2 - (int32_t)choose_from_table(h.choose_tab, (int)rq.n_groups, sg, sc, codes);
+            else
+                key = shape_key((int)rq.n_groups, w.U, sg, sc, codes);
+        }
+    }
+    // distinct shapes of the tile (pods of a tile mostly share a handful): slot 64 tile + j for the j-th one.
+    // No cross-tile interning: it needs a hash table in global memory, and its atomics cost the concurrently
+    // running fit role more than the extra runs of the set model cost the choose role.
+    unsigned long long todo = __ballot(key != 0ull);
+    uint32_t nd = 0;
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const unsigned long long k = shfl64(key, leader);
+        if ((int)lane == leader) h.keys[tile * 64 + nd] = k;
+        if (key == k) slot = (int32_t)(tile * 64 + nd);
+        todo &= ~__ballot(key == k);
+        ++nd;
+    }
+    if (lane == 0) h.count[tile] = nd;
+    if (p < a.P) h.slot_of_pod[p] = slot;
+}
+
+// (2) one wavefront (its lane 0: the model is strictly sequential) per distinct shape.  The model lives in
+// scalar registers (it is wave-uniform); not inlined into k_step so that its SGPR spill slots do not become
+// VGPRs of every role - the fit role's occupancy is set by the kernel's VGPR count.
+__device__ __forceinline__ void role_choose(const ShapeArgs& h, uint32_t w, uint32_t waves, uint32_t tiles) {
+    // wavefront w of the role takes the shapes j = sub, sub + S, ... of tile (w mod tiles): a few shapes per wave
+    // keeps the role on few CUs (its scalar code competes with the fit role for the scalar unit and the I-cache)
+    const uint32_t S = waves / tiles ? waves / tiles : 1u;
+    if (w >= S * tiles) return;
+    const uint32_t tile = w % tiles, sub = w / tiles;
+    const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.count[tile]);
+    for (uint32_t j = sub; j < count; j += S) {
+        const uint32_t k = tile * 64 + j;
+        const unsigned long long kv = h.keys[k];
+        const unsigned long long key = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(kv >> 32)) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kv);
+        const int G = (int)(key & 3), U = (int)((key >> 2) & 1) + 1;
+        uint32_t gcode = 0;
+        int ccode = -1;
+        if (h.st.info && G == 3 && U == 2) {         // ~40 table look-ups instead of the insertion-by-insertion model
+            h.result[k] = choose_g3(h.st, h.asc, (uint32_t)(key >> 3) & 0xFF, (uint32_t)(key >> 19) & 0xFFFF, (uint32_t)(key >> 11) & 0xFF);
+            continue;
+        }
+        const bool ok = choose_tuples<SmallOps>(G, U, (uint32_t)(key >> 3) & 0xFF, (uint32_t)(key >> 19) & 0xFFFF,
+                                                (uint32_t)(key >> 11) & 0xFF, gcode, ccode, h.asc);
+        h.result[k] = ((uint32_t)ok << 8) | ((gcode & 7u) << 4) | ((uint32_t)ccode & 15u);
+    }
+}
+
+// (3) lane = pod: first valid NIC choice under the chosen tuples, from the staged copies; the mappings leave the
+// block as one coalesced store.
+template <int THREADS>
+__device__ __forceinline__ void role_finish(const MapArgs& a, const ShapeArgs& h, uint32_t blk, uint8_t* lds) {
+    constexpr uint32_t PODS = THREADS / 4;
+    const uint32_t pod0 = blk * PODS;
+    const MapStage st = stage_winners<THREADS>(a, pod0, lds);
+    const uint32_t j = threadIdx.x, p = pod0 + j;
+    if (j < PODS) {
+        nhdfit_mapping& m = st.map[j];
+        memset(&m, 0, sizeof(m));
+        const nhdfit_req& rq = st.req[j].r;
+        if (p < a.P && rq.n_groups <= 3) {
+            const int32_t slot = h.slot_of_pod[p];
+            if (slot != -1) {
+                const uint32_t res = slot >= 0 ? h.result[slot] : (uint32_t)(-2 - slot);
+                if ((res >> 8 & 1) && st.w[j].node >= 0) finish_mapping(rq, staged_state(st, j), (res >> 4) & 7u, (int)(res & 15u), m);
+            }
+        }
+    }
+    __syncthreads();
+    // 20-byte records, PODS of them: copied out as words; pods with more than 3 groups belong to k_map<true>
+    const uint32_t live = pod0 < a.P ? (a.P - pod0 < PODS ? a.P - pod0 : PODS) : 0u;
+    constexpr uint32_t kWords = sizeof(nhdfit_mapping) / 4;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(st.map);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(a.out + pod0);
+    for (uint32_t c = threadIdx.x; c < live * kWords; c += THREADS)
+        if (st.req[c / kWords].r.n_groups <= 3) dst[c] = src[c];
+}
