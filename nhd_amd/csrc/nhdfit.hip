@@ -762,7 +762,11 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         }
         if (c->n_chosen < c->n_shaped) {
             a.choose = shape_args((int)(c->n_chosen % kBufs));
-            a.nb_choose = (tiles * c->choose_split + nw - 1) / nw; did_choose = true;
+            // wavefront = tile, lane = shape (NHDFIT_CHOOSE_LANES=0: a wavefront per shape, 16 x the blocks - tuning aid)
+            static const bool lanes_off = getenv("NHDFIT_CHOOSE_LANES") && atoi(getenv("NHDFIT_CHOOSE_LANES")) == 0;
+            const bool lanes = !lanes_off;
+            a.choose_lanes = lanes ? 1u : 0u;
+            a.nb_choose = lanes ? (tiles + nw - 1) / nw : (tiles * c->choose_split + nw - 1) / nw; did_choose = true;
         }
         // scores of step s are final once its fit launch (and, sharded, its all-reduce) is done; sharded runs give
         // the all-reduce one launch of slack so that it overlaps the next fit instead of stalling the stream

@@ -13,6 +13,7 @@ struct StepArgs {
     uint32_t nb_fit, nb_choose, nb_shapes, nb_finish, nb_digest;     // blocks per role, in grid order
     uint32_t shapes_P;                                       // pods (= upper bound of the choose role's shape slots)
     uint32_t side_prio;                                      // raise the side roles' issue priority
+    uint32_t choose_lanes;                                   // choose role: wavefront = tile, lane = shape (else a wavefront per shape)
     ShapeArgs choose;
     MapArgs shapes_m; ShapeArgs shapes_h;
     MapArgs finish_m; ShapeArgs finish_h;
@@ -136,7 +137,9 @@ __global__ __launch_bounds__(BLOCK, SPILL ? (BLOCK == 512 ? 4 : 5) : (BLOCK == 5
     blk -= a.nb_fit;
     if (a.side_prio) __builtin_amdgcn_s_setprio(3);
     if (blk < a.nb_choose) {
-        if ((threadIdx.x & 63) == 0)
+        if (a.choose_lanes)
+            role_choose_lanes(a.choose, (uint32_t)__builtin_amdgcn_readfirstlane((int)(blk * (BLOCK / 64) + (threadIdx.x >> 6))), (a.shapes_P + kTile - 1) / kTile);
+        else if ((threadIdx.x & 63) == 0)
             role_choose(a.choose, (uint32_t)__builtin_amdgcn_readfirstlane((int)(blk * (BLOCK / 64) + (threadIdx.x >> 6))),
                         a.nb_choose * (BLOCK / 64), (a.shapes_P + kTile - 1) / kTile);
         stamp(a.role_clock, 0, t0);
@@ -157,7 +160,9 @@ __global__ __launch_bounds__(BLOCK, 6) void k_role(StepArgs a) {
     extern __shared__ __align__(16) uint8_t lds[];
     const uint32_t blk = blockIdx.x;
     if constexpr (ROLE == 0) {
-        if ((threadIdx.x & 63) == 0)
+        if (a.choose_lanes)
+            role_choose_lanes(a.choose, (uint32_t)__builtin_amdgcn_readfirstlane((int)(blk * (BLOCK / 64) + (threadIdx.x >> 6))), (a.shapes_P + kTile - 1) / kTile);
+        else if ((threadIdx.x & 63) == 0)
             role_choose(a.choose, (uint32_t)__builtin_amdgcn_readfirstlane((int)(blk * (BLOCK / 64) + (threadIdx.x >> 6))),
                         a.nb_choose * (BLOCK / 64), (a.shapes_P + kTile - 1) / kTile);
     } else if constexpr (ROLE == 1) role_shapes<BLOCK>(a.shapes_m, a.shapes_h, blk, lds);

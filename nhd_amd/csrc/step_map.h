@@ -224,6 +224,43 @@ __device__ __forceinline__ void role_choose(const ShapeArgs& h, uint32_t w, uint
     }
 }
 
+// (2') the same role lane-parallel: wavefront = tile, lane = one of its distinct shapes.  The G = 3 state machine is ~40
+// dependent table look-ups per shape whichever lane runs it, so a tile's shapes cost one chain instead of a wavefront each -
+// 8 blocks for 64 tiles instead of 128, which leaves their block slots to the roles that wait for one.  Shapes outside the
+// state machine (no tables, U = 1) run the sequential model one after the other on lane 0, as before.
+__device__ __forceinline__ void role_choose_lanes(const ShapeArgs& h, uint32_t tile, uint32_t tiles) {
+    if (tile >= tiles) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.count[tile]);
+    const uint32_t k = tile * 64 + lane;
+    unsigned long long key = 0;
+    bool generic = false;
+    if (lane < count) {
+        key = h.keys[k];
+        const int G = (int)(key & 3), U = (int)((key >> 2) & 1) + 1;
+        if (h.st.info && G == 3 && U == 2)
+            h.result[k] = choose_g3(h.st, h.asc, (uint32_t)(key >> 3) & 0xFF, (uint32_t)(key >> 19) & 0xFFFF, (uint32_t)(key >> 11) & 0xFF);
+        else
+            generic = true;
+    }
+    unsigned long long todo = __ballot(generic);
+    while (todo) {
+        const int j = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const unsigned long long kv = shfl64(key, j);
+        if (lane == 0) {
+            const unsigned long long kk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(kv >> 32)) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kv);
+            const int G = (int)(kk & 3), U = (int)((kk >> 2) & 1) + 1;
+            uint32_t gcode = 0;
+            int ccode = -1;
+            const bool ok = choose_tuples<SmallOps>(G, U, (uint32_t)(kk >> 3) & 0xFF, (uint32_t)(kk >> 19) & 0xFFFF,
+                                                    (uint32_t)(kk >> 11) & 0xFF, gcode, ccode, h.asc);
+            h.result[tile * 64 + j] = ((uint32_t)ok << 8) | ((gcode & 7u) << 4) | ((uint32_t)ccode & 15u);
+        }
+    }
+}
+
 // (3) lane = pod: first valid NIC choice under the chosen tuples, from the staged copies; the mappings leave the
 // block as one coalesced store.
 template <int THREADS>
