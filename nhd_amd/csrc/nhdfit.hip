@@ -790,7 +790,9 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         for (int w = 0; w < kWClasses; ++w) d.L[w] = c->L[w];
         d.pitch = c->pitch; d.tabs = c->tabs[b].p; d.hdr = c->hdr[b].p; d.score = c->score[b].p;
         d.xcls = c->xcls.p; d.nx = c->xnx.p;
-        a.nb_digest = tiles * kDigestParts;
+        static const uint32_t wc_parts = getenv("NHDFIT_WC_PARTS") && atoi(getenv("NHDFIT_WC_PARTS")) >= 1 ? (uint32_t)atoi(getenv("NHDFIT_WC_PARTS")) : kWcPartsDefault;   // tuning aid
+        d.wc_parts = wc_parts;
+        a.nb_digest = tiles * (1 + wc_parts);
     }
     uint32_t nb_fit = 0;
     int bf = -1;

@@ -54,15 +54,15 @@ struct DigestArgs {
     unsigned long long* score;       // out: zeroed (the fit role accumulates with atomicMax)
     const uint64_t* xcls;            // interned (NUMA, free GPUs, signature) classes of the mirror: key of X row k
     const uint32_t* nx;              // number of classes
+    uint32_t wc_parts;               // blocks per tile that share its CPU rows (free-core count c = part mod wc_parts)
 };
 constexpr uint32_t kDictLdsWords = 6144;             // 12 KB for the staged signature stream (c5: 151 signatures = 1.5 K words)
 constexpr size_t kDigestLds = lds_slice(kTile * sizeof(PaddedReq)) + lds_slice(kTile * sizeof(PodSums)) +
                               lds_slice(kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1) * sizeof(uint16_t)) + lds_slice(kTile * sizeof(PodHeader)) +
                               lds_slice(kDictLdsWords * sizeof(uint16_t));
-constexpr uint32_t kWcParts = 4;                     // blocks per tile that share its CPU rows (free-core count c = part mod 4)
-constexpr uint32_t kDigestParts = 1 + kWcParts;      // part 0 = GPU / NIC rows (cold section + X), parts 1..4 = CPU rows, the last one also HP / GX
+constexpr uint32_t kWcPartsDefault = 4;              // blocks per tile: part 0 = GPU / NIC rows (cold section + X), parts 1..wc_parts = CPU rows, the last one also HP / GX
 
-// Request digest, kDigestParts blocks per 64-pod tile: per-pod subset sums / NIC covers in LDS, then the table rows
+// Request digest, 1 + wc_parts blocks per 64-pod tile: per-pod subset sums / NIC covers in LDS, then the table rows
 // (lane = pod, one ballot per assignment).  The role is a chain of dependent phases, not a lot of work: it is cut
 // into parts by table so that the chain of each block stays short.
 template <int THREADS>
@@ -74,7 +74,7 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
     PodHeader* s_hdr = carve<PodHeader>(lds, kTile);
     uint16_t* s_flat = carve<uint16_t>(lds, kDictLdsWords);
 
-    const uint32_t tile = blk / kDigestParts, part = blk % kDigestParts;
+    const uint32_t tile = blk / (1 + a.wc_parts), part = blk % (1 + a.wc_parts);
     const uint32_t tid = threadIdx.x;
     uint8_t* img = a.tabs + (size_t)tile * a.pitch;
 
@@ -144,14 +144,14 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
                 }
             }
             uint8_t* base = hot + (u ? L.hot_wc1 : L.hot_wc0) + smt * L.fc_dim * L.wc_stride + m * L.row;
-            for (uint32_t c = part - 1; c < L.fc_dim; c += kWcParts) {
+            for (uint32_t c = part - 1; c < L.fc_dim; c += a.wc_parts) {
                 uint32_t v = 0;
 #pragma unroll
                 for (uint32_t p = 0; p < (1u << kMaxG); ++p) v |= (t[p] <= c ? 1u : 0u) << p;
                 emit_row(base + c * L.wc_stride, v);
             }
         }
-        if (part != kWcParts) return;
+        if (part != a.wc_parts) return;
         // 64-bit scalar-predicate rows: ballots over the 64 pods (lane = pod).  HP: one wavefront per row.  GX: there can
         // be hundreds of node-group sets (c5: every 1-3 name combination of 16 names) - a wavefront takes 64 sets at a time,
         // one coalesced load, and hands them round with v_readlane (a scalar load per row costs a memory round trip each);
