@@ -289,34 +289,33 @@ class Packer:
         t1 = [0, 0]
         for u in range(U):
             m0 = m1 = 0
+            base = u * cpp
             for b in range(cpp):
-                c = cores[u * cpp + b]
+                c = cores[base + b]
                 if c.socket != u:
-                    raise UnsupportedNode(f"node {node.name}: core {u * cpp + b} is on socket {c.socket}, expected {u}")
+                    raise UnsupportedNode(f"node {node.name}: core {base + b} is on socket {c.socket}, expected {u}")
                 if not c.used:
                     m0 |= 1 << b
                 if smt and not cores[c.sibling].used:
                     m1 |= 1 << b
             t0[u] = m0
             t1[u] = m1 if smt else 0xFFFFFFFFFFFFFFFF
-        t.p0[i]["t0"] = t0
-        t.p1[i]["t1"] = t1
-        if t.origin is not None:                           # ResetResources: every core outside reserved_cores unused (Node.py:147-149)
-            reserved = set(getattr(node, "reserved_cores", ()))
-            o0, o1 = [0, 0], [0, 0]
-            for u in range(U):
-                for b in range(cpp):
-                    c = cores[u * cpp + b]
-                    if c.core not in reserved:
-                        o0[u] |= 1 << b
-                    if smt and cores[c.sibling].core not in reserved:
-                        o1[u] |= 1 << b
-                if not smt:
-                    o1[u] = 0xFFFFFFFFFFFFFFFF
-            t.origin[i]["t0"] = o0
-            t.origin[i]["t1"] = o1
-            t.origin[i]["hp_total"] = max(-2 ** 31, min(2 ** 31 - 1, int(getattr(node.mem, "ttl_hugepages_gb", 0))))
-            t.origin[i]["nic_base"] = 0
+        t.p0[i] = (t0,)
+        t.p1[i] = (t1,)
+        want_origin = t.origin is not None
+        if want_origin:                                    # ResetResources: every core outside reserved_cores unused (Node.py:147-149)
+            full = (1 << cpp) - 1
+            o0 = [full if u < U else 0 for u in range(2)]
+            o1 = [(full if smt else 0xFFFFFFFFFFFFFFFF) if u < U else 0 for u in range(2)]
+            for r in getattr(node, "reserved_cores", ()):
+                r = int(r)
+                if 0 <= r < U * cpp:                       # a thread-0 core
+                    o0[r // cpp] &= ~(1 << (r % cpp))
+                elif smt and r < len(cores):               # a sibling: the thread-1 bit of the core it belongs to
+                    h = int(cores[r].sibling)
+                    if 0 <= h < U * cpp:
+                        o1[h // cpp] &= ~(1 << (h % cpp))
+            nic_base = [[0] * MAX_NICS_PER_NUMA, [0] * MAX_NICS_PER_NUMA]
 
         gpus = node.gpus
         if len(gpus) > MAX_GPUS:
@@ -333,21 +332,19 @@ class Packer:
 
         gfree = gn1 = 0
         per_numa = [0, 0]
-        det = t.detail[i]
-        det["sw_free"] = 0
-        det["gpu_sw"] = 0
-        det["n_gpus"] = len(gpus)
+        sw_free = [0] * MAX_SWITCHES
+        gpu_sw = [0] * MAX_GPUS
         for g, gpu in enumerate(gpus):
             if gpu.numa_node >= U or gpu.numa_node < 0:
                 raise UnsupportedNode(f"node {node.name}: GPU on NUMA node {gpu.numa_node}")
             per_numa[gpu.numa_node] += 1
             s = local_sw(gpu.pciesw)
-            det["gpu_sw"][g] = s
+            gpu_sw[g] = s
             if gpu.numa_node == 1:
                 gn1 |= 1 << g
             if not gpu.used:
                 gfree |= 1 << g
-                det["sw_free"][s] += 1
+                sw_free[s] += 1
         if max(per_numa) > MAX_GPUS_PER_NUMA:
             raise UnsupportedNode(f"node {node.name}: more than {MAX_GPUS_PER_NUMA} GPUs on one NUMA node")
         if max(per_numa) > self.max_gpus_per_numa:
@@ -359,9 +356,9 @@ class Packer:
         sw_numa: Dict[int, int] = {}
         numa_pool = [dict(), dict()]                       # cls -> count
         pci_pool = [dict(), dict()]                        # local switch -> {cls -> count}
-        det["nic_cls"] = 0
-        det["nic_sw"] = 0
-        det["nic_pods"] = 0
+        nic_cls = [[0] * MAX_NICS_PER_NUMA, [0] * MAX_NICS_PER_NUMA]
+        nic_sw = [[0] * MAX_NICS_PER_NUMA, [0] * MAX_NICS_PER_NUMA]
+        pods_word = 0                                      # 32 three-bit counters (include/nhdfit.h)
         for nic in node.nics:
             u = nic.numa_node
             if u >= U or u < 0:
@@ -371,23 +368,24 @@ class Packer:
                 raise UnsupportedNode(f"node {node.name}: more than {MAX_NICS_PER_NUMA} NICs on NUMA {u}")
             if nic.idx != k:
                 raise UnsupportedNode(f"node {node.name}: NIC ordinal {nic.idx} != position {k} on NUMA {u}")
-            cap = 0 if nic.pods_used > 0 else nic.speed * NIC_BW_AVAIL_PERCENT
-            cls = self.cap_class(cap)
+            full_cap = nic.speed * NIC_BW_AVAIL_PERCENT
+            cls = self.cap_class(0 if nic.pods_used > 0 else full_cap)
             s = local_sw(nic.pciesw)
             if sw_numa.setdefault(s, u) != u:
                 raise UnsupportedNode(f"node {node.name}: PCIe switch {nic.pciesw:#x} has NICs on both NUMA nodes")
-            det["nic_cls"][u][k] = cls
-            det["nic_sw"][u][k] = s
+            nic_cls[u][k] = cls
+            nic_sw[u][k] = s
             if nic.pods_used:
-                set_pods(det, u, k, pods_code(nic.pods_used))
-            if t.origin is not None:
-                t.origin[i]["nic_base"][u][k] = self.cap_class(nic.speed * NIC_BW_AVAIL_PERCENT)
+                pods_word |= pods_code(nic.pods_used) << (3 * (u * MAX_NICS_PER_NUMA + k))
+            if want_origin:
+                nic_base[u][k] = self.cap_class(full_cap)
             numa_pool[u][cls] = numa_pool[u].get(cls, 0) + 1
             d = pci_pool[u].setdefault(s, {})
             d[cls] = d.get(cls, 0) + 1
             cnt[u] = k + 1
-        det["nic_cnt"] = cnt
-        det["numa_nodes"] = U
+        t.detail[i] = (cnt, sw_free, nic_cls, nic_sw, U, len(gpus), list(pods_word.to_bytes(12, "little")), [0, 0], gpu_sw)
+        if want_origin:
+            t.origin[i] = (o0, o1, nic_base, max(-2 ** 31, min(2 ** 31 - 1, int(getattr(node.mem, "ttl_hugepages_gb", 0)))), [0] * 12)
 
         def pairs(d):
             return tuple(sorted((c, min(n, MAX_GROUPS)) for c, n in d.items()))
@@ -398,7 +396,7 @@ class Packer:
                 sig_numa[u] = self.sig_id([(GLIMIT_NONE, pairs(numa_pool[u]))])
             pools = []
             for s, d in pci_pool[u].items():
-                gl = min(int(det["sw_free"][s]), MAX_GROUPS)
+                gl = min(sw_free[s], MAX_GROUPS)
                 if gl > 0:
                     pools.append((gl, pairs(d)))
             sig_pci[u] = self.sig_id(pools)
@@ -408,11 +406,8 @@ class Packer:
         hp = int(node.mem.free_hugepages_gb)
         t.p2[i] = (gfree, gn1, max(-2 ** 31, min(2 ** 31 - 1, hp)), flags)
         gbits = self.group_bits(node.groups)
-        t.p3[i]["groups"] = gbits
-        t.p3[i]["sig_numa"] = sig_numa
-        t.p3[i]["sig_pci"] = sig_pci
-        t.p4[i]["busy_time"] = float(node.busy_time)
-        t.p4[i]["group_set"] = self.group_set_id(gbits)
+        t.p3[i] = (gbits, sig_numa, sig_pci)
+        t.p4[i] = (float(node.busy_time), self.group_set_id(gbits), 0)
 
     def pack_nodes(self, nl: Dict[str, object]) -> NodeTable:
         t = empty_table(len(nl))
