@@ -1,23 +1,28 @@
 #!/bin/bash
-# First GPU call of the next round (run through gpurun, ~3 GPU-minutes): times what round 1 left prepared but
-# unmeasured, with the role clocks that show where a step's time goes.
-#   tools/next_round_first_run.sh            -> gpurun_out/next_round/*.json|log
+# First GPU call of round 3 (run through gpurun, ~4 GPU-minutes): the round-2 end state re-measured on a fresh box, then
+# the block-slot accounting the last experiments of round 2 pointed at.
+#   tools/next_round_first_run.sh            -> gpurun_out/next_round/*
+#
+# Where round 2 stopped: the step kernel is the fit role (22 us alone) plus ~1 us; inside the loop the
+# CU's LDS pipe is the limit, around it ~10 us of launch / staging / tail.  A CU holds three 512-thread blocks = 768 slots;
+# the grid has 568 (fit) + 8 (choose) + 32 + 32 + 320 (digest) = 960 blocks, so ~190 digest blocks queue behind the first
+# finishers.  Freeing the choose role's 120 slots gave -3.5 %.  Candidates, cheapest first:
+#   1. shapes / finish on 16 blocks each (256 pods per block)                                    [host constant]
+#   2. digest part 0 and the CPU-row parts merged differently (NHDFIT_WC_PARTS=3)               [env, measured 4 > 2 > 1]
+#   3. fit items: 8 blocks for the widest tiles too (NHDFIT_XCD_K=1: 512 fit blocks, measured 26.4 vs 26.0 us BEFORE the
+#      choose change - re-measure now that 120 slots are free)
+#   4. CPU pair table C[smt][free cores 0][free cores 1] for the two-group tiles (34 KB: -43 % LDS bytes for 42 % of the work)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/next_round
 mkdir -p $OUT
 cd $ROOT
-B="python bench.py --steps 400 --warmup 20 --no-cpu-baseline"
-timeout 60 $B > $OUT/bench_default.json 2> $OUT/bench_default.err
-NHDFIT_SET_STATES=1 timeout 60 $B > $OUT/bench_set_states.json 2> $OUT/bench_set_states.err       # state machine for G = 3 shapes
-NHDFIT_NODE_RECORDS=1 timeout 60 $B > $OUT/bench_node_records.json 2> $OUT/bench_node_records.err   # precomputed node records in the fit role
-NHDFIT_NODE_RECORDS=1 NHDFIT_SET_STATES=1 timeout 60 $B > $OUT/bench_both.json 2> $OUT/bench_both.err
-NHDFIT_NO_CHOOSE_TABLE=1 timeout 60 $B > $OUT/bench_no_choose_table.json 2> $OUT/bench_no_choose_table.err
-NHDFIT_ROLE_TIMES=100 timeout 60 python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>&1 >/dev/null | grep nhdfit > $OUT/roles_default.log
-NHDFIT_SET_STATES=1 NHDFIT_ROLE_TIMES=100 timeout 60 python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>&1 >/dev/null | grep nhdfit > $OUT/roles_set_states.log
-timeout 120 python tools/exp_outputs.py > $OUT/outputs_cost.json 2>&1                                # bitmap / mapping roles on and off
-NHDFIT_SET_STATES=1 NHDFIT_NODE_RECORDS=1 timeout 300 python -m pytest tests -m gpu -x -q > $OUT/tests_set_states.log 2>&1  # full parity with both opt-ins
-for f in bench_default bench_set_states bench_node_records bench_both bench_no_choose_table; do
-  python -c "import json,sys; j=json.load(open('$OUT/$f.json')); print('$f', round(j['value']/1e12,3), 'T evals/s', round(j['ms_per_step']*1e3,1), 'us/step')"
-done
-cat $OUT/roles_default.log $OUT/roles_set_states.log; tail -1 $OUT/tests_set_states.log
+bash tools/r02_full.sh > $OUT/full.log 2>&1; tail -8 $OUT/full.log
+B="python bench.py --no-cpu-baseline --no-pmc --no-extras"
+line() { python -c "import sys,json; o=json.loads(sys.stdin.read()); print(o['value']/1e12, o['ms_per_step'], o['roofline']['kernel_ms'], o['placed_pods'])"; }
+for v in "" "NHDFIT_XCD_K=1" "NHDFIT_WC_PARTS=3" "NHDFIT_CHOOSE_LANES=0"; do
+  echo "== $v"
+  env $v timeout 300 $B 2>&1 | tail -1 | line
+  env $v timeout 300 $B 2>&1 | tail -1 | line
+done | tee $OUT/slots.log
+NHDFIT_ROLE_TIMES=30 timeout 300 $B 2>&1 | grep "nhdfit\]" | tee $OUT/roles.log
