@@ -151,6 +151,7 @@ class HipMatcher:
         self._deltas: List[np.ndarray] = []                # release / reclaim / reset / SetHugepages waiting for the device, in call order
         self.delta_stats = {"applied": 0, "repacked": 0}
         self._uploaded_ids: Optional[Tuple[int, ...]] = None
+        self._last_subset: Optional[Tuple[List[str], np.ndarray]] = None    # (names, candidate mask) of the last filtered dict seen
 
     # ---- mirror maintenance -------------------------------------------------------------
     def attach(self, nodes: Dict[str, object]) -> None:
@@ -314,6 +315,7 @@ class HipMatcher:
             self._mark(self._attached[name], "explicit")
 
     def _full_upload(self, nl: Dict[str, object]) -> None:
+        self._last_subset = None                           # node indices change
         table = self.packer.pack_nodes(nl)
         self._table = table
         self._names = table.names
@@ -364,14 +366,21 @@ class HipMatcher:
     def _candidates(self, nl: Dict[str, object]) -> Optional[np.ndarray]:
         """Bitmask [chunks] (bit = node) of the attached nodes that are in `nl`; None when nl is everything."""
         n = len(self._names)
-        if len(nl) == n and list(nl) == self._names:          # C-speed comparison (identical str objects short-cut)
+        names = list(nl)
+        if len(names) == n and names == self._names:          # C-speed comparison (identical str objects short-cut)
             return None
-        idx = np.fromiter(map(self._index.__getitem__, nl), dtype=np.int64, count=len(nl))
+        # consecutive pods of one node group get the same filtered dict from InitialNodeFilter: the mask of the last subset
+        # is kept, and recognising it is one C-speed list comparison instead of a dictionary look-up per node
+        if self._last_subset is not None and names == self._last_subset[0]:
+            return self._last_subset[1]
+        idx = np.fromiter(map(self._index.__getitem__, names), dtype=np.int64, count=len(names))
         if len(idx) > 1 and not np.all(idx[1:] > idx[:-1]):
             raise ValueError("FindNode: `nl` must keep the relative order of the attached node dict")
         bits = np.zeros(((n + 63) // 64) * 64, dtype=bool)
         bits[idx] = True
-        return np.ascontiguousarray(np.packbits(bits.reshape(-1, 64), axis=1, bitorder="little").view("<u8").reshape(-1))
+        mask = np.ascontiguousarray(np.packbits(bits.reshape(-1, 64), axis=1, bitorder="little").view("<u8").reshape(-1))
+        self._last_subset = (names, mask)
+        return mask
 
     # ---- the reference interface ----------------------------------------------------------
     def FindNode(self, nl: Dict[str, object], top) -> Tuple:
