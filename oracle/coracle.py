@@ -166,7 +166,7 @@ class Cluster:
                     elif d == 2:
                         tx += c.nic_speed
                 p["rx"][g] = float(rx); p["tx"][g] = float(tx)
-            if pod_groups is not None:
+            if pod_groups is not None and pod_groups[i] is not None:
                 p["use_filter"] = 1
                 p["groups"] = self.group_ids.bits(pod_groups[i])
         return pods

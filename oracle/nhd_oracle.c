@@ -181,5 +181,131 @@ void oracle_find(const ocluster* c, const opod* pods, int64_t P, double now, int
     }
 }
 
+/* ---- mode B support: first-fit scan with early exit, and the commit step on the flat records ---------------------
+ * Reference lines followed:
+ *   SelectNode (first candidate / first GPU-less candidate)     nhd/Matcher.py:393-421
+ *   SetBusy                                                     nhd/Node.py:843-845
+ *   SetPhysicalIdsFromMapping                                   nhd/Node.py:663-841
+ *   GetFreeCpuBatch                                             nhd/Node.py:502-519
+ *   GetNicObjFromIndex / GetFreePciGpuFromNic / GetNextGpuFree  nhd/Node.py:657-661, 648-655, 495-500
+ *   ClaimPodNICResources                                        nhd/Node.py:644-646, nhd/NHDScheduler.py:302-304
+ * The mapping itself (GetNumaGroupIdx, CPython set order) stays in oracle/nhd_oracle.py: oracle/seq_oracle.py asks it
+ * for the winner only. */
+
+/* first feasible node in [0, n) - restricted to nodes without GPUs installed when only_nogpu - or -1.
+ * Blocks of nodes are handed out in ascending order; a thread stops once its block starts past the best hit. */
+int64_t oracle_first_feasible(const ocluster* c, const opod* p, double now, int only_nogpu) {
+    const int64_t B = 256, nblocks = (c->n + B - 1) / B;
+    int64_t best = c->n, next = 0;
+#pragma omp parallel
+    {
+        for (;;) {
+            int64_t b, cur;
+#pragma omp atomic capture
+            b = next++;
+#pragma omp atomic read
+            cur = best;
+            if (b >= nblocks || b * B >= cur) break;
+            const int64_t hi = (b + 1) * B < c->n ? (b + 1) * B : c->n;
+            for (int64_t i = b * B; i < hi; ++i) {
+                if (only_nogpu && c->nodes[i].n_gpus != 0) continue;
+                if (!oracle_feasible(c, i, p, now)) continue;
+#pragma omp critical
+                { if (i < best) best = i; }
+                break;
+            }
+        }
+    }
+    return best < c->n ? best : -1;
+}
+
+/* GetFreeCpuBatch(numa, num, smt) on the flat core records of node nd (nhd/Node.py:502-519).  Scans EVERY core in
+ * index order - sibling range included - and marks nothing while it scans, exactly like the reference. */
+static int free_cpu_batch(const ocluster* c, const onode* nd, int numa, int num, int smt_requested, int32_t* out) {
+    int got = 0;
+    for (int ci = 0; ci < nd->n_cores; ++ci) {
+        if (num == 0) break;
+        const int o = nd->core_off + ci;
+        if (c->core_socket[o] != numa || c->core_used[o]) continue;
+        if (nd->smt) {
+            const int sib = c->core_sibling[o];
+            if (c->core_used[nd->core_off + sib]) continue;
+            if (smt_requested && num >= 2) { out[got++] = ci; out[got++] = sib; num -= 2; }
+            else { out[got++] = ci; num -= 1; }
+        } else { out[got++] = ci; num -= 1; }
+    }
+    return got;
+}
+
+/* SetBusy + SetPhysicalIdsFromMapping + ClaimPodNICResources on node idx.
+ *   map_numa[g] = mapping['gpu'][g], misc_numa = mapping['cpu'][-1], nic_numa/nic_idx[g] = mapping['nic'][g]
+ *   nic_use[g]  = group g has an RX or TX core (its NIC is claimed)
+ *   ids: per group its core batch (GPU cpu_cores first, then proc_cores - the batch in order), helper batch, GPU list
+ *        positions; then the misc batch.  counts[3g..3g+2] = their lengths, counts[3G] = misc length.
+ * Returns 0, or 1 where the reference raises IndexError (its unwind path is itself broken: parity undefined). */
+int oracle_commit(const ocluster* c, int64_t idx, const opod* p, const int32_t* map_numa, int32_t misc_numa,
+                  const int32_t* nic_numa, const int32_t* nic_idx, const int32_t* nic_use, int32_t misc_smt_enabled,
+                  double now, int32_t* ids, int32_t* counts) {
+    onode* nd = (onode*)&c->nodes[idx];
+    uint8_t* core_used = (uint8_t*)c->core_used;
+    uint8_t* gpu_used = (uint8_t*)c->gpu_used;
+    int32_t* nic_pods = (int32_t*)c->nic_pods;
+    int n_ids = 0;
+    int claimed[MAXNIC * MAXU], n_claimed = 0;
+    nd->busy_time = now;                                                    /* SetBusy */
+    for (int g = 0; g < p->G; ++g) {
+        const int numa = map_numa[g];
+        int32_t batch[512];
+        const int want = p->n_proc[g];                                       /* len(proc_cores) + sum(len(gpu.cpu_cores)) */
+        const int got = free_cpu_batch(c, nd, numa, want, p->proc_smt[g], batch);
+        if (got != want) return 1;
+        /* GetNicObjFromIndex: idx is the per-NUMA ordinal in node.nics order (nhd/Node.py:413-418) */
+        int nic_pos = -1, ord = 0;
+        for (int k = 0; k < nd->n_nics && nic_pos < 0; ++k) {
+            if (c->nic_numa[nd->nic_off + k] != nic_numa[g]) continue;
+            if (ord == nic_idx[g]) nic_pos = k;
+            ++ord;
+        }
+        if (nic_pos < 0) return 1;
+        const int nsw = c->nic_sw[nd->nic_off + nic_pos];
+        int n_gpu_ids = 0;
+        int32_t gpu_ids[MAXNIC];
+        for (int q = 0; q < p->n_gpus[g]; ++q) {
+            int dev = -1;
+            for (int x = 0; x < nd->n_gpus && dev < 0; ++x)                  /* GetFreePciGpuFromNic */
+                if (c->gpu_sw[nd->gpu_off + x] == nsw && !gpu_used[nd->gpu_off + x]) dev = x;
+            if (dev < 0) {
+                if (p->map_type == 2) return 1;
+                for (int x = 0; x < nd->n_gpus && dev < 0; ++x)              /* GetNextGpuFree */
+                    if (c->gpu_numa[nd->gpu_off + x] == numa && !gpu_used[nd->gpu_off + x]) dev = x;
+            }
+            if (dev < 0) return 1;
+            gpu_used[nd->gpu_off + dev] = 1;
+            gpu_ids[n_gpu_ids++] = dev;
+        }
+        for (int k = 0; k < got; ++k) { core_used[nd->core_off + batch[k]] = 1; ids[n_ids++] = batch[k]; }
+        if (nic_use[g]) claimed[n_claimed++] = nic_pos;
+        int32_t helpers[512];
+        const int hgot = free_cpu_batch(c, nd, numa, p->n_help[g], p->help_smt[g], helpers);
+        if (hgot != p->n_help[g]) return 1;
+        for (int k = 0; k < hgot; ++k) { core_used[nd->core_off + helpers[k]] = 1; ids[n_ids++] = helpers[k]; }
+        for (int k = 0; k < n_gpu_ids; ++k) ids[n_ids++] = gpu_ids[k];
+        counts[3 * g] = got; counts[3 * g + 1] = hgot; counts[3 * g + 2] = n_gpu_ids;
+    }
+    if (p->hp > 0) nd->hp_free -= p->hp;
+    int32_t misc[512];
+    const int mgot = free_cpu_batch(c, nd, misc_numa, p->n_misc, misc_smt_enabled, misc);
+    if (mgot != p->n_misc) return 1;
+    for (int k = 0; k < mgot; ++k) { core_used[nd->core_off + misc[k]] = 1; ids[n_ids++] = misc[k]; }
+    counts[3 * p->G] = mgot;
+    for (int k = 0; k < n_claimed; ++k) {                                    /* distinct NIC list indices, pods_used += 1 */
+        int dup = 0;
+        for (int j = 0; j < k; ++j) if (claimed[j] == claimed[k]) dup = 1;
+        if (!dup) nic_pods[nd->nic_off + claimed[k]] += 1;
+    }
+    return 0;
+}
+
+
 int oracle_sizeof_node(void) { return (int)sizeof(onode); }
 int oracle_sizeof_pod(void) { return (int)sizeof(opod); }
