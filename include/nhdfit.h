@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NHDFIT_ABI_VERSION        5
+#define NHDFIT_ABI_VERSION        6
 #define NHDFIT_MAX_GROUPS         4      /* proc groups per pod (G)                               */
 #define NHDFIT_MAX_NUMA           2      /* NUMA nodes (= sockets, nhd/Node.py:336) per node (U)  */
 #define NHDFIT_MAX_CORES_PER_NUMA 64     /* physical cores per socket (one uint64 mask)           */
@@ -176,11 +176,13 @@ typedef struct {
 } nhdfit_mapping;                            /* 20 bytes */
 
 /* ---- physical ids of one committed placement = what Node.SetPhysicalIdsFromMapping writes into the pod's
- * CfgTopology (nhd/Node.py:663-841).  A core batch (one GetFreeCpuBatch call, nhd/Node.py:502-519) is two masks
+ * CfgTopology (nhd/Node.py:663-841).  A core batch (one GetFreeCpuBatch call, nhd/Node.py:502-519) is three masks
  * over the physical cores of its socket: `take` = cores whose thread 0 was handed out, `pair` = those whose SMT
- * sibling was handed out with it.  The reference's list is, for ascending core b in `take`: logical id
- * numa * cores_per_proc + b, then - if b is in `pair` - its sibling (id + num_cores).  It assigns that list to the
- * group's GPU cpu_cores first, then to its proc_cores (nhd/Node.py:729-742). */
+ * sibling was handed out with it, `late` = those whose sibling was handed out as a core of its own when the walk ran
+ * on into the sibling range (a request without the SMT flag that the thread-0 cores could not fill - the pod-level
+ * misc cores under quirk Q1).  The reference's list is, for ascending core b in `take`: logical id
+ * numa * cores_per_proc + b, then - if b is in `pair` - its sibling (id + num_cores); then, for ascending b in `late`,
+ * the sibling id.  It assigns that list to the group's GPU cpu_cores first, then to its proc_cores (nhd/Node.py:729-742). */
 #define NHDFIT_PLACEMENT_GPUS 8
 typedef struct {
     uint64_t proc_take[NHDFIT_MAX_GROUPS], proc_pair[NHDFIT_MAX_GROUPS];   /* batch of len(proc_cores) + GPU cores, proc_smt   */
@@ -190,9 +192,12 @@ typedef struct {
     int8_t   numa[NHDFIT_MAX_GROUPS + 1];                                  /* NUMA node of group g / of the misc cores          */
     uint8_t  status;                                                       /* NHDFIT_COMMIT_*                                   */
     uint8_t  pad[2];
-} nhdfit_placement;                                                        /* 184 bytes */
+    uint64_t proc_late[NHDFIT_MAX_GROUPS], help_late[NHDFIT_MAX_GROUPS], misc_late;   /* second threads handed out by the run-on walk */
+} nhdfit_placement;                                                        /* 256 bytes */
 #define NHDFIT_COMMIT_OK          0
-#define NHDFIT_COMMIT_WOULD_RAISE 1   /* the reference's commit would raise (or hand a core out twice): parity undefined        */
+#define NHDFIT_COMMIT_WOULD_RAISE 1   /* the reference's commit raises IndexError (a batch short after the walk over both thread
+                                         ranges, no free GPU on a PCI-mode group's switch, no such NIC) or hands an SMT request
+                                         its own cores twice: parity undefined from here on; the mirror is left as the walk left it */
 #define NHDFIT_COMMIT_NEW_SIG     2   /* committed, but the node's new NIC state has no signature in the dictionary yet: intern
                                          it (download the node, re-derive its signatures) and upload its plane 3           */
 

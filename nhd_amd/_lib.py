@@ -10,6 +10,7 @@ from ctypes import POINTER, c_char_p, c_double, c_int, c_uint32, c_uint64, c_voi
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libnhdfit.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nhdfit.h")
+ABI_VERSION = 6                  # NHDFIT_ABI_VERSION of include/nhdfit.h this binding (and pack.py's record layouts) is written for
 
 
 class NhdFitError(RuntimeError):
@@ -89,9 +90,13 @@ def load():
     elif build.stale() and os.path.exists(build.hipcc()):      # a source is newer than the library (development tree)
         try:
             build.build_lib()
-        except Exception:  # noqa: BLE001 - keep the library that is there
+        except Exception:  # noqa: BLE001 - keep the library that is there; its ABI version is checked below
             pass
     lib = ctypes.CDLL(LIB_PATH)
+    lib.nhdfit_abi_version.restype = c_int
+    got = lib.nhdfit_abi_version()
+    if got != ABI_VERSION:                                      # record layouts differ: never talk to it
+        raise NhdFitError(-5, f"{LIB_PATH} implements ABI {got}, this binding expects {ABI_VERSION}: rebuild it (python -m nhd_amd.build --force)")
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)
         fn.restype = res

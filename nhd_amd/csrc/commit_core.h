@@ -41,18 +41,32 @@ NHD_HD uint64_t lowest_bits(uint64_t x, uint32_t k) {
     return out;
 }
 
-// GetFreeCpuBatch(numa, num, smt) on the bitmaps of socket u.  Returns false if the socket cannot fill the batch
-// from cores whose both threads are free.
-NHD_HD bool take_batch(NodeState& s, uint32_t u, uint32_t num, bool smt_requested, uint64_t& take, uint64_t& pair) {
+// GetFreeCpuBatch(numa, num, smt) on the bitmaps of socket u (nhd/Node.py:502-519).  The reference walks ALL of Node.cores
+// in index order and marks nothing while it walks: first the thread-0 cores of the socket whose both threads are free
+// (`take`; `pair` = those whose sibling went out with them: SMT request and >= 2 cores still wanted), and - if the batch
+// is still short - on into the sibling range, where the very same physical cores qualify again (their thread 0 is still
+// "unused"): a request WITHOUT the SMT flag gets their second threads as cores of their own (`late`, ascending).  That
+// is what happens to the pod-level misc cores of quirk Q1 (the filter halved them, Matcher.py:198; the commit does not,
+// Node.py:799) - defined behaviour, no exception.  An SMT request that runs on is handed its own cores a second time;
+// a batch that is short after both passes raises IndexError (Node.py:686): both return false - the reference's state is
+// garbage or its unwind path (itself broken) runs, parity is undefined from there on.
+NHD_HD bool take_batch(NodeState& s, uint32_t u, uint32_t num, bool smt_requested, uint64_t& take, uint64_t& pair, uint64_t& late) {
     const bool smt_node = (s.p2.flags & NHDFIT_NF_SMT) != 0;
     const uint64_t free = s.p0.t0[u] & s.p1.t1[u];
     const bool pairs = smt_node && smt_requested;
+    const uint32_t avail = (uint32_t)popc64(free);
     const uint32_t n_take = pairs ? (num + 1) / 2 : num, n_pair = pairs ? num / 2 : 0;
     take = lowest_bits(free, n_take);
     pair = lowest_bits(free, n_pair);
+    late = 0;
+    uint32_t n_late = 0;
+    if (smt_node && !pairs && num > avail) {                 // the walk runs on into the sibling range
+        n_late = num - avail;
+        late = lowest_bits(free, n_late);
+    }
     s.p0.t0[u] &= ~take;
-    if (smt_node) s.p1.t1[u] &= ~pair;
-    return (uint32_t)popc64(take) == n_take;
+    if (smt_node) s.p1.t1[u] &= ~(pair | late);
+    return (uint32_t)popc64(take) + (uint32_t)popc64(late) == n_take && (uint32_t)popc64(late) == n_late;
 }
 
 // canonical key of one NIC pool: free-GPU limit (NHDFIT_GLIMIT_NONE for the NUMA-mode pool) and the number of NICs
@@ -147,11 +161,11 @@ NHD_HD int commit_node(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, cons
     const int G = (int)r.n_groups;
     int status = kCommitOk;
     for (int g = 0; g < kMaxG; ++g) {
-        out.proc_take[g] = out.proc_pair[g] = out.help_take[g] = out.help_pair[g] = 0;
+        out.proc_take[g] = out.proc_pair[g] = out.help_take[g] = out.help_pair[g] = out.proc_late[g] = out.help_late[g] = 0;
         for (int k = 0; k < NHDFIT_PLACEMENT_GPUS; ++k) out.gpu[g][k] = 0xFF;
         out.numa[g] = -1;
     }
-    out.misc_take = out.misc_pair = 0;
+    out.misc_take = out.misc_pair = out.misc_late = 0;
     out.numa[kMaxG] = -1;
     out.pad[0] = out.pad[1] = 0;
     s.p4.busy_time = busy_time;                                                     // SetBusy, nhd/Node.py:843-845
@@ -160,7 +174,7 @@ NHD_HD int commit_node(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, cons
     for (int g = 0; g < G; ++g) {
         const uint32_t u = (uint32_t)m.gpu[g] & 1u;
         out.numa[g] = (int8_t)u;
-        if (!take_batch(s, u, r.n_proc[g], (r.smt_bits >> g & 1) != 0, out.proc_take[g], out.proc_pair[g])) status = kCommitWouldRaise;
+        if (!take_batch(s, u, r.n_proc[g], (r.smt_bits >> g & 1) != 0, out.proc_take[g], out.proc_pair[g], out.proc_late[g])) status = kCommitWouldRaise;
         const uint32_t nu = (uint32_t)m.nic_numa[g] & 1u, nk = (uint32_t)m.nic_idx[g] & 15u;
         const uint32_t sw = d.nic_sw[nu][nk];
         for (uint32_t k = 0; k < r.gpus[g]; ++k) {
@@ -176,17 +190,20 @@ NHD_HD int commit_node(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, cons
             gpu_taken = true;
             if (k < (uint32_t)NHDFIT_PLACEMENT_GPUS) out.gpu[g][k] = (uint8_t)pick;
         }
-        if (!take_batch(s, u, r.n_help[g], (r.smt_bits >> (4 + g) & 1) != 0, out.help_take[g], out.help_pair[g])) status = kCommitWouldRaise;
+        if (!take_batch(s, u, r.n_help[g], (r.smt_bits >> (4 + g) & 1) != 0, out.help_take[g], out.help_pair[g], out.help_late[g])) status = kCommitWouldRaise;
         if (r.nic_use >> g & 1) { if (nu) claimed1 |= 1u << nk; else claimed0 |= 1u << nk; }
     }
     if (r.hugepages_gb > 0) s.p2.hp_free -= r.hugepages_gb;                        // Node.py:794-796
     const uint32_t mu = (uint32_t)m.cpu[G] & 1u;
     out.numa[kMaxG] = (int8_t)mu;
-    if (!take_batch(s, mu, r.n_misc, r.misc_smt_enabled != 0, out.misc_take, out.misc_pair)) status = kCommitWouldRaise;   // Node.py:799
-    for (uint32_t k = 0; k < (uint32_t)NHDFIT_MAX_NICS_PER_NUMA; ++k) {                 // ClaimPodNICResources: pods_used += 1; capacity
-        if (claimed0 >> k & 1) { if (pods_add(d, 0, k, 1) != 0) d.nic_cls[0][k] = 0; }  // class 0 = 0.0 while pods_used > 0 (Node.py:292)
-        if (claimed1 >> k & 1) { if (pods_add(d, 1, k, 1) != 0) d.nic_cls[1][k] = 0; }
-    }
+    if (!take_batch(s, mu, r.n_misc, r.misc_smt_enabled != 0, out.misc_take, out.misc_pair, out.misc_late)) status = kCommitWouldRaise;   // Node.py:799
+    // ClaimPodNICResources: pods_used += 1; the capacity class is 0 (= 0.0) while pods_used > 0 (Node.py:292, 644-646).
+    // A counter that is already out of the tracked range keeps its class: it left the range on the side its class
+    // says (free: pods_used < -3, used: > 3), and one more pod does not bring it back across zero.
+    for (uint32_t k = 0; k < (uint32_t)NHDFIT_MAX_NICS_PER_NUMA; ++k)
+        for (uint32_t u = 0; u < 2; ++u)
+            if ((u ? claimed1 : claimed0) >> k & 1)
+                if (pods_get(d, u, k) != kPodsLost && pods_add(d, u, k, 1) != 0) d.nic_cls[u][k] = 0;
     // the node's NIC signatures under the new NIC / GPU state (a NUMA node without a claim keeps its ids unless a GPU
     // was taken: the free-GPU count behind a switch enters the PCI-mode pools)
     for (uint32_t u = 0; u < 2; ++u) {

@@ -1144,6 +1144,15 @@ int nhdfit_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_req* req, const nhd
     if (!c || !req || !map || !place_out) return NHDFIT_E_INVAL;
     if (node >= c->n) return fail(c, NHDFIT_E_INVAL, "node %u out of range (%u nodes)", node, c->n);
     if (!map->valid) return fail(c, NHDFIT_E_INVAL, "the mapping is not valid");
+    if (!req_valid(*req)) return fail(c, NHDFIT_E_INVAL, "the request is not valid (map type NUMA / PCI, 1..%d proc groups)", NHDFIT_MAX_GROUPS);
+    for (uint32_t g = 0; g <= req->n_groups; ++g) {          // entries index two-element arrays / 16-entry NIC tables on the device
+        if (map->cpu[g] < 0 || map->cpu[g] >= NHDFIT_MAX_NUMA) return fail(c, NHDFIT_E_INVAL, "mapping: cpu[%u] = %d is not a NUMA node", g, (int)map->cpu[g]);
+        if (g == req->n_groups) break;
+        if (map->gpu[g] < 0 || map->gpu[g] >= NHDFIT_MAX_NUMA || map->nic_numa[g] < 0 || map->nic_numa[g] >= NHDFIT_MAX_NUMA)
+            return fail(c, NHDFIT_E_INVAL, "mapping: group %u sits on NUMA node %d / its NIC on %d", g, (int)map->gpu[g], (int)map->nic_numa[g]);
+        if (map->nic_idx[g] < 0 || map->nic_idx[g] >= NHDFIT_MAX_NICS_PER_NUMA)
+            return fail(c, NHDFIT_E_INVAL, "mapping: group %u uses NIC ordinal %d", g, (int)map->nic_idx[g]);
+    }
     HIPCHK(c, hipSetDevice(c->dev));
     HIPCHK(c, c->seq_place.reserve(1));
     CommitArgs ca;

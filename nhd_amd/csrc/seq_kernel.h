@@ -532,6 +532,12 @@ __global__ __launch_bounds__(64) void k_commit(CommitArgs a) {
     nhdfit_detail d = a.det[a.node];
     nhdfit_placement pl;
     memset(&pl, 0, sizeof pl);
+    for (uint32_t g = 0; g < a.req.n_groups; ++g)                  // GetNicObjFromIndex returns None: IndexError before anything
+        if ((uint32_t)a.map.nic_idx[g] >= d.nic_cnt[a.map.nic_numa[g] & 1]) {   // of that group is touched (nhd/Node.py:700-704);
+            pl.status = kCommitWouldRaise;                         // the mirror is left alone
+            *a.out = pl;
+            return;
+        }
     commit_node(s, d, a.req, a.map, a.busy_time, a.sigs, pl);
     a.p0[a.node] = s.p0; a.p1[a.node] = s.p1; a.p2[a.node] = s.p2; a.p3[a.node] = s.p3; a.p4[a.node] = s.p4;
     a.det[a.node] = d;

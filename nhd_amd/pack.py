@@ -61,11 +61,11 @@ MAPPING = np.dtype([("gpu", "i1", (4,)), ("cpu", "i1", (5,)), ("nic_numa", "i1",
                     ("valid", "i1"), ("pad", "i1", (2,))])
 PLACEMENT = np.dtype([("proc_take", "<u8", (4,)), ("proc_pair", "<u8", (4,)), ("help_take", "<u8", (4,)), ("help_pair", "<u8", (4,)),
                       ("misc_take", "<u8"), ("misc_pair", "<u8"), ("gpu", "u1", (4, 8)), ("numa", "i1", (5,)), ("status", "u1"),
-                      ("pad", "u1", (2,))])
+                      ("pad", "u1", (2,)), ("proc_late", "<u8", (4,)), ("help_late", "<u8", (4,)), ("misc_late", "<u8")])
 COMMIT_OK, COMMIT_WOULD_RAISE, COMMIT_NEW_SIG = 0, 1, 2
 CC = np.dtype([("cls", "u1"), ("cnt", "u1")])
 assert (P0.itemsize, P1.itemsize, P2.itemsize, P3.itemsize, P4.itemsize) == (16,) * 5
-assert DETAIL.itemsize == 128 and REQ.itemsize == 128 and MAPPING.itemsize == 20 and PLACEMENT.itemsize == 184
+assert DETAIL.itemsize == 128 and REQ.itemsize == 128 and MAPPING.itemsize == 20 and PLACEMENT.itemsize == 256
 assert ORIGIN.itemsize == 80 and DELTA.itemsize == 96
 
 ALL_ONES = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -131,6 +131,7 @@ class Packer:
         self.max_gpus_per_numa = 0                     # table dimensions (fit_core.h Layout)
         self.max_cores_per_numa = 1
         self.dict_version = 0                          # bumped whenever caps / sigs / that maximum grow
+        self._closed_upto = 0                          # close_signatures: sigs[:_closed_upto] have their successors interned
 
     # ---- interning ------------------------------------------------------------------------
     def cap_class(self, cap) -> int:
@@ -241,9 +242,13 @@ class Packer:
         closure interned up front, device-side commits (nhdfit_schedule_batch / nhdfit_commit) never meet a NIC state
         without a signature.  Returns the number of signatures added."""
         added = 0
-        todo = list(self.sigs)
-        seen = set(self.sigs)
-        while todo and added < max_new:
+        todo = list(self.sigs[self._closed_upto:])        # signatures interned since the last closure (successors of the
+        seen = self._sig_index                             # older ones are in the dictionary already)
+        while todo:
+            if added >= max_new:                           # not closed: a commit may still meet an unknown NIC state, which the
+                import logging                             # device reports (NHDFIT_COMMIT_NEW_SIG) and the engine interns on the way
+                logging.getLogger(__name__).warning("NIC signature closure stopped after %d new signatures; the rest is interned on demand", added)
+                return added
             sig = todo.pop()
             for pi, (gl, pairs) in enumerate(sig):
                 succ_pools = []
@@ -266,10 +271,10 @@ class Packer:
                     pools = [p for k, p in enumerate(sig) if k != pi] + ([sp] if sp is not None else [])
                     key = tuple(sorted(pools))
                     if key not in seen:
-                        seen.add(key)
                         self.sig_id(pools)
                         todo.append(key)
                         added += 1
+        self._closed_upto = len(self.sigs)
         return added
 
     # ---- node side ------------------------------------------------------------------------
@@ -556,12 +561,13 @@ class Packer:
         return out
 
 
-def expand_batch(take: int, pair: int, numa: int, cores_per_proc: int, num_cores: int) -> List[int]:
-    """The list one GetFreeCpuBatch call returns (nhd/Node.py:502-519) from the two masks of a placement record:
+def expand_batch(take: int, pair: int, numa: int, cores_per_proc: int, num_cores: int, late: int = 0) -> List[int]:
+    """The list one GetFreeCpuBatch call returns (nhd/Node.py:502-519) from the masks of a placement record:
     ascending physical core b of socket `numa` -> logical id numa * cores_per_proc + b, followed by its SMT
-    sibling (id + num_cores, nhd/Node.py:343-350) when the pair bit is set."""
+    sibling (id + num_cores, nhd/Node.py:343-350) when the pair bit is set; then the siblings the run-on walk over
+    the sibling range handed out as cores of their own (`late`, ascending)."""
     out: List[int] = []
-    take, pair = int(take), int(pair)
+    take, pair, late = int(take), int(pair), int(late)
     b = 0
     while take >> b:
         if take >> b & 1:
@@ -569,6 +575,11 @@ def expand_batch(take: int, pair: int, numa: int, cores_per_proc: int, num_cores
             out.append(core)
             if pair >> b & 1:
                 out.append(core + num_cores)
+        b += 1
+    b = 0
+    while late >> b:
+        if late >> b & 1:
+            out.append(numa * cores_per_proc + b + num_cores)
         b += 1
     return out
 
@@ -581,10 +592,10 @@ def expand_placement(place, n_groups: int, cores_per_proc: int, num_cores: int, 
     groups = []
     for g in range(n_groups):
         u = int(place["numa"][g])
-        groups.append({"cores": expand_batch(place["proc_take"][g], place["proc_pair"][g], u, cores_per_proc, num_cores),
-                       "helpers": expand_batch(place["help_take"][g], place["help_pair"][g], u, cores_per_proc, num_cores),
+        groups.append({"cores": expand_batch(place["proc_take"][g], place["proc_pair"][g], u, cores_per_proc, num_cores, place["proc_late"][g]),
+                       "helpers": expand_batch(place["help_take"][g], place["help_pair"][g], u, cores_per_proc, num_cores, place["help_late"][g]),
                        "gpus": [int(x) for x in place["gpu"][g][:gpus_per_group[g]]]})
-    misc = expand_batch(place["misc_take"], place["misc_pair"], int(place["numa"][MAX_GROUPS]), cores_per_proc, num_cores)
+    misc = expand_batch(place["misc_take"], place["misc_pair"], int(place["numa"][MAX_GROUPS]), cores_per_proc, num_cores, place["misc_late"])
     return {"groups": groups, "misc": misc}
 
 

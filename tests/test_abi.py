@@ -15,12 +15,12 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_lib._SIGS)
-    assert lib.nhdfit_abi_version() == 5
+    assert lib.nhdfit_abi_version() == 6
 
 
 def test_struct_sizes_match_header():
     # sizes asserted on the C side by the struct comments; here: numpy mirrors
-    assert pack.REQ.itemsize == 128 and pack.DETAIL.itemsize == 128 and pack.MAPPING.itemsize == 20 and pack.PLACEMENT.itemsize == 184
+    assert pack.REQ.itemsize == 128 and pack.DETAIL.itemsize == 128 and pack.MAPPING.itemsize == 20 and pack.PLACEMENT.itemsize == 256
     assert ctypes.sizeof(_lib.Stats) == 72
 
 
@@ -61,3 +61,19 @@ def test_delta_and_origin_records_match_header():
     assert pack.DELTA.fields["busy_time"][1] == 72 and pack.DELTA.fields["nic_n"][1] == 80
     assert pack.DETAIL.fields["nic_pods"][1] == 82 and pack.DETAIL.fields["gpu_sw"][1] == 96
     assert pack.ORIGIN.fields["nic_base"][1] == 32 and pack.ORIGIN.fields["hp_total"][1] == 64
+
+
+def test_placement_record_matches_header():
+    assert pack.PLACEMENT.itemsize == 256
+    assert pack.PLACEMENT.fields["misc_take"][1] == 128 and pack.PLACEMENT.fields["gpu"][1] == 144 and pack.PLACEMENT.fields["numa"][1] == 176
+    assert pack.PLACEMENT.fields["status"][1] == 181 and pack.PLACEMENT.fields["proc_late"][1] == 184 and pack.PLACEMENT.fields["misc_late"][1] == 248
+
+
+def test_binding_refuses_a_library_of_another_abi(monkeypatch):
+    """nhd_amd/_lib.py compares nhdfit_abi_version() with the version its record layouts are written for."""
+    assert _lib.load().nhdfit_abi_version() == _lib.ABI_VERSION
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    import pytest
+    with pytest.raises(_lib.NhdFitError):
+        _lib.load()

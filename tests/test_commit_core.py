@@ -125,3 +125,90 @@ def test_single_commit_matches_oracle():
         assert one.p2[0]["gpu_free"] == table.p2[i]["gpu_free"] and one.p2[0]["hp_free"] == table.p2[i]["hp_free"]
         placed += 1
     assert placed >= 20
+
+
+@pytest.mark.parametrize("cfg,n,P", [(3, 40, 200), (4, 30, 250), (5, 80, 400)])
+def test_misc_cores_without_the_smt_flag_take_second_threads(cfg, n, P):
+    """The pods as the generator draws them (misc_cores_smt disabled for half): quirk Q1 lets one free physical core pass
+    the filter for two misc cores, GetFreeCpuBatch's walk runs on into the sibling range (nhd/Node.py:502-519) and hands
+    out the second thread as a core of its own - `misc_late` in the placement record.  Decisions, ids and the packed
+    state after the batch against the oracle's loop; no pod may come back as 'would raise'."""
+    spec = synth.make_cluster(cfg, n_nodes=n)
+    pods, groups = synth.make_pods(cfg, n_pods=P)
+    nodes = spec.build_nodes()
+    tops = [refmodel.make_topology(s) for s in pods]
+    pk = pack.Packer()
+    table = pk.pack_nodes(nodes)
+    reqs = pk.digest_many(tops, groups)
+    pk.close_signatures()
+    node, maps, places, status, done = harness.schedule(pk, table, reqs, spec.clock_now, apply=True)
+    assert done == P and not (status == pack.COMMIT_WOULD_RAISE).any()
+    ids = []
+    want = O.schedule_sequence(nodes, tops, groups, spec.clock_now, ids_out=ids)
+    late = 0
+    for i, (w, wid) in enumerate(zip(want, ids)):
+        if w[0] is None:
+            assert node[i] < 0
+            continue
+        assert table.names[int(node[i])] == w[0]
+        nd = nodes[w[0]]
+        G = int(reqs[i]["n_groups"])
+        got = pack.expand_placement(places[i], G, int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets),
+                                    [int(reqs[i]["gpus"][g]) for g in range(G)])
+        assert got == wid, (i, got, wid)
+        late += int(places[i]["misc_late"] != 0)
+    t2 = pack.Packer().pack_nodes(nodes)
+    for f in ("p0", "p1"):
+        assert np.array_equal(getattr(table, f), getattr(t2, f)), f
+
+
+def test_run_on_walk_tiny_case():
+    """The hand-made Q1 case of tests/test_seq_oracle.py (checked there against the unmodified reference: misc = [3, 11])."""
+    from tests import util
+    from tests.test_seq_oracle import _tiny_cluster
+    pod = dict(map_type="NUMA", hugepages_gb=0, misc=2, misc_smt=False,
+               groups=[dict(proc=2, helpers=0, rx=1, tx=1, gpus=[], proc_smt=False, helper_smt=False)])
+    tops = [refmodel.make_topology(pod) for _ in range(2)]
+    nodes = _tiny_cluster({})
+    pk = pack.Packer()
+    table = pk.pack_nodes(nodes)
+    reqs = pk.digest_many(tops, None)
+    pk.close_signatures()
+    node, maps, places, status, done = harness.schedule(pk, table, reqs, util.CLOCK, apply=True)
+    assert done == 2 and list(node) == [0, 1] and not status.any()
+    got = pack.expand_placement(places[0], 1, 4, 8, [0])
+    assert got == {"groups": [{"cores": [1, 2], "helpers": [], "gpus": []}], "misc": [3, 11]}
+    assert int(places[0]["misc_late"]) == 1 << 3
+    O.schedule_sequence(nodes, tops, [None, None], util.CLOCK)
+    t2 = pack.Packer().pack_nodes(nodes)
+    assert np.array_equal(table.p0, t2.p0) and np.array_equal(table.p1, t2.p1)
+
+
+def test_claim_on_a_counter_outside_the_tracked_range_keeps_the_class():
+    """pods_used = -5 on a free NIC (releases subtract one per pairing, claims add one per NIC): the packed
+    counter says 'out of range', the reference's claim makes it -4 and the NIC keeps its capacity (nhd/Node.py:292)."""
+    from tests import util
+    nl = util.random_cluster(77, 12)
+    name, nd = next((k, v) for k, v in nl.items() if len(v.nics) >= 1 and v.nics[0].numa_node < v.numa_nodes)
+    nd.nics[0].pods_used = -5
+    for c in nd.cores:
+        c.used = c.core in getattr(nd, "reserved_cores", [])
+    pk = pack.Packer()
+    table = pk.pack_nodes(nl)
+    pk.close_signatures()
+    i = table.names.index(name)
+    u, k = int(nd.nics[0].numa_node), int(nd.nics[0].idx)
+    assert pack.get_pods(table.detail[i], u, k) == pack.PODS_LOST and table.detail[i]["nic_cls"][u][k] != 0
+    top = refmodel.make_topology(dict(map_type="NUMA", hugepages_gb=0, misc=0, misc_smt=True,
+                                      groups=[dict(proc=2, helpers=0, rx=1, tx=1, gpus=[], proc_smt=False, helper_smt=False)]))
+    req = pk.digest(top)
+    m = np.zeros((), pack.MAPPING)
+    m["gpu"][0] = u; m["cpu"][:2] = (u, u); m["nic_numa"][0] = u; m["nic_idx"][0] = k; m["valid"] = 1
+    rc, place = harness.commit(pk, table, i, req, m, util.CLOCK)
+    assert rc == pack.COMMIT_OK
+    O.commit(nd, top, {"gpu": (u,), "cpu": (u, u), "nic": [(u, k)]}, util.CLOCK)
+    assert nd.nics[0].pods_used == -4
+    one = pack.empty_table(1)
+    fresh = pack.Packer()
+    fresh.pack_node_into(nd, one, 0)
+    assert fresh.caps[int(one.detail[0]["nic_cls"][u][k])] == pk.caps[int(table.detail[i]["nic_cls"][u][k])] != 0.0
