@@ -8,7 +8,8 @@ import re
 from ctypes import POINTER, c_char_p, c_double, c_int, c_uint32, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libnhdfit.so")
+# NHDFIT_LIBRARY: load another build of the same ABI instead (tools/: the tuning build libnhdfit_tuning.so)
+LIB_PATH = os.environ.get("NHDFIT_LIBRARY") or os.path.join(HERE, "libnhdfit.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nhdfit.h")
 ABI_VERSION = 6                  # NHDFIT_ABI_VERSION of include/nhdfit.h this binding (and pack.py's record layouts) is written for
 

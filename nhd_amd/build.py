@@ -12,6 +12,7 @@ DEPS = [SRC, WIRE, os.path.join(HERE, "csrc", "fit_core.h"), os.path.join(HERE, 
         os.path.join(HERE, "csrc", "seq_core.h"), os.path.join(HERE, "csrc", "set_states.h"), os.path.join(HERE, "csrc", "commit_core.h"), os.path.join(ROOT, "include", "nhdfit.h")] + \
        [os.path.join(HERE, "csrc", f) for f in ("step_digest.h", "step_fit.h", "step_map.h", "step_kernel.h", "seq_kernel.h")]
 LIB = os.path.join(HERE, "libnhdfit.so")
+TUNING_LIB = os.path.join(HERE, "libnhdfit_tuning.so")   # -DNHDFIT_TUNING: environment knobs + ablation switches, for tools/ only
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
 
@@ -24,15 +25,16 @@ def stale() -> bool:
     return (not os.path.exists(LIB)) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
 
 
-def build_lib(force=False, verbose=False, extra=()):
-    if not force and not stale():
-        return LIB
-    cmd = [hipcc()] + FLAGS + list(extra) + [SRC, WIRE, "-o", LIB, "-ldl"]
+def build_lib(force=False, verbose=False, extra=(), tuning=False):
+    out = TUNING_LIB if tuning else LIB
+    if not force and not tuning and not stale():
+        return out
+    cmd = [hipcc()] + FLAGS + (["-DNHDFIT_TUNING"] if tuning else []) + list(extra) + [SRC, WIRE, "-o", out, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=HERE)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_lib(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv))

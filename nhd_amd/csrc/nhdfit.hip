@@ -34,6 +34,14 @@
 
 using namespace nhdfit;
 
+// Tuning / profiling knobs read from the environment exist in the tuning build only (-DNHDFIT_TUNING,
+// `python -m nhd_amd.build --tuning` -> libnhdfit_tuning.so, used by tools/): the shipped library looks nothing up.
+#ifdef NHDFIT_TUNING
+static inline const char* tune_env(const char* name) { return getenv(name); }
+#else
+static inline const char* tune_env(const char*) { return nullptr; }
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -126,14 +134,14 @@ struct nhdfit_ctx {
     // software pipeline: number of steps (since the last stage_requests) whose phase has been launched
     uint64_t n_dig = 0, n_fit = 0, n_shaped = 0, n_chosen = 0, n_finished = 0;
     bool geom_big = true;                // 512-thread step blocks (256 for small problems)
-    uint32_t digest_parts = getenv("NHDFIT_DIGEST_PARTS") ? (uint32_t)atoi(getenv("NHDFIT_DIGEST_PARTS")) : 2;   // tuning aid
-    uint32_t side_prio = getenv("NHDFIT_SIDE_PRIO") ? (uint32_t)atoi(getenv("NHDFIT_SIDE_PRIO")) : 1;   // tuning aid
-    int seq_pods = getenv("NHDFIT_SEQ_PODS") && atoi(getenv("NHDFIT_SEQ_PODS")) == 8 ? 8 : 16;   // tuning aid: pods per round of the sequential kernel
-    uint32_t choose_split = getenv("NHDFIT_CHOOSE_SPLIT") ? (uint32_t)atoi(getenv("NHDFIT_CHOOSE_SPLIT")) : 16;   // tuning aid: wavefronts per tile
-    bool split = getenv("NHDFIT_SPLIT") != nullptr;
-    bool role_kernels = getenv("NHDFIT_ROLE_KERNELS") != nullptr;   // profiling aid: every role as a kernel of its own (512-thread geometry only)
+    uint32_t digest_parts = tune_env("NHDFIT_DIGEST_PARTS") ? (uint32_t)atoi(tune_env("NHDFIT_DIGEST_PARTS")) : 2;   // tuning aid
+    uint32_t side_prio = tune_env("NHDFIT_SIDE_PRIO") ? (uint32_t)atoi(tune_env("NHDFIT_SIDE_PRIO")) : 1;   // tuning aid
+    int seq_pods = tune_env("NHDFIT_SEQ_PODS") && atoi(tune_env("NHDFIT_SEQ_PODS")) == 8 ? 8 : 16;   // tuning aid: pods per round of the sequential kernel
+    uint32_t choose_split = tune_env("NHDFIT_CHOOSE_SPLIT") ? (uint32_t)atoi(tune_env("NHDFIT_CHOOSE_SPLIT")) : 16;   // tuning aid: wavefronts per tile
+    bool split = tune_env("NHDFIT_SPLIT") != nullptr;
+    bool role_kernels = tune_env("NHDFIT_ROLE_KERNELS") != nullptr;   // profiling aid: every role as a kernel of its own (512-thread geometry only)
     DevBuf<unsigned long long> role_clock;            // profiling aid: NHDFIT_ROLE_TIMES=<step> prints the role windows of that step
-    int64_t role_step = getenv("NHDFIT_ROLE_TIMES") ? atoll(getenv("NHDFIT_ROLE_TIMES")) : -1;   // profiling aid: launch the side roles apart from the fit role
+    int64_t role_step = tune_env("NHDFIT_ROLE_TIMES") ? atoll(tune_env("NHDFIT_ROLE_TIMES")) : -1;   // profiling aid: launch the side roles apart from the fit role
     std::string err;
     hipDeviceProp_t prop;
 
@@ -172,6 +180,9 @@ struct nhdfit_ctx {
     DevBuf<uint64_t> cand;               // [chunks] candidate nodes of the call
     DevBuf<uint8_t> tile_wcls;           // row width class per staged tile
     DevBuf<FitItem> items; uint32_t n_items = 0;   // work items of the fit role (blocks), heaviest tiles first
+    // argument blocks of the steady-state step launches, one per buffer set, resident in device memory (k_step_p)
+    DevBuf<StepArgs> step_args; PinBuf<StepArgs> pin_step_args; bool step_args_valid[kBufs] = {};
+    bool args_by_pointer = tune_env("NHDFIT_ARGS_BY_VALUE") == nullptr;   // tuning aid: every launch by value
     std::vector<uint8_t> h_tile_wcls;
     DevBuf<unsigned long long> shape_keys[kBufs]; DevBuf<uint32_t> shape_res[kBufs]; DevBuf<int32_t> shape_slot[kBufs];   // mapping dedup tables
     DevBuf<uint32_t> shape_list[kBufs];  // distinct shapes per tile
@@ -183,13 +194,13 @@ struct nhdfit_ctx {
     DevBuf<unsigned long long> xkeys; DevBuf<uint32_t> xids; DevBuf<uint64_t> xcls; DevBuf<uint32_t> xnx;
     uint32_t rec_lo = 0, rec_hi = 0; bool rec_all = true;
     uint32_t nx = 0, x_cap = kMinXCap;   // interned classes (as of the last record update) / provisioned X rows
-    uint32_t fit_blocks = getenv("NHDFIT_FIT_BLOCKS") ? (uint32_t)atoi(getenv("NHDFIT_FIT_BLOCKS")) : 0;   // tuning aid: blocks of the fit role
-    bool use_choose_tab = getenv("NHDFIT_NO_CHOOSE_TABLE") == nullptr;   // tuning aid: run the set model for every shape
+    uint32_t fit_blocks = tune_env("NHDFIT_FIT_BLOCKS") ? (uint32_t)atoi(tune_env("NHDFIT_FIT_BLOCKS")) : 0;   // tuning aid: blocks of the fit role
+    bool use_choose_tab = tune_env("NHDFIT_NO_CHOOSE_TABLE") == nullptr;   // tuning aid: run the set model for every shape
     // set-layout state machine for three-group pods (set_states.h): verified against the model on the host
     // (tests/test_pyset_emulation.py), parity-green and 10 % faster per step on the GPU (profiles/r02):
     // on by default, NHDFIT_NO_SET_STATES=1 runs the insertion-by-insertion model instead
     DevBuf<uint64_t> st_info; DevBuf<uint32_t> st_next, st_asc; uint32_t st_n = 0;
-    bool use_set_states = getenv("NHDFIT_NO_SET_STATES") == nullptr;
+    bool use_set_states = tune_env("NHDFIT_NO_SET_STATES") == nullptr;
     // mode B
     DevBuf<uint64_t> nogpu, taken, tile_masks; DevBuf<int32_t> touched; DevBuf<uint16_t> gl_tiles; std::vector<uint32_t> order_host; std::vector<SeqResult> seq_host; DevBuf<UndoRec> undo; DevBuf<SeqResult> seq_out; DevBuf<nhdfit_placement> seq_place;
     DevBuf<uint32_t> order, seq_counters;
@@ -347,7 +358,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->origin.release(); c->deltas.release(); c->delta_run.release(); c->delta_status.release();
     c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release();
-    c->reqs.release(); c->bitmap.release(); c->nm.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
+    c->reqs.release(); c->bitmap.release(); c->nm.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->step_args.release(); c->pin_step_args.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); c->shape_list[b].release(); }
     c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->sig_keys.release(); c->sig_ids.release();
     for (int b = 0; b < kBufs; ++b) {
@@ -459,6 +470,10 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_step_p<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_step_p<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_step_p<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_step_p<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return NHDFIT_OK;
 }
 
@@ -692,7 +707,7 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
     // for speed only), so every tile gets a multiple of 8 blocks and block j of a tile works inside eighth j % 8 of the
     // node axis: an XCD's L2 then only ever sees its eighth of the node records (0.7 MB at 65 536 nodes instead of all
     // 5.5 MB of the three row widths + busy times - more than the 4 MB an XCD has), re-read once per pod tile.
-    static const bool xcd_items = !(getenv("NHDFIT_XCD_ITEMS") && atoi(getenv("NHDFIT_XCD_ITEMS")) == 0);
+    static const bool xcd_items = !(tune_env("NHDFIT_XCD_ITEMS") && atoi(tune_env("NHDFIT_XCD_ITEMS")) == 0);
     const bool by_xcd = xcd_items && !c->fit_blocks && chunks >= 8u * 4u * nw && nw == 8;
     for (uint32_t t = 0; t < tiles; ++t) {           // staged order = widest tiles first
         const uint32_t w = c->h_tile_wcls[t];
@@ -700,7 +715,7 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
         uint32_t nb = (uint32_t)((cost * target + total / 2) / total);
         nb = std::max(1u, std::min(nb, (chunks + nw - 1) / nw));          // at least one chunk per wavefront
         if (by_xcd) {
-            static const uint32_t force_k = getenv("NHDFIT_XCD_K") ? (uint32_t)atoi(getenv("NHDFIT_XCD_K")) : 0u;   // tuning aid
+            static const uint32_t force_k = tune_env("NHDFIT_XCD_K") ? (uint32_t)atoi(tune_env("NHDFIT_XCD_K")) : 0u;   // tuning aid
             const uint32_t k = force_k ? force_k : nb <= 11 ? 1u : nb <= 23 ? 2u : 4u;         // 8, 16 or 32 blocks
             for (uint32_t j = 0; j < 8 * k; ++j) {
                 const uint32_t r = (j % 8) * k + j / 8;                     // range r of 8k: the (j / 8)-th piece of eighth j % 8
@@ -763,7 +778,7 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         if (c->n_chosen < c->n_shaped) {
             a.choose = shape_args((int)(c->n_chosen % kBufs));
             // wavefront = tile, lane = shape (NHDFIT_CHOOSE_LANES=0: a wavefront per shape, 16 x the blocks - tuning aid)
-            static const bool lanes_off = getenv("NHDFIT_CHOOSE_LANES") && atoi(getenv("NHDFIT_CHOOSE_LANES")) == 0;
+            static const bool lanes_off = tune_env("NHDFIT_CHOOSE_LANES") && atoi(tune_env("NHDFIT_CHOOSE_LANES")) == 0;
             const bool lanes = !lanes_off;
             a.choose_lanes = lanes ? 1u : 0u;
             a.nb_choose = lanes ? (tiles + nw - 1) / nw : (tiles * c->choose_split + nw - 1) / nw; did_choose = true;
@@ -790,7 +805,7 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         for (int w = 0; w < kWClasses; ++w) d.L[w] = c->L[w];
         d.pitch = c->pitch; d.tabs = c->tabs[b].p; d.hdr = c->hdr[b].p; d.score = c->score[b].p;
         d.xcls = c->xcls.p; d.nx = c->xnx.p;
-        static const uint32_t wc_parts = getenv("NHDFIT_WC_PARTS") && atoi(getenv("NHDFIT_WC_PARTS")) >= 1 ? (uint32_t)atoi(getenv("NHDFIT_WC_PARTS")) : kWcPartsDefault;   // tuning aid
+        static const uint32_t wc_parts = tune_env("NHDFIT_WC_PARTS") && atoi(tune_env("NHDFIT_WC_PARTS")) >= 1 ? (uint32_t)atoi(tune_env("NHDFIT_WC_PARTS")) : kWcPartsDefault;   // tuning aid
         d.wc_parts = wc_parts;
         a.nb_digest = tiles * (1 + wc_parts);
     }
@@ -812,7 +827,7 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         f.nm = c->want_bitmap ? c->nm.p : nullptr;
         f.score = c->score[bf].p;
         f.items = c->items.p;
-        f.dbg_skip = getenv("NHDFIT_FIT_SKIP") ? (uint32_t)atoi(getenv("NHDFIT_FIT_SKIP")) : 0;
+        f.dbg_skip = tune_env("NHDFIT_FIT_SKIP") ? (uint32_t)atoi(tune_env("NHDFIT_FIT_SKIP")) : 0;
         nb_fit = c->n_items;
     }
     a.nb_fit = nb_fit;
@@ -836,6 +851,37 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
     const bool timed = (with_fit && (c->n_fit < 2 || (c->n_fit & 7) == 0)) || (!with_fit && with_digest);
     if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc) return rc; }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][0], c->stream));
+    // Pipelined step (fit + the next digest; in the steady state every role): the block of buffer set bf lives in device memory.
+    // It is compared with the host copy of what is there (the busy threshold travels in the launch itself) and re-sent only
+    // when something changed - staging, uploads, a grown class table; the copy is stream-ordered in front of the launch.
+    const StepArgs* dev_args = nullptr;
+    if (c->args_by_pointer && with_fit && a.nb_digest && !a.role_clock && !c->role_kernels && !c->split) {
+        HIPCHK(c, c->step_args.reserve(kBufs));
+        HIPCHK(c, c->pin_step_args.reserve(kBufs));
+        const double busy_from = a.fit.busy_from;
+        a.fit.busy_from = 0.0;
+        StepArgs& held = c->pin_step_args.p[bf];
+        if (!c->step_args_valid[bf] || memcmp(&held, &a, sizeof a) != 0) {
+            // the pinned copy may still be the source of an earlier copy in flight: that copy was enqueued kBufs launches ago
+            // at the latest only if the stream ran that far - wait for it (rare path)
+            if (c->step_args_valid[bf]) HIPCHK(c, hipStreamSynchronize(c->stream));
+            memcpy(&held, &a, sizeof a);
+            HIPCHK(c, hipMemcpyAsync(c->step_args.p + bf, &held, sizeof a, hipMemcpyHostToDevice, c->stream));
+            c->step_args_valid[bf] = true;
+        }
+        a.fit.busy_from = busy_from;
+        dev_args = c->step_args.p + bf;
+    }
+    if (dev_args) {
+        const double busy_from = a.fit.busy_from;
+        if (c->x_spill) {
+            if (big) hipLaunchKernelGGL((k_step_p<512, true>), dim3(grid), dim3(512), lds, c->stream, dev_args, busy_from);
+            else     hipLaunchKernelGGL((k_step_p<256, true>), dim3(grid), dim3(256), lds, c->stream, dev_args, busy_from);
+        } else {
+            if (big) hipLaunchKernelGGL((k_step_p<512>), dim3(grid), dim3(512), lds, c->stream, dev_args, busy_from);
+            else     hipLaunchKernelGGL((k_step_p<256>), dim3(grid), dim3(256), lds, c->stream, dev_args, busy_from);
+        }
+    } else
     if (c->x_spill) {               // more node classes than LDS rows: the variant whose fit role reads the rest from global memory
         if (big) hipLaunchKernelGGL((k_step<512, true>), dim3(grid), dim3(512), lds, c->stream, a);
         else     hipLaunchKernelGGL((k_step<256, true>), dim3(grid), dim3(256), lds, c->stream, a);
@@ -932,7 +978,7 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
         // others' sweep), 256-thread blocks for small problems so that the grid still covers the chip
         const uint32_t tiles = (c->P + kTile - 1) / kTile, chunks = (c->n + 63) / 64;
         c->geom_big = (uint64_t)tiles * ((chunks + 31) / 32) >= (uint32_t)c->prop.multiProcessorCount;
-        if (const char* b = getenv("NHDFIT_BLOCK")) c->geom_big = atoi(b) >= 512;      // tuning aid
+        if (const char* b = tune_env("NHDFIT_BLOCK")) c->geom_big = atoi(b) >= 512;      // tuning aid
         if (c->role_kernels) c->geom_big = true;
     }
     if (c->n_dig <= c->n_fit) {                      // first step after staging: its digest has not run yet
@@ -992,7 +1038,7 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
 
 int nhdfit_find(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand,
                 uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out) {
-    static const bool prof = getenv("NHDFIT_FIND_PROF") != nullptr;      // tuning aid: host-side phase times of the call
+    static const bool prof = tune_env("NHDFIT_FIND_PROF") != nullptr;      // tuning aid: host-side phase times of the call
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!prof) return;
@@ -1083,7 +1129,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     if (!sa.lds_tables) seq_lds = 0;
     const int seq_pods = c->seq_pods;
     HIPCHK(c, hipFuncSetAttribute(seq_pods == 16 ? (const void*)k_seq<16> : (const void*)k_seq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    const bool seq_prof = getenv("NHDFIT_SEQ_PROF") != nullptr;
+    const bool seq_prof = tune_env("NHDFIT_SEQ_PROF") != nullptr;
     if (seq_prof) { HIPCHK(c, c->role_clock.reserve(16)); sa.prof = c->role_clock.p; }
     if (seq_pods == 16) hipLaunchKernelGGL(k_seq<16>, dim3(1), dim3(1024), seq_lds, sm, sa);
     else hipLaunchKernelGGL(k_seq<8>, dim3(1), dim3(512), seq_lds, sm, sa);
@@ -1309,7 +1355,7 @@ int nhdfit_group_create(const int* devices, int n, nhdfit_group** out) {
         if (rc) { for (auto* x : g->ctx) nhdfit_destroy(x); delete g; return rc; }
         g->ctx.push_back(c);
     }
-    const char* mode = getenv("NHDFIT_GROUP_REDUCE");
+    const char* mode = tune_env("NHDFIT_GROUP_REDUCE");
     if (n > 1 && !(mode && !strcmp(mode, "host"))) {
         std::string err;
         if (!g_rccl.load(err)) { for (auto* x : g->ctx) nhdfit_destroy(x); delete g; return fail(nullptr, NHDFIT_E_RCCL, "%s", err.c_str()); }

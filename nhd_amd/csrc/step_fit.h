@@ -3,6 +3,11 @@
 // step_fit.h, step_map.h, step_kernel.h, seq_kernel.h (one translation unit: the roles are fused into one kernel).
 // gfx950 only.
 struct FitItem { uint32_t tile, wcls, c_begin, c_end; };       // one block of the fit role: chunks [c_begin, c_end) of a tile
+#ifdef NHDFIT_TUNING
+constexpr bool kTuning = true;        // ablation switches (FitArgs::dbg_skip) are compiled into the tuning build only
+#else
+constexpr bool kTuning = false;
+#endif
 
 struct FitArgs {
     const NodeRec* rec[kWClasses];   // node records per row width (k_xrecords), padded to a multiple of 64 nodes
@@ -146,8 +151,13 @@ __device__ __forceinline__ uint64_t sweep_assignments_spill(const uint8_t* hot, 
 // not touch them - all but the first one or two of a run - costs four instructions.  Only a chunk with news is
 // transposed (lane = pod) and scored.
 template <int BLOCK, int W, bool SPILL>
-__device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, uint8_t* lds) {
+__device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_from, const FitItem it, uint8_t* lds) {
     constexpr int NW = BLOCK / 64;
+    const uint32_t dbg = kTuning ? a.dbg_skip : 0u;
+    // the argument block may live behind a pointer (k_step_p): what the chunk loop uses is read once, here
+    const nhdfit_plane4* __restrict__ p4 = a.p4;
+    const uint64_t* __restrict__ cand = a.cand;
+    uint64_t* __restrict__ nm = a.nm;
     constexpr int WC = W == 2 ? 0 : W == 4 ? 1 : W == 8 ? 2 : 3;
     const uint32_t hot_bytes = a.hot_bytes[WC];
     uint8_t* hot = lds;
@@ -160,7 +170,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
     const NodeRec* __restrict__ recs = a.rec[WC];
     const uint32_t len = it.c_end - it.c_begin, per = (len + NW - 1) / NW;
     const uint32_t c_first = it.c_begin + wave * per;
-    const uint32_t c_last = (a.dbg_skip & 64) ? c_first : c_first + per < it.c_end ? c_first + per : it.c_end;
+    const uint32_t c_last = (dbg & 64) ? c_first : c_first + per < it.c_end ? c_first + per : it.c_end;
 
     // Everything the block needs first is requested before anything is waited for: the tile's request headers, the
     // wavefront's first node records and the hot section of the table image are independent L2 round trips - issued one
@@ -170,13 +180,13 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
     double bt = 0.0;
     if (c_first < c_last) {
         rv = *reinterpret_cast<const uint4*>(recs + c_first * 64 + lane);           // {w0,w1}, {x0,x1}, {gx,hp}, {flags,pad}
-        bt = a.p4[c_first * 64 + lane].busy_time;
+        bt = p4[c_first * 64 + lane].busy_time;
     }
     const uint8_t* hot_global = a.tabs + (size_t)tile * a.pitch + a.off_hot[WC];
     {   // stage the hot section of the tile's table image in LDS (16 B per lane, fully coalesced)
         const uint4* src = reinterpret_cast<const uint4*>(hot_global);
         uint4* dst = reinterpret_cast<uint4*>(hot);
-        if (!(a.dbg_skip & 16)) for (uint32_t i = threadIdx.x; i < staged / 16; i += BLOCK) dst[i] = src[i];
+        if (!(dbg & 16)) for (uint32_t i = threadIdx.x; i < staged / 16; i += BLOCK) dst[i] = src[i];
         if (spill) {                                                                 // the HP rows go right behind the prefix
             const uint4* hsrc = reinterpret_cast<const uint4*>(hot_global + a.hot_hp[WC]);
             for (uint32_t i = threadIdx.x; i < a.hp_bytes / 16; i += BLOCK) dst[staged / 16 + i] = hsrc[i];
@@ -200,9 +210,9 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
         const uint32_t i = c * 64 + lane;
         uint4 rv_next = rv;
         double bt_next = bt;
-        if (c + 1 < c_last && !(a.dbg_skip & 4)) {
+        if (c + 1 < c_last && !(dbg & 4)) {
             rv_next = *reinterpret_cast<const uint4*>(recs + i + 64);
-            bt_next = a.p4[i + 64].busy_time;
+            bt_next = p4[i + 64].busy_time;
         }
         const uint32_t a_w0 = (rv.x & 0xFFFFu) << 3, a_w1 = (rv.x >> 16) << 3;
         const uint32_t a_x0 = (rv.y & 0xFFFFu) << 3, a_x1 = (rv.y >> 16) << 3;
@@ -216,21 +226,21 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
         if (SPILL && spill && __ballot(a_x0 + W * 8 > staged || a_x1 + W * 8 > staged))
             okm = sweep_assignments_spill<W>(hot, hot_global, staged, a_w0, a_w1, a_x0, a_x1);
         else
-            okm = (a.dbg_skip & 1) ? ((uint64_t)rv.y << 32 | rv.x) : sweep_assignments<W>(hot, a_w0, a_w1, a_x0, a_x1);
-        const uint2 gx = (a.dbg_skip & 8) ? make_uint2(rv.z, rv.w) : lds8(hot, a_gx), hpw = (a.dbg_skip & 8) ? make_uint2(~0u, ~0u) : lds8(hot, a_hp);
-        const bool busy = bt >= a.busy_from;                                  // Node.IsBusy, nhd/Node.py:847-850
+            okm = (dbg & 1) ? ((uint64_t)rv.y << 32 | rv.x) : sweep_assignments<W>(hot, a_w0, a_w1, a_x0, a_x1);
+        const uint2 gx = (dbg & 8) ? make_uint2(rv.z, rv.w) : lds8(hot, a_gx), hpw = (dbg & 8) ? make_uint2(~0u, ~0u) : lds8(hot, a_hp);
+        const bool busy = bt >= busy_from;                                  // Node.IsBusy, nhd/Node.py:847-850
         uint32_t wlo = (uint32_t)okm & gx.x & hpw.x, whi = (uint32_t)(okm >> 32) & gx.y & hpw.y;
         if (busy) { wlo &= ~(uint32_t)m_need; whi &= ~(uint32_t)(m_need >> 32); }      // Matcher.py:107-111
-        if (a.cand) {                                                         // candidate dict of the call (FindNode's nl)
-            const uint64_t cw = a.cand[c];
+        if (cand) {                                                           // candidate dict of the call (FindNode's nl)
+            const uint64_t cw = cand[c];
             if (!(cw >> lane & 1)) wlo = whi = 0;
         }
-        if (a.nm) a.nm[(size_t)tile * npad + i] = ((uint64_t)whi << 32) | wlo;
+        if (nm) nm[(size_t)tile * npad + i] = ((uint64_t)whi << 32) | wlo;
 
         // (3) does this chunk change any pod's winner?
         const uint32_t nlo = (uint32_t)need_any | (nogpu ? (uint32_t)need_pref : 0u);
         const uint32_t nhi = (uint32_t)(need_any >> 32) | (nogpu ? (uint32_t)(need_pref >> 32) : 0u);
-        if (!(a.dbg_skip & 2) && __ballot(((wlo & nlo) | (whi & nhi)) != 0)) {
+        if (!(dbg & 2) && __ballot(((wlo & nlo) | (whi & nhi)) != 0)) {
             const uint64_t nogpu_mask = __ballot(nogpu);
             transpose64(wlo, whi);                                            // lane j: pod j's verdict over the chunk's 64 nodes
             const uint64_t word = ((uint64_t)whi << 32) | wlo;
@@ -246,7 +256,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
     unsigned long long best = 0;
     if (best_pref != ~0u) best = score_of(true, a.global_base + best_pref);
     else if (best_any != ~0u) best = score_of(false, a.global_base + best_any);
-    if (a.dbg_skip & 32) return;
+    if (dbg & 32) return;
     s_best[wave][lane] = best;
     __syncthreads();
     if (wave == 0 && my_pod_live) {
@@ -258,17 +268,17 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const FitItem it, u
 }
 
 template <int BLOCK, bool SPILL = false>
-__device__ __forceinline__ void role_fit(const FitArgs& a, uint32_t blk, uint8_t* lds) {
+__device__ __forceinline__ void role_fit(const FitArgs& a, const double busy_from, uint32_t blk, uint8_t* lds) {
     FitItem it = a.items[blk];                      // block-uniform: keep it in scalar registers
     it.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.tile);
     it.wcls = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.wcls);
     it.c_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_begin);
     it.c_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_end);
     switch (it.wcls) {
-        case 0: role_fit_w<BLOCK, 2, SPILL>(a, it, lds); break;
-        case 1: role_fit_w<BLOCK, 4, SPILL>(a, it, lds); break;
-        case 2: role_fit_w<BLOCK, 8, SPILL>(a, it, lds); break;
-        default: role_fit_w<BLOCK, 16, SPILL>(a, it, lds); break;
+        case 0: role_fit_w<BLOCK, 2, SPILL>(a, busy_from, it, lds); break;
+        case 1: role_fit_w<BLOCK, 4, SPILL>(a, busy_from, it, lds); break;
+        case 2: role_fit_w<BLOCK, 8, SPILL>(a, busy_from, it, lds); break;
+        default: role_fit_w<BLOCK, 16, SPILL>(a, busy_from, it, lds); break;
     }
 }
 

@@ -32,7 +32,7 @@ __device__ __forceinline__ void stamp(unsigned long long* role_clock, int role, 
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_fit_only(FitArgs a) {
     extern __shared__ __align__(16) uint8_t lds[];
-    role_fit<BLOCK>(a, blockIdx.x, lds);
+    role_fit<BLOCK>(a, a.busy_from, blockIdx.x, lds);
 }
 
 // ---- node records ------------------------------------------------------------------------------------
@@ -121,16 +121,15 @@ __global__ __launch_bounds__(256) void k_rows(const uint64_t* __restrict__ nm, u
     if (pod < P) rows[(size_t)c * P + pod] = ((uint64_t)hi << 32) | lo;
 }
 
-template <int BLOCK, bool SPILL = false>      // SPILL: some tiles stage only a prefix of their hot section (refresh_layouts)
-__global__ __launch_bounds__(BLOCK, SPILL ? (BLOCK == 512 ? 4 : 5) : (BLOCK == 512 ? 6 : 7)) void k_step(StepArgs a) {   // SPILL: two blocks per CU (LDS)   // 512 threads = 2 waves per SIMD: 3 blocks per CU either way
-    extern __shared__ __align__(16) uint8_t lds[];
+template <int BLOCK, bool SPILL>      // SPILL: some tiles stage only a prefix of their hot section (refresh_layouts)
+__device__ __forceinline__ void step_body(const StepArgs& a, const double busy_from, uint8_t* lds) {
     uint32_t blk = blockIdx.x;
     const unsigned long long t0 = a.role_clock ? (unsigned long long)wall_clock64() : 0ull;
     // Grid order: the fit role first.  Its blocks are sized to fill two of the three block slots of every CU, so all of
     // them start at once; the side roles (short latency chains on few wavefronts) take the third slot, with issue
     // priority so that they finish - and hand the slot on - sooner.
     if (blk < a.nb_fit) {
-        role_fit<BLOCK, SPILL>(a.fit, blk, lds);
+        role_fit<BLOCK, SPILL>(a.fit, busy_from, blk, lds);
         stamp(a.role_clock, 4, t0);
         return;
     }
@@ -154,6 +153,23 @@ __global__ __launch_bounds__(BLOCK, SPILL ? (BLOCK == 512 ? 4 : 5) : (BLOCK == 5
     stamp(a.role_clock, 3, t0);
 }
 
+// The step launch, argument block by value (irregular launches: the first step after staging, a single find, the pipeline
+// flush) ...
+template <int BLOCK, bool SPILL = false>
+__global__ __launch_bounds__(BLOCK, SPILL ? (BLOCK == 512 ? 4 : 5) : (BLOCK == 512 ? 6 : 7)) void k_step(StepArgs a) {   // SPILL: two blocks per CU (LDS)   // 512 threads = 2 waves per SIMD: 3 blocks per CU either way
+    extern __shared__ __align__(16) uint8_t lds[];
+    step_body<BLOCK, SPILL>(a, a.fit.busy_from, lds);
+}
+// ... and by pointer: in the steady state of the pipeline the ~3 KB block repeats with the period of the buffer sets and
+// lives in device memory (launch_step keeps one copy per buffer set); the launch then carries 16 bytes - the pointer and
+// the one field that changes with every step, the busy threshold.  A by-value block of this size is copied by the runtime
+// into host-coherent kernarg memory and fetched from there by every block's scalar loads: ~5 us per step.
+template <int BLOCK, bool SPILL = false>
+__global__ __launch_bounds__(BLOCK, SPILL ? (BLOCK == 512 ? 4 : 5) : (BLOCK == 512 ? 6 : 7)) void k_step_p(const StepArgs* __restrict__ a, double busy_from) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    step_body<BLOCK, SPILL>(*a, busy_from, lds);
+}
+
 // Profiling aid (NHDFIT_ROLE_KERNELS=1): one role per launch, so that rocprofv3 --stats names each role's stand-alone time.
 template <int BLOCK, int ROLE>
 __global__ __launch_bounds__(BLOCK, 6) void k_role(StepArgs a) {
@@ -168,5 +184,5 @@ __global__ __launch_bounds__(BLOCK, 6) void k_role(StepArgs a) {
     } else if constexpr (ROLE == 1) role_shapes<BLOCK>(a.shapes_m, a.shapes_h, blk, lds);
     else if constexpr (ROLE == 2) role_finish<BLOCK>(a.finish_m, a.finish_h, blk, lds);
     else if constexpr (ROLE == 3) role_digest<BLOCK>(a.digest, blk, lds);
-    else role_fit<BLOCK>(a.fit, blk, lds);
+    else role_fit<BLOCK>(a.fit, a.fit.busy_from, blk, lds);
 }
