@@ -124,20 +124,28 @@ def check_interpreter_set_model() -> None:
 
 
 class HipMatcher:
-    def __init__(self, device: int = 0, clock=time.monotonic, engine_factory=None, devices: Optional[Sequence[int]] = None):
+    def __init__(self, device: int = 0, clock=time.monotonic, engine_factory=None, devices: Optional[Sequence[int]] = None,
+                 strict: bool = False):
         """`devices=[0, 1, ...]`: shard the mirror over several GPUs of this process (engine.GroupEngine: node axis
         cut into contiguous shards, one RCCL all-reduce(max) of the packed scores per call picks the winners) - the
         reference's one-thread scheduler keeps calling FindNode exactly as before.
         `engine_factory(device)` exists for the test-suite only (it injects the host build of the
         kernels' arithmetic so the host logic of this class can be exercised without a GPU); the
-        default is the HIP engine, which raises when the library or a gfx950 GPU is missing."""
+        default is the HIP engine, which raises when the library or a gfx950 GPU is missing.
+        `strict=False` (default) keeps FindNode's contract - `(name, mapping)` or `(None,)`, never an exception
+        (nhd/Matcher.py:47-63) - where the device layout cannot hold something: a node beyond the
+        layout's capacities (include/nhdfit.h) never matches and is listed in `self.unmirrored` (name -> reason), a
+        request beyond them or a device error makes the call answer `(None,)` (the scheduler leaves the pod pending and
+        tries again, nhd/NHDScheduler.py:278-287); each is logged.  `strict=True` raises instead."""
         self.logger = logging.getLogger(__name__)
+        self.strict = strict
+        self._warned: set = set()
         check_interpreter_set_model()
         if devices is not None:
             self.engine = GroupEngine(devices, engine_factory)
         else:
             self.engine = (engine_factory or Engine)(device)
-        self.packer = pack.Packer()
+        self.packer = pack.Packer(strict=strict)
         self.clock = clock
         self._attached: Optional[Dict[str, object]] = None
         self._index: Dict[str, int] = {}
@@ -160,7 +168,7 @@ class HipMatcher:
         self._mirror_foreign = False
         # a fresh dictionary: NIC signatures, capacity classes and group sets of nodes that left the cluster (or of states
         # nothing is in any more) do not pile up over the life of a scheduler that re-attaches after node churn
-        self.packer = pack.Packer()
+        self.packer = pack.Packer(strict=self.strict)
         self.engine.forget_dictionary()
         for node in nodes.values():
             if type(node) not in _tracked_cache.values():
@@ -428,7 +436,32 @@ class HipMatcher:
         out = self._run(nl, None, pod_groups, now, sequential, reqs=reqs)
         return [(None,) if skip[i] else out[i] for i in range(len(cfg_texts))]
 
+    @property
+    def unmirrored(self) -> Dict[str, str]:
+        """Nodes the device layout cannot hold (name -> reason): they never match; everything else is answered for."""
+        return self.packer.unmirrored
+
+    def _warn_unmirrored(self) -> None:
+        for name, why in self.packer.unmirrored.items():
+            if name not in self._warned:
+                self._warned.add(name)
+                self.logger.warning("node %s is not mirrored on the device and will never be selected: %s", name, why)
+
     def _run(self, nl, tops, pod_groups, now, sequential, reqs=None, apply=False):
+        from ._lib import NhdFitError
+        try:
+            return self._run_checked(nl, tops, pod_groups, now, sequential, reqs, apply)
+        except NhdFitError as e:
+            if self.strict:
+                raise
+            n_pods = len(tops) if reqs is None else len(reqs)
+            self.logger.error("FindNode: the device path failed (%s): %d pod(s) answered (None,)", e, n_pods)
+            self._mirror_foreign = True                   # whatever the mirror holds now, rebuild it before the next call
+            self._last_subset = None
+            self.last_placements = [None] * n_pods
+            return [(None,) for _ in range(n_pods)]
+
+    def _run_checked(self, nl, tops, pod_groups, now, sequential, reqs=None, apply=False):
         if reqs is None:
             if not tops:
                 return []
@@ -457,8 +490,12 @@ class HipMatcher:
         else:
             self._full_upload(nl)
             self._mirror_foreign = self._attached is not None
+        self._warn_unmirrored()
         if reqs is None:
-            reqs = self.packer.digest_many(tops, pod_groups)
+            beyond: List[Tuple[int, str]] = []
+            reqs = self.packer.digest_many(tops, pod_groups, unsupported=beyond)
+            for i, why in beyond:
+                self.logger.error("pod %d of the call cannot be expressed as a request record and is answered (None,): %s", i, why)
         elif pod_groups is not None:                       # requests digested from config texts: InitialNodeFilter in the kernel
             for i in range(n_pods):
                 reqs[i]["flags"] = pack.RF_INITIAL_FILTER

@@ -28,6 +28,7 @@ MAX_SWITCHES = 14
 MAX_CLASSES = 16
 GLIMIT_NONE = 255
 TILE = 64
+MAX_HUGEPAGES_GB = 1022         # fit_core.h kMaxHpRows - 2
 
 NF_MAINTENANCE, NF_ACTIVE, NF_SMT, NF_HAS_GPU = 1, 2, 4, 8
 RF_INITIAL_FILTER = 1
@@ -119,7 +120,13 @@ def get_pods(det, u: int, k: int) -> int:
 
 
 class Packer:
-    def __init__(self):
+    def __init__(self, strict: bool = False):
+        """strict=False (default): a node whose shape exceeds a capacity of the device layout (include/nhdfit.h: more than 2
+        NUMA nodes, more than 64 physical cores per socket, ...) is mirrored as a node that never matches - FindNode keeps
+        answering for every other node, as its contract demands ("never an exception") - and is listed
+        in `unmirrored` (name -> reason).  strict=True raises UnsupportedNode instead."""
+        self.strict = strict
+        self.unmirrored: Dict[str, str] = {}
         self.caps: List[float] = [0.0]                 # class 0 = a claimed NIC (capacity 0, nhd/Node.py:292)
         self._cap_index: Dict[float, int] = {0.0: 0}
         self.sigs: List[tuple] = [()]                  # sig 0 = no NIC pool at all
@@ -279,6 +286,22 @@ class Packer:
 
     # ---- node side ------------------------------------------------------------------------
     def pack_node_into(self, node, t: NodeTable, i: int) -> None:
+        """Node object -> record i of the table.  See __init__ for nodes the layout cannot hold."""
+        try:
+            self._pack_node_into(node, t, i)
+            self.unmirrored.pop(node.name, None)
+        except UnsupportedNode as e:
+            if self.strict:
+                raise
+            self.unmirrored[node.name] = str(e)
+            for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
+                getattr(t, f)[i] = np.zeros((), getattr(t, f).dtype)
+            if t.origin is not None:
+                t.origin[i] = np.zeros((), ORIGIN)
+            t.p2[i]["flags"] = NF_MAINTENANCE                  # GX row 0: never feasible (nhd/Matcher.py:71)
+            t.detail[i]["numa_nodes"] = 1
+
+    def _pack_node_into(self, node, t: NodeTable, i: int) -> None:
         U = int(node.numa_nodes)
         if U < 1 or U > MAX_NUMA:
             raise UnsupportedNode(f"node {node.name}: {U} NUMA nodes (supported: 1..{MAX_NUMA})")
@@ -514,6 +537,8 @@ class Packer:
         if G > MAX_GROUPS:
             raise UnsupportedNode(f"pod with {G} proc groups (> {MAX_GROUPS})")
         r["hugepages_gb"] = max(-2 ** 31, min(2 ** 31 - 1, int(top.hugepages_gb)))
+        if int(top.hugepages_gb) > MAX_HUGEPAGES_GB:
+            raise UnsupportedNode(f"pod asks for {int(top.hugepages_gb)} GiB of hugepages (> {MAX_HUGEPAGES_GB}: the hugepage table of a pod tile)")
 
         def half(n):
             return int(math.ceil(n / 2.0))
@@ -554,10 +579,19 @@ class Packer:
             r["groups"] = self.group_bits_known(pod_groups)
         return r
 
-    def digest_many(self, tops: Sequence[object], pod_groups: Optional[Sequence[Sequence[str]]] = None) -> np.ndarray:
+    def digest_many(self, tops: Sequence[object], pod_groups: Optional[Sequence[Sequence[str]]] = None,
+                    unsupported: Optional[List[Tuple[int, str]]] = None) -> np.ndarray:
+        """One record per pod.  A request beyond the record's limits (more than MAX_GROUPS proc groups, > 255 cores in a
+        group) raises UnsupportedNode - or, with `unsupported` (a list), becomes a record that matches nothing
+        (map type 0, nhd/Matcher.py:45-47) and is reported there as (index, reason)."""
         out = np.zeros(len(tops), REQ)
         for i, top in enumerate(tops):
-            out[i] = self.digest(top, None if pod_groups is None else pod_groups[i])
+            try:
+                out[i] = self.digest(top, None if pod_groups is None else pod_groups[i])
+            except UnsupportedNode as e:
+                if unsupported is None or self.strict:
+                    raise
+                unsupported.append((i, str(e)))
         return out
 
 

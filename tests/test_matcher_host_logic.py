@@ -115,3 +115,72 @@ def test_reattach_after_node_churn_compacts_the_dictionary():
     assert m.packer is not packer_before
     assert len(m.packer.sigs) <= sigs_before and len(m.packer.group_sets) < sets_before
     assert len(m._names) == 50
+
+
+def _odd_cluster():
+    """A cluster with nodes the device layout cannot hold next to ordinary ones: four sockets, 96 physical cores per socket."""
+    from workload.refmodel import NFD
+    nl = util.random_cluster(4321, 24)
+    base = {"DATA_PLANE_VLAN": "1", "DATA_DEFAULT_GW": "10.0.0.1/32",
+            NFD + "nfd-extras-nic.eth0.mlx.0000000000aa.100000Mbs.0.10.0.0": "true",
+            NFD + "nfd-extras-nic.eth1.mlx.0000000000bb.100000Mbs.1.20.1.0": "true"}
+    quad = dict(base, **{NFD + "nfd-extras-cpu.numSockets": "4", NFD + "nfd-extras-cpu.num_cores": "64"})
+    wide = dict(base, **{NFD + "nfd-extras-cpu.numSockets": "2", NFD + "nfd-extras-cpu.num_cores": "192",
+                         NFD + "cpu-hardware_multithreading": "true"})
+    out = {}
+    for k, (name, node) in enumerate(nl.items()):
+        if k == 3:
+            out["quad-socket"] = refmodel.node_from_labels("quad-socket", quad, (64, 64))
+        if k == 9:
+            out["wide-socket"] = refmodel.node_from_labels("wide-socket", wide, (64, 64))
+        out[name] = node
+    return out
+
+
+def test_nodes_beyond_the_layout_never_match_and_nothing_raises(caplog):
+    """"failure is (None,) - never an exception".  A node the packed layout cannot hold (more than two
+    NUMA nodes, more than 64 physical cores per socket) is left out - FindNode answers for all the others exactly as the
+    reference does for them - and is named in `unmirrored` and in the log."""
+    nl = _odd_cluster()
+    supported = {k: v for k, v in nl.items() if k not in ("quad-socket", "wide-socket")}
+    rng = np.random.default_rng(5)
+    for attach in (False, True):
+        m = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)
+        if attach:
+            m.attach(nl)
+        with caplog.at_level("WARNING"):
+            for _ in range(25):
+                top = refmodel.make_topology(util.random_pod_spec(rng))
+                assert m.FindNode(nl, top) == norm(O.find_node(supported, top, util.CLOCK))
+        assert set(m.unmirrored) == {"quad-socket", "wide-socket"}
+        assert "4 NUMA nodes" in m.unmirrored["quad-socket"] and "96 physical cores" in m.unmirrored["wide-socket"]
+    assert "quad-socket" in caplog.text and "never be selected" in caplog.text
+    with pytest.raises(Exception):
+        HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine, strict=True).FindNode(nl, top)
+
+
+def test_requests_beyond_the_record_and_device_errors_answer_none(caplog):
+    nl = util.random_cluster(99, 20)
+    m = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)
+    ok = refmodel.make_topology(dict(map_type="NUMA", hugepages_gb=0, misc=0, misc_smt=True,
+                                     groups=[dict(proc=2, helpers=0, rx=0, tx=0, gpus=[], proc_smt=False, helper_smt=False)]))
+    five = refmodel.make_topology(dict(map_type="NUMA", hugepages_gb=0, misc=0, misc_smt=True,
+                                       groups=[dict(proc=2, helpers=0, rx=0, tx=0, gpus=[], proc_smt=False, helper_smt=False)] * 5))
+    huge = refmodel.make_topology(dict(map_type="NUMA", hugepages_gb=5000, misc=0, misc_smt=True,
+                                       groups=[dict(proc=2, helpers=0, rx=0, tx=0, gpus=[], proc_smt=False, helper_smt=False)]))
+    with caplog.at_level("ERROR"):
+        got = m.FindNodes(nl, [ok, five, huge, ok])
+    assert got[0] == norm(O.find_node(nl, ok, util.CLOCK)) == got[3] and got[1] == (None,) and got[2] == (None,)
+    assert "cannot be expressed" in caplog.text
+
+    from nhd_amd._lib import NhdFitError
+
+    class Broken(harness.HarnessEngine):
+        def find(self, *a, **kw):
+            raise NhdFitError(-3, "hipErrorLaunchFailure (injected)")
+    m2 = HipMatcher(clock=lambda: util.CLOCK, engine_factory=Broken)
+    with caplog.at_level("ERROR"):
+        assert m2.FindNode(nl, ok) == (None,)
+    assert "device path failed" in caplog.text
+    with pytest.raises(NhdFitError):
+        HipMatcher(clock=lambda: util.CLOCK, engine_factory=Broken, strict=True).FindNode(nl, ok)
