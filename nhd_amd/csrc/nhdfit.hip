@@ -52,6 +52,7 @@ namespace {
 #include "step_map.h"
 #include "step_kernel.h"
 #include "seq_kernel.h"
+#include "seq2_kernel.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -204,6 +205,8 @@ struct nhdfit_ctx {
     // mode B
     DevBuf<uint64_t> nogpu, taken, tile_masks; DevBuf<int32_t> touched; DevBuf<uint16_t> gl_tiles; std::vector<uint32_t> order_host; std::vector<SeqResult> seq_host; DevBuf<UndoRec> undo; DevBuf<SeqResult> seq_out; DevBuf<nhdfit_placement> seq_place;
     DevBuf<uint32_t> order, seq_counters;
+    DevBuf<uint32_t> seq_list, seq_assign, seq_flags; std::vector<uint32_t> list_host;   // two-chain form (seq2_kernel.h): chain A's pods, then chain B's
+    bool seq_general = tune_env("NHDFIT_SEQ_GENERAL") != nullptr;   // tuning aid: the one-block kernel for every batch
     DevBuf<uint64_t> sig_keys; DevBuf<uint32_t> sig_ids; uint32_t sig_mask = 0;   // canonical NIC-state key -> signature id (commit_core.h)
     bool use_cand = false, want_bitmap = true, want_map = true;
 
@@ -360,7 +363,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release();
     c->reqs.release(); c->bitmap.release(); c->nm.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->step_args.release(); c->pin_step_args.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); c->shape_list[b].release(); }
-    c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->sig_keys.release(); c->sig_ids.release();
+    c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_list.release(); c->seq_assign.release(); c->seq_flags.release(); c->sig_keys.release(); c->sig_ids.release();
     for (int b = 0; b < kBufs; ++b) {
         c->hdr[b].release(); c->tabs[b].release(); c->score[b].release(); c->maps[b].release();
         if (c->ev_fit[b]) (void)hipEventDestroy(c->ev_fit[b]);
@@ -1076,6 +1079,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     HIPCHK(c, hipSetDevice(c->dev));
     hipStream_t sm = c->stream;
     const uint32_t chunks = (c->n + 63) / 64;
+    const uint32_t tiles = (P + kTile - 1) / kTile;
     int rc;
     {
         // snapshot pass: digest + fit (verdict matrix and first-fit scores; the mapping roles are not needed - every
@@ -1087,29 +1091,38 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         if (!rc) rc = nhdfit_enqueue_step(c, now);
         c->want_bitmap = wb; c->want_map = wm;
         if (rc) return rc;
-        if ((rc = convert_rows(c))) return rc;
-        const uint32_t tiles = (P + kTile - 1) / kTile;
         HIPCHK(c, c->nogpu.reserve(chunks ? chunks : 1));
         HIPCHK(c, c->taken.reserve(chunks ? chunks : 1));
         HIPCHK(c, c->tile_masks.reserve((size_t)tiles * 2));
         HIPCHK(c, c->touched.reserve(c->n ? c->n : 1));
         HIPCHK(c, c->gl_tiles.reserve(tiles));
         HIPCHK(c, c->seq_counters.reserve(4));
-        HIPCHK(c, c->undo.reserve(apply ? 1 : P));
+        HIPCHK(c, c->undo.reserve(P));
         HIPCHK(c, c->seq_out.reserve(P));
         HIPCHK(c, c->seq_place.reserve(P));
         HIPCHK(c, c->order.reserve(P));
+        HIPCHK(c, c->seq_list.reserve(P));
+        HIPCHK(c, c->seq_assign.reserve(P));
+        HIPCHK(c, c->seq_flags.reserve(4));
         c->order_host.resize(P);                              // caller's pod -> staged (class-sorted) position
         for (uint32_t i = 0; i < P; ++i) c->order_host[c->perm[i]] = i;
         HIPCHK(c, hipMemcpyAsync(c->order.p, c->order_host.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
-        HIPCHK(c, hipMemsetAsync(c->taken.p, 0, (size_t)(chunks ? chunks : 1) * sizeof(uint64_t), sm));
-        HIPCHK(c, hipMemsetAsync(c->touched.p, 0xFF, (size_t)c->n * sizeof(int32_t), sm));
-        HIPCHK(c, hipMemsetAsync(c->seq_counters.p, 0, 4 * sizeof(uint32_t), sm));
         hipLaunchKernelGGL(k_nogpu, dim3(chunks), dim3(64), 0, sm, c->p2.p, c->n, c->nogpu.p);
         const int b0 = (int)((c->n_fit - 1) % kBufs);
         hipLaunchKernelGGL(k_tile_masks, dim3(tiles), dim3(64), 0, sm, c->hdr[b0].p, tiles, c->tile_masks.p);
         HIPCHK(c, hipGetLastError());
     }
+    // pod-major verdict rows of the snapshot + empty taken / first-touch state (again before a fallback pass)
+    auto reset_scan_state = [&]() -> int {
+        int rc_ = convert_rows(c);
+        if (rc_) return rc_;
+        HIPCHK(c, hipMemsetAsync(c->taken.p, 0, (size_t)(chunks ? chunks : 1) * sizeof(uint64_t), sm));
+        HIPCHK(c, hipMemsetAsync(c->touched.p, 0xFF, (size_t)c->n * sizeof(int32_t), sm));
+        HIPCHK(c, hipMemsetAsync(c->seq_counters.p, 0, 4 * sizeof(uint32_t), sm));
+        HIPCHK(c, hipMemsetAsync(c->seq_flags.p, 0, 4 * sizeof(uint32_t), sm));
+        return NHDFIT_OK;
+    };
+    if ((rc = reset_scan_state())) return rc;
     const int b = (int)((c->n_fit - 1) % kBufs);
     SeqArgs sa;
     memset(&sa, 0, sizeof sa);
@@ -1121,42 +1134,119 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     sa.rows = c->bitmap.p; sa.taken = c->taken.p; sa.nogpu = c->nogpu.p; sa.tile_masks = c->tile_masks.p;
     sa.caps = c->caps.p; sa.sigs = sig_table(c); sa.fc_dim = c->max_cores + 1; sa.fg_dim = c->max_gpus + 1; sa.ngs = c->ngs;
     sa.mt = map_tables(c);
-    sa.undo = c->undo.p; sa.touched = c->touched.p; sa.counters = c->seq_counters.p; sa.keep_undo = apply ? 0 : 1;
+    sa.undo = c->undo.p; sa.touched = c->touched.p; sa.counters = c->seq_counters.p; sa.keep_undo = 1;
     sa.out = c->seq_out.p; sa.place = c->seq_place.p; sa.n_done = c->seq_counters.p + 1; sa.gl_tiles = c->gl_tiles.p;
-    const uint32_t tiles_b = (P + kTile - 1) / kTile;
-    size_t seq_lds = lds_slice((size_t)tiles_b * 16) + lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4) + lds_slice((size_t)P * 4) + lds_slice(tiles_b);
-    sa.lds_tables = seq_lds <= 96 * 1024;
-    if (!sa.lds_tables) seq_lds = 0;
-    const int seq_pods = c->seq_pods;
-    HIPCHK(c, hipFuncSetAttribute(seq_pods == 16 ? (const void*)k_seq<16> : (const void*)k_seq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    const bool seq_prof = tune_env("NHDFIT_SEQ_PROF") != nullptr;
-    if (seq_prof) { HIPCHK(c, c->role_clock.reserve(16)); sa.prof = c->role_clock.p; }
-    if (seq_pods == 16) hipLaunchKernelGGL(k_seq<16>, dim3(1), dim3(1024), seq_lds, sm, sa);
-    else hipLaunchKernelGGL(k_seq<8>, dim3(1), dim3(512), seq_lds, sm, sa);
-    if (seq_prof) {
-        unsigned long long t[16];
+
+    // The general kernel: one block walks `n_list` pods (all P when list is null) in order, kSeqPods per round.
+    auto run_general = [&](const uint32_t* list_dev, uint32_t n_list, uint32_t& done) -> int {
+        SeqArgs g = sa;
+        g.list = list_dev; g.n_list = n_list;
+        size_t seq_lds = lds_slice((size_t)tiles * 16) + lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4) + lds_slice((size_t)P * 4) + lds_slice(tiles);
+        g.lds_tables = seq_lds <= 96 * 1024;
+        if (!g.lds_tables) seq_lds = 0;
+        const int seq_pods = c->seq_pods;
+        HIPCHK(c, hipFuncSetAttribute(seq_pods == 16 ? (const void*)k_seq<16> : (const void*)k_seq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        const bool seq_prof = tune_env("NHDFIT_SEQ_PROF") != nullptr;
+        if (seq_prof) { HIPCHK(c, c->role_clock.reserve(16)); g.prof = c->role_clock.p; }
+        if (seq_pods == 16) hipLaunchKernelGGL(k_seq<16>, dim3(1), dim3(1024), seq_lds, sm, g);
+        else hipLaunchKernelGGL(k_seq<8>, dim3(1), dim3(512), seq_lds, sm, g);
+        HIPCHK(c, hipGetLastError());
+        if (seq_prof) {
+            unsigned long long t[16];
+            HIPCHK(c, hipStreamSynchronize(sm));
+            HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
+            const double per = 0.01 / (double)(t[3] ? t[3] : 1);
+            fprintf(stderr, "[nhdfit] k_seq wave 0 per round: node load %.1f, NIC bits %.1f, mapping %.1f, commit %.1f, write-back %.1f us\n",
+                    t[5] * per, t[6] * per, t[7] * per, t[8] * per, t[9] * per);
+            fprintf(stderr, "[nhdfit] k_seq: %llu pods in %llu rounds; scan %.1f us, pick %.1f us, map+commit %.1f us, columns %.1f us per round\n", t[4], t[3],
+                    t[0] * per, t[2] * per, t[1] * per, t[10] * per);
+            fprintf(stderr, "[nhdfit] k_seq columns: evaluate %.1f, patch %.1f, fence %.1f, barrier %.1f us per round; %.1f (node, tile) pairs per round\n",
+                    t[11] * per, t[12] * per, t[13] * per, t[14] * per, (double)t[15] / (double)(t[3] ? t[3] : 1));
+        }
+        uint32_t counters[4] = {0, 0, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(counters, c->seq_counters.p, sizeof counters, hipMemcpyDeviceToHost, sm));
         HIPCHK(c, hipStreamSynchronize(sm));
-        HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
-        const double per = 0.01 / (double)(t[3] ? t[3] : 1);
-        fprintf(stderr, "[nhdfit] k_seq wave 0 per round: node load %.1f, NIC bits %.1f, mapping %.1f, commit %.1f, write-back %.1f us\n",
-                t[5] * per, t[6] * per, t[7] * per, t[8] * per, t[9] * per);
-        fprintf(stderr, "[nhdfit] k_seq: %llu pods in %llu rounds; scan %.1f us, pick %.1f us, map+commit %.1f us, columns %.1f us per round\n", t[4], t[3],
-                t[0] * per, t[2] * per, t[1] * per, t[10] * per);
-        fprintf(stderr, "[nhdfit] k_seq columns: evaluate %.1f, patch %.1f, fence %.1f, barrier %.1f us per round; %.1f (node, tile) pairs per round\n",
-                t[11] * per, t[12] * per, t[13] * per, t[14] * per, (double)t[15] / (double)(t[3] ? t[3] : 1));
+        done = counters[1];
+        return NHDFIT_OK;
+    };
+    auto undo_all = [&]() -> int {                              // every node this batch touched goes back to its first-touch copy
+        hipLaunchKernelGGL(k_undo, dim3(P), dim3(64), 0, sm, sa);
+        HIPCHK(c, hipGetLastError());
+        return NHDFIT_OK;
+    };
+
+    uint32_t decided = 0;                                       // pods [0, decided) of the caller's order are decided
+    bool fast = !c->seq_general && (size_t)chunks * 8 <= 64 * 1024 && c->n > 0;
+    if (fast) {
+        // Two chains (seq2_kernel.h): A = the pods without GPUs over the nodes without GPUs, B = the pods with GPUs.
+        c->list_host.resize(P);
+        uint32_t nA = 0, nB = 0;
+        for (uint32_t i = 0; i < P; ++i) {
+            uint32_t g = 0;
+            if (req_valid(reqs[i])) for (uint32_t k = 0; k < reqs[i].n_groups; ++k) g += reqs[i].gpus[k];
+            if (req_valid(reqs[i]) && g == 0) c->list_host[nA++] = i;
+        }
+        for (uint32_t i = 0; i < P; ++i) {
+            uint32_t g = 0;
+            if (req_valid(reqs[i])) for (uint32_t k = 0; k < reqs[i].n_groups; ++k) g += reqs[i].gpus[k];
+            if (!(req_valid(reqs[i]) && g == 0)) c->list_host[nA + nB++] = i;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->seq_list.p, c->list_host.data(), (size_t)P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
+        uint32_t flags[4] = {0, 0, 0, 0};
+        Seq2Args qa;
+        memset(&qa, 0, sizeof qa);
+        qa.s = sa; qa.assign = c->seq_assign.p; qa.flags = c->seq_flags.p;
+        if (nA) {
+            qa.list = c->seq_list.p; qa.n_list = nA;
+            size_t dyn = lds_slice((size_t)chunks * 8);
+            const size_t sig_bytes = lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4);
+            const size_t st_bytes = lds_slice((size_t)c->st_n * 8) + lds_slice((size_t)c->st_n * 32) + lds_slice(256 * 4);
+            if (dyn + sig_bytes <= 112 * 1024) { qa.lds_sigs = 1; dyn += sig_bytes; }
+            if (c->use_set_states && c->st_n && dyn + st_bytes <= 112 * 1024) { qa.lds_states = 1; dyn += st_bytes; }
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_chain_a, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            hipLaunchKernelGGL(k_chain_a, dim3(1), dim3(64 * kChainWaves), dyn, sm, qa);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(flags, c->seq_flags.p, sizeof flags, hipMemcpyDeviceToHost, sm));
+            HIPCHK(c, hipStreamSynchronize(sm));
+        }
+        bool redo = flags[1] != 0;                               // chain A met a NIC state without a signature: prefix protocol below
+        if (!redo && flags[0]) {
+            // leftovers: pods without GPUs that found no GPU-less node but have candidates among the GPU nodes.  They and
+            // chain B's pods go through the general kernel, in the caller's order.
+            c->seq_host.resize(P);
+            HIPCHK(c, hipMemcpy(c->seq_host.data(), c->seq_out.p, (size_t)P * sizeof(SeqResult), hipMemcpyDeviceToHost));
+            std::vector<uint32_t> rest;
+            for (uint32_t k = 0; k < nA; ++k) if (c->seq_host[c->list_host[k]].node == -2) rest.push_back(c->list_host[k]);
+            rest.insert(rest.end(), c->list_host.begin() + nA, c->list_host.begin() + nA + nB);
+            std::sort(rest.begin(), rest.end());
+            HIPCHK(c, hipMemcpyAsync(c->seq_assign.p, rest.data(), rest.size() * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
+            uint32_t done = 0;
+            if ((rc = run_general(c->seq_assign.p, (uint32_t)rest.size(), done))) return rc;
+            redo = done < rest.size();
+        } else if (!redo && nB) {
+            qa.list = c->seq_list.p + nA; qa.n_list = nB;
+            hipLaunchKernelGGL(k_pick_b<16>, dim3(1), dim3(1024), 0, sm, qa);
+            hipLaunchKernelGGL(k_commit_b, dim3((nB + kCommitWaves - 1) / kCommitWaves), dim3(64 * kCommitWaves), 0, sm, qa);
+            HIPCHK(c, hipGetLastError());
+        }
+        if (redo) {            // start over with the kernel whose stop / intern / resume protocol the caller knows
+            if ((rc = undo_all())) return rc;
+            if ((rc = reset_scan_state())) return rc;
+            fast = false;
+        } else decided = P;
     }
-    if (!apply) hipLaunchKernelGGL(k_undo, dim3(P), dim3(64), 0, sm, sa);
-    HIPCHK(c, hipGetLastError());
+    if (!fast) {
+        if ((rc = run_general(nullptr, 0, decided))) return rc;
+    }
+    if (!apply) { if ((rc = undo_all())) return rc; }
     c->seq_host.resize(P);
-    uint32_t counters[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(c->seq_host.data(), c->seq_out.p, P * sizeof(SeqResult), hipMemcpyDeviceToHost, sm));
-    HIPCHK(c, hipMemcpyAsync(counters, c->seq_counters.p, sizeof counters, hipMemcpyDeviceToHost, sm));
     if (place_out) HIPCHK(c, hipMemcpyAsync(place_out, c->seq_place.p, (size_t)P * sizeof(nhdfit_placement), hipMemcpyDeviceToHost, sm));
     rc = nhdfit_sync(c);
     if (rc) return rc;
-    *n_done = counters[1];
+    *n_done = decided;
     int64_t lo = -1, hi = -1;
-    for (uint32_t i = 0; i < counters[1]; ++i) {
+    for (uint32_t i = 0; i < decided; ++i) {
         const SeqResult& o = c->seq_host[i];
         node_out[i] = o.node;
         if (map_out) map_out[i] = o.map;

@@ -23,6 +23,7 @@ struct SeqArgs {
     uint32_t n, chunks; uint64_t global_base; double now;
     const nhdfit_req* reqs; const unsigned long long* score; uint32_t P;
     const uint32_t* order;           // caller's pod i -> staged (class-sorted) position
+    const uint32_t* list; uint32_t n_list;   // optional: the pods to decide (caller's indices, ascending) instead of all P
     const uint8_t* tabs; uint32_t pitch; const uint8_t* tile_wcls; Layout L[kWClasses];
     uint64_t* rows;                  // [chunks][P] verdict rows of the snapshot; kept current for the pods without GPUs
     uint64_t* taken;                 // [chunks] nodes that received a pod of this batch: busy, i.e. gone for every pod with GPUs
@@ -272,16 +273,18 @@ __global__ __launch_bounds__(64 * kSeqPods) void k_seq(SeqArgs a) {
         }
     };
     uint32_t i = 0;
+    const uint32_t n_pods = a.list ? a.n_list : a.P;
     unsigned long long t_find = 0, t_pick = 0, t_map = 0, n_rounds = 0, tick = a.prof ? wall_clock64() : 0;
     unsigned long long t_sub[5] = {0, 0, 0, 0, 0}, sub = 0, t_c[5] = {0, 0, 0, 0, 0};
     auto sublap = [&](int k) { if (a.prof && wave == 0) { const unsigned long long t = wall_clock64(); t_sub[k] += t - sub; sub = t; } };
     auto lap = [&](unsigned long long& acc) { if (a.prof) { const unsigned long long t = wall_clock64(); acc += t - tick; tick = t; } };
-    while (i < a.P) {
+    while (i < n_pods) {
         if (s_stop) break;
         // (1) wavefront w: pod i + w
-        const uint32_t mine = i + wave;
+        const uint32_t entry = i + wave;
+        const uint32_t mine = entry < n_pods ? (a.list ? a.list[entry] : entry) : 0u;
         int32_t have = -2;
-        if (mine < a.P) {
+        if (entry < n_pods) {
             have = 0;
             const uint32_t pos = order[mine];
             if (lane < sizeof(nhdfit_req) / 16) {

@@ -75,9 +75,13 @@ __global__ __launch_bounds__(256) void k_xkeys(RecArgs a) {
     const nhdfit_plane3 q3 = a.p3[i];
     for (uint32_t u = 0; u < 2; ++u) {
         const unsigned long long key = xkey(u, u ? n.f1 : n.f0, q3.sig_numa[u], q3.sig_pci[u]);
+        // a cluster has a few hundred distinct classes at most: all but the first insert of a class find it with a plain
+        // (L2-coherent) read and never issue the compare-and-swap - 131 072 CAS on ~100 words serialised in L2 before
         uint32_t s = xhash(key);
         for (uint32_t probes = 0; probes < kXSlots; ++probes, s = (s + 1) & (kXSlots - 1)) {
-            const unsigned long long prev = atomicCAS(&a.x.key[s], 0ull, key);
+            unsigned long long prev = __hip_atomic_load(&a.x.key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == key) break;
+            if (prev == 0ull) prev = atomicCAS(&a.x.key[s], 0ull, key);
             if (prev == 0ull || prev == key) break;
         }
     }

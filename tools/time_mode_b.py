@@ -12,8 +12,6 @@ n, P = int(sys.argv[1]) if len(sys.argv) > 1 else 65536, int(sys.argv[2]) if len
 cfg = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 spec = synth.make_cluster(cfg, n_nodes=n)
 pods, groups = synth.make_pods(cfg, n_pods=P)
-for p in pods:
-    p["misc_smt"] = True
 tops = [refmodel.make_topology(s) for s in pods]
 pk = pack.Packer(); table = planes.planes_from_spec(pk, spec); reqs = pk.digest_many(tops, groups)
 added = pk.close_signatures()
