@@ -1209,7 +1209,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
             HIPCHK(c, hipMemcpyAsync(flags, c->seq_flags.p, sizeof flags, hipMemcpyDeviceToHost, sm));
             HIPCHK(c, hipStreamSynchronize(sm));
         }
-        bool redo = flags[1] != 0;                               // chain A met a NIC state without a signature: prefix protocol below
+        bool redo = flags[1] != 0 || flags[3] != 0;              // chain A met a NIC state without a signature (prefix protocol below) / gave up
         if (!redo && flags[0]) {
             // leftovers: pods without GPUs that found no GPU-less node but have candidates among the GPU nodes.  They and
             // chain B's pods go through the general kernel, in the caller's order.

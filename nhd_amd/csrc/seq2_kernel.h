@@ -24,7 +24,8 @@ struct Seq2Args {
     const uint32_t* list;        // the chain's pods, caller's indices, ascending
     uint32_t n_list;
     uint32_t* assign;            // chain B: [n_list] local node index or ~0u
-    uint32_t* flags;             // [0] leftovers seen (chain A), [1] a commit met a NIC state without a signature, [2] chain A: pods decided
+    uint32_t* flags;             // [0] leftovers seen (chain A), [1] a commit met a NIC state without a signature, [2] chain A: pods decided,
+                                 // [3] chain A gave up waiting for a helper wavefront (never expected; the host starts over with k_seq)
     uint32_t lds_sigs, lds_states;   // chain A: stage the signature hash table / the set-state tables in LDS (they fit)
 };
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_chain_a(Seq2Args q) {
     __shared__ int32_t s_have[kChainRing];
     __shared__ uint32_t s_ready[kChainRing];                   // sequence number + 1 of the pod parked in the slot
     __shared__ uint32_t s_done;                                // pods the driver is through with
+    __shared__ uint32_t s_abort;                               // a wait ran out (never expected): every wavefront leaves, the host falls back
     __shared__ NodeState s_cst[kChainCache];                   // nodes this batch committed to, most recent kChainCache
     __shared__ nhdfit_detail s_cdet[kChainCache];
     __shared__ uint32_t s_ctag[kChainCache];
@@ -276,7 +278,8 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_chain_a(Seq2Args q) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tiles = (a.P + kTile - 1) / kTile;
     constexpr uint32_t kPatchers = kChainWaves - 1 - kChainFetchers;
-    if (tid == 0) { s_done = 0; s_patch_head = 0; s_ngl = 0; }
+    if (tid == 0) { s_done = 0; s_patch_head = 0; s_ngl = 0; s_abort = 0; }
+    constexpr uint32_t kSpinLimit = 1u << 22;                  // x ~100 cycles of s_sleep: a fraction of a second, then give up
     if (tid < kChainRing) s_ready[tid] = 0;
     if (tid < kChainCache) s_ctag[tid] = kNoNode;
     if (tid < kChainWaves) s_patch_tail[tid] = 0;
@@ -330,7 +333,10 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_chain_a(Seq2Args q) {
         // ---- fetchers: pod e goes to slot e % kChainRing once the driver is past pod e - kChainRing
         for (uint32_t e = wave - 1; e < q.n_list; e += kChainFetchers) {
             const uint32_t slot = e % kChainRing;
-            while (e >= lds_load(&s_done) + kChainRing) __builtin_amdgcn_s_sleep(2);
+            for (uint32_t spin = 0; e >= lds_load(&s_done) + kChainRing; ++spin) {
+                if (spin > kSpinLimit || lds_load(&s_abort)) return;
+                __builtin_amdgcn_s_sleep(2);
+            }
             const uint32_t pos = a.order[q.list[e]];
             if (lane < sizeof(nhdfit_req) / 16) {
                 const uint4 v = reinterpret_cast<const uint4*>(a.reqs + pos)[lane];
@@ -356,9 +362,10 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_chain_a(Seq2Args q) {
         const uint32_t me = wave - 1 - kChainFetchers;                    // 0 .. kPatchers-1: items me, me + kPatchers, ...
         const uint32_t p = lane & 15u, grp = lane >> 4;
         for (uint32_t item = me;; item += kPatchers) {
-            while (lds_load(&s_patch_head) <= item) {
+            for (uint32_t spin = 0; lds_load(&s_patch_head) <= item; ++spin) {
                 // the driver publishes its last item before it reports the last pod: done first, then the head once more
                 if (lds_load(&s_done) >= q.n_list && lds_load(&s_patch_head) <= item) return;
+                if (spin > 64u * kSpinLimit || lds_load(&s_abort)) return;
                 __builtin_amdgcn_s_sleep(4);
             }
             const PatchItem it = s_patch[item % kPatchRing];
@@ -392,7 +399,11 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_chain_a(Seq2Args q) {
     bool stop = false;
     for (uint32_t e = 0; e < q.n_list && !stop; ++e) {
         const uint32_t slot = e % kChainRing, mine = q.list[e];
-        while (lds_load(&s_ready[slot]) != e + 1) __builtin_amdgcn_s_sleep(1);
+        for (uint32_t spin = 0; lds_load(&s_ready[slot]) != e + 1 && !stop; ++spin) {
+            if (spin > kSpinLimit) { stop = true; if (lane == 0) { q.flags[3] = 1u; lds_store(&s_abort, 1u); } }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (stop) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const nhdfit_req& rq = s_req[slot].r;
         const uint32_t pos = s_pos[slot], tile = pos >> 6;
@@ -474,9 +485,10 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_chain_a(Seq2Args q) {
             // its columns, for the pods to come
             if (ngl) {
                 const uint32_t item = n_commit;
-                while (item >= kPatchRing) {                              // ring slot free once its previous item was copied out:
+                for (uint32_t spin = 0; item >= kPatchRing; ++spin) {     // ring slot free once its previous item was copied out:
                     const uint32_t old = item - kPatchRing;               // item x is consumed by patcher x % kPatchers, in order
                     if (lds_load(&s_patch_tail[1 + kChainFetchers + old % kPatchers]) > old) break;
+                    if (spin > kSpinLimit) { stop = true; if (lane == 0) { q.flags[3] = 1u; lds_store(&s_abort, 1u); } break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (lane == 0) {

@@ -25,6 +25,7 @@ container - against the unmodified reference's own loop.
 from __future__ import annotations
 
 import ctypes
+import os
 from types import SimpleNamespace
 from typing import List, Optional, Sequence
 
@@ -40,6 +41,12 @@ def _lib():
     global _proto_done
     L = coracle.lib()
     if not _proto_done:
+        # the scan hands out 256-node blocks in ascending order and stops at the first hit: a handful of threads is all it can
+        # use; a parallel region over every core of a 256-core host costs more to start than the scan itself
+        try:
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(min(16, os.cpu_count() or 1)))
+        except OSError:
+            pass
         L.oracle_first_feasible.restype = ctypes.c_int64
         L.oracle_first_feasible.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
         L.oracle_commit.restype = ctypes.c_int
