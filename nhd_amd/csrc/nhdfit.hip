@@ -183,7 +183,9 @@ struct nhdfit_ctx {
     DevBuf<FitItem> items; uint32_t n_items = 0;   // work items of the fit role (blocks), heaviest tiles first
     // argument blocks of the steady-state step launches, one per buffer set, resident in device memory (k_step_p)
     DevBuf<StepArgs> step_args; PinBuf<StepArgs> pin_step_args; bool step_args_valid[kBufs] = {};
-    bool args_by_pointer = tune_env("NHDFIT_ARGS_BY_VALUE") == nullptr;   // tuning aid: every launch by value
+    // measured (profiles/r03): no gain over the by-value launch - the scalar loads through the pointer cost what the
+    // kernarg fetch saved (236 spilled SGPRs against 19) - so by value is what ships; NHDFIT_ARGS_BY_POINTER=1 in the tuning build
+    bool args_by_pointer = tune_env("NHDFIT_ARGS_BY_POINTER") != nullptr;
     std::vector<uint8_t> h_tile_wcls;
     DevBuf<unsigned long long> shape_keys[kBufs]; DevBuf<uint32_t> shape_res[kBufs]; DevBuf<int32_t> shape_slot[kBufs];   // mapping dedup tables
     DevBuf<uint32_t> shape_list[kBufs];  // distinct shapes per tile
@@ -205,7 +207,7 @@ struct nhdfit_ctx {
     // mode B
     DevBuf<uint64_t> nogpu, taken, tile_masks; DevBuf<int32_t> touched; DevBuf<uint16_t> gl_tiles; std::vector<uint32_t> order_host; std::vector<SeqResult> seq_host; DevBuf<UndoRec> undo; DevBuf<SeqResult> seq_out; DevBuf<nhdfit_placement> seq_place;
     DevBuf<uint32_t> order, seq_counters;
-    DevBuf<uint32_t> seq_list, seq_assign, seq_flags; std::vector<uint32_t> list_host;   // two-chain form (seq2_kernel.h): chain A's pods, then chain B's
+    DevBuf<unsigned long long> seq_queue; DevBuf<uint32_t> seq_ctrl, seq_mat, seq_flags;   // decision-engine form of mode B (seq2_kernel.h)
     bool seq_general = tune_env("NHDFIT_SEQ_GENERAL") != nullptr;   // tuning aid: the one-block kernel for every batch
     DevBuf<uint64_t> sig_keys; DevBuf<uint32_t> sig_ids; uint32_t sig_mask = 0;   // canonical NIC-state key -> signature id (commit_core.h)
     bool use_cand = false, want_bitmap = true, want_map = true;
@@ -363,7 +365,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release();
     c->reqs.release(); c->bitmap.release(); c->nm.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->step_args.release(); c->pin_step_args.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); c->shape_list[b].release(); }
-    c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_list.release(); c->seq_assign.release(); c->seq_flags.release(); c->sig_keys.release(); c->sig_ids.release();
+    c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_queue.release(); c->seq_ctrl.release(); c->seq_mat.release(); c->seq_flags.release(); c->sig_keys.release(); c->sig_ids.release();
     for (int b = 0; b < kBufs; ++b) {
         c->hdr[b].release(); c->tabs[b].release(); c->score[b].release(); c->maps[b].release();
         if (c->ev_fit[b]) (void)hipEventDestroy(c->ev_fit[b]);
@@ -1101,8 +1103,9 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, c->seq_out.reserve(P));
         HIPCHK(c, c->seq_place.reserve(P));
         HIPCHK(c, c->order.reserve(P));
-        HIPCHK(c, c->seq_list.reserve(P));
-        HIPCHK(c, c->seq_assign.reserve(P));
+        HIPCHK(c, c->seq_queue.reserve(2 * (size_t)P));
+        HIPCHK(c, c->seq_ctrl.reserve(4));
+        HIPCHK(c, c->seq_mat.reserve(c->n ? c->n : 1));
         HIPCHK(c, c->seq_flags.reserve(4));
         c->order_host.resize(P);                              // caller's pod -> staged (class-sorted) position
         for (uint32_t i = 0; i < P; ++i) c->order_host[c->perm[i]] = i;
@@ -1176,60 +1179,30 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     };
 
     uint32_t decided = 0;                                       // pods [0, decided) of the caller's order are decided
-    bool fast = !c->seq_general && (size_t)chunks * 8 <= 64 * 1024 && c->n > 0;
+    bool fast = !c->seq_general && (size_t)chunks * 8 <= 64 * 1024 && c->n > 0 && P < (1u << 30);
     if (fast) {
-        // Two chains (seq2_kernel.h): A = the pods without GPUs over the nodes without GPUs, B = the pods with GPUs.
-        c->list_host.resize(P);
-        uint32_t nA = 0, nB = 0;
-        for (uint32_t i = 0; i < P; ++i) {
-            uint32_t g = 0;
-            if (req_valid(reqs[i])) for (uint32_t k = 0; k < reqs[i].n_groups; ++k) g += reqs[i].gpus[k];
-            if (req_valid(reqs[i]) && g == 0) c->list_host[nA++] = i;
-        }
-        for (uint32_t i = 0; i < P; ++i) {
-            uint32_t g = 0;
-            if (req_valid(reqs[i])) for (uint32_t k = 0; k < reqs[i].n_groups; ++k) g += reqs[i].gpus[k];
-            if (!(req_valid(reqs[i]) && g == 0)) c->list_host[nA + nB++] = i;
-        }
-        HIPCHK(c, hipMemcpyAsync(c->seq_list.p, c->list_host.data(), (size_t)P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
-        uint32_t flags[4] = {0, 0, 0, 0};
-        Seq2Args qa;
+        // The decision engine (seq2_kernel.h): one block decides, the rest of the grid commits.
+        HIPCHK(c, hipMemsetAsync(c->seq_queue.p, 0, 2 * (size_t)P * sizeof(unsigned long long), sm));
+        HIPCHK(c, hipMemsetAsync(c->seq_ctrl.p, 0, 4 * sizeof(uint32_t), sm));
+        HIPCHK(c, hipMemsetAsync(c->seq_mat.p, 0, (size_t)c->n * sizeof(uint32_t), sm));
+        DecideArgs qa;
         memset(&qa, 0, sizeof qa);
-        qa.s = sa; qa.assign = c->seq_assign.p; qa.flags = c->seq_flags.p;
-        if (nA) {
-            qa.list = c->seq_list.p; qa.n_list = nA;
-            size_t dyn = lds_slice((size_t)chunks * 8);
-            const size_t sig_bytes = lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4);
-            const size_t st_bytes = lds_slice((size_t)c->st_n * 8) + lds_slice((size_t)c->st_n * 32) + lds_slice(256 * 4);
-            if (dyn + sig_bytes <= 112 * 1024) { qa.lds_sigs = 1; dyn += sig_bytes; }
-            if (c->use_set_states && c->st_n && dyn + st_bytes <= 112 * 1024) { qa.lds_states = 1; dyn += st_bytes; }
-            HIPCHK(c, hipFuncSetAttribute((const void*)k_chain_a, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            hipLaunchKernelGGL(k_chain_a, dim3(1), dim3(64 * kChainWaves), dyn, sm, qa);
-            HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipMemcpyAsync(flags, c->seq_flags.p, sizeof flags, hipMemcpyDeviceToHost, sm));
-            HIPCHK(c, hipStreamSynchronize(sm));
-        }
-        bool redo = flags[1] != 0 || flags[3] != 0;              // chain A met a NIC state without a signature (prefix protocol below) / gave up
-        if (!redo && flags[0]) {
-            // leftovers: pods without GPUs that found no GPU-less node but have candidates among the GPU nodes.  They and
-            // chain B's pods go through the general kernel, in the caller's order.
-            c->seq_host.resize(P);
-            HIPCHK(c, hipMemcpy(c->seq_host.data(), c->seq_out.p, (size_t)P * sizeof(SeqResult), hipMemcpyDeviceToHost));
-            std::vector<uint32_t> rest;
-            for (uint32_t k = 0; k < nA; ++k) if (c->seq_host[c->list_host[k]].node == -2) rest.push_back(c->list_host[k]);
-            rest.insert(rest.end(), c->list_host.begin() + nA, c->list_host.begin() + nA + nB);
-            std::sort(rest.begin(), rest.end());
-            HIPCHK(c, hipMemcpyAsync(c->seq_assign.p, rest.data(), rest.size() * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
-            uint32_t done = 0;
-            if ((rc = run_general(c->seq_assign.p, (uint32_t)rest.size(), done))) return rc;
-            redo = done < rest.size();
-        } else if (!redo && nB) {
-            qa.list = c->seq_list.p + nA; qa.n_list = nB;
-            hipLaunchKernelGGL(k_pick_b<16>, dim3(1), dim3(1024), 0, sm, qa);
-            hipLaunchKernelGGL(k_commit_b, dim3((nB + kCommitWaves - 1) / kCommitWaves), dim3(64 * kCommitWaves), 0, sm, qa);
-            HIPCHK(c, hipGetLastError());
-        }
-        if (redo) {            // start over with the kernel whose stop / intern / resume protocol the caller knows
+        qa.s = sa; qa.queue = c->seq_queue.p; qa.ctrl = c->seq_ctrl.p; qa.mat = c->seq_mat.p; qa.flags = c->seq_flags.p;
+        size_t dyn = lds_slice((size_t)chunks * 8);
+        const size_t sig_bytes = lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4);
+        const size_t st_bytes = lds_slice((size_t)c->st_n * 8) + lds_slice((size_t)c->st_n * 32) + lds_slice(256 * 4);
+        if (dyn + sig_bytes <= 96 * 1024) { qa.lds_sigs = 1; dyn += sig_bytes; }
+        if (c->use_set_states && c->st_n && dyn + st_bytes <= 96 * 1024) { qa.lds_states = 1; dyn += st_bytes; }
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_decide, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+        static const uint32_t workers = tune_env("NHDFIT_SEQ_WORKERS") ? (uint32_t)atoi(tune_env("NHDFIT_SEQ_WORKERS")) : (uint32_t)kWorkerBlocks;   // tuning aid
+        hipLaunchKernelGGL(k_decide, dim3(1 + (workers ? workers : 1u)), dim3(64 * kDecideWaves), dyn, sm, qa);
+        HIPCHK(c, hipGetLastError());
+        uint32_t flags[4] = {0, 0, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(flags, c->seq_flags.p, sizeof flags, hipMemcpyDeviceToHost, sm));
+        HIPCHK(c, hipStreamSynchronize(sm));
+        if (flags[1] || flags[3]) {
+            // a NIC state without a signature id (or a wait that ran out): start over with the kernel whose stop / intern /
+            // resume protocol the caller knows
             if ((rc = undo_all())) return rc;
             if ((rc = reset_scan_state())) return rc;
             fast = false;
