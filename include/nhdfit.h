@@ -211,6 +211,10 @@ typedef struct {
     uint64_t evals_last;        /* pod x node evaluations of the last step                                      */
     uint64_t bytes_last;        /* algorithmic bytes of the last fit role                 */
     uint32_t nodes, nsig, ncls, lds_bytes;
+    uint32_t pipes;             /* step launches in flight at a time: the pipelined form alternates its steps between this many
+                                   independent pipelines on as many streams - a launch's HIP-event duration then overlaps its
+                                   neighbour's, and throughput is pipes x (work per launch) / duration                          */
+    uint32_t reserved;
 } nhdfit_stats;
 
 typedef struct nhdfit_ctx nhdfit_ctx;

@@ -125,15 +125,34 @@ constexpr int kEventRing = 256;
 constexpr int kBufs = 8;          // buffer sets: step s owns set s % kBufs from its digest (one launch before its fit)
                                   // to the end of its mapping (four launches after it, five when sharded)
 
+constexpr int kPipes = 2;
+struct Pipe {                            // one software pipeline of steps: its stream, its buffer sets, how far each phase got
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_fit[kBufs] = {}, ev_red[kBufs] = {};   // stream <-> s_red hand-over (sharded runs only)
+    hipEvent_t ev_staged = nullptr;      // pipe 0 records it behind what it staged (requests, work items, node records); pipe 1 waits for it
+    uint64_t n_dig = 0, n_fit = 0, n_shaped = 0, n_chosen = 0, n_finished = 0;   // steps (since the last stage_requests) whose phase was launched
+    DevBuf<PodHeader> hdr[kBufs]; DevBuf<uint8_t> tabs[kBufs];
+    DevBuf<unsigned long long> score[kBufs]; DevBuf<nhdfit_mapping> maps[kBufs];
+    DevBuf<uint64_t> nm;                 // node-major verdict words [tiles][chunks*64] (one buffer per pipe: its fit roles run in stream order)
+    DevBuf<unsigned long long> shape_keys[kBufs]; DevBuf<uint32_t> shape_res[kBufs]; DevBuf<int32_t> shape_slot[kBufs];   // mapping dedup tables
+    DevBuf<uint32_t> shape_list[kBufs];  // distinct shapes per tile
+};
+
 }  // namespace
 
 struct nhdfit_ctx {
     int dev = -1;
-    hipStream_t stream = nullptr;        // the step launches, in order
+    // Two pipes: the pipelined form (stage, enqueue, enqueue, ...) alternates its steps between two independent software
+    // pipelines on two streams, so that one step's launch gap, table staging and tail are covered by the other step's
+    // blocks (measured: 23 -> 17 us per step, profiles/r03).  Everything else - single finds, mode B, uploads, deltas -
+    // runs on pipe 0, whose stream is `stream`; whatever changes the mirror waits for both (sync_all).
+    Pipe pipe[kPipes];
+    hipStream_t stream = nullptr;        // = pipe[0].stream: uploads, deltas, commits, mode B, single finds
     hipStream_t s_red = nullptr;         // the all-reduce of sharded runs, overlapping the next step launch
-    hipEvent_t ev_fit[kBufs] = {}, ev_red[kBufs] = {};   // stream <-> s_red hand-over (sharded runs only)
-    // software pipeline: number of steps (since the last stage_requests) whose phase has been launched
-    uint64_t n_dig = 0, n_fit = 0, n_shaped = 0, n_chosen = 0, n_finished = 0;
+    bool dual = tune_env("NHDFIT_ONE_PIPE") == nullptr;   // tuning aid: NHDFIT_ONE_PIPE=1 keeps every step on pipe 0
+    uint64_t n_enq = 0;                  // steps enqueued since the last stage_requests (step k runs on pipe k % 2)
+    int last_pipe = 0;                   // the pipe of the most recent step (nhdfit_fetch reads its results)
+    bool staged_dirty = false;           // pipe 0's stream carries staging work pipe 1 has not waited for yet
     bool geom_big = true;                // 512-thread step blocks (256 for small problems)
     uint32_t digest_parts = tune_env("NHDFIT_DIGEST_PARTS") ? (uint32_t)atoi(tune_env("NHDFIT_DIGEST_PARTS")) : 2;   // tuning aid
     uint32_t side_prio = tune_env("NHDFIT_SIDE_PRIO") ? (uint32_t)atoi(tune_env("NHDFIT_SIDE_PRIO")) : 1;   // tuning aid
@@ -174,21 +193,11 @@ struct nhdfit_ctx {
     std::vector<uint32_t> perm;          // device (class-sorted) position -> caller's pod index
     PinBuf<nhdfit_req> pin_reqs; PinBuf<uint8_t> pin_wcls; PinBuf<uint64_t> pin_score; PinBuf<nhdfit_mapping> pin_maps;   // host staging of one call
     PinBuf<uint8_t> pin_items;           // the fit role's work items on their way to the device
-    DevBuf<PodHeader> hdr[kBufs]; DevBuf<uint8_t> tabs[kBufs];
-    DevBuf<unsigned long long> score[kBufs]; DevBuf<nhdfit_mapping> maps[kBufs];
-    DevBuf<uint64_t> nm;                 // node-major verdict words [tiles][chunks*64] (one buffer: the fit roles of consecutive steps run in stream order)
     DevBuf<uint64_t> bitmap;             // pod-major rows [chunks][P], converted from `nm` on demand (fetch, mode B)
     DevBuf<uint64_t> cand;               // [chunks] candidate nodes of the call
     DevBuf<uint8_t> tile_wcls;           // row width class per staged tile
     DevBuf<FitItem> items; uint32_t n_items = 0;   // work items of the fit role (blocks), heaviest tiles first
-    // argument blocks of the steady-state step launches, one per buffer set, resident in device memory (k_step_p)
-    DevBuf<StepArgs> step_args; PinBuf<StepArgs> pin_step_args; bool step_args_valid[kBufs] = {};
-    // measured (profiles/r03): no gain over the by-value launch - the scalar loads through the pointer cost what the
-    // kernarg fetch saved (236 spilled SGPRs against 19) - so by value is what ships; NHDFIT_ARGS_BY_POINTER=1 in the tuning build
-    bool args_by_pointer = tune_env("NHDFIT_ARGS_BY_POINTER") != nullptr;
     std::vector<uint8_t> h_tile_wcls;
-    DevBuf<unsigned long long> shape_keys[kBufs]; DevBuf<uint32_t> shape_res[kBufs]; DevBuf<int32_t> shape_slot[kBufs];   // mapping dedup tables
-    DevBuf<uint32_t> shape_list[kBufs];  // distinct shapes per tile
     DevBuf<AscEntry> asc;                // layouts of ascending-filled CPython sets (static table, built at creation)
     DevBuf<uint8_t> choose_tab;          // choose_tuples tabulated for U = 2, G <= 2 (static table, built at creation)
     // node records (fit_core.h NodeRec) + the class table behind their X rows; [rec_lo, rec_hi) = nodes whose records
@@ -262,7 +271,7 @@ int refresh_layouts(nhdfit_ctx* c);
 
 int sync_all(nhdfit_ctx* c) {
     { int rc_ = flush_pipeline(c); if (rc_) return rc_; }      // pending mapping phases of the last steps
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (Pipe& p : c->pipe) HIPCHK(c, hipStreamSynchronize(p.stream));
     HIPCHK(c, hipStreamSynchronize(c->s_red));
     return NHDFIT_OK;
 }
@@ -306,12 +315,16 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
         delete c;
         return rc;
     }
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_red, hipStreamNonBlocking);
-    for (int b = 0; b < kBufs && e == hipSuccess; ++b) {
-        e = hipEventCreateWithFlags(&c->ev_fit[b], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_red[b], hipEventDisableTiming);
+    e = hipStreamCreateWithFlags(&c->s_red, hipStreamNonBlocking);
+    for (Pipe& p : c->pipe) {
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p.ev_staged, hipEventDisableTiming);
+        for (int b = 0; b < kBufs && e == hipSuccess; ++b) {
+            e = hipEventCreateWithFlags(&p.ev_fit[b], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&p.ev_red[b], hipEventDisableTiming);
+        }
     }
+    c->stream = c->pipe[0].stream;
     for (auto& q : c->ev)
         for (auto& x : q)
             if (e == hipSuccess) e = hipEventCreate(&x);
@@ -363,18 +376,22 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->origin.release(); c->deltas.release(); c->delta_run.release(); c->delta_status.release();
     c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release();
-    c->reqs.release(); c->bitmap.release(); c->nm.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->step_args.release(); c->pin_step_args.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
-    for (int b = 0; b < kBufs; ++b) { c->shape_keys[b].release(); c->shape_res[b].release(); c->shape_slot[b].release(); c->shape_list[b].release(); }
+    c->reqs.release(); c->bitmap.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_queue.release(); c->seq_ctrl.release(); c->seq_mat.release(); c->seq_flags.release(); c->sig_keys.release(); c->sig_ids.release();
-    for (int b = 0; b < kBufs; ++b) {
-        c->hdr[b].release(); c->tabs[b].release(); c->score[b].release(); c->maps[b].release();
-        if (c->ev_fit[b]) (void)hipEventDestroy(c->ev_fit[b]);
-        if (c->ev_red[b]) (void)hipEventDestroy(c->ev_red[b]);
+    for (Pipe& p : c->pipe) {
+        p.nm.release();
+        for (int b = 0; b < kBufs; ++b) {
+            p.hdr[b].release(); p.tabs[b].release(); p.score[b].release(); p.maps[b].release();
+            p.shape_keys[b].release(); p.shape_res[b].release(); p.shape_slot[b].release(); p.shape_list[b].release();
+            if (p.ev_fit[b]) (void)hipEventDestroy(p.ev_fit[b]);
+            if (p.ev_red[b]) (void)hipEventDestroy(p.ev_red[b]);
+        }
+        if (p.ev_staged) (void)hipEventDestroy(p.ev_staged);
+        if (p.stream) (void)hipStreamDestroy(p.stream);
     }
     for (auto& q : c->ev)
         for (auto& x : q)
             if (x) (void)hipEventDestroy(x);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->s_red) (void)hipStreamDestroy(c->s_red);
     delete c;
 }
@@ -475,10 +492,6 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_step_p<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_step_p<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_step_p<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_step_p<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return NHDFIT_OK;
 }
 
@@ -569,7 +582,8 @@ int refresh_layouts(nhdfit_ctx* c) {
     c->x_spill = spill;
     if (c->P) {
         const uint32_t tiles = (c->P + kTile - 1) / kTile;
-        for (int b = 0; b < kBufs; ++b) HIPCHK(c, c->tabs[b].reserve((size_t)tiles * pitch));
+        for (Pipe& p : c->pipe)
+            for (int b = 0; b < kBufs; ++b) HIPCHK(c, p.tabs[b].reserve((size_t)tiles * pitch));
     }
     return NHDFIT_OK;
 }
@@ -582,7 +596,10 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     HIPCHK(c, hipSetDevice(c->dev));
     { int rc_ = sync_all(c); if (rc_) return rc_; }
     { int rc_ = drain_events(c); if (rc_) return rc_; }
-    c->n_dig = c->n_fit = c->n_shaped = c->n_chosen = c->n_finished = 0;
+    for (Pipe& p : c->pipe) p.n_dig = p.n_fit = p.n_shaped = p.n_chosen = p.n_finished = 0;
+    c->n_enq = 0;
+    c->last_pipe = 0;
+    c->staged_dirty = true;
     const uint32_t tiles = (P + kTile - 1) / kTile;
     int32_t hp_max = 0;
     for (uint32_t p = 0; p < P; ++p) {
@@ -592,11 +609,12 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     if (hp_max > kMaxHpRows - 2)
         return fail(c, NHDFIT_E_LIMIT, "a pod asks for %d GiB of hugepages (limit %d)", hp_max, kMaxHpRows - 2);
     HIPCHK(c, c->reqs.reserve(P));
-    for (int b = 0; b < kBufs; ++b) {
-        HIPCHK(c, c->hdr[b].reserve((size_t)tiles * kTile));
-        HIPCHK(c, c->score[b].reserve(P));
-        HIPCHK(c, c->maps[b].reserve(P));
-    }
+    for (Pipe& p : c->pipe)
+        for (int b = 0; b < kBufs; ++b) {
+            HIPCHK(c, p.hdr[b].reserve((size_t)tiles * kTile));
+            HIPCHK(c, p.score[b].reserve(P));
+            HIPCHK(c, p.maps[b].reserve(P));
+        }
     // Pods are staged sorted by request class so that 64-pod tiles are homogeneous (narrow table rows, fast sweep of
     // the fit role) and the lanes of the mapping roles have similar group counts; results are un-permuted in fetch.
     c->perm.resize(P);
@@ -654,6 +672,7 @@ namespace {
 // tile images by the class count).  A grown class count or a changed dictionary re-does every record.
 int ensure_records(nhdfit_ctx* c) {
     if (!c->rec_all && c->rec_lo == c->rec_hi) return NHDFIT_OK;
+    c->staged_dirty = true;                                     // (its kernels run on pipe 0's stream)
     if (!c->n) { c->rec_all = false; c->rec_lo = c->rec_hi = 0; return NHDFIT_OK; }
     const uint32_t npad = (c->n + 63) & ~63u;
     for (int pass = 0; pass < 2; ++pass) {
@@ -687,7 +706,7 @@ int ensure_records(nhdfit_ctx* c) {
         { int rc_ = sync_all(c); if (rc_) return rc_; }
         c->x_cap = x_capacity(nx[0]);
         c->rec_all = true;
-        c->n_dig = c->n_fit;
+        for (Pipe& p : c->pipe) p.n_dig = p.n_fit;              // every staged table image is redone
         int rc = refresh_layouts(c);
         if (rc) return rc;
     }
@@ -741,18 +760,26 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
     memcpy(c->pin_items.p, items.data(), items.size() * sizeof(FitItem));
     HIPCHK(c, hipMemcpyAsync(c->items.p, c->pin_items.p, items.size() * sizeof(FitItem), hipMemcpyHostToDevice, c->stream));
     c->n_items = (uint32_t)items.size();
+    c->staged_dirty = true;
     return NHDFIT_OK;
 }
 
 // One launch of the step kernel with every role that has work (see k_step).  `with_fit`: the fit role for step
 // n_fit plus the digest of step n_fit + 1; `flushing`: nothing new will follow, drain the mapping phases.
-int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool flushing) {
+int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double now, bool flushing) {
     const uint32_t P = c->P, tiles = (P + kTile - 1) / kTile;
     const uint32_t chunks = (c->n + 63) / 64;
     const bool big = c->geom_big;
     const uint32_t block = big ? 512 : 256, nw = block / 64;
     const bool small_map = c->want_map && c->n_big_pods < P;
     if (with_fit || with_digest) { int rc_ = ensure_records(c); if (rc_) return rc_; }
+    if (with_fit && !c->n_items) { int rc_ = build_items(c, nw); if (rc_) return rc_; }
+    if (&p != &c->pipe[0] && c->staged_dirty) {
+        // what pipe 0's stream staged since this pipe last looked (requests, work items, node records) is in front of this launch
+        HIPCHK(c, hipEventRecord(c->pipe[0].ev_staged, c->pipe[0].stream));
+        HIPCHK(c, hipStreamWaitEvent(p.stream, c->pipe[0].ev_staged, 0));
+        c->staged_dirty = false;
+    }
 
     StepArgs a;
     memset(&a, 0, sizeof a);
@@ -762,26 +789,26 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         MapArgs m;
         memset(&m, 0, sizeof m);
         m.p0 = c->p0.p; m.p1 = c->p1.p; m.p2 = c->p2.p; m.p3 = c->p3.p; m.det = c->det.p;
-        m.tabs = c->tabs[b].p; m.pitch = c->pitch; m.tile_wcls = c->tile_wcls.p;
+        m.tabs = p.tabs[b].p; m.pitch = c->pitch; m.tile_wcls = c->tile_wcls.p;
         for (int w = 0; w < kWClasses; ++w) m.L[w] = cold_view(c->L[w]);
         m.n = c->n; m.global_base = c->global_base; m.reqs = c->reqs.p; m.P = P;
-        m.score = c->score[b].p; m.caps = c->caps.p; m.out = c->maps[b].p;
+        m.score = p.score[b].p; m.caps = c->caps.p; m.out = p.maps[b].p;
         return m;
     };
     auto shape_args = [&](int b) {
-        return ShapeArgs{c->shape_keys[b].p, c->shape_res[b].p, c->shape_slot[b].p, c->shape_list[b].p, c->asc.p,
+        return ShapeArgs{p.shape_keys[b].p, p.shape_res[b].p, p.shape_slot[b].p, p.shape_list[b].p, c->asc.p,
                          c->use_choose_tab ? c->choose_tab.p : nullptr,
                          c->use_set_states ? SetStates{c->st_info.p, c->st_next.p, c->st_asc.p, c->st_n} : SetStates{nullptr, nullptr, nullptr, 0}};
     };
     // mapping phases of earlier steps: each advances by at most one step per launch
     bool did_shapes = false, did_choose = false, did_finish = false;
     if (small_map) {
-        if (c->n_finished < c->n_chosen) {
-            const int b = (int)(c->n_finished % kBufs);
+        if (p.n_finished < p.n_chosen) {
+            const int b = (int)(p.n_finished % kBufs);
             a.finish_m = map_args(b); a.finish_h = shape_args(b); a.nb_finish = (P + block / 4 - 1) / (block / 4); did_finish = true;
         }
-        if (c->n_chosen < c->n_shaped) {
-            a.choose = shape_args((int)(c->n_chosen % kBufs));
+        if (p.n_chosen < p.n_shaped) {
+            a.choose = shape_args((int)(p.n_chosen % kBufs));
             // wavefront = tile, lane = shape (NHDFIT_CHOOSE_LANES=0: a wavefront per shape, 16 x the blocks - tuning aid)
             static const bool lanes_off = tune_env("NHDFIT_CHOOSE_LANES") && atoi(tune_env("NHDFIT_CHOOSE_LANES")) == 0;
             const bool lanes = !lanes_off;
@@ -790,25 +817,25 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         }
         // scores of step s are final once its fit launch (and, sharded, its all-reduce) is done; sharded runs give
         // the all-reduce one launch of slack so that it overlaps the next fit instead of stalling the stream
-        const uint64_t ready = c->comm && !flushing && c->n_fit ? c->n_fit - 1 : c->n_fit;
-        if (c->n_shaped < ready) {
-            const int b = (int)(c->n_shaped % kBufs);
-            if (c->comm) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_red[b], 0));
-            HIPCHK(c, c->shape_keys[b].reserve((size_t)tiles * kTile));
-            HIPCHK(c, c->shape_res[b].reserve((size_t)tiles * kTile));
-            HIPCHK(c, c->shape_slot[b].reserve(P));
-            HIPCHK(c, c->shape_list[b].reserve(tiles));
+        const uint64_t ready = c->comm && !flushing && p.n_fit ? p.n_fit - 1 : p.n_fit;
+        if (p.n_shaped < ready) {
+            const int b = (int)(p.n_shaped % kBufs);
+            if (c->comm) HIPCHK(c, hipStreamWaitEvent(p.stream, p.ev_red[b], 0));
+            HIPCHK(c, p.shape_keys[b].reserve((size_t)tiles * kTile));
+            HIPCHK(c, p.shape_res[b].reserve((size_t)tiles * kTile));
+            HIPCHK(c, p.shape_slot[b].reserve(P));
+            HIPCHK(c, p.shape_list[b].reserve(tiles));
             a.shapes_m = map_args(b); a.shapes_h = shape_args(b); a.nb_shapes = (P + block / 4 - 1) / (block / 4); did_shapes = true;
         }
     }
-    with_digest = with_digest && c->n_dig <= c->n_fit + (with_fit ? 1 : 0) + (c->split ? 1 : 0);   // at most one step ahead of the fit
+    with_digest = with_digest && p.n_dig <= p.n_fit + (with_fit ? 1 : 0) + (c->split ? 1 : 0);   // at most one step ahead of the fit
     if (with_digest) {
-        const int b = (int)(c->n_dig % kBufs);                              // the next undigested step
+        const int b = (int)(p.n_dig % kBufs);                              // the next undigested step
         DigestArgs& d = a.digest;
         d.reqs = c->reqs.p; d.P = P;
         d.d = DictView{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}, c->sig_flat.p, c->flat_words};
         for (int w = 0; w < kWClasses; ++w) d.L[w] = c->L[w];
-        d.pitch = c->pitch; d.tabs = c->tabs[b].p; d.hdr = c->hdr[b].p; d.score = c->score[b].p;
+        d.pitch = c->pitch; d.tabs = p.tabs[b].p; d.hdr = p.hdr[b].p; d.score = p.score[b].p;
         d.xcls = c->xcls.p; d.nx = c->xnx.p;
         static const uint32_t wc_parts = tune_env("NHDFIT_WC_PARTS") && atoi(tune_env("NHDFIT_WC_PARTS")) >= 1 ? (uint32_t)atoi(tune_env("NHDFIT_WC_PARTS")) : kWcPartsDefault;   // tuning aid
         d.wc_parts = wc_parts;
@@ -817,9 +844,8 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
     uint32_t nb_fit = 0;
     int bf = -1;
     if (with_fit) {
-        bf = (int)(c->n_fit % kBufs);
-        if (c->want_bitmap) HIPCHK(c, c->nm.reserve((size_t)tiles * chunks * 64));
-        if (!c->n_items) { int rc_ = build_items(c, nw); if (rc_) return rc_; }
+        bf = (int)(p.n_fit % kBufs);
+        if (c->want_bitmap) HIPCHK(c, p.nm.reserve((size_t)tiles * chunks * 64));
         FitArgs& f = a.fit;
         for (int w = 0; w < kWClasses; ++w) {
             f.rec[w] = c->rec[w].p; f.off_hot[w] = c->L[w].off_hot; f.hot_bytes[w] = c->L[w].hot_bytes; f.hot_hp[w] = c->L[w].hot_hp; f.hot_staged[w] = c->hot_staged[w];
@@ -827,10 +853,10 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         f.hp_last = c->hp_rows - 1; f.hp_bytes = align16(c->hp_rows * 8);
         f.p4 = c->p4.p;
         f.n = c->n; f.chunks = chunks; f.global_base = c->global_base; f.busy_from = busy_threshold(now);
-        f.tabs = c->tabs[bf].p; f.pitch = c->pitch; f.hdr = c->hdr[bf].p; f.P = P;
+        f.tabs = p.tabs[bf].p; f.pitch = c->pitch; f.hdr = p.hdr[bf].p; f.P = P;
         f.cand = c->use_cand ? c->cand.p : nullptr;
-        f.nm = c->want_bitmap ? c->nm.p : nullptr;
-        f.score = c->score[bf].p;
+        f.nm = c->want_bitmap ? p.nm.p : nullptr;
+        f.score = p.score[bf].p;
         f.items = c->items.p;
         f.dbg_skip = tune_env("NHDFIT_FIT_SKIP") ? (uint32_t)atoi(tune_env("NHDFIT_FIT_SKIP")) : 0;
         nb_fit = c->n_items;
@@ -845,74 +871,43 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
     if ((a.nb_shapes || a.nb_finish) && map_lds > lds) lds = map_lds;
 
     // HIP-event timing is sampled (every 8th fit launch; every digest-only launch)
-    if (with_fit && (int64_t)c->n_fit == c->role_step) {
+    if (with_fit && (int64_t)p.n_fit == c->role_step) {
         HIPCHK(c, c->role_clock.reserve(10));
         unsigned long long init[10];
         for (int k = 0; k < 5; ++k) { init[2 * k] = ~0ull; init[2 * k + 1] = 0; }
-        HIPCHK(c, hipMemcpyAsync(c->role_clock.p, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->role_clock.p, init, sizeof init, hipMemcpyHostToDevice, p.stream));
+        HIPCHK(c, hipStreamSynchronize(p.stream));
         a.role_clock = c->role_clock.p;
     }
-    const bool timed = (with_fit && (c->n_fit < 2 || (c->n_fit & 7) == 0)) || (!with_fit && with_digest);
+    const bool timed = (with_fit && (p.n_fit < 2 || (p.n_fit & 7) == 0)) || (!with_fit && with_digest);
     if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc) return rc; }
-    if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][0], c->stream));
-    // Pipelined step (fit + the next digest; in the steady state every role): the block of buffer set bf lives in device memory.
-    // It is compared with the host copy of what is there (the busy threshold travels in the launch itself) and re-sent only
-    // when something changed - staging, uploads, a grown class table; the copy is stream-ordered in front of the launch.
-    const StepArgs* dev_args = nullptr;
-    if (c->args_by_pointer && with_fit && a.nb_digest && !a.role_clock && !c->role_kernels && !c->split) {
-        HIPCHK(c, c->step_args.reserve(kBufs));
-        HIPCHK(c, c->pin_step_args.reserve(kBufs));
-        const double busy_from = a.fit.busy_from;
-        a.fit.busy_from = 0.0;
-        StepArgs& held = c->pin_step_args.p[bf];
-        if (!c->step_args_valid[bf] || memcmp(&held, &a, sizeof a) != 0) {
-            // the pinned copy may still be the source of an earlier copy in flight: that copy was enqueued kBufs launches ago
-            // at the latest only if the stream ran that far - wait for it (rare path)
-            if (c->step_args_valid[bf]) HIPCHK(c, hipStreamSynchronize(c->stream));
-            memcpy(&held, &a, sizeof a);
-            HIPCHK(c, hipMemcpyAsync(c->step_args.p + bf, &held, sizeof a, hipMemcpyHostToDevice, c->stream));
-            c->step_args_valid[bf] = true;
-        }
-        a.fit.busy_from = busy_from;
-        dev_args = c->step_args.p + bf;
-    }
-    if (dev_args) {
-        const double busy_from = a.fit.busy_from;
-        if (c->x_spill) {
-            if (big) hipLaunchKernelGGL((k_step_p<512, true>), dim3(grid), dim3(512), lds, c->stream, dev_args, busy_from);
-            else     hipLaunchKernelGGL((k_step_p<256, true>), dim3(grid), dim3(256), lds, c->stream, dev_args, busy_from);
-        } else {
-            if (big) hipLaunchKernelGGL((k_step_p<512>), dim3(grid), dim3(512), lds, c->stream, dev_args, busy_from);
-            else     hipLaunchKernelGGL((k_step_p<256>), dim3(grid), dim3(256), lds, c->stream, dev_args, busy_from);
-        }
-    } else
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][0], p.stream));
     if (c->x_spill) {               // more node classes than LDS rows: the variant whose fit role reads the rest from global memory
-        if (big) hipLaunchKernelGGL((k_step<512, true>), dim3(grid), dim3(512), lds, c->stream, a);
-        else     hipLaunchKernelGGL((k_step<256, true>), dim3(grid), dim3(256), lds, c->stream, a);
+        if (big) hipLaunchKernelGGL((k_step<512, true>), dim3(grid), dim3(512), lds, p.stream, a);
+        else     hipLaunchKernelGGL((k_step<256, true>), dim3(grid), dim3(256), lds, p.stream, a);
     } else
     if (c->role_kernels) {
         const uint32_t nb[5] = {a.nb_choose, a.nb_shapes, a.nb_finish, a.nb_digest, nb_fit};
-        if (nb[0]) hipLaunchKernelGGL((k_role<512, 0>), dim3(nb[0]), dim3(512), 0, c->stream, a);
-        if (nb[1]) hipLaunchKernelGGL((k_role<512, 1>), dim3(nb[1]), dim3(512), map_lds_bytes<512>(), c->stream, a);
-        if (nb[2]) hipLaunchKernelGGL((k_role<512, 2>), dim3(nb[2]), dim3(512), map_lds_bytes<512>(), c->stream, a);
-        if (nb[3]) hipLaunchKernelGGL((k_role<512, 3>), dim3(nb[3]), dim3(512), kDigestLds, c->stream, a);
-        if (nb[4]) hipLaunchKernelGGL((k_role<512, 4>), dim3(nb[4]), dim3(512), lds, c->stream, a);
+        if (nb[0]) hipLaunchKernelGGL((k_role<512, 0>), dim3(nb[0]), dim3(512), 0, p.stream, a);
+        if (nb[1]) hipLaunchKernelGGL((k_role<512, 1>), dim3(nb[1]), dim3(512), map_lds_bytes<512>(), p.stream, a);
+        if (nb[2]) hipLaunchKernelGGL((k_role<512, 2>), dim3(nb[2]), dim3(512), map_lds_bytes<512>(), p.stream, a);
+        if (nb[3]) hipLaunchKernelGGL((k_role<512, 3>), dim3(nb[3]), dim3(512), kDigestLds, p.stream, a);
+        if (nb[4]) hipLaunchKernelGGL((k_role<512, 4>), dim3(nb[4]), dim3(512), lds, p.stream, a);
     } else
     if (grid == nb_fit && c->split) {
-        if (big) hipLaunchKernelGGL((k_fit_only<512>), dim3(grid), dim3(512), lds, c->stream, a.fit);
-        else     hipLaunchKernelGGL((k_fit_only<256>), dim3(grid), dim3(256), lds, c->stream, a.fit);
+        if (big) hipLaunchKernelGGL((k_fit_only<512>), dim3(grid), dim3(512), lds, p.stream, a.fit);
+        else     hipLaunchKernelGGL((k_fit_only<256>), dim3(grid), dim3(256), lds, p.stream, a.fit);
     } else
-    if (big) hipLaunchKernelGGL((k_step<512>), dim3(grid), dim3(512), lds, c->stream, a);
-    else     hipLaunchKernelGGL((k_step<256>), dim3(grid), dim3(256), lds, c->stream, a);
+    if (big) hipLaunchKernelGGL((k_step<512>), dim3(grid), dim3(512), lds, p.stream, a);
+    else     hipLaunchKernelGGL((k_step<256>), dim3(grid), dim3(256), lds, p.stream, a);
     HIPCHK(c, hipGetLastError());
     if (timed) {
-        HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
+        HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][1], p.stream));
         c->ev_kind[c->ev_pending++] = with_fit ? 0 : 1;
     }
     if (a.role_clock) {
         unsigned long long t[10];
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(p.stream));
         HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
         unsigned long long first = ~0ull;
         for (int k = 0; k < 5; ++k) first = t[2 * k] < first ? t[2 * k] : first;
@@ -921,14 +916,14 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
             if (t[2 * k + 1]) fprintf(stderr, "[nhdfit] step %lld role %-6s: first block starts +%.2f us, last block ends +%.2f us\n",
                                       (long long)c->role_step, names[k], (t[2 * k] - first) * 0.01, (t[2 * k + 1] - first) * 0.01);
     }
-    c->n_finished += did_finish; c->n_chosen += did_choose; c->n_shaped += did_shapes;
-    if (with_digest) c->n_dig++;
+    p.n_finished += did_finish; p.n_chosen += did_choose; p.n_shaped += did_shapes;
+    if (with_digest) p.n_dig++;
     if (with_fit) {
-        hipStream_t after = c->stream;           // where the scores of this step become final
+        hipStream_t after = p.stream;           // where the scores of this step become final
         if (c->comm) {      // one communicator -> its collectives stay on one stream (s_red), in step order
-            HIPCHK(c, hipEventRecord(c->ev_fit[bf], c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->s_red, c->ev_fit[bf], 0));
-            ncclResult_t r = g_rccl.AllReduce(c->score[bf].p, c->score[bf].p, P, ncclUint64, ncclMax, c->comm, c->s_red);
+            HIPCHK(c, hipEventRecord(p.ev_fit[bf], p.stream));
+            HIPCHK(c, hipStreamWaitEvent(c->s_red, p.ev_fit[bf], 0));
+            ncclResult_t r = g_rccl.AllReduce(p.score[bf].p, p.score[bf].p, P, ncclUint64, ncclMax, c->comm, c->s_red);
             if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
             after = c->s_red;
         }
@@ -937,10 +932,10 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
             hipLaunchKernelGGL(k_map<true>, mg, mb, 0, after, map_args(bf));
             HIPCHK(c, hipGetLastError());
         }
-        if (c->comm) HIPCHK(c, hipEventRecord(c->ev_red[bf], c->s_red));
-        c->n_fit++;
+        if (c->comm) HIPCHK(c, hipEventRecord(p.ev_red[bf], c->s_red));
+        p.n_fit++;
         // no mapping roles for this step (output switched off, or only 4-group pods): nothing to catch up on later
-        if (!small_map) c->n_shaped = c->n_chosen = c->n_finished = c->n_fit;
+        if (!small_map) p.n_shaped = p.n_chosen = p.n_finished = p.n_fit;
         c->stats.evals_last = (uint64_t)P * c->n;
         // algorithmic bytes of the step, SURVEY.md section 8(d): ceil(P/T) * N * B_node + P * B_req + P * N / 8 + 8 * P
         // with T = 64 pods per tile, B_node = 24 (the 16-byte node record + the 8-byte busy time every tile streams),
@@ -948,26 +943,28 @@ int launch_step(nhdfit_ctx* c, bool with_fit, bool with_digest, double now, bool
         c->stats.bytes_last = (uint64_t)tiles * c->n * 24ull + (uint64_t)P * sizeof(nhdfit_req) +
                               (c->want_bitmap ? (uint64_t)tiles * chunks * 64ull * 8ull : 0ull) + (uint64_t)P * 8ull;
         c->stats.nodes = c->n; c->stats.nsig = c->nsig; c->stats.ncls = c->ncls; c->stats.lds_bytes = c->lds_bytes;
+        c->stats.pipes = c->dual && !c->split && !c->role_kernels ? (uint32_t)kPipes : 1u;
     }
     return NHDFIT_OK;
 }
 
 // pod-major rows [chunks][P] of the last step's verdict matrix (stream-ordered after the step that produced it)
-int convert_rows(nhdfit_ctx* c) {
+int convert_rows(nhdfit_ctx* c, Pipe& p) {
     const uint32_t chunks = (c->n + 63) / 64, tiles = (c->P + kTile - 1) / kTile;
     HIPCHK(c, c->bitmap.reserve((size_t)chunks * c->P));
-    hipLaunchKernelGGL(k_rows, dim3((tiles * chunks + 3) / 4), dim3(256), 0, c->stream, c->nm.p, c->bitmap.p, chunks, c->P);
+    hipLaunchKernelGGL(k_rows, dim3((tiles * chunks + 3) / 4), dim3(256), 0, p.stream, p.nm.p, c->bitmap.p, chunks, c->P);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(p.stream));
     return NHDFIT_OK;
 }
 
 int flush_pipeline(nhdfit_ctx* c) {
     if (!c->P || !c->want_map || c->n_big_pods >= c->P) return NHDFIT_OK;
-    while (c->n_finished < c->n_fit) {
-        int rc = launch_step(c, false, false, 0.0, true);
-        if (rc) return rc;
-    }
+    for (Pipe& p : c->pipe)
+        while (p.n_finished < p.n_fit) {
+            int rc = launch_step(c, p, false, false, 0.0, true);
+            if (rc) return rc;
+        }
     return NHDFIT_OK;
 }
 
@@ -978,7 +975,7 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     if (!c->P) return fail(c, NHDFIT_E_STATE, "stage requests first");
     if (!c->n) return fail(c, NHDFIT_E_STATE, "no nodes uploaded");
     HIPCHK(c, hipSetDevice(c->dev));
-    if (c->n_fit == 0) {
+    if (c->n_enq == 0) {
         // 512-thread blocks (8 waves; 3 co-resident blocks per CU at 70 VGPRs: one block's LDS fill overlaps the
         // others' sweep), 256-thread blocks for small problems so that the grid still covers the chip
         const uint32_t tiles = (c->P + kTile - 1) / kTile, chunks = (c->n + 63) / 64;
@@ -986,16 +983,22 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
         if (const char* b = tune_env("NHDFIT_BLOCK")) c->geom_big = atoi(b) >= 512;      // tuning aid
         if (c->role_kernels) c->geom_big = true;
     }
-    if (c->n_dig <= c->n_fit) {                      // first step after staging: its digest has not run yet
-        int rc = launch_step(c, false, true, now, false);
+    // step k of a staged batch runs on pipe k % 2 (sharded runs too: the all-reduces of both pipes go to the one reduce
+    // stream in step order, the same order on every rank); the profiling forms stay on pipe 0
+    const int which = c->dual && !c->split && !c->role_kernels ? (int)(c->n_enq % kPipes) : 0;
+    Pipe& p = c->pipe[which];
+    c->n_enq++;
+    c->last_pipe = which;
+    if (p.n_dig <= p.n_fit) {                        // this pipe's first step after staging: its digest has not run yet
+        int rc = launch_step(c, p, false, true, now, false);
         if (rc) return rc;
     }
     if (c->split) {                                  // profiling aid: side roles and fit role as two launches
-        int rc = launch_step(c, false, true, now, false);
+        int rc = launch_step(c, p, false, true, now, false);
         if (rc) return rc;
-        return launch_step(c, true, false, now, false);
+        return launch_step(c, p, true, false, now, false);
     }
-    return launch_step(c, true, true, now, false);
+    return launch_step(c, p, true, true, now, false);
 }
 
 int nhdfit_sync(nhdfit_ctx* c) {
@@ -1007,21 +1010,22 @@ int nhdfit_sync(nhdfit_ctx* c) {
 
 int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out) {
     if (!c) return NHDFIT_E_INVAL;
-    if (!c->P || !c->n_fit) return fail(c, NHDFIT_E_STATE, "nothing staged / no step enqueued");
+    Pipe& p = c->pipe[c->last_pipe];
+    if (!c->P || !p.n_fit) return fail(c, NHDFIT_E_STATE, "nothing staged / no step enqueued");
     HIPCHK(c, hipSetDevice(c->dev));
     if (map_out && !c->want_map) return fail(c, NHDFIT_E_STATE, "mapping output is disabled");
     const uint32_t P = c->P;
-    const int b = (int)((c->n_fit - 1) % kBufs);               // results of the most recent step
+    const int b = (int)((p.n_fit - 1) % kBufs);               // results of the most recent step
     // the launches that finish the mappings still in flight, the copies behind them on the same stream, ONE wait
     { int rc_ = flush_pipeline(c); if (rc_) return rc_; }
     if (c->comm) HIPCHK(c, hipStreamSynchronize(c->s_red));
     if (score_out) {
         HIPCHK(c, c->pin_score.reserve(P));
-        HIPCHK(c, hipMemcpyAsync(c->pin_score.p, c->score[b].p, (size_t)P * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->pin_score.p, p.score[b].p, (size_t)P * 8, hipMemcpyDeviceToHost, p.stream));
     }
     if (map_out) {
         HIPCHK(c, c->pin_maps.reserve(P));
-        HIPCHK(c, hipMemcpyAsync(c->pin_maps.p, c->maps[b].p, (size_t)P * sizeof(nhdfit_mapping), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->pin_maps.p, p.maps[b].p, (size_t)P * sizeof(nhdfit_mapping), hipMemcpyDeviceToHost, p.stream));
     }
     int rc = nhdfit_sync(c);
     if (rc) return rc;
@@ -1032,7 +1036,7 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
     if (bitmap_out) {
         if (!c->want_bitmap) return fail(c, NHDFIT_E_STATE, "bitmap output is disabled");
         const size_t chunks = (c->n + 63) / 64;
-        { int rc_ = convert_rows(c); if (rc_) return rc_; }
+        { int rc_ = convert_rows(c, p); if (rc_) return rc_; }
         std::vector<uint64_t> tmp(chunks * P);
         HIPCHK(c, hipMemcpy(tmp.data(), c->bitmap.p, chunks * P * 8, hipMemcpyDeviceToHost));
         for (size_t ch = 0; ch < chunks; ++ch)
@@ -1080,6 +1084,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     if (!std::isfinite(now)) return fail(c, NHDFIT_E_INVAL, "now must be finite (a placed node is busy at `now`)");
     HIPCHK(c, hipSetDevice(c->dev));
     hipStream_t sm = c->stream;
+    Pipe& p = c->pipe[0];                                       // (the one step a freshly staged batch enqueues runs on pipe 0)
     const uint32_t chunks = (c->n + 63) / 64;
     const uint32_t tiles = (P + kTile - 1) / kTile;
     int rc;
@@ -1104,20 +1109,20 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, c->seq_place.reserve(P));
         HIPCHK(c, c->order.reserve(P));
         HIPCHK(c, c->seq_queue.reserve(2 * (size_t)P));
-        HIPCHK(c, c->seq_ctrl.reserve(4));
+        HIPCHK(c, c->seq_ctrl.reserve(16));
         HIPCHK(c, c->seq_mat.reserve(c->n ? c->n : 1));
         HIPCHK(c, c->seq_flags.reserve(4));
         c->order_host.resize(P);                              // caller's pod -> staged (class-sorted) position
         for (uint32_t i = 0; i < P; ++i) c->order_host[c->perm[i]] = i;
         HIPCHK(c, hipMemcpyAsync(c->order.p, c->order_host.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
         hipLaunchKernelGGL(k_nogpu, dim3(chunks), dim3(64), 0, sm, c->p2.p, c->n, c->nogpu.p);
-        const int b0 = (int)((c->n_fit - 1) % kBufs);
-        hipLaunchKernelGGL(k_tile_masks, dim3(tiles), dim3(64), 0, sm, c->hdr[b0].p, tiles, c->tile_masks.p);
+        const int b0 = (int)((p.n_fit - 1) % kBufs);
+        hipLaunchKernelGGL(k_tile_masks, dim3(tiles), dim3(64), 0, sm, p.hdr[b0].p, tiles, c->tile_masks.p);
         HIPCHK(c, hipGetLastError());
     }
     // pod-major verdict rows of the snapshot + empty taken / first-touch state (again before a fallback pass)
     auto reset_scan_state = [&]() -> int {
-        int rc_ = convert_rows(c);
+        int rc_ = convert_rows(c, p);
         if (rc_) return rc_;
         HIPCHK(c, hipMemsetAsync(c->taken.p, 0, (size_t)(chunks ? chunks : 1) * sizeof(uint64_t), sm));
         HIPCHK(c, hipMemsetAsync(c->touched.p, 0xFF, (size_t)c->n * sizeof(int32_t), sm));
@@ -1126,13 +1131,13 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         return NHDFIT_OK;
     };
     if ((rc = reset_scan_state())) return rc;
-    const int b = (int)((c->n_fit - 1) % kBufs);
+    const int b = (int)((p.n_fit - 1) % kBufs);
     SeqArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.p0 = c->p0.p; sa.p1 = c->p1.p; sa.p2 = c->p2.p; sa.p3 = c->p3.p; sa.p4 = c->p4.p; sa.det = c->det.p;
     sa.n = c->n; sa.chunks = chunks; sa.global_base = c->global_base; sa.now = now;
-    sa.reqs = c->reqs.p; sa.score = c->score[b].p; sa.P = P; sa.order = c->order.p;
-    sa.tabs = c->tabs[b].p; sa.pitch = c->pitch; sa.tile_wcls = c->tile_wcls.p;
+    sa.reqs = c->reqs.p; sa.score = p.score[b].p; sa.P = P; sa.order = c->order.p;
+    sa.tabs = p.tabs[b].p; sa.pitch = c->pitch; sa.tile_wcls = c->tile_wcls.p;
     for (int w = 0; w < kWClasses; ++w) sa.L[w] = c->L[w];
     sa.rows = c->bitmap.p; sa.taken = c->taken.p; sa.nogpu = c->nogpu.p; sa.tile_masks = c->tile_masks.p;
     sa.caps = c->caps.p; sa.sigs = sig_table(c); sa.fc_dim = c->max_cores + 1; sa.fg_dim = c->max_gpus + 1; sa.ngs = c->ngs;
@@ -1183,7 +1188,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     if (fast) {
         // The decision engine (seq2_kernel.h): one block decides, the rest of the grid commits.
         HIPCHK(c, hipMemsetAsync(c->seq_queue.p, 0, 2 * (size_t)P * sizeof(unsigned long long), sm));
-        HIPCHK(c, hipMemsetAsync(c->seq_ctrl.p, 0, 4 * sizeof(uint32_t), sm));
+        HIPCHK(c, hipMemsetAsync(c->seq_ctrl.p, 0, 16 * sizeof(uint32_t), sm));
         HIPCHK(c, hipMemsetAsync(c->seq_mat.p, 0, (size_t)c->n * sizeof(uint32_t), sm));
         DecideArgs qa;
         memset(&qa, 0, sizeof qa);
@@ -1200,6 +1205,12 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         uint32_t flags[4] = {0, 0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(flags, c->seq_flags.p, sizeof flags, hipMemcpyDeviceToHost, sm));
         HIPCHK(c, hipStreamSynchronize(sm));
+        if (tune_env("NHDFIT_SEQ_PROF")) {
+            uint32_t ctl[16];
+            HIPCHK(c, hipMemcpy(ctl, c->seq_ctrl.p, sizeof ctl, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[nhdfit] k_decide: %u queue items; GPU-less pods: %u verifications failed, %u looked at a node in LDS, %u at a published one, "
+                            "%u at an untouched one, %u window rescans\n", ctl[1] ? ctl[1] - 1 : 0, ctl[4], ctl[8], ctl[5], ctl[6], ctl[7]);
+        }
         if (flags[1] || flags[3]) {
             // a NIC state without a signature id (or a wait that ran out): start over with the kernel whose stop / intern /
             // resume protocol the caller knows
@@ -1469,12 +1480,13 @@ int nhdfit_group_find(nhdfit_group* g, const nhdfit_req* reqs, uint32_t P, doubl
         ncclResult_t r = g_rccl.GroupStart();
         for (size_t k = 0; k < n && r == ncclSuccess; ++k) {
             nhdfit_ctx* c = g->ctx[k];
+            Pipe& p = c->pipe[0];                                        // (a freshly staged batch's one step runs on pipe 0)
             if (hipSetDevice(c->dev) != hipSuccess) { r = ncclSystemError; break; }
-            const int b = c->n_fit ? (int)((c->n_fit - 1) % kBufs) : 0;
+            const int b = p.n_fit ? (int)((p.n_fit - 1) % kBufs) : 0;
             if (!c->n) {                                                 // a shard without nodes contributes "no feasible node"
-                if (c->score[b].reserve(P) != hipSuccess || hipMemsetAsync(c->score[b].p, 0, (size_t)P * 8, c->stream) != hipSuccess) { r = ncclSystemError; break; }
+                if (p.score[b].reserve(P) != hipSuccess || hipMemsetAsync(p.score[b].p, 0, (size_t)P * 8, c->stream) != hipSuccess) { r = ncclSystemError; break; }
             }
-            r = g_rccl.AllReduce(c->score[b].p, c->score[b].p, P, ncclUint64, ncclMax, g->comm[k], c->stream);
+            r = g_rccl.AllReduce(p.score[b].p, p.score[b].p, P, ncclUint64, ncclMax, g->comm[k], c->stream);
         }
         ncclResult_t r2 = g_rccl.GroupEnd();
         if (r != ncclSuccess || r2 != ncclSuccess) { g->err = std::string("ncclAllReduce (group): ") + g_rccl.GetErrorString(r != ncclSuccess ? r : r2); return NHDFIT_E_RCCL; }
@@ -1484,18 +1496,20 @@ int nhdfit_group_find(nhdfit_group* g, const nhdfit_req* reqs, uint32_t P, doubl
         for (size_t k = 0; k < n; ++k) {
             nhdfit_ctx* c = g->ctx[k];
             if (!c->n) continue;
+            Pipe& p = c->pipe[0];
             HIPCHK(c, hipSetDevice(c->dev));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            const int b = (int)((c->n_fit - 1) % kBufs);
-            HIPCHK(c, hipMemcpy(tmp.data(), c->score[b].p, (size_t)P * 8, hipMemcpyDeviceToHost));
+            const int b = (int)((p.n_fit - 1) % kBufs);
+            HIPCHK(c, hipMemcpy(tmp.data(), p.score[b].p, (size_t)P * 8, hipMemcpyDeviceToHost));
             for (uint32_t i = 0; i < P; ++i) best[i] = std::max(best[i], tmp[i]);
         }
         for (size_t k = 0; k < n; ++k) {
             nhdfit_ctx* c = g->ctx[k];
             if (!c->n) continue;
+            Pipe& p = c->pipe[0];
             HIPCHK(c, hipSetDevice(c->dev));
-            const int b = (int)((c->n_fit - 1) % kBufs);
-            HIPCHK(c, hipMemcpy(c->score[b].p, best.data(), (size_t)P * 8, hipMemcpyHostToDevice));
+            const int b = (int)((p.n_fit - 1) % kBufs);
+            HIPCHK(c, hipMemcpy(p.score[b].p, best.data(), (size_t)P * 8, hipMemcpyHostToDevice));
         }
     }
     // mapping roles per device (each maps the winners it owns), then collect

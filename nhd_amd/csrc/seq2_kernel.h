@@ -123,7 +123,9 @@ __device__ __forceinline__ void patch_columns(const SeqArgs& a, uint32_t v, cons
     }
 }
 
-constexpr int kDecideWaves = 16, kDecideRing = 32, kDecideCache = 16, kWorkerBlocks = 12;
+constexpr int kDecideWaves = 16, kDecideRing = 32, kDecideCache = 16, kWorkerBlocks = 8;
+constexpr uint32_t kHintDistance = 4;     // a GPU-less pod's window is read at most this many pods ahead of the driver: the column patches
+                                          // of the commits before it have mostly landed by then (every stale bit costs a failed verification)
 constexpr uint32_t kSpinLimit = 1u << 22;                      // x ~100 cycles of s_sleep: a fraction of a second, then give up
 
 __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
@@ -327,6 +329,11 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             int32_t have = 0;
             uint32_t wb = 0;
             const unsigned long long score_a = a.score[pos];
+            if (!wants_gpu && score_a)
+                for (uint32_t spin = 0; e > wg_load(&s_done) + kHintDistance; ++spin) {
+                    if (spin > kSpinLimit || wg_load(&s_abort)) return;
+                    __builtin_amdgcn_s_sleep(1);
+                }
             if (score_a) {
                 const int64_t from = (int64_t)(NHDFIT_SCORE_INDEX(score_a) - a.global_base);
                 const uint32_t mode = wants_gpu ? 3u : (score_a >> 63) ? 1u : 2u;
@@ -343,6 +350,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     // ---- the driver ------------------------------------------------------------------------------------------------------
     __builtin_amdgcn_s_setprio(3);
     uint32_t n_items = 0, cache_next = 0;
+    uint32_t c_fail = 0, c_wait = 0, c_plain = 0, c_rescan = 0, c_hit = 0;     // tuning aid: what the GPU-less pods cost (ctrl[4..8])
     bool stop = false;
     auto give_up = [&]() { stop = true; if (lane == 0) { q.flags[3] = 1u; wg_store(&s_abort, 1u); } };
     auto push = [&](unsigned long long item) {                            // one 8-byte store: the entry itself is the signal
@@ -393,6 +401,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 const uint64_t w = s_win[slot][lane];
                 const uint64_t any = __ballot(w != 0);
                 if (!any) {                                               // window exhausted: the next one, then the next pass
+                    ++c_rescan;
                     const uint32_t nb = wbase + 64;
                     if (nb < a.chunks && scan_window(slot, pos, (uint32_t)pass, nb, 0, wbase)) continue;
                     if (pass == 1) { pass = 4; have = scan_window(slot, pos, 4, 0, 0, wbase) ? 2 : 0; continue; }
@@ -412,9 +421,10 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     const uint64_t hit = __ballot(lane < (uint32_t)kDecideCache && s_ctag[lane] == v);
                     if (hit) cidx = __builtin_ctzll(hit);
                 }
-                if (cidx >= 0) { st = &s_cst[cidx]; dd = &s_cdet[cidx]; }
+                if (cidx >= 0) { st = &s_cst[cidx]; dd = &s_cdet[cidx]; ++c_hit; }
                 else {
                     if (taken) {
+                        ++c_wait;
                         uint32_t m = 0;
                         for (uint32_t spin = 0; (m = dev_load(&q.mat[v])) < 2u && !stop; ++spin) {
                             if (spin > kSpinLimit) give_up();
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                         if (m == 3u) stop = true;                         // poisoned: a NIC state without a signature (reported by the committer)
                         if (stop) break;
                         load_node_lds_coherent(a, v, st, dd, lane);
-                    } else load_node_lds(a, v, st, dd, lane);
+                    } else { load_node_lds(a, v, st, dd, lane); ++c_plain; }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -439,6 +449,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 int32_t status = 0;
                 const bool ok = map_commit(rq, *st, *dd, pos, mine, v, true, sigs, mt, s_wres[0], s_wplace[0], status);
                 if (!ok) {                                                // stale hint: not this node (any more)
+                    ++c_fail;
                     if (lane == (uint32_t)l) s_win[slot][lane] = w & ~(1ull << (v & 63));
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -464,6 +475,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         if (lane == 0) wg_store(&s_done, e + 1);
     }
     if (lane == 0) {
+        q.ctrl[4] = c_fail; q.ctrl[5] = c_wait; q.ctrl[6] = c_plain; q.ctrl[7] = c_rescan; q.ctrl[8] = c_hit;
         wg_store(&s_done, n_pods);                                        // the fetchers run out
         __hip_atomic_store(&q.ctrl[1], n_items + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the workers leave once the queue is drained
     }

@@ -157,21 +157,12 @@ __device__ __forceinline__ void step_body(const StepArgs& a, const double busy_f
     stamp(a.role_clock, 3, t0);
 }
 
-// The step launch, argument block by value (irregular launches: the first step after staging, a single find, the pipeline
-// flush) ...
+// The step launch.  (The ~3 KB argument block travels by value: a device-resident copy behind a pointer was measured in
+// round 3 - no gain, the scalar loads through the pointer cost what the kernarg fetch saved: 236 spilled SGPRs against 19.)
 template <int BLOCK, bool SPILL = false>
 __global__ __launch_bounds__(BLOCK, SPILL ? (BLOCK == 512 ? 4 : 5) : (BLOCK == 512 ? 6 : 7)) void k_step(StepArgs a) {   // SPILL: two blocks per CU (LDS)   // 512 threads = 2 waves per SIMD: 3 blocks per CU either way
     extern __shared__ __align__(16) uint8_t lds[];
     step_body<BLOCK, SPILL>(a, a.fit.busy_from, lds);
-}
-// ... and by pointer: in the steady state of the pipeline the ~3 KB block repeats with the period of the buffer sets and
-// lives in device memory (launch_step keeps one copy per buffer set); the launch then carries 16 bytes - the pointer and
-// the one field that changes with every step, the busy threshold.  A by-value block of this size is copied by the runtime
-// into host-coherent kernarg memory and fetched from there by every block's scalar loads: ~5 us per step.
-template <int BLOCK, bool SPILL = false>
-__global__ __launch_bounds__(BLOCK, SPILL ? (BLOCK == 512 ? 4 : 5) : (BLOCK == 512 ? 6 : 7)) void k_step_p(const StepArgs* __restrict__ a, double busy_from) {
-    extern __shared__ __align__(16) uint8_t lds[];
-    step_body<BLOCK, SPILL>(*a, busy_from, lds);
 }
 
 // Profiling aid (NHDFIT_ROLE_KERNELS=1): one role per launch, so that rocprofv3 --stats names each role's stand-alone time.

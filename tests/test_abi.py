@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header():
     # sizes asserted on the C side by the struct comments; here: numpy mirrors
     assert pack.REQ.itemsize == 128 and pack.DETAIL.itemsize == 128 and pack.MAPPING.itemsize == 20 and pack.PLACEMENT.itemsize == 256
-    assert ctypes.sizeof(_lib.Stats) == 72
+    assert ctypes.sizeof(_lib.Stats) == 80
 
 
 def test_create_without_gpu_fails_loudly():

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class _Stats:
-    fit_ms_total, launches, bytes_last, digest_ms_last, step_ms_last, nsig, lds_bytes = 1.0, 1, 1000, 0.1, 0.2, 1, 1
+    fit_ms_total, launches, bytes_last, digest_ms_last, step_ms_last, nsig, lds_bytes, pipes = 1.0, 1, 1000, 0.1, 0.2, 1, 1, 2
 
 
 class DryEngine(harness.HarnessEngine):
