@@ -47,8 +47,8 @@ CLOCK_HZ = 2.4e9
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--config", type=int, default=4, help="BASELINE config whose cluster/pod mix is generated")
     ap.add_argument("--nodes-per-gpu", type=int, default=65536)
     ap.add_argument("--total-nodes", type=int, default=0, help="strong scaling: fixed cluster size, shards of total/N nodes")

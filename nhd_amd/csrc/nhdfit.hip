@@ -216,7 +216,7 @@ struct nhdfit_ctx {
     // mode B
     DevBuf<uint64_t> nogpu, taken, tile_masks; DevBuf<int32_t> touched; DevBuf<uint16_t> gl_tiles; std::vector<uint32_t> order_host; std::vector<SeqResult> seq_host; DevBuf<UndoRec> undo; DevBuf<SeqResult> seq_out; DevBuf<nhdfit_placement> seq_place;
     DevBuf<uint32_t> order, seq_counters;
-    DevBuf<unsigned long long> seq_queue; DevBuf<uint32_t> seq_ctrl, seq_mat, seq_flags;   // decision-engine form of mode B (seq2_kernel.h)
+    DevBuf<unsigned long long> seq_queue; DevBuf<uint32_t> seq_ctrl, seq_mat, seq_flags, seq_tn; std::vector<uint32_t> tn_host;   // decision-engine form of mode B (seq2_kernel.h)
     bool seq_general = tune_env("NHDFIT_SEQ_GENERAL") != nullptr;   // tuning aid: the one-block kernel for every batch
     DevBuf<uint64_t> sig_keys; DevBuf<uint32_t> sig_ids; uint32_t sig_mask = 0;   // canonical NIC-state key -> signature id (commit_core.h)
     bool use_cand = false, want_bitmap = true, want_map = true;
@@ -377,7 +377,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release();
     c->reqs.release(); c->bitmap.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
-    c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_queue.release(); c->seq_ctrl.release(); c->seq_mat.release(); c->seq_flags.release(); c->sig_keys.release(); c->sig_ids.release();
+    c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_queue.release(); c->seq_ctrl.release(); c->seq_mat.release(); c->seq_flags.release(); c->seq_tn.release(); c->sig_keys.release(); c->sig_ids.release();
     for (Pipe& p : c->pipe) {
         p.nm.release();
         for (int b = 0; b < kBufs; ++b) {
@@ -1112,6 +1112,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, c->seq_ctrl.reserve(16));
         HIPCHK(c, c->seq_mat.reserve(c->n ? c->n : 1));
         HIPCHK(c, c->seq_flags.reserve(4));
+        HIPCHK(c, c->seq_tn.reserve(P));
         c->order_host.resize(P);                              // caller's pod -> staged (class-sorted) position
         for (uint32_t i = 0; i < P; ++i) c->order_host[c->perm[i]] = i;
         HIPCHK(c, hipMemcpyAsync(c->order.p, c->order_host.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
@@ -1190,15 +1191,26 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, hipMemsetAsync(c->seq_queue.p, 0, 2 * (size_t)P * sizeof(unsigned long long), sm));
         HIPCHK(c, hipMemsetAsync(c->seq_ctrl.p, 0, 16 * sizeof(uint32_t), sm));
         HIPCHK(c, hipMemsetAsync(c->seq_mat.p, 0, (size_t)c->n * sizeof(uint32_t), sm));
+        c->tn_host.resize(P);
+        uint32_t n_tn = 0;
+        for (uint32_t i = 0; i < P; ++i) {                      // pods without GPUs before pod i (the fetchers pace their hints by it)
+            c->tn_host[i] = n_tn;
+            uint32_t g = 0;
+            if (req_valid(reqs[i])) for (uint32_t k = 0; k < reqs[i].n_groups; ++k) g += reqs[i].gpus[k];
+            if (req_valid(reqs[i]) && g == 0) ++n_tn;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->seq_tn.p, c->tn_host.data(), (size_t)P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
         DecideArgs qa;
         memset(&qa, 0, sizeof qa);
+        qa.tn_before = c->seq_tn.p;
         qa.s = sa; qa.queue = c->seq_queue.p; qa.ctrl = c->seq_ctrl.p; qa.mat = c->seq_mat.p; qa.flags = c->seq_flags.p;
         size_t dyn = lds_slice((size_t)chunks * 8);
         const size_t sig_bytes = lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4);
         const size_t st_bytes = lds_slice((size_t)c->st_n * 8) + lds_slice((size_t)c->st_n * 32) + lds_slice(256 * 4);
         if (dyn + sig_bytes <= 96 * 1024) { qa.lds_sigs = 1; dyn += sig_bytes; }
         if (c->use_set_states && c->st_n && dyn + st_bytes <= 96 * 1024) { qa.lds_states = 1; dyn += st_bytes; }
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_decide, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+        if (c->use_choose_tab && dyn + lds_slice(kChooseEntries) <= 112 * 1024) { qa.lds_choose = 1; dyn += lds_slice(kChooseEntries); }
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_decide, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
         static const uint32_t workers = tune_env("NHDFIT_SEQ_WORKERS") ? (uint32_t)atoi(tune_env("NHDFIT_SEQ_WORKERS")) : (uint32_t)kWorkerBlocks;   // tuning aid
         hipLaunchKernelGGL(k_decide, dim3(1 + (workers ? workers : 1u)), dim3(64 * kDecideWaves), dyn, sm, qa);
         HIPCHK(c, hipGetLastError());
@@ -1210,6 +1222,8 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
             HIPCHK(c, hipMemcpy(ctl, c->seq_ctrl.p, sizeof ctl, hipMemcpyDeviceToHost));
             fprintf(stderr, "[nhdfit] k_decide: %u queue items; GPU-less pods: %u verifications failed, %u looked at a node in LDS, %u at a published one, "
                             "%u at an untouched one, %u window rescans\n", ctl[1] ? ctl[1] - 1 : 0, ctl[4], ctl[8], ctl[5], ctl[6], ctl[7]);
+            fprintf(stderr, "[nhdfit] k_decide driver: waiting for fetchers %.2f ms, pods with GPUs %.2f ms, GPU-less pods: node state %.2f ms, verify + commit %.2f ms, "
+                            "publish %.2f ms\n", ctl[9] * 1e-5, ctl[10] * 1e-5, ctl[11] * 1e-5, ctl[12] * 1e-5, ctl[13] * 1e-5);
         }
         if (flags[1] || flags[3]) {
             // a NIC state without a signature id (or a wait that ran out): start over with the kernel whose stop / intern /

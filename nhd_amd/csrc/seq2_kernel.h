@@ -29,7 +29,8 @@ struct DecideArgs {
     uint32_t* ctrl;              // [0] tickets handed out to workers, [1] 1 + items pushed, once the driver is through
     uint32_t* mat;               // [n] 0 = as the snapshot left it / commit pending, 2 = committed state in global memory, 3 = poisoned
     uint32_t* flags;             // [1] a commit met a NIC state without a signature, [3] a wait ran out (never expected)
-    uint32_t lds_sigs, lds_states;   // block 0: stage the signature hash table / the set-state tables in LDS (they fit)
+    uint32_t lds_sigs, lds_states, lds_choose;   // block 0: stage the signature hash table / the set-state tables / the G <= 2 choose table in LDS (they fit)
+    const uint32_t* tn_before;   // [P] caller's pod i: how many pods without GPUs come before it
 };
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 constexpr unsigned long long kItemValid = 1ull << 63, kItemPatch = 1ull << 62;
@@ -123,9 +124,144 @@ __device__ __forceinline__ void patch_columns(const SeqArgs& a, uint32_t v, cons
     }
 }
 
+// ---- the commit step with the wavefront's lanes (commit_core.h commit_node, same arithmetic) -----------------------------
+// One lane walking GetFreeCpuBatch's picks bit by bit, the GPU lists and the NIC pools of a node costs ~5 us per placement -
+// the chain of the pods without GPUs pays it pod after pod.  Here lane i answers for core i / GPU i / NIC i and a ballot
+// collects the answer: lowest k set bits = "bit set and fewer than k set bits below it".  Every lane ends up with the same
+// (uniform) values; lane 0 writes them to the LDS copies.  The host twin keeps the scalar form; the GPU parity tests compare
+// the two through their results (tests/golden/commit, the oracle's loop).
+__device__ __forceinline__ uint64_t lowest_bits_wave(uint64_t x, uint32_t k, uint32_t lane) {
+    const uint64_t below = lane ? x & ((1ull << lane) - 1ull) : 0ull;
+    return __ballot((x >> lane & 1) && (uint32_t)__popcll(below) < k);
+}
+struct WaveBatch { uint64_t take, pair, late; bool ok; };
+__device__ __forceinline__ WaveBatch take_batch_wave(uint64_t& t0, uint64_t& t1, bool smt_node, uint32_t num, bool smt_requested, uint32_t lane) {
+    const uint64_t free = t0 & t1;
+    const bool pairs = smt_node && smt_requested;
+    const uint32_t avail = (uint32_t)__popcll(free);
+    const uint32_t n_take = pairs ? (num + 1) / 2 : num, n_pair = pairs ? num / 2 : 0;
+    WaveBatch b;
+    b.take = lowest_bits_wave(free, n_take, lane);
+    b.pair = n_pair ? lowest_bits_wave(free, n_pair, lane) : 0ull;
+    b.late = 0;
+    uint32_t n_late = 0;
+    if (smt_node && !pairs && num > avail) { n_late = num - avail; b.late = lowest_bits_wave(free, n_late, lane); }   // the walk runs on into the sibling range
+    t0 &= ~b.take;
+    if (smt_node) t1 &= ~(b.pair | b.late);
+    b.ok = (uint32_t)__popcll(b.take) + (uint32_t)__popcll(b.late) == n_take && (uint32_t)__popcll(b.late) == n_late;
+    return b;
+}
+// key of the NIC pool the lanes flagged `in` form (pool_key_packed over their classes)
+__device__ __forceinline__ uint64_t pool_key_wave(uint32_t glimit, bool in, uint32_t my_cls) {
+    uint64_t k = (uint64_t)(glimit & 0xFFu) << 48;
+#pragma unroll
+    for (uint32_t c = 0; c < (uint32_t)NHDFIT_MAX_CLASSES; ++c) {
+        const uint32_t n = (uint32_t)__popcll(__ballot(in && my_cls == c));
+        k |= (uint64_t)(n > (uint32_t)kMaxG ? (uint32_t)kMaxG : n) << (3 * c);
+    }
+    return k;
+}
+__device__ __forceinline__ void sig_keys_wave(const nhdfit_detail& d, uint32_t u, uint32_t lane, uint64_t& key_numa, uint64_t& key_pci) {
+    key_numa = key_pci = 0;
+    const uint32_t n = d.nic_cnt[u];
+    const bool valid = lane < n;
+    const uint32_t my_cls = valid ? d.nic_cls[u][lane & 15u] : 0xFFu, my_sw = valid ? d.nic_sw[u][lane & 15u] : 0xFFu;
+    if (n) key_numa = sig_key_add(0, pool_key_wave(NHDFIT_GLIMIT_NONE, valid, my_cls));
+    uint64_t todo = __ballot(valid);                                      // NICs whose switch has not been turned into a pool yet
+    while (todo) {
+        const uint32_t k = (uint32_t)__builtin_ctzll(todo);
+        const uint32_t sw = d.nic_sw[u][k];
+        const uint64_t same = __ballot(valid && my_sw == sw);
+        todo &= ~same;
+        const uint32_t gl = d.sw_free[sw] > kMaxG ? kMaxG : d.sw_free[sw];
+        if (!gl) continue;                                                // no free GPU behind it: the pool hosts nothing
+        key_pci = sig_key_add(key_pci, pool_key_wave(gl, valid && my_sw == sw, my_cls));
+    }
+}
+// `s` / `d` / `out` live in LDS (one copy per wavefront); every lane returns the same status
+__device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, const nhdfit_mapping& m, double busy_time,
+                                                const SigTable& sigs, nhdfit_placement& out, uint32_t lane) {
+    const int G = (int)r.n_groups;
+    int status = kCommitOk;
+    {   // the placement record: zeros, 0xFF for the GPU list and the NUMA entries (bytes 144 .. 180 of the 256)
+        const uint32_t o = lane * 4u;
+        reinterpret_cast<uint32_t*>(&out)[lane] = o >= 144u && o < 180u ? 0xFFFFFFFFu : o == 180u ? 0x000000FFu : 0u;
+    }
+    uint64_t t0[2] = {s.p0.t0[0], s.p0.t0[1]}, t1[2] = {s.p1.t1[0], s.p1.t1[1]};
+    const bool smt_node = (s.p2.flags & NHDFIT_NF_SMT) != 0;
+    uint32_t gpu_free = s.p2.gpu_free;
+    const uint32_t gpu_numa1 = s.p2.gpu_numa1, n_gpus = d.n_gpus;
+    const uint32_t my_gsw = lane < n_gpus && lane < (uint32_t)NHDFIT_MAX_GPUS ? d.gpu_sw[lane & 31u] : 0xFFu;
+    uint32_t claimed0 = 0, claimed1 = 0;
+    bool gpu_taken = false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int g = 0; g < G; ++g) {
+        const uint32_t u = (uint32_t)m.gpu[g] & 1u;
+        const WaveBatch pb = take_batch_wave(t0[u], t1[u], smt_node, r.n_proc[g], (r.smt_bits >> g & 1) != 0, lane);
+        if (!pb.ok) status = kCommitWouldRaise;
+        const uint32_t nu = (uint32_t)m.nic_numa[g] & 1u, nk = (uint32_t)m.nic_idx[g] & 15u;
+        const uint32_t sw = d.nic_sw[nu][nk];
+        uint32_t picks = 0xFFFFFFFFu;                                     // up to four picks travel in a register (byte k), the rest through lane 0
+        for (uint32_t k = 0; k < r.gpus[g]; ++k) {
+            const bool mine_free = lane < n_gpus && (gpu_free >> lane & 1);
+            uint64_t cand = __ballot(mine_free && my_gsw == sw);          // GetFreePciGpuFromNic, Node.py:648-655
+            if (!cand && r.map_type != NHDFIT_MAP_PCI) cand = __ballot(mine_free && (gpu_numa1 >> lane & 1) == u);   // GetNextGpuFree, Node.py:495-500
+            if (!cand) { status = kCommitWouldRaise; continue; }
+            const uint32_t pick = (uint32_t)__builtin_ctzll(cand);
+            gpu_free &= ~(1u << pick);
+            gpu_taken = true;
+            if (lane == 0) {
+                const uint32_t psw = d.gpu_sw[pick];
+                if (d.sw_free[psw]) d.sw_free[psw]--;
+                if (k < (uint32_t)NHDFIT_PLACEMENT_GPUS) out.gpu[g][k] = (uint8_t)pick;
+            }
+            (void)picks;
+        }
+        const WaveBatch hb = take_batch_wave(t0[u], t1[u], smt_node, r.n_help[g], (r.smt_bits >> (4 + g) & 1) != 0, lane);
+        if (!hb.ok) status = kCommitWouldRaise;
+        if (r.nic_use >> g & 1) { if (nu) claimed1 |= 1u << nk; else claimed0 |= 1u << nk; }
+        if (lane == 0) {
+            out.numa[g] = (int8_t)u;
+            out.proc_take[g] = pb.take; out.proc_pair[g] = pb.pair; out.proc_late[g] = pb.late;
+            out.help_take[g] = hb.take; out.help_pair[g] = hb.pair; out.help_late[g] = hb.late;
+        }
+    }
+    const uint32_t mu = (uint32_t)m.cpu[G] & 1u;
+    const WaveBatch mb = take_batch_wave(t0[mu], t1[mu], smt_node, r.n_misc, r.misc_smt_enabled != 0, lane);     // Node.py:799
+    if (!mb.ok) status = kCommitWouldRaise;
+    if (lane == 0) {
+        out.numa[kMaxG] = (int8_t)mu;
+        out.misc_take = mb.take; out.misc_pair = mb.pair; out.misc_late = mb.late;
+        s.p0.t0[0] = t0[0]; s.p0.t0[1] = t0[1]; s.p1.t1[0] = t1[0]; s.p1.t1[1] = t1[1];
+        s.p2.gpu_free = gpu_free;
+        if (r.hugepages_gb > 0) s.p2.hp_free -= r.hugepages_gb;              // Node.py:794-796
+        s.p4.busy_time = busy_time;                                          // SetBusy, nhd/Node.py:843-845
+        for (uint32_t k = 0; k < (uint32_t)NHDFIT_MAX_NICS_PER_NUMA; ++k)     // ClaimPodNICResources (commit_core.h: the same rule)
+            for (uint32_t u = 0; u < 2; ++u)
+                if ((u ? claimed1 : claimed0) >> k & 1)
+                    if (pods_get(d, u, k) != kPodsLost && pods_add(d, u, k, 1) != 0) d.nic_cls[u][k] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t u = 0; u < 2; ++u) {
+        if (!(u ? claimed1 : claimed0) && !gpu_taken) continue;
+        uint64_t kn, kp;
+        uint32_t idn = 0, idp = 0;
+        sig_keys_wave(d, u, lane, kn, kp);
+        if (!sig_lookup(sigs, kn, idn) || !sig_lookup(sigs, kp, idp)) { if (status == kCommitOk) status = kCommitNewSig; }
+        if (lane == 0) { s.p3.sig_numa[u] = (uint16_t)idn; s.p3.sig_pci[u] = (uint16_t)idp; }
+    }
+    if (lane == 0) out.status = (uint8_t)status;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return status;
+}
+
 constexpr int kDecideWaves = 16, kDecideRing = 32, kDecideCache = 16, kWorkerBlocks = 8;
-constexpr uint32_t kHintDistance = 4;     // a GPU-less pod's window is read at most this many pods ahead of the driver: the column patches
-                                          // of the commits before it have mostly landed by then (every stale bit costs a failed verification)
+constexpr uint32_t kHintDistance = 3;     // a GPU-less pod's window is read when at most this many GPU-less pods before it are still undecided:
+                                          // the column patches of the earlier commits have mostly landed by then (every stale bit costs a failed
+                                          // verification), and the pods with GPUs in between leave the fetcher the time it needs
 constexpr uint32_t kSpinLimit = 1u << 22;                      // x ~100 cycles of s_sleep: a fraction of a second, then give up
 
 __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
@@ -151,7 +287,8 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     __shared__ int32_t s_have[kDecideRing];                    // 0 no candidate, 1 window of the GPU-less nodes, 2 window of all nodes, -1 no GPU-less node left
     __shared__ uint32_t s_kind[kDecideRing];                   // 1 = the pod requests GPUs
     __shared__ uint32_t s_ready[kDecideRing];                  // sequence number + 1 of the pod parked in the slot
-    __shared__ uint32_t s_done, s_abort;
+    __shared__ uint32_t s_done, s_abort, s_done_tn;
+    __shared__ uint32_t s_tn[kDecideRing];                     // GPU-less pods before the slot's pod
     __shared__ NodeState s_cst[kDecideCache];                  // nodes the driver committed to, most recent kDecideCache
     __shared__ nhdfit_detail s_cdet[kDecideCache];
     __shared__ uint32_t s_ctag[kDecideCache];
@@ -182,6 +319,12 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     auto map_commit = [&](const nhdfit_req& rq, NodeState& st, nhdfit_detail& dd, uint32_t pos, uint32_t mine, uint32_t v, bool verify,
                           const SigTable& sigs, const MapTables& mt, SeqResult& res, nhdfit_placement& pl, int32_t& status) -> bool {
         bool ok = !verify || rq.hugepages_gb <= st.p2.hp_free;            // nhd/Matcher.py:78
+        if (ok && verify) {                                               // cheap necessary condition before the table look-ups: enough free
+            const bool smt = (st.p2.flags & NHDFIT_NF_SMT) != 0;          // physical cores on the node as a whole
+            uint32_t need = smt ? rq.misc_smt : rq.misc_nosmt;
+            for (uint32_t g = 0; g < rq.n_groups; ++g) need += smt ? rq.cpu_smt[g] : rq.cpu_nosmt[g];
+            ok = need <= (uint32_t)popc64(st.p0.t0[0] & st.p1.t1[0]) + (uint32_t)popc64(st.p0.t0[1] & st.p1.t1[1]);
+        }
         nhdfit_mapping mp = nhdfit_mapping{};
         if (ok) {
             const uint32_t tile = pos >> 6;
@@ -193,21 +336,17 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         if (!ok && verify) return false;
         note_first_touch(a, v, st, dd, lane);
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-            res.node = (int64_t)a.global_base + (int64_t)v;
-            res.map = mp;
-            if (ok) res.status = commit_node(st, dd, rq, res.map, a.now, sigs, pl);
-            else {                                                        // the row said feasible, the mapping disagrees: cannot happen
-                memset(&pl, 0, sizeof pl);
-                res.map = nhdfit_mapping{};
-                res.status = kCommitWouldRaise;
-                pl.status = kCommitWouldRaise;
-            }
-            if (res.status == kCommitNewSig) q.flags[1] = 1u;
+        if (lane == 0) { res.node = (int64_t)a.global_base + (int64_t)v; res.map = ok ? mp : nhdfit_mapping{}; }
+        if (ok) status = commit_node_wave(st, dd, rq, mp, a.now, sigs, pl, lane);
+        else {                                                            // the row said feasible, the mapping disagrees: cannot happen
+            if (lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&pl)[lane] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) pl.status = kCommitWouldRaise;
+            status = kCommitWouldRaise;
         }
+        if (lane == 0) { res.status = status; if (status == kCommitNewSig) q.flags[1] = 1u; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        status = res.status;
         if (lane < sizeof(SeqResult) / 4) reinterpret_cast<uint32_t*>(&a.out[mine])[lane] = reinterpret_cast<const uint32_t*>(&res)[lane];
         if (a.place && lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&a.place[mine])[lane] = reinterpret_cast<const uint32_t*>(&pl)[lane];
         store_node_lds(a, v, &st, &dd, lane);
@@ -270,7 +409,8 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     uint64_t* l_skey = nullptr; uint32_t* l_sid = nullptr; uint64_t* l_info = nullptr; uint32_t* l_next = nullptr; uint32_t* l_asc = nullptr;
     if (q.lds_sigs) { l_skey = carve<uint64_t>(dynp, (size_t)a.sigs.mask + 1); l_sid = carve<uint32_t>(dynp, (size_t)a.sigs.mask + 1); }
     if (q.lds_states) { l_info = carve<uint64_t>(dynp, a.mt.st.n); l_next = carve<uint32_t>(dynp, (size_t)a.mt.st.n * 8); l_asc = carve<uint32_t>(dynp, 256); }
-    if (tid == 0) { s_done = 0; s_abort = 0; }
+    uint8_t* l_choose = q.lds_choose ? carve<uint8_t>(dynp, kChooseEntries) : nullptr;
+    if (tid == 0) { s_done = 0; s_abort = 0; s_done_tn = 0; }
     if (tid < kDecideRing) s_ready[tid] = 0;
     if (tid < kDecideCache) s_ctag[tid] = kNoNode;
     for (uint32_t k = tid; k < a.chunks; k += 64 * kDecideWaves) s_taken[k] = 0;
@@ -283,6 +423,12 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         for (uint32_t k = tid; k < a.mt.st.n * 8; k += 64 * kDecideWaves) l_next[k] = a.mt.st.next[k];
         for (uint32_t k = tid; k < 256; k += 64 * kDecideWaves) l_asc[k] = a.mt.st.asc[k];
         mt.st = SetStates{l_info, l_next, l_asc, a.mt.st.n};
+    }
+    if (q.lds_choose) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.mt.choose_tab);
+        uint4* dst = reinterpret_cast<uint4*>(l_choose);
+        for (uint32_t k = tid; k < kChooseEntries / 16; k += 64 * kDecideWaves) dst[k] = src[k];
+        mt.choose_tab = l_choose;
     }
     __syncthreads();
 
@@ -329,8 +475,9 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             int32_t have = 0;
             uint32_t wb = 0;
             const unsigned long long score_a = a.score[pos];
+            const uint32_t tn = q.tn_before[mine];
             if (!wants_gpu && score_a)
-                for (uint32_t spin = 0; e > wg_load(&s_done) + kHintDistance; ++spin) {
+                for (uint32_t spin = 0; tn > wg_load(&s_done_tn) + kHintDistance; ++spin) {
                     if (spin > kSpinLimit || wg_load(&s_abort)) return;
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -340,7 +487,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 if (scan_window(slot, pos, mode, (uint32_t)(from >> 6), (uint32_t)(from & 63), wb)) have = mode == 1 ? 1 : 2;
                 else if (mode == 1) have = -1;                            // no GPU-less node left in the row: the driver tries all nodes
             }
-            if (lane == 0) { s_have[slot] = have; s_kind[slot] = wants_gpu ? 1u : 0u; s_pos[slot] = pos; s_base[slot] = wb; }
+            if (lane == 0) { s_have[slot] = have; s_kind[slot] = wants_gpu ? 1u : 0u; s_pos[slot] = pos; s_base[slot] = wb; s_tn[slot] = tn; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) wg_store(&s_ready[slot], e + 1);
         }
@@ -350,11 +497,15 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     // ---- the driver ------------------------------------------------------------------------------------------------------
     __builtin_amdgcn_s_setprio(3);
     uint32_t n_items = 0, cache_next = 0;
+    uint32_t pend_v = kNoNode;                                            // a commit of the driver whose publication waits for the next pod:
+                                                                          // by then its stores have landed and the fence costs nothing
     uint32_t c_fail = 0, c_wait = 0, c_plain = 0, c_rescan = 0, c_hit = 0;     // tuning aid: what the GPU-less pods cost (ctrl[4..8])
+    unsigned long long t_ready = 0, t_gpu = 0, t_state = 0, t_verify = 0, t_publish = 0, t_last = wall_clock64();   // 100 MHz ticks (ctrl[9..13])
+    auto lap = [&](unsigned long long& acc) { const unsigned long long t = wall_clock64(); acc += t - t_last; t_last = t; };
     bool stop = false;
     auto give_up = [&]() { stop = true; if (lane == 0) { q.flags[3] = 1u; wg_store(&s_abort, 1u); } };
     auto push = [&](unsigned long long item) {                            // one 8-byte store: the entry itself is the signal
-        if (lane == 0) __hip_atomic_store(&q.queue[n_items], item, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(&q.queue[n_items], item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nothing else to order: the entry is the data)
         ++n_items;
     };
     for (uint32_t e = 0; e < n_pods && !stop; ++e) {
@@ -365,6 +516,13 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         }
         if (stop) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        lap(t_ready);
+        if (pend_v != kNoNode) {
+            publish(pend_v, kCommitOk);
+            if (ngl) push(kItemValid | kItemPatch | pend_v);
+            pend_v = kNoNode;
+            lap(t_publish);
+        }
         const nhdfit_req& rq = s_req[slot].r;
         const uint32_t pos = s_pos[slot];
         const bool wants_gpu = s_kind[slot] != 0;
@@ -390,6 +548,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 push(kItemValid | ((unsigned long long)mine << 32) | v);
                 placed = true;
             }
+            lap(t_gpu);
         } else {
             // pass 1: the nodes without GPUs (SelectNode's preference), pass 2: every node; each candidate verified
             int pass = have == 1 ? 1 : 2;
@@ -432,6 +591,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                         }
                         if (m == 3u) stop = true;                         // poisoned: a NIC state without a signature (reported by the committer)
                         if (stop) break;
+                        __threadfence();                                  // (a node the driver itself wrote and evicted: its stores first)
                         load_node_lds_coherent(a, v, st, dd, lane);
                     } else { load_node_lds(a, v, st, dd, lane); ++c_plain; }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -446,8 +606,10 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     __builtin_amdgcn_wave_barrier();
                     st = &s_cst[cidx]; dd = &s_cdet[cidx];
                 }
+                lap(t_state);
                 int32_t status = 0;
                 const bool ok = map_commit(rq, *st, *dd, pos, mine, v, true, sigs, mt, s_wres[0], s_wplace[0], status);
+                lap(t_verify);
                 if (!ok) {                                                // stale hint: not this node (any more)
                     ++c_fail;
                     if (lane == (uint32_t)l) s_win[slot][lane] = w & ~(1ull << (v & 63));
@@ -460,9 +622,8 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     s_taken[v >> 6] |= 1ull << (v & 63);                   // busy for every later pod with GPUs
                 }
                 if ((uint32_t)cidx == cache_next % kDecideCache) ++cache_next;
-                publish(v, status);
-                if (status == kCommitNewSig) stop = true;
-                if (ngl) push(kItemValid | kItemPatch | v);
+                if (status == kCommitNewSig) { publish(v, status); stop = true; }
+                else pend_v = v;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 placed = true;
@@ -472,10 +633,15 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             if (lane == 0) { SeqResult r; r.node = -1; r.map = nhdfit_mapping{}; r.status = 0; a.out[mine] = r; }
             if (a.place && lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&a.place[mine])[lane] = 0u;
         }
-        if (lane == 0) wg_store(&s_done, e + 1);
+        if (lane == 0) { if (!wants_gpu) wg_store(&s_done_tn, s_tn[slot] + 1u); wg_store(&s_done, e + 1); }
+    }
+    if (pend_v != kNoNode) {
+        publish(pend_v, kCommitOk);
+        if (ngl) push(kItemValid | kItemPatch | pend_v);
     }
     if (lane == 0) {
         q.ctrl[4] = c_fail; q.ctrl[5] = c_wait; q.ctrl[6] = c_plain; q.ctrl[7] = c_rescan; q.ctrl[8] = c_hit;
+        q.ctrl[9] = (uint32_t)t_ready; q.ctrl[10] = (uint32_t)t_gpu; q.ctrl[11] = (uint32_t)t_state; q.ctrl[12] = (uint32_t)t_verify; q.ctrl[13] = (uint32_t)t_publish;
         wg_store(&s_done, n_pods);                                        // the fetchers run out
         __hip_atomic_store(&q.ctrl[1], n_items + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the workers leave once the queue is drained
     }
