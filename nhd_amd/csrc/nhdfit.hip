@@ -1108,7 +1108,6 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, c->seq_out.reserve(P));
         HIPCHK(c, c->seq_place.reserve(P));
         HIPCHK(c, c->order.reserve(P));
-        HIPCHK(c, c->seq_queue.reserve(2 * (size_t)P));
         HIPCHK(c, c->seq_ctrl.reserve(16));
         HIPCHK(c, c->seq_mat.reserve(c->n ? c->n : 1));
         HIPCHK(c, c->seq_flags.reserve(4));
@@ -1185,24 +1184,28 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     };
 
     uint32_t decided = 0;                                       // pods [0, decided) of the caller's order are decided
-    bool fast = !c->seq_general && (size_t)chunks * 8 <= 64 * 1024 && c->n > 0 && P < (1u << 30);
+    bool fast = !c->seq_general && (size_t)chunks * 8 <= 64 * 1024 && c->n > 0 && P < (1u << 28);
     if (fast) {
         // The decision engine (seq2_kernel.h): one block decides, the rest of the grid commits.
-        HIPCHK(c, hipMemsetAsync(c->seq_queue.p, 0, 2 * (size_t)P * sizeof(unsigned long long), sm));
         HIPCHK(c, hipMemsetAsync(c->seq_ctrl.p, 0, 16 * sizeof(uint32_t), sm));
         HIPCHK(c, hipMemsetAsync(c->seq_mat.p, 0, (size_t)c->n * sizeof(uint32_t), sm));
-        c->tn_host.resize(P);
-        uint32_t n_tn = 0;
-        for (uint32_t i = 0; i < P; ++i) {                      // pods without GPUs before pod i (the fetchers pace their hints by it)
-            c->tn_host[i] = n_tn;
+        c->tn_host.resize(P);                                   // [the pods without GPUs | every other pod], caller's indices ascending
+        uint32_t n_n = 0, n_g = 0;
+        auto gpu_less = [&](uint32_t i) {
+            if (!req_valid(reqs[i])) return false;
             uint32_t g = 0;
-            if (req_valid(reqs[i])) for (uint32_t k = 0; k < reqs[i].n_groups; ++k) g += reqs[i].gpus[k];
-            if (req_valid(reqs[i]) && g == 0) ++n_tn;
-        }
+            for (uint32_t k = 0; k < reqs[i].n_groups; ++k) g += reqs[i].gpus[k];
+            return g == 0;
+        };
+        for (uint32_t i = 0; i < P; ++i) if (gpu_less(i)) c->tn_host[n_n++] = i;
+        for (uint32_t i = 0; i < P; ++i) if (!gpu_less(i)) c->tn_host[n_n + n_g++] = i;
         HIPCHK(c, hipMemcpyAsync(c->seq_tn.p, c->tn_host.data(), (size_t)P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
+        const uint32_t queue_len = P * 9u;                      // a commit per pod + up to eight patch items per commit of a GPU-less pod
+        HIPCHK(c, c->seq_queue.reserve(queue_len));
+        HIPCHK(c, hipMemsetAsync(c->seq_queue.p, 0, (size_t)queue_len * sizeof(unsigned long long), sm));
         DecideArgs qa;
         memset(&qa, 0, sizeof qa);
-        qa.tn_before = c->seq_tn.p;
+        qa.list_n = c->seq_tn.p; qa.n_n = n_n; qa.list_g = c->seq_tn.p + n_n; qa.n_g = n_g; qa.queue_len = queue_len;
         qa.s = sa; qa.queue = c->seq_queue.p; qa.ctrl = c->seq_ctrl.p; qa.mat = c->seq_mat.p; qa.flags = c->seq_flags.p;
         size_t dyn = lds_slice((size_t)chunks * 8);
         const size_t sig_bytes = lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4);

@@ -30,17 +30,25 @@ struct DecideArgs {
     uint32_t* mat;               // [n] 0 = as the snapshot left it / commit pending, 2 = committed state in global memory, 3 = poisoned
     uint32_t* flags;             // [1] a commit met a NIC state without a signature, [3] a wait ran out (never expected)
     uint32_t lds_sigs, lds_states, lds_choose;   // block 0: stage the signature hash table / the set-state tables / the G <= 2 choose table in LDS (they fit)
-    const uint32_t* tn_before;   // [P] caller's pod i: how many pods without GPUs come before it
+    const uint32_t* list_n; uint32_t n_n;   // the pods without GPUs (valid requests), caller's indices ascending
+    const uint32_t* list_g; uint32_t n_g;   // every other pod
+    uint32_t queue_len;          // entries of `queue`
 };
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 constexpr unsigned long long kItemValid = 1ull << 63, kItemPatch = 1ull << 62;
+// tiles (of those that hold GPU-less pods) one patch item covers: a committed node's column is re-evaluated by up to eight
+// worker wavefronts at once
+__host__ __device__ inline uint32_t patch_span(uint32_t ngl) { return ngl <= 64u ? 8u : (ngl + 7u) / 8u; }
 
 // first-touch copy of a node for apply = 0 (whole wavefront), as in k_seq
-__device__ __forceinline__ void note_first_touch(const SeqArgs& a, uint32_t v, const NodeState& st, const nhdfit_detail& dd, uint32_t lane) {
-    int32_t seen = 0;                 // (read and written past the CU's vector cache: another CU may have touched the node)
-    if (lane == 0) seen = __hip_atomic_load(&a.touched[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    seen = __builtin_amdgcn_readfirstlane(seen);
-    if (seen >= 0) return;
+// known_fresh: the caller knows that nothing touched the node in this batch (no look-up needed)
+__device__ __forceinline__ void note_first_touch(const SeqArgs& a, uint32_t v, const NodeState& st, const nhdfit_detail& dd, uint32_t lane, bool known_fresh = false) {
+    if (!known_fresh) {
+        int32_t seen = 0;             // (read and written past the CU's vector cache: another CU may have touched the node)
+        if (lane == 0) seen = __hip_atomic_load(&a.touched[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seen = __builtin_amdgcn_readfirstlane(seen);
+        if (seen >= 0) return;
+    }
     uint32_t slot = 0;
     if (lane == 0) { slot = atomicAdd(&a.counters[0], 1u); __hip_atomic_store(&a.touched[v], (int32_t)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
@@ -98,12 +106,12 @@ __device__ __forceinline__ void store_node_lds(const SeqArgs& a, uint32_t v, con
 
 // the committed node against the tiles that hold pods without GPUs: sixteen lanes per (node, tile) evaluate the W assignment
 // words, OR them together and clear the node's bit in the rows of the pods that lost it (hints for the pods to come)
-__device__ __forceinline__ void patch_columns(const SeqArgs& a, uint32_t v, const NodeState& st, const uint16_t* gl_tiles, uint32_t ngl,
+__device__ __forceinline__ void patch_columns(const SeqArgs& a, uint32_t v, const NodeState& st, const uint16_t* gl_tiles, uint32_t k_begin, uint32_t ngl,
                                               const Layout* L4, uint32_t lane) {
     const uint32_t p = lane & 15u, grp = lane >> 4;
     const NodeIdx ni = node_index(st.p0, st.p1, st.p2, st.p4, a.fc_dim, a.fg_dim, a.ngs);
     const bool busy = (a.now - st.p4.busy_time) < kMinBusySecs;
-    for (uint32_t k0 = 0; k0 < ngl; k0 += 4) {
+    for (uint32_t k0 = k_begin; k0 < ngl; k0 += 4) {
         const uint32_t k = k0 + grp;
         uint64_t lost = 0;
         uint32_t t = 0;
@@ -288,7 +296,9 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     __shared__ uint32_t s_kind[kDecideRing];                   // 1 = the pod requests GPUs
     __shared__ uint32_t s_ready[kDecideRing];                  // sequence number + 1 of the pod parked in the slot
     __shared__ uint32_t s_done, s_abort, s_done_tn;
-    __shared__ uint32_t s_tn[kDecideRing];                     // GPU-less pods before the slot's pod
+    constexpr uint32_t kNicSigs = 64;                          // dictionaries up to this many NIC signatures: the pod's NIC-feasible assignments
+    __shared__ uint32_t s_nic[kDecideRing][kNicSigs];          // per signature (low half: on NUMA 0, high half: on NUMA 1) ride along with its window
+    __shared__ uint32_t s_nicn[kDecideRing];
     __shared__ NodeState s_cst[kDecideCache];                  // nodes the driver committed to, most recent kDecideCache
     __shared__ nhdfit_detail s_cdet[kDecideCache];
     __shared__ uint32_t s_ctag[kDecideCache];
@@ -316,8 +326,10 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
 
     // map + commit of pod `mine` (request in rq) on node v whose state sits in (st, dd): results and the node written back.
     // `verify`: the row bit is only a hint - false = the node does not (any longer) take the pod, nothing was changed.
-    auto map_commit = [&](const nhdfit_req& rq, NodeState& st, nhdfit_detail& dd, uint32_t pos, uint32_t mine, uint32_t v, bool verify,
-                          const SigTable& sigs, const MapTables& mt, SeqResult& res, nhdfit_placement& pl, int32_t& status) -> bool {
+    //   touch: 0 = the node was touched before in this batch, 1 = never (first-touch copy without a look-up)
+    //   nic_tab: optional per-signature NIC masks of this pod (low half NUMA 0, high half NUMA 1), fetched ahead into LDS
+    auto map_commit = [&](const nhdfit_req& rq, NodeState& st, nhdfit_detail& dd, uint32_t pos, uint32_t mine, uint32_t v, bool verify, int touch,
+                          const uint32_t* nic_tab, const SigTable& sigs, const MapTables& mt, SeqResult& res, nhdfit_placement& pl, int32_t& status) -> bool {
         bool ok = !verify || rq.hugepages_gb <= st.p2.hp_free;            // nhd/Matcher.py:78
         if (ok && verify) {                                               // cheap necessary condition before the table look-ups: enough free
             const bool smt = (st.p2.flags & NHDFIT_NF_SMT) != 0;          // physical cores on the node as a whole
@@ -328,13 +340,14 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         nhdfit_mapping mp = nhdfit_mapping{};
         if (ok) {
             const uint32_t tile = pos >> 6;
-            const uint32_t bits = nic_assignment_bits_wave(a.tabs + (size_t)tile * a.pitch, s_L[a.tile_wcls[tile]], pos & 63,
-                                                           rq.map_type == NHDFIT_MAP_PCI, st.p3, lane);
+            const bool pci = rq.map_type == NHDFIT_MAP_PCI;
+            const uint32_t bits = nic_tab ? (nic_tab[pci ? st.p3.sig_pci[0] : st.p3.sig_numa[0]] & 0xFFFFu) & (nic_tab[pci ? st.p3.sig_pci[1] : st.p3.sig_numa[1]] >> 16)
+                                          : nic_assignment_bits_wave(a.tabs + (size_t)tile * a.pitch, s_L[a.tile_wcls[tile]], pos & 63, pci, st.p3, lane);
             ok = map_on_state_wave(rq, st, dd, s_caps, bits, mt, lane, mp);
         }
         __builtin_amdgcn_wave_barrier();
         if (!ok && verify) return false;
-        note_first_touch(a, v, st, dd, lane);
+        if (touch) note_first_touch(a, v, st, dd, lane, true);
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) { res.node = (int64_t)a.global_base + (int64_t)v; res.map = ok ? mp : nhdfit_mapping{}; }
         if (ok) status = commit_node_wave(st, dd, rq, mp, a.now, sigs, pl, lane);
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             uint32_t ticket = 0;
             if (lane == 0) ticket = atomicAdd(&q.ctrl[0], 1u);
             ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
-            if (ticket >= 2u * a.P) return;
+            if (ticket >= q.queue_len) return;
             unsigned long long item = 0;
             for (uint32_t spin = 0;; ++spin) {
                 item = __hip_atomic_load(&q.queue[ticket], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -382,7 +395,8 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 load_node_lds_coherent(a, v, &st, &dd, lane);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (ngl && seen) patch_columns(a, v, st, gl_tiles, ngl, s_L, lane);
+                const uint32_t k0 = (uint32_t)(item >> 32) & 0xFFFFu;
+                if (ngl && seen) patch_columns(a, v, st, gl_tiles, k0, k0 + patch_span(ngl) < ngl ? k0 + patch_span(ngl) : ngl, s_L, lane);
                 continue;
             }
             const uint32_t mine = (uint32_t)(item >> 32) & 0x3FFFFFFFu, pos = a.order[mine];
@@ -395,9 +409,9 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             int32_t status = 0;
-            map_commit(s_wreq[wave].r, st, dd, pos, mine, v, false, a.sigs, a.mt, s_wres[wave], s_wplace[wave], status);
+            map_commit(s_wreq[wave].r, st, dd, pos, mine, v, false, 1, nullptr, a.sigs, a.mt, s_wres[wave], s_wplace[wave], status);
             publish(v, status);
-            if (ngl) patch_columns(a, v, st, gl_tiles, ngl, s_L, lane);
+            if (ngl) patch_columns(a, v, st, gl_tiles, 0, ngl, s_L, lane);
         }
     }
 
@@ -456,28 +470,32 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     };
 
     if (wave != 0) {
-        // ---- fetchers: pod e goes to slot e % kDecideRing once the driver is past pod e - kDecideRing
-        constexpr uint32_t kFetchers = kDecideWaves - 1;
-        for (uint32_t e = wave - 1; e < n_pods; e += kFetchers) {
+        // ---- fetchers: pod e goes to slot e % kDecideRing once the driver is past pod e - kDecideRing.  Two pools, so that a
+        // GPU-less pod waiting for its turn (below) never holds up the pods with GPUs behind it
+        constexpr uint32_t kFetchN = 6, kFetchG = kDecideWaves - 1 - kFetchN;
+        const bool pool_n = wave <= kFetchN;
+        const uint32_t* list = pool_n ? q.list_n : q.list_g;
+        const uint32_t n_list = pool_n ? q.n_n : q.n_g, stride = pool_n ? kFetchN : kFetchG;
+        for (uint32_t j = pool_n ? wave - 1 : wave - 1 - kFetchN; j < n_list; j += stride) {
+            const uint32_t e = list[j];
             const uint32_t slot = e % kDecideRing;
             for (uint32_t spin = 0; e >= wg_load(&s_done) + kDecideRing; ++spin) {
                 if (spin > kSpinLimit || wg_load(&s_abort)) return;
                 __builtin_amdgcn_s_sleep(2);
             }
-            const uint32_t mine = a.list ? a.list[e] : e;
+            const uint32_t mine = e;
             const uint32_t pos = a.order[mine];
             if (lane < sizeof(nhdfit_req) / 16) {
                 const uint4 v4 = reinterpret_cast<const uint4*>(a.reqs + pos)[lane];
                 uint32_t* dst = reinterpret_cast<uint32_t*>(&s_req[slot]) + lane * 4;
                 dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;
             }
-            const bool wants_gpu = (a.tile_masks[2 * (pos >> 6)] >> (pos & 63) & 1) != 0;
+            const bool wants_gpu = !pool_n;
             int32_t have = 0;
             uint32_t wb = 0;
             const unsigned long long score_a = a.score[pos];
-            const uint32_t tn = q.tn_before[mine];
-            if (!wants_gpu && score_a)
-                for (uint32_t spin = 0; tn > wg_load(&s_done_tn) + kHintDistance; ++spin) {
+            if (pool_n && score_a)                                        // (j = the number of GPU-less pods before this one)
+                for (uint32_t spin = 0; j > wg_load(&s_done_tn) + kHintDistance; ++spin) {
                     if (spin > kSpinLimit || wg_load(&s_abort)) return;
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -487,7 +505,21 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 if (scan_window(slot, pos, mode, (uint32_t)(from >> 6), (uint32_t)(from & 63), wb)) have = mode == 1 ? 1 : 2;
                 else if (mode == 1) have = -1;                            // no GPU-less node left in the row: the driver tries all nodes
             }
-            if (lane == 0) { s_have[slot] = have; s_kind[slot] = wants_gpu ? 1u : 0u; s_pos[slot] = pos; s_base[slot] = wb; s_tn[slot] = tn; }
+            uint32_t nicn = 0;
+            if (!wants_gpu && have != 0 && s_L[0].nsig <= kNicSigs) {     // bit p of a half: assignment p passes the NIC test on that NUMA node
+                const Layout& L = s_L[a.tile_wcls[pos >> 6]];           // for a node with this signature (the cold R rows of the pod's tile)
+                const uint8_t* img = a.tabs + (size_t)(pos >> 6) * a.pitch;
+                nicn = L.nsig;
+                if (lane < L.nsig) {
+                    uint32_t m0 = 0, m1 = 0;
+                    for (uint32_t pp = 0; pp < L.W; ++pp) {
+                        m0 |= (uint32_t)(ld64(img, L.off_r0 + lane * L.row + pp * 8) >> (pos & 63) & 1) << pp;
+                        m1 |= (uint32_t)(ld64(img, L.off_r1 + lane * L.row + pp * 8) >> (pos & 63) & 1) << pp;
+                    }
+                    s_nic[slot][lane] = m0 | (m1 << 16);
+                }
+            }
+            if (lane == 0) { s_have[slot] = have; s_kind[slot] = wants_gpu ? 1u : 0u; s_pos[slot] = pos; s_base[slot] = wb; s_nicn[slot] = nicn; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) wg_store(&s_ready[slot], e + 1);
         }
@@ -496,7 +528,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
 
     // ---- the driver ------------------------------------------------------------------------------------------------------
     __builtin_amdgcn_s_setprio(3);
-    uint32_t n_items = 0, cache_next = 0;
+    uint32_t n_items = 0, cache_next = 0, n_tn_done = 0;
     uint32_t pend_v = kNoNode;                                            // a commit of the driver whose publication waits for the next pod:
                                                                           // by then its stores have landed and the fence costs nothing
     uint32_t c_fail = 0, c_wait = 0, c_plain = 0, c_rescan = 0, c_hit = 0;     // tuning aid: what the GPU-less pods cost (ctrl[4..8])
@@ -519,7 +551,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         lap(t_ready);
         if (pend_v != kNoNode) {
             publish(pend_v, kCommitOk);
-            if (ngl) push(kItemValid | kItemPatch | pend_v);
+            for (uint32_t k0 = 0; k0 < ngl; k0 += patch_span(ngl)) push(kItemValid | kItemPatch | ((unsigned long long)k0 << 32) | pend_v);
             pend_v = kNoNode;
             lap(t_publish);
         }
@@ -608,7 +640,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 }
                 lap(t_state);
                 int32_t status = 0;
-                const bool ok = map_commit(rq, *st, *dd, pos, mine, v, true, sigs, mt, s_wres[0], s_wplace[0], status);
+                const bool ok = map_commit(rq, *st, *dd, pos, mine, v, true, taken ? 0 : 1, s_nicn[slot] ? s_nic[slot] : nullptr, sigs, mt, s_wres[0], s_wplace[0], status);
                 lap(t_verify);
                 if (!ok) {                                                // stale hint: not this node (any more)
                     ++c_fail;
@@ -633,11 +665,12 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             if (lane == 0) { SeqResult r; r.node = -1; r.map = nhdfit_mapping{}; r.status = 0; a.out[mine] = r; }
             if (a.place && lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&a.place[mine])[lane] = 0u;
         }
-        if (lane == 0) { if (!wants_gpu) wg_store(&s_done_tn, s_tn[slot] + 1u); wg_store(&s_done, e + 1); }
+        if (!wants_gpu) ++n_tn_done;
+        if (lane == 0) { if (!wants_gpu) wg_store(&s_done_tn, n_tn_done); wg_store(&s_done, e + 1); }
     }
     if (pend_v != kNoNode) {
         publish(pend_v, kCommitOk);
-        if (ngl) push(kItemValid | kItemPatch | pend_v);
+        for (uint32_t k0 = 0; k0 < ngl; k0 += patch_span(ngl)) push(kItemValid | kItemPatch | ((unsigned long long)k0 << 32) | pend_v);
     }
     if (lane == 0) {
         q.ctrl[4] = c_fail; q.ctrl[5] = c_wait; q.ctrl[6] = c_plain; q.ctrl[7] = c_rescan; q.ctrl[8] = c_hit;
