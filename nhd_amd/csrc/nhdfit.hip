@@ -1213,7 +1213,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         if (dyn + sig_bytes <= 96 * 1024) { qa.lds_sigs = 1; dyn += sig_bytes; }
         if (c->use_set_states && c->st_n && dyn + st_bytes <= 96 * 1024) { qa.lds_states = 1; dyn += st_bytes; }
         if (c->use_choose_tab && dyn + lds_slice(kChooseEntries) <= 112 * 1024) { qa.lds_choose = 1; dyn += lds_slice(kChooseEntries); }
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_decide, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_decide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));   // (static: ~45 KB of the 160)
         static const uint32_t workers = tune_env("NHDFIT_SEQ_WORKERS") ? (uint32_t)atoi(tune_env("NHDFIT_SEQ_WORKERS")) : (uint32_t)kWorkerBlocks;   // tuning aid
         hipLaunchKernelGGL(k_decide, dim3(1 + (workers ? workers : 1u)), dim3(64 * kDecideWaves), dyn, sm, qa);
         HIPCHK(c, hipGetLastError());
