@@ -1200,12 +1200,12 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         for (uint32_t i = 0; i < P; ++i) if (gpu_less(i)) c->tn_host[n_n++] = i;
         for (uint32_t i = 0; i < P; ++i) if (!gpu_less(i)) c->tn_host[n_n + n_g++] = i;
         HIPCHK(c, hipMemcpyAsync(c->seq_tn.p, c->tn_host.data(), (size_t)P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
-        const uint32_t queue_len = P * 9u;                      // a commit per pod + up to eight patch items per commit of a GPU-less pod
+        const uint32_t queue_len = P * 4u;                      // a commit per pod + up to three patch items per commit of a GPU-less pod
         HIPCHK(c, c->seq_queue.reserve(queue_len));
         HIPCHK(c, hipMemsetAsync(c->seq_queue.p, 0, (size_t)queue_len * sizeof(unsigned long long), sm));
         DecideArgs qa;
         memset(&qa, 0, sizeof qa);
-        qa.list_n = c->seq_tn.p; qa.n_n = n_n; qa.list_g = c->seq_tn.p + n_n; qa.n_g = n_g; qa.queue_len = queue_len;
+        qa.list_n = c->seq_tn.p; qa.n_n = n_n; qa.list_g = c->seq_tn.p + n_n; qa.n_g = n_g; qa.queue_len = queue_len; qa.ncls = c->ncls;
         qa.s = sa; qa.queue = c->seq_queue.p; qa.ctrl = c->seq_ctrl.p; qa.mat = c->seq_mat.p; qa.flags = c->seq_flags.p;
         size_t dyn = lds_slice((size_t)chunks * 8);
         const size_t sig_bytes = lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4);

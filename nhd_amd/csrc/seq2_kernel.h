@@ -33,12 +33,13 @@ struct DecideArgs {
     const uint32_t* list_n; uint32_t n_n;   // the pods without GPUs (valid requests), caller's indices ascending
     const uint32_t* list_g; uint32_t n_g;   // every other pod
     uint32_t queue_len;          // entries of `queue`
+    uint32_t ncls;               // NIC capacity classes of the dictionary
 };
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 constexpr unsigned long long kItemValid = 1ull << 63, kItemPatch = 1ull << 62;
-// tiles (of those that hold GPU-less pods) one patch item covers: a committed node's column is re-evaluated by up to eight
+// tiles (of those that hold GPU-less pods) one patch item covers: a committed node's column is re-evaluated by up to three
 // worker wavefronts at once
-__host__ __device__ inline uint32_t patch_span(uint32_t ngl) { return ngl <= 64u ? 8u : (ngl + 7u) / 8u; }
+__host__ __device__ inline uint32_t patch_span(uint32_t ngl) { return ngl <= 24u ? 8u : (ngl + 2u) / 3u; }   // at most three items per commit
 
 // first-touch copy of a node for apply = 0 (whole wavefront), as in k_seq
 // known_fresh: the caller knows that nothing touched the node in this batch (no look-up needed)
@@ -160,21 +161,20 @@ __device__ __forceinline__ WaveBatch take_batch_wave(uint64_t& t0, uint64_t& t1,
     return b;
 }
 // key of the NIC pool the lanes flagged `in` form (pool_key_packed over their classes)
-__device__ __forceinline__ uint64_t pool_key_wave(uint32_t glimit, bool in, uint32_t my_cls) {
+__device__ __forceinline__ uint64_t pool_key_wave(uint32_t glimit, bool in, uint32_t my_cls, uint32_t ncls) {
     uint64_t k = (uint64_t)(glimit & 0xFFu) << 48;
-#pragma unroll
-    for (uint32_t c = 0; c < (uint32_t)NHDFIT_MAX_CLASSES; ++c) {
+    for (uint32_t c = 0; c < ncls; ++c) {                                 // (classes the dictionary does not hold count zero)
         const uint32_t n = (uint32_t)__popcll(__ballot(in && my_cls == c));
         k |= (uint64_t)(n > (uint32_t)kMaxG ? (uint32_t)kMaxG : n) << (3 * c);
     }
     return k;
 }
-__device__ __forceinline__ void sig_keys_wave(const nhdfit_detail& d, uint32_t u, uint32_t lane, uint64_t& key_numa, uint64_t& key_pci) {
+__device__ __forceinline__ void sig_keys_wave(const nhdfit_detail& d, uint32_t u, uint32_t lane, uint32_t ncls, uint64_t& key_numa, uint64_t& key_pci) {
     key_numa = key_pci = 0;
     const uint32_t n = d.nic_cnt[u];
     const bool valid = lane < n;
     const uint32_t my_cls = valid ? d.nic_cls[u][lane & 15u] : 0xFFu, my_sw = valid ? d.nic_sw[u][lane & 15u] : 0xFFu;
-    if (n) key_numa = sig_key_add(0, pool_key_wave(NHDFIT_GLIMIT_NONE, valid, my_cls));
+    if (n) key_numa = sig_key_add(0, pool_key_wave(NHDFIT_GLIMIT_NONE, valid, my_cls, ncls));
     uint64_t todo = __ballot(valid);                                      // NICs whose switch has not been turned into a pool yet
     while (todo) {
         const uint32_t k = (uint32_t)__builtin_ctzll(todo);
@@ -183,12 +183,12 @@ __device__ __forceinline__ void sig_keys_wave(const nhdfit_detail& d, uint32_t u
         todo &= ~same;
         const uint32_t gl = d.sw_free[sw] > kMaxG ? kMaxG : d.sw_free[sw];
         if (!gl) continue;                                                // no free GPU behind it: the pool hosts nothing
-        key_pci = sig_key_add(key_pci, pool_key_wave(gl, valid && my_sw == sw, my_cls));
+        key_pci = sig_key_add(key_pci, pool_key_wave(gl, valid && my_sw == sw, my_cls, ncls));
     }
 }
 // `s` / `d` / `out` live in LDS (one copy per wavefront); every lane returns the same status
 __device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, const nhdfit_mapping& m, double busy_time,
-                                                const SigTable& sigs, nhdfit_placement& out, uint32_t lane) {
+                                                const SigTable& sigs, uint32_t ncls, nhdfit_placement& out, uint32_t lane) {
     const int G = (int)r.n_groups;
     int status = kCommitOk;
     {   // the placement record: zeros, 0xFF for the GPU list and the NUMA entries (bytes 144 .. 180 of the 256)
@@ -256,7 +256,7 @@ __device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, 
         if (!(u ? claimed1 : claimed0) && !gpu_taken) continue;
         uint64_t kn, kp;
         uint32_t idn = 0, idp = 0;
-        sig_keys_wave(d, u, lane, kn, kp);
+        sig_keys_wave(d, u, lane, ncls, kn, kp);
         if (!sig_lookup(sigs, kn, idn) || !sig_lookup(sigs, kp, idp)) { if (status == kCommitOk) status = kCommitNewSig; }
         if (lane == 0) { s.p3.sig_numa[u] = (uint16_t)idn; s.p3.sig_pci[u] = (uint16_t)idp; }
     }
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         if (touch) note_first_touch(a, v, st, dd, lane, true);
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) { res.node = (int64_t)a.global_base + (int64_t)v; res.map = ok ? mp : nhdfit_mapping{}; }
-        if (ok) status = commit_node_wave(st, dd, rq, mp, a.now, sigs, pl, lane);
+        if (ok) status = commit_node_wave(st, dd, rq, mp, a.now, sigs, q.ncls, pl, lane);
         else {                                                            // the row said feasible, the mapping disagrees: cannot happen
             if (lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&pl)[lane] = 0u;
             __builtin_amdgcn_wave_barrier();
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             }
             const uint32_t mine = e;
             const uint32_t pos = a.order[mine];
-            if (lane < sizeof(nhdfit_req) / 16) {
+            if (pool_n && lane < sizeof(nhdfit_req) / 16) {                // (the driver never reads the request of a pod with GPUs)
                 const uint4 v4 = reinterpret_cast<const uint4*>(a.reqs + pos)[lane];
                 uint32_t* dst = reinterpret_cast<uint32_t*>(&s_req[slot]) + lane * 4;
                 dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;
