@@ -1206,6 +1206,8 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         DecideArgs qa;
         memset(&qa, 0, sizeof qa);
         qa.list_n = c->seq_tn.p; qa.n_n = n_n; qa.list_g = c->seq_tn.p + n_n; qa.n_g = n_g; qa.queue_len = queue_len; qa.ncls = c->ncls;
+        static const uint32_t hint_distance = tune_env("NHDFIT_HINT_DISTANCE") ? (uint32_t)atoi(tune_env("NHDFIT_HINT_DISTANCE")) : kHintDistance;   // tuning aid
+        qa.hint_distance = hint_distance;
         qa.s = sa; qa.queue = c->seq_queue.p; qa.ctrl = c->seq_ctrl.p; qa.mat = c->seq_mat.p; qa.flags = c->seq_flags.p;
         size_t dyn = lds_slice((size_t)chunks * 8);
         const size_t sig_bytes = lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4);

@@ -34,12 +34,13 @@ struct DecideArgs {
     const uint32_t* list_g; uint32_t n_g;   // every other pod
     uint32_t queue_len;          // entries of `queue`
     uint32_t ncls;               // NIC capacity classes of the dictionary
+    uint32_t hint_distance;      // see kHintDistance
 };
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 constexpr unsigned long long kItemValid = 1ull << 63, kItemPatch = 1ull << 62;
 // tiles (of those that hold GPU-less pods) one patch item covers: a committed node's column is re-evaluated by up to three
 // worker wavefronts at once
-__host__ __device__ inline uint32_t patch_span(uint32_t ngl) { return ngl <= 24u ? 8u : (ngl + 2u) / 3u; }   // at most three items per commit
+__host__ __device__ inline uint32_t patch_span(uint32_t ngl) { return ngl <= 24u ? 8u : ngl; }   // (many tiles: one item - the workers are the bottleneck then)
 
 // first-touch copy of a node for apply = 0 (whole wavefront), as in k_seq
 // known_fresh: the caller knows that nothing touched the node in this batch (no look-up needed)
@@ -266,8 +267,8 @@ __device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, 
     return status;
 }
 
-constexpr int kDecideWaves = 16, kDecideRing = 32, kDecideCache = 16, kWorkerBlocks = 8;
-constexpr uint32_t kHintDistance = 3;     // a GPU-less pod's window is read when at most this many GPU-less pods before it are still undecided:
+constexpr int kDecideWaves = 16, kDecideRing = 32, kDecideCache = 16, kWorkerBlocks = 12;
+constexpr uint32_t kHintDistance = 2;     // a GPU-less pod's window is read when at most this many GPU-less pods before it are still undecided:
                                           // the column patches of the earlier commits have mostly landed by then (every stale bit costs a failed
                                           // verification), and the pods with GPUs in between leave the fetcher the time it needs
 constexpr uint32_t kSpinLimit = 1u << 22;                      // x ~100 cycles of s_sleep: a fraction of a second, then give up
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             uint32_t wb = 0;
             const unsigned long long score_a = a.score[pos];
             if (pool_n && score_a)                                        // (j = the number of GPU-less pods before this one)
-                for (uint32_t spin = 0; j > wg_load(&s_done_tn) + kHintDistance; ++spin) {
+                for (uint32_t spin = 0; j > wg_load(&s_done_tn) + q.hint_distance; ++spin) {
                     if (spin > kSpinLimit || wg_load(&s_abort)) return;
                     __builtin_amdgcn_s_sleep(1);
                 }
