@@ -1108,7 +1108,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, c->seq_out.reserve(P));
         HIPCHK(c, c->seq_place.reserve(P));
         HIPCHK(c, c->order.reserve(P));
-        HIPCHK(c, c->seq_ctrl.reserve(32));
+        HIPCHK(c, c->seq_ctrl.reserve(16));
         HIPCHK(c, c->seq_mat.reserve(c->n ? c->n : 1));
         HIPCHK(c, c->seq_flags.reserve(4));
         HIPCHK(c, c->seq_tn.reserve(P));
@@ -1187,7 +1187,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     bool fast = !c->seq_general && (size_t)chunks * 8 <= 64 * 1024 && c->n > 0 && P < (1u << 28);
     if (fast) {
         // The decision engine (seq2_kernel.h): one block decides, the rest of the grid commits.
-        HIPCHK(c, hipMemsetAsync(c->seq_ctrl.p, 0, 32 * sizeof(uint32_t), sm));
+        HIPCHK(c, hipMemsetAsync(c->seq_ctrl.p, 0, 16 * sizeof(uint32_t), sm));
         HIPCHK(c, hipMemsetAsync(c->seq_mat.p, 0, (size_t)c->n * sizeof(uint32_t), sm));
         c->tn_host.resize(P);                                   // [the pods without GPUs | every other pod], caller's indices ascending
         uint32_t n_n = 0, n_g = 0;
@@ -1208,6 +1208,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         qa.list_n = c->seq_tn.p; qa.n_n = n_n; qa.list_g = c->seq_tn.p + n_n; qa.n_g = n_g; qa.queue_len = queue_len; qa.ncls = c->ncls;
         static const uint32_t hint_distance = tune_env("NHDFIT_HINT_DISTANCE") ? (uint32_t)atoi(tune_env("NHDFIT_HINT_DISTANCE")) : kHintDistance;   // tuning aid
         qa.hint_distance = hint_distance;
+        qa.dbg = tune_env("NHDFIT_SEQ_SKIP") ? (uint32_t)atoi(tune_env("NHDFIT_SEQ_SKIP")) : 0u;
         qa.s = sa; qa.queue = c->seq_queue.p; qa.ctrl = c->seq_ctrl.p; qa.mat = c->seq_mat.p; qa.flags = c->seq_flags.p;
         size_t dyn = lds_slice((size_t)chunks * 8);
         const size_t sig_bytes = lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4);
@@ -1223,14 +1224,12 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, hipMemcpyAsync(flags, c->seq_flags.p, sizeof flags, hipMemcpyDeviceToHost, sm));
         HIPCHK(c, hipStreamSynchronize(sm));
         if (tune_env("NHDFIT_SEQ_PROF")) {
-            uint32_t ctl[32];
+            uint32_t ctl[16];
             HIPCHK(c, hipMemcpy(ctl, c->seq_ctrl.p, sizeof ctl, hipMemcpyDeviceToHost));
             fprintf(stderr, "[nhdfit] k_decide: %u queue items; GPU-less pods: %u verifications failed, %u looked at a node in LDS, %u at a published one, "
                             "%u at an untouched one, %u window rescans\n", ctl[1] ? ctl[1] - 1 : 0, ctl[4], ctl[8], ctl[5], ctl[6], ctl[7]);
             fprintf(stderr, "[nhdfit] k_decide driver: waiting for fetchers %.2f ms, pods with GPUs %.2f ms, GPU-less pods: node state %.2f ms, verify + commit %.2f ms, "
                             "publish %.2f ms\n", ctl[9] * 1e-5, ctl[10] * 1e-5, ctl[11] * 1e-5, ctl[12] * 1e-5, ctl[13] * 1e-5);
-            fprintf(stderr, "[nhdfit] k_decide verify + commit: mapping %.2f ms, first-touch copy %.2f ms, commit %.2f ms, result + node stores %.2f ms\n",
-                    ctl[14] * 1e-5, ctl[15] * 1e-5, ctl[16] * 1e-5, ctl[17] * 1e-5);
         }
         if (flags[1] || flags[3]) {
             // a NIC state without a signature id (or a wait that ran out): start over with the kernel whose stop / intern /

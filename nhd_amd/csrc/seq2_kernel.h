@@ -35,6 +35,7 @@ struct DecideArgs {
     uint32_t queue_len;          // entries of `queue`
     uint32_t ncls;               // NIC capacity classes of the dictionary
     uint32_t hint_distance;      // see kHintDistance
+    uint32_t dbg;                // tuning aid (NHDFIT_SEQ_SKIP, tuning build; results are wrong with it): 1 no first-touch copy, 2 no commit, 4 no result / node stores
 };
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 constexpr unsigned long long kItemValid = 1ull << 63, kItemPatch = 1ull << 62;
@@ -330,10 +331,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     //   touch: 0 = the node was touched before in this batch, 1 = never (first-touch copy without a look-up)
     //   nic_tab: optional per-signature NIC masks of this pod (low half NUMA 0, high half NUMA 1), fetched ahead into LDS
     auto map_commit = [&](const nhdfit_req& rq, NodeState& st, nhdfit_detail& dd, uint32_t pos, uint32_t mine, uint32_t v, bool verify, int touch,
-                          const uint32_t* nic_tab, const SigTable& sigs, const MapTables& mt, SeqResult& res, nhdfit_placement& pl, int32_t& status,
-                          unsigned long long* tp = nullptr) -> bool {
-        unsigned long long tq = tp ? wall_clock64() : 0ull;
-        auto tick = [&](int k) { if (tp) { const unsigned long long t = wall_clock64(); tp[k] += t - tq; tq = t; } };
+                          const uint32_t* nic_tab, const SigTable& sigs, const MapTables& mt, SeqResult& res, nhdfit_placement& pl, int32_t& status) -> bool {
         bool ok = !verify || rq.hugepages_gb <= st.p2.hp_free;            // nhd/Matcher.py:78
         if (ok && verify) {                                               // cheap necessary condition before the table look-ups: enough free
             const bool smt = (st.p2.flags & NHDFIT_NF_SMT) != 0;          // physical cores on the node as a whole
@@ -350,13 +348,12 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             ok = map_on_state_wave(rq, st, dd, s_caps, bits, mt, lane, mp);
         }
         __builtin_amdgcn_wave_barrier();
-        tick(0);
         if (!ok && verify) return false;
-        if (touch) note_first_touch(a, v, st, dd, lane, true);
+        if (touch && !(kTuning && (q.dbg & 1))) note_first_touch(a, v, st, dd, lane, true);
         __builtin_amdgcn_wave_barrier();
-        tick(1);
         if (lane == 0) { res.node = (int64_t)a.global_base + (int64_t)v; res.map = ok ? mp : nhdfit_mapping{}; }
-        if (ok) status = commit_node_wave(st, dd, rq, mp, a.now, sigs, q.ncls, pl, lane);
+        if (ok && kTuning && (q.dbg & 2)) status = kCommitOk;
+        else if (ok) status = commit_node_wave(st, dd, rq, mp, a.now, sigs, q.ncls, pl, lane);
         else {                                                            // the row said feasible, the mapping disagrees: cannot happen
             if (lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&pl)[lane] = 0u;
             __builtin_amdgcn_wave_barrier();
@@ -366,11 +363,10 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         if (lane == 0) { res.status = status; if (status == kCommitNewSig) q.flags[1] = 1u; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        tick(2);
+        if (kTuning && (q.dbg & 4)) return true;
         if (lane < sizeof(SeqResult) / 4) reinterpret_cast<uint32_t*>(&a.out[mine])[lane] = reinterpret_cast<const uint32_t*>(&res)[lane];
         if (a.place && lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&a.place[mine])[lane] = reinterpret_cast<const uint32_t*>(&pl)[lane];
         store_node_lds(a, v, &st, &dd, lane);
-        tick(3);
         return true;
     };
     auto publish = [&](uint32_t v, int32_t status) {                      // the node's new state is in global memory: tell the driver
@@ -541,7 +537,6 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                                                                           // by then its stores have landed and the fence costs nothing
     uint32_t c_fail = 0, c_wait = 0, c_plain = 0, c_rescan = 0, c_hit = 0;     // tuning aid: what the GPU-less pods cost (ctrl[4..8])
     unsigned long long t_ready = 0, t_gpu = 0, t_state = 0, t_verify = 0, t_publish = 0, t_last = wall_clock64();   // 100 MHz ticks (ctrl[9..13])
-    unsigned long long t_mc[4] = {0, 0, 0, 0};                            // inside map_commit: map, first touch, commit, stores (ctrl[14..17])
     auto lap = [&](unsigned long long& acc) { const unsigned long long t = wall_clock64(); acc += t - t_last; t_last = t; };
     bool stop = false;
     auto give_up = [&]() { stop = true; if (lane == 0) { q.flags[3] = 1u; wg_store(&s_abort, 1u); } };
@@ -649,7 +644,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 }
                 lap(t_state);
                 int32_t status = 0;
-                const bool ok = map_commit(rq, *st, *dd, pos, mine, v, true, taken ? 0 : 1, s_nicn[slot] ? s_nic[slot] : nullptr, sigs, mt, s_wres[0], s_wplace[0], status, t_mc);
+                const bool ok = map_commit(rq, *st, *dd, pos, mine, v, true, taken ? 0 : 1, s_nicn[slot] ? s_nic[slot] : nullptr, sigs, mt, s_wres[0], s_wplace[0], status);
                 lap(t_verify);
                 if (!ok) {                                                // stale hint: not this node (any more)
                     ++c_fail;
@@ -684,7 +679,6 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     if (lane == 0) {
         q.ctrl[4] = c_fail; q.ctrl[5] = c_wait; q.ctrl[6] = c_plain; q.ctrl[7] = c_rescan; q.ctrl[8] = c_hit;
         q.ctrl[9] = (uint32_t)t_ready; q.ctrl[10] = (uint32_t)t_gpu; q.ctrl[11] = (uint32_t)t_state; q.ctrl[12] = (uint32_t)t_verify; q.ctrl[13] = (uint32_t)t_publish;
-        for (int k = 0; k < 4; ++k) q.ctrl[14 + k] = (uint32_t)t_mc[k];
         wg_store(&s_done, n_pods);                                        // the fetchers run out
         __hip_atomic_store(&q.ctrl[1], n_items + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the workers leave once the queue is drained
     }
