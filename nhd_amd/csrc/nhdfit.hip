@@ -1184,7 +1184,17 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     };
 
     uint32_t decided = 0;                                       // pods [0, decided) of the caller's order are decided
-    bool fast = !c->seq_general && (size_t)chunks * 8 <= 64 * 1024 && c->n > 0 && P < (1u << 28);
+    // The decision engine pays off when most pods request GPUs (their decisions are bitmap picks, their commits run on the whole
+    // chip); a batch of mostly GPU-less pods is one long chain either way, and the round-based kernel walks that a little faster
+    // (config 2: 85 k against 74 k decisions/s, profiles/r03).
+    uint32_t n_gpu_less = 0;
+    for (uint32_t i = 0; i < P; ++i) {
+        uint32_t g = 0;
+        if (req_valid(reqs[i])) for (uint32_t k = 0; k < reqs[i].n_groups; ++k) g += reqs[i].gpus[k];
+        n_gpu_less += req_valid(reqs[i]) && g == 0;
+    }
+    static const bool force_decide = tune_env("NHDFIT_SEQ_DECIDE") != nullptr;      // tuning aid
+    bool fast = !c->seq_general && (size_t)chunks * 8 <= 64 * 1024 && c->n > 0 && P < (1u << 28) && (force_decide || 2u * n_gpu_less <= P);
     if (fast) {
         // The decision engine (seq2_kernel.h): one block decides, the rest of the grid commits.
         HIPCHK(c, hipMemsetAsync(c->seq_ctrl.p, 0, 16 * sizeof(uint32_t), sm));
