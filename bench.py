@@ -198,6 +198,12 @@ def main():
         out["score_only"] = score_only(eng, reqs, now, args.pods, n_total)     # last: it changes the context's outputs
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not inner:
         out["cpu_baseline"] = cpu_baseline(spec, tops, pod_groups, args.cpu_sample_pods, score, lo, winner_index, args)
+    if world > 1 and not strong and not args.no_extras:
+        # BASELINE.json's own multi-GPU shapes ride along (strong scaling: the cluster is fixed, the shards shrink), so that one
+        # run per N yields both curves: config 4's 65 536 nodes x 4 096 pods at every N, config 5's 262 144 x 16 384 at N = 8
+        legs = [(4, 65536, 4096)] + ([(5, 262144, 16384)] if world == 8 else [])
+        out["strong_scaling"] = [strong_leg(cfg, total, P, world, rank, local_rank, dist, min(args.steps, 400), min(args.warmup, 400))
+                                 for cfg, total, P in legs]
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
@@ -205,6 +211,50 @@ def main():
         dist.barrier()
         eng.comm_destroy()
         dist.destroy_process_group()
+
+
+def strong_leg(cfg, total_nodes, P, world, rank, local_rank, dist, steps, warmup):
+    """One of BASELINE.json's multi-GPU configurations: `total_nodes` sharded contiguously over the ranks, pods replicated,
+    one all-reduce(max) of the packed scores per step.  Same protocol as the headline: warm-up, barrier, K steps, barrier,
+    MAX of the ranks' times."""
+    import torch
+    from nhd_amd import pack
+    from nhd_amd.engine import Engine
+    from workload import planes, refmodel, synth
+    per = (total_nodes + world - 1) // world
+    lo, hi = rank * per, min(total_nodes, (rank + 1) * per)
+    spec = synth.make_cluster(cfg, n_nodes=total_nodes).shard(lo, hi)
+    pods, groups = synth.make_pods(cfg, n_pods=P)
+    tops = [refmodel.make_topology(s) for s in pods]
+    pk = pack.Packer()
+    table = planes.planes_from_spec(pk, spec)
+    reqs = pk.digest_many(tops, groups)
+    eng = Engine(local_rank)
+    eng.set_dictionary(pk)
+    eng.upload(table, global_base=lo)
+    uid = [eng.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    eng.comm_init(world, rank, uid[0])
+    eng.stage(reqs)
+    for _ in range(warmup):
+        eng.enqueue(spec.clock_now)
+    eng.sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.enqueue(spec.clock_now)
+    eng.sync()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    score, _, _ = eng.fetch(want_bitmap=False, want_map=True)
+    dist.barrier()
+    eng.comm_destroy()
+    eng.close()
+    return {"config": cfg, "nodes_total": total_nodes, "nodes_per_gpu": per, "pods": P, "n_gpus": world, "scaling": "strong",
+            "ms_per_step": dt * 1e3 / steps, "evals_per_s": float(P) * total_nodes * steps / dt,
+            "snapshot_decisions_per_s": P * steps / dt, "placed_pods": int(np.count_nonzero(score))}
 
 
 def roofline(st, fit_ms, achieved, traffic, traffic_source, valu, counters, pipes=1, ms_per_step=None):
