@@ -67,6 +67,60 @@ def test_two_rank_sharding_equals_single_shard(tmp_path, cfg, n, P):
     assert np.count_nonzero(want_score) > 0
 
 
+def _worker_mode_b(rank, world, port, cfg, n, P, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec, tops, groups = _problem(cfg, n, P)
+    lo, hi = shard.shard_bounds(n, world, rank)
+    sub = spec.shard(lo, hi)
+    pk = pack.Packer()
+    table = planes.planes_from_spec(pk, sub)
+    reqs = pk.digest_many(tops, groups)
+    pk.close_signatures()
+    eng = harness.HarnessEngine(0)
+    eng.set_dictionary(pk)
+    eng.upload(table, global_base=lo)
+    bits = np.zeros(((hi - lo + 63) // 64) * 64, np.uint8)
+    bits[:hi - lo] = (sub.n_gpus == 0)
+    nogpu = np.packbits(bits, bitorder="little").view(np.uint64).copy()
+    node, maps, places, status = shard.schedule_batch_sharded(eng, reqs, spec.clock_now, pk, nogpu, dist, apply=True)
+    np.save(os.path.join(out_dir, f"node{rank}.npy"), node)
+    np.save(os.path.join(out_dir, f"maps{rank}.npy"), maps.view(np.int8))
+    np.save(os.path.join(out_dir, f"places{rank}.npy"), places.view(np.uint8))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg,n,P,world", [(4, 640, 200, 2), (5, 900, 260, 3), (2, 256, 120, 2)])
+def test_mode_b_one_process_per_shard_equals_the_scheduler_loop(tmp_path, cfg, n, P, world):
+    """nhd_amd.sharding.schedule_batch_sharded under gloo (host twin per shard): every rank ends up with the decisions,
+    mappings and physical ids the oracle's one-by-one loop over the WHOLE cluster produces."""
+    from oracle import nhd_oracle as O
+    port = _free_port()
+    mp.spawn(_worker_mode_b, args=(world, port, cfg, n, P, str(tmp_path)), nprocs=world, join=True)
+    spec, tops, groups = _problem(cfg, n, P)
+    nl = spec.build_nodes()
+    names = list(nl)
+    ids = []
+    want = O.schedule_sequence(nl, tops, groups, spec.clock_now, ids_out=ids)
+    want_node = np.array([-1 if r[0] is None else names.index(r[0]) for r in want], np.int64)
+    pk = pack.Packer()
+    reqs = pk.digest_many(tops, groups)
+    for rank in range(world):
+        node = np.load(tmp_path / f"node{rank}.npy")
+        assert np.array_equal(node, want_node), rank
+        maps = np.load(tmp_path / f"maps{rank}.npy").view(pack.MAPPING).reshape(-1)
+        places = np.load(tmp_path / f"places{rank}.npy").view(pack.PLACEMENT).reshape(-1)
+        for i, (r, wid) in enumerate(zip(want, ids)):
+            if r[0] is None:
+                continue
+            G = int(reqs[i]["n_groups"])
+            assert tuple(int(x) for x in maps[i]["gpu"][:G]) == tuple(r[1]["gpu"]) and tuple(int(x) for x in maps[i]["cpu"][:G + 1]) == tuple(r[1]["cpu"])
+            phys = int(spec.phys[want_node[i]])
+            assert pack.expand_placement(places[i], G, phys // 2, phys, [int(reqs[i]["gpus"][g]) for g in range(G)]) == wid, (rank, i)
+    assert (want_node >= 0).sum() >= 20
+
+
 def test_order_preserving_score_encoding():
     rng = np.random.default_rng(0)
     s = rng.integers(0, 2 ** 64, size=1000, dtype=np.uint64)
