@@ -136,6 +136,7 @@ struct Pipe {                            // one software pipeline of steps: its 
     DevBuf<uint64_t> nm;                 // node-major verdict words [tiles][chunks*64] (one buffer per pipe: its fit roles run in stream order)
     DevBuf<unsigned long long> shape_keys[kBufs]; DevBuf<uint32_t> shape_res[kBufs]; DevBuf<int32_t> shape_slot[kBufs];   // mapping dedup tables
     DevBuf<uint32_t> shape_list[kBufs];  // distinct shapes per tile
+    DevBuf<uint32_t> dig_count;          // [tiles] arrival counters of the digest blocks that share a tile's signature rows (zero between launches)
 };
 
 }  // namespace
@@ -379,7 +380,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->reqs.release(); c->bitmap.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_queue.release(); c->seq_ctrl.release(); c->seq_mat.release(); c->seq_flags.release(); c->seq_tn.release(); c->sig_keys.release(); c->sig_ids.release();
     for (Pipe& p : c->pipe) {
-        p.nm.release();
+        p.nm.release(); p.dig_count.release();
         for (int b = 0; b < kBufs; ++b) {
             p.hdr[b].release(); p.tabs[b].release(); p.score[b].release(); p.maps[b].release();
             p.shape_keys[b].release(); p.shape_res[b].release(); p.shape_slot[b].release(); p.shape_list[b].release();
@@ -609,6 +610,10 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     if (hp_max > kMaxHpRows - 2)
         return fail(c, NHDFIT_E_LIMIT, "a pod asks for %d GiB of hugepages (limit %d)", hp_max, kMaxHpRows - 2);
     HIPCHK(c, c->reqs.reserve(P));
+    for (Pipe& p : c->pipe) {
+        HIPCHK(c, p.dig_count.reserve(tiles));
+        HIPCHK(c, hipMemsetAsync(p.dig_count.p, 0, (size_t)tiles * sizeof(uint32_t), c->stream));
+    }
     for (Pipe& p : c->pipe)
         for (int b = 0; b < kBufs; ++b) {
             HIPCHK(c, p.hdr[b].reserve((size_t)tiles * kTile));
@@ -839,7 +844,12 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
         d.xcls = c->xcls.p; d.nx = c->xnx.p;
         static const uint32_t wc_parts = tune_env("NHDFIT_WC_PARTS") && atoi(tune_env("NHDFIT_WC_PARTS")) >= 1 ? (uint32_t)atoi(tune_env("NHDFIT_WC_PARTS")) : kWcPartsDefault;   // tuning aid
         d.wc_parts = wc_parts;
-        a.nb_digest = tiles * (1 + wc_parts);
+        // large dictionaries (config 5: 151 signatures, 272 with their successors under claims): the signature rows of a tile are
+        // shared by up to four blocks - the digest was twice the fit role there
+        static const uint32_t force_sp = tune_env("NHDFIT_SIG_PARTS") ? (uint32_t)atoi(tune_env("NHDFIT_SIG_PARTS")) : 0u;   // tuning aid
+        d.sig_parts = force_sp ? force_sp : std::min(4u, std::max(1u, (c->nsig + 63u) / 64u));
+        d.count = p.dig_count.p;
+        a.nb_digest = tiles * (d.sig_parts + wc_parts);
     }
     uint32_t nb_fit = 0;
     int bf = -1;

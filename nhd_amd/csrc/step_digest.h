@@ -55,6 +55,9 @@ struct DigestArgs {
     const uint64_t* xcls;            // interned (NUMA, free GPUs, signature) classes of the mirror: key of X row k
     const uint32_t* nx;              // number of classes
     uint32_t wc_parts;               // blocks per tile that share its CPU rows (free-core count c = part mod wc_parts)
+    uint32_t sig_parts;              // blocks per tile that share its NIC signature rows (signature = part mod sig_parts; 1 for small
+                                     // dictionaries); the last of them to finish derives the X rows
+    uint32_t* count;                 // [tiles] arrival counters of those blocks, zero before and after a launch
 };
 constexpr uint32_t kDictLdsWords = 6144;             // 12 KB for the staged signature stream (c5: 151 signatures = 1.5 K words)
 constexpr size_t kDigestLds = lds_slice(kTile * sizeof(PaddedReq)) + lds_slice(kTile * sizeof(PodSums)) +
@@ -74,8 +77,11 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
     PodHeader* s_hdr = carve<PodHeader>(lds, kTile);
     uint16_t* s_flat = carve<uint16_t>(lds, kDictLdsWords);
 
-    const uint32_t tile = blk / (1 + a.wc_parts), part = blk % (1 + a.wc_parts);
+    // blocks of a tile: sig_parts blocks for the GPU / NIC rows (part 0), then wc_parts blocks for the CPU rows (parts 1 ..)
+    const uint32_t per_tile = a.sig_parts + a.wc_parts, tile = blk / per_tile, idx = blk % per_tile;
+    const uint32_t part = idx < a.sig_parts ? 0u : idx - a.sig_parts + 1u, sig_part = idx < a.sig_parts ? idx : 0u;
     const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t s_last;
     uint8_t* img = a.tabs + (size_t)tile * a.pitch;
 
     stage_requests_lds<THREADS>(a.reqs, tile * kTile, a.P, s_req);
@@ -89,7 +95,7 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
         PodSums& ps = s_sum[tid];
         ps.G = r.n_groups; ps.W = 1u << (r.n_groups & 7u); ps.full = ps.W - 1;
         ps.misc_smt = r.misc_smt; ps.misc_nosmt = r.misc_nosmt;
-        if (part == 0) {
+        if (part == 0 && sig_part == 0) {
             const uint32_t pod = tile * kTile + tid;
             a.hdr[pod] = h;
             if (pod < a.P) a.score[pod] = 0;
@@ -196,7 +202,7 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
             if (s_hdr[j].flags & kPodValid) class_cover_w<WW>(s_req[j].r, a.d.caps[c], s_sum[j].W, s_sum[j].G, s_cover[j][c]);
         }
         __syncthreads();
-        for (uint32_t sig = wave; sig < L.nsig; sig += NW) {    // one reach family per (signature, pod), both sockets' rows from it
+        for (uint32_t sig = sig_part * NW + wave; sig < L.nsig; sig += a.sig_parts * NW) {    // one reach family per (signature, pod), both sockets' rows from it
             uint32_t reach = 0;
             if (staged) {
                 // the record is read with the same address in every lane (LDS broadcast); readfirstlane hands the loop
@@ -227,13 +233,32 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
     else if (W == 4) covers_and_sig_rows(std::integral_constant<uint32_t, 4>{});
     else if (W == 8) covers_and_sig_rows(std::integral_constant<uint32_t, 8>{});
     else covers_and_sig_rows(std::integral_constant<uint32_t, 16>{});
-    for (uint32_t k = wave; k < 2 * L.fg_dim; k += NW) {
-        const uint32_t u = k >= L.fg_dim, f = u ? k - L.fg_dim : k;
-        emit_row(img + (u ? L.off_a1 : L.off_a0) + f * L.row, valid ? entry_a(s_sum[lane], u, f) : 0u);
-    }
-    __syncthreads();                                            // the block reads back the cold rows it just wrote
+    if (sig_part == 0)
+        for (uint32_t k = wave; k < 2 * L.fg_dim; k += NW) {
+            const uint32_t u = k >= L.fg_dim, f = u ? k - L.fg_dim : k;
+            emit_row(img + (u ? L.off_a1 : L.off_a0) + f * L.row, valid ? entry_a(s_sum[lane], u, f) : 0u);
+        }
+    // The X rows need every cold row of the tile.  One block per tile: a barrier.  Several (large dictionaries - config 5
+    // has 151 signatures and as many again under claims): each block publishes its rows and takes a ticket; the last one
+    // to arrive derives the X rows (reading the others' rows past its own L1) and leaves the counter at zero.
+    if (a.sig_parts > 1) {
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t t = atomicAdd(&a.count[tile], 1u);
+            s_last = t == a.sig_parts - 1u ? 1u : 0u;
+            if (s_last) a.count[tile] = 0u;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+    } else __syncthreads();                                     // the block reads back the cold rows it just wrote
     // hot rows X[class] = A_u[f] & (PCI-mode pods: R_u[sigPCI], NUMA-mode pods: R_u[sigNUMA]) - pure word
     // operations on the cold rows, one lane per (class, assignment)
+    auto cold64 = [&](const uint8_t* base, uint32_t off) {
+        const uint64_t* ptr = reinterpret_cast<const uint64_t*>(base + off);
+        return a.sig_parts > 1 ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
+    };
     const uint64_t m_pci = __ballot((s_hdr[lane].flags & kPodPci) != 0);
     const uint32_t nx = a.nx[0] < L.x_cap ? a.nx[0] : L.x_cap;
     for (uint32_t i = tid; i < nx * W; i += THREADS) {
@@ -241,8 +266,8 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
         const uint64_t key = a.xcls[k];
         const uint32_t u = xkey_u(key);
         const uint8_t* rbase = img + (u ? L.off_r1 : L.off_r0) + p * 8;
-        const uint64_t av = ld64(img, (u ? L.off_a1 : L.off_a0) + xkey_f(key) * L.row + p * 8);
-        const uint64_t rn = ld64(rbase, xkey_sig_numa(key) * L.row), rp = ld64(rbase, xkey_sig_pci(key) * L.row);
+        const uint64_t av = cold64(img, (u ? L.off_a1 : L.off_a0) + xkey_f(key) * L.row + p * 8);
+        const uint64_t rn = cold64(rbase, xkey_sig_numa(key) * L.row), rp = cold64(rbase, xkey_sig_pci(key) * L.row);
         *reinterpret_cast<uint64_t*>(hot + L.hot_x + k * L.x_stride + p * 8) = av & ((rp & m_pci) | (rn & ~m_pci));
     }
 }
