@@ -233,6 +233,7 @@ class HipMatcher:
             self._flush_deltas()                               # releases queued before this commit reach the device first
             if node.name in self._dirty_strict:
                 return False
+        from_batch = bool(pending)
         if pending:                                            # ScheduleBatch(apply=True) committed this placement on the device already
             ids = pending.pop(0)
             if not pending:
@@ -255,7 +256,11 @@ class HipMatcher:
                 numa, idx = mapping["nic"][gi]
                 claim.add(next(k for k, n in enumerate(node.nics) if n.idx == idx and n.numa_node == numa))
         self._claims[node.name] = frozenset(claim)             # the device already zeroed these NICs' capacities
-        left = self._reasons.get(node.name, set()) - {"busy_time", "SetBusy"}    # SetBusy marked it: the commit carried the busy time
+        # SetBusy marked the node.  A commit made for this very call carried the node's busy time; a placement the device
+        # committed earlier inside a batch carried the batch's `now` - the busy time SetBusy wrote since (time.monotonic(),
+        # nhd/Node.py:843-845) then follows as a delta of its own
+        carried = set() if from_batch else {"busy_time", "SetBusy"}
+        left = self._reasons.get(node.name, set()) - carried
         if left:
             self._reasons[node.name] = left                    # cordon / maintenance / groups written earlier still go out as deltas
         else:
@@ -485,6 +490,14 @@ class HipMatcher:
                     known = True
                 except KeyError:                           # names the attached dict does not hold: stateless for this call
                     known = False
+        if self._batch_ids:
+            # placements of an earlier ScheduleBatch(apply=True) the caller never applied to its node objects: the mirror holds
+            # commits the objects do not - those nodes are re-packed from their objects
+            for name in list(self._batch_ids):
+                nd = self._attached.get(name) if self._attached is not None else None
+                if nd is not None:
+                    self._mark(nd, "unapplied-batch")
+            self._batch_ids.clear()
         if known:
             self._flush_dirty()
         else:

@@ -184,3 +184,19 @@ def test_requests_beyond_the_record_and_device_errors_answer_none(caplog):
     assert "device path failed" in caplog.text
     with pytest.raises(NhdFitError):
         HipMatcher(clock=lambda: util.CLOCK, engine_factory=Broken, strict=True).FindNode(nl, ok)
+
+
+def test_batch_placements_never_applied_do_not_stay_in_the_mirror():
+    """ScheduleBatch(apply=True) commits on the device; if the caller never applies those placements to its node
+    objects, the next call must see the objects' state again (the nodes are re-packed), not the orphaned commits."""
+    spec = synth.make_cluster(3, n_nodes=48)
+    nl = spec.build_nodes()
+    pods, groups = synth.make_pods(3, n_pods=24)
+    tops = [refmodel.make_topology(s) for s in pods]
+    m = HipMatcher(clock=lambda: spec.clock_now, engine_factory=harness.HarnessEngine)
+    m.attach(nl)
+    before = [norm(O.find_node(nl, t, spec.clock_now)) for t in tops]
+    got = m.ScheduleBatch(nl, tops, apply=True)
+    assert sum(r[0] is not None for r in got) >= 5 and m._batch_ids
+    assert [norm(r) for r in m.FindNodes(nl, tops)] == before          # objects untouched -> same answers as before the batch
+    assert not m._batch_ids
