@@ -62,7 +62,8 @@ struct DigestArgs {
 constexpr uint32_t kDictLdsWords = 6144;             // 12 KB for the staged signature stream (c5: 151 signatures = 1.5 K words)
 constexpr size_t kDigestLds = lds_slice(kTile * sizeof(PaddedReq)) + lds_slice(kTile * sizeof(PodSums)) +
                               lds_slice(kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1) * sizeof(uint16_t)) + lds_slice(kTile * sizeof(PodHeader)) +
-                              lds_slice(kDictLdsWords * sizeof(uint16_t));
+                              lds_slice(kDictLdsWords * sizeof(uint16_t)) + 16;     // (+ the last-arriver flag; no static LDS in the step kernel:
+                                                                                     //  its dynamic allocation may ask for all 160 KB)
 constexpr uint32_t kWcPartsDefault = 4;              // blocks per tile: part 0 = GPU / NIC rows (cold section + X), parts 1..wc_parts = CPU rows, the last one also HP / GX
 
 // Request digest, 1 + wc_parts blocks per 64-pod tile: per-pod subset sums / NIC covers in LDS, then the table rows
@@ -76,12 +77,12 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
         reinterpret_cast<uint16_t (*)[NHDFIT_MAX_CLASSES][kMaxG + 1]>(carve<uint16_t>(lds, kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1)));
     PodHeader* s_hdr = carve<PodHeader>(lds, kTile);
     uint16_t* s_flat = carve<uint16_t>(lds, kDictLdsWords);
+    uint32_t& s_last = *carve<uint32_t>(lds, 4);
 
     // blocks of a tile: sig_parts blocks for the GPU / NIC rows (part 0), then wc_parts blocks for the CPU rows (parts 1 ..)
     const uint32_t per_tile = a.sig_parts + a.wc_parts, tile = blk / per_tile, idx = blk % per_tile;
     const uint32_t part = idx < a.sig_parts ? 0u : idx - a.sig_parts + 1u, sig_part = idx < a.sig_parts ? idx : 0u;
     const uint32_t tid = threadIdx.x;
-    __shared__ uint32_t s_last;
     uint8_t* img = a.tabs + (size_t)tile * a.pitch;
 
     stage_requests_lds<THREADS>(a.reqs, tile * kTile, a.P, s_req);

@@ -6,6 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r03_full
 mkdir -p $OUT
 cd $ROOT
+timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1 || { echo "smoke failed"; tail -5 $OUT/smoke.log; exit 1; }
 SECONDS=0
 timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_full.log 2>&1; echo "pytest rc=$? seconds=$SECONDS" | tee -a $OUT/pytest_full.log
 grep -E "passed|failed|error" $OUT/pytest_full.log | tail -3
