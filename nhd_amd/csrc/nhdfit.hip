@@ -844,10 +844,12 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
         d.xcls = c->xcls.p; d.nx = c->xnx.p;
         static const uint32_t wc_parts = tune_env("NHDFIT_WC_PARTS") && atoi(tune_env("NHDFIT_WC_PARTS")) >= 1 ? (uint32_t)atoi(tune_env("NHDFIT_WC_PARTS")) : kWcPartsDefault;   // tuning aid
         d.wc_parts = wc_parts;
-        // large dictionaries (config 5: 151 signatures, 272 with their successors under claims): the signature rows of a tile are
-        // shared by up to four blocks - the digest was twice the fit role there
+        // One block per tile for the signature rows.  Sharing them among up to four blocks with a last-arriver hand-over
+        // (NHDFIT_SIG_PARTS=<n> in the tuning build) was measured on config 5's 272 signatures in round 3: the step went from 62
+        // to 330 us - the last block derives the X rows from the others' rows past its L1, three dependent 8-byte loads per
+        // (class, assignment), and that costs far more than the signature walk it parallelises (profiles/r03)
         static const uint32_t force_sp = tune_env("NHDFIT_SIG_PARTS") ? (uint32_t)atoi(tune_env("NHDFIT_SIG_PARTS")) : 0u;   // tuning aid
-        d.sig_parts = force_sp ? force_sp : std::min(4u, std::max(1u, (c->nsig + 63u) / 64u));
+        d.sig_parts = force_sp ? std::min(force_sp, 8u) : 1u;
         d.count = p.dig_count.p;
         a.nb_digest = tiles * (d.sig_parts + wc_parts);
     }
