@@ -268,7 +268,7 @@ __device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, 
     return status;
 }
 
-constexpr int kDecideWaves = 16, kDecideRing = 32, kDecideCache = 16, kWorkerBlocks = 12;
+constexpr int kDecideWaves = 16, kDecideRing = 32, kDecideCache = 8, kWorkerBlocks = 12;      // (kDecideCache: a power of two)
 constexpr uint32_t kHintDistance = 2;     // a GPU-less pod's window is read when at most this many GPU-less pods before it are still undecided:
                                           // the column patches of the earlier commits have mostly landed by then (every stale bit costs a failed
                                           // verification), and the pods with GPUs in between leave the fetcher the time it needs
@@ -301,9 +301,11 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     constexpr uint32_t kNicSigs = 64;                          // dictionaries up to this many NIC signatures: the pod's NIC-feasible assignments
     __shared__ uint32_t s_nic[kDecideRing][kNicSigs];          // per signature (low half: on NUMA 0, high half: on NUMA 1) ride along with its window
     __shared__ uint32_t s_nicn[kDecideRing];
-    __shared__ NodeState s_cst[kDecideCache];                  // nodes the driver committed to, most recent kDecideCache
-    __shared__ nhdfit_detail s_cdet[kDecideCache];
-    __shared__ uint32_t s_ctag[kDecideCache];
+    __shared__ NodeState s_cst[2][kDecideCache];               // nodes a driver wavefront committed to, most recent kDecideCache each
+    __shared__ nhdfit_detail s_cdet[2][kDecideCache];
+    __shared__ uint32_t s_ctag[2][kDecideCache];
+    __shared__ uint32_t s_verdict[kDecideRing];                // wavefront 1 -> wavefront 0, per GPU-less pod: (pod + 1) << 2 | 1 placed / 2 yours
+    __shared__ uint32_t s_nitems, s_side_done;                 // queue entries written so far (two writers) / wavefront 1 is through
     extern __shared__ __align__(16) uint8_t s_dyn[];
 
     if (tid == 0) s_ngl = 0;
@@ -428,9 +430,9 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     if (q.lds_sigs) { l_skey = carve<uint64_t>(dynp, (size_t)a.sigs.mask + 1); l_sid = carve<uint32_t>(dynp, (size_t)a.sigs.mask + 1); }
     if (q.lds_states) { l_info = carve<uint64_t>(dynp, a.mt.st.n); l_next = carve<uint32_t>(dynp, (size_t)a.mt.st.n * 8); l_asc = carve<uint32_t>(dynp, 256); }
     uint8_t* l_choose = q.lds_choose ? carve<uint8_t>(dynp, kChooseEntries) : nullptr;
-    if (tid == 0) { s_done = 0; s_abort = 0; s_done_tn = 0; }
-    if (tid < kDecideRing) s_ready[tid] = 0;
-    if (tid < kDecideCache) s_ctag[tid] = kNoNode;
+    if (tid == 0) { s_done = 0; s_abort = 0; s_done_tn = 0; s_nitems = 0; s_side_done = 0; }
+    if (tid < kDecideRing) { s_ready[tid] = 0; s_verdict[tid] = 0; }
+    if (tid < 2 * kDecideCache) s_ctag[tid / kDecideCache][tid % kDecideCache] = kNoNode;
     for (uint32_t k = tid; k < a.chunks; k += 64 * kDecideWaves) s_taken[k] = 0;
     if (q.lds_sigs) {
         for (uint32_t k = tid; k <= a.sigs.mask; k += 64 * kDecideWaves) { l_skey[k] = a.sigs.key[k]; l_sid[k] = a.sigs.id[k]; }
@@ -473,14 +475,14 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         return false;
     };
 
-    if (wave != 0) {
-        // ---- fetchers: pod e goes to slot e % kDecideRing once the driver is past pod e - kDecideRing.  Two pools, so that a
+    if (wave >= 2) {
+        // ---- fetchers: pod e goes to slot e % kDecideRing once wavefront 0 is past pod e - kDecideRing.  Two pools, so that a
         // GPU-less pod waiting for its turn (below) never holds up the pods with GPUs behind it
-        constexpr uint32_t kFetchN = 6, kFetchG = kDecideWaves - 1 - kFetchN;
-        const bool pool_n = wave <= kFetchN;
+        constexpr uint32_t kFetchN = 5, kFetchG = kDecideWaves - 2 - kFetchN;
+        const bool pool_n = wave < 2 + kFetchN;
         const uint32_t* list = pool_n ? q.list_n : q.list_g;
         const uint32_t n_list = pool_n ? q.n_n : q.n_g, stride = pool_n ? kFetchN : kFetchG;
-        for (uint32_t j = pool_n ? wave - 1 : wave - 1 - kFetchN; j < n_list; j += stride) {
+        for (uint32_t j = pool_n ? wave - 2 : wave - 2 - kFetchN; j < n_list; j += stride) {
             const uint32_t e = list[j];
             const uint32_t slot = e % kDecideRing;
             for (uint32_t spin = 0; e >= wg_load(&s_done) + kDecideRing; ++spin) {
@@ -530,36 +532,149 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         return;
     }
 
-    // ---- the driver ------------------------------------------------------------------------------------------------------
+    // ---- the drivers ------------------------------------------------------------------------------------------------------
+    // Wavefront 0 walks every pod in the caller's order.  Wavefront 1 takes one independent piece of the chain off it: the nodes
+    // WITHOUT GPUs only ever change under the GPU-less pods that take them (a pod with GPUs never fits such a node), so the
+    // GPU-less pods' pass over the GPU-less nodes (SelectNode's preference) is a chain of its own.  Wavefront 1 walks that
+    // chain - GPU-less pods in order, GPU-less nodes only - and leaves a verdict per pod: placed, or "yours" (no GPU-less node
+    // takes it: wavefront 0 then tries the nodes with GPUs at the pod's position in the order, as the scheduler's loop would).
+    const bool is_main = wave == 0;
+    const uint32_t dr = is_main ? 0u : 1u;                                // which node cache / scratch slot
     __builtin_amdgcn_s_setprio(3);
-    uint32_t n_items = 0, cache_next = 0, n_tn_done = 0;
-    uint32_t pend_v = kNoNode;                                            // a commit of the driver whose publication waits for the next pod:
-                                                                          // by then its stores have landed and the fence costs nothing
-    uint32_t c_fail = 0, c_wait = 0, c_plain = 0, c_rescan = 0, c_hit = 0;     // tuning aid: what the GPU-less pods cost (ctrl[4..8])
+    uint32_t cache_next = 0, n_tn_done = 0;
+    uint32_t pend_v = kNoNode;                                            // a commit whose publication waits for the next pod: by then its
+                                                                          // stores have landed and the fence costs nothing
+    uint32_t c_fail = 0, c_wait = 0, c_plain = 0, c_rescan = 0, c_hit = 0;     // tuning aid: what the GPU-less pods cost wavefront 0 (ctrl[4..8])
     unsigned long long t_ready = 0, t_gpu = 0, t_state = 0, t_verify = 0, t_publish = 0, t_last = wall_clock64();   // 100 MHz ticks (ctrl[9..13])
     auto lap = [&](unsigned long long& acc) { const unsigned long long t = wall_clock64(); acc += t - t_last; t_last = t; };
     bool stop = false;
     auto give_up = [&]() { stop = true; if (lane == 0) { q.flags[3] = 1u; wg_store(&s_abort, 1u); } };
     auto push = [&](unsigned long long item) {                            // one 8-byte store: the entry itself is the signal
-        if (lane == 0) __hip_atomic_store(&q.queue[n_items], item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nothing else to order: the entry is the data)
-        ++n_items;
+        if (lane == 0) {
+            const uint32_t at = atomicAdd(&s_nitems, 1u);
+            if (at < q.queue_len) __hip_atomic_store(&q.queue[at], item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
-    for (uint32_t e = 0; e < n_pods && !stop; ++e) {
-        const uint32_t slot = e % kDecideRing, mine = a.list ? a.list[e] : e;
+    auto flush_pending = [&]() {
+        if (pend_v == kNoNode) return;
+        publish(pend_v, kCommitOk);
+        for (uint32_t k0 = 0; k0 < ngl; k0 += patch_span(ngl)) push(kItemValid | kItemPatch | ((unsigned long long)k0 << 32) | pend_v);
+        pend_v = kNoNode;
+    };
+    auto take = [&](uint32_t v) { if (lane == 0) atomicOr(reinterpret_cast<unsigned long long*>(&s_taken[v >> 6]), 1ull << (v & 63)); };   // (two writers)
+    // A GPU-less pod against the candidates of its window and the windows behind it (`pass`: 1 the GPU-less nodes, 2 every node,
+    // 4 the nodes with GPUs); every candidate is verified against the node's current state and the first that holds is
+    // committed.  Pass 1 may fall through to pass 4 (wavefront 0 when it works alone on a pod).
+    auto place_gpu_less = [&](uint32_t slot, uint32_t mine, uint32_t pos, int32_t have, uint32_t wbase, int pass, bool fall_through) -> bool {
+        const nhdfit_req& rq = s_req[slot].r;
+        bool placed = false;
+        while (have > 0 && !placed && !stop) {
+            const uint64_t w = s_win[slot][lane];
+            const uint64_t any = __ballot(w != 0);
+            if (!any) {                                                   // window exhausted: the next one, then the next pass
+                ++c_rescan;
+                const uint32_t nb = wbase + 64;
+                if (nb < a.chunks && scan_window(slot, pos, (uint32_t)pass, nb, 0, wbase)) continue;
+                if (pass == 1 && fall_through) { pass = 4; have = scan_window(slot, pos, 4, 0, 0, wbase) ? 2 : 0; continue; }
+                have = 0;
+                continue;
+            }
+            const int l = __builtin_ctzll(any);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, l);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
+            const uint32_t v = (wbase + (uint32_t)l) * 64u + (uint32_t)__builtin_ctzll(((uint64_t)hi << 32) | lo);
+            // the node as it is now: LDS if this wavefront committed to it recently; global memory once its last commit is published
+            NodeState* st = &s_wst[dr];
+            nhdfit_detail* dd = &s_wdet[dr];
+            int cidx = -1;
+            const bool taken = (s_taken[v >> 6] >> (v & 63) & 1) != 0;
+            if (taken) {
+                const uint64_t hit = __ballot(lane < (uint32_t)kDecideCache && s_ctag[dr][lane & (kDecideCache - 1)] == v);
+                if (hit) cidx = __builtin_ctzll(hit);
+            }
+            if (cidx >= 0) { st = &s_cst[dr][cidx]; dd = &s_cdet[dr][cidx]; ++c_hit; }
+            else {
+                if (taken) {
+                    ++c_wait;
+                    uint32_t m = 0;
+                    for (uint32_t spin = 0; (m = dev_load(&q.mat[v])) < 2u && !stop; ++spin) {
+                        if (spin > kSpinLimit) give_up();
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (m == 3u) stop = true;                             // poisoned: a NIC state without a signature (reported by the committer)
+                    if (stop) break;
+                    __threadfence();                                      // (a node this wavefront itself wrote and evicted: its stores first)
+                    load_node_lds_coherent(a, v, st, dd, lane);
+                } else { load_node_lds(a, v, st, dd, lane); ++c_plain; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                cidx = (int)(cache_next % kDecideCache);                  // work on a cache entry of its own (kept only if the commit happens)
+                if (lane < sizeof(NodeState) / 4) reinterpret_cast<uint32_t*>(&s_cst[dr][cidx])[lane] = reinterpret_cast<const uint32_t*>(st)[lane];
+                if (lane < sizeof(nhdfit_detail) / 4) reinterpret_cast<uint32_t*>(&s_cdet[dr][cidx])[lane] = reinterpret_cast<const uint32_t*>(dd)[lane];
+                if (lane == 0) s_ctag[dr][cidx] = kNoNode;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                st = &s_cst[dr][cidx]; dd = &s_cdet[dr][cidx];
+            }
+            if (is_main) lap(t_state);
+            int32_t status = 0;
+            const bool ok = map_commit(rq, *st, *dd, pos, mine, v, true, taken ? 0 : 1, s_nicn[slot] ? s_nic[slot] : nullptr, sigs, mt, s_wres[dr], s_wplace[dr], status);
+            if (is_main) lap(t_verify);
+            if (!ok) {                                                    // stale hint: not this node (any more)
+                ++c_fail;
+                if (lane == (uint32_t)l) s_win[slot][lane] = w & ~(1ull << (v & 63));
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+            if (lane == 0) s_ctag[dr][cidx] = v;
+            take(v);                                                      // busy for every later pod with GPUs
+            if ((uint32_t)cidx == cache_next % kDecideCache) ++cache_next;
+            if (status == kCommitNewSig) { publish(v, status); give_up(); }
+            else pend_v = v;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            placed = true;
+        }
+        return placed;
+    };
+    auto not_placed = [&](uint32_t mine) {
+        if (lane == 0) { SeqResult r; r.node = -1; r.map = nhdfit_mapping{}; r.status = 0; a.out[mine] = r; }
+        if (a.place && lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&a.place[mine])[lane] = 0u;
+    };
+    auto wait_ready = [&](uint32_t slot, uint32_t e) {
         for (uint32_t spin = 0; wg_load(&s_ready[slot]) != e + 1 && !stop; ++spin) {
             if (spin > kSpinLimit) give_up();
+            if (wg_load(&s_abort)) stop = true;
             __builtin_amdgcn_s_sleep(1);
         }
-        if (stop) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        lap(t_ready);
-        if (pend_v != kNoNode) {
-            publish(pend_v, kCommitOk);
-            for (uint32_t k0 = 0; k0 < ngl; k0 += patch_span(ngl)) push(kItemValid | kItemPatch | ((unsigned long long)k0 << 32) | pend_v);
-            pend_v = kNoNode;
-            lap(t_publish);
+    };
+
+    if (!is_main) {
+        // ---- wavefront 1: the GPU-less pods over the GPU-less nodes
+        for (uint32_t j = 0; j < q.n_n && !stop; ++j) {
+            const uint32_t e = q.list_n[j], slot = e % kDecideRing;
+            wait_ready(slot, e);
+            if (stop) break;
+            flush_pending();
+            uint32_t code = 2u;                                           // "yours": nothing among the GPU-less nodes
+            if (s_have[slot] == 1 && place_gpu_less(slot, e, s_pos[slot], 1, s_base[slot], 1, false)) code = 1u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) wg_store(&s_verdict[slot], ((e + 1u) << 2) | code);
         }
-        const nhdfit_req& rq = s_req[slot].r;
+        flush_pending();
+        if (lane == 0) wg_store(&s_side_done, 1u);
+        return;
+    }
+
+    // ---- wavefront 0: every pod, in the caller's order
+    for (uint32_t e = 0; e < n_pods && !stop; ++e) {
+        const uint32_t slot = e % kDecideRing, mine = e;
+        wait_ready(slot, e);
+        if (stop) break;
+        lap(t_ready);
+        if (pend_v != kNoNode) { flush_pending(); lap(t_publish); }
         const uint32_t pos = s_pos[slot];
         const bool wants_gpu = s_kind[slot] != 0;
         int32_t have = s_have[slot];
@@ -580,106 +695,40 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, l);
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
                 const uint32_t v = (wbase + (uint32_t)l) * 64u + (uint32_t)__builtin_ctzll(((uint64_t)hi << 32) | lo);
-                if (lane == 0) s_taken[v >> 6] |= 1ull << (v & 63);
+                take(v);
                 push(kItemValid | ((unsigned long long)mine << 32) | v);
                 placed = true;
             }
             lap(t_gpu);
         } else {
-            // pass 1: the nodes without GPUs (SelectNode's preference), pass 2: every node; each candidate verified
-            int pass = have == 1 ? 1 : 2;
-            if (have == -1) {                                             // the fetcher found no GPU-less candidate any more
+            // what wavefront 1 found among the GPU-less nodes
+            uint32_t verdict = 0;
+            for (uint32_t spin = 0; ((verdict = wg_load(&s_verdict[slot])) >> 2) != e + 1 && !stop; ++spin) {
+                if (spin > kSpinLimit) give_up();
+                if (wg_load(&s_abort)) stop = true;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (stop) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            lap(t_ready);
+            if ((verdict & 3u) == 1u) placed = true;                      // (results written by wavefront 1)
+            else if (have == 2) placed = place_gpu_less(slot, mine, pos, 2, wbase, 2, false);      // no GPU-less candidate in the snapshot: every node, from its winner on
+            else if (have == 1 || have == -1) {                           // the GPU-less nodes gave nothing: the nodes with GPUs, from the first
                 have = scan_window(slot, pos, 4, 0, 0, wbase) ? 2 : 0;
-                pass = 4;
+                placed = place_gpu_less(slot, mine, pos, have, wbase, 4, false);
             }
-            while (have > 0 && !placed && !stop) {
-                const uint64_t w = s_win[slot][lane];
-                const uint64_t any = __ballot(w != 0);
-                if (!any) {                                               // window exhausted: the next one, then the next pass
-                    ++c_rescan;
-                    const uint32_t nb = wbase + 64;
-                    if (nb < a.chunks && scan_window(slot, pos, (uint32_t)pass, nb, 0, wbase)) continue;
-                    if (pass == 1) { pass = 4; have = scan_window(slot, pos, 4, 0, 0, wbase) ? 2 : 0; continue; }
-                    have = 0;
-                    continue;
-                }
-                const int l = __builtin_ctzll(any);
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, l);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
-                const uint32_t v = (wbase + (uint32_t)l) * 64u + (uint32_t)__builtin_ctzll(((uint64_t)hi << 32) | lo);
-                // the node as it is now: LDS if the driver committed to it recently; global memory once its last commit is published
-                NodeState* st = &s_wst[0];
-                nhdfit_detail* dd = &s_wdet[0];
-                int cidx = -1;
-                const bool taken = (s_taken[v >> 6] >> (v & 63) & 1) != 0;
-                if (taken) {
-                    const uint64_t hit = __ballot(lane < (uint32_t)kDecideCache && s_ctag[lane] == v);
-                    if (hit) cidx = __builtin_ctzll(hit);
-                }
-                if (cidx >= 0) { st = &s_cst[cidx]; dd = &s_cdet[cidx]; ++c_hit; }
-                else {
-                    if (taken) {
-                        ++c_wait;
-                        uint32_t m = 0;
-                        for (uint32_t spin = 0; (m = dev_load(&q.mat[v])) < 2u && !stop; ++spin) {
-                            if (spin > kSpinLimit) give_up();
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                        if (m == 3u) stop = true;                         // poisoned: a NIC state without a signature (reported by the committer)
-                        if (stop) break;
-                        __threadfence();                                  // (a node the driver itself wrote and evicted: its stores first)
-                        load_node_lds_coherent(a, v, st, dd, lane);
-                    } else { load_node_lds(a, v, st, dd, lane); ++c_plain; }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (cidx < 0) {                                           // work on a cache entry of its own (kept only if the commit happens)
-                    cidx = (int)(cache_next % kDecideCache);
-                    if (lane < sizeof(NodeState) / 4) reinterpret_cast<uint32_t*>(&s_cst[cidx])[lane] = reinterpret_cast<const uint32_t*>(st)[lane];
-                    if (lane < sizeof(nhdfit_detail) / 4) reinterpret_cast<uint32_t*>(&s_cdet[cidx])[lane] = reinterpret_cast<const uint32_t*>(dd)[lane];
-                    if (lane == 0) s_ctag[cidx] = kNoNode;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    st = &s_cst[cidx]; dd = &s_cdet[cidx];
-                }
-                lap(t_state);
-                int32_t status = 0;
-                const bool ok = map_commit(rq, *st, *dd, pos, mine, v, true, taken ? 0 : 1, s_nicn[slot] ? s_nic[slot] : nullptr, sigs, mt, s_wres[0], s_wplace[0], status);
-                lap(t_verify);
-                if (!ok) {                                                // stale hint: not this node (any more)
-                    ++c_fail;
-                    if (lane == (uint32_t)l) s_win[slot][lane] = w & ~(1ull << (v & 63));
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    continue;
-                }
-                if (lane == 0) {
-                    if (s_ctag[cidx] != v) { s_ctag[cidx] = v; }
-                    s_taken[v >> 6] |= 1ull << (v & 63);                   // busy for every later pod with GPUs
-                }
-                if ((uint32_t)cidx == cache_next % kDecideCache) ++cache_next;
-                if (status == kCommitNewSig) { publish(v, status); stop = true; }
-                else pend_v = v;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                placed = true;
-            }
+            ++n_tn_done;
         }
-        if (!placed && !stop) {
-            if (lane == 0) { SeqResult r; r.node = -1; r.map = nhdfit_mapping{}; r.status = 0; a.out[mine] = r; }
-            if (a.place && lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&a.place[mine])[lane] = 0u;
-        }
-        if (!wants_gpu) ++n_tn_done;
+        if (!placed && !stop) not_placed(mine);
         if (lane == 0) { if (!wants_gpu) wg_store(&s_done_tn, n_tn_done); wg_store(&s_done, e + 1); }
     }
-    if (pend_v != kNoNode) {
-        publish(pend_v, kCommitOk);
-        for (uint32_t k0 = 0; k0 < ngl; k0 += patch_span(ngl)) push(kItemValid | kItemPatch | ((unsigned long long)k0 << 32) | pend_v);
-    }
+    flush_pending();
+    for (uint32_t spin = 0; !wg_load(&s_side_done) && spin < kSpinLimit; ++spin) __builtin_amdgcn_s_sleep(4);   // wavefront 1 has pushed its last item
     if (lane == 0) {
         q.ctrl[4] = c_fail; q.ctrl[5] = c_wait; q.ctrl[6] = c_plain; q.ctrl[7] = c_rescan; q.ctrl[8] = c_hit;
         q.ctrl[9] = (uint32_t)t_ready; q.ctrl[10] = (uint32_t)t_gpu; q.ctrl[11] = (uint32_t)t_state; q.ctrl[12] = (uint32_t)t_verify; q.ctrl[13] = (uint32_t)t_publish;
         wg_store(&s_done, n_pods);                                        // the fetchers run out
-        __hip_atomic_store(&q.ctrl[1], n_items + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the workers leave once the queue is drained
+        const uint32_t n_items = wg_load(&s_nitems);
+        __hip_atomic_store(&q.ctrl[1], (n_items < q.queue_len ? n_items : q.queue_len) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the workers leave once the queue is drained
     }
 }
