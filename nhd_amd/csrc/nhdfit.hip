@@ -745,7 +745,10 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
         nb = std::max(1u, std::min(nb, (chunks + nw - 1) / nw));          // at least one chunk per wavefront
         if (by_xcd) {
             static const uint32_t force_k = tune_env("NHDFIT_XCD_K") ? (uint32_t)atoi(tune_env("NHDFIT_XCD_K")) : 0u;   // tuning aid
-            const uint32_t k = force_k ? force_k : nb <= 11 ? 1u : nb <= 23 ? 2u : 4u;         // 8, 16 or 32 blocks
+            // 8, 16 or 32 blocks per tile by its cost when one launch has the chip to itself; with two pipes the other launch's
+            // blocks fill the gaps, and fewer, longer fit blocks (less staging, fewer tails) win: 8 per tile (-3 %, profiles/r03)
+            const bool two_pipes = c->dual && !c->split && !c->role_kernels;
+            const uint32_t k = force_k ? force_k : two_pipes ? 1u : nb <= 11 ? 1u : nb <= 23 ? 2u : 4u;
             for (uint32_t j = 0; j < 8 * k; ++j) {
                 const uint32_t r = (j % 8) * k + j / 8;                     // range r of 8k: the (j / 8)-th piece of eighth j % 8
                 const uint32_t lo = (uint32_t)((uint64_t)chunks * r / (8 * k)), hi = (uint32_t)((uint64_t)chunks * (r + 1) / (8 * k));
@@ -842,7 +845,9 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
         for (int w = 0; w < kWClasses; ++w) d.L[w] = c->L[w];
         d.pitch = c->pitch; d.tabs = p.tabs[b].p; d.hdr = p.hdr[b].p; d.score = p.score[b].p;
         d.xcls = c->xcls.p; d.nx = c->xnx.p;
-        static const uint32_t wc_parts = tune_env("NHDFIT_WC_PARTS") && atoi(tune_env("NHDFIT_WC_PARTS")) >= 1 ? (uint32_t)atoi(tune_env("NHDFIT_WC_PARTS")) : kWcPartsDefault;   // tuning aid
+        // (two pipes: two blocks per tile for the CPU rows instead of four - the digest's latency hides behind the other launch, its block slots do not: -3 %)
+        static const uint32_t wc_env = tune_env("NHDFIT_WC_PARTS") && atoi(tune_env("NHDFIT_WC_PARTS")) >= 1 ? (uint32_t)atoi(tune_env("NHDFIT_WC_PARTS")) : 0u;   // tuning aid
+        const uint32_t wc_parts = wc_env ? wc_env : (c->dual && !c->split && !c->role_kernels) ? 2u : kWcPartsDefault;
         d.wc_parts = wc_parts;
         // One block per tile for the signature rows.  Sharing them among up to four blocks with a last-arriver hand-over
         // (NHDFIT_SIG_PARTS=<n> in the tuning build) was measured on config 5's 272 signatures in round 3: the step went from 62
