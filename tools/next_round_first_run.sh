@@ -1,28 +1,20 @@
 #!/bin/bash
-# First GPU call of round 3 (run through gpurun, ~4 GPU-minutes): the round-2 end state re-measured on a fresh box, then
-# the block-slot accounting the last experiments of round 2 pointed at.
+# First GPU call of round 4 (run through gpurun, ~8 GPU-minutes): the round-3 end state re-measured on a fresh box.
 #   tools/next_round_first_run.sh            -> gpurun_out/next_round/*
 #
-# Where round 2 stopped: the step kernel is the fit role (22 us alone) plus ~1 us; inside the loop the
-# CU's LDS pipe is the limit, around it ~10 us of launch / staging / tail.  A CU holds three 512-thread blocks = 768 slots;
-# the grid has 568 (fit) + 8 (choose) + 32 + 32 + 320 (digest) = 960 blocks, so ~190 digest blocks queue behind the first
-# finishers.  Freeing the choose role's 120 slots gave -3.5 %.  Candidates, cheapest first:
-#   1. shapes / finish on 16 blocks each (256 pods per block)                                    [host constant]
-#   2. digest part 0 and the CPU-row parts merged differently (NHDFIT_WC_PARTS=3)               [env, measured 4 > 2 > 1]
-#   3. fit items: 8 blocks for the widest tiles too (NHDFIT_XCD_K=1: 512 fit blocks, measured 26.4 vs 26.0 us BEFORE the
-#      choose change - re-measure now that 120 slots are free)
-#   4. CPU pair table C[smt][free cores 0][free cores 1] for the two-group tiles (34 KB: -43 % LDS bytes for 42 % of the work)
+# Where round 3 stopped (DESIGN.md sections 4 and 6):
+#   * mode A: 16.1-16.6 us per step of 65 536 nodes x 4 096 pods (two pipes on two streams, 8 fit blocks per tile, 2 CPU-row
+#     digest blocks); counters per launch: HBM 0.31, LDS 0.43 (43 % of it bank conflicts), VALU 0.34 of peak -> latency / LDS.
+#     Candidates: the pair table C[smt][free cores 0][free cores 1] for the two-group tiles (one row fetch instead of four),
+#     NHDFIT_FIT_BLOCKS=384 (measured -1.5 % in the tuning build), a replicated / skewed WC table against the conflicts.
+#   * mode B: 376-429 k decisions/s (decision engine, two driver wavefronts); ~8.5 us per committed GPU-less pod on a driver
+#     (mapping ~3, commit ~4.2 on the lanes).  Candidates: the commit split over two wavefronts (core batches / signature keys),
+#     the queue entry carrying the patch state (no coherent reload by the patcher).
+#   * single calls: nhdfit_find 0.095 ms for one pod (five launches) - one launch with grid-wide phases for P <= 64 is open.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/next_round
-mkdir -p $OUT
 cd $ROOT
-bash tools/r02_full.sh > $OUT/full.log 2>&1; tail -8 $OUT/full.log
-B="python bench.py --no-cpu-baseline --no-pmc --no-extras"
-line() { python -c "import sys,json; o=json.loads(sys.stdin.read()); print(o['value']/1e12, o['ms_per_step'], o['roofline']['kernel_ms'], o['placed_pods'])"; }
-for v in "" "NHDFIT_XCD_K=1" "NHDFIT_WC_PARTS=3" "NHDFIT_CHOOSE_LANES=0"; do
-  echo "== $v"
-  env $v timeout 300 $B 2>&1 | tail -1 | line
-  env $v timeout 300 $B 2>&1 | tail -1 | line
-done | tee $OUT/slots.log
-NHDFIT_ROLE_TIMES=30 timeout 300 $B 2>&1 | grep "nhdfit\]" | tee $OUT/roles.log
+bash tools/r03_full.sh
+mkdir -p gpurun_out/next_round && cp -r gpurun_out/r03_full/* gpurun_out/next_round/
+TL=$ROOT/nhd_amd/libnhdfit_tuning.so
+NHDFIT_LIBRARY=$TL NHDFIT_SEQ_PROF=1 timeout 300 python tools/time_mode_b.py 65536 4096 4 2>&1 | tail -3 | tee gpurun_out/next_round/mode_b_phases.log
