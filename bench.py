@@ -192,6 +192,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras and not inner:
         out["end_to_end"] = end_to_end(eng, reqs, now, args.pods, n_total)
+        out["single_find"] = single_find(eng, reqs, now, n_total)
         out["mode_b"] = mode_b(eng, pk, reqs, now, args.pods, parity=(spec, tops, pod_groups))
         out["other_configs"] = other_configs(args, local_rank)
         out["deltas"] = delta_rate(eng, table)
@@ -306,6 +307,29 @@ def end_to_end(eng, reqs, now, P, n_total):
     t = min(ts)
     return {"call": "nhdfit_find (stage + H2D + 5 launches + D2H of scores and mappings)", "ms_per_call": t * 1e3,
             "evals_per_s": P * n_total / t, "decisions_per_s": P / t}
+
+
+def single_find(eng, reqs, now, n_total, calls=200):
+    """One pending pod against the whole mirror - the call the scheduler's pod-at-a-time loop makes (nhd/NHDScheduler.py:277):
+    nhdfit_find with P = 1, one kernel launch (digest -> fit -> mapping inside it), request and result in fine-grained host
+    memory.  Median and minimum over `calls` calls with different pods, through ctypes."""
+    sel = np.flatnonzero(reqs["n_groups"] <= 3)[:calls]
+    if not len(sel):
+        return None
+    before = eng.stats().small_finds
+    for k in sel[:8]:
+        eng.find(reqs[k:k + 1], now, want_bitmap=False, want_map=True)
+    ts = []
+    for k in sel:
+        one = reqs[k:k + 1]
+        t0 = time.perf_counter()
+        eng.find(one, now, want_bitmap=False, want_map=True)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    took = eng.stats().small_finds - before
+    return {"call": "nhdfit_find, 1 pod, winner + mapping (single launch)" if took else "nhdfit_find, 1 pod (staged path)",
+            "ms_per_call_median": ts[len(ts) // 2] * 1e3, "ms_per_call_min": ts[0] * 1e3, "calls": len(ts),
+            "single_launch_calls": int(took), "nodes": int(n_total)}
 
 
 def score_only(eng, reqs, now, P, n_total, steps=100):

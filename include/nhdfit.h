@@ -214,7 +214,7 @@ typedef struct {
     uint32_t pipes;             /* step launches in flight at a time: the pipelined form alternates its steps between this many
                                    independent pipelines on as many streams - a launch's HIP-event duration then overlaps its
                                    neighbour's, and throughput is pipes x (work per launch) / duration                          */
-    uint32_t reserved;
+    uint32_t small_finds;       /* nhdfit_find calls answered by the single-launch form (at most one pod tile, no verdict matrix) */
 } nhdfit_stats;
 
 typedef struct nhdfit_ctx nhdfit_ctx;
@@ -270,7 +270,12 @@ int nhdfit_download_nodes(nhdfit_ctx* ctx, uint32_t first, uint32_t count,
  *              (the dict the scheduler passes to FindNode may be a filtered subset of the mirror)
  *   score_out  P score words (after the all-reduce when a communicator is attached)
  *   bitmap_out optional, chunk-major [ceil(n/64)][P] feasibility words of THIS shard
- *   map_out    optional, P mappings (valid only for winners owned by this shard) */
+ *   map_out    optional, P mappings (valid only for winners owned by this shard)
+ * A call with at most one pod tile (64 pods), no bitmap_out, no communicator and no pod with four processing groups - the
+ * scheduler's pod-at-a-time FindNode (nhd/NHDScheduler.py:277) - is ONE kernel launch: digest, fit, mapping in a row inside
+ * it, the requests read from and the results stored into fine-grained host memory (nhdfit_stats.small_finds counts them).
+ * Every other call stages the batch and runs the five launches of a step.  The single-launch form leaves nothing staged:
+ * nhdfit_enqueue_step / nhdfit_fetch need a nhdfit_stage_requests of their own. */
 int nhdfit_find(nhdfit_ctx* ctx, const nhdfit_req* reqs, uint32_t P, double now,
                 const uint64_t* cand, uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out);
 

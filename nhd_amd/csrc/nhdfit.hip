@@ -221,6 +221,13 @@ struct nhdfit_ctx {
     bool seq_general = tune_env("NHDFIT_SEQ_GENERAL") != nullptr;   // tuning aid: the one-block kernel for every batch
     DevBuf<uint64_t> sig_keys; DevBuf<uint32_t> sig_ids; uint32_t sig_mask = 0;   // canonical NIC-state key -> signature id (commit_core.h)
     bool use_cand = false, want_bitmap = true, want_map = true;
+    // single-launch find (k_find, step_kernel.h): the fine-grained host block the launch reads the requests from and stores
+    // its results into, the launch's counters, the sequence number of the last call, and what the device's candidate mask holds
+    FindHost* find_host = nullptr;
+    DevBuf<uint32_t> find_sync;
+    uint32_t find_seq = 0;
+    std::vector<uint64_t> cand_shadow;   // copy of the mask a small find last uploaded to `cand` (empty: unknown)
+    bool fast_find = tune_env("NHDFIT_NO_FAST_FIND") == nullptr;   // tuning aid: every find through the staged five-launch path
 
     // timing
     hipEvent_t ev[kEventRing][2];        // start / end of sampled step launches
@@ -329,6 +336,10 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
     for (auto& q : c->ev)
         for (auto& x : q)
             if (e == hipSuccess) e = hipEventCreate(&x);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->find_host, sizeof(FindHost), hipHostMallocCoherent);
+    if (e == hipSuccess) memset(c->find_host, 0, sizeof(FindHost));
+    if (e == hipSuccess) e = c->find_sync.reserve(4);
+    if (e == hipSuccess) e = hipMemsetAsync(c->find_sync.p, 0, 4 * sizeof(uint32_t), c->stream);
     if (e == hipSuccess) e = c->xkeys.reserve(kXSlots);
     if (e == hipSuccess) e = c->xids.reserve(kXSlots);
     if (e == hipSuccess) e = c->xcls.reserve(kXSlots / 2);
@@ -375,6 +386,8 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->origin.release(); c->deltas.release(); c->delta_run.release(); c->delta_status.release();
+    if (c->find_host) (void)hipHostFree(c->find_host);
+    c->find_host = nullptr; c->find_sync.release();
     c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release();
     c->reqs.release(); c->bitmap.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
@@ -490,6 +503,7 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     HIPCHK(c, hipFuncSetAttribute((const void*)k_role<512, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_role<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_find<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -666,6 +680,7 @@ static int stage_cand(nhdfit_ctx* c, const uint64_t* cand) {
     const size_t chunks = (c->n + 63) / 64;
     HIPCHK(c, c->cand.reserve(chunks ? chunks : 1));
     HIPCHK(c, hipMemcpy(c->cand.p, cand, chunks * sizeof(uint64_t), hipMemcpyHostToDevice));
+    c->cand_shadow.clear();
     c->use_cand = true;
     return NHDFIT_OK;
 }
@@ -772,6 +787,47 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
     return NHDFIT_OK;
 }
 
+// Argument blocks of the roles for buffer set b of pipe p (shared by the step launch and the single-launch find).
+MapArgs make_map_args(nhdfit_ctx* c, Pipe& p, int b) {
+    MapArgs m;
+    memset(&m, 0, sizeof m);
+    m.p0 = c->p0.p; m.p1 = c->p1.p; m.p2 = c->p2.p; m.p3 = c->p3.p; m.det = c->det.p;
+    m.tabs = p.tabs[b].p; m.pitch = c->pitch; m.tile_wcls = c->tile_wcls.p;
+    for (int w = 0; w < kWClasses; ++w) m.L[w] = cold_view(c->L[w]);
+    m.n = c->n; m.global_base = c->global_base; m.reqs = c->reqs.p; m.P = c->P;
+    m.score = p.score[b].p; m.caps = c->caps.p; m.out = p.maps[b].p;
+    return m;
+}
+ShapeArgs make_shape_args(nhdfit_ctx* c, Pipe& p, int b) {
+    return ShapeArgs{p.shape_keys[b].p, p.shape_res[b].p, p.shape_slot[b].p, p.shape_list[b].p, c->asc.p,
+                     c->use_choose_tab ? c->choose_tab.p : nullptr,
+                     c->use_set_states ? SetStates{c->st_info.p, c->st_next.p, c->st_asc.p, c->st_n} : SetStates{nullptr, nullptr, nullptr, 0}};
+}
+void fill_digest_args(nhdfit_ctx* c, Pipe& p, int b, uint32_t wc_parts, uint32_t sig_parts, DigestArgs& d) {
+    d.reqs = c->reqs.p; d.P = c->P;
+    d.d = DictView{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}, c->sig_flat.p, c->flat_words};
+    for (int w = 0; w < kWClasses; ++w) d.L[w] = c->L[w];
+    d.pitch = c->pitch; d.tabs = p.tabs[b].p; d.hdr = p.hdr[b].p; d.score = p.score[b].p;
+    d.xcls = c->xcls.p; d.nx = c->xnx.p;
+    d.wc_parts = wc_parts;
+    d.sig_parts = sig_parts;
+    d.count = p.dig_count.p;
+}
+void fill_fit_args(nhdfit_ctx* c, Pipe& p, int bf, double now, FitArgs& f) {
+    for (int w = 0; w < kWClasses; ++w) {
+        f.rec[w] = c->rec[w].p; f.off_hot[w] = c->L[w].off_hot; f.hot_bytes[w] = c->L[w].hot_bytes; f.hot_hp[w] = c->L[w].hot_hp; f.hot_staged[w] = c->hot_staged[w];
+    }
+    f.hp_last = c->hp_rows - 1; f.hp_bytes = align16(c->hp_rows * 8);
+    f.p4 = c->p4.p;
+    f.n = c->n; f.chunks = (c->n + 63) / 64; f.global_base = c->global_base; f.busy_from = busy_threshold(now);
+    f.tabs = p.tabs[bf].p; f.pitch = c->pitch; f.hdr = p.hdr[bf].p; f.P = c->P;
+    f.cand = c->use_cand ? c->cand.p : nullptr;
+    f.nm = c->want_bitmap ? p.nm.p : nullptr;
+    f.score = p.score[bf].p;
+    f.items = c->items.p;
+    f.dbg_skip = tune_env("NHDFIT_FIT_SKIP") ? (uint32_t)atoi(tune_env("NHDFIT_FIT_SKIP")) : 0;
+}
+
 // One launch of the step kernel with every role that has work (see k_step).  `with_fit`: the fit role for step
 // n_fit plus the digest of step n_fit + 1; `flushing`: nothing new will follow, drain the mapping phases.
 int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double now, bool flushing) {
@@ -793,21 +849,8 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
     memset(&a, 0, sizeof a);
     a.shapes_P = P;
     a.side_prio = c->side_prio;
-    auto map_args = [&](int b) {
-        MapArgs m;
-        memset(&m, 0, sizeof m);
-        m.p0 = c->p0.p; m.p1 = c->p1.p; m.p2 = c->p2.p; m.p3 = c->p3.p; m.det = c->det.p;
-        m.tabs = p.tabs[b].p; m.pitch = c->pitch; m.tile_wcls = c->tile_wcls.p;
-        for (int w = 0; w < kWClasses; ++w) m.L[w] = cold_view(c->L[w]);
-        m.n = c->n; m.global_base = c->global_base; m.reqs = c->reqs.p; m.P = P;
-        m.score = p.score[b].p; m.caps = c->caps.p; m.out = p.maps[b].p;
-        return m;
-    };
-    auto shape_args = [&](int b) {
-        return ShapeArgs{p.shape_keys[b].p, p.shape_res[b].p, p.shape_slot[b].p, p.shape_list[b].p, c->asc.p,
-                         c->use_choose_tab ? c->choose_tab.p : nullptr,
-                         c->use_set_states ? SetStates{c->st_info.p, c->st_next.p, c->st_asc.p, c->st_n} : SetStates{nullptr, nullptr, nullptr, 0}};
-    };
+    auto map_args = [&](int b) { return make_map_args(c, p, b); };
+    auto shape_args = [&](int b) { return make_shape_args(c, p, b); };
     // mapping phases of earlier steps: each advances by at most one step per launch
     bool did_shapes = false, did_choose = false, did_finish = false;
     if (small_map) {
@@ -840,22 +883,15 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
     if (with_digest) {
         const int b = (int)(p.n_dig % kBufs);                              // the next undigested step
         DigestArgs& d = a.digest;
-        d.reqs = c->reqs.p; d.P = P;
-        d.d = DictView{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}, c->sig_flat.p, c->flat_words};
-        for (int w = 0; w < kWClasses; ++w) d.L[w] = c->L[w];
-        d.pitch = c->pitch; d.tabs = p.tabs[b].p; d.hdr = p.hdr[b].p; d.score = p.score[b].p;
-        d.xcls = c->xcls.p; d.nx = c->xnx.p;
         // (two pipes: two blocks per tile for the CPU rows instead of four - the digest's latency hides behind the other launch, its block slots do not: -3 %)
         static const uint32_t wc_env = tune_env("NHDFIT_WC_PARTS") && atoi(tune_env("NHDFIT_WC_PARTS")) >= 1 ? (uint32_t)atoi(tune_env("NHDFIT_WC_PARTS")) : 0u;   // tuning aid
         const uint32_t wc_parts = wc_env ? wc_env : (c->dual && !c->split && !c->role_kernels) ? 2u : kWcPartsDefault;
-        d.wc_parts = wc_parts;
         // One block per tile for the signature rows.  Sharing them among up to four blocks with a last-arriver hand-over
         // (NHDFIT_SIG_PARTS=<n> in the tuning build) was measured on config 5's 272 signatures in round 3: the step went from 62
         // to 330 us - the last block derives the X rows from the others' rows past its L1, three dependent 8-byte loads per
         // (class, assignment), and that costs far more than the signature walk it parallelises (profiles/r03)
         static const uint32_t force_sp = tune_env("NHDFIT_SIG_PARTS") ? (uint32_t)atoi(tune_env("NHDFIT_SIG_PARTS")) : 0u;   // tuning aid
-        d.sig_parts = force_sp ? std::min(force_sp, 8u) : 1u;
-        d.count = p.dig_count.p;
+        fill_digest_args(c, p, b, wc_parts, force_sp ? std::min(force_sp, 8u) : 1u, d);
         a.nb_digest = tiles * (d.sig_parts + wc_parts);
     }
     uint32_t nb_fit = 0;
@@ -863,19 +899,7 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
     if (with_fit) {
         bf = (int)(p.n_fit % kBufs);
         if (c->want_bitmap) HIPCHK(c, p.nm.reserve((size_t)tiles * chunks * 64));
-        FitArgs& f = a.fit;
-        for (int w = 0; w < kWClasses; ++w) {
-            f.rec[w] = c->rec[w].p; f.off_hot[w] = c->L[w].off_hot; f.hot_bytes[w] = c->L[w].hot_bytes; f.hot_hp[w] = c->L[w].hot_hp; f.hot_staged[w] = c->hot_staged[w];
-        }
-        f.hp_last = c->hp_rows - 1; f.hp_bytes = align16(c->hp_rows * 8);
-        f.p4 = c->p4.p;
-        f.n = c->n; f.chunks = chunks; f.global_base = c->global_base; f.busy_from = busy_threshold(now);
-        f.tabs = p.tabs[bf].p; f.pitch = c->pitch; f.hdr = p.hdr[bf].p; f.P = P;
-        f.cand = c->use_cand ? c->cand.p : nullptr;
-        f.nm = c->want_bitmap ? p.nm.p : nullptr;
-        f.score = p.score[bf].p;
-        f.items = c->items.p;
-        f.dbg_skip = tune_env("NHDFIT_FIT_SKIP") ? (uint32_t)atoi(tune_env("NHDFIT_FIT_SKIP")) : 0;
+        fill_fit_args(c, p, bf, now, a.fit);
         nb_fit = c->n_items;
     }
     a.nb_fit = nb_fit;
@@ -1062,6 +1086,137 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
     return NHDFIT_OK;
 }
 
+namespace {
+// nhdfit_find for at most one pod tile and no verdict matrix - the scheduler's pod-at-a-time FindNode - as ONE launch (k_find,
+// step_kernel.h): the requests are read from, and the results stored into, a fine-grained host block; the host polls the
+// sequence word the launch stores last.  Returns 1 when the call is not eligible (or the launch gave up): the caller then
+// takes the staged path, which also words the errors; 0 on success; < 0 on a HIP error.
+int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand, uint64_t* score_out, nhdfit_mapping* map_out) {
+    if (!c->fast_find || !reqs || !P || P > (uint32_t)kTile || c->comm || !c->nsig || !c->n || !c->find_host) return 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (map_out && !c->want_map) return 1;
+    int32_t hp_max = 0;
+    uint32_t wcls = 0;
+    for (uint32_t p = 0; p < P; ++p) {
+        if (reqs[p].hugepages_gb < 0) return 1;
+        hp_max = reqs[p].hugepages_gb > hp_max ? reqs[p].hugepages_gb : hp_max;
+        if (!req_valid(reqs[p])) continue;
+        if (reqs[p].n_groups > 3) return 1;                     // the generic set model is a kernel of its own
+        wcls = std::max(wcls, wclass_of(reqs[p].n_groups));
+    }
+    if (hp_max > kMaxHpRows - 2) return 1;
+    HIPCHK(c, hipSetDevice(c->dev));
+    if (c->P) {                                                 // a staged batch: its steps may be in flight on either pipe
+        { int rc_ = sync_all(c); if (rc_) return rc_; }
+        { int rc_ = drain_events(c); if (rc_) return rc_; }
+    }
+    Pipe& p = c->pipe[0];
+    for (Pipe& q : c->pipe) q.n_dig = q.n_fit = q.n_shaped = q.n_chosen = q.n_finished = 0;
+    c->n_enq = 0; c->last_pipe = 0; c->n_items = 0; c->n_big_pods = 0;
+    c->P = P;                                                   // (for the layout / argument helpers; nothing stays staged: reset below)
+    c->hp_rows = (uint32_t)hp_max + 2;
+    c->max_wcls = wcls;
+    int rc = refresh_layouts(c);
+    if (!rc) rc = ensure_records(c);
+    if (rc || c->x_spill) { c->P = 0; return rc ? rc : 1; }
+    hipError_t e = p.hdr[0].reserve(kTile);
+    if (e == hipSuccess) e = p.score[0].reserve(kTile);
+    if (e == hipSuccess) e = p.shape_keys[0].reserve(kTile);
+    if (e == hipSuccess) e = p.shape_res[0].reserve(kTile);
+    if (e == hipSuccess) e = p.shape_slot[0].reserve(kTile);
+    if (e == hipSuccess) e = p.shape_list[0].reserve(1);
+    const uint32_t chunks = (c->n + 63) / 64;
+    c->use_cand = cand != nullptr;
+    if (e == hipSuccess && cand && (c->cand_shadow.size() != chunks || c->cand.cap < chunks ||
+                                    memcmp(c->cand_shadow.data(), cand, (size_t)chunks * 8) != 0)) {
+        // (consecutive pods of one node group come with the same mask: it is uploaded when it changes)
+        c->cand_shadow.clear();
+        e = c->cand.reserve(chunks);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->cand.p, cand, (size_t)chunks * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) c->cand_shadow.assign(cand, cand + chunks);
+    }
+    if (e != hipSuccess) { c->P = 0; return fail(c, NHDFIT_E_HIP, "small find: %s", hipGetErrorString(e)); }
+
+    FindHost* h = c->find_host;
+    memcpy(h->reqs, reqs, (size_t)P * sizeof *reqs);
+    h->tile_wcls[0] = (uint8_t)wcls;
+    uint32_t seq = ++c->find_seq;
+    if (seq == 0u || seq == kFindAborted) seq = c->find_seq = 1u;
+    FindArgs a;
+    memset(&a, 0, sizeof a);
+    a.s.shapes_P = P;
+    fill_digest_args(c, p, 0, kWcPartsDefault, 1u, a.s.digest);
+    a.s.digest.reqs = h->reqs;
+    a.s.nb_digest = 1u + kWcPartsDefault;
+    fill_fit_args(c, p, 0, now, a.s.fit);
+    a.s.fit.nm = nullptr; a.s.fit.items = nullptr; a.s.fit.dbg_skip = 0;
+    constexpr uint32_t nw = 4;                                  // 256-thread blocks: a wavefront per chunk where the cluster is small enough
+    // Few, longer fit blocks: every block stages the tile's table rows (tens of KB) before its first chunk and waits for the digest
+    // on one counter - measured at 65 536 nodes (profiles/r03): 256 blocks 107 us per call, 64 blocks 54, 32 blocks 50.  Eight
+    // chunks per wavefront, at most one block per CU.
+    static const uint32_t force_nb = tune_env("NHDFIT_FIND_BLOCKS") ? (uint32_t)atoi(tune_env("NHDFIT_FIND_BLOCKS")) : 0u;   // tuning aid
+    a.s.nb_fit = std::max(1u, std::min((chunks + nw - 1) / nw, force_nb ? force_nb : std::min((chunks + 8 * nw - 1) / (8 * nw), (uint32_t)c->prop.multiProcessorCount)));
+    a.s.shapes_m = make_map_args(c, p, 0);
+    a.s.shapes_m.reqs = h->reqs; a.s.shapes_m.tile_wcls = h->tile_wcls;
+    a.s.finish_m = a.s.shapes_m;
+    a.s.finish_m.out = h->maps;
+    a.s.shapes_h = a.s.choose = a.s.finish_h = make_shape_args(c, p, 0);
+    a.wcls = wcls; a.want_map = map_out ? 1u : 0u;
+    a.sync = c->find_sync.p; a.host = h; a.seq = seq;
+    size_t lds = lds_slice(c->lds_bytes) + (size_t)nw * 64 * sizeof(unsigned long long);
+    lds = std::max(lds, std::max(kDigestLds, map_lds_bytes<256>()));
+    const bool clocks = kTuning && c->role_step >= 0;           // tuning aid (NHDFIT_ROLE_TIMES): the phases of the launch on the device clock
+    if (clocks) {
+        HIPCHK(c, c->role_clock.reserve(10));
+        unsigned long long init[10];
+        for (int k = 0; k < 5; ++k) { init[2 * k] = ~0ull; init[2 * k + 1] = 0; }
+        HIPCHK(c, hipMemcpy(c->role_clock.p, init, sizeof init, hipMemcpyHostToDevice));
+        a.s.role_clock = c->role_clock.p;
+    }
+    const auto t_launch = std::chrono::steady_clock::now();
+    c->P = 0;                                                   // nothing is staged for nhdfit_enqueue_step / nhdfit_fetch
+    hipLaunchKernelGGL((k_find<256>), dim3(a.s.nb_digest + a.s.nb_fit), dim3(256), lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    uint32_t seen = 0;
+    for (uint32_t spins = 1;; ++spins) {
+        seen = __atomic_load_n(&h->flag, __ATOMIC_ACQUIRE);
+        if (seen == seq || seen == kFindAborted) break;
+        if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t_launch > std::chrono::microseconds(500)) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));         // a long launch (or host memory the device does not write through): wait for its end
+            seen = __atomic_load_n(&h->flag, __ATOMIC_ACQUIRE);
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    if (seen != seq) {                                          // the launch gave up on a wait: counters back to zero, staged path
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemsetAsync(c->find_sync.p, 0, 4 * sizeof(uint32_t), c->stream));
+        h->flag = 0;
+        return 1;
+    }
+    if (clocks) {
+        const double us_seen = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_launch).count();
+        unsigned long long t[10];
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
+        unsigned long long first = ~0ull;
+        for (int k = 0; k < 5; ++k) first = t[2 * k] < first ? t[2 * k] : first;
+        static const char* names[5] = {"choose", "shapes", "finish", "digest", "fit"};
+        fprintf(stderr, "[nhdfit] single-launch find: %u fit blocks, results seen %.1f us after the launch call began (host prep %.1f us)\n", a.s.nb_fit, us_seen,
+                std::chrono::duration<double, std::micro>(t_launch - t0).count());
+        for (int k = 0; k < 5; ++k)
+            if (t[2 * k + 1]) fprintf(stderr, "[nhdfit]   %-6s: +%.2f us .. +%.2f us\n", names[k], (t[2 * k] - first) * 0.01, (t[2 * k + 1] - first) * 0.01);
+    }
+    if (score_out) memcpy(score_out, h->score, (size_t)P * 8);
+    if (map_out) memcpy(map_out, h->maps, (size_t)P * sizeof(nhdfit_mapping));
+    c->stats.evals_last = (uint64_t)P * c->n;
+    c->stats.bytes_last = (uint64_t)c->n * 24ull + (uint64_t)P * sizeof(nhdfit_req) + (uint64_t)P * 8ull;
+    c->stats.nodes = c->n; c->stats.nsig = c->nsig; c->stats.ncls = c->ncls; c->stats.lds_bytes = c->lds_bytes;
+    c->stats.small_finds++;
+    return NHDFIT_OK;
+}
+}  // namespace
+
 int nhdfit_find(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand,
                 uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out) {
     static const bool prof = tune_env("NHDFIT_FIND_PROF") != nullptr;      // tuning aid: host-side phase times of the call
@@ -1072,6 +1227,10 @@ int nhdfit_find(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, c
         fprintf(stderr, "[nhdfit] find P=%u %s %.1f us\n", P, what, std::chrono::duration<double, std::micro>(t1 - t0).count());
         t0 = t1;
     };
+    if (c && !bitmap_out) {
+        const int rs = find_small(c, reqs, P, now, cand, score_out, map_out);
+        if (rs <= 0) { lap("single launch"); return rs; }
+    }
     int rc = nhdfit_stage_requests(c, reqs, P);
     if (rc) return rc;
     lap("stage");

@@ -267,6 +267,20 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
     }
 }
 
+// (the same for a work item computed by the caller: the single-launch find, k_find)
+template <int BLOCK, bool SPILL = false>
+__device__ __forceinline__ void role_fit_item(const FitArgs& a, const double busy_from, FitItem it, uint8_t* lds) {
+    it.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.tile);      // block-uniform: keep it in scalar registers
+    it.wcls = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.wcls);
+    it.c_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_begin);
+    it.c_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_end);
+    switch (it.wcls) {
+        case 0: role_fit_w<BLOCK, 2, SPILL>(a, busy_from, it, lds); break;
+        case 1: role_fit_w<BLOCK, 4, SPILL>(a, busy_from, it, lds); break;
+        case 2: role_fit_w<BLOCK, 8, SPILL>(a, busy_from, it, lds); break;
+        default: role_fit_w<BLOCK, 16, SPILL>(a, busy_from, it, lds); break;
+    }
+}
 template <int BLOCK, bool SPILL = false>
 __device__ __forceinline__ void role_fit(const FitArgs& a, const double busy_from, uint32_t blk, uint8_t* lds) {
     FitItem it = a.items[blk];                      // block-uniform: keep it in scalar registers

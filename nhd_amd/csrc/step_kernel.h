@@ -181,3 +181,91 @@ __global__ __launch_bounds__(BLOCK, 6) void k_role(StepArgs a) {
     else if constexpr (ROLE == 3) role_digest<BLOCK>(a.digest, blk, lds);
     else role_fit<BLOCK>(a.fit, a.fit.busy_from, blk, lds);
 }
+
+// ---- one launch for a small find ---------------------------------------------------------------------
+// nhdfit_find for at most one pod tile (the scheduler's pod-at-a-time FindNode): the five roles of a step in ONE launch
+// instead of five launches in a row, requests read straight from page-locked host memory, results stored straight into
+// it - no copy engine on either side, no launch gaps: the call's latency is one launch plus the chain of the roles.
+//   * blocks [0, nb_digest): the digest of the tile; each counts itself in sync[0] when its rows are out.
+//   * blocks [nb_digest, +nb_fit): fit blocks, chunk range by block index.  They wait for sync[0] == nb_digest (the digest
+//     blocks lead the grid and wait for nothing, so they are always running or done when a fit block spins), sweep, and
+//     take a ticket in sync[1].
+//   * the fit block with the last ticket sees every score final: it maps the tile's winners (map_one_tile, step_map.h), stores
+//     scores and mappings into the host block and then the call's sequence number behind them (system scope); the host
+//     polls that word.  It also leaves the two counters at zero for the next call.
+// A wait that does not end (it cannot, short of a fault elsewhere) gives up after kFindSpinLimit polls: the launch then
+// reports kFindAborted instead of the sequence number and the host takes the five-launch path.
+struct FindHost {                                    // one per context, hipHostMallocCoherent (fine-grained: visible while the kernel runs)
+    uint32_t flag;                                   // sequence number of the call whose results are below / kFindAborted
+    uint32_t pad[3];
+    uint8_t tile_wcls[16];                           // row width class of the tile (in)
+    unsigned long long score[kTile];                 // out
+    nhdfit_mapping maps[kTile];                      // out
+    nhdfit_req reqs[kTile];                          // in
+};
+constexpr uint32_t kFindAborted = 0xFFFFFFFFu;
+constexpr uint32_t kFindSpinLimit = 1u << 16;
+struct FindArgs {
+    StepArgs s;                                      // digest, fit, shapes_m/_h, choose, finish_m/_h; nb_digest, nb_fit
+    uint32_t wcls, want_map;
+    uint32_t* sync;                                  // [0] digest blocks done, [1] fit tickets, [2] a wait gave up; zero between launches
+    FindHost* host;
+    uint32_t seq;
+};
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_find(FindArgs a) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    uint32_t blk = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const unsigned long long t0 = a.s.role_clock ? (unsigned long long)wall_clock64() : 0ull;
+    if (blk < a.s.nb_digest) {
+        role_digest<BLOCK>(a.s.digest, blk, lds);
+        stamp(a.s.role_clock, 3, t0);
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(&a.sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    blk -= a.s.nb_digest;
+    uint32_t* s_word = reinterpret_cast<uint32_t*>(lds);
+    if (tid == 0) {
+        uint32_t ok = 1u;
+        for (uint32_t spin = 0; __hip_atomic_load(&a.sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.s.nb_digest; ++spin) {
+            if (spin > kFindSpinLimit) { ok = 0u; __hip_atomic_store(&a.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        *s_word = ok;
+    }
+    __syncthreads();
+    const bool go = *s_word != 0u;
+    __syncthreads();                                                     // (the word's LDS is the fit role's from here on)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                    // the digest's rows, past this CU's L1
+    const unsigned long long t1 = a.s.role_clock ? (unsigned long long)wall_clock64() : 0ull;
+    if (go) {
+        const uint32_t chunks = a.s.fit.chunks, nb = a.s.nb_fit;
+        const FitItem it{0u, a.wcls, (uint32_t)((uint64_t)chunks * blk / nb), (uint32_t)((uint64_t)chunks * (blk + 1) / nb)};
+        role_fit_item<BLOCK>(a.s.fit, a.s.fit.busy_from, it, lds);
+    }
+    stamp(a.s.role_clock, 4, t1);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) *s_word = __hip_atomic_fetch_add(&a.sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool last = *s_word == a.s.nb_fit - 1u;
+    __syncthreads();
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                    // every block's scores
+    const bool aborted = __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (a.want_map && !aborted) {
+        const unsigned long long t2 = a.s.role_clock ? (unsigned long long)wall_clock64() : 0ull;
+        map_one_tile<BLOCK>(a.s.finish_m, a.s.finish_h, a.wcls, lds);     // (stores the mappings into the host block)
+        stamp(a.s.role_clock, 2, t2);
+    }
+    for (uint32_t p = tid; p < a.s.shapes_P; p += BLOCK) a.host->score[p] = a.s.fit.score[p];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        a.sync[0] = 0u; a.sync[1] = 0u; a.sync[2] = 0u;
+        __hip_atomic_store(&a.host->flag, aborted ? kFindAborted : a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}

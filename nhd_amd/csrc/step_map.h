@@ -290,3 +290,91 @@ __device__ __forceinline__ void role_finish(const MapArgs& a, const ShapeArgs& h
     for (uint32_t c = threadIdx.x; c < live * kWords; c += THREADS)
         if (st.req[c / kWords].r.n_groups <= 3) dst[c] = src[c];
 }
+
+// The three mapping roles for ONE pod tile in one block with ONE staging - the tail of the single-launch find (k_find).  A tile's
+// pods are one wavefront, its distinct shapes at most 64: lane nd keeps shape nd's key in a register, runs the set model for
+// it (the state machine; anything else one after the other on lane 0, as role_choose_lanes does) and hands the result to the
+// pods of that shape with a lane shuffle - nothing goes through memory between the phases, the winners are staged once.
+// `wcls`: the tile's row width class (the step roles read it from tile_wcls).
+template <int THREADS>
+__device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& h, uint32_t wcls, uint8_t* lds) {
+    static_assert(THREADS / 4 == kTile, "the pods of the tile are one wavefront");
+    const MapStage st = stage_winners<THREADS>(a, 0, lds);
+    const uint32_t j = threadIdx.x;
+    if (j < (uint32_t)kTile) {
+        const uint32_t lane = j;
+        nhdfit_mapping& m = st.map[j];
+        memset(&m, 0, sizeof(m));
+        const nhdfit_req& rq = st.req[j].r;
+        const bool live = j < a.P && rq.n_groups <= 3 && st.w[j].node >= 0;
+        int32_t slot = -1;
+        unsigned long long key = 0;
+        if (live) {                                                       // (1) the pod's shape
+            const WinnerState w = staged_state(st, j);
+            nhdfit_plane3 q3;
+            q3.groups = 0;
+            q3.sig_numa[0] = st.w[j].sig_numa[0]; q3.sig_numa[1] = st.w[j].sig_numa[1];
+            q3.sig_pci[0] = st.w[j].sig_pci[0]; q3.sig_pci[1] = st.w[j].sig_pci[1];
+            const uint32_t bits = nic_assignment_bits(a.tabs, a.L[wcls], lane, rq.map_type == NHDFIT_MAP_PCI, q3);
+            const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
+            uint32_t sg, sc;
+            candidate_masks(rq, w, sg, sc);
+            if (sg && sc && codes) {
+                if (h.choose_tab && choose_tabulated((int)rq.n_groups, w.U))
+                    slot = -2 - (int32_t)choose_from_table(h.choose_tab, (int)rq.n_groups, sg, sc, codes);
+                else
+                    key = shape_key((int)rq.n_groups, w.U, sg, sc, codes);
+            }
+        }
+        unsigned long long todo = __ballot(key != 0ull), mine = 0;
+        uint32_t nd = 0;
+        while (todo) {                                                    // distinct shapes: lane nd keeps the nd-th
+            const int leader = __builtin_ctzll(todo);
+            const unsigned long long k = shfl64(key, leader);
+            if (lane == nd) mine = k;
+            if (key == k) slot = (int32_t)nd;
+            todo &= ~__ballot(key == k);
+            ++nd;
+        }
+        uint32_t res = 0;                                                 // (2) the set model per distinct shape
+        bool generic = false;
+        if (lane < nd) {
+            const int G = (int)(mine & 3), U = (int)((mine >> 2) & 1) + 1;
+            if (h.st.info && G == 3 && U == 2)
+                res = choose_g3(h.st, h.asc, (uint32_t)(mine >> 3) & 0xFF, (uint32_t)(mine >> 19) & 0xFFFF, (uint32_t)(mine >> 11) & 0xFF);
+            else
+                generic = true;
+        }
+        unsigned long long gtodo = __ballot(generic);
+        while (gtodo) {
+            const int jj = __builtin_ctzll(gtodo);
+            gtodo &= gtodo - 1;
+            const unsigned long long kv = shfl64(mine, jj);
+            uint32_t r = 0;
+            if (lane == 0) {
+                const unsigned long long kk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(kv >> 32)) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kv);
+                const int G = (int)(kk & 3), U = (int)((kk >> 2) & 1) + 1;
+                uint32_t gcode = 0;
+                int ccode = -1;
+                const bool ok = choose_tuples<SmallOps>(G, U, (uint32_t)(kk >> 3) & 0xFF, (uint32_t)(kk >> 19) & 0xFFFF,
+                                                        (uint32_t)(kk >> 11) & 0xFF, gcode, ccode, h.asc);
+                r = ((uint32_t)ok << 8) | ((gcode & 7u) << 4) | ((uint32_t)ccode & 15u);
+            }
+            r = (uint32_t)__shfl((int)r, 0, 64);
+            if ((int)lane == jj) res = r;
+        }
+        const uint32_t got = (uint32_t)__shfl((int)res, slot >= 0 ? slot : 0, 64);      // (3) first valid NIC choice under the chosen tuples
+        if (live && slot != -1) {
+            const uint32_t rr = slot >= 0 ? got : (uint32_t)(-2 - slot);
+            if (rr >> 8 & 1) finish_mapping(rq, staged_state(st, j), (rr >> 4) & 7u, (int)(rr & 15u), m);
+        }
+    }
+    __syncthreads();
+    const uint32_t livep = a.P < (uint32_t)kTile ? a.P : (uint32_t)kTile;
+    constexpr uint32_t kWords = sizeof(nhdfit_mapping) / 4;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(st.map);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(a.out);
+    for (uint32_t c = threadIdx.x; c < livep * kWords; c += THREADS)
+        if (st.req[c / kWords].r.n_groups <= 3) dst[c] = src[c];
+}

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class _Stats:
-    fit_ms_total, launches, bytes_last, digest_ms_last, step_ms_last, nsig, lds_bytes, pipes = 1.0, 1, 1000, 0.1, 0.2, 1, 1, 2
+    fit_ms_total, launches, bytes_last, digest_ms_last, step_ms_last, nsig, lds_bytes, pipes, small_finds = 1.0, 1, 1000, 0.1, 0.2, 1, 1, 2, 0
 
 
 class DryEngine(harness.HarnessEngine):
@@ -56,7 +56,7 @@ def test_bench_json_contract(tmp_path):
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert out["mode_b"]["decisions_per_s"] > 0 and out["mode_b"]["placed"] > 0       # decisions under commit semantics
-    assert out["end_to_end"]["evals_per_s"] > 0
+    assert out["end_to_end"]["evals_per_s"] > 0 and out["single_find"]["ms_per_call_median"] > 0
     assert out["score_only"]["evals_per_s"] > 0 and out["deltas"]["mirror_restored"] and out["deltas"]["deltas_per_s"] > 0
     assert out["roofline"]["bound"] in ("hbm", "lds", "valu", "latency") and out["roofline"]["priced_against"] == "hbm"
     assert "limited_by" in out["roofline"] and "traffic_source" in out["roofline"]
