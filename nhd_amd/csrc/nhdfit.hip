@@ -720,13 +720,16 @@ int ensure_records(nhdfit_ctx* c) {
         HIPCHK(c, hipMemcpyAsync(nx, c->xnx.p, sizeof nx, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (nx[1] || nx[0] > kXSlots / 2) return fail(c, NHDFIT_E_LIMIT, "more than %u distinct (free GPUs, NIC signature) node classes", kXSlots / 2);
+        if (nx[0] != c->nx)                                     // new classes: a table image digested ahead of its fit has no X rows for
+            for (Pipe& p : c->pipe)                             // them - it is digested again (nhdfit_enqueue_step looks here first)
+                if (p.n_dig > p.n_fit) p.n_dig = p.n_fit;
         c->nx = nx[0];
         if (nx[0] <= c->x_cap) break;
         // more classes than provisioned rows: every hot-section offset moves -> staged tables and all records are redone
         { int rc_ = sync_all(c); if (rc_) return rc_; }
         c->x_cap = x_capacity(nx[0]);
         c->rec_all = true;
-        for (Pipe& p : c->pipe) p.n_dig = p.n_fit;              // every staged table image is redone
+        for (Pipe& p : c->pipe) p.n_dig = std::min(p.n_dig, p.n_fit);   // every staged table image is redone
         int rc = refresh_layouts(c);
         if (rc) return rc;
     }
@@ -1030,7 +1033,10 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     Pipe& p = c->pipe[which];
     c->n_enq++;
     c->last_pipe = which;
-    if (p.n_dig <= p.n_fit) {                        // this pipe's first step after staging: its digest has not run yet
+    // the mirror may have changed since the last step (uploads, commits, deltas between two steps of one staged batch): node
+    // records first - new node classes put the digests that ran ahead back (ensure_records), and they are redone below
+    { int rc_ = ensure_records(c); if (rc_) return rc_; }
+    if (p.n_dig <= p.n_fit) {                        // this pipe's first step after staging (or after such a change): its digest has not run yet
         int rc = launch_step(c, p, false, true, now, false);
         if (rc) return rc;
     }

@@ -521,30 +521,32 @@ class HipMatcher:
             if (status == pack.COMMIT_WOULD_RAISE).any():
                 self.logger.warning("mode B: the reference's commit step would have failed for pod %d",
                                     int(np.flatnonzero(status == pack.COMMIT_WOULD_RAISE)[0]))
-            index = node - self.engine.global_base
+            index = (node - self.engine.global_base).tolist()
         else:
             score, _, maps = self.engine.find(reqs, now, cand=cand, want_bitmap=False, want_map=True)
-            index = np.array([winner_index(int(s)) - self.engine.global_base if s else -1 for s in score], dtype=np.int64)
+            base = self.engine.global_base
+            index = [winner_index(s) - base if s else -1 for s in score.tolist()]
         out: List[Tuple] = []
         self.last_placements = [None] * n_pods
+        rows = maps.tolist()                               # (gpu[4], cpu[5], nic_numa[4], nic_idx[4], valid, pad) per pod: one C call
+        n_groups = reqs["n_groups"].tolist()
+        names = self._names
         for p in range(n_pods):
-            if index[p] < 0:
+            i = index[p]
+            if i < 0:
                 out.append((None,))
                 continue
+            name = names[i]
+            G = n_groups[p]
             if places is not None and self._attached is not None:
-                nd = self._attached.get(self._names[int(index[p])])
+                nd = self._attached.get(name)
                 if nd is not None:
-                    Gp = int(reqs[p]["n_groups"])
-                    self.last_placements[p] = pack.expand_placement(places[p], Gp, int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets),
-                                                                    [int(reqs[p]["gpus"][g]) for g in range(Gp)])
+                    self.last_placements[p] = pack.expand_placement(places[p], G, int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets),
+                                                                    [int(reqs[p]["gpus"][g]) for g in range(G)])
                     if apply:                                  # the reference mutators that follow find their work mirrored already
                         self._batch_ids.setdefault(nd.name, []).append(self.last_placements[p])
-            name = self._names[int(index[p])]
-            G = int(reqs[p]["n_groups"])
-            m = maps[p]
-            if not m["valid"]:
+            gpu, cpu, nic_numa, nic_idx, valid, _ = rows[p]
+            if not valid:
                 raise RuntimeError(f"internal error: no mapping produced for feasible node {name}")
-            out.append((name, {"gpu": tuple(int(x) for x in m["gpu"][:G]),
-                               "cpu": tuple(int(x) for x in m["cpu"][:G + 1]),
-                               "nic": [(int(a), int(b)) for a, b in zip(m["nic_numa"][:G], m["nic_idx"][:G])]}))
+            out.append((name, {"gpu": tuple(gpu[:G]), "cpu": tuple(cpu[:G + 1]), "nic": list(zip(nic_numa[:G], nic_idx[:G]))}))
         return out

@@ -13,6 +13,7 @@ offers) and node-group names (bit ids of a uint64).
 from __future__ import annotations
 
 import math
+import struct
 from dataclasses import dataclass
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
@@ -66,10 +67,20 @@ PLACEMENT = np.dtype([("proc_take", "<u8", (4,)), ("proc_pair", "<u8", (4,)), ("
 COMMIT_OK, COMMIT_WOULD_RAISE, COMMIT_NEW_SIG = 0, 1, 2
 CC = np.dtype([("cls", "u1"), ("cnt", "u1")])
 assert (P0.itemsize, P1.itemsize, P2.itemsize, P3.itemsize, P4.itemsize) == (16,) * 5
+_REQ_STRUCT = struct.Struct("<IIiIQ4H4H4HHH4B4d4d4BBBBB")          # REQ, field by field (digest_many packs records with it)
+assert _REQ_STRUCT.size == REQ.itemsize
 assert DETAIL.itemsize == 128 and REQ.itemsize == 128 and MAPPING.itemsize == 20 and PLACEMENT.itemsize == 256
 assert ORIGIN.itemsize == 80 and DELTA.itemsize == 96
 
 ALL_ONES = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _enum_value(x):
+    """x.value, through the member's plain attribute when x is an Enum (its .value is a descriptor call)."""
+    try:
+        return x._value_
+    except AttributeError:
+        return x.value
 
 
 class UnsupportedNode(ValueError):
@@ -522,62 +533,65 @@ class Packer:
         return d
 
     # ---- request side ---------------------------------------------------------------------
+    def _digest_fields(self, top, pod_groups: Optional[Sequence[str]] = None) -> tuple:
+        """The record's 38 scalars in REQ's field order (plain Python arithmetic: one struct.pack instead of ~30 numpy field
+        writes - the digest is on FindNode's per-pod path)."""
+        groups = top.proc_groups
+        G = len(groups)
+        mt = getattr(top.map_type, "value", top.map_type)
+        map_type = int(mt) if isinstance(mt, (int, np.integer)) else 0
+        if G > MAX_GROUPS:
+            raise UnsupportedNode(f"pod with {G} proc groups (> {MAX_GROUPS})")
+        hp = int(top.hugepages_gb)
+        if hp > MAX_HUGEPAGES_GB:
+            raise UnsupportedNode(f"pod asks for {hp} GiB of hugepages (> {MAX_HUGEPAGES_GB}: the hugepage table of a pod tile)")
+        gpus, cpu_smt, cpu_nosmt, procs, helps = [0] * 4, [0] * 4, [0] * 4, [0] * 4, [0] * 4
+        rxs, txs = [0.0] * 4, [0.0] * 4
+        smt_bits = nic_use = 0
+        for i, pg in enumerate(groups):
+            n_proc = len(pg.proc_cores) + sum(len(g.cpu_cores) for g in pg.group_gpus)
+            n_help = len(pg.misc_cores)
+            gpus[i] = len(pg.group_gpus)
+            if n_proc > 255 or n_help > 255:
+                raise UnsupportedNode("a proc group asks for more than 255 cores")
+            procs[i] = n_proc
+            helps[i] = n_help
+            p_smt, h_smt = _enum_value(pg.proc_smt), _enum_value(pg.helper_smt)
+            if p_smt:
+                smt_bits |= 1 << i
+            if h_smt:
+                smt_bits |= 1 << (4 + i)
+            cpu_nosmt[i] = n_proc + n_help
+            cpu_smt[i] = ((n_proc + 1) // 2 if p_smt else n_proc) + ((n_help + 1) // 2 if h_smt else n_help)   # ceil(n / 2.0)
+            rx = tx = 0
+            for c in pg.proc_cores:
+                d = c.nic_dir
+                try:
+                    d = d._value_                                   # (Enum member: the plain attribute behind .value)
+                except AttributeError:
+                    d = getattr(d, "value", d)
+                if d == 1:
+                    rx += c.nic_speed
+                    nic_use |= 1 << i
+                elif d == 2:
+                    tx += c.nic_speed
+                    nic_use |= 1 << i
+            rxs[i] = float(rx)
+            txs[i] = float(tx)
+        n_misc = len(top.misc_cores)
+        flags, gbits = (RF_INITIAL_FILTER, self.group_bits_known(pod_groups)) if pod_groups is not None else (0, 0)
+        return (G, map_type, max(-2 ** 31, min(2 ** 31 - 1, hp)), flags, int(gbits), *gpus, *cpu_smt, *cpu_nosmt,
+                (n_misc + 1) // 2 if top.misc_cores_smt else n_misc,                       # Enum truthiness, quirk Q1
+                n_misc, *procs, *rxs, *txs, *helps, min(n_misc, 255), smt_bits,
+                1 if getattr(top.misc_cores_smt, "value", top.misc_cores_smt) == 1 else 0, nic_use)
+
     def digest(self, top, pod_groups: Optional[Sequence[str]] = None) -> np.ndarray:
         """CfgTopology -> nhdfit_req (nhd/CfgTopology.py:199-232 + nhd/Matcher.py:178-204).
 
         pod_groups given  -> the kernel applies InitialNodeFilter (NHDScheduler.py:235-247) itself;
         pod_groups None   -> the caller already filtered (`nl` of FindNode) and passes a candidate mask.
         """
-        r = np.zeros((), REQ)
-        groups = top.proc_groups
-        G = len(groups)
-        mt = getattr(top.map_type, "value", top.map_type)
-        r["map_type"] = int(mt) if isinstance(mt, (int, np.integer)) else 0
-        r["n_groups"] = G
-        if G > MAX_GROUPS:
-            raise UnsupportedNode(f"pod with {G} proc groups (> {MAX_GROUPS})")
-        r["hugepages_gb"] = max(-2 ** 31, min(2 ** 31 - 1, int(top.hugepages_gb)))
-        if int(top.hugepages_gb) > MAX_HUGEPAGES_GB:
-            raise UnsupportedNode(f"pod asks for {int(top.hugepages_gb)} GiB of hugepages (> {MAX_HUGEPAGES_GB}: the hugepage table of a pod tile)")
-
-        def half(n):
-            return int(math.ceil(n / 2.0))
-
-        for i, pg in enumerate(groups):
-            n_proc = len(pg.proc_cores) + sum(len(g.cpu_cores) for g in pg.group_gpus)
-            n_help = len(pg.misc_cores)
-            r["gpus"][i] = len(pg.group_gpus)
-            if n_proc > 255 or n_help > 255:
-                raise UnsupportedNode("a proc group asks for more than 255 cores")
-            r["n_proc"][i] = n_proc
-            r["n_help"][i] = n_help
-            if pg.proc_smt.value:
-                r["smt_bits"] |= 1 << i
-            if pg.helper_smt.value:
-                r["smt_bits"] |= 1 << (4 + i)
-            r["cpu_nosmt"][i] = n_proc + n_help
-            r["cpu_smt"][i] = (half(n_proc) if pg.proc_smt.value else n_proc) + \
-                              (half(n_help) if pg.helper_smt.value else n_help)
-            rx = tx = 0
-            for c in pg.proc_cores:
-                d = getattr(c.nic_dir, "value", c.nic_dir)
-                if d == 1:
-                    rx += c.nic_speed
-                elif d == 2:
-                    tx += c.nic_speed
-                if d in (1, 2):
-                    r["nic_use"] |= 1 << i
-            r["rx"][i] = float(rx)
-            r["tx"][i] = float(tx)
-        n_misc = len(top.misc_cores)
-        r["misc_nosmt"] = n_misc
-        r["n_misc"] = min(n_misc, 255)
-        r["misc_smt_enabled"] = 1 if getattr(top.misc_cores_smt, "value", top.misc_cores_smt) == 1 else 0
-        r["misc_smt"] = half(n_misc) if top.misc_cores_smt else n_misc      # Enum truthiness, quirk Q1
-        if pod_groups is not None:
-            r["flags"] = RF_INITIAL_FILTER
-            r["groups"] = self.group_bits_known(pod_groups)
-        return r
+        return self.digest_many([top], None if pod_groups is None else [pod_groups])[0]
 
     def digest_many(self, tops: Sequence[object], pod_groups: Optional[Sequence[Sequence[str]]] = None,
                     unsupported: Optional[List[Tuple[int, str]]] = None) -> np.ndarray:
@@ -585,9 +599,12 @@ class Packer:
         group) raises UnsupportedNode - or, with `unsupported` (a list), becomes a record that matches nothing
         (map type 0, nhd/Matcher.py:45-47) and is reported there as (index, reason)."""
         out = np.zeros(len(tops), REQ)
+        raw = memoryview(out).cast("B") if len(tops) else None
         for i, top in enumerate(tops):
             try:
-                out[i] = self.digest(top, None if pod_groups is None else pod_groups[i])
+                _REQ_STRUCT.pack_into(raw, i * REQ.itemsize, *self._digest_fields(top, None if pod_groups is None else pod_groups[i]))
+            except struct.error as e:                              # a count beyond its field (65 536 misc cores ...)
+                raise OverflowError(str(e)) from None
             except UnsupportedNode as e:
                 if unsupported is None or self.strict:
                     raise
