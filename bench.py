@@ -288,6 +288,8 @@ def roofline(st, fit_ms, achieved, traffic, traffic_source, valu, counters, pipe
             "achieved_from_wall": None if not ms_per_step else st.bytes_last / (ms_per_step * 1e-3) / 1e9,
             "bytes_formula": "SURVEY.md 8(d): ceil(P/64) * N * 24 (16-byte node record + 8-byte busy time per node and tile) "
                              "+ P * 128 (requests) + P * N / 8 (verdict matrix) + 8 * P (scores)",
+            "frac_note": "algorithmic bytes re-count the node records once per pod tile (SURVEY.md 8(d)'s definition) although L2 / Infinity "
+                         "Cache serve those re-reads: this fraction can pass 1 and says nothing about HBM - hbm_counter.frac is what HBM moved",
             "hbm_counter": hbm, "lds": lds, "issue": issue, "unit_fracs": fr,
             "limited_by": "no unit above half of its peak -> latency: dependent L2 / LDS round trips inside short blocks plus the fixed cost "
                           "of a launch" if bound == "latency" else bound,
