@@ -1127,10 +1127,6 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     if (rc || c->x_spill) { c->P = 0; return rc ? rc : 1; }
     hipError_t e = p.hdr[0].reserve(kTile);
     if (e == hipSuccess) e = p.score[0].reserve(kTile);
-    if (e == hipSuccess) e = p.shape_keys[0].reserve(kTile);
-    if (e == hipSuccess) e = p.shape_res[0].reserve(kTile);
-    if (e == hipSuccess) e = p.shape_slot[0].reserve(kTile);
-    if (e == hipSuccess) e = p.shape_list[0].reserve(1);
     const uint32_t chunks = (c->n + 63) / 64;
     c->use_cand = cand != nullptr;
     if (e == hipSuccess && cand && (c->cand_shadow.size() != chunks || c->cand.cap < chunks ||
@@ -1145,15 +1141,15 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
 
     FindHost* h = c->find_host;
     memcpy(h->reqs, reqs, (size_t)P * sizeof *reqs);
-    h->tile_wcls[0] = (uint8_t)wcls;
     uint32_t seq = ++c->find_seq;
     if (seq == 0u || seq == kFindAborted) seq = c->find_seq = 1u;
     FindArgs a;
     memset(&a, 0, sizeof a);
     a.s.shapes_P = P;
-    fill_digest_args(c, p, 0, kWcPartsDefault, 1u, a.s.digest);
+    static const uint32_t find_wc = tune_env("NHDFIT_FIND_WC_PARTS") && atoi(tune_env("NHDFIT_FIND_WC_PARTS")) >= 1 ? (uint32_t)atoi(tune_env("NHDFIT_FIND_WC_PARTS")) : kWcPartsDefault;   // tuning aid
+    fill_digest_args(c, p, 0, find_wc, 1u, a.s.digest);
     a.s.digest.reqs = h->reqs;
-    a.s.nb_digest = 1u + kWcPartsDefault;
+    a.s.nb_digest = 1u + find_wc;
     fill_fit_args(c, p, 0, now, a.s.fit);
     a.s.fit.nm = nullptr; a.s.fit.items = nullptr; a.s.fit.dbg_skip = 0;
     constexpr uint32_t nw = 4;                                  // 256-thread blocks: a wavefront per chunk where the cluster is small enough
@@ -1162,11 +1158,9 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     // chunks per wavefront, at most one block per CU.
     static const uint32_t force_nb = tune_env("NHDFIT_FIND_BLOCKS") ? (uint32_t)atoi(tune_env("NHDFIT_FIND_BLOCKS")) : 0u;   // tuning aid
     a.s.nb_fit = std::max(1u, std::min((chunks + nw - 1) / nw, force_nb ? force_nb : std::min((chunks + 8 * nw - 1) / (8 * nw), (uint32_t)c->prop.multiProcessorCount)));
-    a.s.shapes_m = make_map_args(c, p, 0);
-    a.s.shapes_m.reqs = h->reqs; a.s.shapes_m.tile_wcls = h->tile_wcls;
-    a.s.finish_m = a.s.shapes_m;
-    a.s.finish_m.out = h->maps;
-    a.s.shapes_h = a.s.choose = a.s.finish_h = make_shape_args(c, p, 0);
+    a.s.finish_m = make_map_args(c, p, 0);                      // the mapping tail (map_one_tile): requests in, mappings out of the host block
+    a.s.finish_m.reqs = h->reqs; a.s.finish_m.tile_wcls = nullptr; a.s.finish_m.out = h->maps;
+    a.s.finish_h = make_shape_args(c, p, 0);
     a.wcls = wcls; a.want_map = map_out ? 1u : 0u;
     a.sync = c->find_sync.p; a.host = h; a.seq = seq;
     size_t lds = lds_slice(c->lds_bytes) + (size_t)nw * 64 * sizeof(unsigned long long);

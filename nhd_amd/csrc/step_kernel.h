@@ -198,7 +198,6 @@ __global__ __launch_bounds__(BLOCK, 6) void k_role(StepArgs a) {
 struct FindHost {                                    // one per context, hipHostMallocCoherent (fine-grained: visible while the kernel runs)
     uint32_t flag;                                   // sequence number of the call whose results are below / kFindAborted
     uint32_t pad[3];
-    uint8_t tile_wcls[16];                           // row width class of the tile (in)
     unsigned long long score[kTile];                 // out
     nhdfit_mapping maps[kTile];                      // out
     nhdfit_req reqs[kTile];                          // in
@@ -206,7 +205,7 @@ struct FindHost {                                    // one per context, hipHost
 constexpr uint32_t kFindAborted = 0xFFFFFFFFu;
 constexpr uint32_t kFindSpinLimit = 1u << 16;
 struct FindArgs {
-    StepArgs s;                                      // digest, fit, shapes_m/_h, choose, finish_m/_h; nb_digest, nb_fit
+    StepArgs s;                                      // of it: digest, fit, finish_m / finish_h (the mapping tail), nb_digest, nb_fit, shapes_P, role_clock
     uint32_t wcls, want_map;
     uint32_t* sync;                                  // [0] digest blocks done, [1] fit tickets, [2] a wait gave up; zero between launches
     FindHost* host;
