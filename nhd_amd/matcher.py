@@ -30,6 +30,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import pack
+from ._lib import NhdFitError
 from .engine import Engine, GroupEngine, winner_index
 
 _MUTATORS = ("SetPhysicalIdsFromMapping", "RemoveResourcesFromTopology", "AddResourcesFromTopology",
@@ -453,7 +454,6 @@ class HipMatcher:
                 self.logger.warning("node %s is not mirrored on the device and will never be selected: %s", name, why)
 
     def _run(self, nl, tops, pod_groups, now, sequential, reqs=None, apply=False):
-        from ._lib import NhdFitError
         try:
             return self._run_checked(nl, tops, pod_groups, now, sequential, reqs, apply)
         except NhdFitError as e:
