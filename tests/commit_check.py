@@ -21,9 +21,11 @@ def load(path):
 
 def build(case):
     spec = synth.make_cluster(case["config"], n_nodes=case["n_nodes"])
-    pods, groups = synth.make_pods(case["config"], n_pods=case["n_pods"])
-    for p in pods:
-        p["misc_smt"] = True
+    pods, groups = synth.make_pods(case["config"], n_pods=case.get("n_pods_drawn", case["n_pods"]))
+    pods, groups = pods[:case["n_pods"]], groups[:case["n_pods"]]
+    if case.get("force_misc_smt", True):                       # (commit_q1_*: the pods as drawn - quirk Q1's run-on walk)
+        for p in pods:
+            p["misc_smt"] = True
     nodes = spec.build_nodes()
     tops = [refmodel.make_topology(p) for p in pods]
     pk = pack.Packer()

@@ -143,9 +143,11 @@ def test_against_reference_commit_fixtures(path):
     """tests/golden/commit: what the unmodified reference decided, mapped and wrote into the pods' topologies."""
     case = commit_check.load(path)
     spec = synth.make_cluster(case["config"], n_nodes=case["n_nodes"])
-    pods, groups = synth.make_pods(case["config"], n_pods=case["n_pods"])
-    for p in pods:
-        p["misc_smt"] = True
+    pods, groups = synth.make_pods(case["config"], n_pods=case.get("n_pods_drawn", case["n_pods"]))
+    pods, groups = pods[:case["n_pods"]], groups[:case["n_pods"]]
+    if case.get("force_misc_smt", True):                       # (commit_q1_*: the pods as drawn - quirk Q1's run-on walk)
+        for p in pods:
+            p["misc_smt"] = True
     tops = [refmodel.make_topology(p) for p in pods]
     sc = seq_oracle.SeqCluster(coracle.Cluster.from_spec(spec), [spec.name(i) for i in range(spec.n)])
     win, maps, ids, n_def = seq_oracle.schedule_sequence(sc, tops, groups, case["clock"])
