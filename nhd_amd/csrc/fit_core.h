@@ -459,6 +459,51 @@ NHD_HD uint32_t nic_assignment_bits(const uint8_t* img, const Layout& L, uint32_
     return nic_assignment_bits(img, cold_view(L), col, pci, q3);
 }
 
+// ---- one pod against the nodes directly --------------------------------------------------------------
+// For a LONE pod (the scheduler's pod-at-a-time FindNode) the bit-sliced tile image is overhead: 63 of its 64 columns are
+// empty and every row is a ballot.  The same verdict comes from the pod's own masks over its 2^G assignments (bit p =
+// assignment p passes) - the 16-bit entries the digest would have bit-sliced - looked up per node: node_word_cold for one pod.
+//   a0 / a1 [fg_dim]            entry_a(u, f)
+//   w0 / w1 [2 * fc_dim][2]     entry_w(u, smt, c, m) at ((smt * fc_dim + c) * 2 + m): NodeIdx::w0 / w1 index the record
+//   r0 / r1 [nsig]              entry_r(reach(sig), u)
+struct LoneMasks {
+    const uint16_t* a0; const uint16_t* a1;
+    const uint16_t* w0; const uint16_t* w1;
+    const uint16_t* r0; const uint16_t* r1;
+};
+NHD_HD bool lone_pod_fits(const LoneMasks& t, const PodHeader& h, const NodeIdx& n, const nhdfit_plane3& q3, bool busy,
+                          const uint64_t* group_sets) {
+    const bool pci = (h.flags & kPodPci) != 0;
+    const uint32_t s0 = pci ? q3.sig_pci[0] : q3.sig_numa[0], s1 = pci ? q3.sig_pci[1] : q3.sig_numa[1];
+    const uint32_t cpu = ((uint32_t)t.w0[n.w0 * 2 + 1] & t.w1[n.w1 * 2]) | ((uint32_t)t.w0[n.w0 * 2] & t.w1[n.w1 * 2 + 1]);
+    if (!(cpu & t.a0[n.f0] & t.a1[n.f1] & t.r0[s0] & t.r1[s1])) return false;
+    if (!gx_bit(h, n.gx, group_sets) || !hp_bit(h, n.hp)) return false;          // (hp_bit: the row clamp of a batch changes nothing for its own pods)
+    return !(busy && (h.flags & kPodNeedGpu));                                   // Matcher.py:107-111
+}
+// NIC-feasible assignment bits of the pod on a node (nic_assignment_bits for the lone pod)
+NHD_HD uint32_t lone_nic_bits(const LoneMasks& t, bool pci, const nhdfit_plane3& q3) {
+    return (uint32_t)t.r0[pci ? q3.sig_pci[0] : q3.sig_numa[0]] & t.r1[pci ? q3.sig_pci[1] : q3.sig_numa[1]];
+}
+// reach family of one signature from the dictionary's 16-bit stream (DictView::flat: [0, nsig] word offset of each
+// signature's record behind the table; record = { #pools, per pool: glimit << 8 | #cc, then #cc x (cls << 8 | cnt) }) -
+// sig_reach_w with every lane on a signature of its own; cover = [ncls][kMaxG+1]
+NHD_HD uint32_t sig_reach_flat(const uint16_t* flat, uint32_t nsig, uint32_t sig, const uint16_t* cover, uint32_t W) {
+    uint32_t at = nsig + 1 + flat[sig];
+    const uint32_t npools = flat[at++];
+    uint32_t reach = 1;
+    for (uint32_t pl = 0; pl < npools; ++pl) {
+        const uint32_t head = flat[at++], ncc = head & 0xFFu, glimit = head >> 8;
+        uint32_t pool = 1;
+        for (uint32_t k = 0; k < ncc; ++k) {
+            const uint32_t e = flat[at++], cnt = e & 0xFFu, cls = e >> 8;
+            pool = dunion_n<1u << kMaxG>(pool, cover[cls * (kMaxG + 1) + (cnt > (uint32_t)kMaxG ? (uint32_t)kMaxG : cnt)]);
+        }
+        if (glimit != NHDFIT_GLIMIT_NONE) pool &= size_le_mask(W, glimit);
+        reach = dunion_n<1u << kMaxG>(reach, pool);
+    }
+    return reach;
+}
+
 // ---- selection (Matcher.py:393-421) ----------------------------------------------------------
 // word = feasibility of 64 consecutive nodes for one pod, nogpu = nodes with no GPU installed.
 NHD_HD uint64_t chunk_score(uint64_t word, uint64_t nogpu, bool pod_needs_gpu, uint64_t first_global_index) {

@@ -53,6 +53,27 @@ def find(packer: pack.Packer, table: pack.NodeTable, reqs: np.ndarray, now: floa
     return score, bitmap, maps
 
 
+def find_lone(packer: pack.Packer, table: pack.NodeTable, reqs: np.ndarray, now: float, cand=None, global_base=0):
+    """The lone-pod form of the find on the host build (fit_core.h lone_pod_fits), every pod on its own: scores, chunk-major
+    bitmap and the NIC-feasible assignment bits of each winner."""
+    L = lib()
+    caps, sig_off, pool_off, glimit, cc, ncls, nsig, npools, ncc = packer.dictionary_arrays()
+    gs = packer.group_set_array()
+    n, P = table.n, len(reqs)
+    score = np.zeros(P, np.uint64)
+    bitmap = np.zeros(((n + 63) // 64, P), np.uint64)
+    bits = np.zeros(P, np.uint32)
+    reqs = np.ascontiguousarray(reqs)
+    L.hh_find_lone.restype = ctypes.c_int
+    rc = L.hh_find_lone(_p(table.p0), _p(table.p1), _p(table.p2), _p(table.p3), _p(table.p4), ctypes.c_uint32(n), ctypes.c_uint64(global_base),
+                        _p(reqs), ctypes.c_uint32(P), ctypes.c_double(now), ctypes.c_uint32(packer.max_cores_per_numa),
+                        ctypes.c_uint32(packer.max_gpus_per_numa), _p(gs), ctypes.c_uint32(len(packer.group_sets)), _p(caps), ctypes.c_uint32(ncls),
+                        _p(sig_off), ctypes.c_uint32(nsig), _p(pool_off), _p(glimit), _p(cc), _p(cand) if cand is not None else None,
+                        _p(score), _p(bitmap), _p(bits))
+    assert rc == 0, f"{rc}: the dictionary stream does not fit / winners whose NIC-feasible assignment bits differ from the table form's"
+    return score, bitmap, bits
+
+
 def _dict_args(packer):
     caps, sig_off, pool_off, glimit, cc, ncls, nsig, npools, ncc = packer.dictionary_arrays()
     return caps, sig_off, pool_off, glimit, cc, ncls, nsig

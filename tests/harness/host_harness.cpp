@@ -173,6 +173,87 @@ int hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane
     return mismatches;
 }
 
+// The lone-pod form of the find (fit_core.h lone_pod_fits: the pod's own 16-bit masks looked up per node instead of the
+// bit-sliced tile image), pod by pod: scores and chunk-major bitmap as hh_find returns them.  The signature reach families
+// come from the dictionary's 16-bit stream (sig_reach_flat), built here as nhdfit_set_dictionary builds it.
+int hh_find_lone(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
+                 const nhdfit_plane4* p4, uint32_t n, uint64_t global_base,
+                 const nhdfit_req* reqs, uint32_t P, double now, uint32_t fcmax, uint32_t fgmax,
+                 const uint64_t* gs, uint32_t ngs, const double* caps, uint32_t ncls,
+                 const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit,
+                 const nhdfit_cc* cc, const uint64_t* cand, uint64_t* score, uint64_t* bitmap, uint32_t* nic_bits_of_winner) {
+    const uint32_t chunks = (n + 63) / 64, fc_dim = fcmax + 1, fg_dim = fgmax + 1;
+    std::vector<uint16_t> flat(nsig + 1, 0);
+    for (uint32_t sg = 0; sg < nsig; ++sg) {
+        const size_t at = flat.size() - (nsig + 1);
+        if (at > 0xFFFFu) return -1;
+        flat[sg] = (uint16_t)at;
+        flat.push_back((uint16_t)(sig_off[sg + 1] - sig_off[sg]));
+        for (uint32_t pl = sig_off[sg]; pl < sig_off[sg + 1]; ++pl) {
+            const uint32_t ncc_pl = pool_off[pl + 1] - pool_off[pl];
+            if (ncc_pl > 255u) return -1;
+            flat.push_back((uint16_t)(pool_glimit[pl] << 8 | ncc_pl));
+            for (uint32_t k = pool_off[pl]; k < pool_off[pl + 1]; ++k) flat.push_back((uint16_t)((cc[k].cls & 0xFFu) << 8 | cc[k].cnt));
+        }
+    }
+    const double busy_from = busy_threshold(now);
+    int mismatches = 0;
+    std::vector<uint16_t> cover(ncls * (kMaxG + 1)), a0(fg_dim), a1(fg_dim), w0(2 * fc_dim * 2), w1(2 * fc_dim * 2), r0(nsig), r1(nsig);
+    for (uint32_t p = 0; p < P; ++p) {
+        score[p] = 0;
+        if (nic_bits_of_winner) nic_bits_of_winner[p] = 0;
+        const nhdfit_req& r = reqs[p];
+        const PodHeader h = pod_header(r);
+        std::fill(a0.begin(), a0.end(), 0); std::fill(a1.begin(), a1.end(), 0);
+        std::fill(w0.begin(), w0.end(), 0); std::fill(w1.begin(), w1.end(), 0);
+        std::fill(r0.begin(), r0.end(), 0); std::fill(r1.begin(), r1.end(), 0);
+        if (h.flags & kPodValid) {
+            PodSums s;
+            pod_sums(r, s);
+            for (uint32_t c = 0; c < ncls; ++c) class_cover(r, caps[c], s.W, s.G, &cover[c * (kMaxG + 1)]);
+            for (uint32_t f = 0; f < fg_dim; ++f) { a0[f] = (uint16_t)entry_a(s, 0, f); a1[f] = (uint16_t)entry_a(s, 1, f); }
+            for (uint32_t smt = 0; smt < 2; ++smt)
+                for (uint32_t c = 0; c < fc_dim; ++c)
+                    for (uint32_t m = 0; m < 2; ++m) {
+                        w0[(smt * fc_dim + c) * 2 + m] = (uint16_t)entry_w(s, 0, smt, c, m);
+                        w1[(smt * fc_dim + c) * 2 + m] = (uint16_t)entry_w(s, 1, smt, c, m);
+                    }
+            for (uint32_t sig = 0; sig < nsig; ++sig) {
+                const uint32_t reach = sig_reach_flat(flat.data(), nsig, sig, cover.data(), s.W);
+                r0[sig] = (uint16_t)entry_r(reach, s.W, 0);
+                r1[sig] = (uint16_t)entry_r(reach, s.W, 1);
+            }
+        }
+        const LoneMasks t{a0.data(), a1.data(), w0.data(), w1.data(), r0.data(), r1.data()};
+        for (uint32_t c = 0; c < chunks; ++c) {
+            uint64_t w = 0, nogpu = 0;
+            const uint32_t cnt = n - c * 64 < 64 ? n - c * 64 : 64;
+            for (uint32_t l = 0; l < cnt; ++l) {
+                const uint32_t i = c * 64 + l;
+                const NodeIdx ni = node_index(p0[i], p1[i], p2[i], p4[i], fc_dim, fg_dim, ngs);
+                if (ni.nogpu) nogpu |= 1ull << l;
+                if (cand && !(cand[c] >> l & 1)) continue;
+                if (lone_pod_fits(t, h, ni, p3[i], p4[i].busy_time >= busy_from, gs)) w |= 1ull << l;
+            }
+            if (bitmap) bitmap[(size_t)c * P + p] = w;
+            const uint64_t sc = chunk_score(w, nogpu, h.flags & kPodNeedGpu, global_base + (uint64_t)c * 64);
+            if (sc > score[p]) score[p] = sc;
+        }
+        if (nic_bits_of_winner && score[p]) {
+            const uint64_t i = NHDFIT_SCORE_INDEX(score[p]) - global_base;
+            nic_bits_of_winner[p] = lone_nic_bits(t, (h.flags & kPodPci) != 0, p3[i]);
+            // the table form's bits for the same winner: a one-pod tile image, column 0
+            const Dict d{fcmax, fgmax, gs, ngs, caps, ncls, SigDict{sig_off, pool_off, pool_glimit, cc, nsig}};
+            const Layout L = make_layout(2u << wclass_of(r.n_groups), fcmax, fgmax, nsig, ngs, (uint32_t)(r.hugepages_gb > 0 ? r.hugepages_gb : 0) + 2, kMinXCap);
+            std::vector<uint8_t> img(L.bytes);
+            std::vector<PodHeader> hdr(kTile);
+            build_tile(&r, 1, d, L, std::vector<uint64_t>(), img.data(), hdr.data());
+            if (nic_assignment_bits(img.data(), L, 0, (h.flags & kPodPci) != 0, p3[i]) != nic_bits_of_winner[p]) ++mismatches;
+        }
+    }
+    return mismatches;
+}
+
 // CPU twin of nhdfit_schedule_batch (mode B with the commit step on the packed state): the algorithm of seq_core.h /
 // k_seq, pod by pod, on host copies of the planes (modified in place = apply).  Inputs as hh_find plus the snapshot
 // rows / scores hh_find produced.  Returns the number of pods decided (< P: a commit produced an unknown NIC state).
