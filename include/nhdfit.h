@@ -273,7 +273,8 @@ int nhdfit_download_nodes(nhdfit_ctx* ctx, uint32_t first, uint32_t count,
  *   map_out    optional, P mappings (valid only for winners owned by this shard)
  * A call with at most one pod tile (64 pods), no bitmap_out, no communicator and no pod with four processing groups - the
  * scheduler's pod-at-a-time FindNode (nhd/NHDScheduler.py:277) - is ONE kernel launch: digest, fit, mapping in a row inside
- * it, the requests read from and the results stored into fine-grained host memory (nhdfit_stats.small_finds counts them).
+ * it, the requests read from and the results stored into fine-grained host memory (nhdfit_stats.small_finds counts them);
+ * a lone pod skips the table image altogether (every block derives the pod's own assignment masks and sweeps nodes with them).
  * Every other call stages the batch and runs the five launches of a step.  The single-launch form leaves nothing staged:
  * nhdfit_enqueue_step / nhdfit_fetch need a nhdfit_stage_requests of their own. */
 int nhdfit_find(nhdfit_ctx* ctx, const nhdfit_req* reqs, uint32_t P, double now,

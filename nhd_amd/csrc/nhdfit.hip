@@ -228,6 +228,7 @@ struct nhdfit_ctx {
     uint32_t find_seq = 0;
     std::vector<uint64_t> cand_shadow;   // copy of the mask a small find last uploaded to `cand` (empty: unknown)
     bool fast_find = tune_env("NHDFIT_NO_FAST_FIND") == nullptr;   // tuning aid: every find through the staged five-launch path
+    bool lone_pod = tune_env("NHDFIT_NO_LONE_POD") == nullptr;      // one pod: the table-free launch (k_find1); tuning aid: NHDFIT_NO_LONE_POD=1 takes k_find
 
     // timing
     hipEvent_t ev[kEventRing][2];        // start / end of sampled step launches
@@ -338,8 +339,8 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
             if (e == hipSuccess) e = hipEventCreate(&x);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->find_host, sizeof(FindHost), hipHostMallocCoherent);
     if (e == hipSuccess) memset(c->find_host, 0, sizeof(FindHost));
-    if (e == hipSuccess) e = c->find_sync.reserve(4);
-    if (e == hipSuccess) e = hipMemsetAsync(c->find_sync.p, 0, 4 * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = c->find_sync.reserve(8);                  // [0..2] counters of k_find / k_find1, [4..5] k_find1's 64-bit score word
+    if (e == hipSuccess) e = hipMemsetAsync(c->find_sync.p, 0, 8 * sizeof(uint32_t), c->stream);
     if (e == hipSuccess) e = c->xkeys.reserve(kXSlots);
     if (e == hipSuccess) e = c->xids.reserve(kXSlots);
     if (e == hipSuccess) e = c->xcls.reserve(kXSlots / 2);
@@ -504,6 +505,7 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     HIPCHK(c, hipFuncSetAttribute((const void*)k_role<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_find<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_find1<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1119,13 +1121,15 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     Pipe& p = c->pipe[0];
     for (Pipe& q : c->pipe) q.n_dig = q.n_fit = q.n_shaped = q.n_chosen = q.n_finished = 0;
     c->n_enq = 0; c->last_pipe = 0; c->n_items = 0; c->n_big_pods = 0;
+    // one pod: no table image at all (k_find1) when the dictionary's 16-bit stream and its signature count fit the block's LDS
+    const bool lone = P == 1 && c->lone_pod && c->flat_words && c->flat_words <= kDictLdsWords && c->nsig <= kLoneMaxSigs;
     c->P = P;                                                   // (for the layout / argument helpers; nothing stays staged: reset below)
     c->hp_rows = (uint32_t)hp_max + 2;
     c->max_wcls = wcls;
-    int rc = refresh_layouts(c);
-    if (!rc) rc = ensure_records(c);
-    if (rc || c->x_spill) { c->P = 0; return rc ? rc : 1; }
-    hipError_t e = p.hdr[0].reserve(kTile);
+    int rc = lone ? NHDFIT_OK : refresh_layouts(c);
+    if (!rc && !lone) rc = ensure_records(c);
+    if (rc || (!lone && c->x_spill)) { c->P = 0; return rc ? rc : 1; }
+    hipError_t e = lone ? hipSuccess : p.hdr[0].reserve(kTile);
     if (e == hipSuccess) e = p.score[0].reserve(kTile);
     const uint32_t chunks = (c->n + 63) / 64;
     c->use_cand = cand != nullptr;
@@ -1143,6 +1147,23 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     memcpy(h->reqs, reqs, (size_t)P * sizeof *reqs);
     uint32_t seq = ++c->find_seq;
     if (seq == 0u || seq == kFindAborted) seq = c->find_seq = 1u;
+    Find1Args a1;
+    memset(&a1, 0, sizeof a1);
+    if (lone) {
+        a1.m = make_map_args(c, p, 0);
+        a1.m.reqs = h->reqs; a1.m.tile_wcls = nullptr; a1.m.tabs = nullptr; a1.m.out = h->maps;
+        a1.m.score = reinterpret_cast<const unsigned long long*>(c->find_sync.p + 4);
+        a1.h = make_shape_args(c, p, 0);
+        a1.p4 = c->p4.p;
+        a1.d = DictView{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}, c->sig_flat.p, c->flat_words};
+        a1.nsig = c->nsig; a1.fc_dim = c->max_cores + 1; a1.fg_dim = c->max_gpus + 1; a1.ngs = c->ngs;
+        a1.chunks = chunks;
+        static const uint32_t lone_nb = tune_env("NHDFIT_FIND_BLOCKS") ? (uint32_t)atoi(tune_env("NHDFIT_FIND_BLOCKS")) : 0u;   // tuning aid
+        a1.nb = std::max(1u, std::min(chunks, lone_nb ? lone_nb : std::min((chunks + 7) / 8, (uint32_t)c->prop.multiProcessorCount)));   // two chunks per wavefront
+        a1.busy_from = busy_threshold(now);
+        a1.cand = c->use_cand ? c->cand.p : nullptr;
+        a1.sync = c->find_sync.p; a1.host = h; a1.seq = seq; a1.want_map = map_out ? 1u : 0u;
+    }
     FindArgs a;
     memset(&a, 0, sizeof a);
     a.s.shapes_P = P;
@@ -1172,10 +1193,12 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
         for (int k = 0; k < 5; ++k) { init[2 * k] = ~0ull; init[2 * k + 1] = 0; }
         HIPCHK(c, hipMemcpy(c->role_clock.p, init, sizeof init, hipMemcpyHostToDevice));
         a.s.role_clock = c->role_clock.p;
+        a1.role_clock = c->role_clock.p;
     }
     const auto t_launch = std::chrono::steady_clock::now();
     c->P = 0;                                                   // nothing is staged for nhdfit_enqueue_step / nhdfit_fetch
-    hipLaunchKernelGGL((k_find<256>), dim3(a.s.nb_digest + a.s.nb_fit), dim3(256), lds, c->stream, a);
+    if (lone) hipLaunchKernelGGL((k_find1<256>), dim3(a1.nb), dim3(256), kLoneLds + map_lds_bytes<256>(), c->stream, a1);
+    else hipLaunchKernelGGL((k_find<256>), dim3(a.s.nb_digest + a.s.nb_fit), dim3(256), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     uint32_t seen = 0;
     for (uint32_t spins = 1;; ++spins) {
@@ -1190,7 +1213,7 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     }
     if (seen != seq) {                                          // the launch gave up on a wait: counters back to zero, staged path
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipMemsetAsync(c->find_sync.p, 0, 4 * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->find_sync.p, 0, 8 * sizeof(uint32_t), c->stream));
         h->flag = 0;
         return 1;
     }
@@ -1202,7 +1225,7 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
         unsigned long long first = ~0ull;
         for (int k = 0; k < 5; ++k) first = t[2 * k] < first ? t[2 * k] : first;
         static const char* names[5] = {"choose", "shapes", "finish", "digest", "fit"};
-        fprintf(stderr, "[nhdfit] single-launch find: %u fit blocks, results seen %.1f us after the launch call began (host prep %.1f us)\n", a.s.nb_fit, us_seen,
+        fprintf(stderr, "[nhdfit] single-launch find%s: %u fit blocks, results seen %.1f us after the launch call began (host prep %.1f us)\n", lone ? " (lone pod, no tables)" : "", lone ? a1.nb : a.s.nb_fit, us_seen,
                 std::chrono::duration<double, std::micro>(t_launch - t0).count());
         for (int k = 0; k < 5; ++k)
             if (t[2 * k + 1]) fprintf(stderr, "[nhdfit]   %-6s: +%.2f us .. +%.2f us\n", names[k], (t[2 * k] - first) * 0.01, (t[2 * k + 1] - first) * 0.01);

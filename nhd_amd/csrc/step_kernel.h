@@ -268,3 +268,143 @@ __global__ __launch_bounds__(BLOCK) void k_find(FindArgs a) {
         __hip_atomic_store(&a.host->flag, aborted ? kFindAborted : a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+
+// ---- one launch for a LONE pod, no tables --------------------------------------------------------------
+// nhdfit_find with ONE pod.  The tile image is overhead then (63 of 64 columns empty, every row a ballot, and the fit blocks
+// wait for it): every block computes the pod's own masks over its 2^G assignments in LDS instead (fit_core.h LoneMasks - the
+// 16-bit entries the digest would have bit-sliced; lane = signature for the reach families, read from the dictionary's 16-bit
+// stream), waits for nobody, and sweeps its chunks with lane = node: the node's planes, popcounts, eight look-ups.  The block
+// with the last ticket maps the winner (map_one_tile<., LONE>).  Host side as k_find.
+struct Find1Args {
+    MapArgs m;                                       // planes, detail, caps; reqs / out in the host block; score = the launch's score word
+    ShapeArgs h;
+    const nhdfit_plane4* p4;
+    DictView d;                                      // caps, ncls, group_sets, flat / flat_words
+    uint32_t nsig, fc_dim, fg_dim, ngs;
+    uint32_t chunks, nb;
+    double busy_from;
+    const uint64_t* cand;
+    uint32_t* sync;                                  // [1] fit tickets; zero between launches (as the score word)
+    FindHost* host;
+    uint32_t seq, want_map;
+    unsigned long long* role_clock;
+};
+constexpr uint32_t kLoneMaxSigs = 4096;              // r0 / r1 in LDS: 2 x 8 KB
+constexpr uint32_t kLoneGpuDim = NHDFIT_MAX_GPUS_PER_NUMA + 1, kLoneCoreDim = NHDFIT_MAX_CORES_PER_NUMA + 1;
+constexpr size_t kLoneLds = lds_slice(sizeof(nhdfit_req)) + lds_slice(sizeof(PodSums)) + lds_slice(sizeof(PodHeader)) +
+                            lds_slice(NHDFIT_MAX_CLASSES * (kMaxG + 1) * sizeof(uint16_t)) + 2 * lds_slice(kLoneGpuDim * sizeof(uint16_t)) +
+                            2 * lds_slice(2 * kLoneCoreDim * 2 * sizeof(uint16_t)) + lds_slice(kDictLdsWords * sizeof(uint16_t)) +
+                            2 * lds_slice(kLoneMaxSigs * sizeof(uint16_t)) + lds_slice(8 * sizeof(unsigned long long));
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_find1(Find1Args a) {
+    extern __shared__ __align__(16) uint8_t lds_all[];
+    uint8_t* lds = lds_all;
+    nhdfit_req* s_req = carve<nhdfit_req>(lds, 1);
+    PodSums* s_sum = carve<PodSums>(lds, 1);
+    PodHeader* s_hdr = carve<PodHeader>(lds, 1);
+    uint16_t* s_cover = carve<uint16_t>(lds, NHDFIT_MAX_CLASSES * (kMaxG + 1));
+    uint16_t* s_a0 = carve<uint16_t>(lds, kLoneGpuDim);
+    uint16_t* s_a1 = carve<uint16_t>(lds, kLoneGpuDim);
+    uint16_t* s_w0 = carve<uint16_t>(lds, 2 * kLoneCoreDim * 2);
+    uint16_t* s_w1 = carve<uint16_t>(lds, 2 * kLoneCoreDim * 2);
+    uint16_t* s_flat = carve<uint16_t>(lds, kDictLdsWords);
+    uint16_t* s_r0 = carve<uint16_t>(lds, kLoneMaxSigs);
+    uint16_t* s_r1 = carve<uint16_t>(lds, kLoneMaxSigs);
+    unsigned long long* s_best = carve<unsigned long long>(lds, 8);
+    uint8_t* lds_map = lds;                                              // the mapping tail's staging area
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const unsigned long long t0 = a.role_clock ? (unsigned long long)wall_clock64() : 0ull;
+
+    // ---- the pod's masks
+    if (tid < sizeof(nhdfit_req) / 16) reinterpret_cast<uint4*>(s_req)[tid] = reinterpret_cast<const uint4*>(a.m.reqs)[tid];
+    for (uint32_t w = tid; w < a.d.flat_words / 2; w += BLOCK)          // (the stream is padded to an even word count)
+        reinterpret_cast<uint32_t*>(s_flat)[w] = reinterpret_cast<const uint32_t*>(a.d.flat)[w];
+    __syncthreads();
+    const nhdfit_req& r = *s_req;
+    const bool valid = req_valid(r);
+    if (tid == 0) {
+        *s_hdr = pod_header(r);
+        s_sum->G = r.n_groups; s_sum->W = 1u << (r.n_groups & 7u); s_sum->full = s_sum->W - 1;
+        s_sum->misc_smt = r.misc_smt; s_sum->misc_nosmt = r.misc_nosmt;
+    }
+    if (valid && tid < (1u << r.n_groups)) {                             // subset sums (pod_sums), one subset per thread
+        uint32_t g = 0, x = 0, y = 0;
+        for (uint32_t i = 0; i < r.n_groups; ++i)
+            if (tid >> i & 1) { g += r.gpus[i]; x += r.cpu_smt[i]; y += r.cpu_nosmt[i]; }
+        s_sum->gpu[tid] = g; s_sum->cpu_smt[tid] = x; s_sum->cpu_nosmt[tid] = y;
+    }
+    __syncthreads();
+    const uint32_t W = s_sum->W, G = s_sum->G;
+    if (valid && tid < a.d.ncls) class_cover(r, a.d.caps[tid], W, G, &s_cover[tid * (kMaxG + 1)]);
+    for (uint32_t k = tid; k < 2 * a.fg_dim; k += BLOCK) {
+        const uint32_t u = k >= a.fg_dim, f = u ? k - a.fg_dim : k;
+        (u ? s_a1 : s_a0)[f] = valid ? (uint16_t)entry_a(*s_sum, u, f) : (uint16_t)0;
+    }
+    for (uint32_t k = tid; k < 2 * (2 * a.fc_dim * 2); k += BLOCK) {     // [u][smt * fc_dim + c][m]
+        const uint32_t u = k >= 2 * a.fc_dim * 2, e = u ? k - 2 * a.fc_dim * 2 : k, m = e & 1, rec = e >> 1, smt = rec >= a.fc_dim, c = smt ? rec - a.fc_dim : rec;
+        (u ? s_w1 : s_w0)[e] = valid ? (uint16_t)entry_w(*s_sum, u, smt != 0, c, m) : (uint16_t)0;
+    }
+    __syncthreads();
+    for (uint32_t sig = tid; sig < a.nsig; sig += BLOCK) {               // lane = signature
+        const uint32_t reach = valid ? sig_reach_flat(s_flat, a.nsig, sig, s_cover, W) : 0u;
+        s_r0[sig] = (uint16_t)entry_r(reach, W, 0);
+        s_r1[sig] = (uint16_t)entry_r(reach, W, 1);
+    }
+    __syncthreads();
+    const LoneMasks t{s_a0, s_a1, s_w0, s_w1, s_r0, s_r1};
+    const PodHeader h = *s_hdr;
+    stamp(a.role_clock, 3, t0);
+
+    // ---- lane = node
+    const unsigned long long t1 = a.role_clock ? (unsigned long long)wall_clock64() : 0ull;
+    constexpr uint32_t NW = BLOCK / 64;
+    const uint32_t c_lo = (uint32_t)((uint64_t)a.chunks * blockIdx.x / a.nb), c_hi = (uint32_t)((uint64_t)a.chunks * (blockIdx.x + 1) / a.nb);
+    const bool needs_gpu = (h.flags & kPodNeedGpu) != 0;
+    uint32_t best_any = ~0u, best_pref = ~0u;
+    for (uint32_t c = c_lo + wave; c < c_hi; c += NW) {
+        const uint32_t i = c * 64 + lane;
+        bool ok = false, nogpu = false;
+        if (i < a.m.n) {
+            const NodeIdx ni = node_index(a.m.p0[i], a.m.p1[i], a.m.p2[i], a.p4[i], a.fc_dim, a.fg_dim, a.ngs);
+            nogpu = ni.nogpu != 0;
+            ok = lone_pod_fits(t, h, ni, a.m.p3[i], a.p4[i].busy_time >= a.busy_from, a.d.group_sets);
+            if (a.cand && !(a.cand[c] >> lane & 1)) ok = false;
+        }
+        const uint64_t word = __ballot(ok), pref = needs_gpu ? 0ull : word & __ballot(nogpu);
+        if (word && best_any == ~0u) best_any = c * 64 + (uint32_t)__builtin_ctzll(word);
+        if (pref && best_pref == ~0u) best_pref = c * 64 + (uint32_t)__builtin_ctzll(pref);
+    }
+    unsigned long long best = 0;
+    if (best_pref != ~0u) best = score_of(true, a.m.global_base + best_pref);
+    else if (best_any != ~0u) best = score_of(false, a.m.global_base + best_any);
+    if (lane == 0) s_best[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long mx = s_best[0];
+#pragma unroll
+        for (int w = 1; w < (int)NW; ++w) mx = s_best[w] > mx ? s_best[w] : mx;
+        if (mx) atomicMax(const_cast<unsigned long long*>(a.m.score), mx);
+    }
+    stamp(a.role_clock, 4, t1);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_best[0] = __hip_atomic_fetch_add(&a.sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool last = (uint32_t)s_best[0] == a.nb - 1u;
+    __syncthreads();
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                    // every block's score
+    if (a.want_map) {
+        const unsigned long long t2 = a.role_clock ? (unsigned long long)wall_clock64() : 0ull;
+        map_one_tile<BLOCK, true>(a.m, a.h, 0, lds_map, &t);              // (stores the mapping into the host block)
+        stamp(a.role_clock, 2, t2);
+    }
+    if (tid == 0) a.host->score[0] = __hip_atomic_load(a.m.score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        a.sync[1] = 0u;
+        *const_cast<unsigned long long*>(a.m.score) = 0ull;
+        __hip_atomic_store(&a.host->flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}

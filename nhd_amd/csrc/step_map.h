@@ -296,8 +296,9 @@ __device__ __forceinline__ void role_finish(const MapArgs& a, const ShapeArgs& h
 // it (the state machine; anything else one after the other on lane 0, as role_choose_lanes does) and hands the result to the
 // pods of that shape with a lane shuffle - nothing goes through memory between the phases, the winners are staged once.
 // `wcls`: the tile's row width class (the step roles read it from tile_wcls).
-template <int THREADS>
-__device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& h, uint32_t wcls, uint8_t* lds) {
+// LONE: the tile is one pod and there is no table image - the NIC-feasible assignments come from the pod's own masks (`lone`).
+template <int THREADS, bool LONE = false>
+__device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& h, uint32_t wcls, uint8_t* lds, const LoneMasks* lone = nullptr) {
     static_assert(THREADS / 4 == kTile, "the pods of the tile are one wavefront");
     const MapStage st = stage_winners<THREADS>(a, 0, lds);
     const uint32_t j = threadIdx.x;
@@ -315,7 +316,9 @@ __device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& 
             q3.groups = 0;
             q3.sig_numa[0] = st.w[j].sig_numa[0]; q3.sig_numa[1] = st.w[j].sig_numa[1];
             q3.sig_pci[0] = st.w[j].sig_pci[0]; q3.sig_pci[1] = st.w[j].sig_pci[1];
-            const uint32_t bits = nic_assignment_bits(a.tabs, a.L[wcls], lane, rq.map_type == NHDFIT_MAP_PCI, q3);
+            uint32_t bits;
+            if constexpr (LONE) bits = lone_nic_bits(*lone, rq.map_type == NHDFIT_MAP_PCI, q3);
+            else bits = nic_assignment_bits(a.tabs, a.L[wcls], lane, rq.map_type == NHDFIT_MAP_PCI, q3);
             const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
             uint32_t sg, sc;
             candidate_masks(rq, w, sg, sc);
