@@ -10,9 +10,9 @@
 #   * mode B: 396-445 k decisions/s (decision engine, two driver wavefronts); ~8.5 us per committed GPU-less pod on a driver
 #     (mapping ~3, commit ~4.2 on the lanes).  Candidates: the commit split over two wavefronts (core batches / signature keys),
 #     the queue entry carrying the patch state (no coherent reload by the patcher).
-#   * single calls: nhdfit_find for one pod is ONE launch (k_find): 0.039-0.043 ms at 4 096 ... 65 536 nodes, 0.058 on the c5
-#     shard; on the device clock digest 11 us, fit 6, mapping 9-12 (c5: digest 32, mapping 31-36).  Candidates: a direct
-#     per-node evaluation for a lone pod (no tables at all), the request through device memory the host writes over the BAR.
+#   * single calls: nhdfit_find for one pod is ONE launch without tables (k_find1): 27 / 30 / 37 us at 4 096 / 16 384 / 65 536
+#     nodes, 35 on the c5 shard; 2..64 pods: k_find (digest -> fit -> mapping in one launch), 61-86 us.  Open: k_find1's block
+#     count was never swept (NHDFIT_FIND_BLOCKS in the tuning build), its mapping tail is 8-17 us on one lane.
 #   * limits the product still degrades on: > 2 NUMA nodes, > 64 physical cores per socket, > 4 groups.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
