@@ -1,5 +1,5 @@
 """Offline soak (not part of the suite; `python tools/soak_cpu.py <seeds> [<delta streams>]`, CPU only): many more seeds of the CPU differential tests - host twin of the kernel arithmetic
-vs the Python oracle: find (bitmap, winner, mapping), mode B with commits + physical ids, deltas vs stand-in mutators."""
+vs the Python oracle: find (bitmap, winner, mapping; the lone-pod form against the table form), mode B with commits + physical ids, deltas vs stand-in mutators."""
 import sys, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,6 +20,9 @@ for seed in range(1000, 1000 + int(sys.argv[1])):
     tops = [refmodel.make_topology(s) for s in specs]
     pk = pack.Packer(); table = pk.pack_nodes(nl); reqs = pk.digest_many(tops)
     score, bitmap, maps = harness.find(pk, table, reqs, util.CLOCK)
+    ls, lb, _ = harness.find_lone(pk, table, reqs, util.CLOCK)           # the lone-pod form (k_find1's arithmetic): the same scores and bitmaps
+    if not (np.array_equal(ls, score) and np.array_equal(lb, bitmap)):
+        bad += 1; print("LONE FORM MISMATCH seed", seed)
     got = decode(pk, table, reqs, score, maps, table.names)
     rows = bitmap_rows(bitmap, table.n, len(reqs))
     for p, top in enumerate(tops):
