@@ -10,6 +10,9 @@
 #   * mode B: 396-445 k decisions/s (decision engine, two driver wavefronts); ~8.5 us per committed GPU-less pod on a driver
 #     (mapping ~3, commit ~4.2 on the lanes).  Candidates: the commit split over two wavefronts (core batches / signature keys),
 #     the queue entry carrying the patch state (no coherent reload by the patcher).
+#     Measured on the oracle's decisions (tools/mode_b_conflicts.py, profiles/r03/mode_b_conflict_structure.log): at c4 only 71 of the 396
+#     GPU-less pods that land on nodes with GPUs meet a node an earlier one took (median 93 pods earlier) - that 4.2 ms chain can be
+#     walked by several wavefronts speculatively with a per-node claim (atomicMin of the pod position) and a re-verify for the displaced.
 #   * single calls: nhdfit_find for one pod is ONE launch without tables (k_find1): 27 / 30 / 37 us at 4 096 / 16 384 / 65 536
 #     nodes, 35 on the c5 shard; 2..64 pods: k_find (digest -> fit -> mapping in one launch), 61-86 us.  Open: k_find1's block
 #     count was never swept (NHDFIT_FIND_BLOCKS in the tuning build), its mapping tail is 8-17 us on one lane.
