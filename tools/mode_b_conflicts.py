@@ -3,7 +3,9 @@
 Which pods really wait for which?  A pod's choice depends on an earlier pod only through the nodes both touch, and a commit
 only ever removes resources (feasibility is monotone): pod k's pick v is invalidated by an earlier pod j only if j commits
 to v itself.  So the chain the decision engine walks today (one wavefront, ~8 us per committed GPU-less pod) is mostly
-artificial where pods land on different nodes.    python tools/mode_b_conflicts.py [config nodes pods]"""
+artificial where pods land on different nodes.    python tools/mode_b_conflicts.py [config nodes pods [--candidates]]
+--candidates: for the GPU-less pods that end on nodes with GPUs, how many snapshot-feasible candidates precede the winner and how
+many of those an earlier pod of the batch touched (needs the P x N snapshot matrix of the C oracle)."""
 import collections, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -44,3 +46,23 @@ on_gpu_nodes = [k for k in gpu_less if win[k] >= 0 and node_has_gpu[win[k]]]
 describe("GPU-less pods placed on nodes WITH GPUs", on_gpu_nodes)
 print(f"     ... {sum(win[k] in taken_by_gpu_pod for k in on_gpu_nodes)} of them on a node a pod with GPUs of this batch also took")
 describe("GPU-less pods placed on GPU-less nodes", [k for k in gpu_less if win[k] >= 0 and not node_has_gpu[win[k]]])
+
+if "--candidates" in sys.argv and on_gpu_nodes:
+    cl0 = coracle.Cluster.from_spec(spec)
+    op = cl0.pods_from_tops([tops[k] for k in on_gpu_nodes], [groups[k] for k in on_gpu_nodes] if groups else None)
+    _, feas = cl0.find(op, spec.clock_now, threads=min(16, os.cpu_count() or 1))
+    pos = {k: i for i, k in enumerate(on_gpu_nodes)}
+    touched, stats, n_cand, n_touched = {}, collections.Counter(), [], []
+    for k in range(P):
+        v = win[k]
+        if v < 0:
+            continue
+        if k in pos:
+            cands = np.flatnonzero(feas[pos[k]][:v + 1] & node_has_gpu[:v + 1])
+            n_cand.append(len(cands)); n_touched.append(sum(1 for c in cands if c in touched))
+            stats["winner untouched so far" if v not in touched else "winner touched before by " + "+".join(sorted(set(touched[v])))] += 1
+        touched.setdefault(v, []).append("a GPU-less pod" if k in set(gpu_less) else "a pod with GPUs")
+    print(f"  GPU-less pods on nodes with GPUs, snapshot-feasible candidates up to the winner: median {int(np.median(n_cand))}, max {max(n_cand)}; "
+          f"of them touched by an earlier pod of the batch: median {int(np.median(n_touched))}, max {max(n_touched)}")
+    for key, val in sorted(stats.items()):
+        print(f"     {key}: {val}")
