@@ -126,9 +126,38 @@ def handcrafted(ref):
     return run_case(ref, clock, nodes, pods)
 
 
+def beyond_layout(ref):
+    """tests/golden/beyond/beyond_layout.json: a cluster that holds two nodes the device layout cannot mirror - four sockets; two
+    sockets of 96 physical cores - among ordinary ones.  The product answers for the other nodes exactly as the reference does
+    for THEM and names the two (FindNode never raises): `expected` is the reference on the
+    cluster without the two, `expected_whole` the reference on the whole cluster (where they differ the reference chose one of the
+    two), `feasible` the reference's per-node verdicts on the whole cluster."""
+    clock = 2.0e6
+    rng = np.random.default_rng(4242)
+    nodes = util.random_cluster_desc(4243, 14)
+    odd = [node_desc("quad-socket", sockets=4, phys=64, nics=((0, 100000, 0x10), (1, 100000, 0x20), (2, 100000, 0x30), (3, 100000, 0x40)),
+                     gpus=((0, 0x10), (3, 0x40))),
+           node_desc("wide-socket", sockets=2, phys=192, gpus=((0, 0x10), (1, 0x20)))]
+    nodes = nodes[:4] + [odd[0]] + nodes[4:9] + [odd[1]] + nodes[9:]
+    pods = [{"spec": util.random_pod_spec(rng), "groups": ["default"]} for _ in range(30)]
+    pods += [pod([grp(40)]), pod([grp(20), grp(20)], misc=2), pod([grp(70, proc_smt=True)])]     # only the wide node has that many cores per socket
+    whole = run_case(ref, clock, nodes, pods)
+    rest = run_case(ref, clock, [d for d in nodes if d["name"] not in ("quad-socket", "wide-socket")], pods)
+    whole["expected_whole"] = whole["expected"]
+    whole["expected"] = rest["expected"]
+    whole["unmirrored"] = ["quad-socket", "wide-socket"]
+    return whole
+
+
 def main():
     ref = ref_loader.load()
     os.makedirs(OUT, exist_ok=True)
+    os.makedirs(os.path.join(OUT, "beyond"), exist_ok=True)
+    case = beyond_layout(ref)
+    with open(os.path.join(OUT, "beyond", "beyond_layout.json"), "w") as f:
+        json.dump(case, f, separators=(",", ":"))
+    print("beyond/beyond_layout:", len(case["nodes"]), "nodes x", len(case["pods"]), "pods,",
+          sum(1 for a, b in zip(case["expected"], case["expected_whole"]) if a != b), "pods the reference places on a node beyond the layout")
     cases = {"handcrafted": handcrafted(ref)}
     for seed in range(4):
         rng = np.random.default_rng(9000 + seed)

@@ -200,3 +200,16 @@ def test_batch_placements_never_applied_do_not_stay_in_the_mirror():
     assert sum(r[0] is not None for r in got) >= 5 and m._batch_ids
     assert [norm(r) for r in m.FindNodes(nl, tops)] == before          # objects untouched -> same answers as before the batch
     assert not m._batch_ids
+
+
+def test_reference_fixture_with_nodes_beyond_the_layout():
+    """tests/golden/beyond: the unmodified reference's answers on a cluster with a four-socket node and a 96-core-per-socket node."""
+    from tests import beyond_check
+
+    def unpack(bm, n):
+        chunks, P = bm.shape
+        bits = np.unpackbits(bm.view(np.uint8).reshape(chunks, P, 8), axis=2, bitorder="little")
+        return bits.transpose(1, 0, 2).reshape(P, chunks * 64)[:, :n]
+
+    beyond_check.check(lambda clock: HipMatcher(clock=lambda: clock, engine_factory=harness.HarnessEngine), unpack)
+
