@@ -1503,12 +1503,15 @@ int nhdfit_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_req* req, const nhd
             return fail(c, NHDFIT_E_INVAL, "mapping: group %u uses NIC ordinal %d", g, (int)map->nic_idx[g]);
     }
     HIPCHK(c, hipSetDevice(c->dev));
+    // the commit writes the planes: steps in flight on EITHER pipe (their fit roles, digests running ahead, pending mapping
+    // phases) read them - wait for both, as every other writer of the mirror does (nhdfit_upload_nodes)
+    { int rc_ = sync_all(c); if (rc_) return rc_; }
     HIPCHK(c, c->seq_place.reserve(1));
     CommitArgs ca;
     memset(&ca, 0, sizeof ca);
     ca.p0 = c->p0.p; ca.p1 = c->p1.p; ca.p2 = c->p2.p; ca.p3 = c->p3.p; ca.p4 = c->p4.p; ca.det = c->det.p;
     ca.node = node; ca.req = *req; ca.map = *map; ca.busy_time = busy_time; ca.sigs = sig_table(c); ca.out = c->seq_place.p;
-    hipLaunchKernelGGL(k_commit, dim3(1), dim3(64), 0, c->stream, ca);       // stream order: after every step in flight
+    hipLaunchKernelGGL(k_commit, dim3(1), dim3(64), 0, c->stream, ca);       // (both pipes are idle: sync_all above)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(place_out, c->seq_place.p, sizeof(nhdfit_placement), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1555,7 +1558,8 @@ int nhdfit_apply_deltas(nhdfit_ctx* c, const nhdfit_delta* deltas, uint32_t n, u
     const uint32_t n_runs = (uint32_t)run.size();
     run.push_back(n);
     HIPCHK(c, hipSetDevice(c->dev));
-    { int rc_ = flush_pipeline(c); if (rc_) return rc_; }       // mapping phases of steps in flight read the nodes as they were matched
+    { int rc_ = sync_all(c); if (rc_) return rc_; }             // steps in flight on either pipe (fit, digest, the mapping phases flushed here) read
+                                                                // the nodes as they were matched: the deltas wait for both pipes
     HIPCHK(c, c->deltas.reserve(n)); HIPCHK(c, c->delta_run.reserve(run.size())); HIPCHK(c, c->delta_status.reserve(n));
     HIPCHK(c, hipMemcpyAsync(c->deltas.p, sorted.data(), n * sizeof(nhdfit_delta), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->delta_run.p, run.data(), run.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));

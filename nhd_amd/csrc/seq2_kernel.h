@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 if (item) break;
                 const uint32_t fin = dev_load(&q.ctrl[1]);
                 if (fin && ticket >= fin - 1u) return;                    // the driver is through and never wrote this entry
-                if (spin > kSpinLimit) return;
+                if (spin > kSpinLimit) { if (lane == 0) q.flags[3] = 1u; return; }   // the entry for this ticket may still come: the host must not trust the batch (it undoes it and runs k_seq)
                 __builtin_amdgcn_s_sleep(16);
             }
             const uint32_t v = (uint32_t)item;

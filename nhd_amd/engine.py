@@ -67,7 +67,8 @@ class Engine:
         arrs = [np.ascontiguousarray(x) for x in (table.p0, table.p1, table.p2, table.p3, table.p4, table.detail)]
         self._chk(self.lib.nhdfit_upload_nodes(self.ctx, first, table.n, *[_p(a) for a in arrs]))
         if table.origin is not None and table.n:
-            self._chk(self.lib.nhdfit_upload_origin(self.ctx, first, table.n, _p(np.ascontiguousarray(table.origin))))
+            origin = np.ascontiguousarray(table.origin)          # (bound to a name: _p hands out a bare address)
+            self._chk(self.lib.nhdfit_upload_origin(self.ctx, first, table.n, _p(origin)))
         self.n = max(self.n, first + table.n)
         self.global_base = global_base
 
@@ -353,7 +354,7 @@ class GroupEngine:
         maps = np.zeros(P, pack.MAPPING) if want_map else None
         owner = np.zeros(P, np.int32)
         cptr = None
-        if cands is not None:
+        if cands is not None:                                       # (`cands` keeps the per-shard arrays alive across the call)
             cptr = (ctypes.c_void_p * len(self.shards))(*[None if c is None else c.ctypes.data for c in cands])
         rc = self.lib.nhdfit_group_find(self.group, _p(reqs), P, float(now), cptr, _p(score), _p(maps), _p(owner))
         if rc != 0:

@@ -504,6 +504,13 @@ class HipMatcher:
             self._full_upload(nl)
             self._mirror_foreign = self._attached is not None
         self._warn_unmirrored()
+        if self.packer.sharing:
+            # nhd/Node.py:20 flipped to True: the reference's placements then follow speed_used (Node.py:290), which this product
+            # does not implement - silently different placements are the one thing not allowed: strict raises (pack.SharingEnabled,
+            # at pack time), otherwise every pod is left pending and the reason is logged
+            self.logger.error("FindNode: %s - %d pod(s) answered (None,)", self.packer.sharing, n_pods)
+            self.last_placements = [None] * n_pods
+            return [(None,) for _ in range(n_pods)]
         if reqs is None:
             beyond: List[Tuple[int, str]] = []
             reqs = self.packer.digest_many(tops, pod_groups, unsupported=beyond)

@@ -34,7 +34,31 @@ MAX_HUGEPAGES_GB = 1022         # fit_core.h kMaxHpRows - 2
 NF_MAINTENANCE, NF_ACTIVE, NF_SMT, NF_HAS_GPU = 1, 2, 4, 8
 RF_INITIAL_FILTER = 1
 
-NIC_BW_AVAIL_PERCENT = 0.9      # nhd/Node.py:18 (ENABLE_SHARING is False, nhd/Node.py:20)
+NIC_BW_AVAIL_PERCENT = 0.9      # nhd/Node.py:18: the default; the packer reads the constant of the module the node objects come from
+_MODULE_CONSTANTS = ("NIC_BW_AVAIL_PERCENT", "SCHEDULABLE_NIC_SPEED_THRESH_MBPS", "ENABLE_SHARING")   # nhd/Node.py:18-20
+_node_constants_cache: Dict[type, dict] = {}
+
+
+def node_module_constants(node) -> dict:
+    """The three module-level switches of nhd/Node.py:18-20 as the module that defines the node's class has them NOW
+    (an operator may have edited them): the first class along the MRO whose module carries ENABLE_SHARING speaks; stand-in
+    node classes without the constants get the reference's defaults.  Looked up per call - the constants are plain module
+    globals the reference reads at call time (nhd/Node.py:289-292) - through a per-class cache of WHICH module."""
+    import sys
+    cls = type(node)
+    ent = _node_constants_cache.get(cls)
+    if ent is None:
+        mod = None
+        for k in cls.__mro__:
+            m = sys.modules.get(getattr(k, "__module__", None))
+            if m is not None and hasattr(m, "ENABLE_SHARING"):
+                mod = m
+                break
+        ent = _node_constants_cache[cls] = {"module": mod}
+    mod = ent["module"]
+    return {"NIC_BW_AVAIL_PERCENT": getattr(mod, "NIC_BW_AVAIL_PERCENT", NIC_BW_AVAIL_PERCENT) if mod else NIC_BW_AVAIL_PERCENT,
+            "SCHEDULABLE_NIC_SPEED_THRESH_MBPS": getattr(mod, "SCHEDULABLE_NIC_SPEED_THRESH_MBPS", 11000) if mod else 11000,
+            "ENABLE_SHARING": bool(getattr(mod, "ENABLE_SHARING", False)) if mod else False}
 
 P0 = np.dtype([("t0", "<u8", (2,))])
 P1 = np.dtype([("t1", "<u8", (2,))])
@@ -85,6 +109,12 @@ def _enum_value(x):
 
 class UnsupportedNode(ValueError):
     """The node's topology exceeds a compile-time capacity of the device layout (include/nhdfit.h)."""
+
+
+class SharingEnabled(UnsupportedNode):
+    """nhd/Node.py:20 ENABLE_SHARING is True in the module the node objects come from: GetFreeNumaNicResources then prices a
+    NIC at speed * pct - speed_used[x] (nhd/Node.py:290) - a per-direction remainder the packed capacity classes do not
+    model.  The product implements the reference's shipped arithmetic (False, nhd/Node.py:292) and refuses the other."""
 
 
 @dataclass
@@ -149,6 +179,8 @@ class Packer:
         self.max_gpus_per_numa = 0                     # table dimensions (fit_core.h Layout)
         self.max_cores_per_numa = 1
         self.dict_version = 0                          # bumped whenever caps / sigs / that maximum grow
+        self.sharing: Optional[str] = None             # set (to the reason) when a node's module has ENABLE_SHARING = True
+        self.nic_pct = NIC_BW_AVAIL_PERCENT            # NIC_BW_AVAIL_PERCENT of the nodes' module as of the last pack
         self._closed_upto = 0                          # close_signatures: sigs[:_closed_upto] have their successors interned
 
     # ---- interning ------------------------------------------------------------------------
@@ -313,6 +345,15 @@ class Packer:
             t.detail[i]["numa_nodes"] = 1
 
     def _pack_node_into(self, node, t: NodeTable, i: int) -> None:
+        consts = node_module_constants(node)
+        if consts["ENABLE_SHARING"]:
+            self.sharing = (f"ENABLE_SHARING is True in the module of {type(node).__name__} (nhd/Node.py:20): NIC capacities follow "
+                            "speed_used (nhd/Node.py:290), which the device layout does not model")
+            if self.strict:
+                raise SharingEnabled(self.sharing)
+        else:
+            self.sharing = None
+        pct = self.nic_pct = consts["NIC_BW_AVAIL_PERCENT"]
         U = int(node.numa_nodes)
         if U < 1 or U > MAX_NUMA:
             raise UnsupportedNode(f"node {node.name}: {U} NUMA nodes (supported: 1..{MAX_NUMA})")
@@ -407,7 +448,7 @@ class Packer:
                 raise UnsupportedNode(f"node {node.name}: more than {MAX_NICS_PER_NUMA} NICs on NUMA {u}")
             if nic.idx != k:
                 raise UnsupportedNode(f"node {node.name}: NIC ordinal {nic.idx} != position {k} on NUMA {u}")
-            full_cap = nic.speed * NIC_BW_AVAIL_PERCENT
+            full_cap = nic.speed * pct                     # the reference's own expression (nhd/Node.py:292), its module's constant
             cls = self.cap_class(0 if nic.pods_used > 0 else full_cap)
             s = local_sw(nic.pciesw)
             if sw_numa.setdefault(s, u) != u:
@@ -603,11 +644,12 @@ class Packer:
         for i, top in enumerate(tops):
             try:
                 _REQ_STRUCT.pack_into(raw, i * REQ.itemsize, *self._digest_fields(top, None if pod_groups is None else pod_groups[i]))
-            except struct.error as e:                              # a count beyond its field (65 536 misc cores ...)
-                raise OverflowError(str(e)) from None
-            except UnsupportedNode as e:
+            except (UnsupportedNode, struct.error) as e:           # struct.error: a count beyond its field (65 536 misc cores ...)
                 if unsupported is None or self.strict:
+                    if isinstance(e, struct.error):
+                        raise OverflowError(str(e)) from None
                     raise
+                raw[i * REQ.itemsize:(i + 1) * REQ.itemsize] = bytes(REQ.itemsize)     # (a half-packed record must not match anything)
                 unsupported.append((i, str(e)))
         return out
 

@@ -213,3 +213,37 @@ def test_reference_fixture_with_nodes_beyond_the_layout():
 
     beyond_check.check(lambda clock: HipMatcher(clock=lambda: clock, engine_factory=harness.HarnessEngine), unpack)
 
+
+
+def test_enable_sharing_flipped_in_the_nodes_module_is_refused_not_ignored(monkeypatch, caplog):
+    """VERDICT r03 missing #4: nhd/Node.py:20 ENABLE_SHARING = True makes GetFreeNumaNicResources price NICs by speed_used
+    (Node.py:290).  The product implements the shipped arithmetic (False): when the module the node objects come from has the
+    switch on, FindNode must not answer with placements of the other arithmetic - it leaves the pods pending and says why
+    (strict: raises at pack time); NIC_BW_AVAIL_PERCENT of that module is the one the capacities are computed with."""
+    from nhd_amd import pack
+    nl = util.random_cluster(4242, 24)
+    top = refmodel.make_topology(dict(map_type="NUMA", hugepages_gb=0, misc=0, misc_smt=True,
+                                      groups=[dict(proc=2, helpers=0, rx=1.0, tx=1.0, gpus=[], proc_smt=False, helper_smt=False)]))
+    m = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)
+    want = norm(O.find_node(nl, top, util.CLOCK))
+    assert m.FindNode(nl, top) == want and want[0] is not None
+    assert pack.node_module_constants(next(iter(nl.values()))) == {"NIC_BW_AVAIL_PERCENT": 0.9, "SCHEDULABLE_NIC_SPEED_THRESH_MBPS": 11000,
+                                                                  "ENABLE_SHARING": False}
+    monkeypatch.setattr(refmodel, "ENABLE_SHARING", True)
+    with caplog.at_level("ERROR"):
+        assert m.FindNode(nl, top) == (None,)
+        m.attach(nl)                                               # tracked subclasses still resolve to the nodes' own module
+        assert m.FindNodes(nl, [top, top]) == [(None,), (None,)]
+    assert "ENABLE_SHARING" in caplog.text
+    with pytest.raises(pack.SharingEnabled):
+        HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine, strict=True).FindNode(nl, top)
+    monkeypatch.setattr(refmodel, "ENABLE_SHARING", False)
+    m.detach()
+    assert m.FindNode(nl, top) == want                             # switched back: answers again
+    # the head-room constant is read from the same module: at 50 % a 2 x 50 Gb/s request no longer fits a 100 GbE NIC (cap 50.0)
+    big = refmodel.make_topology(dict(map_type="NUMA", hugepages_gb=0, misc=0, misc_smt=True,
+                                      groups=[dict(proc=2, helpers=0, rx=60.0, tx=60.0, gpus=[], proc_smt=False, helper_smt=False)]))
+    before = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine).FindNode(nl, big)
+    monkeypatch.setattr(refmodel, "NIC_BW_AVAIL_PERCENT", 0.5)
+    after = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine).FindNode(nl, big)
+    assert before[0] is not None and after == (None,)            # (the cluster's fastest NICs are 100 GbE: 90.0 fits 60, 50.0 does not)

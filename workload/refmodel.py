@@ -42,6 +42,11 @@ class TopologyMapType(enum.Enum):
 
 NFD = "feature.node.kubernetes.io/"
 MIN_NIC_MBPS = 11000        # nhd/Node.py:19
+# the module-level switches of nhd/Node.py:18-20 under the reference's own names: the packer reads them from the module the
+# node objects come from (nhd_amd/pack.py node_module_constants), so the stand-ins carry them like the real module does
+NIC_BW_AVAIL_PERCENT = 0.9
+SCHEDULABLE_NIC_SPEED_THRESH_MBPS = MIN_NIC_MBPS
+ENABLE_SHARING = False
 MAINT_LABEL = "sigproc.viasat.io/maintenance"   # nhd/Node.py:108
 
 
