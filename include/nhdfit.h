@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NHDFIT_ABI_VERSION        6
+#define NHDFIT_ABI_VERSION        7
 #define NHDFIT_MAX_GROUPS         4      /* proc groups per pod (G)                               */
 #define NHDFIT_MAX_NUMA           2      /* NUMA nodes (= sockets, nhd/Node.py:336) per node (U)  */
 #define NHDFIT_MAX_CORES_PER_NUMA 64     /* physical cores per socket (one uint64 mask)           */
@@ -198,8 +198,63 @@ typedef struct {
 #define NHDFIT_COMMIT_WOULD_RAISE 1   /* the reference's commit raises IndexError (a batch short after the walk over both thread
                                          ranges, no free GPU on a PCI-mode group's switch, no such NIC) or hands an SMT request
                                          its own cores twice: parity undefined from here on; the mirror is left as the walk left it */
+#define NHDFIT_COMMIT_WIDE        3   /* nhdfit_schedule_batch: the pod landed on a wide node - its physical ids are in nhdfit_wide_placements */
 #define NHDFIT_COMMIT_NEW_SIG     2   /* committed, but the node's new NIC state has no signature in the dictionary yet: intern
                                          it (download the node, re-derive its signatures) and upload its plane 3           */
+
+/* ---- nodes beyond the fast layout: the general path ("wide" nodes) -------------------------------------------------------
+ * The reference enumerates range(v.numa_nodes) for any socket count and repeat=len(req) for any group count
+ * (nhd/Matcher.py:118,203,242) over any cores_per_proc (nhd/Node.py:257,336-350).  The planes above hold two sockets of up to
+ * 64 physical cores - what the table-driven P x N pass is built for.  A node outside that shape (3 or 4 sockets, 65..128
+ * physical cores per socket) is mirrored TWICE: as a placeholder in the planes (flags = NHDFIT_NF_MAINTENANCE: the table pass
+ * never matches it, node indices stay what they are) and as one self-contained record below, which the general path evaluates
+ * by explicit enumeration - lane = (wide node, pod) - with the reference's own arithmetic (wide_core.h): its verdict bit lands
+ * in the same verdict matrix, its score in the same score word (atomicMax: the word carries the global node index, so the first
+ * feasible node of the whole candidate order wins wherever it is mirrored), its mapping comes from the general CPython set
+ * model (tuples over range(U), tables of up to 4 096 slots).  The commit step and mode B are served for these nodes too
+ * (nhdfit_wide_commit; nhdfit_schedule_batch decides pod by pod when the mirror holds wide nodes).  Release / reclaim / reset
+ * re-upload the node's record (640 bytes) instead of travelling as a delta.  Slower per (pod, node) pair than the table pass by
+ * three orders of magnitude - and exact. */
+#define NHDFIT_WIDE_MAX_NUMA      4      /* sockets (= NUMA nodes, nhd/Node.py:336) of a wide node                         */
+#define NHDFIT_WIDE_CORE_WORDS    8      /* flat bitmaps over the node's physical cores: 512 = 4 sockets x 128            */
+#define NHDFIT_WIDE_MAX_CORES_PER_NUMA 128
+typedef struct {
+    uint64_t t0[NHDFIT_WIDE_CORE_WORDS];      /* bit c: logical core c (thread 0 of physical core c, socket c / cores_per_proc) unused */
+    uint64_t t1[NHDFIT_WIDE_CORE_WORDS];      /* bit c: its SMT sibling (logical id c + num_cores) unused; all ones without SMT         */
+    uint64_t o0[NHDFIT_WIDE_CORE_WORDS];      /* t0 / t1 as ResetResources leaves them (nhd/Node.py:144-161)                            */
+    uint64_t o1[NHDFIT_WIDE_CORE_WORDS];
+    uint64_t groups;                          /* interned NHD_GROUP set                                                                  */
+    double   busy_time;                       /* Node.busy_time                                                                          */
+    uint32_t gpu_free;                        /* bit g: Node.gpus[g] unused                                                              */
+    uint32_t flags;                           /* NHDFIT_NF_*                                                                             */
+    int32_t  hp_free, hp_total;               /* Node.mem.free_hugepages_gb / ttl_hugepages_gb                                           */
+    uint32_t index;                           /* the node's local index in the mirror (candidate order)                                  */
+    uint16_t cores_per_proc;                  /* physical cores per socket, 1..128                                                       */
+    uint8_t  numa_nodes;                      /* 1..4                                                                                    */
+    uint8_t  n_gpus;                          /* len(Node.gpus), <= 32                                                                   */
+    uint8_t  nic_cnt[NHDFIT_WIDE_MAX_NUMA];
+    uint8_t  gpu_numa[NHDFIT_MAX_GPUS];       /* Node.gpus[g].numa_node                                                                  */
+    uint8_t  gpu_sw[NHDFIT_MAX_GPUS];         /* local id of its PCIe switch (ids are per node: equal id = same switch)                  */
+    uint8_t  nic_cls[NHDFIT_WIDE_MAX_NUMA][NHDFIT_MAX_NICS_PER_NUMA];    /* capacity class of NIC (numa, idx) as it is now              */
+    uint8_t  nic_base[NHDFIT_WIDE_MAX_NUMA][NHDFIT_MAX_NICS_PER_NUMA];   /* ... of speed * pct: its class whenever pods_used <= 0        */
+    uint8_t  nic_sw[NHDFIT_WIDE_MAX_NUMA][NHDFIT_MAX_NICS_PER_NUMA];     /* local switch id                                               */
+    int8_t   nic_pods[NHDFIT_WIDE_MAX_NUMA][NHDFIT_MAX_NICS_PER_NUMA];   /* Node.nics[].pods_used, saturating at +-127                    */
+    uint8_t  pad[20];
+} nhdfit_wide_node;                           /* 640 bytes */
+
+/* physical ids of one placement on a wide node: nhdfit_placement with two mask words per batch (bit b of the pair = physical
+ * core b of the batch's socket, logical id numa * cores_per_proc + b; sibling id + num_cores) */
+typedef struct {
+    uint64_t proc_take[NHDFIT_MAX_GROUPS][2], proc_pair[NHDFIT_MAX_GROUPS][2], proc_late[NHDFIT_MAX_GROUPS][2];
+    uint64_t help_take[NHDFIT_MAX_GROUPS][2], help_pair[NHDFIT_MAX_GROUPS][2], help_late[NHDFIT_MAX_GROUPS][2];
+    uint64_t misc_take[2], misc_pair[2], misc_late[2];
+    uint8_t  gpu[NHDFIT_MAX_GROUPS][NHDFIT_PLACEMENT_GPUS];
+    int8_t   numa[NHDFIT_MAX_GROUPS + 1];
+    uint8_t  status;                          /* NHDFIT_COMMIT_OK / NHDFIT_COMMIT_WOULD_RAISE */
+    uint8_t  pad[2];
+    uint32_t pod;                             /* nhdfit_wide_placements: index of the pod in the batch */
+    uint32_t node;                            /* ... and the local index of the node                    */
+} nhdfit_wide_placement;                      /* 480 bytes */
 
 typedef struct {
     uint64_t launches;          /* step-kernel launches carrying a fit role that were timed (every 8th step)   */
@@ -251,6 +306,20 @@ int nhdfit_upload_nodes(nhdfit_ctx* ctx, uint32_t first, uint32_t count,
                         const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2,
                         const nhdfit_plane3* p3, const nhdfit_plane4* p4, const nhdfit_detail* detail);
 int nhdfit_set_node_count(nhdfit_ctx* ctx, uint32_t n_nodes);
+
+/* The wide records of the mirror's nodes [first, first + count): `n_wide` records (ascending `index`, each inside the range)
+ * replace whatever wide records the mirror held for that range (none: the range holds ordinary nodes only).  Call it for every
+ * range nhdfit_upload_nodes is called for when the packer produced wide nodes (their planes carry the placeholder). */
+int nhdfit_wide_upload(nhdfit_ctx* ctx, uint32_t first, uint32_t count, const nhdfit_wide_node* wide, uint32_t n_wide);
+/* how many wide records the mirror holds / read them back (ascending index) */
+int nhdfit_wide_count(nhdfit_ctx* ctx, uint32_t* n_wide);
+int nhdfit_wide_download(nhdfit_ctx* ctx, nhdfit_wide_node* out, uint32_t cap, uint32_t* n_wide);
+/* nhdfit_commit for a wide node (`node` = its local index in the mirror): updates its record, returns the physical ids */
+int nhdfit_wide_commit(nhdfit_ctx* ctx, uint32_t node, const nhdfit_req* req, const nhdfit_mapping* map, double busy_time,
+                       nhdfit_wide_placement* place_out);
+/* placements nhdfit_schedule_batch's last call made on wide nodes (their nhdfit_placement entries carry status
+ * NHDFIT_COMMIT_WIDE): up to `cap` records, *n = how many there are */
+int nhdfit_wide_placements(nhdfit_ctx* ctx, nhdfit_wide_placement* out, uint32_t cap, uint32_t* n);
 
 /* The nhdfit_origin records of nodes [first, first+count) (needed by nhdfit_apply_deltas; uploaded next to the planes). */
 int nhdfit_upload_origin(nhdfit_ctx* ctx, uint32_t first, uint32_t count, const nhdfit_origin* origin);

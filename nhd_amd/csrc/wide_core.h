@@ -1,0 +1,446 @@
+// wide_core.h - the general path: nodes beyond the fast layout (3 or 4 sockets, 65..128 physical cores per socket),
+// evaluated by explicit enumeration with the reference's own arithmetic.  Written once for the gfx950 kernels
+// (wide_kernel.h) and the host twin of the tests.
+//
+// The table-driven pass (fit_core.h) is built around two sockets of at most 64 physical cores: an assignment is a bit
+// pattern, a table row a mask over 2^G assignments.  The reference itself is general - it enumerates
+// itertools.product(range(v.numa_nodes), repeat=len(req)) for whatever v.numa_nodes is (nhd/Matcher.py:118, 203, 242) over
+// whatever cores_per_proc the labels say (nhd/Node.py:257, 336-350).  A node outside the fast shape is therefore carried
+// as ONE self-contained record (nhdfit_wide_node, include/nhdfit.h) and every question the path asks about it is answered
+// here the way the reference answers it, assignment by assignment:
+//
+//   wide_fits      FilterPodResources + the GPU / CPU / NIC stages + the PCI pruning + the intersection   Matcher.py:65-391
+//   wide_map       GetNumaGroupIdx over the lists those stages leave, i.e. over CPython sets of int       Matcher.py:337-452
+//                  tuples: the set model of winner_map.h for tuples over range(U), U <= 4, with tables of
+//                  up to 4 096 slots held in caller-provided scratch (keys only: hashes are recomputed)
+//   wide_commit    SetBusy + SetPhysicalIdsFromMapping + ClaimPodNICResources                             Node.py:663-841, 644
+//
+// Nothing here is fast; everything here is exact (f64 NIC arithmetic in the reference's order, -ffp-contract=off).
+#pragma once
+#include "winner_map.h"
+
+namespace nhdfit {
+
+constexpr int kWideU = NHDFIT_WIDE_MAX_NUMA;
+constexpr int kWideMaxTuples = 1024;                 // U^(G+1) <= 4^5
+constexpr int kWideSetSlotsG = 1024;                 // a CPython set of <= 256 keys never outgrows 1 024 slots (growth: fill*5 >= mask*3 -> 4 x used)
+constexpr int kWideSetSlotsC = 4096;                 // ... of <= 1 024 keys: 2 048; 4 096 leaves the model room to say so itself
+// scratch of one mapping (int16 keys): sg, a, b, c, ab, abc over G-tuples; sc over (G+1)-tuples; one resize buffer
+constexpr int kWideScratchWords = 6 * kWideSetSlotsG + 2 * kWideSetSlotsC;
+static_assert(sizeof(nhdfit_wide_node) == 640 && sizeof(nhdfit_wide_placement) == 480, "record sizes of include/nhdfit.h");
+
+NHD_HD uint32_t wide_ipow(uint32_t b, uint32_t e) { uint32_t r = 1; for (uint32_t i = 0; i < e; ++i) r *= b; return r; }
+// digit i (i = 0: first element) of tuple `code` of length `len` over range(U): first element most significant, so that
+// ascending codes are itertools.product order
+NHD_HD uint32_t wide_digit(uint32_t code, uint32_t len, uint32_t U, uint32_t i) {
+    for (uint32_t k = i + 1; k < len; ++k) code /= U;
+    return code % U;
+}
+
+// ---- the node's free resources ------------------------------------------------------------------------------------------
+NHD_HD bool wide_bit(const uint64_t* w, uint32_t c) { return (w[c >> 6] >> (c & 63)) & 1u; }
+NHD_HD void wide_clear(uint64_t* w, uint32_t c) { w[c >> 6] &= ~(1ull << (c & 63)); }
+
+struct WideFree { uint32_t U; bool smt; uint32_t c[kWideU], g[kWideU]; };
+
+NHD_HD bool wide_shape_ok(const nhdfit_wide_node& n) {
+    return n.numa_nodes >= 1 && n.numa_nodes <= kWideU && n.cores_per_proc >= 1 && n.cores_per_proc <= NHDFIT_WIDE_MAX_CORES_PER_NUMA &&
+           n.n_gpus <= NHDFIT_MAX_GPUS;
+}
+
+// GetFreeCpuCores (nhd/Node.py:250-264) / GetFreeNumaGPUs (456-462)
+NHD_HD WideFree wide_free(const nhdfit_wide_node& n) {
+    WideFree f;
+    f.U = n.numa_nodes;
+    f.smt = (n.flags & NHDFIT_NF_SMT) != 0;
+    for (uint32_t u = 0; u < (uint32_t)kWideU; ++u) { f.c[u] = 0; f.g[u] = 0; }
+    const uint32_t cpp = n.cores_per_proc;
+    for (uint32_t u = 0; u < f.U; ++u)
+        for (uint32_t b = 0; b < cpp; ++b) {
+            const uint32_t c = u * cpp + b;
+            if (wide_bit(n.t0, c) && wide_bit(n.t1, c)) f.c[u]++;
+        }
+    for (uint32_t x = 0; x < n.n_gpus; ++x)
+        if ((n.gpu_free >> x & 1u) && n.gpu_numa[x] < f.U) f.g[n.gpu_numa[x]]++;
+    return f;
+}
+// GetFreeGPUPCICount (nhd/Node.py:266-273) for one local switch id
+NHD_HD uint32_t wide_sw_free(const nhdfit_wide_node& n, uint32_t sw) {
+    uint32_t k = 0;
+    for (uint32_t x = 0; x < n.n_gpus; ++x)
+        if ((n.gpu_free >> x & 1u) && n.gpu_sw[x] == sw) ++k;
+    return k;
+}
+
+// ---- stages ------------------------------------------------------------------------------------------------------------
+// GPU stage, one assignment (Matcher.py:120-131)
+NHD_HD bool wide_gpu_ok(const nhdfit_req& r, const WideFree& f, uint32_t code) {
+    uint32_t ttl[kWideU] = {0, 0, 0, 0};
+    for (uint32_t g = 0; g < r.n_groups; ++g) ttl[wide_digit(code, r.n_groups, f.U, g)] += r.gpus[g];
+    for (uint32_t u = 0; u < f.U; ++u)
+        if (ttl[u] > f.g[u]) return false;
+    return true;
+}
+// CPU stage, one (G+1)-tuple: the last element places the pod-level misc cores (Matcher.py:206-216)
+NHD_HD bool wide_cpu_ok(const nhdfit_req& r, const WideFree& f, uint32_t code) {
+    uint32_t ttl[kWideU] = {0, 0, 0, 0};
+    const uint32_t len = r.n_groups + 1;
+    for (uint32_t g = 0; g < len; ++g) {
+        const uint32_t d = g < r.n_groups ? (f.smt ? r.cpu_smt[g] : r.cpu_nosmt[g]) : (f.smt ? r.misc_smt : r.misc_nosmt);
+        ttl[wide_digit(code, len, f.U, g)] += d;
+    }
+    for (uint32_t u = 0; u < f.U; ++u)
+        if (ttl[u] > f.c[u]) return false;
+    return true;
+}
+
+// First NIC choice, in the reference's enumeration order (Matcher.py:242-268: itertools.product over the NUMA nodes of
+// itertools.product(range(K_u), repeat=#groups on u) - an odometer whose most significant digits are the groups of NUMA node
+// 0 in ascending group index, then those of NUMA node 1, ...), that passes the bandwidth test (261-267: each NIC's [cap, cap]
+// minus the requests of its groups in group order, nothing below zero) and, in PCI mode, the switch test (312-322: no more
+// groups behind a switch than it has free GPUs).  Both tests only get harder as groups are added when every request is
+// >= 0, so depth-first search in the same order with prefix pruning returns the same first combination (first_nic_choice,
+// winner_map.h); requests that are negative or NaN take the plain odometer.
+NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const nhdfit_req& r, const double* caps, uint32_t gcode, int8_t nic_idx[kMaxG]) {
+    const uint32_t G = r.n_groups, U = n.numa_nodes;
+    const bool pci = r.map_type == NHDFIT_MAP_PCI;
+    uint32_t order[kMaxG], numa[kMaxG], pick[kMaxG];
+    uint32_t cnt = 0;
+    for (uint32_t g = 0; g < G; ++g) { numa[g] = wide_digit(gcode, G, U, g); pick[g] = 0; }
+    for (uint32_t u = 0; u < U; ++u)
+        for (uint32_t g = 0; g < G; ++g)
+            if (numa[g] == u) order[cnt++] = g;
+    for (uint32_t g = 0; g < G; ++g)
+        if (n.nic_cnt[numa[g]] == 0) return false;             // a NUMA node without NICs hosts no group (quirk Q3)
+    bool prune = true;
+    for (uint32_t g = 0; g < G; ++g)
+        if (!(r.rx[g] >= 0) || !(r.tx[g] >= 0)) prune = false;
+    // groups order[0..pos] assigned: does the NIC of the newest one still hold, and its switch?
+    auto nic_holds = [&](uint32_t upto, uint32_t u, uint32_t k) {
+        double rx = caps[n.nic_cls[u][k]], tx = rx;
+        for (uint32_t q = 0; q <= upto; ++q) {                 // same NUMA node => ascending group index along `order`
+            const uint32_t h = order[q];
+            if (numa[h] == u && pick[h] == k) { rx = rx - r.rx[h]; tx = tx - r.tx[h]; }
+        }
+        return !(rx < 0) && !(tx < 0);                         // Matcher.py:267
+    };
+    auto switch_holds = [&](uint32_t upto, uint32_t sw) {
+        uint32_t c = 0;
+        for (uint32_t q = 0; q <= upto; ++q) {
+            const uint32_t h = order[q];
+            if (n.nic_sw[numa[h]][pick[h]] == sw) ++c;
+        }
+        return c <= wide_sw_free(n, sw);                       // Matcher.py:318-322
+    };
+    if (prune) {
+        int pos = 0;
+        for (;;) {
+            const uint32_t g = order[pos];
+            const bool ok = nic_holds((uint32_t)pos, numa[g], pick[g]) && (!pci || switch_holds((uint32_t)pos, n.nic_sw[numa[g]][pick[g]]));
+            if (ok) {
+                if (pos == (int)G - 1) { for (uint32_t q = 0; q < G; ++q) nic_idx[q] = (int8_t)pick[q]; return true; }
+                ++pos;                                         // (the next group starts at its first NIC: its pick is 0)
+                continue;
+            }
+            for (;;) {                                         // next candidate: advance this digit, or back up
+                const uint32_t h = order[pos];
+                if (pick[h] + 1 < n.nic_cnt[numa[h]]) { pick[h]++; break; }
+                pick[h] = 0;
+                if (--pos < 0) return false;
+            }
+        }
+    }
+    for (;;) {                                                 // the enumeration as the reference writes it
+        bool ok = true;
+        for (uint32_t q = 0; q < G && ok; ++q) {
+            const uint32_t g = order[q];
+            ok = nic_holds(G - 1, numa[g], pick[g]) && (!pci || switch_holds(G - 1, n.nic_sw[numa[g]][pick[g]]));
+        }
+        if (ok) { for (uint32_t q = 0; q < G; ++q) nic_idx[q] = (int8_t)pick[q]; return true; }
+        int pos = (int)G - 1;
+        while (pos >= 0) {
+            const uint32_t h = order[pos];
+            if (pick[h] + 1 < n.nic_cnt[numa[h]]) { pick[h]++; break; }
+            pick[h] = 0;
+            --pos;
+        }
+        if (pos < 0) return false;
+    }
+}
+
+// scalar predicates (Matcher.py:65-84, 107-111; InitialNodeFilter NHDScheduler.py:235-247 when the request asks for it)
+NHD_HD bool wide_scalar_ok(const nhdfit_wide_node& n, const nhdfit_req& r, bool busy) {
+    if (!req_valid(r) || !wide_shape_ok(n)) return false;
+    if (n.flags & NHDFIT_NF_MAINTENANCE) return false;
+    if (r.hugepages_gb > n.hp_free) return false;
+    if (r.flags & NHDFIT_RF_INITIAL_FILTER)
+        if (!(n.flags & NHDFIT_NF_ACTIVE) || !(n.groups & r.groups)) return false;
+    if (busy) {
+        uint32_t want = 0;
+        for (uint32_t g = 0; g < r.n_groups; ++g) want += r.gpus[g];
+        if (want) return false;
+    }
+    return true;
+}
+
+// feasible(node, pod): some assignment passes all three stages (the set intersection of Matcher.py:346 is non-empty)
+NHD_HD bool wide_fits(const nhdfit_wide_node& n, const nhdfit_req& r, bool busy, const double* caps) {
+    if (!wide_scalar_ok(n, r, busy)) return false;
+    const WideFree f = wide_free(n);
+    const uint32_t G = r.n_groups, nG = wide_ipow(f.U, G);
+    int8_t nic[kMaxG];
+    for (uint32_t code = 0; code < nG; ++code) {
+        if (!wide_gpu_ok(r, f, code)) continue;
+        bool cpu = false;
+        for (uint32_t m = 0; m < f.U && !cpu; ++m) cpu = wide_cpu_ok(r, f, code * f.U + m);
+        if (!cpu) continue;
+        if (wide_nic_choice(n, r, caps, code, nic)) return true;
+    }
+    return false;
+}
+
+// ---- CPython sets of int tuples over range(U) (winner_map.h's model, tables in scratch) --------------------------------------
+// hash((d0, d1, ..)): Objects/tupleobject.c tuplehash() with hash(int k) == k
+NHD_HD uint64_t wide_tuple_hash(uint32_t code, uint32_t len, uint32_t U) {
+    uint64_t acc = kXX5;
+    for (uint32_t i = 0; i < len; ++i) {
+        const uint64_t lane = wide_digit(code, len, U, i);
+        acc += lane * kXX2;
+        acc = (acc << 31) | (acc >> 33);
+        acc *= kXX1;
+    }
+    acc += (uint64_t)len ^ (kXX5 ^ 3527539ULL);
+    if (acc == (uint64_t)-1) return 1546275796ULL;
+    return acc;
+}
+
+struct WideSet {
+    int16_t* key;          // [cap] -1 = unused slot
+    int32_t cap, mask, fill;
+    uint32_t len, U;       // tuple length, digit base
+    bool overflow;         // the table would have outgrown `cap` (cannot happen for the sizes above; reported, never silent)
+};
+NHD_HD void ws_init(WideSet& s, int16_t* mem, int32_t cap, uint32_t len, uint32_t U) {
+    s.key = mem; s.cap = cap; s.mask = 7; s.fill = 0; s.len = len; s.U = U; s.overflow = false;
+    for (int32_t i = 0; i < 8; ++i) mem[i] = -1;
+}
+NHD_HD void ws_insert_clean(int16_t* key, int32_t mask, int16_t k, uint64_t h) {      // set_insert_clean()
+    uint64_t perturb = h;
+    uint64_t i = h & (uint64_t)mask;
+    for (;;) {
+        if (key[i] < 0) break;
+        bool found = false;
+        if (i + 9 <= (uint64_t)mask)
+            for (int j = 1; j <= 9; ++j)
+                if (key[i + j] < 0) { i += j; found = true; break; }
+        if (found) break;
+        perturb >>= 5;
+        i = (i * 5 + 1 + perturb) & (uint64_t)mask;
+    }
+    key[i] = k;
+}
+NHD_HD void ws_resize(WideSet& s, int32_t minused, int16_t* tmp) {                    // set_table_resize()
+    int32_t newsize = 8;
+    while (newsize <= minused) newsize <<= 1;
+    if (newsize > s.cap) { s.overflow = true; return; }
+    const int32_t oldmask = s.mask;
+    for (int32_t i = 0; i <= oldmask; ++i) tmp[i] = s.key[i];
+    for (int32_t i = 0; i < newsize; ++i) s.key[i] = -1;
+    s.mask = newsize - 1;
+    for (int32_t i = 0; i <= oldmask; ++i)
+        if (tmp[i] >= 0) ws_insert_clean(s.key, s.mask, tmp[i], wide_tuple_hash((uint32_t)tmp[i], s.len, s.U));
+}
+NHD_HD bool ws_has(const WideSet& s, int16_t k) {
+    const uint64_t h = wide_tuple_hash((uint32_t)k, s.len, s.U);
+    uint64_t perturb = h;
+    uint64_t i = h & (uint64_t)s.mask;
+    for (;;) {
+        const int probes = (i + 9 <= (uint64_t)s.mask) ? 9 : 0;
+        for (int j = 0; j <= probes; ++j) {
+            if (s.key[i + j] < 0) return false;
+            if (s.key[i + j] == k) return true;
+        }
+        perturb >>= 5;
+        i = (i * 5 + 1 + perturb) & (uint64_t)s.mask;
+    }
+}
+NHD_HD void ws_add(WideSet& s, int16_t k, int16_t* tmp) {                             // set_add_entry()
+    if (s.overflow) return;
+    const uint64_t h = wide_tuple_hash((uint32_t)k, s.len, s.U);
+    uint64_t perturb = h;
+    uint64_t i = h & (uint64_t)s.mask;
+    for (;;) {
+        const int probes = (i + 9 <= (uint64_t)s.mask) ? 9 : 0;
+        for (int j = 0; j <= probes; ++j) {
+            if (s.key[i + j] < 0) {
+                s.key[i + j] = k;
+                s.fill++;
+                if (s.fill * 5 >= s.mask * 3) ws_resize(s, s.fill * 4, tmp);
+                return;
+            }
+            if (s.key[i + j] == k) return;
+        }
+        perturb >>= 5;
+        i = (i * 5 + 1 + perturb) & (uint64_t)s.mask;
+    }
+}
+NHD_HD int32_t ws_next(const WideSet& s, int32_t from) {                              // iteration = slot order
+    for (int32_t i = from; i <= s.mask; ++i)
+        if (s.key[i] >= 0) return i;
+    return -1;
+}
+// out = a & b: iterate the smaller operand (b on ties) in slot order, probe the other (set_intersection())
+NHD_HD void ws_intersect(const WideSet& a, const WideSet& b, WideSet& out, int16_t* tmp) {
+    const WideSet* probe = &a;
+    const WideSet* iter = &b;
+    if (b.fill > a.fill) { probe = &b; iter = &a; }
+    for (int32_t i = ws_next(*iter, 0); i >= 0; i = ws_next(*iter, i + 1))
+        if (ws_has(*probe, iter->key[i])) ws_add(out, iter->key[i], tmp);
+}
+
+// max - min over y in range(U) of tuple.count(y) (GetNumaGroupIdx's node_delta, Matcher.py:428-430)
+NHD_HD int wide_spread(uint32_t code, uint32_t G, uint32_t U) {
+    int cnt[kWideU] = {0, 0, 0, 0};
+    for (uint32_t g = 0; g < G; ++g) cnt[wide_digit(code, G, U, g)]++;
+    int mx = cnt[0], mn = cnt[0];
+    for (uint32_t u = 1; u < U; ++u) { mx = cnt[u] > mx ? cnt[u] : mx; mn = cnt[u] < mn ? cnt[u] : mn; }
+    return mx - mn;
+}
+NHD_HD int32_t wide_pick_gpu_tuple(const WideSet& s, uint32_t G, uint32_t U) {        // first maximiser in list(set) order
+    int32_t best = -1;
+    int best_spread = -1;
+    for (int32_t i = ws_next(s, 0); i >= 0; i = ws_next(s, i + 1)) {
+        const int sp = wide_spread((uint32_t)s.key[i], G, U);
+        if (sp > best_spread) { best_spread = sp; best = s.key[i]; }
+    }
+    return best;
+}
+
+// The winner-only tail of FindNode on a wide node (Matcher.py:337-391 + 423-452).  `scratch`: kWideScratchWords int16.
+// Returns 1 = mapped, 0 = the node does not take the pod, -1 = a set outgrew its table (never expected; the caller reports it).
+NHD_HD int wide_map(const nhdfit_wide_node& n, const nhdfit_req& r, const double* caps, int16_t* scratch, nhdfit_mapping& out) {
+    for (int g = 0; g < kMaxG; ++g) { out.gpu[g] = out.nic_numa[g] = out.nic_idx[g] = -1; }
+    for (int g = 0; g <= kMaxG; ++g) out.cpu[g] = -1;
+    out.valid = 0; out.pad[0] = out.pad[1] = 0;
+    if (!req_valid(r) || !wide_shape_ok(n)) return 0;
+    const WideFree f = wide_free(n);
+    const uint32_t G = r.n_groups, U = f.U, nG = wide_ipow(U, G), nC = nG * U;
+    if (nC > (uint32_t)kWideMaxTuples) return -1;
+    int16_t* mem = scratch;
+    WideSet sg, sc, a, b, c, ab, abc;
+    ws_init(sg, mem, kWideSetSlotsG, G, U); mem += kWideSetSlotsG;
+    ws_init(a, mem, kWideSetSlotsG, G, U); mem += kWideSetSlotsG;
+    ws_init(b, mem, kWideSetSlotsG, G, U); mem += kWideSetSlotsG;
+    ws_init(c, mem, kWideSetSlotsG, G, U); mem += kWideSetSlotsG;
+    ws_init(ab, mem, kWideSetSlotsG, G, U); mem += kWideSetSlotsG;
+    ws_init(abc, mem, kWideSetSlotsG, G, U); mem += kWideSetSlotsG;
+    ws_init(sc, mem, kWideSetSlotsC, G + 1, U); mem += kWideSetSlotsC;
+    int16_t* tmp = mem;
+    // candidate sets, filled in product order (Matcher.py:116-141, 206-220, 242-268 + 294-335)
+    int8_t nic[kMaxG];
+    for (uint32_t code = 0; code < nG; ++code) {
+        if (wide_gpu_ok(r, f, code)) ws_add(sg, (int16_t)code, tmp);
+        if (wide_nic_choice(n, r, caps, code, nic)) ws_add(c, (int16_t)code, tmp);
+    }
+    for (uint32_t code = 0; code < nC; ++code)
+        if (wide_cpu_ok(r, f, code)) ws_add(sc, (int16_t)code, tmp);
+    if (!sg.fill || !sc.fill || !c.fill) return 0;
+    // set(gpu_tuples) & set(cpu_tuples) & set(nic_tuples): set(list) re-inserts in list (= slot) order
+    for (int32_t i = ws_next(sg, 0); i >= 0; i = ws_next(sg, i + 1)) ws_add(a, sg.key[i], tmp);
+    for (int32_t i = ws_next(sc, 0); i >= 0; i = ws_next(sc, i + 1)) ws_add(b, (int16_t)(sc.key[i] / (int16_t)U), tmp);     // tuple[:-1]
+    ws_intersect(a, b, ab, tmp);
+    ws_intersect(ab, c, abc, tmp);
+    if (sg.overflow || sc.overflow || a.overflow || b.overflow || c.overflow || ab.overflow || abc.overflow) return -1;
+    if (!abc.fill) return 0;
+    // the GPU list is replaced by the intersection only if that drops something (Matcher.py:363-366)
+    const int32_t gcode = abc.fill < sg.fill ? wide_pick_gpu_tuple(abc, G, U) : wide_pick_gpu_tuple(sg, G, U);
+    int32_t ccode = -1;                                                              // Matcher.py:441-444
+    for (int32_t i = ws_next(sc, 0); i >= 0 && ccode < 0; i = ws_next(sc, i + 1))
+        if (sc.key[i] / (int16_t)U == gcode) ccode = sc.key[i];
+    if (gcode < 0 || ccode < 0) return 0;
+    if (!wide_nic_choice(n, r, caps, (uint32_t)gcode, out.nic_idx)) return 0;
+    for (uint32_t g = 0; g < G; ++g) { out.gpu[g] = (int8_t)wide_digit((uint32_t)gcode, G, U, g); out.nic_numa[g] = out.gpu[g]; }
+    for (uint32_t g = 0; g <= G; ++g) out.cpu[g] = (int8_t)wide_digit((uint32_t)ccode, G + 1, U, g);
+    out.valid = 1;
+    return 1;
+}
+
+// ---- the commit step (commit_core.h, on the wide record) -----------------------------------------------------------------
+// GetFreeCpuBatch(numa, num, smt) (nhd/Node.py:502-519) over socket u's range of the flat bitmaps; masks are relative to the
+// socket.  See take_batch (commit_core.h) for the walk, its run-on into the sibling range (`late`) and what "false" means.
+NHD_HD bool wide_take_batch(nhdfit_wide_node& n, uint32_t u, uint32_t num, bool smt_requested, uint64_t take[2], uint64_t pair[2], uint64_t late[2]) {
+    const bool smt_node = (n.flags & NHDFIT_NF_SMT) != 0;
+    const bool pairs = smt_node && smt_requested;
+    const uint32_t cpp = n.cores_per_proc, base = u * cpp;
+    take[0] = take[1] = pair[0] = pair[1] = late[0] = late[1] = 0;
+    uint32_t avail = 0;
+    for (uint32_t b = 0; b < cpp; ++b) avail += wide_bit(n.t0, base + b) && wide_bit(n.t1, base + b);
+    const uint32_t n_take = pairs ? (num + 1) / 2 : num, n_pair = pairs ? num / 2 : 0;
+    const uint32_t n_late = (smt_node && !pairs && num > avail) ? num - avail : 0;
+    uint32_t rank = 0, got_take = 0, got_late = 0;
+    for (uint32_t b = 0; b < cpp; ++b) {
+        const uint32_t c = base + b;
+        if (!(wide_bit(n.t0, c) && wide_bit(n.t1, c))) continue;
+        if (rank < n_take) { take[b >> 6] |= 1ull << (b & 63); ++got_take; }
+        if (rank < n_pair) pair[b >> 6] |= 1ull << (b & 63);
+        if (rank < n_late) { late[b >> 6] |= 1ull << (b & 63); ++got_late; }
+        ++rank;
+    }
+    for (uint32_t b = 0; b < cpp; ++b) {
+        const uint32_t c = base + b;
+        if (take[b >> 6] >> (b & 63) & 1) wide_clear(n.t0, c);
+        if (smt_node && ((pair[b >> 6] | late[b >> 6]) >> (b & 63) & 1)) wide_clear(n.t1, c);
+    }
+    return got_take + got_late == n_take && got_late == n_late;
+}
+
+NHD_HD int wide_commit(nhdfit_wide_node& n, const nhdfit_req& r, const nhdfit_mapping& m, double busy_time, nhdfit_wide_placement& out) {
+    const uint32_t G = r.n_groups, U = n.numa_nodes;
+    int status = kCommitOk;
+    for (int g = 0; g < kMaxG; ++g) {
+        for (int w = 0; w < 2; ++w)
+            out.proc_take[g][w] = out.proc_pair[g][w] = out.proc_late[g][w] = out.help_take[g][w] = out.help_pair[g][w] = out.help_late[g][w] = 0;
+        for (int k = 0; k < NHDFIT_PLACEMENT_GPUS; ++k) out.gpu[g][k] = 0xFF;
+        out.numa[g] = -1;
+    }
+    for (int w = 0; w < 2; ++w) out.misc_take[w] = out.misc_pair[w] = out.misc_late[w] = 0;
+    out.numa[kMaxG] = -1;
+    out.pad[0] = out.pad[1] = 0;
+    n.busy_time = busy_time;                                                          // SetBusy, nhd/Node.py:843-845
+    uint32_t claimed[kWideU] = {0, 0, 0, 0};
+    for (uint32_t g = 0; g < G; ++g) {
+        const uint32_t u = (uint32_t)m.gpu[g] % U;
+        out.numa[g] = (int8_t)u;
+        if (!wide_take_batch(n, u, r.n_proc[g], (r.smt_bits >> g & 1) != 0, out.proc_take[g], out.proc_pair[g], out.proc_late[g])) status = kCommitWouldRaise;
+        const uint32_t nu = (uint32_t)m.nic_numa[g] % U, nk = (uint32_t)m.nic_idx[g] & 15u;
+        if (nk >= n.nic_cnt[nu]) { status = kCommitWouldRaise; continue; }            // GetNicObjFromIndex finds nothing (Node.py:657-661)
+        const uint32_t sw = n.nic_sw[nu][nk];
+        for (uint32_t k = 0; k < r.gpus[g]; ++k) {
+            int pick = -1;
+            for (int x = 0; x < n.n_gpus && pick < 0; ++x)                            // GetFreePciGpuFromNic, Node.py:648-655
+                if ((n.gpu_free >> x & 1) && n.gpu_sw[x] == sw) pick = x;
+            if (pick < 0 && r.map_type != NHDFIT_MAP_PCI)
+                for (int x = 0; x < n.n_gpus && pick < 0; ++x)                        // GetNextGpuFree, Node.py:495-500
+                    if ((n.gpu_free >> x & 1) && n.gpu_numa[x] == u) pick = x;
+            if (pick < 0) { status = kCommitWouldRaise; continue; }
+            n.gpu_free &= ~(1u << pick);
+            if (k < (uint32_t)NHDFIT_PLACEMENT_GPUS) out.gpu[g][k] = (uint8_t)pick;
+        }
+        if (!wide_take_batch(n, u, r.n_help[g], (r.smt_bits >> (4 + g) & 1) != 0, out.help_take[g], out.help_pair[g], out.help_late[g])) status = kCommitWouldRaise;
+        if (r.nic_use >> g & 1) claimed[nu] |= 1u << nk;
+    }
+    if (r.hugepages_gb > 0) n.hp_free -= r.hugepages_gb;                              // Node.py:794-796
+    const uint32_t mu = (uint32_t)m.cpu[G] % U;
+    out.numa[kMaxG] = (int8_t)mu;
+    if (!wide_take_batch(n, mu, r.n_misc, r.misc_smt_enabled != 0, out.misc_take, out.misc_pair, out.misc_late)) status = kCommitWouldRaise;   // Node.py:799
+    for (uint32_t u = 0; u < U; ++u)                                                  // ClaimPodNICResources, Node.py:644-646; capacity 0 while pods_used > 0 (292)
+        for (uint32_t k = 0; k < (uint32_t)NHDFIT_MAX_NICS_PER_NUMA; ++k)
+            if (claimed[u] >> k & 1) {
+                if (n.nic_pods[u][k] < 127) n.nic_pods[u][k]++;
+                n.nic_cls[u][k] = n.nic_pods[u][k] > 0 ? 0 : n.nic_base[u][k];
+            }
+    out.status = (uint8_t)status;
+    return status;
+}
+
+}  // namespace nhdfit

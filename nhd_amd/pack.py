@@ -88,7 +88,20 @@ MAPPING = np.dtype([("gpu", "i1", (4,)), ("cpu", "i1", (5,)), ("nic_numa", "i1",
 PLACEMENT = np.dtype([("proc_take", "<u8", (4,)), ("proc_pair", "<u8", (4,)), ("help_take", "<u8", (4,)), ("help_pair", "<u8", (4,)),
                       ("misc_take", "<u8"), ("misc_pair", "<u8"), ("gpu", "u1", (4, 8)), ("numa", "i1", (5,)), ("status", "u1"),
                       ("pad", "u1", (2,)), ("proc_late", "<u8", (4,)), ("help_late", "<u8", (4,)), ("misc_late", "<u8")])
-COMMIT_OK, COMMIT_WOULD_RAISE, COMMIT_NEW_SIG = 0, 1, 2
+COMMIT_OK, COMMIT_WOULD_RAISE, COMMIT_NEW_SIG, COMMIT_WIDE = 0, 1, 2, 3
+# nodes beyond the fast layout: one self-contained record each (include/nhdfit.h nhdfit_wide_node)
+WIDE_MAX_NUMA, WIDE_CORE_WORDS, WIDE_MAX_CORES_PER_NUMA = 4, 8, 128
+WIDE = np.dtype([("t0", "<u8", (WIDE_CORE_WORDS,)), ("t1", "<u8", (WIDE_CORE_WORDS,)), ("o0", "<u8", (WIDE_CORE_WORDS,)), ("o1", "<u8", (WIDE_CORE_WORDS,)),
+                 ("groups", "<u8"), ("busy_time", "<f8"), ("gpu_free", "<u4"), ("flags", "<u4"), ("hp_free", "<i4"), ("hp_total", "<i4"),
+                 ("index", "<u4"), ("cores_per_proc", "<u2"), ("numa_nodes", "u1"), ("n_gpus", "u1"), ("nic_cnt", "u1", (WIDE_MAX_NUMA,)),
+                 ("gpu_numa", "u1", (MAX_GPUS,)), ("gpu_sw", "u1", (MAX_GPUS,)),
+                 ("nic_cls", "u1", (WIDE_MAX_NUMA, MAX_NICS_PER_NUMA)), ("nic_base", "u1", (WIDE_MAX_NUMA, MAX_NICS_PER_NUMA)),
+                 ("nic_sw", "u1", (WIDE_MAX_NUMA, MAX_NICS_PER_NUMA)), ("nic_pods", "i1", (WIDE_MAX_NUMA, MAX_NICS_PER_NUMA)), ("pad", "u1", (20,))])
+WIDE_PLACEMENT = np.dtype([("proc_take", "<u8", (4, 2)), ("proc_pair", "<u8", (4, 2)), ("proc_late", "<u8", (4, 2)),
+                           ("help_take", "<u8", (4, 2)), ("help_pair", "<u8", (4, 2)), ("help_late", "<u8", (4, 2)),
+                           ("misc_take", "<u8", (2,)), ("misc_pair", "<u8", (2,)), ("misc_late", "<u8", (2,)),
+                           ("gpu", "u1", (4, 8)), ("numa", "i1", (5,)), ("status", "u1"), ("pad", "u1", (2,)), ("pod", "<u4"), ("node", "<u4")])
+assert WIDE.itemsize == 640 and WIDE_PLACEMENT.itemsize == 480
 CC = np.dtype([("cls", "u1"), ("cnt", "u1")])
 assert (P0.itemsize, P1.itemsize, P2.itemsize, P3.itemsize, P4.itemsize) == (16,) * 5
 _REQ_STRUCT = struct.Struct("<IIiIQ4H4H4HHH4B4d4d4BBBBB")          # REQ, field by field (digest_many packs records with it)
@@ -127,6 +140,7 @@ class NodeTable:
     p4: np.ndarray
     detail: np.ndarray
     origin: Optional[np.ndarray] = None          # nhdfit_origin records (what ResetResources / a released NIC go back to)
+    wide: Optional[Dict[int, np.ndarray]] = None  # index -> nhdfit_wide_node record of the nodes beyond the fast layout (their planes hold a placeholder)
 
     @property
     def n(self) -> int:
@@ -135,12 +149,22 @@ class NodeTable:
     def slice(self, lo: int, hi: int) -> "NodeTable":
         return NodeTable(self.names[lo:hi] if self.names else [], self.p0[lo:hi], self.p1[lo:hi], self.p2[lo:hi],
                          self.p3[lo:hi], self.p4[lo:hi], self.detail[lo:hi],
-                         None if self.origin is None else self.origin[lo:hi])
+                         None if self.origin is None else self.origin[lo:hi],
+                         None if not self.wide else {i - lo: r for i, r in self.wide.items() if lo <= i < hi})
+
+    def wide_records(self, first: int = 0) -> np.ndarray:
+        """The wide records of this table in ascending order, `index` = first + position in the table (what nhdfit_wide_upload takes)."""
+        idx = sorted(self.wide) if self.wide else []
+        out = np.zeros(len(idx), WIDE)
+        for k, i in enumerate(idx):
+            out[k] = self.wide[i]
+            out[k]["index"] = first + i
+        return out
 
 
 def empty_table(n: int) -> NodeTable:
     t = NodeTable([], np.zeros(n, P0), np.zeros(n, P1), np.zeros(n, P2), np.zeros(n, P3), np.zeros(n, P4),
-                  np.zeros(n, DETAIL), np.zeros(n, ORIGIN))
+                  np.zeros(n, DETAIL), np.zeros(n, ORIGIN), {})
     return t
 
 
@@ -330,19 +354,33 @@ class Packer:
     # ---- node side ------------------------------------------------------------------------
     def pack_node_into(self, node, t: NodeTable, i: int) -> None:
         """Node object -> record i of the table.  See __init__ for nodes the layout cannot hold."""
+        if t.wide is None:
+            t.wide = {}
         try:
             self._pack_node_into(node, t, i)
             self.unmirrored.pop(node.name, None)
+            t.wide.pop(i, None)
+            return
+        except SharingEnabled:
+            raise
         except UnsupportedNode as e:
+            why = str(e)
+        # beyond the fast layout: a placeholder in the planes (never matches the table pass, indices stay what they are) ...
+        for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
+            getattr(t, f)[i] = np.zeros((), getattr(t, f).dtype)
+        if t.origin is not None:
+            t.origin[i] = np.zeros((), ORIGIN)
+        t.p2[i]["flags"] = NF_MAINTENANCE                      # GX row 0: never feasible (nhd/Matcher.py:71)
+        t.detail[i]["numa_nodes"] = 1
+        # ... and, where the general path can hold it (<= 4 sockets of <= 128 physical cores), its own record
+        try:
+            t.wide[i] = self.pack_wide(node)
+            self.unmirrored.pop(node.name, None)
+        except UnsupportedNode as e2:
+            t.wide.pop(i, None)
             if self.strict:
-                raise
-            self.unmirrored[node.name] = str(e)
-            for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
-                getattr(t, f)[i] = np.zeros((), getattr(t, f).dtype)
-            if t.origin is not None:
-                t.origin[i] = np.zeros((), ORIGIN)
-            t.p2[i]["flags"] = NF_MAINTENANCE                  # GX row 0: never feasible (nhd/Matcher.py:71)
-            t.detail[i]["numa_nodes"] = 1
+                raise UnsupportedNode(f"{why}; and not as a wide node either: {e2}") from None
+            self.unmirrored[node.name] = f"{why}; and not as a wide node either: {e2}"
 
     def _pack_node_into(self, node, t: NodeTable, i: int) -> None:
         consts = node_module_constants(node)
@@ -488,6 +526,96 @@ class Packer:
         gbits = self.group_bits(node.groups)
         t.p3[i] = (gbits, sig_numa, sig_pci)
         t.p4[i] = (float(node.busy_time), self.group_set_id(gbits), 0)
+
+    def pack_wide(self, node) -> np.ndarray:
+        """Node object -> nhdfit_wide_node (include/nhdfit.h): the general path's record of a node the five planes cannot hold
+        (3 or 4 sockets, 65..128 physical cores per socket, more than 8 GPUs on a NUMA node, a switch with NICs on two NUMA
+        nodes).  Read by attribute like _pack_node_into; `index` is filled in at upload."""
+        consts = node_module_constants(node)
+        pct = consts["NIC_BW_AVAIL_PERCENT"]
+        U, cpp = int(node.numa_nodes), int(node.cores_per_proc)
+        if U < 1 or U > WIDE_MAX_NUMA or int(node.sockets) != U:
+            raise UnsupportedNode(f"node {node.name}: {U} NUMA nodes on {int(node.sockets)} sockets (general path: 1..{WIDE_MAX_NUMA}, one per socket)")
+        if cpp < 1 or cpp > WIDE_MAX_CORES_PER_NUMA:
+            raise UnsupportedNode(f"node {node.name}: {cpp} physical cores per socket (general path: <= {WIDE_MAX_CORES_PER_NUMA})")
+        smt = bool(node.smt_enabled)
+        cores = node.cores
+        n_phys = U * cpp
+        if len(cores) != (2 * n_phys if smt else n_phys):
+            raise UnsupportedNode(f"node {node.name}: {len(cores)} logical cores do not divide into {U} sockets of {cpp}")
+        w = np.zeros((), WIDE)
+        t0 = t1 = 0
+        for c in range(n_phys):
+            core = cores[c]
+            if core.socket != c // cpp:
+                raise UnsupportedNode(f"node {node.name}: core {c} is on socket {core.socket}, expected {c // cpp}")
+            if smt and core.sibling != c + n_phys:
+                raise UnsupportedNode(f"node {node.name}: sibling of core {c} is {core.sibling}, expected {c + n_phys}")
+            if not core.used:
+                t0 |= 1 << c
+            if smt and not cores[core.sibling].used:
+                t1 |= 1 << c
+        full = (1 << n_phys) - 1
+        if not smt:
+            t1 = (1 << 512) - 1
+        o0, o1 = full, (full if smt else (1 << 512) - 1)
+        for r in getattr(node, "reserved_cores", ()):
+            r = int(r)
+            if 0 <= r < n_phys:
+                o0 &= ~(1 << r)
+            elif smt and r < len(cores):
+                o1 &= ~(1 << (r - n_phys))
+
+        def words(x):
+            return [(x >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(WIDE_CORE_WORDS)]
+        w["t0"], w["t1"], w["o0"], w["o1"] = words(t0), words(t1), words(o0), words(o1)
+        gpus = node.gpus
+        if len(gpus) > MAX_GPUS:
+            raise UnsupportedNode(f"node {node.name}: {len(gpus)} GPUs (> {MAX_GPUS})")
+        sw_local: Dict[int, int] = {}
+
+        def local_sw(sw) -> int:
+            k = sw_local.get(sw)
+            if k is None:
+                if len(sw_local) >= 255:
+                    raise UnsupportedNode(f"node {node.name}: more than 255 PCIe switches")
+                k = sw_local[sw] = len(sw_local)
+            return k
+        gfree = 0
+        for g, gpu in enumerate(gpus):
+            if not (0 <= gpu.numa_node < U):
+                raise UnsupportedNode(f"node {node.name}: GPU on NUMA node {gpu.numa_node}")
+            w["gpu_numa"][g] = gpu.numa_node
+            w["gpu_sw"][g] = local_sw(gpu.pciesw)
+            if not gpu.used:
+                gfree |= 1 << g
+        cnt = [0] * WIDE_MAX_NUMA
+        for nic in node.nics:
+            u = nic.numa_node
+            if u >= U or u < 0:
+                continue                                   # invisible to the NIC stage (Node.py:293-294)
+            k = cnt[u]
+            if k >= MAX_NICS_PER_NUMA:
+                raise UnsupportedNode(f"node {node.name}: more than {MAX_NICS_PER_NUMA} NICs on NUMA {u}")
+            if nic.idx != k:
+                raise UnsupportedNode(f"node {node.name}: NIC ordinal {nic.idx} != position {k} on NUMA {u}")
+            full_cap = nic.speed * pct                     # the reference's own expression (nhd/Node.py:292)
+            w["nic_base"][u][k] = self.cap_class(full_cap)
+            w["nic_cls"][u][k] = self.cap_class(0 if nic.pods_used > 0 else full_cap)
+            w["nic_sw"][u][k] = local_sw(nic.pciesw)
+            w["nic_pods"][u][k] = max(-127, min(127, int(nic.pods_used)))
+            cnt[u] = k + 1
+        w["nic_cnt"] = cnt
+        w["groups"] = self.group_bits(node.groups)
+        self.group_set_id(int(w["groups"]))
+        w["busy_time"] = float(node.busy_time)
+        w["gpu_free"] = gfree
+        w["flags"] = (NF_MAINTENANCE if node.maintenance else 0) | (NF_ACTIVE if node.active else 0) | \
+                     (NF_SMT if smt else 0) | (NF_HAS_GPU if len(gpus) > 0 else 0)
+        w["hp_free"] = max(-2 ** 31, min(2 ** 31 - 1, int(node.mem.free_hugepages_gb)))
+        w["hp_total"] = max(-2 ** 31, min(2 ** 31 - 1, int(getattr(node.mem, "ttl_hugepages_gb", 0))))
+        w["cores_per_proc"], w["numa_nodes"], w["n_gpus"] = cpp, U, len(gpus)
+        return w
 
     def pack_nodes(self, nl: Dict[str, object]) -> NodeTable:
         t = empty_table(len(nl))
@@ -689,6 +817,22 @@ def expand_placement(place, n_groups: int, cores_per_proc: int, num_cores: int, 
                        "helpers": expand_batch(place["help_take"][g], place["help_pair"][g], u, cores_per_proc, num_cores, place["help_late"][g]),
                        "gpus": [int(x) for x in place["gpu"][g][:gpus_per_group[g]]]})
     misc = expand_batch(place["misc_take"], place["misc_pair"], int(place["numa"][MAX_GROUPS]), cores_per_proc, num_cores, place["misc_late"])
+    return {"groups": groups, "misc": misc}
+
+
+def _mask2(words) -> int:
+    return int(words[0]) | (int(words[1]) << 64)
+
+
+def expand_wide_placement(place, n_groups: int, cores_per_proc: int, num_cores: int, gpus_per_group: Sequence[int]) -> dict:
+    """nhdfit_wide_placement -> the ids of expand_placement (two mask words per batch)."""
+    groups = []
+    for g in range(n_groups):
+        u = int(place["numa"][g])
+        groups.append({"cores": expand_batch(_mask2(place["proc_take"][g]), _mask2(place["proc_pair"][g]), u, cores_per_proc, num_cores, _mask2(place["proc_late"][g])),
+                       "helpers": expand_batch(_mask2(place["help_take"][g]), _mask2(place["help_pair"][g]), u, cores_per_proc, num_cores, _mask2(place["help_late"][g])),
+                       "gpus": [int(x) for x in place["gpu"][g][:gpus_per_group[g]]]})
+    misc = expand_batch(_mask2(place["misc_take"]), _mask2(place["misc_pair"]), int(place["numa"][MAX_GROUPS]), cores_per_proc, num_cores, _mask2(place["misc_late"]))
     return {"groups": groups, "misc": misc}
 
 
