@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "seq_core.h"
+#include "wide_core.h"
 
 using namespace nhdfit;
 
@@ -53,6 +54,7 @@ namespace {
 #include "step_kernel.h"
 #include "seq_kernel.h"
 #include "seq2_kernel.h"
+#include "wide_kernel.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -230,6 +232,16 @@ struct nhdfit_ctx {
     bool fast_find = tune_env("NHDFIT_NO_FAST_FIND") == nullptr;   // tuning aid: every find through the staged five-launch path
     bool lone_pod = tune_env("NHDFIT_NO_LONE_POD") == nullptr;      // one pod: the table-free launch (k_find1); tuning aid: NHDFIT_NO_LONE_POD=1 takes k_find
 
+    // nodes beyond the fast layout (wide_core.h): records sorted by index; the device copy is the truth once commits ran on it
+    DevBuf<nhdfit_wide_node> wide; uint32_t n_wide = 0;
+    DevBuf<int16_t> wide_scratch; DevBuf<uint32_t> wide_flags; DevBuf<nhdfit_wide_placement> wide_place;
+    std::vector<nhdfit_wide_placement> wide_places_last;   // placements the last nhdfit_schedule_batch made on wide nodes
+    std::vector<uint32_t> wide_index;                      // host copy of the records' node indices (ascending)
+    int wide_slot(uint32_t node) const {
+        auto it = std::lower_bound(wide_index.begin(), wide_index.end(), node);
+        return it != wide_index.end() && *it == node ? (int)(it - wide_index.begin()) : -1;
+    }
+
     // timing
     hipEvent_t ev[kEventRing][2];        // start / end of sampled step launches
     uint8_t ev_kind[kEventRing] = {};    // 0 = step launch with a fit role, 1 = digest-only launch
@@ -387,6 +399,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->origin.release(); c->deltas.release(); c->delta_run.release(); c->delta_status.release();
+    c->wide.release(); c->wide_scratch.release(); c->wide_flags.release(); c->wide_place.release();
     if (c->find_host) (void)hipHostFree(c->find_host);
     c->find_host = nullptr; c->find_sync.release();
     c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
@@ -518,6 +531,7 @@ int nhdfit_reserve_nodes(nhdfit_ctx* c, uint32_t capacity, uint64_t global_base)
     { int rc_ = sync_all(c); if (rc_) return rc_; }
     if (capacity > c->capacity) {
         c->n = 0;                                   // growing drops the contents: the caller re-uploads
+        c->n_wide = 0; c->wide_index.clear();
         c->rec_all = true;
         const size_t padded = ((size_t)capacity + 63) & ~size_t(63);       // the fit role reads whole 64-node chunks
         HIPCHK(c, c->p0.reserve(padded)); HIPCHK(c, c->p1.reserve(padded)); HIPCHK(c, c->p2.reserve(padded));
@@ -540,6 +554,14 @@ int nhdfit_set_node_count(nhdfit_ctx* c, uint32_t n) {
         c->rec_all = true;                                  // the padding records of the last chunk move
         c->n_items = 0;
         c->n = n;
+        if (c->n_wide) {                                    // wide records past the new end go with their nodes
+            std::vector<nhdfit_wide_node> h(c->n_wide);
+            HIPCHK(c, hipMemcpy(h.data(), c->wide.p, h.size() * sizeof h[0], hipMemcpyDeviceToHost));
+            uint32_t keep = 0;
+            while (keep < c->n_wide && h[keep].index < n) ++keep;
+            c->n_wide = keep;
+            c->wide_index.resize(keep);
+        }
     }
     return NHDFIT_OK;
 }
@@ -947,6 +969,19 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
     if (big) hipLaunchKernelGGL((k_step<512>), dim3(grid), dim3(512), lds, p.stream, a);
     else     hipLaunchKernelGGL((k_step<256>), dim3(grid), dim3(256), lds, p.stream, a);
     HIPCHK(c, hipGetLastError());
+    if (with_fit && c->n_wide) {
+        // the general path for the nodes beyond the fast layout: their verdict bits and scores join this step's (same stream,
+        // behind the fit role; in front of the all-reduce of a sharded run and of every mapping phase)
+        WideArgs wa;
+        memset(&wa, 0, sizeof wa);
+        wa.wide = c->wide.p; wa.n_wide = c->n_wide; wa.reqs = c->reqs.p; wa.P = P; wa.caps = c->caps.p; wa.busy_from = busy_threshold(now);
+        wa.cand = c->use_cand ? c->cand.p : nullptr;
+        wa.nm = c->want_bitmap ? reinterpret_cast<unsigned long long*>(p.nm.p) : nullptr; wa.chunks = chunks;
+        wa.score = p.score[bf].p; wa.global_base = c->global_base;
+        const uint64_t pairs = (uint64_t)c->n_wide * P;
+        hipLaunchKernelGGL(k_wide_eval, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, p.stream, wa);
+        HIPCHK(c, hipGetLastError());
+    }
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][1], p.stream));
         c->ev_kind[c->ev_pending++] = with_fit ? 0 : 1;
@@ -1068,6 +1103,24 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
     // the launches that finish the mappings still in flight, the copies behind them on the same stream, ONE wait
     { int rc_ = flush_pipeline(c); if (rc_) return rc_; }
     if (c->comm) HIPCHK(c, hipStreamSynchronize(c->s_red));
+    if (map_out && c->n_wide) {
+        // winners that are wide nodes: their mappings from the general set model, over what the mapping roles left for them
+        constexpr uint32_t kWideMapThreads = 512;
+        HIPCHK(c, c->wide_scratch.reserve((size_t)kWideMapThreads * kWideScratchWords));
+        HIPCHK(c, c->wide_flags.reserve(4));
+        HIPCHK(c, hipMemsetAsync(c->wide_flags.p, 0, 4 * sizeof(uint32_t), p.stream));
+        WideMapArgs wm;
+        memset(&wm, 0, sizeof wm);
+        wm.wide = c->wide.p; wm.n_wide = c->n_wide; wm.reqs = c->reqs.p; wm.P = P; wm.caps = c->caps.p;
+        wm.score = p.score[b].p; wm.global_base = c->global_base; wm.n = c->n; wm.out = p.maps[b].p;
+        wm.scratch = c->wide_scratch.p; wm.flags = c->wide_flags.p;
+        hipLaunchKernelGGL(k_wide_map, dim3(kWideMapThreads / 64), dim3(64), 0, p.stream, wm);
+        HIPCHK(c, hipGetLastError());
+        uint32_t fl[4] = {0, 0, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(fl, c->wide_flags.p, sizeof fl, hipMemcpyDeviceToHost, p.stream));
+        HIPCHK(c, hipStreamSynchronize(p.stream));
+        if (fl[0]) return fail(c, NHDFIT_E_LIMIT, "the set model of a wide node's mapping outgrew its table");
+    }
     if (score_out) {
         HIPCHK(c, c->pin_score.reserve(P));
         HIPCHK(c, hipMemcpyAsync(c->pin_score.p, p.score[b].p, (size_t)P * 8, hipMemcpyDeviceToHost, p.stream));
@@ -1100,7 +1153,7 @@ namespace {
 // sequence word the launch stores last.  Returns 1 when the call is not eligible (or the launch gave up): the caller then
 // takes the staged path, which also words the errors; 0 on success; < 0 on a HIP error.
 int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand, uint64_t* score_out, nhdfit_mapping* map_out) {
-    if (!c->fast_find || !reqs || !P || P > (uint32_t)kTile || c->comm || !c->nsig || !c->n || !c->find_host) return 1;
+    if (!c->fast_find || !reqs || !P || P > (uint32_t)kTile || c->comm || !c->nsig || !c->n || !c->find_host || c->n_wide) return 1;   // (wide nodes: the staged path carries the general pass)
     const auto t0 = std::chrono::steady_clock::now();
     if (map_out && !c->want_map) return 1;
     int32_t hp_max = 0;
@@ -1274,6 +1327,165 @@ MapTables map_tables(nhdfit_ctx* c) {
 SigTable sig_table(nhdfit_ctx* c) { return SigTable{c->sig_keys.p, c->sig_ids.p, c->sig_mask}; }
 }  // namespace
 
+// ---- nodes beyond the fast layout (wide_core.h / wide_kernel.h) -------------------------------------------------------------
+int nhdfit_wide_count(nhdfit_ctx* c, uint32_t* n_wide) {
+    if (!c || !n_wide) return NHDFIT_E_INVAL;
+    *n_wide = c->n_wide;
+    return NHDFIT_OK;
+}
+
+int nhdfit_wide_download(nhdfit_ctx* c, nhdfit_wide_node* out, uint32_t cap, uint32_t* n_wide) {
+    if (!c || !n_wide) return NHDFIT_E_INVAL;
+    *n_wide = c->n_wide;
+    if (!c->n_wide || !out) return NHDFIT_OK;
+    if (cap < c->n_wide) return fail(c, NHDFIT_E_INVAL, "%u wide records, room for %u", c->n_wide, cap);
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->wide.p, (size_t)c->n_wide * sizeof *out, hipMemcpyDeviceToHost));
+    return NHDFIT_OK;
+}
+
+int nhdfit_wide_upload(nhdfit_ctx* c, uint32_t first, uint32_t count, const nhdfit_wide_node* wide, uint32_t n_wide) {
+    if (!c) return NHDFIT_E_INVAL;
+    if (n_wide && !wide) return fail(c, NHDFIT_E_INVAL, "NULL wide records");
+    if ((uint64_t)first + count > c->capacity) return fail(c, NHDFIT_E_INVAL, "wide upload [%u,%u) exceeds capacity %u", first, first + count, c->capacity);
+    for (uint32_t k = 0; k < n_wide; ++k) {
+        if (wide[k].index < first || wide[k].index >= first + count || (k && wide[k].index <= wide[k - 1].index))
+            return fail(c, NHDFIT_E_INVAL, "wide record %u: index %u outside [%u,%u) or not ascending", k, wide[k].index, first, first + count);
+        if (!wide_shape_ok(wide[k])) return fail(c, NHDFIT_E_LIMIT, "wide record %u: %u NUMA nodes of %u cores, %u GPUs (general path: <= %d of <= %d, <= %d)", k,
+                                                 (unsigned)wide[k].numa_nodes, (unsigned)wide[k].cores_per_proc, (unsigned)wide[k].n_gpus,
+                                                 NHDFIT_WIDE_MAX_NUMA, NHDFIT_WIDE_MAX_CORES_PER_NUMA, NHDFIT_MAX_GPUS);
+        for (uint32_t u = 0; u < (uint32_t)NHDFIT_WIDE_MAX_NUMA; ++u)
+            if (wide[k].nic_cnt[u] > NHDFIT_MAX_NICS_PER_NUMA || (u >= wide[k].numa_nodes && wide[k].nic_cnt[u]))
+                return fail(c, NHDFIT_E_LIMIT, "wide record %u: %u NICs on NUMA node %u", k, (unsigned)wide[k].nic_cnt[u], u);
+    }
+    if (!n_wide && !c->n_wide) return NHDFIT_OK;
+    HIPCHK(c, hipSetDevice(c->dev));
+    { int rc_ = sync_all(c); if (rc_) return rc_; }
+    std::vector<nhdfit_wide_node> cur(c->n_wide), next;
+    if (c->n_wide) HIPCHK(c, hipMemcpy(cur.data(), c->wide.p, cur.size() * sizeof cur[0], hipMemcpyDeviceToHost));   // (commits may have changed them)
+    size_t k = 0;
+    for (; k < cur.size() && cur[k].index < first; ++k) next.push_back(cur[k]);
+    for (uint32_t j = 0; j < n_wide; ++j) next.push_back(wide[j]);
+    for (; k < cur.size(); ++k)
+        if (cur[k].index >= first + count) next.push_back(cur[k]);
+    HIPCHK(c, c->wide.reserve(next.size() ? next.size() : 1));
+    if (!next.empty()) HIPCHK(c, hipMemcpy(c->wide.p, next.data(), next.size() * sizeof next[0], hipMemcpyHostToDevice));
+    c->n_wide = (uint32_t)next.size();
+    c->wide_index.resize(next.size());
+    for (size_t j = 0; j < next.size(); ++j) c->wide_index[j] = next[j].index;
+    return NHDFIT_OK;
+}
+
+int nhdfit_wide_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_req* req, const nhdfit_mapping* map, double busy_time,
+                       nhdfit_wide_placement* place_out) {
+    if (!c || !req || !map || !place_out) return NHDFIT_E_INVAL;
+    const int slot = c->wide_slot(node);
+    if (slot < 0) return fail(c, NHDFIT_E_INVAL, "node %u is not a wide node", node);
+    if (!map->valid) return fail(c, NHDFIT_E_INVAL, "the mapping is not valid");
+    if (!req_valid(*req)) return fail(c, NHDFIT_E_INVAL, "the request is not valid (map type NUMA / PCI, 1..%d proc groups)", NHDFIT_MAX_GROUPS);
+    for (uint32_t g = 0; g <= req->n_groups; ++g) {
+        if (map->cpu[g] < 0 || map->cpu[g] >= NHDFIT_WIDE_MAX_NUMA) return fail(c, NHDFIT_E_INVAL, "mapping: cpu[%u] = %d is not a NUMA node", g, (int)map->cpu[g]);
+        if (g == req->n_groups) break;
+        if (map->gpu[g] < 0 || map->gpu[g] >= NHDFIT_WIDE_MAX_NUMA || map->nic_numa[g] < 0 || map->nic_numa[g] >= NHDFIT_WIDE_MAX_NUMA)
+            return fail(c, NHDFIT_E_INVAL, "mapping: group %u sits on NUMA node %d / its NIC on %d", g, (int)map->gpu[g], (int)map->nic_numa[g]);
+        if (map->nic_idx[g] < 0 || map->nic_idx[g] >= NHDFIT_MAX_NICS_PER_NUMA)
+            return fail(c, NHDFIT_E_INVAL, "mapping: group %u uses NIC ordinal %d", g, (int)map->nic_idx[g]);
+    }
+    HIPCHK(c, hipSetDevice(c->dev));
+    { int rc_ = sync_all(c); if (rc_) return rc_; }             // steps in flight read the wide records
+    HIPCHK(c, c->wide_place.reserve(1));
+    WideCommitArgs wa;
+    memset(&wa, 0, sizeof wa);
+    wa.wide = c->wide.p; wa.slot = (uint32_t)slot; wa.req = *req; wa.map = *map; wa.busy_time = busy_time; wa.out = c->wide_place.p;
+    hipLaunchKernelGGL(k_wide_commit, dim3(1), dim3(64), 0, c->stream, wa);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(place_out, c->wide_place.p, sizeof *place_out, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NHDFIT_OK;
+}
+
+int nhdfit_wide_placements(nhdfit_ctx* c, nhdfit_wide_placement* out, uint32_t cap, uint32_t* n) {
+    if (!c || !n) return NHDFIT_E_INVAL;
+    *n = (uint32_t)c->wide_places_last.size();
+    if (out)
+        for (uint32_t k = 0; k < *n && k < cap; ++k) out[k] = c->wide_places_last[k];
+    return NHDFIT_OK;
+}
+
+namespace {
+// Mode B while the mirror holds wide nodes: the scheduler's loop as it stands (nhd/NHDScheduler.py:425-437) - FindNode for
+// pod k (table pass + general pass, one score word), the commit step on whichever mirror holds the winner, then pod k + 1.
+// No decision engine here: a cluster with wide nodes is served exactly, pod by pod.
+int schedule_batch_general(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand, int apply,
+                           int64_t* node_out, nhdfit_mapping* map_out, nhdfit_placement* place_out, int32_t* status_out, uint32_t* n_done) {
+    struct Saved { uint32_t node; nhdfit_plane0 p0; nhdfit_plane1 p1; nhdfit_plane2 p2; nhdfit_plane3 p3; nhdfit_plane4 p4; nhdfit_detail det; };
+    std::vector<Saved> saved;                                   // first-touch copies of ordinary nodes (apply = 0)
+    std::vector<nhdfit_wide_node> wide_before(c->n_wide);
+    if (!apply && c->n_wide) {
+        uint32_t nw = 0;
+        int rc = nhdfit_wide_download(c, wide_before.data(), (uint32_t)wide_before.size(), &nw);
+        if (rc) return rc;
+    }
+    uint32_t done = 0;
+    int rc = NHDFIT_OK;
+    for (uint32_t i = 0; i < P && rc == NHDFIT_OK; ++i) {
+        uint64_t score = 0;
+        nhdfit_mapping mp;
+        memset(&mp, 0, sizeof mp);
+        node_out[i] = -1;
+        if (map_out) memset(&map_out[i], 0, sizeof map_out[i]);
+        if (place_out) memset(&place_out[i], 0, sizeof place_out[i]);
+        if (status_out) status_out[i] = 0;
+        done = i + 1;
+        if (!req_valid(reqs[i])) continue;
+        if ((rc = nhdfit_find(c, reqs + i, 1, now, cand, &score, nullptr, &mp))) break;
+        if (!score) continue;
+        const uint64_t gi = NHDFIT_SCORE_INDEX(score);
+        const uint32_t v = (uint32_t)(gi - c->global_base);
+        node_out[i] = (int64_t)gi;
+        if (map_out) map_out[i] = mp;
+        if (!mp.valid) { rc = fail(c, NHDFIT_E_STATE, "pod %u: no mapping for its feasible node %u", i, v); break; }
+        if (c->wide_slot(v) >= 0) {
+            nhdfit_wide_placement wp;
+            if ((rc = nhdfit_wide_commit(c, v, reqs + i, &mp, now, &wp))) break;
+            wp.pod = i; wp.node = v;
+            c->wide_places_last.push_back(wp);
+            if (place_out) place_out[i].status = NHDFIT_COMMIT_WIDE;
+            if (status_out) status_out[i] = wp.status == NHDFIT_COMMIT_WOULD_RAISE ? NHDFIT_COMMIT_WOULD_RAISE : 0;
+            continue;
+        }
+        if (!apply) {
+            bool seen = false;
+            for (const Saved& sv : saved) seen = seen || sv.node == v;
+            if (!seen) {
+                Saved sv; sv.node = v;
+                if ((rc = nhdfit_download_nodes(c, v, 1, &sv.p0, &sv.p1, &sv.p2, &sv.p3, &sv.p4, &sv.det))) break;
+                saved.push_back(sv);
+            }
+        }
+        nhdfit_placement pl;
+        if ((rc = nhdfit_commit(c, v, reqs + i, &mp, now, &pl))) break;
+        if (place_out) place_out[i] = pl;
+        if (status_out) status_out[i] = pl.status;
+        if (pl.status == NHDFIT_COMMIT_NEW_SIG) break;          // the caller interns the state and submits the rest (include/nhdfit.h)
+    }
+    if (!apply) {                                               // the mirror as it was
+        for (const Saved& sv : saved) {
+            const int r2 = nhdfit_upload_nodes(c, sv.node, 1, &sv.p0, &sv.p1, &sv.p2, &sv.p3, &sv.p4, &sv.det);
+            if (r2 && !rc) rc = r2;
+        }
+        if (!wide_before.empty()) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipMemcpy(c->wide.p, wide_before.data(), wide_before.size() * sizeof wide_before[0], hipMemcpyHostToDevice));
+        }
+    }
+    if (rc) return rc;
+    *n_done = done;
+    return NHDFIT_OK;
+}
+}  // namespace
+
 int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand, int apply,
                           int64_t* node_out, nhdfit_mapping* map_out, nhdfit_placement* place_out, int32_t* status_out,
                           uint32_t* n_done) {
@@ -1282,6 +1494,8 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     if (!node_out || !n_done) return fail(c, NHDFIT_E_INVAL, "node_out / n_done is NULL");
     if (!std::isfinite(now)) return fail(c, NHDFIT_E_INVAL, "now must be finite (a placed node is busy at `now`)");
     HIPCHK(c, hipSetDevice(c->dev));
+    c->wide_places_last.clear();
+    if (c->n_wide) return schedule_batch_general(c, reqs, P, now, cand, apply, node_out, map_out, place_out, status_out, n_done);
     hipStream_t sm = c->stream;
     Pipe& p = c->pipe[0];                                       // (the one step a freshly staged batch enqueues runs on pipe 0)
     const uint32_t chunks = (c->n + 63) / 64;
@@ -1494,6 +1708,7 @@ int nhdfit_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_req* req, const nhd
     if (node >= c->n) return fail(c, NHDFIT_E_INVAL, "node %u out of range (%u nodes)", node, c->n);
     if (!map->valid) return fail(c, NHDFIT_E_INVAL, "the mapping is not valid");
     if (!req_valid(*req)) return fail(c, NHDFIT_E_INVAL, "the request is not valid (map type NUMA / PCI, 1..%d proc groups)", NHDFIT_MAX_GROUPS);
+    if (c->wide_slot(node) >= 0) return fail(c, NHDFIT_E_INVAL, "node %u is a wide node: its commit step is nhdfit_wide_commit", node);
     for (uint32_t g = 0; g <= req->n_groups; ++g) {          // entries index two-element arrays / 16-entry NIC tables on the device
         if (map->cpu[g] < 0 || map->cpu[g] >= NHDFIT_MAX_NUMA) return fail(c, NHDFIT_E_INVAL, "mapping: cpu[%u] = %d is not a NUMA node", g, (int)map->cpu[g]);
         if (g == req->n_groups) break;
@@ -1544,6 +1759,8 @@ int nhdfit_apply_deltas(nhdfit_ctx* c, const nhdfit_delta* deltas, uint32_t n, u
         if (deltas[i].node >= c->n) return fail(c, NHDFIT_E_INVAL, "delta %u: node %u out of range (%u nodes)", i, deltas[i].node, c->n);
         if (deltas[i].op < NHDFIT_DELTA_TAKE || deltas[i].op > NHDFIT_DELTA_SET_HUGEPAGES) return fail(c, NHDFIT_E_INVAL, "delta %u: unknown op %u", i, deltas[i].op);
         if (deltas[i].nic_n > NHDFIT_DELTA_MAX_NICS) return fail(c, NHDFIT_E_INVAL, "delta %u: %u NIC entries", i, (unsigned)deltas[i].nic_n);
+        if (c->n_wide && c->wide_slot(deltas[i].node) >= 0)
+            return fail(c, NHDFIT_E_INVAL, "delta %u: node %u is a wide node - its record is re-uploaded (nhdfit_wide_upload), deltas are for the planes", i, deltas[i].node);
         order[i] = i;
     }
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return deltas[x].node < deltas[y].node; });

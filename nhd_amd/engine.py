@@ -30,6 +30,7 @@ class Engine:
         self.P = 0
         self.global_base = 0
         self._dict_version = -1
+        self.n_wide = 0
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -69,8 +70,40 @@ class Engine:
         if table.origin is not None and table.n:
             origin = np.ascontiguousarray(table.origin)          # (bound to a name: _p hands out a bare address)
             self._chk(self.lib.nhdfit_upload_origin(self.ctx, first, table.n, _p(origin)))
+        if table.n and (table.wide or self.n_wide):               # nodes beyond the fast layout: their records replace those of this range
+            recs = table.wide_records(first)
+            self._chk(self.lib.nhdfit_wide_upload(self.ctx, first, table.n, _p(recs) if len(recs) else None, len(recs)))
+            self.n_wide = self.wide_count()
         self.n = max(self.n, first + table.n)
         self.global_base = global_base
+
+    def wide_count(self) -> int:
+        k = ctypes.c_uint32(0)
+        self._chk(self.lib.nhdfit_wide_count(self.ctx, ctypes.byref(k)))
+        return int(k.value)
+
+    def wide_download(self) -> np.ndarray:
+        """The mirror's wide records (ascending node index) as they are now - after device-side commits."""
+        k = ctypes.c_uint32(0)
+        out = np.zeros(self.wide_count(), pack.WIDE)
+        self._chk(self.lib.nhdfit_wide_download(self.ctx, _p(out) if len(out) else None, len(out), ctypes.byref(k)))
+        return out
+
+    def wide_commit(self, node: int, req: np.ndarray, mapping: np.ndarray, busy_time: float) -> np.ndarray:
+        out = np.zeros((), pack.WIDE_PLACEMENT)
+        req = np.ascontiguousarray(req)
+        mapping = np.ascontiguousarray(mapping)
+        self._chk(self.lib.nhdfit_wide_commit(self.ctx, int(node), _p(req), _p(mapping), float(busy_time), _p(out)))
+        return out
+
+    def wide_placements(self) -> np.ndarray:
+        """Placements the last schedule_batch made on wide nodes (`pod` = index in that call's batch, `node` = local index)."""
+        k = ctypes.c_uint32(0)
+        self._chk(self.lib.nhdfit_wide_placements(self.ctx, None, 0, ctypes.byref(k)))
+        out = np.zeros(int(k.value), pack.WIDE_PLACEMENT)
+        if len(out):
+            self._chk(self.lib.nhdfit_wide_placements(self.ctx, _p(out), len(out), ctypes.byref(k)))
+        return out
 
     def apply_deltas(self, deltas: np.ndarray) -> np.ndarray:
         """K3 (nhdfit_apply_deltas): release / reclaim / reset / scalar writes applied to the device mirror in array order.
@@ -84,6 +117,7 @@ class Engine:
     def reset_nodes(self):
         self._chk(self.lib.nhdfit_set_node_count(self.ctx, 0))
         self.n = 0
+        self.n_wide = 0
 
     def set_outputs(self, bitmap=True, mapping=True):
         self._chk(self.lib.nhdfit_set_outputs(self.ctx, int(bitmap), int(mapping)))
@@ -130,12 +164,16 @@ class Engine:
         if cand is not None:
             cand = np.ascontiguousarray(cand, dtype=np.uint64)
         first = 0
+        self.last_wide_places = {}                                  # pod index of THIS call -> nhdfit_wide_placement (pods that landed on wide nodes)
         while first < P:
             done = ctypes.c_uint32(0)
             self._chk(self.lib.nhdfit_schedule_batch(self.ctx, _p(reqs[first:]), P - first, float(now), _p(cand), int(apply),
                                                      _p(node[first:]), _p(maps[first:]), _p(places[first:]), _p(status[first:]),
                                                      ctypes.byref(done)))
             last = first + done.value
+            if self.n_wide:
+                for wp in self.wide_placements():
+                    self.last_wide_places[first + int(wp["pod"])] = wp.copy()
             stuck = [int(node[i] - self.global_base) for i in range(first, last) if status[i] == pack.COMMIT_NEW_SIG]
             if last < P and not (apply and stuck):
                 raise _lib.NhdFitError(-5, "the device stopped a sequential batch early without a NIC state to intern")
@@ -167,6 +205,8 @@ class Engine:
         t = pack.empty_table(count)
         t.origin = None                                     # not read back: uploading this table leaves the origin records alone
         self._chk(self.lib.nhdfit_download_nodes(self.ctx, first, count, _p(t.p0), _p(t.p1), _p(t.p2), _p(t.p3), _p(t.p4), _p(t.detail)))
+        if self.n_wide:
+            t.wide = {int(w["index"]) - first: w.copy() for w in self.wide_download() if first <= int(w["index"]) < first + count}
         return t
 
     # ---- pipelined --------------------------------------------------------------------
@@ -222,6 +262,7 @@ class _ShardView(Engine):
         self.P = 0
         self.global_base = 0
         self._dict_version = -1
+        self.n_wide = 0
 
     def close(self):
         self.ctx = None
@@ -243,6 +284,7 @@ class GroupEngine:
         self.global_base = 0
         self.group = None
         self._bounds = []
+        self.last_wide_places = {}
         if engine_factory is not None:
             self.lib = None
             self.shards = [engine_factory(d) for d in self.devices]
@@ -386,6 +428,7 @@ class GroupEngine:
         nogpu = {k: self._nogpu_words(k) for k in live}
         wants_gpu = reqs["gpus"].sum(axis=1) > 0
         touched = {}
+        self.last_wide_places = {}
 
         def offer(pods: np.ndarray, gpu_less_nodes_only: bool) -> np.ndarray:
             for k in live:
@@ -398,6 +441,10 @@ class GroupEngine:
                     if not mask.any():
                         continue
                 nd, mp, pl, st = self.shards[k].schedule_batch(reqs[pods], now, packer, cand=mask, apply=True)
+                for j, wp in getattr(self.shards[k], "last_wide_places", {}).items():   # pods that landed on a wide node of this shard
+                    wp = wp.copy()
+                    wp["node"] = int(wp["node"]) + lo                                    # (global node index, as `node` below)
+                    self.last_wide_places[int(pods[j])] = wp
                 got = nd >= 0
                 node[pods[got]] = nd[got]
                 maps[pods[got]] = mp[got]
@@ -429,6 +476,14 @@ class GroupEngine:
         k = self._shard_of(node)
         return self.shards[k].commit(node - self._bounds[k][0], req, mapping, busy_time)
 
+    def wide_commit(self, node: int, req, mapping, busy_time):
+        k = self._shard_of(node)
+        return self.shards[k].wide_commit(node - self._bounds[k][0], req, mapping, busy_time)
+
+    @property
+    def n_wide(self) -> int:
+        return sum(getattr(s, "n_wide", 0) for s in self.shards)
+
     def apply_deltas(self, deltas: np.ndarray) -> np.ndarray:
         """Deltas with GLOBAL node indices, routed to the shards that own the nodes (order kept per shard)."""
         deltas = np.ascontiguousarray(deltas, dtype=pack.DELTA).reshape(-1)
@@ -453,6 +508,8 @@ class GroupEngine:
             part = self.shards[k].download(i - lo, j - i)
             for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
                 getattr(out, f)[i - first:j - first] = getattr(part, f)
+            for q, w in (part.wide or {}).items():
+                out.wide[q + i - first] = w
             i = j
         return out
 

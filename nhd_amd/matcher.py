@@ -192,6 +192,12 @@ class HipMatcher:
         self._attached = None
 
     # ---- commit step mirrored on the device (row f1) ---------------------------------------
+    def _off_planes(self, name: str) -> bool:
+        """The node is not (only) held by the five planes: a wide node (its record is re-uploaded whenever it changes - the
+        general path has no delta form) or one no layout holds (never matches; nothing to keep current)."""
+        i = self._index.get(name)
+        return name in self.packer.unmirrored or (i is not None and self._table is not None and bool(self._table.wide) and i in self._table.wide)
+
     def _mapping_record(self, mapping) -> np.ndarray:
         m = np.zeros((), pack.MAPPING)
         G = len(mapping["gpu"])
@@ -211,6 +217,12 @@ class HipMatcher:
         node = self._attached[name] if self._attached is not None else None
         req = self.packer.digest(top)
         bt = float(node.busy_time if busy_time is None and node is not None else busy_time)
+        if self._table is not None and self._table.wide and i in self._table.wide:      # a wide node: the general path's commit step
+            place = self.engine.wide_commit(i, req, self._mapping_record(mapping), bt)
+            G = int(req["n_groups"])
+            cpp = int(node.cores_per_proc) if node is not None else int(self._table.wide[i]["cores_per_proc"])
+            U = int(node.sockets) if node is not None else int(self._table.wide[i]["numa_nodes"])
+            return pack.expand_wide_placement(place, G, cpp, cpp * U, [int(req["gpus"][g]) for g in range(G)])
         place = self.engine.commit(i, req, self._mapping_record(mapping), bt)
         if int(place["status"]) == pack.COMMIT_NEW_SIG:        # cannot happen after close_signatures(); handled anyway
             one = self.engine.download(i, 1)
@@ -226,7 +238,7 @@ class HipMatcher:
     def _on_commit(self, node, mapping, top) -> bool:
         """After the reference's own SetPhysicalIdsFromMapping succeeded on an attached node: the same commit on the
         device mirror, checked against what the reference just wrote into `top`.  True = the mirror is current."""
-        if self._attached is None or node.name not in self._index or node.name in self._dirty_strict:
+        if self._attached is None or node.name not in self._index or node.name in self._dirty_strict or self._off_planes(node.name):
             self._batch_ids.pop(node.name, None)
             return False
         pending = self._batch_ids.get(node.name)
@@ -279,7 +291,7 @@ class HipMatcher:
     def _on_topology(self, node, name, top) -> bool:
         """After the reference's RemoveResourcesFromTopology / AddResourcesFromTopology ran on an attached node: the same
         change as a delta record for nhdfit_apply_deltas (sent with the next flush).  True = no re-pack needed."""
-        if self._attached is None or node.name not in self._index or node.name in self._dirty_strict:
+        if self._attached is None or node.name not in self._index or node.name in self._dirty_strict or self._off_planes(node.name):
             return False
         try:
             op = pack.DELTA_TAKE if name == "RemoveResourcesFromTopology" else pack.DELTA_GIVE
@@ -289,7 +301,7 @@ class HipMatcher:
         return True
 
     def _on_queued_scalar(self, node, what: str) -> bool:
-        if self._attached is None or node.name not in self._index or node.name in self._dirty_strict:
+        if self._attached is None or node.name not in self._index or node.name in self._dirty_strict or self._off_planes(node.name):
             return False
         self._deltas.append(self.packer.delta_scalar(self._index[node.name], node, what))
         return True
@@ -322,7 +334,7 @@ class HipMatcher:
     def _dirty_strict(self):
         """Nodes that wait for a re-pack: their pending change is more than writes to scalar fields (those travel as deltas
         of their own and commute with commits and releases)."""
-        return {nm for nm in self._dirty if not self._reasons.get(nm, {""}) <= self._SCALAR_REASONS}
+        return {nm for nm in self._dirty if not self._reasons.get(nm, {""}) <= self._SCALAR_REASONS or self._off_planes(nm)}
 
     def mark_dirty(self, name: str) -> None:
         if self._attached is not None and name in self._attached:
@@ -347,7 +359,7 @@ class HipMatcher:
             self._deltas = []
             return
         # writes to scalar fields (cordon / maintenance / groups / busy time, nhd/NHDScheduler.py:533-570) travel as deltas too
-        for name in [nm for nm in self._dirty if self._reasons.get(nm, {""}) <= self._SCALAR_REASONS]:
+        for name in [nm for nm in self._dirty if self._reasons.get(nm, {""}) <= self._SCALAR_REASONS and not self._off_planes(nm)]:
             node, why = self._dirty.pop(name), self._reasons.pop(name)
             i = self._index[name]
             if why & {"active", "maintenance"}:
@@ -365,6 +377,12 @@ class HipMatcher:
             self.packer.pack_node_into(node, one, 0)
             for f in ("p0", "p1", "p2", "p3", "p4", "detail", "origin"):
                 getattr(self._table, f)[i] = getattr(one, f)[0]
+            if self._table.wide is None:
+                self._table.wide = {}
+            if one.wide and 0 in one.wide:                     # a wide node: its record travels with the (placeholder) planes
+                self._table.wide[i] = one.wide[0].copy()
+            else:
+                self._table.wide.pop(i, None)
         self.engine.set_dictionary(self.packer)        # signatures may have been added
         idx = sorted(self._index[nm] for nm in self._dirty)
         lo = 0
@@ -444,8 +462,17 @@ class HipMatcher:
 
     @property
     def unmirrored(self) -> Dict[str, str]:
-        """Nodes the device layout cannot hold (name -> reason): they never match; everything else is answered for."""
+        """Nodes NEITHER layout holds (more than four sockets, more than 128 physical cores per socket ...; name -> reason): they never
+        match, everything else is answered for.  Nodes beyond the fast layout but within the general path's (wide nodes) are not here:
+        they are answered for exactly, by enumeration (`wide_nodes`)."""
         return self.packer.unmirrored
+
+    @property
+    def wide_nodes(self) -> List[str]:
+        """Names of the mirrored nodes the general path serves (3-4 sockets, 65-128 physical cores per socket, ...)."""
+        if self._table is None or not self._table.wide:
+            return []
+        return [self._names[i] for i in sorted(self._table.wide)]
 
     def _warn_unmirrored(self) -> None:
         for name, why in self.packer.unmirrored.items():
@@ -547,7 +574,14 @@ class HipMatcher:
             G = n_groups[p]
             if places is not None and self._attached is not None:
                 nd = self._attached.get(name)
-                if nd is not None:
+                if nd is not None and int(places[p]["status"]) == pack.COMMIT_WIDE:     # the pod landed on a wide node
+                    wp = getattr(self.engine, "last_wide_places", {}).get(p)
+                    if wp is not None:
+                        self.last_placements[p] = pack.expand_wide_placement(wp, G, int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets),
+                                                                             [int(reqs[p]["gpus"][g]) for g in range(G)])
+                    if apply:                                  # its record is re-packed from the object before the next call, whether or not
+                        self._mark(nd, "wide-batch")           # the caller applies the placement to it (no delta form on the general path)
+                elif nd is not None:
                     self.last_placements[p] = pack.expand_placement(places[p], G, int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets),
                                                                     [int(reqs[p]["gpus"][g]) for g in range(G)])
                     if apply:                                  # the reference mutators that follow find their work mirrored already

@@ -17,7 +17,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    deps = [SRC] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "winner_map.h", "seq_core.h", "set_states.h", "commit_core.h")] + \
+    deps = [SRC] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "winner_map.h", "seq_core.h", "set_states.h", "commit_core.h", "wide_core.h")] + \
            [os.path.join(HERE, "..", "..", "include", "nhdfit.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", SRC, "-o", SO])
@@ -145,6 +145,47 @@ def apply_deltas(packer, table, deltas):
     return status
 
 
+def wide_eval(wide: np.ndarray, reqs: np.ndarray, now: float, packer, cand=None, global_base=0, score=None):
+    """k_wide_eval on the host build: (fits [n_wide][P] bytes, score max-merged)."""
+    L = lib()
+    wide = np.ascontiguousarray(wide, dtype=pack.WIDE)
+    reqs = np.ascontiguousarray(reqs)
+    P = len(reqs)
+    fits = np.zeros((len(wide), P), np.uint8)
+    score = np.zeros(P, np.uint64) if score is None else np.ascontiguousarray(score, dtype=np.uint64)
+    caps = np.zeros(pack.MAX_CLASSES, "<f8")
+    caps[:len(packer.caps)] = packer.caps
+    if len(wide):
+        L.hh_wide_eval(_p(wide), ctypes.c_uint32(len(wide)), _p(reqs), ctypes.c_uint32(P), ctypes.c_double(now), _p(caps),
+                       _p(cand) if cand is not None else None, ctypes.c_uint64(global_base), _p(fits), _p(score))
+    return fits, score
+
+
+def wide_map(rec, req, packer):
+    L = lib()
+    caps = np.zeros(pack.MAX_CLASSES, "<f8")
+    caps[:len(packer.caps)] = packer.caps
+    out = np.zeros((), pack.MAPPING)
+    rec = np.ascontiguousarray(rec, dtype=pack.WIDE).reshape(1)
+    req = np.ascontiguousarray(req).reshape(1)
+    L.hh_wide_map.restype = ctypes.c_int
+    rc = L.hh_wide_map(_p(rec), _p(req), _p(caps), _p(out))
+    assert rc >= 0, "a set of the general model outgrew its table"
+    return out
+
+
+def wide_commit(rec, req, mapping, busy_time):
+    """wide_commit on the host build: (status, placement, record after the commit)."""
+    L = lib()
+    rec = np.array(rec, dtype=pack.WIDE).reshape(1)
+    out = np.zeros((), pack.WIDE_PLACEMENT)
+    req = np.ascontiguousarray(req).reshape(1)
+    mapping = np.ascontiguousarray(mapping).reshape(1)
+    L.hh_wide_commit.restype = ctypes.c_int
+    st = L.hh_wide_commit(_p(rec), _p(req), _p(mapping), ctypes.c_double(busy_time), _p(out))
+    return int(st), out, rec[0]
+
+
 class HarnessEngine:
     """Engine-compatible front-end of the host build (TEST ONLY): lets HipMatcher's host logic (packing,
     dirty tracking, candidate masks, result decoding) and the sharding helpers run on CPU."""
@@ -155,6 +196,20 @@ class HarnessEngine:
         self.global_base = 0
         self.packer = None
         self.table = None
+        self.wide = {}                                  # local index -> nhdfit_wide_node (the general path's records)
+        self.last_wide_places = {}
+
+    @property
+    def n_wide(self):
+        return len(self.wide)
+
+    def _wide_records(self):
+        idx = sorted(self.wide)
+        out = np.zeros(len(idx), pack.WIDE)
+        for k, i in enumerate(idx):
+            out[k] = self.wide[i]
+            out[k]["index"] = i
+        return out
 
     def close(self):
         pass
@@ -168,6 +223,7 @@ class HarnessEngine:
     def reset_nodes(self):
         self.n = 0
         self.table = None
+        self.wide = {}
 
     def upload(self, table, global_base=0, first=0, capacity=None):
         if first == 0 and (self.table is None or table.n >= self.n):
@@ -179,22 +235,86 @@ class HarnessEngine:
                 getattr(self.table, f)[first:first + table.n] = getattr(table, f)
         self.n = self.table.n
         self.global_base = global_base
+        for i in [i for i in self.wide if first <= i < first + table.n]:      # nhdfit_wide_upload: the range's records are replaced
+            del self.wide[i]
+        for i, rec in (table.wide or {}).items():
+            self.wide[first + i] = np.array(rec, dtype=pack.WIDE)
 
     def find(self, reqs, now, cand=None, want_bitmap=True, want_map=True):
-        return find(self.packer, self.table, reqs, now, cand=cand, global_base=self.global_base,
-                    want_bitmap=want_bitmap, want_map=want_map)
+        score, bitmap, maps = find(self.packer, self.table, reqs, now, cand=cand, global_base=self.global_base,
+                                   want_bitmap=want_bitmap, want_map=want_map)
+        if self.wide:                                   # the general pass, merged as nhdfit.hip merges it (launch_step / nhdfit_fetch)
+            recs = self._wide_records()
+            fits, score = wide_eval(recs, reqs, now, self.packer, cand=cand, global_base=self.global_base, score=score)
+            if want_bitmap:
+                for k, rec in enumerate(recs):
+                    i = int(rec["index"])
+                    bitmap[i >> 6, :] |= fits[k].astype(np.uint64) << np.uint64(i & 63)
+            if want_map:
+                idx = np.where(score == 0, -1, (0x7FFFFFFFFFFFFFFF - (score & np.uint64(0x7FFFFFFFFFFFFFFF))).astype(np.int64) - self.global_base)
+                for p in np.flatnonzero(score != 0):
+                    if int(idx[p]) in self.wide:
+                        maps[p] = wide_map(recs[sorted(self.wide).index(int(idx[p]))], reqs[p], self.packer)
+        return score, bitmap, maps
 
     def find_sequential(self, reqs, now, cand=None):
         return resolve(self.packer, self.table, reqs, now, global_base=self.global_base, cand=cand)
 
     def schedule_batch(self, reqs, now, packer, cand=None, apply=True):
+        self.last_wide_places = {}
+        if self.wide:
+            return self._schedule_general(reqs, now, packer, cand, apply)
         node, maps, places, status, done = schedule(packer, self.table, reqs, now, global_base=self.global_base, cand=cand, apply=apply)
         assert done == len(reqs)
         self.n_done = done
         return node, maps, places, status
 
+    def _schedule_general(self, reqs, now, packer, cand, apply):
+        """schedule_batch_general of nhdfit.hip: FindNode for pod k, the commit step on whichever mirror holds the winner, pod k + 1."""
+        P = len(reqs)
+        node = np.full(P, -1, np.int64)
+        maps = np.zeros(P, pack.MAPPING)
+        places = np.zeros(P, pack.PLACEMENT)
+        status = np.zeros(P, np.int32)
+        saved_table = None if apply else pack.NodeTable(list(self.table.names), *[np.array(getattr(self.table, f)) for f in
+                                                                                  ("p0", "p1", "p2", "p3", "p4", "detail")], np.array(self.table.origin))
+        saved_wide = None if apply else {i: np.array(r) for i, r in self.wide.items()}
+        for i in range(P):
+            r = reqs[i:i + 1]
+            if not (int(r[0]["map_type"]) in (1, 2) and 1 <= int(r[0]["n_groups"]) <= pack.MAX_GROUPS):
+                continue
+            sc, _, mp = self.find(r, now, cand=cand, want_bitmap=False, want_map=True)
+            if not sc[0]:
+                continue
+            v = int(0x7FFFFFFFFFFFFFFF - (int(sc[0]) & 0x7FFFFFFFFFFFFFFF)) - self.global_base
+            node[i] = v + self.global_base
+            maps[i] = mp[0]
+            if v in self.wide:
+                st, wp, rec = wide_commit(self.wide[v], r[0], mp[0], now)
+                self.wide[v] = rec
+                wp["pod"], wp["node"] = i, v
+                self.last_wide_places[i] = wp
+                places[i]["status"] = pack.COMMIT_WIDE
+                status[i] = st if st == pack.COMMIT_WOULD_RAISE else 0
+            else:
+                st, pl = commit(packer, self.table, v, r[0], mp[0], now)
+                places[i] = pl
+                status[i] = st
+        if not apply:
+            for f in ("p0", "p1", "p2", "p3", "p4", "detail", "origin"):
+                getattr(self.table, f)[...] = getattr(saved_table, f)
+            self.wide = saved_wide
+        self.n_done = P
+        return node, maps, places, status
+
     def commit(self, node, req, mapping, busy_time):
         return commit(self.packer, self.table, node, req, mapping, busy_time)[1]
+
+    def wide_commit(self, node, req, mapping, busy_time):
+        st, wp, rec = wide_commit(self.wide[node], req, mapping, busy_time)
+        self.wide[node] = rec
+        wp["node"] = node
+        return wp
 
     def apply_deltas(self, deltas):
         return apply_deltas(self.packer, self.table, deltas)
@@ -202,4 +322,8 @@ class HarnessEngine:
     def download(self, first=0, count=None):
         count = self.n - first if count is None else count
         t = self.table.slice(first, first + count)
-        return pack.NodeTable(list(t.names), *[np.array(getattr(t, f)) for f in ("p0", "p1", "p2", "p3", "p4", "detail")])   # a copy, as a device read-back is
+        out = pack.NodeTable(list(t.names), *[np.array(getattr(t, f)) for f in ("p0", "p1", "p2", "p3", "p4", "detail")])   # a copy, as a device read-back is
+        out.wide = {i - first: np.array(r) for i, r in self.wide.items() if first <= i < first + count}
+        for q, r in out.wide.items():
+            r["index"] = q + first
+        return out

@@ -522,3 +522,63 @@ extern "C" int hh_apply_deltas(nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plan
     }
     return 0;
 }
+
+// ---- the general path (wide_core.h) on the host ------------------------------------------------------------------------
+#include "../../nhd_amd/csrc/wide_core.h"
+
+// what k_wide_eval computes: verdict byte per (wide node, pod), scores max-merged into score[] (caller's pod order)
+extern "C" void hh_wide_eval(const nhdfit_wide_node* wide, uint32_t n_wide, const nhdfit_req* reqs, uint32_t P, double now, const double* caps,
+                             const uint64_t* cand, uint64_t global_base, uint8_t* fits /* [n_wide][P] */, uint64_t* score /* in-out */) {
+    const double busy_from = busy_threshold(now);
+    for (uint32_t w = 0; w < n_wide; ++w)
+        for (uint32_t i = 0; i < P; ++i) {
+            const nhdfit_wide_node& n = wide[w];
+            bool ok = !(cand && !(cand[n.index >> 6] >> (n.index & 63) & 1ull));
+            const bool busy = n.busy_time >= busy_from;
+            if (busy != ((now - n.busy_time) < kMinBusySecs)) std::abort();       // both forms of IsBusy agree
+            ok = ok && wide_fits(n, reqs[i], busy, caps);
+            fits[(size_t)w * P + i] = ok ? 1 : 0;
+            if (!ok) continue;
+            uint32_t want = 0;
+            for (uint32_t g = 0; g < reqs[i].n_groups; ++g) want += reqs[i].gpus[g];
+            const uint64_t s = score_of(want == 0 && n.n_gpus == 0, global_base + n.index);
+            if (s > score[i]) score[i] = s;
+        }
+}
+extern "C" int hh_wide_map(const nhdfit_wide_node* n, const nhdfit_req* r, const double* caps, nhdfit_mapping* out) {
+    std::vector<int16_t> scratch(kWideScratchWords);
+    return wide_map(*n, *r, caps, scratch.data(), *out);
+}
+extern "C" int hh_wide_commit(nhdfit_wide_node* n, const nhdfit_req* r, const nhdfit_mapping* m, double busy_time, nhdfit_wide_placement* out) {
+    const int st = wide_commit(*n, *r, *m, busy_time, *out);
+    out->pod = 0; out->node = n->index;
+    return st;
+}
+extern "C" uint64_t hh_wide_tuple_hash(uint32_t code, uint32_t len, uint32_t U) { return wide_tuple_hash(code, len, U); }
+// list(set) after adding `codes` one by one; returns the length, -1 on table overflow
+extern "C" int hh_wide_set_list(const int16_t* codes, int n, uint32_t len, uint32_t U, int16_t* out) {
+    std::vector<int16_t> mem(kWideSetSlotsC), tmp(kWideSetSlotsC);
+    WideSet s;
+    ws_init(s, mem.data(), kWideSetSlotsC, len, U);
+    for (int i = 0; i < n; ++i) ws_add(s, codes[i], tmp.data());
+    if (s.overflow) return -1;
+    int k = 0;
+    for (int32_t i = ws_next(s, 0); i >= 0; i = ws_next(s, i + 1)) out[k++] = s.key[i];
+    return k;
+}
+// list(set(a) & set(b) & set(c)), each operand built by adding its codes in the order given
+extern "C" int hh_wide_isect3(const int16_t* a, int na, const int16_t* b, int nb, const int16_t* c, int nc, uint32_t len, uint32_t U, int16_t* out) {
+    std::vector<int16_t> mem(5 * kWideSetSlotsC), tmp(kWideSetSlotsC);
+    WideSet A, B, C, AB, ABC;
+    ws_init(A, mem.data(), kWideSetSlotsC, len, U); ws_init(B, mem.data() + kWideSetSlotsC, kWideSetSlotsC, len, U);
+    ws_init(C, mem.data() + 2 * kWideSetSlotsC, kWideSetSlotsC, len, U); ws_init(AB, mem.data() + 3 * kWideSetSlotsC, kWideSetSlotsC, len, U);
+    ws_init(ABC, mem.data() + 4 * kWideSetSlotsC, kWideSetSlotsC, len, U);
+    for (int i = 0; i < na; ++i) ws_add(A, a[i], tmp.data());
+    for (int i = 0; i < nb; ++i) ws_add(B, b[i], tmp.data());
+    for (int i = 0; i < nc; ++i) ws_add(C, c[i], tmp.data());
+    ws_intersect(A, B, AB, tmp.data());
+    ws_intersect(AB, C, ABC, tmp.data());
+    int k = 0;
+    for (int32_t i = ws_next(ABC, 0); i >= 0; i = ws_next(ABC, i + 1)) out[k++] = ABC.key[i];
+    return k;
+}

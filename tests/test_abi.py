@@ -15,12 +15,12 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_lib._SIGS)
-    assert lib.nhdfit_abi_version() == 6
+    assert lib.nhdfit_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_struct_sizes_match_header():
     # sizes asserted on the C side by the struct comments; here: numpy mirrors
-    assert pack.REQ.itemsize == 128 and pack.DETAIL.itemsize == 128 and pack.MAPPING.itemsize == 20 and pack.PLACEMENT.itemsize == 256
+    assert pack.REQ.itemsize == 128 and pack.DETAIL.itemsize == 128 and pack.MAPPING.itemsize == 20 and pack.PLACEMENT.itemsize == 256 and pack.WIDE.itemsize == 640 and pack.WIDE_PLACEMENT.itemsize == 480
     assert ctypes.sizeof(_lib.Stats) == 80
 
 
@@ -64,7 +64,7 @@ def test_delta_and_origin_records_match_header():
 
 
 def test_placement_record_matches_header():
-    assert pack.PLACEMENT.itemsize == 256
+    assert pack.PLACEMENT.itemsize == 256 and pack.WIDE.itemsize == 640 and pack.WIDE_PLACEMENT.itemsize == 480
     assert pack.PLACEMENT.fields["misc_take"][1] == 128 and pack.PLACEMENT.fields["gpu"][1] == 144 and pack.PLACEMENT.fields["numa"][1] == 176
     assert pack.PLACEMENT.fields["status"][1] == 181 and pack.PLACEMENT.fields["proc_late"][1] == 184 and pack.PLACEMENT.fields["misc_late"][1] == 248
 

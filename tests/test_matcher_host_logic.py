@@ -127,8 +127,14 @@ def _odd_cluster():
     quad = dict(base, **{NFD + "nfd-extras-cpu.numSockets": "4", NFD + "nfd-extras-cpu.num_cores": "64"})
     wide = dict(base, **{NFD + "nfd-extras-cpu.numSockets": "2", NFD + "nfd-extras-cpu.num_cores": "192",
                          NFD + "cpu-hardware_multithreading": "true"})
+    penta = {NFD + "nfd-extras-cpu.numSockets": "5", NFD + "nfd-extras-cpu.num_cores": "40",
+             NFD + "nfd-extras-nic.eth0.mlx.0000000000c0.100000Mbs.0.10.0.0": "true",
+             NFD + "nfd-extras-nic.eth1.mlx.0000000000c1.100000Mbs.4.20.1.0": "true",
+             "DATA_PLANE_VLAN": "7", "DATA_DEFAULT_GW": "10.1.0.1/32"}
     out = {}
     for k, (name, node) in enumerate(nl.items()):
+        if k == 1:
+            out["penta-socket"] = refmodel.node_from_labels("penta-socket", penta, (64, 64))
         if k == 3:
             out["quad-socket"] = refmodel.node_from_labels("quad-socket", quad, (64, 64))
         if k == 9:
@@ -137,13 +143,15 @@ def _odd_cluster():
     return out
 
 
-def test_nodes_beyond_the_layout_never_match_and_nothing_raises(caplog):
-    """"failure is (None,) - never an exception".  A node the packed layout cannot hold (more than two
-    NUMA nodes, more than 64 physical cores per socket) is left out - FindNode answers for all the others exactly as the
-    reference does for them - and is named in `unmirrored` and in the log."""
+def test_nodes_beyond_the_layouts_never_match_wide_nodes_do_and_nothing_raises(caplog):
+    """"failure is (None,) - never an exception".  A node beyond the fast layout (four sockets, 96 physical
+    cores per socket) is served by the general path: FindNode's answers equal the oracle's on the cluster WITH them.  A node
+    no layout holds (five sockets) is left out - every other node is answered for exactly - and is named in `unmirrored` and in
+    the log."""
     nl = _odd_cluster()
-    supported = {k: v for k, v in nl.items() if k not in ("quad-socket", "wide-socket")}
+    supported = {k: v for k, v in nl.items() if k != "penta-socket"}
     rng = np.random.default_rng(5)
+    on_wide = 0
     for attach in (False, True):
         m = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)
         if attach:
@@ -151,10 +159,13 @@ def test_nodes_beyond_the_layout_never_match_and_nothing_raises(caplog):
         with caplog.at_level("WARNING"):
             for _ in range(25):
                 top = refmodel.make_topology(util.random_pod_spec(rng))
-                assert m.FindNode(nl, top) == norm(O.find_node(supported, top, util.CLOCK))
-        assert set(m.unmirrored) == {"quad-socket", "wide-socket"}
-        assert "4 NUMA nodes" in m.unmirrored["quad-socket"] and "96 physical cores" in m.unmirrored["wide-socket"]
-    assert "quad-socket" in caplog.text and "never be selected" in caplog.text
+                got = m.FindNode(nl, top)
+                assert got == norm(O.find_node(supported, top, util.CLOCK))
+                on_wide += got[0] in ("quad-socket", "wide-socket")
+        assert set(m.unmirrored) == {"penta-socket"} and set(m.wide_nodes) == {"quad-socket", "wide-socket"}
+        assert "5 NUMA nodes" in m.unmirrored["penta-socket"]
+    assert on_wide > 0
+    assert "penta-socket" in caplog.text and "never be selected" in caplog.text
     with pytest.raises(Exception):
         HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine, strict=True).FindNode(nl, top)
 
