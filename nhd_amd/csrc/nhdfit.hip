@@ -1597,17 +1597,17 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     };
 
     uint32_t decided = 0;                                       // pods [0, decided) of the caller's order are decided
-    // The decision engine pays off when most pods request GPUs (their decisions are bitmap picks, their commits run on the whole
-    // chip); a batch of mostly GPU-less pods is one long chain either way, and the round-based kernel walks that a little faster
-    // (config 2: 85 k against 74 k decisions/s, profiles/r03).
+    // The decision engine (seq2_kernel.h) takes every batch its block 0 has the LDS for: two bit maps over the nodes, one entry per
+    // GPU-less pod (the multiset of their commits), one bit per pod; the optional tables go in after those.
     uint32_t n_gpu_less = 0;
     for (uint32_t i = 0; i < P; ++i) {
         uint32_t g = 0;
         if (req_valid(reqs[i])) for (uint32_t k = 0; k < reqs[i].n_groups; ++k) g += reqs[i].gpus[k];
         n_gpu_less += req_valid(reqs[i]) && g == 0;
     }
-    static const bool force_decide = tune_env("NHDFIT_SEQ_DECIDE") != nullptr;      // tuning aid
-    bool fast = !c->seq_general && (size_t)chunks * 8 <= 64 * 1024 && c->n > 0 && P < (1u << 28) && (force_decide || 2u * n_gpu_less <= P);
+    const uint32_t hash_slots = decide_hash_slots(n_gpu_less);
+    const size_t dyn_base = 2 * lds_slice((size_t)chunks * 8) + lds_slice((size_t)hash_slots * 4) + lds_slice((size_t)((P + 31) / 32) * 4);
+    bool fast = !c->seq_general && dyn_base <= 64 * 1024 && c->n > 0 && P < (1u << 26);
     if (fast) {
         // The decision engine (seq2_kernel.h): one block decides, the rest of the grid commits.
         HIPCHK(c, hipMemsetAsync(c->seq_ctrl.p, 0, 16 * sizeof(uint32_t), sm));
@@ -1629,11 +1629,10 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         DecideArgs qa;
         memset(&qa, 0, sizeof qa);
         qa.list_n = c->seq_tn.p; qa.n_n = n_n; qa.list_g = c->seq_tn.p + n_n; qa.n_g = n_g; qa.queue_len = queue_len; qa.ncls = c->ncls;
-        static const uint32_t hint_distance = tune_env("NHDFIT_HINT_DISTANCE") ? (uint32_t)atoi(tune_env("NHDFIT_HINT_DISTANCE")) : kHintDistance;   // tuning aid
-        qa.hint_distance = hint_distance;
+        qa.hash_slots = hash_slots;
         qa.dbg = tune_env("NHDFIT_SEQ_SKIP") ? (uint32_t)atoi(tune_env("NHDFIT_SEQ_SKIP")) : 0u;
         qa.s = sa; qa.queue = c->seq_queue.p; qa.ctrl = c->seq_ctrl.p; qa.mat = c->seq_mat.p; qa.flags = c->seq_flags.p;
-        size_t dyn = lds_slice((size_t)chunks * 8);
+        size_t dyn = dyn_base;
         const size_t sig_bytes = lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4);
         const size_t st_bytes = lds_slice((size_t)c->st_n * 8) + lds_slice((size_t)c->st_n * 32) + lds_slice(256 * 4);
         if (dyn + sig_bytes <= 96 * 1024) { qa.lds_sigs = 1; dyn += sig_bytes; }
@@ -1650,9 +1649,10 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
             uint32_t ctl[16];
             HIPCHK(c, hipMemcpy(ctl, c->seq_ctrl.p, sizeof ctl, hipMemcpyDeviceToHost));
             fprintf(stderr, "[nhdfit] k_decide: %u queue items; GPU-less pods: %u verifications failed, %u looked at a node in LDS, %u at a published one, "
-                            "%u at an untouched one, %u window rescans\n", ctl[1] ? ctl[1] - 1 : 0, ctl[4], ctl[8], ctl[5], ctl[6], ctl[7]);
-            fprintf(stderr, "[nhdfit] k_decide driver: waiting for fetchers %.2f ms, pods with GPUs %.2f ms, GPU-less pods: node state %.2f ms, verify + commit %.2f ms, "
-                            "publish %.2f ms\n", ctl[9] * 1e-5, ctl[10] * 1e-5, ctl[11] * 1e-5, ctl[12] * 1e-5, ctl[13] * 1e-5);
+                            "%u at an untouched one, %u waited for an earlier pod's target, %u window rescans, %u sent back by the sequencer\n",
+                    ctl[1] ? ctl[1] - 1 : 0, ctl[4], ctl[5], ctl[6], ctl[7], ctl[8], ctl[14], ctl[15]);
+            fprintf(stderr, "[nhdfit] k_decide sequencer: waiting for fetchers %.2f ms, pods with GPUs %.2f ms, GPU-less pods: waiting for their speculators %.2f ms, "
+                            "validation %.2f ms\n", ctl[9] * 1e-5, ctl[10] * 1e-5, ctl[11] * 1e-5, ctl[12] * 1e-5);
         }
         if (flags[1] || flags[3]) {
             // a NIC state without a signature id (or a wait that ran out): start over with the kernel whose stop / intern /

@@ -12,29 +12,26 @@
 //   * a pod without GPUs is not stopped by busy nodes: it takes the first node (GPU-less nodes first, SelectNode,
 //     nhd/Matcher.py:401-413) that still has the resources, and so needs the state the earlier commits left on the nodes
 //     it looks at - a true chain: consecutive such pods pile onto the same node until it is full.
-// k_decide: block 0 is the decision engine.  Its wavefront 0 (the driver) walks the pods in the caller's order: a pod
-// with GPUs costs it a window look-up, a bit set and a queue entry; a pod without GPUs is verified against the candidate's
-// CURRENT state (the verdict rows are only hints for those pods: a set bit is checked by mapping the pod onto the node as
-// it is now; feasibility only ever shrinks, so a cleared bit stays right) and committed on the spot, the node staying in
-// LDS for the pods that follow.  The other wavefronts of block 0 fetch ahead (request record, first window of the pod's
-// row).  Blocks 1.. are workers: they take queue entries - map + commit a GPU pod on its node, publish the node
-// (mat[v] = 2), re-evaluate the committed node's column for the tiles that hold GPU-less pods and clear the bits of the
-// pods that lost it.  The driver waits for a node's publication only when a GPU-less pod runs into that very node.
-// A commit that leaves a node in a NIC state without a signature id poisons the node (mat[v] = 3) and is reported: the
-// host undoes the batch and runs the general kernel (k_seq), whose stop / intern / resume protocol the caller knows.
+// k_decide (below): block 0 decides - a sequencer wavefront walks the pods in the caller's order, speculator wavefronts run ahead
+// of it for the pods without GPUs (verification against the node's current version, commit computed while the sequencer
+// validates the version), fetcher wavefronts park the windows of the pods with GPUs; blocks 1.. are workers: they take queue
+// entries - map + commit a pod with GPUs on its node, publish the node (pub[v] = 1), re-evaluate a committed node's column for
+// the tiles that hold GPU-less pods and clear the bits of the pods that lost it (hints).
+// A commit that leaves a node in a NIC state without a signature id poisons the node and is reported: the host undoes the
+// batch and runs the general kernel (k_seq), whose stop / intern / resume protocol the caller knows.
 struct DecideArgs {
     SeqArgs s;
     unsigned long long* queue;   // [2 P] work items, 0 = not written yet (pre-zeroed): bit 63 valid, bit 62 kind (0 commit, 1 patch),
                                  // bits 32..61 caller's pod index (commit), bits 0..31 node
     uint32_t* ctrl;              // [0] tickets handed out to workers, [1] 1 + items pushed, once the driver is through
-    uint32_t* mat;               // [n] 0 = as the snapshot left it / commit pending, 2 = committed state in global memory, 3 = poisoned
+    uint32_t* mat;               // [n] pub[v]: commits of this batch whose state is in the mirror (0 = as the snapshot left it); bit 31 = poisoned
     uint32_t* flags;             // [1] a commit met a NIC state without a signature, [3] a wait ran out (never expected)
     uint32_t lds_sigs, lds_states, lds_choose;   // block 0: stage the signature hash table / the set-state tables / the G <= 2 choose table in LDS (they fit)
     const uint32_t* list_n; uint32_t n_n;   // the pods without GPUs (valid requests), caller's indices ascending
     const uint32_t* list_g; uint32_t n_g;   // every other pod
     uint32_t queue_len;          // entries of `queue`
     uint32_t ncls;               // NIC capacity classes of the dictionary
-    uint32_t hint_distance;      // see kHintDistance
+    uint32_t hash_slots;         // block 0's multiset of GPU-less commits (decide_hash_slots)
     uint32_t dbg;                // tuning aid (NHDFIT_SEQ_SKIP, tuning build; results are wrong with it): 1 no first-touch copy, 2 no commit, 4 no result / node stores
 };
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
@@ -268,44 +265,71 @@ __device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, 
     return status;
 }
 
-constexpr int kDecideWaves = 16, kDecideRing = 32, kDecideCache = 8, kWorkerBlocks = 12;      // (kDecideCache: a power of two)
-constexpr uint32_t kHintDistance = 2;     // a GPU-less pod's window is read when at most this many GPU-less pods before it are still undecided:
-                                          // the column patches of the earlier commits have mostly landed by then (every stale bit costs a failed
-                                          // verification), and the pods with GPUs in between leave the fetcher the time it needs
+// ---- k_decide: speculate, then retire in order ------------------------------------------------------------------------------
+// Block 0 decides; blocks 1.. commit the pods with GPUs (workers).  Inside block 0:
+//   wavefront 0, the SEQUENCER, walks the pods in the caller's order.  A pod with GPUs costs it a window look-up, a bit and a
+//     queue entry (as before).  A pod without GPUs costs it a VALIDATION: some speculator has already found the pod's node and
+//     says which version of that node it looked at; the sequencer compares that with the number of decisions made on the node
+//     so far and either retires the pod (the decision stands: count + 1, node taken) or sends it back.
+//   kSpecWaves SPECULATORS take the pods without GPUs round robin and run ahead of the sequencer: window of the pod's row,
+//     candidates in SelectNode's order, each verified against the node's state at the latest version there is (map_on_state_wave).
+//     Feasibility only ever shrinks inside a batch, so a candidate that is rejected on ANY past or present state of the node
+//     is rejected for good - whatever happens before the pod's turn; only the one candidate that ACCEPTS needs its version
+//     checked at the pod's turn.  The speculator posts (node, version), computes the commit while it waits, and on "retire"
+//     publishes: the new state goes live in an LDS cache of the block (pods that pile onto the same node read it from there),
+//     then into the mirror, results and placement to the caller's arrays, a patch item to the workers.  On "again" it
+//     re-examines the node (the sequencer stands still meanwhile, so the second answer is final).
+//   Versions: decisions on node v so far = [a pod with GPUs took it] (bit map) + the GPU-less pods retired on it (a small multiset in
+//     LDS: one entry per such commit, open addressing) - both written by the sequencer only.  pub[v] (`mat`, global) = commits
+//     whose state is in the mirror.  A reader assumes version D, waits for pub[v] == D (D > 0), reads, and confirms afterwards
+//     that the count is still D: writers of version D + 1 only start once the count says D + 1, so the read was not torn.
+//   the other wavefronts fetch ahead for the pods with GPUs (first window of the row nobody took).
+constexpr int kDecideWaves = 16, kDecideRing = 32, kSpecWaves = 6, kSpecCache = 4, kWorkerBlocks = 12;
 constexpr uint32_t kSpinLimit = 1u << 22;                      // x ~100 cycles of s_sleep: a fraction of a second, then give up
+constexpr uint32_t kPubPoison = 1u << 31;                      // pub[v]: the node was left in a NIC state without a signature id
+constexpr uint32_t kNicSigs = 64;                              // dictionaries up to this many NIC signatures: the pod's NIC-feasible assignments
+                                                               // per signature ride along in LDS
+__host__ __device__ inline uint32_t decide_hash_slots(uint32_t n_gpu_less) {      // multiset of GPU-less commits: load <= 1/2, >= one wavefront's probe
+    uint32_t h = 64;
+    while (h < 2u * n_gpu_less) h <<= 1;
+    return h;
+}
 
 __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     const SeqArgs& a = q.s;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tiles = (a.P + kTile - 1) / kTile;
-    const uint32_t n_pods = a.list ? a.n_list : a.P;
+    const uint32_t n_pods = a.P;
     __shared__ Layout s_L[kWClasses];
     __shared__ double s_caps[NHDFIT_MAX_CLASSES];
     __shared__ uint32_t s_ngl;
     constexpr uint32_t kGlLds = 1024;                        // (more tiles with GPU-less pods than this: the rest goes unpatched - hints only)
     __shared__ uint16_t s_gl[kGlLds];
-    // per-wavefront scratch: the worker wavefronts' node / request / result, and the driver's (slot 0)
+    // per-wavefront scratch: request / result / placement (workers and speculators), node (workers)
     __shared__ PaddedReq s_wreq[kDecideWaves];
     __shared__ NodeState s_wst[kDecideWaves];
     __shared__ nhdfit_detail s_wdet[kDecideWaves];
     __shared__ nhdfit_placement s_wplace[kDecideWaves];
     __shared__ SeqResult s_wres[kDecideWaves];
-    // block 0 only
-    __shared__ PaddedReq s_req[kDecideRing];
+    // block 0 only.  Pods with GPUs: ring of parked windows
     __shared__ uint64_t s_win[kDecideRing][64];
     __shared__ uint32_t s_base[kDecideRing], s_pos[kDecideRing];
-    __shared__ int32_t s_have[kDecideRing];                    // 0 no candidate, 1 window of the GPU-less nodes, 2 window of all nodes, -1 no GPU-less node left
-    __shared__ uint32_t s_kind[kDecideRing];                   // 1 = the pod requests GPUs
+    __shared__ int32_t s_have[kDecideRing];                    // 0 no candidate, 2 window parked
     __shared__ uint32_t s_ready[kDecideRing];                  // sequence number + 1 of the pod parked in the slot
-    __shared__ uint32_t s_done, s_abort, s_done_tn;
-    constexpr uint32_t kNicSigs = 64;                          // dictionaries up to this many NIC signatures: the pod's NIC-feasible assignments
-    __shared__ uint32_t s_nic[kDecideRing][kNicSigs];          // per signature (low half: on NUMA 0, high half: on NUMA 1) ride along with its window
-    __shared__ uint32_t s_nicn[kDecideRing];
-    __shared__ NodeState s_cst[2][kDecideCache];               // nodes a driver wavefront committed to, most recent kDecideCache each
-    __shared__ nhdfit_detail s_cdet[2][kDecideCache];
-    __shared__ uint32_t s_ctag[2][kDecideCache];
-    __shared__ uint32_t s_verdict[kDecideRing];                // wavefront 1 -> wavefront 0, per GPU-less pod: (pod + 1) << 2 | 1 placed / 2 yours
-    __shared__ uint32_t s_nitems, s_side_done;                 // queue entries written so far (two writers) / wavefront 1 is through
+    __shared__ uint32_t s_done, s_abort, s_nitems, s_spec_done;
+    // speculators
+    __shared__ uint64_t s_swin[kSpecWaves][64];
+    __shared__ uint32_t s_snic[kSpecWaves][kNicSigs];          // per signature: low half = assignments that pass the NIC test on NUMA 0, high half on NUMA 1
+    __shared__ NodeState s_cst[kSpecWaves * kSpecCache];       // nodes the speculators committed to, most recent kSpecCache each; the entry a
+    __shared__ nhdfit_detail s_cdet[kSpecWaves * kSpecCache];  // speculator works in is tagged kNoNode until its commit is retired
+    __shared__ uint32_t s_ctag[64], s_cver[64];
+    __shared__ NodeState s_pst[kSpecWaves];                    // a never-touched node as it was (first-touch copy, written at retirement)
+    __shared__ nhdfit_detail s_pdet[kSpecWaves];
+    __shared__ uint32_t s_post[kSpecWaves], s_verd[kSpecWaves];  // speculator -> sequencer: (pod + 1) << 4 | attempt; back: the same << 1 | retire
+    __shared__ uint32_t s_rv[kSpecWaves], s_rd[kSpecWaves];    // the posted node (kNoNode: none takes the pod) and the version looked at
+    __shared__ uint32_t s_pendv[kSpecWaves], s_pende[kSpecWaves];   // a posted, not yet retired target and its pod (later pods wait instead of working on a dead version)
+    __shared__ uint32_t s_cnt[8];                              // tuning aid: [0] failed verifications [1] LDS cache hits [2] published states read [3] untouched [4] waits for an earlier pod's target [5] window rescans
+    static_assert(kSpecWaves * kSpecCache <= 64, "the cache tags are searched by one wavefront");
     extern __shared__ __align__(16) uint8_t s_dyn[];
 
     if (tid == 0) s_ngl = 0;
@@ -328,54 +352,6 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     auto wg_store = [](uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto dev_load = [](const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); };
 
-    // map + commit of pod `mine` (request in rq) on node v whose state sits in (st, dd): results and the node written back.
-    // `verify`: the row bit is only a hint - false = the node does not (any longer) take the pod, nothing was changed.
-    //   touch: 0 = the node was touched before in this batch, 1 = never (first-touch copy without a look-up)
-    //   nic_tab: optional per-signature NIC masks of this pod (low half NUMA 0, high half NUMA 1), fetched ahead into LDS
-    auto map_commit = [&](const nhdfit_req& rq, NodeState& st, nhdfit_detail& dd, uint32_t pos, uint32_t mine, uint32_t v, bool verify, int touch,
-                          const uint32_t* nic_tab, const SigTable& sigs, const MapTables& mt, SeqResult& res, nhdfit_placement& pl, int32_t& status) -> bool {
-        bool ok = !verify || rq.hugepages_gb <= st.p2.hp_free;            // nhd/Matcher.py:78
-        if (ok && verify) {                                               // cheap necessary condition before the table look-ups: enough free
-            const bool smt = (st.p2.flags & NHDFIT_NF_SMT) != 0;          // physical cores on the node as a whole
-            uint32_t need = smt ? rq.misc_smt : rq.misc_nosmt;
-            for (uint32_t g = 0; g < rq.n_groups; ++g) need += smt ? rq.cpu_smt[g] : rq.cpu_nosmt[g];
-            ok = need <= (uint32_t)popc64(st.p0.t0[0] & st.p1.t1[0]) + (uint32_t)popc64(st.p0.t0[1] & st.p1.t1[1]);
-        }
-        nhdfit_mapping mp = nhdfit_mapping{};
-        if (ok) {
-            const uint32_t tile = pos >> 6;
-            const bool pci = rq.map_type == NHDFIT_MAP_PCI;
-            const uint32_t bits = nic_tab ? (nic_tab[pci ? st.p3.sig_pci[0] : st.p3.sig_numa[0]] & 0xFFFFu) & (nic_tab[pci ? st.p3.sig_pci[1] : st.p3.sig_numa[1]] >> 16)
-                                          : nic_assignment_bits_wave(a.tabs + (size_t)tile * a.pitch, s_L[a.tile_wcls[tile]], pos & 63, pci, st.p3, lane);
-            ok = map_on_state_wave(rq, st, dd, s_caps, bits, mt, lane, mp);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (!ok && verify) return false;
-        if (touch && !(kTuning && (q.dbg & 1))) note_first_touch(a, v, st, dd, lane, true);
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) { res.node = (int64_t)a.global_base + (int64_t)v; res.map = ok ? mp : nhdfit_mapping{}; }
-        if (ok && kTuning && (q.dbg & 2)) status = kCommitOk;
-        else if (ok) status = commit_node_wave(st, dd, rq, mp, a.now, sigs, q.ncls, pl, lane);
-        else {                                                            // the row said feasible, the mapping disagrees: cannot happen
-            if (lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&pl)[lane] = 0u;
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) pl.status = kCommitWouldRaise;
-            status = kCommitWouldRaise;
-        }
-        if (lane == 0) { res.status = status; if (status == kCommitNewSig) q.flags[1] = 1u; }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (kTuning && (q.dbg & 4)) return true;
-        if (lane < sizeof(SeqResult) / 4) reinterpret_cast<uint32_t*>(&a.out[mine])[lane] = reinterpret_cast<const uint32_t*>(&res)[lane];
-        if (a.place && lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&a.place[mine])[lane] = reinterpret_cast<const uint32_t*>(&pl)[lane];
-        store_node_lds(a, v, &st, &dd, lane);
-        return true;
-    };
-    auto publish = [&](uint32_t v, int32_t status) {                      // the node's new state is in global memory: tell the driver
-        __threadfence();
-        if (lane == 0) __hip_atomic_store(&q.mat[v], status == kCommitNewSig ? 3u : 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    };
-
     if (blockIdx.x != 0) {
         // ---- workers: one wavefront per queue entry ----------------------------------------------------------------------
         for (;;) {
@@ -388,21 +364,19 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 item = __hip_atomic_load(&q.queue[ticket], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                 if (item) break;
                 const uint32_t fin = dev_load(&q.ctrl[1]);
-                if (fin && ticket >= fin - 1u) return;                    // the driver is through and never wrote this entry
+                if (fin && ticket >= fin - 1u) return;                    // block 0 is through and never wrote this entry
                 if (spin > kSpinLimit) { if (lane == 0) q.flags[3] = 1u; return; }   // the entry for this ticket may still come: the host must not trust the batch (it undoes it and runs k_seq)
                 __builtin_amdgcn_s_sleep(16);
             }
             const uint32_t v = (uint32_t)item;
             NodeState& st = s_wst[wave];
             nhdfit_detail& dd = s_wdet[wave];
-            if (item & kItemPatch) {                                      // a node the driver committed to: its column
-                bool seen = false;
-                for (uint32_t spin = 0; spin < kSpinLimit && !seen; ++spin) { seen = dev_load(&q.mat[v]) >= 2u; if (!seen) __builtin_amdgcn_s_sleep(4); }
-                load_node_lds_coherent(a, v, &st, &dd, lane);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (item & kItemPatch) {                                      // a node a GPU-less pod was retired on: its column (hints; a state
+                load_node_lds_coherent(a, v, &st, &dd, lane);             // torn by a later commit lies between two real ones: it clears no
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // bit the later one would not clear)
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t k0 = (uint32_t)(item >> 32) & 0xFFFFu;
-                if (ngl && seen) patch_columns(a, v, st, gl_tiles, k0, k0 + patch_span(ngl) < ngl ? k0 + patch_span(ngl) : ngl, s_L, lane);
+                if (ngl) patch_columns(a, v, st, gl_tiles, k0, k0 + patch_span(ngl) < ngl ? k0 + patch_span(ngl) : ngl, s_L, lane);
                 continue;
             }
             const uint32_t mine = (uint32_t)(item >> 32) & 0x3FFFFFFFu, pos = a.order[mine];
@@ -414,26 +388,63 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             load_node_lds(a, v, &st, &dd, lane);                          // never written before in this batch: the snapshot's copy
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            int32_t status = 0;
-            map_commit(s_wreq[wave].r, st, dd, pos, mine, v, false, 1, nullptr, a.sigs, a.mt, s_wres[wave], s_wplace[wave], status);
-            publish(v, status);
+            // map + commit of a pod with GPUs on the node the sequencer gave it (the snapshot's verdict stands: nothing touched the node)
+            const nhdfit_req& rq = s_wreq[wave].r;
+            SeqResult& res = s_wres[wave];
+            nhdfit_placement& pl = s_wplace[wave];
+            nhdfit_mapping mp = nhdfit_mapping{};
+            const uint32_t tile = pos >> 6;
+            const uint32_t bits = nic_assignment_bits_wave(a.tabs + (size_t)tile * a.pitch, s_L[a.tile_wcls[tile]], pos & 63, rq.map_type == NHDFIT_MAP_PCI, st.p3, lane);
+            const bool ok = map_on_state_wave(rq, st, dd, s_caps, bits, a.mt, lane, mp);
+            __builtin_amdgcn_wave_barrier();
+            if (!(kTuning && (q.dbg & 1))) note_first_touch(a, v, st, dd, lane, true);
+            __builtin_amdgcn_wave_barrier();
+            int32_t status;
+            if (lane == 0) { res.node = (int64_t)a.global_base + (int64_t)v; res.map = ok ? mp : nhdfit_mapping{}; }
+            if (ok && kTuning && (q.dbg & 2)) status = kCommitOk;
+            else if (ok) status = commit_node_wave(st, dd, rq, mp, a.now, a.sigs, q.ncls, pl, lane);
+            else {                                                        // the row said feasible, the mapping disagrees: cannot happen
+                if (lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&pl)[lane] = 0u;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) pl.status = kCommitWouldRaise;
+                status = kCommitWouldRaise;
+            }
+            if (lane == 0) { res.status = status; if (status == kCommitNewSig) q.flags[1] = 1u; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (!(kTuning && (q.dbg & 4))) {
+                if (lane < sizeof(SeqResult) / 4) reinterpret_cast<uint32_t*>(&a.out[mine])[lane] = reinterpret_cast<const uint32_t*>(&res)[lane];
+                if (a.place && lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&a.place[mine])[lane] = reinterpret_cast<const uint32_t*>(&pl)[lane];
+                store_node_lds(a, v, &st, &dd, lane);
+            }
+            __threadfence();                                              // the node's new state is in the mirror: version 1 (a pod with GPUs is
+            if (lane == 0)                                                // always the first to touch its node)
+                __hip_atomic_store(&q.mat[v], status == kCommitNewSig ? (kPubPoison | 1u) : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             if (ngl) patch_columns(a, v, st, gl_tiles, 0, ngl, s_L, lane);
         }
     }
 
     // ---- block 0: the decision engine ------------------------------------------------------------------------------------
     uint8_t* dynp = s_dyn;
-    uint64_t* s_taken = carve<uint64_t>(dynp, a.chunks);                  // nodes that received a pod of this batch
+    uint64_t* s_taken = carve<uint64_t>(dynp, a.chunks);                  // nodes that received a pod of this batch (busy: gone for pods with GPUs)
+    uint64_t* s_tgpu = carve<uint64_t>(dynp, a.chunks);                   // ... a pod with GPUs
+    uint32_t* s_hash = carve<uint32_t>(dynp, q.hash_slots);               // one entry per GPU-less pod retired: its node
+    uint32_t* s_isn = carve<uint32_t>(dynp, (a.P + 31) / 32);             // pods without GPUs
+    const uint32_t hmask = q.hash_slots - 1u;
     SigTable sigs = a.sigs;
     MapTables mt = a.mt;
     uint64_t* l_skey = nullptr; uint32_t* l_sid = nullptr; uint64_t* l_info = nullptr; uint32_t* l_next = nullptr; uint32_t* l_asc = nullptr;
     if (q.lds_sigs) { l_skey = carve<uint64_t>(dynp, (size_t)a.sigs.mask + 1); l_sid = carve<uint32_t>(dynp, (size_t)a.sigs.mask + 1); }
     if (q.lds_states) { l_info = carve<uint64_t>(dynp, a.mt.st.n); l_next = carve<uint32_t>(dynp, (size_t)a.mt.st.n * 8); l_asc = carve<uint32_t>(dynp, 256); }
     uint8_t* l_choose = q.lds_choose ? carve<uint8_t>(dynp, kChooseEntries) : nullptr;
-    if (tid == 0) { s_done = 0; s_abort = 0; s_done_tn = 0; s_nitems = 0; s_side_done = 0; }
-    if (tid < kDecideRing) { s_ready[tid] = 0; s_verdict[tid] = 0; }
-    if (tid < 2 * kDecideCache) s_ctag[tid / kDecideCache][tid % kDecideCache] = kNoNode;
-    for (uint32_t k = tid; k < a.chunks; k += 64 * kDecideWaves) s_taken[k] = 0;
+    if (tid == 0) { s_done = 0; s_abort = 0; s_nitems = 0; s_spec_done = 0; }
+    if (tid < kDecideRing) s_ready[tid] = 0;
+    if (tid < 64) { s_ctag[tid] = kNoNode; s_cver[tid] = 0; }
+    if (tid < kSpecWaves) { s_post[tid] = 0; s_verd[tid] = 0; s_pendv[tid] = kNoNode; s_pende[tid] = 0; }
+    if (tid < 8) s_cnt[tid] = 0;
+    for (uint32_t k = tid; k < a.chunks; k += 64 * kDecideWaves) { s_taken[k] = 0; s_tgpu[k] = 0; }
+    for (uint32_t k = tid; k < q.hash_slots; k += 64 * kDecideWaves) s_hash[k] = kNoNode;
+    for (uint32_t k = tid; k < (a.P + 31) / 32; k += 64 * kDecideWaves) s_isn[k] = 0;
     if (q.lds_sigs) {
         for (uint32_t k = tid; k <= a.sigs.mask; k += 64 * kDecideWaves) { l_skey[k] = a.sigs.key[k]; l_sid[k] = a.sigs.id[k]; }
         sigs = SigTable{l_skey, l_sid, a.sigs.mask};
@@ -451,11 +462,13 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         mt.choose_tab = l_choose;
     }
     __syncthreads();
+    for (uint32_t k = tid; k < q.n_n; k += 64 * kDecideWaves) { const uint32_t e = q.list_n[k]; atomicOr(&s_isn[e >> 5], 1u << (e & 31)); }
+    __syncthreads();
 
-    // first window of 64 chunks at or after (from_chunk, from_bit) of pod `pos`'s row that holds a candidate -> slot.
+    // first window of 64 chunks at or after (from_chunk, from_bit) of pod `pos`'s row that holds a candidate -> win.
     //   mode 1: the nodes without GPUs; 2: every node; 3: every node nobody took yet (a pod that requests GPUs);
     //   4: the nodes with GPUs (a GPU-less pod whose pass over the GPU-less nodes found nothing)
-    auto scan_window = [&](uint32_t slot, uint32_t pos, uint32_t mode, uint32_t from_chunk, uint32_t from_bit, uint32_t& base_out) -> bool {
+    auto scan_window = [&](uint64_t* win, uint32_t pos, uint32_t mode, uint32_t from_chunk, uint32_t from_bit, uint32_t& base_out) -> bool {
         for (uint32_t base = from_chunk; base < a.chunks; base += 64) {
             const uint32_t c = base + lane;
             uint64_t w = 0;
@@ -467,86 +480,24 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             }
             if (c == from_chunk) w &= ~0ull << from_bit;
             if (__ballot(w != 0)) {
-                s_win[slot][lane] = w;
+                win[lane] = w;
                 base_out = base;
                 return true;
             }
         }
         return false;
     };
-
-    if (wave >= 2) {
-        // ---- fetchers: pod e goes to slot e % kDecideRing once wavefront 0 is past pod e - kDecideRing.  Two pools, so that a
-        // GPU-less pod waiting for its turn (below) never holds up the pods with GPUs behind it
-        constexpr uint32_t kFetchN = 5, kFetchG = kDecideWaves - 2 - kFetchN;
-        const bool pool_n = wave < 2 + kFetchN;
-        const uint32_t* list = pool_n ? q.list_n : q.list_g;
-        const uint32_t n_list = pool_n ? q.n_n : q.n_g, stride = pool_n ? kFetchN : kFetchG;
-        for (uint32_t j = pool_n ? wave - 2 : wave - 2 - kFetchN; j < n_list; j += stride) {
-            const uint32_t e = list[j];
-            const uint32_t slot = e % kDecideRing;
-            for (uint32_t spin = 0; e >= wg_load(&s_done) + kDecideRing; ++spin) {
-                if (spin > kSpinLimit || wg_load(&s_abort)) return;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            const uint32_t mine = e;
-            const uint32_t pos = a.order[mine];
-            if (pool_n && lane < sizeof(nhdfit_req) / 16) {                // (the driver never reads the request of a pod with GPUs)
-                const uint4 v4 = reinterpret_cast<const uint4*>(a.reqs + pos)[lane];
-                uint32_t* dst = reinterpret_cast<uint32_t*>(&s_req[slot]) + lane * 4;
-                dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;
-            }
-            const bool wants_gpu = !pool_n;
-            int32_t have = 0;
-            uint32_t wb = 0;
-            const unsigned long long score_a = a.score[pos];
-            if (pool_n && score_a)                                        // (j = the number of GPU-less pods before this one)
-                for (uint32_t spin = 0; j > wg_load(&s_done_tn) + q.hint_distance; ++spin) {
-                    if (spin > kSpinLimit || wg_load(&s_abort)) return;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            if (score_a) {
-                const int64_t from = (int64_t)(NHDFIT_SCORE_INDEX(score_a) - a.global_base);
-                const uint32_t mode = wants_gpu ? 3u : (score_a >> 63) ? 1u : 2u;
-                if (scan_window(slot, pos, mode, (uint32_t)(from >> 6), (uint32_t)(from & 63), wb)) have = mode == 1 ? 1 : 2;
-                else if (mode == 1) have = -1;                            // no GPU-less node left in the row: the driver tries all nodes
-            }
-            uint32_t nicn = 0;
-            if (!wants_gpu && have != 0 && s_L[0].nsig <= kNicSigs) {     // bit p of a half: assignment p passes the NIC test on that NUMA node
-                const Layout& L = s_L[a.tile_wcls[pos >> 6]];           // for a node with this signature (the cold R rows of the pod's tile)
-                const uint8_t* img = a.tabs + (size_t)(pos >> 6) * a.pitch;
-                nicn = L.nsig;
-                if (lane < L.nsig) {
-                    uint32_t m0 = 0, m1 = 0;
-                    for (uint32_t pp = 0; pp < L.W; ++pp) {
-                        m0 |= (uint32_t)(ld64(img, L.off_r0 + lane * L.row + pp * 8) >> (pos & 63) & 1) << pp;
-                        m1 |= (uint32_t)(ld64(img, L.off_r1 + lane * L.row + pp * 8) >> (pos & 63) & 1) << pp;
-                    }
-                    s_nic[slot][lane] = m0 | (m1 << 16);
-                }
-            }
-            if (lane == 0) { s_have[slot] = have; s_kind[slot] = wants_gpu ? 1u : 0u; s_pos[slot] = pos; s_base[slot] = wb; s_nicn[slot] = nicn; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) wg_store(&s_ready[slot], e + 1);
+    // decisions made on node v so far (wave-uniform): the sequencer's two structures
+    auto hash_of = [&](uint32_t v) { return (v * 2654435761u) >> 7; };
+    auto decisions_on = [&](uint32_t v) -> uint32_t {
+        uint32_t d = (uint32_t)(__hip_atomic_load(&s_tgpu[v >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (v & 63)) & 1u;
+        for (uint32_t h = hash_of(v);; h += 64) {
+            const uint32_t key = __hip_atomic_load(&s_hash[(h + lane) & hmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint64_t eq = __ballot(key == v), em = __ballot(key == kNoNode);
+            if (em) return d + (uint32_t)__popcll(eq & ((1ull << __builtin_ctzll(em)) - 1ull));
+            d += (uint32_t)__popcll(eq);
         }
-        return;
-    }
-
-    // ---- the drivers ------------------------------------------------------------------------------------------------------
-    // Wavefront 0 walks every pod in the caller's order.  Wavefront 1 takes one independent piece of the chain off it: the nodes
-    // WITHOUT GPUs only ever change under the GPU-less pods that take them (a pod with GPUs never fits such a node), so the
-    // GPU-less pods' pass over the GPU-less nodes (SelectNode's preference) is a chain of its own.  Wavefront 1 walks that
-    // chain - GPU-less pods in order, GPU-less nodes only - and leaves a verdict per pod: placed, or "yours" (no GPU-less node
-    // takes it: wavefront 0 then tries the nodes with GPUs at the pod's position in the order, as the scheduler's loop would).
-    const bool is_main = wave == 0;
-    const uint32_t dr = is_main ? 0u : 1u;                                // which node cache / scratch slot
-    __builtin_amdgcn_s_setprio(3);
-    uint32_t cache_next = 0, n_tn_done = 0;
-    uint32_t pend_v = kNoNode;                                            // a commit whose publication waits for the next pod: by then its
-                                                                          // stores have landed and the fence costs nothing
-    uint32_t c_fail = 0, c_wait = 0, c_plain = 0, c_rescan = 0, c_hit = 0;     // tuning aid: what the GPU-less pods cost wavefront 0 (ctrl[4..8])
-    unsigned long long t_ready = 0, t_gpu = 0, t_state = 0, t_verify = 0, t_publish = 0, t_last = wall_clock64();   // 100 MHz ticks (ctrl[9..13])
-    auto lap = [&](unsigned long long& acc) { const unsigned long long t = wall_clock64(); acc += t - t_last; t_last = t; };
+    };
     bool stop = false;
     auto give_up = [&]() { stop = true; if (lane == 0) { q.flags[3] = 1u; wg_store(&s_abort, 1u); } };
     auto push = [&](unsigned long long item) {                            // one 8-byte store: the entry itself is the signal
@@ -555,155 +506,245 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             if (at < q.queue_len) __hip_atomic_store(&q.queue[at], item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    auto flush_pending = [&]() {
-        if (pend_v == kNoNode) return;
-        publish(pend_v, kCommitOk);
-        for (uint32_t k0 = 0; k0 < ngl; k0 += patch_span(ngl)) push(kItemValid | kItemPatch | ((unsigned long long)k0 << 32) | pend_v);
-        pend_v = kNoNode;
-    };
-    auto take = [&](uint32_t v) { if (lane == 0) atomicOr(reinterpret_cast<unsigned long long*>(&s_taken[v >> 6]), 1ull << (v & 63)); };   // (two writers)
-    // A GPU-less pod against the candidates of its window and the windows behind it (`pass`: 1 the GPU-less nodes, 2 every node,
-    // 4 the nodes with GPUs); every candidate is verified against the node's current state and the first that holds is
-    // committed.  Pass 1 may fall through to pass 4 (wavefront 0 when it works alone on a pod).
-    auto place_gpu_less = [&](uint32_t slot, uint32_t mine, uint32_t pos, int32_t have, uint32_t wbase, int pass, bool fall_through) -> bool {
-        const nhdfit_req& rq = s_req[slot].r;
-        bool placed = false;
-        while (have > 0 && !placed && !stop) {
-            const uint64_t w = s_win[slot][lane];
-            const uint64_t any = __ballot(w != 0);
-            if (!any) {                                                   // window exhausted: the next one, then the next pass
-                ++c_rescan;
-                const uint32_t nb = wbase + 64;
-                if (nb < a.chunks && scan_window(slot, pos, (uint32_t)pass, nb, 0, wbase)) continue;
-                if (pass == 1 && fall_through) { pass = 4; have = scan_window(slot, pos, 4, 0, 0, wbase) ? 2 : 0; continue; }
-                have = 0;
-                continue;
-            }
-            const int l = __builtin_ctzll(any);
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, l);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
-            const uint32_t v = (wbase + (uint32_t)l) * 64u + (uint32_t)__builtin_ctzll(((uint64_t)hi << 32) | lo);
-            // the node as it is now: LDS if this wavefront committed to it recently; global memory once its last commit is published
-            NodeState* st = &s_wst[dr];
-            nhdfit_detail* dd = &s_wdet[dr];
-            int cidx = -1;
-            const bool taken = (s_taken[v >> 6] >> (v & 63) & 1) != 0;
-            if (taken) {
-                const uint64_t hit = __ballot(lane < (uint32_t)kDecideCache && s_ctag[dr][lane & (kDecideCache - 1)] == v);
-                if (hit) cidx = __builtin_ctzll(hit);
-            }
-            if (cidx >= 0) { st = &s_cst[dr][cidx]; dd = &s_cdet[dr][cidx]; ++c_hit; }
-            else {
-                if (taken) {
-                    ++c_wait;
-                    uint32_t m = 0;
-                    for (uint32_t spin = 0; (m = dev_load(&q.mat[v])) < 2u && !stop; ++spin) {
-                        if (spin > kSpinLimit) give_up();
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    if (m == 3u) stop = true;                             // poisoned: a NIC state without a signature (reported by the committer)
-                    if (stop) break;
-                    __threadfence();                                      // (a node this wavefront itself wrote and evicted: its stores first)
-                    load_node_lds_coherent(a, v, st, dd, lane);
-                } else { load_node_lds(a, v, st, dd, lane); ++c_plain; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                cidx = (int)(cache_next % kDecideCache);                  // work on a cache entry of its own (kept only if the commit happens)
-                if (lane < sizeof(NodeState) / 4) reinterpret_cast<uint32_t*>(&s_cst[dr][cidx])[lane] = reinterpret_cast<const uint32_t*>(st)[lane];
-                if (lane < sizeof(nhdfit_detail) / 4) reinterpret_cast<uint32_t*>(&s_cdet[dr][cidx])[lane] = reinterpret_cast<const uint32_t*>(dd)[lane];
-                if (lane == 0) s_ctag[dr][cidx] = kNoNode;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                st = &s_cst[dr][cidx]; dd = &s_cdet[dr][cidx];
-            }
-            if (is_main) lap(t_state);
-            int32_t status = 0;
-            const bool ok = map_commit(rq, *st, *dd, pos, mine, v, true, taken ? 0 : 1, s_nicn[slot] ? s_nic[slot] : nullptr, sigs, mt, s_wres[dr], s_wplace[dr], status);
-            if (is_main) lap(t_verify);
-            if (!ok) {                                                    // stale hint: not this node (any more)
-                ++c_fail;
-                if (lane == (uint32_t)l) s_win[slot][lane] = w & ~(1ull << (v & 63));
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                continue;
-            }
-            if (lane == 0) s_ctag[dr][cidx] = v;
-            take(v);                                                      // busy for every later pod with GPUs
-            if ((uint32_t)cidx == cache_next % kDecideCache) ++cache_next;
-            if (status == kCommitNewSig) { publish(v, status); give_up(); }
-            else pend_v = v;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            placed = true;
-        }
-        return placed;
-    };
     auto not_placed = [&](uint32_t mine) {
         if (lane == 0) { SeqResult r; r.node = -1; r.map = nhdfit_mapping{}; r.status = 0; a.out[mine] = r; }
         if (a.place && lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&a.place[mine])[lane] = 0u;
     };
-    auto wait_ready = [&](uint32_t slot, uint32_t e) {
-        for (uint32_t spin = 0; wg_load(&s_ready[slot]) != e + 1 && !stop; ++spin) {
-            if (spin > kSpinLimit) give_up();
-            if (wg_load(&s_abort)) stop = true;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
+    constexpr uint32_t kFetchWaves = kDecideWaves - 1 - kSpecWaves;
+    // wavefronts 1, 2, 3, 5, 6, 7 speculate (the sequencer shares its SIMD with fetchers only), the rest fetch
+    const int spec_id = wave >= 1 && wave <= 3 ? (int)wave - 1 : wave >= 5 && wave <= 7 ? (int)wave - 2 : -1;
+    static_assert(kSpecWaves == 6, "wavefront roles of block 0");
 
-    if (!is_main) {
-        // ---- wavefront 1: the GPU-less pods over the GPU-less nodes
-        for (uint32_t j = 0; j < q.n_n && !stop; ++j) {
-            const uint32_t e = q.list_n[j], slot = e % kDecideRing;
-            wait_ready(slot, e);
-            if (stop) break;
-            flush_pending();
-            uint32_t code = 2u;                                           // "yours": nothing among the GPU-less nodes
-            if (s_have[slot] == 1 && place_gpu_less(slot, e, s_pos[slot], 1, s_base[slot], 1, false)) code = 1u;
+    if (wave != 0 && spec_id < 0) {
+        // ---- fetchers: pod e (with GPUs) goes to slot e % kDecideRing once the sequencer is past pod e - kDecideRing
+        const uint32_t fid = wave == 4 ? 0u : wave - 7u;                  // 0 .. kFetchWaves - 1
+        for (uint32_t j = fid; j < q.n_g; j += kFetchWaves) {
+            const uint32_t e = q.list_g[j];
+            const uint32_t slot = e % kDecideRing;
+            for (uint32_t spin = 0; e >= wg_load(&s_done) + kDecideRing; ++spin) {
+                if (spin > kSpinLimit || wg_load(&s_abort)) return;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const uint32_t pos = a.order[e];
+            int32_t have = 0;
+            uint32_t wb = 0;
+            const unsigned long long score_a = a.score[pos];
+            if (score_a) {
+                const int64_t from = (int64_t)(NHDFIT_SCORE_INDEX(score_a) - a.global_base);
+                if (scan_window(s_win[slot], pos, 3u, (uint32_t)(from >> 6), (uint32_t)(from & 63), wb)) have = 2;
+            }
+            if (lane == 0) { s_have[slot] = have; s_pos[slot] = pos; s_base[slot] = wb; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) wg_store(&s_verdict[slot], ((e + 1u) << 2) | code);
+            if (lane == 0) wg_store(&s_ready[slot], e + 1);
         }
-        flush_pending();
-        if (lane == 0) wg_store(&s_side_done, 1u);
         return;
     }
 
-    // ---- wavefront 0: every pod, in the caller's order
-    for (uint32_t e = 0; e < n_pods && !stop; ++e) {
-        const uint32_t slot = e % kDecideRing, mine = e;
-        wait_ready(slot, e);
-        if (stop) break;
-        lap(t_ready);
-        if (pend_v != kNoNode) { flush_pending(); lap(t_publish); }
-        const uint32_t pos = s_pos[slot];
-        const bool wants_gpu = s_kind[slot] != 0;
-        int32_t have = s_have[slot];
-        uint32_t wbase = s_base[slot];
-        bool placed = false;
-        if (wants_gpu) {
-            // first bit of the window nobody took since it was parked
-            while (have == 2 && !placed) {
-                const uint32_t c = wbase + lane;
-                const uint64_t w = s_win[slot][lane] & (c < a.chunks ? ~s_taken[c] : 0ull);
+    if (spec_id >= 0) {
+        // ---- speculators ----------------------------------------------------------------------------------------------
+        const uint32_t sp = (uint32_t)spec_id;
+        __builtin_amdgcn_s_setprio(2);
+        uint64_t* win = s_swin[sp];
+        const nhdfit_req& rq = s_wreq[wave].r;
+        SeqResult& res = s_wres[wave];
+        nhdfit_placement& pl = s_wplace[wave];
+        uint32_t cache_next = 0;
+        uint32_t c_fail = 0, c_hit = 0, c_pub = 0, c_plain = 0, c_chain = 0, c_rescan = 0;
+        for (uint32_t j = sp; j < q.n_n && !stop; j += kSpecWaves) {
+            const uint32_t e = q.list_n[j], mine = e, pos = a.order[mine];
+            if (lane < sizeof(nhdfit_req) / 16) {
+                const uint4 v4 = reinterpret_cast<const uint4*>(a.reqs + pos)[lane];
+                uint32_t* dst = reinterpret_cast<uint32_t*>(&s_wreq[wave]) + lane * 4;
+                dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;
+            }
+            const unsigned long long score_a = a.score[pos];
+            const uint32_t tile = pos >> 6;
+            const Layout& L = s_L[a.tile_wcls[tile]];
+            const uint8_t* img = a.tabs + (size_t)tile * a.pitch;
+            const bool nic_tab = score_a && L.nsig <= kNicSigs;
+            if (nic_tab && lane < L.nsig) {                               // bit p of a half: assignment p passes the NIC test on that NUMA node
+                uint32_t m0 = 0, m1 = 0;                                  // for a node with this signature (the cold R rows of the pod's tile)
+                for (uint32_t pp = 0; pp < L.W; ++pp) {
+                    m0 |= (uint32_t)(ld64(img, L.off_r0 + lane * L.row + pp * 8) >> (pos & 63) & 1) << pp;
+                    m1 |= (uint32_t)(ld64(img, L.off_r1 + lane * L.row + pp * 8) >> (pos & 63) & 1) << pp;
+                }
+                s_snic[sp][lane] = m0 | (m1 << 16);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t attempt = 0, wbase = 0, pass = 0;
+            bool have = false, placed = false;
+            if (score_a) {
+                const int64_t from = (int64_t)(NHDFIT_SCORE_INDEX(score_a) - a.global_base);
+                pass = (score_a >> 63) ? 1u : 2u;                         // SelectNode: the nodes without GPUs first (the snapshot's winner says whether there is one)
+                have = scan_window(win, pos, pass, (uint32_t)(from >> 6), (uint32_t)(from & 63), wbase);
+                if (!have && pass == 1u) { pass = 4u; have = scan_window(win, pos, 4u, 0, 0, wbase); }
+            }
+            // posts (v, version) and waits for the sequencer's word: true = retire
+            auto post_and_wait = [&](uint32_t v, uint32_t ver, auto&& meanwhile) -> bool {
+                const uint32_t id = ((e + 1u) << 4) | (attempt & 15u);
+                if (lane == 0) { s_rv[sp] = v; s_rd[sp] = ver; s_pende[sp] = e; s_pendv[sp] = v; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) wg_store(&s_post[sp], id);
+                meanwhile();
+                uint32_t word = 0;
+                for (uint32_t spin = 0; ((word = wg_load(&s_verd[sp])) >> 1) != id && !stop; ++spin) {
+                    if (spin > kSpinLimit) give_up();
+                    if (wg_load(&s_abort)) stop = true;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                ++attempt;
+                return !stop && (word & 1u);
+            };
+            while (have && !placed && !stop) {
+                const uint64_t w = win[lane];
                 const uint64_t any = __ballot(w != 0);
-                if (!any) {
+                if (!any) {                                               // window exhausted: the next one, then the next pass
+                    ++c_rescan;
                     const uint32_t nb = wbase + 64;
-                    have = nb < a.chunks && scan_window(slot, pos, 3, nb, 0, wbase) ? 2 : 0;
+                    if (nb < a.chunks && scan_window(win, pos, pass, nb, 0, wbase)) continue;
+                    if (pass == 1u) { pass = 4u; have = scan_window(win, pos, 4u, 0, 0, wbase); continue; }
+                    have = false;
                     continue;
                 }
                 const int l = __builtin_ctzll(any);
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, l);
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
                 const uint32_t v = (wbase + (uint32_t)l) * 64u + (uint32_t)__builtin_ctzll(((uint64_t)hi << 32) | lo);
-                take(v);
-                push(kItemValid | ((unsigned long long)mine << 32) | v);
+                // the node at the latest version there is -> the cache entry this speculator works in (tagged kNoNode)
+                const uint32_t ce = sp * kSpecCache + cache_next % kSpecCache;
+                NodeState& st = s_cst[ce];
+                nhdfit_detail& dd = s_cdet[ce];
+                uint32_t ver = 0;
+                bool stale_bit = false;
+                for (uint32_t spin = 0; !stop; ++spin) {
+                    if (spin > kSpinLimit) { give_up(); break; }
+                    if (wg_load(&s_abort)) { stop = true; break; }
+                    // an earlier pod has posted this very node and is not retired yet: its commit comes first
+                    if (__ballot(lane < (uint32_t)kSpecWaves && lane != sp && wg_load(&s_pendv[lane]) == v && wg_load(&s_pende[lane]) < e)) {
+                        if (spin == 0) ++c_chain;
+                        __builtin_amdgcn_s_sleep(2);
+                        continue;
+                    }
+                    ver = decisions_on(v);
+                    if (ver == 0) { load_node_lds(a, v, &st, &dd, lane); ++c_plain; }
+                    else {
+                        const uint64_t hit = __ballot(wg_load(&s_ctag[lane]) == v && wg_load(&s_cver[lane]) == ver);
+                        bool got = false;
+                        if (hit) {
+                            const uint32_t src = (uint32_t)__builtin_ctzll(hit);
+                            if (lane < sizeof(NodeState) / 4) reinterpret_cast<uint32_t*>(&st)[lane] = reinterpret_cast<const uint32_t*>(&s_cst[src])[lane];
+                            if (lane < sizeof(nhdfit_detail) / 4) reinterpret_cast<uint32_t*>(&dd)[lane] = reinterpret_cast<const uint32_t*>(&s_cdet[src])[lane];
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                            got = wg_load(&s_ctag[src]) == v && wg_load(&s_cver[src]) == ver;      // (the owner may have recycled the entry meanwhile)
+                            if (got) ++c_hit;
+                        }
+                        if (!got) {
+                            // the mirror, once that version is in it; the row's word for the chunk rides along (bits the workers cleared meanwhile)
+                            const uint32_t m = dev_load(&q.mat[v]);
+                            const uint64_t fresh = __hip_atomic_load(&a.rows[(size_t)(v >> 6) * a.P + pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (m & kPubPoison) { stop = true; break; }   // a NIC state without a signature id (reported by the committer)
+                            if (!(fresh >> (v & 63) & 1)) { stale_bit = true; break; }
+                            if (m < ver) { __builtin_amdgcn_s_sleep(1); continue; }      // its commit is in flight
+                            if (m > ver) continue;                                         // decided and published since: count again
+                            load_node_lds_coherent(a, v, &st, &dd, lane);
+                            ++c_pub;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    if (decisions_on(v) == ver) break;                    // nobody was allowed to write the node while it was read
+                }
+                if (stop) break;
+                bool ok = !stale_bit && rq.hugepages_gb <= st.p2.hp_free;                  // nhd/Matcher.py:78
+                if (ok) {                                                 // cheap necessary condition before the table look-ups: enough free
+                    const bool smt = (st.p2.flags & NHDFIT_NF_SMT) != 0;  // physical cores on the node as a whole
+                    uint32_t need = smt ? rq.misc_smt : rq.misc_nosmt;
+                    for (uint32_t g = 0; g < rq.n_groups; ++g) need += smt ? rq.cpu_smt[g] : rq.cpu_nosmt[g];
+                    ok = need <= (uint32_t)popc64(st.p0.t0[0] & st.p1.t1[0]) + (uint32_t)popc64(st.p0.t0[1] & st.p1.t1[1]);
+                }
+                nhdfit_mapping mp = nhdfit_mapping{};
+                if (ok) {
+                    const bool pci = rq.map_type == NHDFIT_MAP_PCI;
+                    const uint32_t bits = nic_tab ? (s_snic[sp][pci ? st.p3.sig_pci[0] : st.p3.sig_numa[0]] & 0xFFFFu) & (s_snic[sp][pci ? st.p3.sig_pci[1] : st.p3.sig_numa[1]] >> 16)
+                                                  : nic_assignment_bits_wave(img, L, pos & 63, pci, st.p3, lane);
+                    ok = map_on_state_wave(rq, st, dd, s_caps, bits, mt, lane, mp);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (!ok) {                                                // not this node - at no later version either
+                    ++c_fail;
+                    if (lane == (uint32_t)l) win[lane] = w & ~(1ull << (v & 63));
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    continue;
+                }
+                int32_t status = kCommitOk;
+                const bool retire = post_and_wait(v, ver, [&]() {        // the commit is computed while the sequencer validates
+                    if (ver == 0) {                                       // (a never-touched node: its first-touch copy is taken at retirement)
+                        if (lane < sizeof(NodeState) / 4) reinterpret_cast<uint32_t*>(&s_pst[sp])[lane] = reinterpret_cast<const uint32_t*>(&st)[lane];
+                        if (lane < sizeof(nhdfit_detail) / 4) reinterpret_cast<uint32_t*>(&s_pdet[sp])[lane] = reinterpret_cast<const uint32_t*>(&dd)[lane];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) { res.node = (int64_t)a.global_base + (int64_t)v; res.map = mp; }
+                    status = kTuning && (q.dbg & 2) ? kCommitOk : commit_node_wave(st, dd, rq, mp, a.now, sigs, q.ncls, pl, lane);
+                    if (lane == 0) res.status = status;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                });
+                if (!retire) {                                            // the node moved on since it was read: again, from this node
+                    if (lane == 0) wg_store(&s_pendv[sp], kNoNode);
+                    continue;
+                }
+                // retired: the new state goes live in the block's cache, then everything else
+                if (lane == 0) { s_cver[ce] = ver + 1u; wg_store(&s_ctag[ce], v); wg_store(&s_pendv[sp], kNoNode); }
+                ++cache_next;
+                if (lane == 0) wg_store(&s_ctag[sp * kSpecCache + cache_next % kSpecCache], kNoNode);     // the entry worked in next
+                if (status == kCommitNewSig && lane == 0) q.flags[1] = 1u;
+                if (!(kTuning && (q.dbg & 4))) {
+                    if (lane < sizeof(SeqResult) / 4) reinterpret_cast<uint32_t*>(&a.out[mine])[lane] = reinterpret_cast<const uint32_t*>(&res)[lane];
+                    if (a.place && lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&a.place[mine])[lane] = reinterpret_cast<const uint32_t*>(&pl)[lane];
+                    if (ver == 0 && !(kTuning && (q.dbg & 1))) note_first_touch(a, v, s_pst[sp], s_pdet[sp], lane, true);
+                    store_node_lds(a, v, &st, &dd, lane);
+                }
+                __threadfence();
+                if (lane == 0) __hip_atomic_store(&q.mat[v], (status == kCommitNewSig ? kPubPoison : 0u) | (ver + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                for (uint32_t k0 = 0; k0 < ngl; k0 += patch_span(ngl)) push(kItemValid | kItemPatch | ((unsigned long long)k0 << 32) | v);
+                if (status == kCommitNewSig) give_up();
                 placed = true;
             }
-            lap(t_gpu);
-        } else {
-            // what wavefront 1 found among the GPU-less nodes
-            uint32_t verdict = 0;
-            for (uint32_t spin = 0; ((verdict = wg_load(&s_verdict[slot])) >> 2) != e + 1 && !stop; ++spin) {
+            if (!placed && !stop) {                                       // no node takes the pod - at no later version either
+                (void)post_and_wait(kNoNode, 0u, [] {});
+                if (lane == 0) wg_store(&s_pendv[sp], kNoNode);
+                if (!stop) not_placed(mine);
+            }
+        }
+        if (lane == 0) {
+            atomicAdd(&s_cnt[0], c_fail); atomicAdd(&s_cnt[1], c_hit); atomicAdd(&s_cnt[2], c_pub); atomicAdd(&s_cnt[3], c_plain);
+            atomicAdd(&s_cnt[4], c_chain); atomicAdd(&s_cnt[5], c_rescan);
+            __hip_atomic_fetch_add(&s_spec_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+
+    // ---- wavefront 0: the sequencer - every pod, in the caller's order ------------------------------------------------------
+    __builtin_amdgcn_s_setprio(3);
+    uint32_t n_tn_done = 0, c_redo = 0;
+    unsigned long long t_ready = 0, t_gpu = 0, t_post = 0, t_retire = 0, t_last = wall_clock64();   // tuning aid, 100 MHz ticks (ctrl[9..12])
+    auto lap = [&](unsigned long long& acc) { const unsigned long long t = wall_clock64(); acc += t - t_last; t_last = t; };
+    auto take = [&](uint32_t v, bool gpu_pod) {
+        if (lane == 0) {
+            atomicOr(reinterpret_cast<unsigned long long*>(&s_taken[v >> 6]), 1ull << (v & 63));
+            if (gpu_pod) atomicOr(reinterpret_cast<unsigned long long*>(&s_tgpu[v >> 6]), 1ull << (v & 63));
+        }
+    };
+    for (uint32_t e = 0; e < n_pods && !stop; ++e) {
+        const uint32_t mine = e;
+        if (!(s_isn[e >> 5] >> (e & 31) & 1u)) {
+            // a pod with GPUs (or an invalid request): first bit of its parked window nobody took since
+            const uint32_t slot = e % kDecideRing;
+            for (uint32_t spin = 0; wg_load(&s_ready[slot]) != e + 1 && !stop; ++spin) {
                 if (spin > kSpinLimit) give_up();
                 if (wg_load(&s_abort)) stop = true;
                 __builtin_amdgcn_s_sleep(1);
@@ -711,22 +752,72 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             if (stop) break;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             lap(t_ready);
-            if ((verdict & 3u) == 1u) placed = true;                      // (results written by wavefront 1)
-            else if (have == 2) placed = place_gpu_less(slot, mine, pos, 2, wbase, 2, false);      // no GPU-less candidate in the snapshot: every node, from its winner on
-            else if (have == 1 || have == -1) {                           // the GPU-less nodes gave nothing: the nodes with GPUs, from the first
-                have = scan_window(slot, pos, 4, 0, 0, wbase) ? 2 : 0;
-                placed = place_gpu_less(slot, mine, pos, have, wbase, 4, false);
+            const uint32_t pos = s_pos[slot];
+            int32_t have = s_have[slot];
+            uint32_t wbase = s_base[slot];
+            bool placed = false;
+            while (have == 2 && !placed) {
+                const uint32_t c = wbase + lane;
+                const uint64_t w = s_win[slot][lane] & (c < a.chunks ? ~s_taken[c] : 0ull);
+                const uint64_t any = __ballot(w != 0);
+                if (!any) {
+                    const uint32_t nb = wbase + 64;
+                    have = nb < a.chunks && scan_window(s_win[slot], pos, 3, nb, 0, wbase) ? 2 : 0;
+                    continue;
+                }
+                const int l = __builtin_ctzll(any);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, l);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
+                const uint32_t v = (wbase + (uint32_t)l) * 64u + (uint32_t)__builtin_ctzll(((uint64_t)hi << 32) | lo);
+                take(v, true);
+                push(kItemValid | ((unsigned long long)mine << 32) | v);
+                placed = true;
+            }
+            if (!placed) not_placed(mine);
+            lap(t_gpu);
+        } else {
+            // a pod without GPUs: validate what its speculator found
+            const uint32_t sp = n_tn_done % kSpecWaves;
+            for (uint32_t attempt = 0; !stop; ++attempt) {
+                const uint32_t id = ((e + 1u) << 4) | (attempt & 15u);
+                for (uint32_t spin = 0; wg_load(&s_post[sp]) != id && !stop; ++spin) {
+                    if (spin > kSpinLimit) give_up();
+                    if (wg_load(&s_abort)) stop = true;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (stop) break;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                lap(t_post);
+                const uint32_t v = s_rv[sp], ver = s_rd[sp];
+                bool retire = true;
+                if (v != kNoNode) {
+                    // decisions on v so far, and where the next one goes in the multiset
+                    uint32_t d = (uint32_t)(s_tgpu[v >> 6] >> (v & 63)) & 1u, at = 0;
+                    for (uint32_t h = hash_of(v);; h += 64) {
+                        const uint32_t key = s_hash[(h + lane) & hmask];
+                        const uint64_t eq = __ballot(key == v), em = __ballot(key == kNoNode);
+                        if (em) { const uint32_t f = (uint32_t)__builtin_ctzll(em); d += (uint32_t)__popcll(eq & ((1ull << f) - 1ull)); at = (h + f) & hmask; break; }
+                        d += (uint32_t)__popcll(eq);
+                    }
+                    retire = d == ver;
+                    if (retire) {
+                        if (lane == 0) __hip_atomic_store(&s_hash[at], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        take(v, false);                                   // busy for every later pod with GPUs
+                    } else ++c_redo;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) wg_store(&s_verd[sp], (id << 1) | (retire ? 1u : 0u));
+                lap(t_retire);
+                if (retire) break;
             }
             ++n_tn_done;
         }
-        if (!placed && !stop) not_placed(mine);
-        if (lane == 0) { if (!wants_gpu) wg_store(&s_done_tn, n_tn_done); wg_store(&s_done, e + 1); }
+        if (lane == 0) wg_store(&s_done, e + 1);
     }
-    flush_pending();
-    for (uint32_t spin = 0; !wg_load(&s_side_done) && spin < kSpinLimit; ++spin) __builtin_amdgcn_s_sleep(4);   // wavefront 1 has pushed its last item
+    for (uint32_t spin = 0; wg_load(&s_spec_done) < (uint32_t)kSpecWaves && spin < kSpinLimit && !wg_load(&s_abort); ++spin) __builtin_amdgcn_s_sleep(4);   // the speculators have pushed their last items
     if (lane == 0) {
-        q.ctrl[4] = c_fail; q.ctrl[5] = c_wait; q.ctrl[6] = c_plain; q.ctrl[7] = c_rescan; q.ctrl[8] = c_hit;
-        q.ctrl[9] = (uint32_t)t_ready; q.ctrl[10] = (uint32_t)t_gpu; q.ctrl[11] = (uint32_t)t_state; q.ctrl[12] = (uint32_t)t_verify; q.ctrl[13] = (uint32_t)t_publish;
+        q.ctrl[4] = s_cnt[0]; q.ctrl[5] = s_cnt[1]; q.ctrl[6] = s_cnt[2]; q.ctrl[7] = s_cnt[3]; q.ctrl[8] = s_cnt[4]; q.ctrl[14] = s_cnt[5]; q.ctrl[15] = c_redo;
+        q.ctrl[9] = (uint32_t)t_ready; q.ctrl[10] = (uint32_t)t_gpu; q.ctrl[11] = (uint32_t)t_post; q.ctrl[12] = (uint32_t)t_retire;
         wg_store(&s_done, n_pods);                                        // the fetchers run out
         const uint32_t n_items = wg_load(&s_nitems);
         __hip_atomic_store(&q.ctrl[1], (n_items < q.queue_len ? n_items : q.queue_len) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the workers leave once the queue is drained
