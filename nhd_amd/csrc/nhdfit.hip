@@ -219,7 +219,7 @@ struct nhdfit_ctx {
     // mode B
     DevBuf<uint64_t> nogpu, taken, tile_masks; DevBuf<int32_t> touched; DevBuf<uint16_t> gl_tiles; std::vector<uint32_t> order_host; std::vector<SeqResult> seq_host; DevBuf<UndoRec> undo; DevBuf<SeqResult> seq_out; DevBuf<nhdfit_placement> seq_place;
     DevBuf<uint32_t> order, seq_counters;
-    DevBuf<unsigned long long> seq_queue; DevBuf<uint32_t> seq_ctrl, seq_mat, seq_flags, seq_tn; std::vector<uint32_t> tn_host;   // decision-engine form of mode B (seq2_kernel.h)
+    DevBuf<unsigned long long> seq_queue; DevBuf<uint32_t> seq_ctrl, seq_mat, seq_flags, seq_tn; DevBuf<uint4> seq_ent; std::vector<uint32_t> tn_host;   // decision-engine form of mode B (seq2_kernel.h)
     bool seq_general = tune_env("NHDFIT_SEQ_GENERAL") != nullptr;   // tuning aid: the one-block kernel for every batch
     DevBuf<uint64_t> sig_keys; DevBuf<uint32_t> sig_ids; uint32_t sig_mask = 0;   // canonical NIC-state key -> signature id (commit_core.h)
     bool use_cand = false, want_bitmap = true, want_map = true;
@@ -405,7 +405,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release();
     c->reqs.release(); c->bitmap.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
-    c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_queue.release(); c->seq_ctrl.release(); c->seq_mat.release(); c->seq_flags.release(); c->seq_tn.release(); c->sig_keys.release(); c->sig_ids.release();
+    c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_queue.release(); c->seq_ctrl.release(); c->seq_mat.release(); c->seq_flags.release(); c->seq_tn.release(); c->seq_ent.release(); c->sig_keys.release(); c->sig_ids.release();
     for (Pipe& p : c->pipe) {
         p.nm.release(); p.dig_count.release();
         for (int b = 0; b < kBufs; ++b) {
@@ -1521,7 +1521,8 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, c->seq_out.reserve(P));
         HIPCHK(c, c->seq_place.reserve(P));
         HIPCHK(c, c->order.reserve(P));
-        HIPCHK(c, c->seq_ctrl.reserve(16));
+        HIPCHK(c, c->seq_ctrl.reserve(32));
+        HIPCHK(c, c->seq_ent.reserve(P));
         HIPCHK(c, c->seq_mat.reserve(c->n ? c->n : 1));
         HIPCHK(c, c->seq_flags.reserve(4));
         HIPCHK(c, c->seq_tn.reserve(P));
@@ -1610,7 +1611,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     bool fast = !c->seq_general && dyn_base <= 64 * 1024 && c->n > 0 && P < (1u << 26);
     if (fast) {
         // The decision engine (seq2_kernel.h): one block decides, the rest of the grid commits.
-        HIPCHK(c, hipMemsetAsync(c->seq_ctrl.p, 0, 16 * sizeof(uint32_t), sm));
+        HIPCHK(c, hipMemsetAsync(c->seq_ctrl.p, 0, 32 * sizeof(uint32_t), sm));
         HIPCHK(c, hipMemsetAsync(c->seq_mat.p, 0, (size_t)c->n * sizeof(uint32_t), sm));
         c->tn_host.resize(P);                                   // [the pods without GPUs | every other pod], caller's indices ascending
         uint32_t n_n = 0, n_g = 0;
@@ -1623,12 +1624,14 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         for (uint32_t i = 0; i < P; ++i) if (gpu_less(i)) c->tn_host[n_n++] = i;
         for (uint32_t i = 0; i < P; ++i) if (!gpu_less(i)) c->tn_host[n_n + n_g++] = i;
         HIPCHK(c, hipMemcpyAsync(c->seq_tn.p, c->tn_host.data(), (size_t)P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
+        hipLaunchKernelGGL(k_decide_prep, dim3((P + 255) / 256), dim3(256), 0, sm, c->seq_tn.p, P, c->order.p, p.score[b].p, c->global_base, c->seq_ent.p);
+        HIPCHK(c, hipGetLastError());
         const uint32_t queue_len = P * 4u;                      // a commit per pod + up to three patch items per commit of a GPU-less pod
         HIPCHK(c, c->seq_queue.reserve(queue_len));
         HIPCHK(c, hipMemsetAsync(c->seq_queue.p, 0, (size_t)queue_len * sizeof(unsigned long long), sm));
         DecideArgs qa;
         memset(&qa, 0, sizeof qa);
-        qa.list_n = c->seq_tn.p; qa.n_n = n_n; qa.list_g = c->seq_tn.p + n_n; qa.n_g = n_g; qa.queue_len = queue_len; qa.ncls = c->ncls;
+        qa.list_n = c->seq_tn.p; qa.n_n = n_n; qa.list_g = c->seq_tn.p + n_n; qa.n_g = n_g; qa.ent_n = c->seq_ent.p; qa.ent_g = c->seq_ent.p + n_n; qa.queue_len = queue_len; qa.ncls = c->ncls;
         qa.hash_slots = hash_slots;
         qa.dbg = tune_env("NHDFIT_SEQ_SKIP") ? (uint32_t)atoi(tune_env("NHDFIT_SEQ_SKIP")) : 0u;
         qa.s = sa; qa.queue = c->seq_queue.p; qa.ctrl = c->seq_ctrl.p; qa.mat = c->seq_mat.p; qa.flags = c->seq_flags.p;
@@ -1646,13 +1649,15 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, hipMemcpyAsync(flags, c->seq_flags.p, sizeof flags, hipMemcpyDeviceToHost, sm));
         HIPCHK(c, hipStreamSynchronize(sm));
         if (tune_env("NHDFIT_SEQ_PROF")) {
-            uint32_t ctl[16];
+            uint32_t ctl[32];
             HIPCHK(c, hipMemcpy(ctl, c->seq_ctrl.p, sizeof ctl, hipMemcpyDeviceToHost));
             fprintf(stderr, "[nhdfit] k_decide: %u queue items; GPU-less pods: %u verifications failed, %u looked at a node in LDS, %u at a published one, "
                             "%u at an untouched one, %u waited for an earlier pod's target, %u window rescans, %u sent back by the sequencer\n",
                     ctl[1] ? ctl[1] - 1 : 0, ctl[4], ctl[5], ctl[6], ctl[7], ctl[8], ctl[14], ctl[15]);
             fprintf(stderr, "[nhdfit] k_decide sequencer: waiting for fetchers %.2f ms, pods with GPUs %.2f ms, GPU-less pods: waiting for their speculators %.2f ms, "
                             "validation %.2f ms\n", ctl[9] * 1e-5, ctl[10] * 1e-5, ctl[11] * 1e-5, ctl[12] * 1e-5);
+            fprintf(stderr, "[nhdfit] k_decide speculators (%d, summed): set-up %.2f ms, node state %.2f ms, verification %.2f ms, commit %.2f ms, waiting (sequencer, earlier pods) %.2f ms, "
+                            "publication %.2f ms\n", kSpecWaves, ctl[16] * 1e-5, ctl[17] * 1e-5, ctl[18] * 1e-5, ctl[19] * 1e-5, ctl[20] * 1e-5, ctl[21] * 1e-5);
         }
         if (flags[1] || flags[3]) {
             // a NIC state without a signature id (or a wait that ran out): start over with the kernel whose stop / intern /

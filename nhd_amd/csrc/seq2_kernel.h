@@ -29,6 +29,8 @@ struct DecideArgs {
     uint32_t lds_sigs, lds_states, lds_choose;   // block 0: stage the signature hash table / the set-state tables / the G <= 2 choose table in LDS (they fit)
     const uint32_t* list_n; uint32_t n_n;   // the pods without GPUs (valid requests), caller's indices ascending
     const uint32_t* list_g; uint32_t n_g;   // every other pod
+    const uint4* ent_n; const uint4* ent_g; // per list entry (k_decide_prep): caller's index, staged position, the snapshot winner's local index
+                                            // (kNoNode: none), 1 = that winner is a node without GPUs
     uint32_t queue_len;          // entries of `queue`
     uint32_t ncls;               // NIC capacity classes of the dictionary
     uint32_t hash_slots;         // block 0's multiset of GPU-less commits (decide_hash_slots)
@@ -201,13 +203,21 @@ __device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, 
     const uint32_t my_gsw = lane < n_gpus && lane < (uint32_t)NHDFIT_MAX_GPUS ? d.gpu_sw[lane & 31u] : 0xFFu;
     uint32_t claimed0 = 0, claimed1 = 0;
     bool gpu_taken = false;
+    // the mapping bit / nibble-packed under compile-time indices: indexed by the run-time group number it would live in scratch memory
+    uint32_t m_gpu = 0, m_nnuma = 0, m_nidx = 0, mu = 0;
+#pragma unroll
+    for (int g = 0; g < kMaxG; ++g) {
+        m_gpu |= ((uint32_t)m.gpu[g] & 1u) << g; m_nnuma |= ((uint32_t)m.nic_numa[g] & 1u) << g; m_nidx |= ((uint32_t)m.nic_idx[g] & 15u) << (4 * g);
+    }
+#pragma unroll
+    for (int g = 0; g <= kMaxG; ++g) if (g == G) mu = (uint32_t)m.cpu[g] & 1u;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int g = 0; g < G; ++g) {
-        const uint32_t u = (uint32_t)m.gpu[g] & 1u;
+        const uint32_t u = (m_gpu >> g) & 1u;
         const WaveBatch pb = take_batch_wave(t0[u], t1[u], smt_node, r.n_proc[g], (r.smt_bits >> g & 1) != 0, lane);
         if (!pb.ok) status = kCommitWouldRaise;
-        const uint32_t nu = (uint32_t)m.nic_numa[g] & 1u, nk = (uint32_t)m.nic_idx[g] & 15u;
+        const uint32_t nu = (m_nnuma >> g) & 1u, nk = (m_nidx >> (4 * g)) & 15u;
         const uint32_t sw = d.nic_sw[nu][nk];
         uint32_t picks = 0xFFFFFFFFu;                                     // up to four picks travel in a register (byte k), the rest through lane 0
         for (uint32_t k = 0; k < r.gpus[g]; ++k) {
@@ -234,7 +244,6 @@ __device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, 
             out.help_take[g] = hb.take; out.help_pair[g] = hb.pair; out.help_late[g] = hb.late;
         }
     }
-    const uint32_t mu = (uint32_t)m.cpu[G] & 1u;
     const WaveBatch mb = take_batch_wave(t0[mu], t1[mu], smt_node, r.n_misc, r.misc_smt_enabled != 0, lane);     // Node.py:799
     if (!mb.ok) status = kCommitWouldRaise;
     if (lane == 0) {
@@ -244,10 +253,10 @@ __device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, 
         s.p2.gpu_free = gpu_free;
         if (r.hugepages_gb > 0) s.p2.hp_free -= r.hugepages_gb;              // Node.py:794-796
         s.p4.busy_time = busy_time;                                          // SetBusy, nhd/Node.py:843-845
-        for (uint32_t k = 0; k < (uint32_t)NHDFIT_MAX_NICS_PER_NUMA; ++k)     // ClaimPodNICResources (commit_core.h: the same rule)
-            for (uint32_t u = 0; u < 2; ++u)
-                if ((u ? claimed1 : claimed0) >> k & 1)
-                    if (pods_get(d, u, k) != kPodsLost && pods_add(d, u, k, 1) != 0) d.nic_cls[u][k] = 0;
+        for (uint32_t cl = claimed0 | (claimed1 << 16); cl; cl &= cl - 1u) {  // ClaimPodNICResources (commit_core.h: the same rule; every NIC touched once)
+            const uint32_t b = (uint32_t)__builtin_ctz(cl), u = b >> 4, k = b & 15u;
+            if (pods_get(d, u, k) != kPodsLost && pods_add(d, u, k, 1) != 0) d.nic_cls[u][k] = 0;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -284,7 +293,11 @@ __device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, 
 //     whose state is in the mirror.  A reader assumes version D, waits for pub[v] == D (D > 0), reads, and confirms afterwards
 //     that the count is still D: writers of version D + 1 only start once the count says D + 1, so the read was not torn.
 //   the other wavefronts fetch ahead for the pods with GPUs (first window of the row nobody took).
-constexpr int kDecideWaves = 16, kDecideRing = 32, kSpecWaves = 6, kSpecCache = 4, kWorkerBlocks = 12;
+#ifndef NHDFIT_SPEC_WAVES
+#define NHDFIT_SPEC_WAVES 9
+#endif
+constexpr int kDecideWaves = 16, kDecideRing = 32, kSpecWaves = NHDFIT_SPEC_WAVES, kSpecCache = 4, kWorkerBlocks = 12;
+static_assert(kSpecWaves == 6 || kSpecWaves == 9, "wavefront roles of block 0: speculators sit on SIMDs 1-3 (wave & 3 != 0), two or three deep");
 constexpr uint32_t kSpinLimit = 1u << 22;                      // x ~100 cycles of s_sleep: a fraction of a second, then give up
 constexpr uint32_t kPubPoison = 1u << 31;                      // pub[v]: the node was left in a NIC state without a signature id
 constexpr uint32_t kNicSigs = 64;                              // dictionaries up to this many NIC signatures: the pod's NIC-feasible assignments
@@ -293,6 +306,16 @@ __host__ __device__ inline uint32_t decide_hash_slots(uint32_t n_gpu_less) {    
     uint32_t h = 64;
     while (h < 2u * n_gpu_less) h <<= 1;
     return h;
+}
+
+// what a fetcher / speculator needs to start on list entry j, gathered once for the whole batch (three dependent look-ups otherwise)
+__global__ __launch_bounds__(256) void k_decide_prep(const uint32_t* __restrict__ list, uint32_t n, const uint32_t* __restrict__ order,
+                                                     const unsigned long long* __restrict__ score, uint64_t global_base, uint4* __restrict__ out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t e = list[j], pos = order[e];
+    const unsigned long long sc = score[pos];
+    out[j] = make_uint4(e, pos, sc ? (uint32_t)(NHDFIT_SCORE_INDEX(sc) - global_base) : kNoNode, (uint32_t)(sc >> 63));
 }
 
 __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
@@ -327,8 +350,10 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     __shared__ nhdfit_detail s_pdet[kSpecWaves];
     __shared__ uint32_t s_post[kSpecWaves], s_verd[kSpecWaves];  // speculator -> sequencer: (pod + 1) << 4 | attempt; back: the same << 1 | retire
     __shared__ uint32_t s_rv[kSpecWaves], s_rd[kSpecWaves];    // the posted node (kNoNode: none takes the pod) and the version looked at
-    __shared__ uint32_t s_pendv[kSpecWaves], s_pende[kSpecWaves];   // a posted, not yet retired target and its pod (later pods wait instead of working on a dead version)
-    __shared__ uint32_t s_cnt[8];                              // tuning aid: [0] failed verifications [1] LDS cache hits [2] published states read [3] untouched [4] waits for an earlier pod's target [5] window rescans
+    __shared__ uint32_t s_examv[kSpecWaves], s_pende[kSpecWaves];   // the node a speculator is examining / has posted, and its pod: a later pod does not post
+                                                               // that node before the earlier one has made up its mind
+    __shared__ uint32_t s_cnt[16];                             // tuning aid: [0] failed verifications [1] LDS cache hits [2] published states read [3] untouched [4] waits for an earlier pod's target [5] window rescans
+                                                               // [8..13] speculator ticks: set-up, node state, verification, commit, waiting for the sequencer, publication
     static_assert(kSpecWaves * kSpecCache <= 64, "the cache tags are searched by one wavefront");
     extern __shared__ __align__(16) uint8_t s_dyn[];
 
@@ -440,8 +465,8 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     if (tid == 0) { s_done = 0; s_abort = 0; s_nitems = 0; s_spec_done = 0; }
     if (tid < kDecideRing) s_ready[tid] = 0;
     if (tid < 64) { s_ctag[tid] = kNoNode; s_cver[tid] = 0; }
-    if (tid < kSpecWaves) { s_post[tid] = 0; s_verd[tid] = 0; s_pendv[tid] = kNoNode; s_pende[tid] = 0; }
-    if (tid < 8) s_cnt[tid] = 0;
+    if (tid < kSpecWaves) { s_post[tid] = 0; s_verd[tid] = 0; s_examv[tid] = kNoNode; s_pende[tid] = 0xFFFFFFFFu; }
+    if (tid < 16) s_cnt[tid] = 0;
     for (uint32_t k = tid; k < a.chunks; k += 64 * kDecideWaves) { s_taken[k] = 0; s_tgpu[k] = 0; }
     for (uint32_t k = tid; k < q.hash_slots; k += 64 * kDecideWaves) s_hash[k] = kNoNode;
     for (uint32_t k = tid; k < (a.P + 31) / 32; k += 64 * kDecideWaves) s_isn[k] = 0;
@@ -511,28 +536,25 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         if (a.place && lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&a.place[mine])[lane] = 0u;
     };
     constexpr uint32_t kFetchWaves = kDecideWaves - 1 - kSpecWaves;
-    // wavefronts 1, 2, 3, 5, 6, 7 speculate (the sequencer shares its SIMD with fetchers only), the rest fetch
-    const int spec_id = wave >= 1 && wave <= 3 ? (int)wave - 1 : wave >= 5 && wave <= 7 ? (int)wave - 2 : -1;
-    static_assert(kSpecWaves == 6, "wavefront roles of block 0");
+    // wavefronts with wave & 3 != 0 below 4 * kSpecWaves / 3 speculate (the sequencer shares its SIMD with fetchers only), the rest fetch
+    const int spec_id = (wave & 3u) && wave < 4u * (uint32_t)kSpecWaves / 3u ? (int)((wave >> 2) * 3u + (wave & 3u) - 1u) : -1;
 
     if (wave != 0 && spec_id < 0) {
         // ---- fetchers: pod e (with GPUs) goes to slot e % kDecideRing once the sequencer is past pod e - kDecideRing
-        const uint32_t fid = wave == 4 ? 0u : wave - 7u;                  // 0 .. kFetchWaves - 1
+        const uint32_t first_all = 4u * (uint32_t)kSpecWaves / 3u;        // wavefronts from here on all fetch; below, those with wave & 3 == 0
+        const uint32_t fid = wave < first_all ? (wave >> 2) - 1u : first_all / 4u - 1u + (wave - first_all);     // 0 .. kFetchWaves - 1
         for (uint32_t j = fid; j < q.n_g; j += kFetchWaves) {
-            const uint32_t e = q.list_g[j];
+            const uint4 ent = q.ent_g[j];
+            const uint32_t e = ent.x;
             const uint32_t slot = e % kDecideRing;
             for (uint32_t spin = 0; e >= wg_load(&s_done) + kDecideRing; ++spin) {
                 if (spin > kSpinLimit || wg_load(&s_abort)) return;
                 __builtin_amdgcn_s_sleep(2);
             }
-            const uint32_t pos = a.order[e];
+            const uint32_t pos = ent.y;
             int32_t have = 0;
             uint32_t wb = 0;
-            const unsigned long long score_a = a.score[pos];
-            if (score_a) {
-                const int64_t from = (int64_t)(NHDFIT_SCORE_INDEX(score_a) - a.global_base);
-                if (scan_window(s_win[slot], pos, 3u, (uint32_t)(from >> 6), (uint32_t)(from & 63), wb)) have = 2;
-            }
+            if (ent.z != kNoNode && scan_window(s_win[slot], pos, 3u, ent.z >> 6, ent.z & 63u, wb)) have = 2;
             if (lane == 0) { s_have[slot] = have; s_pos[slot] = pos; s_base[slot] = wb; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) wg_store(&s_ready[slot], e + 1);
@@ -550,40 +572,52 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         nhdfit_placement& pl = s_wplace[wave];
         uint32_t cache_next = 0;
         uint32_t c_fail = 0, c_hit = 0, c_pub = 0, c_plain = 0, c_chain = 0, c_rescan = 0;
+        unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_last = kTuning ? wall_clock64() : 0;    // tuning aid (100 MHz ticks)
+        auto lap = [&](int k) { if (kTuning) { const unsigned long long t = wall_clock64(); t_acc[k] += t - t_last; t_last = t; } };
+        // an earlier pod is examining / has posted node v: its word on that node comes first
+        auto earlier_pod_on = [&](uint32_t v, uint32_t e) {
+            return __ballot(lane < (uint32_t)kSpecWaves && lane != sp && wg_load(&s_examv[lane]) == v && wg_load(&s_pende[lane]) < e) != 0;
+        };
         for (uint32_t j = sp; j < q.n_n && !stop; j += kSpecWaves) {
-            const uint32_t e = q.list_n[j], mine = e, pos = a.order[mine];
-            if (lane < sizeof(nhdfit_req) / 16) {
-                const uint4 v4 = reinterpret_cast<const uint4*>(a.reqs + pos)[lane];
-                uint32_t* dst = reinterpret_cast<uint32_t*>(&s_wreq[wave]) + lane * 4;
-                dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;
-            }
-            const unsigned long long score_a = a.score[pos];
+            const uint4 ent = q.ent_n[j];
+            const uint32_t e = ent.x, mine = e, pos = ent.y;
             const uint32_t tile = pos >> 6;
             const Layout& L = s_L[a.tile_wcls[tile]];
             const uint8_t* img = a.tabs + (size_t)tile * a.pitch;
-            const bool nic_tab = score_a && L.nsig <= kNicSigs;
+            const bool has_winner = ent.z != kNoNode;
+            const bool nic_tab = has_winner && L.nsig <= kNicSigs;
+            // the request, the pod's NIC-feasible assignments per signature and its first window: three fetches in flight together
+            uint4 r4 = make_uint4(0, 0, 0, 0);
+            if (lane < sizeof(nhdfit_req) / 16) r4 = reinterpret_cast<const uint4*>(a.reqs + pos)[lane];
+            uint32_t nic_word = 0;
             if (nic_tab && lane < L.nsig) {                               // bit p of a half: assignment p passes the NIC test on that NUMA node
                 uint32_t m0 = 0, m1 = 0;                                  // for a node with this signature (the cold R rows of the pod's tile)
                 for (uint32_t pp = 0; pp < L.W; ++pp) {
                     m0 |= (uint32_t)(ld64(img, L.off_r0 + lane * L.row + pp * 8) >> (pos & 63) & 1) << pp;
                     m1 |= (uint32_t)(ld64(img, L.off_r1 + lane * L.row + pp * 8) >> (pos & 63) & 1) << pp;
                 }
-                s_snic[sp][lane] = m0 | (m1 << 16);
+                nic_word = m0 | (m1 << 16);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
             uint32_t attempt = 0, wbase = 0, pass = 0;
             bool have = false, placed = false;
-            if (score_a) {
-                const int64_t from = (int64_t)(NHDFIT_SCORE_INDEX(score_a) - a.global_base);
-                pass = (score_a >> 63) ? 1u : 2u;                         // SelectNode: the nodes without GPUs first (the snapshot's winner says whether there is one)
-                have = scan_window(win, pos, pass, (uint32_t)(from >> 6), (uint32_t)(from & 63), wbase);
+            if (has_winner) {
+                pass = ent.w ? 1u : 2u;                                   // SelectNode: the nodes without GPUs first (the snapshot's winner says whether there is one)
+                have = scan_window(win, pos, pass, ent.z >> 6, ent.z & 63u, wbase);
                 if (!have && pass == 1u) { pass = 4u; have = scan_window(win, pos, 4u, 0, 0, wbase); }
             }
+            if (lane < sizeof(nhdfit_req) / 16) {
+                uint32_t* dst = reinterpret_cast<uint32_t*>(&s_wreq[wave]) + lane * 4;
+                dst[0] = r4.x; dst[1] = r4.y; dst[2] = r4.z; dst[3] = r4.w;
+            }
+            if (nic_tab) s_snic[sp][lane] = nic_word;
+            if (lane == 0) { s_pende[sp] = e; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            lap(0);
             // posts (v, version) and waits for the sequencer's word: true = retire
             auto post_and_wait = [&](uint32_t v, uint32_t ver, auto&& meanwhile) -> bool {
                 const uint32_t id = ((e + 1u) << 4) | (attempt & 15u);
-                if (lane == 0) { s_rv[sp] = v; s_rd[sp] = ver; s_pende[sp] = e; s_pendv[sp] = v; }
+                if (lane == 0) { s_rv[sp] = v; s_rd[sp] = ver; }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) wg_store(&s_post[sp], id);
                 meanwhile();
@@ -612,6 +646,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, l);
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
                 const uint32_t v = (wbase + (uint32_t)l) * 64u + (uint32_t)__builtin_ctzll(((uint64_t)hi << 32) | lo);
+                if (lane == 0) wg_store(&s_examv[sp], v);
                 // the node at the latest version there is -> the cache entry this speculator works in (tagged kNoNode)
                 const uint32_t ce = sp * kSpecCache + cache_next % kSpecCache;
                 NodeState& st = s_cst[ce];
@@ -621,12 +656,6 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 for (uint32_t spin = 0; !stop; ++spin) {
                     if (spin > kSpinLimit) { give_up(); break; }
                     if (wg_load(&s_abort)) { stop = true; break; }
-                    // an earlier pod has posted this very node and is not retired yet: its commit comes first
-                    if (__ballot(lane < (uint32_t)kSpecWaves && lane != sp && wg_load(&s_pendv[lane]) == v && wg_load(&s_pende[lane]) < e)) {
-                        if (spin == 0) ++c_chain;
-                        __builtin_amdgcn_s_sleep(2);
-                        continue;
-                    }
                     ver = decisions_on(v);
                     if (ver == 0) { load_node_lds(a, v, &st, &dd, lane); ++c_plain; }
                     else {
@@ -648,7 +677,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                             if (!(fresh >> (v & 63) & 1)) { stale_bit = true; break; }
                             if (m < ver) { __builtin_amdgcn_s_sleep(1); continue; }      // its commit is in flight
                             if (m > ver) continue;                                         // decided and published since: count again
-                            load_node_lds_coherent(a, v, &st, &dd, lane);
+                            load_node_lds_coherent(a, v, &st, &dd, lane);                  // (after pub[v] was seen: the planes are at least that new)
                             ++c_pub;
                         }
                     }
@@ -657,6 +686,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     if (decisions_on(v) == ver) break;                    // nobody was allowed to write the node while it was read
                 }
                 if (stop) break;
+                lap(1);
                 bool ok = !stale_bit && rq.hugepages_gb <= st.p2.hp_free;                  // nhd/Matcher.py:78
                 if (ok) {                                                 // cheap necessary condition before the table look-ups: enough free
                     const bool smt = (st.p2.flags & NHDFIT_NF_SMT) != 0;  // physical cores on the node as a whole
@@ -672,12 +702,26 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     ok = map_on_state_wave(rq, st, dd, s_caps, bits, mt, lane, mp);
                 }
                 __builtin_amdgcn_wave_barrier();
+                lap(2);
                 if (!ok) {                                                // not this node - at no later version either
                     ++c_fail;
+                    if (lane == 0) wg_store(&s_examv[sp], kNoNode);
                     if (lane == (uint32_t)l) win[lane] = w & ~(1ull << (v & 63));
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     continue;
+                }
+                // an earlier pod that is looking at this node (or has posted it) goes first; if it takes the node, this one looks again
+                if (earlier_pod_on(v, e)) {
+                    ++c_chain;
+                    for (uint32_t spin = 0; earlier_pod_on(v, e) && !stop; ++spin) {
+                        if (spin > kSpinLimit) give_up();
+                        if (wg_load(&s_abort)) stop = true;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    lap(4);
+                    if (stop) break;
+                    if (decisions_on(v) != ver) continue;                 // (the bit is still set: the same node at its new version)
                 }
                 int32_t status = kCommitOk;
                 const bool retire = post_and_wait(v, ver, [&]() {        // the commit is computed while the sequencer validates
@@ -692,13 +736,12 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     if (lane == 0) res.status = status;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    lap(3);
                 });
-                if (!retire) {                                            // the node moved on since it was read: again, from this node
-                    if (lane == 0) wg_store(&s_pendv[sp], kNoNode);
-                    continue;
-                }
+                lap(4);
+                if (!retire) continue;                                    // the node moved on since it was read: again, from this node
                 // retired: the new state goes live in the block's cache, then everything else
-                if (lane == 0) { s_cver[ce] = ver + 1u; wg_store(&s_ctag[ce], v); wg_store(&s_pendv[sp], kNoNode); }
+                if (lane == 0) { s_cver[ce] = ver + 1u; wg_store(&s_ctag[ce], v); wg_store(&s_examv[sp], kNoNode); }
                 ++cache_next;
                 if (lane == 0) wg_store(&s_ctag[sp * kSpecCache + cache_next % kSpecCache], kNoNode);     // the entry worked in next
                 if (status == kCommitNewSig && lane == 0) q.flags[1] = 1u;
@@ -713,16 +756,20 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 for (uint32_t k0 = 0; k0 < ngl; k0 += patch_span(ngl)) push(kItemValid | kItemPatch | ((unsigned long long)k0 << 32) | v);
                 if (status == kCommitNewSig) give_up();
                 placed = true;
+                lap(5);
             }
+            if (lane == 0) wg_store(&s_examv[sp], kNoNode);
             if (!placed && !stop) {                                       // no node takes the pod - at no later version either
                 (void)post_and_wait(kNoNode, 0u, [] {});
-                if (lane == 0) wg_store(&s_pendv[sp], kNoNode);
                 if (!stop) not_placed(mine);
+                lap(4);
             }
         }
         if (lane == 0) {
+            wg_store(&s_pende[sp], 0xFFFFFFFFu);
             atomicAdd(&s_cnt[0], c_fail); atomicAdd(&s_cnt[1], c_hit); atomicAdd(&s_cnt[2], c_pub); atomicAdd(&s_cnt[3], c_plain);
             atomicAdd(&s_cnt[4], c_chain); atomicAdd(&s_cnt[5], c_rescan);
+            if (kTuning) for (int k = 0; k < 6; ++k) atomicAdd(&s_cnt[8 + k], (uint32_t)t_acc[k]);
             __hip_atomic_fetch_add(&s_spec_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         return;
@@ -818,6 +865,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     if (lane == 0) {
         q.ctrl[4] = s_cnt[0]; q.ctrl[5] = s_cnt[1]; q.ctrl[6] = s_cnt[2]; q.ctrl[7] = s_cnt[3]; q.ctrl[8] = s_cnt[4]; q.ctrl[14] = s_cnt[5]; q.ctrl[15] = c_redo;
         q.ctrl[9] = (uint32_t)t_ready; q.ctrl[10] = (uint32_t)t_gpu; q.ctrl[11] = (uint32_t)t_post; q.ctrl[12] = (uint32_t)t_retire;
+        if (kTuning) for (int k = 0; k < 6; ++k) q.ctrl[16 + k] = s_cnt[8 + k];
         wg_store(&s_done, n_pods);                                        // the fetchers run out
         const uint32_t n_items = wg_load(&s_nitems);
         __hip_atomic_store(&q.ctrl[1], (n_items < q.queue_len ? n_items : q.queue_len) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the workers leave once the queue is drained

@@ -72,7 +72,9 @@ __device__ __forceinline__ void candidate_masks_wave(const nhdfit_req& r, const 
 }
 // first_nic_choice: lane = position in the reference's enumeration order (an odometer whose most significant digits are
 // the NUMA-0 groups in ascending order, then the NUMA-1 groups; last digit fastest), 64 positions per pass
-__device__ __forceinline__ bool first_nic_choice_wave(const nhdfit_req& r, const WinnerState& w, uint32_t gcode, bool pci, uint32_t lane, int8_t nic_idx[kMaxG]) {
+// (the choice comes back nibble-packed, group g in nibble g: a mapping indexed by a run-time group number would live in scratch
+// memory - a memory round trip per access on the chain of the sequential kernels)
+__device__ __forceinline__ bool first_nic_choice_wave(const nhdfit_req& r, const WinnerState& w, uint32_t gcode, bool pci, uint32_t lane, uint32_t& nic_nibbles) {
     const int G = (int)r.n_groups;
     uint32_t order = 0, numa = 0;
     int n = 0;
@@ -117,8 +119,7 @@ __device__ __forceinline__ bool first_nic_choice_wave(const nhdfit_req& r, const
         }
         const uint64_t any = __ballot(ok);
         if (any) {
-            const uint32_t best = (uint32_t)__builtin_amdgcn_readlane((int)pick, __builtin_ctzll(any));
-            for (int g = 0; g < G; ++g) nic_idx[g] = (int8_t)nib_get(best, g);
+            nic_nibbles = (uint32_t)__builtin_amdgcn_readlane((int)pick, __builtin_ctzll(any));
             return true;
         }
     }
@@ -142,7 +143,13 @@ __device__ __forceinline__ bool map_on_state_wave(const nhdfit_req& r, const Nod
     const int G = (int)r.n_groups, U = w.U;
     m = nhdfit_mapping{};
     const uint32_t codes = nic_codes_from_table_bits(nic_bits, G, U);
-    if (G > 3) return map_generic_cold(&r, &w, codes, &m);
+    if (G > 3) {                                                          // (copies: nothing the hot path keeps in registers has its address taken)
+        WinnerState wc = w;
+        nhdfit_mapping tmp = nhdfit_mapping{};
+        const bool ok = map_generic_cold(&r, &wc, codes, &tmp);
+        m = tmp;
+        return ok;
+    }
     uint32_t sg, sc;
     candidate_masks_wave(r, w, lane, sg, sc);
     const uint32_t cd = codes & ((1u << ipow(U, G)) - 1u);
@@ -154,13 +161,21 @@ __device__ __forceinline__ bool map_on_state_wave(const nhdfit_req& r, const Nod
     if (!(res >> 8 & 1)) return false;
     const uint32_t gcode = (res >> 4) & 7u;
     const int ccode = (int)(res & 15u);
-    for (int g = 0; g < kMaxG; ++g) { m.gpu[g] = m.nic_numa[g] = m.nic_idx[g] = -1; }
-    for (int g = 0; g <= kMaxG; ++g) m.cpu[g] = -1;
-    if (!first_nic_choice_wave(r, w, gcode, r.map_type == NHDFIT_MAP_PCI, lane, m.nic_idx)) return false;
-    for (int g = 0; g < G; ++g) { m.gpu[g] = (int8_t)tup_digit(gcode, G, U, g); m.nic_numa[g] = m.gpu[g]; }
-    for (int g = 0; g <= G; ++g) m.cpu[g] = (int8_t)tup_digit((uint32_t)ccode, G + 1, U, g);
-    m.valid = 1;
-    return true;
+    uint32_t nic_nibbles = 0;
+    const bool nic_ok = first_nic_choice_wave(r, w, gcode, r.map_type == NHDFIT_MAP_PCI, lane, nic_nibbles);
+    // every element written under a compile-time index (the struct stays in registers)
+#pragma unroll
+    for (int g = 0; g < kMaxG; ++g) {
+        const bool in = g < G;
+        m.gpu[g] = in ? (int8_t)tup_digit(gcode, G, U, g) : (int8_t)-1;
+        m.nic_numa[g] = m.gpu[g];
+        m.nic_idx[g] = in ? (int8_t)nib_get(nic_nibbles, g) : (int8_t)-1;
+    }
+#pragma unroll
+    for (int g = 0; g <= kMaxG; ++g) m.cpu[g] = g <= G ? (int8_t)tup_digit((uint32_t)ccode, G + 1, U, g) : (int8_t)-1;
+    m.valid = nic_ok ? 1 : 0;
+    if (!nic_ok) m = nhdfit_mapping{};
+    return nic_ok;
 }
 
 // One block walks the batch in the caller's order, kSeqPods pods per round (one per wavefront).
