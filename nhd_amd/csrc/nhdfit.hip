@@ -196,7 +196,8 @@ struct nhdfit_ctx {
     std::vector<uint32_t> perm;          // device (class-sorted) position -> caller's pod index
     PinBuf<nhdfit_req> pin_reqs; PinBuf<uint8_t> pin_wcls; PinBuf<uint64_t> pin_score; PinBuf<nhdfit_mapping> pin_maps;   // host staging of one call
     PinBuf<uint8_t> pin_items;           // the fit role's work items on their way to the device
-    DevBuf<uint64_t> bitmap;             // pod-major rows [chunks][P], converted from `nm` on demand (fetch, mode B)
+    DevBuf<uint64_t> bitmap;             // pod-major rows [chunks][P], converted from `nm` on demand (fetch)
+    DevBuf<uint64_t> rows_t;             // ... [P][chunks] for the sequential kernels (mode B)
     DevBuf<uint64_t> cand;               // [chunks] candidate nodes of the call
     DevBuf<uint8_t> tile_wcls;           // row width class per staged tile
     DevBuf<FitItem> items; uint32_t n_items = 0;   // work items of the fit role (blocks), heaviest tiles first
@@ -404,7 +405,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->find_host = nullptr; c->find_sync.release();
     c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release();
-    c->reqs.release(); c->bitmap.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
+    c->reqs.release(); c->bitmap.release(); c->rows_t.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_queue.release(); c->seq_ctrl.release(); c->seq_mat.release(); c->seq_flags.release(); c->seq_tn.release(); c->seq_ent.release(); c->sig_keys.release(); c->sig_ids.release();
     for (Pipe& p : c->pipe) {
         p.nm.release(); p.dig_count.release();
@@ -1039,6 +1040,16 @@ int convert_rows(nhdfit_ctx* c, Pipe& p) {
     return NHDFIT_OK;
 }
 
+// the sequential kernels' copy, [P][chunks]; stream order is all they need
+int convert_rows_t(nhdfit_ctx* c, Pipe& p) {
+    const uint32_t chunks = (c->n + 63) / 64, tiles = (c->P + kTile - 1) / kTile;
+    const uint32_t groups = (chunks + kRowsTChunks - 1) / kRowsTChunks;
+    HIPCHK(c, c->rows_t.reserve((size_t)chunks * c->P));
+    hipLaunchKernelGGL(k_rows_t, dim3((tiles * groups + 3) / 4), dim3(256), 0, p.stream, p.nm.p, c->rows_t.p, chunks, c->P);
+    HIPCHK(c, hipGetLastError());
+    return NHDFIT_OK;
+}
+
 int flush_pipeline(nhdfit_ctx* c) {
     if (!c->P || !c->want_map || c->n_big_pods >= c->P) return NHDFIT_OK;
     for (Pipe& p : c->pipe)
@@ -1536,7 +1547,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     }
     // pod-major verdict rows of the snapshot + empty taken / first-touch state (again before a fallback pass)
     auto reset_scan_state = [&]() -> int {
-        int rc_ = convert_rows(c, p);
+        int rc_ = convert_rows_t(c, p);
         if (rc_) return rc_;
         HIPCHK(c, hipMemsetAsync(c->taken.p, 0, (size_t)(chunks ? chunks : 1) * sizeof(uint64_t), sm));
         HIPCHK(c, hipMemsetAsync(c->touched.p, 0xFF, (size_t)c->n * sizeof(int32_t), sm));
@@ -1553,7 +1564,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     sa.reqs = c->reqs.p; sa.score = p.score[b].p; sa.P = P; sa.order = c->order.p;
     sa.tabs = p.tabs[b].p; sa.pitch = c->pitch; sa.tile_wcls = c->tile_wcls.p;
     for (int w = 0; w < kWClasses; ++w) sa.L[w] = c->L[w];
-    sa.rows = c->bitmap.p; sa.taken = c->taken.p; sa.nogpu = c->nogpu.p; sa.tile_masks = c->tile_masks.p;
+    sa.rows = c->rows_t.p; sa.taken = c->taken.p; sa.nogpu = c->nogpu.p; sa.tile_masks = c->tile_masks.p;
     sa.caps = c->caps.p; sa.sigs = sig_table(c); sa.fc_dim = c->max_cores + 1; sa.fg_dim = c->max_gpus + 1; sa.ngs = c->ngs;
     sa.mt = map_tables(c);
     sa.undo = c->undo.p; sa.touched = c->touched.p; sa.counters = c->seq_counters.p; sa.keep_undo = 1;

@@ -129,7 +129,7 @@ __device__ __forceinline__ void patch_columns(const SeqArgs& a, uint32_t v, cons
         for (uint32_t qq = 0; qq < 4; ++qq) {
             const uint32_t j = qq * 16 + p;
             if ((lost >> j & 1) && (size_t)t * 64 + j < a.P)
-                atomicAnd(reinterpret_cast<unsigned long long*>(&a.rows[(size_t)(v >> 6) * a.P + (size_t)t * 64 + j]), ~(1ull << (v & 63)));
+                atomicAnd(reinterpret_cast<unsigned long long*>(&NHDFIT_ROW(a, v >> 6, (size_t)t * 64 + j)), ~(1ull << (v & 63)));
         }
     }
 }
@@ -294,10 +294,15 @@ __device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, 
 //     that the count is still D: writers of version D + 1 only start once the count says D + 1, so the read was not torn.
 //   the other wavefronts fetch ahead for the pods with GPUs (first window of the row nobody took).
 #ifndef NHDFIT_SPEC_WAVES
-#define NHDFIT_SPEC_WAVES 9
+#define NHDFIT_SPEC_WAVES 6
 #endif
-constexpr int kDecideWaves = 16, kDecideRing = 32, kSpecWaves = NHDFIT_SPEC_WAVES, kSpecCache = 4, kWorkerBlocks = 12;
-static_assert(kSpecWaves == 6 || kSpecWaves == 9, "wavefront roles of block 0: speculators sit on SIMDs 1-3 (wave & 3 != 0), two or three deep");
+#ifndef NHDFIT_DECIDE_WAVES
+#define NHDFIT_DECIDE_WAVES 8
+#endif
+constexpr int kDecideWaves = NHDFIT_DECIDE_WAVES, kDecideRing = 64, kSpecWaves = NHDFIT_SPEC_WAVES, kSpecCache = 4, kWorkerBlocks = 8;
+static_assert((kSpecWaves == 6 || kSpecWaves == 9) && kDecideWaves >= 4 * kSpecWaves / 3 && kDecideWaves - 1 - kSpecWaves >= 1, "wavefront roles of block 0: speculators sit on SIMDs 1-3 (wave & 3 != 0), two or three deep; at least one fetcher");
+// (eight wavefronts: 256 registers each - with sixteen the speculators' verification and commit spilled 114 VGPRs to scratch memory and
+// every step of the chain paid for it: config 4 677 k -> 800 k decisions/s with a single fetcher, profiles/r04/mode_b_variants.log)
 constexpr uint32_t kSpinLimit = 1u << 22;                      // x ~100 cycles of s_sleep: a fraction of a second, then give up
 constexpr uint32_t kPubPoison = 1u << 31;                      // pub[v]: the node was left in a NIC state without a signature id
 constexpr uint32_t kNicSigs = 64;                              // dictionaries up to this many NIC signatures: the pod's NIC-feasible assignments
@@ -494,20 +499,29 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     //   mode 1: the nodes without GPUs; 2: every node; 3: every node nobody took yet (a pod that requests GPUs);
     //   4: the nodes with GPUs (a GPU-less pod whose pass over the GPU-less nodes found nothing)
     auto scan_window = [&](uint64_t* win, uint32_t pos, uint32_t mode, uint32_t from_chunk, uint32_t from_bit, uint32_t& base_out) -> bool {
-        for (uint32_t base = from_chunk; base < a.chunks; base += 64) {
-            const uint32_t c = base + lane;
-            uint64_t w = 0;
-            if (c < a.chunks) {
-                w = __hip_atomic_load(&a.rows[(size_t)c * a.P + pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (mode == 1) w &= a.nogpu[c];
-                else if (mode == 3) w &= ~s_taken[c];
-                else if (mode == 4) w &= ~a.nogpu[c];
+        constexpr uint32_t kAhead = 4;                                    // windows requested together: a scan that has to go deep pays one round trip per four
+        for (uint32_t base = from_chunk; base < a.chunks; base += 64 * kAhead) {
+            uint64_t w[kAhead];
+#pragma unroll
+            for (uint32_t k = 0; k < kAhead; ++k) {
+                const uint32_t c = base + 64 * k + lane;
+                w[k] = c < a.chunks ? __hip_atomic_load(&NHDFIT_ROW(a, c, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             }
-            if (c == from_chunk) w &= ~0ull << from_bit;
-            if (__ballot(w != 0)) {
-                win[lane] = w;
-                base_out = base;
-                return true;
+#pragma unroll
+            for (uint32_t k = 0; k < kAhead; ++k) {
+                const uint32_t c = base + 64 * k + lane;
+                uint64_t x = w[k];
+                if (c < a.chunks) {
+                    if (mode == 1) x &= a.nogpu[c];
+                    else if (mode == 3) x &= ~s_taken[c];
+                    else if (mode == 4) x &= ~a.nogpu[c];
+                } else x = 0;
+                if (c == from_chunk) x &= ~0ull << from_bit;
+                if (__ballot(x != 0)) {
+                    win[lane] = x;
+                    base_out = base + 64 * k;
+                    return true;
+                }
             }
         }
         return false;
@@ -540,24 +554,63 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     const int spec_id = (wave & 3u) && wave < 4u * (uint32_t)kSpecWaves / 3u ? (int)((wave >> 2) * 3u + (wave & 3u) - 1u) : -1;
 
     if (wave != 0 && spec_id < 0) {
-        // ---- fetchers: pod e (with GPUs) goes to slot e % kDecideRing once the sequencer is past pod e - kDecideRing
+        // ---- fetchers: pod e (with GPUs) goes to slot e % kDecideRing once the sequencer is past pod e - kDecideRing.  A fetcher takes
+        // 64 list entries with one load and then eight pods at a time: their first windows are requested together (one round trip
+        // for eight pods, the next eight requested before these are parked), masked with what is taken by the time each is parked
         const uint32_t first_all = 4u * (uint32_t)kSpecWaves / 3u;        // wavefronts from here on all fetch; below, those with wave & 3 == 0
         const uint32_t fid = wave < first_all ? (wave >> 2) - 1u : first_all / 4u - 1u + (wave - first_all);     // 0 .. kFetchWaves - 1
-        for (uint32_t j = fid; j < q.n_g; j += kFetchWaves) {
-            const uint4 ent = q.ent_g[j];
-            const uint32_t e = ent.x;
-            const uint32_t slot = e % kDecideRing;
-            for (uint32_t spin = 0; e >= wg_load(&s_done) + kDecideRing; ++spin) {
-                if (spin > kSpinLimit || wg_load(&s_abort)) return;
-                __builtin_amdgcn_s_sleep(2);
+        constexpr uint32_t kFetchBatch = 8;
+        struct Batch { uint32_t e[kFetchBatch], pos[kFetchBatch], from[kFetchBatch]; uint64_t w[kFetchBatch]; };
+        for (uint32_t j0 = fid * 64u; j0 < q.n_g; j0 += kFetchWaves * 64u) {
+            const uint32_t cnt = q.n_g - j0 < 64u ? q.n_g - j0 : 64u;
+            uint4 ent = make_uint4(0, 0, kNoNode, 0);
+            if (lane < cnt) ent = q.ent_g[j0 + lane];
+            // entries k0 .. k0 + 7: their first windows requested (one load instruction each, all in flight together)
+            auto issue = [&](uint32_t k0, Batch& t) {
+#pragma unroll
+                for (uint32_t i = 0; i < kFetchBatch; ++i) {
+                    const uint32_t k = k0 + i < cnt ? k0 + i : cnt - 1u;  // (past the end: the last entry again, never parked)
+                    t.e[i] = (uint32_t)__builtin_amdgcn_readlane((int)ent.x, (int)k);
+                    t.pos[i] = (uint32_t)__builtin_amdgcn_readlane((int)ent.y, (int)k);
+                    t.from[i] = (uint32_t)__builtin_amdgcn_readlane((int)ent.z, (int)k);
+                    const uint32_t c = (t.from[i] >> 6) + lane;
+                    t.w[i] = 0;
+                    if (t.from[i] != kNoNode && c < a.chunks) t.w[i] = __hip_atomic_load(&NHDFIT_ROW(a, c, t.pos[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            };
+            // ... parked, each once the sequencer has left its slot; false = the batch was given up
+            auto park = [&](uint32_t k0, const Batch& t) -> bool {
+#pragma unroll
+                for (uint32_t i = 0; i < kFetchBatch; ++i) {
+                    if (k0 + i >= cnt) break;
+                    const uint32_t e = t.e[i], slot = e % kDecideRing;
+                    for (uint32_t spin = 0; e >= wg_load(&s_done) + kDecideRing; ++spin) {
+                        if (spin > kSpinLimit || wg_load(&s_abort)) return false;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    int32_t have = 0;
+                    uint32_t wb = t.from[i] >> 6;
+                    if (t.from[i] != kNoNode) {
+                        const uint32_t c = wb + lane;
+                        uint64_t w = t.w[i] & (c < a.chunks ? ~s_taken[c] : 0ull);
+                        if (lane == 0) w &= ~0ull << (t.from[i] & 63u);
+                        if (__ballot(w != 0)) { s_win[slot][lane] = w; have = 2; }
+                        else if (wb + 64u < a.chunks && scan_window(s_win[slot], t.pos[i], 3u, wb + 64u, 0, wb)) have = 2;
+                    }
+                    if (lane == 0) { s_have[slot] = have; s_pos[slot] = t.pos[i]; s_base[slot] = wb; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) wg_store(&s_ready[slot], e + 1);
+                }
+                return true;
+            };
+            Batch ba, bb;                                                 // one batch is always in flight while the other is parked
+            issue(0, ba);
+            for (uint32_t k0 = 0; k0 < cnt; k0 += 2 * kFetchBatch) {
+                if (k0 + kFetchBatch < cnt) issue(k0 + kFetchBatch, bb);
+                if (!park(k0, ba)) return;
+                if (k0 + 2 * kFetchBatch < cnt) issue(k0 + 2 * kFetchBatch, ba);
+                if (k0 + kFetchBatch < cnt && !park(k0 + kFetchBatch, bb)) return;
             }
-            const uint32_t pos = ent.y;
-            int32_t have = 0;
-            uint32_t wb = 0;
-            if (ent.z != kNoNode && scan_window(s_win[slot], pos, 3u, ent.z >> 6, ent.z & 63u, wb)) have = 2;
-            if (lane == 0) { s_have[slot] = have; s_pos[slot] = pos; s_base[slot] = wb; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) wg_store(&s_ready[slot], e + 1);
         }
         return;
     }
@@ -672,7 +725,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                         if (!got) {
                             // the mirror, once that version is in it; the row's word for the chunk rides along (bits the workers cleared meanwhile)
                             const uint32_t m = dev_load(&q.mat[v]);
-                            const uint64_t fresh = __hip_atomic_load(&a.rows[(size_t)(v >> 6) * a.P + pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const uint64_t fresh = __hip_atomic_load(&NHDFIT_ROW(a, v >> 6, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (m & kPubPoison) { stop = true; break; }   // a NIC state without a signature id (reported by the committer)
                             if (!(fresh >> (v & 63) & 1)) { stale_bit = true; break; }
                             if (m < ver) { __builtin_amdgcn_s_sleep(1); continue; }      // its commit is in flight

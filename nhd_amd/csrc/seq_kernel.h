@@ -16,6 +16,9 @@ __global__ __launch_bounds__(64) void k_tile_masks(const PodHeader* __restrict__
     if (threadIdx.x == 0) { out[2 * blockIdx.x] = need; out[2 * blockIdx.x + 1] = pci; }
 }
 
+// word `c` of the verdict row of the pod staged at position `pos`
+#define NHDFIT_ROW(a, c, pos) ((a).rows[(size_t)(pos) * (a).chunks + (c)])
+
 struct UndoRec { uint32_t node, pad[3]; NodeState st; nhdfit_detail d; };
 
 struct SeqArgs {
@@ -25,7 +28,8 @@ struct SeqArgs {
     const uint32_t* order;           // caller's pod i -> staged (class-sorted) position
     const uint32_t* list; uint32_t n_list;   // optional: the pods to decide (caller's indices, ascending) instead of all P
     const uint8_t* tabs; uint32_t pitch; const uint8_t* tile_wcls; Layout L[kWClasses];
-    uint64_t* rows;                  // [chunks][P] verdict rows of the snapshot; kept current for the pods without GPUs
+    uint64_t* rows;                  // [P][chunks] verdict rows of the snapshot (k_rows_t: a pod's window of 64 chunks is 512 contiguous bytes -
+                                     // with [chunks][P] it was 64 cache lines on 64 pages); kept current for the pods without GPUs
     uint64_t* taken;                 // [chunks] nodes that received a pod of this batch: busy, i.e. gone for every pod with GPUs
     const uint64_t* nogpu;           // [chunks] nodes without a GPU installed
     const uint64_t* tile_masks;      // [tiles][2]: pods that request GPUs / are in PCI mode
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(64 * kSeqPods) void k_seq(SeqArgs a) {
                         uint64_t w = 0;
                         if (c < a.chunks) {
                             // rows / taken: patched with atomics by the other wavefronts, read past the CU's vector cache
-                            w = __hip_atomic_load(&a.rows[(size_t)c * a.P + pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            w = __hip_atomic_load(&NHDFIT_ROW(a, c, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (wants_gpu) w &= ~__hip_atomic_load(&a.taken[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (pref) w &= a.nogpu[c];
                         }
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(64 * kSeqPods) void k_seq(SeqArgs a) {
                         const uint32_t j = q * 16 + p;
                         // already clear for most: no harm; two nodes of one 64-node chunk may hit the same word: atomic
                         if ((lost[u] >> j & 1) && (size_t)tt[u] * 64 + j < a.P)
-                            atomicAnd(reinterpret_cast<unsigned long long*>(&a.rows[(size_t)(vv[u] >> 6) * a.P + (size_t)tt[u] * 64 + j]), ~(1ull << (vv[u] & 63)));
+                            atomicAnd(reinterpret_cast<unsigned long long*>(&NHDFIT_ROW(a, vv[u] >> 6, (size_t)tt[u] * 64 + j)), ~(1ull << (vv[u] & 63)));
                     }
             }
             if (a.prof && tid == 0) { const unsigned long long tq = wall_clock64(); t_c[1] += tq - tick; tick = tq; }

@@ -125,6 +125,34 @@ __global__ __launch_bounds__(256) void k_rows(const uint64_t* __restrict__ nm, u
     if (pod < P) rows[(size_t)c * P + pod] = ((uint64_t)hi << 32) | lo;
 }
 
+// the same matrix for the sequential kernels, [P][chunks]: a pod's row contiguous.  One wavefront per (tile, 16 chunks): sixteen
+// 64 x 64 bit transposes in registers, staged through LDS (17-word rows: lane = pod hits 64 banks), written as 128-byte runs
+constexpr uint32_t kRowsTChunks = 16;
+__global__ __launch_bounds__(256) void k_rows_t(const uint64_t* __restrict__ nm, uint64_t* __restrict__ rows, uint32_t chunks, uint32_t P) {
+    __shared__ uint64_t s_t[4][64][kRowsTChunks + 1];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t groups = (chunks + kRowsTChunks - 1) / kRowsTChunks;
+    const uint32_t tiles = (P + kTile - 1) / kTile;
+    const uint32_t w = blockIdx.x * 4 + wv;
+    if (w >= tiles * groups) return;
+    const uint32_t tile = w / groups, c0 = (w % groups) * kRowsTChunks;
+#pragma unroll 4
+    for (uint32_t k = 0; k < kRowsTChunks; ++k) {
+        const uint32_t c = c0 + k;
+        const uint64_t v = c < chunks ? nm[((size_t)tile * chunks + c) * 64 + lane] : 0ull;
+        uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+        transpose64(lo, hi);
+        s_t[wv][lane][k] = ((uint64_t)hi << 32) | lo;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t ck = lane & (kRowsTChunks - 1);
+    for (uint32_t r = 0; r < 64; r += 64 / kRowsTChunks) {
+        const uint32_t j = r + lane / kRowsTChunks, pod = tile * kTile + j;
+        if (pod < P && c0 + ck < chunks) rows[(size_t)pod * chunks + c0 + ck] = s_t[wv][j][ck];
+    }
+}
+
 template <int BLOCK, bool SPILL>      // SPILL: some tiles stage only a prefix of their hot section (refresh_layouts)
 __device__ __forceinline__ void step_body(const StepArgs& a, const double busy_from, uint8_t* lds) {
     uint32_t blk = blockIdx.x;
