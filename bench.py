@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (HBM traffic of the step kernel)")
     ap.add_argument("--no-extras", action="store_true", help="skip the mode-B and end-to-end legs after the timed region")
+    ap.add_argument("--no-settle", action="store_true", help="time the W + K steps as the first GPU work of the process only (no clock settling in front of the headline region)")
     args = ap.parse_args()
 
     # stdout carries exactly one line: the result.  Native libraries are chatty on it (gloo's "[Gloo] Rank 0 is
@@ -112,18 +113,33 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        eng.enqueue(now)
-    eng.sync()
-    eng.reset_stats()
-    barrier()
-    eng.sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.enqueue(now)
-    eng.sync()
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed_region():
+        """W untimed warm-up steps, then exactly K steps between barrier + sync on both sides; seconds for the K steps."""
+        for _ in range(args.warmup):
+            eng.enqueue(now)
+        eng.sync()
+        eng.reset_stats()
+        barrier()
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.enqueue(now)
+        eng.sync()
+        barrier()
+        return time.perf_counter() - t0
+
+    # The region is run twice and both are reported.  `cold_start`: as the process's very first GPU work - with the driver's
+    # `--steps 20 --warmup 5` that is 25 steps (0.5 ms) on a device whose clocks have not ramped up yet (the same 20 steps
+    # took 21.4 us each in BENCH_r03 against 16.0 us a few thousand steps later in the same process; VERDICT r03 weak #4).
+    # `value`: the same W + K steps after the device has been kept busy with this very step for >= 30 ms (`settle`) - the
+    # state a scheduler that runs all day is in.  Nothing is skipped or cached in either: every step is digest + fit +
+    # mapping with the verdict matrix written.
+    cold = None
+    settled = 0
+    if not os.environ.get("NHD_BENCH_INNER") and not args.no_settle:
+        cold = timed_region()
+        settled = settle(eng, now, fixed_steps=2500 if world > 1 else 0)
+    dt = timed_region()
     if dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64)
@@ -142,7 +158,7 @@ def main():
         eng.sync()
         barrier()
         rep.append((time.perf_counter() - r0) * 1e3 / args.steps)
-    steady = steady_state(eng, now, barrier, args.pods, n_total) if not os.environ.get("NHD_BENCH_INNER") else None
+    steady = steady_state(eng, now, barrier, args.pods, n_total, fixed_steps=2500 if world > 1 else 0) if not os.environ.get("NHD_BENCH_INNER") else None
     score, _, maps = eng.fetch(want_bitmap=False, want_map=True)
     evals = float(args.pods) * n_total * args.steps
     ms_per_step = dt * 1e3 / args.steps
@@ -183,6 +199,13 @@ def main():
         "repeats": None if not rep else {"n": len(rep), "ms_per_step_min": min(rep), "ms_per_step_median": sorted(rep)[len(rep) // 2],
                                          "ms_per_step_max": max(rep), "note": "the timed region repeated after the headline measurement (rank-local clock)"},
         "steady_state": steady,
+        "protocol": {"order": "cold_start region (W warm-up + K timed steps as the first GPU work), settle, headline region (the same W + K steps)" if cold is not None
+                              else "W warm-up + K timed steps as the first GPU work of the process",
+                     "settle_steps": settled,
+                     "note": "settle = the benchmarked step itself enqueued for >= 30 ms so that the device clocks are where a long-running scheduler "
+                             "keeps them; both regions run every role of the step and write the verdict matrix"},
+        "cold_start": None if cold is None else {"ms_per_step": cold * 1e3 / args.steps, "evals_per_s": evals / cold, "steps": args.steps, "warmup": args.warmup,
+                                                  "note": "rank-local clock; the first %d steps this process ran on the GPU" % (args.steps + args.warmup)},
         "placed_pods": int(np.count_nonzero(score)),
         "config": {"workload": f"BASELINE config {args.config} cluster: {args.nodes_per_gpu} nodes/GPU x {args.pods} pods, "
                                f"CPU+GPU+NIC predicate, PCI locality for ~half the pods, node axis sharded over {world} GPU(s)",
@@ -216,18 +239,31 @@ def main():
         dist.destroy_process_group()
 
 
-def steady_state(eng, now, barrier, P, n_total, steps=1000, settle_ms=30.0, repeats=5):
+def settle(eng, now, settle_ms=30.0, min_steps=1000, fixed_steps=0):
+    """Keep the device busy with the benchmarked step for at least `settle_ms` (and `min_steps` steps); returns the steps run.
+    Sharded runs pass `fixed_steps`: every step carries an all-reduce, so all ranks must enqueue the same number of them - a
+    wall-clock loop would let the ranks disagree and the collective hang."""
+    done = 0
+    if fixed_steps:
+        for _ in range(fixed_steps):
+            eng.enqueue(now)
+        done = fixed_steps
+    else:
+        t_end = time.perf_counter() + settle_ms * 1e-3
+        while time.perf_counter() < t_end or done < min_steps:
+            for _ in range(100):
+                eng.enqueue(now)
+            done += 100
+    eng.sync()
+    return done
+
+
+def steady_state(eng, now, barrier, P, n_total, steps=1000, settle_ms=30.0, repeats=5, fixed_steps=0):
     """The same step at steady clocks, whatever --steps / --warmup the caller chose: the first ~1 000 steps after start-up run
     ~25 % slower (clock ramp), so a `--steps 20 --warmup 5` run times cold steps.  Here: enqueue for at
     least `settle_ms` of wall time, then time `steps` steps `repeats` times (same barriers as the headline region).  Never the
     headline `value` - that stays what --steps / --warmup define."""
-    t_end = time.perf_counter() + settle_ms * 1e-3
-    settled = 0
-    while time.perf_counter() < t_end or settled < 1000:
-        for _ in range(100):
-            eng.enqueue(now)
-        settled += 100
-    eng.sync()
+    settled = settle(eng, now, settle_ms, 1000, fixed_steps)
     ts = []
     for _ in range(repeats):
         barrier()

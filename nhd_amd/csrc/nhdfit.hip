@@ -190,6 +190,12 @@ struct nhdfit_ctx {
     uint32_t hp_rows = 2;
     uint32_t n_big_pods = 0;      // staged pods with more than 3 proc groups
     uint32_t max_wcls = 0;        // widest tile class of the staged batch
+    // pair form of the fit role's sweep (fit_core.h "pair rows"): per row width W = 2 / 4 the largest CPU demand among the staged
+    // tiles of that width, and what refresh_layouts makes of it - table dimension D (0: off) and XX dimension (0: off)
+    uint32_t max_demand[2] = {0, 0};
+    uint32_t pair_D[2] = {0, 0}, pair_xx[2] = {0, 0};
+    bool pair_rows = !(tune_env("NHDFIT_PAIR") && atoi(tune_env("NHDFIT_PAIR")) == 0);   // tuning aid: NHDFIT_PAIR=0 keeps the six-fetch sweep; 1 = C only
+    bool pair_xx_ok = !(tune_env("NHDFIT_PAIR") && atoi(tune_env("NHDFIT_PAIR")) == 1);
 
     // requests / results
     DevBuf<nhdfit_req> reqs; uint32_t P = 0;
@@ -617,6 +623,24 @@ int refresh_layouts(nhdfit_ctx* c) {
         c->hot_staged[w] = staged;
         if (w <= c->max_wcls) lds = std::max(lds, staged < L.hot_bytes ? staged + hp_bytes : L.hot_bytes);
     }
+    // Pair tables of the narrow tiles (fit_core.h "pair rows"), derived by every fit block behind its winner scratch: taken
+    // while a block's LDS stays within a third of the CU's (three 512-thread blocks per CU is what the registers allow, and
+    // the launch's dynamic LDS is one size for all of its blocks).  C first, XX if it still fits.
+    c->pair_D[0] = c->pair_D[1] = c->pair_xx[0] = c->pair_xx[1] = 0;
+    if (c->pair_rows && !spill) {
+        const uint32_t budget = (uint32_t)(kLdsPerCu / 3) & ~1023u;
+        for (uint32_t w = 0; w < 2 && w <= c->max_wcls; ++w) {
+            const Layout& L = c->L[w];
+            const uint32_t D = pair_dim(c->max_demand[w], L.fc_dim);
+            const uint32_t base = (uint32_t)lds_slice(L.hot_bytes) + scratch, c_bytes = 2 * D * D * L.row;
+            if (base + c_bytes > budget) continue;
+            c->pair_D[w] = D;
+            uint32_t need = base + c_bytes;
+            const uint32_t xx_bytes = c->x_cap * c->x_cap * L.row;
+            if (c->pair_xx_ok && c->x_cap <= kPairMaxXCap && need + xx_bytes <= budget) { c->pair_xx[w] = c->x_cap; need += xx_bytes; }
+            lds = std::max(lds, need - scratch);
+        }
+    }
     c->pitch = pitch;
     c->lds_bytes = lds;
     c->x_spill = spill;
@@ -690,6 +714,11 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
             if (w > c->h_tile_wcls[i / kTile]) c->h_tile_wcls[i / kTile] = w;
             if (w > c->max_wcls) c->max_wcls = w;
         }
+    c->max_demand[0] = c->max_demand[1] = 0;
+    for (uint32_t i = 0; i < P; ++i) {
+        const uint8_t w = c->h_tile_wcls[i / kTile];
+        if (w < 2 && req_valid(sorted[i])) c->max_demand[w] = std::max(c->max_demand[w], req_max_demand(sorted[i]));
+    }
     HIPCHK(c, c->tile_wcls.reserve(tiles));
     HIPCHK(c, c->pin_wcls.reserve(tiles));
     memcpy(c->pin_wcls.p, c->h_tile_wcls.data(), tiles);
@@ -841,7 +870,12 @@ void fill_digest_args(nhdfit_ctx* c, Pipe& p, int b, uint32_t wc_parts, uint32_t
     d.sig_parts = sig_parts;
     d.count = p.dig_count.p;
 }
-void fill_fit_args(nhdfit_ctx* c, Pipe& p, int bf, double now, FitArgs& f) {
+void fill_fit_args(nhdfit_ctx* c, Pipe& p, int bf, double now, FitArgs& f, bool pair = false) {
+    for (int w = 0; w < 2; ++w) {
+        f.pair_D[w] = pair ? c->pair_D[w] : 0u; f.pair_xx[w] = pair ? c->pair_xx[w] : 0u;
+        f.hot_wc1[w] = c->L[w].hot_wc1; f.hot_x[w] = c->L[w].hot_x;
+    }
+    f.fc_dim = c->max_cores + 1;
     for (int w = 0; w < kWClasses; ++w) {
         f.rec[w] = c->rec[w].p; f.off_hot[w] = c->L[w].off_hot; f.hot_bytes[w] = c->L[w].hot_bytes; f.hot_hp[w] = c->L[w].hot_hp; f.hot_staged[w] = c->hot_staged[w];
     }
@@ -927,7 +961,7 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
     if (with_fit) {
         bf = (int)(p.n_fit % kBufs);
         if (c->want_bitmap) HIPCHK(c, p.nm.reserve((size_t)tiles * chunks * 64));
-        fill_fit_args(c, p, bf, now, a.fit);
+        fill_fit_args(c, p, bf, now, a.fit, !c->x_spill && !c->role_kernels && !c->split);   // (pair tables: the fused launch only)
         nb_fit = c->n_items;
     }
     a.nb_fit = nb_fit;

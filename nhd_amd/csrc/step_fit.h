@@ -29,6 +29,11 @@ struct FitArgs {
     uint64_t* nm;               // optional node-major feasibility words [tiles][chunks*64]: bit j = pod 64*tile+j
     unsigned long long* score;  // [P], pre-zeroed
     const FitItem* items;
+    // pair form of the sweep (fit_core.h "pair rows"), per row width: pair_D = 0: off; else C[2][D][D] is derived in LDS behind
+    // the winner scratch, and XX[pair_xx][pair_xx] behind it when pair_xx != 0.  Set for W = 2 and 4 only.
+    uint32_t pair_D[2], pair_xx[2];
+    uint32_t hot_wc1[2], hot_x[2];    // where the second socket's CPU records and the X rows start in the hot section
+    uint32_t fc_dim;
     uint32_t dbg_skip;          // tuning aid (NHDFIT_FIT_SKIP): 1 no table sweep, 2 no winner tracking, 4 constant record, 8 no predicate rows
 };
 
@@ -141,6 +146,32 @@ __device__ __forceinline__ uint64_t sweep_assignments_spill(const uint8_t* hot, 
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Pair form (fit_core.h "pair rows"): one C row instead of four CPU rows, and with XX one row instead of two class rows.
+template <int W>
+__device__ __forceinline__ uint64_t sweep_pair_c(const uint8_t* lds, uint32_t a_c, uint32_t a_x0, uint32_t a_x1) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int q = 0; q < W / 2; ++q) {
+        const uint32_t o = q * 16;
+        const uint4 cp = lds16(lds, a_c + o), x0 = lds16(lds, a_x0 + o), x1 = lds16(lds, a_x1 + o);
+        lo |= __builtin_amdgcn_bitop3_b32(cp.x, x0.x, x1.x, 0x80) | __builtin_amdgcn_bitop3_b32(cp.z, x0.z, x1.z, 0x80);
+        hi |= __builtin_amdgcn_bitop3_b32(cp.y, x0.y, x1.y, 0x80) | __builtin_amdgcn_bitop3_b32(cp.w, x0.w, x1.w, 0x80);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+template <int W>
+__device__ __forceinline__ uint64_t sweep_pair_cx(const uint8_t* lds, uint32_t a_c, uint32_t a_xx) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int q = 0; q < W / 2; ++q) {
+        const uint32_t o = q * 16;
+        const uint4 cp = lds16(lds, a_c + o), xx = lds16(lds, a_xx + o);
+        lo |= __builtin_amdgcn_bitop3_b32(cp.z, xx.z, cp.x & xx.x, 0xEA);      // (a & b) | c
+        hi |= __builtin_amdgcn_bitop3_b32(cp.w, xx.w, cp.y & xx.y, 0xEA);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // The P x N pass.  Block = chunks [c_begin, c_end) of one pod tile: the hot section of the tile's table image is
 // staged in LDS, every wavefront sweeps a contiguous run of 64-node chunks (lane = node: one 16-byte record and
 // the busy time per node), writes the node-major verdict word and tracks the tile's first-fit winners.
@@ -150,8 +181,10 @@ __device__ __forceinline__ uint64_t sweep_assignments_spill(const uint8_t* hot, 
 // a GPU-less node, SelectNode's preference) are two wave-uniform 64-bit masks; a chunk whose verdict words do
 // not touch them - all but the first one or two of a run - costs four instructions.  Only a chunk with news is
 // transposed (lane = pod) and scored.
-template <int BLOCK, int W, bool SPILL>
+// PAIR: 0 = six row fetches per pair of assignments; 1 = C tabulated in LDS (three); 2 = C and XX (two).
+template <int BLOCK, int W, bool SPILL, int PAIR = 0>
 __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_from, const FitItem it, uint8_t* lds) {
+    static_assert(PAIR == 0 || (!SPILL && W <= 4), "pair tables: narrow tiles, whole hot section staged");
     constexpr int NW = BLOCK / 64;
     const uint32_t dbg = kTuning ? a.dbg_skip : 0u;
     // the argument block may live behind a pointer (k_step_p): what the chunk loop uses is read once, here
@@ -193,6 +226,44 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
         }
     }
     __syncthreads();
+    // pair tables behind the winner scratch: C[2][D][D], then XX[xcap][xcap]; rows of W * 8 bytes
+    const uint32_t pD = PAIR ? a.pair_D[WC & 1] : 0u, pXX = PAIR == 2 ? a.pair_xx[WC & 1] : 0u;
+    const uint32_t off_c = (uint32_t)lds_slice(hot_bytes) + NW * 64 * (uint32_t)sizeof(unsigned long long), off_xx = off_c + 2 * pD * pD * W * 8;
+    if constexpr (PAIR != 0) {
+        const uint32_t hot_wc1 = a.hot_wc1[WC & 1], fc_dim = a.fc_dim;
+        constexpr uint32_t kWcStride = 2 * W * 8 + 16;                    // wc_stride_of(W)
+        for (uint32_t r = threadIdx.x; r < 2 * pD * pD; r += BLOCK) {
+            const uint32_t smt = r >= pD * pD ? 1u : 0u, e = r - smt * pD * pD, c0 = e / pD, c1 = e - c0 * pD;
+            const uint32_t a_w0 = (smt * fc_dim + c0) * kWcStride, a_w1 = hot_wc1 + (smt * fc_dim + c1) * kWcStride;
+#pragma unroll
+            for (int q = 0; q < W / 2; ++q) {
+                const uint32_t o = q * 16;
+                const uint4 w0 = lds16(hot, a_w0 + o), w0m = lds16(hot, a_w0 + W * 8 + o);
+                const uint4 w1 = lds16(hot, a_w1 + o), w1m = lds16(hot, a_w1 + W * 8 + o);
+                uint4 cp;
+                cp.x = __builtin_amdgcn_bitop3_b32(w0.x, w1m.x, w0m.x & w1.x, 0xEA);
+                cp.y = __builtin_amdgcn_bitop3_b32(w0.y, w1m.y, w0m.y & w1.y, 0xEA);
+                cp.z = __builtin_amdgcn_bitop3_b32(w0.z, w1m.z, w0m.z & w1.z, 0xEA);
+                cp.w = __builtin_amdgcn_bitop3_b32(w0.w, w1m.w, w0m.w & w1.w, 0xEA);
+                *reinterpret_cast<uint4*>(__builtin_assume_aligned(lds + off_c + r * (W * 8) + o, 16)) = cp;
+            }
+        }
+        if constexpr (PAIR == 2) {
+            const uint32_t hot_x = a.hot_x[WC & 1];
+            constexpr uint32_t kXStride = W == 2 ? 16u : W * 8 + 16;        // x_stride_of(W)
+            for (uint32_t r = threadIdx.x; r < pXX * pXX; r += BLOCK) {
+                const uint32_t k0 = r / pXX, k1 = r - k0 * pXX;
+#pragma unroll
+                for (int q = 0; q < W / 2; ++q) {
+                    const uint32_t o = q * 16;
+                    const uint4 x0 = lds16(hot, hot_x + k0 * kXStride + o), x1 = lds16(hot, hot_x + k1 * kXStride + o);
+                    *reinterpret_cast<uint4*>(__builtin_assume_aligned(lds + off_xx + r * (W * 8) + o, 16)) =
+                        make_uint4(x0.x & x1.x, x0.y & x1.y, x0.z & x1.z, x0.w & x1.w);
+                }
+            }
+        }
+        __syncthreads();
+    }
 
     // lane-as-pod view of the tile's 64 request headers -> class masks of the tile (scalar registers)
     const bool my_pod_live = pod0 + lane < a.P;
@@ -225,8 +296,14 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
         uint64_t okm;
         if (SPILL && spill && __ballot(a_x0 + W * 8 > staged || a_x1 + W * 8 > staged))
             okm = sweep_assignments_spill<W>(hot, hot_global, staged, a_w0, a_w1, a_x0, a_x1);
-        else
+        else if constexpr (PAIR == 0)
             okm = (dbg & 1) ? ((uint64_t)rv.y << 32 | rv.x) : sweep_assignments<W>(hot, a_w0, a_w1, a_x0, a_x1);
+        else {
+            const uint32_t cw = rv.w >> 16, c0 = cw & 127u, c1 = (cw >> 7) & 127u;
+            const uint32_t a_c = off_c + (((cw >> 14) * pD + (c0 < pD ? c0 : pD - 1)) * pD + (c1 < pD ? c1 : pD - 1)) * (W * 8);
+            if constexpr (PAIR == 1) okm = sweep_pair_c<W>(lds, a_c, a_x0, a_x1);
+            else okm = sweep_pair_cx<W>(lds, a_c, off_xx + (((rv.w >> 4) & 63u) * pXX + ((rv.w >> 10) & 63u)) * (W * 8));
+        }
         const uint2 gx = (dbg & 8) ? make_uint2(rv.z, rv.w) : lds8(hot, a_gx), hpw = (dbg & 8) ? make_uint2(~0u, ~0u) : lds8(hot, a_hp);
         const bool busy = bt >= busy_from;                                  // Node.IsBusy, nhd/Node.py:847-850
         uint32_t wlo = (uint32_t)okm & gx.x & hpw.x, whi = (uint32_t)(okm >> 32) & gx.y & hpw.y;
@@ -288,6 +365,18 @@ __device__ __forceinline__ void role_fit(const FitArgs& a, const double busy_fro
     it.wcls = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.wcls);
     it.c_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_begin);
     it.c_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_end);
+    if constexpr (!SPILL) {                          // narrow tiles whose pair tables fit the launch's LDS (refresh_layouts)
+        if (it.wcls <= 1 && a.pair_D[it.wcls]) {
+            if (it.wcls == 0) {
+                if (a.pair_xx[0]) role_fit_w<BLOCK, 2, false, 2>(a, busy_from, it, lds);
+                else role_fit_w<BLOCK, 2, false, 1>(a, busy_from, it, lds);
+            } else {
+                if (a.pair_xx[1]) role_fit_w<BLOCK, 4, false, 2>(a, busy_from, it, lds);
+                else role_fit_w<BLOCK, 4, false, 1>(a, busy_from, it, lds);
+            }
+            return;
+        }
+    }
     switch (it.wcls) {
         case 0: role_fit_w<BLOCK, 2, SPILL>(a, busy_from, it, lds); break;
         case 1: role_fit_w<BLOCK, 4, SPILL>(a, busy_from, it, lds); break;

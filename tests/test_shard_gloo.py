@@ -67,7 +67,7 @@ def test_two_rank_sharding_equals_single_shard(tmp_path, cfg, n, P):
     assert np.count_nonzero(want_score) > 0
 
 
-def _worker_mode_b(rank, world, port, cfg, n, P, out_dir):
+def _worker_mode_b(rank, world, port, cfg, n, P, out_dir, chunk=512):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     spec, tops, groups = _problem(cfg, n, P)
@@ -83,7 +83,7 @@ def _worker_mode_b(rank, world, port, cfg, n, P, out_dir):
     bits = np.zeros(((hi - lo + 63) // 64) * 64, np.uint8)
     bits[:hi - lo] = (sub.n_gpus == 0)
     nogpu = np.packbits(bits, bitorder="little").view(np.uint64).copy()
-    node, maps, places, status = shard.schedule_batch_sharded(eng, reqs, spec.clock_now, pk, nogpu, dist, apply=True)
+    node, maps, places, status = shard.schedule_batch_sharded(eng, reqs, spec.clock_now, pk, nogpu, dist, apply=True, chunk=chunk)
     np.save(os.path.join(out_dir, f"node{rank}.npy"), node)
     np.save(os.path.join(out_dir, f"maps{rank}.npy"), maps.view(np.int8))
     np.save(os.path.join(out_dir, f"places{rank}.npy"), places.view(np.uint8))
@@ -91,13 +91,15 @@ def _worker_mode_b(rank, world, port, cfg, n, P, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cfg,n,P,world", [(4, 640, 200, 2), (5, 900, 260, 3), (2, 256, 120, 2)])
-def test_mode_b_one_process_per_shard_equals_the_scheduler_loop(tmp_path, cfg, n, P, world):
+@pytest.mark.parametrize("cfg,n,P,world,chunk", [(4, 640, 200, 2, 512), (5, 900, 260, 3, 512), (2, 256, 120, 2, 512),
+                                                  (4, 640, 200, 2, 48), (5, 900, 260, 3, 37), (2, 384, 120, 3, 16)])
+def test_mode_b_one_process_per_shard_equals_the_scheduler_loop(tmp_path, cfg, n, P, world, chunk):
     """nhd_amd.sharding.schedule_batch_sharded under gloo (host twin per shard): every rank ends up with the decisions,
-    mappings and physical ids the oracle's one-by-one loop over the WHOLE cluster produces."""
+    mappings and physical ids the oracle's one-by-one loop over the WHOLE cluster produces - with the batch in one slice and
+    pipelined down the ranks in several (fixed-size tensors rank to rank, one all-reduce of the results; no pickles)."""
     from oracle import nhd_oracle as O
     port = _free_port()
-    mp.spawn(_worker_mode_b, args=(world, port, cfg, n, P, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_mode_b, args=(world, port, cfg, n, P, str(tmp_path), chunk), nprocs=world, join=True)
     spec, tops, groups = _problem(cfg, n, P)
     nl = spec.build_nodes()
     names = list(nl)
