@@ -234,6 +234,7 @@ struct nhdfit_ctx {
     // its results into, the launch's counters, the sequence number of the last call, and what the device's candidate mask holds
     FindHost* find_host = nullptr;
     DevBuf<uint32_t> find_sync;
+    DevBuf<unsigned long long> find_red;   // sharded single-launch find: the tile's scores on their way through the all-reduce
     uint32_t find_seq = 0;
     std::vector<uint64_t> cand_shadow;   // copy of the mask a small find last uploaded to `cand` (empty: unknown)
     bool fast_find = tune_env("NHDFIT_NO_FAST_FIND") == nullptr;   // tuning aid: every find through the staged five-launch path
@@ -408,7 +409,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->origin.release(); c->deltas.release(); c->delta_run.release(); c->delta_status.release();
     c->wide.release(); c->wide_scratch.release(); c->wide_flags.release(); c->wide_place.release();
     if (c->find_host) (void)hipHostFree(c->find_host);
-    c->find_host = nullptr; c->find_sync.release();
+    c->find_host = nullptr; c->find_sync.release(); c->find_red.release();
     c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release();
     c->reqs.release(); c->bitmap.release(); c->rows_t.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
@@ -1086,11 +1087,33 @@ int convert_rows_t(nhdfit_ctx* c, Pipe& p) {
 
 int flush_pipeline(nhdfit_ctx* c) {
     if (!c->P || !c->want_map || c->n_big_pods >= c->P) return NHDFIT_OK;
-    for (Pipe& p : c->pipe)
-        while (p.n_finished < p.n_fit) {
-            int rc = launch_step(c, p, false, false, 0.0, true);
-            if (rc) return rc;
+    static const bool role_drain = tune_env("NHDFIT_ROLE_DRAIN") != nullptr;   // tuning aid: drain with role launches, as the steps ran
+    const uint32_t tiles = (c->P + kTile - 1) / kTile;
+    for (Pipe& p : c->pipe) {
+        if (role_drain || c->role_kernels || c->split) {
+            while (p.n_finished < p.n_fit) {
+                int rc = launch_step(c, p, false, false, 0.0, true);
+                if (rc) return rc;
+            }
+            continue;
         }
+        // the steps whose mapping phases have not all run: mapped from their scores in one launch (k_map_tiles, step_map.h)
+        while (p.n_finished < p.n_fit) {
+            DrainArgs a;
+            memset(&a, 0, sizeof a);
+            a.tiles = tiles;
+            a.h = make_shape_args(c, p, 0);
+            while (a.nsteps < (uint32_t)kDrainSteps && p.n_finished + a.nsteps < p.n_fit) {
+                const int b = (int)((p.n_finished + a.nsteps) % kBufs);
+                if (c->comm) HIPCHK(c, hipStreamWaitEvent(p.stream, p.ev_red[b], 0));      // the step's scores are final behind its all-reduce
+                a.m[a.nsteps++] = make_map_args(c, p, b);
+            }
+            hipLaunchKernelGGL(k_map_tiles, dim3(a.nsteps * tiles), dim3(256), map_lds_bytes<256>(), p.stream, a);
+            HIPCHK(c, hipGetLastError());
+            p.n_finished += a.nsteps;
+        }
+        p.n_shaped = p.n_chosen = p.n_finished;
+    }
     return NHDFIT_OK;
 }
 
@@ -1198,7 +1221,7 @@ namespace {
 // sequence word the launch stores last.  Returns 1 when the call is not eligible (or the launch gave up): the caller then
 // takes the staged path, which also words the errors; 0 on success; < 0 on a HIP error.
 int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand, uint64_t* score_out, nhdfit_mapping* map_out) {
-    if (!c->fast_find || !reqs || !P || P > (uint32_t)kTile || c->comm || !c->nsig || !c->n || !c->find_host || c->n_wide) return 1;   // (wide nodes: the staged path carries the general pass)
+    if (!c->fast_find || !reqs || !P || P > (uint32_t)kTile || !c->nsig || !c->n || !c->find_host || c->n_wide) return 1;   // (wide nodes: the staged path carries the general pass)
     const auto t0 = std::chrono::steady_clock::now();
     if (map_out && !c->want_map) return 1;
     int32_t hp_max = 0;
@@ -1327,6 +1350,23 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
                 std::chrono::duration<double, std::micro>(t_launch - t0).count());
         for (int k = 0; k < 5; ++k)
             if (t[2 * k + 1]) fprintf(stderr, "[nhdfit]   %-6s: +%.2f us .. +%.2f us\n", names[k], (t[2 * k] - first) * 0.01, (t[2 * k + 1] - first) * 0.01);
+    }
+    if (c->comm) {
+        // sharded: every rank ran the launch on its shard and mapped its own winner; one all-reduce(max) of the packed scores
+        // (<= 64 words) picks the cluster's winner, and a rank that does not own it drops its mapping - exactly what the
+        // staged path returns (its mapping roles skip winners outside the shard).  All on the reduce stream: the launch is
+        // over (the host saw its flag), and the communicator's collectives stay on one stream.
+        HIPCHK(c, c->find_red.reserve(kTile));
+        HIPCHK(c, c->pin_score.reserve(kTile));
+        HIPCHK(c, hipMemcpyAsync(c->find_red.p, h->score, (size_t)P * 8, hipMemcpyHostToDevice, c->s_red));
+        ncclResult_t r = g_rccl.AllReduce(c->find_red.p, c->find_red.p, P, ncclUint64, ncclMax, c->comm, c->s_red);
+        if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+        HIPCHK(c, hipMemcpyAsync(c->pin_score.p, c->find_red.p, (size_t)P * 8, hipMemcpyDeviceToHost, c->s_red));
+        HIPCHK(c, hipStreamSynchronize(c->s_red));
+        for (uint32_t i = 0; i < P; ++i) {
+            if (c->pin_score.p[i] != h->score[i]) memset(&h->maps[i], 0, sizeof(nhdfit_mapping));
+            h->score[i] = c->pin_score.p[i];
+        }
     }
     if (score_out) memcpy(score_out, h->score, (size_t)P * 8);
     if (map_out) memcpy(map_out, h->maps, (size_t)P * sizeof(nhdfit_mapping));

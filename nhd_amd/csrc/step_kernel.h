@@ -424,7 +424,9 @@ __global__ __launch_bounds__(BLOCK) void k_find1(Find1Args a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                    // every block's score
     if (a.want_map) {
         const unsigned long long t2 = a.role_clock ? (unsigned long long)wall_clock64() : 0ull;
-        map_one_tile<BLOCK, true>(a.m, a.h, 0, lds_map, &t);              // (stores the mapping into the host block)
+        MapArgs m = a.m;
+        m.reqs = s_req;                                                   // the request is in this block's LDS already: no second read of the host block
+        map_one_tile<BLOCK, true>(m, a.h, 0, lds_map, &t);                // (stores the mapping into the host block)
         stamp(a.role_clock, 2, t2);
     }
     if (tid == 0) a.host->score[0] = __hip_atomic_load(a.m.score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

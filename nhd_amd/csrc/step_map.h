@@ -297,17 +297,20 @@ __device__ __forceinline__ void role_finish(const MapArgs& a, const ShapeArgs& h
 // pods of that shape with a lane shuffle - nothing goes through memory between the phases, the winners are staged once.
 // `wcls`: the tile's row width class (the step roles read it from tile_wcls).
 // LONE: the tile is one pod and there is no table image - the NIC-feasible assignments come from the pod's own masks (`lone`).
+// `tile`: which tile of the staged batch (k_find: its only one; k_map_tiles: any).
 template <int THREADS, bool LONE = false>
-__device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& h, uint32_t wcls, uint8_t* lds, const LoneMasks* lone = nullptr) {
+__device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& h, uint32_t wcls, uint8_t* lds, const LoneMasks* lone = nullptr,
+                                             uint32_t tile = 0) {
     static_assert(THREADS / 4 == kTile, "the pods of the tile are one wavefront");
-    const MapStage st = stage_winners<THREADS>(a, 0, lds);
+    const uint32_t pod0 = tile * kTile;
+    const MapStage st = stage_winners<THREADS>(a, pod0, lds);
     const uint32_t j = threadIdx.x;
     if (j < (uint32_t)kTile) {
         const uint32_t lane = j;
         nhdfit_mapping& m = st.map[j];
         memset(&m, 0, sizeof(m));
         const nhdfit_req& rq = st.req[j].r;
-        const bool live = j < a.P && rq.n_groups <= 3 && st.w[j].node >= 0;
+        const bool live = pod0 + j < a.P && rq.n_groups <= 3 && st.w[j].node >= 0;
         int32_t slot = -1;
         unsigned long long key = 0;
         if (live) {                                                       // (1) the pod's shape
@@ -318,7 +321,7 @@ __device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& 
             q3.sig_pci[0] = st.w[j].sig_pci[0]; q3.sig_pci[1] = st.w[j].sig_pci[1];
             uint32_t bits;
             if constexpr (LONE) bits = lone_nic_bits(*lone, rq.map_type == NHDFIT_MAP_PCI, q3);
-            else bits = nic_assignment_bits(a.tabs, a.L[wcls], lane, rq.map_type == NHDFIT_MAP_PCI, q3);
+            else bits = nic_assignment_bits(a.tabs + (size_t)tile * a.pitch, a.L[wcls], lane, rq.map_type == NHDFIT_MAP_PCI, q3);
             const uint32_t codes = nic_codes_from_table_bits(bits, (int)rq.n_groups, w.U);
             uint32_t sg, sc;
             candidate_masks(rq, w, sg, sc);
@@ -374,10 +377,28 @@ __device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& 
         }
     }
     __syncthreads();
-    const uint32_t livep = a.P < (uint32_t)kTile ? a.P : (uint32_t)kTile;
+    const uint32_t livep = pod0 < a.P ? (a.P - pod0 < (uint32_t)kTile ? a.P - pod0 : (uint32_t)kTile) : 0u;
     constexpr uint32_t kWords = sizeof(nhdfit_mapping) / 4;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(st.map);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(a.out);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(a.out + pod0);
     for (uint32_t c = threadIdx.x; c < livep * kWords; c += THREADS)
         if (st.req[c / kWords].r.n_groups <= 3) dst[c] = src[c];
+}
+
+// Draining the pipeline (sync / fetch behind the last step): the steps whose mapping phases have not all run are mapped from
+// their scores in ONE launch, one block per (step, tile) with the three phases back to back in the block (map_one_tile) -
+// instead of up to three more role launches in a row, each a latency chain of its own behind a launch gap (~70 us -> ~30
+// for a drain; it is what a short run of steps pays at its end).  The phases a step had already been through are simply
+// redone: they are pure functions of the step's scores, the mirror and the staged requests.
+constexpr int kDrainSteps = 3;
+struct DrainArgs {
+    uint32_t nsteps, tiles;
+    MapArgs m[kDrainSteps];
+    ShapeArgs h;                      // its static tables only (asc, choose_tab, st); the per-step shape buffers are not used
+};
+__global__ __launch_bounds__(256) void k_map_tiles(DrainArgs a) {
+    extern __shared__ __align__(16) uint8_t lds_drain[];
+    const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / a.tiles)), tile = blockIdx.x - s * a.tiles;
+    const MapArgs& m = a.m[s < (uint32_t)kDrainSteps ? s : 0];
+    map_one_tile<256>(m, a.h, m.tile_wcls[tile], lds_drain, nullptr, tile);
 }
