@@ -127,12 +127,13 @@ constexpr int kEventRing = 256;
 constexpr int kBufs = 8;          // buffer sets: step s owns set s % kBufs from its digest (one launch before its fit)
                                   // to the end of its mapping (four launches after it, five when sharded)
 
-constexpr int kPipes = 2;
+constexpr int kPipes = 4;           // pipelines a context owns; a staged batch alternates its steps over two of them (four for small problems)
 struct Pipe {                            // one software pipeline of steps: its stream, its buffer sets, how far each phase got
     hipStream_t stream = nullptr;
     hipEvent_t ev_fit[kBufs] = {}, ev_red[kBufs] = {};   // stream <-> s_red hand-over (sharded runs only)
     hipEvent_t ev_staged = nullptr;      // pipe 0 records it behind what it staged (requests, work items, node records); pipe 1 waits for it
     uint64_t n_dig = 0, n_fit = 0, n_shaped = 0, n_chosen = 0, n_finished = 0;   // steps (since the last stage_requests) whose phase was launched
+    uint64_t seen_gen = 0;               // the staging generation of pipe 0's stream this pipe has waited for (nhdfit_ctx::staged_gen)
     DevBuf<PodHeader> hdr[kBufs]; DevBuf<uint8_t> tabs[kBufs];
     DevBuf<unsigned long long> score[kBufs]; DevBuf<nhdfit_mapping> maps[kBufs];
     DevBuf<uint64_t> nm;                 // node-major verdict words [tiles][chunks*64] (one buffer per pipe: its fit roles run in stream order)
@@ -155,7 +156,8 @@ struct nhdfit_ctx {
     bool dual = tune_env("NHDFIT_ONE_PIPE") == nullptr;   // tuning aid: NHDFIT_ONE_PIPE=1 keeps every step on pipe 0
     uint64_t n_enq = 0;                  // steps enqueued since the last stage_requests (step k runs on pipe k % 2)
     int last_pipe = 0;                   // the pipe of the most recent step (nhdfit_fetch reads its results)
-    bool staged_dirty = false;           // pipe 0's stream carries staging work pipe 1 has not waited for yet
+    uint64_t staged_gen = 1;             // bumped whenever pipe 0's stream gets staging work (requests, work items, node records): the other pipes wait for it once
+    int npipes = 2;                      // pipes the staged batch alternates over: 2; 4 for problems too small to fill the chip (launch-bound: more launches in flight)
     bool geom_big = true;                // 512-thread step blocks (256 for small problems)
     uint32_t digest_parts = tune_env("NHDFIT_DIGEST_PARTS") ? (uint32_t)atoi(tune_env("NHDFIT_DIGEST_PARTS")) : 2;   // tuning aid
     uint32_t side_prio = tune_env("NHDFIT_SIDE_PRIO") ? (uint32_t)atoi(tune_env("NHDFIT_SIDE_PRIO")) : 1;   // tuning aid
@@ -664,7 +666,7 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     for (Pipe& p : c->pipe) p.n_dig = p.n_fit = p.n_shaped = p.n_chosen = p.n_finished = 0;
     c->n_enq = 0;
     c->last_pipe = 0;
-    c->staged_dirty = true;
+    c->staged_gen++;
     const uint32_t tiles = (P + kTile - 1) / kTile;
     int32_t hp_max = 0;
     for (uint32_t p = 0; p < P; ++p) {
@@ -747,7 +749,7 @@ namespace {
 // tile images by the class count).  A grown class count or a changed dictionary re-does every record.
 int ensure_records(nhdfit_ctx* c) {
     if (!c->rec_all && c->rec_lo == c->rec_hi) return NHDFIT_OK;
-    c->staged_dirty = true;                                     // (its kernels run on pipe 0's stream)
+    c->staged_gen++;                                            // (its kernels run on pipe 0's stream)
     if (!c->n) { c->rec_all = false; c->rec_lo = c->rec_hi = 0; return NHDFIT_OK; }
     const uint32_t npad = (c->n + 63) & ~63u;
     for (int pass = 0; pass < 2; ++pass) {
@@ -841,7 +843,7 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
     memcpy(c->pin_items.p, items.data(), items.size() * sizeof(FitItem));
     HIPCHK(c, hipMemcpyAsync(c->items.p, c->pin_items.p, items.size() * sizeof(FitItem), hipMemcpyHostToDevice, c->stream));
     c->n_items = (uint32_t)items.size();
-    c->staged_dirty = true;
+    c->staged_gen++;
     return NHDFIT_OK;
 }
 
@@ -901,11 +903,11 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
     const bool small_map = c->want_map && c->n_big_pods < P;
     if (with_fit || with_digest) { int rc_ = ensure_records(c); if (rc_) return rc_; }
     if (with_fit && !c->n_items) { int rc_ = build_items(c, nw); if (rc_) return rc_; }
-    if (&p != &c->pipe[0] && c->staged_dirty) {
+    if (&p != &c->pipe[0] && p.seen_gen != c->staged_gen) {
         // what pipe 0's stream staged since this pipe last looked (requests, work items, node records) is in front of this launch
-        HIPCHK(c, hipEventRecord(c->pipe[0].ev_staged, c->pipe[0].stream));
-        HIPCHK(c, hipStreamWaitEvent(p.stream, c->pipe[0].ev_staged, 0));
-        c->staged_dirty = false;
+        HIPCHK(c, hipEventRecord(p.ev_staged, c->pipe[0].stream));
+        HIPCHK(c, hipStreamWaitEvent(p.stream, p.ev_staged, 0));
+        p.seen_gen = c->staged_gen;
     }
 
     StepArgs a;
@@ -1060,7 +1062,7 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
         c->stats.bytes_last = (uint64_t)tiles * c->n * 24ull + (uint64_t)P * sizeof(nhdfit_req) +
                               (c->want_bitmap ? (uint64_t)tiles * chunks * 64ull * 8ull : 0ull) + (uint64_t)P * 8ull;
         c->stats.nodes = c->n; c->stats.nsig = c->nsig; c->stats.ncls = c->ncls; c->stats.lds_bytes = c->lds_bytes;
-        c->stats.pipes = c->dual && !c->split && !c->role_kernels ? (uint32_t)kPipes : 1u;
+        c->stats.pipes = c->dual && !c->split && !c->role_kernels ? (uint32_t)c->npipes : 1u;
     }
     return NHDFIT_OK;
 }
@@ -1131,10 +1133,14 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
         c->geom_big = (uint64_t)tiles * ((chunks + 31) / 32) >= (uint32_t)c->prop.multiProcessorCount;
         if (const char* b = tune_env("NHDFIT_BLOCK")) c->geom_big = atoi(b) >= 512;      // tuning aid
         if (c->role_kernels) c->geom_big = true;
+        // a problem that does not fill the chip is bound by the latency of a launch (config 2: ~24 us for 1 M evaluations): four
+        // launches in flight instead of two
+        static const int force_pipes = tune_env("NHDFIT_PIPES") ? atoi(tune_env("NHDFIT_PIPES")) : 0;   // tuning aid
+        c->npipes = force_pipes >= 1 && force_pipes <= kPipes ? force_pipes : c->geom_big ? 2 : kPipes;
     }
     // step k of a staged batch runs on pipe k % 2 (sharded runs too: the all-reduces of both pipes go to the one reduce
     // stream in step order, the same order on every rank); the profiling forms stay on pipe 0
-    const int which = c->dual && !c->split && !c->role_kernels ? (int)(c->n_enq % kPipes) : 0;
+    const int which = c->dual && !c->split && !c->role_kernels ? (int)(c->n_enq % (uint64_t)c->npipes) : 0;
     Pipe& p = c->pipe[which];
     c->n_enq++;
     c->last_pipe = which;

@@ -203,24 +203,58 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
             if (s_hdr[j].flags & kPodValid) class_cover_w<WW>(s_req[j].r, a.d.caps[c], s_sum[j].W, s_sum[j].G, s_cover[j][c]);
         }
         __syncthreads();
-        for (uint32_t sig = sig_part * NW + wave; sig < L.nsig; sig += a.sig_parts * NW) {    // one reach family per (signature, pod), both sockets' rows from it
+        // Walking a signature's record word by word through LDS is a chain of dependent round trips (broadcast read, wait,
+        // readfirstlane: ~17 of them for a signature of eight one-NIC pools, ~2 000 cycles before any union is formed - what made
+        // config 5's digest the longest role of its step).  Instead: the offsets of the wavefront's next 64 signatures are read
+        // with one load (lane = signature of the wavefront's sequence), a signature's whole record with one more (lane = word),
+        // and the walk hands words to the scalar unit with v_readlane - two LDS round trips per signature.  Records longer than a
+        // wavefront keep the word-by-word walk.
+        const uint32_t sig_first = sig_part * NW + wave, sig_step = a.sig_parts * NW;
+        uint32_t offs_lo = 0, offs_hi = 0;                                   // lane i: record start / end of signature sig_first + (base + i) * sig_step
+        uint32_t seq = 0;
+        for (uint32_t sig = sig_first; sig < L.nsig; sig += sig_step, ++seq) {    // one reach family per (signature, pod), both sockets' rows from it
             uint32_t reach = 0;
             if (staged) {
-                // the record is read with the same address in every lane (LDS broadcast); readfirstlane hands the loop
-                // bounds to the scalar unit so the walk stays wave-uniform
-                auto word = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flat[i]); };
-                uint32_t at = a.d.sig.nsig + 1 + word(sig);
-                const uint32_t npools = word(at++);
+                if ((seq & 63u) == 0) {
+                    const uint32_t mine = sig + lane * sig_step;
+                    offs_lo = mine < L.nsig ? s_flat[mine] : 0u;
+                    offs_hi = mine + 1 < L.nsig ? s_flat[mine + 1] : a.d.flat_words - (a.d.sig.nsig + 1);   // (the last record ends with the stream, padding included)
+                }
+                const uint32_t rec0 = (uint32_t)__builtin_amdgcn_readlane((int)offs_lo, (int)(seq & 63u));
+                const uint32_t rec1 = (uint32_t)__builtin_amdgcn_readlane((int)offs_hi, (int)(seq & 63u));
+                const uint32_t base = a.d.sig.nsig + 1 + rec0;
                 reach = 1;
-                for (uint32_t pl = 0; pl < npools; ++pl) {
-                    const uint32_t head = word(at++), ncc = head & 0xFFu, glimit = head >> 8;
-                    uint32_t pool = 1;
-                    for (uint32_t k = 0; k < ncc; ++k) {
-                        const uint32_t e = word(at++), cnt = e & 0xFFu, cls = e >> 8;
-                        pool = dunion_n<WW>(pool, s_cover[lane][cls][cnt > (uint32_t)kMaxG ? kMaxG : cnt]);
+                if (rec1 - rec0 <= 64u) {
+                    const uint32_t my_word = lane < rec1 - rec0 ? s_flat[base + lane] : 0u;
+                    auto word = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readlane((int)my_word, (int)i); };
+                    uint32_t at = 0;
+                    const uint32_t npools = word(at++);
+                    for (uint32_t pl = 0; pl < npools; ++pl) {
+                        const uint32_t head = word(at++), ncc = head & 0xFFu, glimit = head >> 8;
+                        uint32_t pool = 1;
+                        for (uint32_t k = 0; k < ncc; ++k) {
+                            const uint32_t e = word(at++), cnt = e & 0xFFu, cls = e >> 8;
+                            pool = dunion_n<WW>(pool, s_cover[lane][cls][cnt > (uint32_t)kMaxG ? kMaxG : cnt]);
+                        }
+                        if (glimit != NHDFIT_GLIMIT_NONE) pool &= size_le_mask(s_sum[lane].W, glimit);
+                        reach = dunion_n<WW>(reach, pool);
                     }
-                    if (glimit != NHDFIT_GLIMIT_NONE) pool &= size_le_mask(s_sum[lane].W, glimit);
-                    reach = dunion_n<WW>(reach, pool);
+                } else {
+                    // the record is read with the same address in every lane (LDS broadcast); readfirstlane hands the loop
+                    // bounds to the scalar unit so the walk stays wave-uniform
+                    auto word = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flat[i]); };
+                    uint32_t at = base;
+                    const uint32_t npools = word(at++);
+                    for (uint32_t pl = 0; pl < npools; ++pl) {
+                        const uint32_t head = word(at++), ncc = head & 0xFFu, glimit = head >> 8;
+                        uint32_t pool = 1;
+                        for (uint32_t k = 0; k < ncc; ++k) {
+                            const uint32_t e = word(at++), cnt = e & 0xFFu, cls = e >> 8;
+                            pool = dunion_n<WW>(pool, s_cover[lane][cls][cnt > (uint32_t)kMaxG ? kMaxG : cnt]);
+                        }
+                        if (glimit != NHDFIT_GLIMIT_NONE) pool &= size_le_mask(s_sum[lane].W, glimit);
+                        reach = dunion_n<WW>(reach, pool);
+                    }
                 }
                 if (!valid) reach = 0;
             } else {
