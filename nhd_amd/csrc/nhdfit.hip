@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -181,6 +182,7 @@ struct nhdfit_ctx {
     // dictionary
     DevBuf<double> caps; DevBuf<uint32_t> sig_off, pool_off; DevBuf<uint8_t> pool_glimit; DevBuf<nhdfit_cc> cc;
     DevBuf<uint16_t> sig_flat; uint32_t flat_words = 0;
+    DevBuf<uint16_t> sig_flat2; uint32_t flat2_words = 0;   // the same by pool type (DictView::flat2)
     uint32_t ncls = 0, nsig = 0;
     uint32_t max_cores = 1, max_gpus = 0, ngs = 0;
     DevBuf<uint64_t> group_sets;
@@ -218,6 +220,10 @@ struct nhdfit_ctx {
     DevBuf<unsigned long long> xkeys; DevBuf<uint32_t> xids; DevBuf<uint64_t> xcls; DevBuf<uint32_t> xnx;
     uint32_t rec_lo = 0, rec_hi = 0; bool rec_all = true;
     uint32_t nx = 0, x_cap = kMinXCap;   // interned classes (as of the last record update) / provisioned X rows
+    // signatures some interned class refers to, ascending (DigestArgs::sig_list): rebuilt when classes are added; all_sigs: the
+    // digest of the step being enqueued forms every signature's rows (mode B's snapshot pass reads them for committed nodes)
+    DevBuf<uint16_t> sig_use; uint32_t n_sig_use = 0, sig_use_nx = 0; bool all_sigs = false;
+    bool sig_use_on = tune_env("NHDFIT_ALL_SIGS") == nullptr;   // tuning aid: NHDFIT_ALL_SIGS=1 digests every signature in every step
     uint32_t fit_blocks = tune_env("NHDFIT_FIT_BLOCKS") ? (uint32_t)atoi(tune_env("NHDFIT_FIT_BLOCKS")) : 0;   // tuning aid: blocks of the fit role
     bool use_choose_tab = tune_env("NHDFIT_NO_CHOOSE_TABLE") == nullptr;   // tuning aid: run the set model for every shape
     // set-layout state machine for three-group pods (set_states.h): verified against the model on the host
@@ -413,8 +419,8 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     if (c->find_host) (void)hipHostFree(c->find_host);
     c->find_host = nullptr; c->find_sync.release(); c->find_red.release();
     c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
-    c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release();
-    c->reqs.release(); c->bitmap.release(); c->rows_t.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
+    c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release(); c->sig_flat2.release();
+    c->reqs.release(); c->bitmap.release(); c->rows_t.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); c->sig_use.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_queue.release(); c->seq_ctrl.release(); c->seq_mat.release(); c->seq_flags.release(); c->seq_tn.release(); c->seq_ent.release(); c->sig_keys.release(); c->sig_ids.release();
     for (Pipe& p : c->pipe) {
         p.nm.release(); p.dig_count.release();
@@ -514,6 +520,64 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
         if (fits) {
             HIPCHK(c, c->sig_flat.reserve(flat.size()));
             HIPCHK(c, hipMemcpy(c->sig_flat.p, flat.data(), flat.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
+    }
+    {   // the dictionary by pool type (DictView::flat2, step_digest.h): distinct pools, and every signature as (type, multiplicity) pairs
+        std::map<std::vector<uint16_t>, uint32_t> type_of;
+        std::vector<std::vector<uint16_t>> types;
+        std::vector<std::vector<uint16_t>> sig_recs(nsig);
+        bool fits = true;
+        for (uint32_t sg = 0; sg < nsig && fits; ++sg) {
+            std::vector<std::pair<uint32_t, uint32_t>> ent;           // (type, count) in order of first appearance
+            for (uint32_t pl = sig_off[sg]; pl < sig_off[sg + 1] && fits; ++pl) {
+                const uint32_t ncc_pl = pool_off[pl + 1] - pool_off[pl];
+                if (ncc_pl == 0) continue;                            // a pool without NICs hosts the empty set only: the neutral element
+                if (ncc_pl > 255u) { fits = false; break; }
+                std::vector<uint16_t> body;
+                for (uint32_t k = pool_off[pl]; k < pool_off[pl + 1]; ++k) body.push_back((uint16_t)((cc[k].cls & 0xFFu) << 8 | cc[k].cnt));
+                std::sort(body.begin(), body.end());
+                std::vector<uint16_t> rec{(uint16_t)(pool_glimit[pl] << 8 | ncc_pl)};
+                rec.insert(rec.end(), body.begin(), body.end());
+                auto it = type_of.find(rec);
+                if (it == type_of.end()) {
+                    if (types.size() >= kPoolTypes) { fits = false; break; }
+                    it = type_of.emplace(rec, (uint32_t)types.size()).first;
+                    types.push_back(rec);
+                }
+                bool seen = false;
+                for (auto& e : ent)
+                    if (e.first == it->second) { if (e.second < 255u) e.second++; seen = true; }
+                if (!seen) ent.emplace_back(it->second, 1u);
+            }
+            sig_recs[sg].push_back((uint16_t)ent.size());
+            for (auto& e : ent) sig_recs[sg].push_back((uint16_t)(e.first << 8 | e.second));
+        }
+        std::vector<uint16_t> f2;
+        if (fits) {
+            const uint32_t nt = (uint32_t)types.size();
+            f2.assign(2 + (nt + 1) + (nsig + 1), 0);
+            f2[0] = (uint16_t)nt;
+            const size_t recs = f2.size();
+            for (uint32_t t = 0; t < nt && fits; ++t) {
+                if (f2.size() - recs > 0xFFFFu) { fits = false; break; }
+                f2[2 + t] = (uint16_t)(f2.size() - recs);
+                f2.insert(f2.end(), types[t].begin(), types[t].end());
+            }
+            if (fits) f2[2 + nt] = (uint16_t)(f2.size() - recs);
+            for (uint32_t sg = 0; sg < nsig && fits; ++sg) {
+                if (f2.size() - recs > 0xFFFFu) { fits = false; break; }
+                f2[2 + nt + 1 + sg] = (uint16_t)(f2.size() - recs);
+                f2.insert(f2.end(), sig_recs[sg].begin(), sig_recs[sg].end());
+            }
+            if (fits && f2.size() - recs > 0xFFFFu) fits = false;
+            if (fits) f2[2 + nt + 1 + nsig] = (uint16_t)(f2.size() - recs);
+            if (f2.size() & 1) f2.push_back(0);
+        }
+        static const bool typed_off = tune_env("NHDFIT_NO_POOL_TYPES") != nullptr;   // tuning aid: the digest walks pool by pool
+        c->flat2_words = fits && !typed_off ? (uint32_t)f2.size() : 0;
+        if (c->flat2_words) {
+            HIPCHK(c, c->sig_flat2.reserve(f2.size()));
+            HIPCHK(c, hipMemcpy(c->sig_flat2.p, f2.data(), f2.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
     }
     c->ncls = ncls;
@@ -781,6 +845,19 @@ int ensure_records(nhdfit_ctx* c) {
             for (Pipe& p : c->pipe)                             // them - it is digested again (nhdfit_enqueue_step looks here first)
                 if (p.n_dig > p.n_fit) p.n_dig = p.n_fit;
         c->nx = nx[0];
+        if (c->sig_use_on && c->sig_use_nx != c->nx) {              // the signatures the classes refer to (classes are only ever added)
+            std::vector<uint64_t> keys(c->nx);
+            if (c->nx) HIPCHK(c, hipMemcpy(keys.data(), c->xcls.p, (size_t)c->nx * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            std::vector<uint8_t> used(0x10000u, 0);
+            for (uint64_t k : keys) { used[xkey_sig_numa(k)] = 1; used[xkey_sig_pci(k)] = 1; }
+            std::vector<uint16_t> list;
+            for (uint32_t sg = 0; sg < 0x10000u; ++sg)
+                if (used[sg]) list.push_back((uint16_t)sg);
+            HIPCHK(c, c->sig_use.reserve(list.size() ? list.size() : 1));
+            if (!list.empty()) HIPCHK(c, hipMemcpy(c->sig_use.p, list.data(), list.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            c->n_sig_use = (uint32_t)list.size();
+            c->sig_use_nx = c->nx;
+        }
         if (nx[0] <= c->x_cap) break;
         // more classes than provisioned rows: every hot-section offset moves -> staged tables and all records are redone
         { int rc_ = sync_all(c); if (rc_) return rc_; }
@@ -865,12 +942,16 @@ ShapeArgs make_shape_args(nhdfit_ctx* c, Pipe& p, int b) {
 }
 void fill_digest_args(nhdfit_ctx* c, Pipe& p, int b, uint32_t wc_parts, uint32_t sig_parts, DigestArgs& d) {
     d.reqs = c->reqs.p; d.P = c->P;
-    d.d = DictView{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}, c->sig_flat.p, c->flat_words};
+    d.d = DictView{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}, c->sig_flat.p, c->flat_words,
+                   c->sig_flat2.p, c->flat2_words};
     for (int w = 0; w < kWClasses; ++w) d.L[w] = c->L[w];
     d.pitch = c->pitch; d.tabs = p.tabs[b].p; d.hdr = p.hdr[b].p; d.score = p.score[b].p;
     d.xcls = c->xcls.p; d.nx = c->xnx.p;
     d.wc_parts = wc_parts;
     d.sig_parts = sig_parts;
+    const bool listed = c->sig_use_on && !c->all_sigs && c->sig_use_nx == c->nx && c->nx != 0;
+    d.sig_list = listed ? c->sig_use.p : nullptr;
+    d.n_sig_list = listed ? c->n_sig_use : 0;
     d.count = p.dig_count.p;
 }
 void fill_fit_args(nhdfit_ctx* c, Pipe& p, int bf, double now, FitArgs& f, bool pair = false) {
@@ -1110,7 +1191,7 @@ int flush_pipeline(nhdfit_ctx* c) {
                 if (c->comm) HIPCHK(c, hipStreamWaitEvent(p.stream, p.ev_red[b], 0));      // the step's scores are final behind its all-reduce
                 a.m[a.nsteps++] = make_map_args(c, p, b);
             }
-            hipLaunchKernelGGL(k_map_tiles, dim3(a.nsteps * tiles), dim3(256), map_lds_bytes<256>(), p.stream, a);
+            hipLaunchKernelGGL(k_map_tiles, dim3(a.nsteps * tiles), dim3(256), map_tile_lds_bytes<256>(), p.stream, a);
             HIPCHK(c, hipGetLastError());
             p.n_finished += a.nsteps;
         }
@@ -1282,7 +1363,7 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
         a1.m.score = reinterpret_cast<const unsigned long long*>(c->find_sync.p + 4);
         a1.h = make_shape_args(c, p, 0);
         a1.p4 = c->p4.p;
-        a1.d = DictView{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}, c->sig_flat.p, c->flat_words};
+        a1.d = DictView{c->caps.p, c->ncls, c->group_sets.p, SigDict{c->sig_off.p, c->pool_off.p, c->pool_glimit.p, c->cc.p, c->nsig}, c->sig_flat.p, c->flat_words, nullptr, 0};
         a1.nsig = c->nsig; a1.fc_dim = c->max_cores + 1; a1.fg_dim = c->max_gpus + 1; a1.ngs = c->ngs;
         a1.chunks = chunks;
         static const uint32_t lone_nb = tune_env("NHDFIT_FIND_BLOCKS") ? (uint32_t)atoi(tune_env("NHDFIT_FIND_BLOCKS")) : 0u;   // tuning aid
@@ -1312,7 +1393,7 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     a.wcls = wcls; a.want_map = map_out ? 1u : 0u;
     a.sync = c->find_sync.p; a.host = h; a.seq = seq;
     size_t lds = lds_slice(c->lds_bytes) + (size_t)nw * 64 * sizeof(unsigned long long);
-    lds = std::max(lds, std::max(kDigestLds, map_lds_bytes<256>()));
+    lds = std::max(lds, std::max(kDigestLds, map_tile_lds_bytes<256>()));
     const bool clocks = kTuning && c->role_step >= 0;           // tuning aid (NHDFIT_ROLE_TIMES): the phases of the launch on the device clock
     if (clocks) {
         HIPCHK(c, c->role_clock.reserve(10));
@@ -1324,7 +1405,7 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     }
     const auto t_launch = std::chrono::steady_clock::now();
     c->P = 0;                                                   // nothing is staged for nhdfit_enqueue_step / nhdfit_fetch
-    if (lone) hipLaunchKernelGGL((k_find1<256>), dim3(a1.nb), dim3(256), kLoneLds + map_lds_bytes<256>(), c->stream, a1);
+    if (lone) hipLaunchKernelGGL((k_find1<256>), dim3(a1.nb), dim3(256), kLoneLds + map_tile_lds_bytes<256>(), c->stream, a1);
     else hipLaunchKernelGGL((k_find<256>), dim3(a.s.nb_digest + a.s.nb_fit), dim3(256), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     uint32_t seen = 0;
@@ -1597,9 +1678,11 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         // placement of the batch is mapped against the node's state at ITS turn)
         const bool wb = c->want_bitmap, wm = c->want_map;
         c->want_bitmap = true; c->want_map = false;
+        c->all_sigs = true;                              // the decisions read R rows for states no node is in yet (a committed node's new signature)
         rc = nhdfit_stage_requests(c, reqs, P);
         if (!rc && cand) rc = stage_cand(c, cand);
         if (!rc) rc = nhdfit_enqueue_step(c, now);
+        c->all_sigs = false;
         c->want_bitmap = wb; c->want_map = wm;
         if (rc) return rc;
         HIPCHK(c, c->nogpu.reserve(chunks ? chunks : 1));

@@ -13,7 +13,17 @@ struct DictView {
     // then #cc x (cls << 8 | cnt) }
     const uint16_t* flat;
     uint32_t flat_words;             // 0: not available (the stream would not fit 16-bit offsets)
+    // The dictionary by POOL TYPE (nhdfit_set_dictionary): a signature's reach family is the disjoint union over its pools, the
+    // operation is commutative and associative, and a dictionary holds few distinct pools (config 5: eight one-NIC pools per
+    // PCI-mode signature, a handful of kinds) - so a signature is stored as (type, multiplicity) pairs.  Per pod the digest forms
+    // each type's family and its 2-, 3-, 4-fold disjoint unions once (more than four pools of a kind add nothing: a pod has at
+    // most four groups to spread over them), and a signature then costs one union per distinct type instead of two per pool.
+    // Stream of 16-bit words: [0] ntypes, [1] 0, type offsets [ntypes + 1], signature offsets [nsig + 1], then the records (offsets
+    // count from there): type = { glimit << 8 | #cc, #cc x (cls << 8 | cnt) }, signature = { #entries, entries x (type << 8 | count) }.
+    const uint16_t* flat2;
+    uint32_t flat2_words;            // 0: not available (more than kPoolTypes types, offsets beyond 16 bits)
 };
+constexpr uint32_t kPoolTypes = 32;                  // pool types whose unions a digest block keeps in LDS
 
 // v_writelane_b32 (SGPR -> one lane of a VGPR).  This clang has no __builtin_amdgcn_writelane; the
 // asm label binds the declaration straight to the LLVM intrinsic, as the ROCm device libs do.
@@ -58,12 +68,21 @@ struct DigestArgs {
     uint32_t sig_parts;              // blocks per tile that share its NIC signature rows (signature = part mod sig_parts; 1 for small
                                      // dictionaries); the last of them to finish derives the X rows
     uint32_t* count;                 // [tiles] arrival counters of those blocks, zero before and after a launch
+    // The signatures some node class of the mirror refers to, ascending (ensure_records, nhdfit.hip), or null = all of them.  A
+    // dictionary closed under claims (mode B needs every state a commit can produce) holds many signatures no node is in yet -
+    // config 5: 121 of 272 - and a snapshot step reads R rows through node classes (X rows) and winners (mapping) only.
+    const uint16_t* sig_list;
+    uint32_t n_sig_list;
 };
 constexpr uint32_t kDictLdsWords = 6144;             // 12 KB for the staged signature stream (c5: 151 signatures = 1.5 K words)
-constexpr size_t kDigestLds = lds_slice(kTile * sizeof(PaddedReq)) + lds_slice(kTile * sizeof(PodSums)) +
+// the request copies come last: once the covers are formed they are dead, and the per-type unions (kPoolTypes x 4 x 64 x 2 bytes) take
+// their place plus the pad behind them
+constexpr size_t kPoolLds = (size_t)kPoolTypes * kMaxG * kTile * sizeof(uint16_t);
+constexpr size_t kDigestLds = lds_slice(kTile * sizeof(PodSums)) +
                               lds_slice(kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1) * sizeof(uint16_t)) + lds_slice(kTile * sizeof(PodHeader)) +
-                              lds_slice(kDictLdsWords * sizeof(uint16_t)) + 16;     // (+ the last-arriver flag; no static LDS in the step kernel:
+                              lds_slice(kDictLdsWords * sizeof(uint16_t)) + 16 +    // (+ the last-arriver flag; no static LDS in the step kernel:
                                                                                      //  its dynamic allocation may ask for all 160 KB)
+                              (lds_slice(kTile * sizeof(PaddedReq)) > kPoolLds ? lds_slice(kTile * sizeof(PaddedReq)) : kPoolLds);
 constexpr uint32_t kWcPartsDefault = 4;              // blocks per tile: part 0 = GPU / NIC rows (cold section + X), parts 1..wc_parts = CPU rows, the last one also HP / GX
 
 // Request digest, 1 + wc_parts blocks per 64-pod tile: per-pod subset sums / NIC covers in LDS, then the table rows
@@ -71,13 +90,14 @@ constexpr uint32_t kWcPartsDefault = 4;              // blocks per tile: part 0 
 // into parts by table so that the chain of each block stays short.
 template <int THREADS>
 __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, uint8_t* lds) {
-    PaddedReq* s_req = carve<PaddedReq>(lds, kTile);
     PodSums* s_sum = carve<PodSums>(lds, kTile);
     uint16_t (*s_cover)[NHDFIT_MAX_CLASSES][kMaxG + 1] =
         reinterpret_cast<uint16_t (*)[NHDFIT_MAX_CLASSES][kMaxG + 1]>(carve<uint16_t>(lds, kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1)));
     PodHeader* s_hdr = carve<PodHeader>(lds, kTile);
     uint16_t* s_flat = carve<uint16_t>(lds, kDictLdsWords);
     uint32_t& s_last = *carve<uint32_t>(lds, 4);
+    PaddedReq* s_req = reinterpret_cast<PaddedReq*>(lds);                 // (last: see kDigestLds)
+    uint16_t* s_pw = reinterpret_cast<uint16_t*>(lds);                    // [type][k][pod]: the (k + 1)-fold union of type's family - over s_req, after the covers
 
     // blocks of a tile: sig_parts blocks for the GPU / NIC rows (part 0), then wc_parts blocks for the CPU rows (parts 1 ..)
     const uint32_t per_tile = a.sig_parts + a.wc_parts, tile = blk / per_tile, idx = blk % per_tile;
@@ -125,7 +145,7 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
     uint8_t* hot = img + L.off_hot;
     // bit-sliced row: lane = pod holds its 16-bit entry (bit p = assignment p passes), one ballot per assignment
     // turns the 64 entries into the row's W words (bit j of word p = assignment p of pod j passes)
-    auto emit_row = [&](uint8_t* row, uint32_t v) {
+    auto emit_row = [&](uint8_t* row, uint32_t v) __attribute__((always_inline)) {
         unsigned long long mine = 0;
         for (uint32_t p = 0; p < W; ++p) {
             const unsigned long long word = __ballot(v >> p & 1);
@@ -138,13 +158,15 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
         // CPU records WC[u][smt][c] = {m=0 row, m=1 row}: for a pod, socket, SMT mode and misc placement the entry is
         // { p : demand_p <= c } - the demands are read once per (socket, misc, smt) group and swept over c in
         // registers (one group per wavefront) instead of being re-read from LDS for each of the rows of the group
+        // (the tile's row width W is uniform over the block: a one-group tile compares 2 demands per row, not 16 - the guards below are
+        // scalar branches.  One instantiation on purpose: four, one per width, cost the whole step kernel 1.5 KB of scratch per lane)
         for (uint32_t g = wave; g < 8; g += NW) {
             const uint32_t u = g >> 2, m = (g >> 1) & 1, smt = g & 1;
             uint32_t t[1 << kMaxG];
 #pragma unroll
             for (uint32_t p = 0; p < (1u << kMaxG); ++p) {
                 t[p] = 0xFFFFFFFFu;
-                if (valid && p < s_sum[lane].W) {
+                if (p < W && valid && p < s_sum[lane].W) {
                     const uint32_t* sum = smt ? s_sum[lane].cpu_smt : s_sum[lane].cpu_nosmt;
                     const uint32_t extra = m ? (smt ? s_sum[lane].misc_smt : s_sum[lane].misc_nosmt) : 0;
                     t[p] = sum[u ? p : (~p & s_sum[lane].full)] + extra;
@@ -154,7 +176,8 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
             for (uint32_t c = part - 1; c < L.fc_dim; c += a.wc_parts) {
                 uint32_t v = 0;
 #pragma unroll
-                for (uint32_t p = 0; p < (1u << kMaxG); ++p) v |= (t[p] <= c ? 1u : 0u) << p;
+                for (uint32_t p = 0; p < (1u << kMaxG); ++p)
+                    if (p < W) v |= (t[p] <= c ? 1u : 0u) << p;
                 emit_row(base + c * L.wc_stride, v);
             }
         }
@@ -192,17 +215,74 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
 
     // part 0: NIC covers per (pod, capacity class), then the cold rows A0/A1[f], R0/R1[sig].  The unions behind both are
     // instantiated per row width (uniform over the block): a two-group tile pays 4 terms per union, not 16.
-    const bool staged = a.d.flat_words != 0 && a.d.flat_words <= kDictLdsWords;
+    const bool typed = a.d.flat2_words != 0 && a.d.flat2_words <= kDictLdsWords;      // block-uniform
+    const bool staged = !typed && a.d.flat_words != 0 && a.d.flat_words <= kDictLdsWords;
+    if (typed)
+        for (uint32_t w = tid; w < a.d.flat2_words / 2; w += THREADS)       // (the streams are padded to an even word count)
+            reinterpret_cast<uint32_t*>(s_flat)[w] = reinterpret_cast<const uint32_t*>(a.d.flat2)[w];
     if (staged)
-        for (uint32_t w = tid; w < a.d.flat_words / 2; w += THREADS)        // (the stream is padded to an even word count)
+        for (uint32_t w = tid; w < a.d.flat_words / 2; w += THREADS)
             reinterpret_cast<uint32_t*>(s_flat)[w] = reinterpret_cast<const uint32_t*>(a.d.flat)[w];
-    auto covers_and_sig_rows = [&](auto width) {
+    auto covers_and_sig_rows = [&](auto width) __attribute__((always_inline)) {
         constexpr uint32_t WW = decltype(width)::value;
         for (uint32_t w = tid; w < kTile * a.d.ncls; w += THREADS) {
             const uint32_t j = w % kTile, c = w / kTile;
             if (s_hdr[j].flags & kPodValid) class_cover_w<WW>(s_req[j].r, a.d.caps[c], s_sum[j].W, s_sum[j].G, s_cover[j][c]);
         }
         __syncthreads();
+        if (typed) {
+            // (A) every pool type's family and its 2-, 3-, 4-fold unions, lane = pod, a type per wavefront iteration
+            auto bword = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flat[i]); };
+            const uint32_t ntypes = bword(0), nsig_d = a.d.sig.nsig;
+            const uint32_t t_off = 2, s_off = t_off + ntypes + 1, recs = s_off + nsig_d + 1;
+            for (uint32_t t = wave; t < ntypes; t += NW) {
+                uint32_t at = recs + bword(t_off + t);
+                const uint32_t head = bword(at++), ncc = head & 0xFFu, glimit = head >> 8;
+                uint32_t pool = 1;
+                for (uint32_t k = 0; k < ncc; ++k) {
+                    const uint32_t e = bword(at++), cnt = e & 0xFFu, cls = e >> 8;
+                    pool = dunion_n<WW>(pool, s_cover[lane][cls][cnt > (uint32_t)kMaxG ? kMaxG : cnt]);
+                }
+                if (glimit != NHDFIT_GLIMIT_NONE) pool &= size_le_mask(s_sum[lane].W, glimit);
+                uint32_t pw = pool;
+#pragma unroll
+                for (uint32_t k = 0; k < (uint32_t)kMaxG; ++k) {
+                    s_pw[(t * kMaxG + k) * kTile + lane] = (uint16_t)pw;          // (s_req is dead: the covers are formed, the barrier passed)
+                    pw = dunion_n<WW>(pw, pool);
+                }
+            }
+            __syncthreads();
+            // (B) a signature = the union over its (type, multiplicity) pairs; record offsets and records by bulk load + v_readlane
+            const uint32_t sig_first = sig_part * NW + wave, sig_step = a.sig_parts * NW;
+            uint32_t offs_lo = 0, offs_hi = 0, seq = 0;
+            const uint32_t n_sigs = a.sig_list ? a.n_sig_list : L.nsig;
+            uint32_t sig_ids = 0;                                                   // lane i: the signature at position idx + i * sig_step
+            for (uint32_t idx = sig_first; idx < n_sigs; idx += sig_step, ++seq) {
+                if ((seq & 63u) == 0) {
+                    const uint32_t at = idx + lane * sig_step;
+                    const uint32_t mine = at < n_sigs ? (a.sig_list ? (uint32_t)a.sig_list[at] : at) : L.nsig;
+                    sig_ids = mine;
+                    offs_lo = mine < L.nsig ? s_flat[s_off + mine] : 0u;
+                    offs_hi = mine < L.nsig ? s_flat[s_off + mine + 1] : 0u;
+                }
+                const uint32_t sig = (uint32_t)__builtin_amdgcn_readlane((int)sig_ids, (int)(seq & 63u));
+                const uint32_t rec0 = (uint32_t)__builtin_amdgcn_readlane((int)offs_lo, (int)(seq & 63u));
+                const uint32_t rec1 = (uint32_t)__builtin_amdgcn_readlane((int)offs_hi, (int)(seq & 63u));
+                const uint32_t len = rec1 - rec0;                                   // 1 + entries, <= 1 + kPoolTypes
+                const uint32_t my_word = lane < len ? s_flat[recs + rec0 + lane] : 0u;
+                const uint32_t nent = (uint32_t)__builtin_amdgcn_readlane((int)my_word, 0);
+                uint32_t reach = 1;
+                for (uint32_t e = 0; e < nent; ++e) {
+                    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)my_word, (int)(1 + e));
+                    const uint32_t type = w >> 8, cnt = w & 0xFFu, k = (cnt > (uint32_t)kMaxG ? (uint32_t)kMaxG : cnt) - 1u;
+                    reach = dunion_n<WW>(reach, s_pw[(type * kMaxG + k) * kTile + lane]);
+                }
+                if (!valid) reach = 0;
+                emit_row(img + L.off_r0 + sig * L.row, valid ? entry_r(reach, s_sum[lane].W, 0) : 0u);
+                emit_row(img + L.off_r1 + sig * L.row, valid ? entry_r(reach, s_sum[lane].W, 1) : 0u);
+            }
+            return;
+        }
         // Walking a signature's record word by word through LDS is a chain of dependent round trips (broadcast read, wait,
         // readfirstlane: ~17 of them for a signature of eight one-NIC pools, ~2 000 cycles before any union is formed - what made
         // config 5's digest the longest role of its step).  Instead: the offsets of the wavefront's next 64 signatures are read
@@ -212,11 +292,18 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
         const uint32_t sig_first = sig_part * NW + wave, sig_step = a.sig_parts * NW;
         uint32_t offs_lo = 0, offs_hi = 0;                                   // lane i: record start / end of signature sig_first + (base + i) * sig_step
         uint32_t seq = 0;
-        for (uint32_t sig = sig_first; sig < L.nsig; sig += sig_step, ++seq) {    // one reach family per (signature, pod), both sockets' rows from it
+        const uint32_t n_sigs = a.sig_list ? a.n_sig_list : L.nsig;
+        uint32_t sig_ids = 0;
+        for (uint32_t idx = sig_first; idx < n_sigs; idx += sig_step, ++seq) {    // one reach family per (signature, pod), both sockets' rows from it
             uint32_t reach = 0;
+            if ((seq & 63u) == 0) {
+                const uint32_t at = idx + lane * sig_step;
+                sig_ids = at < n_sigs ? (a.sig_list ? (uint32_t)a.sig_list[at] : at) : L.nsig;
+            }
+            const uint32_t sig = (uint32_t)__builtin_amdgcn_readlane((int)sig_ids, (int)(seq & 63u));
             if (staged) {
                 if ((seq & 63u) == 0) {
-                    const uint32_t mine = sig + lane * sig_step;
+                    const uint32_t mine = sig_ids;
                     offs_lo = mine < L.nsig ? s_flat[mine] : 0u;
                     offs_hi = mine + 1 < L.nsig ? s_flat[mine + 1] : a.d.flat_words - (a.d.sig.nsig + 1);   // (the last record ends with the stream, padding included)
                 }

@@ -78,6 +78,11 @@ constexpr size_t map_lds_bytes() {
     return lds_slice(pods * sizeof(PaddedReq)) + lds_slice(pods * sizeof(PaddedDet)) + lds_slice(pods * sizeof(StagedNode)) +
            lds_slice(pods * sizeof(nhdfit_mapping)) + lds_slice(NHDFIT_MAX_CLASSES * sizeof(double));
 }
+// map_one_tile also keeps the set-state tables behind the staging area (up to kStLdsStates states; the enumeration yields 338)
+constexpr uint32_t kStLdsStates = 384;
+constexpr size_t kStLdsBytes = lds_slice(kStLdsStates * sizeof(uint64_t)) + lds_slice((size_t)kStLdsStates * 8 * sizeof(uint32_t)) + lds_slice(256 * sizeof(uint32_t));
+template <int THREADS>
+constexpr size_t map_tile_lds_bytes() { return map_lds_bytes<THREADS>() + kStLdsBytes; }
 template <int THREADS>
 __device__ __forceinline__ MapStage stage_winners(const MapArgs& a, uint32_t pod0, uint8_t* lds) {
     constexpr uint32_t PODS = THREADS / 4;
@@ -303,6 +308,21 @@ __device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& 
                                              uint32_t tile = 0) {
     static_assert(THREADS / 4 == kTile, "the pods of the tile are one wavefront");
     const uint32_t pod0 = tile * kTile;
+    // The set-layout state machine of the three-group shapes is ~40 DEPENDENT look-ups per shape: against global memory that is
+    // the longest chain of the block (the tiles with three-group pods set the length of a drain launch, ~30 us).  Its tables are
+    // 14.5 KB - every thread copies its share into LDS behind the staging area (the copy rides along with the winners' staging)
+    // and the look-ups stay in the CU.
+    SetStates lst = h.st;
+    if (h.st.info && h.st.n <= kStLdsStates) {
+        uint8_t* q = lds + map_lds_bytes<THREADS>();
+        uint64_t* l_info = carve<uint64_t>(q, kStLdsStates);
+        uint32_t* l_next = carve<uint32_t>(q, (size_t)kStLdsStates * 8);
+        uint32_t* l_asc = carve<uint32_t>(q, 256);
+        for (uint32_t i = threadIdx.x; i < h.st.n; i += THREADS) l_info[i] = h.st.info[i];
+        for (uint32_t i = threadIdx.x; i < h.st.n * 8; i += THREADS) l_next[i] = h.st.next[i];
+        for (uint32_t i = threadIdx.x; i < 256; i += THREADS) l_asc[i] = h.st.asc[i];
+        lst = SetStates{l_info, l_next, l_asc, h.st.n};                   // (stage_winners' barriers below order the copies)
+    }
     const MapStage st = stage_winners<THREADS>(a, pod0, lds);
     const uint32_t j = threadIdx.x;
     if (j < (uint32_t)kTile) {
@@ -346,8 +366,8 @@ __device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& 
         bool generic = false;
         if (lane < nd) {
             const int G = (int)(mine & 3), U = (int)((mine >> 2) & 1) + 1;
-            if (h.st.info && G == 3 && U == 2)
-                res = choose_g3(h.st, h.asc, (uint32_t)(mine >> 3) & 0xFF, (uint32_t)(mine >> 19) & 0xFFFF, (uint32_t)(mine >> 11) & 0xFF);
+            if (lst.info && G == 3 && U == 2)
+                res = choose_g3(lst, h.asc, (uint32_t)(mine >> 3) & 0xFF, (uint32_t)(mine >> 19) & 0xFFFF, (uint32_t)(mine >> 11) & 0xFF);
             else
                 generic = true;
         }

@@ -1,0 +1,39 @@
+"""Build-time guard: the step kernel must not fall back on scratch memory.  A harmless-looking change (four instantiations of the
+digest's CPU-row loop) once cost every wavefront of k_step 1.5 KB of private memory per lane and made the step 8x slower while
+every parity test stayed green - so the compiler's own resource report is asserted here (hipcc cross-compiles without a GPU)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_step_kernel_uses_no_scratch_to_speak_of(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "nhd_amd", "csrc", "nhdfit.hip")
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "--cuda-device-only", "-c", src,
+                          "-o", str(tmp_path / "dev.o"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    usage = {}
+    name = None
+    for line in res.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and name:
+            usage[name][m.group(1).strip()] = int(m.group(2))
+    step = {k: v for k, v in usage.items() if "k_stepILi" in k and "ELb0E" in k}      # k_step<512|256, false>: the launch of every step
+    assert len(step) == 2, list(usage)
+    for k, v in step.items():
+        assert v["ScratchSize"] <= 64, (k, v)              # a few spilled registers in the rare transpose branch, not arrays in memory
+        assert v["VGPRs"] <= 84, (k, v)                    # three 512-thread blocks per CU (6 waves per SIMD) need <= 85
+    for k, v in usage.items():
+        if "k_find" in k or "k_map_tiles" in k:
+            assert v.get("ScratchSize", 0) <= 64, (k, v)

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 4: the digest's signature walk with one record load + v_readlane (step_digest.h) - parity of the digest-sensitive tests,
+# Round 4: the digest's signature walk (one record load + v_readlane; then signatures by pool type) and four pipes for small problems
+# - parity of the digest- and pipeline-sensitive tests,
 # then the step time of the config-5 shard against all 16 384 pods and of config 4, and the role windows inside one launch.
 #   gpurun -- bash tools/r04_digest.sh [tag]
 set -u
@@ -9,13 +10,13 @@ OUT=$ROOT/gpurun_out/r04_digest_$TAG
 mkdir -p $OUT
 cd $ROOT
 SECONDS=0
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "golden or random_clusters or baseline_configs or node_classes or single_launch_find_equals or edge_cases or pipelined_steps_match" > $OUT/pytest_digest.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "golden or random_clusters or baseline_configs or node_classes or single_launch_find_equals or edge_cases or pipelined_steps or commits_and_deltas_between or full_size_config4 or scheduler_loop or wide_nodes_at_scale" > $OUT/pytest_digest.log 2>&1
 echo "pytest rc=$? seconds=$SECONDS" | tee -a $OUT/pytest_digest.log
 grep -E "passed|failed|error|Error|assert" $OUT/pytest_digest.log | tail -6
 B="--no-pmc --no-extras --no-cpu-baseline --steps 1000 --warmup 200"
 TL=$ROOT/nhd_amd/libnhdfit_tuning.so
 {
-for shape in "--config 5 --nodes-per-gpu 32768 --pods 16384" "--config 5 --nodes-per-gpu 32768 --pods 2048" "--config 4 --nodes-per-gpu 65536 --pods 4096"; do
+for shape in "--config 5 --nodes-per-gpu 32768 --pods 16384" "--config 5 --nodes-per-gpu 32768 --pods 2048" "--config 4 --nodes-per-gpu 65536 --pods 4096" "--config 2 --nodes-per-gpu 4096 --pods 256" "--config 3 --nodes-per-gpu 16384 --pods 1024"; do
   echo "== ship $shape"
   timeout 300 python bench.py $B $shape 2>/dev/null | python -c "
 import json,sys
