@@ -128,7 +128,7 @@ constexpr int kEventRing = 256;
 constexpr int kBufs = 8;          // buffer sets: step s owns set s % kBufs from its digest (one launch before its fit)
                                   // to the end of its mapping (four launches after it, five when sharded)
 
-constexpr int kPipes = 4;           // pipelines a context owns; a staged batch alternates its steps over two of them (four for small problems)
+constexpr int kPipes = 3;           // pipelines a context owns; a staged batch deals its steps to two of them, or to all three (nhdfit_enqueue_step)
 struct Pipe {                            // one software pipeline of steps: its stream, its buffer sets, how far each phase got
     hipStream_t stream = nullptr;
     hipEvent_t ev_fit[kBufs] = {}, ev_red[kBufs] = {};   // stream <-> s_red hand-over (sharded runs only)
@@ -147,10 +147,11 @@ struct Pipe {                            // one software pipeline of steps: its 
 
 struct nhdfit_ctx {
     int dev = -1;
-    // Two pipes: the pipelined form (stage, enqueue, enqueue, ...) alternates its steps between two independent software
-    // pipelines on two streams, so that one step's launch gap, table staging and tail are covered by the other step's
-    // blocks (measured: 23 -> 17 us per step, profiles/r03).  Everything else - single finds, mode B, uploads, deltas -
-    // runs on pipe 0, whose stream is `stream`; whatever changes the mirror waits for both (sync_all).
+    // Several pipes: the pipelined form (stage, enqueue, enqueue, ...) deals its steps round robin to independent software
+    // pipelines on their own streams, so that one step's launch gap, table staging and tail are covered by the other steps'
+    // blocks (two against one: 23 -> 17 us per step, profiles/r03; a third where the digest is a long chain, profiles/r04).
+    // Everything else - single finds, mode B, uploads, deltas - runs on pipe 0, whose stream is `stream`; whatever changes the
+    // mirror waits for all of them (sync_all).
     Pipe pipe[kPipes];
     hipStream_t stream = nullptr;        // = pipe[0].stream: uploads, deltas, commits, mode B, single finds
     hipStream_t s_red = nullptr;         // the all-reduce of sharded runs, overlapping the next step launch
@@ -158,7 +159,7 @@ struct nhdfit_ctx {
     uint64_t n_enq = 0;                  // steps enqueued since the last stage_requests (step k runs on pipe k % 2)
     int last_pipe = 0;                   // the pipe of the most recent step (nhdfit_fetch reads its results)
     uint64_t staged_gen = 1;             // bumped whenever pipe 0's stream gets staging work (requests, work items, node records): the other pipes wait for it once
-    int npipes = 2;                      // pipes the staged batch alternates over: 2; 4 for problems too small to fill the chip (launch-bound: more launches in flight)
+    int npipes = 2;                      // pipes the staged batch's steps are dealt to: 2, or 3 (nhdfit_enqueue_step decides per batch)
     bool geom_big = true;                // 512-thread step blocks (256 for small problems)
     uint32_t digest_parts = tune_env("NHDFIT_DIGEST_PARTS") ? (uint32_t)atoi(tune_env("NHDFIT_DIGEST_PARTS")) : 2;   // tuning aid
     uint32_t side_prio = tune_env("NHDFIT_SIDE_PRIO") ? (uint32_t)atoi(tune_env("NHDFIT_SIDE_PRIO")) : 1;   // tuning aid
@@ -1214,10 +1215,13 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
         c->geom_big = (uint64_t)tiles * ((chunks + 31) / 32) >= (uint32_t)c->prop.multiProcessorCount;
         if (const char* b = tune_env("NHDFIT_BLOCK")) c->geom_big = atoi(b) >= 512;      // tuning aid
         if (c->role_kernels) c->geom_big = true;
-        // a problem that does not fill the chip is bound by the latency of a launch (config 2: ~24 us for 1 M evaluations): four
-        // launches in flight instead of two
+        // How many launches in flight (profiles/r04/pipes_*.log).  A third one covers long latency chains inside a launch: with a
+        // large dictionary the digest role is one (config 5, 151 signatures: 15.9 -> 10.9 us per step of 2 048 pods).  Where the
+        // fit role fills the launch (config 4) it buys 3 % in steady state and costs as much in a short run, whose end waits for
+        // every launch in flight (20 steps: 19.1 -> 19.7 us each); problems too small to fill the chip are bound by the host's
+        // ~11 us per enqueue whatever the count (config 2, config 3: flat from two to four).
         static const int force_pipes = tune_env("NHDFIT_PIPES") ? atoi(tune_env("NHDFIT_PIPES")) : 0;   // tuning aid
-        c->npipes = force_pipes >= 1 && force_pipes <= kPipes ? force_pipes : c->geom_big ? 2 : kPipes;
+        c->npipes = force_pipes >= 1 && force_pipes <= kPipes ? force_pipes : (c->geom_big && c->nsig > 64) ? 3 : 2;
     }
     // step k of a staged batch runs on pipe k % 2 (sharded runs too: the all-reduces of both pipes go to the one reduce
     // stream in step order, the same order on every rank); the profiling forms stay on pipe 0
