@@ -464,7 +464,8 @@ def delta_rate(eng, table, n=4096):
 
 
 def other_configs(args, device):
-    """BASELINE.json's other shapes on one GPU, same step, same clock (not the headline; 60 steps each): config 2 whole
+    """BASELINE.json's other shapes on one GPU, same step, same clock (not the headline; 300 steps each after 20 warm-up steps on a
+    fresh engine - a region's end costs one launch's tail plus the drain, ~60-100 us, whatever its length): config 2 whole
     (4 096 nodes x 256 pods), config 3 whole (16 384 x 1 024), a config-5 shard cut both ways (32 768 x 2 048: an eighth of
     its nodes, an eighth of its pods) and as one GPU of the 8-GPU run has it (32 768 nodes x all 16 384 pods).  Mode A step rate
     and the mode-B decision rate of each."""
@@ -486,10 +487,10 @@ def other_configs(args, device):
         eng.set_dictionary(pk)
         eng.upload(table)
         eng.stage(reqs)
-        for _ in range(5):
+        for _ in range(20):
             eng.enqueue(spec.clock_now)
         eng.sync()
-        steps = 60
+        steps = 300
         t0 = time.perf_counter()
         for _ in range(steps):
             eng.enqueue(spec.clock_now)
@@ -498,7 +499,7 @@ def other_configs(args, device):
         score, _, _ = eng.fetch(want_bitmap=False, want_map=True)
         mb = mode_b(eng, pk, reqs, spec.clock_now, P, parity=(spec, tops, groups))     # (parity asserted: a mismatch ends the run)
         rows.append({"config": cfg, "nodes": n, "pods": P, "ms_per_step": dt * 1e3 / steps, "evals_per_s": float(P) * n * steps / dt,
-                     "placed_pods": int(np.count_nonzero(score)), "nic_signatures": len(pk.sigs),
+                     "steps": steps, "placed_pods": int(np.count_nonzero(score)), "nic_signatures": len(pk.sigs),
                      "mode_b_decisions_per_s": mb["decisions_per_s"], "mode_b_placed": mb["placed"], "mode_b_parity": mb["parity"]})
         eng.close()
     return rows

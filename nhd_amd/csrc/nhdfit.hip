@@ -33,6 +33,7 @@
 
 #include "seq_core.h"
 #include "wide_core.h"
+#include "dict_stream.h"
 
 using namespace nhdfit;
 
@@ -523,59 +524,12 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
             HIPCHK(c, hipMemcpy(c->sig_flat.p, flat.data(), flat.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
     }
-    {   // the dictionary by pool type (DictView::flat2, step_digest.h): distinct pools, and every signature as (type, multiplicity) pairs
-        std::map<std::vector<uint16_t>, uint32_t> type_of;
-        std::vector<std::vector<uint16_t>> types;
-        std::vector<std::vector<uint16_t>> sig_recs(nsig);
-        bool fits = true;
-        for (uint32_t sg = 0; sg < nsig && fits; ++sg) {
-            std::vector<std::pair<uint32_t, uint32_t>> ent;           // (type, count) in order of first appearance
-            for (uint32_t pl = sig_off[sg]; pl < sig_off[sg + 1] && fits; ++pl) {
-                const uint32_t ncc_pl = pool_off[pl + 1] - pool_off[pl];
-                if (ncc_pl == 0) continue;                            // a pool without NICs hosts the empty set only: the neutral element
-                if (ncc_pl > 255u) { fits = false; break; }
-                std::vector<uint16_t> body;
-                for (uint32_t k = pool_off[pl]; k < pool_off[pl + 1]; ++k) body.push_back((uint16_t)((cc[k].cls & 0xFFu) << 8 | cc[k].cnt));
-                std::sort(body.begin(), body.end());
-                std::vector<uint16_t> rec{(uint16_t)(pool_glimit[pl] << 8 | ncc_pl)};
-                rec.insert(rec.end(), body.begin(), body.end());
-                auto it = type_of.find(rec);
-                if (it == type_of.end()) {
-                    if (types.size() >= kPoolTypes) { fits = false; break; }
-                    it = type_of.emplace(rec, (uint32_t)types.size()).first;
-                    types.push_back(rec);
-                }
-                bool seen = false;
-                for (auto& e : ent)
-                    if (e.first == it->second) { if (e.second < 255u) e.second++; seen = true; }
-                if (!seen) ent.emplace_back(it->second, 1u);
-            }
-            sig_recs[sg].push_back((uint16_t)ent.size());
-            for (auto& e : ent) sig_recs[sg].push_back((uint16_t)(e.first << 8 | e.second));
-        }
-        std::vector<uint16_t> f2;
-        if (fits) {
-            const uint32_t nt = (uint32_t)types.size();
-            f2.assign(2 + (nt + 1) + (nsig + 1), 0);
-            f2[0] = (uint16_t)nt;
-            const size_t recs = f2.size();
-            for (uint32_t t = 0; t < nt && fits; ++t) {
-                if (f2.size() - recs > 0xFFFFu) { fits = false; break; }
-                f2[2 + t] = (uint16_t)(f2.size() - recs);
-                f2.insert(f2.end(), types[t].begin(), types[t].end());
-            }
-            if (fits) f2[2 + nt] = (uint16_t)(f2.size() - recs);
-            for (uint32_t sg = 0; sg < nsig && fits; ++sg) {
-                if (f2.size() - recs > 0xFFFFu) { fits = false; break; }
-                f2[2 + nt + 1 + sg] = (uint16_t)(f2.size() - recs);
-                f2.insert(f2.end(), sig_recs[sg].begin(), sig_recs[sg].end());
-            }
-            if (fits && f2.size() - recs > 0xFFFFu) fits = false;
-            if (fits) f2[2 + nt + 1 + nsig] = (uint16_t)(f2.size() - recs);
-            if (f2.size() & 1) f2.push_back(0);
-        }
+    {   // the dictionary by pool type (DictView::flat2; dict_stream.h): distinct pools, and every signature as (type, multiplicity) pairs
+        static_assert(kPoolSlotsMax == kPoolSlots, "dict_stream.h and step_digest.h agree on the slot capacity");
+        const SigDict hd{sig_off, pool_off, pool_glimit, cc, nsig};
+        const std::vector<uint16_t> f2 = build_typed_stream(hd);
         static const bool typed_off = tune_env("NHDFIT_NO_POOL_TYPES") != nullptr;   // tuning aid: the digest walks pool by pool
-        c->flat2_words = fits && !typed_off ? (uint32_t)f2.size() : 0;
+        c->flat2_words = !typed_off ? (uint32_t)f2.size() : 0;
         if (c->flat2_words) {
             HIPCHK(c, c->sig_flat2.reserve(f2.size()));
             HIPCHK(c, hipMemcpy(c->sig_flat2.p, f2.data(), f2.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -890,12 +844,19 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
     // node axis: an XCD's L2 then only ever sees its eighth of the node records (0.7 MB at 65 536 nodes instead of all
     // 5.5 MB of the three row widths + busy times - more than the 4 MB an XCD has), re-read once per pod tile.
     static const bool xcd_items = !(tune_env("NHDFIT_XCD_ITEMS") && atoi(tune_env("NHDFIT_XCD_ITEMS")) == 0);
-    const bool by_xcd = xcd_items && !c->fit_blocks && chunks >= 8u * 4u * nw && nw == 8;
+    // ... unless the shard's records fit any XCD's L2 several times over (config 5's shard: 32 768 nodes, 1.8 MB with all three row
+    // widths and the busy times): then there is nothing to partition for, and a batch of many tiles is better served by FEW, LONG
+    // blocks per tile - every fit block stages the tile's hot section and derives its pair tables first (config 5: 35-50 KB), and
+    // 2 300 blocks of eight chunks per wavefront spent a fifth of the step doing that.
+    const uint64_t rec_bytes = (uint64_t)chunks * 64u * (16u * (c->max_wcls + 1u) + 8u);
+    const bool small_shard = rec_bytes <= (2u << 20);
+    const bool by_xcd = xcd_items && !c->fit_blocks && chunks >= 8u * 4u * nw && nw == 8 && !small_shard;
     for (uint32_t t = 0; t < tiles; ++t) {           // staged order = widest tiles first
         const uint32_t w = c->h_tile_wcls[t];
         const uint64_t cost = (uint64_t)chunks * (6u + (2u << w));
         uint32_t nb = (uint32_t)((cost * target + total / 2) / total);
         nb = std::max(1u, std::min(nb, (chunks + nw - 1) / nw));          // at least one chunk per wavefront
+        if (small_shard && nw == 8 && !c->fit_blocks) nb = std::min(nb, 8u);   // (few tiles: as the XCD form would cut them)
         if (by_xcd) {
             static const uint32_t force_k = tune_env("NHDFIT_XCD_K") ? (uint32_t)atoi(tune_env("NHDFIT_XCD_K")) : 0u;   // tuning aid
             // 8, 16 or 32 blocks per tile by its cost when one launch has the chip to itself; with two pipes the other launch's

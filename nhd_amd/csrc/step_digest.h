@@ -13,17 +13,15 @@ struct DictView {
     // then #cc x (cls << 8 | cnt) }
     const uint16_t* flat;
     uint32_t flat_words;             // 0: not available (the stream would not fit 16-bit offsets)
-    // The dictionary by POOL TYPE (nhdfit_set_dictionary): a signature's reach family is the disjoint union over its pools, the
-    // operation is commutative and associative, and a dictionary holds few distinct pools (config 5: eight one-NIC pools per
-    // PCI-mode signature, a handful of kinds) - so a signature is stored as (type, multiplicity) pairs.  Per pod the digest forms
-    // each type's family and its 2-, 3-, 4-fold disjoint unions once (more than four pools of a kind add nothing: a pod has at
-    // most four groups to spread over them), and a signature then costs one union per distinct type instead of two per pool.
-    // Stream of 16-bit words: [0] ntypes, [1] 0, type offsets [ntypes + 1], signature offsets [nsig + 1], then the records (offsets
-    // count from there): type = { glimit << 8 | #cc, #cc x (cls << 8 | cnt) }, signature = { #entries, entries x (type << 8 | count) }.
+    // The dictionary by POOL TYPE (dict_stream.h, built by nhdfit_set_dictionary): a signature's reach family is the disjoint union
+    // over its pools, the operation is commutative and associative, and a dictionary holds few distinct pools (config 5: eight
+    // one-NIC pools per PCI-mode signature, a handful of kinds).  Per pod the digest forms each type's family and as many of its
+    // 2-, 3-, 4-fold unions as the dictionary asks for, each in a slot of LDS, and a signature is the list of the slots to unite:
+    // one union per distinct type instead of two per pool.  Stream layout: dict_stream.h.
     const uint16_t* flat2;
-    uint32_t flat2_words;            // 0: not available (more than kPoolTypes types, offsets beyond 16 bits)
+    uint32_t flat2_words;            // 0: not available (more than kPoolSlots slots, offsets beyond 16 bits)
 };
-constexpr uint32_t kPoolTypes = 32;                  // pool types whose unions a digest block keeps in LDS
+constexpr uint32_t kPoolSlots = 128;                 // unions a digest block keeps in LDS (x 64 pods x 2 bytes = 16 KB)
 
 // v_writelane_b32 (SGPR -> one lane of a VGPR).  This clang has no __builtin_amdgcn_writelane; the
 // asm label binds the declaration straight to the LLVM intrinsic, as the ROCm device libs do.
@@ -75,9 +73,9 @@ struct DigestArgs {
     uint32_t n_sig_list;
 };
 constexpr uint32_t kDictLdsWords = 6144;             // 12 KB for the staged signature stream (c5: 151 signatures = 1.5 K words)
-// the request copies come last: once the covers are formed they are dead, and the per-type unions (kPoolTypes x 4 x 64 x 2 bytes) take
+// the request copies come last: once the covers are formed they are dead, and the per-type unions (kPoolSlots x 64 x 2 bytes) take
 // their place plus the pad behind them
-constexpr size_t kPoolLds = (size_t)kPoolTypes * kMaxG * kTile * sizeof(uint16_t);
+constexpr size_t kPoolLds = (size_t)kPoolSlots * kTile * sizeof(uint16_t);
 constexpr size_t kDigestLds = lds_slice(kTile * sizeof(PodSums)) +
                               lds_slice(kTile * NHDFIT_MAX_CLASSES * (kMaxG + 1) * sizeof(uint16_t)) + lds_slice(kTile * sizeof(PodHeader)) +
                               lds_slice(kDictLdsWords * sizeof(uint16_t)) + 16 +    // (+ the last-arriver flag; no static LDS in the step kernel:
@@ -97,7 +95,7 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
     uint16_t* s_flat = carve<uint16_t>(lds, kDictLdsWords);
     uint32_t& s_last = *carve<uint32_t>(lds, 4);
     PaddedReq* s_req = reinterpret_cast<PaddedReq*>(lds);                 // (last: see kDigestLds)
-    uint16_t* s_pw = reinterpret_cast<uint16_t*>(lds);                    // [type][k][pod]: the (k + 1)-fold union of type's family - over s_req, after the covers
+    uint16_t* s_pw = reinterpret_cast<uint16_t*>(lds);                    // [slot][pod]: a pool type's family or one of its k-fold unions - over s_req, after the covers
 
     // blocks of a tile: sig_parts blocks for the GPU / NIC rows (part 0), then wc_parts blocks for the CPU rows (parts 1 ..)
     const uint32_t per_tile = a.sig_parts + a.wc_parts, tile = blk / per_tile, idx = blk % per_tile;
@@ -231,13 +229,14 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
         }
         __syncthreads();
         if (typed) {
-            // (A) every pool type's family and its 2-, 3-, 4-fold unions, lane = pod, a type per wavefront iteration
+            // (A) every pool type's family and the k-fold unions the dictionary asks for, lane = pod, a type per wavefront iteration
             auto bword = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flat[i]); };
             const uint32_t ntypes = bword(0), nsig_d = a.d.sig.nsig;
             const uint32_t t_off = 2, s_off = t_off + ntypes + 1, recs = s_off + nsig_d + 1;
             for (uint32_t t = wave; t < ntypes; t += NW) {
                 uint32_t at = recs + bword(t_off + t);
                 const uint32_t head = bword(at++), ncc = head & 0xFFu, glimit = head >> 8;
+                const uint32_t ks = bword(at++), kmax = ks >> 8, first = ks & 0xFFu;
                 uint32_t pool = 1;
                 for (uint32_t k = 0; k < ncc; ++k) {
                     const uint32_t e = bword(at++), cnt = e & 0xFFu, cls = e >> 8;
@@ -245,14 +244,13 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
                 }
                 if (glimit != NHDFIT_GLIMIT_NONE) pool &= size_le_mask(s_sum[lane].W, glimit);
                 uint32_t pw = pool;
-#pragma unroll
-                for (uint32_t k = 0; k < (uint32_t)kMaxG; ++k) {
-                    s_pw[(t * kMaxG + k) * kTile + lane] = (uint16_t)pw;          // (s_req is dead: the covers are formed, the barrier passed)
+                for (uint32_t k = 0; k < kmax; ++k) {
+                    s_pw[(first + k) * kTile + lane] = (uint16_t)pw;              // (s_req is dead: the covers are formed, the barrier passed)
                     pw = dunion_n<WW>(pw, pool);
                 }
             }
             __syncthreads();
-            // (B) a signature = the union over its (type, multiplicity) pairs; record offsets and records by bulk load + v_readlane
+            // (B) a signature = the union over its slots; record offsets and records by bulk load + v_readlane
             const uint32_t sig_first = sig_part * NW + wave, sig_step = a.sig_parts * NW;
             uint32_t offs_lo = 0, offs_hi = 0, seq = 0;
             const uint32_t n_sigs = a.sig_list ? a.n_sig_list : L.nsig;
@@ -268,14 +266,13 @@ __device__ __forceinline__ void role_digest(const DigestArgs& a, uint32_t blk, u
                 const uint32_t sig = (uint32_t)__builtin_amdgcn_readlane((int)sig_ids, (int)(seq & 63u));
                 const uint32_t rec0 = (uint32_t)__builtin_amdgcn_readlane((int)offs_lo, (int)(seq & 63u));
                 const uint32_t rec1 = (uint32_t)__builtin_amdgcn_readlane((int)offs_hi, (int)(seq & 63u));
-                const uint32_t len = rec1 - rec0;                                   // 1 + entries, <= 1 + kPoolTypes
+                const uint32_t len = rec1 - rec0;                                   // 1 + entries, <= 64 (dict_stream.h)
                 const uint32_t my_word = lane < len ? s_flat[recs + rec0 + lane] : 0u;
                 const uint32_t nent = (uint32_t)__builtin_amdgcn_readlane((int)my_word, 0);
                 uint32_t reach = 1;
                 for (uint32_t e = 0; e < nent; ++e) {
-                    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)my_word, (int)(1 + e));
-                    const uint32_t type = w >> 8, cnt = w & 0xFFu, k = (cnt > (uint32_t)kMaxG ? (uint32_t)kMaxG : cnt) - 1u;
-                    reach = dunion_n<WW>(reach, s_pw[(type * kMaxG + k) * kTile + lane]);
+                    const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)my_word, (int)(1 + e));
+                    reach = dunion_n<WW>(reach, s_pw[slot * kTile + lane]);
                 }
                 if (!valid) reach = 0;
                 emit_row(img + L.off_r0 + sig * L.row, valid ? entry_r(reach, s_sum[lane].W, 0) : 0u);

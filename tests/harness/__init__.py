@@ -17,7 +17,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    deps = [SRC] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "winner_map.h", "seq_core.h", "set_states.h", "commit_core.h", "wide_core.h")] + \
+    deps = [SRC] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "winner_map.h", "seq_core.h", "set_states.h", "commit_core.h", "wide_core.h", "dict_stream.h")] + \
            [os.path.join(HERE, "..", "..", "include", "nhdfit.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", SRC, "-o", SO])
@@ -49,8 +49,18 @@ def find(packer: pack.Packer, table: pack.NodeTable, reqs: np.ndarray, now: floa
               _p(gs), ctypes.c_uint32(len(packer.group_sets)), _p(caps), ctypes.c_uint32(ncls), _p(sig_off), ctypes.c_uint32(nsig), _p(pool_off), _p(glimit), _p(cc),
               _p(cand) if cand is not None else None, _p(score), _p(bitmap) if want_bitmap else None,
               _p(maps) if want_map else None, ctypes.c_int(int(force_generic)))
-    assert bad == 0, f"{bad} (node, tile) verdicts differ between the hot and the cold table section / the two forms of IsBusy"
+    assert bad == 0, f"{bad} verdicts differ between the hot and the cold table section / the six-fetch and the pair form of the sweep / the two forms of IsBusy / the pool-by-pool and the by-pool-type form of a signature's reach family"
     return score, bitmap, maps
+
+
+def typed_stream(packer: pack.Packer):
+    """(words, pool types) of the dictionary's stream by pool type as nhdfit_set_dictionary builds it (dict_stream.h); 0 words: not in use."""
+    L = lib()
+    caps, sig_off, pool_off, glimit, cc, ncls, nsig, npools, ncc = packer.dictionary_arrays()
+    nt = ctypes.c_uint32(0)
+    L.hh_typed_stream.restype = ctypes.c_int
+    words = L.hh_typed_stream(_p(sig_off), ctypes.c_uint32(nsig), _p(pool_off), _p(glimit), _p(cc), ctypes.byref(nt))
+    return int(words), int(nt.value)
 
 
 def find_lone(packer: pack.Packer, table: pack.NodeTable, reqs: np.ndarray, now: float, cand=None, global_base=0):

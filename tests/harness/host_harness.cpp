@@ -7,6 +7,7 @@
 #include <vector>
 #include "../../nhd_amd/csrc/seq_core.h"
 #include "../../nhd_amd/csrc/set_states.h"
+#include "../../nhd_amd/csrc/dict_stream.h"
 
 using namespace nhdfit;
 
@@ -22,7 +23,7 @@ struct Dict {
 
 // table image of one tile (up to 64 pods): the bytes the digest role produces, built pod by pod
 void build_tile(const nhdfit_req* reqs, uint32_t npods, const Dict& d, const Layout& L, const std::vector<uint64_t>& xcls,
-                uint8_t* img, PodHeader* hdr) {
+                uint8_t* img, PodHeader* hdr, const std::vector<uint16_t>* typed = nullptr, int* typed_mismatches = nullptr) {
     std::memset(img, 0, L.bytes);
     std::vector<uint16_t> cover(d.ncls * (kMaxG + 1));
     uint8_t* hot = img + L.off_hot;
@@ -53,6 +54,7 @@ void build_tile(const nhdfit_req* reqs, uint32_t npods, const Dict& d, const Lay
             for (uint32_t f = 0; f < L.fg_dim; ++f) set_bits(img + (u ? L.off_a1 : L.off_a0) + f * L.row, entry_a(s, u, f), j);
         for (uint32_t sig = 0; sig < L.nsig; ++sig) {
             const uint32_t reach = sig_reach(d.sig, sig, cover.data(), s.W);
+            if (typed && !typed->empty() && typed_reach(typed->data(), L.nsig, sig, cover.data(), s.W) != reach) ++*typed_mismatches;   // the digest's form by pool type
             set_bits(img + L.off_r0 + sig * L.row, entry_r(reach, s.W, 0), j);
             set_bits(img + L.off_r1 + sig * L.row, entry_r(reach, s.W, 1), j);
         }
@@ -70,6 +72,14 @@ void build_tile(const nhdfit_req* reqs, uint32_t npods, const Dict& d, const Lay
 }  // namespace
 
 extern "C" {
+
+// words of the dictionary's stream by pool type (dict_stream.h), pool types in it; 0 words: the dictionary does not fit the format
+int hh_typed_stream(const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit, const nhdfit_cc* cc,
+                    uint32_t* ntypes) {
+    const std::vector<uint16_t> f2 = build_typed_stream(SigDict{sig_off, pool_off, pool_glimit, cc, nsig});
+    if (ntypes) *ntypes = f2.empty() ? 0u : f2[0];
+    return (int)f2.size();
+}
 
 // CPU twin of nhdfit_find (mode A), same outputs, chunk-major bitmap [ceil(n/64)][P].  cand: [chunks] node mask.
 // Returns the number of (node, tile) pairs whose hot-section verdict differs from the cold-section one (must be 0).
@@ -101,6 +111,7 @@ int hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane
     const uint32_t x_cap = x_capacity((uint32_t)xcls.size());
     const double busy_from = busy_threshold(now);
     int mismatches = 0;
+    const std::vector<uint16_t> typed_stream = build_typed_stream(d.sig);      // (empty: the dictionary does not fit the format)
     std::vector<uint8_t> img;
     std::vector<PodHeader> hdr(kTile);
     std::vector<uint8_t> tile_wcls((P + kTile - 1) / kTile, 0);
@@ -112,7 +123,7 @@ int hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane
         const uint32_t np = P - t0 < (uint32_t)kTile ? P - t0 : kTile;
         const Layout L = make_layout(2u << tile_wcls[t0 / kTile], fcmax, fgmax, nsig, ngs, (uint32_t)hpmax + 2, x_cap);
         img.assign(L.bytes, 0);
-        build_tile(reqs + t0, np, d, L, xcls, img.data(), hdr.data());
+        build_tile(reqs + t0, np, d, L, xcls, img.data(), hdr.data(), &typed_stream, &mismatches);
         uint64_t m_need = 0, m_pci = 0;
         for (uint32_t j = 0; j < np; ++j) {
             if (hdr[j].flags & kPodNeedGpu) m_need |= 1ull << j;

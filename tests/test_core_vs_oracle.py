@@ -148,3 +148,26 @@ def test_hot_and_cold_table_sections_agree_on_heterogeneous_clusters():
     rng = np.random.default_rng(5)
     reqs = pk.digest_many([refmodel.make_topology(util.random_pod_spec(rng, max_groups=4)) for _ in range(70)])
     harness.find(pk, t, reqs, util.CLOCK, want_map=False)
+
+
+def test_digest_forms_agree_on_a_closed_config5_dictionary():
+    """The digest's signature rows by pool type (dict_stream.h: (type, multiplicity) pairs, k-fold unions per type) and the fit
+    role's pair rows against the plain forms, on config 5's dictionary closed under claims (272 signatures, eight one-NIC pools per
+    PCI-mode signature) - the harness counts every disagreement (harness.find asserts zero) - and the typed stream really is in use."""
+    import ctypes
+    from nhd_amd import pack
+    from workload import planes, refmodel, synth
+    from tests import harness
+    spec = synth.make_cluster(5, n_nodes=1536)
+    pods, groups = synth.make_pods(5, n_pods=150)
+    tops = [refmodel.make_topology(s) for s in pods]
+    pk = pack.Packer()
+    table = planes.planes_from_spec(pk, spec)
+    reqs = pk.digest_many(tops, groups)
+    before = len(pk.sigs)
+    pk.close_signatures()
+    assert len(pk.sigs) > before + 50                           # the closure added states no node is in
+    words, ntypes = harness.typed_stream(pk)
+    assert 0 < words <= 6144 and ntypes >= 4, (words, ntypes)   # in use on the device: the stream fits the digest block's LDS
+    score, _, _ = harness.find(pk, table, reqs, spec.clock_now, want_bitmap=False)
+    assert (score != 0).sum() > 50

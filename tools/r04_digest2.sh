@@ -24,7 +24,7 @@ done
 echo "== single find"; timeout 200 python tools/time_single_find.py | tail -1
 echo "== mode B c4"; timeout 300 python tools/time_mode_b.py 65536 4096 4 2>&1 | tail -1
 TL=$ROOT/nhd_amd/libnhdfit_tuning.so
-for np in 2 3 4; do echo "== tuning build NHDFIT_PIPES=$np config 4"; NHDFIT_LIBRARY=$TL NHDFIT_PIPES=$np timeout 300 python bench.py $B --config 4 --nodes-per-gpu 65536 --pods 4096 2>/dev/null | line; done
+for fb in 512 1024 2048; do echo "== tuning build NHDFIT_FIT_BLOCKS=$fb c5 x 16384"; NHDFIT_LIBRARY=$TL NHDFIT_FIT_BLOCKS=$fb timeout 300 python bench.py $B --config 5 --nodes-per-gpu 32768 --pods 16384 2>/dev/null | line; done
 echo "== tuning build NHDFIT_ALL_SIGS=1 c5 x 16384"; NHDFIT_LIBRARY=$TL NHDFIT_ALL_SIGS=1 timeout 300 python bench.py $B --config 5 --nodes-per-gpu 32768 --pods 16384 2>/dev/null | line
 } 2>&1 | tee $OUT/times.log
 echo "seconds=$SECONDS"
