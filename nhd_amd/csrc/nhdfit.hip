@@ -850,6 +850,7 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
     // 2 300 blocks of eight chunks per wavefront spent a fifth of the step doing that.
     const uint64_t rec_bytes = (uint64_t)chunks * 64u * (16u * (c->max_wcls + 1u) + 8u);
     const bool small_shard = rec_bytes <= (2u << 20);
+    if (small_shard && nw == 8 && !c->fit_blocks) target = cus;          // (config 5 shard x 16 384 pods: 256 blocks 44.9 us per step, 512: 45.9, 1 024: 47.6, 2 048: 51.7)
     const bool by_xcd = xcd_items && !c->fit_blocks && chunks >= 8u * 4u * nw && nw == 8 && !small_shard;
     for (uint32_t t = 0; t < tiles; ++t) {           // staged order = widest tiles first
         const uint32_t w = c->h_tile_wcls[t];
