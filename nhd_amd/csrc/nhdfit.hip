@@ -200,8 +200,9 @@ struct nhdfit_ctx {
     // tiles of that width, and what refresh_layouts makes of it - table dimension D (0: off) and XX dimension (0: off)
     uint32_t max_demand[2] = {0, 0};
     uint32_t pair_D[2] = {0, 0}, pair_xx[2] = {0, 0};
-    bool pair_rows = !(tune_env("NHDFIT_PAIR") && atoi(tune_env("NHDFIT_PAIR")) == 0);   // tuning aid: NHDFIT_PAIR=0 keeps the six-fetch sweep; 1 = C only
-    bool pair_xx_ok = !(tune_env("NHDFIT_PAIR") && atoi(tune_env("NHDFIT_PAIR")) == 1);
+    bool pair_rows = !(tune_env("NHDFIT_PAIR") && atoi(tune_env("NHDFIT_PAIR")) == 0);   // tuning aid: NHDFIT_PAIR=0 keeps the six-fetch sweep; 2 = C and XX
+    bool pair_xx_ok = tune_env("NHDFIT_PAIR") && atoi(tune_env("NHDFIT_PAIR")) == 2;   // XX is built and measured (15.64 us per step against 15.52 with C alone:
+                                                                                             // its 1 024-row derivation per block costs what the saved fetch gives) - off; NHDFIT_PAIR=2 in the tuning build
 
     // requests / results
     DevBuf<nhdfit_req> reqs; uint32_t P = 0;
@@ -1209,8 +1210,9 @@ int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
 int nhdfit_sync(nhdfit_ctx* c) {
     if (!c) return NHDFIT_E_INVAL;
     HIPCHK(c, hipSetDevice(c->dev));
-    { int rc_ = sync_all(c); if (rc_) return rc_; }
-    return drain_events(c);
+    // (the HIP events of the sampled launches are read where the statistics are asked for, nhdfit_get_stats - a few
+    // hipEventElapsedTime calls are ~10 us, half a microsecond per step of a 20-step region, and nobody waiting here wants them)
+    return sync_all(c);
 }
 
 int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out) {
@@ -2134,6 +2136,11 @@ int nhdfit_group_find(nhdfit_group* g, const nhdfit_req* reqs, uint32_t P, doubl
 
 int nhdfit_get_stats(nhdfit_ctx* c, nhdfit_stats* out) {
     if (!c || !out) return NHDFIT_E_INVAL;
+    if (c->ev_pending) {                                    // sampled launches whose events have not been read yet (waits for them if need be)
+        HIPCHK(c, hipSetDevice(c->dev));
+        int rc = drain_events(c);
+        if (rc) return rc;
+    }
     *out = c->stats;
     return NHDFIT_OK;
 }
@@ -2141,6 +2148,7 @@ int nhdfit_get_stats(nhdfit_ctx* c, nhdfit_stats* out) {
 int nhdfit_reset_stats(nhdfit_ctx* c) {
     if (!c) return NHDFIT_E_INVAL;
     int rc = nhdfit_sync(c);
+    if (!rc) rc = drain_events(c);
     if (rc) return rc;
     c->stats.launches = 0;
     c->stats.fit_ms_total = 0;
