@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-#define NHDFIT_ABI_VERSION        7
-#define NHDFIT_MAX_GROUPS         4      /* proc groups per pod (G)                               */
+#define NHDFIT_ABI_VERSION        8
+#define NHDFIT_MAX_GROUPS         4      /* proc groups per pod (G) of the table-driven pass; 5..8: nhdfit_big_req below */
 #define NHDFIT_MAX_NUMA           2      /* NUMA nodes (= sockets, nhd/Node.py:336) per node (U)  */
 #define NHDFIT_MAX_CORES_PER_NUMA 64     /* physical cores per socket (one uint64 mask)           */
 #define NHDFIT_MAX_GPUS           32     /* GPUs per node (one uint32 mask)                       */
@@ -256,6 +256,61 @@ typedef struct {
     uint32_t node;                            /* ... and the local index of the node                    */
 } nhdfit_wide_placement;                      /* 480 bytes */
 
+/* ---- pods with more than NHDFIT_MAX_GROUPS processing groups: the general path for requests ("big" requests) ---------------
+ * The reference enumerates itertools.product(range(numa_nodes), repeat=len(req)) for whatever len(top.proc_groups) is
+ * (nhd/Matcher.py:118,203,242).  The table-driven pass is built around masks over 2^G <= 16 assignments; a pod with 5..8
+ * processing groups is carried as a record of its own kind and answered by the general path - explicit enumeration with the
+ * reference's own arithmetic (wide_core.h), lane = node, against EVERY node of the mirror (ordinary nodes are read through the
+ * same view a wide node's record gives) - its winner by the same score word, its mapping from the general CPython set model,
+ * its commit step on whichever form the winner is mirrored in.  Every node either layout holds (<= 4 sockets) answers for any
+ * G <= 8: up to NHDFIT_BIG_MAX_TUPLES = 4^9 assignment tuples, the set model's tables sized per call.  One bound: a search
+ * budget per (pod, node) for the NIC stage (NHDFIT_BIG_NIC_BUDGET steps of the pruned depth-first search; the reference's own
+ * enumeration at such a pair is K^G deepcopies): exceeding it fails the call (NHDFIT_E_LIMIT), it is never answered wrong. */
+#define NHDFIT_BIG_MAX_GROUPS     8
+#define NHDFIT_BIG_MAX_TUPLES     262144
+#define NHDFIT_BIG_NIC_BUDGET     (1u << 22)
+typedef struct {
+    uint32_t n_groups;                           /* len(top.proc_groups), 1..NHDFIT_BIG_MAX_GROUPS                       */
+    uint32_t map_type;
+    int32_t  hugepages_gb;
+    uint32_t flags;                              /* NHDFIT_RF_*                                                          */
+    uint64_t groups;
+    uint16_t gpus[NHDFIT_BIG_MAX_GROUPS];
+    uint16_t cpu_smt[NHDFIT_BIG_MAX_GROUPS];
+    uint16_t cpu_nosmt[NHDFIT_BIG_MAX_GROUPS];
+    uint16_t misc_smt, misc_nosmt;
+    uint16_t smt_bits;                           /* bit g: group g proc_smt enabled; bit 8+g: helper_smt enabled          */
+    uint8_t  n_misc;
+    uint8_t  misc_smt_enabled;
+    double   rx[NHDFIT_BIG_MAX_GROUPS];
+    double   tx[NHDFIT_BIG_MAX_GROUPS];
+    uint8_t  n_proc[NHDFIT_BIG_MAX_GROUPS];
+    uint8_t  n_help[NHDFIT_BIG_MAX_GROUPS];
+    uint8_t  nic_use;                            /* bit g: group g has RX/TX cores                                       */
+    uint8_t  pad[31];
+} nhdfit_big_req;                                /* 256 bytes; field for field nhdfit_req with eight groups               */
+typedef struct {
+    int8_t gpu[NHDFIT_BIG_MAX_GROUPS];
+    int8_t cpu[NHDFIT_BIG_MAX_GROUPS + 1];
+    int8_t nic_numa[NHDFIT_BIG_MAX_GROUPS];
+    int8_t nic_idx[NHDFIT_BIG_MAX_GROUPS];
+    int8_t valid;
+    int8_t pad[2];
+} nhdfit_big_mapping;                            /* 36 bytes */
+/* physical ids of a big request's placement: nhdfit_wide_placement with eight groups (an ordinary node uses word 0 of each pair) */
+typedef struct {
+    uint64_t proc_take[NHDFIT_BIG_MAX_GROUPS][2], proc_pair[NHDFIT_BIG_MAX_GROUPS][2], proc_late[NHDFIT_BIG_MAX_GROUPS][2];
+    uint64_t help_take[NHDFIT_BIG_MAX_GROUPS][2], help_pair[NHDFIT_BIG_MAX_GROUPS][2], help_late[NHDFIT_BIG_MAX_GROUPS][2];
+    uint64_t misc_take[2], misc_pair[2], misc_late[2];
+    uint8_t  gpu[NHDFIT_BIG_MAX_GROUPS][NHDFIT_PLACEMENT_GPUS];
+    int8_t   numa[NHDFIT_BIG_MAX_GROUPS + 1];
+    uint8_t  status;                             /* NHDFIT_COMMIT_OK / _WOULD_RAISE / _NEW_SIG (ordinary node: as nhdfit_commit) */
+    uint8_t  pad[2];
+    uint32_t pod;
+    uint32_t node;
+    uint8_t  pad2[4];
+} nhdfit_big_placement;                          /* 904 bytes */
+
 typedef struct {
     uint64_t launches;          /* step-kernel launches carrying a fit role that were timed (every 8th step)   */
     double   fit_ms_total;      /* sum of their HIP-event durations (ms): the whole fused launch - fit role plus
@@ -320,6 +375,15 @@ int nhdfit_wide_commit(nhdfit_ctx* ctx, uint32_t node, const nhdfit_req* req, co
 /* placements nhdfit_schedule_batch's last call made on wide nodes (their nhdfit_placement entries carry status
  * NHDFIT_COMMIT_WIDE): up to `cap` records, *n = how many there are */
 int nhdfit_wide_placements(nhdfit_ctx* ctx, nhdfit_wide_placement* out, uint32_t cap, uint32_t* n);
+
+/* FindNode for `P` big requests (mode A: one snapshot), every node of the mirror - ordinary and wide - by the general path.
+ * cand / score_out / map_out as nhdfit_find (the score word is the same: with a communicator attached the P words are
+ * all-reduced(max) and the owner of each winner maps it).  NHDFIT_E_LIMIT: a (pod, node) pair ran out of NIC search budget. */
+int nhdfit_big_find(nhdfit_ctx* ctx, const nhdfit_big_req* reqs, uint32_t P, double now, const uint64_t* cand,
+                    uint64_t* score_out, nhdfit_big_mapping* map_out);
+/* nhdfit_commit / nhdfit_wide_commit for a big request, on whichever form `node` (local index) is mirrored in */
+int nhdfit_big_commit(nhdfit_ctx* ctx, uint32_t node, const nhdfit_big_req* req, const nhdfit_big_mapping* map, double busy_time,
+                      nhdfit_big_placement* place_out);
 
 /* The nhdfit_origin records of nodes [first, first+count) (needed by nhdfit_apply_deltas; uploaded next to the planes). */
 int nhdfit_upload_origin(nhdfit_ctx* ctx, uint32_t first, uint32_t count, const nhdfit_origin* origin);

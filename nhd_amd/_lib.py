@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # NHDFIT_LIBRARY: load another build of the same ABI instead (tools/: the tuning build libnhdfit_tuning.so)
 LIB_PATH = os.environ.get("NHDFIT_LIBRARY") or os.path.join(HERE, "libnhdfit.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nhdfit.h")
-ABI_VERSION = 7                  # NHDFIT_ABI_VERSION of include/nhdfit.h this binding (and pack.py's record layouts) is written for
+ABI_VERSION = 8                  # NHDFIT_ABI_VERSION of include/nhdfit.h this binding (and pack.py's record layouts) is written for
 
 
 class NhdFitError(RuntimeError):
@@ -50,6 +50,8 @@ _SIGS = {
     "nhdfit_wide_download": (c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]),
     "nhdfit_wide_commit": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_double, c_void_p]),
     "nhdfit_wide_placements": (c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]),
+    "nhdfit_big_find": (c_int, [c_void_p, c_void_p, c_uint32, c_double, c_void_p, c_void_p, c_void_p]),
+    "nhdfit_big_commit": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_double, c_void_p]),
     "nhdfit_download_nodes": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nhdfit_stage_requests": (c_int, [c_void_p, c_void_p, c_uint32]),
     "nhdfit_enqueue_step": (c_int, [c_void_p, c_double]),

@@ -156,16 +156,23 @@ NHD_HD int pods_add(nhdfit_detail& d, uint32_t u, uint32_t k, int delta) {
 }
 
 // One placement on one node.  `s` / `d` are modified in place; `out` receives the physical ids.
-NHD_HD int commit_node(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, const nhdfit_mapping& m, double busy_time,
-                       const SigTable& sigs, nhdfit_placement& out) {
+// Written over both request forms (fit_core.h req_traits): a big request's placement record carries two mask words per batch
+// (nhdfit_big_placement, shared with the wide nodes) of which a node of the planes fills word 0.
+NHD_HD uint64_t& batch_mask(uint64_t& m) { return m; }
+NHD_HD uint64_t& batch_mask(uint64_t (&m)[2]) { m[1] = 0; return m[0]; }
+template <class R, class PL>
+NHD_HD int commit_node_t(NodeState& s, nhdfit_detail& d, const R& r, const typename req_traits<R>::Mapping& m, double busy_time,
+                         const SigTable& sigs, PL& out) {
+    constexpr int kMaxG = req_traits<R>::kG;                                        // (per request form; shadows the table pass's constant)
     const int G = (int)r.n_groups;
     int status = kCommitOk;
     for (int g = 0; g < kMaxG; ++g) {
-        out.proc_take[g] = out.proc_pair[g] = out.help_take[g] = out.help_pair[g] = out.proc_late[g] = out.help_late[g] = 0;
+        batch_mask(out.proc_take[g]) = batch_mask(out.proc_pair[g]) = batch_mask(out.help_take[g]) = batch_mask(out.help_pair[g]) =
+            batch_mask(out.proc_late[g]) = batch_mask(out.help_late[g]) = 0;
         for (int k = 0; k < NHDFIT_PLACEMENT_GPUS; ++k) out.gpu[g][k] = 0xFF;
         out.numa[g] = -1;
     }
-    out.misc_take = out.misc_pair = out.misc_late = 0;
+    batch_mask(out.misc_take) = batch_mask(out.misc_pair) = batch_mask(out.misc_late) = 0;
     out.numa[kMaxG] = -1;
     out.pad[0] = out.pad[1] = 0;
     s.p4.busy_time = busy_time;                                                     // SetBusy, nhd/Node.py:843-845
@@ -174,7 +181,7 @@ NHD_HD int commit_node(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, cons
     for (int g = 0; g < G; ++g) {
         const uint32_t u = (uint32_t)m.gpu[g] & 1u;
         out.numa[g] = (int8_t)u;
-        if (!take_batch(s, u, r.n_proc[g], (r.smt_bits >> g & 1) != 0, out.proc_take[g], out.proc_pair[g], out.proc_late[g])) status = kCommitWouldRaise;
+        if (!take_batch(s, u, r.n_proc[g], (r.smt_bits >> g & 1) != 0, batch_mask(out.proc_take[g]), batch_mask(out.proc_pair[g]), batch_mask(out.proc_late[g]))) status = kCommitWouldRaise;
         const uint32_t nu = (uint32_t)m.nic_numa[g] & 1u, nk = (uint32_t)m.nic_idx[g] & 15u;
         const uint32_t sw = d.nic_sw[nu][nk];
         for (uint32_t k = 0; k < r.gpus[g]; ++k) {
@@ -190,13 +197,13 @@ NHD_HD int commit_node(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, cons
             gpu_taken = true;
             if (k < (uint32_t)NHDFIT_PLACEMENT_GPUS) out.gpu[g][k] = (uint8_t)pick;
         }
-        if (!take_batch(s, u, r.n_help[g], (r.smt_bits >> (4 + g) & 1) != 0, out.help_take[g], out.help_pair[g], out.help_late[g])) status = kCommitWouldRaise;
+        if (!take_batch(s, u, r.n_help[g], (r.smt_bits >> (kMaxG + g) & 1) != 0, batch_mask(out.help_take[g]), batch_mask(out.help_pair[g]), batch_mask(out.help_late[g]))) status = kCommitWouldRaise;
         if (r.nic_use >> g & 1) { if (nu) claimed1 |= 1u << nk; else claimed0 |= 1u << nk; }
     }
     if (r.hugepages_gb > 0) s.p2.hp_free -= r.hugepages_gb;                        // Node.py:794-796
     const uint32_t mu = (uint32_t)m.cpu[G] & 1u;
     out.numa[kMaxG] = (int8_t)mu;
-    if (!take_batch(s, mu, r.n_misc, r.misc_smt_enabled != 0, out.misc_take, out.misc_pair, out.misc_late)) status = kCommitWouldRaise;   // Node.py:799
+    if (!take_batch(s, mu, r.n_misc, r.misc_smt_enabled != 0, batch_mask(out.misc_take), batch_mask(out.misc_pair), batch_mask(out.misc_late))) status = kCommitWouldRaise;   // Node.py:799
     // ClaimPodNICResources: pods_used += 1; the capacity class is 0 (= 0.0) while pods_used > 0 (Node.py:292, 644-646).
     // A counter that is already out of the tracked range keeps its class: it left the range on the side its class
     // says (free: pods_used < -3, used: > 3), and one more pod does not bring it back across zero.
@@ -217,6 +224,10 @@ NHD_HD int commit_node(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, cons
     }
     out.status = (uint8_t)status;
     return status;
+}
+NHD_HD int commit_node(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, const nhdfit_mapping& m, double busy_time,
+                       const SigTable& sigs, nhdfit_placement& out) {
+    return commit_node_t<nhdfit_req, nhdfit_placement>(s, d, r, m, busy_time, sigs, out);
 }
 
 // ---- K3: one delta on one node ---------------------------------------------------------

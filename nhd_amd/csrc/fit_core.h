@@ -156,6 +156,31 @@ NHD_HD bool req_valid(const nhdfit_req& r) {
            r.n_groups <= (uint32_t)kMaxG;
 }
 
+// ---- the two request forms (include/nhdfit.h): nhdfit_req - the table-driven pass, G <= 4 - and nhdfit_big_req - 5..8
+// processing groups, answered by the general path only (wide_core.h).  The general path is written once over both.
+template <class R> struct req_traits;
+template <> struct req_traits<nhdfit_req> {
+    static constexpr int kG = NHDFIT_MAX_GROUPS;
+    static constexpr bool kBig = false;
+    using Key = int16_t;                                  // tuple codes of the general path's set model (wide_core.h): U^(G+1) <= 4^5
+    static constexpr int kMaxTuples = 1024;
+    using Mapping = nhdfit_mapping;
+    using WidePlacement = nhdfit_wide_placement;
+};
+template <> struct req_traits<nhdfit_big_req> {
+    static constexpr int kG = NHDFIT_BIG_MAX_GROUPS;
+    static constexpr bool kBig = true;
+    using Key = int32_t;                                  // ... <= 4^9
+    static constexpr int kMaxTuples = NHDFIT_BIG_MAX_TUPLES;
+    using Mapping = nhdfit_big_mapping;
+    using WidePlacement = nhdfit_big_placement;
+};
+static_assert(sizeof(nhdfit_big_req) == 256 && sizeof(nhdfit_big_mapping) == 36 && sizeof(nhdfit_big_placement) == 904, "record sizes of include/nhdfit.h");
+NHD_HD bool req_valid(const nhdfit_big_req& r) {
+    return (r.map_type == NHDFIT_MAP_NUMA || r.map_type == NHDFIT_MAP_PCI) && r.n_groups >= 1 &&
+           r.n_groups <= (uint32_t)NHDFIT_BIG_MAX_GROUPS;
+}
+
 NHD_HD void pod_sums(const nhdfit_req& r, PodSums& s) {
     s.G = r.n_groups;
     s.W = 1u << s.G;

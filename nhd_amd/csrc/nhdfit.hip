@@ -57,6 +57,7 @@ namespace {
 #include "seq_kernel.h"
 #include "seq2_kernel.h"
 #include "wide_kernel.h"
+#include "big_kernel.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -256,6 +257,10 @@ struct nhdfit_ctx {
     DevBuf<int16_t> wide_scratch; DevBuf<uint32_t> wide_flags; DevBuf<nhdfit_wide_placement> wide_place;
     std::vector<nhdfit_wide_placement> wide_places_last;   // placements the last nhdfit_schedule_batch made on wide nodes
     std::vector<uint32_t> wide_index;                      // host copy of the records' node indices (ascending)
+    // big requests (5..8 processing groups, big_kernel.h): buffers of nhdfit_big_find / nhdfit_big_commit
+    DevBuf<nhdfit_big_req> big_reqs; DevBuf<unsigned long long> big_score; DevBuf<nhdfit_big_mapping> big_maps;
+    DevBuf<uint32_t> big_flags; DevBuf<nhdfit_big_placement> big_place; DevBuf<uint64_t> big_cand; DevBuf<int32_t> big_scratch;
+    uint32_t wide_max_numa = 0;                            // most sockets among the wide records (sizes a big request's set tables)
     int wide_slot(uint32_t node) const {
         auto it = std::lower_bound(wide_index.begin(), wide_index.end(), node);
         return it != wide_index.end() && *it == node ? (int)(it - wide_index.begin()) : -1;
@@ -419,6 +424,8 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->origin.release(); c->deltas.release(); c->delta_run.release(); c->delta_status.release();
     c->wide.release(); c->wide_scratch.release(); c->wide_flags.release(); c->wide_place.release();
+    c->big_reqs.release(); c->big_score.release(); c->big_maps.release(); c->big_flags.release(); c->big_place.release();
+    c->big_cand.release(); c->big_scratch.release();
     if (c->find_host) (void)hipHostFree(c->find_host);
     c->find_host = nullptr; c->find_sync.release(); c->find_red.release();
     c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
@@ -1512,6 +1519,8 @@ int nhdfit_wide_upload(nhdfit_ctx* c, uint32_t first, uint32_t count, const nhdf
     HIPCHK(c, c->wide.reserve(next.size() ? next.size() : 1));
     if (!next.empty()) HIPCHK(c, hipMemcpy(c->wide.p, next.data(), next.size() * sizeof next[0], hipMemcpyHostToDevice));
     c->n_wide = (uint32_t)next.size();
+    c->wide_max_numa = 0;
+    for (const auto& w : next) c->wide_max_numa = std::max<uint32_t>(c->wide_max_numa, w.numa_nodes);
     c->wide_index.resize(next.size());
     for (size_t j = 0; j < next.size(); ++j) c->wide_index[j] = next[j].index;
     return NHDFIT_OK;
@@ -1542,6 +1551,107 @@ int nhdfit_wide_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_req* req, cons
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(place_out, c->wide_place.p, sizeof *place_out, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NHDFIT_OK;
+}
+
+// ---- big requests: pods with 5..8 processing groups, the general path over every node (big_kernel.h) ------------------------
+int nhdfit_big_find(nhdfit_ctx* c, const nhdfit_big_req* reqs, uint32_t P, double now, const uint64_t* cand,
+                    uint64_t* score_out, nhdfit_big_mapping* map_out) {
+    if (!c || !reqs || !P || !score_out) return NHDFIT_E_INVAL;
+    if (P > 65535u) return fail(c, NHDFIT_E_LIMIT, "%u big requests in one call (<= 65535)", P);
+    if (c->n && !c->ncls) return fail(c, NHDFIT_E_STATE, "set the dictionary first (nhdfit_set_dictionary: the NIC capacity classes)");
+    HIPCHK(c, hipSetDevice(c->dev));
+    { int rc_ = sync_all(c); if (rc_) return rc_; }             // (a rare call: no need to run beside steps in flight)
+    const size_t chunks = (c->n + 63) / 64;
+    HIPCHK(c, c->big_reqs.reserve(P));
+    HIPCHK(c, c->big_score.reserve(P));
+    HIPCHK(c, c->big_maps.reserve(P));
+    HIPCHK(c, c->big_flags.reserve(4));
+    HIPCHK(c, hipMemcpyAsync(c->big_reqs.p, reqs, (size_t)P * sizeof *reqs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->big_score.p, 0, (size_t)P * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->big_flags.p, 0, 4 * sizeof(uint32_t), c->stream));
+    if (cand && chunks) {
+        HIPCHK(c, c->big_cand.reserve(chunks));
+        HIPCHK(c, hipMemcpyAsync(c->big_cand.p, cand, chunks * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    }
+    const uint32_t units = c->n + c->n_wide;
+    if (units) {
+        BigEvalArgs ea;
+        memset(&ea, 0, sizeof ea);
+        ea.p0 = c->p0.p; ea.p1 = c->p1.p; ea.p2 = c->p2.p; ea.p3 = c->p3.p; ea.p4 = c->p4.p; ea.det = c->det.p; ea.n = c->n;
+        ea.wide = c->wide.p; ea.n_wide = c->n_wide; ea.reqs = c->big_reqs.p; ea.P = P; ea.caps = c->caps.p; ea.busy_from = busy_threshold(now);
+        ea.cand = cand && chunks ? c->big_cand.p : nullptr; ea.score = c->big_score.p; ea.global_base = c->global_base; ea.flags = c->big_flags.p;
+        hipLaunchKernelGGL(k_big_eval, dim3((units + 63) / 64, P), dim3(64), 0, c->stream, ea);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (c->comm) {      // sharded: one all-reduce(max) of the P packed scores picks the cluster's winners; the owner maps (k_big_map skips the rest)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        ncclResult_t r = g_rccl.AllReduce(c->big_score.p, c->big_score.p, P, ncclUint64, ncclMax, c->comm, c->s_red);
+        if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+        HIPCHK(c, hipStreamSynchronize(c->s_red));
+    }
+    if (map_out && c->n) {
+        // set tables of one mapping: sized for the call's largest group count on the mirror's widest node (2 sockets, 8 groups:
+        // 6 x 512 + 2 x 2 048 words; 4 sockets, 8 groups: 6 x 262 144 + 2 x 1 048 576); as many mappings at a time as 1 GiB holds
+        uint32_t gmax = 1;
+        for (uint32_t i = 0; i < P; ++i) gmax = std::max(gmax, std::min<uint32_t>(reqs[i].n_groups, NHDFIT_BIG_MAX_GROUPS));
+        const uint32_t umax = std::max<uint32_t>(NHDFIT_MAX_NUMA, c->n_wide ? c->wide_max_numa : 0);
+        const size_t stride = big_scratch_words(umax, gmax);
+        const uint32_t workers = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(P, 128), ((size_t)1 << 28) / stride));
+        HIPCHK(c, c->big_scratch.reserve((size_t)workers * stride));
+        BigMapArgs ma;
+        memset(&ma, 0, sizeof ma);
+        ma.p0 = c->p0.p; ma.p1 = c->p1.p; ma.p2 = c->p2.p; ma.p3 = c->p3.p; ma.p4 = c->p4.p; ma.det = c->det.p; ma.n = c->n;
+        ma.wide = c->wide.p; ma.n_wide = c->n_wide; ma.reqs = c->big_reqs.p; ma.P = P; ma.caps = c->caps.p;
+        ma.score = c->big_score.p; ma.global_base = c->global_base; ma.out = c->big_maps.p; ma.scratch = c->big_scratch.p; ma.flags = c->big_flags.p;
+        ma.stride = stride; ma.slots_g = (int32_t)wide_table_slots(wide_ipow(umax, gmax)); ma.slots_c = (int32_t)wide_table_slots(wide_ipow(umax, gmax + 1)); ma.workers = workers;
+        hipLaunchKernelGGL(k_big_map, dim3((workers + 63) / 64), dim3(64), 0, c->stream, ma);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(map_out, c->big_maps.p, (size_t)P * sizeof *map_out, hipMemcpyDeviceToHost, c->stream));
+    } else if (map_out) {
+        memset(map_out, 0, (size_t)P * sizeof *map_out);
+    }
+    uint32_t fl[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(score_out, c->big_score.p, (size_t)P * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(fl, c->big_flags.p, sizeof fl, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (fl[1]) return fail(c, NHDFIT_E_LIMIT, "a big request's NIC stage ran out of search budget on some node (%u steps per pod and node)", (unsigned)NHDFIT_BIG_NIC_BUDGET);
+    if (fl[0]) return fail(c, NHDFIT_E_LIMIT, "the set model of a big request's mapping outgrew its table");
+    return NHDFIT_OK;
+}
+
+int nhdfit_big_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_big_req* req, const nhdfit_big_mapping* map, double busy_time,
+                      nhdfit_big_placement* place_out) {
+    if (!c || !req || !map || !place_out) return NHDFIT_E_INVAL;
+    if (node >= c->n) return fail(c, NHDFIT_E_INVAL, "node %u out of range (%u nodes)", node, c->n);
+    if (!map->valid) return fail(c, NHDFIT_E_INVAL, "the mapping is not valid");
+    if (!req_valid(*req)) return fail(c, NHDFIT_E_INVAL, "the request is not valid (map type NUMA / PCI, 1..%d proc groups)", NHDFIT_BIG_MAX_GROUPS);
+    const int slot = c->wide_slot(node);
+    const int numa_lim = slot >= 0 ? NHDFIT_WIDE_MAX_NUMA : NHDFIT_MAX_NUMA;
+    for (uint32_t g = 0; g <= req->n_groups; ++g) {
+        if (map->cpu[g] < 0 || map->cpu[g] >= numa_lim) return fail(c, NHDFIT_E_INVAL, "mapping: cpu[%u] = %d is not a NUMA node", g, (int)map->cpu[g]);
+        if (g == req->n_groups) break;
+        if (map->gpu[g] < 0 || map->gpu[g] >= numa_lim || map->nic_numa[g] < 0 || map->nic_numa[g] >= numa_lim)
+            return fail(c, NHDFIT_E_INVAL, "mapping: group %u sits on NUMA node %d / its NIC on %d", g, (int)map->gpu[g], (int)map->nic_numa[g]);
+        if (map->nic_idx[g] < 0 || map->nic_idx[g] >= NHDFIT_MAX_NICS_PER_NUMA)
+            return fail(c, NHDFIT_E_INVAL, "mapping: group %u uses NIC ordinal %d", g, (int)map->nic_idx[g]);
+    }
+    HIPCHK(c, hipSetDevice(c->dev));
+    { int rc_ = sync_all(c); if (rc_) return rc_; }             // the commit writes the mirror: steps in flight on either pipe read it
+    HIPCHK(c, c->big_place.reserve(1));
+    BigCommitArgs ba;
+    memset(&ba, 0, sizeof ba);
+    ba.p0 = c->p0.p; ba.p1 = c->p1.p; ba.p2 = c->p2.p; ba.p3 = c->p3.p; ba.p4 = c->p4.p; ba.det = c->det.p;
+    ba.wide = c->wide.p; ba.slot = slot; ba.node = node; ba.req = *req; ba.map = *map; ba.busy_time = busy_time; ba.sigs = sig_table(c);
+    ba.out = c->big_place.p;
+    hipLaunchKernelGGL(k_big_commit, dim3(1), dim3(64), 0, c->stream, ba);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(place_out, c->big_place.p, sizeof *place_out, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (slot < 0) {                                             // the node's records (X class, free-core counts) follow its planes
+        if (c->rec_lo == c->rec_hi) { c->rec_lo = node; c->rec_hi = node + 1; }
+        else { c->rec_lo = std::min(c->rec_lo, node); c->rec_hi = std::max(c->rec_hi, node + 1); }
+    }
     return NHDFIT_OK;
 }
 

@@ -22,14 +22,32 @@
 namespace nhdfit {
 
 constexpr int kWideU = NHDFIT_WIDE_MAX_NUMA;
-constexpr int kWideMaxTuples = 1024;                 // U^(G+1) <= 4^5
+NHD_HD uint32_t wide_ipow(uint32_t b, uint32_t e) { uint32_t r = 1; for (uint32_t i = 0; i < e; ++i) r *= b; return r; }
+// the set model's tables for an ORDINARY request (nhdfit_req on a wide node): U^(G+1) <= 4^5 tuples, int16 keys
+constexpr int kWideMaxTuples = 1024;
 constexpr int kWideSetSlotsG = 1024;                 // a CPython set of <= 256 keys never outgrows 1 024 slots (growth: fill*5 >= mask*3 -> 4 x used)
 constexpr int kWideSetSlotsC = 4096;                 // ... of <= 1 024 keys: 2 048; 4 096 leaves the model room to say so itself
-// scratch of one mapping (int16 keys): sg, a, b, c, ab, abc over G-tuples; sc over (G+1)-tuples; one resize buffer
+// scratch of one mapping (keys): sg, a, b, c, ab, abc over G-tuples; sc over (G+1)-tuples; one resize buffer
 constexpr int kWideScratchWords = 6 * kWideSetSlotsG + 2 * kWideSetSlotsC;
+// ... for a BIG request the tables are sized per call: the slots a CPython set of `keys` distinct keys ends up with (the growth
+// sequence depends on the count alone: fill*5 >= mask*3 -> smallest power of two > used*4, or > used*2 beyond 50 000 keys),
+// int32 keys (tuple codes reach 4^9)
+NHD_HD uint32_t wide_table_slots(uint32_t keys) {
+    uint32_t size = 8;
+    for (;;) {
+        const uint32_t at = ((size - 1) * 3 + 4) / 5;                   // first fill with fill*5 >= mask*3
+        if (at > keys) return size;
+        const uint64_t minused = at > 50000 ? (uint64_t)at * 2 : (uint64_t)at * 4;
+        uint32_t ns = 8;
+        while ((uint64_t)ns <= minused) ns <<= 1;
+        size = ns;
+    }
+}
+NHD_HD size_t big_scratch_words(uint32_t U, uint32_t G) {             // of one mapping, int32 words (wide_map's carving)
+    return 6 * (size_t)wide_table_slots(wide_ipow(U, G)) + 2 * (size_t)wide_table_slots(wide_ipow(U, G + 1));
+}
 static_assert(sizeof(nhdfit_wide_node) == 640 && sizeof(nhdfit_wide_placement) == 480, "record sizes of include/nhdfit.h");
 
-NHD_HD uint32_t wide_ipow(uint32_t b, uint32_t e) { uint32_t r = 1; for (uint32_t i = 0; i < e; ++i) r *= b; return r; }
 // digit i (i = 0: first element) of tuple `code` of length `len` over range(U): first element most significant, so that
 // ascending codes are itertools.product order
 NHD_HD uint32_t wide_digit(uint32_t code, uint32_t len, uint32_t U, uint32_t i) {
@@ -72,9 +90,39 @@ NHD_HD uint32_t wide_sw_free(const nhdfit_wide_node& n, uint32_t sw) {
     return k;
 }
 
+// An ordinary node - five planes and its detail record - read through the wide record: what the general path needs to answer
+// for it (fits, map; the commit step of an ordinary node stays on the planes, commit_core.h).  Socket u's cores sit in word u
+// of the flat bitmaps (64 cores per socket: bits past the node's own core count are never set in t0).  A placeholder (a wide
+// node's entry in the planes, a node no layout holds) comes out with numa_nodes == 0: wide_shape_ok says no.
+NHD_HD void wide_view(const nhdfit_plane0& p0, const nhdfit_plane1& p1, const nhdfit_plane2& p2, const nhdfit_plane3& p3,
+                      const nhdfit_plane4& p4, const nhdfit_detail& d, uint32_t index, nhdfit_wide_node& w) {
+    for (int k = 0; k < NHDFIT_WIDE_CORE_WORDS; ++k) w.t0[k] = w.t1[k] = w.o0[k] = w.o1[k] = 0;
+    for (int u = 0; u < NHDFIT_MAX_NUMA; ++u) { w.t0[u] = p0.t0[u]; w.t1[u] = p1.t1[u]; }
+    w.groups = p3.groups;
+    w.busy_time = p4.busy_time;
+    w.gpu_free = p2.gpu_free;
+    w.flags = p2.flags;
+    w.hp_free = p2.hp_free; w.hp_total = 0;
+    w.index = index;
+    w.cores_per_proc = NHDFIT_MAX_CORES_PER_NUMA;
+    w.numa_nodes = d.numa_nodes <= NHDFIT_MAX_NUMA ? d.numa_nodes : 0;
+    w.n_gpus = d.n_gpus;
+    for (int u = 0; u < NHDFIT_WIDE_MAX_NUMA; ++u) {
+        w.nic_cnt[u] = u < NHDFIT_MAX_NUMA ? d.nic_cnt[u] : 0;
+        for (int k = 0; k < NHDFIT_MAX_NICS_PER_NUMA; ++k) {
+            w.nic_cls[u][k] = u < NHDFIT_MAX_NUMA ? d.nic_cls[u][k] : 0;
+            w.nic_sw[u][k] = u < NHDFIT_MAX_NUMA ? d.nic_sw[u][k] : 0;
+            w.nic_base[u][k] = 0;
+            w.nic_pods[u][k] = 0;
+        }
+    }
+    for (int x = 0; x < NHDFIT_MAX_GPUS; ++x) { w.gpu_numa[x] = (uint8_t)(p2.gpu_numa1 >> x & 1u); w.gpu_sw[x] = d.gpu_sw[x]; }
+    for (int k = 0; k < (int)sizeof w.pad; ++k) w.pad[k] = 0;
+}
+
 // ---- stages ------------------------------------------------------------------------------------------------------------
 // GPU stage, one assignment (Matcher.py:120-131)
-NHD_HD bool wide_gpu_ok(const nhdfit_req& r, const WideFree& f, uint32_t code) {
+template <class R> NHD_HD bool wide_gpu_ok(const R& r, const WideFree& f, uint32_t code) {
     uint32_t ttl[kWideU] = {0, 0, 0, 0};
     for (uint32_t g = 0; g < r.n_groups; ++g) ttl[wide_digit(code, r.n_groups, f.U, g)] += r.gpus[g];
     for (uint32_t u = 0; u < f.U; ++u)
@@ -82,7 +130,7 @@ NHD_HD bool wide_gpu_ok(const nhdfit_req& r, const WideFree& f, uint32_t code) {
     return true;
 }
 // CPU stage, one (G+1)-tuple: the last element places the pod-level misc cores (Matcher.py:206-216)
-NHD_HD bool wide_cpu_ok(const nhdfit_req& r, const WideFree& f, uint32_t code) {
+template <class R> NHD_HD bool wide_cpu_ok(const R& r, const WideFree& f, uint32_t code) {
     uint32_t ttl[kWideU] = {0, 0, 0, 0};
     const uint32_t len = r.n_groups + 1;
     for (uint32_t g = 0; g < len; ++g) {
@@ -101,10 +149,22 @@ NHD_HD bool wide_cpu_ok(const nhdfit_req& r, const WideFree& f, uint32_t code) {
 // groups behind a switch than it has free GPUs).  Both tests only get harder as groups are added when every request is
 // >= 0, so depth-first search in the same order with prefix pruning returns the same first combination (first_nic_choice,
 // winner_map.h); requests that are negative or NaN take the plain odometer.
-NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const nhdfit_req& r, const double* caps, uint32_t gcode, int8_t nic_idx[kMaxG]) {
+//
+// Big requests (5..8 groups, req_traits<R>::kBig) search with two more things, neither of which changes the answer:
+//   * among NICs of one NUMA node that are interchangeable - same capacity class (bit-identical f64), same switch - and that
+//     no earlier group of the search order uses yet, only the lowest index is tried: a solution whose first use of such a NIC
+//     k is ahead of its first use of an equal NIC k' < k becomes, with the roles of k and k' swapped throughout, a solution
+//     that is earlier in the enumeration order (same per-NIC subtraction sequences, same switch counts), so the FIRST
+//     solution is never in a pruned branch.  Eight VFs of one PF then cost set partitions, not 8^G.
+//   * a budget of search steps per (pod, node) pair (NicSearch): when it runs out the pair is reported, the call fails
+//     (NHDFIT_E_LIMIT) - the reference would be making K^G deepcopies there.
+struct NicSearch { uint32_t left; bool exhausted; };
+template <class R>
+NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const R& r, const double* caps, uint32_t gcode, int8_t* nic_idx, NicSearch* ns = nullptr) {
+    constexpr int kG = req_traits<R>::kG;
     const uint32_t G = r.n_groups, U = n.numa_nodes;
     const bool pci = r.map_type == NHDFIT_MAP_PCI;
-    uint32_t order[kMaxG], numa[kMaxG], pick[kMaxG];
+    uint32_t order[kG], numa[kG], pick[kG];
     uint32_t cnt = 0;
     for (uint32_t g = 0; g < G; ++g) { numa[g] = wide_digit(gcode, G, U, g); pick[g] = 0; }
     for (uint32_t u = 0; u < U; ++u)
@@ -132,11 +192,31 @@ NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const nhdfit_req& r, cons
         }
         return c <= wide_sw_free(n, sw);                       // Matcher.py:318-322
     };
+    // big requests: NIC (u, k) has an equal twin of lower index that, like itself, no group of order[0..pos) uses
+    auto twin_skipped = [&](int pos, uint32_t u, uint32_t k) {
+        for (int q = 0; q < pos; ++q)
+            if (numa[order[q]] == u && pick[order[q]] == k) return false;                    // in use: its own state
+        for (uint32_t k2 = 0; k2 < k; ++k2) {
+            if (n.nic_cls[u][k2] != n.nic_cls[u][k] || n.nic_sw[u][k2] != n.nic_sw[u][k]) continue;
+            bool used = false;
+            for (int q = 0; q < pos && !used; ++q) used = numa[order[q]] == u && pick[order[q]] == k2;
+            if (!used) return true;
+        }
+        return false;
+    };
+    auto spend = [&]() {
+        if (!ns) return true;
+        if (ns->left == 0) { ns->exhausted = true; return false; }
+        ns->left--;
+        return true;
+    };
     if (prune) {
         int pos = 0;
         for (;;) {
             const uint32_t g = order[pos];
-            const bool ok = nic_holds((uint32_t)pos, numa[g], pick[g]) && (!pci || switch_holds((uint32_t)pos, n.nic_sw[numa[g]][pick[g]]));
+            if (!spend()) return false;
+            const bool ok = !(req_traits<R>::kBig && twin_skipped(pos, numa[g], pick[g])) &&
+                            nic_holds((uint32_t)pos, numa[g], pick[g]) && (!pci || switch_holds((uint32_t)pos, n.nic_sw[numa[g]][pick[g]]));
             if (ok) {
                 if (pos == (int)G - 1) { for (uint32_t q = 0; q < G; ++q) nic_idx[q] = (int8_t)pick[q]; return true; }
                 ++pos;                                         // (the next group starts at its first NIC: its pick is 0)
@@ -151,6 +231,7 @@ NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const nhdfit_req& r, cons
         }
     }
     for (;;) {                                                 // the enumeration as the reference writes it
+        if (!spend()) return false;
         bool ok = true;
         for (uint32_t q = 0; q < G && ok; ++q) {
             const uint32_t g = order[q];
@@ -169,7 +250,7 @@ NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const nhdfit_req& r, cons
 }
 
 // scalar predicates (Matcher.py:65-84, 107-111; InitialNodeFilter NHDScheduler.py:235-247 when the request asks for it)
-NHD_HD bool wide_scalar_ok(const nhdfit_wide_node& n, const nhdfit_req& r, bool busy) {
+template <class R> NHD_HD bool wide_scalar_ok(const nhdfit_wide_node& n, const R& r, bool busy) {
     if (!req_valid(r) || !wide_shape_ok(n)) return false;
     if (n.flags & NHDFIT_NF_MAINTENANCE) return false;
     if (r.hugepages_gb > n.hp_free) return false;
@@ -184,17 +265,19 @@ NHD_HD bool wide_scalar_ok(const nhdfit_wide_node& n, const nhdfit_req& r, bool 
 }
 
 // feasible(node, pod): some assignment passes all three stages (the set intersection of Matcher.py:346 is non-empty)
-NHD_HD bool wide_fits(const nhdfit_wide_node& n, const nhdfit_req& r, bool busy, const double* caps) {
+template <class R>
+NHD_HD bool wide_fits(const nhdfit_wide_node& n, const R& r, bool busy, const double* caps, NicSearch* ns = nullptr) {
     if (!wide_scalar_ok(n, r, busy)) return false;
     const WideFree f = wide_free(n);
     const uint32_t G = r.n_groups, nG = wide_ipow(f.U, G);
-    int8_t nic[kMaxG];
+    int8_t nic[req_traits<R>::kG];
     for (uint32_t code = 0; code < nG; ++code) {
         if (!wide_gpu_ok(r, f, code)) continue;
         bool cpu = false;
         for (uint32_t m = 0; m < f.U && !cpu; ++m) cpu = wide_cpu_ok(r, f, code * f.U + m);
         if (!cpu) continue;
-        if (wide_nic_choice(n, r, caps, code, nic)) return true;
+        if (wide_nic_choice(n, r, caps, code, nic, ns)) return true;
+        if (ns && ns->exhausted) return false;
     }
     return false;
 }
@@ -214,17 +297,18 @@ NHD_HD uint64_t wide_tuple_hash(uint32_t code, uint32_t len, uint32_t U) {
     return acc;
 }
 
-struct WideSet {
-    int16_t* key;          // [cap] -1 = unused slot
+template <class K> struct WideSetT {
+    K* key;          // [cap] -1 = unused slot
     int32_t cap, mask, fill;
     uint32_t len, U;       // tuple length, digit base
     bool overflow;         // the table would have outgrown `cap` (cannot happen for the sizes above; reported, never silent)
 };
-NHD_HD void ws_init(WideSet& s, int16_t* mem, int32_t cap, uint32_t len, uint32_t U) {
+using WideSet = WideSetT<int16_t>;      // keys of an ordinary request's tuples (< 1 024); a big request's reach 4^9: int32 (req_traits<R>::Key)
+template <class K> NHD_HD void ws_init(WideSetT<K>& s, K* mem, int32_t cap, uint32_t len, uint32_t U) {
     s.key = mem; s.cap = cap; s.mask = 7; s.fill = 0; s.len = len; s.U = U; s.overflow = false;
     for (int32_t i = 0; i < 8; ++i) mem[i] = -1;
 }
-NHD_HD void ws_insert_clean(int16_t* key, int32_t mask, int16_t k, uint64_t h) {      // set_insert_clean()
+template <class K> NHD_HD void ws_insert_clean(K* key, int32_t mask, K k, uint64_t h) {      // set_insert_clean()
     uint64_t perturb = h;
     uint64_t i = h & (uint64_t)mask;
     for (;;) {
@@ -239,7 +323,7 @@ NHD_HD void ws_insert_clean(int16_t* key, int32_t mask, int16_t k, uint64_t h) {
     }
     key[i] = k;
 }
-NHD_HD void ws_resize(WideSet& s, int32_t minused, int16_t* tmp) {                    // set_table_resize()
+template <class K> NHD_HD void ws_resize(WideSetT<K>& s, int32_t minused, K* tmp) {                    // set_table_resize()
     int32_t newsize = 8;
     while (newsize <= minused) newsize <<= 1;
     if (newsize > s.cap) { s.overflow = true; return; }
@@ -250,7 +334,7 @@ NHD_HD void ws_resize(WideSet& s, int32_t minused, int16_t* tmp) {              
     for (int32_t i = 0; i <= oldmask; ++i)
         if (tmp[i] >= 0) ws_insert_clean(s.key, s.mask, tmp[i], wide_tuple_hash((uint32_t)tmp[i], s.len, s.U));
 }
-NHD_HD bool ws_has(const WideSet& s, int16_t k) {
+template <class K> NHD_HD bool ws_has(const WideSetT<K>& s, K k) {
     const uint64_t h = wide_tuple_hash((uint32_t)k, s.len, s.U);
     uint64_t perturb = h;
     uint64_t i = h & (uint64_t)s.mask;
@@ -264,7 +348,7 @@ NHD_HD bool ws_has(const WideSet& s, int16_t k) {
         i = (i * 5 + 1 + perturb) & (uint64_t)s.mask;
     }
 }
-NHD_HD void ws_add(WideSet& s, int16_t k, int16_t* tmp) {                             // set_add_entry()
+template <class K> NHD_HD void ws_add(WideSetT<K>& s, K k, K* tmp) {                             // set_add_entry()
     if (s.overflow) return;
     const uint64_t h = wide_tuple_hash((uint32_t)k, s.len, s.U);
     uint64_t perturb = h;
@@ -275,7 +359,7 @@ NHD_HD void ws_add(WideSet& s, int16_t k, int16_t* tmp) {                       
             if (s.key[i + j] < 0) {
                 s.key[i + j] = k;
                 s.fill++;
-                if (s.fill * 5 >= s.mask * 3) ws_resize(s, s.fill * 4, tmp);
+                if (s.fill * 5 >= s.mask * 3) ws_resize(s, s.fill > 50000 ? s.fill * 2 : s.fill * 4, tmp);   // set_add_entry: used > 50000 ? used*2 : used*4
                 return;
             }
             if (s.key[i + j] == k) return;
@@ -284,15 +368,15 @@ NHD_HD void ws_add(WideSet& s, int16_t k, int16_t* tmp) {                       
         i = (i * 5 + 1 + perturb) & (uint64_t)s.mask;
     }
 }
-NHD_HD int32_t ws_next(const WideSet& s, int32_t from) {                              // iteration = slot order
+template <class K> NHD_HD int32_t ws_next(const WideSetT<K>& s, int32_t from) {                              // iteration = slot order
     for (int32_t i = from; i <= s.mask; ++i)
         if (s.key[i] >= 0) return i;
     return -1;
 }
 // out = a & b: iterate the smaller operand (b on ties) in slot order, probe the other (set_intersection())
-NHD_HD void ws_intersect(const WideSet& a, const WideSet& b, WideSet& out, int16_t* tmp) {
-    const WideSet* probe = &a;
-    const WideSet* iter = &b;
+template <class K> NHD_HD void ws_intersect(const WideSetT<K>& a, const WideSetT<K>& b, WideSetT<K>& out, K* tmp) {
+    const WideSetT<K>* probe = &a;
+    const WideSetT<K>* iter = &b;
     if (b.fill > a.fill) { probe = &b; iter = &a; }
     for (int32_t i = ws_next(*iter, 0); i >= 0; i = ws_next(*iter, i + 1))
         if (ws_has(*probe, iter->key[i])) ws_add(out, iter->key[i], tmp);
@@ -306,7 +390,7 @@ NHD_HD int wide_spread(uint32_t code, uint32_t G, uint32_t U) {
     for (uint32_t u = 1; u < U; ++u) { mx = cnt[u] > mx ? cnt[u] : mx; mn = cnt[u] < mn ? cnt[u] : mn; }
     return mx - mn;
 }
-NHD_HD int32_t wide_pick_gpu_tuple(const WideSet& s, uint32_t G, uint32_t U) {        // first maximiser in list(set) order
+template <class K> NHD_HD int32_t wide_pick_gpu_tuple(const WideSetT<K>& s, uint32_t G, uint32_t U) {        // first maximiser in list(set) order
     int32_t best = -1;
     int best_spread = -1;
     for (int32_t i = ws_next(s, 0); i >= 0; i = ws_next(s, i + 1)) {
@@ -316,38 +400,48 @@ NHD_HD int32_t wide_pick_gpu_tuple(const WideSet& s, uint32_t G, uint32_t U) {  
     return best;
 }
 
-// The winner-only tail of FindNode on a wide node (Matcher.py:337-391 + 423-452).  `scratch`: kWideScratchWords int16.
+// The winner-only tail of FindNode on a wide node (Matcher.py:337-391 + 423-452).  `scratch`: kWideScratchWords int16 (ordinary) / big_scratch_words(U, G) int32 (big).
 // Returns 1 = mapped, 0 = the node does not take the pod, -1 = a set outgrew its table (never expected; the caller reports it).
-NHD_HD int wide_map(const nhdfit_wide_node& n, const nhdfit_req& r, const double* caps, int16_t* scratch, nhdfit_mapping& out) {
-    for (int g = 0; g < kMaxG; ++g) { out.gpu[g] = out.nic_numa[g] = out.nic_idx[g] = -1; }
-    for (int g = 0; g <= kMaxG; ++g) out.cpu[g] = -1;
+// -2 = the NIC search budget of a big request ran out (reported like -1).
+// slots_g / slots_c: table sizes of the sets over G- and (G+1)-tuples (ordinary requests: kWideSetSlotsG / kWideSetSlotsC).
+template <class R>
+NHD_HD int wide_map(const nhdfit_wide_node& n, const R& r, const double* caps, typename req_traits<R>::Key* scratch,
+                    typename req_traits<R>::Mapping& out, int32_t slots_g = kWideSetSlotsG, int32_t slots_c = kWideSetSlotsC) {
+    using K = typename req_traits<R>::Key;
+    constexpr int kG = req_traits<R>::kG;
+    for (int g = 0; g < kG; ++g) { out.gpu[g] = out.nic_numa[g] = out.nic_idx[g] = -1; }
+    for (int g = 0; g <= kG; ++g) out.cpu[g] = -1;
     out.valid = 0; out.pad[0] = out.pad[1] = 0;
     if (!req_valid(r) || !wide_shape_ok(n)) return 0;
     const WideFree f = wide_free(n);
     const uint32_t G = r.n_groups, U = f.U, nG = wide_ipow(U, G), nC = nG * U;
-    if (nC > (uint32_t)kWideMaxTuples) return -1;
-    int16_t* mem = scratch;
-    WideSet sg, sc, a, b, c, ab, abc;
-    ws_init(sg, mem, kWideSetSlotsG, G, U); mem += kWideSetSlotsG;
-    ws_init(a, mem, kWideSetSlotsG, G, U); mem += kWideSetSlotsG;
-    ws_init(b, mem, kWideSetSlotsG, G, U); mem += kWideSetSlotsG;
-    ws_init(c, mem, kWideSetSlotsG, G, U); mem += kWideSetSlotsG;
-    ws_init(ab, mem, kWideSetSlotsG, G, U); mem += kWideSetSlotsG;
-    ws_init(abc, mem, kWideSetSlotsG, G, U); mem += kWideSetSlotsG;
-    ws_init(sc, mem, kWideSetSlotsC, G + 1, U); mem += kWideSetSlotsC;
-    int16_t* tmp = mem;
+    const int32_t kSlotsG = slots_g, kSlotsC = slots_c;
+    if ((uint64_t)nG * U > (uint64_t)req_traits<R>::kMaxTuples) return -1;
+    K* mem = scratch;
+    WideSetT<K> sg, sc, a, b, c, ab, abc;
+    ws_init(sg, mem, kSlotsG, G, U); mem += kSlotsG;
+    ws_init(a, mem, kSlotsG, G, U); mem += kSlotsG;
+    ws_init(b, mem, kSlotsG, G, U); mem += kSlotsG;
+    ws_init(c, mem, kSlotsG, G, U); mem += kSlotsG;
+    ws_init(ab, mem, kSlotsG, G, U); mem += kSlotsG;
+    ws_init(abc, mem, kSlotsG, G, U); mem += kSlotsG;
+    ws_init(sc, mem, kSlotsC, G + 1, U); mem += kSlotsC;
+    K* tmp = mem;
     // candidate sets, filled in product order (Matcher.py:116-141, 206-220, 242-268 + 294-335)
-    int8_t nic[kMaxG];
+    int8_t nic[kG];
+    NicSearch budget{req_traits<R>::kBig ? 8u * NHDFIT_BIG_NIC_BUDGET : 0u, false};    // (every assignment is searched here, not only up to the first hit)
+    NicSearch* ns = req_traits<R>::kBig ? &budget : nullptr;
     for (uint32_t code = 0; code < nG; ++code) {
-        if (wide_gpu_ok(r, f, code)) ws_add(sg, (int16_t)code, tmp);
-        if (wide_nic_choice(n, r, caps, code, nic)) ws_add(c, (int16_t)code, tmp);
+        if (wide_gpu_ok(r, f, code)) ws_add(sg, (K)code, tmp);
+        if (wide_nic_choice(n, r, caps, code, nic, ns)) ws_add(c, (K)code, tmp);
+        if (budget.exhausted) return -2;
     }
     for (uint32_t code = 0; code < nC; ++code)
-        if (wide_cpu_ok(r, f, code)) ws_add(sc, (int16_t)code, tmp);
+        if (wide_cpu_ok(r, f, code)) ws_add(sc, (K)code, tmp);
     if (!sg.fill || !sc.fill || !c.fill) return 0;
     // set(gpu_tuples) & set(cpu_tuples) & set(nic_tuples): set(list) re-inserts in list (= slot) order
     for (int32_t i = ws_next(sg, 0); i >= 0; i = ws_next(sg, i + 1)) ws_add(a, sg.key[i], tmp);
-    for (int32_t i = ws_next(sc, 0); i >= 0; i = ws_next(sc, i + 1)) ws_add(b, (int16_t)(sc.key[i] / (int16_t)U), tmp);     // tuple[:-1]
+    for (int32_t i = ws_next(sc, 0); i >= 0; i = ws_next(sc, i + 1)) ws_add(b, (K)(sc.key[i] / (K)U), tmp);     // tuple[:-1]
     ws_intersect(a, b, ab, tmp);
     ws_intersect(ab, c, abc, tmp);
     if (sg.overflow || sc.overflow || a.overflow || b.overflow || c.overflow || ab.overflow || abc.overflow) return -1;
@@ -356,9 +450,10 @@ NHD_HD int wide_map(const nhdfit_wide_node& n, const nhdfit_req& r, const double
     const int32_t gcode = abc.fill < sg.fill ? wide_pick_gpu_tuple(abc, G, U) : wide_pick_gpu_tuple(sg, G, U);
     int32_t ccode = -1;                                                              // Matcher.py:441-444
     for (int32_t i = ws_next(sc, 0); i >= 0 && ccode < 0; i = ws_next(sc, i + 1))
-        if (sc.key[i] / (int16_t)U == gcode) ccode = sc.key[i];
+        if (sc.key[i] / (K)U == gcode) ccode = sc.key[i];
     if (gcode < 0 || ccode < 0) return 0;
-    if (!wide_nic_choice(n, r, caps, (uint32_t)gcode, out.nic_idx)) return 0;
+    budget.left = req_traits<R>::kBig ? NHDFIT_BIG_NIC_BUDGET : 0u;
+    if (!wide_nic_choice(n, r, caps, (uint32_t)gcode, out.nic_idx, ns)) return budget.exhausted ? -2 : 0;
     for (uint32_t g = 0; g < G; ++g) { out.gpu[g] = (int8_t)wide_digit((uint32_t)gcode, G, U, g); out.nic_numa[g] = out.gpu[g]; }
     for (uint32_t g = 0; g <= G; ++g) out.cpu[g] = (int8_t)wide_digit((uint32_t)ccode, G + 1, U, g);
     out.valid = 1;
@@ -394,7 +489,10 @@ NHD_HD bool wide_take_batch(nhdfit_wide_node& n, uint32_t u, uint32_t num, bool 
     return got_take + got_late == n_take && got_late == n_late;
 }
 
-NHD_HD int wide_commit(nhdfit_wide_node& n, const nhdfit_req& r, const nhdfit_mapping& m, double busy_time, nhdfit_wide_placement& out) {
+template <class R>
+NHD_HD int wide_commit(nhdfit_wide_node& n, const R& r, const typename req_traits<R>::Mapping& m, double busy_time,
+                       typename req_traits<R>::WidePlacement& out) {
+    constexpr int kMaxG = req_traits<R>::kG;                                          // (shadows the table pass's constant: this body is per request form)
     const uint32_t G = r.n_groups, U = n.numa_nodes;
     int status = kCommitOk;
     for (int g = 0; g < kMaxG; ++g) {
@@ -426,7 +524,7 @@ NHD_HD int wide_commit(nhdfit_wide_node& n, const nhdfit_req& r, const nhdfit_ma
             n.gpu_free &= ~(1u << pick);
             if (k < (uint32_t)NHDFIT_PLACEMENT_GPUS) out.gpu[g][k] = (uint8_t)pick;
         }
-        if (!wide_take_batch(n, u, r.n_help[g], (r.smt_bits >> (4 + g) & 1) != 0, out.help_take[g], out.help_pair[g], out.help_late[g])) status = kCommitWouldRaise;
+        if (!wide_take_batch(n, u, r.n_help[g], (r.smt_bits >> (kMaxG + g) & 1) != 0, out.help_take[g], out.help_pair[g], out.help_late[g])) status = kCommitWouldRaise;
         if (r.nic_use >> g & 1) claimed[nu] |= 1u << nk;
     }
     if (r.hugepages_gb > 0) n.hp_free -= r.hugepages_gb;                              // Node.py:794-796

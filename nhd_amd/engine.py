@@ -200,6 +200,28 @@ class Engine:
         self._chk(self.lib.nhdfit_commit(self.ctx, int(node), _p(req), _p(mapping), float(busy_time), _p(out)))
         return out
 
+    # ---- pods with 5..8 processing groups: the general path over every node (nhdfit_big_find / nhdfit_big_commit) --------
+    def big_find(self, reqs: np.ndarray, now: float, cand: Optional[np.ndarray] = None, want_map=True):
+        """Mode A for big requests (pack.BIG_REQ): (scores, mappings pack.BIG_MAPPING)."""
+        reqs = np.ascontiguousarray(reqs, dtype=pack.BIG_REQ)
+        P = len(reqs)
+        score = np.zeros(P, np.uint64)
+        maps = np.zeros(P, pack.BIG_MAPPING) if want_map else None
+        if cand is not None:
+            cand = np.ascontiguousarray(cand, dtype=np.uint64)
+            assert cand.shape == ((self.n + 63) // 64,)
+        if P:
+            self._chk(self.lib.nhdfit_big_find(self.ctx, _p(reqs), P, float(now), _p(cand), _p(score), _p(maps)))
+        return score, maps
+
+    def big_commit(self, node: int, req: np.ndarray, mapping: np.ndarray, busy_time: float) -> np.ndarray:
+        """The commit step of a big request on node `node` (ordinary or wide): updates the mirror, returns pack.BIG_PLACEMENT."""
+        out = np.zeros((), pack.BIG_PLACEMENT)
+        req = np.ascontiguousarray(req, dtype=pack.BIG_REQ)
+        mapping = np.ascontiguousarray(mapping, dtype=pack.BIG_MAPPING)
+        self._chk(self.lib.nhdfit_big_commit(self.ctx, int(node), _p(req), _p(mapping), float(busy_time), _p(out)))
+        return out
+
     def download(self, first: int = 0, count: Optional[int] = None) -> pack.NodeTable:
         count = self.n - first if count is None else count
         t = pack.empty_table(count)
@@ -479,6 +501,36 @@ class GroupEngine:
     def wide_commit(self, node: int, req, mapping, busy_time):
         k = self._shard_of(node)
         return self.shards[k].wide_commit(node - self._bounds[k][0], req, mapping, busy_time)
+
+    def big_find(self, reqs: np.ndarray, now: float, cand: Optional[np.ndarray] = None, want_map=True):
+        """Big requests over every shard: each device runs the general pass on its nodes (nhdfit_big_find), the score words -
+        which carry the global node index - are max-merged and the owner's mapping kept.  (A rare path: the merge of
+        len(shards) x P words is done here, not by a collective.)"""
+        reqs = np.ascontiguousarray(reqs, dtype=pack.BIG_REQ)
+        P = len(reqs)
+        score = np.zeros(P, np.uint64)
+        maps = np.zeros(P, pack.BIG_MAPPING)
+        parts = []
+        for k, s in enumerate(self.shards):
+            lo, hi = self._bounds[k]
+            if hi > lo:
+                mask = None if cand is None else np.ascontiguousarray(np.ascontiguousarray(cand, dtype=np.uint64)[lo // 64:(hi + 63) // 64])
+                parts.append((k, s.big_find(reqs, now, cand=mask, want_map=want_map)))
+        for k, (sc, mp) in parts:
+            score = np.maximum(score, sc)
+        idx = np.where(score == 0, -1, (SCORE_MASK - (score & np.uint64(SCORE_MASK))).astype(np.int64))
+        for k, (sc, mp) in parts:
+            lo, hi = self._bounds[k]
+            own = (sc == score) & (idx >= lo) & (idx < hi)
+            if want_map:
+                maps[own] = mp[own]
+        return score, (maps if want_map else None)
+
+    def big_commit(self, node: int, req, mapping, busy_time):
+        k = self._shard_of(node)
+        out = self.shards[k].big_commit(node - self._bounds[k][0], req, mapping, busy_time)
+        out["node"] = node
+        return out
 
     @property
     def n_wide(self) -> int:

@@ -198,9 +198,9 @@ class HipMatcher:
         i = self._index.get(name)
         return name in self.packer.unmirrored or (i is not None and self._table is not None and bool(self._table.wide) and i in self._table.wide)
 
-    def _mapping_record(self, mapping) -> np.ndarray:
-        m = np.zeros((), pack.MAPPING)
+    def _mapping_record(self, mapping, big: bool = False) -> np.ndarray:
         G = len(mapping["gpu"])
+        m = np.zeros((), pack.BIG_MAPPING if big or G > pack.MAX_GROUPS else pack.MAPPING)
         m["gpu"][:G] = mapping["gpu"]
         m["cpu"][:G + 1] = mapping["cpu"]
         m["nic_numa"][:G] = [x[0] for x in mapping["nic"]]
@@ -215,8 +215,10 @@ class HipMatcher:
         not touched."""
         i = self._index[name]
         node = self._attached[name] if self._attached is not None else None
-        req = self.packer.digest(top)
         bt = float(node.busy_time if busy_time is None and node is not None else busy_time)
+        if pack.needs_general_path(top):                                                # a pod with 5..8 processing groups (or beyond the hugepage table): the general path's commit step
+            return self._commit_big(i, node, self.packer.digest_big(top), self._mapping_record(mapping, big=True), bt)
+        req = self.packer.digest(top)
         if self._table is not None and self._table.wide and i in self._table.wide:      # a wide node: the general path's commit step
             place = self.engine.wide_commit(i, req, self._mapping_record(mapping), bt)
             G = int(req["n_groups"])
@@ -234,6 +236,26 @@ class HipMatcher:
         G = int(req["n_groups"])
         return pack.expand_placement(place, G, cpp, cpp * int(node.sockets) if node is not None else 0,
                                      [int(req["gpus"][g]) for g in range(G)])
+
+    def _commit_big(self, i: int, node, req, mapping_rec, busy_time: float) -> dict:
+        """nhdfit_big_commit on node i (ordinary or wide) -> the physical ids (pack.expand_wide_placement: a big placement
+        carries two mask words per batch whichever form the node is mirrored in)."""
+        place = self.engine.big_commit(i, req, mapping_rec, busy_time)
+        wide = self._table is not None and self._table.wide and i in self._table.wide
+        if not wide and int(place["status"]) == pack.COMMIT_NEW_SIG:    # cannot happen after close_signatures(); handled anyway
+            one = self.engine.download(i, 1)
+            sn, sp = self.packer.sigs_from_detail(one.detail[0])
+            one.p3[0]["sig_numa"], one.p3[0]["sig_pci"] = sn, sp
+            self.engine.set_dictionary(self.packer)
+            self.engine.upload(one, first=i, capacity=len(self._names))
+        G = int(req["n_groups"])
+        if node is not None:
+            cpp, U = int(node.cores_per_proc), int(node.sockets)
+        elif wide:
+            cpp, U = int(self._table.wide[i]["cores_per_proc"]), int(self._table.wide[i]["numa_nodes"])
+        else:
+            cpp, U = 0, 0
+        return pack.expand_wide_placement(place, G, cpp, cpp * U, [int(req["gpus"][g]) for g in range(G)])
 
     def _on_commit(self, node, mapping, top) -> bool:
         """After the reference's own SetPhysicalIdsFromMapping succeeded on an attached node: the same commit on the
@@ -538,6 +560,8 @@ class HipMatcher:
             self.logger.error("FindNode: %s - %d pod(s) answered (None,)", self.packer.sharing, n_pods)
             self.last_placements = [None] * n_pods
             return [(None,) for _ in range(n_pods)]
+        if reqs is None and any(pack.needs_general_path(top) for top in tops):
+            return self._run_with_big(nl, tops, pod_groups, now, cand, sequential, apply)
         if reqs is None:
             beyond: List[Tuple[int, str]] = []
             reqs = self.packer.digest_many(tops, pod_groups, unsupported=beyond)
@@ -590,4 +614,109 @@ class HipMatcher:
             if not valid:
                 raise RuntimeError(f"internal error: no mapping produced for feasible node {name}")
             out.append((name, {"gpu": tuple(gpu[:G]), "cpu": tuple(cpu[:G + 1]), "nic": list(zip(nic_numa[:G], nic_idx[:G]))}))
+        return out
+
+    # ---- pods with 5..8 processing groups (nhdfit_big_req): the general path ---------------------------------------------
+    def _run_with_big(self, nl, tops, pod_groups, now, cand, sequential, apply):
+        """FindNodes / ScheduleBatch for a call that holds pods with more than pack.MAX_GROUPS processing groups (the reference
+        takes any group count, nhd/Matcher.py:118,203,242).  Such a pod is digested as a nhdfit_big_req and answered on the
+        device by the general path (nhdfit_big_find: every node by explicit enumeration, the same score word, the general CPython
+        set model for its mapping; nhdfit_big_commit for its commit step); the other pods of the call take the table-driven pass
+        as always.  Mode A: two device calls, results interleaved.  Mode B: the scheduler's loop as it stands
+        (nhd/NHDScheduler.py:425-437) - pod after pod, each decided and committed on the device before the next is matched."""
+        n_pods = len(tops)
+        big = [pack.needs_general_path(top) for top in tops]
+        groups_of = (lambda p: pod_groups[p]) if pod_groups is not None else (lambda p: None)
+        small_idx = [p for p in range(n_pods) if not big[p]]
+        big_idx = [p for p in range(n_pods) if big[p]]
+        beyond: List[Tuple[int, str]] = []
+        small_reqs = self.packer.digest_many([tops[p] for p in small_idx], None if pod_groups is None else [pod_groups[p] for p in small_idx],
+                                             unsupported=beyond)
+        for k, why in beyond:
+            self.logger.error("pod %d of the call cannot be expressed as a request record and is answered (None,): %s", small_idx[k], why)
+        big_reqs = np.zeros(len(big_idx), pack.BIG_REQ)
+        for k, p in enumerate(big_idx):
+            big_reqs[k] = self.packer.digest_big(tops[p], groups_of(p))
+        base = self.engine.global_base
+        names = self._names
+        out: List[Tuple] = [(None,)] * n_pods
+        self.last_placements = [None] * n_pods
+
+        def answer(p, i, row):
+            G = len(tops[p].proc_groups)
+            gpu, cpu, nic_numa, nic_idx, valid, _ = row
+            if not valid:
+                raise RuntimeError(f"internal error: no mapping produced for feasible node {names[i]}")
+            out[p] = (names[i], {"gpu": tuple(gpu[:G]), "cpu": tuple(cpu[:G + 1]), "nic": list(zip(nic_numa[:G], nic_idx[:G]))})
+
+        if not sequential:
+            if small_idx:
+                score, _, maps = self.engine.find(small_reqs, now, cand=cand, want_bitmap=False, want_map=True)
+                rows = maps.tolist()
+                for k, s in enumerate(score.tolist()):
+                    if s:
+                        answer(small_idx[k], winner_index(s) - base, rows[k])
+            score, maps = self.engine.big_find(big_reqs, now, cand=cand)
+            rows = maps.tolist()
+            for k, s in enumerate(score.tolist()):
+                if s:
+                    answer(big_idx[k], winner_index(s) - base, rows[k])
+            return out
+
+        self.packer.close_signatures()                     # every NIC state a commit can produce has a signature
+        self.engine.set_dictionary(self.packer)
+        objects = self._attached if self._attached is not None else nl
+        touched = []
+        pos_small = {p: k for k, p in enumerate(small_idx)}
+        pos_big = {p: k for k, p in enumerate(big_idx)}
+        for p in range(n_pods):
+            G = len(tops[p].proc_groups)
+            if big[p]:
+                req = big_reqs[pos_big[p]]
+                score, maps = self.engine.big_find(big_reqs[pos_big[p]:pos_big[p] + 1], now, cand=cand)
+                if not score[0]:
+                    continue
+                i = winner_index(int(score[0])) - base
+                answer(p, i, maps.tolist()[0])
+                nd = objects.get(names[i])
+                ids = self._commit_big(i, nd, req, maps[0], now)
+                on_wide = self._table is not None and bool(self._table.wide) and i in self._table.wide
+            else:
+                k = pos_small[p]
+                node, maps, places, status = self.engine.schedule_batch(small_reqs[k:k + 1], now, self.packer, cand=cand, apply=True)
+                if node[0] < 0:
+                    continue
+                if status[0] == pack.COMMIT_WOULD_RAISE:
+                    self.logger.warning("mode B: the reference's commit step would have failed for pod %d", p)
+                i = int(node[0]) - base
+                answer(p, i, maps.tolist()[0])
+                nd = objects.get(names[i])
+                on_wide = int(places[0]["status"]) == pack.COMMIT_WIDE
+                ids = None
+                if nd is not None:
+                    gp = [int(small_reqs[k]["gpus"][g]) for g in range(G)]
+                    cpp, n_log = int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets)
+                    if on_wide:
+                        wp = getattr(self.engine, "last_wide_places", {}).get(0)
+                        ids = pack.expand_wide_placement(wp, G, cpp, n_log, gp) if wp is not None else None
+                    else:
+                        ids = pack.expand_placement(places[0], G, cpp, n_log, gp)
+            touched.append(names[i])
+            nd = objects.get(names[i])
+            if nd is None:
+                continue
+            self.last_placements[p] = ids
+            if self._attached is not None and apply:
+                if on_wide:
+                    self._mark(nd, "wide-batch")           # a wide record is re-packed from the object before the next call (no delta form)
+                else:
+                    self._batch_ids.setdefault(nd.name, []).append(ids)     # the reference mutators that follow find their work mirrored already
+        if not apply:
+            # the mirror goes back to what the node objects say (nobody applied anything to them): attached - those nodes are
+            # re-packed before the next call; stateless - every call packs `nl` again anyway
+            if self._attached is not None:
+                for name in touched:
+                    nd = self._attached.get(name)
+                    if nd is not None:
+                        self._mark(nd, "unapplied-batch")
         return out

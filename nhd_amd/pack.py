@@ -102,6 +102,20 @@ WIDE_PLACEMENT = np.dtype([("proc_take", "<u8", (4, 2)), ("proc_pair", "<u8", (4
                            ("misc_take", "<u8", (2,)), ("misc_pair", "<u8", (2,)), ("misc_late", "<u8", (2,)),
                            ("gpu", "u1", (4, 8)), ("numa", "i1", (5,)), ("status", "u1"), ("pad", "u1", (2,)), ("pod", "<u4"), ("node", "<u4")])
 assert WIDE.itemsize == 640 and WIDE_PLACEMENT.itemsize == 480
+# pods with 5..8 processing groups: the general path's request / mapping / placement records (include/nhdfit.h nhdfit_big_*)
+BIG_MAX_GROUPS, BIG_MAX_TUPLES = 8, 262144
+BIG_REQ = np.dtype([("n_groups", "<u4"), ("map_type", "<u4"), ("hugepages_gb", "<i4"), ("flags", "<u4"), ("groups", "<u8"),
+                    ("gpus", "<u2", (8,)), ("cpu_smt", "<u2", (8,)), ("cpu_nosmt", "<u2", (8,)), ("misc_smt", "<u2"), ("misc_nosmt", "<u2"),
+                    ("smt_bits", "<u2"), ("n_misc", "u1"), ("misc_smt_enabled", "u1"), ("rx", "<f8", (8,)), ("tx", "<f8", (8,)),
+                    ("n_proc", "u1", (8,)), ("n_help", "u1", (8,)), ("nic_use", "u1"), ("pad", "u1", (31,))])
+BIG_MAPPING = np.dtype([("gpu", "i1", (8,)), ("cpu", "i1", (9,)), ("nic_numa", "i1", (8,)), ("nic_idx", "i1", (8,)), ("valid", "i1"), ("pad", "i1", (2,))])
+BIG_PLACEMENT = np.dtype([("proc_take", "<u8", (8, 2)), ("proc_pair", "<u8", (8, 2)), ("proc_late", "<u8", (8, 2)),
+                          ("help_take", "<u8", (8, 2)), ("help_pair", "<u8", (8, 2)), ("help_late", "<u8", (8, 2)),
+                          ("misc_take", "<u8", (2,)), ("misc_pair", "<u8", (2,)), ("misc_late", "<u8", (2,)),
+                          ("gpu", "u1", (8, 8)), ("numa", "i1", (9,)), ("status", "u1"), ("pad", "u1", (2,)), ("pod", "<u4"), ("node", "<u4"),
+                          ("pad2", "u1", (4,))])
+_BIG_REQ_STRUCT = struct.Struct("<IIiIQ8H8H8HHHHBB8d8d8B8BB31x")
+assert BIG_REQ.itemsize == 256 and _BIG_REQ_STRUCT.size == 256 and BIG_MAPPING.itemsize == 36 and BIG_PLACEMENT.itemsize == 904
 CC = np.dtype([("cls", "u1"), ("cnt", "u1")])
 assert (P0.itemsize, P1.itemsize, P2.itemsize, P3.itemsize, P4.itemsize) == (16,) * 5
 _REQ_STRUCT = struct.Struct("<IIiIQ4H4H4HHH4B4d4d4BBBBB")          # REQ, field by field (digest_many packs records with it)
@@ -118,6 +132,21 @@ def _enum_value(x):
         return x._value_
     except AttributeError:
         return x.value
+
+
+def needs_general_path(top) -> bool:
+    """The pod cannot ride the table-driven pass but the general path answers it exactly (nhdfit_big_req): 5..8 processing
+    groups, or a hugepage request beyond the pod tile's hugepage table (the general path compares the integers themselves,
+    nhd/Matcher.py:78)."""
+    G = len(top.proc_groups)
+    if G > BIG_MAX_GROUPS or G < 1:
+        return False
+    if G > MAX_GROUPS:
+        return True
+    try:
+        return int(top.hugepages_gb) > MAX_HUGEPAGES_GB
+    except (TypeError, ValueError):
+        return False
 
 
 class UnsupportedNode(ValueError):
@@ -702,20 +731,22 @@ class Packer:
         return d
 
     # ---- request side ---------------------------------------------------------------------
-    def _digest_fields(self, top, pod_groups: Optional[Sequence[str]] = None) -> tuple:
+    def _digest_fields(self, top, pod_groups: Optional[Sequence[str]] = None, big: bool = False) -> tuple:
         """The record's 38 scalars in REQ's field order (plain Python arithmetic: one struct.pack instead of ~30 numpy field
-        writes - the digest is on FindNode's per-pod path)."""
+        writes - the digest is on FindNode's per-pod path).  big=True: the scalars of a nhdfit_big_req (eight groups, BIG_REQ's
+        field order) - a pod with 5..8 processing groups, answered by the general path."""
         groups = top.proc_groups
         G = len(groups)
         mt = getattr(top.map_type, "value", top.map_type)
         map_type = int(mt) if isinstance(mt, (int, np.integer)) else 0
-        if G > MAX_GROUPS:
-            raise UnsupportedNode(f"pod with {G} proc groups (> {MAX_GROUPS})")
+        W = BIG_MAX_GROUPS if big else MAX_GROUPS
+        if G > W:
+            raise UnsupportedNode(f"pod with {G} proc groups (> {W})")
         hp = int(top.hugepages_gb)
-        if hp > MAX_HUGEPAGES_GB:
+        if hp > MAX_HUGEPAGES_GB and not big:
             raise UnsupportedNode(f"pod asks for {hp} GiB of hugepages (> {MAX_HUGEPAGES_GB}: the hugepage table of a pod tile)")
-        gpus, cpu_smt, cpu_nosmt, procs, helps = [0] * 4, [0] * 4, [0] * 4, [0] * 4, [0] * 4
-        rxs, txs = [0.0] * 4, [0.0] * 4
+        gpus, cpu_smt, cpu_nosmt, procs, helps = [0] * W, [0] * W, [0] * W, [0] * W, [0] * W
+        rxs, txs = [0.0] * W, [0.0] * W
         smt_bits = nic_use = 0
         for i, pg in enumerate(groups):
             n_proc = len(pg.proc_cores) + sum(len(g.cpu_cores) for g in pg.group_gpus)
@@ -729,7 +760,7 @@ class Packer:
             if p_smt:
                 smt_bits |= 1 << i
             if h_smt:
-                smt_bits |= 1 << (4 + i)
+                smt_bits |= 1 << (W + i)
             cpu_nosmt[i] = n_proc + n_help
             cpu_smt[i] = ((n_proc + 1) // 2 if p_smt else n_proc) + ((n_help + 1) // 2 if h_smt else n_help)   # ceil(n / 2.0)
             rx = tx = 0
@@ -749,6 +780,10 @@ class Packer:
             txs[i] = float(tx)
         n_misc = len(top.misc_cores)
         flags, gbits = (RF_INITIAL_FILTER, self.group_bits_known(pod_groups)) if pod_groups is not None else (0, 0)
+        if big:
+            return (G, map_type, max(-2 ** 31, min(2 ** 31 - 1, hp)), flags, int(gbits), *gpus, *cpu_smt, *cpu_nosmt,
+                    (n_misc + 1) // 2 if top.misc_cores_smt else n_misc, n_misc, smt_bits, min(n_misc, 255),
+                    1 if getattr(top.misc_cores_smt, "value", top.misc_cores_smt) == 1 else 0, *rxs, *txs, *procs, *helps, nic_use)
         return (G, map_type, max(-2 ** 31, min(2 ** 31 - 1, hp)), flags, int(gbits), *gpus, *cpu_smt, *cpu_nosmt,
                 (n_misc + 1) // 2 if top.misc_cores_smt else n_misc,                       # Enum truthiness, quirk Q1
                 n_misc, *procs, *rxs, *txs, *helps, min(n_misc, 255), smt_bits,
@@ -761,6 +796,16 @@ class Packer:
         pod_groups None   -> the caller already filtered (`nl` of FindNode) and passes a candidate mask.
         """
         return self.digest_many([top], None if pod_groups is None else [pod_groups])[0]
+
+    def digest_big(self, top, pod_groups: Optional[Sequence[str]] = None) -> np.ndarray:
+        """CfgTopology -> nhdfit_big_req: a pod with up to BIG_MAX_GROUPS processing groups (the reference enumerates
+        repeat=len(req) for any group count, nhd/Matcher.py:118,203,242), for the general path (nhdfit_big_find)."""
+        out = np.zeros(1, BIG_REQ)
+        try:
+            _BIG_REQ_STRUCT.pack_into(memoryview(out).cast("B"), 0, *self._digest_fields(top, pod_groups, big=True))
+        except struct.error as e:
+            raise UnsupportedNode(str(e)) from None
+        return out[0]
 
     def digest_many(self, tops: Sequence[object], pod_groups: Optional[Sequence[Sequence[str]]] = None,
                     unsupported: Optional[List[Tuple[int, str]]] = None) -> np.ndarray:
@@ -832,7 +877,8 @@ def expand_wide_placement(place, n_groups: int, cores_per_proc: int, num_cores: 
         groups.append({"cores": expand_batch(_mask2(place["proc_take"][g]), _mask2(place["proc_pair"][g]), u, cores_per_proc, num_cores, _mask2(place["proc_late"][g])),
                        "helpers": expand_batch(_mask2(place["help_take"][g]), _mask2(place["help_pair"][g]), u, cores_per_proc, num_cores, _mask2(place["help_late"][g])),
                        "gpus": [int(x) for x in place["gpu"][g][:gpus_per_group[g]]]})
-    misc = expand_batch(_mask2(place["misc_take"]), _mask2(place["misc_pair"]), int(place["numa"][MAX_GROUPS]), cores_per_proc, num_cores, _mask2(place["misc_late"]))
+    misc = expand_batch(_mask2(place["misc_take"]), _mask2(place["misc_pair"]), int(place["numa"][len(place["numa"]) - 1]), cores_per_proc, num_cores,
+                        _mask2(place["misc_late"]))                       # (numa[-1]: nhdfit_wide_placement has five entries, nhdfit_big_placement nine)
     return {"groups": groups, "misc": misc}
 
 

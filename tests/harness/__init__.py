@@ -20,7 +20,9 @@ def lib():
     deps = [SRC] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "winner_map.h", "seq_core.h", "set_states.h", "commit_core.h", "wide_core.h", "dict_stream.h")] + \
            [os.path.join(HERE, "..", "..", "include", "nhdfit.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", SRC, "-o", SO])
+        tmp = f"{SO}.{os.getpid()}.tmp"                    # (several ranks of a gloo test may find it stale at once: each builds its own, the rename is atomic)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", SRC, "-o", tmp])
+        os.replace(tmp, SO)
     _lib = ctypes.CDLL(SO)
     _lib.hh_tuple_hash.restype = ctypes.c_uint64
     return _lib
@@ -196,6 +198,71 @@ def wide_commit(rec, req, mapping, busy_time):
     return int(st), out, rec[0]
 
 
+def _caps(packer):
+    caps = np.zeros(pack.MAX_CLASSES, "<f8")
+    caps[:len(packer.caps)] = packer.caps
+    return caps
+
+
+def big_eval(packer, table, wide: np.ndarray, reqs: np.ndarray, now: float, cand=None, global_base=0):
+    """k_big_eval on the host build: big requests (5..8 groups) against every node - the planes through wide_view, the wide
+    records as they are.  Returns (fits [n][P] by node index, scores, budget_exhausted)."""
+    L = lib()
+    reqs = np.ascontiguousarray(reqs, dtype=pack.BIG_REQ)
+    wide = np.ascontiguousarray(wide, dtype=pack.WIDE)
+    P, n = len(reqs), table.n
+    fits = np.zeros((n, P), np.uint8)
+    score = np.zeros(P, np.uint64)
+    flags = np.zeros(4, np.uint32)
+    caps = _caps(packer)
+    planes = [np.ascontiguousarray(getattr(table, f)) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
+    L.hh_big_eval(*[_p(x) for x in planes], ctypes.c_uint32(n), _p(wide) if len(wide) else None, ctypes.c_uint32(len(wide)), _p(reqs), ctypes.c_uint32(P),
+                  ctypes.c_double(now), _p(caps), _p(cand) if cand is not None else None, ctypes.c_uint64(global_base), _p(fits), _p(score), _p(flags))
+    return fits, score, bool(flags[1])
+
+
+def big_map(packer, table, v: int, wide_rec, req):
+    """wide_map for a big request on node v of `table` (wide_rec: that node's wide record, or None for an ordinary node)."""
+    L = lib()
+    out = np.zeros((), pack.BIG_MAPPING)
+    req = np.ascontiguousarray(req, dtype=pack.BIG_REQ).reshape(1)
+    caps = _caps(packer)
+    planes = [np.ascontiguousarray(getattr(table, f)) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
+    rec = None if wide_rec is None else np.ascontiguousarray(wide_rec, dtype=pack.WIDE).reshape(1)
+    L.hh_big_map.restype = ctypes.c_int
+    rc = L.hh_big_map(*[_p(x) for x in planes], ctypes.c_uint32(v), _p(rec) if rec is not None else None, _p(req), _p(caps), _p(out))
+    assert rc >= 0, "a set of the general model outgrew its table / the NIC search budget ran out"
+    return out
+
+
+def big_commit(packer, table, i, req, mapping, busy_time):
+    """commit_node_t<big> on node i of `table` (an ordinary node; modified in place).  Returns (status, pack.BIG_PLACEMENT)."""
+    L = lib()
+    _, sig_off, pool_off, glimit, cc, _, nsig = _dict_args(packer)
+    out = np.zeros((), pack.BIG_PLACEMENT)
+    req = np.ascontiguousarray(req, dtype=pack.BIG_REQ).reshape(1)
+    mapping = np.ascontiguousarray(mapping, dtype=pack.BIG_MAPPING).reshape(1)
+    rows = [np.ascontiguousarray(getattr(table, f)[i:i + 1]) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
+    L.hh_big_commit.restype = ctypes.c_int
+    rc = L.hh_big_commit(*[_p(x) for x in rows], _p(req), _p(mapping), ctypes.c_double(busy_time), _p(sig_off), ctypes.c_uint32(nsig),
+                         _p(pool_off), _p(glimit), _p(cc), _p(out))
+    for f, r in zip(("p0", "p1", "p2", "p3", "p4", "detail"), rows):
+        getattr(table, f)[i] = r[0]
+    out["node"] = i
+    return int(rc), out
+
+
+def big_commit_wide(rec, req, mapping, busy_time):
+    L = lib()
+    rec = np.array(rec, dtype=pack.WIDE).reshape(1)
+    out = np.zeros((), pack.BIG_PLACEMENT)
+    req = np.ascontiguousarray(req, dtype=pack.BIG_REQ).reshape(1)
+    mapping = np.ascontiguousarray(mapping, dtype=pack.BIG_MAPPING).reshape(1)
+    L.hh_big_commit_wide.restype = ctypes.c_int
+    st = L.hh_big_commit_wide(_p(rec), _p(req), _p(mapping), ctypes.c_double(busy_time), _p(out))
+    return int(st), out, rec[0]
+
+
 class HarnessEngine:
     """Engine-compatible front-end of the host build (TEST ONLY): lets HipMatcher's host logic (packing,
     dirty tracking, candidate masks, result decoding) and the sharding helpers run on CPU."""
@@ -325,6 +392,31 @@ class HarnessEngine:
         self.wide[node] = rec
         wp["node"] = node
         return wp
+
+    def big_find(self, reqs, now, cand=None, want_map=True):
+        """nhdfit_big_find as nhdfit.hip does it: k_big_eval over planes + wide records, k_big_map for the winners this mirror holds."""
+        reqs = np.ascontiguousarray(reqs, dtype=pack.BIG_REQ)
+        recs = self._wide_records()
+        _, score, exhausted = big_eval(self.packer, self.table, recs, reqs, now, cand=cand, global_base=self.global_base)
+        if exhausted:
+            from nhd_amd._lib import NhdFitError
+            raise NhdFitError(-6, "a big request's NIC stage ran out of search budget on some node")
+        maps = np.zeros(len(reqs), pack.BIG_MAPPING)
+        if want_map:
+            order = sorted(self.wide)
+            for p in np.flatnonzero(score != 0):
+                v = int(0x7FFFFFFFFFFFFFFF - (int(score[p]) & 0x7FFFFFFFFFFFFFFF)) - self.global_base
+                if 0 <= v < self.n:
+                    maps[p] = big_map(self.packer, self.table, v, recs[order.index(v)] if v in self.wide else None, reqs[p])
+        return score, (maps if want_map else None)
+
+    def big_commit(self, node, req, mapping, busy_time):
+        if node in self.wide:
+            st, pl, rec = big_commit_wide(self.wide[node], req, mapping, busy_time)
+            self.wide[node] = rec
+            pl["node"] = node
+            return pl
+        return big_commit(self.packer, self.table, node, req, mapping, busy_time)[1]
 
     def apply_deltas(self, deltas):
         return apply_deltas(self.packer, self.table, deltas)

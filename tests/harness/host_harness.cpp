@@ -600,3 +600,84 @@ extern "C" int hh_wide_isect3(const int16_t* a, int na, const int16_t* b, int nb
     for (int32_t i = ws_next(ABC, 0); i >= 0; i = ws_next(ABC, i + 1)) out[k++] = ABC.key[i];
     return k;
 }
+
+// ---- big requests (5..8 processing groups): the general path over every node (wide_core.h templates, commit_core.h commit_node_t) ----
+// fits [n][P] by node index (a wide node's verdict at its own index), scores max-merged; flags[1] = a pair ran out of NIC budget
+extern "C" void hh_big_eval(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
+                            const nhdfit_plane4* p4, const nhdfit_detail* det, uint32_t n, const nhdfit_wide_node* wide, uint32_t n_wide,
+                            const nhdfit_big_req* reqs, uint32_t P, double now, const double* caps, const uint64_t* cand,
+                            uint64_t global_base, uint8_t* fits, uint64_t* score, uint32_t* flags) {
+    const double busy_from = busy_threshold(now);
+    for (uint32_t v = 0; v < n + n_wide; ++v) {
+        nhdfit_wide_node view;
+        if (v < n) wide_view(p0[v], p1[v], p2[v], p3[v], p4[v], det[v], v, view);
+        else view = wide[v - n];
+        if (cand && !(cand[view.index >> 6] >> (view.index & 63) & 1ull)) continue;
+        const bool busy = view.busy_time >= busy_from;
+        for (uint32_t i = 0; i < P; ++i) {
+            NicSearch ns{NHDFIT_BIG_NIC_BUDGET, false};
+            const bool ok = wide_fits(view, reqs[i], busy, caps, &ns);
+            if (ns.exhausted) flags[1] = 1;
+            if (!ok) continue;
+            fits[(size_t)view.index * P + i] = 1;
+            uint32_t want = 0;
+            for (uint32_t g = 0; g < reqs[i].n_groups; ++g) want += reqs[i].gpus[g];
+            const uint64_t s = score_of(want == 0 && view.n_gpus == 0, global_base + view.index);
+            if (s > score[i]) score[i] = s;
+        }
+    }
+}
+// mapping of one winner: `wide` != NULL: that record, else node `v` of the planes
+extern "C" int hh_big_map(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
+                          const nhdfit_plane4* p4, const nhdfit_detail* det, uint32_t v, const nhdfit_wide_node* wide,
+                          const nhdfit_big_req* r, const double* caps, nhdfit_big_mapping* out) {
+    nhdfit_wide_node view;
+    if (wide) view = *wide; else wide_view(p0[v], p1[v], p2[v], p3[v], p4[v], det[v], v, view);
+    const uint32_t U = view.numa_nodes ? view.numa_nodes : 1, G = r->n_groups <= NHDFIT_BIG_MAX_GROUPS ? r->n_groups : NHDFIT_BIG_MAX_GROUPS;
+    std::vector<int32_t> scratch(big_scratch_words(U, G));           // (the device sizes them for the mirror's widest node: any size >= the need gives the same answer)
+    return wide_map(view, *r, caps, scratch.data(), *out, (int32_t)wide_table_slots(wide_ipow(U, G)), (int32_t)wide_table_slots(wide_ipow(U, G + 1)));
+}
+extern "C" int hh_big_commit_wide(nhdfit_wide_node* n, const nhdfit_big_req* r, const nhdfit_big_mapping* m, double busy_time, nhdfit_big_placement* out) {
+    const int st = wide_commit(*n, *r, *m, busy_time, *out);
+    out->pod = 0; out->node = n->index;
+    return st;
+}
+extern "C" int hh_big_commit(nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plane2* p2, nhdfit_plane3* p3, nhdfit_plane4* p4, nhdfit_detail* det,
+                             const nhdfit_big_req* req, const nhdfit_big_mapping* map, double busy_time,
+                             const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit, const nhdfit_cc* cc,
+                             nhdfit_big_placement* out) {
+    uint32_t slots = 64;
+    while (slots < 4 * nsig) slots <<= 1;
+    std::vector<uint64_t> skeys(slots, 0);
+    std::vector<uint32_t> sids(slots, 0);
+    for (uint32_t sg = 1; sg < nsig; ++sg) {
+        uint64_t key = 0;
+        for (uint32_t pl = sig_off[sg]; pl < sig_off[sg + 1]; ++pl) {
+            uint8_t cnt[NHDFIT_MAX_CLASSES] = {0};
+            for (uint32_t k = pool_off[pl]; k < pool_off[pl + 1]; ++k) cnt[cc[k].cls & 15u] = cc[k].cnt;
+            key = sig_key_add(key, pool_key(pool_glimit[pl], cnt));
+        }
+        if (!key) continue;
+        uint32_t sl = (uint32_t)mix64(key) & (slots - 1);
+        while (skeys[sl] != 0 && skeys[sl] != key) sl = (sl + 1) & (slots - 1);
+        skeys[sl] = key; sids[sl] = sg;
+    }
+    NodeState st{*p0, *p1, *p2, *p3, *p4};
+    std::memset(out, 0, sizeof *out);
+    const int rc = commit_node_t<nhdfit_big_req, nhdfit_big_placement>(st, *det, *req, *map, busy_time, SigTable{skeys.data(), sids.data(), slots - 1}, *out);
+    *p0 = st.p0; *p1 = st.p1; *p2 = st.p2; *p3 = st.p3; *p4 = st.p4;
+    return rc;
+}
+// list(set) after adding `codes` one by one with the big requests' tables (int32 keys, slots sized by wide_table_slots); -1 on overflow
+extern "C" int hh_big_set_list(const int32_t* codes, int n, uint32_t len, uint32_t U, int32_t* out) {
+    const uint32_t slots = wide_table_slots((uint32_t)n);
+    std::vector<int32_t> mem(slots), tmp(slots);
+    WideSetT<int32_t> s;
+    ws_init(s, mem.data(), (int32_t)slots, len, U);
+    for (int i = 0; i < n; ++i) ws_add(s, codes[i], tmp.data());
+    if (s.overflow) return -1;
+    int k = 0;
+    for (int32_t i = ws_next(s, 0); i >= 0; i = ws_next(s, i + 1)) out[k++] = s.key[i];
+    return k;
+}
+extern "C" uint32_t hh_table_slots(uint32_t keys) { return wide_table_slots(keys); }

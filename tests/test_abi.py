@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_lib._SIGS)
-    assert lib.nhdfit_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.nhdfit_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_struct_sizes_match_header():
@@ -67,6 +67,24 @@ def test_placement_record_matches_header():
     assert pack.PLACEMENT.itemsize == 256 and pack.WIDE.itemsize == 640 and pack.WIDE_PLACEMENT.itemsize == 480
     assert pack.PLACEMENT.fields["misc_take"][1] == 128 and pack.PLACEMENT.fields["gpu"][1] == 144 and pack.PLACEMENT.fields["numa"][1] == 176
     assert pack.PLACEMENT.fields["status"][1] == 181 and pack.PLACEMENT.fields["proc_late"][1] == 184 and pack.PLACEMENT.fields["misc_late"][1] == 248
+
+
+def test_big_request_records_match_header():
+    """nhdfit_big_req / nhdfit_big_mapping / nhdfit_big_placement (pods with 5..8 processing groups): sizes and the offsets
+    `gcc offsetof` gives for include/nhdfit.h."""
+    assert (pack.BIG_REQ.itemsize, pack.BIG_MAPPING.itemsize, pack.BIG_PLACEMENT.itemsize) == (256, 36, 904)
+    f = pack.BIG_REQ.fields
+    assert {k: f[k][1] for k in ("gpus", "cpu_smt", "misc_smt", "smt_bits", "n_misc", "rx", "tx", "n_proc", "n_help", "nic_use")} == \
+        {"gpus": 24, "cpu_smt": 40, "misc_smt": 72, "smt_bits": 76, "n_misc": 78, "rx": 80, "tx": 144, "n_proc": 208, "n_help": 216, "nic_use": 224}
+    f = pack.BIG_MAPPING.fields
+    assert {k: f[k][1] for k in ("cpu", "nic_numa", "nic_idx", "valid")} == {"cpu": 8, "nic_numa": 17, "nic_idx": 25, "valid": 33}
+    f = pack.BIG_PLACEMENT.fields
+    assert {k: f[k][1] for k in ("help_take", "misc_take", "gpu", "numa", "status", "pod", "node")} == \
+        {"help_take": 384, "misc_take": 768, "gpu": 816, "numa": 880, "status": 889, "pod": 892, "node": 896}
+    lib = _lib.load()
+    buf = (ctypes.c_uint8 * 1024)()
+    assert lib.nhdfit_big_find(None, buf, 1, 0.0, None, buf, None) == -1
+    assert lib.nhdfit_big_commit(None, 0, buf, buf, 0.0, buf) == -1
 
 
 def test_binding_refuses_a_library_of_another_abi(monkeypatch):

@@ -179,10 +179,20 @@ def test_requests_beyond_the_record_and_device_errors_answer_none(caplog):
                                        groups=[dict(proc=2, helpers=0, rx=0, tx=0, gpus=[], proc_smt=False, helper_smt=False)] * 5))
     huge = refmodel.make_topology(dict(map_type="NUMA", hugepages_gb=5000, misc=0, misc_smt=True,
                                        groups=[dict(proc=2, helpers=0, rx=0, tx=0, gpus=[], proc_smt=False, helper_smt=False)]))
+    nine = refmodel.make_topology(dict(map_type="NUMA", hugepages_gb=0, misc=0, misc_smt=True,
+                                       groups=[dict(proc=2, helpers=0, rx=0, tx=0, gpus=[], proc_smt=False, helper_smt=False)] * 9))
     with caplog.at_level("ERROR"):
-        got = m.FindNodes(nl, [ok, five, huge, ok])
-    assert got[0] == norm(O.find_node(nl, ok, util.CLOCK)) == got[3] and got[1] == (None,) and got[2] == (None,)
-    assert "cannot be expressed" in caplog.text
+        got = m.FindNodes(nl, [ok, five, huge, ok, nine])
+    # five groups, or more hugepages than the pod tile's table holds: answered by the general path (nhdfit_big_req), as the reference would
+    assert got[0] == norm(O.find_node(nl, ok, util.CLOCK)) == got[3] and got[1] == norm(O.find_node(nl, five, util.CLOCK)) and got[1][0] is not None
+    assert got[2] == norm(O.find_node(nl, huge, util.CLOCK)) == (None,)
+    assert got[4] == (None,) and "cannot be expressed" in caplog.text              # nine groups: beyond every record
+    roomy = refmodel.make_topology(dict(map_type="NUMA", hugepages_gb=2000, misc=0, misc_smt=True,
+                                        groups=[dict(proc=2, helpers=0, rx=0, tx=0, gpus=[], proc_smt=False, helper_smt=False)]))
+    big_mem = dict(nl)
+    last = list(big_mem)[-1]
+    big_mem[last].mem.free_hugepages_gb = 4096                                      # a node with terabytes of 1G pages takes the 2 000 GiB pod
+    assert norm(m.FindNode(big_mem, roomy)) == norm(O.find_node(big_mem, roomy, util.CLOCK)) and m.FindNode(big_mem, roomy)[0] is not None
 
     from nhd_amd._lib import NhdFitError
 
