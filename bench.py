@@ -221,6 +221,7 @@ def main():
         out["mode_b"] = mode_b(eng, pk, reqs, now, args.pods, parity=(spec, tops, pod_groups))
         out["other_configs"] = other_configs(args, local_rank)
         out["deltas"] = delta_rate(eng, table)
+        out["big_pod_find"] = big_pod_find(eng, pk, pods, pod_groups, tops, reqs, now, n_total)
         out["score_only"] = score_only(eng, reqs, now, args.pods, n_total)     # last: it changes the context's outputs
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not inner:
         out["cpu_baseline"] = cpu_baseline(spec, tops, pod_groups, args.cpu_sample_pods, score, lo, winner_index, args)
@@ -405,6 +406,54 @@ def single_find(eng, reqs, now, n_total, calls=200):
     return {"call": "nhdfit_find, 1 pod, winner + mapping (single launch)" if took else "nhdfit_find, 1 pod (staged path)",
             "ms_per_call_median": ts[len(ts) // 2] * 1e3, "ms_per_call_min": ts[0] * 1e3, "calls": len(ts),
             "single_launch_calls": int(took), "nodes": int(n_total)}
+
+
+def big_pod_find(eng, pk, pods, pod_groups, tops, reqs, now, n_total, calls=12):
+    """Pods beyond the table pass (5..8 processing groups; nhdfit_big_req): one such pod against the whole
+    mirror through nhdfit_big_find - the general path, explicit enumeration per (pod, node), lane = node.  A rare path with no
+    rate to defend: reported so that its cost is known (milliseconds per pod against the table pass's microseconds).  Parity is
+    asserted in the run the only way it can be without a second implementation on the box: ordinary pods digested as big
+    requests must get the score word and mapping the table pass gives them.  Never raises: an error is reported in place."""
+    try:
+        from workload import refmodel
+        ordinary = [k for k in range(len(tops)) if len(tops[k].proc_groups) <= 3][:calls]
+        big_ord = np.zeros(len(ordinary), pack_mod().BIG_REQ)
+        for j, k in enumerate(ordinary):
+            big_ord[j] = pk.digest_big(tops[k], pod_groups[k])
+        score, _, maps = eng.find(reqs[ordinary], now, want_bitmap=False, want_map=True)
+        bscore, bmaps = eng.big_find(big_ord, now)
+        same = bool(np.array_equal(score, bscore))
+        for j in np.flatnonzero(score != 0):
+            G = int(reqs[ordinary[j]]["n_groups"])
+            same = same and all(list(maps[j][f][:n]) == list(bmaps[j][f][:n]) for f, n in (("gpu", G), ("cpu", G + 1), ("nic_numa", G), ("nic_idx", G)))
+        # real big pods: the groups of two or three of the batch's pods under one topology (5..8 groups)
+        merged, k = [], 0
+        while len(merged) < calls and k + 3 <= len(pods):
+            groups = [g for s in pods[k:k + 3] for g in s["groups"]]
+            k += 3
+            if 5 <= len(groups) <= 8:
+                merged.append((dict(pods[k - 3], groups=groups), pod_groups[k - 3]))
+        ts, placed = [], 0
+        for sp, grp in merged:
+            r = pk.digest_big(refmodel.make_topology(sp), grp).reshape(1)
+            eng.big_find(r, now)
+            t0 = time.perf_counter()
+            sc, _ = eng.big_find(r, now)
+            ts.append(time.perf_counter() - t0)
+            placed += int(sc[0] != 0)
+        ts.sort()
+        return {"call": "nhdfit_big_find, 1 pod with 5..8 processing groups, winner + mapping (general path, every node enumerated)",
+                "ms_per_call_median": ts[len(ts) // 2] * 1e3 if ts else None, "ms_per_call_min": ts[0] * 1e3 if ts else None, "calls": len(ts),
+                "placed": placed, "nodes": int(n_total),
+                "parity": {"identical": same, "pods": len(ordinary),
+                           "against": "the table-driven pass on the same (ordinary) pods digested both ways: score words and mappings"}}
+    except Exception as e:  # noqa: BLE001 - an extra must not cost the run its line
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def pack_mod():
+    from nhd_amd import pack
+    return pack
 
 
 def score_only(eng, reqs, now, P, n_total, steps=100):

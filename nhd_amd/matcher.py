@@ -613,7 +613,8 @@ class HipMatcher:
             gpu, cpu, nic_numa, nic_idx, valid, _ = rows[p]
             if not valid:
                 raise RuntimeError(f"internal error: no mapping produced for feasible node {name}")
-            out.append((name, {"gpu": tuple(gpu[:G]), "cpu": tuple(cpu[:G + 1]), "nic": list(zip(nic_numa[:G], nic_idx[:G]))}))
+            out.append((name, {"gpu": tuple(gpu[:G].tolist()), "cpu": tuple(cpu[:G + 1].tolist()),        # (plain ints, as the reference's tuples hold)
+                               "nic": list(zip(nic_numa[:G].tolist(), nic_idx[:G].tolist()))}))
         return out
 
     # ---- pods with 5..8 processing groups (nhdfit_big_req): the general path ---------------------------------------------
@@ -647,7 +648,8 @@ class HipMatcher:
             gpu, cpu, nic_numa, nic_idx, valid, _ = row
             if not valid:
                 raise RuntimeError(f"internal error: no mapping produced for feasible node {names[i]}")
-            out[p] = (names[i], {"gpu": tuple(gpu[:G]), "cpu": tuple(cpu[:G + 1]), "nic": list(zip(nic_numa[:G], nic_idx[:G]))})
+            out[p] = (names[i], {"gpu": tuple(gpu[:G].tolist()), "cpu": tuple(cpu[:G + 1].tolist()),
+                                 "nic": list(zip(nic_numa[:G].tolist(), nic_idx[:G].tolist()))})
 
         if not sequential:
             if small_idx:

@@ -90,6 +90,21 @@ def vf_node_desc(rng, name, vfs):
                 busy_time=util.CLOCK - 500.0)
 
 
+def multi_socket_desc(rng, name, sockets, cpp, nics_on, gpus_on=()):
+    """`sockets` sockets of `cpp` physical cores (SMT), one 100 GbE NIC on each NUMA node of `nics_on` (switch 0x10 * (numa + 1)),
+    one GPU on each NUMA node of `gpus_on` behind that NUMA node's switch."""
+    phys = sockets * cpp
+    lab = {NFD + "nfd-extras-cpu.numSockets": str(sockets), NFD + "nfd-extras-cpu.num_cores": str(phys), NFD + "cpu-hardware_multithreading": "true"}
+    for j, numa in enumerate(nics_on):
+        lab[NFD + f"nfd-extras-nic.eth{j}.mlx.{0xABF000 + j:012x}.100000Mbs.{numa}.{0x10 * (numa + 1):x}.{j}.0"] = "true"
+    for g, numa in enumerate(gpus_on):
+        lab[NFD + f"nfd-extras-gpu.{g}.V100.{numa}.{0x10 * (numa + 1):x}"] = "true"
+    lab["DATA_PLANE_VLAN"] = "7"
+    lab["DATA_DEFAULT_GW"] = "10.1.0.1/32"
+    return dict(name=name, labels=lab, hugepages=[16, 16], active=True, used_cores=[c for c in range(phys) if rng.random() < 0.1],
+                used_gpus=[], nic_pods_used=[0] * len(nics_on), busy_time=util.CLOCK - 500.0)
+
+
 def run_case(ref, descs, specs, fname, extra=None):
     t_start = time.time()
     clock = ref_loader.VirtualClock(util.CLOCK).install()
@@ -164,6 +179,36 @@ def main():
                 g["rx"] = float(rng.choice([10, 25, 40, 45]))
                 g["tx"] = float(rng.choice([5, 10, 45]))
         run_case(ref, descs, specs, "big_vf")
+
+
+    if not only or "big_quad" in only:                        # three and four sockets with seven and eight groups: 3^8 .. 4^9 assignment tuples
+        rng = np.random.default_rng(82004)
+        descs = [multi_socket_desc(rng, "w0000", 4, 12, (0, 1, 2, 3), (0, 2)), util.random_node_desc(rng, "n0001", 0.1),
+                 multi_socket_desc(rng, "w0002", 3, 20, (0, 1, 2)), multi_socket_desc(rng, "w0003", 4, 16, (0, 0, 2, 3), (1,)),
+                 cap_nics(util.random_node_desc(rng, "n0004", 0.1), 3), multi_socket_desc(rng, "w0005", 4, 10, (1, 3))]
+        specs = []
+        for k in range(8):                                    # (seven groups at most here: at 4^9 tuples the reference's own list scans,
+            s = big_pod_spec(rng, 7 if k < 3 else 5, 7 if k < 3 else 6, small_share=0.0)   # nhd/Matcher.py:371-373, take hours per node)
+            if len(s["groups"]) >= 7:
+                s["map_type"] = "NUMA"                        # (the reference's PCI pruning is quadratic in the NIC combinations, nhd/Matcher.py:329-335)
+            for g in s["groups"]:
+                g["proc"], g["helpers"] = 2, 0
+            specs.append(s)
+        run_case(ref, descs, specs, "big_quad", {"drawn_wide": ["w0000", "w0002", "w0003", "w0005"]})
+
+
+    if not only or "big_tri" in only:                         # three sockets, eight groups: 3^9 tuples
+        rng = np.random.default_rng(82005)
+        descs = [multi_socket_desc(rng, "w0000", 3, 24, (0, 1, 2), (0,)), multi_socket_desc(rng, "w0001", 3, 16, (0, 2, 2)),
+                 cap_nics(util.random_node_desc(rng, "n0002", 0.1), 2), multi_socket_desc(rng, "w0003", 3, 32, (1, 2))]
+        specs = []
+        for k in range(6):
+            s = big_pod_spec(rng, 8, 8, small_share=0.0)
+            s["map_type"] = "NUMA" if k % 3 else "PCI"
+            for g in s["groups"]:
+                g["proc"], g["helpers"] = 2, 0
+            specs.append(s)
+        run_case(ref, descs, specs, "big_tri", {"drawn_wide": ["w0000", "w0001", "w0003"]})
 
 
 if __name__ == "__main__":
