@@ -483,8 +483,10 @@ int nhdfit_reset_stats(nhdfit_ctx* ctx);
  * Returns 0, or one of the codes below with a message in err[errlen]. */
 #define NHDFIT_WIRE_NONE   1   /* the reference's CfgToTopology returns None for this text (pod not scheduled) */
 #define NHDFIT_WIRE_RAISE  2   /* the reference would raise (malformed text, value of the wrong type)           */
-#define NHDFIT_WIRE_LIMIT  3   /* more than NHDFIT_MAX_GROUPS proc groups or 255 cores in a group               */
+#define NHDFIT_WIRE_LIMIT  3   /* more proc groups than the record holds (4 / 8) or 255 cores in a group        */
 int nhdfit_digest_triad_config(const char* text, size_t len, nhdfit_req* out, char* err, size_t errlen);
+/* the same text into a nhdfit_big_req: a pod with up to NHDFIT_BIG_MAX_GROUPS processing groups (what NHDFIT_WIRE_LIMIT above turns away) */
+int nhdfit_digest_triad_config_big(const char* text, size_t len, nhdfit_big_req* out, char* err, size_t errlen);
 /* n texts in one call: codes[i] as above, out[i] zeroed unless codes[i] == 0; returns how many codes are non-zero */
 int nhdfit_digest_triad_configs(const char* const* texts, const size_t* lens, uint32_t n, nhdfit_req* out, int32_t* codes);
 

@@ -70,6 +70,7 @@ _SIGS = {
     "nhdfit_group_last_error": (c_char_p, [c_void_p]),
     "nhdfit_group_find": (c_int, [c_void_p, c_void_p, c_uint32, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nhdfit_digest_triad_config": (c_int, [c_char_p, ctypes.c_size_t, c_void_p, c_char_p, ctypes.c_size_t]),
+    "nhdfit_digest_triad_config_big": (c_int, [c_char_p, ctypes.c_size_t, c_void_p, c_char_p, ctypes.c_size_t]),
     "nhdfit_digest_triad_configs": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_void_p]),
 }
 

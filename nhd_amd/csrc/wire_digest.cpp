@@ -693,7 +693,10 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
 
 unsigned half_up(unsigned n) { return (n + 1) / 2; }                        // math.ceil(n / 2.0)
 
-void digest(const char* text, size_t len, nhdfit_req& r) {
+// R = nhdfit_req (up to four processing groups) or nhdfit_big_req (up to eight: the general path's request record)
+template <class R>
+void digest(const char* text, size_t len, R& r) {
+    constexpr unsigned kGroups = sizeof(r.gpus) / sizeof(r.gpus[0]);
     g_arena.reset();
     Reader reader(text, len);
     const ValuePtr rootp = reader.parse_document();
@@ -747,7 +750,7 @@ void digest(const char* text, size_t len, nhdfit_req& r) {
     if (bad_speed) throw Raise{"a NIC speed is not a number (the reference fails when FindNode adds the speeds up)"};
 
     // the integers FindNode derives from the object graph (nhd/CfgTopology.py:199-232, nhd/Matcher.py:178-204)
-    if (groups.size() > NHDFIT_MAX_GROUPS) throw Limit{"more proc groups than NHDFIT_MAX_GROUPS"};
+    if (groups.size() > kGroups) throw Limit{kGroups == NHDFIT_MAX_GROUPS ? "more proc groups than NHDFIT_MAX_GROUPS" : "more proc groups than NHDFIT_BIG_MAX_GROUPS"};
     std::memset(&r, 0, sizeof r);
     r.n_groups = (uint32_t)groups.size();
     r.map_type = map_type;
@@ -758,8 +761,8 @@ void digest(const char* text, size_t len, nhdfit_req& r) {
         r.gpus[i] = (uint16_t)g.gpus;
         r.n_proc[i] = (uint8_t)g.proc;
         r.n_help[i] = (uint8_t)g.help;
-        if (g.proc_smt) r.smt_bits |= (uint8_t)(1u << i);
-        if (g.helper_smt) r.smt_bits |= (uint8_t)(1u << (4 + i));
+        if (g.proc_smt) r.smt_bits |= (decltype(r.smt_bits))(1u << i);
+        if (g.helper_smt) r.smt_bits |= (decltype(r.smt_bits))(1u << (kGroups + i));
         r.cpu_nosmt[i] = (uint16_t)(g.proc + g.help);
         r.cpu_smt[i] = (uint16_t)((g.proc_smt ? half_up(g.proc) : g.proc) + (g.helper_smt ? half_up(g.help) : g.help));
         r.rx[i] = g.rx;
@@ -781,6 +784,21 @@ void set_err(char* err, size_t errlen, const std::string& msg) {
 }  // namespace
 
 extern "C" int nhdfit_digest_triad_config(const char* text, size_t len, nhdfit_req* out, char* err, size_t errlen) {
+    if (!text || !out) { set_err(err, errlen, "null argument"); return NHDFIT_E_INVAL; }
+    try {
+        digest(text, len, *out);
+        set_err(err, errlen, "");
+        return NHDFIT_OK;
+    } catch (const Reject& e) { set_err(err, errlen, e.why); return NHDFIT_WIRE_NONE; }
+      catch (const Raise& e) { set_err(err, errlen, e.why); return NHDFIT_WIRE_RAISE; }
+      catch (const AttrMissing& e) { set_err(err, errlen, e.why); return NHDFIT_WIRE_RAISE; }
+      catch (const Limit& e) { set_err(err, errlen, e.why); return NHDFIT_WIRE_LIMIT; }
+      catch (const std::exception& e) { set_err(err, errlen, e.what()); return NHDFIT_E_INVAL; }
+      catch (...) { set_err(err, errlen, "unknown failure"); return NHDFIT_E_INVAL; }
+}
+
+// the same text into the general path's request record (5..8 processing groups; include/nhdfit.h nhdfit_big_req)
+extern "C" int nhdfit_digest_triad_config_big(const char* text, size_t len, nhdfit_big_req* out, char* err, size_t errlen) {
     if (!text || !out) { set_err(err, errlen, "null argument"); return NHDFIT_E_INVAL; }
     try {
         digest(text, len, *out);

@@ -472,14 +472,18 @@ class HipMatcher:
         if not cfg_texts:
             return []
         reqs, codes = wire.digest_configs(cfg_texts)
-        for i in np.flatnonzero(codes > wire.WIRE_NONE):     # what the reference would raise on: report it properly
-            wire.digest_config(cfg_texts[int(i)])
+        big_reqs = {}
+        for i in np.flatnonzero(codes > wire.WIRE_NONE):
+            if codes[i] == wire.WIRE_LIMIT:                  # more than four processing groups: up to eight ride the general path
+                big_reqs[int(i)] = wire.digest_config_big(cfg_texts[int(i)])       # (raises what the limit really is beyond that)
+            else:                                            # what the reference would raise on: report it properly
+                wire.digest_config(cfg_texts[int(i)])
         skip = codes == wire.WIRE_NONE                       # all-zero (= never matching) requests
         # (the pods' group bits are filled in by _run, after the mirror - and with it the dictionary - is current)
         for i in np.flatnonzero(~skip):
-            if reqs[i]["n_groups"] == 0 and len(nl):
+            if int(i) not in big_reqs and reqs[i]["n_groups"] == 0 and len(nl):
                 raise IndexError("pod without processing groups (the reference fails the same way, Matcher.py:346)")
-        out = self._run(nl, None, pod_groups, now, sequential, reqs=reqs)
+        out = self._run(nl, None, pod_groups, now, sequential, reqs=reqs, big_reqs=big_reqs)
         return [(None,) if skip[i] else out[i] for i in range(len(cfg_texts))]
 
     @property
@@ -502,9 +506,9 @@ class HipMatcher:
                 self._warned.add(name)
                 self.logger.warning("node %s is not mirrored on the device and will never be selected: %s", name, why)
 
-    def _run(self, nl, tops, pod_groups, now, sequential, reqs=None, apply=False):
+    def _run(self, nl, tops, pod_groups, now, sequential, reqs=None, apply=False, big_reqs=None):
         try:
-            return self._run_checked(nl, tops, pod_groups, now, sequential, reqs, apply)
+            return self._run_checked(nl, tops, pod_groups, now, sequential, reqs, apply, big_reqs)
         except NhdFitError as e:
             if self.strict:
                 raise
@@ -515,7 +519,7 @@ class HipMatcher:
             self.last_placements = [None] * n_pods
             return [(None,) for _ in range(n_pods)]
 
-    def _run_checked(self, nl, tops, pod_groups, now, sequential, reqs=None, apply=False):
+    def _run_checked(self, nl, tops, pod_groups, now, sequential, reqs=None, apply=False, big_reqs=None):
         if reqs is None:
             if not tops:
                 return []
@@ -561,7 +565,28 @@ class HipMatcher:
             self.last_placements = [None] * n_pods
             return [(None,) for _ in range(n_pods)]
         if reqs is None and any(pack.needs_general_path(top) for top in tops):
-            return self._run_with_big(nl, tops, pod_groups, now, cand, sequential, apply)
+            # pods the table pass cannot express but the general path answers (5..8 processing groups, huge hugepage requests)
+            is_big = [pack.needs_general_path(top) for top in tops]
+            small_idx = [p for p in range(n_pods) if not is_big[p]]
+            beyond = []
+            small = self.packer.digest_many([tops[p] for p in small_idx], None if pod_groups is None else [pod_groups[p] for p in small_idx],
+                                            unsupported=beyond)
+            for k, why in beyond:
+                self.logger.error("pod %d of the call cannot be expressed as a request record and is answered (None,): %s", small_idx[k], why)
+            bigs = np.zeros(n_pods - len(small_idx), pack.BIG_REQ)
+            for k, p in enumerate(p for p in range(n_pods) if is_big[p]):
+                bigs[k] = self.packer.digest_big(tops[p], None if pod_groups is None else pod_groups[p])
+            return self._run_with_big(nl, is_big, small, bigs, now, cand, sequential, apply)
+        if reqs is not None and big_reqs:                  # digested from config texts (FindNodesFromConfigs)
+            is_big = [p in big_reqs for p in range(n_pods)]
+            small = reqs[[p for p in range(n_pods) if not is_big[p]]]
+            bigs = np.array([big_reqs[p] for p in range(n_pods) if is_big[p]], dtype=pack.BIG_REQ)
+            if pod_groups is not None:
+                for arr, idx in ((small, [p for p in range(n_pods) if not is_big[p]]), (bigs, [p for p in range(n_pods) if is_big[p]])):
+                    for k, p in enumerate(idx):
+                        arr[k]["flags"] = pack.RF_INITIAL_FILTER
+                        arr[k]["groups"] = self.packer.group_bits_known(pod_groups[p])
+            return self._run_with_big(nl, is_big, small, bigs, now, cand, sequential, apply)
         if reqs is None:
             beyond: List[Tuple[int, str]] = []
             reqs = self.packer.digest_many(tops, pod_groups, unsupported=beyond)
@@ -618,33 +643,30 @@ class HipMatcher:
         return out
 
     # ---- pods with 5..8 processing groups (nhdfit_big_req): the general path ---------------------------------------------
-    def _run_with_big(self, nl, tops, pod_groups, now, cand, sequential, apply):
-        """FindNodes / ScheduleBatch for a call that holds pods with more than pack.MAX_GROUPS processing groups (the reference
-        takes any group count, nhd/Matcher.py:118,203,242).  Such a pod is digested as a nhdfit_big_req and answered on the
-        device by the general path (nhdfit_big_find: every node by explicit enumeration, the same score word, the general CPython
-        set model for its mapping; nhdfit_big_commit for its commit step); the other pods of the call take the table-driven pass
-        as always.  Mode A: two device calls, results interleaved.  Mode B: the scheduler's loop as it stands
-        (nhd/NHDScheduler.py:425-437) - pod after pod, each decided and committed on the device before the next is matched."""
-        n_pods = len(tops)
-        big = [pack.needs_general_path(top) for top in tops]
-        groups_of = (lambda p: pod_groups[p]) if pod_groups is not None else (lambda p: None)
+    def _run_with_big(self, nl, big, small_reqs, big_reqs, now, cand, sequential, apply):
+        """FindNodes / ScheduleBatch for a call that holds pods the table-driven pass cannot express: more than pack.MAX_GROUPS
+        processing groups (the reference takes any group count, nhd/Matcher.py:118,203,242) or a hugepage request beyond the pod
+        tile's table.  `big[p]` says which; `small_reqs` / `big_reqs` are the two kinds' records in pod order.  A big pod is a
+        nhdfit_big_req answered on the device by the general path (nhdfit_big_find: every node by explicit enumeration, the same
+        score word, the general CPython set model for its mapping; nhdfit_big_commit for its commit step); the other pods of the
+        call take the table-driven pass as always.  Mode A: two device calls, results interleaved.  Mode B: the scheduler's loop
+        as it stands (nhd/NHDScheduler.py:425-437) - pod after pod, each decided and committed on the device before the next is
+        matched."""
+        n_pods = len(big)
         small_idx = [p for p in range(n_pods) if not big[p]]
         big_idx = [p for p in range(n_pods) if big[p]]
-        beyond: List[Tuple[int, str]] = []
-        small_reqs = self.packer.digest_many([tops[p] for p in small_idx], None if pod_groups is None else [pod_groups[p] for p in small_idx],
-                                             unsupported=beyond)
-        for k, why in beyond:
-            self.logger.error("pod %d of the call cannot be expressed as a request record and is answered (None,): %s", small_idx[k], why)
-        big_reqs = np.zeros(len(big_idx), pack.BIG_REQ)
+        n_groups = [0] * n_pods
+        for k, p in enumerate(small_idx):
+            n_groups[p] = int(small_reqs[k]["n_groups"])
         for k, p in enumerate(big_idx):
-            big_reqs[k] = self.packer.digest_big(tops[p], groups_of(p))
+            n_groups[p] = int(big_reqs[k]["n_groups"])
         base = self.engine.global_base
         names = self._names
         out: List[Tuple] = [(None,)] * n_pods
         self.last_placements = [None] * n_pods
 
         def answer(p, i, row):
-            G = len(tops[p].proc_groups)
+            G = n_groups[p]
             gpu, cpu, nic_numa, nic_idx, valid, _ = row
             if not valid:
                 raise RuntimeError(f"internal error: no mapping produced for feasible node {names[i]}")
@@ -672,7 +694,7 @@ class HipMatcher:
         pos_small = {p: k for k, p in enumerate(small_idx)}
         pos_big = {p: k for k, p in enumerate(big_idx)}
         for p in range(n_pods):
-            G = len(tops[p].proc_groups)
+            G = n_groups[p]
             if big[p]:
                 req = big_reqs[pos_big[p]]
                 score, maps = self.engine.big_find(big_reqs[pos_big[p]:pos_big[p] + 1], now, cand=cand)

@@ -49,6 +49,26 @@ def digest_config(text, pod_groups: Optional[Sequence[str]] = None, packer: Opti
     return req
 
 
+def digest_config_big(text) -> Optional[np.ndarray]:
+    """libconfig text -> nhdfit_big_req (pack.BIG_REQ): a pod with up to eight processing groups, for the general path
+    (HipMatcher.FindNodesFromConfigs sends the texts digest_configs turns away with WIRE_LIMIT here).  None / ConfigError /
+    UnsupportedNode as digest_config."""
+    lib = _lib.load()
+    raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+    req = np.zeros((), pack.BIG_REQ)
+    err = ctypes.create_string_buffer(256)
+    rc = lib.nhdfit_digest_triad_config_big(raw, len(raw), req.ctypes.data_as(ctypes.c_void_p), err, len(err))
+    if rc == WIRE_NONE:
+        return None
+    if rc == WIRE_RAISE:
+        raise ConfigError(err.value.decode("utf-8", "replace"))
+    if rc == WIRE_LIMIT:
+        raise pack.UnsupportedNode(err.value.decode("utf-8", "replace"))
+    if rc != 0:
+        raise _lib.NhdFitError(rc, err.value.decode("utf-8", "replace"))
+    return req
+
+
 def digest_configs(texts: Sequence) -> "tuple[np.ndarray, np.ndarray]":
     """Many texts in one library call: (requests [n] of dtype pack.REQ, codes [n] int32).  codes[i] is 0, WIRE_NONE,
     WIRE_RAISE or WIRE_LIMIT; requests of non-zero codes are all-zero records (= never matching)."""

@@ -149,3 +149,64 @@ def test_sequential_batch_from_config_texts():
     tops = [ref_loader.config_to_topology(t) for t in texts]
     m = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)
     assert m.FindNodesFromConfigs(nl, texts, sequential=True) == m.ScheduleBatch(nl, tops)
+
+
+def test_configs_with_more_groups_than_the_table_pass_holds():
+    """Texts with 5..8 processing groups: digest_config turns them away (WIRE_LIMIT), digest_config_big gives the bytes
+    Packer.digest_big gives for the reference parser's CfgTopology - the record the general path answers (nhdfit_big_find)."""
+    seen = {}
+    for seed in range(700):
+        text = wire_gen.make_config(50_000 + seed, types_hi=5, inst_hi=3)
+        try:
+            top = ref_loader.config_to_topology(text)
+        except Exception:  # noqa: BLE001
+            continue
+        if top is None or len(top.proc_groups) <= pack.MAX_GROUPS:
+            continue
+        G = len(top.proc_groups)
+        try:
+            want = pack.Packer().digest_big(top)
+        except Exception:  # noqa: BLE001 - e.g. a string NIC speed
+            continue
+        with pytest.raises(pack.UnsupportedNode):
+            wire.digest_config(text)
+        got = wire.digest_config_big(text)
+        assert got is not None and got.tobytes() == want.tobytes(), (seed, G, want, got)
+        seen[G] = seen.get(G, 0) + 1
+    assert set(seen) >= {5, 6, 8}, seen
+
+
+def test_matcher_from_config_texts_with_big_pods():
+    """FindNodesFromConfigs on texts of which some have 5..8 processing groups: equal to FindNodes / ScheduleBatch on the
+    reference-parsed topologies (the big ones through nhdfit_big_req both ways), and to the oracle.  Host build."""
+    from nhd_amd.matcher import HipMatcher
+    from oracle import nhd_oracle as O
+    from tests import harness, util
+    descs = util.random_cluster_desc(52, 40, occupancy=0.05)
+    nl = util.build_cluster(descs)
+    texts, tops = [], []
+    for seed in range(900):
+        t = wire_gen.make_config(50_000 + seed, types_hi=5, inst_hi=3)
+        try:
+            top = ref_loader.config_to_topology(t)
+            if top is None or not len(top.proc_groups):
+                continue
+            (pack.Packer().digest_big if len(top.proc_groups) > 4 else pack.Packer().digest)(top)
+        except Exception:  # noqa: BLE001
+            continue
+        if len(top.proc_groups) > 4 or len(texts) % 3 == 0:
+            texts.append(t)
+            tops.append(top)
+        if len(texts) == 36:
+            break
+    assert sum(len(t.proc_groups) > 4 for t in tops) >= 15
+    m = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)
+    got = m.FindNodesFromConfigs(nl, texts)
+    assert got == m.FindNodes(nl, tops)
+    placed_big = 0
+    for t, g in zip(tops, got):
+        ref = O.find_node(nl, t, util.CLOCK)
+        assert (g[0], g[1:] and g[1]["gpu"]) == (ref[0], ref[1:] and tuple(ref[1]["gpu"]))
+        placed_big += g[0] is not None and len(t.proc_groups) > 4
+    assert placed_big >= 1
+    assert m.FindNodesFromConfigs(nl, texts, sequential=True) == m.ScheduleBatch(nl, tops)

@@ -39,7 +39,7 @@ def _setting(rng, name, value):
     return f"{name}{eq}{value}{end}{note}\n"
 
 
-def make_config(seed, defect=None):
+def make_config(seed, defect=None, types_hi=4, inst_hi=3):
     """Returns the config text.  defect in {None, 'no_topology', 'no_cpu_arch', 'bad_arch', 'no_ext_smt', 'ext_missing',
     'no_map_type', 'no_module', 'two_numa_dp', 'nic_cores_len', 'no_hugepages', 'helper_missing', 'int_of_string',
     'speed_index', 'syntax', 'helper_smt_missing', 'no_mod_defs'}"""
@@ -53,12 +53,12 @@ def make_config(seed, defect=None):
     ext_names = [f"misc.c{i}" if rng.random() < 0.7 else f"misc.arr[{i}]" for i in range(n_ext)]
     misc_fields = "".join(_setting(rng, f"c{i}", _int(rng, -1)) for i in range(n_ext))
     misc_fields += _setting(rng, "arr", _seq(rng, [_int(rng, -1)] * max(n_ext, 1), "[]"))
-    n_types = int(rng.integers(1, 4))
+    n_types = int(rng.integers(1, types_hi))            # (module types x instances = processing groups: up to 6 by default)
     mod_defs, sections = [], []
     for t in range(n_types):
         mname = f"Mod{chr(65 + t)}"
         md = _setting(rng, "module", _string(rng, mname))
-        n_inst = int(rng.integers(1, 3))
+        n_inst = int(rng.integers(1, inst_hi))
         has_helpers = rng.random() < 0.6
         has_dp = rng.random() < 0.7
         has_nic = rng.random() < 0.3 or not has_dp
