@@ -367,9 +367,9 @@ class GroupEngine:
                 else:
                     s.global_base = lo
             self.n = n
-            self._has_gpu = np.array((table.p2["flags"] & pack.NF_HAS_GPU) != 0)
+            self._has_gpu = self._gpu_flags(table)
             return
-        self._has_gpu[first:first + table.n] = (table.p2["flags"] & pack.NF_HAS_GPU) != 0
+        self._has_gpu[first:first + table.n] = self._gpu_flags(table)
         lo_i = first
         while lo_i < first + table.n:                               # a run may straddle shards
             k = self._shard_of(lo_i)
@@ -377,6 +377,15 @@ class GroupEngine:
             hi_i = min(first + table.n, hi)
             self.shards[k].upload(table.slice(lo_i - first, hi_i - first), global_base=lo, first=lo_i - lo, capacity=hi - lo)
             lo_i = hi_i
+
+    @staticmethod
+    def _gpu_flags(table: pack.NodeTable) -> np.ndarray:
+        """len(Node.gpus) > 0 per node of `table` (Matcher.SelectNode's preference, nhd/Matcher.py:401-413): the planes' flag - and,
+        for a wide node, its record's GPU count (its entry in the planes is a placeholder without flags)."""
+        has = np.array((table.p2["flags"] & pack.NF_HAS_GPU) != 0)
+        for i, rec in (table.wide or {}).items():
+            has[i] = int(rec["n_gpus"]) > 0
+        return has
 
     def set_outputs(self, bitmap=True, mapping=True):
         for s in self.shards:

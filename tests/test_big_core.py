@@ -233,3 +233,46 @@ def test_more_than_eight_groups_stay_unanswered_not_wrong():
     assert m.FindNodes(nl, [refmodel.make_topology(spec)]) == [(None,)]
     with pytest.raises(pack.UnsupportedNode):
         HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine, strict=True).FindNodes(nl, [refmodel.make_topology(spec)])
+
+
+@pytest.mark.parametrize("ndev", [2, 3])
+def test_big_pods_on_a_sharded_mirror(ndev):
+    """HipMatcher(devices=[...]) (engine.GroupEngine over host-twin shards): pods with 5..7 groups mixed with ordinary ones - FindNodes,
+    the one-by-one form with a candidate dict, ScheduleBatch with its physical ids - equal the single-shard answers (score words
+    carry the global node index, the owner's mapping is kept, the commit lands on the owner's mirror)."""
+    descs = util.mixed_cluster_desc(48000 + ndev, 200, wide_share=0.1, occupancy=0.1)
+    for d in descs:
+        keep, lab = 0, {}
+        for k, v in d["labels"].items():
+            if "nfd-extras-nic" in k:
+                keep += 1
+                if keep > 4:
+                    continue
+            lab[k] = v
+        d["labels"] = lab
+        d["nic_pods_used"] = d["nic_pods_used"][:sum(1 for k in lab if "nfd-extras-nic" in k and "10000Mbs" not in k.replace("100000Mbs", ""))]
+    nl = util.build_cluster(descs)
+    rng = np.random.default_rng(ndev)
+    specs = []
+    for _ in range(30):
+        s = big_spec(rng, 5, 7) if rng.random() < 0.6 else util.random_pod_spec(rng)
+        s["misc_smt"] = True
+        if s["map_type"] == "NONE":
+            s["map_type"] = "NUMA"
+        specs.append(s)
+    tops = [refmodel.make_topology(s) for s in specs]
+    one = host_matcher()
+    many = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine, devices=list(range(ndev)))
+    want = one.FindNodes(nl, tops)
+    assert many.FindNodes(nl, tops) == want
+    assert sum(1 for t, w in zip(tops, want) if len(t.proc_groups) > 4 and w[0] is not None) >= 3
+    sub = {k: v for i, (k, v) in enumerate(nl.items()) if i % 3}
+    for top in [t for t in tops if len(t.proc_groups) > 4][:6]:
+        assert many.FindNode(sub, top) == one.FindNode(sub, top)
+    one.attach(nl)
+    a = one.ScheduleBatch(nl, tops, now=util.CLOCK)
+    ids_a = list(one.last_placements)
+    many.attach(nl)
+    b = many.ScheduleBatch(nl, tops, now=util.CLOCK)
+    assert a == b and ids_a == many.last_placements
+    assert len({r[0] for r in a if r[0] is not None}) >= 3
