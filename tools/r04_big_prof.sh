@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/r04_big_prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 SECONDS=0
-timeout 100 rocprofv3 --kernel-trace --stats -d $OUT/prof -o big -- python $ROOT/tools/time_big_find.py > $OUT/time_big_find.json 2> $OUT/time_big_find.err
+timeout 100 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o big -- python $ROOT/tools/time_big_find.py > $OUT/time_big_find.json 2> $OUT/time_big_find.err
 echo "rc=$? seconds=$SECONDS"
 cat $OUT/time_big_find.json
 find $OUT/prof -name "*kernel_stats*" | head -3
