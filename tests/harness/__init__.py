@@ -204,7 +204,7 @@ def _caps(packer):
     return caps
 
 
-def big_eval(packer, table, wide: np.ndarray, reqs: np.ndarray, now: float, cand=None, global_base=0):
+def big_eval(packer, table, wide: np.ndarray, reqs: np.ndarray, now: float, cand=None, global_base=0, budget=0):
     """k_big_eval on the host build: big requests (5..8 groups) against every node - the planes through wide_view, the wide
     records as they are.  Returns (fits [n][P] by node index, scores, budget_exhausted)."""
     L = lib()
@@ -217,7 +217,8 @@ def big_eval(packer, table, wide: np.ndarray, reqs: np.ndarray, now: float, cand
     caps = _caps(packer)
     planes = [np.ascontiguousarray(getattr(table, f)) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
     L.hh_big_eval(*[_p(x) for x in planes], ctypes.c_uint32(n), _p(wide) if len(wide) else None, ctypes.c_uint32(len(wide)), _p(reqs), ctypes.c_uint32(P),
-                  ctypes.c_double(now), _p(caps), _p(cand) if cand is not None else None, ctypes.c_uint64(global_base), _p(fits), _p(score), _p(flags))
+                  ctypes.c_double(now), _p(caps), _p(cand) if cand is not None else None, ctypes.c_uint64(global_base), _p(fits), _p(score), _p(flags),
+                  ctypes.c_uint32(budget))
     return fits, score, bool(flags[1])
 
 
@@ -397,7 +398,8 @@ class HarnessEngine:
         """nhdfit_big_find as nhdfit.hip does it: k_big_eval over planes + wide records, k_big_map for the winners this mirror holds."""
         reqs = np.ascontiguousarray(reqs, dtype=pack.BIG_REQ)
         recs = self._wide_records()
-        _, score, exhausted = big_eval(self.packer, self.table, recs, reqs, now, cand=cand, global_base=self.global_base)
+        _, score, exhausted = big_eval(self.packer, self.table, recs, reqs, now, cand=cand, global_base=self.global_base,
+                                       budget=getattr(self, "nic_budget", 0))
         if exhausted:
             from nhd_amd._lib import NhdFitError
             raise NhdFitError(-6, "a big request's NIC stage ran out of search budget on some node")

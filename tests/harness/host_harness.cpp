@@ -606,7 +606,7 @@ extern "C" int hh_wide_isect3(const int16_t* a, int na, const int16_t* b, int nb
 extern "C" void hh_big_eval(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
                             const nhdfit_plane4* p4, const nhdfit_detail* det, uint32_t n, const nhdfit_wide_node* wide, uint32_t n_wide,
                             const nhdfit_big_req* reqs, uint32_t P, double now, const double* caps, const uint64_t* cand,
-                            uint64_t global_base, uint8_t* fits, uint64_t* score, uint32_t* flags) {
+                            uint64_t global_base, uint8_t* fits, uint64_t* score, uint32_t* flags, uint32_t budget /* 0: NHDFIT_BIG_NIC_BUDGET */) {
     const double busy_from = busy_threshold(now);
     for (uint32_t v = 0; v < n + n_wide; ++v) {
         nhdfit_wide_node view;
@@ -615,7 +615,7 @@ extern "C" void hh_big_eval(const nhdfit_plane0* p0, const nhdfit_plane1* p1, co
         if (cand && !(cand[view.index >> 6] >> (view.index & 63) & 1ull)) continue;
         const bool busy = view.busy_time >= busy_from;
         for (uint32_t i = 0; i < P; ++i) {
-            NicSearch ns{NHDFIT_BIG_NIC_BUDGET, false};
+            NicSearch ns{budget ? budget : NHDFIT_BIG_NIC_BUDGET, false};
             const bool ok = wide_fits(view, reqs[i], busy, caps, &ns);
             if (ns.exhausted) flags[1] = 1;
             if (!ok) continue;

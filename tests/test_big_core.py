@@ -276,3 +276,25 @@ def test_big_pods_on_a_sharded_mirror(ndev):
     b = many.ScheduleBatch(nl, tops, now=util.CLOCK)
     assert a == b and ids_a == many.last_placements
     assert len({r[0] for r in a if r[0] is not None}) >= 3
+
+
+def test_nic_search_budget_fails_the_call_never_the_answer(caplog):
+    """A (pod, node) pair whose NIC search runs out of steps (NHDFIT_BIG_NIC_BUDGET on the device; a tiny budget injected into the
+    host twin here) makes the call fail: FindNode answers (None,) and says why, strict raises - no verdict is guessed."""
+    from nhd_amd._lib import NhdFitError
+    rng = np.random.default_rng(4)
+    nl = util.random_cluster(49500, 16, occupancy=0.0)
+    for _ in range(50):                                                  # a pod some node takes: its NIC stage is reached
+        top = refmodel.make_topology(big_spec(rng, 6, 6))
+        if O.find_node(nl, top, util.CLOCK)[0] is not None:
+            break
+    assert O.find_node(nl, top, util.CLOCK)[0] is not None
+
+    class Tight(harness.HarnessEngine):
+        nic_budget = 3
+    with caplog.at_level("ERROR"):
+        assert HipMatcher(clock=lambda: util.CLOCK, engine_factory=Tight).FindNode(nl, top) == (None,)
+    assert "search budget" in caplog.text
+    with pytest.raises(NhdFitError):
+        HipMatcher(clock=lambda: util.CLOCK, engine_factory=Tight, strict=True).FindNode(nl, top)
+    assert host_matcher().FindNode(nl, top) == norm(O.find_node(nl, top, util.CLOCK))
