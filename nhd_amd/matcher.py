@@ -650,8 +650,9 @@ class HipMatcher:
         nhdfit_big_req answered on the device by the general path (nhdfit_big_find: every node by explicit enumeration, the same
         score word, the general CPython set model for its mapping; nhdfit_big_commit for its commit step); the other pods of the
         call take the table-driven pass as always.  Mode A: two device calls, results interleaved.  Mode B: the scheduler's loop
-        as it stands (nhd/NHDScheduler.py:425-437) - pod after pod, each decided and committed on the device before the next is
-        matched."""
+        (nhd/NHDScheduler.py:425-437) cut at the big pods - every run of ordinary pods between two of them is ONE device batch
+        (nhdfit_schedule_batch, commits left in the mirror), every big pod is decided and committed on the device before the run
+        behind it is matched."""
         n_pods = len(big)
         small_idx = [p for p in range(n_pods) if not big[p]]
         big_idx = [p for p in range(n_pods) if big[p]]
@@ -693,48 +694,61 @@ class HipMatcher:
         touched = []
         pos_small = {p: k for k, p in enumerate(small_idx)}
         pos_big = {p: k for k, p in enumerate(big_idx)}
-        for p in range(n_pods):
-            G = n_groups[p]
-            if big[p]:
-                req = big_reqs[pos_big[p]]
-                score, maps = self.engine.big_find(big_reqs[pos_big[p]:pos_big[p] + 1], now, cand=cand)
-                if not score[0]:
-                    continue
-                i = winner_index(int(score[0])) - base
-                answer(p, i, maps.tolist()[0])
-                nd = objects.get(names[i])
-                ids = self._commit_big(i, nd, req, maps[0], now)
-                on_wide = self._table is not None and bool(self._table.wide) and i in self._table.wide
-            else:
-                k = pos_small[p]
-                node, maps, places, status = self.engine.schedule_batch(small_reqs[k:k + 1], now, self.packer, cand=cand, apply=True)
-                if node[0] < 0:
-                    continue
-                if status[0] == pack.COMMIT_WOULD_RAISE:
-                    self.logger.warning("mode B: the reference's commit step would have failed for pod %d", p)
-                i = int(node[0]) - base
-                answer(p, i, maps.tolist()[0])
-                nd = objects.get(names[i])
-                on_wide = int(places[0]["status"]) == pack.COMMIT_WIDE
-                ids = None
-                if nd is not None:
-                    gp = [int(small_reqs[k]["gpus"][g]) for g in range(G)]
-                    cpp, n_log = int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets)
-                    if on_wide:
-                        wp = getattr(self.engine, "last_wide_places", {}).get(0)
-                        ids = pack.expand_wide_placement(wp, G, cpp, n_log, gp) if wp is not None else None
-                    else:
-                        ids = pack.expand_placement(places[0], G, cpp, n_log, gp)
+
+        def record(p, i, ids, on_wide):
             touched.append(names[i])
             nd = objects.get(names[i])
             if nd is None:
-                continue
+                return
             self.last_placements[p] = ids
             if self._attached is not None and apply:
                 if on_wide:
                     self._mark(nd, "wide-batch")           # a wide record is re-packed from the object before the next call (no delta form)
                 else:
                     self._batch_ids.setdefault(nd.name, []).append(ids)     # the reference mutators that follow find their work mirrored already
+
+        p = 0
+        while p < n_pods:
+            if big[p]:
+                req = big_reqs[pos_big[p]]
+                score, maps = self.engine.big_find(big_reqs[pos_big[p]:pos_big[p] + 1], now, cand=cand)
+                if score[0]:
+                    i = winner_index(int(score[0])) - base
+                    answer(p, i, maps.tolist()[0])
+                    ids = self._commit_big(i, objects.get(names[i]), req, maps[0], now)
+                    record(p, i, ids, self._table is not None and bool(self._table.wide) and i in self._table.wide)
+                p += 1
+                continue
+            # a run of ordinary pods between two big ones: one device batch (the decision engine), commits left in the mirror
+            q = p
+            while q < n_pods and not big[q]:
+                q += 1
+            ka, kb = pos_small[p], pos_small[p] + (q - p)
+            node, maps, places, status = self.engine.schedule_batch(small_reqs[ka:kb], now, self.packer, cand=cand, apply=True)
+            if (status == pack.COMMIT_WOULD_RAISE).any():
+                self.logger.warning("mode B: the reference's commit step would have failed for pod %d",
+                                    p + int(np.flatnonzero(status == pack.COMMIT_WOULD_RAISE)[0]))
+            rows = maps.tolist()
+            wide_places = getattr(self.engine, "last_wide_places", {})
+            for j in range(q - p):
+                if node[j] < 0:
+                    continue
+                i = int(node[j]) - base
+                answer(p + j, i, rows[j])
+                nd = objects.get(names[i])
+                on_wide = int(places[j]["status"]) == pack.COMMIT_WIDE
+                ids = None
+                if nd is not None:
+                    G = n_groups[p + j]
+                    gp = [int(small_reqs[ka + j]["gpus"][g]) for g in range(G)]
+                    cpp, n_log = int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets)
+                    if on_wide:
+                        wp = wide_places.get(j)
+                        ids = pack.expand_wide_placement(wp, G, cpp, n_log, gp) if wp is not None else None
+                    else:
+                        ids = pack.expand_placement(places[j], G, cpp, n_log, gp)
+                record(p + j, i, ids, on_wide)
+            p = q
         if not apply:
             # the mirror goes back to what the node objects say (nobody applied anything to them): attached - those nodes are
             # re-packed before the next call; stateless - every call packs `nl` again anyway
