@@ -298,3 +298,32 @@ def test_nic_search_budget_fails_the_call_never_the_answer(caplog):
     with pytest.raises(NhdFitError):
         HipMatcher(clock=lambda: util.CLOCK, engine_factory=Tight, strict=True).FindNode(nl, top)
     assert host_matcher().FindNode(nl, top) == norm(O.find_node(nl, top, util.CLOCK))
+
+
+def test_big_pods_with_the_initial_node_filter_and_invalid_map_types():
+    """pod_groups given: the general path applies InitialNodeFilter itself (active && node groups intersect the pod's,
+    nhd/NHDScheduler.py:235-247) - against the oracle's filter followed by its FindNode, and against the scheduler's form (filtered
+    dict -> FindNode).  A big pod whose map type is neither NUMA nor PCI matches nothing (nhd/Matcher.py:45-47)."""
+    descs = util.random_cluster_desc(49700, 60, occupancy=0.05)
+    for d in descs:
+        d["nic_pods_used"] = [0] * len(d["nic_pods_used"])
+    nl = util.build_cluster(descs)
+    rng = np.random.default_rng(12)
+    tops, groups = [], []
+    for _ in range(30):
+        s = big_spec(rng, 5, 6)
+        for g in s["groups"]:
+            g["rx"] = g["tx"] = 0.0
+        tops.append(refmodel.make_topology(s))
+        groups.append(list(rng.choice(["default", "alpha", "beta", "nobody"], size=int(rng.integers(1, 3)), replace=False)))
+    m = host_matcher()
+    got = m.FindNodes(nl, tops, pod_groups=groups)
+    want = [norm(O.find_node(O.initial_node_filter(nl, g), t, util.CLOCK)) for t, g in zip(tops, groups)]
+    assert [norm(r) for r in got] == want
+    assert sum(w[0] is not None for w in want) >= 5 and len({w[0] for w in want}) >= 3
+    m.attach(nl)
+    for t, g, w in list(zip(tops, groups, want))[:12]:
+        assert norm(m.FindNode(O.initial_node_filter(nl, g), t)) == w
+    none = big_spec(rng, 6, 6)
+    none["map_type"] = "NONE"
+    assert m.FindNode(nl, refmodel.make_topology(none)) == (None,)
