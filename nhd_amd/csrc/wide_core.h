@@ -158,7 +158,7 @@ template <class R> NHD_HD bool wide_cpu_ok(const R& r, const WideFree& f, uint32
 //     solution is never in a pruned branch.  Eight VFs of one PF then cost set partitions, not 8^G.
 //   * a budget of search steps per (pod, node) pair (NicSearch): when it runs out the pair is reported, the call fails
 //     (NHDFIT_E_LIMIT) - the reference would be making K^G deepcopies there.
-struct NicSearch { uint32_t left; bool exhausted; };
+struct NicSearch { uint32_t left; bool exhausted; };        // a big request's budget of search steps per (pod, node) pair (see wide_nic_choice)
 template <class R>
 NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const R& r, const double* caps, uint32_t gcode, int8_t* nic_idx, NicSearch* ns = nullptr) {
     constexpr int kG = req_traits<R>::kG;
@@ -249,6 +249,59 @@ NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const R& r, const double*
     }
 }
 
+// ---- big requests: the NIC stage asked per NUMA node ----------------------------------------------------------------------------
+// Whether an assignment passes the NIC stage is, NUMA node by NUMA node, a question about the SET of groups it puts there: the groups
+// of different NUMA nodes choose among disjoint NICs, and - unless one PCIe switch carries NICs of two NUMA nodes, which PCI mode
+// then has to count jointly - behind disjoint switches.  U^G assignments share at most U * 2^G such sets, and a search over one NUMA
+// node's groups is far shorter than one over all of them, so a big request's stage remembers each set's answer (1 KB per pair).
+// The answer itself is the search's own: the same depth-first search (wide_nic_choice) over the request cut down to the set's groups,
+// in ascending group index - per NIC the same subtractions in the same order, per switch the same counts.
+struct NicMemo {
+    uint8_t known[kWideU][1 << NHDFIT_BIG_MAX_GROUPS];         // 0 = not asked yet, 1 = no, 2 = yes
+    bool separable;
+};
+template <class R> NHD_HD void nic_memo_init(NicMemo& m, const nhdfit_wide_node& n, const R& r) {
+    for (int u = 0; u < kWideU; ++u)
+        for (int s = 0; s < (1 << NHDFIT_BIG_MAX_GROUPS); ++s) m.known[u][s] = 0;
+    m.separable = true;
+    if (r.map_type != NHDFIT_MAP_PCI) return;                  // NUMA mode applies no switch test (Matcher.py:294-296)
+    for (uint32_t u = 0; u < n.numa_nodes && u < (uint32_t)kWideU; ++u)
+        for (uint32_t k = 0; k < n.nic_cnt[u]; ++k)
+            for (uint32_t u2 = u + 1; u2 < n.numa_nodes && u2 < (uint32_t)kWideU; ++u2)
+                for (uint32_t k2 = 0; k2 < n.nic_cnt[u2]; ++k2)
+                    if (n.nic_sw[u][k] == n.nic_sw[u2][k2]) m.separable = false;
+}
+// can the NICs of NUMA node u host the groups of `set` (bit g = group g)?
+template <class R>
+NHD_HD bool nic_set_ok(NicMemo& m, const nhdfit_wide_node& n, const R& r, const double* caps, uint32_t u, uint32_t set, NicSearch* ns) {
+    if (!set) return true;
+    uint8_t& known = m.known[u][set];
+    if (known) return known == 2;
+    R sub = r;
+    uint32_t k = 0, code = 0;
+    for (uint32_t g = 0; g < r.n_groups; ++g)
+        if (set >> g & 1u) { sub.rx[k] = r.rx[g]; sub.tx[k] = r.tx[g]; ++k; code = code * n.numa_nodes + u; }   // every group of the cut-down request on NUMA node u
+    sub.n_groups = k;
+    int8_t nic[req_traits<R>::kG];
+    const bool ok = wide_nic_choice(n, sub, caps, code, nic, ns);
+    if (ns && ns->exhausted) return false;                     // (no answer: nothing is remembered)
+    known = ok ? 2 : 1;
+    return ok;
+}
+// the NIC stage of assignment `gcode` through the memo (separable nodes) or by the joint search
+template <class R>
+NHD_HD bool nic_stage_ok(NicMemo& m, const nhdfit_wide_node& n, const R& r, const double* caps, uint32_t gcode, NicSearch* ns) {
+    if (!m.separable) {
+        int8_t nic[req_traits<R>::kG];
+        return wide_nic_choice(n, r, caps, gcode, nic, ns);
+    }
+    uint32_t sets[kWideU] = {0, 0, 0, 0};
+    for (uint32_t g = 0; g < r.n_groups; ++g) sets[wide_digit(gcode, r.n_groups, n.numa_nodes, g)] |= 1u << g;
+    for (uint32_t u = 0; u < n.numa_nodes; ++u)
+        if (!nic_set_ok(m, n, r, caps, u, sets[u], ns)) return false;
+    return true;
+}
+
 // scalar predicates (Matcher.py:65-84, 107-111; InitialNodeFilter NHDScheduler.py:235-247 when the request asks for it)
 template <class R> NHD_HD bool wide_scalar_ok(const nhdfit_wide_node& n, const R& r, bool busy) {
     if (!req_valid(r) || !wide_shape_ok(n)) return false;
@@ -271,6 +324,53 @@ NHD_HD bool wide_fits(const nhdfit_wide_node& n, const R& r, bool busy, const do
     const WideFree f = wide_free(n);
     const uint32_t G = r.n_groups, nG = wide_ipow(f.U, G);
     int8_t nic[req_traits<R>::kG];
+    if constexpr (req_traits<R>::kBig) {
+        // A big request walks the assignments as an odometer - the last group's digit turns fastest: ascending codes, i.e.
+        // itertools.product order - carrying the per-NUMA-node GPU and core totals along instead of re-deriving every tuple's digits
+        // (the stages above, wide_gpu_ok / wide_cpu_ok, asked per code, cost O(G^2) each: at 2^8 .. 4^8 assignments per pair that
+        // was the whole pass).  Same integers, same comparisons.  Before any of it: a node whose free GPUs or free cores do not
+        // cover the pod's totals passes no assignment at all (most nodes, for a pod of this size).
+        constexpr int kG = req_traits<R>::kG;
+        const uint32_t U = f.U;
+        const uint32_t misc = f.smt ? r.misc_smt : r.misc_nosmt;
+        uint32_t dg[kG], dc[kG], digit[kG];
+        uint32_t need_g = 0, need_c = misc, have_g = 0, have_c = 0;
+        for (uint32_t g = 0; g < G; ++g) {
+            dg[g] = r.gpus[g];
+            dc[g] = f.smt ? r.cpu_smt[g] : r.cpu_nosmt[g];
+            digit[g] = 0;
+            need_g += dg[g]; need_c += dc[g];
+        }
+        for (uint32_t u = 0; u < U; ++u) { have_g += f.g[u]; have_c += f.c[u]; }
+        if (need_g > have_g || need_c > have_c) return false;
+        uint32_t tg[kWideU] = {need_g, 0, 0, 0}, tc[kWideU] = {need_c - misc, 0, 0, 0};       // code 0: every group on NUMA node 0
+        NicMemo memo;
+        nic_memo_init(memo, n, r);
+        for (uint32_t code = 0; code < nG; ++code) {
+            bool ok = true;
+            for (uint32_t u = 0; u < U; ++u) ok = ok && tg[u] <= f.g[u];                         // GPU stage, Matcher.py:120-131
+            if (ok) {                                                                              // CPU stage: the misc cores on some NUMA node m, Matcher.py:206-216
+                bool cpu = false;
+                for (uint32_t m = 0; m < U && !cpu; ++m) {
+                    bool fit = true;
+                    for (uint32_t u = 0; u < U; ++u) fit = fit && tc[u] + (u == m ? misc : 0u) <= f.c[u];
+                    cpu = fit;
+                }
+                ok = cpu;
+            }
+            if (ok) {
+                if (nic_stage_ok(memo, n, r, caps, code, ns)) return true;
+                if (ns && ns->exhausted) return false;
+            }
+            for (int g = (int)G - 1; g >= 0; --g) {                                               // next tuple
+                const uint32_t u = digit[g];
+                tg[u] -= dg[g]; tc[u] -= dc[g];
+                if (u + 1 < U) { digit[g] = u + 1; tg[u + 1] += dg[g]; tc[u + 1] += dc[g]; break; }
+                digit[g] = 0; tg[0] += dg[g]; tc[0] += dc[g];
+            }
+        }
+        return false;
+    }
     for (uint32_t code = 0; code < nG; ++code) {
         if (!wide_gpu_ok(r, f, code)) continue;
         bool cpu = false;
@@ -431,10 +531,20 @@ NHD_HD int wide_map(const nhdfit_wide_node& n, const R& r, const double* caps, t
     int8_t nic[kG];
     NicSearch budget{req_traits<R>::kBig ? 8u * NHDFIT_BIG_NIC_BUDGET : 0u, false};    // (every assignment is searched here, not only up to the first hit)
     NicSearch* ns = req_traits<R>::kBig ? &budget : nullptr;
-    for (uint32_t code = 0; code < nG; ++code) {
-        if (wide_gpu_ok(r, f, code)) ws_add(sg, (K)code, tmp);
-        if (wide_nic_choice(n, r, caps, code, nic, ns)) ws_add(c, (K)code, tmp);
-        if (budget.exhausted) return -2;
+    if constexpr (req_traits<R>::kBig) {
+        NicMemo memo;
+        nic_memo_init(memo, n, r);
+        for (uint32_t code = 0; code < nG; ++code) {
+            if (wide_gpu_ok(r, f, code)) ws_add(sg, (K)code, tmp);
+            if (nic_stage_ok(memo, n, r, caps, code, ns)) ws_add(c, (K)code, tmp);
+            if (budget.exhausted) return -2;
+        }
+    } else {
+        for (uint32_t code = 0; code < nG; ++code) {
+            if (wide_gpu_ok(r, f, code)) ws_add(sg, (K)code, tmp);
+            if (wide_nic_choice(n, r, caps, code, nic, ns)) ws_add(c, (K)code, tmp);
+            if (budget.exhausted) return -2;
+        }
     }
     for (uint32_t code = 0; code < nC; ++code)
         if (wide_cpu_ok(r, f, code)) ws_add(sc, (K)code, tmp);

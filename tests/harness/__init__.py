@@ -219,6 +219,7 @@ def big_eval(packer, table, wide: np.ndarray, reqs: np.ndarray, now: float, cand
     L.hh_big_eval(*[_p(x) for x in planes], ctypes.c_uint32(n), _p(wide) if len(wide) else None, ctypes.c_uint32(len(wide)), _p(reqs), ctypes.c_uint32(P),
                   ctypes.c_double(now), _p(caps), _p(cand) if cand is not None else None, ctypes.c_uint64(global_base), _p(fits), _p(score), _p(flags),
                   ctypes.c_uint32(budget))
+    big_eval.last_steps = int(flags[2])                               # NIC search steps of the call (diagnostics)
     return fits, score, bool(flags[1])
 
 

@@ -618,6 +618,7 @@ extern "C" void hh_big_eval(const nhdfit_plane0* p0, const nhdfit_plane1* p1, co
             NicSearch ns{budget ? budget : NHDFIT_BIG_NIC_BUDGET, false};
             const bool ok = wide_fits(view, reqs[i], busy, caps, &ns);
             if (ns.exhausted) flags[1] = 1;
+            flags[2] += (budget ? budget : NHDFIT_BIG_NIC_BUDGET) - ns.left;      // search steps spent (diagnostics)
             if (!ok) continue;
             fits[(size_t)view.index * P + i] = 1;
             uint32_t want = 0;
