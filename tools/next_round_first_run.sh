@@ -20,10 +20,9 @@
 #   * single calls: nhdfit_find one pod 26 / 28 / 35 / 33 us (4 096 / 16 384 / 65 536 nodes / c5 shard); HIP_FORCE_DEV_KERNARG=1 changes
 #     nothing; nhdfit_find with 4 096 pods 0.20 ms (host copies of 512 KB of requests on both sides of three launches).
 #   * pods beyond the table pass (5..8 processing groups, hugepage requests > 1 022 GiB): nhdfit_big_req through the general path
-#     (big_kernel.h), 0.2-2.5 ms per pod at 65 536 nodes, up to 0.3 s on the config-5 shard where thousands of nodes search eight
-#     interchangeable VFs for six or seven groups (k_big_eval's longest lane per wavefront decides; candidates if it ever matters:
-#     per-node free-GPU-per-switch counts computed once instead of per switch test, the scalar tests and the GPU / CPU stages for all
-#     assignments before any NIC search, lanes = (node, assignment range) for the nodes that reach the NIC stage).
+#     (big_kernel.h), 0.16-1.9 ms per pod at 65 536 nodes, up to 25 ms on the config-5 shard (odometer walk, totals pre-filter,
+#     NIC stage remembered per NUMA node and group set: k_big_eval mean 1.0 ms; what is left is k_big_map, one thread per winner,
+#     2.2 ms - its NIC searches over every assignment and the set model could spread over a wavefront if it ever matters).
 #     tools/time_big_find.py + tools/r04_big_prof.sh re-measure it (30 s of box time).
 #   * tests/test_kernel_resources.py guards the step kernels' scratch / VGPR budget on every CPU run - look at it first when a step
 #     time jumps.
