@@ -213,3 +213,79 @@ def test_pod_lifecycle_through_the_unmodified_scheduler(ref, sched_mod, cfg):
     want = m.packer.pack_nodes(b.nodes)
     for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
         assert np.array_equal(getattr(got, f), getattr(want, f)), f
+
+
+def test_attempt_scheduling_with_pods_of_more_than_four_groups(ref, sched_mod):
+    """The same proof with pods the table pass cannot express (5..6 processing groups, nhdfit_big_req) among ordinary ones: the
+    UNMODIFIED AttemptScheduling binds every pod to the reference Matcher's node and leaves the nodes in the same state; on the
+    HipMatcher side the reference's own commit of such a pod is mirrored by nhdfit_big_commit (the host twin's here) - no node of
+    the planes is re-packed for it - and a released big pod's resources go back as a delta."""
+    import contextlib, io
+    from oracle import ref_loader
+    from tests import util
+    from tests.test_big_core import big_spec
+    S = sched_mod
+    clock = ref_loader.VirtualClock(1.0e6).install()
+    descs = util.random_cluster_desc(77100, 30, occupancy=0.05)
+    for d in descs:
+        keep, lab = 0, {}
+        for k, v in d["labels"].items():
+            if "nfd-extras-nic" in k:
+                keep += 1
+                if keep > 4:
+                    continue
+            lab[k] = v
+        d["labels"] = lab
+        d["nic_pods_used"] = [0] * sum(1 for k in lab if "nfd-extras-nic" in k and "10000Mbs" not in k.replace("100000Mbs", ""))
+        d["labels"].pop("NHD_GROUP", None)
+    rng = np.random.default_rng(5)
+    pods = []
+    for _ in range(40):
+        s = big_spec(rng, 5, 6) if rng.random() < 0.5 else util.random_pod_spec(rng)
+        s["misc_smt"] = True
+        if s["map_type"] == "NONE":
+            s["map_type"] = "NUMA"
+        pods.append(s)
+    names = [f"pod{i}" for i in range(len(pods))]
+    pg = {nm: ["default"] for nm in names}
+
+    def make():
+        fake = LifecycleK8S(pg)
+        S.K8SMgr.GetInstance = staticmethod(lambda: fake)
+        import queue
+        sched = S.NHDScheduler(queue.Queue())
+        sched.nodes = {d["name"]: refmodel.build_node(d, ref) for d in descs}
+        tops = {nm: refmodel.make_topology(sp, ref) for nm, sp in zip(names, pods)}
+        sched.GetCfgParser = lambda t, s, _tops=tops: FakeParser(_tops[s] if s in _tops else _tops[s[1]])
+        return sched, fake, tops
+
+    a, ka, _ = make()
+    b, kb, tops_b = make()
+    m = HipMatcher(clock=lambda: clock.t, engine_factory=harness.HarnessEngine)
+    b.matcher = m
+    m.attach(b.nodes)
+    uploads = []
+    orig_upload = m.engine.upload
+    m.engine.upload = lambda *x, **k: (uploads.append(x[0].n), orig_upload(*x, **k))[1]
+    placed_big = 0
+    for name, sp in zip(names, pods):
+        clock.t += 1.0
+        with contextlib.redirect_stdout(io.StringIO()):
+            ra = a.AttemptScheduling(name, "ns")
+        rb = b.AttemptScheduling(name, "ns")
+        assert ra == rb and ka.binds.get(name) == kb.binds.get(name), name
+        for k in a.nodes:
+            assert node_state(a.nodes[k]) == node_state(b.nodes[k]), (name, k)
+        placed_big += bool(ra) and len(sp["groups"]) > 4
+    assert placed_big >= 3
+    for name in [nm for nm, sp in zip(names, pods) if nm in ka.binds and len(sp["groups"]) > 4][:2]:    # a big pod completes
+        clock.t += 1.0
+        with contextlib.redirect_stdout(io.StringIO()):
+            a.ReleasePodResources(name, "ns")
+        b.ReleasePodResources(name, "ns")
+        ka.gone.add(name); kb.gone.add(name)
+    m.FindNode(b.nodes, tops_b[names[0]])                                     # flush
+    assert uploads == [] and m.delta_stats["repacked"] == 0                   # commits and releases travelled as records, nothing was re-packed
+    got, want = m.engine.download(), m.packer.pack_nodes(b.nodes)
+    for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
+        assert np.array_equal(getattr(got, f), getattr(want, f)), f
