@@ -61,8 +61,8 @@ struct BigMapArgs {
     uint32_t* flags;
 };
 __global__ __launch_bounds__(64) void k_big_map(BigMapArgs a) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= a.workers) return;
+    const uint32_t tid = blockIdx.x;                // one worker per wavefront, its first lane: the set model is one long serial walk, and
+    if (threadIdx.x != 0 || tid >= a.workers) return;   // lanes walking different pods' sets would only take turns inside a wavefront
     int32_t* scratch = a.scratch + (size_t)tid * a.stride;
     for (uint32_t i = tid; i < a.P; i += a.workers) {
         nhdfit_big_mapping m;

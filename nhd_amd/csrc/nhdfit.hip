@@ -1244,7 +1244,7 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
         wm.wide = c->wide.p; wm.n_wide = c->n_wide; wm.reqs = c->reqs.p; wm.P = P; wm.caps = c->caps.p;
         wm.score = p.score[b].p; wm.global_base = c->global_base; wm.n = c->n; wm.out = p.maps[b].p;
         wm.scratch = c->wide_scratch.p; wm.flags = c->wide_flags.p;
-        hipLaunchKernelGGL(k_wide_map, dim3(kWideMapThreads / 64), dim3(64), 0, p.stream, wm);
+        hipLaunchKernelGGL(k_wide_map, dim3(kWideMapThreads), dim3(64), 0, p.stream, wm);
         HIPCHK(c, hipGetLastError());
         uint32_t fl[4] = {0, 0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(fl, c->wide_flags.p, sizeof fl, hipMemcpyDeviceToHost, p.stream));
@@ -1605,7 +1605,7 @@ int nhdfit_big_find(nhdfit_ctx* c, const nhdfit_big_req* reqs, uint32_t P, doubl
         ma.wide = c->wide.p; ma.n_wide = c->n_wide; ma.reqs = c->big_reqs.p; ma.P = P; ma.caps = c->caps.p;
         ma.score = c->big_score.p; ma.global_base = c->global_base; ma.out = c->big_maps.p; ma.scratch = c->big_scratch.p; ma.flags = c->big_flags.p;
         ma.stride = stride; ma.slots_g = (int32_t)wide_table_slots(wide_ipow(umax, gmax)); ma.slots_c = (int32_t)wide_table_slots(wide_ipow(umax, gmax + 1)); ma.workers = workers;
-        hipLaunchKernelGGL(k_big_map, dim3((workers + 63) / 64), dim3(64), 0, c->stream, ma);
+        hipLaunchKernelGGL(k_big_map, dim3(workers), dim3(64), 0, c->stream, ma);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(map_out, c->big_maps.p, (size_t)P * sizeof *map_out, hipMemcpyDeviceToHost, c->stream));
     } else if (map_out) {

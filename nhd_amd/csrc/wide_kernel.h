@@ -51,7 +51,10 @@ __device__ inline int wide_slot_of(const nhdfit_wide_node* wide, uint32_t n_wide
     return -1;
 }
 __global__ __launch_bounds__(64) void k_wide_map(WideMapArgs a) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    // one worker per wavefront (its first lane): the set model is a long serial walk - lanes of one wavefront walking different
+    // pods' sets would only take turns
+    if (threadIdx.x != 0) return;
+    const uint32_t tid = blockIdx.x, nthreads = gridDim.x;
     int16_t* scratch = a.scratch + (size_t)tid * kWideScratchWords;
     for (uint32_t i = tid; i < a.P; i += nthreads) {
         const unsigned long long s = a.score[i];
