@@ -63,6 +63,8 @@ def test_bench_json_contract(tmp_path):
     par = out["mode_b"]["parity"]
     assert par["identical"] and par["pods_checked"] == 96 and out["mode_b"]["commits_that_would_raise"] == 0
     assert out["repeats"]["n"] == 5 and out["cpu_baseline"]["python_restatement"]["value"] > 0
+    big = out["big_pod_find"]                                 # pods beyond the table pass: the leg runs, its in-run parity holds
+    assert "error" not in big and big["parity"]["identical"] and big["parity"]["pods"] > 0 and big["calls"] > 0
 
 
 _RANK_SCRIPT = r"""

@@ -150,7 +150,8 @@ def test_big_pods_vs_python_oracle(seed):
         d["nic_pods_used"] = d["nic_pods_used"][:sum(1 for k in lab if "nfd-extras-nic" in k and "10000Mbs" not in k.replace("100000Mbs", ""))]
     nl = util.build_cluster(descs)
     rng = np.random.default_rng(seed)
-    tops = [refmodel.make_topology(big_spec(rng, 5, 7) if rng.random() < 0.7 else util.random_pod_spec(rng, 4)) for _ in range(24)]
+    hi = 6 if seed % 2 else 7          # (the Python oracle enumerates 4^G x 4^(G+1) on a four-socket node: seven groups there are tests/golden/big/big_quad's)
+    tops = [refmodel.make_topology(big_spec(rng, 5, hi) if rng.random() < 0.7 else util.random_pod_spec(rng, 4)) for _ in range(24)]
     m = host_matcher()
     got = m.FindNodes(nl, tops)
     want = [norm(O.find_node(nl, t, util.CLOCK)) for t in tops]
