@@ -567,15 +567,23 @@ class HipMatcher:
         if reqs is None and any(pack.needs_general_path(top) for top in tops):
             # pods the table pass cannot express but the general path answers (5..8 processing groups, huge hugepage requests)
             is_big = [pack.needs_general_path(top) for top in tops]
+            big_recs = []
+            for p in range(n_pods):
+                if not is_big[p]:
+                    continue
+                try:
+                    big_recs.append(self.packer.digest_big(tops[p], None if pod_groups is None else pod_groups[p]))
+                except pack.UnsupportedNode:               # beyond the big record too (a group of more than 255 cores ...): strict raises,
+                    if self.strict:                        # otherwise the pod goes the ordinary pods' way below and is answered (None,), logged
+                        raise
+                    is_big[p] = False
             small_idx = [p for p in range(n_pods) if not is_big[p]]
             beyond = []
             small = self.packer.digest_many([tops[p] for p in small_idx], None if pod_groups is None else [pod_groups[p] for p in small_idx],
                                             unsupported=beyond)
             for k, why in beyond:
                 self.logger.error("pod %d of the call cannot be expressed as a request record and is answered (None,): %s", small_idx[k], why)
-            bigs = np.zeros(n_pods - len(small_idx), pack.BIG_REQ)
-            for k, p in enumerate(p for p in range(n_pods) if is_big[p]):
-                bigs[k] = self.packer.digest_big(tops[p], None if pod_groups is None else pod_groups[p])
+            bigs = np.array(big_recs, dtype=pack.BIG_REQ) if big_recs else np.zeros(0, pack.BIG_REQ)
             return self._run_with_big(nl, is_big, small, bigs, now, cand, sequential, apply)
         if reqs is not None and big_reqs:                  # digested from config texts (FindNodesFromConfigs)
             is_big = [p in big_reqs for p in range(n_pods)]

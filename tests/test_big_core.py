@@ -328,3 +328,23 @@ def test_big_pods_with_the_initial_node_filter_and_invalid_map_types():
     none = big_spec(rng, 6, 6)
     none["map_type"] = "NONE"
     assert m.FindNode(nl, refmodel.make_topology(none)) == (None,)
+
+
+def test_a_big_pod_beyond_the_big_record_is_answered_none_not_raised(caplog):
+    """Six groups of which one asks for 300 cores: no record holds it (255 cores per group) - (None,) with the reason in the log,
+    the other pods of the call answered as always; strict raises."""
+    rng = np.random.default_rng(21)
+    nl = util.random_cluster(49800, 16, occupancy=0.0)
+    fat = big_spec(rng, 6, 6)
+    fat["groups"][2]["proc"] = 300
+    ok = big_spec(rng, 5, 5)
+    plain = util.random_pod_spec(rng)
+    tops = [refmodel.make_topology(s) for s in (ok, fat, plain)]
+    m = host_matcher()
+    with caplog.at_level("ERROR"):
+        got = m.FindNodes(nl, tops)
+    assert got[1] == (None,) and "cannot be expressed" in caplog.text
+    assert norm(got[0]) == norm(O.find_node(nl, tops[0], util.CLOCK)) and norm(got[2]) == norm(O.find_node(nl, tops[2], util.CLOCK))
+    assert m.ScheduleBatch(nl, tops, now=util.CLOCK)[1] == (None,)
+    with pytest.raises(pack.UnsupportedNode):
+        HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine, strict=True).FindNodes(nl, tops)
