@@ -9,6 +9,9 @@
 #     HBM 0.37, LDS 0.37-0.43 (47 % of it bank conflicts), VALU 0.37-0.43 -> latency.  The host's enqueue costs ~11 us per step:
 #     configs 2 and 3 sit on it (11.5 / 14.7 us), config 4 is 4 us above it - a hipGraph over a cycle of steps (busy_from read from
 #     a device cell instead of the argument block) is the next lever once the GPU side drops further.
+#     Untried against the LDS bank conflicts: order each fit block's nodes by (class pair, free-core pair) in k_xrecords (the lane <->
+#     node assignment inside a block is free: verdict words are stored by node index) so that a wavefront's row fetches hit a few
+#     addresses (broadcasts) instead of sixteen bank groups at random.
 #     Candidates inside the fit role: the three-group tiles still sweep six rows (D = 31: C does not fit; XX with dense per-NUMA class
 #     ranks would be 6.4 KB), two tiles per block (record fetch + address arithmetic shared).
 #   * digest: signatures by pool type, R rows only for signatures in use, CPU rows per tile width: config 5 shard 21.7 -> 10.9 us
