@@ -31,6 +31,12 @@ sys.path.insert(0, {root!r})
 from tests.test_bench_dryrun import DryEngine
 import nhd_amd.engine as eng_mod
 eng_mod.Engine = DryEngine
+# the other BASELINE shapes of the `other_configs` leg (up to 32 768 nodes x 16 384 pods) are cut down for the host twin: the leg's
+# control flow and its in-run parity assert are what is exercised here, not its sizes
+from workload import synth
+_mc, _mp = synth.make_cluster, synth.make_pods
+synth.make_cluster = lambda cfg, n_nodes=None, **kw: _mc(cfg, n_nodes=min(n_nodes, 1024) if n_nodes else n_nodes, **kw)
+synth.make_pods = lambda cfg, n_pods=None, **kw: _mp(cfg, n_pods=min(n_pods, 96) if n_pods else n_pods, **kw)
 sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--nodes-per-gpu", "1024", "--pods", "96", "--cpu-sample-pods", "32", "--no-pmc"]
 print("library chatter that must not reach the result stream", file=sys.stderr)
 runpy.run_path({bench!r}, run_name="__main__")

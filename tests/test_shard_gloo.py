@@ -91,8 +91,8 @@ def _worker_mode_b(rank, world, port, cfg, n, P, out_dir, chunk=512):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cfg,n,P,world,chunk", [(4, 640, 200, 2, 512), (5, 900, 260, 3, 512), (2, 256, 120, 2, 512),
-                                                  (4, 640, 200, 2, 48), (5, 900, 260, 3, 37), (2, 384, 120, 3, 16)])
+@pytest.mark.parametrize("cfg,n,P,world,chunk", [(4, 640, 200, 2, 512), (5, 600, 160, 3, 512), (2, 256, 120, 2, 512),
+                                                  (4, 640, 200, 2, 48), (5, 600, 160, 3, 37), (2, 384, 120, 3, 16)])
 def test_mode_b_one_process_per_shard_equals_the_scheduler_loop(tmp_path, cfg, n, P, world, chunk):
     """nhd_amd.sharding.schedule_batch_sharded under gloo (host twin per shard): every rank ends up with the decisions,
     mappings and physical ids the oracle's one-by-one loop over the WHOLE cluster produces - with the batch in one slice and
