@@ -160,7 +160,10 @@ class HipMatcher:
         self._deltas: List[np.ndarray] = []                # release / reclaim / reset / SetHugepages waiting for the device, in call order
         self.delta_stats = {"applied": 0, "repacked": 0}
         self._uploaded_ids: Optional[Tuple[int, ...]] = None
-        self._last_subset: Optional[Tuple[List[str], np.ndarray]] = None    # (names, candidate mask) of the last filtered dict seen
+        # candidate masks of the filtered dicts seen lately, by (length, first, middle, last name) -> [(names, mask)]: pods of a few
+        # node groups take turns in the pending list, each group with its own filtered dict (nhd/NHDScheduler.py:235-247)
+        self._last_subset: Optional[Dict[tuple, List[Tuple[List[str], np.ndarray]]]] = None
+        self._subset_count = self._subset_names = 0
 
     # ---- mirror maintenance -------------------------------------------------------------
     def attach(self, nodes: Dict[str, object]) -> None:
@@ -423,17 +426,24 @@ class HipMatcher:
         names = list(nl)
         if len(names) == n and names == self._names:          # C-speed comparison (identical str objects short-cut)
             return None
-        # consecutive pods of one node group get the same filtered dict from InitialNodeFilter: the mask of the last subset
-        # is kept, and recognising it is one C-speed list comparison instead of a dictionary look-up per node
-        if self._last_subset is not None and names == self._last_subset[0]:
-            return self._last_subset[1]
+        # pods of one node group get the same filtered dict from InitialNodeFilter time after time: the masks of the subsets seen
+        # lately are kept, and recognising one is a C-speed list comparison instead of a dictionary look-up per node
+        key = (len(names), names[0], names[len(names) // 2], names[-1]) if names else (0,)
+        if self._last_subset is not None:
+            for cached, cached_mask in self._last_subset.get(key, ()):
+                if names == cached:                            # (identical str objects short-cut: a pointer comparison per name)
+                    return cached_mask
         idx = np.fromiter(map(self._index.__getitem__, names), dtype=np.int64, count=len(names))
         if len(idx) > 1 and not np.all(idx[1:] > idx[:-1]):
             raise ValueError("FindNode: `nl` must keep the relative order of the attached node dict")
         bits = np.zeros(((n + 63) // 64) * 64, dtype=bool)
         bits[idx] = True
         mask = np.ascontiguousarray(np.packbits(bits.reshape(-1, 64), axis=1, bitorder="little").view("<u8").reshape(-1))
-        self._last_subset = (names, mask)
+        if self._last_subset is None or self._subset_names + len(names) > (1 << 22):   # (bounded: four million names kept, then start over)
+            self._last_subset, self._subset_count, self._subset_names = {}, 0, 0
+        self._last_subset.setdefault(key, []).append((names, mask))
+        self._subset_count += 1
+        self._subset_names += len(names)
         return mask
 
     # ---- the reference interface ----------------------------------------------------------

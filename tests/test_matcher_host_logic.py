@@ -268,3 +268,26 @@ def test_enable_sharing_flipped_in_the_nodes_module_is_refused_not_ignored(monke
     monkeypatch.setattr(refmodel, "NIC_BW_AVAIL_PERCENT", 0.5)
     after = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine).FindNode(nl, big)
     assert before[0] is not None and after == (None,)            # (the cluster's fastest NICs are 100 GbE: 90.0 fits 60, 50.0 does not)
+
+
+def test_filtered_dicts_of_several_node_groups_taking_turns():
+    """Pods of different node groups alternate in the pending list, each with its own filtered dict (InitialNodeFilter builds a
+    new dict object per pod): the candidate masks of the subsets seen lately are all kept - a subset is computed once, recognised
+    afterwards - and the answers are the oracle's on every call."""
+    descs = util.random_cluster_desc(4711, 90, occupancy=0.1)
+    for i, d in enumerate(descs):
+        d["labels"]["NHD_GROUP"] = ("alpha", "beta", "alpha.gamma")[i % 3]
+    nl = util.build_cluster(descs)
+    rng = np.random.default_rng(8)
+    tops = [refmodel.make_topology(util.random_pod_spec(rng)) for _ in range(24)]
+    m = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)
+    m.attach(nl)
+    groups = (["alpha"], ["beta"], ["gamma"], ["alpha", "beta"])
+    for k, top in enumerate(tops):
+        sub = O.initial_node_filter(nl, groups[k % 4])                     # a fresh dict object every time
+        assert m.FindNode(sub, top) == norm(O.find_node(sub, top, util.CLOCK))
+    assert m._subset_count == 4 and sum(len(v) for v in m._last_subset.values()) == 4
+    nl[list(nl)[3]].active = False                                         # the filter's outcome changes: a fifth subset, the others stay
+    sub = O.initial_node_filter(nl, ["alpha"])
+    assert m.FindNode(sub, tops[0]) == norm(O.find_node(sub, tops[0], util.CLOCK))
+    assert m._subset_count == 5
