@@ -210,3 +210,52 @@ def test_matcher_from_config_texts_with_big_pods():
         placed_big += g[0] is not None and len(t.proc_groups) > 4
     assert placed_big >= 1
     assert m.FindNodesFromConfigs(nl, texts, sequential=True) == m.ScheduleBatch(nl, tops)
+
+
+def test_mutated_big_configs_agree():
+    """The fuzz of test_mutated_configs_agree on texts with up to eight processing groups, through the big record: outcome (request
+    bytes, None, raise, limit) identical to the reference parser's followed by Packer.digest_big."""
+    def ref_outcome(text):
+        try:
+            top = ref_loader.config_to_topology(text)
+        except Exception:  # noqa: BLE001
+            return ("raise",)
+        if top is None:
+            return ("none",)
+        try:
+            return ("ok", pack.Packer().digest_big(top))
+        except pack.UnsupportedNode:
+            return ("limit",)
+        except Exception:  # noqa: BLE001
+            return ("raise",)
+
+    def big_outcome(text):
+        try:
+            req = wire.digest_config_big(text)
+        except wire.ConfigError:
+            return ("raise",)
+        except pack.UnsupportedNode:
+            return ("limit",)
+        return ("none",) if req is None else ("ok", req)
+
+    rng = np.random.default_rng(20260922)
+    alphabet = list('{}[]()=:;,."\\\\#/* -+eExL0123456789abtrue\\n')
+    outcomes = set()
+    for _ in range(500):
+        t = list(wire_gen.make_config(50_000 + int(rng.integers(0, 300)), types_hi=6, inst_hi=3))
+        for _e in range(int(rng.integers(0, 3))):
+            pos = int(rng.integers(0, len(t)))
+            op = rng.random()
+            if op < 0.4:
+                del t[pos]
+            elif op < 0.8:
+                t.insert(pos, alphabet[int(rng.integers(0, len(alphabet)))])
+            else:
+                t[pos] = alphabet[int(rng.integers(0, len(alphabet)))]
+        text = "".join(t)
+        want, got = ref_outcome(text), big_outcome(text)
+        assert want[0] == got[0], (want[0], got[0], text)
+        if want[0] == "ok":
+            assert want[1].tobytes() == got[1].tobytes(), text
+        outcomes.add(want[0])
+    assert outcomes >= {"ok", "none", "raise", "limit"}, outcomes
