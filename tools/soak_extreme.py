@@ -26,7 +26,7 @@ SPEEDS = [9000, 10999, 11000, 12000, 20000, 25000, 40000, 50000, 56000, 100000, 
 NAMES = ["default"] + ["grp%02d" % k for k in range(40)]
 
 
-def edge_labels(rng, heavy, few=False):
+def edge_labels(rng, heavy, few=False, beyond=False):
     wide = rng.random() < 0.25
     if wide:
         sockets = int(rng.choice([1, 2, 3, 4], p=[0.1, 0.4, 0.25, 0.25]))
@@ -55,6 +55,8 @@ def edge_labels(rng, heavy, few=False):
             lab[NFD + "nfd-extras-cpu.isolcpus"] = "_".join(f"{a}-{b}" for a, b in spans)
     n_sw = int(rng.integers(1, 8 if wide else 7))          # switches per NUMA node (<= 14 per node on the fast layout)
     per_numa = [int(rng.integers(0, 17)) if heavy else int(rng.choice([0, 1, 2] if few else [0, 1, 2, 3, 4])) for _ in range(sockets)]
+    if beyond and rng.random() < 0.5:
+        per_numa[int(rng.integers(0, sockets))] = int(rng.integers(17, 21))      # more NICs on a NUMA node than any record holds: the node never matches
     speeds = rng.choice(SPEEDS, size=int(rng.integers(1, 5)), replace=False)
     j = 0
     for numa in range(sockets):
@@ -66,7 +68,7 @@ def edge_labels(rng, heavy, few=False):
             j += 1
     g = 0
     for numa in range(sockets):
-        for _ in range(int(rng.choice([0, 1, 2, 4, 8], p=[0.4, 0.15, 0.2, 0.15, 0.1]))):
+        for _ in range(9 if beyond and rng.random() < 0.3 else int(rng.choice([0, 1, 2, 4, 8], p=[0.4, 0.15, 0.2, 0.15, 0.1]))):
             if g >= 32:
                 break
             sw = 0x10 * (numa + 1) + int(rng.integers(0, n_sw))
@@ -81,8 +83,8 @@ def edge_labels(rng, heavy, few=False):
     return lab
 
 
-def edge_node(rng, name, heavy, occupancy, few=False):
-    lab = edge_labels(rng, heavy, few)
+def edge_node(rng, name, heavy, occupancy, few=False, beyond=False):
+    lab = edge_labels(rng, heavy, few, beyond)
     phys = int(lab[NFD + "nfd-extras-cpu.num_cores"])
     smt = (NFD + "cpu-hardware_multithreading") in lab
     used = []
@@ -162,8 +164,10 @@ def main():
         # (the oracle enumerates K^G NIC choices per NUMA assignment in Python: NIC-heavy nodes meet pods of one or two groups, pods of
         # five or six groups meet nodes of at most two NICs per NUMA node)
         max_groups = 2 if heavy_share else 6 if seed % 5 == 0 else 4 if seed % 2 else 3
-        descs = [edge_node(rng, f"e{i:04d}", rng.random() < heavy_share, occupancy=float(rng.choice([0.0, 0.1, 0.3, 0.6])), few=max_groups > 4)
-                 for i in range(14)]
+        # seed % 7 == 3: a few nodes beyond EVERY record (17..20 NICs or nine GPUs on a NUMA node) - they never match (listed in
+        # HipMatcher.unmirrored), every other node is answered for as the oracle answers without them
+        descs = [edge_node(rng, f"e{i:04d}", rng.random() < heavy_share, occupancy=float(rng.choice([0.0, 0.1, 0.3, 0.6])), few=max_groups > 4,
+                           beyond=bool(heavy_share) and seed % 7 == 3 and rng.random() < 0.3) for i in range(14)]
         nl = util.build_cluster(descs)
         specs = [edge_pod(rng, max_groups) for _ in range(16)]
         tops = [refmodel.make_topology(s) for s in specs]
