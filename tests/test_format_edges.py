@@ -21,7 +21,7 @@ def soak_module():
     return mod
 
 
-@pytest.mark.parametrize("first,with_ref", [(0, False), (21, False), (12000, True)]   # (seed 24: nodes beyond every record - they never match, the rest as the oracle says))
+@pytest.mark.parametrize("first,with_ref", [(0, False), (21, False), (12000, True)])   # (seed 24: nodes beyond every record - never matched, the rest as the oracle says)
 def test_edges_of_the_record_formats(monkeypatch, first, with_ref):
     if with_ref and not ref_loader.available():
         pytest.skip("reference tree not present (GPU box)")
