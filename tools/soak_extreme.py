@@ -157,7 +157,7 @@ def main():
         ref = ref_loader.load()
         ref_loader.VirtualClock(util.CLOCK).install()
     t0 = time.time()
-    bad = pods = placed = refchecked = unmirrored = streams = 0
+    bad = pods = placed = refchecked = unmirrored = streams = sharded = 0
     for seed in range(first, first + n_seeds):
         rng = np.random.default_rng(880000 + seed)
         heavy_share = 0.12 if seed % 3 == 0 else 0.0
@@ -191,6 +191,14 @@ def main():
                 if norm(rwant) != norm(want):
                     bad += 1
                     print("FIND oracle != REFERENCE seed", seed, "pod", p, s, norm(want), norm(rwant), flush=True)
+        if seed % 4 == 1:                                   # the same through a mirror sharded over three host-twin shards (engine.GroupEngine)
+            ms = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine, devices=[0, 1, 2])
+            ms.attach(util.build_cluster(descs))
+            gs = ms.FindNodes(ms._attached, tops)
+            if [norm(x) for x in gs] != [norm(x) for x in got]:
+                bad += 1
+                print("SHARDED FIND mismatch seed", seed, flush=True)
+            sharded += 1
         # InitialNodeFilter in front (filtered dict handed to FindNode) for the pods that carry groups
         for p, (top, pg) in enumerate(zip(tops, pgs)):
             if pg is None:
@@ -228,6 +236,14 @@ def main():
             want.append(r)
             ids.append(rec if r[0] is not None else None)
         k = len(want)
+        if seed % 4 == 1:
+            nl_s = util.build_cluster(descs)
+            ms = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine, devices=[0, 1, 2])
+            ms.attach(nl_s)
+            rs = ms.ScheduleBatch(nl_s, tops, now=util.CLOCK)
+            if [norm(x) for x in rs[:k]] != [norm(w) for w in want] or ms.last_placements[:k] != ids:
+                bad += 1
+                print("SHARDED MODE B mismatch seed", seed, flush=True)
         if [norm(x) for x in res[:k]] != [norm(w) for w in want]:
             bad += 1
             print("MODE B decisions mismatch seed", seed, [(norm(a), norm(b)) for a, b in zip(res[:k], want) if norm(a) != norm(b)][:2], flush=True)
@@ -279,10 +295,10 @@ def main():
                         print("OP-STREAM final find mismatch seed", seed, "pod", j, norm(g1), norm(w1), flush=True)
                 streams += 1
         if (seed - first) % 10 == 9:
-            print("seed", seed, "pods", pods, "placed", placed, "ref-checked", refchecked, "unmirrored nodes", unmirrored, "op streams", streams, "mismatches", bad,
+            print("seed", seed, "pods", pods, "placed", placed, "ref-checked", refchecked, "unmirrored nodes", unmirrored, "op streams", streams, "sharded", sharded, "mismatches", bad,
                   "seconds", round(time.time() - t0, 1), flush=True)
     print("seeds", n_seeds, "from", first, "pods", pods, "placed", placed, "ref-checked", refchecked, "unmirrored nodes", unmirrored,
-          "op streams", streams, "mismatches", bad, "seconds", round(time.time() - t0, 1))
+          "op streams", streams, "sharded", sharded, "mismatches", bad, "seconds", round(time.time() - t0, 1))
     return bad
 
 
