@@ -82,7 +82,9 @@ def main():
     if world > 1:
         import torch.distributed as dist          # control plane only (rendezvous, barrier, max-reduce of the time)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        import datetime
+        # (a rank that fails inside a rank-to-rank exchange must not leave the others waiting for the default half hour)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
 
     from nhd_amd import pack
     from nhd_amd.engine import Engine, winner_index
@@ -298,6 +300,7 @@ def strong_leg(cfg, total_nodes, P, world, rank, local_rank, dist, steps, warmup
     pk = pack.Packer()
     table = planes.planes_from_spec(pk, spec)
     reqs = pk.digest_many(tops, groups)
+    pk.close_signatures()                 # (as in the headline run: every NIC state a commit can produce has its signature - the mode-B leg below)
     eng = Engine(local_rank)
     eng.set_dictionary(pk)
     eng.upload(table, global_base=lo)
@@ -320,10 +323,65 @@ def strong_leg(cfg, total_nodes, P, world, rank, local_rank, dist, steps, warmup
     score, _, _ = eng.fetch(want_bitmap=False, want_map=True)
     dist.barrier()
     eng.comm_destroy()
+    out = {"config": cfg, "nodes_total": total_nodes, "nodes_per_gpu": per, "pods": P, "n_gpus": world, "scaling": "strong",
+           "ms_per_step": dt * 1e3 / steps, "evals_per_s": float(P) * total_nodes * steps / dt,
+           "snapshot_decisions_per_s": P * steps / dt, "placed_pods": int(np.count_nonzero(score))}
+    if cfg == 4:
+        # BASELINE's own unit at N > 1: placement decisions/s under the scheduler's commit semantics over the sharded cluster
+        out["mode_b"] = sharded_mode_b(eng, pk, table, reqs, spec, lo, hi, cfg, total_nodes, tops, groups, dist, rank, world)
     eng.close()
-    return {"config": cfg, "nodes_total": total_nodes, "nodes_per_gpu": per, "pods": P, "n_gpus": world, "scaling": "strong",
-            "ms_per_step": dt * 1e3 / steps, "evals_per_s": float(P) * total_nodes * steps / dt,
-            "snapshot_decisions_per_s": P * steps / dt, "placed_pods": int(np.count_nonzero(score))}
+    return out
+
+
+def sharded_mode_b(eng, pk, table, reqs, spec, lo, hi, cfg, total_nodes, tops, groups, dist, rank, world):
+    """Mode B with one process per GPU (nhd_amd.sharding.schedule_batch_sharded: the shards' sequential passes pipelined over pod
+    slices, pods travelling rank to rank as fixed-size tensors over the control plane, one all-reduce of the results): the commits
+    stay in the shards' mirrors (apply), every timed call starts from freshly uploaded shards, time = MAX over the ranks.  Rank 0
+    then decides the batch again with the independent oracle over the WHOLE cluster and compares node, mapping and physical ids of
+    every pod.  Nothing here may take the run down: an error is reported in the leg's place."""
+    import torch
+    from nhd_amd import sharding
+    from workload import synth
+    P = len(reqs)
+    now = spec.clock_now
+    err = None
+    ts, res = [], None
+    try:
+        bits = np.zeros(((hi - lo + 63) // 64) * 64, np.uint8)
+        bits[:hi - lo] = (np.asarray(spec.n_gpus) == 0)
+        nogpu = np.packbits(bits, bitorder="little").view(np.uint64).copy()
+        for _ in range(3):
+            eng.upload(table, global_base=lo)                 # the shard as the snapshot has it (the previous call's commits are gone)
+            dist.barrier()
+            t0 = time.perf_counter()
+            res = sharding.schedule_batch_sharded(eng, reqs, now, pk, nogpu, dist, apply=True)
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ts.append(float(t.item()))
+    except BaseException as e:                               # (incl. SystemExit: never leave the other ranks waiting)
+        err = f"{type(e).__name__}: {e}"[:300]
+    flag = torch.tensor([1 if err else 0], dtype=torch.int32)
+    try:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    except BaseException as e:
+        err = err or f"{type(e).__name__}: {e}"[:300]
+        flag[0] = 1
+    if int(flag.item()):
+        return {"error": err or "another rank failed", "call": "nhd_amd.sharding.schedule_batch_sharded"}
+    node, maps, places, status = res
+    t = min(ts[1:]) if len(ts) > 1 else ts[0]
+    out = {"call": "nhd_amd.sharding.schedule_batch_sharded (one process per GPU: nhdfit_schedule_batch per shard and pod slice, pods rank to rank over gloo, "
+                   "one all-reduce of the results; commits left in the shards' mirrors)",
+           "decisions_per_s": P / t, "ms_per_batch": t * 1e3, "placed": int((node >= 0).sum()), "n_gpus": world,
+           "commits_that_would_raise": int((status == 1).sum())}
+    if rank == 0:
+        try:
+            out["parity"] = mode_b_parity(synth.make_cluster(cfg, n_nodes=total_nodes), tops, groups, now, reqs, node, maps, places, status)
+        except BaseException as e:
+            out["parity"] = {"identical": False, "error": f"{type(e).__name__}: {e}"[:300]}
+    dist.barrier()
+    return out
 
 
 def roofline(st, fit_ms, achieved, traffic, traffic_source, valu, counters, pipes=1, ms_per_step=None):

@@ -110,6 +110,10 @@ def test_bench_two_ranks_control_plane(tmp_path):
     assert out["n_gpus"] == 2 and out["config"]["nodes_total"] == 1024 and "cpu_baseline" not in out
     leg = out["strong_scaling"][0]                            # BASELINE config 4's own shape rides along at every N > 1
     assert leg["config"] == 4 and leg["nodes_total"] == 65536 and leg["nodes_per_gpu"] == 32768 and leg["pods"] == 4096 and leg["placed_pods"] > 0
+    mb = leg["mode_b"]                                        # ... with BASELINE's own unit: decisions/s under commit semantics over the shards,
+    assert "error" not in mb, mb                              # decided again by the independent oracle over the whole cluster
+    assert mb["n_gpus"] == 2 and mb["decisions_per_s"] > 0 and mb["placed"] > 0
+    assert mb["parity"]["identical"] and mb["parity"]["pods_checked"] == 4096, mb["parity"]
 
 
 _STRONG_SCRIPT = _RANK_SCRIPT.replace('"--nodes-per-gpu", "512", "--pods", "40"', '"--config", "5", "--total-nodes", "1500", "--pods", "70"')
