@@ -345,6 +345,7 @@ def sharded_mode_b(eng, pk, table, reqs, spec, lo, hi, cfg, total_nodes, tops, g
     P = len(reqs)
     now = spec.clock_now
     per = (total_nodes + world - 1) // world
+    chunk = max(512, P // 4)              # pod slices of the pipeline down the ranks: few and long (a slice costs every rank two device passes)
     err = None
     ts, res = [], None
     try:
@@ -355,7 +356,7 @@ def sharded_mode_b(eng, pk, table, reqs, spec, lo, hi, cfg, total_nodes, tops, g
             eng.upload(table, global_base=lo)                 # the shard as the snapshot has it (the previous call's commits are gone)
             dist.barrier()
             t0 = time.perf_counter()
-            res = sharding.schedule_batch_sharded(eng, reqs, now, pk, nogpu, dist, apply=True)
+            res = sharding.schedule_batch_sharded(eng, reqs, now, pk, nogpu, dist, apply=True, chunk=chunk)
             dist.barrier()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -374,7 +375,7 @@ def sharded_mode_b(eng, pk, table, reqs, spec, lo, hi, cfg, total_nodes, tops, g
     t = min(ts[1:]) if len(ts) > 1 else ts[0]
     out = {"call": "nhd_amd.sharding.schedule_batch_sharded (one process per GPU: nhdfit_schedule_batch per shard and pod slice, pods rank to rank over gloo, "
                    "one all-reduce of the results; commits left in the shards' mirrors)",
-           "decisions_per_s": P / t, "ms_per_batch": t * 1e3, "placed": int((node >= 0).sum()), "n_gpus": world,
+           "decisions_per_s": P / t, "ms_per_batch": t * 1e3, "placed": int((node >= 0).sum()), "n_gpus": world, "pods_per_slice": chunk,
            "commits_that_would_raise": int((status == 1).sum()),
            "placed_per_shard": [int(((node >= r * per) & (node < (r + 1) * per)).sum()) for r in range(world)],
            "note": "first-fit hands a pod to the first shard that still has room for it, so the commit chain stays serial whatever the number of "
