@@ -146,6 +146,52 @@ def commit(packer, table, i, req, mapping, busy_time):
     return int(rc), out
 
 
+# ---- the wavefront form of the commit step (device source text of seq2_kernel.h) under a 64-thread wavefront emulation ---------
+WAVE_SRC = os.path.join(HERE, "wave_emul.cpp")
+WAVE_SO = os.path.join(HERE, "_wave_emul.so")
+WAVE_INC = os.path.join(HERE, "_wave_commit_block.inc")
+_WAVE_FROM, _WAVE_TO = "// ---- the commit step with the wavefront's lanes", "// ---- k_decide: speculate, then retire in order"
+_wave = None
+
+
+def wave_lib():
+    """Builds tests/harness/wave_emul.cpp around the commit section of nhd_amd/csrc/seq2_kernel.h (cut out unmodified)."""
+    global _wave
+    if _wave is not None:
+        return _wave
+    kernel = os.path.join(HERE, "..", "..", "nhd_amd", "csrc", "seq2_kernel.h")
+    deps = [WAVE_SRC, kernel] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "seq_core.h", "commit_core.h")] + \
+           [os.path.join(HERE, "..", "..", "include", "nhdfit.h")]
+    if not os.path.exists(WAVE_SO) or any(os.path.getmtime(d) > os.path.getmtime(WAVE_SO) for d in deps):
+        lines = open(kernel).read().split("\n")
+        a = next(i for i, ln in enumerate(lines) if ln.startswith(_WAVE_FROM))
+        b = next(i for i, ln in enumerate(lines) if ln.startswith(_WAVE_TO))
+        assert a < b and any("commit_node_wave" in ln for ln in lines[a:b])
+        with open(WAVE_INC, "w") as f:
+            f.write("\n".join(lines[a:b]) + "\n")
+        tmp = f"{WAVE_SO}.{os.getpid()}.tmp"
+        subprocess.check_call(["g++", "-O2", "-std=c++20", "-ffp-contract=off", "-shared", "-fPIC", "-pthread", WAVE_SRC, "-o", tmp])
+        os.replace(tmp, WAVE_SO)
+    _wave = ctypes.CDLL(WAVE_SO)
+    return _wave
+
+
+def wave_commit(packer, table, i, req, mapping, busy_time):
+    """commit() above through the WAVEFRONT form of the commit step (commit_node_wave, emulated lanes); `table` modified in place."""
+    L = wave_lib()
+    _, sig_off, pool_off, glimit, cc, ncls, nsig = _dict_args(packer)
+    out = np.zeros((), pack.PLACEMENT)
+    req = np.ascontiguousarray(req)
+    mapping = np.ascontiguousarray(mapping)
+    rows = [np.ascontiguousarray(getattr(table, f)[i:i + 1]) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
+    L.we_commit.restype = ctypes.c_int
+    rc = L.we_commit(*[_p(x) for x in rows], _p(req), _p(mapping), ctypes.c_double(busy_time), _p(sig_off), ctypes.c_uint32(nsig),
+                     _p(pool_off), _p(glimit), _p(cc), ctypes.c_uint32(ncls), _p(out))
+    for f, r in zip(("p0", "p1", "p2", "p3", "p4", "detail"), rows):
+        getattr(table, f)[i] = r[0]
+    return int(rc), out
+
+
 def apply_deltas(packer, table, deltas):
     """K3 on the host build: `deltas` (pack.DELTA, local node indices) applied in order to `table` (in place)."""
     L = lib()

@@ -1,0 +1,84 @@
+"""The WAVEFRONT form of the commit step - the device source text of nhd_amd/csrc/seq2_kernel.h (commit_node_wave and its helpers:
+what k_decide's speculators and workers run) cut out of the kernel header and executed on the host by 64 threads emulating the
+lanes (tests/harness/wave_emul.cpp) - against the scalar form (commit_core.h commit_node: the host twin's and k_commit's): node
+state, detail record, placement record and status byte for byte, on placements found for random pods on random clusters and on
+the same placement committed again and again until the node runs dry (the would-raise statuses)."""
+import copy
+
+import numpy as np
+import pytest
+
+from nhd_amd import pack
+from tests import harness, util
+from workload import refmodel, synth
+
+
+def _rows(table, i):
+    return [bytes(np.ascontiguousarray(getattr(table, f)[i:i + 1]).tobytes()) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
+
+
+def _both(pk, table, i, req, mp, bt):
+    ta, tb = copy.deepcopy(table), copy.deepcopy(table)
+    sa, pa = harness.commit(pk, ta, i, req, mp, bt)
+    sb, pb = harness.wave_commit(pk, tb, i, req, mp, bt)
+    assert sb != -100, "the lanes of the wavefront form disagree on the status"
+    assert sa == sb, (sa, sb)
+    assert pa.tobytes() == pb.tobytes(), (pa, pb)
+    assert _rows(ta, i) == _rows(tb, i)
+    return sa, ta
+
+
+def _run(nl, specs, repeats, seed):
+    tops = [refmodel.make_topology(s) for s in specs]
+    pk = pack.Packer()
+    table = pk.pack_nodes(nl)
+    reqs = pk.digest_many(tops)
+    pk.close_signatures()
+    score, _, maps = harness.find(pk, table, reqs, util.CLOCK, want_bitmap=False)
+    checked = raised = 0
+    for p in np.flatnonzero(score != 0):
+        i = int(0x7FFFFFFFFFFFFFFF - (int(score[p]) & 0x7FFFFFFFFFFFFFFF))
+        if table.wide and i in table.wide:
+            continue
+        t = table
+        for _ in range(repeats):                              # the same placement again: sooner or later cores / GPUs / NICs run out
+            st, t = _both(pk, t, i, reqs[p], maps[p], util.CLOCK + 1.0)
+            checked += 1
+            raised += st == pack.COMMIT_WOULD_RAISE
+    return checked, raised
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_wavefront_commit_equals_the_scalar_commit_on_random_clusters(seed):
+    rng = np.random.default_rng(4100 + seed)
+    nl = util.random_cluster(61000 + seed, 24, occupancy=0.15)
+    specs = []
+    for _ in range(24):
+        s = util.random_pod_spec(rng, max_groups=4 if seed % 2 else 3)
+        if s["map_type"] == "NONE":
+            s["map_type"] = "PCI"
+        specs.append(s)
+    checked, raised = _run(nl, specs, repeats=4, seed=seed)
+    assert checked >= 20 and raised >= 1
+
+
+def test_wavefront_commit_on_the_baseline_mixes():
+    """config 4 (GPUs, NICs, PCI locality) and config 5 (eight VFs per NUMA node: the signature keys over many NICs)"""
+    total = 0
+    for cfg in (4, 5):
+        spec = synth.make_cluster(cfg, n_nodes=48)
+        nl = spec.build_nodes()
+        pods, _ = synth.make_pods(cfg, n_pods=40)
+        tops = [refmodel.make_topology(s) for s in pods]
+        pk = pack.Packer()
+        table = pk.pack_nodes(nl)
+        reqs = pk.digest_many(tops)
+        pk.close_signatures()
+        score, _, maps = harness.find(pk, table, reqs, spec.clock_now, want_bitmap=False)
+        for p in np.flatnonzero(score != 0):
+            i = int(0x7FFFFFFFFFFFFFFF - (int(score[p]) & 0x7FFFFFFFFFFFFFFF))
+            t = table
+            for _ in range(3):
+                _, t = _both(pk, t, i, reqs[p], maps[p], spec.clock_now)
+                total += 1
+    assert total >= 60
