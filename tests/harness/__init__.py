@@ -151,6 +151,8 @@ WAVE_SRC = os.path.join(HERE, "wave_emul.cpp")
 WAVE_SO = os.path.join(HERE, "_wave_emul.so")
 WAVE_INC = os.path.join(HERE, "_wave_commit_block.inc")
 _WAVE_FROM, _WAVE_TO = "// ---- the commit step with the wavefront's lanes", "// ---- k_decide: speculate, then retire in order"
+WAVE_MAP_INC = os.path.join(HERE, "_wave_map_block.inc")
+_WAVE_MAP_FROM, _WAVE_MAP_TO = "// ---- wave-cooperative forms of the mapping arithmetic", "// One block walks the batch in the caller's order"
 _wave = None
 
 
@@ -160,7 +162,8 @@ def wave_lib():
     if _wave is not None:
         return _wave
     kernel = os.path.join(HERE, "..", "..", "nhd_amd", "csrc", "seq2_kernel.h")
-    deps = [WAVE_SRC, kernel] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "seq_core.h", "commit_core.h")] + \
+    kernel1 = os.path.join(HERE, "..", "..", "nhd_amd", "csrc", "seq_kernel.h")
+    deps = [WAVE_SRC, kernel, kernel1] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "seq_core.h", "commit_core.h", "winner_map.h", "set_states.h")] + \
            [os.path.join(HERE, "..", "..", "include", "nhdfit.h")]
     if not os.path.exists(WAVE_SO) or any(os.path.getmtime(d) > os.path.getmtime(WAVE_SO) for d in deps):
         lines = open(kernel).read().split("\n")
@@ -169,11 +172,31 @@ def wave_lib():
         assert a < b and any("commit_node_wave" in ln for ln in lines[a:b])
         with open(WAVE_INC, "w") as f:
             f.write("\n".join(lines[a:b]) + "\n")
+        lines = open(kernel1).read().split("\n")
+        a = next(i for i, ln in enumerate(lines) if ln.startswith(_WAVE_MAP_FROM))
+        b = next(i for i, ln in enumerate(lines) if ln.startswith(_WAVE_MAP_TO))
+        assert a < b and any("map_on_state_wave" in ln for ln in lines[a:b])
+        with open(WAVE_MAP_INC, "w") as f:
+            f.write("\n".join(lines[a:b]) + "\n")
         tmp = f"{WAVE_SO}.{os.getpid()}.tmp"
         subprocess.check_call(["g++", "-O2", "-std=c++20", "-ffp-contract=off", "-shared", "-fPIC", "-pthread", WAVE_SRC, "-o", tmp])
         os.replace(tmp, WAVE_SO)
     _wave = ctypes.CDLL(WAVE_SO)
     return _wave
+
+
+def wave_map_on_state(packer, table, i, req, tables=2):
+    """seq_core.h map_on_state (scalar) and seq_kernel.h map_on_state_wave (emulated lanes) for pod `req` on node i as it stands in
+    `table`: (return code of we_map_on_state, ok bits, scalar mapping, wavefront mapping)."""
+    L = wave_lib()
+    caps = _dict_args(packer)[0]
+    req = np.ascontiguousarray(req)
+    rows = [np.ascontiguousarray(getattr(table, f)[i:i + 1]) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
+    ms, mw = np.zeros((), pack.MAPPING), np.zeros((), pack.MAPPING)
+    ok = ctypes.c_int(0)
+    L.we_map_on_state.restype = ctypes.c_int
+    rc = L.we_map_on_state(*[_p(x) for x in rows], _p(req), _p(caps), ctypes.c_int(tables), _p(ms), _p(mw), ctypes.byref(ok))
+    return int(rc), ok.value, ms, mw
 
 
 def wave_commit(packer, table, i, req, mapping, busy_time):

@@ -32,6 +32,14 @@ inline uint64_t ballot(bool p) {
     return m;
 }
 inline void wave_barrier() { bar.arrive_and_wait(); }
+int slots[kLanes];
+inline int readlane(int v, int l) {                                  // every lane calls it (wave-uniform control flow)
+    slots[t_lane] = v;
+    bar.arrive_and_wait();
+    const int r = slots[l & (kLanes - 1)];
+    bar.arrive_and_wait();
+    return r;
+}
 }  // namespace emu
 
 #define __device__
@@ -40,9 +48,41 @@ inline void wave_barrier() { bar.arrive_and_wait(); }
 #define __popcll(x) __builtin_popcountll(x)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
+#define __builtin_amdgcn_readlane(v, l) emu::readlane((v), (l))
+#define __noinline__ __attribute__((noinline))
 
 namespace {
-#include "_wave_commit_block.inc"
+#include "_wave_map_block.inc"       // seq_kernel.h: "wave-cooperative forms of the mapping arithmetic" (map_on_state_wave and its helpers)
+#include "_wave_commit_block.inc"    // seq2_kernel.h: "the commit step with the wavefront's lanes"
+
+// the mapping tables as the device builds them (k_build_asc / k_build_choose / the set-layout state machine)
+const AscEntry* asc_table() {
+    static std::vector<AscEntry> t;
+    if (t.empty()) {
+        t.resize(kAscEntries);
+        for (int len = 1; len <= 4; ++len)
+            for (uint32_t sub = 0; sub < (1u << (1u << len)); ++sub) t[kAscOffset[len] + sub] = asc_entry_build(len, sub);
+    }
+    return t.data();
+}
+const uint8_t* choose_table() {
+    static std::vector<uint8_t> t;
+    if (t.empty()) {
+        t.resize(kChooseEntries);
+        for (uint32_t e = 0; e < kChooseEntries; ++e) t[e] = choose_entry_build(asc_table(), e);
+    }
+    return t.data();
+}
+const SetStates& set_states() {
+    static std::vector<uint64_t> info;
+    static std::vector<uint32_t> next, asc;
+    static SetStates t{};
+    if (info.empty()) {
+        build_set_states(info, next, asc);
+        t = SetStates{info.data(), next.data(), asc.data(), (uint32_t)info.size()};
+    }
+    return t;
+}
 }
 
 extern "C" {
@@ -88,6 +128,53 @@ int we_commit(nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plane2* p2, nhdfit_pl
     *det = dd;
     *out = pl;
     return status[0];
+}
+
+// The mapping FindNode returns for pod `req` on the node in state (planes, det): seq_core.h map_on_state (scalar: the host twin's)
+// against seq_kernel.h map_on_state_wave (the sequential kernels' wavefront form, emulated lanes).  nic_bits: the NIC-feasible
+// NUMA assignments, here from the scalar NIC walk itself (on the device: the cold R rows of the pod's tile image).
+// tables: 0 = the set model alone, 1 = with the ascending-set table, 2 = with every table the device uses.
+// Returns 0 when both forms agree (ok flag; mapping when ok), 1 otherwise, -100 if the lanes disagree among themselves.
+int we_map_on_state(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3, const nhdfit_plane4* p4,
+                    const nhdfit_detail* det, const nhdfit_req* req, const double* caps, int tables,
+                    nhdfit_mapping* scalar_out, nhdfit_mapping* wave_out, int* ok_out) {
+    const NodeState st{*p0, *p1, *p2, *p3, *p4};
+    const nhdfit_detail dd = *det;
+    const WinnerState w = state_view(st, dd, caps);
+    const int G = (int)req->n_groups, U = w.U;
+    uint32_t nic_bits = 0;
+    if (G >= 1 && G <= kMaxG)
+        for (uint32_t p = 0; p < (1u << G); ++p) {
+            if (U == 1 && p) break;
+            int8_t idx[kMaxG];
+            if (first_nic_choice(*req, w, p, req->map_type == NHDFIT_MAP_PCI, idx)) nic_bits |= 1u << p;
+        }
+    MapTables mt{nullptr, nullptr, SetStates{nullptr, nullptr, nullptr, 0}};
+    if (tables >= 1) mt.asc = asc_table();
+    if (tables >= 2) { mt.choose_tab = choose_table(); mt.st = set_states(); }
+    nhdfit_mapping ms;
+    std::memset(&ms, 0, sizeof ms);
+    const bool ok_s = map_on_state(*req, st, dd, caps, nic_bits, mt, ms);
+    nhdfit_mapping mw[emu::kLanes];
+    bool ok_w[emu::kLanes];
+    emu::acc[0] = emu::acc[1] = 0;
+    std::vector<std::thread> lanes;
+    for (int i = 0; i < emu::kLanes; ++i)
+        lanes.emplace_back([&, i] {
+            emu::t_lane = (uint32_t)i; emu::t_count = 0;
+            ok_w[i] = map_on_state_wave(*req, st, dd, caps, nic_bits, mt, (uint32_t)i, mw[i]);
+        });
+    for (auto& t : lanes) t.join();
+    for (int i = 1; i < emu::kLanes; ++i)
+        if (ok_w[i] != ok_w[0] || std::memcmp(&mw[i], &mw[0], sizeof(nhdfit_mapping)) != 0) return -100;
+    *scalar_out = ms; *wave_out = mw[0];
+    *ok_out = (ok_s ? 1 : 0) | (ok_w[0] ? 2 : 0);
+    if (ok_s != ok_w[0]) return 1;
+    if (!ok_s) return 0;
+    for (int g = 0; g < G; ++g)
+        if (ms.gpu[g] != mw[0].gpu[g] || ms.nic_numa[g] != mw[0].nic_numa[g] || ms.nic_idx[g] != mw[0].nic_idx[g]) return 1;
+    for (int g = 0; g <= G; ++g) if (ms.cpu[g] != mw[0].cpu[g]) return 1;
+    return ms.valid == mw[0].valid ? 0 : 1;
 }
 
 }  // extern "C"

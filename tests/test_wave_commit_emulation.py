@@ -82,3 +82,34 @@ def test_wavefront_commit_on_the_baseline_mixes():
                 _, t = _both(pk, t, i, reqs[p], maps[p], spec.clock_now)
                 total += 1
     assert total >= 60
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_wavefront_mapping_equals_the_scalar_mapping(seed):
+    """seq_kernel.h map_on_state_wave (what k_seq's wavefronts and k_decide's speculators verify a candidate with: the tuple codes, NIC
+    choices and table rows spread over the lanes) against seq_core.h map_on_state, for every (pod, node) pair of a random cluster - the
+    feasible and the infeasible ones - with the set model alone, with the ascending-set table and with every table the device uses."""
+    rng = np.random.default_rng(5200 + seed)
+    nl = util.random_cluster(62000 + seed, 14, occupancy=float(rng.choice([0.0, 0.2, 0.4])))
+    specs = []
+    for _ in range(12):
+        s = util.random_pod_spec(rng, max_groups=4 if seed % 2 else 3)
+        if s["map_type"] == "NONE":
+            s["map_type"] = "PCI"
+        specs.append(s)
+    tops = [refmodel.make_topology(s) for s in specs]
+    pk = pack.Packer()
+    table = pk.pack_nodes(nl)
+    reqs = pk.digest_many(tops)
+    pk.close_signatures()
+    pairs = mapped = 0
+    for i in range(table.n):
+        if table.wide and i in table.wide:
+            continue
+        for p in range(len(reqs)):
+            for tables in (0, 1, 2):
+                rc, ok, ms, mw = harness.wave_map_on_state(pk, table, i, reqs[p], tables)
+                assert rc == 0, (rc, ok, i, specs[p], ms, mw, tables)
+            pairs += 1
+            mapped += ok == 3
+    assert pairs >= 100 and mapped >= 5
