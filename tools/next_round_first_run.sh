@@ -20,6 +20,12 @@
 #   * mode B: 0.81-0.85 M decisions/s at config 4 (speculate + retire), 0.13 M at config 2 (every pod GPU-less, piling onto the same
 #     nodes: verify ~3 us -> commit ~4 us is a real chain; next: the commit's summary - counts, signature ids - first, the core picks on a
 #     second wavefront).
+#     What the chain executes can be read without a GPU: tools/probe_wave_isa.sh (commit_node_wave: 1 385 instructions static, 40 LDS
+#     round trips with a full wait - the request's byte fields one ds_read_u8 at a time, 5-6 per processing group; map_on_state_wave:
+#     1 601 / 37) and checked without one: tests/harness/wave_emul.cpp runs the routines' SOURCE TEXT on 64 emulated lanes against the
+#     scalar forms (tests/test_wave_commit_emulation.py) - rewrite there first (request fields from a lane-distributed register through
+#     v_readlane instead of LDS bytes; the summary of a commit - free-core / GPU counts, hugepages, NIC classes - published before the
+#     core picks so that the next pod's verification starts ~3.7 us earlier), then measure with NHDFIT_SEQ_PROF=1.
 #   * single calls: nhdfit_find one pod 26 / 28 / 35 / 33 us (4 096 / 16 384 / 65 536 nodes / c5 shard); HIP_FORCE_DEV_KERNARG=1 changes
 #     nothing; nhdfit_find with 4 096 pods 0.20 ms (host copies of 512 KB of requests on both sides of three launches).
 #   * pods beyond the table pass (5..8 processing groups, hugepage requests > 1 022 GiB): nhdfit_big_req through the general path

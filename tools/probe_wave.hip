@@ -1,0 +1,29 @@
+// probe_wave.hip - NOT part of the product: the wavefront forms of the commit step and of the mapping on a node state (what the
+// chain of mode B's GPU-less pods executes pod after pod) as stand-alone kernels, so that their ISA can be read and counted without a GPU
+// (tools/probe_wave_isa.sh: hipcc --cuda-device-only -S; instruction histogram, LDS reads followed by a full wait).
+#include "../nhd_amd/csrc/nhdfit.hip"
+namespace {
+__global__ __launch_bounds__(64) void probe_commit(NodeState* s, nhdfit_detail* d, const nhdfit_req* r, const nhdfit_mapping* m, double bt,
+                                                   SigTable sigs, uint32_t ncls, nhdfit_placement* out, int* st) {
+    __shared__ NodeState ls; __shared__ nhdfit_detail ld; __shared__ nhdfit_placement lo; __shared__ PaddedReq lr; __shared__ nhdfit_mapping lm;
+    const uint32_t lane = threadIdx.x;
+    if (lane == 0) { ls = *s; ld = *d; lm = *m; }
+    if (lane < sizeof(nhdfit_req) / 16) reinterpret_cast<uint4*>(&lr)[lane] = reinterpret_cast<const uint4*>(r)[lane];
+    __syncthreads();
+    const int status = commit_node_wave(ls, ld, reinterpret_cast<const nhdfit_req&>(lr), lm, bt, sigs, ncls, lo, lane);
+    __syncthreads();
+    if (lane == 0) { *s = ls; *d = ld; *out = lo; *st = status; }
+}
+__global__ __launch_bounds__(64) void probe_map(const NodeState* s, const nhdfit_detail* d, const nhdfit_req* r, const double* caps, uint32_t bits, MapTables mt,
+                                                nhdfit_mapping* out, int* ok) {
+    __shared__ NodeState ls; __shared__ nhdfit_detail ld; __shared__ PaddedReq lr; __shared__ double lc[NHDFIT_MAX_CLASSES];
+    const uint32_t lane = threadIdx.x;
+    if (lane == 0) { ls = *s; ld = *d; }
+    if (lane < NHDFIT_MAX_CLASSES) lc[lane] = caps[lane];
+    if (lane < sizeof(nhdfit_req) / 16) reinterpret_cast<uint4*>(&lr)[lane] = reinterpret_cast<const uint4*>(r)[lane];
+    __syncthreads();
+    nhdfit_mapping mp;
+    const bool k = map_on_state_wave(reinterpret_cast<const nhdfit_req&>(lr), ls, ld, lc, bits, mt, lane, mp);
+    if (lane == 0) { *out = mp; *ok = k; }
+}
+}
