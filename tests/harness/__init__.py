@@ -163,7 +163,7 @@ def wave_lib():
         return _wave
     kernel = os.path.join(HERE, "..", "..", "nhd_amd", "csrc", "seq2_kernel.h")
     kernel1 = os.path.join(HERE, "..", "..", "nhd_amd", "csrc", "seq_kernel.h")
-    deps = [WAVE_SRC, kernel, kernel1] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "seq_core.h", "commit_core.h", "winner_map.h", "set_states.h")] + \
+    deps = [WAVE_SRC, kernel, kernel1] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "seq_core.h", "commit_core.h", "winner_map.h", "set_states.h", "seq2_commit_v2.h")] + \
            [os.path.join(HERE, "..", "..", "include", "nhdfit.h")]
     if not os.path.exists(WAVE_SO) or any(os.path.getmtime(d) > os.path.getmtime(WAVE_SO) for d in deps):
         lines = open(kernel).read().split("\n")
@@ -199,8 +199,9 @@ def wave_map_on_state(packer, table, i, req, tables=2):
     return int(rc), ok.value, ms, mw
 
 
-def wave_commit(packer, table, i, req, mapping, busy_time):
-    """commit() above through the WAVEFRONT form of the commit step (commit_node_wave, emulated lanes); `table` modified in place."""
+def wave_commit(packer, table, i, req, mapping, busy_time, form=1):
+    """commit() above through the WAVEFRONT form of the commit step (commit_node_wave, emulated lanes); `table` modified in place.
+    form=2: the candidate form of nhd_amd/csrc/seq2_commit_v2.h."""
     L = wave_lib()
     _, sig_off, pool_off, glimit, cc, ncls, nsig = _dict_args(packer)
     out = np.zeros((), pack.PLACEMENT)
@@ -209,7 +210,7 @@ def wave_commit(packer, table, i, req, mapping, busy_time):
     rows = [np.ascontiguousarray(getattr(table, f)[i:i + 1]) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
     L.we_commit.restype = ctypes.c_int
     rc = L.we_commit(*[_p(x) for x in rows], _p(req), _p(mapping), ctypes.c_double(busy_time), _p(sig_off), ctypes.c_uint32(nsig),
-                     _p(pool_off), _p(glimit), _p(cc), ctypes.c_uint32(ncls), _p(out))
+                     _p(pool_off), _p(glimit), _p(cc), ctypes.c_uint32(ncls), _p(out), ctypes.c_int(form))
     for f, r in zip(("p0", "p1", "p2", "p3", "p4", "detail"), rows):
         getattr(table, f)[i] = r[0]
     return int(rc), out

@@ -10,6 +10,7 @@
 // NOT part of libnhdfit.so; nothing in nhd_amd/ loads it.
 #include <atomic>
 #include <barrier>
+#include <cstddef>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -54,6 +55,7 @@ inline int readlane(int v, int l) {                                  // every la
 namespace {
 #include "_wave_map_block.inc"       // seq_kernel.h: "wave-cooperative forms of the mapping arithmetic" (map_on_state_wave and its helpers)
 #include "_wave_commit_block.inc"    // seq2_kernel.h: "the commit step with the wavefront's lanes"
+#include "../../nhd_amd/csrc/seq2_commit_v2.h"   // the candidate form (request read once, fields by v_readlane): not in libnhdfit.so yet
 
 // the mapping tables as the device builds them (k_build_asc / k_build_choose / the set-layout state machine)
 const AscEntry* asc_table() {
@@ -92,7 +94,7 @@ extern "C" {
 int we_commit(nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plane2* p2, nhdfit_plane3* p3, nhdfit_plane4* p4, nhdfit_detail* det,
               const nhdfit_req* req, const nhdfit_mapping* map, double busy_time,
               const uint32_t* sig_off, uint32_t nsig, const uint32_t* pool_off, const uint8_t* pool_glimit, const nhdfit_cc* cc,
-              uint32_t ncls, nhdfit_placement* out) {
+              uint32_t ncls, nhdfit_placement* out, int form) {
     uint32_t slots = 64;
     while (slots < 4 * nsig) slots <<= 1;
     std::vector<uint64_t> skeys(slots, 0);
@@ -120,7 +122,8 @@ int we_commit(nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plane2* p2, nhdfit_pl
     for (int i = 0; i < emu::kLanes; ++i)
         lanes.emplace_back([&, i] {
             emu::t_lane = (uint32_t)i; emu::t_count = 0;
-            status[i] = commit_node_wave(st, dd, *req, *map, busy_time, sigs, ncls, pl, (uint32_t)i);
+            status[i] = form == 2 ? commit_node_wave_v2(st, dd, *req, *map, busy_time, sigs, ncls, pl, (uint32_t)i)
+                                  : commit_node_wave(st, dd, *req, *map, busy_time, sigs, ncls, pl, (uint32_t)i);
         });
     for (auto& t : lanes) t.join();
     for (int i = 1; i < emu::kLanes; ++i) if (status[i] != status[0]) return -100;

@@ -25,6 +25,9 @@ def _both(pk, table, i, req, mp, bt):
     assert sa == sb, (sa, sb)
     assert pa.tobytes() == pb.tobytes(), (pa, pb)
     assert _rows(ta, i) == _rows(tb, i)
+    tc = copy.deepcopy(table)                                  # the candidate form (seq2_commit_v2.h: the request read once)
+    sc, pc = harness.wave_commit(pk, tc, i, req, mp, bt, form=2)
+    assert sc == sa and pc.tobytes() == pa.tobytes() and _rows(tc, i) == _rows(ta, i), ("v2", sa, sc, pa, pc)
     return sa, ta
 
 

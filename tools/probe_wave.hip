@@ -3,6 +3,18 @@
 // (tools/probe_wave_isa.sh: hipcc --cuda-device-only -S; instruction histogram, LDS reads followed by a full wait).
 #include "../nhd_amd/csrc/nhdfit.hip"
 namespace {
+#include "../nhd_amd/csrc/seq2_commit_v2.h"
+__global__ __launch_bounds__(64) void probe_commit_v2(NodeState* s, nhdfit_detail* d, const nhdfit_req* r, const nhdfit_mapping* m, double bt,
+                                                      SigTable sigs, uint32_t ncls, nhdfit_placement* out, int* st) {
+    __shared__ NodeState ls; __shared__ nhdfit_detail ld; __shared__ nhdfit_placement lo; __shared__ PaddedReq lr; __shared__ nhdfit_mapping lm;
+    const uint32_t lane = threadIdx.x;
+    if (lane == 0) { ls = *s; ld = *d; lm = *m; }
+    if (lane < sizeof(nhdfit_req) / 16) reinterpret_cast<uint4*>(&lr)[lane] = reinterpret_cast<const uint4*>(r)[lane];
+    __syncthreads();
+    const int status = commit_node_wave_v2(ls, ld, reinterpret_cast<const nhdfit_req&>(lr), lm, bt, sigs, ncls, lo, lane);
+    __syncthreads();
+    if (lane == 0) { *s = ls; *d = ld; *out = lo; *st = status; }
+}
 __global__ __launch_bounds__(64) void probe_commit(NodeState* s, nhdfit_detail* d, const nhdfit_req* r, const nhdfit_mapping* m, double bt,
                                                    SigTable sigs, uint32_t ncls, nhdfit_placement* out, int* st) {
     __shared__ NodeState ls; __shared__ nhdfit_detail ld; __shared__ nhdfit_placement lo; __shared__ PaddedReq lr; __shared__ nhdfit_mapping lm;
