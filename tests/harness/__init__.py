@@ -185,9 +185,10 @@ def wave_lib():
     return _wave
 
 
-def wave_map_on_state(packer, table, i, req, tables=2):
+def wave_map_on_state(packer, table, i, req, tables=2, nic_bits=-1):
     """seq_core.h map_on_state (scalar) and seq_kernel.h map_on_state_wave (emulated lanes) for pod `req` on node i as it stands in
-    `table`: (return code of we_map_on_state, ok bits, scalar mapping, wavefront mapping)."""
+    `table`: (return code of we_map_on_state, ok bits, scalar mapping, wavefront mapping).  nic_bits >= 0: the NIC-feasible
+    assignments to use (find_lone's) instead of the scalar NIC walk's."""
     L = wave_lib()
     caps = _dict_args(packer)[0]
     req = np.ascontiguousarray(req)
@@ -195,7 +196,7 @@ def wave_map_on_state(packer, table, i, req, tables=2):
     ms, mw = np.zeros((), pack.MAPPING), np.zeros((), pack.MAPPING)
     ok = ctypes.c_int(0)
     L.we_map_on_state.restype = ctypes.c_int
-    rc = L.we_map_on_state(*[_p(x) for x in rows], _p(req), _p(caps), ctypes.c_int(tables), _p(ms), _p(mw), ctypes.byref(ok))
+    rc = L.we_map_on_state(*[_p(x) for x in rows], _p(req), _p(caps), ctypes.c_int(tables), ctypes.c_int64(int(nic_bits)), _p(ms), _p(mw), ctypes.byref(ok))
     return int(rc), ok.value, ms, mw
 
 

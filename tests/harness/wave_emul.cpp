@@ -136,17 +136,18 @@ int we_commit(nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plane2* p2, nhdfit_pl
 // The mapping FindNode returns for pod `req` on the node in state (planes, det): seq_core.h map_on_state (scalar: the host twin's)
 // against seq_kernel.h map_on_state_wave (the sequential kernels' wavefront form, emulated lanes).  nic_bits: the NIC-feasible
 // NUMA assignments, here from the scalar NIC walk itself (on the device: the cold R rows of the pod's tile image).
-// tables: 0 = the set model alone, 1 = with the ascending-set table, 2 = with every table the device uses.
+// nic_bits_in >= 0: use these bits instead.  tables: 0 = the set model alone, 1 = with the ascending-set table, 2 = with every table the device uses.
 // Returns 0 when both forms agree (ok flag; mapping when ok), 1 otherwise, -100 if the lanes disagree among themselves.
 int we_map_on_state(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3, const nhdfit_plane4* p4,
-                    const nhdfit_detail* det, const nhdfit_req* req, const double* caps, int tables,
+                    const nhdfit_detail* det, const nhdfit_req* req, const double* caps, int tables, int64_t nic_bits_in,
                     nhdfit_mapping* scalar_out, nhdfit_mapping* wave_out, int* ok_out) {
     const NodeState st{*p0, *p1, *p2, *p3, *p4};
     const nhdfit_detail dd = *det;
     const WinnerState w = state_view(st, dd, caps);
     const int G = (int)req->n_groups, U = w.U;
     uint32_t nic_bits = 0;
-    if (G >= 1 && G <= kMaxG)
+    if (nic_bits_in >= 0) nic_bits = (uint32_t)nic_bits_in;            // the caller's (the lone-pod form's masks: fit_core.h lone_nic_bits)
+    else if (G >= 1 && G <= kMaxG)
         for (uint32_t p = 0; p < (1u << G); ++p) {
             if (U == 1 && p) break;
             int8_t idx[kMaxG];

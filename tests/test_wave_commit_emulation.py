@@ -116,3 +116,32 @@ def test_wavefront_mapping_equals_the_scalar_mapping(seed):
             pairs += 1
             mapped += ok == 3
     assert pairs >= 100 and mapped >= 5
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_lone_pod_winner_mapped_by_the_wavefront_form(seed):
+    """What a wave-cooperative mapping tail of the one-pod launch (k_find1) would compute: the winner of the lone-pod form, its
+    NIC-feasible assignments from the pod's own masks (fit_core.h lone_nic_bits), map_on_state_wave on the winner's state - against
+    the mapping the table pass returns for the same pod (the mode-A roles' answer, pinned to the reference elsewhere)."""
+    rng = np.random.default_rng(5300 + seed)
+    nl = util.random_cluster(63000 + seed, 30, occupancy=0.2)
+    specs = [util.random_pod_spec(rng, max_groups=3) for _ in range(30)]
+    tops = [refmodel.make_topology(s) for s in specs]
+    pk = pack.Packer()
+    table = pk.pack_nodes(nl)
+    reqs = pk.digest_many(tops)
+    score, _, maps = harness.find(pk, table, reqs, util.CLOCK, want_bitmap=False)
+    ls, _, bits = harness.find_lone(pk, table, reqs, util.CLOCK)
+    assert np.array_equal(ls, score)
+    mapped = 0
+    for p in np.flatnonzero(score != 0):
+        i = int(0x7FFFFFFFFFFFFFFF - (int(score[p]) & 0x7FFFFFFFFFFFFFFF))
+        if table.wide and i in table.wide:
+            continue
+        rc, ok, ms, mw = harness.wave_map_on_state(pk, table, i, reqs[p], tables=2, nic_bits=int(bits[p]))
+        assert rc == 0 and ok == 3, (rc, ok, specs[p])
+        G = int(reqs[p]["n_groups"])
+        for f, k in (("gpu", G), ("cpu", G + 1), ("nic_numa", G), ("nic_idx", G)):
+            assert mw[f][:k].tolist() == maps[p][f][:k].tolist(), (f, specs[p], mw, maps[p])
+        mapped += 1
+    assert mapped >= 8

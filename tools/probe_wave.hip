@@ -4,6 +4,22 @@
 #include "../nhd_amd/csrc/nhdfit.hip"
 namespace {
 #include "../nhd_amd/csrc/seq2_commit_v2.h"
+#include "../nhd_amd/csrc/find1_wave_map.h"
+__global__ __launch_bounds__(256) void probe_lone_map(MapArgs m, ShapeArgs h, LoneMasks t, const nhdfit_req* r, const double* caps) {
+    extern __shared__ __align__(16) uint8_t lds_probe[];
+    __shared__ nhdfit_req lr;
+    if (threadIdx.x < sizeof(nhdfit_req) / 16) reinterpret_cast<uint4*>(&lr)[threadIdx.x] = reinterpret_cast<const uint4*>(r)[threadIdx.x];
+    __syncthreads();
+    map_lone_pod_wave(m, h, t, lr, caps, lds_probe);
+}
+__global__ __launch_bounds__(256) void probe_lone_map_shipped(MapArgs m, ShapeArgs h, LoneMasks t, const nhdfit_req* r) {
+    extern __shared__ __align__(16) uint8_t lds_probe2[];
+    __shared__ nhdfit_req lr;
+    if (threadIdx.x < sizeof(nhdfit_req) / 16) reinterpret_cast<uint4*>(&lr)[threadIdx.x] = reinterpret_cast<const uint4*>(r)[threadIdx.x];
+    __syncthreads();
+    m.reqs = &lr;
+    map_one_tile<256, true>(m, h, 0, lds_probe2, &t);
+}
 __global__ __launch_bounds__(64) void probe_commit_v2(NodeState* s, nhdfit_detail* d, const nhdfit_req* r, const nhdfit_mapping* m, double bt,
                                                       SigTable sigs, uint32_t ncls, nhdfit_placement* out, int* st) {
     __shared__ NodeState ls; __shared__ nhdfit_detail ld; __shared__ nhdfit_placement lo; __shared__ PaddedReq lr; __shared__ nhdfit_mapping lm;
