@@ -91,8 +91,10 @@ def _worker_mode_b(rank, world, port, cfg, n, P, out_dir, chunk=512):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cfg,n,P,world,chunk", [(4, 640, 200, 2, 512), (5, 600, 160, 3, 512), (2, 256, 120, 2, 512),
-                                                  (4, 640, 200, 2, 48), (5, 600, 160, 3, 37), (2, 384, 120, 3, 16)])
+# (clusters small enough for the pods to spill into the later shards - first-fit fills shard 0 first: 130 / 70, 92 / 8 / 0, 79 / 42 / 39
+#  pods per shard; with the 600-node clusters this list used to hold, every pod stayed in shard 0 and only empty lists travelled)
+@pytest.mark.parametrize("cfg,n,P,world,chunk", [(4, 256, 200, 2, 512), (5, 256, 100, 3, 512), (4, 192, 160, 3, 512), (2, 128, 160, 2, 512),
+                                                  (4, 256, 200, 2, 48), (5, 256, 100, 3, 37), (4, 192, 160, 3, 16)])
 def test_mode_b_one_process_per_shard_equals_the_scheduler_loop(tmp_path, cfg, n, P, world, chunk):
     """nhd_amd.sharding.schedule_batch_sharded under gloo (host twin per shard): every rank ends up with the decisions,
     mappings and physical ids the oracle's one-by-one loop over the WHOLE cluster produces - with the batch in one slice and
@@ -121,6 +123,8 @@ def test_mode_b_one_process_per_shard_equals_the_scheduler_loop(tmp_path, cfg, n
             phys = int(spec.phys[want_node[i]])
             assert pack.expand_placement(places[i], G, phys // 2, phys, [int(reqs[i]["gpus"][g]) for g in range(G)]) == wid, (rank, i)
     assert (want_node >= 0).sum() >= 20
+    lo1 = shard.shard_bounds(n, world, 1)[0]
+    assert (want_node >= lo1).sum() >= 5, "the case must send pods past the first shard"
 
 
 def test_order_preserving_score_encoding():

@@ -15,6 +15,8 @@ def planes_from_spec(packer, spec) -> NodeTable:
     SR-IOV, on its physical function's switch numa*2 + j // (K/2); every NIC is 100 GbE."""
     n = spec.n
     t = empty_table(n)
+    if n == 0:                                           # (a shard without nodes: more ranks than 64-node blocks)
+        return t
     cpp = (spec.phys // 2).astype(np.uint64)
     if int(cpp.max()) > packer.max_cores_per_numa:
         packer.max_cores_per_numa = int(cpp.max())
