@@ -1,5 +1,5 @@
-// find1_wave_map.h - CANDIDATE for the next GPU measurement, NOT part of libnhdfit.so yet (nothing includes it but
-// tools/probe_wave.hip).  The mapping tail of the one-pod launch (k_find1, step_kernel.h) on ONE wavefront whose lanes work
+// find1_wave_map.h - CANDIDATE for the next GPU measurement, compiled OUT of libnhdfit.so (nhdfit.hip includes it only under
+// -DNHDFIT_CAND_FIND1_WAVE, which nhd_amd/build.py does not pass; tools/r05_candidates.sh builds and measures it).  The mapping tail of the one-pod launch (k_find1, step_kernel.h) on ONE wavefront whose lanes work
 // together: today the block with the last ticket runs map_one_tile<BLOCK, true> - the tile machinery with a single live
 // lane walking candidate_masks and the NIC choices one after the other, 12-20 us of the 35 us call (DESIGN.md section 4
 // "One pod, one launch").  The sequential kernels already own the wave-cooperative form of the same arithmetic
@@ -7,10 +7,41 @@
 // planes and detail, the capacity classes, and the NIC-feasible assignments from the pod's own masks (fit_core.h
 // lone_nic_bits) instead of a tile image.  tests/test_wave_commit_emulation.py (test_lone_pod_winner_mapped_by_the_wavefront_form)
 // runs exactly this composition on emulated lanes against the table pass's mapping.
-// To try it on the device: include this file behind seq_kernel.h (it needs map_on_state_wave), replace k_find1's
-//     map_one_tile<BLOCK, true>(m, a.h, 0, lds_map, &t);
-// by  map_lone_pod_wave(m, a.h, t, *s_req, a.d.caps, lds_map);
-// run tests/test_gpu_parity.py -k "single or lone or find" and tools/time_single_find.py.
+// map_on_state_wave (seq_kernel.h) for a pod of at most three groups: the same steps without the call into the generic set model
+// (four groups), whose scratch arrays would size the private segment of every k_find1 launch (10 KB per lane)
+__device__ __forceinline__ bool map_on_state_wave_small(const nhdfit_req& r, const NodeState& s, const nhdfit_detail& d, const double* caps, uint32_t nic_bits,
+                                                        const MapTables& t, uint32_t lane, nhdfit_mapping& m) {
+    const WinnerState w = state_view(s, d, caps);
+    const int G = (int)r.n_groups, U = w.U;
+    m = nhdfit_mapping{};
+    if (G > 3) return false;
+    const uint32_t codes = nic_codes_from_table_bits(nic_bits, G, U);
+    uint32_t sg, sc;
+    candidate_masks_wave(r, w, lane, sg, sc);
+    const uint32_t cd = codes & ((1u << ipow(U, G)) - 1u);
+    if (!sg || !sc || !cd) return false;
+    uint32_t res;
+    if (t.choose_tab && choose_tabulated(G, U)) res = choose_from_table(t.choose_tab, G, sg, sc, cd);
+    else if (t.st.info && G == 3 && U == 2) res = choose_g3(t.st, t.asc, sg, sc, cd);
+    else res = choose_model_cold(G, U, sg, sc, cd, t.asc);
+    if (!(res >> 8 & 1)) return false;
+    const uint32_t gcode = (res >> 4) & 7u;
+    const int ccode = (int)(res & 15u);
+    uint32_t nic_nibbles = 0;
+    const bool nic_ok = first_nic_choice_wave(r, w, gcode, r.map_type == NHDFIT_MAP_PCI, lane, nic_nibbles);
+#pragma unroll
+    for (int g = 0; g < kMaxG; ++g) {
+        const bool in = g < G;
+        m.gpu[g] = in ? (int8_t)tup_digit(gcode, G, U, g) : (int8_t)-1;
+        m.nic_numa[g] = m.gpu[g];
+        m.nic_idx[g] = in ? (int8_t)nib_get(nic_nibbles, g) : (int8_t)-1;
+    }
+#pragma unroll
+    for (int g = 0; g <= kMaxG; ++g) m.cpu[g] = g <= G ? (int8_t)tup_digit((uint32_t)ccode, G + 1, U, g) : (int8_t)-1;
+    m.valid = nic_ok ? 1 : 0;
+    if (!nic_ok) m = nhdfit_mapping{};
+    return nic_ok;
+}
 __device__ __forceinline__ void map_lone_pod_wave(const MapArgs& a, const ShapeArgs& h, const LoneMasks& t, const nhdfit_req& r,
                                                   const double* __restrict__ caps, uint8_t* lds) {
     NodeState* st = carve<NodeState>(lds, 1);
@@ -40,7 +71,7 @@ __device__ __forceinline__ void map_lone_pod_wave(const MapArgs& a, const ShapeA
             __builtin_amdgcn_wave_barrier();
             const uint32_t bits = lone_nic_bits(t, r.map_type == NHDFIT_MAP_PCI, st->p3);
             const MapTables mt{h.asc, h.choose_tab, h.st};
-            map_on_state_wave(r, *st, *dd, l_caps, bits, mt, lane, mp);   // every lane: the same mapping (zeros when nothing fits)
+            map_on_state_wave_small(r, *st, *dd, l_caps, bits, mt, lane, mp);   // every lane: the same mapping (zeros when nothing fits)
         }
         if (lane == 0u && r.n_groups <= 3u) a.out[0] = mp;                // (a pod with four groups is mapped by k_map<true>, as before)
     }

@@ -1,13 +1,12 @@
-// seq2_commit_v2.h - CANDIDATE for the next GPU measurement, NOT part of libnhdfit.so yet (nothing includes it but
-// tests/harness/wave_emul.cpp and tools/probe_wave.hip).  The wavefront form of the commit step (seq2_kernel.h
+// seq2_commit_v2.h - CANDIDATE for the next GPU measurement, compiled OUT of libnhdfit.so (seq2_kernel.h includes it only under
+// -DNHDFIT_CAND_COMMIT_V2, which nhd_amd/build.py does not pass; tools/r05_candidates.sh builds and measures it).  The wavefront form of the commit step (seq2_kernel.h
 // commit_node_wave) with the request read ONCE: tools/probe_wave_isa.sh shows the shipped form fetching the request's byte
 // fields one ds_read_u8 + s_waitcnt lgkmcnt(0) at a time - five or six LDS round trips per processing group on the chain
 // of mode B's GPU-less pods.  Here every lane reads one dword of the 128-byte record, the eight dwords that hold the
 // commit's fields are broadcast with v_readlane (wave-uniform values in scalar registers), and a group's counts are
 // shifts of those words; the NIC's switch is only looked up for a group that asks for GPUs.  Same arithmetic, same
 // results: tests/test_wave_commit_emulation.py runs this text on emulated lanes against the scalar commit_node and
-// against the shipped wavefront form.  To try it on the device: include this file behind seq2_kernel.h's commit section
-// and call commit_node_wave_v2 in k_decide's speculators / workers (same signature).
+// against the shipped wavefront form.
 // Needs lowest_bits_wave / take_batch_wave / sig_keys_wave of seq2_kernel.h in front of it.
 struct ReqWords {                   // the commit's fields of a nhdfit_req, wave-uniform
     uint32_t G, map_type, np4, nh4, n_misc, smt_bits, misc_smt_enabled, nic_use;

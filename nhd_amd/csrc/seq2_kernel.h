@@ -273,6 +273,10 @@ __device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, 
     __builtin_amdgcn_wave_barrier();
     return status;
 }
+#ifdef NHDFIT_CAND_COMMIT_V2       // candidate build only (tools/r05_candidates.sh): the commit with the request read once, seq2_commit_v2.h
+#include "seq2_commit_v2.h"
+#define commit_node_wave commit_node_wave_v2
+#endif
 
 // ---- k_decide: speculate, then retire in order ------------------------------------------------------------------------------
 // Block 0 decides; blocks 1.. commit the pods with GPUs (workers).  Inside block 0:

@@ -24,11 +24,10 @@
 #     round trips with a full wait - the request's byte fields one ds_read_u8 at a time, 5-6 per processing group; map_on_state_wave:
 #     1 601 / 37) and checked without one: tests/harness/wave_emul.cpp runs the routines' SOURCE TEXT on 64 emulated lanes against the
 #     scalar forms (tests/test_wave_commit_emulation.py) - rewrite there first (request fields from a lane-distributed register through
-#     v_readlane instead of LDS bytes - nhd_amd/csrc/seq2_commit_v2.h is that for the commit, emulation-checked, NOT wired in: include it behind
-#     seq2_kernel.h's commit section, call commit_node_wave_v2 in k_decide, run the mode-B GPU tests, then tools/time_mode_b.py; the summary of a commit - free-core / GPU counts, hugepages, NIC classes - published before the
+#     v_readlane instead of LDS bytes - nhd_amd/csrc/seq2_commit_v2.h is that for the commit, emulation-checked, wired in behind -DNHDFIT_CAND_COMMIT_V2 (off: the shipped binary is bit-identical): tools/r05_candidates.sh build, then gpurun ... run; the summary of a commit - free-core / GPU counts, hugepages, NIC classes - published before the
 #     core picks so that the next pod's verification starts ~3.7 us earlier), then measure with NHDFIT_SEQ_PROF=1.
-#   * single calls (candidate, emulation-checked, NOT wired in: nhd_amd/csrc/find1_wave_map.h - k_find1's mapping tail through map_on_state_wave;
-#     its header says which line of k_find1 to replace; then tests/test_gpu_parity.py -k "single or lone or find" and tools/time_single_find.py):
+#   * single calls (candidate, emulation-checked, behind -DNHDFIT_CAND_FIND1_WAVE: nhd_amd/csrc/find1_wave_map.h - k_find1's mapping tail through
+#     map_on_state_wave; measured by the same tools/r05_candidates.sh run):
 #   * single calls: nhdfit_find one pod 26 / 28 / 35 / 33 us (4 096 / 16 384 / 65 536 nodes / c5 shard); HIP_FORCE_DEV_KERNARG=1 changes
 #     nothing; nhdfit_find with 4 096 pods 0.20 ms (host copies of 512 KB of requests on both sides of three launches).
 #   * pods beyond the table pass (5..8 processing groups, hugepage requests > 1 022 GiB): nhdfit_big_req through the general path
