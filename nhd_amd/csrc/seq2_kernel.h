@@ -19,6 +19,10 @@
 // the tiles that hold GPU-less pods and clear the bits of the pods that lost it (hints).
 // A commit that leaves a node in a NIC state without a signature id poisons the node and is reported: the host undoes the
 // batch and runs the general kernel (k_seq), whose stop / intern / resume protocol the caller knows.
+#ifdef NHDFIT_CAND_MAP_V2          // candidate build only (tools/r05_candidates.sh): the verification with the NIC walk's uniform operands read once, seq_map_v2.h
+#include "seq_map_v2.h"
+#define map_on_state_wave map_on_state_wave_v2
+#endif
 struct DecideArgs {
     SeqArgs s;
     unsigned long long* queue;   // [2 P] work items, 0 = not written yet (pre-zeroed): bit 63 valid, bit 62 kind (0 commit, 1 patch),

@@ -163,7 +163,7 @@ def wave_lib():
         return _wave
     kernel = os.path.join(HERE, "..", "..", "nhd_amd", "csrc", "seq2_kernel.h")
     kernel1 = os.path.join(HERE, "..", "..", "nhd_amd", "csrc", "seq_kernel.h")
-    deps = [WAVE_SRC, kernel, kernel1] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "seq_core.h", "commit_core.h", "winner_map.h", "set_states.h", "seq2_commit_v2.h")] + \
+    deps = [WAVE_SRC, kernel, kernel1] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "seq_core.h", "commit_core.h", "winner_map.h", "set_states.h", "seq2_commit_v2.h", "seq_map_v2.h")] + \
            [os.path.join(HERE, "..", "..", "include", "nhdfit.h")]
     if not os.path.exists(WAVE_SO) or any(os.path.getmtime(d) > os.path.getmtime(WAVE_SO) for d in deps):
         lines = open(kernel).read().split("\n")
@@ -185,7 +185,7 @@ def wave_lib():
     return _wave
 
 
-def wave_map_on_state(packer, table, i, req, tables=2, nic_bits=-1):
+def wave_map_on_state(packer, table, i, req, tables=2, nic_bits=-1, form=1):
     """seq_core.h map_on_state (scalar) and seq_kernel.h map_on_state_wave (emulated lanes) for pod `req` on node i as it stands in
     `table`: (return code of we_map_on_state, ok bits, scalar mapping, wavefront mapping).  nic_bits >= 0: the NIC-feasible
     assignments to use (find_lone's) instead of the scalar NIC walk's."""
@@ -196,7 +196,7 @@ def wave_map_on_state(packer, table, i, req, tables=2, nic_bits=-1):
     ms, mw = np.zeros((), pack.MAPPING), np.zeros((), pack.MAPPING)
     ok = ctypes.c_int(0)
     L.we_map_on_state.restype = ctypes.c_int
-    rc = L.we_map_on_state(*[_p(x) for x in rows], _p(req), _p(caps), ctypes.c_int(tables), ctypes.c_int64(int(nic_bits)), _p(ms), _p(mw), ctypes.byref(ok))
+    rc = L.we_map_on_state(*[_p(x) for x in rows], _p(req), _p(caps), ctypes.c_int(tables), ctypes.c_int64(int(nic_bits)), _p(ms), _p(mw), ctypes.byref(ok), ctypes.c_int(form))
     return int(rc), ok.value, ms, mw
 
 

@@ -54,6 +54,7 @@ inline int readlane(int v, int l) {                                  // every la
 
 namespace {
 #include "_wave_map_block.inc"       // seq_kernel.h: "wave-cooperative forms of the mapping arithmetic" (map_on_state_wave and its helpers)
+#include "../../nhd_amd/csrc/seq_map_v2.h"       // the candidate form of the verification (the NIC walk's uniform operands read once)
 #include "_wave_commit_block.inc"    // seq2_kernel.h: "the commit step with the wavefront's lanes"
 #include "../../nhd_amd/csrc/seq2_commit_v2.h"   // the candidate form (request read once, fields by v_readlane): not in libnhdfit.so yet
 
@@ -140,7 +141,7 @@ int we_commit(nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plane2* p2, nhdfit_pl
 // Returns 0 when both forms agree (ok flag; mapping when ok), 1 otherwise, -100 if the lanes disagree among themselves.
 int we_map_on_state(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3, const nhdfit_plane4* p4,
                     const nhdfit_detail* det, const nhdfit_req* req, const double* caps, int tables, int64_t nic_bits_in,
-                    nhdfit_mapping* scalar_out, nhdfit_mapping* wave_out, int* ok_out) {
+                    nhdfit_mapping* scalar_out, nhdfit_mapping* wave_out, int* ok_out, int form) {
     const NodeState st{*p0, *p1, *p2, *p3, *p4};
     const nhdfit_detail dd = *det;
     const WinnerState w = state_view(st, dd, caps);
@@ -166,7 +167,8 @@ int we_map_on_state(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdf
     for (int i = 0; i < emu::kLanes; ++i)
         lanes.emplace_back([&, i] {
             emu::t_lane = (uint32_t)i; emu::t_count = 0;
-            ok_w[i] = map_on_state_wave(*req, st, dd, caps, nic_bits, mt, (uint32_t)i, mw[i]);
+            ok_w[i] = form == 2 ? map_on_state_wave_v2(*req, st, dd, caps, nic_bits, mt, (uint32_t)i, mw[i])
+                                : map_on_state_wave(*req, st, dd, caps, nic_bits, mt, (uint32_t)i, mw[i]);
         });
     for (auto& t : lanes) t.join();
     for (int i = 1; i < emu::kLanes; ++i)

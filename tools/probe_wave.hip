@@ -5,6 +5,19 @@
 namespace {
 #include "../nhd_amd/csrc/seq2_commit_v2.h"
 #include "../nhd_amd/csrc/find1_wave_map.h"
+#include "../nhd_amd/csrc/seq_map_v2.h"
+__global__ __launch_bounds__(64) void probe_map_v2(const NodeState* s, const nhdfit_detail* d, const nhdfit_req* r, const double* caps, uint32_t bits, MapTables mt,
+                                                   nhdfit_mapping* out, int* ok) {
+    __shared__ NodeState ls; __shared__ nhdfit_detail ld; __shared__ PaddedReq lr; __shared__ double lc[NHDFIT_MAX_CLASSES];
+    const uint32_t lane = threadIdx.x;
+    if (lane == 0) { ls = *s; ld = *d; }
+    if (lane < NHDFIT_MAX_CLASSES) lc[lane] = caps[lane];
+    if (lane < sizeof(nhdfit_req) / 16) reinterpret_cast<uint4*>(&lr)[lane] = reinterpret_cast<const uint4*>(r)[lane];
+    __syncthreads();
+    nhdfit_mapping mp;
+    const bool k = map_on_state_wave_v2(reinterpret_cast<const nhdfit_req&>(lr), ls, ld, lc, bits, mt, lane, mp);
+    if (lane == 0) { *out = mp; *ok = k; }
+}
 __global__ __launch_bounds__(256) void probe_lone_map(MapArgs m, ShapeArgs h, LoneMasks t, const nhdfit_req* r, const double* caps) {
     extern __shared__ __align__(16) uint8_t lds_probe[];
     __shared__ nhdfit_req lr;
