@@ -444,7 +444,7 @@ def end_to_end(eng, reqs, now, P, n_total):
         eng.find(reqs, now, want_bitmap=False, want_map=True)
         ts.append(time.perf_counter() - t0)
     t = min(ts)
-    return {"call": "nhdfit_find (stage + H2D + 5 launches + D2H of scores and mappings)", "ms_per_call": t * 1e3,
+    return {"call": "nhdfit_find (stage + H2D + 3 launches: digest, fused step, one-launch drain + D2H of scores and mappings)", "ms_per_call": t * 1e3,
             "evals_per_s": P * n_total / t, "decisions_per_s": P / t}
 
 
