@@ -361,12 +361,12 @@ def sharded_mode_b(eng, pk, table, reqs, spec, lo, hi, cfg, total_nodes, tops, g
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ts.append(float(t.item()))
-    except BaseException as e:                               # (incl. SystemExit: never leave the other ranks waiting)
+    except (Exception, SystemExit) as e:                     # (incl. SystemExit: never leave the other ranks waiting)
         err = f"{type(e).__name__}: {e}"[:300]
     flag = torch.tensor([1 if err else 0], dtype=torch.int32)
     try:
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-    except BaseException as e:
+    except (Exception, SystemExit) as e:
         err = err or f"{type(e).__name__}: {e}"[:300]
         flag[0] = 1
     if int(flag.item()):
@@ -383,7 +383,7 @@ def sharded_mode_b(eng, pk, table, reqs, spec, lo, hi, cfg, total_nodes, tops, g
     if rank == 0:
         try:
             out["parity"] = mode_b_parity(synth.make_cluster(cfg, n_nodes=total_nodes), tops, groups, now, reqs, node, maps, places, status)
-        except BaseException as e:
+        except (Exception, SystemExit) as e:
             out["parity"] = {"identical": False, "error": f"{type(e).__name__}: {e}"[:300]}
     dist.barrier()
     return out
