@@ -1,12 +1,12 @@
-// find1_wave_map.h - CANDIDATE for the next GPU measurement, compiled OUT of libnhdfit.so (nhdfit.hip includes it only under
-// -DNHDFIT_CAND_FIND1_WAVE, which nhd_amd/build.py does not pass; tools/r05_candidates.sh builds and measures it).  The mapping tail of the one-pod launch (k_find1, step_kernel.h) on ONE wavefront whose lanes work
-// together: today the block with the last ticket runs map_one_tile<BLOCK, true> - the tile machinery with a single live
-// lane walking candidate_masks and the NIC choices one after the other, 12-20 us of the 35 us call (DESIGN.md section 4
-// "One pod, one launch").  The sequential kernels already own the wave-cooperative form of the same arithmetic
-// (seq_kernel.h map_on_state_wave: a lane per tuple code / NIC choice); for a lone pod its inputs are at hand - the winner's
-// planes and detail, the capacity classes, and the NIC-feasible assignments from the pod's own masks (fit_core.h
-// lone_nic_bits) instead of a tile image.  tests/test_wave_commit_emulation.py (test_lone_pod_winner_mapped_by_the_wavefront_form)
-// runs exactly this composition on emulated lanes against the table pass's mapping.
+// find1_wave_map.h - the mapping tail of the one-pod launch (k_find1, step_kernel.h) on ONE wavefront whose lanes work together.
+// Round 4 ran map_one_tile<BLOCK, true> there - the tile machinery with a single live lane walking candidate_masks and the NIC
+// choices one after the other, 12-20 us of the 35 us call.  The sequential kernels already own the wave-cooperative form of the
+// same arithmetic (seq_kernel.h map_on_state_wave: a lane per tuple code / NIC choice); for a lone pod its inputs are at hand - the
+// winner's planes and detail, the capacity classes, and the NIC-feasible assignments from the pod's own masks (fit_core.h
+// lone_nic_bits) instead of a tile image.  Measured in round 5's first GPU call (profiles/r05/candidates.md): per nhdfit_find call
+// with one pod 27.9 -> 24.8 us at 4 096 nodes, 30.1 -> 27.3 at 16 384, 37.1 -> 34.3 at 65 536, 35.4 -> 30.7 on the config-5 shard,
+// single-launch and lone-pod parity tests green - adopted.  tests/test_wave_commit_emulation.py
+// (test_lone_pod_winner_mapped_by_the_wavefront_form) runs exactly this composition on emulated lanes against the table pass's mapping.
 // map_on_state_wave (seq_kernel.h) for a pod of at most three groups: the same steps without the call into the generic set model
 // (four groups), whose scratch arrays would size the private segment of every k_find1 launch (10 KB per lane)
 __device__ __forceinline__ bool map_on_state_wave_small(const nhdfit_req& r, const NodeState& s, const nhdfit_detail& d, const double* caps, uint32_t nic_bits,

@@ -55,9 +55,7 @@ namespace {
 #include "step_map.h"
 #include "step_kernel.h"
 #include "seq_kernel.h"
-#ifdef NHDFIT_CAND_FIND1_WAVE
 #include "find1_wave_map.h"
-#endif
 #include "seq2_kernel.h"
 #include "wide_kernel.h"
 #include "big_kernel.h"

@@ -19,10 +19,6 @@
 // the tiles that hold GPU-less pods and clear the bits of the pods that lost it (hints).
 // A commit that leaves a node in a NIC state without a signature id poisons the node and is reported: the host undoes the
 // batch and runs the general kernel (k_seq), whose stop / intern / resume protocol the caller knows.
-#ifdef NHDFIT_CAND_MAP_V2          // candidate build only (tools/r05_candidates.sh): the verification with the NIC walk's uniform operands read once, seq_map_v2.h
-#include "seq_map_v2.h"
-#define map_on_state_wave map_on_state_wave_v2
-#endif
 struct DecideArgs {
     SeqArgs s;
     unsigned long long* queue;   // [2 P] work items, 0 = not written yet (pre-zeroed): bit 63 valid, bit 62 kind (0 commit, 1 patch),
@@ -277,10 +273,6 @@ __device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, 
     __builtin_amdgcn_wave_barrier();
     return status;
 }
-#ifdef NHDFIT_CAND_COMMIT_V2       // candidate build only (tools/r05_candidates.sh): the commit with the request read once, seq2_commit_v2.h
-#include "seq2_commit_v2.h"
-#define commit_node_wave commit_node_wave_v2
-#endif
 
 // ---- k_decide: speculate, then retire in order ------------------------------------------------------------------------------
 // Block 0 decides; blocks 1.. commit the pods with GPUs (workers).  Inside block 0:

@@ -323,10 +323,8 @@ constexpr size_t kLoneLds = lds_slice(sizeof(nhdfit_req)) + lds_slice(sizeof(Pod
                             lds_slice(NHDFIT_MAX_CLASSES * (kMaxG + 1) * sizeof(uint16_t)) + 2 * lds_slice(kLoneGpuDim * sizeof(uint16_t)) +
                             2 * lds_slice(2 * kLoneCoreDim * 2 * sizeof(uint16_t)) + lds_slice(kDictLdsWords * sizeof(uint16_t)) +
                             2 * lds_slice(kLoneMaxSigs * sizeof(uint16_t)) + lds_slice(8 * sizeof(unsigned long long));
-#ifdef NHDFIT_CAND_FIND1_WAVE
 __device__ __forceinline__ void map_lone_pod_wave(const MapArgs& a, const ShapeArgs& h, const LoneMasks& t, const nhdfit_req& r,
                                                   const double* __restrict__ caps, uint8_t* lds);      // find1_wave_map.h, behind seq_kernel.h
-#endif
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_find1(Find1Args a) {
     extern __shared__ __align__(16) uint8_t lds_all[];
@@ -430,11 +428,9 @@ __global__ __launch_bounds__(BLOCK) void k_find1(Find1Args a) {
         const unsigned long long t2 = a.role_clock ? (unsigned long long)wall_clock64() : 0ull;
         MapArgs m = a.m;
         m.reqs = s_req;                                                   // the request is in this block's LDS already: no second read of the host block
-#ifdef NHDFIT_CAND_FIND1_WAVE      // candidate build only (tools/r05_candidates.sh): one wavefront, the lanes working together, find1_wave_map.h
+        // one wavefront, the lanes working together (find1_wave_map.h; round 5: -3 us per call against the tile machinery with one
+        // live lane, profiles/r05/candidates.md); stores the mapping into the host block
         map_lone_pod_wave(m, a.h, t, *s_req, a.d.caps, lds_map);
-#else
-        map_one_tile<BLOCK, true>(m, a.h, 0, lds_map, &t);                // (stores the mapping into the host block)
-#endif
         stamp(a.role_clock, 2, t2);
     }
     if (tid == 0) a.host->score[0] = __hip_atomic_load(a.m.score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -163,7 +163,7 @@ def wave_lib():
         return _wave
     kernel = os.path.join(HERE, "..", "..", "nhd_amd", "csrc", "seq2_kernel.h")
     kernel1 = os.path.join(HERE, "..", "..", "nhd_amd", "csrc", "seq_kernel.h")
-    deps = [WAVE_SRC, kernel, kernel1] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "seq_core.h", "commit_core.h", "winner_map.h", "set_states.h", "seq2_commit_v2.h", "seq_map_v2.h")] + \
+    deps = [WAVE_SRC, kernel, kernel1] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "seq_core.h", "commit_core.h", "winner_map.h", "set_states.h")] + \
            [os.path.join(HERE, "..", "..", "include", "nhdfit.h")]
     if not os.path.exists(WAVE_SO) or any(os.path.getmtime(d) > os.path.getmtime(WAVE_SO) for d in deps):
         lines = open(kernel).read().split("\n")

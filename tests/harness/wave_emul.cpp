@@ -54,9 +54,7 @@ inline int readlane(int v, int l) {                                  // every la
 
 namespace {
 #include "_wave_map_block.inc"       // seq_kernel.h: "wave-cooperative forms of the mapping arithmetic" (map_on_state_wave and its helpers)
-#include "../../nhd_amd/csrc/seq_map_v2.h"       // the candidate form of the verification (the NIC walk's uniform operands read once)
 #include "_wave_commit_block.inc"    // seq2_kernel.h: "the commit step with the wavefront's lanes"
-#include "../../nhd_amd/csrc/seq2_commit_v2.h"   // the candidate form (request read once, fields by v_readlane): not in libnhdfit.so yet
 
 // the mapping tables as the device builds them (k_build_asc / k_build_choose / the set-layout state machine)
 const AscEntry* asc_table() {
@@ -123,8 +121,7 @@ int we_commit(nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plane2* p2, nhdfit_pl
     for (int i = 0; i < emu::kLanes; ++i)
         lanes.emplace_back([&, i] {
             emu::t_lane = (uint32_t)i; emu::t_count = 0;
-            status[i] = form == 2 ? commit_node_wave_v2(st, dd, *req, *map, busy_time, sigs, ncls, pl, (uint32_t)i)
-                                  : commit_node_wave(st, dd, *req, *map, busy_time, sigs, ncls, pl, (uint32_t)i);
+            status[i] = commit_node_wave(st, dd, *req, *map, busy_time, sigs, ncls, pl, (uint32_t)i);
         });
     for (auto& t : lanes) t.join();
     for (int i = 1; i < emu::kLanes; ++i) if (status[i] != status[0]) return -100;
@@ -167,8 +164,7 @@ int we_map_on_state(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdf
     for (int i = 0; i < emu::kLanes; ++i)
         lanes.emplace_back([&, i] {
             emu::t_lane = (uint32_t)i; emu::t_count = 0;
-            ok_w[i] = form == 2 ? map_on_state_wave_v2(*req, st, dd, caps, nic_bits, mt, (uint32_t)i, mw[i])
-                                : map_on_state_wave(*req, st, dd, caps, nic_bits, mt, (uint32_t)i, mw[i]);
+            ok_w[i] = map_on_state_wave(*req, st, dd, caps, nic_bits, mt, (uint32_t)i, mw[i]);
         });
     for (auto& t : lanes) t.join();
     for (int i = 1; i < emu::kLanes; ++i)

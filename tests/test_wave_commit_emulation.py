@@ -25,9 +25,6 @@ def _both(pk, table, i, req, mp, bt):
     assert sa == sb, (sa, sb)
     assert pa.tobytes() == pb.tobytes(), (pa, pb)
     assert _rows(ta, i) == _rows(tb, i)
-    tc = copy.deepcopy(table)                                  # the candidate form (seq2_commit_v2.h: the request read once)
-    sc, pc = harness.wave_commit(pk, tc, i, req, mp, bt, form=2)
-    assert sc == sa and pc.tobytes() == pa.tobytes() and _rows(tc, i) == _rows(ta, i), ("v2", sa, sc, pa, pc)
     return sa, ta
 
 
@@ -113,8 +110,6 @@ def test_wavefront_mapping_equals_the_scalar_mapping(seed):
             for tables in (0, 1, 2):
                 rc, ok, ms, mw = harness.wave_map_on_state(pk, table, i, reqs[p], tables)
                 assert rc == 0, (rc, ok, i, specs[p], ms, mw, tables)
-            rc2, ok2, _, mw2 = harness.wave_map_on_state(pk, table, i, reqs[p], 2, form=2)      # the candidate form (seq_map_v2.h)
-            assert rc2 == 0 and ok2 == ok and mw2.tobytes() == mw.tobytes(), ("v2", rc2, ok2, ok, specs[p])
             pairs += 1
             mapped += ok == 3
     assert pairs >= 100 and mapped >= 5
