@@ -379,53 +379,63 @@ NHD_HD uint32_t xkey_sig_numa(uint64_t k) { return (uint32_t)(k >> 16) & 0xFFFFu
 NHD_HD uint32_t xkey_sig_pci(uint64_t k) { return (uint32_t)k & 0xFFFFu; }
 
 // The 16-byte node record the fit role streams (one array per row width W): hot-section offsets in units of
-// 8 bytes, so that a node costs two loads (record + busy time) and one shift per row address.  The last two fields carry
-// the same facts unscaled (free cores per socket, SMT, class ids): the pair form of the sweep (below) indexes tables it
-// derives in LDS with them.
+// 8 bytes, so that a node costs two loads (record + busy time) and one shift per row address.  The last field carries
+// the free cores per socket and the SMT flag unscaled: the pair form of the sweep (below) indexes the table it derives in LDS
+// with them.
+// LANE ORDER (round 5).  The 64 records of a chunk need not sit in node order: the verdict word is stored by node index and a
+// winner carries its index, so which lane of the wavefront works on which node of the chunk is free - and it decides how the
+// lanes' row fetches meet in the LDS banks (chunk_lane_order below).  A record therefore names its node's position in the
+// chunk (`pos`, the top six bits of `hp`); position = lane is the order k_xrecords writes and every consumer accepts.
 struct alignas(16) NodeRec {
     uint16_t w0, w1, x0, x1;          // WC records of socket 0 / 1, X rows of NUMA 0 / 1   (offset / 8)
     uint16_t gx;                      // GX row (offset / 8)
-    uint16_t hp;                      // HP row INDEX (clamped to the batch's rows in the kernel)
-    uint16_t flags;                   // kRecNoGpu | (X class of NUMA 0 & 63) << 4 | (X class of NUMA 1 & 63) << 10
+    uint16_t hp;                      // bits 0..9: HP row INDEX (clamped to the batch's rows in the kernel); bits 10..15: the node's position in its chunk
+    uint16_t flags;                   // kRecNoGpu
     uint16_t cc;                      // free physical cores socket 0 | socket 1 << 7 | SMT << 14
 };
 static_assert(sizeof(NodeRec) == 16, "one 16-byte load per node");
+static_assert(kMaxHpRows <= 1024, "NodeRec::hp keeps ten bits for the row index");
 constexpr uint16_t kRecNoGpu = 1;
-constexpr uint32_t kPairMaxXCap = 64;  // class ids the record's six-bit fields can name
+NHD_HD uint32_t rec_hp(const NodeRec& r) { return r.hp & 1023u; }
+NHD_HD uint32_t rec_pos(const NodeRec& r) { return r.hp >> 10; }
 
-NHD_HD NodeRec make_record(const NodeIdx& n, uint32_t x0, uint32_t x1, const Layout& L) {
+NHD_HD NodeRec make_record(const NodeIdx& n, uint32_t x0, uint32_t x1, const Layout& L, uint32_t pos) {
     NodeRec r;
     r.w0 = (uint16_t)((L.hot_wc0 + n.w0 * L.wc_stride) >> 3);
     r.w1 = (uint16_t)((L.hot_wc1 + n.w1 * L.wc_stride) >> 3);
     r.x0 = (uint16_t)((L.hot_x + x0 * L.x_stride) >> 3);
     r.x1 = (uint16_t)((L.hot_x + x1 * L.x_stride) >> 3);
     r.gx = (uint16_t)((L.hot_gx + n.gx * 8) >> 3);
-    r.hp = (uint16_t)n.hp;
-    r.flags = (uint16_t)((n.nogpu ? kRecNoGpu : 0) | (x0 & 63u) << 4 | (x1 & 63u) << 10);
+    r.hp = (uint16_t)(n.hp | (pos & 63u) << 10);
+    r.flags = (uint16_t)(n.nogpu ? kRecNoGpu : 0);
     const uint32_t smt = n.w0 >= L.fc_dim ? 1u : 0u;                       // node_index: w = smt * fc_dim + free cores
     r.cc = (uint16_t)((n.w0 - smt * L.fc_dim) | (n.w1 - smt * L.fc_dim) << 7 | smt << 14);
     return r;
 }
-NHD_HD NodeRec dead_record(const Layout& L) {                    // lanes past the end of the mirror: GX row 0 = never
+NHD_HD NodeRec dead_record(const Layout& L, uint32_t pos) {      // lanes past the end of the mirror: GX row 0 = never
     NodeRec r;
     r.w0 = (uint16_t)(L.hot_wc0 >> 3); r.w1 = (uint16_t)(L.hot_wc1 >> 3);
     r.x0 = r.x1 = (uint16_t)(L.hot_x >> 3);
     r.gx = (uint16_t)(L.hot_gx >> 3);
-    r.hp = 0; r.flags = 0; r.cc = 0;
+    r.hp = (uint16_t)((pos & 63u) << 10); r.flags = 0; r.cc = 0;
     return r;
 }
 
 // ---- pair rows ---------------------------------------------------------------------------------------------------------
 // The sweep of a node fetches, per pair of assignments, four CPU rows (both sockets, m = 0 / 1) and two class rows.  What
-// it ANDs them into depends on the node through (SMT, free cores 0, free cores 1) and (class 0, class 1) only, so a fit
-// block can tabulate both products once, in LDS, when it stages the tile:
+// the CPU rows are ANDed into depends on the node through (SMT, free cores 0, free cores 1) only, so a fit block can tabulate
+// the product once, in LDS, when it stages the tile:
 //     C[smt][c0][c1]  = (WC0[smt][c0].m1 & WC1[smt][c1].m0) | (WC0[smt][c0].m0 & WC1[smt][c1].m1)         one fetch for four
-//     XX[k0][k1]      = X[k0] & X[k1]                                                                        one fetch for two
 // C would be 2 x 65 x 65 rows over all free-core counts; but a CPU row only says "demand <= c", so every row at or above
 // the tile's largest demand (all groups on one socket plus the misc cores, the larger of the SMT / non-SMT counts) is the
 // same row: with D = 1 + that demand, counts are clamped to D - 1 and the table is 2 x D x D rows (two-group tiles of
-// BASELINE config 4: D = 24, 37 KB).  XX is x_cap x x_cap rows and only built while that is small.  The launch decides per
-// row width whether the tables fit its LDS budget (nhdfit.hip refresh_layouts); the verdicts are the same bits either way
+// BASELINE config 4: D = 24, 37 KB).  The table is stored as W / 2 PLANES of 16-byte pieces, piece q of row r at
+// (q * rows + r) * 16 (round 5): rows of W * 8 = 32 bytes put two neighbouring rows' pieces 32 bytes apart - the 16 lanes a
+// ds_read_b128 is serviced for then share 8 of the 16 bank groups and every fetch of a four-assignment tile cost twice its
+// cycles (16.3 LDS cycles per wavefront fetch against 8.2 on config 4's cluster, tools/lds_bank_model.py).  (A table of the
+// products of two class rows, XX[k0][k1], was built and measured in round 4 and is gone: its row index put 32 rows on one
+// bank group - 13.6 cycles per fetch against 4 + 4 for the two class rows it replaced.)  The launch decides per
+// row width whether the table fits its LDS budget (nhdfit.hip refresh_layouts); the verdicts are the same bits either way
 // (host twin: node_word_pair == node_word_hot on every node of every CPU test).
 NHD_HD uint32_t req_max_demand(const nhdfit_req& r) {
     uint32_t a = r.misc_smt, b = r.misc_nosmt;
@@ -462,26 +472,25 @@ NHD_HD uint64_t node_word_hot(const uint8_t* hot, const Layout& L, const NodeRec
         const uint64_t cpu = (ld64(hot, w0 + L.row + o) & ld64(hot, w1 + o)) | (ld64(hot, w0 + o) & ld64(hot, w1 + L.row + o));
         acc |= cpu & ld64(hot, x0 + o) & ld64(hot, x1 + o);
     }
-    const uint32_t hp = r.hp < L.hp_rows ? r.hp : L.hp_rows - 1;
+    const uint32_t hp = rec_hp(r) < L.hp_rows ? rec_hp(r) : L.hp_rows - 1;
     uint64_t pred = ld64(hot, (uint32_t)r.gx << 3) & ld64(hot, L.hot_hp + hp * 8);
     if (busy) pred &= ~m_need;                                           // Matcher.py:107-111
     return acc & pred;
 }
 
-// The pair form of the same verdict (what the fit role computes when its block tabulated C, and XX when `xx_cap`): the rows
-// are derived here on the fly from the hot section, addressed through the record's unscaled fields exactly as the kernel does.
-NHD_HD uint64_t node_word_pair(const uint8_t* hot, const Layout& L, const NodeRec& r, uint32_t D, uint32_t xx_cap, bool busy, uint64_t m_need) {
+// The pair form of the same verdict (what the fit role computes when its block tabulated C): the row is derived here on the
+// fly from the hot section, addressed through the record's unscaled fields exactly as the kernel does.
+NHD_HD uint64_t node_word_pair(const uint8_t* hot, const Layout& L, const NodeRec& r, uint32_t D, bool busy, uint64_t m_need) {
     const uint32_t row = pair_c_row(r.cc, D), smt = r.cc >> 14, c0 = (row / D) % D, c1 = row % D;
     const uint32_t w0 = L.hot_wc0 + (smt * L.fc_dim + c0) * L.wc_stride, w1 = L.hot_wc1 + (smt * L.fc_dim + c1) * L.wc_stride;
-    const uint32_t x0 = xx_cap ? L.hot_x + ((r.flags >> 4) & 63u) * L.x_stride : (uint32_t)r.x0 << 3;
-    const uint32_t x1 = xx_cap ? L.hot_x + ((r.flags >> 10) & 63u) * L.x_stride : (uint32_t)r.x1 << 3;
+    const uint32_t x0 = (uint32_t)r.x0 << 3, x1 = (uint32_t)r.x1 << 3;
     uint64_t acc = 0;
     for (uint32_t p = 0; p < L.W; ++p) {
         const uint32_t o = p * 8;
         const uint64_t cpu = (ld64(hot, w0 + L.row + o) & ld64(hot, w1 + o)) | (ld64(hot, w0 + o) & ld64(hot, w1 + L.row + o));
         acc |= cpu & ld64(hot, x0 + o) & ld64(hot, x1 + o);
     }
-    const uint32_t hp = r.hp < L.hp_rows ? r.hp : L.hp_rows - 1;
+    const uint32_t hp = rec_hp(r) < L.hp_rows ? rec_hp(r) : L.hp_rows - 1;
     uint64_t pred = ld64(hot, (uint32_t)r.gx << 3) & ld64(hot, L.hot_hp + hp * 8);
     if (busy) pred &= ~m_need;
     return acc & pred;

@@ -199,12 +199,10 @@ struct nhdfit_ctx {
     uint32_t n_big_pods = 0;      // staged pods with more than 3 proc groups
     uint32_t max_wcls = 0;        // widest tile class of the staged batch
     // pair form of the fit role's sweep (fit_core.h "pair rows"): per row width W = 2 / 4 the largest CPU demand among the staged
-    // tiles of that width, and what refresh_layouts makes of it - table dimension D (0: off) and XX dimension (0: off)
+    // tiles of that width, and what refresh_layouts makes of it - table dimension D (0: off)
     uint32_t max_demand[2] = {0, 0};
-    uint32_t pair_D[2] = {0, 0}, pair_xx[2] = {0, 0};
-    bool pair_rows = !(tune_env("NHDFIT_PAIR") && atoi(tune_env("NHDFIT_PAIR")) == 0);   // tuning aid: NHDFIT_PAIR=0 keeps the six-fetch sweep; 2 = C and XX
-    bool pair_xx_ok = tune_env("NHDFIT_PAIR") && atoi(tune_env("NHDFIT_PAIR")) == 2;   // XX is built and measured (15.64 us per step against 15.52 with C alone:
-                                                                                             // its 1 024-row derivation per block costs what the saved fetch gives) - off; NHDFIT_PAIR=2 in the tuning build
+    uint32_t pair_D[2] = {0, 0};
+    bool pair_rows = !(tune_env("NHDFIT_PAIR") && atoi(tune_env("NHDFIT_PAIR")) == 0);   // tuning aid: NHDFIT_PAIR=0 keeps the six-fetch sweep
 
     // requests / results
     DevBuf<nhdfit_req> reqs; uint32_t P = 0;
@@ -222,6 +220,11 @@ struct nhdfit_ctx {
     // node records (fit_core.h NodeRec) + the class table behind their X rows; [rec_lo, rec_hi) = nodes whose records
     // are stale (uploads, commits), rec_all = every record (dictionary / capacity / node count changed)
     DevBuf<NodeRec> rec[kWClasses];
+    DevBuf<double> rec_bt[kWClasses];    // busy times beside the records, in the records' (lane) order
+    // lane order of the chunks' records (step_kernel.h k_xorder): built for the pair-table dimensions order_D; ord_all = every chunk is
+    // (re)dealt at the next step (a staged batch changed a dimension); chunks k_xrecords rewrites are dealt right behind it
+    bool lane_order = !(tune_env("NHDFIT_LANE_ORDER") && atoi(tune_env("NHDFIT_LANE_ORDER")) == 0);   // tuning aid: NHDFIT_LANE_ORDER=0 keeps node order
+    uint32_t order_D[2] = {~0u, ~0u}; bool ord_all = false;
     DevBuf<unsigned long long> xkeys; DevBuf<uint32_t> xids; DevBuf<uint64_t> xcls; DevBuf<uint32_t> xnx;
     uint32_t rec_lo = 0, rec_hi = 0; bool rec_all = true;
     uint32_t nx = 0, x_cap = kMinXCap;   // interned classes (as of the last record update) / provisioned X rows
@@ -576,6 +579,7 @@ int nhdfit_reserve_nodes(nhdfit_ctx* c, uint32_t capacity, uint64_t global_base)
         HIPCHK(c, c->p3.reserve(padded)); HIPCHK(c, c->p4.reserve(padded)); HIPCHK(c, c->det.reserve(capacity));
         HIPCHK(c, c->origin.reserve(capacity)); c->origin_hi = 0;
         for (auto& r : c->rec) HIPCHK(c, r.reserve(padded));
+        for (auto& r : c->rec_bt) HIPCHK(c, r.reserve(padded));
         HIPCHK(c, hipMemset(c->p4.p, 0, padded * sizeof(nhdfit_plane4)));   // busy times of the padding lanes: any finite value
         c->capacity = capacity;
     }
@@ -654,10 +658,10 @@ int refresh_layouts(nhdfit_ctx* c) {
         c->hot_staged[w] = staged;
         if (w <= c->max_wcls) lds = std::max(lds, staged < L.hot_bytes ? staged + hp_bytes : L.hot_bytes);
     }
-    // Pair tables of the narrow tiles (fit_core.h "pair rows"), derived by every fit block behind its winner scratch: taken
+    // Pair table of the narrow tiles (fit_core.h "pair rows"), derived by every fit block behind its winner scratch: taken
     // while a block's LDS stays within a third of the CU's (three 512-thread blocks per CU is what the registers allow, and
-    // the launch's dynamic LDS is one size for all of its blocks).  C first, XX if it still fits.
-    c->pair_D[0] = c->pair_D[1] = c->pair_xx[0] = c->pair_xx[1] = 0;
+    // the launch's dynamic LDS is one size for all of its blocks).
+    c->pair_D[0] = c->pair_D[1] = 0;
     if (c->pair_rows && !spill) {
         const uint32_t budget = (uint32_t)(kLdsPerCu / 3) & ~1023u;
         for (uint32_t w = 0; w < 2 && w <= c->max_wcls; ++w) {
@@ -666,10 +670,7 @@ int refresh_layouts(nhdfit_ctx* c) {
             const uint32_t base = (uint32_t)lds_slice(L.hot_bytes) + scratch, c_bytes = 2 * D * D * L.row;
             if (base + c_bytes > budget) continue;
             c->pair_D[w] = D;
-            uint32_t need = base + c_bytes;
-            const uint32_t xx_bytes = c->x_cap * c->x_cap * L.row;
-            if (c->pair_xx_ok && c->x_cap <= kPairMaxXCap && need + xx_bytes <= budget) { c->pair_xx[w] = c->x_cap; need += xx_bytes; }
-            lds = std::max(lds, need - scratch);
+            lds = std::max(lds, base + c_bytes - scratch);
         }
     }
     c->pitch = pitch;
@@ -758,7 +759,11 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     c->hp_rows = (uint32_t)hp_max + 2;
     c->n_items = 0;                                 // the fit role's work items are rebuilt at the next step
     c->use_cand = false;
-    return refresh_layouts(c);
+    { int rc_ = refresh_layouts(c); if (rc_) return rc_; }
+    // a node's C row depends on the pair table's dimension: a batch that changes it has the chunks' records dealt to the lanes again
+    // (ensure_records, in front of the batch's first step) - a full tile and more only: smaller batches are latency, not throughput
+    if (P > (uint32_t)kTile && (c->pair_D[0] != c->order_D[0] || c->pair_D[1] != c->order_D[1])) c->ord_all = true;
+    return NHDFIT_OK;
 }
 
 static int stage_cand(nhdfit_ctx* c, const uint64_t* cand) {
@@ -772,16 +777,45 @@ static int stage_cand(nhdfit_ctx* c, const uint64_t* cand) {
 
 namespace {
 
+// `every`: all chunks, for the pair-table dimensions of the staged batch (they become order_D); otherwise the chunks k_xrecords just
+// rewrote, for the dimensions the others were dealt for
+int order_chunks(nhdfit_ctx* c, uint32_t first_chunk, uint32_t n_chunks, bool every) {
+    if (every) { c->order_D[0] = c->pair_D[0]; c->order_D[1] = c->pair_D[1]; }
+    if (!n_chunks) return NHDFIT_OK;
+    OrderArgs o;
+    memset(&o, 0, sizeof o);
+    for (int w = 0; w < kWClasses; ++w) { o.rec[w] = c->rec[w].p; o.bt[w] = c->rec_bt[w].p; }
+    o.first_chunk = first_chunk; o.n_chunks = n_chunks;
+    o.pair_D[0] = c->order_D[0] == ~0u ? 0u : c->order_D[0]; o.pair_D[1] = c->order_D[1] == ~0u ? 0u : c->order_D[1];
+    hipLaunchKernelGGL(k_xorder, dim3((n_chunks * (uint32_t)kWClasses + 3) / 4), dim3(256), 0, c->stream, o);
+    HIPCHK(c, hipGetLastError());
+    return NHDFIT_OK;
+}
+
 // Bring the node records (and the class table behind their X rows) up to date with the mirror.  Cheap no-op when
 // nothing changed; otherwise three small kernels over the touched nodes and one 8-byte read-back (the host sizes the
 // tile images by the class count).  A grown class count or a changed dictionary re-does every record.
 int ensure_records(nhdfit_ctx* c) {
-    if (!c->rec_all && c->rec_lo == c->rec_hi) return NHDFIT_OK;
+    const uint32_t all_chunks = (c->n + 63) / 64;
+    // dealing the records to the lanes pays where the fit role is more than a launch: from 128 chunks on
+    const bool deal = c->lane_order && all_chunks >= 128;
+    if (!c->rec_all && c->rec_lo == c->rec_hi) {
+        if (c->ord_all && c->n) {                               // the records stand, a staged batch changed the pair table's dimension
+            { int rc_ = sync_all(c); if (rc_) return rc_; }     // (steps in flight read the records)
+            c->staged_gen++;
+            if (deal) { int rc_ = order_chunks(c, 0, all_chunks, true); if (rc_) return rc_; }
+        }
+        c->ord_all = false;
+        return NHDFIT_OK;
+    }
     c->staged_gen++;                                            // (its kernels run on pipe 0's stream)
-    if (!c->n) { c->rec_all = false; c->rec_lo = c->rec_hi = 0; return NHDFIT_OK; }
+    if (!c->n) { c->rec_all = false; c->rec_lo = c->rec_hi = 0; c->ord_all = false; return NHDFIT_OK; }
     const uint32_t npad = (c->n + 63) & ~63u;
+    uint32_t dealt_first = 0, dealt_count = 0;
     for (int pass = 0; pass < 2; ++pass) {
-        const uint32_t first = c->rec_all ? 0 : c->rec_lo, count = c->rec_all ? npad : c->rec_hi - c->rec_lo;
+        // whole chunks: k_xrecords writes the records in node order (whatever order the chunk's lanes had before)
+        const uint32_t first = c->rec_all ? 0 : c->rec_lo & ~63u, count = c->rec_all ? npad : std::min(npad, (c->rec_hi + 63u) & ~63u) - first;
+        dealt_first = first / 64; dealt_count = count / 64;
         RecArgs r;
         memset(&r, 0, sizeof r);
         r.p0 = c->p0.p; r.p1 = c->p1.p; r.p2 = c->p2.p; r.p3 = c->p3.p; r.p4 = c->p4.p;
@@ -792,6 +826,7 @@ int ensure_records(nhdfit_ctx* c) {
             // records hold hot-section offsets: they depend on the dictionary and the provisioned X rows, not on the batch
             r.L[w] = make_layout(2u << w, c->max_cores, c->max_gpus, c->nsig, c->ngs, 2, c->x_cap);
             r.rec[w] = c->rec[w].p;
+            r.bt[w] = c->rec_bt[w].p;
         }
         const dim3 grid((count + 255) / 256), block(256);
         if (pass == 0) {
@@ -831,6 +866,13 @@ int ensure_records(nhdfit_ctx* c) {
         int rc = refresh_layouts(c);
         if (rc) return rc;
     }
+    if (deal) {
+        // a few rewritten chunks (the scheduler's loop: one commit, then the next find) stay in node order until the next full deal -
+        // a launch of its own in front of a 60 us call costs more than their bank conflicts
+        const bool every = c->ord_all || c->rec_all;
+        if (every || dealt_count >= 16) { int rc_ = order_chunks(c, every ? 0 : dealt_first, every ? all_chunks : dealt_count, every); if (rc_) return rc_; }
+    }
+    c->ord_all = false;
     c->rec_all = false;
     c->rec_lo = c->rec_hi = 0;
     return NHDFIT_OK;
@@ -928,15 +970,14 @@ void fill_digest_args(nhdfit_ctx* c, Pipe& p, int b, uint32_t wc_parts, uint32_t
 }
 void fill_fit_args(nhdfit_ctx* c, Pipe& p, int bf, double now, FitArgs& f, bool pair = false) {
     for (int w = 0; w < 2; ++w) {
-        f.pair_D[w] = pair ? c->pair_D[w] : 0u; f.pair_xx[w] = pair ? c->pair_xx[w] : 0u;
-        f.hot_wc1[w] = c->L[w].hot_wc1; f.hot_x[w] = c->L[w].hot_x;
+        f.pair_D[w] = pair ? c->pair_D[w] : 0u;
+        f.hot_wc1[w] = c->L[w].hot_wc1;
     }
     f.fc_dim = c->max_cores + 1;
     for (int w = 0; w < kWClasses; ++w) {
-        f.rec[w] = c->rec[w].p; f.off_hot[w] = c->L[w].off_hot; f.hot_bytes[w] = c->L[w].hot_bytes; f.hot_hp[w] = c->L[w].hot_hp; f.hot_staged[w] = c->hot_staged[w];
+        f.rec[w] = c->rec[w].p; f.bt[w] = c->rec_bt[w].p; f.off_hot[w] = c->L[w].off_hot; f.hot_bytes[w] = c->L[w].hot_bytes; f.hot_hp[w] = c->L[w].hot_hp; f.hot_staged[w] = c->hot_staged[w];
     }
     f.hp_last = c->hp_rows - 1; f.hp_bytes = align16(c->hp_rows * 8);
-    f.p4 = c->p4.p;
     f.n = c->n; f.chunks = (c->n + 63) / 64; f.global_base = c->global_base; f.busy_from = busy_threshold(now);
     f.tabs = p.tabs[bf].p; f.pitch = c->pitch; f.hdr = p.hdr[bf].p; f.P = c->P;
     f.cand = c->use_cand ? c->cand.p : nullptr;
@@ -1909,8 +1950,8 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
                     ctl[1] ? ctl[1] - 1 : 0, ctl[4], ctl[5], ctl[6], ctl[7], ctl[8], ctl[14], ctl[15]);
             fprintf(stderr, "[nhdfit] k_decide sequencer: waiting for fetchers %.2f ms, pods with GPUs %.2f ms, GPU-less pods: waiting for their speculators %.2f ms, "
                             "validation %.2f ms\n", ctl[9] * 1e-5, ctl[10] * 1e-5, ctl[11] * 1e-5, ctl[12] * 1e-5);
-            fprintf(stderr, "[nhdfit] k_decide speculators (%d, summed): set-up %.2f ms, node state %.2f ms, verification %.2f ms, commit %.2f ms, waiting (sequencer, earlier pods) %.2f ms, "
-                            "publication %.2f ms\n", kSpecWaves, ctl[16] * 1e-5, ctl[17] * 1e-5, ctl[18] * 1e-5, ctl[19] * 1e-5, ctl[20] * 1e-5, ctl[21] * 1e-5);
+            fprintf(stderr, "[nhdfit] k_decide speculators (%d, summed): set-up %.2f ms, node state %.2f ms, verification %.2f ms, commit stage 1 %.2f ms, waiting (sequencer, earlier pods) %.2f ms, "
+                            "commit stage 2 %.2f ms, publication %.2f ms\n", kSpecWaves, ctl[16] * 1e-5, ctl[17] * 1e-5, ctl[18] * 1e-5, ctl[19] * 1e-5, ctl[20] * 1e-5, ctl[22] * 1e-5, ctl[21] * 1e-5);
         }
         if (flags[1] || flags[3]) {
             // a NIC state without a signature id (or a wait that ran out): start over with the kernel whose stop / intern /

@@ -105,6 +105,25 @@ __device__ __forceinline__ void store_node_lds(const SeqArgs& a, uint32_t v, con
     }
 }
 
+// a speculator's publication (two-stage commit): every plane but thread 1's whole; thread 1 loses the bits stage 2 found - an AND,
+// because the copy in LDS holds a superset of them and the stage 2 of a later pod on the same node may already have cleared its own
+__device__ __forceinline__ void store_node_lds_chain(const SeqArgs& a, uint32_t v, const NodeState* st_in, const nhdfit_detail* det_in, uint32_t lane,
+                                                     uint64_t clear0, uint64_t clear1) {
+    const uint32_t* st = reinterpret_cast<const uint32_t*>(st_in);
+    if (lane < 5 && lane != 1) {
+        const uint4 q = make_uint4(st[lane * 4], st[lane * 4 + 1], st[lane * 4 + 2], st[lane * 4 + 3]);
+        if (lane == 0) *reinterpret_cast<uint4*>(a.p0 + v) = q;
+        else if (lane == 2) *reinterpret_cast<uint4*>(a.p2 + v) = q;
+        else if (lane == 3) *reinterpret_cast<uint4*>(a.p3 + v) = q;
+        else *reinterpret_cast<uint4*>(a.p4 + v) = q;
+    }
+    if (lane == 1 && clear0) atomicAnd(reinterpret_cast<unsigned long long*>(&a.p1[v].t1[0]), ~(unsigned long long)clear0);
+    if (lane == 5 && clear1) atomicAnd(reinterpret_cast<unsigned long long*>(&a.p1[v].t1[1]), ~(unsigned long long)clear1);
+    if (lane >= 8 && lane < 16) {
+        const uint32_t* dd = reinterpret_cast<const uint32_t*>(det_in) + (lane - 8) * 4;
+        reinterpret_cast<uint4*>(a.det + v)[lane - 8] = make_uint4(dd[0], dd[1], dd[2], dd[3]);
+    }
+}
 
 // the committed node against the tiles that hold pods without GPUs: sixteen lanes per (node, tile) evaluate the W assignment
 // words, OR them together and clear the node's bit in the rows of the pods that lost it (hints for the pods to come)
@@ -274,6 +293,112 @@ __device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, 
     return status;
 }
 
+// The commit of a pod WITHOUT GPUs in two stages (round 5).  Consecutive GPU-less pods pile onto the same node, so
+// pod k + 1's verification waits for pod k's commit - and what it needs of it is little: the free-core COUNTS, hugepages, the NIC
+// classes and the signature ids.  A batch of cores takes the lowest free bits of its socket, batch after batch, so the socket's free
+// set after ALL of a pod's batches is the free set minus its lowest N bits, N = the sum of what the batches take - one ballot per
+// socket instead of one to three per batch.  Stage 1 (commit_summary_wave, on the chain) does that, the scalar writes, the NIC
+// claims and the signature ids, and leaves thread 1's bitmap alone: the sibling bits of cores handed out in pairs (or by the run-on
+// walk, quirk Q1) are cleared by stage 2 - until then the copy holds a SUPERSET of thread 1's final bits, all of them inside the N
+// bits just cleared in thread 0, so `t0 & t1` (the only form the verification and every later pick read the bitmaps in) is exact.
+// Stage 2 (commit_picks_wave, off the chain) walks the batches on the socket's free sets as they were BEFORE the pod - the placement
+// record's masks - and returns the thread-1 bits to clear; the caller ANDs them into the mirror (commutative: later pods' stage 2
+// may overtake).  Together: commit_node_wave's state, record and status (tests/harness/wave_emul.cpp runs both on emulated lanes).
+__device__ __forceinline__ int commit_summary_wave(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, const nhdfit_mapping& m, double busy_time,
+                                                   const SigTable& sigs, uint32_t ncls, uint32_t lane, uint64_t& free0, uint64_t& free1) {
+    const int G = (int)r.n_groups;
+    free0 = s.p0.t0[0] & s.p1.t1[0];
+    free1 = s.p0.t0[1] & s.p1.t1[1];
+    const bool smt_node = (s.p2.flags & NHDFIT_NF_SMT) != 0;
+    uint32_t m_gpu = 0, m_nnuma = 0, m_nidx = 0, mu = 0;
+#pragma unroll
+    for (int g = 0; g < kMaxG; ++g) {
+        m_gpu |= ((uint32_t)m.gpu[g] & 1u) << g; m_nnuma |= ((uint32_t)m.nic_numa[g] & 1u) << g; m_nidx |= ((uint32_t)m.nic_idx[g] & 15u) << (4 * g);
+    }
+#pragma unroll
+    for (int g = 0; g <= kMaxG; ++g) if (g == G) mu = (uint32_t)m.cpu[g] & 1u;
+    // cores each socket loses: batch by batch min(asked, left) - a batch that asks for more than is left takes what is there
+    uint32_t left0 = (uint32_t)__popcll(free0), left1 = (uint32_t)__popcll(free1), took0 = 0, took1 = 0;
+    auto batch = [&](uint32_t u, uint32_t num, bool smt_requested) {
+        const uint32_t want = smt_node && smt_requested ? (num + 1u) / 2u : num;
+        if (u) { const uint32_t t = want < left1 ? want : left1; left1 -= t; took1 += t; }
+        else   { const uint32_t t = want < left0 ? want : left0; left0 -= t; took0 += t; }
+    };
+    uint32_t claimed0 = 0, claimed1 = 0;
+    for (int g = 0; g < G; ++g) {
+        const uint32_t u = (m_gpu >> g) & 1u;
+        batch(u, r.n_proc[g], (r.smt_bits >> g & 1) != 0);
+        batch(u, r.n_help[g], (r.smt_bits >> (4 + g) & 1) != 0);
+        const uint32_t nu = (m_nnuma >> g) & 1u, nk = (m_nidx >> (4 * g)) & 15u;
+        if (r.nic_use >> g & 1) { if (nu) claimed1 |= 1u << nk; else claimed0 |= 1u << nk; }
+    }
+    batch(mu, r.n_misc, r.misc_smt_enabled != 0);
+    const uint64_t gone0 = took0 ? lowest_bits_wave(free0, took0, lane) : 0ull, gone1 = took1 ? lowest_bits_wave(free1, took1, lane) : 0ull;
+    if (lane == 0) {
+        s.p0.t0[0] &= ~gone0; s.p0.t0[1] &= ~gone1;
+        if (r.hugepages_gb > 0) s.p2.hp_free -= r.hugepages_gb;              // Node.py:794-796
+        s.p4.busy_time = busy_time;                                          // SetBusy, nhd/Node.py:843-845
+        for (uint32_t cl = claimed0 | (claimed1 << 16); cl; cl &= cl - 1u) {  // ClaimPodNICResources (as commit_node_wave)
+            const uint32_t b = (uint32_t)__builtin_ctz(cl), u = b >> 4, k = b & 15u;
+            if (pods_get(d, u, k) != kPodsLost && pods_add(d, u, k, 1) != 0) d.nic_cls[u][k] = 0;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int status = kCommitOk;
+    for (uint32_t u = 0; u < 2; ++u) {
+        if (!(u ? claimed1 : claimed0)) continue;                            // (no GPU is taken: a NUMA node without a claim keeps its ids)
+        uint64_t kn, kp;
+        uint32_t idn = 0, idp = 0;
+        sig_keys_wave(d, u, lane, ncls, kn, kp);
+        if (!sig_lookup(sigs, kn, idn) || !sig_lookup(sigs, kp, idp)) status = kCommitNewSig;
+        if (lane == 0) { s.p3.sig_numa[u] = (uint16_t)idn; s.p3.sig_pci[u] = (uint16_t)idp; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return status;
+}
+// stage 2: `free0` / `free1` = the sockets' free sets as stage 1 found them; `out` in LDS; clear0 / clear1 = thread-1 bits to clear
+__device__ __forceinline__ int commit_picks_wave(uint64_t free0, uint64_t free1, bool smt_node, const nhdfit_req& r, const nhdfit_mapping& m,
+                                                 nhdfit_placement& out, uint32_t lane, uint64_t& clear0, uint64_t& clear1) {
+    const int G = (int)r.n_groups;
+    int status = kCommitOk;
+    {   // the placement record: zeros, 0xFF for the GPU list and the NUMA entries (bytes 144 .. 180 of the 256)
+        const uint32_t o = lane * 4u;
+        reinterpret_cast<uint32_t*>(&out)[lane] = o >= 144u && o < 180u ? 0xFFFFFFFFu : o == 180u ? 0x000000FFu : 0u;
+    }
+    uint64_t t0[2] = {free0, free1}, t1[2] = {free0, free1};                  // (take_batch_wave reads t0 & t1 only)
+    uint32_t m_gpu = 0, mu = 0;
+#pragma unroll
+    for (int g = 0; g < kMaxG; ++g) m_gpu |= ((uint32_t)m.gpu[g] & 1u) << g;
+#pragma unroll
+    for (int g = 0; g <= kMaxG; ++g) if (g == G) mu = (uint32_t)m.cpu[g] & 1u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int g = 0; g < G; ++g) {
+        const uint32_t u = (m_gpu >> g) & 1u;
+        const WaveBatch pb = take_batch_wave(t0[u], t1[u], smt_node, r.n_proc[g], (r.smt_bits >> g & 1) != 0, lane);
+        const WaveBatch hb = take_batch_wave(t0[u], t1[u], smt_node, r.n_help[g], (r.smt_bits >> (4 + g) & 1) != 0, lane);
+        if (!pb.ok || !hb.ok) status = kCommitWouldRaise;
+        if (lane == 0) {
+            out.numa[g] = (int8_t)u;
+            out.proc_take[g] = pb.take; out.proc_pair[g] = pb.pair; out.proc_late[g] = pb.late;
+            out.help_take[g] = hb.take; out.help_pair[g] = hb.pair; out.help_late[g] = hb.late;
+        }
+    }
+    const WaveBatch mb = take_batch_wave(t0[mu], t1[mu], smt_node, r.n_misc, r.misc_smt_enabled != 0, lane);     // Node.py:799
+    if (!mb.ok) status = kCommitWouldRaise;
+    if (lane == 0) {
+        out.numa[kMaxG] = (int8_t)mu;
+        out.misc_take = mb.take; out.misc_pair = mb.pair; out.misc_late = mb.late;
+    }
+    clear0 = free0 & ~t1[0];                                                  // the pairs' and the run-on walk's sibling bits
+    clear1 = free1 & ~t1[1];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return status;
+}
+
 // ---- k_decide: speculate, then retire in order ------------------------------------------------------------------------------
 // Block 0 decides; blocks 1.. commit the pods with GPUs (workers).  Inside block 0:
 //   wavefront 0, the SEQUENCER, walks the pods in the caller's order.  A pod with GPUs costs it a window look-up, a bit and a
@@ -358,7 +483,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     __shared__ uint32_t s_examv[kSpecWaves], s_pende[kSpecWaves];   // the node a speculator is examining / has posted, and its pod: a later pod does not post
                                                                // that node before the earlier one has made up its mind
     __shared__ uint32_t s_cnt[16];                             // tuning aid: [0] failed verifications [1] LDS cache hits [2] published states read [3] untouched [4] waits for an earlier pod's target [5] window rescans
-                                                               // [8..13] speculator ticks: set-up, node state, verification, commit, waiting for the sequencer, publication
+                                                               // [8..14] speculator ticks: set-up, node state, verification, commit stage 1, waiting for the sequencer, publication, commit stage 2
     static_assert(kSpecWaves * kSpecCache <= 64, "the cache tags are searched by one wavefront");
     extern __shared__ __align__(16) uint8_t s_dyn[];
 
@@ -625,7 +750,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         nhdfit_placement& pl = s_wplace[wave];
         uint32_t cache_next = 0;
         uint32_t c_fail = 0, c_hit = 0, c_pub = 0, c_plain = 0, c_chain = 0, c_rescan = 0;
-        unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_last = kTuning ? wall_clock64() : 0;    // tuning aid (100 MHz ticks)
+        unsigned long long t_acc[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = kTuning ? wall_clock64() : 0;    // tuning aid (100 MHz ticks)
         auto lap = [&](int k) { if (kTuning) { const unsigned long long t = wall_clock64(); t_acc[k] += t - t_last; t_last = t; } };
         // an earlier pod is examining / has posted node v: its word on that node comes first
         auto earlier_pod_on = [&](uint32_t v, uint32_t e) {
@@ -777,7 +902,9 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     if (decisions_on(v) != ver) continue;                 // (the bit is still set: the same node at its new version)
                 }
                 int32_t status = kCommitOk;
-                const bool retire = post_and_wait(v, ver, [&]() {        // the commit is computed while the sequencer validates
+                uint64_t free0 = 0, free1 = 0;                            // the sockets' free sets as this pod found them (stage 2 picks from them)
+                const bool smt_node = (st.p2.flags & NHDFIT_NF_SMT) != 0;
+                const bool retire = post_and_wait(v, ver, [&]() {        // stage 1 of the commit is computed while the sequencer validates
                     if (ver == 0) {                                       // (a never-touched node: its first-touch copy is taken at retirement)
                         if (lane < sizeof(NodeState) / 4) reinterpret_cast<uint32_t*>(&s_pst[sp])[lane] = reinterpret_cast<const uint32_t*>(&st)[lane];
                         if (lane < sizeof(nhdfit_detail) / 4) reinterpret_cast<uint32_t*>(&s_pdet[sp])[lane] = reinterpret_cast<const uint32_t*>(&dd)[lane];
@@ -785,24 +912,39 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     if (lane == 0) { res.node = (int64_t)a.global_base + (int64_t)v; res.map = mp; }
-                    status = kTuning && (q.dbg & 2) ? kCommitOk : commit_node_wave(st, dd, rq, mp, a.now, sigs, q.ncls, pl, lane);
-                    if (lane == 0) res.status = status;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                    // what the next pod's verification reads of this commit: counts, hugepages, NIC classes, signature ids (commit_summary_wave)
+                    status = kTuning && (q.dbg & 2) ? kCommitOk : commit_summary_wave(st, dd, rq, mp, a.now, sigs, q.ncls, lane, free0, free1);
                     lap(3);
                 });
                 lap(4);
                 if (!retire) continue;                                    // the node moved on since it was read: again, from this node
-                // retired: the new state goes live in the block's cache, then everything else
+                // retired: the new state goes live in the block's cache - the next pod on this node starts from here - then everything else
                 if (lane == 0) { s_cver[ce] = ver + 1u; wg_store(&s_ctag[ce], v); wg_store(&s_examv[sp], kNoNode); }
                 ++cache_next;
                 if (lane == 0) wg_store(&s_ctag[sp * kSpecCache + cache_next % kSpecCache], kNoNode);     // the entry worked in next
+                // stage 2, off the chain: the batches' picks (placement record) and thread 1's bits
+                uint64_t clear0 = 0, clear1 = 0;
+                if (!(kTuning && (q.dbg & 2))) {
+                    const int st2 = commit_picks_wave(free0, free1, smt_node, rq, mp, pl, lane, clear0, clear1);
+                    if (st2 == kCommitWouldRaise) status = kCommitWouldRaise;
+                }
+                if (lane == 0) { res.status = status; pl.status = (uint8_t)status; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                lap(6);
                 if (status == kCommitNewSig && lane == 0) q.flags[1] = 1u;
+                // the mirror takes version ver + 1 behind version ver (whose writer may still be in its own stage 2)
+                for (uint32_t spin = 0; ver != 0 && (dev_load(&q.mat[v]) & ~kPubPoison) < ver && !stop; ++spin) {
+                    if (spin > kSpinLimit) give_up();
+                    if (wg_load(&s_abort)) stop = true;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (stop) break;
                 if (!(kTuning && (q.dbg & 4))) {
                     if (lane < sizeof(SeqResult) / 4) reinterpret_cast<uint32_t*>(&a.out[mine])[lane] = reinterpret_cast<const uint32_t*>(&res)[lane];
                     if (a.place && lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&a.place[mine])[lane] = reinterpret_cast<const uint32_t*>(&pl)[lane];
                     if (ver == 0 && !(kTuning && (q.dbg & 1))) note_first_touch(a, v, s_pst[sp], s_pdet[sp], lane, true);
-                    store_node_lds(a, v, &st, &dd, lane);
+                    store_node_lds_chain(a, v, &st, &dd, lane, clear0, clear1);
                 }
                 __threadfence();
                 if (lane == 0) __hip_atomic_store(&q.mat[v], (status == kCommitNewSig ? kPubPoison : 0u) | (ver + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -822,7 +964,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             wg_store(&s_pende[sp], 0xFFFFFFFFu);
             atomicAdd(&s_cnt[0], c_fail); atomicAdd(&s_cnt[1], c_hit); atomicAdd(&s_cnt[2], c_pub); atomicAdd(&s_cnt[3], c_plain);
             atomicAdd(&s_cnt[4], c_chain); atomicAdd(&s_cnt[5], c_rescan);
-            if (kTuning) for (int k = 0; k < 6; ++k) atomicAdd(&s_cnt[8 + k], (uint32_t)t_acc[k]);
+            if (kTuning) for (int k = 0; k < 7; ++k) atomicAdd(&s_cnt[8 + k], (uint32_t)t_acc[k]);
             __hip_atomic_fetch_add(&s_spec_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         return;
@@ -918,7 +1060,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     if (lane == 0) {
         q.ctrl[4] = s_cnt[0]; q.ctrl[5] = s_cnt[1]; q.ctrl[6] = s_cnt[2]; q.ctrl[7] = s_cnt[3]; q.ctrl[8] = s_cnt[4]; q.ctrl[14] = s_cnt[5]; q.ctrl[15] = c_redo;
         q.ctrl[9] = (uint32_t)t_ready; q.ctrl[10] = (uint32_t)t_gpu; q.ctrl[11] = (uint32_t)t_post; q.ctrl[12] = (uint32_t)t_retire;
-        if (kTuning) for (int k = 0; k < 6; ++k) q.ctrl[16 + k] = s_cnt[8 + k];
+        if (kTuning) for (int k = 0; k < 7; ++k) q.ctrl[16 + k] = s_cnt[8 + k];
         wg_store(&s_done, n_pods);                                        // the fetchers run out
         const uint32_t n_items = wg_load(&s_nitems);
         __hip_atomic_store(&q.ctrl[1], (n_items < q.queue_len ? n_items : q.queue_len) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the workers leave once the queue is drained

@@ -11,7 +11,7 @@ constexpr bool kTuning = false;
 
 struct FitArgs {
     const NodeRec* rec[kWClasses];   // node records per row width (k_xrecords), padded to a multiple of 64 nodes
-    const nhdfit_plane4* p4;         // busy times (padded likewise)
+    const double* bt[kWClasses];     // busy times in the records' lane order (k_xrecords / k_xorder), padded likewise
     uint32_t n;                 // nodes in this shard
     uint32_t chunks;            // ceil(n / 64)
     uint64_t global_base;
@@ -30,9 +30,9 @@ struct FitArgs {
     unsigned long long* score;  // [P], pre-zeroed
     const FitItem* items;
     // pair form of the sweep (fit_core.h "pair rows"), per row width: pair_D = 0: off; else C[2][D][D] is derived in LDS behind
-    // the winner scratch, and XX[pair_xx][pair_xx] behind it when pair_xx != 0.  Set for W = 2 and 4 only.
-    uint32_t pair_D[2], pair_xx[2];
-    uint32_t hot_wc1[2], hot_x[2];    // where the second socket's CPU records and the X rows start in the hot section
+    // the winner scratch (W / 2 planes of 16-byte pieces).  Set for W = 2 and 4 only.
+    uint32_t pair_D[2];
+    uint32_t hot_wc1[2];             // where the second socket's CPU records start in the hot section
     uint32_t fc_dim;
     uint32_t dbg_skip;          // tuning aid (NHDFIT_FIT_SKIP): 1 no table sweep, 2 no winner tracking, 4 constant record, 8 no predicate rows
 };
@@ -146,28 +146,17 @@ __device__ __forceinline__ uint64_t sweep_assignments_spill(const uint8_t* hot, 
     return ((uint64_t)hi << 32) | lo;
 }
 
-// Pair form (fit_core.h "pair rows"): one C row instead of four CPU rows, and with XX one row instead of two class rows.
+// Pair form (fit_core.h "pair rows"): one C row instead of four CPU rows.  a_c = address of the row's piece 0; piece q lies one
+// plane (`plane` bytes) further.
 template <int W>
-__device__ __forceinline__ uint64_t sweep_pair_c(const uint8_t* lds, uint32_t a_c, uint32_t a_x0, uint32_t a_x1) {
+__device__ __forceinline__ uint64_t sweep_pair_c(const uint8_t* lds, uint32_t a_c, uint32_t plane, uint32_t a_x0, uint32_t a_x1) {
     uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int q = 0; q < W / 2; ++q) {
         const uint32_t o = q * 16;
-        const uint4 cp = lds16(lds, a_c + o), x0 = lds16(lds, a_x0 + o), x1 = lds16(lds, a_x1 + o);
+        const uint4 cp = lds16(lds, a_c + q * plane), x0 = lds16(lds, a_x0 + o), x1 = lds16(lds, a_x1 + o);
         lo |= __builtin_amdgcn_bitop3_b32(cp.x, x0.x, x1.x, 0x80) | __builtin_amdgcn_bitop3_b32(cp.z, x0.z, x1.z, 0x80);
         hi |= __builtin_amdgcn_bitop3_b32(cp.y, x0.y, x1.y, 0x80) | __builtin_amdgcn_bitop3_b32(cp.w, x0.w, x1.w, 0x80);
-    }
-    return ((uint64_t)hi << 32) | lo;
-}
-template <int W>
-__device__ __forceinline__ uint64_t sweep_pair_cx(const uint8_t* lds, uint32_t a_c, uint32_t a_xx) {
-    uint32_t lo = 0, hi = 0;
-#pragma unroll
-    for (int q = 0; q < W / 2; ++q) {
-        const uint32_t o = q * 16;
-        const uint4 cp = lds16(lds, a_c + o), xx = lds16(lds, a_xx + o);
-        lo |= __builtin_amdgcn_bitop3_b32(cp.z, xx.z, cp.x & xx.x, 0xEA);      // (a & b) | c
-        hi |= __builtin_amdgcn_bitop3_b32(cp.w, xx.w, cp.y & xx.y, 0xEA);
     }
     return ((uint64_t)hi << 32) | lo;
 }
@@ -181,14 +170,14 @@ __device__ __forceinline__ uint64_t sweep_pair_cx(const uint8_t* lds, uint32_t a
 // a GPU-less node, SelectNode's preference) are two wave-uniform 64-bit masks; a chunk whose verdict words do
 // not touch them - all but the first one or two of a run - costs four instructions.  Only a chunk with news is
 // transposed (lane = pod) and scored.
-// PAIR: 0 = six row fetches per pair of assignments; 1 = C tabulated in LDS (three); 2 = C and XX (two).
+// PAIR: 0 = six row fetches per pair of assignments; 1 = C tabulated in LDS (three).
+// The lanes of a chunk work in the records' order (NodeRec::hp names the node's position in the chunk, fit_core.h "lane order").
 template <int BLOCK, int W, bool SPILL, int PAIR = 0>
 __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_from, const FitItem it, uint8_t* lds) {
     static_assert(PAIR == 0 || (!SPILL && W <= 4), "pair tables: narrow tiles, whole hot section staged");
     constexpr int NW = BLOCK / 64;
     const uint32_t dbg = kTuning ? a.dbg_skip : 0u;
     // the argument block may live behind a pointer (k_step_p): what the chunk loop uses is read once, here
-    const nhdfit_plane4* __restrict__ p4 = a.p4;
     const uint64_t* __restrict__ cand = a.cand;
     uint64_t* __restrict__ nm = a.nm;
     constexpr int WC = W == 2 ? 0 : W == 4 ? 1 : W == 8 ? 2 : 3;
@@ -201,6 +190,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
     const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t pod0 = tile * kTile;
     const NodeRec* __restrict__ recs = a.rec[WC];
+    const double* __restrict__ bts = a.bt[WC];
     const uint32_t len = it.c_end - it.c_begin, per = (len + NW - 1) / NW;
     const uint32_t c_first = it.c_begin + wave * per;
     const uint32_t c_last = (dbg & 64) ? c_first : c_first + per < it.c_end ? c_first + per : it.c_end;
@@ -213,7 +203,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
     double bt = 0.0;
     if (c_first < c_last) {
         rv = *reinterpret_cast<const uint4*>(recs + c_first * 64 + lane);           // {w0,w1}, {x0,x1}, {gx,hp}, {flags,pad}
-        bt = p4[c_first * 64 + lane].busy_time;
+        bt = bts[c_first * 64 + lane];
     }
     const uint8_t* hot_global = a.tabs + (size_t)tile * a.pitch + a.off_hot[WC];
     {   // stage the hot section of the tile's table image in LDS (16 B per lane, fully coalesced)
@@ -226,9 +216,9 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
         }
     }
     __syncthreads();
-    // pair tables behind the winner scratch: C[2][D][D], then XX[xcap][xcap]; rows of W * 8 bytes
-    const uint32_t pD = PAIR ? a.pair_D[WC & 1] : 0u, pXX = PAIR == 2 ? a.pair_xx[WC & 1] : 0u;
-    const uint32_t off_c = (uint32_t)lds_slice(hot_bytes) + NW * 64 * (uint32_t)sizeof(unsigned long long), off_xx = off_c + 2 * pD * pD * W * 8;
+    // pair table behind the winner scratch: C[2][D][D] as W / 2 planes of 16-byte pieces (fit_core.h "pair rows")
+    const uint32_t pD = PAIR ? a.pair_D[WC & 1] : 0u;
+    const uint32_t off_c = (uint32_t)lds_slice(hot_bytes) + NW * 64 * (uint32_t)sizeof(unsigned long long), c_plane = 2 * pD * pD * 16;
     if constexpr (PAIR != 0) {
         const uint32_t hot_wc1 = a.hot_wc1[WC & 1], fc_dim = a.fc_dim;
         constexpr uint32_t kWcStride = 2 * W * 8 + 16;                    // wc_stride_of(W)
@@ -245,21 +235,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
                 cp.y = __builtin_amdgcn_bitop3_b32(w0.y, w1m.y, w0m.y & w1.y, 0xEA);
                 cp.z = __builtin_amdgcn_bitop3_b32(w0.z, w1m.z, w0m.z & w1.z, 0xEA);
                 cp.w = __builtin_amdgcn_bitop3_b32(w0.w, w1m.w, w0m.w & w1.w, 0xEA);
-                *reinterpret_cast<uint4*>(__builtin_assume_aligned(lds + off_c + r * (W * 8) + o, 16)) = cp;
-            }
-        }
-        if constexpr (PAIR == 2) {
-            const uint32_t hot_x = a.hot_x[WC & 1];
-            constexpr uint32_t kXStride = W == 2 ? 16u : W * 8 + 16;        // x_stride_of(W)
-            for (uint32_t r = threadIdx.x; r < pXX * pXX; r += BLOCK) {
-                const uint32_t k0 = r / pXX, k1 = r - k0 * pXX;
-#pragma unroll
-                for (int q = 0; q < W / 2; ++q) {
-                    const uint32_t o = q * 16;
-                    const uint4 x0 = lds16(hot, hot_x + k0 * kXStride + o), x1 = lds16(hot, hot_x + k1 * kXStride + o);
-                    *reinterpret_cast<uint4*>(__builtin_assume_aligned(lds + off_xx + r * (W * 8) + o, 16)) =
-                        make_uint4(x0.x & x1.x, x0.y & x1.y, x0.z & x1.z, x0.w & x1.w);
-                }
+                *reinterpret_cast<uint4*>(__builtin_assume_aligned(lds + off_c + q * c_plane + r * 16, 16)) = cp;
             }
         }
         __syncthreads();
@@ -283,12 +259,12 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
         double bt_next = bt;
         if (c + 1 < c_last && !(dbg & 4)) {
             rv_next = *reinterpret_cast<const uint4*>(recs + i + 64);
-            bt_next = p4[i + 64].busy_time;
+            bt_next = bts[i + 64];
         }
         const uint32_t a_w0 = (rv.x & 0xFFFFu) << 3, a_w1 = (rv.x >> 16) << 3;
         const uint32_t a_x0 = (rv.y & 0xFFFFu) << 3, a_x1 = (rv.y >> 16) << 3;
         const uint32_t a_gx = (rv.z & 0xFFFFu) << 3;
-        const uint32_t hp = rv.z >> 16;
+        const uint32_t hp = (rv.z >> 16) & 1023u, pos = rv.z >> 26;       // pos: this lane's node is node c * 64 + pos
         const uint32_t a_hp = hot_hp + (hp < hp_last ? hp : hp_last) * 8;
         const bool nogpu = (rv.w & kRecNoGpu) != 0;
 
@@ -300,9 +276,8 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
             okm = (dbg & 1) ? ((uint64_t)rv.y << 32 | rv.x) : sweep_assignments<W>(hot, a_w0, a_w1, a_x0, a_x1);
         else {
             const uint32_t cw = rv.w >> 16, c0 = cw & 127u, c1 = (cw >> 7) & 127u;
-            const uint32_t a_c = off_c + (((cw >> 14) * pD + (c0 < pD ? c0 : pD - 1)) * pD + (c1 < pD ? c1 : pD - 1)) * (W * 8);
-            if constexpr (PAIR == 1) okm = sweep_pair_c<W>(lds, a_c, a_x0, a_x1);
-            else okm = sweep_pair_cx<W>(lds, a_c, off_xx + (((rv.w >> 4) & 63u) * pXX + ((rv.w >> 10) & 63u)) * (W * 8));
+            const uint32_t a_c = off_c + (((cw >> 14) * pD + (c0 < pD ? c0 : pD - 1)) * pD + (c1 < pD ? c1 : pD - 1)) * 16;
+            okm = sweep_pair_c<W>(lds, a_c, c_plane, a_x0, a_x1);
         }
         const uint2 gx = (dbg & 8) ? make_uint2(rv.z, rv.w) : lds8(hot, a_gx), hpw = (dbg & 8) ? make_uint2(~0u, ~0u) : lds8(hot, a_hp);
         const bool busy = bt >= busy_from;                                  // Node.IsBusy, nhd/Node.py:847-850
@@ -310,15 +285,18 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
         if (busy) { wlo &= ~(uint32_t)m_need; whi &= ~(uint32_t)(m_need >> 32); }      // Matcher.py:107-111
         if (cand) {                                                           // candidate dict of the call (FindNode's nl)
             const uint64_t cw = cand[c];
-            if (!(cw >> lane & 1)) wlo = whi = 0;
+            if (!(cw >> pos & 1)) wlo = whi = 0;
         }
-        if (nm) nm[(size_t)tile * npad + i] = ((uint64_t)whi << 32) | wlo;
+        if (nm) nm[(size_t)tile * npad + c * 64 + pos] = ((uint64_t)whi << 32) | wlo;      // (the chunk's 512 bytes, whatever the lane order)
 
         // (3) does this chunk change any pod's winner?
         const uint32_t nlo = (uint32_t)need_any | (nogpu ? (uint32_t)need_pref : 0u);
         const uint32_t nhi = (uint32_t)(need_any >> 32) | (nogpu ? (uint32_t)(need_pref >> 32) : 0u);
         if (!(dbg & 2) && __ballot(((wlo & nlo) | (whi & nhi)) != 0)) {
-            const uint64_t nogpu_mask = __ballot(nogpu);
+            // back to node order first (rare path): lane p receives the words of the lane that worked on node c * 64 + p
+            wlo = (uint32_t)__builtin_amdgcn_ds_permute((int)(pos << 2), (int)wlo);
+            whi = (uint32_t)__builtin_amdgcn_ds_permute((int)(pos << 2), (int)whi);
+            const uint64_t nogpu_mask = __ballot(__builtin_amdgcn_ds_permute((int)(pos << 2), nogpu ? 1 : 0) != 0);
             transpose64(wlo, whi);                                            // lane j: pod j's verdict over the chunk's 64 nodes
             const uint64_t word = ((uint64_t)whi << 32) | wlo;
             const uint64_t pref = my_pod_needs_gpu ? 0ull : word & nogpu_mask;
@@ -365,15 +343,10 @@ __device__ __forceinline__ void role_fit(const FitArgs& a, const double busy_fro
     it.wcls = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.wcls);
     it.c_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_begin);
     it.c_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_end);
-    if constexpr (!SPILL) {                          // narrow tiles whose pair tables fit the launch's LDS (refresh_layouts)
+    if constexpr (!SPILL) {                          // narrow tiles whose pair table fits the launch's LDS (refresh_layouts)
         if (it.wcls <= 1 && a.pair_D[it.wcls]) {
-            if (it.wcls == 0) {
-                if (a.pair_xx[0]) role_fit_w<BLOCK, 2, false, 2>(a, busy_from, it, lds);
-                else role_fit_w<BLOCK, 2, false, 1>(a, busy_from, it, lds);
-            } else {
-                if (a.pair_xx[1]) role_fit_w<BLOCK, 4, false, 2>(a, busy_from, it, lds);
-                else role_fit_w<BLOCK, 4, false, 1>(a, busy_from, it, lds);
-            }
+            if (it.wcls == 0) role_fit_w<BLOCK, 2, false, 1>(a, busy_from, it, lds);
+            else role_fit_w<BLOCK, 4, false, 1>(a, busy_from, it, lds);
             return;
         }
     }

@@ -202,7 +202,7 @@ def wave_map_on_state(packer, table, i, req, tables=2, nic_bits=-1, form=1):
 
 def wave_commit(packer, table, i, req, mapping, busy_time, form=1):
     """commit() above through the WAVEFRONT form of the commit step (commit_node_wave, emulated lanes); `table` modified in place.
-    form=2: the candidate form of nhd_amd/csrc/seq2_commit_v2.h."""
+    form=2: the two-stage form of k_decide's speculators for a pod without GPUs (commit_summary_wave, then commit_picks_wave)."""
     L = wave_lib()
     _, sig_off, pool_off, glimit, cc, ncls, nsig = _dict_args(packer)
     out = np.zeros((), pack.PLACEMENT)

@@ -133,7 +133,7 @@ int hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane
         uint32_t max_demand = 0;
         for (uint32_t j = 0; j < np; ++j)
             if (req_valid(reqs[t0 + j])) max_demand = std::max(max_demand, req_max_demand(reqs[t0 + j]));
-        const uint32_t pair_D = pair_dim(max_demand, fcmax + 1), pair_xx = x_cap <= kPairMaxXCap ? x_cap : 0u;
+        const uint32_t pair_D = pair_dim(max_demand, fcmax + 1);
         for (uint32_t c = 0; c < chunks; ++c) {
             uint64_t nogpu = 0;
             uint64_t fm[64];
@@ -142,11 +142,11 @@ int hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane
                 const uint32_t i = c * 64 + l;
                 const bool busy = p4[i].busy_time >= busy_from;
                 if (busy != ((now - p4[i].busy_time) < kMinBusySecs)) ++mismatches;      // the threshold form of IsBusy
-                const NodeRec rec = make_record(nidx[i], x0[i], x1[i], L);
+                const NodeRec rec = make_record(nidx[i], x0[i], x1[i], L, l);
                 fm[l] = node_word_hot(img.data() + L.off_hot, L, rec, busy, m_need);
                 if (fm[l] != node_word_cold(img.data(), L, nidx[i], p3[i], busy, m_need, m_pci)) ++mismatches;
-                if (fm[l] != node_word_pair(img.data() + L.off_hot, L, rec, pair_D, pair_xx, busy, m_need)) ++mismatches;
-                if (fm[l] != node_word_pair(img.data() + L.off_hot, L, rec, pair_D, 0u, busy, m_need)) ++mismatches;
+                if (fm[l] != node_word_pair(img.data() + L.off_hot, L, rec, pair_D, busy, m_need)) ++mismatches;
+                if (rec_pos(rec) != l) ++mismatches;
                 if (cand && !(cand[c] >> l & 1)) fm[l] = 0;
                 if (nidx[i].nogpu) nogpu |= 1ull << l;
             }

@@ -117,10 +117,24 @@ int we_commit(nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plane2* p2, nhdfit_pl
     std::memset(&pl, 0xA5, sizeof pl);                           // (the wavefront form initialises the record itself)
     int status[emu::kLanes];
     emu::acc[0] = emu::acc[1] = 0;
+    bool with_gpus = false;
+    for (uint32_t g = 0; g < req->n_groups && g < (uint32_t)kMaxG; ++g) with_gpus = with_gpus || req->gpus[g] != 0;
     std::vector<std::thread> lanes;
     for (int i = 0; i < emu::kLanes; ++i)
         lanes.emplace_back([&, i] {
             emu::t_lane = (uint32_t)i; emu::t_count = 0;
+            if (form == 2 && !with_gpus) {
+                // the two-stage form k_decide's speculators run for a pod without GPUs: stage 1 (summary) in place, then stage 2 (picks)
+                // on the free sets stage 1 found; thread 1 loses the bits stage 2 returns (the kernel: an AND into the mirror)
+                uint64_t f0 = 0, f1 = 0, c0 = 0, c1 = 0;
+                const bool smt_node = (st.p2.flags & NHDFIT_NF_SMT) != 0;
+                int s1 = commit_summary_wave(st, dd, *req, *map, busy_time, sigs, ncls, (uint32_t)i, f0, f1);
+                const int s2 = commit_picks_wave(f0, f1, smt_node, *req, *map, pl, (uint32_t)i, c0, c1);
+                if (s2 == kCommitWouldRaise) s1 = kCommitWouldRaise;
+                if (i == 0) { st.p1.t1[0] &= ~c0; st.p1.t1[1] &= ~c1; pl.status = (uint8_t)s1; }
+                emu::wave_barrier();
+                status[i] = s1;
+            } else
             status[i] = commit_node_wave(st, dd, *req, *map, busy_time, sigs, ncls, pl, (uint32_t)i);
         });
     for (auto& t : lanes) t.join();

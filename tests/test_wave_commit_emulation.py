@@ -25,6 +25,9 @@ def _both(pk, table, i, req, mp, bt):
     assert sa == sb, (sa, sb)
     assert pa.tobytes() == pb.tobytes(), (pa, pb)
     assert _rows(ta, i) == _rows(tb, i)
+    tc = copy.deepcopy(table)                                  # the two-stage form (commit_summary_wave + commit_picks_wave; pods without GPUs)
+    sc, pc = harness.wave_commit(pk, tc, i, req, mp, bt, form=2)
+    assert sc == sa and pc.tobytes() == pa.tobytes() and _rows(tc, i) == _rows(ta, i), ("two-stage", sa, sc, pa, pc)
     return sa, ta
 
 
