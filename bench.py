@@ -335,7 +335,8 @@ def strong_leg(cfg, total_nodes, P, world, rank, local_rank, dist, steps, warmup
 
 def sharded_mode_b(eng, pk, table, reqs, spec, lo, hi, cfg, total_nodes, tops, groups, dist, rank, world):
     """Mode B with one process per GPU (nhd_amd.sharding.schedule_batch_sharded: the shards' sequential passes pipelined over pod
-    slices, pods travelling rank to rank as fixed-size tensors over the control plane, one all-reduce of the results): the commits
+    slices in a lock-step ring, pods travelling rank to rank over the context's RCCL communicator - nhdfit_comm_sendrecv -, one
+    all-reduce of the results): the commits
     stay in the shards' mirrors (apply), every timed call starts from freshly uploaded shards, time = MAX over the ranks.  Rank 0
     then decides the batch again with the independent oracle over the WHOLE cluster and compares node, mapping and physical ids of
     every pod.  Nothing here may take the run down: an error is reported in the leg's place."""
@@ -352,11 +353,12 @@ def sharded_mode_b(eng, pk, table, reqs, spec, lo, hi, cfg, total_nodes, tops, g
         bits = np.zeros(((hi - lo + 63) // 64) * 64, np.uint8)
         bits[:hi - lo] = (np.asarray(spec.n_gpus) == 0)
         nogpu = np.packbits(bits, bitorder="little").view(np.uint64).copy()
+        transport = sharding.RcclTransport(eng)               # the pods travel rank to rank over the context's own communicator (ncclSend / ncclRecv behind the C-ABI)
         for _ in range(3):
             eng.upload(table, global_base=lo)                 # the shard as the snapshot has it (the previous call's commits are gone)
             dist.barrier()
             t0 = time.perf_counter()
-            res = sharding.schedule_batch_sharded(eng, reqs, now, pk, nogpu, dist, apply=True, chunk=chunk)
+            res = sharding.schedule_batch_sharded(eng, reqs, now, pk, nogpu, transport, apply=True, chunk=chunk)
             dist.barrier()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -373,8 +375,8 @@ def sharded_mode_b(eng, pk, table, reqs, spec, lo, hi, cfg, total_nodes, tops, g
         return {"error": err or "another rank failed", "call": "nhd_amd.sharding.schedule_batch_sharded"}
     node, maps, places, status = res
     t = min(ts[1:]) if len(ts) > 1 else ts[0]
-    out = {"call": "nhd_amd.sharding.schedule_batch_sharded (one process per GPU: nhdfit_schedule_batch per shard and pod slice, pods rank to rank over gloo, "
-                   "one all-reduce of the results; commits left in the shards' mirrors)",
+    out = {"call": "nhd_amd.sharding.schedule_batch_sharded (one process per GPU: nhdfit_schedule_batch per shard and pod slice, pods rank to rank over RCCL "
+                   "(nhdfit_comm_sendrecv), one all-reduce of the results; commits left in the shards' mirrors)",
            "decisions_per_s": P / t, "ms_per_batch": t * 1e3, "placed": int((node >= 0).sum()), "n_gpus": world, "pods_per_slice": chunk,
            "commits_that_would_raise": int((status == 1).sum()),
            "placed_per_shard": [int(((node >= r * per) & (node < (r + 1) * per)).sum()) for r in range(world)],

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NHDFIT_ABI_VERSION        8
+#define NHDFIT_ABI_VERSION        9
 #define NHDFIT_MAX_GROUPS         4      /* proc groups per pod (G) of the table-driven pass; 5..8: nhdfit_big_req below */
 #define NHDFIT_MAX_NUMA           2      /* NUMA nodes (= sockets, nhd/Node.py:336) per node (U)  */
 #define NHDFIT_MAX_CORES_PER_NUMA 64     /* physical cores per socket (one uint64 mask)           */
@@ -453,6 +453,20 @@ int nhdfit_fetch(nhdfit_ctx* ctx, uint64_t* score_out, uint64_t* bitmap_out, nhd
 int nhdfit_comm_unique_id(void* id128);
 int nhdfit_comm_init(nhdfit_ctx* ctx, int nranks, int rank, const void* id128);
 int nhdfit_comm_destroy(nhdfit_ctx* ctx);
+/* Rank-to-rank traffic of mode B across shards (ABI 9): the scheduler's loop - nhd/NHDScheduler.py:425-437, FindNode then commit,
+ * pod after pod - takes the FIRST feasible node of the cluster (nhd/Matcher.py:393-421), so with the node axis sharded a pod
+ * reaches shard s only if the shards before it turned it down at its turn: the pods a shard could not place travel to the next
+ * rank (nhd_amd/sharding.py).  One call = one step of that pipeline: `send_bytes` from `send_buf` go to rank `dst` while
+ * `recv_bytes` from rank `src` arrive in `recv_buf` - ONE grouped ncclSend / ncclRecv on the context's communicator and reduce
+ * stream over xGMI, host buffers staged through device memory; blocks until both are done.  Either side may be absent
+ * (dst < 0 / src < 0); dst == src == own rank is a self-exchange.  Every rank of the communicator must make the matching
+ * call.  Without a communicator (a single GPU) only the self-exchange is possible and is a copy. */
+int nhdfit_comm_sendrecv(nhdfit_ctx* ctx, const void* send_buf, size_t send_bytes, int dst, void* recv_buf, size_t recv_bytes, int src);
+/* Element-wise sum of `bytes` uint8 over the ranks, in place (ncclAllReduce(ncclUint8, ncclSum)): how the per-pod results of
+ * mode B across shards meet - every pod is placed by at most one rank, all others hold zeros.  A no-op without a communicator. */
+int nhdfit_comm_allreduce_sum_u8(nhdfit_ctx* ctx, void* buf, size_t bytes);
+/* rank and size of the context's communicator (0 of 1 without one) */
+int nhdfit_comm_rank(nhdfit_ctx* ctx, int* rank, int* nranks);
 
 /* One process, several GPUs (the reference calls FindNode from its one scheduler thread, nhd/NHDScheduler.py:43,277):
  * a group owns one context per device; the caller shards the node axis contiguously over them (nhdfit_group_ctx(g, k) +

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # NHDFIT_LIBRARY: load another build of the same ABI instead (tools/: the tuning build libnhdfit_tuning.so)
 LIB_PATH = os.environ.get("NHDFIT_LIBRARY") or os.path.join(HERE, "libnhdfit.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nhdfit.h")
-ABI_VERSION = 8                  # NHDFIT_ABI_VERSION of include/nhdfit.h this binding (and pack.py's record layouts) is written for
+ABI_VERSION = 9                  # NHDFIT_ABI_VERSION of include/nhdfit.h this binding (and pack.py's record layouts) is written for
 
 
 class NhdFitError(RuntimeError):
@@ -60,6 +60,9 @@ _SIGS = {
     "nhdfit_comm_unique_id": (c_int, [c_void_p]),
     "nhdfit_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "nhdfit_comm_destroy": (c_int, [c_void_p]),
+    "nhdfit_comm_sendrecv": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p, ctypes.c_size_t, c_int]),
+    "nhdfit_comm_allreduce_sum_u8": (c_int, [c_void_p, c_void_p, ctypes.c_size_t]),
+    "nhdfit_comm_rank": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "nhdfit_set_outputs": (c_int, [c_void_p, c_int, c_int]),
     "nhdfit_get_stats": (c_int, [c_void_p, POINTER(Stats)]),
     "nhdfit_reset_stats": (c_int, [c_void_p]),

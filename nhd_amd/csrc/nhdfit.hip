@@ -74,6 +74,8 @@ struct Rccl {
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool load(std::string& err) {
         if (handle) return true;
@@ -89,8 +91,10 @@ struct Rccl {
         CommInitAll = (decltype(CommInitAll))dlsym(handle, "ncclCommInitAll");
         GroupStart = (decltype(GroupStart))dlsym(handle, "ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))dlsym(handle, "ncclGroupEnd");
+        Send = (decltype(Send))dlsym(handle, "ncclSend");
+        Recv = (decltype(Recv))dlsym(handle, "ncclRecv");
         GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
-        if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy || !GetErrorString || !CommInitAll || !GroupStart || !GroupEnd) {
+        if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy || !GetErrorString || !CommInitAll || !GroupStart || !GroupEnd || !Send || !Recv) {
             err = "librccl lacks a required symbol";
             return false;
         }
@@ -279,6 +283,7 @@ struct nhdfit_ctx {
     // collective
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
+    DevBuf<uint8_t> xfer_send, xfer_recv;   // nhdfit_comm_sendrecv / nhdfit_comm_allreduce_sum_u8: device staging of the host buffers
 };
 
 namespace {
@@ -298,6 +303,26 @@ int fail(nhdfit_ctx* c, int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                 \
         if (e_ != hipSuccess) return fail((c), NHDFIT_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+// Waiting for a stream: the runtime's own wait parks the thread on the queue's interrupt, and the wake-up costs tens of
+// microseconds - as much as a whole step of the pipelined form, half of what a 20-step region loses at its end, a third of a
+// batch call through host buffers.  The scheduler's thread has nothing else to do while its one call is in flight (the reference
+// calls FindNode from one thread, nhd/NHDScheduler.py:43,277), so it polls the stream first - for at most kSpinWaitUs, the length of
+// the longest ordinary call (a mode-B batch) - and only then goes to sleep on it.
+constexpr long kSpinWaitUs = 20000;
+hipError_t wait_stream(hipStream_t s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t polls = 0;; ++polls) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) {
+            if (polls && e == hipSuccess) (void)hipGetLastError();      // ("not ready" must not be what the next launch's error check finds)
+            return e;
+        }
+        if ((polls & 63u) == 63u && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kSpinWaitUs) break;
+    }
+    (void)hipGetLastError();
+    return hipStreamSynchronize(s);
+}
 
 int drain_events(nhdfit_ctx* c) {
     for (int k = 0; k < c->ev_pending; ++k) {
@@ -320,8 +345,8 @@ int refresh_layouts(nhdfit_ctx* c);
 
 int sync_all(nhdfit_ctx* c) {
     { int rc_ = flush_pipeline(c); if (rc_) return rc_; }      // pending mapping phases of the last steps
-    for (Pipe& p : c->pipe) HIPCHK(c, hipStreamSynchronize(p.stream));
-    HIPCHK(c, hipStreamSynchronize(c->s_red));
+    for (Pipe& p : c->pipe) HIPCHK(c, wait_stream(p.stream));
+    HIPCHK(c, wait_stream(c->s_red));
     return NHDFIT_OK;
 }
 
@@ -409,7 +434,7 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
             hipLaunchKernelGGL(k_build_choose, dim3((kChooseEntries + 255) / 256), dim3(256), 0, c->stream, c->asc.p, c->choose_tab.p);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = wait_stream(c->stream);
     }
     if (e != hipSuccess) {
         int rc = fail(nullptr, NHDFIT_E_HIP, "stream / event / table creation: %s", hipGetErrorString(e));
@@ -838,7 +863,7 @@ int ensure_records(nhdfit_ctx* c) {
         if (pass == 1) break;
         uint32_t nx[2] = {0, 0};
         HIPCHK(c, hipMemcpyAsync(nx, c->xnx.p, sizeof nx, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, wait_stream(c->stream));
         if (nx[1] || nx[0] > kXSlots / 2) return fail(c, NHDFIT_E_LIMIT, "more than %u distinct (free GPUs, NIC signature) node classes", kXSlots / 2);
         if (nx[0] != c->nx)                                     // new classes: a table image digested ahead of its fit has no X rows for
             for (Pipe& p : c->pipe)                             // them - it is digested again (nhdfit_enqueue_step looks here first)
@@ -1076,7 +1101,7 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
         unsigned long long init[10];
         for (int k = 0; k < 5; ++k) { init[2 * k] = ~0ull; init[2 * k + 1] = 0; }
         HIPCHK(c, hipMemcpyAsync(c->role_clock.p, init, sizeof init, hipMemcpyHostToDevice, p.stream));
-        HIPCHK(c, hipStreamSynchronize(p.stream));
+        HIPCHK(c, wait_stream(p.stream));
         a.role_clock = c->role_clock.p;
     }
     const bool timed = (with_fit && (p.n_fit < 2 || (p.n_fit & 7) == 0)) || (!with_fit && with_digest);
@@ -1120,7 +1145,7 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
     }
     if (a.role_clock) {
         unsigned long long t[10];
-        HIPCHK(c, hipStreamSynchronize(p.stream));
+        HIPCHK(c, wait_stream(p.stream));
         HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
         unsigned long long first = ~0ull;
         for (int k = 0; k < 5; ++k) first = t[2 * k] < first ? t[2 * k] : first;
@@ -1167,7 +1192,7 @@ int convert_rows(nhdfit_ctx* c, Pipe& p) {
     HIPCHK(c, c->bitmap.reserve((size_t)chunks * c->P));
     hipLaunchKernelGGL(k_rows, dim3((tiles * chunks + 3) / 4), dim3(256), 0, p.stream, p.nm.p, c->bitmap.p, chunks, c->P);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(p.stream));
+    HIPCHK(c, wait_stream(p.stream));
     return NHDFIT_OK;
 }
 
@@ -1274,7 +1299,7 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
     const int b = (int)((p.n_fit - 1) % kBufs);               // results of the most recent step
     // the launches that finish the mappings still in flight, the copies behind them on the same stream, ONE wait
     { int rc_ = flush_pipeline(c); if (rc_) return rc_; }
-    if (c->comm) HIPCHK(c, hipStreamSynchronize(c->s_red));
+    if (c->comm) HIPCHK(c, wait_stream(c->s_red));
     if (map_out && c->n_wide) {
         // winners that are wide nodes: their mappings from the general set model, over what the mapping roles left for them
         constexpr uint32_t kWideMapThreads = 512;
@@ -1290,7 +1315,7 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
         HIPCHK(c, hipGetLastError());
         uint32_t fl[4] = {0, 0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(fl, c->wide_flags.p, sizeof fl, hipMemcpyDeviceToHost, p.stream));
-        HIPCHK(c, hipStreamSynchronize(p.stream));
+        HIPCHK(c, wait_stream(p.stream));
         if (fl[0]) return fail(c, NHDFIT_E_LIMIT, "the set model of a wide node's mapping outgrew its table");
     }
     if (score_out) {
@@ -1430,14 +1455,14 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
         seen = __atomic_load_n(&h->flag, __ATOMIC_ACQUIRE);
         if (seen == seq || seen == kFindAborted) break;
         if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t_launch > std::chrono::microseconds(500)) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));         // a long launch (or host memory the device does not write through): wait for its end
+            HIPCHK(c, wait_stream(c->stream));         // a long launch (or host memory the device does not write through): wait for its end
             seen = __atomic_load_n(&h->flag, __ATOMIC_ACQUIRE);
             break;
         }
         __builtin_ia32_pause();
     }
     if (seen != seq) {                                          // the launch gave up on a wait: counters back to zero, staged path
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, wait_stream(c->stream));
         HIPCHK(c, hipMemsetAsync(c->find_sync.p, 0, 8 * sizeof(uint32_t), c->stream));
         h->flag = 0;
         return 1;
@@ -1445,7 +1470,7 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     if (clocks) {
         const double us_seen = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_launch).count();
         unsigned long long t[10];
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, wait_stream(c->stream));
         HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
         unsigned long long first = ~0ull;
         for (int k = 0; k < 5; ++k) first = t[2 * k] < first ? t[2 * k] : first;
@@ -1466,7 +1491,7 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
         ncclResult_t r = g_rccl.AllReduce(c->find_red.p, c->find_red.p, P, ncclUint64, ncclMax, c->comm, c->s_red);
         if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
         HIPCHK(c, hipMemcpyAsync(c->pin_score.p, c->find_red.p, (size_t)P * 8, hipMemcpyDeviceToHost, c->s_red));
-        HIPCHK(c, hipStreamSynchronize(c->s_red));
+        HIPCHK(c, wait_stream(c->s_red));
         for (uint32_t i = 0; i < P; ++i) {
             if (c->pin_score.p[i] != h->score[i]) memset(&h->maps[i], 0, sizeof(nhdfit_mapping));
             h->score[i] = c->pin_score.p[i];
@@ -1529,7 +1554,7 @@ int nhdfit_wide_download(nhdfit_ctx* c, nhdfit_wide_node* out, uint32_t cap, uin
     if (!c->n_wide || !out) return NHDFIT_OK;
     if (cap < c->n_wide) return fail(c, NHDFIT_E_INVAL, "%u wide records, room for %u", c->n_wide, cap);
     HIPCHK(c, hipSetDevice(c->dev));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, wait_stream(c->stream));
     HIPCHK(c, hipMemcpy(out, c->wide.p, (size_t)c->n_wide * sizeof *out, hipMemcpyDeviceToHost));
     return NHDFIT_OK;
 }
@@ -1592,7 +1617,7 @@ int nhdfit_wide_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_req* req, cons
     hipLaunchKernelGGL(k_wide_commit, dim3(1), dim3(64), 0, c->stream, wa);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(place_out, c->wide_place.p, sizeof *place_out, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, wait_stream(c->stream));
     return NHDFIT_OK;
 }
 
@@ -1627,10 +1652,10 @@ int nhdfit_big_find(nhdfit_ctx* c, const nhdfit_big_req* reqs, uint32_t P, doubl
         HIPCHK(c, hipGetLastError());
     }
     if (c->comm) {      // sharded: one all-reduce(max) of the P packed scores picks the cluster's winners; the owner maps (k_big_map skips the rest)
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, wait_stream(c->stream));
         ncclResult_t r = g_rccl.AllReduce(c->big_score.p, c->big_score.p, P, ncclUint64, ncclMax, c->comm, c->s_red);
         if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
-        HIPCHK(c, hipStreamSynchronize(c->s_red));
+        HIPCHK(c, wait_stream(c->s_red));
     }
     if (map_out && c->n) {
         // set tables of one mapping: sized for the call's largest group count on the mirror's widest node (2 sockets, 8 groups:
@@ -1656,7 +1681,7 @@ int nhdfit_big_find(nhdfit_ctx* c, const nhdfit_big_req* reqs, uint32_t P, doubl
     uint32_t fl[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(score_out, c->big_score.p, (size_t)P * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(fl, c->big_flags.p, sizeof fl, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, wait_stream(c->stream));
     if (fl[1]) return fail(c, NHDFIT_E_LIMIT, "a big request's NIC stage ran out of search budget on some node (%u steps per pod and node)", (unsigned)NHDFIT_BIG_NIC_BUDGET);
     if (fl[0]) return fail(c, NHDFIT_E_LIMIT, "the set model of a big request's mapping outgrew its table");
     return NHDFIT_OK;
@@ -1689,7 +1714,7 @@ int nhdfit_big_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_big_req* req, c
     hipLaunchKernelGGL(k_big_commit, dim3(1), dim3(64), 0, c->stream, ba);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(place_out, c->big_place.p, sizeof *place_out, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, wait_stream(c->stream));
     if (slot < 0) {                                             // the node's records (X class, free-core counts) follow its planes
         if (c->rec_lo == c->rec_hi) { c->rec_lo = node; c->rec_hi = node + 1; }
         else { c->rec_lo = std::min(c->rec_lo, node); c->rec_hi = std::max(c->rec_hi, node + 1); }
@@ -1768,7 +1793,7 @@ int schedule_batch_general(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, do
             if (r2 && !rc) rc = r2;
         }
         if (!wide_before.empty()) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, wait_stream(c->stream));
             HIPCHK(c, hipMemcpy(c->wide.p, wide_before.data(), wide_before.size() * sizeof wide_before[0], hipMemcpyHostToDevice));
         }
     }
@@ -1869,7 +1894,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, hipGetLastError());
         if (seq_prof) {
             unsigned long long t[16];
-            HIPCHK(c, hipStreamSynchronize(sm));
+            HIPCHK(c, wait_stream(sm));
             HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
             const double per = 0.01 / (double)(t[3] ? t[3] : 1);
             fprintf(stderr, "[nhdfit] k_seq wave 0 per round: node load %.1f, NIC bits %.1f, mapping %.1f, commit %.1f, write-back %.1f us\n",
@@ -1881,7 +1906,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         }
         uint32_t counters[4] = {0, 0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(counters, c->seq_counters.p, sizeof counters, hipMemcpyDeviceToHost, sm));
-        HIPCHK(c, hipStreamSynchronize(sm));
+        HIPCHK(c, wait_stream(sm));
         done = counters[1];
         return NHDFIT_OK;
     };
@@ -1941,7 +1966,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, hipGetLastError());
         uint32_t flags[4] = {0, 0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(flags, c->seq_flags.p, sizeof flags, hipMemcpyDeviceToHost, sm));
-        HIPCHK(c, hipStreamSynchronize(sm));
+        HIPCHK(c, wait_stream(sm));
         if (tune_env("NHDFIT_SEQ_PROF")) {
             uint32_t ctl[32];
             HIPCHK(c, hipMemcpy(ctl, c->seq_ctrl.p, sizeof ctl, hipMemcpyDeviceToHost));
@@ -2028,7 +2053,7 @@ int nhdfit_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_req* req, const nhd
     hipLaunchKernelGGL(k_commit, dim3(1), dim3(64), 0, c->stream, ca);       // (both pipes are idle: sync_all above)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(place_out, c->seq_place.p, sizeof(nhdfit_placement), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, wait_stream(c->stream));
     if (c->rec_lo == c->rec_hi) { c->rec_lo = node; c->rec_hi = node + 1; }
     else { c->rec_lo = std::min(c->rec_lo, node); c->rec_hi = std::max(c->rec_hi, node + 1); }
     return NHDFIT_OK;
@@ -2041,7 +2066,7 @@ int nhdfit_upload_origin(nhdfit_ctx* c, uint32_t first, uint32_t count, const nh
     if ((uint64_t)first + count > c->capacity) return fail(c, NHDFIT_E_INVAL, "upload [%u,%u) exceeds capacity %u", first, first + count, c->capacity);
     if (first > c->origin_hi) return fail(c, NHDFIT_E_INVAL, "origin records [%u,%u) are missing", c->origin_hi, first);
     HIPCHK(c, hipSetDevice(c->dev));
-    HIPCHK(c, hipStreamSynchronize(c->stream));                  // a delta kernel in flight may still write its records
+    HIPCHK(c, wait_stream(c->stream));                  // a delta kernel in flight may still write its records
     HIPCHK(c, hipMemcpy(c->origin.p + first, origin, count * sizeof *origin, hipMemcpyHostToDevice));
     c->origin_hi = std::max(c->origin_hi, first + count);
     return NHDFIT_OK;
@@ -2087,7 +2112,7 @@ int nhdfit_apply_deltas(nhdfit_ctx* c, const nhdfit_delta* deltas, uint32_t n, u
     HIPCHK(c, hipGetLastError());
     std::vector<uint8_t> st(n);
     HIPCHK(c, hipMemcpyAsync(st.data(), c->delta_status.p, n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));                  // (also keeps `sorted` / `run` alive until the copies are done)
+    HIPCHK(c, wait_stream(c->stream));                  // (also keeps `sorted` / `run` alive until the copies are done)
     for (uint32_t i = 0; i < n; ++i) status_out[order[i]] = st[i];
     if (c->rec_lo == c->rec_hi) { c->rec_lo = lo; c->rec_hi = hi; }
     else { c->rec_lo = std::min(c->rec_lo, lo); c->rec_hi = std::max(c->rec_hi, hi); }
@@ -2099,7 +2124,7 @@ int nhdfit_download_nodes(nhdfit_ctx* c, uint32_t first, uint32_t count, nhdfit_
     if (!c) return NHDFIT_E_INVAL;
     if ((uint64_t)first + count > c->n) return fail(c, NHDFIT_E_INVAL, "download [%u,%u) exceeds the %u nodes of the mirror", first, first + count, c->n);
     HIPCHK(c, hipSetDevice(c->dev));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, wait_stream(c->stream));
     if (p0) HIPCHK(c, hipMemcpy(p0, c->p0.p + first, count * sizeof *p0, hipMemcpyDeviceToHost));
     if (p1) HIPCHK(c, hipMemcpy(p1, c->p1.p + first, count * sizeof *p1, hipMemcpyDeviceToHost));
     if (p2) HIPCHK(c, hipMemcpy(p2, c->p2.p + first, count * sizeof *p2, hipMemcpyDeviceToHost));
@@ -2157,6 +2182,55 @@ int nhdfit_comm_destroy(nhdfit_ctx* c) {
     }
     c->nranks = 1;
     c->rank = 0;
+    return NHDFIT_OK;
+}
+
+int nhdfit_comm_rank(nhdfit_ctx* c, int* rank, int* nranks) {
+    if (!c) return NHDFIT_E_INVAL;
+    if (rank) *rank = c->comm ? c->rank : 0;
+    if (nranks) *nranks = c->comm ? c->nranks : 1;
+    return NHDFIT_OK;
+}
+
+int nhdfit_comm_sendrecv(nhdfit_ctx* c, const void* send_buf, size_t send_bytes, int dst, void* recv_buf, size_t recv_bytes, int src) {
+    if (!c) return NHDFIT_E_INVAL;
+    const int nranks = c->comm ? c->nranks : 1, me = c->comm ? c->rank : 0;
+    const bool sending = dst >= 0 && send_bytes, receiving = src >= 0 && recv_bytes;
+    if ((sending && (!send_buf || dst >= nranks)) || (receiving && (!recv_buf || src >= nranks))) return fail(c, NHDFIT_E_INVAL, "sendrecv: bad peer or buffer");
+    if (!sending && !receiving) return NHDFIT_OK;
+    if (!c->comm) {                                             // one GPU, no communicator: the self-exchange is a copy
+        if (sending != receiving || send_bytes != recv_bytes) return fail(c, NHDFIT_E_INVAL, "sendrecv without a communicator: only a self-exchange of equal sizes");
+        memmove(recv_buf, send_buf, recv_bytes);
+        return NHDFIT_OK;
+    }
+    if (sending && receiving && dst == me && src == me && send_bytes != recv_bytes) return fail(c, NHDFIT_E_INVAL, "self-exchange of unequal sizes");
+    HIPCHK(c, hipSetDevice(c->dev));
+    // staged through two device buffers: RCCL moves device memory over xGMI; the reduce stream carries every collective of the
+    // communicator in call order (the same order on every rank)
+    HIPCHK(c, c->xfer_send.reserve(send_bytes ? send_bytes : 1));
+    HIPCHK(c, c->xfer_recv.reserve(recv_bytes ? recv_bytes : 1));
+    if (sending) HIPCHK(c, hipMemcpyAsync(c->xfer_send.p, send_buf, send_bytes, hipMemcpyHostToDevice, c->s_red));
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r == ncclSuccess && sending) r = g_rccl.Send(c->xfer_send.p, send_bytes, ncclUint8, dst, c->comm, c->s_red);
+    if (r == ncclSuccess && receiving) r = g_rccl.Recv(c->xfer_recv.p, recv_bytes, ncclUint8, src, c->comm, c->s_red);
+    const ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclSend / ncclRecv: %s", g_rccl.GetErrorString(r != ncclSuccess ? r : r2));
+    if (receiving) HIPCHK(c, hipMemcpyAsync(recv_buf, c->xfer_recv.p, recv_bytes, hipMemcpyDeviceToHost, c->s_red));
+    HIPCHK(c, wait_stream(c->s_red));
+    return NHDFIT_OK;
+}
+
+int nhdfit_comm_allreduce_sum_u8(nhdfit_ctx* c, void* buf, size_t bytes) {
+    if (!c) return NHDFIT_E_INVAL;
+    if (!c->comm || !bytes) return NHDFIT_OK;
+    if (!buf) return fail(c, NHDFIT_E_INVAL, "allreduce: no buffer");
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, c->xfer_send.reserve(bytes));
+    HIPCHK(c, hipMemcpyAsync(c->xfer_send.p, buf, bytes, hipMemcpyHostToDevice, c->s_red));
+    ncclResult_t r = g_rccl.AllReduce(c->xfer_send.p, c->xfer_send.p, bytes, ncclUint8, ncclSum, c->comm, c->s_red);
+    if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce(uint8, sum): %s", g_rccl.GetErrorString(r));
+    HIPCHK(c, hipMemcpyAsync(buf, c->xfer_send.p, bytes, hipMemcpyDeviceToHost, c->s_red));
+    HIPCHK(c, wait_stream(c->s_red));
     return NHDFIT_OK;
 }
 
@@ -2247,7 +2321,7 @@ int nhdfit_group_find(nhdfit_group* g, const nhdfit_req* reqs, uint32_t P, doubl
             if (!c->n) continue;
             Pipe& p = c->pipe[0];
             HIPCHK(c, hipSetDevice(c->dev));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, wait_stream(c->stream));
             const int b = (int)((p.n_fit - 1) % kBufs);
             HIPCHK(c, hipMemcpy(tmp.data(), p.score[b].p, (size_t)P * 8, hipMemcpyDeviceToHost));
             for (uint32_t i = 0; i < P; ++i) best[i] = std::max(best[i], tmp[i]);

@@ -757,6 +757,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             return __ballot(lane < (uint32_t)kSpecWaves && lane != sp && wg_load(&s_examv[lane]) == v && wg_load(&s_pende[lane]) < e) != 0;
         };
         for (uint32_t j = sp; j < q.n_n && !stop; j += kSpecWaves) {
+            __builtin_amdgcn_s_setprio(2);
             const uint4 ent = q.ent_n[j];
             const uint32_t e = ent.x, mine = e, pos = ent.y;
             const uint32_t tile = pos >> 6;
@@ -825,6 +826,25 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
                 const uint32_t v = (wbase + (uint32_t)l) * 64u + (uint32_t)__builtin_ctzll(((uint64_t)hi << 32) | lo);
                 if (lane == 0) wg_store(&s_examv[sp], v);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                // An earlier pod that is looking at this node (or has posted it) goes first - and this one waits for it BEFORE it
+                // reads and verifies the node (round 5): consecutive pods without GPUs pile onto the same node, so the state an
+                // earlier pod is about to change is not worth a verification, and a wavefront verifying in vain shares its SIMD's
+                // issue slots with the one whose pod is next to retire (config 2: 3.75 verifications per pod, one of them needed).
+                if (earlier_pod_on(v, e)) {
+                    ++c_chain;
+                    __builtin_amdgcn_s_setprio(0);
+                    for (uint32_t spin = 0; earlier_pod_on(v, e) && !stop; ++spin) {
+                        if (spin > kSpinLimit) give_up();
+                        if (wg_load(&s_abort)) stop = true;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    __builtin_amdgcn_s_setprio(2);
+                    lap(4);
+                    if (stop) break;
+                }
+                // the pod the sequencer is waiting for runs ahead of its SIMD's other wavefront
+                if (wg_load(&s_done) == e) __builtin_amdgcn_s_setprio(3);
                 // the node at the latest version there is -> the cache entry this speculator works in (tagged kNoNode)
                 const uint32_t ce = sp * kSpecCache + cache_next % kSpecCache;
                 NodeState& st = s_cst[ce];
@@ -890,17 +910,20 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     continue;
                 }
                 // an earlier pod that is looking at this node (or has posted it) goes first; if it takes the node, this one looks again
-                if (earlier_pod_on(v, e)) {
+                if (earlier_pod_on(v, e)) {                               // (one that came to this node while it was verified)
                     ++c_chain;
+                    __builtin_amdgcn_s_setprio(0);
                     for (uint32_t spin = 0; earlier_pod_on(v, e) && !stop; ++spin) {
                         if (spin > kSpinLimit) give_up();
                         if (wg_load(&s_abort)) stop = true;
-                        __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_s_sleep(2);
                     }
+                    __builtin_amdgcn_s_setprio(2);
                     lap(4);
                     if (stop) break;
                     if (decisions_on(v) != ver) continue;                 // (the bit is still set: the same node at its new version)
                 }
+                if (wg_load(&s_done) == e) __builtin_amdgcn_s_setprio(3);
                 int32_t status = kCommitOk;
                 uint64_t free0 = 0, free1 = 0;                            // the sockets' free sets as this pod found them (stage 2 picks from them)
                 const bool smt_node = (st.p2.flags & NHDFIT_NF_SMT) != 0;
@@ -923,6 +946,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 ++cache_next;
                 if (lane == 0) wg_store(&s_ctag[sp * kSpecCache + cache_next % kSpecCache], kNoNode);     // the entry worked in next
                 // stage 2, off the chain: the batches' picks (placement record) and thread 1's bits
+                __builtin_amdgcn_s_setprio(1);
                 uint64_t clear0 = 0, clear1 = 0;
                 if (!(kTuning && (q.dbg & 2))) {
                     const int st2 = commit_picks_wave(free0, free1, smt_node, rq, mp, pl, lane, clear0, clear1);

@@ -272,6 +272,28 @@ class Engine:
     def comm_destroy(self):
         self._chk(self.lib.nhdfit_comm_destroy(self.ctx))
 
+    def comm_rank(self):
+        """(rank, ranks) of the context's communicator; (0, 1) without one."""
+        r, n = ctypes.c_int(0), ctypes.c_int(1)
+        self._chk(self.lib.nhdfit_comm_rank(self.ctx, ctypes.byref(r), ctypes.byref(n)))
+        return r.value, n.value
+
+    def comm_sendrecv(self, send: np.ndarray, dst: int, recv: np.ndarray, src: int) -> None:
+        """One grouped ncclSend / ncclRecv over the context's communicator (nhdfit_comm_sendrecv): `send` goes to rank `dst`,
+        `recv` is filled from rank `src`; either may be None (with its peer -1)."""
+        if send is not None:
+            send = np.ascontiguousarray(send)
+        if recv is not None and not recv.flags["C_CONTIGUOUS"]:
+            raise ValueError("recv buffer must be contiguous")
+        self._chk(self.lib.nhdfit_comm_sendrecv(self.ctx, send.ctypes.data if send is not None else None, send.nbytes if send is not None else 0, int(dst),
+                                                recv.ctypes.data if recv is not None else None, recv.nbytes if recv is not None else 0, int(src)))
+
+    def comm_allreduce_sum_u8(self, buf: np.ndarray) -> None:
+        """In-place element-wise sum of a contiguous uint8 array over the ranks (nhdfit_comm_allreduce_sum_u8)."""
+        if buf.dtype != np.uint8 or not buf.flags["C_CONTIGUOUS"]:
+            raise ValueError("a contiguous uint8 array")
+        self._chk(self.lib.nhdfit_comm_allreduce_sum_u8(self.ctx, buf.ctypes.data, buf.nbytes))
+
 
 class _ShardView(Engine):
     """An Engine whose context belongs to a group (the group destroys it)."""

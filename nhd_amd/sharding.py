@@ -1,7 +1,10 @@
 """Node-axis sharding across GPUs: contiguous blocks of the candidate order, pods replicated,
 winners picked by a max-reduction of the packed score words (inside libnhdfit: RCCL, `nhdfit_comm_init` for one
 process per GPU, `nhdfit_group_find` for one process driving several GPUs).  This module holds the host-side
-arithmetic around it: shard bounds and the order-preserving uint64 <-> int64 map (for reducers without uint64 MAX).
+arithmetic around it: shard bounds, the order-preserving uint64 <-> int64 map (for reducers without uint64 MAX), and mode B
+with one process per GPU (`schedule_batch_sharded`) over a plain transport object - `RcclTransport` is the product's: the
+communicator of the rank's own context behind the C-ABI (nhdfit_comm_sendrecv / nhdfit_comm_allreduce_sum_u8: RCCL over xGMI).
+Nothing here imports torch.
 """
 from __future__ import annotations
 
@@ -31,8 +34,28 @@ def from_ordered_int64(x: np.ndarray) -> np.ndarray:
     return x.view(np.uint64) ^ SIGN
 
 
-def schedule_batch_sharded(engine, reqs: np.ndarray, now: float, packer, nogpu_words: np.ndarray, dist, apply: bool = True,
-                           chunk: int = 512, device: str = "cpu"):
+class RcclTransport:
+    """Rank-to-rank traffic over the communicator of this rank's context (`Engine.comm_init`): ncclSend / ncclRecv and
+    ncclAllReduce behind the C-ABI.  The interface `schedule_batch_sharded` needs of any transport:
+        rank, world                              ints
+        sendrecv(send, dst, recv, src)           `send` (contiguous ndarray) to rank dst while `recv` is filled from rank src;
+                                                 every rank calls it at the same point of the algorithm (a ring step)
+        allreduce_sum_u8(buf)                    in-place element-wise sum of a uint8 array over the ranks
+    (tests drive the same algorithm over gloo with workload.dist.TorchTransport and the host twin per shard)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.rank, self.world = engine.comm_rank()
+
+    def sendrecv(self, send: np.ndarray, dst: int, recv: np.ndarray, src: int) -> None:
+        self.engine.comm_sendrecv(send, dst, recv, src)
+
+    def allreduce_sum_u8(self, buf: np.ndarray) -> None:
+        self.engine.comm_allreduce_sum_u8(buf)
+
+
+def schedule_batch_sharded(engine, reqs: np.ndarray, now: float, packer, nogpu_words: np.ndarray, transport=None, apply: bool = True,
+                           chunk: int = 512):
     """Mode B with one process per GPU: every rank holds an :class:`nhd_amd.engine.Engine` with its
     contiguous node shard (global_base set) and calls this collectively with the same `reqs`.  Returns the decisions of the
     one-by-one scheduler loop over the WHOLE cluster (nhd/NHDScheduler.py:425-437 with Matcher.SelectNode's order,
@@ -43,22 +66,25 @@ def schedule_batch_sharded(engine, reqs: np.ndarray, now: float, packer, nogpu_w
     pass (nhdfit_schedule_batch with its GPU-less nodes as candidates) hands the pods it could not place to the next rank.
     What is left of them at the last rank, and the pods with GPUs, then walk the shards over all nodes in the same manner
     (walk 2): a pod reaches shard s iff no node of the shards before could take it at its turn, shard s's state depends only
-    on the pods placed there before, and a GPU-less node that refused a pod has only lost resources since.
+    on the pods placed there before, and a GPU-less node that refused a pod has only lost resources since - walk 2 therefore
+    only ever places on nodes with GPUs, walk 1 on nodes without: the two walks never meet on a node.
 
-    Both walks are PIPELINED over slices of `chunk` pods in the caller's order: rank k works on slice c while rank k+1 works
-    on what rank k left of slice c-1, so the batch costs about one rank's passes over it plus the pipeline's fill, not the sum
-    of all ranks' passes (a shard's decisions for a slice depend only on the earlier slices' pods offered to it - the order of
-    the walk inside a shard is kept).  Walk 1 of every slice runs first on each rank, then walk 2: the two touch disjoint node
-    sets except for the left-over GPU-less pods, which walk 2 receives from the last rank before it starts on their slice.
-
-    Traffic: the pods a rank could not place travel to the next rank as ONE fixed-size int32 tensor per slice and walk
-    (`dist.isend` / `dist.recv`, 4 * (chunk + 1) bytes); the results meet in ONE `dist.all_reduce(SUM)` of a byte buffer at
-    the end - every pod is placed by at most one rank, all others contribute zeros.  No pickled objects.  `dist` is
-    torch.distributed (gloo: `device="cpu"`; nccl = RCCL: `device="cuda"`).  `nogpu_words`: this shard's nodes without a GPU
-    installed, one bit per node ([chunks] uint64 words).  apply=False restores this rank's shard afterwards."""
-    import torch
+    A RING IN LOCK STEP over slices of `chunk` pods in the caller's order.  The 2 * world stations of a slice are rank 0 ..
+    world - 1 in walk 1, then rank 0 .. world - 1 in walk 2; slice c is at station j in tick c + j.  In every tick a rank
+    runs its walk-1 station (slice t - rank) and its walk-2 station (slice t - rank - world), then ONE exchange: what both
+    passes left goes to the next rank while the previous rank's arrives (`transport.sendrecv`, one fixed-size int32 buffer of
+    two slots - the last rank's walk-1 left-overs are rank 0's walk-2 input, merged in the caller's order with the slice's
+    pods with GPUs).  Rank k thus works on slice c while rank k + 1 works on what rank k left of slice c - 1: the batch costs
+    about one rank's passes over it plus the ring's fill, not the sum of all ranks' passes; and every rank makes the same
+    sequence of exchanges whatever the pods do - nothing to dead-lock on, nothing to match up by hand (round 4 sent tensors
+    with torch.distributed.isend from inside this package).  The results meet in ONE `transport.allreduce_sum_u8` of a byte
+    buffer - every pod is placed by at most one rank, all others contribute zeros.  `transport`: see RcclTransport (default:
+    the engine's own communicator).  `nogpu_words`: this shard's nodes without a GPU installed, one bit per node ([chunks]
+    uint64 words).  apply=False restores this rank's shard afterwards."""
     from . import pack as _pack
-    rank, world = dist.get_rank(), dist.get_world_size()
+    if transport is None:
+        transport = RcclTransport(engine)
+    rank, world = int(transport.rank), int(transport.world)
     reqs = np.ascontiguousarray(reqs)
     P = len(reqs)
     chunk = max(1, int(chunk))
@@ -71,7 +97,8 @@ def schedule_batch_sharded(engine, reqs: np.ndarray, now: float, packer, nogpu_w
     touched = None
     mask_nogpu = np.ascontiguousarray(nogpu_words, dtype=np.uint64)
     slices = [np.arange(a, min(P, a + chunk), dtype=np.int64) for a in range(0, P, chunk)]
-    pending = []                                          # (request, tensor) of sends in flight: both stay alive until waited for
+    S = len(slices)
+    empty = np.zeros(0, np.int64)
 
     def run(pods: np.ndarray, gpu_less_nodes_only: bool) -> np.ndarray:
         """This shard's sequential pass over `pods` (ascending); returns the pods it could not place."""
@@ -88,54 +115,41 @@ def schedule_batch_sharded(engine, reqs: np.ndarray, now: float, packer, nogpu_w
             touched = (a, b) if touched is None else (min(a, touched[0]), max(b, touched[1]))
         return pods[~got]
 
-    def send(dst: int, pods: np.ndarray) -> None:
-        buf = torch.full((chunk + 1,), -1, dtype=torch.int32)
-        buf[0] = len(pods)
-        if len(pods):
-            buf[1:1 + len(pods)] = torch.from_numpy(pods.astype(np.int32))
-        buf = buf.to(device)
-        pending.append((dist.isend(buf, dst), buf))
+    slot = chunk + 1                                      # a slot: count, then the pods (caller's indices)
+    out_buf = np.zeros(2 * slot, np.int32)
+    in_buf = np.zeros(2 * slot, np.int32)
 
-    def recv(src: int) -> np.ndarray:
-        buf = torch.empty(chunk + 1, dtype=torch.int32, device=device)
-        dist.recv(buf, src)
-        host = buf.cpu().numpy()
-        return host[1:1 + int(host[0])].astype(np.int64)
+    def put(k: int, pods: np.ndarray) -> None:
+        out_buf[k * slot] = len(pods)
+        out_buf[k * slot + 1:k * slot + 1 + len(pods)] = pods
 
-    # walk 1: pods without GPUs over the nodes without GPUs, slice by slice down the ranks
-    left_over = []                                        # rank 0 only: what the last rank could not place, per slice
-    for sl in slices:
-        pods = sl[~wants_gpu[sl]] if rank == 0 else recv(rank - 1)
-        left = run(pods, True)
-        if rank + 1 < world:
-            send(rank + 1, left)
-        elif world > 1:
-            send(0, left)                                 # the last rank's left-overs start walk 2 at rank 0
-        else:
-            left_over.append(left)
-    # walk 2: pods with GPUs and the left-overs of walk 1, in the caller's order, over all nodes
-    for c, sl in enumerate(slices):
-        if rank == 0:
-            left = left_over[c] if world == 1 else recv(world - 1)
-            pods = np.sort(np.concatenate([sl[wants_gpu[sl]], left]))
-        else:
-            pods = recv(rank - 1)
-        left = run(pods, False)
-        if rank + 1 < world:
-            send(rank + 1, left)
-    for req, _ in pending:
-        req.wait()
+    def get(k: int) -> np.ndarray:
+        return in_buf[k * slot + 1:k * slot + 1 + int(in_buf[k * slot])].astype(np.int64)
+
+    in1 = in2 = empty                                     # what the previous rank left of the slices this rank meets next
+    for t in range(S + 2 * world - 1):
+        left1 = left2 = empty
+        c1, c2 = t - rank, t - rank - world
+        if 0 <= c1 < S:                                   # walk 1: pods without GPUs over the nodes without GPUs
+            sl = slices[c1]
+            left1 = run(sl[~wants_gpu[sl]] if rank == 0 else in1, True)
+        if 0 <= c2 < S:                                   # walk 2: pods with GPUs and walk 1's left-overs, in the caller's order, over all nodes
+            sl = slices[c2]
+            left2 = run(np.sort(np.concatenate([sl[wants_gpu[sl]], in1])) if rank == 0 else in2, False)
+        put(0, left1)
+        put(1, left2)
+        transport.sendrecv(out_buf, (rank + 1) % world, in_buf, (rank - 1) % world)
+        in1, in2 = get(0), get(1)                         # (rank 0: slot 0 = the last rank's walk-1 left-overs; its slot 1 - pods no node takes - is dropped)
 
     # every pod was placed by at most one rank: the element-wise sum of the ranks' (zero-initialised) results is the result
     if world > 1:
         parts = [node1.view(np.uint8), maps.view(np.uint8).reshape(-1), places.view(np.uint8).reshape(-1), status.view(np.uint8)]
-        flat = torch.from_numpy(np.concatenate(parts)).to(device)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        host = flat.cpu().numpy()
+        flat = np.ascontiguousarray(np.concatenate(parts))
+        transport.allreduce_sum_u8(flat)
         at = 0
         for arr in (node1, maps, places, status):
             nbytes = arr.nbytes
-            arr.view(np.uint8).reshape(-1)[:] = host[at:at + nbytes]
+            arr.view(np.uint8).reshape(-1)[:] = flat[at:at + nbytes]
             at += nbytes
     if saved is not None and touched is not None:
         a, b = touched

@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_lib._SIGS)
-    assert lib.nhdfit_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.nhdfit_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_struct_sizes_match_header():

@@ -80,9 +80,15 @@ from tests.test_bench_dryrun import DryEngine
 import nhd_amd.engine as eng_mod
 
 class ShardedDry(DryEngine):
+    # the communicator of the host twin: the C-ABI's rank-to-rank entry points (RCCL on the device) over gloo
     def unique_id(self): return b"\0" * 128
-    def comm_init(self, nranks, rank, uid): self.nranks = nranks
+    def comm_init(self, nranks, rank, uid):
+        from workload.dist import TorchTransport
+        self.nranks = nranks; self._tt = TorchTransport()
     def comm_destroy(self): pass
+    def comm_rank(self): return self._tt.rank, self._tt.world
+    def comm_sendrecv(self, send, dst, recv, src): self._tt.sendrecv(send, dst, recv, src)
+    def comm_allreduce_sum_u8(self, buf): self._tt.allreduce_sum_u8(buf)
 
 eng_mod.Engine = ShardedDry
 sys.argv = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--nodes-per-gpu", "512", "--pods", "40"]

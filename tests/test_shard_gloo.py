@@ -83,7 +83,7 @@ def _worker_mode_b(rank, world, port, cfg, n, P, out_dir, chunk=512):
     bits = np.zeros(((hi - lo + 63) // 64) * 64, np.uint8)
     bits[:hi - lo] = (sub.n_gpus == 0)
     nogpu = np.packbits(bits, bitorder="little").view(np.uint64).copy()
-    node, maps, places, status = shard.schedule_batch_sharded(eng, reqs, spec.clock_now, pk, nogpu, dist, apply=True, chunk=chunk)
+    node, maps, places, status = shard.schedule_batch_sharded(eng, reqs, spec.clock_now, pk, nogpu, dist_util.TorchTransport(dist), apply=True, chunk=chunk)
     np.save(os.path.join(out_dir, f"node{rank}.npy"), node)
     np.save(os.path.join(out_dir, f"maps{rank}.npy"), maps.view(np.int8))
     np.save(os.path.join(out_dir, f"places{rank}.npy"), places.view(np.uint8))
@@ -96,9 +96,10 @@ def _worker_mode_b(rank, world, port, cfg, n, P, out_dir, chunk=512):
 @pytest.mark.parametrize("cfg,n,P,world,chunk", [(4, 256, 200, 2, 512), (5, 256, 100, 3, 512), (4, 192, 160, 3, 512), (2, 128, 160, 2, 512),
                                                   (4, 256, 200, 2, 48), (5, 256, 100, 3, 37), (4, 192, 160, 3, 16)])
 def test_mode_b_one_process_per_shard_equals_the_scheduler_loop(tmp_path, cfg, n, P, world, chunk):
-    """nhd_amd.sharding.schedule_batch_sharded under gloo (host twin per shard): every rank ends up with the decisions,
-    mappings and physical ids the oracle's one-by-one loop over the WHOLE cluster produces - with the batch in one slice and
-    pipelined down the ranks in several (fixed-size tensors rank to rank, one all-reduce of the results; no pickles)."""
+    """nhd_amd.sharding.schedule_batch_sharded under gloo (host twin per shard; the product's ring over workload.dist.TorchTransport
+    instead of RcclTransport): every rank ends up with the decisions, mappings and physical ids the oracle's one-by-one loop over
+    the WHOLE cluster produces - with the batch in one slice and in several (one fixed-size buffer per ring step, one all-reduce
+    of the results)."""
     from oracle import nhd_oracle as O
     port = _free_port()
     mp.spawn(_worker_mode_b, args=(world, port, cfg, n, P, str(tmp_path), chunk), nprocs=world, join=True)
