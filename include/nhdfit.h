@@ -325,6 +325,9 @@ typedef struct {
                                    independent pipelines on as many streams - a launch's HIP-event duration then overlaps its
                                    neighbour's, and throughput is pipes x (work per launch) / duration                          */
     uint32_t small_finds;       /* nhdfit_find calls answered by the single-launch form (at most one pod tile, no verdict matrix) */
+    uint32_t big_nic_steps_max; /* nhdfit_big_find: the most NIC-search steps any (pod, node) pair took since the last reset - to be read against
+                                   NHDFIT_BIG_NIC_BUDGET, at which a call fails (ABI 9) */
+    uint32_t pad;
 } nhdfit_stats;
 
 typedef struct nhdfit_ctx nhdfit_ctx;

@@ -18,7 +18,8 @@ struct BigEvalArgs {
     const double* caps; double busy_from;
     const uint64_t* cand;                          // optional [chunks] candidate nodes
     unsigned long long* score; uint64_t global_base;
-    uint32_t* flags;                               // [0] a set of the model outgrew its table, [1] a (pod, node) pair ran out of NIC search budget
+    uint32_t* flags;                               // [0] a set of the model outgrew its table, [1] a (pod, node) pair ran out of NIC search budget,
+                                                   // [2] the most search steps any (pod, node) pair of the call took
 };
 
 __global__ __launch_bounds__(64) void k_big_eval(BigEvalArgs a) {
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(64) void k_big_eval(BigEvalArgs a) {
             NicSearch ns{NHDFIT_BIG_NIC_BUDGET, false};
             const bool ok = wide_fits(view, r, view.busy_time >= a.busy_from, a.caps, &ns);
             if (ns.exhausted) atomicOr(&a.flags[1], 1u);
+            if (ns.left != NHDFIT_BIG_NIC_BUDGET) atomicMax(&a.flags[2], NHDFIT_BIG_NIC_BUDGET - ns.left);   // the deepest NIC search of the call (nhdfit_stats)
             if (ok) {
                 uint32_t want = 0;
                 for (uint32_t g = 0; g < r.n_groups; ++g) want += r.gpus[g];
@@ -58,12 +60,16 @@ struct BigMapArgs {
     nhdfit_big_mapping* out;
     int32_t* scratch;                              // [workers][stride]: the set tables of one mapping each (wide_core.h big_scratch_words)
     size_t stride; int32_t slots_g, slots_c; uint32_t workers;
+    uint32_t lds_tables;                           // the set tables of a mapping fit the block's LDS (launched with stride * 4 bytes of it)
     uint32_t* flags;
 };
 __global__ __launch_bounds__(64) void k_big_map(BigMapArgs a) {
+    extern __shared__ __align__(16) int32_t s_tables[];
     const uint32_t tid = blockIdx.x;                // one worker per wavefront, its first lane: the set model is one long serial walk, and
     if (threadIdx.x != 0 || tid >= a.workers) return;   // lanes walking different pods' sets would only take turns inside a wavefront
-    int32_t* scratch = a.scratch + (size_t)tid * a.stride;
+    // The walk is a chain of dependent probes into the sets' tables: in LDS when they fit (two sockets, eight groups: 28 KB - a probe
+    // costs an LDS round trip instead of one to L2; round 5), in the call's scratch memory otherwise (nodes with more sockets)
+    int32_t* scratch = a.lds_tables ? s_tables : a.scratch + (size_t)tid * a.stride;
     for (uint32_t i = tid; i < a.P; i += a.workers) {
         nhdfit_big_mapping m;
         for (int g = 0; g < NHDFIT_BIG_MAX_GROUPS; ++g) { m.gpu[g] = m.nic_numa[g] = m.nic_idx[g] = -1; }

@@ -578,10 +578,12 @@ int nhdfit_set_dictionary(nhdfit_ctx* c, uint32_t max_cores_per_numa, uint32_t m
     c->max_cores = max_cores_per_numa;
     c->max_gpus = max_gpus_per_numa;
     c->P = 0;                                       // staged tables (if any) were built for the old dictionary
+#ifdef NHDFIT_TUNING
     HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_only<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_fit_only<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_role<512, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_role<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
     HIPCHK(c, hipFuncSetAttribute((const void*)k_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_find<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_find1<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -710,6 +712,28 @@ int refresh_layouts(nhdfit_ctx* c) {
 }
 }  // namespace
 
+namespace {
+// The order a call's pods are staged in (perm[k] = caller's index of the pod at device position k): a function of the requests
+// alone.  It is also the order in which EVERY form of a sharded find hands its score words to the all-reduce - the staged step and
+// the single-launch find alike - so that ranks that take different forms for the same call (one shard holds a wide node, spilled
+// class rows, a launch that gave up: rank-local facts) still reduce pod against pod.
+void staged_order(const nhdfit_req* reqs, uint32_t P, std::vector<uint32_t>& perm) {
+    perm.resize(P);
+    std::vector<uint16_t> key(P);
+    uint32_t start[512 + 1] = {0};
+    for (uint32_t p = 0; p < P; ++p) {
+        const PodHeader h = pod_header(reqs[p]);
+        // group count is the major key, descending: the tiles with the most assignments to sweep are the
+        // first blocks of the fit grid (longest-first keeps the tail of the launch short)
+        key[p] = (uint16_t)(((h.flags & kPodValid) ? 0u : 1u << 8) | ((reqs[p].n_groups > 3 ? 1u : 0u) << 7) |
+                            ((15u - (reqs[p].n_groups & 15u)) << 3) | ((h.flags & (kPodNeedGpu | kPodPci | kPodFilter)) >> 1));
+        start[key[p] + 1]++;
+    }
+    for (uint32_t k = 0; k < 512; ++k) start[k + 1] += start[k];          // stable counting sort: 9-bit keys
+    for (uint32_t p = 0; p < P; ++p) perm[start[key[p]]++] = p;
+}
+}  // namespace
+
 int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     if (!c) return NHDFIT_E_INVAL;
     if (!reqs || !P) return fail(c, NHDFIT_E_INVAL, "no requests");
@@ -742,21 +766,9 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
         }
     // Pods are staged sorted by request class so that 64-pod tiles are homogeneous (narrow table rows, fast sweep of
     // the fit role) and the lanes of the mapping roles have similar group counts; results are un-permuted in fetch.
-    c->perm.resize(P);
-    std::vector<uint16_t> key(P);
     c->n_big_pods = 0;
-    uint32_t start[512 + 1] = {0};
-    for (uint32_t p = 0; p < P; ++p) {
-        const PodHeader h = pod_header(reqs[p]);
-        // group count is the major key, descending: the tiles with the most assignments to sweep are the
-        // first blocks of the fit grid (longest-first keeps the tail of the launch short)
-        key[p] = (uint16_t)(((h.flags & kPodValid) ? 0u : 1u << 8) | ((reqs[p].n_groups > 3 ? 1u : 0u) << 7) |
-                            ((15u - (reqs[p].n_groups & 15u)) << 3) | ((h.flags & (kPodNeedGpu | kPodPci | kPodFilter)) >> 1));
-        c->n_big_pods += reqs[p].n_groups > 3;
-        start[key[p] + 1]++;
-    }
-    for (uint32_t k = 0; k < 512; ++k) start[k + 1] += start[k];          // stable counting sort: 9-bit keys
-    for (uint32_t p = 0; p < P; ++p) c->perm[start[key[p]]++] = p;
+    for (uint32_t p = 0; p < P; ++p) c->n_big_pods += reqs[p].n_groups > 3;
+    staged_order(reqs, P, c->perm);
     HIPCHK(c, c->pin_reqs.reserve(P));
     nhdfit_req* sorted = c->pin_reqs.p;                                   // (free again: sync_all above waited for the last copy out of it)
     for (uint32_t i = 0; i < P; ++i) sorted[i] = reqs[c->perm[i]];
@@ -1111,6 +1123,7 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
         if (big) hipLaunchKernelGGL((k_step<512, true>), dim3(grid), dim3(512), lds, p.stream, a);
         else     hipLaunchKernelGGL((k_step<256, true>), dim3(grid), dim3(256), lds, p.stream, a);
     } else
+#ifdef NHDFIT_TUNING         // (role_kernels / split are switched by the tuning build's environment only: never set in libnhdfit.so)
     if (c->role_kernels) {
         const uint32_t nb[5] = {a.nb_choose, a.nb_shapes, a.nb_finish, a.nb_digest, nb_fit};
         if (nb[0]) hipLaunchKernelGGL((k_role<512, 0>), dim3(nb[0]), dim3(512), 0, p.stream, a);
@@ -1123,6 +1136,7 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
         if (big) hipLaunchKernelGGL((k_fit_only<512>), dim3(grid), dim3(512), lds, p.stream, a.fit);
         else     hipLaunchKernelGGL((k_fit_only<256>), dim3(grid), dim3(256), lds, p.stream, a.fit);
     } else
+#endif
     if (big) hipLaunchKernelGGL((k_step<512>), dim3(grid), dim3(512), lds, p.stream, a);
     else     hipLaunchKernelGGL((k_step<256>), dim3(grid), dim3(256), lds, p.stream, a);
     HIPCHK(c, hipGetLastError());
@@ -1485,16 +1499,23 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
         // (<= 64 words) picks the cluster's winner, and a rank that does not own it drops its mapping - exactly what the
         // staged path returns (its mapping roles skip winners outside the shard).  All on the reduce stream: the launch is
         // over (the host saw its flag), and the communicator's collectives stay on one stream.
+        // The words travel in the STAGED order of the call's pods (staged_order): whether a rank takes this form or the staged
+        // step is decided by rank-local facts (a wide node in its shard, spilled class rows, a launch that gave up), so the two
+        // forms must pair the same pods in the one collective they both issue per call.
         HIPCHK(c, c->find_red.reserve(kTile));
-        HIPCHK(c, c->pin_score.reserve(kTile));
-        HIPCHK(c, hipMemcpyAsync(c->find_red.p, h->score, (size_t)P * 8, hipMemcpyHostToDevice, c->s_red));
+        HIPCHK(c, c->pin_score.reserve(2 * kTile));
+        staged_order(reqs, P, c->perm);
+        uint64_t* send = c->pin_score.p + kTile;
+        for (uint32_t k = 0; k < P; ++k) send[k] = h->score[c->perm[k]];
+        HIPCHK(c, hipMemcpyAsync(c->find_red.p, send, (size_t)P * 8, hipMemcpyHostToDevice, c->s_red));
         ncclResult_t r = g_rccl.AllReduce(c->find_red.p, c->find_red.p, P, ncclUint64, ncclMax, c->comm, c->s_red);
         if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
         HIPCHK(c, hipMemcpyAsync(c->pin_score.p, c->find_red.p, (size_t)P * 8, hipMemcpyDeviceToHost, c->s_red));
         HIPCHK(c, wait_stream(c->s_red));
-        for (uint32_t i = 0; i < P; ++i) {
-            if (c->pin_score.p[i] != h->score[i]) memset(&h->maps[i], 0, sizeof(nhdfit_mapping));
-            h->score[i] = c->pin_score.p[i];
+        for (uint32_t k = 0; k < P; ++k) {
+            const uint32_t i = c->perm[k];
+            if (c->pin_score.p[k] != h->score[i]) memset(&h->maps[i], 0, sizeof(nhdfit_mapping));
+            h->score[i] = c->pin_score.p[k];
         }
     }
     if (score_out) memcpy(score_out, h->score, (size_t)P * 8);
@@ -1664,15 +1685,18 @@ int nhdfit_big_find(nhdfit_ctx* c, const nhdfit_big_req* reqs, uint32_t P, doubl
         for (uint32_t i = 0; i < P; ++i) gmax = std::max(gmax, std::min<uint32_t>(reqs[i].n_groups, NHDFIT_BIG_MAX_GROUPS));
         const uint32_t umax = std::max<uint32_t>(NHDFIT_MAX_NUMA, c->n_wide ? c->wide_max_numa : 0);
         const size_t stride = big_scratch_words(umax, gmax);
+        const bool lds_tables = stride * sizeof(int32_t) <= 96 * 1024;
         const uint32_t workers = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(P, 128), ((size_t)1 << 28) / stride));
-        HIPCHK(c, c->big_scratch.reserve((size_t)workers * stride));
+        HIPCHK(c, c->big_scratch.reserve(lds_tables ? 1 : (size_t)workers * stride));
         BigMapArgs ma;
         memset(&ma, 0, sizeof ma);
         ma.p0 = c->p0.p; ma.p1 = c->p1.p; ma.p2 = c->p2.p; ma.p3 = c->p3.p; ma.p4 = c->p4.p; ma.det = c->det.p; ma.n = c->n;
         ma.wide = c->wide.p; ma.n_wide = c->n_wide; ma.reqs = c->big_reqs.p; ma.P = P; ma.caps = c->caps.p;
         ma.score = c->big_score.p; ma.global_base = c->global_base; ma.out = c->big_maps.p; ma.scratch = c->big_scratch.p; ma.flags = c->big_flags.p;
         ma.stride = stride; ma.slots_g = (int32_t)wide_table_slots(wide_ipow(umax, gmax)); ma.slots_c = (int32_t)wide_table_slots(wide_ipow(umax, gmax + 1)); ma.workers = workers;
-        hipLaunchKernelGGL(k_big_map, dim3(workers), dim3(64), 0, c->stream, ma);
+        ma.lds_tables = lds_tables ? 1u : 0u;
+        if (lds_tables) HIPCHK(c, hipFuncSetAttribute((const void*)k_big_map, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        hipLaunchKernelGGL(k_big_map, dim3(workers), dim3(64), lds_tables ? stride * sizeof(int32_t) : 0, c->stream, ma);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(map_out, c->big_maps.p, (size_t)P * sizeof *map_out, hipMemcpyDeviceToHost, c->stream));
     } else if (map_out) {
@@ -1682,6 +1706,7 @@ int nhdfit_big_find(nhdfit_ctx* c, const nhdfit_big_req* reqs, uint32_t P, doubl
     HIPCHK(c, hipMemcpyAsync(score_out, c->big_score.p, (size_t)P * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(fl, c->big_flags.p, sizeof fl, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, wait_stream(c->stream));
+    c->stats.big_nic_steps_max = std::max(c->stats.big_nic_steps_max, fl[2]);
     if (fl[1]) return fail(c, NHDFIT_E_LIMIT, "a big request's NIC stage ran out of search budget on some node (%u steps per pod and node)", (unsigned)NHDFIT_BIG_NIC_BUDGET);
     if (fl[0]) return fail(c, NHDFIT_E_LIMIT, "the set model of a big request's mapping outgrew its table");
     return NHDFIT_OK;
@@ -2378,6 +2403,7 @@ int nhdfit_reset_stats(nhdfit_ctx* c) {
     if (rc) return rc;
     c->stats.launches = 0;
     c->stats.fit_ms_total = 0;
+    c->stats.big_nic_steps_max = 0;
     return NHDFIT_OK;
 }
 

@@ -29,11 +29,13 @@ __device__ __forceinline__ void stamp(unsigned long long* role_clock, int role, 
     }
 }
 
+#ifdef NHDFIT_TUNING      // profiling aid of the tuning build (NHDFIT_SPLIT): the fit role as a launch of its own
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_fit_only(FitArgs a) {
     extern __shared__ __align__(16) uint8_t lds[];
     role_fit<BLOCK>(a, a.busy_from, blockIdx.x, lds);
 }
+#endif
 
 // ---- node records ------------------------------------------------------------------------------------
 // Everything the fit role needs from a node's five planes depends only on the mirror and the dictionary, not on the
@@ -289,7 +291,9 @@ __global__ __launch_bounds__(BLOCK, SPILL ? (BLOCK == 512 ? 4 : 5) : (BLOCK == 5
     step_body<BLOCK, SPILL>(a, a.fit.busy_from, lds);
 }
 
-// Profiling aid (NHDFIT_ROLE_KERNELS=1): one role per launch, so that rocprofv3 --stats names each role's stand-alone time.
+#ifdef NHDFIT_TUNING
+// Profiling aid of the tuning build (NHDFIT_ROLE_KERNELS=1): one role per launch, so that rocprofv3 --stats names each role's
+// stand-alone time.  Not in libnhdfit.so.
 template <int BLOCK, int ROLE>
 __global__ __launch_bounds__(BLOCK, 6) void k_role(StepArgs a) {
     extern __shared__ __align__(16) uint8_t lds[];
@@ -305,6 +309,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_role(StepArgs a) {
     else if constexpr (ROLE == 3) role_digest<BLOCK>(a.digest, blk, lds);
     else role_fit<BLOCK>(a.fit, a.fit.busy_from, blk, lds);
 }
+#endif
 
 // ---- one launch for a small find ---------------------------------------------------------------------
 // nhdfit_find for at most one pod tile (the scheduler's pod-at-a-time FindNode): the five roles of a step in ONE launch
