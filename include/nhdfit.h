@@ -435,7 +435,9 @@ int nhdfit_find_sequential(nhdfit_ctx* ctx, const nhdfit_req* reqs, uint32_t P, 
  *              id for (status NHDFIT_COMMIT_NEW_SIG on one or more pods of [0, n_done)): intern the state, patch those
  *              nodes (nhdfit_download_nodes / nhdfit_set_dictionary / nhdfit_upload_nodes) and submit the remaining pods
  *              as a new batch - with apply != 0 the mirror already holds the placements made so far.  With the
- *              signature closure interned up front (nhd_amd.pack.Packer.close_signatures) this never happens. */
+ *              signature closure interned up front (nhd_amd.pack.Packer.close_signatures) this never happens.
+ * The batch is decided on THIS context's nodes, with a communicator attached too (no collective inside): across shards the
+ * loop's first-fit order is kept by handing the pods a shard could not place to the next rank, nhdfit_comm_sendrecv. */
 int nhdfit_schedule_batch(nhdfit_ctx* ctx, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand, int apply,
                           int64_t* node_out, nhdfit_mapping* map_out, nhdfit_placement* place_out, int32_t* status_out,
                           uint32_t* n_done);

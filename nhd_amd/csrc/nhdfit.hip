@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -283,6 +284,7 @@ struct nhdfit_ctx {
     // collective
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
+    bool warned_general_loop = false;
     DevBuf<uint8_t> xfer_send, xfer_recv;   // nhdfit_comm_sendrecv / nhdfit_comm_allreduce_sum_u8: device staging of the host buffers
 };
 
@@ -1763,6 +1765,12 @@ int schedule_batch_general(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, do
                            int64_t* node_out, nhdfit_mapping* map_out, nhdfit_placement* place_out, int32_t* status_out, uint32_t* n_done) {
     struct Saved { uint32_t node; nhdfit_plane0 p0; nhdfit_plane1 p1; nhdfit_plane2 p2; nhdfit_plane3 p3; nhdfit_plane4 p4; nhdfit_detail det; };
     std::vector<Saved> saved;                                   // first-touch copies of ordinary nodes (apply = 0)
+    std::set<uint32_t> saved_nodes;
+    if (!c->warned_general_loop) {                              // (once per context: the whole cluster pays for its wide nodes here)
+        c->warned_general_loop = true;
+        fprintf(stderr, "[nhdfit] the mirror holds %u node(s) beyond the fast layout: nhdfit_schedule_batch runs the scheduler's loop pod by pod "
+                        "(a find and a commit each) instead of the decision engine\n", c->n_wide);
+    }
     std::vector<nhdfit_wide_node> wide_before(c->n_wide);
     if (!apply && c->n_wide) {
         uint32_t nw = 0;
@@ -1798,9 +1806,7 @@ int schedule_batch_general(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, do
             continue;
         }
         if (!apply) {
-            bool seen = false;
-            for (const Saved& sv : saved) seen = seen || sv.node == v;
-            if (!seen) {
+            if (saved_nodes.insert(v).second) {
                 Saved sv; sv.node = v;
                 if ((rc = nhdfit_download_nodes(c, v, 1, &sv.p0, &sv.p1, &sv.p2, &sv.p3, &sv.p4, &sv.det))) break;
                 saved.push_back(sv);
@@ -1832,8 +1838,18 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
                           int64_t* node_out, nhdfit_mapping* map_out, nhdfit_placement* place_out, int32_t* status_out,
                           uint32_t* n_done) {
     if (!c) return NHDFIT_E_INVAL;
-    if (c->comm) return fail(c, NHDFIT_E_STATE, "sequential (mode B) batches are single-shard: detach the communicator");
     if (!node_out || !n_done) return fail(c, NHDFIT_E_INVAL, "node_out / n_done is NULL");
+    // A sequential batch is decided on THIS context's nodes alone - with a communicator attached too: it is the per-shard pass of
+    // mode B across shards (nhd_amd/sharding.py hands the pods a shard could not place to the next rank), so its snapshot step
+    // must not all-reduce its scores with ranks that are working on other slices.  (Round 4 refused the call outright; the ring's
+    // first run on real ranks would have ended there - found by the rank-to-rank GPU test of round 5.)
+    struct CommOff {
+        nhdfit_ctx* c; ncclComm_t saved;
+        explicit CommOff(nhdfit_ctx* c_) : c(c_), saved(c_->comm) { c->comm = nullptr; }
+        ~CommOff() { c->comm = saved; }
+    };
+    if (c->comm) { int rc_ = sync_all(c); if (rc_) return rc_; }   // (steps of a staged batch still carry their all-reduce)
+    CommOff comm_off(c);
     if (!std::isfinite(now)) return fail(c, NHDFIT_E_INVAL, "now must be finite (a placed node is busy at `now`)");
     HIPCHK(c, hipSetDevice(c->dev));
     c->wide_places_last.clear();

@@ -488,6 +488,10 @@ class HipMatcher:
                 big_reqs[int(i)] = wire.digest_config_big(cfg_texts[int(i)])       # (raises what the limit really is beyond that)
             else:                                            # what the reference would raise on: report it properly
                 wire.digest_config(cfg_texts[int(i)])
+        # a hugepage request beyond the tile's table digests without a code: such a pod is a big request too, as FindNodes(tops)
+        # routes it (pack.needs_general_path) - staged with the others it would fail the whole call with NHDFIT_E_LIMIT
+        for i in np.flatnonzero((codes == 0) & (reqs["hugepages_gb"] > pack.MAX_HUGEPAGES_GB)):
+            big_reqs[int(i)] = wire.digest_config_big(cfg_texts[int(i)])
         skip = codes == wire.WIRE_NONE                       # all-zero (= never matching) requests
         # (the pods' group bits are filled in by _run, after the mirror - and with it the dictionary - is current)
         for i in np.flatnonzero(~skip):

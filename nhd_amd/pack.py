@@ -508,8 +508,13 @@ class Packer:
         pods_word = 0                                      # 32 three-bit counters (include/nhdfit.h)
         for nic in node.nics:
             u = nic.numa_node
-            if u >= U or u < 0:
-                continue                                   # invisible to the NIC stage (Node.py:293-294)
+            if u < 0:
+                # ninfo[n.numa_node] (nhd/Node.py:289-294) is Python indexing: -1 counts the NIC on the LAST NUMA node, while
+                # GetNicObjFromIndex (Node.py:657-661) compares the label's value itself - a node the reference answers for
+                # inconsistently is not mirrored (listed in HipMatcher.unmirrored) rather than answered differently
+                raise UnsupportedNode(f"node {node.name}: NIC with NUMA node {u}")
+            if u >= U:
+                continue                                   # invisible to the NIC stage (IndexError caught, Node.py:293-294)
             k = cnt[u]
             if k >= MAX_NICS_PER_NUMA:
                 raise UnsupportedNode(f"node {node.name}: more than {MAX_NICS_PER_NUMA} NICs on NUMA {u}")
@@ -621,8 +626,13 @@ class Packer:
         cnt = [0] * WIDE_MAX_NUMA
         for nic in node.nics:
             u = nic.numa_node
-            if u >= U or u < 0:
-                continue                                   # invisible to the NIC stage (Node.py:293-294)
+            if u < 0:
+                # ninfo[n.numa_node] (nhd/Node.py:289-294) is Python indexing: -1 counts the NIC on the LAST NUMA node, while
+                # GetNicObjFromIndex (Node.py:657-661) compares the label's value itself - a node the reference answers for
+                # inconsistently is not mirrored (listed in HipMatcher.unmirrored) rather than answered differently
+                raise UnsupportedNode(f"node {node.name}: NIC with NUMA node {u}")
+            if u >= U:
+                continue                                   # invisible to the NIC stage (IndexError caught, Node.py:293-294)
             k = cnt[u]
             if k >= MAX_NICS_PER_NUMA:
                 raise UnsupportedNode(f"node {node.name}: more than {MAX_NICS_PER_NUMA} NICs on NUMA {u}")

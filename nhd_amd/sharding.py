@@ -107,6 +107,12 @@ def schedule_batch_sharded(engine, reqs: np.ndarray, now: float, packer, nogpu_w
         if len(pods) == 0 or engine.n == 0 or (mask is not None and not mask.any()):
             return pods
         nd, mp_, pl, st = engine.schedule_batch(reqs[pods], now, packer, cand=mask, apply=True)
+        if (st == _pack.COMMIT_WIDE).any():
+            # a pod landed on a node beyond the fast layout: its physical ids live in the owning rank's wide placement records
+            # (Engine.last_wide_places), which this function does not carry to the other ranks - refuse rather than hand every
+            # rank an empty placement
+            raise NotImplementedError("schedule_batch_sharded: a pod was placed on a wide node (3-4 sockets / more than 64 cores per socket); "
+                                      "such shards take HipMatcher(devices=[...]).ScheduleBatch, which returns their placement records")
         got = nd >= 0
         idx = pods[got]
         node1[idx], maps[idx], places[idx], status[idx] = nd[got] + 1, mp_[got], pl[got], st[got]

@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/r05_step3
 mkdir -p $OUT
 cd $ROOT
 SECONDS=0
-timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider -s > $OUT/pytest_gpu.log 2>&1
+timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -s > $OUT/pytest_gpu.log 2>&1
 echo "pytest rc=$? seconds=$SECONDS" | tee -a $OUT/pytest_gpu.log
 grep -E "big pods at scale|passed|failed|Error|error" $OUT/pytest_gpu.log | tail -n 12
 timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_form.json 2> $OUT/bench_driver_form.err
