@@ -256,6 +256,19 @@ typedef struct {
     uint32_t node;                            /* ... and the local index of the node                    */
 } nhdfit_wide_placement;                      /* 480 bytes */
 
+/* ---- nhd/Node.py:20 ENABLE_SHARING = True (ABI 9) ----------------------------------------------------------------------------
+ * The shipped reference prices a NIC at its full capacity until a pod uses it, then at nothing (pods_used).  With the module
+ * constant flipped, GetFreeNumaNicResources (nhd/Node.py:289-291) prices it per direction at
+ *     n.speed * NIC_BW_AVAIL_PERCENT - n.speed_used[x]            x = 0 (rx), 1 (tx)
+ * and the commit step adds every RX / TX core's speed to speed_used (nhd/Node.py:754).  Such capacities are sums of whatever the
+ * pods asked for, not a handful of classes, so a cluster whose node module has the switch on is mirrored for the GENERAL path
+ * only: every node a wide record, and beside record k one nhdfit_wide_share with the NICs' speed_used as they are - the path's own
+ * f64 arithmetic then computes `capacity(nic_base) - used[x]` exactly as the reference does, before the per-group subtractions
+ * (wide_core.h).  nhdfit_wide_share_upload(NULL) switches a context back to the shipped arithmetic. */
+typedef struct {
+    double used[NHDFIT_WIDE_MAX_NUMA][NHDFIT_MAX_NICS_PER_NUMA][2];   /* Node.nics[..].speed_used[0 / 1] of NIC (numa, idx) */
+} nhdfit_wide_share;                              /* 1024 bytes */
+
 /* ---- pods with more than NHDFIT_MAX_GROUPS processing groups: the general path for requests ("big" requests) ---------------
  * The reference enumerates itertools.product(range(numa_nodes), repeat=len(req)) for whatever len(top.proc_groups) is
  * (nhd/Matcher.py:118,203,242).  The table-driven pass is built around masks over 2^G <= 16 assignments; a pod with 5..8
@@ -369,6 +382,11 @@ int nhdfit_set_node_count(nhdfit_ctx* ctx, uint32_t n_nodes);
  * replace whatever wide records the mirror held for that range (none: the range holds ordinary nodes only).  Call it for every
  * range nhdfit_upload_nodes is called for when the packer produced wide nodes (their planes carry the placeholder). */
 int nhdfit_wide_upload(nhdfit_ctx* ctx, uint32_t first, uint32_t count, const nhdfit_wide_node* wide, uint32_t n_wide);
+/* ENABLE_SHARING = True (nhd/Node.py:20, 289-291; see nhdfit_wide_share): record k = the NICs' speed_used of wide record k, for
+ * ALL wide records of the mirror, which must be all of its nodes; sent again after every nhdfit_wide_upload.  NULL: back to the
+ * shipped arithmetic.  nhdfit_wide_share_download reads them back as the device's commits left them. */
+int nhdfit_wide_share_upload(nhdfit_ctx* ctx, const nhdfit_wide_share* share, uint32_t n_wide);
+int nhdfit_wide_share_download(nhdfit_ctx* ctx, nhdfit_wide_share* out, uint32_t cap, uint32_t* n_wide);
 /* how many wide records the mirror holds / read them back (ascending index) */
 int nhdfit_wide_count(nhdfit_ctx* ctx, uint32_t* n_wide);
 int nhdfit_wide_download(nhdfit_ctx* ctx, nhdfit_wide_node* out, uint32_t cap, uint32_t* n_wide);

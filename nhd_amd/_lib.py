@@ -46,6 +46,8 @@ _SIGS = {
                                       POINTER(c_uint32)]),
     "nhdfit_commit": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_double, c_void_p]),
     "nhdfit_wide_upload": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_uint32]),
+    "nhdfit_wide_share_upload": (c_int, [c_void_p, c_void_p, c_uint32]),
+    "nhdfit_wide_share_download": (c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]),
     "nhdfit_wide_count": (c_int, [c_void_p, POINTER(c_uint32)]),
     "nhdfit_wide_download": (c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]),
     "nhdfit_wide_commit": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_double, c_void_p]),

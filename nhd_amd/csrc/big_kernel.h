@@ -20,6 +20,7 @@ struct BigEvalArgs {
     unsigned long long* score; uint64_t global_base;
     uint32_t* flags;                               // [0] a set of the model outgrew its table, [1] a (pod, node) pair ran out of NIC search budget,
                                                    // [2] the most search steps any (pod, node) pair of the call took
+    const nhdfit_wide_share* share;                // optional [n_wide]: ENABLE_SHARING arithmetic
 };
 
 __global__ __launch_bounds__(64) void k_big_eval(BigEvalArgs a) {
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(64) void k_big_eval(BigEvalArgs a) {
         if (listed && view.numa_nodes) {           // (a placeholder of the planes has no NUMA nodes: its record answers, further down the grid)
             const nhdfit_big_req& r = a.reqs[i];
             NicSearch ns{NHDFIT_BIG_NIC_BUDGET, false};
-            const bool ok = wide_fits(view, r, view.busy_time >= a.busy_from, a.caps, &ns);
+            const bool ok = wide_fits(view, r, view.busy_time >= a.busy_from, WideCaps(a.caps, a.share && v >= a.n ? a.share + (v - a.n) : nullptr), &ns);
             if (ns.exhausted) atomicOr(&a.flags[1], 1u);
             if (ns.left != NHDFIT_BIG_NIC_BUDGET) atomicMax(&a.flags[2], NHDFIT_BIG_NIC_BUDGET - ns.left);   // the deepest NIC search of the call (nhdfit_stats)
             if (ok) {
@@ -62,6 +63,7 @@ struct BigMapArgs {
     size_t stride; int32_t slots_g, slots_c; uint32_t workers;
     uint32_t lds_tables;                           // the set tables of a mapping fit the block's LDS (launched with stride * 4 bytes of it)
     uint32_t* flags;
+    const nhdfit_wide_share* share;                // optional [n_wide]
 };
 __global__ __launch_bounds__(64) void k_big_map(BigMapArgs a) {
     extern __shared__ __align__(16) int32_t s_tables[];
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(64) void k_big_map(BigMapArgs a) {
             const int slot = a.n_wide ? wide_slot_of(a.wide, a.n_wide, v) : -1;
             if (slot >= 0) view = a.wide[slot];
             else wide_view(a.p0[v], a.p1[v], a.p2[v], a.p3[v], a.p4[v], a.det[v], v, view);
-            const int rc = wide_map(view, a.reqs[i], a.caps, scratch, m, a.slots_g, a.slots_c);
+            const int rc = wide_map(view, a.reqs[i], WideCaps(a.caps, a.share && slot >= 0 ? a.share + slot : nullptr), scratch, m, a.slots_g, a.slots_c);
             if (rc < 0) { m.valid = 0; atomicOr(&a.flags[rc == -2 ? 1 : 0], 1u); }
         }
         a.out[i] = m;
@@ -95,6 +97,7 @@ struct BigCommitArgs {
     nhdfit_wide_node* wide; int slot;              // slot >= 0: the node is that wide record
     uint32_t node; nhdfit_big_req req; nhdfit_big_mapping map; double busy_time; SigTable sigs;
     nhdfit_big_placement* out;
+    nhdfit_wide_share* share;                      // optional [n_wide]
 };
 __global__ __launch_bounds__(64) void k_big_commit(BigCommitArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(64) void k_big_commit(BigCommitArgs a) {
     memset(&pl, 0, sizeof pl);
     if (a.slot >= 0) {
         nhdfit_wide_node n = a.wide[a.slot];
-        wide_commit(n, r, m, a.busy_time, pl);
+        wide_commit(n, r, m, a.busy_time, pl, a.share ? a.share + a.slot : nullptr);
         pl.pod = 0; pl.node = n.index;
         a.wide[a.slot] = n;
         *a.out = pl;

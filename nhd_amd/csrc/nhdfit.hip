@@ -263,6 +263,7 @@ struct nhdfit_ctx {
 
     // nodes beyond the fast layout (wide_core.h): records sorted by index; the device copy is the truth once commits ran on it
     DevBuf<nhdfit_wide_node> wide; uint32_t n_wide = 0;
+    DevBuf<nhdfit_wide_share> wide_share; bool sharing = false;   // ENABLE_SHARING arithmetic: one record beside every wide record (nhdfit_wide_share_upload)
     DevBuf<int16_t> wide_scratch; DevBuf<uint32_t> wide_flags; DevBuf<nhdfit_wide_placement> wide_place;
     std::vector<nhdfit_wide_placement> wide_places_last;   // placements the last nhdfit_schedule_batch made on wide nodes
     std::vector<uint32_t> wide_index;                      // host copy of the records' node indices (ascending)
@@ -454,7 +455,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->p0.release(); c->p1.release(); c->p2.release(); c->p3.release(); c->p4.release(); c->det.release();
     c->origin.release(); c->deltas.release(); c->delta_run.release(); c->delta_status.release();
-    c->wide.release(); c->wide_scratch.release(); c->wide_flags.release(); c->wide_place.release();
+    c->wide.release(); c->wide_share.release(); c->wide_scratch.release(); c->wide_flags.release(); c->wide_place.release();
     c->big_reqs.release(); c->big_score.release(); c->big_maps.release(); c->big_flags.release(); c->big_place.release();
     c->big_cand.release(); c->big_scratch.release();
     if (c->find_host) (void)hipHostFree(c->find_host);
@@ -1150,7 +1151,7 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
         wa.wide = c->wide.p; wa.n_wide = c->n_wide; wa.reqs = c->reqs.p; wa.P = P; wa.caps = c->caps.p; wa.busy_from = busy_threshold(now);
         wa.cand = c->use_cand ? c->cand.p : nullptr;
         wa.nm = c->want_bitmap ? reinterpret_cast<unsigned long long*>(p.nm.p) : nullptr; wa.chunks = chunks;
-        wa.score = p.score[bf].p; wa.global_base = c->global_base;
+        wa.score = p.score[bf].p; wa.global_base = c->global_base; wa.share = c->sharing ? c->wide_share.p : nullptr;
         const uint64_t pairs = (uint64_t)c->n_wide * P;
         hipLaunchKernelGGL(k_wide_eval, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, p.stream, wa);
         HIPCHK(c, hipGetLastError());
@@ -1326,7 +1327,7 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
         memset(&wm, 0, sizeof wm);
         wm.wide = c->wide.p; wm.n_wide = c->n_wide; wm.reqs = c->reqs.p; wm.P = P; wm.caps = c->caps.p;
         wm.score = p.score[b].p; wm.global_base = c->global_base; wm.n = c->n; wm.out = p.maps[b].p;
-        wm.scratch = c->wide_scratch.p; wm.flags = c->wide_flags.p;
+        wm.scratch = c->wide_scratch.p; wm.flags = c->wide_flags.p; wm.share = c->sharing ? c->wide_share.p : nullptr;
         hipLaunchKernelGGL(k_wide_map, dim3(kWideMapThreads), dim3(64), 0, p.stream, wm);
         HIPCHK(c, hipGetLastError());
         uint32_t fl[4] = {0, 0, 0, 0};
@@ -1609,10 +1610,35 @@ int nhdfit_wide_upload(nhdfit_ctx* c, uint32_t first, uint32_t count, const nhdf
     HIPCHK(c, c->wide.reserve(next.size() ? next.size() : 1));
     if (!next.empty()) HIPCHK(c, hipMemcpy(c->wide.p, next.data(), next.size() * sizeof next[0], hipMemcpyHostToDevice));
     c->n_wide = (uint32_t)next.size();
+    c->sharing = false;                                          // (speed_used records go with the wide records: sent again after them)
     c->wide_max_numa = 0;
     for (const auto& w : next) c->wide_max_numa = std::max<uint32_t>(c->wide_max_numa, w.numa_nodes);
     c->wide_index.resize(next.size());
     for (size_t j = 0; j < next.size(); ++j) c->wide_index[j] = next[j].index;
+    return NHDFIT_OK;
+}
+
+int nhdfit_wide_share_upload(nhdfit_ctx* c, const nhdfit_wide_share* share, uint32_t n_wide) {
+    if (!c) return NHDFIT_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    { int rc_ = sync_all(c); if (rc_) return rc_; }
+    if (!share) { c->sharing = false; return NHDFIT_OK; }
+    if (n_wide != c->n_wide) return fail(c, NHDFIT_E_INVAL, "%u speed_used records for %u wide records", n_wide, c->n_wide);
+    if (c->n_wide != c->n) return fail(c, NHDFIT_E_STATE, "ENABLE_SHARING: every node of the mirror must be a wide record (%u of %u are)", c->n_wide, c->n);
+    HIPCHK(c, c->wide_share.reserve(n_wide ? n_wide : 1));
+    if (n_wide) HIPCHK(c, hipMemcpy(c->wide_share.p, share, (size_t)n_wide * sizeof *share, hipMemcpyHostToDevice));
+    c->sharing = true;
+    return NHDFIT_OK;
+}
+
+int nhdfit_wide_share_download(nhdfit_ctx* c, nhdfit_wide_share* out, uint32_t cap, uint32_t* n_wide) {
+    if (!c || !n_wide) return NHDFIT_E_INVAL;
+    *n_wide = c->sharing ? c->n_wide : 0;
+    if (!c->sharing || !c->n_wide) return NHDFIT_OK;
+    if (!out || cap < c->n_wide) return fail(c, NHDFIT_E_INVAL, "room for %u speed_used records, the mirror holds %u", cap, c->n_wide);
+    HIPCHK(c, hipSetDevice(c->dev));
+    { int rc_ = sync_all(c); if (rc_) return rc_; }
+    HIPCHK(c, hipMemcpy(out, c->wide_share.p, (size_t)c->n_wide * sizeof *out, hipMemcpyDeviceToHost));
     return NHDFIT_OK;
 }
 
@@ -1637,6 +1663,7 @@ int nhdfit_wide_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_req* req, cons
     WideCommitArgs wa;
     memset(&wa, 0, sizeof wa);
     wa.wide = c->wide.p; wa.slot = (uint32_t)slot; wa.req = *req; wa.map = *map; wa.busy_time = busy_time; wa.out = c->wide_place.p;
+    wa.share = c->sharing ? c->wide_share.p : nullptr;
     hipLaunchKernelGGL(k_wide_commit, dim3(1), dim3(64), 0, c->stream, wa);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(place_out, c->wide_place.p, sizeof *place_out, hipMemcpyDeviceToHost, c->stream));
@@ -1670,6 +1697,7 @@ int nhdfit_big_find(nhdfit_ctx* c, const nhdfit_big_req* reqs, uint32_t P, doubl
         memset(&ea, 0, sizeof ea);
         ea.p0 = c->p0.p; ea.p1 = c->p1.p; ea.p2 = c->p2.p; ea.p3 = c->p3.p; ea.p4 = c->p4.p; ea.det = c->det.p; ea.n = c->n;
         ea.wide = c->wide.p; ea.n_wide = c->n_wide; ea.reqs = c->big_reqs.p; ea.P = P; ea.caps = c->caps.p; ea.busy_from = busy_threshold(now);
+        ea.share = c->sharing ? c->wide_share.p : nullptr;
         ea.cand = cand && chunks ? c->big_cand.p : nullptr; ea.score = c->big_score.p; ea.global_base = c->global_base; ea.flags = c->big_flags.p;
         hipLaunchKernelGGL(k_big_eval, dim3((units + 63) / 64, P), dim3(64), 0, c->stream, ea);
         HIPCHK(c, hipGetLastError());
@@ -1693,7 +1721,7 @@ int nhdfit_big_find(nhdfit_ctx* c, const nhdfit_big_req* reqs, uint32_t P, doubl
         BigMapArgs ma;
         memset(&ma, 0, sizeof ma);
         ma.p0 = c->p0.p; ma.p1 = c->p1.p; ma.p2 = c->p2.p; ma.p3 = c->p3.p; ma.p4 = c->p4.p; ma.det = c->det.p; ma.n = c->n;
-        ma.wide = c->wide.p; ma.n_wide = c->n_wide; ma.reqs = c->big_reqs.p; ma.P = P; ma.caps = c->caps.p;
+        ma.wide = c->wide.p; ma.n_wide = c->n_wide; ma.reqs = c->big_reqs.p; ma.P = P; ma.caps = c->caps.p; ma.share = c->sharing ? c->wide_share.p : nullptr;
         ma.score = c->big_score.p; ma.global_base = c->global_base; ma.out = c->big_maps.p; ma.scratch = c->big_scratch.p; ma.flags = c->big_flags.p;
         ma.stride = stride; ma.slots_g = (int32_t)wide_table_slots(wide_ipow(umax, gmax)); ma.slots_c = (int32_t)wide_table_slots(wide_ipow(umax, gmax + 1)); ma.workers = workers;
         ma.lds_tables = lds_tables ? 1u : 0u;
@@ -1737,6 +1765,7 @@ int nhdfit_big_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_big_req* req, c
     memset(&ba, 0, sizeof ba);
     ba.p0 = c->p0.p; ba.p1 = c->p1.p; ba.p2 = c->p2.p; ba.p3 = c->p3.p; ba.p4 = c->p4.p; ba.det = c->det.p;
     ba.wide = c->wide.p; ba.slot = slot; ba.node = node; ba.req = *req; ba.map = *map; ba.busy_time = busy_time; ba.sigs = sig_table(c);
+    ba.share = c->sharing ? c->wide_share.p : nullptr;
     ba.out = c->big_place.p;
     hipLaunchKernelGGL(k_big_commit, dim3(1), dim3(64), 0, c->stream, ba);
     HIPCHK(c, hipGetLastError());
@@ -1772,9 +1801,11 @@ int schedule_batch_general(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, do
                         "(a find and a commit each) instead of the decision engine\n", c->n_wide);
     }
     std::vector<nhdfit_wide_node> wide_before(c->n_wide);
+    std::vector<nhdfit_wide_share> share_before(c->sharing ? c->n_wide : 0);
     if (!apply && c->n_wide) {
         uint32_t nw = 0;
         int rc = nhdfit_wide_download(c, wide_before.data(), (uint32_t)wide_before.size(), &nw);
+        if (!rc && !share_before.empty()) rc = nhdfit_wide_share_download(c, share_before.data(), (uint32_t)share_before.size(), &nw);
         if (rc) return rc;
     }
     uint32_t done = 0;
@@ -1826,6 +1857,7 @@ int schedule_batch_general(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, do
         if (!wide_before.empty()) {
             HIPCHK(c, wait_stream(c->stream));
             HIPCHK(c, hipMemcpy(c->wide.p, wide_before.data(), wide_before.size() * sizeof wide_before[0], hipMemcpyHostToDevice));
+            if (!share_before.empty()) HIPCHK(c, hipMemcpy(c->wide_share.p, share_before.data(), share_before.size() * sizeof share_before[0], hipMemcpyHostToDevice));
         }
     }
     if (rc) return rc;

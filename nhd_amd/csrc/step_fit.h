@@ -257,7 +257,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
         const uint32_t i = c * 64 + lane;
         uint4 rv_next = rv;
         double bt_next = bt;
-        if (c + 1 < c_last && !(dbg & 4)) {
+        if (c + 1 < c_last && !(dbg & 4)) {      // (a second record in flight for the narrow tiles: measured in round 5, no gain - profiles/r05)
             rv_next = *reinterpret_cast<const uint4*>(recs + i + 64);
             bt_next = bts[i + 64];
         }

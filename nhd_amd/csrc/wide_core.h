@@ -159,8 +159,25 @@ template <class R> NHD_HD bool wide_cpu_ok(const R& r, const WideFree& f, uint32
 //   * a budget of search steps per (pod, node) pair (NicSearch): when it runs out the pair is reported, the call fails
 //     (NHDFIT_E_LIMIT) - the reference would be making K^G deepcopies there.
 struct NicSearch { uint32_t left; bool exhausted; };        // a big request's budget of search steps per (pod, node) pair (see wide_nic_choice)
+// What a NIC can still carry, per direction (nhd/Node.py:283-296).  Shipped arithmetic (ENABLE_SHARING = False): the capacity class
+// of the NIC as it is now - 0 while a pod uses it, speed * 0.9 otherwise - for both directions.  ENABLE_SHARING = True (`sh` = the
+// node's nhdfit_wide_share): `speed * 0.9 - speed_used[x]`, ONE f64 subtraction from the class value of the NIC's own capacity,
+// as the reference writes it; pods_used plays no part.  A bare capacity table converts (every caller of the shipped arithmetic).
+struct WideCaps {
+    const double* cls;
+    const nhdfit_wide_share* sh;
+    NHD_HD WideCaps(const double* c, const nhdfit_wide_share* s = nullptr) : cls(c), sh(s) {}
+    NHD_HD double free_of(const nhdfit_wide_node& n, uint32_t u, uint32_t k, uint32_t dir) const {
+        return sh ? cls[n.nic_base[u][k]] - sh->used[u][k][dir] : cls[n.nic_cls[u][k]];
+    }
+    // NICs a search may treat as interchangeable: same price in both directions (and, the caller checks, the same switch)
+    NHD_HD bool same_price(const nhdfit_wide_node& n, uint32_t u, uint32_t k, uint32_t k2) const {
+        if (!sh) return n.nic_cls[u][k] == n.nic_cls[u][k2];
+        return n.nic_base[u][k] == n.nic_base[u][k2] && sh->used[u][k][0] == sh->used[u][k2][0] && sh->used[u][k][1] == sh->used[u][k2][1];
+    }
+};
 template <class R>
-NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const R& r, const double* caps, uint32_t gcode, int8_t* nic_idx, NicSearch* ns = nullptr) {
+NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const R& r, const WideCaps& caps, uint32_t gcode, int8_t* nic_idx, NicSearch* ns = nullptr) {
     constexpr int kG = req_traits<R>::kG;
     const uint32_t G = r.n_groups, U = n.numa_nodes;
     const bool pci = r.map_type == NHDFIT_MAP_PCI;
@@ -177,7 +194,7 @@ NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const R& r, const double*
         if (!(r.rx[g] >= 0) || !(r.tx[g] >= 0)) prune = false;
     // groups order[0..pos] assigned: does the NIC of the newest one still hold, and its switch?
     auto nic_holds = [&](uint32_t upto, uint32_t u, uint32_t k) {
-        double rx = caps[n.nic_cls[u][k]], tx = rx;
+        double rx = caps.free_of(n, u, k, 0), tx = caps.free_of(n, u, k, 1);
         for (uint32_t q = 0; q <= upto; ++q) {                 // same NUMA node => ascending group index along `order`
             const uint32_t h = order[q];
             if (numa[h] == u && pick[h] == k) { rx = rx - r.rx[h]; tx = tx - r.tx[h]; }
@@ -197,7 +214,7 @@ NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const R& r, const double*
         for (int q = 0; q < pos; ++q)
             if (numa[order[q]] == u && pick[order[q]] == k) return false;                    // in use: its own state
         for (uint32_t k2 = 0; k2 < k; ++k2) {
-            if (n.nic_cls[u][k2] != n.nic_cls[u][k] || n.nic_sw[u][k2] != n.nic_sw[u][k]) continue;
+            if (!caps.same_price(n, u, k, k2) || n.nic_sw[u][k2] != n.nic_sw[u][k]) continue;
             bool used = false;
             for (int q = 0; q < pos && !used; ++q) used = numa[order[q]] == u && pick[order[q]] == k2;
             if (!used) return true;
@@ -273,7 +290,7 @@ template <class R> NHD_HD void nic_memo_init(NicMemo& m, const nhdfit_wide_node&
 }
 // can the NICs of NUMA node u host the groups of `set` (bit g = group g)?
 template <class R>
-NHD_HD bool nic_set_ok(NicMemo& m, const nhdfit_wide_node& n, const R& r, const double* caps, uint32_t u, uint32_t set, NicSearch* ns) {
+NHD_HD bool nic_set_ok(NicMemo& m, const nhdfit_wide_node& n, const R& r, const WideCaps& caps, uint32_t u, uint32_t set, NicSearch* ns) {
     if (!set) return true;
     uint8_t& known = m.known[u][set];
     if (known) return known == 2;
@@ -290,7 +307,7 @@ NHD_HD bool nic_set_ok(NicMemo& m, const nhdfit_wide_node& n, const R& r, const 
 }
 // the NIC stage of assignment `gcode` through the memo (separable nodes) or by the joint search
 template <class R>
-NHD_HD bool nic_stage_ok(NicMemo& m, const nhdfit_wide_node& n, const R& r, const double* caps, uint32_t gcode, NicSearch* ns) {
+NHD_HD bool nic_stage_ok(NicMemo& m, const nhdfit_wide_node& n, const R& r, const WideCaps& caps, uint32_t gcode, NicSearch* ns) {
     if (!m.separable) {
         int8_t nic[req_traits<R>::kG];
         return wide_nic_choice(n, r, caps, gcode, nic, ns);
@@ -319,7 +336,7 @@ template <class R> NHD_HD bool wide_scalar_ok(const nhdfit_wide_node& n, const R
 
 // feasible(node, pod): some assignment passes all three stages (the set intersection of Matcher.py:346 is non-empty)
 template <class R>
-NHD_HD bool wide_fits(const nhdfit_wide_node& n, const R& r, bool busy, const double* caps, NicSearch* ns = nullptr) {
+NHD_HD bool wide_fits(const nhdfit_wide_node& n, const R& r, bool busy, const WideCaps& caps, NicSearch* ns = nullptr) {
     if (!wide_scalar_ok(n, r, busy)) return false;
     const WideFree f = wide_free(n);
     const uint32_t G = r.n_groups, nG = wide_ipow(f.U, G);
@@ -505,7 +522,7 @@ template <class K> NHD_HD int32_t wide_pick_gpu_tuple(const WideSetT<K>& s, uint
 // -2 = the NIC search budget of a big request ran out (reported like -1).
 // slots_g / slots_c: table sizes of the sets over G- and (G+1)-tuples (ordinary requests: kWideSetSlotsG / kWideSetSlotsC).
 template <class R>
-NHD_HD int wide_map(const nhdfit_wide_node& n, const R& r, const double* caps, typename req_traits<R>::Key* scratch,
+NHD_HD int wide_map(const nhdfit_wide_node& n, const R& r, const WideCaps& caps, typename req_traits<R>::Key* scratch,
                     typename req_traits<R>::Mapping& out, int32_t slots_g = kWideSetSlotsG, int32_t slots_c = kWideSetSlotsC) {
     using K = typename req_traits<R>::Key;
     constexpr int kG = req_traits<R>::kG;
@@ -601,7 +618,7 @@ NHD_HD bool wide_take_batch(nhdfit_wide_node& n, uint32_t u, uint32_t num, bool 
 
 template <class R>
 NHD_HD int wide_commit(nhdfit_wide_node& n, const R& r, const typename req_traits<R>::Mapping& m, double busy_time,
-                       typename req_traits<R>::WidePlacement& out) {
+                       typename req_traits<R>::WidePlacement& out, nhdfit_wide_share* sh = nullptr) {
     constexpr int kMaxG = req_traits<R>::kG;                                          // (shadows the table pass's constant: this body is per request form)
     const uint32_t G = r.n_groups, U = n.numa_nodes;
     int status = kCommitOk;
@@ -635,7 +652,12 @@ NHD_HD int wide_commit(nhdfit_wide_node& n, const R& r, const typename req_trait
             if (k < (uint32_t)NHDFIT_PLACEMENT_GPUS) out.gpu[g][k] = (uint8_t)pick;
         }
         if (!wide_take_batch(n, u, r.n_help[g], (r.smt_bits >> (kMaxG + g) & 1) != 0, out.help_take[g], out.help_pair[g], out.help_late[g])) status = kCommitWouldRaise;
-        if (r.nic_use >> g & 1) claimed[nu] |= 1u << nk;
+        if (r.nic_use >> g & 1) {
+            claimed[nu] |= 1u << nk;
+            // speed_used[0 / 1] += the RX / TX core's speed (nhd/Node.py:754): a group's rx / tx is its one RX / TX core's speed (the
+            // packer turns away groups with several under ENABLE_SHARING), a direction without a core adds 0.0
+            if (sh) { sh->used[nu][nk][0] += r.rx[g]; sh->used[nu][nk][1] += r.tx[g]; }
+        }
     }
     if (r.hugepages_gb > 0) n.hp_free -= r.hugepages_gb;                              // Node.py:794-796
     const uint32_t mu = (uint32_t)m.cpu[G] % U;

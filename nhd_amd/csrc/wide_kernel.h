@@ -14,6 +14,7 @@ struct WideArgs {
     const uint64_t* cand;                          // optional [chunks] candidate nodes
     unsigned long long* nm; uint32_t chunks;       // optional node-major verdict words [tiles][chunks * 64]
     unsigned long long* score; uint64_t global_base;
+    const nhdfit_wide_share* share;                // optional [n_wide]: ENABLE_SHARING arithmetic (include/nhdfit.h)
 };
 
 __global__ __launch_bounds__(256) void k_wide_eval(WideArgs a) {
@@ -24,7 +25,7 @@ __global__ __launch_bounds__(256) void k_wide_eval(WideArgs a) {
     if (a.cand && !(a.cand[n.index >> 6] >> (n.index & 63) & 1ull)) return;
     const nhdfit_req& r = a.reqs[i];
     const bool busy = n.busy_time >= a.busy_from;                          // IsBusy, as the fit role asks it (fit_core.h busy_threshold)
-    if (!wide_fits(n, r, busy, a.caps)) return;
+    if (!wide_fits(n, r, busy, WideCaps(a.caps, a.share ? a.share + w : nullptr))) return;
     if (a.nm) atomicOr(&a.nm[(size_t)(i >> 6) * a.chunks * 64 + n.index], 1ull << (i & 63));
     uint32_t want = 0;
     for (uint32_t g = 0; g < r.n_groups; ++g) want += r.gpus[g];
@@ -39,6 +40,7 @@ struct WideMapArgs {
     nhdfit_mapping* out;
     int16_t* scratch;                              // [threads][kWideScratchWords]
     uint32_t* flags;                               // [0] a set of the model outgrew its table (never expected)
+    const nhdfit_wide_share* share;                // optional [n_wide]
 };
 __device__ inline int wide_slot_of(const nhdfit_wide_node* wide, uint32_t n_wide, uint32_t index) {   // records are sorted by index
     int lo = 0, hi = (int)n_wide - 1;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(64) void k_wide_map(WideMapArgs a) {
         const int slot = wide_slot_of(a.wide, a.n_wide, (uint32_t)(gi - a.global_base));
         if (slot < 0) continue;                                             // an ordinary node: the mapping roles answered
         nhdfit_mapping m;
-        const int rc = wide_map(a.wide[slot], a.reqs[i], a.caps, scratch, m);
+        const int rc = wide_map(a.wide[slot], a.reqs[i], WideCaps(a.caps, a.share ? a.share + slot : nullptr), scratch, m);
         if (rc < 0) { m.valid = 0; atomicOr(&a.flags[0], 1u); }
         a.out[i] = m;
     }
@@ -74,12 +76,13 @@ struct WideCommitArgs {
     nhdfit_wide_node* wide; uint32_t slot;
     nhdfit_req req; nhdfit_mapping map; double busy_time;
     nhdfit_wide_placement* out;
+    nhdfit_wide_share* share;                      // optional [n_wide]
 };
 __global__ void k_wide_commit(WideCommitArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     nhdfit_wide_node n = a.wide[a.slot];
     nhdfit_wide_placement pl;
-    wide_commit(n, a.req, a.map, a.busy_time, pl);
+    wide_commit(n, a.req, a.map, a.busy_time, pl, a.share ? a.share + a.slot : nullptr);
     pl.pod = 0; pl.node = n.index;
     a.wide[a.slot] = n;
     *a.out = pl;

@@ -97,6 +97,7 @@ WIDE = np.dtype([("t0", "<u8", (WIDE_CORE_WORDS,)), ("t1", "<u8", (WIDE_CORE_WOR
                  ("gpu_numa", "u1", (MAX_GPUS,)), ("gpu_sw", "u1", (MAX_GPUS,)),
                  ("nic_cls", "u1", (WIDE_MAX_NUMA, MAX_NICS_PER_NUMA)), ("nic_base", "u1", (WIDE_MAX_NUMA, MAX_NICS_PER_NUMA)),
                  ("nic_sw", "u1", (WIDE_MAX_NUMA, MAX_NICS_PER_NUMA)), ("nic_pods", "i1", (WIDE_MAX_NUMA, MAX_NICS_PER_NUMA)), ("pad", "u1", (20,))])
+WIDE_SHARE = np.dtype([("used", "<f8", (WIDE_MAX_NUMA, MAX_NICS_PER_NUMA, 2))])    # nhdfit_wide_share: Node.nics[].speed_used per (numa, idx, rx / tx)
 WIDE_PLACEMENT = np.dtype([("proc_take", "<u8", (4, 2)), ("proc_pair", "<u8", (4, 2)), ("proc_late", "<u8", (4, 2)),
                            ("help_take", "<u8", (4, 2)), ("help_pair", "<u8", (4, 2)), ("help_late", "<u8", (4, 2)),
                            ("misc_take", "<u8", (2,)), ("misc_pair", "<u8", (2,)), ("misc_late", "<u8", (2,)),
@@ -155,8 +156,9 @@ class UnsupportedNode(ValueError):
 
 class SharingEnabled(UnsupportedNode):
     """nhd/Node.py:20 ENABLE_SHARING is True in the module the node objects come from: GetFreeNumaNicResources then prices a
-    NIC at speed * pct - speed_used[x] (nhd/Node.py:290) - a per-direction remainder the packed capacity classes do not
-    model.  The product implements the reference's shipped arithmetic (False, nhd/Node.py:292) and refuses the other."""
+    NIC at speed * pct - speed_used[x] (nhd/Node.py:290) - a per-direction remainder the packed capacity classes of the fast
+    layout do not model.  Such a node is mirrored for the general path only (a wide record + its nhdfit_wide_share record of the
+    NICs' speed_used: round 5), where that subtraction is done in f64 as the reference writes it."""
 
 
 @dataclass
@@ -170,6 +172,7 @@ class NodeTable:
     detail: np.ndarray
     origin: Optional[np.ndarray] = None          # nhdfit_origin records (what ResetResources / a released NIC go back to)
     wide: Optional[Dict[int, np.ndarray]] = None  # index -> nhdfit_wide_node record of the nodes beyond the fast layout (their planes hold a placeholder)
+    share: Optional[Dict[int, np.ndarray]] = None  # index -> nhdfit_wide_share record (ENABLE_SHARING = True: every node is a wide node and has one)
 
     @property
     def n(self) -> int:
@@ -179,7 +182,8 @@ class NodeTable:
         return NodeTable(self.names[lo:hi] if self.names else [], self.p0[lo:hi], self.p1[lo:hi], self.p2[lo:hi],
                          self.p3[lo:hi], self.p4[lo:hi], self.detail[lo:hi],
                          None if self.origin is None else self.origin[lo:hi],
-                         None if not self.wide else {i - lo: r for i, r in self.wide.items() if lo <= i < hi})
+                         None if not self.wide else {i - lo: r for i, r in self.wide.items() if lo <= i < hi},
+                         None if not self.share else {i - lo: r for i, r in self.share.items() if lo <= i < hi})
 
     def wide_records(self, first: int = 0) -> np.ndarray:
         """The wide records of this table in ascending order, `index` = first + position in the table (what nhdfit_wide_upload takes)."""
@@ -188,6 +192,16 @@ class NodeTable:
         for k, i in enumerate(idx):
             out[k] = self.wide[i]
             out[k]["index"] = first + i
+        return out
+
+    def share_records(self) -> Optional[np.ndarray]:
+        """The nhdfit_wide_share records in the order of wide_records(), or None when the cluster does not share NICs."""
+        if not self.share:
+            return None
+        idx = sorted(self.wide) if self.wide else []
+        out = np.zeros(len(idx), WIDE_SHARE)
+        for k, i in enumerate(idx):
+            out[k] = self.share[i]
         return out
 
 
@@ -385,14 +399,15 @@ class Packer:
         """Node object -> record i of the table.  See __init__ for nodes the layout cannot hold."""
         if t.wide is None:
             t.wide = {}
+        if t.share is None:
+            t.share = {}
         try:
             self._pack_node_into(node, t, i)
             self.unmirrored.pop(node.name, None)
             t.wide.pop(i, None)
+            t.share.pop(i, None)
             return
-        except SharingEnabled:
-            raise
-        except UnsupportedNode as e:
+        except UnsupportedNode as e:                          # (SharingEnabled among them: the general path's arithmetic)
             why = str(e)
         # beyond the fast layout: a placeholder in the planes (never matches the table pass, indices stay what they are) ...
         for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
@@ -404,9 +419,14 @@ class Packer:
         # ... and, where the general path can hold it (<= 4 sockets of <= 128 physical cores), its own record
         try:
             t.wide[i] = self.pack_wide(node)
+            if self.sharing:
+                t.share[i] = self.pack_share(node)
+            else:
+                t.share.pop(i, None)
             self.unmirrored.pop(node.name, None)
         except UnsupportedNode as e2:
             t.wide.pop(i, None)
+            t.share.pop(i, None)
             if self.strict:
                 raise UnsupportedNode(f"{why}; and not as a wide node either: {e2}") from None
             self.unmirrored[node.name] = f"{why}; and not as a wide node either: {e2}"
@@ -415,11 +435,10 @@ class Packer:
         consts = node_module_constants(node)
         if consts["ENABLE_SHARING"]:
             self.sharing = (f"ENABLE_SHARING is True in the module of {type(node).__name__} (nhd/Node.py:20): NIC capacities follow "
-                            "speed_used (nhd/Node.py:290), which the device layout does not model")
-            if self.strict:
-                raise SharingEnabled(self.sharing)
-        else:
-            self.sharing = None
+                            "speed_used (nhd/Node.py:290) - every node is mirrored for the general path")
+            self.nic_pct = consts["NIC_BW_AVAIL_PERCENT"]
+            raise SharingEnabled(self.sharing)
+        self.sharing = None
         pct = self.nic_pct = consts["NIC_BW_AVAIL_PERCENT"]
         U = int(node.numa_nodes)
         if U < 1 or U > MAX_NUMA:
@@ -655,6 +674,21 @@ class Packer:
         w["hp_total"] = max(-2 ** 31, min(2 ** 31 - 1, int(getattr(node.mem, "ttl_hugepages_gb", 0))))
         w["cores_per_proc"], w["numa_nodes"], w["n_gpus"] = cpp, U, len(gpus)
         return w
+
+    def pack_share(self, node) -> np.ndarray:
+        """Node.nics[].speed_used as one nhdfit_wide_share record, NIC (numa, idx) as pack_wide orders them (nhd/Node.py:290)."""
+        sh = np.zeros((), WIDE_SHARE)
+        U = int(node.numa_nodes)
+        cnt = [0] * WIDE_MAX_NUMA
+        for nic in node.nics:
+            u = nic.numa_node
+            if u >= U or u < 0:
+                continue
+            k = cnt[u]
+            sh["used"][u][k][0] = float(nic.speed_used[0])
+            sh["used"][u][k][1] = float(nic.speed_used[1])
+            cnt[u] = k + 1
+        return sh
 
     def pack_nodes(self, nl: Dict[str, object]) -> NodeTable:
         t = empty_table(len(nl))
