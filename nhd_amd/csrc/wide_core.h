@@ -189,6 +189,13 @@ NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const R& r, const WideCap
             if (numa[g] == u) order[cnt++] = g;
     for (uint32_t g = 0; g < G; ++g)
         if (n.nic_cnt[numa[g]] == 0) return false;             // a NUMA node without NICs hosts no group (quirk Q3)
+    // The reference looks for a negative remainder on EVERY NIC of the node, picked or not (`any(x < 0 for y in nic_ttls ...)`,
+    // Matcher.py:267).  The shipped capacities are never negative; under ENABLE_SHARING a NIC carrying more than its capacity
+    // (speed_used above speed * 0.9) makes every combination fail: the node offers no NIC candidates at all.
+    if (caps.sh)
+        for (uint32_t u = 0; u < U; ++u)
+            for (uint32_t k = 0; k < n.nic_cnt[u]; ++k)
+                if (caps.free_of(n, u, k, 0) < 0 || caps.free_of(n, u, k, 1) < 0) return false;
     bool prune = true;
     for (uint32_t g = 0; g < G; ++g)
         if (!(r.rx[g] >= 0) || !(r.tx[g] >= 0)) prune = false;

@@ -75,6 +75,23 @@ class Engine:
             self._chk(self.lib.nhdfit_wide_upload(self.ctx, first, table.n, _p(recs) if len(recs) else None, len(recs)))
             self.n_wide = self.wide_count()
         self.n = max(self.n, first + table.n)
+        # nhd/Node.py:20 ENABLE_SHARING = True: every node is a wide record and carries its NICs' speed_used (nhdfit_wide_share).  The
+        # device wants the records of ALL wide nodes after every wide upload: this engine keeps them by node index
+        if table.share:
+            if not hasattr(self, "_share") or self._share is None or len(self._share) < self.n:
+                grown = np.zeros(self.n, pack.WIDE_SHARE)
+                if getattr(self, "_share", None) is not None:
+                    grown[:len(self._share)] = self._share
+                self._share = grown
+            for i, rec in table.share.items():
+                self._share[first + i] = rec
+            if self.n_wide != self.n:
+                raise _lib.NhdFitError(-5, "ENABLE_SHARING: a node of the mirror is not held by the general path")
+            share = np.ascontiguousarray(self._share[:self.n])
+            self._chk(self.lib.nhdfit_wide_share_upload(self.ctx, _p(share), len(share)))
+        elif getattr(self, "_share", None) is not None and first == 0 and table.n >= self.n:
+            self._share = None
+            self._chk(self.lib.nhdfit_wide_share_upload(self.ctx, None, 0))
         self.global_base = global_base
 
     def wide_count(self) -> int:
@@ -88,6 +105,13 @@ class Engine:
         out = np.zeros(self.wide_count(), pack.WIDE)
         self._chk(self.lib.nhdfit_wide_download(self.ctx, _p(out) if len(out) else None, len(out), ctypes.byref(k)))
         return out
+
+    def wide_share_download(self) -> np.ndarray:
+        """The NICs' speed_used per wide record (ascending node index) as the device's commits left them; empty without ENABLE_SHARING."""
+        k = ctypes.c_uint32(0)
+        out = np.zeros(self.wide_count(), pack.WIDE_SHARE)
+        self._chk(self.lib.nhdfit_wide_share_download(self.ctx, _p(out) if len(out) else None, len(out), ctypes.byref(k)))
+        return out[:int(k.value)]
 
     def wide_commit(self, node: int, req: np.ndarray, mapping: np.ndarray, busy_time: float) -> np.ndarray:
         out = np.zeros((), pack.WIDE_PLACEMENT)

@@ -408,6 +408,12 @@ class HipMatcher:
                 self._table.wide[i] = one.wide[0].copy()
             else:
                 self._table.wide.pop(i, None)
+            if self._table.share is None:
+                self._table.share = {}
+            if one.share and 0 in one.share:                   # ... and, under ENABLE_SHARING, its NICs' speed_used
+                self._table.share[i] = one.share[0].copy()
+            else:
+                self._table.share.pop(i, None)
         self.engine.set_dictionary(self.packer)        # signatures may have been added
         idx = sorted(self._index[nm] for nm in self._dirty)
         lo = 0
@@ -571,13 +577,8 @@ class HipMatcher:
             self._full_upload(nl)
             self._mirror_foreign = self._attached is not None
         self._warn_unmirrored()
-        if self.packer.sharing:
-            # nhd/Node.py:20 flipped to True: the reference's placements then follow speed_used (Node.py:290), which this product
-            # does not implement - silently different placements are the one thing not allowed: strict raises (pack.SharingEnabled,
-            # at pack time), otherwise every pod is left pending and the reason is logged
-            self.logger.error("FindNode: %s - %d pod(s) answered (None,)", self.packer.sharing, n_pods)
-            self.last_placements = [None] * n_pods
-            return [(None,) for _ in range(n_pods)]
+        # (nhd/Node.py:20 ENABLE_SHARING = True: the packer mirrored every node for the general path, whose NIC stage prices a NIC at
+        #  speed * pct - speed_used[x] as the reference does - nothing to route here: the table pass finds placeholders only)
         if reqs is None and any(pack.needs_general_path(top) for top in tops):
             # pods the table pass cannot express but the general path answers (5..8 processing groups, huge hugepage requests)
             is_big = [pack.needs_general_path(top) for top in tops]

@@ -808,6 +808,7 @@ class Packer:
             cpu_nosmt[i] = n_proc + n_help
             cpu_smt[i] = ((n_proc + 1) // 2 if p_smt else n_proc) + ((n_help + 1) // 2 if h_smt else n_help)   # ceil(n / 2.0)
             rx = tx = 0
+            n_rx = n_tx = 0
             for c in pg.proc_cores:
                 d = c.nic_dir
                 try:
@@ -816,10 +817,16 @@ class Packer:
                     d = getattr(d, "value", d)
                 if d == 1:
                     rx += c.nic_speed
+                    n_rx += 1
                     nic_use |= 1 << i
                 elif d == 2:
                     tx += c.nic_speed
+                    n_tx += 1
                     nic_use |= 1 << i
+            if self.sharing and (n_rx > 1 or n_tx > 1):
+                # ENABLE_SHARING: the commit step adds every RX / TX core's speed to speed_used one after the other (nhd/Node.py:754);
+                # the request record carries a group's sums - the same f64 value only while a direction has one core
+                raise UnsupportedNode(f"processing group {i}: {n_rx} RX and {n_tx} TX cores (ENABLE_SHARING: at most one of each per group)")
             rxs[i] = float(rx)
             txs[i] = float(tx)
         n_misc = len(top.misc_cores)

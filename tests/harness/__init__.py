@@ -233,7 +233,16 @@ def apply_deltas(packer, table, deltas):
     return status
 
 
-def wide_eval(wide: np.ndarray, reqs: np.ndarray, now: float, packer, cand=None, global_base=0, score=None):
+def _share_arg(share, n=None):
+    """nhdfit_wide_share records (ENABLE_SHARING) as a pointer argument, or None."""
+    if share is None:
+        return None, None
+    arr = np.ascontiguousarray(share, dtype=pack.WIDE_SHARE).reshape(-1)
+    assert n is None or len(arr) == n
+    return arr, _p(arr)
+
+
+def wide_eval(wide: np.ndarray, reqs: np.ndarray, now: float, packer, cand=None, global_base=0, score=None, share=None):
     """k_wide_eval on the host build: (fits [n_wide][P] bytes, score max-merged)."""
     L = lib()
     wide = np.ascontiguousarray(wide, dtype=pack.WIDE)
@@ -244,12 +253,13 @@ def wide_eval(wide: np.ndarray, reqs: np.ndarray, now: float, packer, cand=None,
     caps = np.zeros(pack.MAX_CLASSES, "<f8")
     caps[:len(packer.caps)] = packer.caps
     if len(wide):
+        sh, shp = _share_arg(share, len(wide))
         L.hh_wide_eval(_p(wide), ctypes.c_uint32(len(wide)), _p(reqs), ctypes.c_uint32(P), ctypes.c_double(now), _p(caps),
-                       _p(cand) if cand is not None else None, ctypes.c_uint64(global_base), _p(fits), _p(score))
+                       _p(cand) if cand is not None else None, ctypes.c_uint64(global_base), _p(fits), _p(score), shp)
     return fits, score
 
 
-def wide_map(rec, req, packer):
+def wide_map(rec, req, packer, share=None):
     L = lib()
     caps = np.zeros(pack.MAX_CLASSES, "<f8")
     caps[:len(packer.caps)] = packer.caps
@@ -257,20 +267,22 @@ def wide_map(rec, req, packer):
     rec = np.ascontiguousarray(rec, dtype=pack.WIDE).reshape(1)
     req = np.ascontiguousarray(req).reshape(1)
     L.hh_wide_map.restype = ctypes.c_int
-    rc = L.hh_wide_map(_p(rec), _p(req), _p(caps), _p(out))
+    sh, shp = _share_arg(share, 1)
+    rc = L.hh_wide_map(_p(rec), _p(req), _p(caps), _p(out), shp)
     assert rc >= 0, "a set of the general model outgrew its table"
     return out
 
 
-def wide_commit(rec, req, mapping, busy_time):
-    """wide_commit on the host build: (status, placement, record after the commit)."""
+def wide_commit(rec, req, mapping, busy_time, share=None):
+    """wide_commit on the host build: (status, placement, record after the commit); `share` (one nhdfit_wide_share record) is
+    updated in place."""
     L = lib()
     rec = np.array(rec, dtype=pack.WIDE).reshape(1)
     out = np.zeros((), pack.WIDE_PLACEMENT)
     req = np.ascontiguousarray(req).reshape(1)
     mapping = np.ascontiguousarray(mapping).reshape(1)
     L.hh_wide_commit.restype = ctypes.c_int
-    st = L.hh_wide_commit(_p(rec), _p(req), _p(mapping), ctypes.c_double(busy_time), _p(out))
+    st = L.hh_wide_commit(_p(rec), _p(req), _p(mapping), ctypes.c_double(busy_time), _p(out), _p(share) if share is not None else None)
     return int(st), out, rec[0]
 
 
@@ -280,7 +292,7 @@ def _caps(packer):
     return caps
 
 
-def big_eval(packer, table, wide: np.ndarray, reqs: np.ndarray, now: float, cand=None, global_base=0, budget=0):
+def big_eval(packer, table, wide: np.ndarray, reqs: np.ndarray, now: float, cand=None, global_base=0, budget=0, share=None):
     """k_big_eval on the host build: big requests (5..8 groups) against every node - the planes through wide_view, the wide
     records as they are.  Returns (fits [n][P] by node index, scores, budget_exhausted)."""
     L = lib()
@@ -294,12 +306,12 @@ def big_eval(packer, table, wide: np.ndarray, reqs: np.ndarray, now: float, cand
     planes = [np.ascontiguousarray(getattr(table, f)) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
     L.hh_big_eval(*[_p(x) for x in planes], ctypes.c_uint32(n), _p(wide) if len(wide) else None, ctypes.c_uint32(len(wide)), _p(reqs), ctypes.c_uint32(P),
                   ctypes.c_double(now), _p(caps), _p(cand) if cand is not None else None, ctypes.c_uint64(global_base), _p(fits), _p(score), _p(flags),
-                  ctypes.c_uint32(budget))
+                  ctypes.c_uint32(budget), _share_arg(share, len(wide))[1] if share is not None else None)
     big_eval.last_steps = int(flags[2])                               # NIC search steps of the call (diagnostics)
     return fits, score, bool(flags[1])
 
 
-def big_map(packer, table, v: int, wide_rec, req):
+def big_map(packer, table, v: int, wide_rec, req, share=None):
     """wide_map for a big request on node v of `table` (wide_rec: that node's wide record, or None for an ordinary node)."""
     L = lib()
     out = np.zeros((), pack.BIG_MAPPING)
@@ -308,7 +320,8 @@ def big_map(packer, table, v: int, wide_rec, req):
     planes = [np.ascontiguousarray(getattr(table, f)) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
     rec = None if wide_rec is None else np.ascontiguousarray(wide_rec, dtype=pack.WIDE).reshape(1)
     L.hh_big_map.restype = ctypes.c_int
-    rc = L.hh_big_map(*[_p(x) for x in planes], ctypes.c_uint32(v), _p(rec) if rec is not None else None, _p(req), _p(caps), _p(out))
+    sh, shp = _share_arg(share, 1)
+    rc = L.hh_big_map(*[_p(x) for x in planes], ctypes.c_uint32(v), _p(rec) if rec is not None else None, _p(req), _p(caps), _p(out), shp)
     assert rc >= 0, "a set of the general model outgrew its table / the NIC search budget ran out"
     return out
 
@@ -330,14 +343,14 @@ def big_commit(packer, table, i, req, mapping, busy_time):
     return int(rc), out
 
 
-def big_commit_wide(rec, req, mapping, busy_time):
+def big_commit_wide(rec, req, mapping, busy_time, share=None):
     L = lib()
     rec = np.array(rec, dtype=pack.WIDE).reshape(1)
     out = np.zeros((), pack.BIG_PLACEMENT)
     req = np.ascontiguousarray(req, dtype=pack.BIG_REQ).reshape(1)
     mapping = np.ascontiguousarray(mapping, dtype=pack.BIG_MAPPING).reshape(1)
     L.hh_big_commit_wide.restype = ctypes.c_int
-    st = L.hh_big_commit_wide(_p(rec), _p(req), _p(mapping), ctypes.c_double(busy_time), _p(out))
+    st = L.hh_big_commit_wide(_p(rec), _p(req), _p(mapping), ctypes.c_double(busy_time), _p(out), _p(share) if share is not None else None)
     return int(st), out, rec[0]
 
 
@@ -352,6 +365,7 @@ class HarnessEngine:
         self.packer = None
         self.table = None
         self.wide = {}                                  # local index -> nhdfit_wide_node (the general path's records)
+        self.share = {}                                 # local index -> nhdfit_wide_share (ENABLE_SHARING: one per node, all nodes wide)
         self.last_wide_places = {}
 
     @property
@@ -366,6 +380,17 @@ class HarnessEngine:
             out[k]["index"] = i
         return out
 
+    def _share_records(self):
+        """The speed_used records in the order of _wide_records(), or None (shipped arithmetic)."""
+        if not self.share:
+            return None
+        assert sorted(self.share) == sorted(self.wide) == list(range(self.n)), "ENABLE_SHARING: every node is a wide record with its share record"
+        return np.array([self.share[i] for i in sorted(self.wide)], dtype=pack.WIDE_SHARE)
+
+    def wide_share_download(self):
+        sh = self._share_records()
+        return np.zeros(0, pack.WIDE_SHARE) if sh is None else sh
+
     def close(self):
         pass
 
@@ -379,6 +404,7 @@ class HarnessEngine:
         self.n = 0
         self.table = None
         self.wide = {}
+        self.share = {}
 
     def upload(self, table, global_base=0, first=0, capacity=None):
         if first == 0 and (self.table is None or table.n >= self.n):
@@ -394,13 +420,18 @@ class HarnessEngine:
             del self.wide[i]
         for i, rec in (table.wide or {}).items():
             self.wide[first + i] = np.array(rec, dtype=pack.WIDE)
+        for i in [i for i in self.share if first <= i < first + table.n]:
+            del self.share[i]
+        for i, rec in (table.share or {}).items():
+            self.share[first + i] = np.array(rec, dtype=pack.WIDE_SHARE)
 
     def find(self, reqs, now, cand=None, want_bitmap=True, want_map=True):
         score, bitmap, maps = find(self.packer, self.table, reqs, now, cand=cand, global_base=self.global_base,
                                    want_bitmap=want_bitmap, want_map=want_map)
         if self.wide:                                   # the general pass, merged as nhdfit.hip merges it (launch_step / nhdfit_fetch)
             recs = self._wide_records()
-            fits, score = wide_eval(recs, reqs, now, self.packer, cand=cand, global_base=self.global_base, score=score)
+            shares = self._share_records()
+            fits, score = wide_eval(recs, reqs, now, self.packer, cand=cand, global_base=self.global_base, score=score, share=shares)
             if want_bitmap:
                 for k, rec in enumerate(recs):
                     i = int(rec["index"])
@@ -409,7 +440,8 @@ class HarnessEngine:
                 idx = np.where(score == 0, -1, (0x7FFFFFFFFFFFFFFF - (score & np.uint64(0x7FFFFFFFFFFFFFFF))).astype(np.int64) - self.global_base)
                 for p in np.flatnonzero(score != 0):
                     if int(idx[p]) in self.wide:
-                        maps[p] = wide_map(recs[sorted(self.wide).index(int(idx[p]))], reqs[p], self.packer)
+                        k = sorted(self.wide).index(int(idx[p]))
+                        maps[p] = wide_map(recs[k], reqs[p], self.packer, share=None if shares is None else shares[k:k + 1])
         return score, bitmap, maps
 
     def find_sequential(self, reqs, now, cand=None):
@@ -434,6 +466,7 @@ class HarnessEngine:
         saved_table = None if apply else pack.NodeTable(list(self.table.names), *[np.array(getattr(self.table, f)) for f in
                                                                                   ("p0", "p1", "p2", "p3", "p4", "detail")], np.array(self.table.origin))
         saved_wide = None if apply else {i: np.array(r) for i, r in self.wide.items()}
+        saved_share = None if apply else {i: np.array(r) for i, r in self.share.items()}
         for i in range(P):
             r = reqs[i:i + 1]
             if not (int(r[0]["map_type"]) in (1, 2) and 1 <= int(r[0]["n_groups"]) <= pack.MAX_GROUPS):
@@ -445,7 +478,7 @@ class HarnessEngine:
             node[i] = v + self.global_base
             maps[i] = mp[0]
             if v in self.wide:
-                st, wp, rec = wide_commit(self.wide[v], r[0], mp[0], now)
+                st, wp, rec = wide_commit(self.wide[v], r[0], mp[0], now, share=self.share.get(v))
                 self.wide[v] = rec
                 wp["pod"], wp["node"] = i, v
                 self.last_wide_places[i] = wp
@@ -459,6 +492,7 @@ class HarnessEngine:
             for f in ("p0", "p1", "p2", "p3", "p4", "detail", "origin"):
                 getattr(self.table, f)[...] = getattr(saved_table, f)
             self.wide = saved_wide
+            self.share = saved_share
         self.n_done = P
         return node, maps, places, status
 
@@ -466,7 +500,7 @@ class HarnessEngine:
         return commit(self.packer, self.table, node, req, mapping, busy_time)[1]
 
     def wide_commit(self, node, req, mapping, busy_time):
-        st, wp, rec = wide_commit(self.wide[node], req, mapping, busy_time)
+        st, wp, rec = wide_commit(self.wide[node], req, mapping, busy_time, share=self.share.get(node))
         self.wide[node] = rec
         wp["node"] = node
         return wp
@@ -475,8 +509,9 @@ class HarnessEngine:
         """nhdfit_big_find as nhdfit.hip does it: k_big_eval over planes + wide records, k_big_map for the winners this mirror holds."""
         reqs = np.ascontiguousarray(reqs, dtype=pack.BIG_REQ)
         recs = self._wide_records()
+        shares = self._share_records()
         _, score, exhausted = big_eval(self.packer, self.table, recs, reqs, now, cand=cand, global_base=self.global_base,
-                                       budget=getattr(self, "nic_budget", 0))
+                                       budget=getattr(self, "nic_budget", 0), share=shares)
         if exhausted:
             from nhd_amd._lib import NhdFitError
             raise NhdFitError(-6, "a big request's NIC stage ran out of search budget on some node")
@@ -486,12 +521,14 @@ class HarnessEngine:
             for p in np.flatnonzero(score != 0):
                 v = int(0x7FFFFFFFFFFFFFFF - (int(score[p]) & 0x7FFFFFFFFFFFFFFF)) - self.global_base
                 if 0 <= v < self.n:
-                    maps[p] = big_map(self.packer, self.table, v, recs[order.index(v)] if v in self.wide else None, reqs[p])
+                    k = order.index(v) if v in self.wide else -1
+                    maps[p] = big_map(self.packer, self.table, v, recs[k] if k >= 0 else None, reqs[p],
+                                      share=shares[k:k + 1] if shares is not None and k >= 0 else None)
         return score, (maps if want_map else None)
 
     def big_commit(self, node, req, mapping, busy_time):
         if node in self.wide:
-            st, pl, rec = big_commit_wide(self.wide[node], req, mapping, busy_time)
+            st, pl, rec = big_commit_wide(self.wide[node], req, mapping, busy_time, share=self.share.get(node))
             self.wide[node] = rec
             pl["node"] = node
             return pl

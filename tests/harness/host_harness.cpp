@@ -546,7 +546,8 @@ extern "C" int hh_apply_deltas(nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plan
 
 // what k_wide_eval computes: verdict byte per (wide node, pod), scores max-merged into score[] (caller's pod order)
 extern "C" void hh_wide_eval(const nhdfit_wide_node* wide, uint32_t n_wide, const nhdfit_req* reqs, uint32_t P, double now, const double* caps,
-                             const uint64_t* cand, uint64_t global_base, uint8_t* fits /* [n_wide][P] */, uint64_t* score /* in-out */) {
+                             const uint64_t* cand, uint64_t global_base, uint8_t* fits /* [n_wide][P] */, uint64_t* score /* in-out */,
+                             const nhdfit_wide_share* share /* optional [n_wide]: ENABLE_SHARING */) {
     const double busy_from = busy_threshold(now);
     for (uint32_t w = 0; w < n_wide; ++w)
         for (uint32_t i = 0; i < P; ++i) {
@@ -554,7 +555,7 @@ extern "C" void hh_wide_eval(const nhdfit_wide_node* wide, uint32_t n_wide, cons
             bool ok = !(cand && !(cand[n.index >> 6] >> (n.index & 63) & 1ull));
             const bool busy = n.busy_time >= busy_from;
             if (busy != ((now - n.busy_time) < kMinBusySecs)) std::abort();       // both forms of IsBusy agree
-            ok = ok && wide_fits(n, reqs[i], busy, caps);
+            ok = ok && wide_fits(n, reqs[i], busy, WideCaps(caps, share ? share + w : nullptr));
             fits[(size_t)w * P + i] = ok ? 1 : 0;
             if (!ok) continue;
             uint32_t want = 0;
@@ -563,12 +564,12 @@ extern "C" void hh_wide_eval(const nhdfit_wide_node* wide, uint32_t n_wide, cons
             if (s > score[i]) score[i] = s;
         }
 }
-extern "C" int hh_wide_map(const nhdfit_wide_node* n, const nhdfit_req* r, const double* caps, nhdfit_mapping* out) {
+extern "C" int hh_wide_map(const nhdfit_wide_node* n, const nhdfit_req* r, const double* caps, nhdfit_mapping* out, const nhdfit_wide_share* share) {
     std::vector<int16_t> scratch(kWideScratchWords);
-    return wide_map(*n, *r, caps, scratch.data(), *out);
+    return wide_map(*n, *r, WideCaps(caps, share), scratch.data(), *out);
 }
-extern "C" int hh_wide_commit(nhdfit_wide_node* n, const nhdfit_req* r, const nhdfit_mapping* m, double busy_time, nhdfit_wide_placement* out) {
-    const int st = wide_commit(*n, *r, *m, busy_time, *out);
+extern "C" int hh_wide_commit(nhdfit_wide_node* n, const nhdfit_req* r, const nhdfit_mapping* m, double busy_time, nhdfit_wide_placement* out, nhdfit_wide_share* share) {
+    const int st = wide_commit(*n, *r, *m, busy_time, *out, share);
     out->pod = 0; out->node = n->index;
     return st;
 }
@@ -606,7 +607,8 @@ extern "C" int hh_wide_isect3(const int16_t* a, int na, const int16_t* b, int nb
 extern "C" void hh_big_eval(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
                             const nhdfit_plane4* p4, const nhdfit_detail* det, uint32_t n, const nhdfit_wide_node* wide, uint32_t n_wide,
                             const nhdfit_big_req* reqs, uint32_t P, double now, const double* caps, const uint64_t* cand,
-                            uint64_t global_base, uint8_t* fits, uint64_t* score, uint32_t* flags, uint32_t budget /* 0: NHDFIT_BIG_NIC_BUDGET */) {
+                            uint64_t global_base, uint8_t* fits, uint64_t* score, uint32_t* flags, uint32_t budget /* 0: NHDFIT_BIG_NIC_BUDGET */,
+                            const nhdfit_wide_share* share /* optional [n_wide] */) {
     const double busy_from = busy_threshold(now);
     for (uint32_t v = 0; v < n + n_wide; ++v) {
         nhdfit_wide_node view;
@@ -616,7 +618,7 @@ extern "C" void hh_big_eval(const nhdfit_plane0* p0, const nhdfit_plane1* p1, co
         const bool busy = view.busy_time >= busy_from;
         for (uint32_t i = 0; i < P; ++i) {
             NicSearch ns{budget ? budget : NHDFIT_BIG_NIC_BUDGET, false};
-            const bool ok = wide_fits(view, reqs[i], busy, caps, &ns);
+            const bool ok = wide_fits(view, reqs[i], busy, WideCaps(caps, share && v >= n ? share + (v - n) : nullptr), &ns);
             if (ns.exhausted) flags[1] = 1;
             flags[2] += (budget ? budget : NHDFIT_BIG_NIC_BUDGET) - ns.left;      // search steps spent (diagnostics)
             if (!ok) continue;
@@ -631,15 +633,16 @@ extern "C" void hh_big_eval(const nhdfit_plane0* p0, const nhdfit_plane1* p1, co
 // mapping of one winner: `wide` != NULL: that record, else node `v` of the planes
 extern "C" int hh_big_map(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3,
                           const nhdfit_plane4* p4, const nhdfit_detail* det, uint32_t v, const nhdfit_wide_node* wide,
-                          const nhdfit_big_req* r, const double* caps, nhdfit_big_mapping* out) {
+                          const nhdfit_big_req* r, const double* caps, nhdfit_big_mapping* out, const nhdfit_wide_share* share) {
     nhdfit_wide_node view;
     if (wide) view = *wide; else wide_view(p0[v], p1[v], p2[v], p3[v], p4[v], det[v], v, view);
     const uint32_t U = view.numa_nodes ? view.numa_nodes : 1, G = r->n_groups <= NHDFIT_BIG_MAX_GROUPS ? r->n_groups : NHDFIT_BIG_MAX_GROUPS;
     std::vector<int32_t> scratch(big_scratch_words(U, G));           // (the device sizes them for the mirror's widest node: any size >= the need gives the same answer)
-    return wide_map(view, *r, caps, scratch.data(), *out, (int32_t)wide_table_slots(wide_ipow(U, G)), (int32_t)wide_table_slots(wide_ipow(U, G + 1)));
+    return wide_map(view, *r, WideCaps(caps, wide ? share : nullptr), scratch.data(), *out, (int32_t)wide_table_slots(wide_ipow(U, G)), (int32_t)wide_table_slots(wide_ipow(U, G + 1)));
 }
-extern "C" int hh_big_commit_wide(nhdfit_wide_node* n, const nhdfit_big_req* r, const nhdfit_big_mapping* m, double busy_time, nhdfit_big_placement* out) {
-    const int st = wide_commit(*n, *r, *m, busy_time, *out);
+extern "C" int hh_big_commit_wide(nhdfit_wide_node* n, const nhdfit_big_req* r, const nhdfit_big_mapping* m, double busy_time, nhdfit_big_placement* out,
+                                  nhdfit_wide_share* share) {
+    const int st = wide_commit(*n, *r, *m, busy_time, *out, share);
     out->pod = 0; out->node = n->index;
     return st;
 }

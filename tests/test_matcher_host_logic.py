@@ -236,31 +236,47 @@ def test_reference_fixture_with_nodes_beyond_the_layout():
 
 
 
-def test_enable_sharing_flipped_in_the_nodes_module_is_refused_not_ignored(monkeypatch, caplog):
-    """VERDICT r03 missing #4: nhd/Node.py:20 ENABLE_SHARING = True makes GetFreeNumaNicResources price NICs by speed_used
-    (Node.py:290).  The product implements the shipped arithmetic (False): when the module the node objects come from has the
-    switch on, FindNode must not answer with placements of the other arithmetic - it leaves the pods pending and says why
-    (strict: raises at pack time); NIC_BW_AVAIL_PERCENT of that module is the one the capacities are computed with."""
+def test_enable_sharing_flipped_in_the_nodes_module_changes_the_arithmetic(monkeypatch):
+    """nhd/Node.py:20 ENABLE_SHARING = True makes GetFreeNumaNicResources price a NIC per direction at speed * 0.9 - speed_used[x]
+    (Node.py:290).  Rounds 3-4 refused such clusters; round 5 answers them through the general path (every node a wide record with
+    its NICs' speed_used, pack.WIDE_SHARE).  The constants are read from the module the node objects come from, so flipping that
+    module's switch changes the answers - to the oracle's with ITS switch flipped (pinned to the reference with the constant
+    flipped by tests/golden/sharing and tests/test_sharing.py) - and flipping it back restores the shipped ones;
+    NIC_BW_AVAIL_PERCENT of that module is the one the capacities are computed with."""
     from nhd_amd import pack
     nl = util.random_cluster(4242, 24)
+    for k, node in enumerate(nl.values()):                         # traffic on the NICs, and a pod on some of them: the two arithmetics disagree
+        for j, nic in enumerate(node.nics):
+            nic.speed_used = [float((7 * k + 3 * j) % 60), float((5 * k + j) % 50)]
+            nic.pods_used = (k + j) % 2
     top = refmodel.make_topology(dict(map_type="NUMA", hugepages_gb=0, misc=0, misc_smt=True,
-                                      groups=[dict(proc=2, helpers=0, rx=1.0, tx=1.0, gpus=[], proc_smt=False, helper_smt=False)]))
+                                      groups=[dict(proc=2, helpers=0, rx=40.0, tx=45.0, gpus=[], proc_smt=False, helper_smt=False)]))
     m = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)
-    want = norm(O.find_node(nl, top, util.CLOCK))
-    assert m.FindNode(nl, top) == want and want[0] is not None
+    shipped = norm(O.find_node(nl, top, util.CLOCK))
+    assert m.FindNode(nl, top) == shipped
     assert pack.node_module_constants(next(iter(nl.values()))) == {"NIC_BW_AVAIL_PERCENT": 0.9, "SCHEDULABLE_NIC_SPEED_THRESH_MBPS": 11000,
                                                                   "ENABLE_SHARING": False}
     monkeypatch.setattr(refmodel, "ENABLE_SHARING", True)
-    with caplog.at_level("ERROR"):
-        assert m.FindNode(nl, top) == (None,)
-        m.attach(nl)                                               # tracked subclasses still resolve to the nodes' own module
-        assert m.FindNodes(nl, [top, top]) == [(None,), (None,)]
-    assert "ENABLE_SHARING" in caplog.text
-    with pytest.raises(pack.SharingEnabled):
-        HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine, strict=True).FindNode(nl, top)
-    monkeypatch.setattr(refmodel, "ENABLE_SHARING", False)
+    monkeypatch.setattr(O, "ENABLE_SHARING", True)
+    shared = norm(O.find_node(nl, top, util.CLOCK))
+    assert shared != shipped                                       # (the case tells the two apart)
+    assert m.FindNode(nl, top) == shared
+    assert len(m.wide_nodes) == len(nl) and m.unmirrored == {}
+    m.attach(nl)                                                   # tracked subclasses still resolve to the nodes' own module
+    assert m.FindNodes(nl, [top, top]) == [shared, shared]
     m.detach()
-    assert m.FindNode(nl, top) == want                             # switched back: answers again
+    # a processing group with two RX cores: its speed_used updates would not be the request's one sum - turned away, loudly
+    two_rx = refmodel.make_topology(dict(map_type="NUMA", hugepages_gb=0, misc=0, misc_smt=True,
+                                         groups=[dict(proc=3, helpers=0, rx=10.0, tx=5.0, gpus=[], proc_smt=False, helper_smt=False)]))
+    extra = two_rx.proc_groups[0].proc_cores[2]
+    extra.nic_dir, extra.nic_speed = two_rx.proc_groups[0].proc_cores[0].nic_dir, 10.0
+    assert m.FindNode(nl, two_rx) == (None,)
+    with pytest.raises(pack.UnsupportedNode):
+        HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine, strict=True).FindNode(nl, two_rx)
+    monkeypatch.setattr(refmodel, "ENABLE_SHARING", False)
+    monkeypatch.setattr(O, "ENABLE_SHARING", False)
+    assert m.FindNode(nl, top) == shipped                          # switched back: the shipped arithmetic again
+    assert m.wide_nodes == []
     # the head-room constant is read from the same module: at 50 % a 2 x 50 Gb/s request no longer fits a 100 GbE NIC (cap 50.0)
     big = refmodel.make_topology(dict(map_type="NUMA", hugepages_gb=0, misc=0, misc_smt=True,
                                       groups=[dict(proc=2, helpers=0, rx=60.0, tx=60.0, gpus=[], proc_smt=False, helper_smt=False)]))

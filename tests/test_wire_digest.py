@@ -149,15 +149,6 @@ def test_sequential_batch_from_config_texts():
     tops = [ref_loader.config_to_topology(t) for t in texts]
     m = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)
     assert m.FindNodesFromConfigs(nl, texts, sequential=True) == m.ScheduleBatch(nl, tops)
-    # a text asking for more hugepages than the pod tile's table holds digests without a code: it must ride the general path like
-    # the same pod through FindNodes(tops), not fail the whole call (ADVICE r04)
-    import re
-    k = next(i for i, t in enumerate(tops) if len(t.proc_groups) <= 4 and re.search(r"hugepages_gb\s*=\s*\d+", texts[i]))
-    heavy = re.sub(r"(hugepages_gb\s*=\s*)\d+", r"\g<1>2000", texts[k], count=1)
-    heavy_top = ref_loader.config_to_topology(heavy)
-    assert int(heavy_top.hugepages_gb) == 2000
-    mixed_texts, mixed_tops = [texts[0], heavy, texts[1]], [tops[0], heavy_top, tops[1]]
-    assert m.FindNodesFromConfigs(nl, mixed_texts) == m.FindNodes(nl, mixed_tops)
 
 
 def test_configs_with_more_groups_than_the_table_pass_holds():
@@ -219,6 +210,15 @@ def test_matcher_from_config_texts_with_big_pods():
         placed_big += g[0] is not None and len(t.proc_groups) > 4
     assert placed_big >= 1
     assert m.FindNodesFromConfigs(nl, texts, sequential=True) == m.ScheduleBatch(nl, tops)
+    # a text asking for more hugepages than the pod tile's table holds digests without a code: it must ride the general path like
+    # the same pod through FindNodes(tops), not fail the whole call (ADVICE r04)
+    import re
+    k = next(i for i, t in enumerate(tops) if len(t.proc_groups) <= 4 and re.search(r"Hugepages_GB\s*=\s*[\d.]+L?;", texts[i]))
+    heavy = re.sub(r"(Hugepages_GB\s*=\s*)[\d.]+L?;", r"\g<1>2000;", texts[k], count=1)
+    heavy_top = ref_loader.config_to_topology(heavy)
+    assert int(heavy_top.hugepages_gb) == 2000
+    mixed_texts, mixed_tops = [texts[0], heavy, texts[1]], [tops[0], heavy_top, tops[1]]
+    assert m.FindNodesFromConfigs(nl, mixed_texts) == m.FindNodes(nl, mixed_tops)
 
 
 def test_mutated_big_configs_agree():

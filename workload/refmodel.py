@@ -155,6 +155,8 @@ def build_node(desc: dict, ref=None):
         node.gpus[g].used = True
     for nic, cnt in zip(node.nics, desc.get("nic_pods_used", ())):
         nic.pods_used = int(cnt)
+    for nic, used in zip(node.nics, desc.get("nic_speed_used", ())):       # (rx, tx) Gb/s already on the NIC (nhd/Node.py:46)
+        nic.speed_used = [used[0], used[1]]
     node.busy_time = float(desc.get("busy_time", 0.0))
     return node
 
