@@ -306,6 +306,15 @@ __device__ __forceinline__ int commit_node_wave(NodeState& s, nhdfit_detail& d, 
 // may overtake).  Together: commit_node_wave's state, record and status (tests/harness/wave_emul.cpp runs both on emulated lanes).
 __device__ __forceinline__ int commit_summary_wave(NodeState& s, nhdfit_detail& d, const nhdfit_req& r, const nhdfit_mapping& m, double busy_time,
                                                    const SigTable& sigs, uint32_t ncls, uint32_t lane, uint64_t& free0, uint64_t& free1) {
+    // the request's commit counts read ONCE, as independent dword loads: n_proc[0..3], n_help[0..3], (n_misc, smt_bits,
+    // misc_smt_enabled, nic_use) - byte by byte inside the group loop every one was a round trip with a wait on the chain
+    static_assert(kMaxG == 4 && offsetof(nhdfit_req, n_proc) % 4 == 0 && offsetof(nhdfit_req, n_help) % 4 == 0 && offsetof(nhdfit_req, n_misc) % 4 == 0 &&
+                  offsetof(nhdfit_req, smt_bits) == offsetof(nhdfit_req, n_misc) + 1 && offsetof(nhdfit_req, misc_smt_enabled) == offsetof(nhdfit_req, n_misc) + 2 &&
+                  offsetof(nhdfit_req, nic_use) == offsetof(nhdfit_req, n_misc) + 3, "packed reads of the request");
+    const uint32_t w_proc = *reinterpret_cast<const uint32_t*>(r.n_proc), w_help = *reinterpret_cast<const uint32_t*>(r.n_help);
+    const uint32_t w_tail = *reinterpret_cast<const uint32_t*>(&r.n_misc);
+    const int32_t hugepages = r.hugepages_gb;
+    const uint32_t smt_bits = (w_tail >> 8) & 0xFFu, nic_use = w_tail >> 24;
     const int G = (int)r.n_groups;
     free0 = s.p0.t0[0] & s.p1.t1[0];
     free1 = s.p0.t0[1] & s.p1.t1[1];
@@ -327,16 +336,16 @@ __device__ __forceinline__ int commit_summary_wave(NodeState& s, nhdfit_detail& 
     uint32_t claimed0 = 0, claimed1 = 0;
     for (int g = 0; g < G; ++g) {
         const uint32_t u = (m_gpu >> g) & 1u;
-        batch(u, r.n_proc[g], (r.smt_bits >> g & 1) != 0);
-        batch(u, r.n_help[g], (r.smt_bits >> (4 + g) & 1) != 0);
+        batch(u, (w_proc >> (8 * g)) & 0xFFu, (smt_bits >> g & 1) != 0);
+        batch(u, (w_help >> (8 * g)) & 0xFFu, (smt_bits >> (4 + g) & 1) != 0);
         const uint32_t nu = (m_nnuma >> g) & 1u, nk = (m_nidx >> (4 * g)) & 15u;
-        if (r.nic_use >> g & 1) { if (nu) claimed1 |= 1u << nk; else claimed0 |= 1u << nk; }
+        if (nic_use >> g & 1) { if (nu) claimed1 |= 1u << nk; else claimed0 |= 1u << nk; }
     }
-    batch(mu, r.n_misc, r.misc_smt_enabled != 0);
+    batch(mu, w_tail & 0xFFu, ((w_tail >> 16) & 0xFFu) != 0);
     const uint64_t gone0 = took0 ? lowest_bits_wave(free0, took0, lane) : 0ull, gone1 = took1 ? lowest_bits_wave(free1, took1, lane) : 0ull;
     if (lane == 0) {
         s.p0.t0[0] &= ~gone0; s.p0.t0[1] &= ~gone1;
-        if (r.hugepages_gb > 0) s.p2.hp_free -= r.hugepages_gb;              // Node.py:794-796
+        if (hugepages > 0) s.p2.hp_free -= hugepages;                        // Node.py:794-796
         s.p4.busy_time = busy_time;                                          // SetBusy, nhd/Node.py:843-845
         for (uint32_t cl = claimed0 | (claimed1 << 16); cl; cl &= cl - 1u) {  // ClaimPodNICResources (as commit_node_wave)
             const uint32_t b = (uint32_t)__builtin_ctz(cl), u = b >> 4, k = b & 15u;
@@ -482,7 +491,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     __shared__ uint32_t s_rv[kSpecWaves], s_rd[kSpecWaves];    // the posted node (kNoNode: none takes the pod) and the version looked at
     __shared__ uint32_t s_examv[kSpecWaves], s_pende[kSpecWaves];   // the node a speculator is examining / has posted, and its pod: a later pod does not post
                                                                // that node before the earlier one has made up its mind
-    __shared__ uint32_t s_cnt[16];                             // tuning aid: [0] failed verifications [1] LDS cache hits [2] published states read [3] untouched [4] waits for an earlier pod's target [5] window rescans
+    __shared__ uint32_t s_cnt[32];                             // tuning aid: [0] failed verifications [1] LDS cache hits [2] published states read [3] untouched [4] waits for an earlier pod's target [5] window rescans
                                                                // [8..14] speculator ticks: set-up, node state, verification, commit stage 1, waiting for the sequencer, publication, commit stage 2
     static_assert(kSpecWaves * kSpecCache <= 64, "the cache tags are searched by one wavefront");
     extern __shared__ __align__(16) uint8_t s_dyn[];
@@ -596,7 +605,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     if (tid < kDecideRing) s_ready[tid] = 0;
     if (tid < 64) { s_ctag[tid] = kNoNode; s_cver[tid] = 0; }
     if (tid < kSpecWaves) { s_post[tid] = 0; s_verd[tid] = 0; s_examv[tid] = kNoNode; s_pende[tid] = 0xFFFFFFFFu; }
-    if (tid < 16) s_cnt[tid] = 0;
+    if (tid < 32) s_cnt[tid] = 0;
     for (uint32_t k = tid; k < a.chunks; k += 64 * kDecideWaves) { s_taken[k] = 0; s_tgpu[k] = 0; }
     for (uint32_t k = tid; k < q.hash_slots; k += 64 * kDecideWaves) s_hash[k] = kNoNode;
     for (uint32_t k = tid; k < (a.P + 31) / 32; k += 64 * kDecideWaves) s_isn[k] = 0;
@@ -750,7 +759,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         nhdfit_placement& pl = s_wplace[wave];
         uint32_t cache_next = 0;
         uint32_t c_fail = 0, c_hit = 0, c_pub = 0, c_plain = 0, c_chain = 0, c_rescan = 0;
-        unsigned long long t_acc[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = kTuning ? wall_clock64() : 0;    // tuning aid (100 MHz ticks)
+        unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = kTuning ? wall_clock64() : 0;    // tuning aid (100 MHz ticks)
         auto lap = [&](int k) { if (kTuning) { const unsigned long long t = wall_clock64(); t_acc[k] += t - t_last; t_last = t; } };
         // an earlier pod is examining / has posted node v: its word on that node comes first
         auto earlier_pod_on = [&](uint32_t v, uint32_t e) {
@@ -845,6 +854,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 }
                 // the pod the sequencer is waiting for runs ahead of its SIMD's other wavefront
                 if (wg_load(&s_done) == e) __builtin_amdgcn_s_setprio(3);
+                lap(7);
                 // the node at the latest version there is -> the cache entry this speculator works in (tagged kNoNode)
                 const uint32_t ce = sp * kSpecCache + cache_next % kSpecCache;
                 NodeState& st = s_cst[ce];
@@ -888,15 +898,18 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 bool ok = !stale_bit && rq.hugepages_gb <= st.p2.hp_free;                  // nhd/Matcher.py:78
                 if (ok) {                                                 // cheap necessary condition before the table look-ups: enough free
                     const bool smt = (st.p2.flags & NHDFIT_NF_SMT) != 0;  // physical cores on the node as a whole
+                    const uint64_t w_cpu = smt ? *reinterpret_cast<const uint64_t*>(rq.cpu_smt) : *reinterpret_cast<const uint64_t*>(rq.cpu_nosmt);   // (one read, not one per group)
                     uint32_t need = smt ? rq.misc_smt : rq.misc_nosmt;
-                    for (uint32_t g = 0; g < rq.n_groups; ++g) need += smt ? rq.cpu_smt[g] : rq.cpu_nosmt[g];
+                    for (uint32_t g = 0; g < rq.n_groups; ++g) need += (uint32_t)(w_cpu >> (16 * g)) & 0xFFFFu;
                     ok = need <= (uint32_t)popc64(st.p0.t0[0] & st.p1.t1[0]) + (uint32_t)popc64(st.p0.t0[1] & st.p1.t1[1]);
                 }
                 nhdfit_mapping mp = nhdfit_mapping{};
+                lap(8);
                 if (ok) {
                     const bool pci = rq.map_type == NHDFIT_MAP_PCI;
                     const uint32_t bits = nic_tab ? (s_snic[sp][pci ? st.p3.sig_pci[0] : st.p3.sig_numa[0]] & 0xFFFFu) & (s_snic[sp][pci ? st.p3.sig_pci[1] : st.p3.sig_numa[1]] >> 16)
                                                   : nic_assignment_bits_wave(img, L, pos & 63, pci, st.p3, lane);
+                    lap(9);
                     ok = map_on_state_wave(rq, st, dd, s_caps, bits, mt, lane, mp);
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -924,6 +937,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     if (decisions_on(v) != ver) continue;                 // (the bit is still set: the same node at its new version)
                 }
                 if (wg_load(&s_done) == e) __builtin_amdgcn_s_setprio(3);
+                lap(10);
                 int32_t status = kCommitOk;
                 uint64_t free0 = 0, free1 = 0;                            // the sockets' free sets as this pod found them (stage 2 picks from them)
                 const bool smt_node = (st.p2.flags & NHDFIT_NF_SMT) != 0;
@@ -935,6 +949,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     if (lane == 0) { res.node = (int64_t)a.global_base + (int64_t)v; res.map = mp; }
+                    lap(11);
                     // what the next pod's verification reads of this commit: counts, hugepages, NIC classes, signature ids (commit_summary_wave)
                     status = kTuning && (q.dbg & 2) ? kCommitOk : commit_summary_wave(st, dd, rq, mp, a.now, sigs, q.ncls, lane, free0, free1);
                     lap(3);
@@ -988,7 +1003,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             wg_store(&s_pende[sp], 0xFFFFFFFFu);
             atomicAdd(&s_cnt[0], c_fail); atomicAdd(&s_cnt[1], c_hit); atomicAdd(&s_cnt[2], c_pub); atomicAdd(&s_cnt[3], c_plain);
             atomicAdd(&s_cnt[4], c_chain); atomicAdd(&s_cnt[5], c_rescan);
-            if (kTuning) for (int k = 0; k < 7; ++k) atomicAdd(&s_cnt[8 + k], (uint32_t)t_acc[k]);
+            if (kTuning) for (int k = 0; k < 16; ++k) atomicAdd(&s_cnt[8 + k], (uint32_t)t_acc[k]);
             __hip_atomic_fetch_add(&s_spec_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         return;
@@ -1084,7 +1099,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     if (lane == 0) {
         q.ctrl[4] = s_cnt[0]; q.ctrl[5] = s_cnt[1]; q.ctrl[6] = s_cnt[2]; q.ctrl[7] = s_cnt[3]; q.ctrl[8] = s_cnt[4]; q.ctrl[14] = s_cnt[5]; q.ctrl[15] = c_redo;
         q.ctrl[9] = (uint32_t)t_ready; q.ctrl[10] = (uint32_t)t_gpu; q.ctrl[11] = (uint32_t)t_post; q.ctrl[12] = (uint32_t)t_retire;
-        if (kTuning) for (int k = 0; k < 7; ++k) q.ctrl[16 + k] = s_cnt[8 + k];
+        if (kTuning) for (int k = 0; k < 16; ++k) q.ctrl[16 + k] = s_cnt[8 + k];
         wg_store(&s_done, n_pods);                                        // the fetchers run out
         const uint32_t n_items = wg_load(&s_nitems);
         __hip_atomic_store(&q.ctrl[1], (n_items < q.queue_len ? n_items : q.queue_len) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the workers leave once the queue is drained

@@ -56,17 +56,25 @@ __device__ __forceinline__ uint32_t nic_assignment_bits_wave(const uint8_t* img,
 __device__ __forceinline__ void candidate_masks_wave(const nhdfit_req& r, const WinnerState& w, uint32_t lane, uint32_t& sg_mask, uint32_t& sc_mask) {
     const int G = (int)r.n_groups, U = w.U;
     const uint32_t nG = ipow(U, G), nC = ipow(U, G + 1);
+    // the request lives in LDS and the wavefront walks this chain alone: its operands are read ONCE, as four independent loads
+    // (16-bit fields, four groups per 64-bit word), not field by field inside the loops - each of those a round trip with a wait
+    static_assert(kMaxG == 4 && offsetof(nhdfit_req, gpus) % 8 == 0 && offsetof(nhdfit_req, cpu_smt) % 8 == 0 && offsetof(nhdfit_req, cpu_nosmt) % 8 == 0 &&
+                  offsetof(nhdfit_req, misc_nosmt) == offsetof(nhdfit_req, misc_smt) + 2 && offsetof(nhdfit_req, misc_smt) % 4 == 0, "packed reads of the request");
+    const uint64_t w_gpus = *reinterpret_cast<const uint64_t*>(r.gpus);
+    const uint64_t w_cpu = w.smt ? *reinterpret_cast<const uint64_t*>(r.cpu_smt) : *reinterpret_cast<const uint64_t*>(r.cpu_nosmt);
+    const uint32_t w_misc = *reinterpret_cast<const uint32_t*>(&r.misc_smt);
+    const uint32_t misc = w.smt ? (w_misc & 0xFFFFu) : (w_misc >> 16);
     bool okg = false, okc = false;
     if (lane < nG) {
         uint32_t t0 = 0, t1 = 0;
-        for (int g = 0; g < G; ++g) { if (tup_digit(lane, G, U, g)) t1 += r.gpus[g]; else t0 += r.gpus[g]; }
+        for (int g = 0; g < G; ++g) { const uint32_t d = (uint32_t)(w_gpus >> (16 * g)) & 0xFFFFu; if (tup_digit(lane, G, U, g)) t1 += d; else t0 += d; }
         okg = t0 <= (uint32_t)w.free_g[0] && t1 <= (uint32_t)w.free_g[1];
     }
     if (lane >= 32 && lane - 32 < nC) {
         const uint32_t code = lane - 32;
         uint32_t t0 = 0, t1 = 0;
         for (int g = 0; g <= G; ++g) {
-            const uint32_t d = g < G ? (w.smt ? r.cpu_smt[g] : r.cpu_nosmt[g]) : (w.smt ? r.misc_smt : r.misc_nosmt);
+            const uint32_t d = g < G ? (uint32_t)(w_cpu >> (16 * g)) & 0xFFFFu : misc;
             if (tup_digit(code, G + 1, U, g)) t1 += d; else t0 += d;
         }
         okc = t0 <= (uint32_t)w.free_c[0] && t1 <= (uint32_t)w.free_c[1];
@@ -80,6 +88,13 @@ __device__ __forceinline__ void candidate_masks_wave(const nhdfit_req& r, const 
 // memory - a memory round trip per access on the chain of the sequential kernels)
 __device__ __forceinline__ bool first_nic_choice_wave(const nhdfit_req& r, const WinnerState& w, uint32_t gcode, bool pci, uint32_t lane, uint32_t& nic_nibbles) {
     const int G = (int)r.n_groups;
+    // wave-uniform operands read ONCE (request and detail live in LDS: a read inside the loops below is a round trip with a wait
+    // on a chain this wavefront walks alone): the two NIC counts, the four groups' rx / tx - picked by run-time group with selects
+    static_assert(kMaxG == 4, "sel4 picks among four groups");
+    const uint32_t cnt0 = w.d->nic_cnt[0], cnt1 = w.d->nic_cnt[1];
+    const double rx0 = r.rx[0], rx1 = r.rx[1], rx2 = r.rx[2], rx3 = r.rx[3];
+    const double tx0 = r.tx[0], tx1 = r.tx[1], tx2 = r.tx[2], tx3 = r.tx[3];
+    auto sel4 = [](int h, double a0, double a1, double a2, double a3) { return h == 0 ? a0 : h == 1 ? a1 : h == 2 ? a2 : a3; };
     uint32_t order = 0, numa = 0;
     int n = 0;
     for (int u = 0; u < w.U; ++u)
@@ -87,7 +102,7 @@ __device__ __forceinline__ bool first_nic_choice_wave(const nhdfit_req& r, const
             if (tup_digit(gcode, G, w.U, g) == u) { order = nib_set(order, n, (uint32_t)g); numa |= (uint32_t)u << g; ++n; }
     uint32_t total = 1;
     for (int g = 0; g < G; ++g) {
-        const uint32_t k = w.d->nic_cnt[(numa >> g) & 1];
+        const uint32_t k = (numa >> g) & 1 ? cnt1 : cnt0;
         if (k == 0) return false;
         total *= k;
     }
@@ -96,7 +111,7 @@ __device__ __forceinline__ bool first_nic_choice_wave(const nhdfit_req& r, const
         const bool live = rem < total;
         for (int pos = G - 1; pos >= 0; --pos) {
             const int g = (int)nib_get(order, pos);
-            const uint32_t k = w.d->nic_cnt[(numa >> g) & 1];
+            const uint32_t k = (numa >> g) & 1 ? cnt1 : cnt0;
             pick = nib_set(pick, g, rem % k);
             rem /= k;
         }
@@ -109,7 +124,7 @@ __device__ __forceinline__ bool first_nic_choice_wave(const nhdfit_req& r, const
             if (!first_on_nic) continue;
             double rx = w.caps[w.d->nic_cls[u][k]], tx = rx;                     // Matcher.py:261-263, group order
             for (int h = g; h < G; ++h)
-                if (((numa >> h) & 1) == u && nib_get(pick, h) == k) { rx = rx - r.rx[h]; tx = tx - r.tx[h]; }
+                if (((numa >> h) & 1) == u && nib_get(pick, h) == k) { rx = rx - sel4(h, rx0, rx1, rx2, rx3); tx = tx - sel4(h, tx0, tx1, tx2, tx3); }
             if (rx < 0 || tx < 0) ok = false;                                    // Matcher.py:267
         }
         if (ok && pci) {                                                         // Matcher.py:312-322
