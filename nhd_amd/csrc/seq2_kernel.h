@@ -333,7 +333,7 @@ __device__ __forceinline__ int commit_summary_wave(NodeState& s, nhdfit_detail& 
         if (u) { const uint32_t t = want < left1 ? want : left1; left1 -= t; took1 += t; }
         else   { const uint32_t t = want < left0 ? want : left0; left0 -= t; took0 += t; }
     };
-    uint32_t claimed0 = 0, claimed1 = 0;
+    uint32_t claimed0 = 0, claimed1 = 0, repriced = 0;
     for (int g = 0; g < G; ++g) {
         const uint32_t u = (m_gpu >> g) & 1u;
         batch(u, (w_proc >> (8 * g)) & 0xFFu, (smt_bits >> g & 1) != 0);
@@ -349,14 +349,18 @@ __device__ __forceinline__ int commit_summary_wave(NodeState& s, nhdfit_detail& 
         s.p4.busy_time = busy_time;                                          // SetBusy, nhd/Node.py:843-845
         for (uint32_t cl = claimed0 | (claimed1 << 16); cl; cl &= cl - 1u) {  // ClaimPodNICResources (as commit_node_wave)
             const uint32_t b = (uint32_t)__builtin_ctz(cl), u = b >> 4, k = b & 15u;
-            if (pods_get(d, u, k) != kPodsLost && pods_add(d, u, k, 1) != 0) d.nic_cls[u][k] = 0;
+            if (pods_get(d, u, k) != kPodsLost && pods_add(d, u, k, 1) != 0 && d.nic_cls[u][k] != 0) { d.nic_cls[u][k] = 0; repriced |= 1u << u; }
         }
     }
+    repriced = (uint32_t)__builtin_amdgcn_readfirstlane((int)repriced);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     int status = kCommitOk;
     for (uint32_t u = 0; u < 2; ++u) {
-        if (!(u ? claimed1 : claimed0)) continue;                            // (no GPU is taken: a NUMA node without a claim keeps its ids)
+        // A NUMA node's signature ids are a function of its NICs' capacity classes and the free GPUs behind their switches.  No GPU
+        // is taken here, so they only move when a claim takes a NIC's capacity away - its FIRST claim: pods that pile onto a node
+        // claim the NIC their predecessor claimed, and the keys (64-bit mixes, hash look-ups: most of this stage) need not be formed
+        if (!(repriced >> u & 1u)) continue;
         uint64_t kn, kp;
         uint32_t idn = 0, idp = 0;
         sig_keys_wave(d, u, lane, ncls, kn, kp);

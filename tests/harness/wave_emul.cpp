@@ -50,6 +50,7 @@ inline int readlane(int v, int l) {                                  // every la
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
 #define __builtin_amdgcn_readlane(v, l) emu::readlane((v), (l))
+#define __builtin_amdgcn_readfirstlane(v) emu::readlane((v), 0)      // (all 64 lanes are active in every routine run here)
 #define __noinline__ __attribute__((noinline))
 
 namespace {

@@ -8,7 +8,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-/tmp/probe_wave}
 mkdir -p "$OUT"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off --cuda-device-only -S "$ROOT/tools/probe_wave.hip" -I"$ROOT/include" -o "$OUT/probe.s" 2>/dev/null
-for k in probe_commitEP probe_commit_v2 probe_mapE probe_map_v2 probe_lone_mapE probe_lone_map_shipped; do
+for k in probe_commitEP probe_summary probe_mapE probe_lone_mapE probe_lone_map_shipped; do
     awk -v k="$k" '$0 ~ "^_ZN.*" k ".*: ; @" {f=1} f {print} f && /^\.Lfunc_end/ {f=0}' "$OUT/probe.s" > "$OUT/$k.s"
     total=$(grep -cE '^\s+(v_|s_|ds_|global_|buffer_|flat_|scratch_)' "$OUT/$k.s" || true)
     echo "== $k: $total instructions (static)"
