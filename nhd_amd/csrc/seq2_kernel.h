@@ -347,9 +347,33 @@ __device__ __forceinline__ int commit_summary_wave(NodeState& s, nhdfit_detail& 
         s.p0.t0[0] &= ~gone0; s.p0.t0[1] &= ~gone1;
         if (hugepages > 0) s.p2.hp_free -= hugepages;                        // Node.py:794-796
         s.p4.busy_time = busy_time;                                          // SetBusy, nhd/Node.py:843-845
-        for (uint32_t cl = claimed0 | (claimed1 << 16); cl; cl &= cl - 1u) {  // ClaimPodNICResources (as commit_node_wave)
-            const uint32_t b = (uint32_t)__builtin_ctz(cl), u = b >> 4, k = b & 15u;
-            if (pods_get(d, u, k) != kPodsLost && pods_add(d, u, k, 1) != 0 && d.nic_cls[u][k] != 0) { d.nic_cls[u][k] = 0; repriced |= 1u << u; }
+        if (claimed0 | claimed1) {
+            // ClaimPodNICResources (pods_add / the capacity class, as commit_node_wave) on the counters and classes READ ONCE: the 32
+            // three-bit counters are bytes 82..93 of the record - NUMA 0's sixteen in bits 16..63 of the 8 bytes at 80, NUMA 1's in
+            // bits 0..47 of the 8 bytes at 88 -, a NUMA node's sixteen classes two 8-byte words.  (pods_get / pods_add walk them byte
+            // by byte: six dependent LDS round trips per claimed NIC on the chain.)
+            static_assert(offsetof(nhdfit_detail, nic_pods) == 82 && offsetof(nhdfit_detail, nic_cls) == 16 && NHDFIT_MAX_NICS_PER_NUMA == 16 && sizeof(d.nic_pods) == 12,
+                          "packed reads of the detail record");
+            uint64_t* dw = reinterpret_cast<uint64_t*>(__builtin_assume_aligned(&d, 8));
+            uint64_t pods[2] = {dw[10], dw[11]}, cls[2][2] = {{dw[2], dw[3]}, {dw[4], dw[5]}};
+            const uint64_t pods_was[2] = {pods[0], pods[1]};
+            for (uint32_t cl = claimed0 | (claimed1 << 16); cl; cl &= cl - 1u) {
+                const uint32_t b = (uint32_t)__builtin_ctz(cl), u = b >> 4, k = b & 15u;
+                const uint32_t sh = (u ? 0u : 16u) + 3u * k;
+                const uint32_t cur = (uint32_t)(pods[u] >> sh) & 7u;
+                if (cur == kPodsLost) continue;
+                const int nv = (cur < 4u ? (int)cur : (int)cur - 8) + 1;
+                const bool lost = nv > 3;                                     // (a claim only ever counts up)
+                pods[u] = (pods[u] & ~(7ull << sh)) | ((uint64_t)(lost ? kPodsLost : ((uint32_t)nv & 7u)) << sh);
+                if (lost || nv > 0) {                                         // pods_used > 0 (or unknown): the NIC's capacity is gone
+                    const uint32_t cs = 8u * (k & 7u);
+                    if ((cls[u][k >> 3] >> cs) & 0xFFull) { cls[u][k >> 3] &= ~(0xFFull << cs); repriced |= 1u << u; }
+                }
+            }
+            if (pods[0] != pods_was[0]) dw[10] = pods[0];
+            if (pods[1] != pods_was[1]) dw[11] = pods[1];
+            if (repriced & 1u) { dw[2] = cls[0][0]; dw[3] = cls[0][1]; }
+            if (repriced & 2u) { dw[4] = cls[1][0]; dw[5] = cls[1][1]; }
         }
     }
     repriced = (uint32_t)__builtin_amdgcn_readfirstlane((int)repriced);
@@ -487,7 +511,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     __shared__ uint64_t s_swin[kSpecWaves][64];
     __shared__ uint32_t s_snic[kSpecWaves][kNicSigs];          // per signature: low half = assignments that pass the NIC test on NUMA 0, high half on NUMA 1
     __shared__ NodeState s_cst[kSpecWaves * kSpecCache];       // nodes the speculators committed to, most recent kSpecCache each; the entry a
-    __shared__ nhdfit_detail s_cdet[kSpecWaves * kSpecCache];  // speculator works in is tagged kNoNode until its commit is retired
+    __shared__ __align__(16) nhdfit_detail s_cdet[kSpecWaves * kSpecCache];  // speculator works in is tagged kNoNode until its commit is retired
     __shared__ uint32_t s_ctag[64], s_cver[64];
     __shared__ NodeState s_pst[kSpecWaves];                    // a never-touched node as it was (first-touch copy, written at retirement)
     __shared__ nhdfit_detail s_pdet[kSpecWaves];

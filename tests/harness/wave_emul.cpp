@@ -113,7 +113,7 @@ int we_commit(nhdfit_plane0* p0, nhdfit_plane1* p1, nhdfit_plane2* p2, nhdfit_pl
     }
     const SigTable sigs{skeys.data(), sids.data(), slots - 1};
     NodeState st{*p0, *p1, *p2, *p3, *p4};                       // the wavefront's LDS copies
-    nhdfit_detail dd = *det;
+    alignas(16) nhdfit_detail dd = *det;
     nhdfit_placement pl;
     std::memset(&pl, 0xA5, sizeof pl);                           // (the wavefront form initialises the record itself)
     int status[emu::kLanes];
