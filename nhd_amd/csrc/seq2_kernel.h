@@ -517,12 +517,6 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     __shared__ nhdfit_detail s_pdet[kSpecWaves];
     __shared__ uint32_t s_post[kSpecWaves], s_verd[kSpecWaves];  // speculator -> sequencer: (pod + 1) << 4 | attempt; back: the same << 1 | retire
     __shared__ uint32_t s_rv[kSpecWaves], s_rd[kSpecWaves];    // the posted node (kNoNode: none takes the pod) and the version looked at
-    // chained speculation (round 5): a posted pod's working entry holds the node's COMPLETE state after its commit (stage 1 runs before
-    // the post), so the next pod on that node may start from it while the sequencer still validates - and says so when it posts
-    __shared__ uint32_t s_prov[kSpecWaves], s_pce[kSpecWaves];      // post id whose cache entry (s_pce) is complete; 0 = none
-    __shared__ uint32_t s_dslot[kSpecWaves], s_dpod[kSpecWaves], s_dv[kSpecWaves], s_dver[kSpecWaves];   // what a post depends on: speculator slot (kNoNode: nothing),
-                                                                    // that slot's pod, and the (node, version) it must have retired on
-    __shared__ uint32_t s_lpod[kSpecWaves], s_lv[kSpecWaves], s_lver[kSpecWaves];                          // sequencer only: a slot's last retirement
     __shared__ uint32_t s_examv[kSpecWaves], s_pende[kSpecWaves];   // the node a speculator is examining / has posted, and its pod: a later pod does not post
                                                                // that node before the earlier one has made up its mind
     __shared__ uint32_t s_cnt[32];                             // tuning aid: [0] failed verifications [1] LDS cache hits [2] published states read [3] untouched [4] waits for an earlier pod's target [5] window rescans
@@ -638,8 +632,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     if (tid == 0) { s_done = 0; s_abort = 0; s_nitems = 0; s_spec_done = 0; }
     if (tid < kDecideRing) s_ready[tid] = 0;
     if (tid < 64) { s_ctag[tid] = kNoNode; s_cver[tid] = 0; }
-    if (tid < kSpecWaves) { s_post[tid] = 0; s_verd[tid] = 0; s_examv[tid] = kNoNode; s_pende[tid] = 0xFFFFFFFFu; s_prov[tid] = 0; s_pce[tid] = 0;
-                            s_dslot[tid] = kNoNode; s_lpod[tid] = kNoNode; s_lv[tid] = kNoNode; s_lver[tid] = 0; }
+    if (tid < kSpecWaves) { s_post[tid] = 0; s_verd[tid] = 0; s_examv[tid] = kNoNode; s_pende[tid] = 0xFFFFFFFFu; }
     if (tid < 32) s_cnt[tid] = 0;
     for (uint32_t k = tid; k < a.chunks; k += 64 * kDecideWaves) { s_taken[k] = 0; s_tgpu[k] = 0; }
     for (uint32_t k = tid; k < q.hash_slots; k += 64 * kDecideWaves) s_hash[k] = kNoNode;
@@ -838,11 +831,9 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             __builtin_amdgcn_wave_barrier();
             lap(0);
             // posts (v, version) and waits for the sequencer's word: true = retire
-            // `dslot` != kNoNode: the answer holds only if that speculator's pod `dpod` retired on node `dv` at version `dver`
-            uint32_t dslot = kNoNode, dpod = 0, dv = 0, dver = 0;
             auto post_and_wait = [&](uint32_t v, uint32_t ver, auto&& meanwhile) -> bool {
                 const uint32_t id = ((e + 1u) << 4) | (attempt & 15u);
-                if (lane == 0) { s_rv[sp] = v; s_rd[sp] = ver; s_dslot[sp] = dslot; s_dpod[sp] = dpod; s_dv[sp] = dv; s_dver[sp] = dver; }
+                if (lane == 0) { s_rv[sp] = v; s_rd[sp] = ver; }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) wg_store(&s_post[sp], id);
                 meanwhile();
@@ -856,17 +847,6 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 ++attempt;
                 return !stop && (word & 1u);
             };
-            // a rejection (or "no node takes the pod") decided on a predecessor's not yet retired state is conditional on that
-            // retirement: one such condition travels with the post; when it fails the pod starts over from its first window
-            bool cond_set = false;
-            uint32_t cslot = 0, cpod = 0, cv = 0, cver = 0;
-            auto restart = [&]() {
-                cond_set = false;
-                pass = ent.w ? 1u : 2u;
-                have = scan_window(win, pos, pass, ent.z >> 6, ent.z & 63u, wbase);
-                if (!have && pass == 1u) { pass = 4u; have = scan_window(win, pos, 4u, 0, 0, wbase); }
-            };
-            for (;;) {
             while (have && !placed && !stop) {
                 const uint64_t w = win[lane];
                 const uint64_t any = __ballot(w != 0);
@@ -888,26 +868,12 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 // reads and verifies the node (round 5): consecutive pods without GPUs pile onto the same node, so the state an
                 // earlier pod is about to change is not worth a verification, and a wavefront verifying in vain shares its SIMD's
                 // issue slots with the one whose pod is next to retire (config 2: 3.75 verifications per pod, one of them needed).
-                // ... unless the LAST of them has posted this node: its working entry then holds the node as its commit leaves it
-                // (stage 1 runs before the post), and this pod starts from that copy while the sequencer still validates the other -
-                // its own post names the dependency and the sequencer ties the two retirements together (chained speculation).
-                uint32_t chain_slot = kNoNode, chain_id = 0;
                 if (earlier_pod_on(v, e)) {
                     ++c_chain;
                     __builtin_amdgcn_s_setprio(0);
-                    for (uint32_t spin = 0; !stop; ++spin) {
+                    for (uint32_t spin = 0; earlier_pod_on(v, e) && !stop; ++spin) {
                         if (spin > kSpinLimit) give_up();
                         if (wg_load(&s_abort)) stop = true;
-                        const uint32_t my_pod = lane < (uint32_t)kSpecWaves ? wg_load(&s_pende[lane]) : 0u;
-                        const uint64_t blk = __ballot(lane < (uint32_t)kSpecWaves && lane != sp && wg_load(&s_examv[lane]) == v && my_pod < e);
-                        if (!blk) break;
-                        uint32_t last = 0, last_pod = 0;                  // the blocker with the largest pod index: the immediate predecessor on v
-                        for (uint64_t m = blk; m; m &= m - 1ull) {
-                            const uint32_t k = (uint32_t)__builtin_ctzll(m), pk = (uint32_t)__builtin_amdgcn_readlane((int)my_pod, (int)k);
-                            if (pk >= last_pod) { last = k; last_pod = pk; }
-                        }
-                        const uint32_t idq = wg_load(&s_post[last]);
-                        if (!cond_set && (idq >> 4) == last_pod + 1u && wg_load(&s_prov[last]) == idq && wg_load(&s_rv[last]) == v) { chain_slot = last; chain_id = idq; break; }
                         __builtin_amdgcn_s_sleep(2);
                     }
                     __builtin_amdgcn_s_setprio(2);
@@ -923,16 +889,6 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 nhdfit_detail& dd = s_cdet[ce];
                 uint32_t ver = 0;
                 bool stale_bit = false;
-                if (chain_slot != kNoNode) {
-                    const uint32_t src = wg_load(&s_pce[chain_slot]);
-                    ver = wg_load(&s_rd[chain_slot]) + 1u;                // the version the predecessor's commit makes
-                    if (lane < sizeof(NodeState) / 4) reinterpret_cast<uint32_t*>(&st)[lane] = reinterpret_cast<const uint32_t*>(&s_cst[src])[lane];
-                    if (lane < sizeof(nhdfit_detail) / 4) reinterpret_cast<uint32_t*>(&dd)[lane] = reinterpret_cast<const uint32_t*>(&s_cdet[src])[lane];
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    if (wg_load(&s_prov[chain_slot]) != chain_id) continue;   // the predecessor was sent back meanwhile (it overwrites its entry): look again
-                    ++c_hit;
-                } else
                 for (uint32_t spin = 0; !stop; ++spin) {
                     if (spin > kSpinLimit) { give_up(); break; }
                     if (wg_load(&s_abort)) { stop = true; break; }
@@ -988,11 +944,6 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 lap(2);
                 if (!ok) {                                                // not this node - at no later version either
                     ++c_fail;
-                    if (chain_slot != kNoNode) {
-                        // ... if the predecessor retires as posted: until then "at no later version" is a condition, not a fact (feasibility
-                        // shrinks along REAL history only).  It travels with this pod's post (cond_set keeps a second chain from forming)
-                        cond_set = true; cslot = chain_slot; cpod = (chain_id >> 4) - 1u; cv = v; cver = ver - 1u;
-                    }
                     if (lane == 0) wg_store(&s_examv[sp], kNoNode);
                     if (lane == (uint32_t)l) win[lane] = w & ~(1ull << (v & 63));
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1000,16 +951,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     continue;
                 }
                 // an earlier pod that is looking at this node (or has posted it) goes first; if it takes the node, this one looks again
-                bool wait_them = earlier_pod_on(v, e);                    // (one that came to this node while it was verified)
-                if (wait_them && chain_slot != kNoNode) {
-                    // chained: the predecessor and ITS predecessors are still on the node, by design.  Anyone else - an earlier pod with a
-                    // larger index than the predecessor's, or the predecessor no longer standing by its post - breaks the chain
-                    const uint32_t my_pod = lane < (uint32_t)kSpecWaves ? wg_load(&s_pende[lane]) : 0u;
-                    const uint32_t chain_pod = (chain_id >> 4) - 1u;
-                    const uint64_t newer = __ballot(lane < (uint32_t)kSpecWaves && lane != sp && wg_load(&s_examv[lane]) == v && my_pod < e && my_pod > chain_pod);
-                    wait_them = newer != 0ull || wg_load(&s_prov[chain_slot]) != chain_id;
-                }
-                if (wait_them) {
+                if (earlier_pod_on(v, e)) {                               // (one that came to this node while it was verified)
                     ++c_chain;
                     __builtin_amdgcn_s_setprio(0);
                     for (uint32_t spin = 0; earlier_pod_on(v, e) && !stop; ++spin) {
@@ -1020,42 +962,28 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     __builtin_amdgcn_s_setprio(2);
                     lap(4);
                     if (stop) break;
-                    if (chain_slot != kNoNode || decisions_on(v) != ver) continue;   // (the bit is still set: the same node at its new version)
+                    if (decisions_on(v) != ver) continue;                 // (the bit is still set: the same node at its new version)
                 }
                 if (wg_load(&s_done) == e) __builtin_amdgcn_s_setprio(3);
                 lap(10);
                 int32_t status = kCommitOk;
                 uint64_t free0 = 0, free1 = 0;                            // the sockets' free sets as this pod found them (stage 2 picks from them)
                 const bool smt_node = (st.p2.flags & NHDFIT_NF_SMT) != 0;
-                // Stage 1 of the commit BEFORE the post (round 5, chained speculation): what the next pod's verification reads of this
-                // commit - counts, hugepages, NIC classes, signature ids - is then in this speculator's working entry when the post
-                // becomes visible, and a successor on the same node copies it from there without waiting for the retirement.
-                if (ver == 0) {                                           // (a never-touched node: its first-touch copy is taken at retirement)
-                    if (lane < sizeof(NodeState) / 4) reinterpret_cast<uint32_t*>(&s_pst[sp])[lane] = reinterpret_cast<const uint32_t*>(&st)[lane];
-                    if (lane < sizeof(nhdfit_detail) / 4) reinterpret_cast<uint32_t*>(&s_pdet[sp])[lane] = reinterpret_cast<const uint32_t*>(&dd)[lane];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 0) { res.node = (int64_t)a.global_base + (int64_t)v; res.map = mp; }
-                lap(11);
-                status = kTuning && (q.dbg & 2) ? kCommitOk : commit_summary_wave(st, dd, rq, mp, a.now, sigs, q.ncls, lane, free0, free1);
-                lap(3);
-                // one dependency per post: the chain's predecessor, or the condition of an earlier rejection (never both: cond_set keeps
-                // a chain from forming)
-                if (chain_slot != kNoNode) { dslot = chain_slot; dpod = (chain_id >> 4) - 1u; dv = v; dver = ver - 1u; }
-                else if (cond_set) { dslot = cslot; dpod = cpod; dv = cv; dver = cver; }
-                else dslot = kNoNode;
-                if (lane == 0 && status != kCommitNewSig) { s_pce[sp] = ce; wg_store(&s_prov[sp], ((e + 1u) << 4) | (attempt & 15u)); }   // (a state without a signature id is not handed on)
-                const bool retire = post_and_wait(v, ver, [] {});
+                const bool retire = post_and_wait(v, ver, [&]() {        // stage 1 of the commit is computed while the sequencer validates
+                    if (ver == 0) {                                       // (a never-touched node: its first-touch copy is taken at retirement)
+                        if (lane < sizeof(NodeState) / 4) reinterpret_cast<uint32_t*>(&s_pst[sp])[lane] = reinterpret_cast<const uint32_t*>(&st)[lane];
+                        if (lane < sizeof(nhdfit_detail) / 4) reinterpret_cast<uint32_t*>(&s_pdet[sp])[lane] = reinterpret_cast<const uint32_t*>(&dd)[lane];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) { res.node = (int64_t)a.global_base + (int64_t)v; res.map = mp; }
+                    lap(11);
+                    // what the next pod's verification reads of this commit: counts, hugepages, NIC classes, signature ids (commit_summary_wave)
+                    status = kTuning && (q.dbg & 2) ? kCommitOk : commit_summary_wave(st, dd, rq, mp, a.now, sigs, q.ncls, lane, free0, free1);
+                    lap(3);
+                });
                 lap(4);
-                if (!retire) {
-                    // the node moved on since it was read - or what this answer depended on did not happen: the entry is no longer
-                    // anybody's starting point, and the pod looks again (from its first window when a rejection was conditional)
-                    if (lane == 0) wg_store(&s_prov[sp], 0u);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    if (cond_set) restart();
-                    continue;
-                }
+                if (!retire) continue;                                    // the node moved on since it was read: again, from this node
                 // retired: the new state goes live in the block's cache - the next pod on this node starts from here - then everything else
                 if (lane == 0) { s_cver[ce] = ver + 1u; wg_store(&s_ctag[ce], v); wg_store(&s_examv[sp], kNoNode); }
                 ++cache_next;
@@ -1094,13 +1022,9 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             }
             if (lane == 0) wg_store(&s_examv[sp], kNoNode);
             if (!placed && !stop) {                                       // no node takes the pod - at no later version either
-                if (cond_set) { dslot = cslot; dpod = cpod; dv = cv; dver = cver; } else dslot = kNoNode;
-                const bool final_word = post_and_wait(kNoNode, 0u, [] {});
-                lap(4);
-                if (!final_word && !stop) { restart(); continue; }        // (the condition of a rejection failed: from the first window again)
+                (void)post_and_wait(kNoNode, 0u, [] {});
                 if (!stop) not_placed(mine);
-            }
-            break;
+                lap(4);
             }
         }
         if (lane == 0) {
@@ -1175,28 +1099,21 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 lap(t_post);
                 const uint32_t v = s_rv[sp], ver = s_rd[sp];
                 bool retire = true;
-                uint32_t at_slot = 0;
                 if (v != kNoNode) {
                     // decisions on v so far, and where the next one goes in the multiset
                     uint32_t d = (uint32_t)(s_tgpu[v >> 6] >> (v & 63)) & 1u, at = 0;
                     for (uint32_t h = hash_of(v);; h += 64) {
                         const uint32_t key = s_hash[(h + lane) & hmask];
                         const uint64_t eq = __ballot(key == v), em = __ballot(key == kNoNode);
-                        if (em) { const uint32_t f = (uint32_t)__builtin_ctzll(em); d += (uint32_t)__popcll(eq & ((1ull << f) - 1ull)); at = (h + f) & hmask; at_slot = at; break; }
+                        if (em) { const uint32_t f = (uint32_t)__builtin_ctzll(em); d += (uint32_t)__popcll(eq & ((1ull << f) - 1ull)); at = (h + f) & hmask; break; }
                         d += (uint32_t)__popcll(eq);
                     }
                     retire = d == ver;
-                }
-                // what the answer depends on (chained speculation): that speculator's pod retired exactly as the answer assumed
-                const uint32_t ds = s_dslot[sp];
-                if (retire && ds != kNoNode) retire = s_lpod[ds] == s_dpod[sp] && s_lv[ds] == s_dv[sp] && s_lver[ds] == s_dver[sp];
-                if (v != kNoNode) {
                     if (retire) {
-                        if (lane == 0) __hip_atomic_store(&s_hash[at_slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (lane == 0) __hip_atomic_store(&s_hash[at], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         take(v, false);                                   // busy for every later pod with GPUs
                     } else ++c_redo;
                 }
-                if (retire && lane == 0) { s_lpod[sp] = e; s_lv[sp] = v; s_lver[sp] = ver; }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) wg_store(&s_verd[sp], (id << 1) | (retire ? 1u : 0u));
                 lap(t_retire);
