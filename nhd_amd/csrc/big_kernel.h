@@ -51,6 +51,86 @@ __global__ __launch_bounds__(64) void k_big_eval(BigEvalArgs a) {
     if (threadIdx.x == 0 && s) atomicMax(&a.score[i], s);
 }
 
+// ---- the winner's mapping with the wavefront's lanes ---------------------------------------------------------------------------------
+// wide_map (wide_core.h) for a big request on a node of at most two NUMA nodes - 2^G <= 256 G-tuples, 2^(G+1) (G+1)-tuples.  One thread
+// spent its time (profiles/r04: 1.9 ms per mapping) on the stages - per tuple a GPU / CPU sum and two NIC searches on a cut-down copy of
+// the request - and on tuple hashes, recomputed digit by digit at every probe of the set model.  Both are independent per tuple: lane =
+// tuple answers the three stages into bit rows and computes every tuple's hash once, into LDS; the set model itself (CPython sets filled
+// in product order, intersected, iterated in slot order: a chain) then runs on the first lane over those tables (wide_map_model with
+// WideStagesLds).  Same searches, same steps in total (nic_stage_ok_plain), same model: the answer is wide_map's, bit for bit
+// (tests/test_wave_commit_emulation.py runs this text under the 64-thread emulation against wide_map).
+constexpr uint32_t kBigWaveG = 256, kBigWaveC = 512;             // tuples the LDS tables hold: two NUMA nodes, eight groups
+struct BigWaveLds {
+    nhdfit_wide_node view;                                        // the winner, as the general path reads it
+    nhdfit_big_req req;
+    uint64_t hash_g[kBigWaveG], hash_c[kBigWaveC];                // tuplehash of every G- / (G+1)-tuple
+    uint64_t bit_g[kBigWaveG / 64], bit_n[kBigWaveG / 64], bit_c[kBigWaveC / 64];   // the stages' answers, bit = tuple
+    uint32_t steps[64];                                           // NIC search steps per lane
+    int32_t rc;
+};
+struct WideStagesLds {
+    const BigWaveLds& t;
+    NHD_HD bool gpu(uint32_t code) const { return t.bit_g[code >> 6] >> (code & 63) & 1ull; }
+    NHD_HD bool nic(uint32_t code) const { return t.bit_n[code >> 6] >> (code & 63) & 1ull; }
+    NHD_HD bool cpu(uint32_t code) const { return t.bit_c[code >> 6] >> (code & 63) & 1ull; }
+    NHD_HD bool exhausted() const { return false; }               // (decided before the model starts)
+    NHD_HD const uint64_t* hash_g() const { return t.hash_g; }
+    NHD_HD const uint64_t* hash_c() const { return t.hash_c; }
+};
+// `t.view` / `t.req` are in place (and visible to every lane); `tables`: big_scratch_words(2, G) int32 of LDS.  Every lane returns wide_map's
+// code; lane 0 holds the mapping in `out`.
+__device__ __noinline__ int wide_map_wave(BigWaveLds& t, const WideCaps& caps, int32_t* tables, nhdfit_big_mapping& out, int32_t slots_g, int32_t slots_c, uint32_t lane) {
+    const nhdfit_wide_node& n = t.view;
+    const nhdfit_big_req& r = t.req;
+    wide_map_clear(out, NHDFIT_BIG_MAX_GROUPS);
+    if (!req_valid(r) || !wide_shape_ok(n)) return 0;
+    const WideFree f = wide_free(n);
+    const uint32_t G = r.n_groups, U = f.U, nG = wide_ipow(U, G), nC = nG * U;
+    const bool separable = nic_separable(n, r);
+    NicSearch ns{8u * NHDFIT_BIG_NIC_BUDGET, false};              // (a lane that alone outruns the call's budget has outrun it)
+    for (uint32_t base = 0; base < nG; base += 64) {
+        const uint32_t code = base + lane;
+        bool g = false, k = false;
+        if (code < nG) {
+            g = wide_gpu_ok(r, f, code);
+            k = nic_stage_ok_plain(separable, n, r, caps, code, &ns);
+            t.hash_g[code] = wide_tuple_hash(code, G, U);
+        }
+        const uint64_t mg = __ballot(g), mk = __ballot(k);
+        if (lane == 0) { t.bit_g[base >> 6] = mg; t.bit_n[base >> 6] = mk; }
+    }
+    for (uint32_t base = 0; base < nC; base += 64) {
+        const uint32_t code = base + lane;
+        bool ok = false;
+        if (code < nC) {
+            ok = wide_cpu_ok(r, f, code);
+            t.hash_c[code] = wide_tuple_hash(code, G + 1, U);
+        }
+        const uint64_t mc = __ballot(ok);
+        if (lane == 0) t.bit_c[base >> 6] = mc;
+    }
+    t.steps[lane] = 8u * NHDFIT_BIG_NIC_BUDGET - ns.left;
+    const bool any_out = __ballot(ns.exhausted) != 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane == 0) {
+        uint64_t total = 0;
+        for (int l = 0; l < 64; ++l) total += t.steps[l];
+        int rc = -2;                                              // the budget of the call's searches, summed over the tuples as one thread spends it
+        if (!any_out && total <= (uint64_t)(8u * NHDFIT_BIG_NIC_BUDGET)) {
+            WideStagesLds st{t};
+            rc = wide_map_model(n, r, caps, f, tables, out, slots_g, slots_c, st);
+        }
+        t.rc = rc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return t.rc;
+}
+
+// ---- k_big_map -----------------------------------------------------------------------------------------------------------------------
 struct BigMapArgs {
     const nhdfit_plane0* p0; const nhdfit_plane1* p1; const nhdfit_plane2* p2; const nhdfit_plane3* p3; const nhdfit_plane4* p4;
     const nhdfit_detail* det; uint32_t n;
@@ -67,28 +147,38 @@ struct BigMapArgs {
 };
 __global__ __launch_bounds__(64) void k_big_map(BigMapArgs a) {
     extern __shared__ __align__(16) int32_t s_tables[];
-    const uint32_t tid = blockIdx.x;                // one worker per wavefront, its first lane: the set model is one long serial walk, and
-    if (threadIdx.x != 0 || tid >= a.workers) return;   // lanes walking different pods' sets would only take turns inside a wavefront
-    // The walk is a chain of dependent probes into the sets' tables: in LDS when they fit (two sockets, eight groups: 28 KB - a probe
-    // costs an LDS round trip instead of one to L2; round 5), in the call's scratch memory otherwise (nodes with more sockets)
+    __shared__ BigWaveLds s_wave;
+    const uint32_t tid = blockIdx.x, lane = threadIdx.x;          // one mapping per wavefront at a time
+    if (tid >= a.workers) return;
+    // The set model's walk is a chain of dependent probes into the sets' tables: in LDS when they fit (two sockets, eight groups: 28 KB - a probe
+    // costs an LDS round trip instead of one to L2), in the call's scratch memory otherwise (nodes with more sockets)
     int32_t* scratch = a.lds_tables ? s_tables : a.scratch + (size_t)tid * a.stride;
     for (uint32_t i = tid; i < a.P; i += a.workers) {
         nhdfit_big_mapping m;
-        for (int g = 0; g < NHDFIT_BIG_MAX_GROUPS; ++g) { m.gpu[g] = m.nic_numa[g] = m.nic_idx[g] = -1; }
-        for (int g = 0; g <= NHDFIT_BIG_MAX_GROUPS; ++g) m.cpu[g] = -1;
-        m.valid = 0; m.pad[0] = m.pad[1] = 0;
+        wide_map_clear(m, NHDFIT_BIG_MAX_GROUPS);
         const unsigned long long s = a.score[i];
         const uint64_t gi = s ? NHDFIT_SCORE_INDEX(s) : 0;
         if (s && gi >= a.global_base && gi < a.global_base + a.n) {          // this shard's node (else: another shard maps it)
             const uint32_t v = (uint32_t)(gi - a.global_base);
-            nhdfit_wide_node view;
             const int slot = a.n_wide ? wide_slot_of(a.wide, a.n_wide, v) : -1;
-            if (slot >= 0) view = a.wide[slot];
-            else wide_view(a.p0[v], a.p1[v], a.p2[v], a.p3[v], a.p4[v], a.det[v], v, view);
-            const int rc = wide_map(view, a.reqs[i], WideCaps(a.caps, a.share && slot >= 0 ? a.share + slot : nullptr), scratch, m, a.slots_g, a.slots_c);
-            if (rc < 0) { m.valid = 0; atomicOr(&a.flags[rc == -2 ? 1 : 0], 1u); }
+            if (lane == 0) {
+                if (slot >= 0) s_wave.view = a.wide[slot];
+                else wide_view(a.p0[v], a.p1[v], a.p2[v], a.p3[v], a.p4[v], a.det[v], v, s_wave.view);
+            }
+            reinterpret_cast<uint32_t*>(&s_wave.req)[lane] = reinterpret_cast<const uint32_t*>(&a.reqs[i])[lane];     // (256 bytes: a dword per lane)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const WideCaps caps(a.caps, a.share && slot >= 0 ? a.share + slot : nullptr);
+            // lane = tuple where the tuples fit the LDS tables (every node of the fast layout: two NUMA nodes); else one thread, as before
+            const bool wave = a.lds_tables && s_wave.view.numa_nodes <= 2u;
+            int rc = 0;
+            if (wave) rc = wide_map_wave(s_wave, caps, scratch, m, a.slots_g, a.slots_c, lane);
+            else if (lane == 0) rc = wide_map(s_wave.view, s_wave.req, caps, scratch, m, a.slots_g, a.slots_c);
+            if (lane == 0 && rc < 0) { m.valid = 0; atomicOr(&a.flags[rc == -2 ? 1 : 0], 1u); }
         }
-        a.out[i] = m;
+        if (lane == 0) a.out[i] = m;
+        __builtin_amdgcn_wave_barrier();                                      // (the LDS record is the next mapping's)
     }
 }
 

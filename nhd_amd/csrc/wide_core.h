@@ -284,30 +284,38 @@ struct NicMemo {
     uint8_t known[kWideU][1 << NHDFIT_BIG_MAX_GROUPS];         // 0 = not asked yet, 1 = no, 2 = yes
     bool separable;
 };
-template <class R> NHD_HD void nic_memo_init(NicMemo& m, const nhdfit_wide_node& n, const R& r) {
-    for (int u = 0; u < kWideU; ++u)
-        for (int s = 0; s < (1 << NHDFIT_BIG_MAX_GROUPS); ++s) m.known[u][s] = 0;
-    m.separable = true;
-    if (r.map_type != NHDFIT_MAP_PCI) return;                  // NUMA mode applies no switch test (Matcher.py:294-296)
+template <class R> NHD_HD bool nic_separable(const nhdfit_wide_node& n, const R& r) {
+    if (r.map_type != NHDFIT_MAP_PCI) return true;             // NUMA mode applies no switch test (Matcher.py:294-296)
     for (uint32_t u = 0; u < n.numa_nodes && u < (uint32_t)kWideU; ++u)
         for (uint32_t k = 0; k < n.nic_cnt[u]; ++k)
             for (uint32_t u2 = u + 1; u2 < n.numa_nodes && u2 < (uint32_t)kWideU; ++u2)
                 for (uint32_t k2 = 0; k2 < n.nic_cnt[u2]; ++k2)
-                    if (n.nic_sw[u][k] == n.nic_sw[u2][k2]) m.separable = false;
+                    if (n.nic_sw[u][k] == n.nic_sw[u2][k2]) return false;
+    return true;
 }
-// can the NICs of NUMA node u host the groups of `set` (bit g = group g)?
+template <class R> NHD_HD void nic_memo_init(NicMemo& m, const nhdfit_wide_node& n, const R& r) {
+    for (int u = 0; u < kWideU; ++u)
+        for (int s = 0; s < (1 << NHDFIT_BIG_MAX_GROUPS); ++s) m.known[u][s] = 0;
+    m.separable = nic_separable(n, r);
+}
+// can the NICs of NUMA node u host the groups of the non-empty `set` (bit g = group g)?  The search itself:
 template <class R>
-NHD_HD bool nic_set_ok(NicMemo& m, const nhdfit_wide_node& n, const R& r, const WideCaps& caps, uint32_t u, uint32_t set, NicSearch* ns) {
-    if (!set) return true;
-    uint8_t& known = m.known[u][set];
-    if (known) return known == 2;
+NHD_HD bool nic_set_search(const nhdfit_wide_node& n, const R& r, const WideCaps& caps, uint32_t u, uint32_t set, NicSearch* ns) {
     R sub = r;
     uint32_t k = 0, code = 0;
     for (uint32_t g = 0; g < r.n_groups; ++g)
         if (set >> g & 1u) { sub.rx[k] = r.rx[g]; sub.tx[k] = r.tx[g]; ++k; code = code * n.numa_nodes + u; }   // every group of the cut-down request on NUMA node u
     sub.n_groups = k;
     int8_t nic[req_traits<R>::kG];
-    const bool ok = wide_nic_choice(n, sub, caps, code, nic, ns);
+    return wide_nic_choice(n, sub, caps, code, nic, ns);
+}
+// ... and through the memo
+template <class R>
+NHD_HD bool nic_set_ok(NicMemo& m, const nhdfit_wide_node& n, const R& r, const WideCaps& caps, uint32_t u, uint32_t set, NicSearch* ns) {
+    if (!set) return true;
+    uint8_t& known = m.known[u][set];
+    if (known) return known == 2;
+    const bool ok = nic_set_search(n, r, caps, u, set, ns);
     if (ns && ns->exhausted) return false;                     // (no answer: nothing is remembered)
     known = ok ? 2 : 1;
     return ok;
@@ -323,6 +331,20 @@ NHD_HD bool nic_stage_ok(NicMemo& m, const nhdfit_wide_node& n, const R& r, cons
     for (uint32_t g = 0; g < r.n_groups; ++g) sets[wide_digit(gcode, r.n_groups, n.numa_nodes, g)] |= 1u << g;
     for (uint32_t u = 0; u < n.numa_nodes; ++u)
         if (!nic_set_ok(m, n, r, caps, u, sets[u], ns)) return false;
+    return true;
+}
+// ... without a memo: the same searches in the same order.  On two NUMA nodes every assignment has its own pair of sets - nothing
+// would be remembered twice, so the search steps taken over all assignments are the memo's (wide_map_wave, big_kernel.h: lane = tuple)
+template <class R>
+NHD_HD bool nic_stage_ok_plain(bool separable, const nhdfit_wide_node& n, const R& r, const WideCaps& caps, uint32_t gcode, NicSearch* ns) {
+    if (!separable) {
+        int8_t nic[req_traits<R>::kG];
+        return wide_nic_choice(n, r, caps, gcode, nic, ns);
+    }
+    uint32_t sets[kWideU] = {0, 0, 0, 0};
+    for (uint32_t g = 0; g < r.n_groups; ++g) sets[wide_digit(gcode, r.n_groups, n.numa_nodes, g)] |= 1u << g;
+    for (uint32_t u = 0; u < n.numa_nodes; ++u)
+        if (sets[u] && !nic_set_search(n, r, caps, u, sets[u], ns)) return false;
     return true;
 }
 
@@ -426,10 +448,12 @@ template <class K> struct WideSetT {
     int32_t cap, mask, fill;
     uint32_t len, U;       // tuple length, digit base
     bool overflow;         // the table would have outgrown `cap` (cannot happen for the sizes above; reported, never silent)
+    const uint64_t* htab;  // optional: hash of every tuple code, computed beforehand (wide_map_wave: lane = tuple); else recomputed per probe
 };
+template <class K> NHD_HD uint64_t ws_hash(const WideSetT<K>& s, K k) { return s.htab ? s.htab[(uint32_t)k] : wide_tuple_hash((uint32_t)k, s.len, s.U); }
 using WideSet = WideSetT<int16_t>;      // keys of an ordinary request's tuples (< 1 024); a big request's reach 4^9: int32 (req_traits<R>::Key)
 template <class K> NHD_HD void ws_init(WideSetT<K>& s, K* mem, int32_t cap, uint32_t len, uint32_t U) {
-    s.key = mem; s.cap = cap; s.mask = 7; s.fill = 0; s.len = len; s.U = U; s.overflow = false;
+    s.key = mem; s.cap = cap; s.mask = 7; s.fill = 0; s.len = len; s.U = U; s.overflow = false; s.htab = nullptr;
     for (int32_t i = 0; i < 8; ++i) mem[i] = -1;
 }
 template <class K> NHD_HD void ws_insert_clean(K* key, int32_t mask, K k, uint64_t h) {      // set_insert_clean()
@@ -456,10 +480,10 @@ template <class K> NHD_HD void ws_resize(WideSetT<K>& s, int32_t minused, K* tmp
     for (int32_t i = 0; i < newsize; ++i) s.key[i] = -1;
     s.mask = newsize - 1;
     for (int32_t i = 0; i <= oldmask; ++i)
-        if (tmp[i] >= 0) ws_insert_clean(s.key, s.mask, tmp[i], wide_tuple_hash((uint32_t)tmp[i], s.len, s.U));
+        if (tmp[i] >= 0) ws_insert_clean(s.key, s.mask, tmp[i], ws_hash(s, tmp[i]));
 }
 template <class K> NHD_HD bool ws_has(const WideSetT<K>& s, K k) {
-    const uint64_t h = wide_tuple_hash((uint32_t)k, s.len, s.U);
+    const uint64_t h = ws_hash(s, k);
     uint64_t perturb = h;
     uint64_t i = h & (uint64_t)s.mask;
     for (;;) {
@@ -474,7 +498,7 @@ template <class K> NHD_HD bool ws_has(const WideSetT<K>& s, K k) {
 }
 template <class K> NHD_HD void ws_add(WideSetT<K>& s, K k, K* tmp) {                             // set_add_entry()
     if (s.overflow) return;
-    const uint64_t h = wide_tuple_hash((uint32_t)k, s.len, s.U);
+    const uint64_t h = ws_hash(s, k);
     uint64_t perturb = h;
     uint64_t i = h & (uint64_t)s.mask;
     for (;;) {
@@ -528,19 +552,36 @@ template <class K> NHD_HD int32_t wide_pick_gpu_tuple(const WideSetT<K>& s, uint
 // Returns 1 = mapped, 0 = the node does not take the pod, -1 = a set outgrew its table (never expected; the caller reports it).
 // -2 = the NIC search budget of a big request ran out (reported like -1).
 // slots_g / slots_c: table sizes of the sets over G- and (G+1)-tuples (ordinary requests: kWideSetSlotsG / kWideSetSlotsC).
-template <class R>
-NHD_HD int wide_map(const nhdfit_wide_node& n, const R& r, const WideCaps& caps, typename req_traits<R>::Key* scratch,
-                    typename req_traits<R>::Mapping& out, int32_t slots_g = kWideSetSlotsG, int32_t slots_c = kWideSetSlotsC) {
+//
+// Two parts.  The STAGES answer, per tuple, whether the GPU / NIC / CPU stage lists it (Matcher.py:116-141, 206-220, 242-268 + 294-335):
+// independent questions - asked on the spot by one thread (WideStagesScalar), or beforehand by a wavefront with lane = tuple
+// (big_kernel.h wide_map_wave, which also hands over every tuple's hash).  The MODEL (wide_map_model) is the serial part: CPython
+// sets filled in product order, their intersections, the picks in slot order.
+template <bool> struct NicMemoBox { NicMemo m; };
+template <> struct NicMemoBox<false> {};
+template <class R> struct WideStagesScalar {
+    const nhdfit_wide_node& n; const R& r; const WideCaps& caps; const WideFree& f;
+    NicMemoBox<req_traits<R>::kBig> memo;
+    NicSearch budget;
+    NHD_HD WideStagesScalar(const nhdfit_wide_node& n_, const R& r_, const WideCaps& c_, const WideFree& f_)
+        : n(n_), r(r_), caps(c_), f(f_), budget{req_traits<R>::kBig ? 8u * NHDFIT_BIG_NIC_BUDGET : 0u, false} {     // (every assignment is searched here, not only up to the first hit)
+        if constexpr (req_traits<R>::kBig) nic_memo_init(memo.m, n, r);
+    }
+    NHD_HD bool gpu(uint32_t code) { return wide_gpu_ok(r, f, code); }
+    NHD_HD bool nic(uint32_t code) {
+        if constexpr (req_traits<R>::kBig) return nic_stage_ok(memo.m, n, r, caps, code, &budget);
+        else { int8_t idx[req_traits<R>::kG]; return wide_nic_choice(n, r, caps, code, idx, nullptr); }
+    }
+    NHD_HD bool cpu(uint32_t code) { return wide_cpu_ok(r, f, code); }
+    NHD_HD bool exhausted() const { return budget.exhausted; }
+    NHD_HD const uint64_t* hash_g() const { return nullptr; }
+    NHD_HD const uint64_t* hash_c() const { return nullptr; }
+};
+template <class R, class Stages>
+NHD_HD int wide_map_model(const nhdfit_wide_node& n, const R& r, const WideCaps& caps, const WideFree& f, typename req_traits<R>::Key* scratch,
+                          typename req_traits<R>::Mapping& out, int32_t kSlotsG, int32_t kSlotsC, Stages& st) {
     using K = typename req_traits<R>::Key;
-    constexpr int kG = req_traits<R>::kG;
-    for (int g = 0; g < kG; ++g) { out.gpu[g] = out.nic_numa[g] = out.nic_idx[g] = -1; }
-    for (int g = 0; g <= kG; ++g) out.cpu[g] = -1;
-    out.valid = 0; out.pad[0] = out.pad[1] = 0;
-    if (!req_valid(r) || !wide_shape_ok(n)) return 0;
-    const WideFree f = wide_free(n);
     const uint32_t G = r.n_groups, U = f.U, nG = wide_ipow(U, G), nC = nG * U;
-    const int32_t kSlotsG = slots_g, kSlotsC = slots_c;
-    if ((uint64_t)nG * U > (uint64_t)req_traits<R>::kMaxTuples) return -1;
     K* mem = scratch;
     WideSetT<K> sg, sc, a, b, c, ab, abc;
     ws_init(sg, mem, kSlotsG, G, U); mem += kSlotsG;
@@ -550,28 +591,17 @@ NHD_HD int wide_map(const nhdfit_wide_node& n, const R& r, const WideCaps& caps,
     ws_init(ab, mem, kSlotsG, G, U); mem += kSlotsG;
     ws_init(abc, mem, kSlotsG, G, U); mem += kSlotsG;
     ws_init(sc, mem, kSlotsC, G + 1, U); mem += kSlotsC;
+    sg.htab = a.htab = b.htab = c.htab = ab.htab = abc.htab = st.hash_g();
+    sc.htab = st.hash_c();
     K* tmp = mem;
-    // candidate sets, filled in product order (Matcher.py:116-141, 206-220, 242-268 + 294-335)
-    int8_t nic[kG];
-    NicSearch budget{req_traits<R>::kBig ? 8u * NHDFIT_BIG_NIC_BUDGET : 0u, false};    // (every assignment is searched here, not only up to the first hit)
-    NicSearch* ns = req_traits<R>::kBig ? &budget : nullptr;
-    if constexpr (req_traits<R>::kBig) {
-        NicMemo memo;
-        nic_memo_init(memo, n, r);
-        for (uint32_t code = 0; code < nG; ++code) {
-            if (wide_gpu_ok(r, f, code)) ws_add(sg, (K)code, tmp);
-            if (nic_stage_ok(memo, n, r, caps, code, ns)) ws_add(c, (K)code, tmp);
-            if (budget.exhausted) return -2;
-        }
-    } else {
-        for (uint32_t code = 0; code < nG; ++code) {
-            if (wide_gpu_ok(r, f, code)) ws_add(sg, (K)code, tmp);
-            if (wide_nic_choice(n, r, caps, code, nic, ns)) ws_add(c, (K)code, tmp);
-            if (budget.exhausted) return -2;
-        }
+    // candidate sets, filled in product order
+    for (uint32_t code = 0; code < nG; ++code) {
+        if (st.gpu(code)) ws_add(sg, (K)code, tmp);
+        if (st.nic(code)) ws_add(c, (K)code, tmp);
+        if (st.exhausted()) return -2;
     }
     for (uint32_t code = 0; code < nC; ++code)
-        if (wide_cpu_ok(r, f, code)) ws_add(sc, (K)code, tmp);
+        if (st.cpu(code)) ws_add(sc, (K)code, tmp);
     if (!sg.fill || !sc.fill || !c.fill) return 0;
     // set(gpu_tuples) & set(cpu_tuples) & set(nic_tuples): set(list) re-inserts in list (= slot) order
     for (int32_t i = ws_next(sg, 0); i >= 0; i = ws_next(sg, i + 1)) ws_add(a, sg.key[i], tmp);
@@ -586,12 +616,27 @@ NHD_HD int wide_map(const nhdfit_wide_node& n, const R& r, const WideCaps& caps,
     for (int32_t i = ws_next(sc, 0); i >= 0 && ccode < 0; i = ws_next(sc, i + 1))
         if (sc.key[i] / (K)U == gcode) ccode = sc.key[i];
     if (gcode < 0 || ccode < 0) return 0;
-    budget.left = req_traits<R>::kBig ? NHDFIT_BIG_NIC_BUDGET : 0u;
-    if (!wide_nic_choice(n, r, caps, (uint32_t)gcode, out.nic_idx, ns)) return budget.exhausted ? -2 : 0;
+    NicSearch last{req_traits<R>::kBig ? NHDFIT_BIG_NIC_BUDGET : 0u, false};
+    if (!wide_nic_choice(n, r, caps, (uint32_t)gcode, out.nic_idx, req_traits<R>::kBig ? &last : nullptr)) return last.exhausted ? -2 : 0;
     for (uint32_t g = 0; g < G; ++g) { out.gpu[g] = (int8_t)wide_digit((uint32_t)gcode, G, U, g); out.nic_numa[g] = out.gpu[g]; }
     for (uint32_t g = 0; g <= G; ++g) out.cpu[g] = (int8_t)wide_digit((uint32_t)ccode, G + 1, U, g);
     out.valid = 1;
     return 1;
+}
+template <class M> NHD_HD void wide_map_clear(M& out, int kG) {
+    for (int g = 0; g < kG; ++g) { out.gpu[g] = out.nic_numa[g] = out.nic_idx[g] = -1; }
+    for (int g = 0; g <= kG; ++g) out.cpu[g] = -1;
+    out.valid = 0; out.pad[0] = out.pad[1] = 0;
+}
+template <class R>
+NHD_HD int wide_map(const nhdfit_wide_node& n, const R& r, const WideCaps& caps, typename req_traits<R>::Key* scratch,
+                    typename req_traits<R>::Mapping& out, int32_t slots_g = kWideSetSlotsG, int32_t slots_c = kWideSetSlotsC) {
+    wide_map_clear(out, req_traits<R>::kG);
+    if (!req_valid(r) || !wide_shape_ok(n)) return 0;
+    const WideFree f = wide_free(n);
+    if ((uint64_t)wide_ipow(f.U, r.n_groups) * f.U > (uint64_t)req_traits<R>::kMaxTuples) return -1;
+    WideStagesScalar<R> st(n, r, caps, f);
+    return wide_map_model(n, r, caps, f, scratch, out, slots_g, slots_c, st);
 }
 
 // ---- the commit step (commit_core.h, on the wide record) -----------------------------------------------------------------

@@ -153,6 +153,8 @@ WAVE_INC = os.path.join(HERE, "_wave_commit_block.inc")
 _WAVE_FROM, _WAVE_TO = "// ---- the commit step with the wavefront's lanes", "// ---- k_decide: speculate, then retire in order"
 WAVE_MAP_INC = os.path.join(HERE, "_wave_map_block.inc")
 _WAVE_MAP_FROM, _WAVE_MAP_TO = "// ---- wave-cooperative forms of the mapping arithmetic", "// One block walks the batch in the caller's order"
+WAVE_BIG_INC = os.path.join(HERE, "_wave_bigmap_block.inc")
+_WAVE_BIG_FROM, _WAVE_BIG_TO = "// ---- the winner's mapping with the wavefront's lanes", "// ---- k_big_map"
 _wave = None
 
 
@@ -163,7 +165,8 @@ def wave_lib():
         return _wave
     kernel = os.path.join(HERE, "..", "..", "nhd_amd", "csrc", "seq2_kernel.h")
     kernel1 = os.path.join(HERE, "..", "..", "nhd_amd", "csrc", "seq_kernel.h")
-    deps = [WAVE_SRC, kernel, kernel1] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "seq_core.h", "commit_core.h", "winner_map.h", "set_states.h")] + \
+    kernel2 = os.path.join(HERE, "..", "..", "nhd_amd", "csrc", "big_kernel.h")
+    deps = [WAVE_SRC, kernel, kernel1, kernel2] + [os.path.join(HERE, "..", "..", "nhd_amd", "csrc", f) for f in ("fit_core.h", "seq_core.h", "commit_core.h", "winner_map.h", "set_states.h", "wide_core.h")] + \
            [os.path.join(HERE, "..", "..", "include", "nhdfit.h")]
     if not os.path.exists(WAVE_SO) or any(os.path.getmtime(d) > os.path.getmtime(WAVE_SO) for d in deps):
         lines = open(kernel).read().split("\n")
@@ -177,6 +180,12 @@ def wave_lib():
         b = next(i for i, ln in enumerate(lines) if ln.startswith(_WAVE_MAP_TO))
         assert a < b and any("map_on_state_wave" in ln for ln in lines[a:b])
         with open(WAVE_MAP_INC, "w") as f:
+            f.write("\n".join(lines[a:b]) + "\n")
+        lines = open(kernel2).read().split("\n")
+        a = next(i for i, ln in enumerate(lines) if ln.startswith(_WAVE_BIG_FROM))
+        b = next(i for i, ln in enumerate(lines) if ln.startswith(_WAVE_BIG_TO))
+        assert a < b and any("wide_map_wave" in ln for ln in lines[a:b])
+        with open(WAVE_BIG_INC, "w") as f:
             f.write("\n".join(lines[a:b]) + "\n")
         tmp = f"{WAVE_SO}.{os.getpid()}.tmp"
         subprocess.check_call(["g++", "-O2", "-std=c++20", "-ffp-contract=off", "-shared", "-fPIC", "-pthread", WAVE_SRC, "-o", tmp])
@@ -198,6 +207,22 @@ def wave_map_on_state(packer, table, i, req, tables=2, nic_bits=-1, form=1):
     L.we_map_on_state.restype = ctypes.c_int
     rc = L.we_map_on_state(*[_p(x) for x in rows], _p(req), _p(caps), ctypes.c_int(tables), ctypes.c_int64(int(nic_bits)), _p(ms), _p(mw), ctypes.byref(ok), ctypes.c_int(form))
     return int(rc), ok.value, ms, mw
+
+
+def wave_big_map(packer, table, v, big_req, wide=None, share=None):
+    """A big request's mapping on node `v` of `table` (or on the wide record `wide`): wide_core.h wide_map (one thread) against
+    big_kernel.h wide_map_wave (lane = tuple, emulated lanes).  (return code of we_big_map, (scalar rc, wave rc), scalar mapping, wave mapping)."""
+    L = wave_lib()
+    caps = _dict_args(packer)[0]
+    req = np.ascontiguousarray(big_req)
+    rows = [np.ascontiguousarray(getattr(table, f)[v:v + 1]) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
+    ms, mw = np.zeros((), pack.BIG_MAPPING), np.zeros((), pack.BIG_MAPPING)
+    rcs = (ctypes.c_int * 2)(0, 0)
+    w = None if wide is None else np.ascontiguousarray(wide, dtype=pack.WIDE).reshape(-1)[:1]
+    sh_arr, sh_ptr = _share_arg(share, 1) if share is not None else (None, None)
+    L.we_big_map.restype = ctypes.c_int
+    rc = L.we_big_map(*[_p(x) for x in rows], None if w is None else _p(w), _p(req), _p(caps), sh_ptr, _p(ms), _p(mw), rcs)
+    return int(rc), (int(rcs[0]), int(rcs[1])), ms, mw
 
 
 def wave_commit(packer, table, i, req, mapping, busy_time, form=1):

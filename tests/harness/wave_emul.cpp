@@ -15,6 +15,7 @@
 #include <thread>
 #include <vector>
 #include "../../nhd_amd/csrc/seq_core.h"
+#include "../../nhd_amd/csrc/wide_core.h"
 
 using namespace nhdfit;
 
@@ -56,6 +57,7 @@ inline int readlane(int v, int l) {                                  // every la
 namespace {
 #include "_wave_map_block.inc"       // seq_kernel.h: "wave-cooperative forms of the mapping arithmetic" (map_on_state_wave and its helpers)
 #include "_wave_commit_block.inc"    // seq2_kernel.h: "the commit step with the wavefront's lanes"
+#include "_wave_bigmap_block.inc"    // big_kernel.h: "the winner's mapping with the wavefront's lanes" (wide_map_wave)
 
 // the mapping tables as the device builds them (k_build_asc / k_build_choose / the set-layout state machine)
 const AscEntry* asc_table() {
@@ -192,6 +194,39 @@ int we_map_on_state(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdf
         if (ms.gpu[g] != mw[0].gpu[g] || ms.nic_numa[g] != mw[0].nic_numa[g] || ms.nic_idx[g] != mw[0].nic_idx[g]) return 1;
     for (int g = 0; g <= G; ++g) if (ms.cpu[g] != mw[0].cpu[g]) return 1;
     return ms.valid == mw[0].valid ? 0 : 1;
+}
+
+// A big request's mapping on one winner: wide_core.h wide_map (one thread: the host twin's and the device's form for nodes of more than two
+// NUMA nodes) against big_kernel.h wide_map_wave (lane = tuple, emulated lanes).  `wide` != NULL: that record, else node 0 of the planes.
+// Returns 0 when return code and mapping agree, 1 otherwise, -100 if the lanes disagree on the code.
+int we_big_map(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3, const nhdfit_plane4* p4,
+               const nhdfit_detail* det, const nhdfit_wide_node* wide, const nhdfit_big_req* r, const double* caps, const nhdfit_wide_share* share,
+               nhdfit_big_mapping* scalar_out, nhdfit_big_mapping* wave_out, int* rc_out) {
+    static BigWaveLds t;                                              // (the block's LDS record)
+    if (wide) t.view = *wide; else wide_view(*p0, *p1, *p2, *p3, *p4, *det, 0, t.view);
+    t.req = *r;
+    const uint32_t U = t.view.numa_nodes ? t.view.numa_nodes : 1, G = r->n_groups <= NHDFIT_BIG_MAX_GROUPS ? r->n_groups : NHDFIT_BIG_MAX_GROUPS;
+    if (U > 2) return -2;                                             // (the kernel takes the one-thread form there)
+    const WideCaps wc(caps, wide ? share : nullptr);
+    const int32_t sg = (int32_t)wide_table_slots(wide_ipow(2, G)), sc = (int32_t)wide_table_slots(wide_ipow(2, G + 1));   // sized as the device sizes them (two NUMA nodes)
+    std::vector<int32_t> scratch(big_scratch_words(2, G)), tables(big_scratch_words(2, G));
+    nhdfit_big_mapping ms;
+    const int rs = wide_map(t.view, *r, wc, scratch.data(), ms, sg, sc);
+    nhdfit_big_mapping mw[emu::kLanes];
+    int rw[emu::kLanes];
+    emu::acc[0] = emu::acc[1] = 0;
+    std::vector<std::thread> lanes;
+    for (int i = 0; i < emu::kLanes; ++i)
+        lanes.emplace_back([&, i] {
+            emu::t_lane = (uint32_t)i; emu::t_count = 0;
+            rw[i] = wide_map_wave(t, wc, tables.data(), mw[i], sg, sc, (uint32_t)i);
+        });
+    for (auto& th : lanes) th.join();
+    for (int i = 1; i < emu::kLanes; ++i) if (rw[i] != rw[0]) return -100;
+    *scalar_out = ms; *wave_out = mw[0];
+    rc_out[0] = rs; rc_out[1] = rw[0];
+    if (rs != rw[0]) return 1;
+    return std::memcmp(&ms, &mw[0], sizeof ms) == 0 ? 0 : 1;
 }
 
 }  // extern "C"

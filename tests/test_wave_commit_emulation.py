@@ -145,3 +145,57 @@ def test_lone_pod_winner_mapped_by_the_wavefront_form(seed):
             assert mw[f][:k].tolist() == maps[p][f][:k].tolist(), (f, specs[p], mw, maps[p])
         mapped += 1
     assert mapped >= 8
+
+
+# ---- a big request's mapping with lane = tuple (big_kernel.h wide_map_wave) against wide_map --------------------------------------------
+@pytest.mark.parametrize("seed", range(6))
+def test_big_mapping_lane_per_tuple_equals_the_one_thread_form(seed):
+    """k_big_map's wavefront form - the three stages answered with lane = tuple into bit rows, every tuple's hash computed once, the CPython
+    set model then run by the first lane over those tables - against wide_map as the host twin (and the device, for nodes of more than two NUMA
+    nodes) runs it: return code and mapping on EVERY node of a random cluster that takes the pod, and on some that do not, for pods of 5..8
+    groups in both map types.  The device text, cut out of big_kernel.h unmodified, under the 64-thread emulation."""
+    from tests.test_big_core import big_spec, host_matcher
+    nl = util.random_cluster(47000 + seed, 40, occupancy=0.15 if seed % 2 else 0.0)
+    rng = np.random.default_rng(900 + seed)
+    tops = [refmodel.make_topology(big_spec(rng, 5, 8)) for _ in range(10)]
+    m = host_matcher()
+    m.FindNodes(nl, tops[:1])                                           # packs the cluster, sets the dictionary
+    big = np.array([m.packer.digest_big(t) for t in tops], dtype=pack.BIG_REQ)
+    fits, _, exhausted = harness.big_eval(m.packer, m.engine.table, m.engine._wide_records(), big, util.CLOCK)
+    assert not exhausted
+    mapped = 0
+    for p in range(len(tops)):
+        takers = np.flatnonzero(fits[:len(nl), p])
+        others = np.flatnonzero(fits[:len(nl), p] == 0)[:3]
+        for v in list(takers[:6]) + list(others):
+            rc, rcs, ms, mw = harness.wave_big_map(m.packer, m.engine.table, int(v), big[p])
+            assert rc == 0, (p, int(v), rcs, ms, mw)
+            assert rcs[0] == 1 or not fits[v, p], (p, int(v), rcs)      # (a node the scalar filters turn away may still map: wide_map asks the stages only)
+            mapped += rcs[0] == 1
+    assert mapped >= 6
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_big_mapping_lane_per_tuple_on_wide_records_of_two_sockets(seed):
+    """The same on nodes the mirror carries as wide records (65..128 cores per socket) where they have at most two NUMA nodes - the
+    wavefront form reads the record instead of the planes' view; records of three or four sockets keep the one-thread form (we_big_map: -2)."""
+    from tests.test_big_core import big_spec, host_matcher
+    nl = util.build_cluster(util.mixed_cluster_desc(48000 + seed, 30, wide_share=0.6, occupancy=0.05))
+    rng = np.random.default_rng(950 + seed)
+    tops = [refmodel.make_topology(big_spec(rng, 5, 7)) for _ in range(8)]
+    m = host_matcher()
+    m.FindNodes(nl, tops[:1])
+    big = np.array([m.packer.digest_big(t) for t in tops], dtype=pack.BIG_REQ)
+    wide = m.engine._wide_records()
+    two = [k for k in range(len(wide)) if int(wide[k]["numa_nodes"]) <= 2]
+    assert two and len(two) < len(wide)
+    agreed = mapped = 0
+    for p in range(len(tops)):
+        for k in two[:8]:
+            rc, rcs, ms, mw = harness.wave_big_map(m.packer, m.engine.table, 0, big[p], wide=wide[k:k + 1])
+            assert rc == 0, (p, k, rcs, ms, mw)
+            agreed += 1
+            mapped += rcs[0] == 1
+    k4 = next(k for k in range(len(wide)) if int(wide[k]["numa_nodes"]) > 2)
+    assert harness.wave_big_map(m.packer, m.engine.table, 0, big[0], wide=wide[k4:k4 + 1])[0] == -2
+    assert agreed and mapped >= 1
