@@ -340,7 +340,8 @@ typedef struct {
     uint32_t small_finds;       /* nhdfit_find calls answered by the single-launch form (at most one pod tile, no verdict matrix) */
     uint32_t big_nic_steps_max; /* nhdfit_big_find: the most NIC-search steps any (pod, node) pair took since the last reset - to be read against
                                    NHDFIT_BIG_NIC_BUDGET, at which a call fails (ABI 9) */
-    uint32_t pad;
+    uint32_t batch_finds;       /* nhdfit_find calls of more than one pod tile answered by ONE launch (k_findn): digest, fit and mapping tile by
+                                   tile inside it, results through a fine-grained host block (the word was padding before: same layout) */
 } nhdfit_stats;
 
 typedef struct nhdfit_ctx nhdfit_ctx;
@@ -429,8 +430,12 @@ int nhdfit_download_nodes(nhdfit_ctx* ctx, uint32_t first, uint32_t count,
  * scheduler's pod-at-a-time FindNode (nhd/NHDScheduler.py:277) - is ONE kernel launch: digest, fit, mapping in a row inside
  * it, the requests read from and the results stored into fine-grained host memory (nhdfit_stats.small_finds counts them);
  * a lone pod skips the table image altogether (every block derives the pod's own assignment masks and sweeps nodes with them).
- * Every other call stages the batch and runs the five launches of a step.  The single-launch form leaves nothing staged:
- * nhdfit_enqueue_step / nhdfit_fetch need a nhdfit_stage_requests of their own. */
+ * A larger call without bitmap_out, communicator, wide nodes or four-group pods is ONE launch as well (nhdfit_stats.batch_finds):
+ * the batch is sorted into tiles and copied to the device as nhdfit_stage_requests does it, then digest, fit and mapping run tile by
+ * tile inside one kernel - a tile's fit blocks wait for its digest, the last of them maps its winners - and scores and mappings
+ * arrive in fine-grained host memory behind one polled word.
+ * Every other call stages the batch and runs the launches of a step (digest, fused step, drain).  The single-launch forms leave
+ * nothing staged: nhdfit_enqueue_step / nhdfit_fetch need a nhdfit_stage_requests of their own. */
 int nhdfit_find(nhdfit_ctx* ctx, const nhdfit_req* reqs, uint32_t P, double now,
                 const uint64_t* cand, uint64_t* score_out, uint64_t* bitmap_out, nhdfit_mapping* map_out);
 

@@ -24,7 +24,7 @@ class Stats(ctypes.Structure):
     _fields_ = [("launches", c_uint64), ("fit_ms_total", c_double), ("fit_ms_last", c_double),
                 ("digest_ms_last", c_double), ("step_ms_last", c_double), ("evals_last", c_uint64),
                 ("bytes_last", c_uint64), ("nodes", c_uint32), ("nsig", c_uint32), ("ncls", c_uint32),
-                ("lds_bytes", c_uint32), ("pipes", c_uint32), ("small_finds", c_uint32), ("big_nic_steps_max", c_uint32), ("pad", c_uint32)]
+                ("lds_bytes", c_uint32), ("pipes", c_uint32), ("small_finds", c_uint32), ("big_nic_steps_max", c_uint32), ("batch_finds", c_uint32)]
 
 
 _SIGS = {

@@ -130,6 +130,59 @@ __device__ __noinline__ int wide_map_wave(BigWaveLds& t, const WideCaps& caps, i
     return t.rc;
 }
 
+// feasible(node, pod) with the wavefront's lanes - wide_fits (wide_core.h) for a big request on a node of at most two NUMA nodes.  With
+// lane = node, 64 nodes walk their assignments side by side in one wavefront: each until its own first hit, each with NIC searches of
+// its own length - the wavefront executes every lane's path one after the other (profiles/r05: k_big_eval 0.44 ms mean, 2.4 ms worst
+// on 65 536 nodes, the scalar tests alone 50 us).  Here the 64 lanes take ONE node: lane = assignment, the three stages asked per lane
+// (the searches of different assignments run beside each other), a ballot finds the first assignment that passes.  The answer is a
+// boolean over the assignments - their order only matters for the search budget and its statistic, which count the steps one thread
+// spends up to and including the first hit: the lanes' step counts, summed in assignment order to that point (nic_stage_ok_plain: the
+// searches and their steps are the memo's on two NUMA nodes).  `n`, `r` visible to every lane; `steps`: 64 words of LDS.
+// Returns feasible; `spent` = search steps as wide_fits counts them, `exhausted` = they exceed `budget`.
+__device__ __noinline__ bool wide_fits_wave(const nhdfit_wide_node& n, const nhdfit_big_req& r, bool busy, const WideCaps& caps, uint32_t budget,
+                                            uint32_t* steps, uint32_t lane, uint32_t& spent_out, bool& exhausted) {
+    spent_out = 0; exhausted = false;
+    if (!wide_scalar_ok(n, r, busy)) return false;
+    const WideFree f = wide_free(n);
+    const uint32_t G = r.n_groups, U = f.U, nG = wide_ipow(U, G);
+    {   // a node whose free GPUs or free cores do not cover the pod's totals passes no assignment at all
+        uint32_t need_g = 0, need_c = f.smt ? r.misc_smt : r.misc_nosmt, have_g = 0, have_c = 0;
+        for (uint32_t g = 0; g < G; ++g) { need_g += r.gpus[g]; need_c += f.smt ? r.cpu_smt[g] : r.cpu_nosmt[g]; }
+        for (uint32_t u = 0; u < U; ++u) { have_g += f.g[u]; have_c += f.c[u]; }
+        if (need_g > have_g || need_c > have_c) return false;
+    }
+    const bool separable = nic_separable(n, r);
+    uint64_t spent = 0;
+    bool found = false;
+    for (uint32_t base = 0; base < nG && !found && spent <= (uint64_t)budget; base += 64) {
+        const uint32_t code = base + lane;
+        bool ok = false;
+        uint32_t mine = 0;
+        if (code < nG && wide_gpu_ok(r, f, code)) {
+            bool cpu = false;
+            for (uint32_t m = 0; m < U && !cpu; ++m) cpu = wide_cpu_ok(r, f, code * U + m);
+            if (cpu) {
+                NicSearch ns{budget, false};
+                ok = nic_stage_ok_plain(separable, n, r, caps, code, &ns);
+                mine = ns.exhausted ? budget + 1u : budget - ns.left;      // (ran out by itself: whatever it would have found, one thread never got past it)
+                if (ns.exhausted) ok = false;
+            }
+        }
+        steps[lane] = mine;
+        const uint64_t hits = __ballot(ok);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t upto = hits ? (uint32_t)__builtin_ctzll(hits) : 63u;     // the first hit's lane, or the whole chunk
+        for (uint32_t l = 0; l <= upto; ++l) spent += steps[l];
+        found = hits != 0ull;
+        __builtin_amdgcn_wave_barrier();                                        // (the words are the next chunk's)
+    }
+    exhausted = spent > (uint64_t)budget;
+    spent_out = exhausted ? budget : (uint32_t)spent;
+    return found && !exhausted;
+}
+
 // ---- k_big_map -----------------------------------------------------------------------------------------------------------------------
 struct BigMapArgs {
     const nhdfit_plane0* p0; const nhdfit_plane1* p1; const nhdfit_plane2* p2; const nhdfit_plane3* p3; const nhdfit_plane4* p4;

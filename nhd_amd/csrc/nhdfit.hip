@@ -259,6 +259,11 @@ struct nhdfit_ctx {
     uint32_t find_seq = 0;
     std::vector<uint64_t> cand_shadow;   // copy of the mask a small find last uploaded to `cand` (empty: unknown)
     bool fast_find = tune_env("NHDFIT_NO_FAST_FIND") == nullptr;   // tuning aid: every find through the staged five-launch path
+    // single-launch find of a whole batch (k_findn): its host block (flag | scores | mappings, grown with the largest call), its counters
+    uint8_t* findn_host = nullptr; size_t findn_cap = 0;
+    DevBuf<uint32_t> findn_sync; uint32_t findn_sync_words = 0;
+    DevBuf<uint32_t> tile_items; std::vector<uint32_t> h_tile_items;   // fit items per staged tile (build_items)
+    bool batch_find = tune_env("NHDFIT_NO_BATCH_FIND") == nullptr;   // tuning aid: batches of more than one tile through the staged path
     bool lone_pod = tune_env("NHDFIT_NO_LONE_POD") == nullptr;      // one pod: the table-free launch (k_find1); tuning aid: NHDFIT_NO_LONE_POD=1 takes k_find
 
     // nodes beyond the fast layout (wide_core.h): records sorted by index; the device copy is the truth once commits ran on it
@@ -459,6 +464,8 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->big_reqs.release(); c->big_score.release(); c->big_maps.release(); c->big_flags.release(); c->big_place.release();
     c->big_cand.release(); c->big_scratch.release();
     if (c->find_host) (void)hipHostFree(c->find_host);
+    if (c->findn_host) (void)hipHostFree(c->findn_host);
+    c->findn_host = nullptr; c->findn_cap = 0; c->findn_sync.release(); c->tile_items.release();
     c->find_host = nullptr; c->find_sync.release(); c->find_red.release();
     c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release(); c->sig_flat2.release();
@@ -922,7 +929,7 @@ int ensure_records(nhdfit_ctx* c) {
 // same cost - a chunk of a tile with W assignments costs ~(6 + W) - and the block count is a fixed multiple of what
 // the chip holds at once (NHDFIT_FIT_BLOCKS overrides the target).  Wide tiles first: longest-first keeps the tail
 // of the launch short.  Small problems simply get one wavefront-run per chunk.
-int build_items(nhdfit_ctx* c, uint32_t nw) {
+int build_items(nhdfit_ctx* c, uint32_t nw, bool batch_find = false) {
     const uint32_t tiles = (c->P + kTile - 1) / kTile, chunks = (c->n + 63) / 64;
     const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
     // two of the three 512-thread blocks a CU holds (the side roles of the same launch live in the third slot)
@@ -942,7 +949,8 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
     const uint64_t rec_bytes = (uint64_t)chunks * 64u * (16u * (c->max_wcls + 1u) + 8u);
     const bool small_shard = rec_bytes <= (2u << 20);
     if (small_shard && nw == 8 && !c->fit_blocks) target = cus;          // (config 5 shard x 16 384 pods: 256 blocks 44.9 us per step, 512: 45.9, 1 024: 47.6, 2 048: 51.7)
-    const bool by_xcd = xcd_items && !c->fit_blocks && chunks >= 8u * 4u * nw && nw == 8 && !small_shard;
+    // (the single-launch find of a batch, k_findn, runs 256-thread blocks: the same cut into eighths of the node axis, two pieces each)
+    const bool by_xcd = xcd_items && !c->fit_blocks && chunks >= 8u * 4u * nw && (nw == 8 || batch_find) && !small_shard;
     for (uint32_t t = 0; t < tiles; ++t) {           // staged order = widest tiles first
         const uint32_t w = c->h_tile_wcls[t];
         const uint64_t cost = (uint64_t)chunks * (6u + (2u << w));
@@ -954,7 +962,7 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
             // 8, 16 or 32 blocks per tile by its cost when one launch has the chip to itself; with two pipes the other launch's
             // blocks fill the gaps, and fewer, longer fit blocks (less staging, fewer tails) win: 8 per tile (-3 %, profiles/r03)
             const bool two_pipes = c->dual && !c->split && !c->role_kernels;
-            const uint32_t k = force_k ? force_k : two_pipes ? 1u : nb <= 11 ? 1u : nb <= 23 ? 2u : 4u;
+            const uint32_t k = force_k ? force_k : batch_find ? 2u : two_pipes ? 1u : nb <= 11 ? 1u : nb <= 23 ? 2u : 4u;
             for (uint32_t j = 0; j < 8 * k; ++j) {
                 const uint32_t r = (j % 8) * k + j / 8;                     // range r of 8k: the (j / 8)-th piece of eighth j % 8
                 const uint32_t lo = (uint32_t)((uint64_t)chunks * r / (8 * k)), hi = (uint32_t)((uint64_t)chunks * (r + 1) / (8 * k));
@@ -970,9 +978,16 @@ int build_items(nhdfit_ctx* c, uint32_t nw) {
     HIPCHK(c, c->items.reserve(items.size() ? items.size() : 1));
     // page-locked staging, no wait: the list is only rebuilt after something drained the stream (stage_requests,
     // upload_nodes, set_node_count all sync first), so the previous copy out of this buffer is long done
-    HIPCHK(c, c->pin_items.reserve(items.size() * sizeof(FitItem) + 1));
+    HIPCHK(c, c->pin_items.reserve(items.size() * sizeof(FitItem) + (size_t)tiles * sizeof(uint32_t) + 1));
     memcpy(c->pin_items.p, items.data(), items.size() * sizeof(FitItem));
     HIPCHK(c, hipMemcpyAsync(c->items.p, c->pin_items.p, items.size() * sizeof(FitItem), hipMemcpyHostToDevice, c->stream));
+    if (batch_find) {                                           // how many tickets each tile's last block waits for
+        uint32_t* per_tile = reinterpret_cast<uint32_t*>(c->pin_items.p + items.size() * sizeof(FitItem));
+        for (uint32_t t = 0; t < tiles; ++t) per_tile[t] = 0;
+        for (const FitItem& it : items) per_tile[it.tile]++;
+        HIPCHK(c, c->tile_items.reserve(tiles));
+        HIPCHK(c, hipMemcpyAsync(c->tile_items.p, per_tile, (size_t)tiles * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    }
     c->n_items = (uint32_t)items.size();
     c->staged_gen++;
     return NHDFIT_OK;
@@ -1529,6 +1544,97 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     c->stats.small_finds++;
     return NHDFIT_OK;
 }
+
+// nhdfit_find for more than one pod tile as ONE launch (k_findn, step_kernel.h) behind the staging of the batch: the requests go to
+// the device as the staged path sends them (sorted into tiles, one async copy), digest -> fit -> mapping run tile by tile inside the
+// launch, scores and mappings arrive in a fine-grained host block, the host polls the sequence word stored last.
+// Returns 0 = done (nothing stays staged), 1 = not eligible, nothing touched; 2 = the batch is STAGED but the launch did not run or
+// gave up: the caller goes on with nhdfit_enqueue_step / nhdfit_fetch; < 0 = error (worded).
+int find_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand, uint64_t* score_out, nhdfit_mapping* map_out) {
+    if (!c->batch_find || !c->fast_find || !reqs || P <= (uint32_t)kTile || !c->nsig || !c->n || c->n_wide || c->comm || c->role_kernels || c->split) return 1;
+    if (map_out && !c->want_map) return 1;
+    int rc = nhdfit_stage_requests(c, reqs, P);                 // (sorted into tiles, on their way to the device; the layouts are the batch's)
+    if (rc) return rc;
+    if (c->n_big_pods) return 2;                                // four-group pods: their set model is a kernel of its own
+    if (cand && (rc = stage_cand(c, cand))) return rc;
+    if ((rc = ensure_records(c))) return rc;
+    if (c->x_spill) return 2;
+    constexpr uint32_t nw = 4;                                  // 256-thread blocks: a tile's pods are one wavefront of the mapping tail
+    if ((rc = build_items(c, nw, true))) return rc;
+    const uint32_t tiles = (P + kTile - 1) / kTile, chunks = (c->n + 63) / 64;
+    Pipe& p = c->pipe[0];
+    // the host block: flag word (16 bytes), P score words, P mappings
+    if (P > c->findn_cap) {
+        if (c->findn_host) (void)hipHostFree(c->findn_host);
+        c->findn_host = nullptr; c->findn_cap = 0;
+        const size_t cap = std::max<size_t>(4096, (size_t)P + P / 2);
+        HIPCHK(c, hipHostMalloc((void**)&c->findn_host, 16 + cap * (8 + sizeof(nhdfit_mapping)), hipHostMallocCoherent));
+        memset(c->findn_host, 0, 16);
+        c->findn_cap = cap;
+    }
+    uint32_t* h_flag = reinterpret_cast<uint32_t*>(c->findn_host);
+    unsigned long long* h_score = reinterpret_cast<unsigned long long*>(c->findn_host + 16);
+    nhdfit_mapping* h_maps = reinterpret_cast<nhdfit_mapping*>(c->findn_host + 16 + c->findn_cap * 8);
+    const uint32_t sync_words = 2u + 2u * tiles;
+    if (sync_words > c->findn_sync_words) {
+        const uint32_t words = std::max(sync_words, 2u + 2u * 256u);
+        HIPCHK(c, c->findn_sync.reserve(words));
+        HIPCHK(c, hipMemsetAsync(c->findn_sync.p, 0, (size_t)words * sizeof(uint32_t), c->stream));
+        c->findn_sync_words = words;
+    }
+    uint32_t seq = ++c->find_seq;
+    if (seq == 0u || seq == kFindAborted) seq = c->find_seq = 1u;
+
+    FindNArgs a;
+    memset(&a, 0, sizeof a);
+    a.s.shapes_P = P;
+    const uint32_t wc_parts = 2u;                               // (as the fused step's digest: two blocks per tile for the CPU rows)
+    fill_digest_args(c, p, 0, wc_parts, 1u, a.s.digest);
+    a.dig_parts = 1u + wc_parts;
+    a.s.nb_digest = tiles * a.dig_parts;
+    a.nb_lead = (a.s.nb_digest + 7u) & ~7u;
+    fill_fit_args(c, p, 0, now, a.s.fit, true);
+    a.s.fit.nm = nullptr; a.s.fit.dbg_skip = 0;                 // (no verdict matrix in this form)
+    a.s.nb_fit = c->n_items;
+    a.s.finish_m = make_map_args(c, p, 0);
+    a.s.finish_m.out = h_maps;
+    a.s.finish_h = make_shape_args(c, p, 0);
+    a.want_map = map_out ? 1u : 0u; a.tiles = tiles;
+    a.tile_wcls = c->tile_wcls.p; a.tile_items = c->tile_items.p;
+    a.sync = c->findn_sync.p; a.host_score = h_score; a.host_flag = h_flag; a.seq = seq;
+    size_t lds = lds_slice(c->lds_bytes) + (size_t)nw * 64 * sizeof(unsigned long long);
+    lds = std::max(lds, std::max(kDigestLds, map_tile_lds_bytes<256>()));
+    const auto t_launch = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL((k_findn<256>), dim3(a.nb_lead + a.s.nb_fit), dim3(256), lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    uint32_t seen = 0;
+    for (uint32_t spins = 1;; ++spins) {
+        seen = __atomic_load_n(h_flag, __ATOMIC_ACQUIRE);
+        if (seen == seq || seen == kFindAborted) break;
+        if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t_launch > std::chrono::microseconds(2000)) {
+            HIPCHK(c, wait_stream(c->stream));                  // a long launch (or host memory the device does not write through): wait for its end
+            seen = __atomic_load_n(h_flag, __ATOMIC_ACQUIRE);
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    if (seen != seq) {                                          // the launch gave up on a wait: counters back to zero, staged path
+        HIPCHK(c, wait_stream(c->stream));
+        HIPCHK(c, hipMemsetAsync(c->findn_sync.p, 0, (size_t)c->findn_sync_words * sizeof(uint32_t), c->stream));
+        *h_flag = 0;
+        c->n_items = 0;                                         // (the step's own work items: 512-thread blocks)
+        return 2;
+    }
+    if (score_out) for (uint32_t i = 0; i < P; ++i) score_out[c->perm[i]] = h_score[i];
+    if (map_out) for (uint32_t i = 0; i < P; ++i) map_out[c->perm[i]] = h_maps[i];
+    c->stats.evals_last = (uint64_t)P * c->n;
+    c->stats.bytes_last = (uint64_t)tiles * c->n * 24ull + (uint64_t)P * sizeof(nhdfit_req) + (uint64_t)P * 8ull;
+    c->stats.nodes = c->n; c->stats.nsig = c->nsig; c->stats.ncls = c->ncls; c->stats.lds_bytes = c->lds_bytes;
+    c->stats.batch_finds++;
+    c->P = 0; c->n_items = 0;                                   // nothing stays staged for nhdfit_enqueue_step / nhdfit_fetch
+    (void)chunks;
+    return NHDFIT_OK;
+}
 }  // namespace
 
 int nhdfit_find(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand,
@@ -1545,8 +1651,17 @@ int nhdfit_find(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, c
         const int rs = find_small(c, reqs, P, now, cand, score_out, map_out);
         if (rs <= 0) { lap("single launch"); return rs; }
     }
-    int rc = nhdfit_stage_requests(c, reqs, P);
-    if (rc) return rc;
+    int rc;
+    bool staged = false;
+    if (c && !bitmap_out) {
+        const int rb = find_batch(c, reqs, P, now, cand, score_out, map_out);
+        if (rb <= 0) { lap("single launch, batch"); return rb; }
+        staged = rb == 2;                                       // (the launch did not run: the staged batch takes the steps' path)
+    }
+    if (!staged) {
+        rc = nhdfit_stage_requests(c, reqs, P);
+        if (rc) return rc;
+    }
     lap("stage");
     if (cand && (rc = stage_cand(c, cand))) return rc;
     if ((rc = nhdfit_enqueue_step(c, now))) return rc;

@@ -398,6 +398,85 @@ __global__ __launch_bounds__(BLOCK) void k_find(FindArgs a) {
     }
 }
 
+// ---- one launch for a whole batch ---------------------------------------------------------------------
+// nhdfit_find for MORE than one pod tile: the staged path costs three launches in a row behind the copy of the requests - digest,
+// step, drain: each a latency chain of its own behind a launch gap - then two copies back and a stream wait: 170-205 us per call
+// whatever the size (profiles/r05: 256 pods x 4 096 nodes 0.169 ms, 4 096 x 65 536 0.188), of which the device is busy for a third.
+// Here the same roles run in ONE launch, tile by tile:
+//   * blocks [0, nb_digest): the digests, dig_parts blocks per tile; each counts itself in its tile's word when its rows are out.
+//     (The grid is padded to a multiple of eight blocks behind them so that fit block j still lands on XCD j % 8.)
+//   * then the fit role's work items (step_fit.h; the host's list, widest tiles first).  A fit block waits for its tile's digests -
+//     blocks of lower index: always running or done when it spins - sweeps its chunk range and takes a ticket of its tile.
+//   * the block with a tile's last ticket sees the tile's scores final: it maps the tile's winners (map_one_tile), stores mappings
+//     and scores into the fine-grained host block and counts the tile; the last tile's block stores the call's sequence number behind
+//     everything (system scope) - the host polls that word - and leaves every counter at zero.
+// Tiles finish at different times: the mapping of the early ones runs beside the sweep of the late ones.  A wait that does not end
+// gives up as in k_find: the launch reports kFindAborted and the host takes the staged path.
+struct FindNArgs {
+    StepArgs s;                                      // of it: digest, fit (with its items), finish_m / finish_h (the mapping tail), nb_digest, nb_fit, shapes_P
+    uint32_t want_map, tiles, dig_parts, nb_lead;    // nb_lead: nb_digest rounded up to a multiple of eight
+    const uint8_t* tile_wcls;                        // [tiles]
+    const uint32_t* tile_items;                      // [tiles] fit items per tile
+    uint32_t* sync;                                  // [0] tiles done, [1] a wait gave up, [2 + t] digest blocks of tile t done, [2 + tiles + t] tickets of tile t; zero between launches
+    unsigned long long* host_score;                  // [P] fine-grained host memory (finish_m.out: the mappings, likewise)
+    uint32_t* host_flag;
+    uint32_t seq;
+};
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_findn(FindNArgs a) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    uint32_t blk = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    if (blk < a.nb_lead) {
+        if (blk >= a.s.nb_digest) return;                                    // padding
+        role_digest<BLOCK>(a.s.digest, blk, lds);
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(&a.sync[2u + blk / a.dig_parts], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    blk -= a.nb_lead;
+    FitItem it = a.s.fit.items[blk];
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.tile);
+    uint32_t* s_word = reinterpret_cast<uint32_t*>(lds);
+    if (tid == 0) {
+        uint32_t ok = 1u;
+        for (uint32_t spin = 0; __hip_atomic_load(&a.sync[2u + tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.dig_parts; ++spin) {
+            if (spin > kFindSpinLimit) { ok = 0u; __hip_atomic_store(&a.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        *s_word = ok;
+    }
+    __syncthreads();
+    const bool go = *s_word != 0u;
+    __syncthreads();                                                         // (the word's LDS is the fit role's from here on)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                        // the digests' rows, past this CU's L1
+    if (go) role_fit_item<BLOCK>(a.s.fit, a.s.fit.busy_from, it, lds);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) *s_word = __hip_atomic_fetch_add(&a.sync[2u + a.tiles + tile], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool last = *s_word == a.tile_items[tile] - 1u;
+    __syncthreads();
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                        // every block's scores of this tile
+    const bool gave_up = __hip_atomic_load(&a.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (a.want_map && !gave_up) map_one_tile<BLOCK>(a.s.finish_m, a.s.finish_h, a.tile_wcls[tile], lds, nullptr, tile);   // (stores the mappings into the host block)
+    const uint32_t pod0 = tile * kTile;
+    if (tid < (uint32_t)kTile && pod0 + tid < a.s.shapes_P) a.host_score[pod0 + tid] = a.s.fit.score[pod0 + tid];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        a.sync[2u + tile] = 0u; a.sync[2u + a.tiles + tile] = 0u;
+        const uint32_t done = __hip_atomic_fetch_add(&a.sync[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == a.tiles - 1u) {                                           // every tile's results are out (each block fenced before it counted)
+            const bool aborted = __hip_atomic_load(&a.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            a.sync[0] = 0u; a.sync[1] = 0u;
+            __hip_atomic_store(a.host_flag, aborted ? kFindAborted : a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // ---- one launch for a LONE pod, no tables --------------------------------------------------------------
 // nhdfit_find with ONE pod.  The tile image is overhead then (63 of 64 columns empty, every row a ballot, and the fit blocks
 // wait for it): every block computes the pod's own masks over its 2^G assignments in LDS instead (fit_core.h LoneMasks - the
