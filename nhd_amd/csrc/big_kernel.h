@@ -10,47 +10,6 @@
 // whichever form the winner is mirrored in (commit_node_t on the planes, wide_commit on a wide record).
 // Nothing here is fast - a cluster's rare many-group pod costs milliseconds, not the table pass's microseconds - everything
 // here is exact.
-struct BigEvalArgs {
-    const nhdfit_plane0* p0; const nhdfit_plane1* p1; const nhdfit_plane2* p2; const nhdfit_plane3* p3; const nhdfit_plane4* p4;
-    const nhdfit_detail* det; uint32_t n;
-    const nhdfit_wide_node* wide; uint32_t n_wide;
-    const nhdfit_big_req* reqs; uint32_t P;
-    const double* caps; double busy_from;
-    const uint64_t* cand;                          // optional [chunks] candidate nodes
-    unsigned long long* score; uint64_t global_base;
-    uint32_t* flags;                               // [0] a set of the model outgrew its table, [1] a (pod, node) pair ran out of NIC search budget,
-                                                   // [2] the most search steps any (pod, node) pair of the call took
-    const nhdfit_wide_share* share;                // optional [n_wide]: ENABLE_SHARING arithmetic
-};
-
-__global__ __launch_bounds__(64) void k_big_eval(BigEvalArgs a) {
-    const uint32_t v = blockIdx.x * 64u + threadIdx.x, i = blockIdx.y;
-    unsigned long long s = 0;
-    if (v < a.n + a.n_wide) {
-        nhdfit_wide_node view;
-        if (v < a.n) wide_view(a.p0[v], a.p1[v], a.p2[v], a.p3[v], a.p4[v], a.det[v], v, view);
-        else view = a.wide[v - a.n];
-        const bool listed = !a.cand || (a.cand[view.index >> 6] >> (view.index & 63) & 1ull);
-        if (listed && view.numa_nodes) {           // (a placeholder of the planes has no NUMA nodes: its record answers, further down the grid)
-            const nhdfit_big_req& r = a.reqs[i];
-            NicSearch ns{NHDFIT_BIG_NIC_BUDGET, false};
-            const bool ok = wide_fits(view, r, view.busy_time >= a.busy_from, WideCaps(a.caps, a.share && v >= a.n ? a.share + (v - a.n) : nullptr), &ns);
-            if (ns.exhausted) atomicOr(&a.flags[1], 1u);
-            if (ns.left != NHDFIT_BIG_NIC_BUDGET) atomicMax(&a.flags[2], NHDFIT_BIG_NIC_BUDGET - ns.left);   // the deepest NIC search of the call (nhdfit_stats)
-            if (ok) {
-                uint32_t want = 0;
-                for (uint32_t g = 0; g < r.n_groups; ++g) want += r.gpus[g];
-                s = (unsigned long long)score_of(want == 0 && view.n_gpus == 0, a.global_base + view.index);   // SelectNode, Matcher.py:401-421
-            }
-        }
-    }
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long o = __shfl_xor(s, d, 64);
-        s = o > s ? o : s;
-    }
-    if (threadIdx.x == 0 && s) atomicMax(&a.score[i], s);
-}
-
 // ---- the winner's mapping with the wavefront's lanes ---------------------------------------------------------------------------------
 // wide_map (wide_core.h) for a big request on a node of at most two NUMA nodes - 2^G <= 256 G-tuples, 2^(G+1) (G+1)-tuples.  One thread
 // spent its time (profiles/r04: 1.9 ms per mapping) on the stages - per tuple a GPU / CPU sum and two NIC searches on a cut-down copy of
@@ -183,7 +142,78 @@ __device__ __noinline__ bool wide_fits_wave(const nhdfit_wide_node& n, const nhd
     return found && !exhausted;
 }
 
-// ---- k_big_map -----------------------------------------------------------------------------------------------------------------------
+// ---- the kernels of the general path for requests ----------------------------------------------------------------------------------------
+struct BigEvalArgs {
+    const nhdfit_plane0* p0; const nhdfit_plane1* p1; const nhdfit_plane2* p2; const nhdfit_plane3* p3; const nhdfit_plane4* p4;
+    const nhdfit_detail* det; uint32_t n;
+    const nhdfit_wide_node* wide; uint32_t n_wide;
+    const nhdfit_big_req* reqs; uint32_t P;
+    const double* caps; double busy_from;
+    const uint64_t* cand;                          // optional [chunks] candidate nodes
+    unsigned long long* score; uint64_t global_base;
+    uint32_t* flags;                               // [0] a set of the model outgrew its table, [1] a (pod, node) pair ran out of NIC search budget,
+                                                   // [2] the most search steps any (pod, node) pair of the call took
+    const nhdfit_wide_share* share;                // optional [n_wide]: ENABLE_SHARING arithmetic
+};
+
+// grid.x = 64-node chunks (the planes' nodes, then the wide records), grid.y = pod.  Lane = node for the scalar tests and the totals - most
+// nodes of a cluster end there for a pod of this size; the nodes that pass (two NUMA nodes) are then taken one after the other by the
+// whole wavefront, lane = assignment (wide_fits_wave); a node of three or four NUMA nodes keeps the one-thread walk (wide_fits).
+__global__ __launch_bounds__(64) void k_big_eval(BigEvalArgs a) {
+    __shared__ uint32_t s_steps[64];
+    const uint32_t lane = threadIdx.x, v = blockIdx.x * 64u + lane, i = blockIdx.y;
+    const nhdfit_big_req& r = a.reqs[i];
+    auto load_view = [&](uint32_t vv, nhdfit_wide_node& view) {
+        if (vv < a.n) wide_view(a.p0[vv], a.p1[vv], a.p2[vv], a.p3[vv], a.p4[vv], a.det[vv], vv, view);
+        else view = a.wide[vv - a.n];
+    };
+    auto caps_of = [&](uint32_t vv) { return WideCaps(a.caps, a.share && vv >= a.n ? a.share + (vv - a.n) : nullptr); };
+    auto score_for = [&](const nhdfit_wide_node& view) {
+        uint32_t want = 0;
+        for (uint32_t g = 0; g < r.n_groups; ++g) want += r.gpus[g];
+        return (unsigned long long)score_of(want == 0 && view.n_gpus == 0, a.global_base + view.index);   // SelectNode, Matcher.py:401-421
+    };
+    unsigned long long s = 0;
+    bool coop = false;
+    if (v < a.n + a.n_wide) {
+        nhdfit_wide_node view;
+        load_view(v, view);
+        const bool listed = !a.cand || (a.cand[view.index >> 6] >> (view.index & 63) & 1ull);
+        if (listed && view.numa_nodes) {           // (a placeholder of the planes has no NUMA nodes: its record answers, further down the grid)
+            if (view.numa_nodes <= 2u) {
+                coop = wide_scalar_ok(view, r, view.busy_time >= a.busy_from);      // (the totals: wide_fits_wave's first question)
+            } else {
+                NicSearch ns{NHDFIT_BIG_NIC_BUDGET, false};
+                const bool ok = wide_fits(view, r, view.busy_time >= a.busy_from, caps_of(v), &ns);
+                if (ns.exhausted) atomicOr(&a.flags[1], 1u);
+                if (ns.left != NHDFIT_BIG_NIC_BUDGET) atomicMax(&a.flags[2], NHDFIT_BIG_NIC_BUDGET - ns.left);   // the deepest NIC search of the call (nhdfit_stats)
+                if (ok) s = score_for(view);
+            }
+        }
+    }
+    unsigned long long todo = __ballot(coop);
+    while (todo) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t vl = blockIdx.x * 64u + l;
+        nhdfit_wide_node nv;
+        load_view(vl, nv);                         // (every lane its own copy of the one node: uniform addresses, broadcast loads)
+        uint32_t spent = 0;
+        bool out = false;
+        const bool ok = wide_fits_wave(nv, r, nv.busy_time >= a.busy_from, caps_of(vl), NHDFIT_BIG_NIC_BUDGET, s_steps, lane, spent, out);
+        if (lane == l) {
+            if (out) atomicOr(&a.flags[1], 1u);
+            if (spent) atomicMax(&a.flags[2], spent);
+            if (ok) s = score_for(nv);
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(s, d, 64);
+        s = o > s ? o : s;
+    }
+    if (threadIdx.x == 0 && s) atomicMax(&a.score[i], s);
+}
+
 struct BigMapArgs {
     const nhdfit_plane0* p0; const nhdfit_plane1* p1; const nhdfit_plane2* p2; const nhdfit_plane3* p3; const nhdfit_plane4* p4;
     const nhdfit_detail* det; uint32_t n;

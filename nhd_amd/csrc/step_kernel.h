@@ -311,6 +311,37 @@ __global__ __launch_bounds__(BLOCK, 6) void k_role(StepArgs a) {
 }
 #endif
 
+// ---- hand-offs between the blocks of one launch (k_find, k_find1, k_findn) -----------------------------------------------------------------
+// gfx950: a CU's L1 is never refreshed by other CUs' stores, the XCDs' L2s are not coherent with each other.  What a block publishes -
+// plain stores - becomes visible through ONE agent-scope release by one lane behind the block's barrier (every storing wave drains its
+// stores first), then a relaxed agent-scope counter; the consumer polls that counter RELAXED (an acquire per poll costs ~1.7 us each and
+// a few hundred pollers take a third of the chip's bandwidth), ONE lane acquires once behind the match, a barrier, then plain loads.
+// Agent-scope atomics (the fit role's atomicMax on the score words) need no release: they are performed at the coherence point, the
+// wave waits for them (vmcnt) and the counter follows.  The fences are per lane, not per thread: 256 threads fencing cost 2-4 x one.
+#define NHDFIT_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// every thread of the block calls it behind its last store; returns the counter's value before this block's arrival (thread 0 only)
+__device__ __forceinline__ uint32_t publish_and_count(uint32_t* counter, bool plain_stores) {
+    NHDFIT_DRAIN_VMEM();
+    __syncthreads();
+    uint32_t before = 0;
+    if (threadIdx.x == 0) {
+        if (plain_stores) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); NHDFIT_DRAIN_VMEM(); }
+        before = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        NHDFIT_DRAIN_VMEM();
+    }
+    return before;
+}
+// thread 0 only: wait until *counter >= want (false: gave up), then the one acquire
+__device__ __forceinline__ bool poll_then_acquire(const uint32_t* counter, uint32_t want, uint32_t limit) {
+    bool ok = true;
+    for (uint32_t spin = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++spin) {
+        if (spin > limit) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return ok;
+}
+
 // ---- one launch for a small find ---------------------------------------------------------------------
 // nhdfit_find for at most one pod tile (the scheduler's pod-at-a-time FindNode): the five roles of a step in ONE launch
 // instead of five launches in a row, requests read straight from page-locked host memory, results stored straight into
@@ -349,25 +380,19 @@ __global__ __launch_bounds__(BLOCK) void k_find(FindArgs a) {
     if (blk < a.s.nb_digest) {
         role_digest<BLOCK>(a.s.digest, blk, lds);
         stamp(a.s.role_clock, 3, t0);
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(&a.sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        (void)publish_and_count(&a.sync[0], true);                           // (rows, headers, zeroed scores: plain stores)
         return;
     }
     blk -= a.s.nb_digest;
     uint32_t* s_word = reinterpret_cast<uint32_t*>(lds);
     if (tid == 0) {
-        uint32_t ok = 1u;
-        for (uint32_t spin = 0; __hip_atomic_load(&a.sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.s.nb_digest; ++spin) {
-            if (spin > kFindSpinLimit) { ok = 0u; __hip_atomic_store(&a.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        *s_word = ok;
+        const bool ok = poll_then_acquire(&a.sync[0], a.s.nb_digest, kFindSpinLimit);      // the digest's rows, past this CU's L1
+        if (!ok) __hip_atomic_store(&a.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_word = ok ? 1u : 0u;
     }
     __syncthreads();
     const bool go = *s_word != 0u;
     __syncthreads();                                                     // (the word's LDS is the fit role's from here on)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                    // the digest's rows, past this CU's L1
     const unsigned long long t1 = a.s.role_clock ? (unsigned long long)wall_clock64() : 0ull;
     if (go) {
         const uint32_t chunks = a.s.fit.chunks, nb = a.s.nb_fit;
@@ -375,14 +400,15 @@ __global__ __launch_bounds__(BLOCK) void k_find(FindArgs a) {
         role_fit_item<BLOCK>(a.s.fit, a.s.fit.busy_from, it, lds);
     }
     stamp(a.s.role_clock, 4, t1);
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) *s_word = __hip_atomic_fetch_add(&a.sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t ticket = publish_and_count(&a.sync[1], false);         // (the sweep's only stores: atomicMax on the score words)
+    if (tid == 0) {
+        if (ticket == a.s.nb_fit - 1u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // every block's scores
+        *s_word = ticket;
+    }
     __syncthreads();
     const bool last = *s_word == a.s.nb_fit - 1u;
     __syncthreads();
     if (!last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                    // every block's scores
     const bool aborted = __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     if (a.want_map && !aborted) {
         const unsigned long long t2 = a.s.role_clock ? (unsigned long long)wall_clock64() : 0ull;
@@ -390,7 +416,7 @@ __global__ __launch_bounds__(BLOCK) void k_find(FindArgs a) {
         stamp(a.s.role_clock, 2, t2);
     }
     for (uint32_t p = tid; p < a.s.shapes_P; p += BLOCK) a.host->score[p] = a.s.fit.score[p];
-    __threadfence_system();
+    NHDFIT_DRAIN_VMEM();                                                  // every wave's stores into the host block, then the word behind them
     __syncthreads();
     if (tid == 0) {
         a.sync[0] = 0u; a.sync[1] = 0u; a.sync[2] = 0u;
@@ -430,9 +456,7 @@ __global__ __launch_bounds__(BLOCK) void k_findn(FindNArgs a) {
     if (blk < a.nb_lead) {
         if (blk >= a.s.nb_digest) return;                                    // padding
         role_digest<BLOCK>(a.s.digest, blk, lds);
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(&a.sync[2u + blk / a.dig_parts], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        (void)publish_and_count(&a.sync[2u + blk / a.dig_parts], true);      // (rows, headers, zeroed scores: plain stores)
         return;
     }
     blk -= a.nb_lead;
@@ -440,36 +464,37 @@ __global__ __launch_bounds__(BLOCK) void k_findn(FindNArgs a) {
     const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.tile);
     uint32_t* s_word = reinterpret_cast<uint32_t*>(lds);
     if (tid == 0) {
-        uint32_t ok = 1u;
-        for (uint32_t spin = 0; __hip_atomic_load(&a.sync[2u + tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.dig_parts; ++spin) {
-            if (spin > kFindSpinLimit) { ok = 0u; __hip_atomic_store(&a.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        *s_word = ok;
+        const bool ok = poll_then_acquire(&a.sync[2u + tile], a.dig_parts, kFindSpinLimit);   // the digests' rows, past this CU's L1
+        if (!ok) __hip_atomic_store(&a.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_word = ok ? 1u : 0u;
     }
     __syncthreads();
     const bool go = *s_word != 0u;
     __syncthreads();                                                         // (the word's LDS is the fit role's from here on)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                        // the digests' rows, past this CU's L1
     if (go) role_fit_item<BLOCK>(a.s.fit, a.s.fit.busy_from, it, lds);
-    __threadfence();
+    const uint32_t ticket = publish_and_count(&a.sync[2u + a.tiles + tile], false);   // (the sweep's only stores: atomicMax on the score words)
+    if (tid == 0) {
+        const bool mine = ticket == a.tile_items[tile] - 1u;
+        if (mine) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // every block's scores of this tile
+        *s_word = mine ? 1u : 0u;
+    }
     __syncthreads();
-    if (tid == 0) *s_word = __hip_atomic_fetch_add(&a.sync[2u + a.tiles + tile], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const bool last = *s_word == a.tile_items[tile] - 1u;
+    const bool last = *s_word != 0u;
     __syncthreads();
     if (!last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                        // every block's scores of this tile
     const bool gave_up = __hip_atomic_load(&a.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     if (a.want_map && !gave_up) map_one_tile<BLOCK>(a.s.finish_m, a.s.finish_h, a.tile_wcls[tile], lds, nullptr, tile);   // (stores the mappings into the host block)
     const uint32_t pod0 = tile * kTile;
     if (tid < (uint32_t)kTile && pod0 + tid < a.s.shapes_P) a.host_score[pod0 + tid] = a.s.fit.score[pod0 + tid];
-    __threadfence_system();
+    NHDFIT_DRAIN_VMEM();                                                      // every wave's stores into the host block
     __syncthreads();
     if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                         // (system scope: the host block) ... then the tile counts
+        NHDFIT_DRAIN_VMEM();
         a.sync[2u + tile] = 0u; a.sync[2u + a.tiles + tile] = 0u;
-        const uint32_t done = __hip_atomic_fetch_add(&a.sync[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == a.tiles - 1u) {                                           // every tile's results are out (each block fenced before it counted)
+        const uint32_t done = __hip_atomic_fetch_add(&a.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        NHDFIT_DRAIN_VMEM();
+        if (done == a.tiles - 1u) {                                           // every tile's results are out (each block released before it counted)
             const bool aborted = __hip_atomic_load(&a.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             a.sync[0] = 0u; a.sync[1] = 0u;
             __hip_atomic_store(a.host_flag, aborted ? kFindAborted : a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -596,14 +621,17 @@ __global__ __launch_bounds__(BLOCK) void k_find1(Find1Args a) {
         if (mx) atomicMax(const_cast<unsigned long long*>(a.m.score), mx);
     }
     stamp(a.role_clock, 4, t1);
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_best[0] = __hip_atomic_fetch_add(&a.sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    // the block's only store is thread 0's atomicMax on the score word - performed at the coherence point: the ticket follows it on the
+    // same lane, no fence; the last block reads the word with an agent-scope load (everything else it reads is older than the launch)
+    if (tid == 0) {
+        NHDFIT_DRAIN_VMEM();
+        s_best[0] = __hip_atomic_fetch_add(&a.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        NHDFIT_DRAIN_VMEM();
+    }
     __syncthreads();
     const bool last = (uint32_t)s_best[0] == a.nb - 1u;
     __syncthreads();
     if (!last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                    // every block's score
     if (a.want_map) {
         const unsigned long long t2 = a.role_clock ? (unsigned long long)wall_clock64() : 0ull;
         MapArgs m = a.m;
@@ -614,7 +642,7 @@ __global__ __launch_bounds__(BLOCK) void k_find1(Find1Args a) {
         stamp(a.role_clock, 2, t2);
     }
     if (tid == 0) a.host->score[0] = __hip_atomic_load(a.m.score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
+    NHDFIT_DRAIN_VMEM();                                                  // every wave's stores into the host block, then the word behind them
     __syncthreads();
     if (tid == 0) {
         a.sync[1] = 0u;

@@ -154,7 +154,7 @@ _WAVE_FROM, _WAVE_TO = "// ---- the commit step with the wavefront's lanes", "//
 WAVE_MAP_INC = os.path.join(HERE, "_wave_map_block.inc")
 _WAVE_MAP_FROM, _WAVE_MAP_TO = "// ---- wave-cooperative forms of the mapping arithmetic", "// One block walks the batch in the caller's order"
 WAVE_BIG_INC = os.path.join(HERE, "_wave_bigmap_block.inc")
-_WAVE_BIG_FROM, _WAVE_BIG_TO = "// ---- the winner's mapping with the wavefront's lanes", "// ---- k_big_map"
+_WAVE_BIG_FROM, _WAVE_BIG_TO = "// ---- the winner's mapping with the wavefront's lanes", "// ---- the kernels of the general path for requests"
 _wave = None
 
 
@@ -223,6 +223,23 @@ def wave_big_map(packer, table, v, big_req, wide=None, share=None):
     L.we_big_map.restype = ctypes.c_int
     rc = L.we_big_map(*[_p(x) for x in rows], None if w is None else _p(w), _p(req), _p(caps), sh_ptr, _p(ms), _p(mw), rcs)
     return int(rc), (int(rcs[0]), int(rcs[1])), ms, mw
+
+
+def wave_big_fits(packer, table, v, big_req, busy=False, budget=1 << 22, wide=None, share=None):
+    """feasible(node, pod) for a big request on node `v` of `table` (or the wide record `wide`): wide_core.h wide_fits (one thread) against
+    big_kernel.h wide_fits_wave (lane = assignment, emulated lanes).  (return code of we_big_fits, (feasible, exhausted, steps) of one thread,
+    the same of the wavefront)."""
+    L = wave_lib()
+    caps = _dict_args(packer)[0]
+    req = np.ascontiguousarray(big_req)
+    rows = [np.ascontiguousarray(getattr(table, f)[v:v + 1]) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
+    out = (ctypes.c_int * 6)(*([0] * 6))
+    w = None if wide is None else np.ascontiguousarray(wide, dtype=pack.WIDE).reshape(-1)[:1]
+    sh_arr, sh_ptr = _share_arg(share, 1) if share is not None else (None, None)
+    L.we_big_fits.restype = ctypes.c_int
+    rc = L.we_big_fits(*[_p(x) for x in rows], None if w is None else _p(w), _p(req), _p(caps), sh_ptr, ctypes.c_int(1 if busy else 0),
+                       ctypes.c_uint32(int(budget)), out)
+    return int(rc), tuple(out[:3]), tuple(out[3:])
 
 
 def wave_commit(packer, table, i, req, mapping, busy_time, form=1):
