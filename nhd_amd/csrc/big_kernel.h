@@ -89,59 +89,6 @@ __device__ __noinline__ int wide_map_wave(BigWaveLds& t, const WideCaps& caps, i
     return t.rc;
 }
 
-// feasible(node, pod) with the wavefront's lanes - wide_fits (wide_core.h) for a big request on a node of at most two NUMA nodes.  With
-// lane = node, 64 nodes walk their assignments side by side in one wavefront: each until its own first hit, each with NIC searches of
-// its own length - the wavefront executes every lane's path one after the other (profiles/r05: k_big_eval 0.44 ms mean, 2.4 ms worst
-// on 65 536 nodes, the scalar tests alone 50 us).  Here the 64 lanes take ONE node: lane = assignment, the three stages asked per lane
-// (the searches of different assignments run beside each other), a ballot finds the first assignment that passes.  The answer is a
-// boolean over the assignments - their order only matters for the search budget and its statistic, which count the steps one thread
-// spends up to and including the first hit: the lanes' step counts, summed in assignment order to that point (nic_stage_ok_plain: the
-// searches and their steps are the memo's on two NUMA nodes).  `n`, `r` visible to every lane; `steps`: 64 words of LDS.
-// Returns feasible; `spent` = search steps as wide_fits counts them, `exhausted` = they exceed `budget`.
-__device__ __noinline__ bool wide_fits_wave(const nhdfit_wide_node& n, const nhdfit_big_req& r, bool busy, const WideCaps& caps, uint32_t budget,
-                                            uint32_t* steps, uint32_t lane, uint32_t& spent_out, bool& exhausted) {
-    spent_out = 0; exhausted = false;
-    if (!wide_scalar_ok(n, r, busy)) return false;
-    const WideFree f = wide_free(n);
-    const uint32_t G = r.n_groups, U = f.U, nG = wide_ipow(U, G);
-    {   // a node whose free GPUs or free cores do not cover the pod's totals passes no assignment at all
-        uint32_t need_g = 0, need_c = f.smt ? r.misc_smt : r.misc_nosmt, have_g = 0, have_c = 0;
-        for (uint32_t g = 0; g < G; ++g) { need_g += r.gpus[g]; need_c += f.smt ? r.cpu_smt[g] : r.cpu_nosmt[g]; }
-        for (uint32_t u = 0; u < U; ++u) { have_g += f.g[u]; have_c += f.c[u]; }
-        if (need_g > have_g || need_c > have_c) return false;
-    }
-    const bool separable = nic_separable(n, r);
-    uint64_t spent = 0;
-    bool found = false;
-    for (uint32_t base = 0; base < nG && !found && spent <= (uint64_t)budget; base += 64) {
-        const uint32_t code = base + lane;
-        bool ok = false;
-        uint32_t mine = 0;
-        if (code < nG && wide_gpu_ok(r, f, code)) {
-            bool cpu = false;
-            for (uint32_t m = 0; m < U && !cpu; ++m) cpu = wide_cpu_ok(r, f, code * U + m);
-            if (cpu) {
-                NicSearch ns{budget, false};
-                ok = nic_stage_ok_plain(separable, n, r, caps, code, &ns);
-                mine = ns.exhausted ? budget + 1u : budget - ns.left;      // (ran out by itself: whatever it would have found, one thread never got past it)
-                if (ns.exhausted) ok = false;
-            }
-        }
-        steps[lane] = mine;
-        const uint64_t hits = __ballot(ok);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint32_t upto = hits ? (uint32_t)__builtin_ctzll(hits) : 63u;     // the first hit's lane, or the whole chunk
-        for (uint32_t l = 0; l <= upto; ++l) spent += steps[l];
-        found = hits != 0ull;
-        __builtin_amdgcn_wave_barrier();                                        // (the words are the next chunk's)
-    }
-    exhausted = spent > (uint64_t)budget;
-    spent_out = exhausted ? budget : (uint32_t)spent;
-    return found && !exhausted;
-}
-
 // ---- the kernels of the general path for requests ----------------------------------------------------------------------------------------
 struct BigEvalArgs {
     const nhdfit_plane0* p0; const nhdfit_plane1* p1; const nhdfit_plane2* p2; const nhdfit_plane3* p3; const nhdfit_plane4* p4;
@@ -156,55 +103,30 @@ struct BigEvalArgs {
     const nhdfit_wide_share* share;                // optional [n_wide]: ENABLE_SHARING arithmetic
 };
 
-// grid.x = 64-node chunks (the planes' nodes, then the wide records), grid.y = pod.  Lane = node for the scalar tests and the totals - most
-// nodes of a cluster end there for a pod of this size; the nodes that pass (two NUMA nodes) are then taken one after the other by the
-// whole wavefront, lane = assignment (wide_fits_wave); a node of three or four NUMA nodes keeps the one-thread walk (wide_fits).
+// grid.x = 64-node chunks (the planes' nodes, then the wide records), grid.y = pod; lane = node: the scalar tests and the totals turn most nodes
+// of a cluster away for a pod of this size, the others walk their assignments to the first one that passes (wide_fits).  (Round 5 also
+// measured the walk with the wavefront's lanes - the 64 lanes take the nodes that pass one after the other, lane = assignment - against
+// this form: 2.8 ms against 0.44 per call on config 4's 65 536 nodes.  The nodes of a chunk are mostly of one kind, so their walks run in
+// step and lane = node wastes little; one node at a time pays the walk's set-up 64 times over.  profiles/r05/README.md.)
 __global__ __launch_bounds__(64) void k_big_eval(BigEvalArgs a) {
-    __shared__ uint32_t s_steps[64];
-    const uint32_t lane = threadIdx.x, v = blockIdx.x * 64u + lane, i = blockIdx.y;
-    const nhdfit_big_req& r = a.reqs[i];
-    auto load_view = [&](uint32_t vv, nhdfit_wide_node& view) {
-        if (vv < a.n) wide_view(a.p0[vv], a.p1[vv], a.p2[vv], a.p3[vv], a.p4[vv], a.det[vv], vv, view);
-        else view = a.wide[vv - a.n];
-    };
-    auto caps_of = [&](uint32_t vv) { return WideCaps(a.caps, a.share && vv >= a.n ? a.share + (vv - a.n) : nullptr); };
-    auto score_for = [&](const nhdfit_wide_node& view) {
-        uint32_t want = 0;
-        for (uint32_t g = 0; g < r.n_groups; ++g) want += r.gpus[g];
-        return (unsigned long long)score_of(want == 0 && view.n_gpus == 0, a.global_base + view.index);   // SelectNode, Matcher.py:401-421
-    };
+    const uint32_t v = blockIdx.x * 64u + threadIdx.x, i = blockIdx.y;
     unsigned long long s = 0;
-    bool coop = false;
     if (v < a.n + a.n_wide) {
         nhdfit_wide_node view;
-        load_view(v, view);
+        if (v < a.n) wide_view(a.p0[v], a.p1[v], a.p2[v], a.p3[v], a.p4[v], a.det[v], v, view);
+        else view = a.wide[v - a.n];
         const bool listed = !a.cand || (a.cand[view.index >> 6] >> (view.index & 63) & 1ull);
         if (listed && view.numa_nodes) {           // (a placeholder of the planes has no NUMA nodes: its record answers, further down the grid)
-            if (view.numa_nodes <= 2u) {
-                coop = wide_scalar_ok(view, r, view.busy_time >= a.busy_from);      // (the totals: wide_fits_wave's first question)
-            } else {
-                NicSearch ns{NHDFIT_BIG_NIC_BUDGET, false};
-                const bool ok = wide_fits(view, r, view.busy_time >= a.busy_from, caps_of(v), &ns);
-                if (ns.exhausted) atomicOr(&a.flags[1], 1u);
-                if (ns.left != NHDFIT_BIG_NIC_BUDGET) atomicMax(&a.flags[2], NHDFIT_BIG_NIC_BUDGET - ns.left);   // the deepest NIC search of the call (nhdfit_stats)
-                if (ok) s = score_for(view);
+            const nhdfit_big_req& r = a.reqs[i];
+            NicSearch ns{NHDFIT_BIG_NIC_BUDGET, false};
+            const bool ok = wide_fits(view, r, view.busy_time >= a.busy_from, WideCaps(a.caps, a.share && v >= a.n ? a.share + (v - a.n) : nullptr), &ns);
+            if (ns.exhausted) atomicOr(&a.flags[1], 1u);
+            if (ns.left != NHDFIT_BIG_NIC_BUDGET) atomicMax(&a.flags[2], NHDFIT_BIG_NIC_BUDGET - ns.left);   // the deepest NIC search of the call (nhdfit_stats)
+            if (ok) {
+                uint32_t want = 0;
+                for (uint32_t g = 0; g < r.n_groups; ++g) want += r.gpus[g];
+                s = (unsigned long long)score_of(want == 0 && view.n_gpus == 0, a.global_base + view.index);   // SelectNode, Matcher.py:401-421
             }
-        }
-    }
-    unsigned long long todo = __ballot(coop);
-    while (todo) {
-        const uint32_t l = (uint32_t)__builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        const uint32_t vl = blockIdx.x * 64u + l;
-        nhdfit_wide_node nv;
-        load_view(vl, nv);                         // (every lane its own copy of the one node: uniform addresses, broadcast loads)
-        uint32_t spent = 0;
-        bool out = false;
-        const bool ok = wide_fits_wave(nv, r, nv.busy_time >= a.busy_from, caps_of(vl), NHDFIT_BIG_NIC_BUDGET, s_steps, lane, spent, out);
-        if (lane == l) {
-            if (out) atomicOr(&a.flags[1], 1u);
-            if (spent) atomicMax(&a.flags[2], spent);
-            if (ok) s = score_for(nv);
         }
     }
     for (int d = 32; d >= 1; d >>= 1) {

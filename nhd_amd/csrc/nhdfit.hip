@@ -727,11 +727,18 @@ namespace {
 // alone.  It is also the order in which EVERY form of a sharded find hands its score words to the all-reduce - the staged step and
 // the single-launch find alike - so that ranks that take different forms for the same call (one shard holds a wide node, spilled
 // class rows, a launch that gave up: rank-local facts) still reduce pod against pod.
-void staged_order(const nhdfit_req* reqs, uint32_t P, std::vector<uint32_t>& perm) {
+// `seen` (optional): what the staging wants to know of every request anyway - one pass over the records instead of three
+struct StagedSeen { int32_t hp_min = 0, hp_max = 0; uint32_t n_big = 0; };
+void staged_order(const nhdfit_req* reqs, uint32_t P, std::vector<uint32_t>& perm, StagedSeen* seen = nullptr) {
     perm.resize(P);
-    std::vector<uint16_t> key(P);
+    static thread_local std::vector<uint16_t> key;
+    key.resize(P);
     uint32_t start[512 + 1] = {0};
+    StagedSeen sn;
     for (uint32_t p = 0; p < P; ++p) {
+        const int32_t hp = reqs[p].hugepages_gb;
+        sn.hp_min = hp < sn.hp_min ? hp : sn.hp_min; sn.hp_max = hp > sn.hp_max ? hp : sn.hp_max;
+        sn.n_big += reqs[p].n_groups > 3;
         const PodHeader h = pod_header(reqs[p]);
         // group count is the major key, descending: the tiles with the most assignments to sweep are the
         // first blocks of the fit grid (longest-first keeps the tail of the launch short)
@@ -741,6 +748,7 @@ void staged_order(const nhdfit_req* reqs, uint32_t P, std::vector<uint32_t>& per
     }
     for (uint32_t k = 0; k < 512; ++k) start[k + 1] += start[k];          // stable counting sort: 9-bit keys
     for (uint32_t p = 0; p < P; ++p) perm[start[key[p]]++] = p;
+    if (seen) *seen = sn;
 }
 }  // namespace
 
@@ -756,48 +764,51 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     c->last_pipe = 0;
     c->staged_gen++;
     const uint32_t tiles = (P + kTile - 1) / kTile;
-    int32_t hp_max = 0;
-    for (uint32_t p = 0; p < P; ++p) {
-        if (reqs[p].hugepages_gb < 0) return fail(c, NHDFIT_E_INVAL, "pod %u asks for a negative number of hugepages", p);
-        hp_max = reqs[p].hugepages_gb > hp_max ? reqs[p].hugepages_gb : hp_max;
-    }
+    // Pods are staged sorted by request class so that 64-pod tiles are homogeneous (narrow table rows, fast sweep of
+    // the fit role) and the lanes of the mapping roles have similar group counts; results are un-permuted in fetch.
+    StagedSeen seen;
+    staged_order(reqs, P, c->perm, &seen);
+    if (seen.hp_min < 0)
+        for (uint32_t p = 0; p < P; ++p)
+            if (reqs[p].hugepages_gb < 0) return fail(c, NHDFIT_E_INVAL, "pod %u asks for a negative number of hugepages", p);
+    const int32_t hp_max = seen.hp_max;
     if (hp_max > kMaxHpRows - 2)
         return fail(c, NHDFIT_E_LIMIT, "a pod asks for %d GiB of hugepages (limit %d)", hp_max, kMaxHpRows - 2);
     HIPCHK(c, c->reqs.reserve(P));
-    for (Pipe& p : c->pipe) {
-        HIPCHK(c, p.dig_count.reserve(tiles));
-        HIPCHK(c, hipMemsetAsync(p.dig_count.p, 0, (size_t)tiles * sizeof(uint32_t), c->stream));
-    }
+    for (Pipe& p : c->pipe)
+        if (tiles > p.dig_count.cap) {                 // (the digest role leaves its arrival counters at zero: cleared when the buffer is new)
+            HIPCHK(c, p.dig_count.reserve(std::max<size_t>(tiles, 256)));
+            HIPCHK(c, hipMemsetAsync(p.dig_count.p, 0, p.dig_count.cap * sizeof(uint32_t), c->stream));
+        }
     for (Pipe& p : c->pipe)
         for (int b = 0; b < kBufs; ++b) {
             HIPCHK(c, p.hdr[b].reserve((size_t)tiles * kTile));
             HIPCHK(c, p.score[b].reserve(P));
             HIPCHK(c, p.maps[b].reserve(P));
         }
-    // Pods are staged sorted by request class so that 64-pod tiles are homogeneous (narrow table rows, fast sweep of
-    // the fit role) and the lanes of the mapping roles have similar group counts; results are un-permuted in fetch.
-    c->n_big_pods = 0;
-    for (uint32_t p = 0; p < P; ++p) c->n_big_pods += reqs[p].n_groups > 3;
-    staged_order(reqs, P, c->perm);
+    c->n_big_pods = seen.n_big;
     HIPCHK(c, c->pin_reqs.reserve(P));
     nhdfit_req* sorted = c->pin_reqs.p;                                   // (free again: sync_all above waited for the last copy out of it)
-    for (uint32_t i = 0; i < P; ++i) sorted[i] = reqs[c->perm[i]];
-    HIPCHK(c, hipMemcpyAsync(c->reqs.p, sorted, (size_t)P * sizeof *reqs, hipMemcpyHostToDevice, c->stream));
-    // row width class of every tile: 2^(largest group count among its valid pods) assignments - the digest role
-    // derives the same class from the same records
+    // tile by tile: the records gathered into the page-locked block, then - while they are in the core's cache - the tile's row width
+    // class (2^(largest group count among its valid pods) assignments: the digest role derives the same class from the same records)
+    // and, for the narrow tiles, the largest CPU demand (the pair table's dimension)
     c->h_tile_wcls.assign(tiles, 0);
     c->max_wcls = 0;
-    for (uint32_t i = 0; i < P; ++i)
-        if (req_valid(sorted[i])) {
-            const uint8_t w = (uint8_t)wclass_of(sorted[i].n_groups);
-            if (w > c->h_tile_wcls[i / kTile]) c->h_tile_wcls[i / kTile] = w;
-            if (w > c->max_wcls) c->max_wcls = w;
-        }
     c->max_demand[0] = c->max_demand[1] = 0;
-    for (uint32_t i = 0; i < P; ++i) {
-        const uint8_t w = c->h_tile_wcls[i / kTile];
-        if (w < 2 && req_valid(sorted[i])) c->max_demand[w] = std::max(c->max_demand[w], req_max_demand(sorted[i]));
+    for (uint32_t t = 0; t < tiles; ++t) {
+        const uint32_t lo = t * kTile, hi = std::min(P, lo + (uint32_t)kTile);
+        uint8_t w = 0;
+        for (uint32_t i = lo; i < hi; ++i) {
+            sorted[i] = reqs[c->perm[i]];
+            if (req_valid(sorted[i])) w = std::max(w, (uint8_t)wclass_of(sorted[i].n_groups));
+        }
+        c->h_tile_wcls[t] = w;
+        if (w > c->max_wcls) c->max_wcls = w;
+        if (w < 2)
+            for (uint32_t i = lo; i < hi; ++i)
+                if (req_valid(sorted[i])) c->max_demand[w] = std::max(c->max_demand[w], req_max_demand(sorted[i]));
     }
+    HIPCHK(c, hipMemcpyAsync(c->reqs.p, sorted, (size_t)P * sizeof *reqs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->tile_wcls.reserve(tiles));
     HIPCHK(c, c->pin_wcls.reserve(tiles));
     memcpy(c->pin_wcls.p, c->h_tile_wcls.data(), tiles);
@@ -1553,8 +1564,17 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
 int find_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, const uint64_t* cand, uint64_t* score_out, nhdfit_mapping* map_out) {
     if (!c->batch_find || !c->fast_find || !reqs || P <= (uint32_t)kTile || !c->nsig || !c->n || c->n_wide || c->comm || c->role_kernels || c->split) return 1;
     if (map_out && !c->want_map) return 1;
+    static const bool prof = tune_env("NHDFIT_FIND_PROF") != nullptr;      // tuning aid: host-side phase times of the call
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!prof) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[nhdfit] batch find P=%u %s %.1f us\n", P, what, std::chrono::duration<double, std::micro>(t1 - t_prev).count());
+        t_prev = t1;
+    };
     int rc = nhdfit_stage_requests(c, reqs, P);                 // (sorted into tiles, on their way to the device; the layouts are the batch's)
     if (rc) return rc;
+    lap("stage");
     if (c->n_big_pods) return 2;                                // four-group pods: their set model is a kernel of its own
     if (cand && (rc = stage_cand(c, cand))) return rc;
     if ((rc = ensure_records(c))) return rc;
@@ -1604,9 +1624,11 @@ int find_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     a.sync = c->findn_sync.p; a.host_score = h_score; a.host_flag = h_flag; a.seq = seq;
     size_t lds = lds_slice(c->lds_bytes) + (size_t)nw * 64 * sizeof(unsigned long long);
     lds = std::max(lds, std::max(kDigestLds, map_tile_lds_bytes<256>()));
+    lap("records, items, arguments");
     const auto t_launch = std::chrono::steady_clock::now();
     hipLaunchKernelGGL((k_findn<256>), dim3(a.nb_lead + a.s.nb_fit), dim3(256), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
+    lap("launch call");
     uint32_t seen = 0;
     for (uint32_t spins = 1;; ++spins) {
         seen = __atomic_load_n(h_flag, __ATOMIC_ACQUIRE);
@@ -1625,8 +1647,10 @@ int find_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
         c->n_items = 0;                                         // (the step's own work items: 512-thread blocks)
         return 2;
     }
+    lap("poll");
     if (score_out) for (uint32_t i = 0; i < P; ++i) score_out[c->perm[i]] = h_score[i];
     if (map_out) for (uint32_t i = 0; i < P; ++i) map_out[c->perm[i]] = h_maps[i];
+    lap("results to the caller's order");
     c->stats.evals_last = (uint64_t)P * c->n;
     c->stats.bytes_last = (uint64_t)tiles * c->n * 24ull + (uint64_t)P * sizeof(nhdfit_req) + (uint64_t)P * 8ull;
     c->stats.nodes = c->n; c->stats.nsig = c->nsig; c->stats.ncls = c->ncls; c->stats.lds_bytes = c->lds_bytes;

@@ -73,11 +73,16 @@ NHD_HD WideFree wide_free(const nhdfit_wide_node& n) {
     f.smt = (n.flags & NHDFIT_NF_SMT) != 0;
     for (uint32_t u = 0; u < (uint32_t)kWideU; ++u) { f.c[u] = 0; f.g[u] = 0; }
     const uint32_t cpp = n.cores_per_proc;
-    for (uint32_t u = 0; u < f.U; ++u)
-        for (uint32_t b = 0; b < cpp; ++b) {
-            const uint32_t c = u * cpp + b;
-            if (wide_bit(n.t0, c) && wide_bit(n.t1, c)) f.c[u]++;
+    for (uint32_t u = 0; u < f.U; ++u) {             // cores [u * cpp, (u + 1) * cpp) of the flat bitmaps, word by word
+        const uint32_t lo = u * cpp, hi = lo + cpp;
+        for (uint32_t w = lo >> 6; w < (uint32_t)NHDFIT_WIDE_CORE_WORDS && w * 64u < hi; ++w) {
+            uint64_t m = n.t0[w] & n.t1[w];
+            const uint32_t s = w * 64u;
+            if (lo > s) m &= ~0ull << (lo - s);
+            if (hi < s + 64u) m &= ~0ull >> (s + 64u - hi);
+            f.c[u] += (uint32_t)popc64(m);
         }
+    }
     for (uint32_t x = 0; x < n.n_gpus; ++x)
         if ((n.gpu_free >> x & 1u) && n.gpu_numa[x] < f.U) f.g[n.gpu_numa[x]]++;
     return f;
@@ -390,8 +395,12 @@ NHD_HD bool wide_fits(const nhdfit_wide_node& n, const R& r, bool busy, const Wi
         for (uint32_t u = 0; u < U; ++u) { have_g += f.g[u]; have_c += f.c[u]; }
         if (need_g > have_g || need_c > have_c) return false;
         uint32_t tg[kWideU] = {need_g, 0, 0, 0}, tc[kWideU] = {need_c - misc, 0, 0, 0};       // code 0: every group on NUMA node 0
+        // (on two NUMA nodes every assignment has its own pair of sets: nothing to remember - the searches are asked directly, and the
+        // kilobyte of answers is neither cleared nor carried)
+        const bool remember = U > 2;
+        const bool separable = remember ? true : nic_separable(n, r);
         NicMemo memo;
-        nic_memo_init(memo, n, r);
+        if (remember) nic_memo_init(memo, n, r);
         for (uint32_t code = 0; code < nG; ++code) {
             bool ok = true;
             for (uint32_t u = 0; u < U; ++u) ok = ok && tg[u] <= f.g[u];                         // GPU stage, Matcher.py:120-131
@@ -405,7 +414,7 @@ NHD_HD bool wide_fits(const nhdfit_wide_node& n, const R& r, bool busy, const Wi
                 ok = cpu;
             }
             if (ok) {
-                if (nic_stage_ok(memo, n, r, caps, code, ns)) return true;
+                if (remember ? nic_stage_ok(memo, n, r, caps, code, ns) : nic_stage_ok_plain(separable, n, r, caps, code, ns)) return true;
                 if (ns && ns->exhausted) return false;
             }
             for (int g = (int)G - 1; g >= 0; --g) {                                               // next tuple

@@ -225,23 +225,6 @@ def wave_big_map(packer, table, v, big_req, wide=None, share=None):
     return int(rc), (int(rcs[0]), int(rcs[1])), ms, mw
 
 
-def wave_big_fits(packer, table, v, big_req, busy=False, budget=1 << 22, wide=None, share=None):
-    """feasible(node, pod) for a big request on node `v` of `table` (or the wide record `wide`): wide_core.h wide_fits (one thread) against
-    big_kernel.h wide_fits_wave (lane = assignment, emulated lanes).  (return code of we_big_fits, (feasible, exhausted, steps) of one thread,
-    the same of the wavefront)."""
-    L = wave_lib()
-    caps = _dict_args(packer)[0]
-    req = np.ascontiguousarray(big_req)
-    rows = [np.ascontiguousarray(getattr(table, f)[v:v + 1]) for f in ("p0", "p1", "p2", "p3", "p4", "detail")]
-    out = (ctypes.c_int * 6)(*([0] * 6))
-    w = None if wide is None else np.ascontiguousarray(wide, dtype=pack.WIDE).reshape(-1)[:1]
-    sh_arr, sh_ptr = _share_arg(share, 1) if share is not None else (None, None)
-    L.we_big_fits.restype = ctypes.c_int
-    rc = L.we_big_fits(*[_p(x) for x in rows], None if w is None else _p(w), _p(req), _p(caps), sh_ptr, ctypes.c_int(1 if busy else 0),
-                       ctypes.c_uint32(int(budget)), out)
-    return int(rc), tuple(out[:3]), tuple(out[3:])
-
-
 def wave_commit(packer, table, i, req, mapping, busy_time, form=1):
     """commit() above through the WAVEFRONT form of the commit step (commit_node_wave, emulated lanes); `table` modified in place.
     form=2: the two-stage form of k_decide's speculators for a pod without GPUs (commit_summary_wave, then commit_picks_wave)."""

@@ -229,33 +229,4 @@ int we_big_map(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_pl
     return std::memcmp(&ms, &mw[0], sizeof ms) == 0 ? 0 : 1;
 }
 
-// feasible(node, pod) for a big request: wide_core.h wide_fits (one thread) against big_kernel.h wide_fits_wave (lane = assignment).
-// out[0..2] = one thread's (feasible, exhausted, steps), out[3..5] = the wavefront's.  Returns 0 when they agree, 1 otherwise, -100 if the lanes
-// disagree among themselves, -2 for a node of more than two NUMA nodes (the kernel keeps the one-thread walk there).
-int we_big_fits(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane2* p2, const nhdfit_plane3* p3, const nhdfit_plane4* p4,
-                const nhdfit_detail* det, const nhdfit_wide_node* wide, const nhdfit_big_req* r, const double* caps, const nhdfit_wide_share* share,
-                int busy, uint32_t budget, int* out) {
-    nhdfit_wide_node view;
-    if (wide) view = *wide; else wide_view(*p0, *p1, *p2, *p3, *p4, *det, 0, view);
-    if (view.numa_nodes > 2) return -2;
-    const WideCaps wc(caps, wide ? share : nullptr);
-    NicSearch ns{budget, false};
-    const bool ok_s = wide_fits(view, *r, busy != 0, wc, &ns);
-    out[0] = ok_s; out[1] = ns.exhausted; out[2] = (int)(budget - ns.left);
-    static uint32_t steps[emu::kLanes];
-    bool ok_w[emu::kLanes], ex_w[emu::kLanes];
-    uint32_t sp_w[emu::kLanes];
-    emu::acc[0] = emu::acc[1] = 0;
-    std::vector<std::thread> lanes;
-    for (int i = 0; i < emu::kLanes; ++i)
-        lanes.emplace_back([&, i] {
-            emu::t_lane = (uint32_t)i; emu::t_count = 0;
-            ok_w[i] = wide_fits_wave(view, *r, busy != 0, wc, budget, steps, (uint32_t)i, sp_w[i], ex_w[i]);
-        });
-    for (auto& th : lanes) th.join();
-    for (int i = 1; i < emu::kLanes; ++i) if (ok_w[i] != ok_w[0] || ex_w[i] != ex_w[0] || sp_w[i] != sp_w[0]) return -100;
-    out[3] = ok_w[0]; out[4] = ex_w[0]; out[5] = (int)sp_w[0];
-    return (out[0] == out[3] && out[1] == out[4] && out[2] == out[5]) ? 0 : 1;
-}
-
 }  // extern "C"

@@ -199,35 +199,3 @@ def test_big_mapping_lane_per_tuple_on_wide_records_of_two_sockets(seed):
     k4 = next(k for k in range(len(wide)) if int(wide[k]["numa_nodes"]) > 2)
     assert harness.wave_big_map(m.packer, m.engine.table, 0, big[0], wide=wide[k4:k4 + 1])[0] == -2
     assert agreed and mapped >= 1
-
-
-@pytest.mark.parametrize("seed", range(6))
-def test_big_feasibility_lane_per_assignment_equals_the_one_thread_walk(seed):
-    """k_big_eval's wavefront form for one node - lane = assignment, a ballot finds the first one that passes, the search steps summed in
-    assignment order up to it - against wide_fits: verdict, budget verdict and step count (the statistic nhdfit_stats reports) on every
-    node of a random cluster, busy or not, with the call's budget and with budgets small enough to run out in the middle of the walk."""
-    from tests.test_big_core import big_spec, host_matcher
-    nl = util.random_cluster(49000 + seed, 36, occupancy=0.2 if seed % 2 else 0.0)
-    rng = np.random.default_rng(970 + seed)
-    tops = [refmodel.make_topology(big_spec(rng, 5, 8)) for _ in range(8)]
-    m = host_matcher()
-    m.FindNodes(nl, tops[:1])
-    big = np.array([m.packer.digest_big(t) for t in tops], dtype=pack.BIG_REQ)
-    fits, _, _ = harness.big_eval(m.packer, m.engine.table, m.engine._wide_records(), big, util.CLOCK)
-    yes = ran_out = searched = 0
-    for p in range(len(tops)):
-        for v in range(len(nl)):
-            rc, one, wave = harness.wave_big_fits(m.packer, m.engine.table, v, big[p])
-            assert rc == 0, (p, v, one, wave)
-            yes += one[0]
-            searched += one[2] > 0
-            if one[2] > 1:                                              # a budget that runs out inside this pair's walk, and one that just suffices
-                for budget in (1, one[2] // 2, one[2] - 1, one[2]):
-                    rc, o2, w2 = harness.wave_big_fits(m.packer, m.engine.table, v, big[p], budget=budget)
-                    assert rc == 0, (p, v, budget, o2, w2)
-                    ran_out += o2[1]
-            if v % 7 == 0:
-                rc, o3, w3 = harness.wave_big_fits(m.packer, m.engine.table, v, big[p], busy=True)
-                assert rc == 0, (p, v, o3, w3)
-    assert yes >= 3 and searched >= 10 and ran_out >= 5
-    assert yes >= int(fits[:len(nl)].sum())                             # (big_eval adds the busy clock's verdict; never more feasible pairs than here)
