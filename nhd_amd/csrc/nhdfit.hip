@@ -756,9 +756,18 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     if (!c) return NHDFIT_E_INVAL;
     if (!reqs || !P) return fail(c, NHDFIT_E_INVAL, "no requests");
     if (!c->nsig) return fail(c, NHDFIT_E_STATE, "set the dictionary first");
+    static const bool prof = tune_env("NHDFIT_FIND_PROF") != nullptr;      // tuning aid: host-side phase times of the staging
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!prof) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[nhdfit]   stage P=%u %s %.1f us\n", P, what, std::chrono::duration<double, std::micro>(t1 - t_prev).count());
+        t_prev = t1;
+    };
     HIPCHK(c, hipSetDevice(c->dev));
     { int rc_ = sync_all(c); if (rc_) return rc_; }
     { int rc_ = drain_events(c); if (rc_) return rc_; }
+    lap("streams idle, events read");
     for (Pipe& p : c->pipe) p.n_dig = p.n_fit = p.n_shaped = p.n_chosen = p.n_finished = 0;
     c->n_enq = 0;
     c->last_pipe = 0;
@@ -786,6 +795,7 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
             HIPCHK(c, p.score[b].reserve(P));
             HIPCHK(c, p.maps[b].reserve(P));
         }
+    lap("order, buffers");
     c->n_big_pods = seen.n_big;
     HIPCHK(c, c->pin_reqs.reserve(P));
     nhdfit_req* sorted = c->pin_reqs.p;                                   // (free again: sync_all above waited for the last copy out of it)
@@ -808,6 +818,7 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
             for (uint32_t i = lo; i < hi; ++i)
                 if (req_valid(sorted[i])) c->max_demand[w] = std::max(c->max_demand[w], req_max_demand(sorted[i]));
     }
+    lap("gather");
     HIPCHK(c, hipMemcpyAsync(c->reqs.p, sorted, (size_t)P * sizeof *reqs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->tile_wcls.reserve(tiles));
     HIPCHK(c, c->pin_wcls.reserve(tiles));
@@ -817,7 +828,9 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     c->hp_rows = (uint32_t)hp_max + 2;
     c->n_items = 0;                                 // the fit role's work items are rebuilt at the next step
     c->use_cand = false;
+    lap("copies enqueued");
     { int rc_ = refresh_layouts(c); if (rc_) return rc_; }
+    lap("layouts");
     // a node's C row depends on the pair table's dimension: a batch that changes it has the chunks' records dealt to the lanes again
     // (ensure_records, in front of the batch's first step) - a full tile and more only: smaller batches are latency, not throughput
     if (P > (uint32_t)kTile && (c->pair_D[0] != c->order_D[0] || c->pair_D[1] != c->order_D[1])) c->ord_all = true;
@@ -858,10 +871,10 @@ int ensure_records(nhdfit_ctx* c) {
     // dealing the records to the lanes pays where the fit role is more than a launch: from 128 chunks on
     const bool deal = c->lane_order && all_chunks >= 128;
     if (!c->rec_all && c->rec_lo == c->rec_hi) {
-        if (c->ord_all && c->n) {                               // the records stand, a staged batch changed the pair table's dimension
+        if (c->ord_all && c->n && deal) {                       // the records stand, a staged batch changed the pair table's dimension
             { int rc_ = sync_all(c); if (rc_) return rc_; }     // (steps in flight read the records)
             c->staged_gen++;
-            if (deal) { int rc_ = order_chunks(c, 0, all_chunks, true); if (rc_) return rc_; }
+            { int rc_ = order_chunks(c, 0, all_chunks, true); if (rc_) return rc_; }
         }
         c->ord_all = false;
         return NHDFIT_OK;
@@ -1608,7 +1621,8 @@ int find_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     FindNArgs a;
     memset(&a, 0, sizeof a);
     a.s.shapes_P = P;
-    const uint32_t wc_parts = 2u;                               // (as the fused step's digest: two blocks per tile for the CPU rows)
+    static const uint32_t wc_env = tune_env("NHDFIT_FIND_WC_PARTS") && atoi(tune_env("NHDFIT_FIND_WC_PARTS")) >= 1 ? (uint32_t)atoi(tune_env("NHDFIT_FIND_WC_PARTS")) : 0u;   // tuning aid
+    const uint32_t wc_parts = wc_env ? wc_env : kWcPartsDefault;   // (the digest is on the call's critical path here: the CPU rows cut four ways, as the one-tile find cuts them)
     fill_digest_args(c, p, 0, wc_parts, 1u, a.s.digest);
     a.dig_parts = 1u + wc_parts;
     a.s.nb_digest = tiles * a.dig_parts;
