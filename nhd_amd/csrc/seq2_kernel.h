@@ -552,14 +552,22 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
             if (ticket >= q.queue_len) return;
             unsigned long long item = 0;
+            // (relaxed polls, ONE acquire behind the match: an acquire per poll is an L1 invalidate per poll - microseconds each, and a
+            // hundred idle pollers doing it take a good part of the chip's bandwidth from the block that decides)
             for (uint32_t spin = 0;; ++spin) {
-                item = __hip_atomic_load(&q.queue[ticket], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                item = __hip_atomic_load(&q.queue[ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (item) break;
-                const uint32_t fin = dev_load(&q.ctrl[1]);
-                if (fin && ticket >= fin - 1u) return;                    // block 0 is through and never wrote this entry
+                const uint32_t fin = __hip_atomic_load(&q.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fin && ticket >= fin - 1u) {                          // block 0 is through: did it write this entry before it said so?
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    item = __hip_atomic_load(&q.queue[ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (item) break;
+                    return;
+                }
                 if (spin > kSpinLimit) { if (lane == 0) q.flags[3] = 1u; return; }   // the entry for this ticket may still come: the host must not trust the batch (it undoes it and runs k_seq)
                 __builtin_amdgcn_s_sleep(16);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const uint32_t v = (uint32_t)item;
             NodeState& st = s_wst[wave];
             nhdfit_detail& dd = s_wdet[wave];
@@ -1001,11 +1009,12 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 lap(6);
                 if (status == kCommitNewSig && lane == 0) q.flags[1] = 1u;
                 // the mirror takes version ver + 1 behind version ver (whose writer may still be in its own stage 2)
-                for (uint32_t spin = 0; ver != 0 && (dev_load(&q.mat[v]) & ~kPubPoison) < ver && !stop; ++spin) {
+                for (uint32_t spin = 0; ver != 0 && (__hip_atomic_load(&q.mat[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~kPubPoison) < ver && !stop; ++spin) {
                     if (spin > kSpinLimit) give_up();
                     if (wg_load(&s_abort)) stop = true;
                     __builtin_amdgcn_s_sleep(1);
                 }
+                if (ver != 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (one acquire behind the match, not one per poll)
                 if (stop) break;
                 if (!(kTuning && (q.dbg & 4))) {
                     if (lane < sizeof(SeqResult) / 4) reinterpret_cast<uint32_t*>(&a.out[mine])[lane] = reinterpret_cast<const uint32_t*>(&res)[lane];
