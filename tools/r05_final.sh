@@ -58,3 +58,10 @@ grep -A12 "k_step" $OUT/pmc_summary.txt | head -60
 # the per-counter directories hold every dispatch: keep the summaries only (gpurun_out is capped)
 rm -rf $OUT/pmc_*/ $ST
 timeout 200 python tools/time_single_find.py > $OUT/single_find_latency.json 2>/dev/null; tail -c 900 $OUT/single_find_latency.json
+# the whole-batch call (nhdfit_find: one launch) on the BASELINE shapes, and the general path for requests under the kernel trace
+timeout 200 python tools/time_batch_find.py "4:65536:4096,2:0:0,3:0:0,5:32768:2048,5:32768:16384" > $OUT/batch_find_latency.json 2>/dev/null; cat $OUT/batch_find_latency.json
+BP=$OUT/bigprof; rm -rf $BP; mkdir -p $BP
+(cd /tmp && export TMPDIR=/tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $BP -o big -- python $ROOT/tools/time_big_find.py > $OUT/big_find_latency.json 2> $BP/err.log)
+find $BP -name "*kernel_stats.csv" -exec cp {} $OUT/big_kernel_stats.csv \;
+head -5 $OUT/big_kernel_stats.csv | cut -c1-200; cut -c1-900 $OUT/big_find_latency.json
+rm -rf $BP
