@@ -725,14 +725,21 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
 
     if (wave != 0 && spec_id < 0) {
         // ---- fetchers: pod e (with GPUs) goes to slot e % kDecideRing once the sequencer is past pod e - kDecideRing.  A fetcher takes
-        // 64 list entries with one load and then eight pods at a time: their first windows are requested together (one round trip
+        // kFetchChunk list entries with one load and then eight pods at a time: their first windows are requested together (one round trip
         // for eight pods, the next eight requested before these are parked), masked with what is taken by the time each is parked
         const uint32_t first_all = 4u * (uint32_t)kSpecWaves / 3u;        // wavefronts from here on all fetch; below, those with wave & 3 == 0
         const uint32_t fid = wave < first_all ? (wave >> 2) - 1u : first_all / 4u - 1u + (wave - first_all);     // 0 .. kFetchWaves - 1
         constexpr uint32_t kFetchBatch = 8;
+#ifndef NHDFIT_FETCH_CHUNK
+#define NHDFIT_FETCH_CHUNK 16
+#endif
+        // consecutive list entries per fetcher: the ring holds kDecideRing pods, so with 64 entries per fetcher the sequencer is served by
+        // one fetcher at a time (the others are a ring ahead and wait); 16 keeps four of them inside the ring
+        constexpr uint32_t kFetchChunk = NHDFIT_FETCH_CHUNK;
+        static_assert(kFetchChunk <= 64 && kFetchChunk % (2 * kFetchBatch) == 0, "two batches of eight in flight per chunk");
         struct Batch { uint32_t e[kFetchBatch], pos[kFetchBatch], from[kFetchBatch]; uint64_t w[kFetchBatch]; };
-        for (uint32_t j0 = fid * 64u; j0 < q.n_g; j0 += kFetchWaves * 64u) {
-            const uint32_t cnt = q.n_g - j0 < 64u ? q.n_g - j0 : 64u;
+        for (uint32_t j0 = fid * kFetchChunk; j0 < q.n_g; j0 += kFetchWaves * kFetchChunk) {
+            const uint32_t cnt = q.n_g - j0 < kFetchChunk ? q.n_g - j0 : kFetchChunk;
             uint4 ent = make_uint4(0, 0, kNoNode, 0);
             if (lane < cnt) ent = q.ent_g[j0 + lane];
             // entries k0 .. k0 + 7: their first windows requested (one load instruction each, all in flight together)
