@@ -163,6 +163,7 @@ struct nhdfit_ctx {
     Pipe pipe[kPipes];
     hipStream_t stream = nullptr;        // = pipe[0].stream: uploads, deltas, commits, mode B, single finds
     hipStream_t s_red = nullptr;         // the all-reduce of sharded runs, overlapping the next step launch
+    bool side_streams_used = true;       // something was enqueued on a pipe other than the first, or on s_red, since sync_all last waited for them
     bool dual = tune_env("NHDFIT_ONE_PIPE") == nullptr;   // tuning aid: NHDFIT_ONE_PIPE=1 keeps every step on pipe 0
     uint64_t n_enq = 0;                  // steps enqueued since the last stage_requests (step k runs on pipe k % 2)
     int last_pipe = 0;                   // the pipe of the most recent step (nhdfit_fetch reads its results)
@@ -353,8 +354,13 @@ int refresh_layouts(nhdfit_ctx* c);
 
 int sync_all(nhdfit_ctx* c) {
     { int rc_ = flush_pipeline(c); if (rc_) return rc_; }      // pending mapping phases of the last steps
-    for (Pipe& p : c->pipe) HIPCHK(c, wait_stream(p.stream));
-    HIPCHK(c, wait_stream(c->s_red));
+    // the other pipes' streams and the reduce stream only ever carry the steps of a staged batch (launch_step, flush_pipeline) and calls
+    // that wait for their own work: nothing was put on them since the last wait here -> nothing to ask (a query of an idle stream is ~3 us,
+    // four of them were a tenth of a small nhdfit_find)
+    for (Pipe& p : c->pipe)
+        if (&p == &c->pipe[0] || c->side_streams_used) HIPCHK(c, wait_stream(p.stream));
+    if (c->side_streams_used) HIPCHK(c, wait_stream(c->s_red));
+    c->side_streams_used = false;
     return NHDFIT_OK;
 }
 
@@ -805,6 +811,8 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     c->h_tile_wcls.assign(tiles, 0);
     c->max_wcls = 0;
     c->max_demand[0] = c->max_demand[1] = 0;
+    const uint32_t piece = (tiles + 3) / 4;
+    uint32_t sent = 0;
     for (uint32_t t = 0; t < tiles; ++t) {
         const uint32_t lo = t * kTile, hi = std::min(P, lo + (uint32_t)kTile);
         uint8_t w = 0;
@@ -817,9 +825,14 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
         if (w < 2)
             for (uint32_t i = lo; i < hi; ++i)
                 if (req_valid(sorted[i])) c->max_demand[w] = std::max(c->max_demand[w], req_max_demand(sorted[i]));
+        // a large batch travels in four pieces: a piece's transfer (512 KB at config 4: ~20 us on the link) runs while the next is gathered
+        if (tiles >= 16 && ((t + 1) % piece == 0 || t + 1 == tiles)) {
+            HIPCHK(c, hipMemcpyAsync(c->reqs.p + sent, sorted + sent, (size_t)(hi - sent) * sizeof *reqs, hipMemcpyHostToDevice, c->stream));
+            sent = hi;
+        }
     }
     lap("gather");
-    HIPCHK(c, hipMemcpyAsync(c->reqs.p, sorted, (size_t)P * sizeof *reqs, hipMemcpyHostToDevice, c->stream));
+    if (sent < P) HIPCHK(c, hipMemcpyAsync(c->reqs.p + sent, sorted + sent, (size_t)(P - sent) * sizeof *reqs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->tile_wcls.reserve(tiles));
     HIPCHK(c, c->pin_wcls.reserve(tiles));
     memcpy(c->pin_wcls.p, c->h_tile_wcls.data(), tiles);
@@ -1069,6 +1082,7 @@ void fill_fit_args(nhdfit_ctx* c, Pipe& p, int bf, double now, FitArgs& f, bool 
 // One launch of the step kernel with every role that has work (see k_step).  `with_fit`: the fit role for step
 // n_fit plus the digest of step n_fit + 1; `flushing`: nothing new will follow, drain the mapping phases.
 int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double now, bool flushing) {
+    c->side_streams_used = true;
     const uint32_t P = c->P, tiles = (P + kTile - 1) / kTile;
     const uint32_t chunks = (c->n + 63) / 64;
     const bool big = c->geom_big;
@@ -1285,6 +1299,7 @@ int flush_pipeline(nhdfit_ctx* c) {
                 if (c->comm) HIPCHK(c, hipStreamWaitEvent(p.stream, p.ev_red[b], 0));      // the step's scores are final behind its all-reduce
                 a.m[a.nsteps++] = make_map_args(c, p, b);
             }
+            c->side_streams_used = true;
             hipLaunchKernelGGL(k_map_tiles, dim3(a.nsteps * tiles), dim3(256), map_tile_lds_bytes<256>(), p.stream, a);
             HIPCHK(c, hipGetLastError());
             p.n_finished += a.nsteps;
@@ -1349,6 +1364,7 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
     if (!c) return NHDFIT_E_INVAL;
     Pipe& p = c->pipe[c->last_pipe];
     if (!c->P || !p.n_fit) return fail(c, NHDFIT_E_STATE, "nothing staged / no step enqueued");
+    c->side_streams_used = true;                                // (the copies below ride the last step's pipe)
     HIPCHK(c, hipSetDevice(c->dev));
     if (map_out && !c->want_map) return fail(c, NHDFIT_E_STATE, "mapping output is disabled");
     const uint32_t P = c->P;
