@@ -265,6 +265,7 @@ struct nhdfit_ctx {
     DevBuf<uint32_t> findn_sync; uint32_t findn_sync_words = 0;
     DevBuf<uint32_t> tile_items; std::vector<uint32_t> h_tile_items;   // fit items per staged tile (build_items)
     bool batch_find = tune_env("NHDFIT_NO_BATCH_FIND") == nullptr;   // tuning aid: batches of more than one tile through the staged path
+    bool reqs_deferred = false, wcls_deferred = false;   // the staged batch's request records / tile classes are in the page-locked block only (finish_deferred_copies)
     bool lone_pod = tune_env("NHDFIT_NO_LONE_POD") == nullptr;      // one pod: the table-free launch (k_find1); tuning aid: NHDFIT_NO_LONE_POD=1 takes k_find
 
     // nodes beyond the fast layout (wide_core.h): records sorted by index; the device copy is the truth once commits ran on it
@@ -758,8 +759,28 @@ void staged_order(const nhdfit_req* reqs, uint32_t P, std::vector<uint32_t>& per
 }
 }  // namespace
 
+namespace {
+// What the staging leaves in page-locked host memory goes to the device by copy commands - one per array, and every command costs the
+// copy engine ~10 us before its first byte moves.  The single-launch find of a batch reads the small arrays (tile classes, work items)
+// straight from the host block and, for a batch of a few tiles, the request records too; the copies it skipped are made up for here
+// when the call takes the steps' path after all.
+int stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, bool defer_small_copies, bool defer_request_copy);
+int finish_deferred_copies(nhdfit_ctx* c) {
+    const uint32_t tiles = (c->P + kTile - 1) / kTile;
+    if (c->reqs_deferred) HIPCHK(c, hipMemcpyAsync(c->reqs.p, c->pin_reqs.p, (size_t)c->P * sizeof(nhdfit_req), hipMemcpyHostToDevice, c->stream));
+    if (c->wcls_deferred) HIPCHK(c, hipMemcpyAsync(c->tile_wcls.p, c->pin_wcls.p, tiles, hipMemcpyHostToDevice, c->stream));
+    c->reqs_deferred = c->wcls_deferred = false;
+    return NHDFIT_OK;
+}
+}  // namespace
+
 int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     if (!c) return NHDFIT_E_INVAL;
+    return stage_requests(c, reqs, P, false, false);
+}
+
+namespace {
+int stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, bool defer_small_copies, bool defer_request_copy) {
     if (!reqs || !P) return fail(c, NHDFIT_E_INVAL, "no requests");
     if (!c->nsig) return fail(c, NHDFIT_E_STATE, "set the dictionary first");
     static const bool prof = tune_env("NHDFIT_FIND_PROF") != nullptr;      // tuning aid: host-side phase times of the staging
@@ -811,8 +832,6 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     c->h_tile_wcls.assign(tiles, 0);
     c->max_wcls = 0;
     c->max_demand[0] = c->max_demand[1] = 0;
-    const uint32_t piece = (tiles + 3) / 4;
-    uint32_t sent = 0;
     for (uint32_t t = 0; t < tiles; ++t) {
         const uint32_t lo = t * kTile, hi = std::min(P, lo + (uint32_t)kTile);
         uint8_t w = 0;
@@ -825,18 +844,17 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
         if (w < 2)
             for (uint32_t i = lo; i < hi; ++i)
                 if (req_valid(sorted[i])) c->max_demand[w] = std::max(c->max_demand[w], req_max_demand(sorted[i]));
-        // a large batch travels in four pieces: a piece's transfer (512 KB at config 4: ~20 us on the link) runs while the next is gathered
-        if (tiles >= 16 && ((t + 1) % piece == 0 || t + 1 == tiles)) {
-            HIPCHK(c, hipMemcpyAsync(c->reqs.p + sent, sorted + sent, (size_t)(hi - sent) * sizeof *reqs, hipMemcpyHostToDevice, c->stream));
-            sent = hi;
-        }
     }
     lap("gather");
-    if (sent < P) HIPCHK(c, hipMemcpyAsync(c->reqs.p + sent, sorted + sent, (size_t)(P - sent) * sizeof *reqs, hipMemcpyHostToDevice, c->stream));
+    // ONE copy: the batch in four pieces, each piece's transfer beside the next piece's gather, was measured and is slower - every copy
+    // command costs the copy engine ~10 us before its first byte moves (config 4: 0.166 -> 0.193 ms per call, profiles/r05)
+    c->reqs_deferred = defer_request_copy;
+    if (!defer_request_copy) HIPCHK(c, hipMemcpyAsync(c->reqs.p, sorted, (size_t)P * sizeof *reqs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->tile_wcls.reserve(tiles));
     HIPCHK(c, c->pin_wcls.reserve(tiles));
     memcpy(c->pin_wcls.p, c->h_tile_wcls.data(), tiles);
-    HIPCHK(c, hipMemcpyAsync(c->tile_wcls.p, c->pin_wcls.p, tiles, hipMemcpyHostToDevice, c->stream));
+    c->wcls_deferred = defer_small_copies;
+    if (!defer_small_copies) HIPCHK(c, hipMemcpyAsync(c->tile_wcls.p, c->pin_wcls.p, tiles, hipMemcpyHostToDevice, c->stream));
     c->P = P;
     c->hp_rows = (uint32_t)hp_max + 2;
     c->n_items = 0;                                 // the fit role's work items are rebuilt at the next step
@@ -849,6 +867,7 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
     if (P > (uint32_t)kTile && (c->pair_D[0] != c->order_D[0] || c->pair_D[1] != c->order_D[1])) c->ord_all = true;
     return NHDFIT_OK;
 }
+}  // namespace
 
 static int stage_cand(nhdfit_ctx* c, const uint64_t* cand) {
     const size_t chunks = (c->n + 63) / 64;
@@ -1017,14 +1036,12 @@ int build_items(nhdfit_ctx* c, uint32_t nw, bool batch_find = false) {
     // upload_nodes, set_node_count all sync first), so the previous copy out of this buffer is long done
     HIPCHK(c, c->pin_items.reserve(items.size() * sizeof(FitItem) + (size_t)tiles * sizeof(uint32_t) + 1));
     memcpy(c->pin_items.p, items.data(), items.size() * sizeof(FitItem));
-    HIPCHK(c, hipMemcpyAsync(c->items.p, c->pin_items.p, items.size() * sizeof(FitItem), hipMemcpyHostToDevice, c->stream));
-    if (batch_find) {                                           // how many tickets each tile's last block waits for
-        uint32_t* per_tile = reinterpret_cast<uint32_t*>(c->pin_items.p + items.size() * sizeof(FitItem));
+    if (batch_find) {                                           // (k_findn reads the list where it is: no copy command in front of the launch)
+        uint32_t* per_tile = reinterpret_cast<uint32_t*>(c->pin_items.p + items.size() * sizeof(FitItem));   // how many tickets each tile's last block waits for
         for (uint32_t t = 0; t < tiles; ++t) per_tile[t] = 0;
         for (const FitItem& it : items) per_tile[it.tile]++;
-        HIPCHK(c, c->tile_items.reserve(tiles));
-        HIPCHK(c, hipMemcpyAsync(c->tile_items.p, per_tile, (size_t)tiles * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    }
+    } else
+        HIPCHK(c, hipMemcpyAsync(c->items.p, c->pin_items.p, items.size() * sizeof(FitItem), hipMemcpyHostToDevice, c->stream));
     c->n_items = (uint32_t)items.size();
     c->staged_gen++;
     return NHDFIT_OK;
@@ -1601,13 +1618,18 @@ int find_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
         fprintf(stderr, "[nhdfit] batch find P=%u %s %.1f us\n", P, what, std::chrono::duration<double, std::micro>(t1 - t_prev).count());
         t_prev = t1;
     };
-    int rc = nhdfit_stage_requests(c, reqs, P);                 // (sorted into tiles, on their way to the device; the layouts are the batch's)
+    // sorted into tiles in the page-locked block.  What the launch reads once per block - tile classes, work items - it reads there; the
+    // request records of a FEW tiles too (five digest blocks and the mapping read a tile's 8 KB over the link: cheaper than a copy
+    // command's ~10 us up to a few hundred pods, dearer than the copy beyond)
+    const bool host_reqs = P <= 512u;
+    int rc = stage_requests(c, reqs, P, true, host_reqs);
     if (rc) return rc;
     lap("stage");
-    if (c->n_big_pods) return 2;                                // four-group pods: their set model is a kernel of its own
+    auto to_steps = [&]() { const int r2 = finish_deferred_copies(c); return r2 ? r2 : 2; };
+    if (c->n_big_pods) return to_steps();                       // four-group pods: their set model is a kernel of its own
     if (cand && (rc = stage_cand(c, cand))) return rc;
     if ((rc = ensure_records(c))) return rc;
-    if (c->x_spill) return 2;
+    if (c->x_spill) return to_steps();
     constexpr uint32_t nw = 4;                                  // 256-thread blocks: a tile's pods are one wavefront of the mapping tail
     if ((rc = build_items(c, nw, true))) return rc;
     const uint32_t tiles = (P + kTile - 1) / kTile, chunks = (c->n + 63) / 64;
@@ -1640,17 +1662,21 @@ int find_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     static const uint32_t wc_env = tune_env("NHDFIT_FIND_WC_PARTS") && atoi(tune_env("NHDFIT_FIND_WC_PARTS")) >= 1 ? (uint32_t)atoi(tune_env("NHDFIT_FIND_WC_PARTS")) : 0u;   // tuning aid
     const uint32_t wc_parts = wc_env ? wc_env : kWcPartsDefault;   // (the digest is on the call's critical path here: the CPU rows cut four ways, as the one-tile find cuts them)
     fill_digest_args(c, p, 0, wc_parts, 1u, a.s.digest);
+    if (host_reqs) a.s.digest.reqs = c->pin_reqs.p;
     a.dig_parts = 1u + wc_parts;
     a.s.nb_digest = tiles * a.dig_parts;
     a.nb_lead = (a.s.nb_digest + 7u) & ~7u;
     fill_fit_args(c, p, 0, now, a.s.fit, true);
     a.s.fit.nm = nullptr; a.s.fit.dbg_skip = 0;                 // (no verdict matrix in this form)
     a.s.nb_fit = c->n_items;
+    a.s.fit.items = reinterpret_cast<const FitItem*>(c->pin_items.p);
     a.s.finish_m = make_map_args(c, p, 0);
     a.s.finish_m.out = h_maps;
+    if (host_reqs) a.s.finish_m.reqs = c->pin_reqs.p;
     a.s.finish_h = make_shape_args(c, p, 0);
     a.want_map = map_out ? 1u : 0u; a.tiles = tiles;
-    a.tile_wcls = c->tile_wcls.p; a.tile_items = c->tile_items.p;
+    a.tile_wcls = c->pin_wcls.p;
+    a.tile_items = reinterpret_cast<const uint32_t*>(c->pin_items.p + (size_t)c->n_items * sizeof(FitItem));
     a.sync = c->findn_sync.p; a.host_score = h_score; a.host_flag = h_flag; a.seq = seq;
     size_t lds = lds_slice(c->lds_bytes) + (size_t)nw * 64 * sizeof(unsigned long long);
     lds = std::max(lds, std::max(kDigestLds, map_tile_lds_bytes<256>()));
@@ -1675,7 +1701,7 @@ int find_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
         HIPCHK(c, hipMemsetAsync(c->findn_sync.p, 0, (size_t)c->findn_sync_words * sizeof(uint32_t), c->stream));
         *h_flag = 0;
         c->n_items = 0;                                         // (the step's own work items: 512-thread blocks)
-        return 2;
+        return to_steps();
     }
     lap("poll");
     if (score_out) for (uint32_t i = 0; i < P; ++i) score_out[c->perm[i]] = h_score[i];
