@@ -764,7 +764,7 @@ namespace {
 // copy engine ~10 us before its first byte moves.  The single-launch find of a batch reads the small arrays (tile classes, work items)
 // straight from the host block and, for a batch of a few tiles, the request records too; the copies it skipped are made up for here
 // when the call takes the steps' path after all.
-int stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, bool defer_small_copies, bool defer_request_copy);
+int stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, bool defer_small_copies, bool defer_request_copy, size_t tail_bytes = 0);
 int finish_deferred_copies(nhdfit_ctx* c) {
     const uint32_t tiles = (c->P + kTile - 1) / kTile;
     if (c->reqs_deferred) HIPCHK(c, hipMemcpyAsync(c->reqs.p, c->pin_reqs.p, (size_t)c->P * sizeof(nhdfit_req), hipMemcpyHostToDevice, c->stream));
@@ -780,7 +780,7 @@ int nhdfit_stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P) {
 }
 
 namespace {
-int stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, bool defer_small_copies, bool defer_request_copy) {
+int stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, bool defer_small_copies, bool defer_request_copy, size_t tail_bytes) {
     if (!reqs || !P) return fail(c, NHDFIT_E_INVAL, "no requests");
     if (!c->nsig) return fail(c, NHDFIT_E_STATE, "set the dictionary first");
     static const bool prof = tune_env("NHDFIT_FIND_PROF") != nullptr;      // tuning aid: host-side phase times of the staging
@@ -810,7 +810,8 @@ int stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, bool defer
     const int32_t hp_max = seen.hp_max;
     if (hp_max > kMaxHpRows - 2)
         return fail(c, NHDFIT_E_LIMIT, "a pod asks for %d GiB of hugepages (limit %d)", hp_max, kMaxHpRows - 2);
-    HIPCHK(c, c->reqs.reserve(P));
+    const size_t tail_records = (tail_bytes + sizeof(nhdfit_req) - 1) / sizeof(nhdfit_req);   // (room behind the records for what rides the same copy)
+    HIPCHK(c, c->reqs.reserve((size_t)P + tail_records));
     for (Pipe& p : c->pipe)
         if (tiles > p.dig_count.cap) {                 // (the digest role leaves its arrival counters at zero: cleared when the buffer is new)
             HIPCHK(c, p.dig_count.reserve(std::max<size_t>(tiles, 256)));
@@ -824,7 +825,7 @@ int stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, bool defer
         }
     lap("order, buffers");
     c->n_big_pods = seen.n_big;
-    HIPCHK(c, c->pin_reqs.reserve(P));
+    HIPCHK(c, c->pin_reqs.reserve((size_t)P + tail_records));
     nhdfit_req* sorted = c->pin_reqs.p;                                   // (free again: sync_all above waited for the last copy out of it)
     // tile by tile: the records gathered into the page-locked block, then - while they are in the core's cache - the tile's row width
     // class (2^(largest group count among its valid pods) assignments: the digest role derives the same class from the same records)
@@ -1622,7 +1623,10 @@ int find_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     // request records of a FEW tiles too (five digest blocks and the mapping read a tile's 8 KB over the link: cheaper than a copy
     // command's ~10 us up to a few hundred pods, dearer than the copy beyond)
     const bool host_reqs = P <= 512u;
-    int rc = stage_requests(c, reqs, P, true, host_reqs);
+    const uint32_t tiles_ = (P + kTile - 1) / kTile;
+    // (a larger batch: the records, and behind them in the same block the work items, their per-tile counts and the tile classes - ONE copy command)
+    const size_t tail_cap = host_reqs ? 0 : ((size_t)tiles_ * 32 + 4096) * sizeof(FitItem) + (size_t)tiles_ * 8 + 64;
+    int rc = stage_requests(c, reqs, P, true, true, tail_cap);
     if (rc) return rc;
     lap("stage");
     auto to_steps = [&]() { const int r2 = finish_deferred_copies(c); return r2 ? r2 : 2; };
@@ -1662,21 +1666,35 @@ int find_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     static const uint32_t wc_env = tune_env("NHDFIT_FIND_WC_PARTS") && atoi(tune_env("NHDFIT_FIND_WC_PARTS")) >= 1 ? (uint32_t)atoi(tune_env("NHDFIT_FIND_WC_PARTS")) : 0u;   // tuning aid
     const uint32_t wc_parts = wc_env ? wc_env : kWcPartsDefault;   // (the digest is on the call's critical path here: the CPU rows cut four ways, as the one-tile find cuts them)
     fill_digest_args(c, p, 0, wc_parts, 1u, a.s.digest);
-    if (host_reqs) a.s.digest.reqs = c->pin_reqs.p;
     a.dig_parts = 1u + wc_parts;
     a.s.nb_digest = tiles * a.dig_parts;
     a.nb_lead = (a.s.nb_digest + 7u) & ~7u;
     fill_fit_args(c, p, 0, now, a.s.fit, true);
     a.s.fit.nm = nullptr; a.s.fit.dbg_skip = 0;                 // (no verdict matrix in this form)
     a.s.nb_fit = c->n_items;
-    a.s.fit.items = reinterpret_cast<const FitItem*>(c->pin_items.p);
     a.s.finish_m = make_map_args(c, p, 0);
     a.s.finish_m.out = h_maps;
-    if (host_reqs) a.s.finish_m.reqs = c->pin_reqs.p;
     a.s.finish_h = make_shape_args(c, p, 0);
     a.want_map = map_out ? 1u : 0u; a.tiles = tiles;
-    a.tile_wcls = c->pin_wcls.p;
-    a.tile_items = reinterpret_cast<const uint32_t*>(c->pin_items.p + (size_t)c->n_items * sizeof(FitItem));
+    const size_t items_bytes = (size_t)c->n_items * sizeof(FitItem), counts_bytes = (size_t)tiles * sizeof(uint32_t);
+    if (host_reqs || items_bytes + counts_bytes + tiles > tail_cap) {
+        // everything where the staging left it: the launch reads the page-locked block (few tiles: a few dozen reads over the link)
+        if (!host_reqs) { HIPCHK(c, hipMemcpyAsync(c->reqs.p, c->pin_reqs.p, (size_t)P * sizeof(nhdfit_req), hipMemcpyHostToDevice, c->stream)); c->reqs_deferred = false; }
+        else { a.s.digest.reqs = c->pin_reqs.p; a.s.finish_m.reqs = c->pin_reqs.p; }
+        a.s.fit.items = reinterpret_cast<const FitItem*>(c->pin_items.p);
+        a.tile_items = reinterpret_cast<const uint32_t*>(c->pin_items.p + items_bytes);
+        a.tile_wcls = c->pin_wcls.p;
+    } else {
+        uint8_t* tail_h = reinterpret_cast<uint8_t*>(c->pin_reqs.p + P);
+        const uint8_t* tail_d = reinterpret_cast<const uint8_t*>(c->reqs.p + P);
+        memcpy(tail_h, c->pin_items.p, items_bytes + counts_bytes);
+        memcpy(tail_h + items_bytes + counts_bytes, c->pin_wcls.p, tiles);
+        HIPCHK(c, hipMemcpyAsync(c->reqs.p, c->pin_reqs.p, (size_t)P * sizeof(nhdfit_req) + items_bytes + counts_bytes + tiles, hipMemcpyHostToDevice, c->stream));
+        c->reqs_deferred = false;
+        a.s.fit.items = reinterpret_cast<const FitItem*>(tail_d);
+        a.tile_items = reinterpret_cast<const uint32_t*>(tail_d + items_bytes);
+        a.tile_wcls = tail_d + items_bytes + counts_bytes;
+    }
     a.sync = c->findn_sync.p; a.host_score = h_score; a.host_flag = h_flag; a.seq = seq;
     size_t lds = lds_slice(c->lds_bytes) + (size_t)nw * 64 * sizeof(unsigned long long);
     lds = std::max(lds, std::max(kDigestLds, map_tile_lds_bytes<256>()));
