@@ -265,6 +265,7 @@ struct nhdfit_ctx {
     DevBuf<uint32_t> findn_sync; uint32_t findn_sync_words = 0;
     DevBuf<uint32_t> tile_items; std::vector<uint32_t> h_tile_items;   // fit items per staged tile (build_items)
     bool batch_find = tune_env("NHDFIT_NO_BATCH_FIND") == nullptr;   // tuning aid: batches of more than one tile through the staged path
+    PinBuf<uint32_t> pin_order; uint32_t tn_n = 0;   // mode B: [order | list] on their way to the device; pods without GPUs in the list
     bool reqs_deferred = false, wcls_deferred = false;   // the staged batch's request records / tile classes are in the page-locked block only (finish_deferred_copies)
     bool lone_pod = tune_env("NHDFIT_NO_LONE_POD") == nullptr;      // one pod: the table-free launch (k_find1); tuning aid: NHDFIT_NO_LONE_POD=1 takes k_find
 
@@ -474,7 +475,7 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     if (c->findn_host) (void)hipHostFree(c->findn_host);
     c->findn_host = nullptr; c->findn_cap = 0; c->findn_sync.release(); c->tile_items.release();
     c->find_host = nullptr; c->find_sync.release(); c->find_red.release();
-    c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
+    c->pin_order.release(); c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release(); c->sig_flat2.release();
     c->reqs.release(); c->bitmap.release(); c->rows_t.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); c->sig_use.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
     c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_queue.release(); c->seq_ctrl.release(); c->seq_mat.release(); c->seq_flags.release(); c->seq_tn.release(); c->seq_ent.release(); c->sig_keys.release(); c->sig_ids.release();
@@ -2125,31 +2126,54 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, c->undo.reserve(P));
         HIPCHK(c, c->seq_out.reserve(P));
         HIPCHK(c, c->seq_place.reserve(P));
-        HIPCHK(c, c->order.reserve(P));
         HIPCHK(c, c->seq_ctrl.reserve(32));
         HIPCHK(c, c->seq_ent.reserve(P));
         HIPCHK(c, c->seq_mat.reserve(c->n ? c->n : 1));
         HIPCHK(c, c->seq_flags.reserve(4));
-        HIPCHK(c, c->seq_tn.reserve(P));
-        c->order_host.resize(P);                              // caller's pod -> staged (class-sorted) position
-        for (uint32_t i = 0; i < P; ++i) c->order_host[c->perm[i]] = i;
-        HIPCHK(c, hipMemcpyAsync(c->order.p, c->order_host.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
+        // caller's pod -> staged (class-sorted) position, and behind it the decision engine's list [the pods without GPUs | every other
+        // pod] (caller's indices ascending): one page-locked block, ONE copy command (each costs the copy engine ~10 us; out of pageable
+        // memory the runtime stages it besides)
+        HIPCHK(c, c->order.reserve(2 * (size_t)P));
+        HIPCHK(c, c->pin_order.reserve(2 * (size_t)P));
+        uint32_t* order_h = c->pin_order.p;
+        uint32_t* tn_h = c->pin_order.p + P;
+        for (uint32_t i = 0; i < P; ++i) order_h[c->perm[i]] = i;
+        {
+            uint32_t at = 0;
+            c->tn_n = 0;
+            for (int pass = 0; pass < 2; ++pass) {
+                for (uint32_t i = 0; i < P; ++i) {
+                    uint32_t g = 0;
+                    const bool valid = req_valid(reqs[i]);
+                    if (valid) for (uint32_t k = 0; k < reqs[i].n_groups; ++k) g += reqs[i].gpus[k];
+                    if ((valid && g == 0) == (pass == 0)) tn_h[at++] = i;
+                }
+                if (pass == 0) c->tn_n = at;
+            }
+        }
+        HIPCHK(c, hipMemcpyAsync(c->order.p, order_h, 2 * (size_t)P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
         hipLaunchKernelGGL(k_nogpu, dim3(chunks), dim3(64), 0, sm, c->p2.p, c->n, c->nogpu.p);
         const int b0 = (int)((p.n_fit - 1) % kBufs);
         hipLaunchKernelGGL(k_tile_masks, dim3(tiles), dim3(64), 0, sm, p.hdr[b0].p, tiles, c->tile_masks.p);
         HIPCHK(c, hipGetLastError());
     }
     // pod-major verdict rows of the snapshot + empty taken / first-touch state (again before a fallback pass)
-    auto reset_scan_state = [&]() -> int {
+    // (one launch clears everything a pass starts from - seven fill commands in a row cost more than the fills: `engine` adds the
+    // decision engine's words)
+    uint32_t queue_len = 0;
+    auto reset_scan_state = [&](bool engine) -> int {
         int rc_ = convert_rows_t(c, p);
         if (rc_) return rc_;
-        HIPCHK(c, hipMemsetAsync(c->taken.p, 0, (size_t)(chunks ? chunks : 1) * sizeof(uint64_t), sm));
-        HIPCHK(c, hipMemsetAsync(c->touched.p, 0xFF, (size_t)c->n * sizeof(int32_t), sm));
-        HIPCHK(c, hipMemsetAsync(c->seq_counters.p, 0, 4 * sizeof(uint32_t), sm));
-        HIPCHK(c, hipMemsetAsync(c->seq_flags.p, 0, 4 * sizeof(uint32_t), sm));
+        SeqResetArgs ra;
+        memset(&ra, 0, sizeof ra);
+        ra.taken = c->taken.p; ra.chunks = chunks ? chunks : 1; ra.touched = c->touched.p; ra.n = c->n;
+        ra.counters = c->seq_counters.p; ra.flags = c->seq_flags.p;
+        if (engine) { ra.ctrl = c->seq_ctrl.p; ra.mat = c->seq_mat.p; ra.queue = c->seq_queue.p; ra.queue_len = queue_len; }
+        const uint32_t most = std::max(std::max(ra.chunks, ra.n), ra.queue_len);
+        hipLaunchKernelGGL(k_seq_reset, dim3(std::min<uint32_t>((most + 255) / 256, 1024u)), dim3(256), 0, sm, ra);
+        HIPCHK(c, hipGetLastError());
         return NHDFIT_OK;
     };
-    if ((rc = reset_scan_state())) return rc;
     const int b = (int)((p.n_fit - 1) % kBufs);
     SeqArgs sa;
     memset(&sa, 0, sizeof sa);
@@ -2205,38 +2229,24 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     uint32_t decided = 0;                                       // pods [0, decided) of the caller's order are decided
     // The decision engine (seq2_kernel.h) takes every batch its block 0 has the LDS for: two bit maps over the nodes, one entry per
     // GPU-less pod (the multiset of their commits), one bit per pod; the optional tables go in after those.
-    uint32_t n_gpu_less = 0;
-    for (uint32_t i = 0; i < P; ++i) {
-        uint32_t g = 0;
-        if (req_valid(reqs[i])) for (uint32_t k = 0; k < reqs[i].n_groups; ++k) g += reqs[i].gpus[k];
-        n_gpu_less += req_valid(reqs[i]) && g == 0;
-    }
+    const uint32_t n_gpu_less = c->tn_n;
     const uint32_t hash_slots = decide_hash_slots(n_gpu_less);
     const size_t dyn_base = 2 * lds_slice((size_t)chunks * 8) + lds_slice((size_t)hash_slots * 4) + lds_slice((size_t)((P + 31) / 32) * 4);
     bool fast = !c->seq_general && dyn_base <= 64 * 1024 && c->n > 0 && P < (1u << 26);
     if (fast) {
-        // The decision engine (seq2_kernel.h): one block decides, the rest of the grid commits.
-        HIPCHK(c, hipMemsetAsync(c->seq_ctrl.p, 0, 32 * sizeof(uint32_t), sm));
-        HIPCHK(c, hipMemsetAsync(c->seq_mat.p, 0, (size_t)c->n * sizeof(uint32_t), sm));
-        c->tn_host.resize(P);                                   // [the pods without GPUs | every other pod], caller's indices ascending
-        uint32_t n_n = 0, n_g = 0;
-        auto gpu_less = [&](uint32_t i) {
-            if (!req_valid(reqs[i])) return false;
-            uint32_t g = 0;
-            for (uint32_t k = 0; k < reqs[i].n_groups; ++k) g += reqs[i].gpus[k];
-            return g == 0;
-        };
-        for (uint32_t i = 0; i < P; ++i) if (gpu_less(i)) c->tn_host[n_n++] = i;
-        for (uint32_t i = 0; i < P; ++i) if (!gpu_less(i)) c->tn_host[n_n + n_g++] = i;
-        HIPCHK(c, hipMemcpyAsync(c->seq_tn.p, c->tn_host.data(), (size_t)P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
-        hipLaunchKernelGGL(k_decide_prep, dim3((P + 255) / 256), dim3(256), 0, sm, c->seq_tn.p, P, c->order.p, p.score[b].p, c->global_base, c->seq_ent.p);
-        HIPCHK(c, hipGetLastError());
-        const uint32_t queue_len = P * 4u;                      // a commit per pod + up to three patch items per commit of a GPU-less pod
+        queue_len = P * 4u;                                     // a commit per pod + up to three patch items per commit of a GPU-less pod
         HIPCHK(c, c->seq_queue.reserve(queue_len));
-        HIPCHK(c, hipMemsetAsync(c->seq_queue.p, 0, (size_t)queue_len * sizeof(unsigned long long), sm));
+    }
+    if ((rc = reset_scan_state(fast))) return rc;
+    if (fast) {
+        // The decision engine (seq2_kernel.h): one block decides, the rest of the grid commits.
+        const uint32_t* list_dev = c->order.p + P;              // [the pods without GPUs | every other pod] (uploaded behind the order)
+        const uint32_t n_n = c->tn_n, n_g = P - c->tn_n;
+        hipLaunchKernelGGL(k_decide_prep, dim3((P + 255) / 256), dim3(256), 0, sm, list_dev, P, c->order.p, p.score[b].p, c->global_base, c->seq_ent.p);
+        HIPCHK(c, hipGetLastError());
         DecideArgs qa;
         memset(&qa, 0, sizeof qa);
-        qa.list_n = c->seq_tn.p; qa.n_n = n_n; qa.list_g = c->seq_tn.p + n_n; qa.n_g = n_g; qa.ent_n = c->seq_ent.p; qa.ent_g = c->seq_ent.p + n_n; qa.queue_len = queue_len; qa.ncls = c->ncls;
+        qa.list_n = list_dev; qa.n_n = n_n; qa.list_g = list_dev + n_n; qa.n_g = n_g; qa.ent_n = c->seq_ent.p; qa.ent_g = c->seq_ent.p + n_n; qa.queue_len = queue_len; qa.ncls = c->ncls;
         qa.hash_slots = hash_slots;
         qa.dbg = tune_env("NHDFIT_SEQ_SKIP") ? (uint32_t)atoi(tune_env("NHDFIT_SEQ_SKIP")) : 0u;
         qa.s = sa; qa.queue = c->seq_queue.p; qa.ctrl = c->seq_ctrl.p; qa.mat = c->seq_mat.p; qa.flags = c->seq_flags.p;
@@ -2270,7 +2280,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
             // a NIC state without a signature id (or a wait that ran out): start over with the kernel whose stop / intern /
             // resume protocol the caller knows
             if ((rc = undo_all())) return rc;
-            if ((rc = reset_scan_state())) return rc;
+            if ((rc = reset_scan_state(false))) return rc;
             fast = false;
         } else decided = P;
     }

@@ -475,6 +475,23 @@ __host__ __device__ inline uint32_t decide_hash_slots(uint32_t n_gpu_less) {    
     return h;
 }
 
+// everything a sequential pass starts from, cleared by one launch (it was seven fill commands in a row in front of the pass)
+struct SeqResetArgs {
+    uint64_t* taken; uint32_t chunks;            // nodes that received a pod of this batch
+    int32_t* touched; uint32_t n;                // first-touch slots (-1 = none)
+    uint32_t* counters; uint32_t* flags;         // [4] each
+    uint32_t* ctrl; uint32_t* mat;               // the decision engine's: [32] control words, [n] published versions (null: not this pass)
+    unsigned long long* queue; uint32_t queue_len;
+};
+__global__ __launch_bounds__(256) void k_seq_reset(SeqResetArgs a) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+    for (uint32_t i = t; i < a.chunks; i += stride) a.taken[i] = 0ull;
+    for (uint32_t i = t; i < a.n; i += stride) { a.touched[i] = -1; if (a.mat) a.mat[i] = 0u; }
+    if (t < 4u) { a.counters[t] = 0u; a.flags[t] = 0u; }
+    if (a.ctrl && t < 32u) a.ctrl[t] = 0u;
+    if (a.queue) for (uint32_t i = t; i < a.queue_len; i += stride) a.queue[i] = 0ull;
+}
+
 // what a fetcher / speculator needs to start on list entry j, gathered once for the whole batch (three dependent look-ups otherwise)
 __global__ __launch_bounds__(256) void k_decide_prep(const uint32_t* __restrict__ list, uint32_t n, const uint32_t* __restrict__ order,
                                                      const unsigned long long* __restrict__ score, uint64_t global_base, uint4* __restrict__ out) {
