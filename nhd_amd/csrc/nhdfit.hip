@@ -2130,6 +2130,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, c->seq_ent.reserve(P));
         HIPCHK(c, c->seq_mat.reserve(c->n ? c->n : 1));
         HIPCHK(c, c->seq_flags.reserve(4));
+        HIPCHK(c, c->rows_t.reserve((size_t)chunks * P));         // (convert_rows_t's: the arguments below hold its address before the first pass fills it)
         // caller's pod -> staged (class-sorted) position, and behind it the decision engine's list [the pods without GPUs | every other
         // pod] (caller's indices ascending): one page-locked block, ONE copy command (each costs the copy engine ~10 us; out of pageable
         // memory the runtime stages it besides)
