@@ -246,9 +246,9 @@ struct nhdfit_ctx {
     DevBuf<uint64_t> st_info; DevBuf<uint32_t> st_next, st_asc; uint32_t st_n = 0;
     bool use_set_states = tune_env("NHDFIT_NO_SET_STATES") == nullptr;
     // mode B
-    DevBuf<uint64_t> nogpu, taken, tile_masks; DevBuf<int32_t> touched; DevBuf<uint16_t> gl_tiles; std::vector<uint32_t> order_host; std::vector<SeqResult> seq_host; DevBuf<UndoRec> undo; DevBuf<SeqResult> seq_out; DevBuf<nhdfit_placement> seq_place;
+    DevBuf<uint64_t> nogpu, taken, tile_masks; DevBuf<int32_t> touched; DevBuf<uint16_t> gl_tiles; std::vector<SeqResult> seq_host; DevBuf<UndoRec> undo; DevBuf<SeqResult> seq_out; DevBuf<nhdfit_placement> seq_place;
     DevBuf<uint32_t> order, seq_counters;
-    DevBuf<unsigned long long> seq_queue; DevBuf<uint32_t> seq_ctrl, seq_mat, seq_flags, seq_tn; DevBuf<uint4> seq_ent; std::vector<uint32_t> tn_host;   // decision-engine form of mode B (seq2_kernel.h)
+    DevBuf<unsigned long long> seq_queue; DevBuf<uint32_t> seq_ctrl, seq_mat, seq_flags; DevBuf<uint4> seq_ent;   // decision-engine form of mode B (seq2_kernel.h)
     bool seq_general = tune_env("NHDFIT_SEQ_GENERAL") != nullptr;   // tuning aid: the one-block kernel for every batch
     DevBuf<uint64_t> sig_keys; DevBuf<uint32_t> sig_ids; uint32_t sig_mask = 0;   // canonical NIC-state key -> signature id (commit_core.h)
     bool use_cand = false, want_bitmap = true, want_map = true;
@@ -263,7 +263,6 @@ struct nhdfit_ctx {
     // single-launch find of a whole batch (k_findn): its host block (flag | scores | mappings, grown with the largest call), its counters
     uint8_t* findn_host = nullptr; size_t findn_cap = 0;
     DevBuf<uint32_t> findn_sync; uint32_t findn_sync_words = 0;
-    DevBuf<uint32_t> tile_items; std::vector<uint32_t> h_tile_items;   // fit items per staged tile (build_items)
     bool batch_find = tune_env("NHDFIT_NO_BATCH_FIND") == nullptr;   // tuning aid: batches of more than one tile through the staged path
     PinBuf<uint32_t> pin_order; uint32_t tn_n = 0;   // mode B: [order | list] on their way to the device; pods without GPUs in the list
     bool reqs_deferred = false, wcls_deferred = false;   // the staged batch's request records / tile classes are in the page-locked block only (finish_deferred_copies)
@@ -473,12 +472,12 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->big_cand.release(); c->big_scratch.release();
     if (c->find_host) (void)hipHostFree(c->find_host);
     if (c->findn_host) (void)hipHostFree(c->findn_host);
-    c->findn_host = nullptr; c->findn_cap = 0; c->findn_sync.release(); c->tile_items.release();
+    c->findn_host = nullptr; c->findn_cap = 0; c->findn_sync.release();
     c->find_host = nullptr; c->find_sync.release(); c->find_red.release();
     c->pin_order.release(); c->pin_reqs.release(); c->pin_wcls.release(); c->pin_score.release(); c->pin_maps.release(); c->pin_items.release();
     c->caps.release(); c->sig_off.release(); c->pool_off.release(); c->pool_glimit.release(); c->cc.release(); c->sig_flat.release(); c->sig_flat2.release();
     c->reqs.release(); c->bitmap.release(); c->rows_t.release(); c->cand.release(); c->tile_wcls.release(); c->items.release(); c->xkeys.release(); c->xids.release(); c->xcls.release(); c->xnx.release(); c->sig_use.release(); for (auto& r : c->rec) r.release(); c->role_clock.release(); c->asc.release(); c->choose_tab.release(); c->st_info.release(); c->st_next.release(); c->st_asc.release(); c->group_sets.release();
-    c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_queue.release(); c->seq_ctrl.release(); c->seq_mat.release(); c->seq_flags.release(); c->seq_tn.release(); c->seq_ent.release(); c->sig_keys.release(); c->sig_ids.release();
+    c->nogpu.release(); c->taken.release(); c->tile_masks.release(); c->touched.release(); c->gl_tiles.release(); c->seq_counters.release(); c->undo.release(); c->seq_out.release(); c->seq_place.release(); c->order.release(); c->seq_queue.release(); c->seq_ctrl.release(); c->seq_mat.release(); c->seq_flags.release(); c->seq_ent.release(); c->sig_keys.release(); c->sig_ids.release();
     for (Pipe& p : c->pipe) {
         p.nm.release(); p.dig_count.release();
         for (int b = 0; b < kBufs; ++b) {
