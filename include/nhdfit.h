@@ -431,8 +431,9 @@ int nhdfit_download_nodes(nhdfit_ctx* ctx, uint32_t first, uint32_t count,
  * it, the requests read from and the results stored into fine-grained host memory (nhdfit_stats.small_finds counts them);
  * a lone pod skips the table image altogether (every block derives the pod's own assignment masks and sweeps nodes with them).
  * A larger call without bitmap_out, communicator, wide nodes or four-group pods is ONE launch as well (nhdfit_stats.batch_finds):
- * the batch is sorted into tiles and copied to the device as nhdfit_stage_requests does it, then digest, fit and mapping run tile by
- * tile inside one kernel - a tile's fit blocks wait for its digest, the last of them maps its winners - and scores and mappings
+ * the batch is sorted into tiles as nhdfit_stage_requests sorts it - up to 512 pods are then read by the launch straight from the
+ * page-locked block, a larger batch travels by ONE copy command with its work items behind the records -, digest, fit and mapping run
+ * tile by tile inside one kernel - a tile's fit blocks wait for its digest, the last of them maps its winners - and scores and mappings
  * arrive in fine-grained host memory behind one polled word.
  * Every other call stages the batch and runs the launches of a step (digest, fused step, drain).  The single-launch forms leave
  * nothing staged: nhdfit_enqueue_step / nhdfit_fetch need a nhdfit_stage_requests of their own. */
