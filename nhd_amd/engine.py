@@ -198,7 +198,8 @@ class Engine:
             if self.n_wide:
                 for wp in self.wide_placements():
                     self.last_wide_places[first + int(wp["pod"])] = wp.copy()
-            stuck = [int(node[i] - self.global_base) for i in range(first, last) if status[i] == pack.COMMIT_NEW_SIG]
+            # (vectorised: a Python loop over the pods here was 0.25-0.4 ms per 4 096 pods - a tenth of the whole call)
+            stuck = (node[first:last][status[first:last] == pack.COMMIT_NEW_SIG] - self.global_base).tolist()
             if last < P and not (apply and stuck):
                 raise _lib.NhdFitError(-5, "the device stopped a sequential batch early without a NIC state to intern")
             patched = []
