@@ -634,9 +634,11 @@ class HipMatcher:
             index = [winner_index(s) - base if s else -1 for s in score.tolist()]
         out: List[Tuple] = []
         self.last_placements = [None] * n_pods
-        rows = maps.tolist()                               # (gpu[4], cpu[5], nic_numa[4], nic_idx[4], valid, pad) per pod: one C call
+        rows = pack.unpack_mappings(maps)                  # (gpu[4], cpu[5], nic_numa[4], nic_idx[4], valid) per pod as Python ints: one pass
         n_groups = reqs["n_groups"].tolist()
         names = self._names
+        place_rows = pack.unpack_placements(places) if places is not None and self._attached is not None else None   # (Python ints, one C call)
+        gpus_of = reqs["gpus"].tolist() if place_rows is not None else None
         for p in range(n_pods):
             i = index[p]
             if i < 0:
@@ -646,23 +648,23 @@ class HipMatcher:
             G = n_groups[p]
             if places is not None and self._attached is not None:
                 nd = self._attached.get(name)
-                if nd is not None and int(places[p]["status"]) == pack.COMMIT_WIDE:     # the pod landed on a wide node
+                if nd is not None and place_rows[p][55] == pack.COMMIT_WIDE:            # (status) the pod landed on a wide node
                     wp = getattr(self.engine, "last_wide_places", {}).get(p)
                     if wp is not None:
                         self.last_placements[p] = pack.expand_wide_placement(wp, G, int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets),
-                                                                             [int(reqs[p]["gpus"][g]) for g in range(G)])
+                                                                             gpus_of[p][:G])
                     if apply:                                  # its record is re-packed from the object before the next call, whether or not
                         self._mark(nd, "wide-batch")           # the caller applies the placement to it (no delta form on the general path)
                 elif nd is not None:
-                    self.last_placements[p] = pack.expand_placement(places[p], G, int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets),
-                                                                    [int(reqs[p]["gpus"][g]) for g in range(G)])
+                    self.last_placements[p] = pack.expand_placement(place_rows[p], G, int(nd.cores_per_proc), int(nd.cores_per_proc) * int(nd.sockets),
+                                                                    gpus_of[p][:G])
                     if apply:                                  # the reference mutators that follow find their work mirrored already
                         self._batch_ids.setdefault(nd.name, []).append(self.last_placements[p])
-            gpu, cpu, nic_numa, nic_idx, valid, _ = rows[p]
+            gpu, cpu, nic_numa, nic_idx, valid = rows[p]
             if not valid:
                 raise RuntimeError(f"internal error: no mapping produced for feasible node {name}")
-            out.append((name, {"gpu": tuple(gpu[:G].tolist()), "cpu": tuple(cpu[:G + 1].tolist()),        # (plain ints, as the reference's tuples hold)
-                               "nic": list(zip(nic_numa[:G].tolist(), nic_idx[:G].tolist()))}))
+            out.append((name, {"gpu": gpu[:G], "cpu": cpu[:G + 1],                                          # (tuples of plain ints, as the reference's hold)
+                               "nic": list(zip(nic_numa[:G], nic_idx[:G]))}))
         return out
 
     # ---- pods with 5..8 processing groups (nhdfit_big_req): the general path ---------------------------------------------
@@ -691,21 +693,20 @@ class HipMatcher:
 
         def answer(p, i, row):
             G = n_groups[p]
-            gpu, cpu, nic_numa, nic_idx, valid, _ = row
+            gpu, cpu, nic_numa, nic_idx, valid = row
             if not valid:
                 raise RuntimeError(f"internal error: no mapping produced for feasible node {names[i]}")
-            out[p] = (names[i], {"gpu": tuple(gpu[:G].tolist()), "cpu": tuple(cpu[:G + 1].tolist()),
-                                 "nic": list(zip(nic_numa[:G].tolist(), nic_idx[:G].tolist()))})
+            out[p] = (names[i], {"gpu": gpu[:G], "cpu": cpu[:G + 1], "nic": list(zip(nic_numa[:G], nic_idx[:G]))})
 
         if not sequential:
             if small_idx:
                 score, _, maps = self.engine.find(small_reqs, now, cand=cand, want_bitmap=False, want_map=True)
-                rows = maps.tolist()
+                rows = pack.unpack_mappings(maps)
                 for k, s in enumerate(score.tolist()):
                     if s:
                         answer(small_idx[k], winner_index(s) - base, rows[k])
             score, maps = self.engine.big_find(big_reqs, now, cand=cand)
-            rows = maps.tolist()
+            rows = pack.unpack_big_mappings(maps)
             for k, s in enumerate(score.tolist()):
                 if s:
                     answer(big_idx[k], winner_index(s) - base, rows[k])
@@ -737,7 +738,7 @@ class HipMatcher:
                 score, maps = self.engine.big_find(big_reqs[pos_big[p]:pos_big[p] + 1], now, cand=cand)
                 if score[0]:
                     i = winner_index(int(score[0])) - base
-                    answer(p, i, maps.tolist()[0])
+                    answer(p, i, pack.unpack_big_mappings(maps)[0])
                     ids = self._commit_big(i, objects.get(names[i]), req, maps[0], now)
                     record(p, i, ids, self._table is not None and bool(self._table.wide) and i in self._table.wide)
                 p += 1
@@ -751,7 +752,7 @@ class HipMatcher:
             if (status == pack.COMMIT_WOULD_RAISE).any():
                 self.logger.warning("mode B: the reference's commit step would have failed for pod %d",
                                     p + int(np.flatnonzero(status == pack.COMMIT_WOULD_RAISE)[0]))
-            rows = maps.tolist()
+            rows = pack.unpack_mappings(maps)
             wide_places = getattr(self.engine, "last_wide_places", {})
             for j in range(q - p):
                 if node[j] < 0:

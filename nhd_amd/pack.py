@@ -885,34 +885,66 @@ def expand_batch(take: int, pair: int, numa: int, cores_per_proc: int, num_cores
     the sibling range handed out as cores of their own (`late`, ascending)."""
     out: List[int] = []
     take, pair, late = int(take), int(pair), int(late)
-    b = 0
-    while take >> b:
-        if take >> b & 1:
-            core = numa * cores_per_proc + b
-            out.append(core)
-            if pair >> b & 1:
-                out.append(core + num_cores)
-        b += 1
-    b = 0
-    while late >> b:
-        if late >> b & 1:
-            out.append(numa * cores_per_proc + b + num_cores)
-        b += 1
+    base = numa * cores_per_proc
+    while take:                                       # set bits, ascending
+        low = take & -take
+        core = base + low.bit_length() - 1
+        out.append(core)
+        if pair & low:
+            out.append(core + num_cores)
+        take ^= low
+    base += num_cores
+    while late:
+        low = late & -late
+        out.append(base + low.bit_length() - 1)
+        late ^= low
     return out
+
+
+# one C call turns a placement record into Python ints (a field access on a numpy record costs about as much as the whole expansion):
+# 18 mask words (proc_take[4], proc_pair[4], help_take[4], help_pair[4], misc_take, misc_pair), gpu[4][8], numa[5], status, 9 more words
+# (proc_late[4], help_late[4], misc_late) - the field order of PLACEMENT
+_PLACEMENT_STRUCT = struct.Struct("<18Q32B5bB2x9Q")
+assert _PLACEMENT_STRUCT.size == PLACEMENT.itemsize and PLACEMENT.names == (
+    "proc_take", "proc_pair", "help_take", "help_pair", "misc_take", "misc_pair", "gpu", "numa", "status", "pad", "proc_late", "help_late", "misc_late")
+
+
+_MAPPING_STRUCT = struct.Struct("<4b5b4b4bb2x")          # gpu[4], cpu[5], nic_numa[4], nic_idx[4], valid - the field order of MAPPING
+assert _MAPPING_STRUCT.size == MAPPING.itemsize and MAPPING.names == ("gpu", "cpu", "nic_numa", "nic_idx", "valid", "pad")
+
+
+def unpack_mappings(maps: np.ndarray) -> List[tuple]:
+    """MAPPING records -> (gpu[4], cpu[5], nic_numa[4], nic_idx[4], valid) as tuples of Python ints per record, in one pass."""
+    return [(r[0:4], r[4:9], r[9:13], r[13:17], r[17]) for r in _MAPPING_STRUCT.iter_unpack(np.ascontiguousarray(maps, dtype=MAPPING).tobytes())]
+
+
+_BIG_MAPPING_STRUCT = struct.Struct("<8b9b8b8bb2x")
+assert _BIG_MAPPING_STRUCT.size == BIG_MAPPING.itemsize and BIG_MAPPING.names == ("gpu", "cpu", "nic_numa", "nic_idx", "valid", "pad")
+
+
+def unpack_big_mappings(maps: np.ndarray) -> List[tuple]:
+    """BIG_MAPPING records (eight groups) in unpack_mappings' form."""
+    return [(r[0:8], r[8:17], r[17:25], r[25:33], r[33]) for r in _BIG_MAPPING_STRUCT.iter_unpack(np.ascontiguousarray(maps, dtype=BIG_MAPPING).tobytes())]
+
+
+def unpack_placements(places: np.ndarray) -> List[tuple]:
+    """PLACEMENT records -> flat tuples of Python ints for expand_placement (a caller with many records converts the array once)."""
+    return list(_PLACEMENT_STRUCT.iter_unpack(np.ascontiguousarray(places, dtype=PLACEMENT).tobytes()))
 
 
 def expand_placement(place, n_groups: int, cores_per_proc: int, num_cores: int, gpus_per_group: Sequence[int]) -> dict:
     """nhdfit_placement -> the physical ids Node.SetPhysicalIdsFromMapping hands out, in its order:
     {'groups': [{'cores': [...], 'helpers': [...], 'gpus': [positions in Node.gpus]}], 'misc': [...]}.
     `cores` is the group's whole batch: the reference gives its first entries to the GPUs' cpu_cores (in GPU order),
-    the rest to proc_cores (nhd/Node.py:729-742)."""
+    the rest to proc_cores (nhd/Node.py:729-742).  `place`: one PLACEMENT record, or its tuple from unpack_placements."""
+    f = place if isinstance(place, tuple) else _PLACEMENT_STRUCT.unpack(np.asarray(place, dtype=PLACEMENT).tobytes())
     groups = []
     for g in range(n_groups):
-        u = int(place["numa"][g])
-        groups.append({"cores": expand_batch(place["proc_take"][g], place["proc_pair"][g], u, cores_per_proc, num_cores, place["proc_late"][g]),
-                       "helpers": expand_batch(place["help_take"][g], place["help_pair"][g], u, cores_per_proc, num_cores, place["help_late"][g]),
-                       "gpus": [int(x) for x in place["gpu"][g][:gpus_per_group[g]]]})
-    misc = expand_batch(place["misc_take"], place["misc_pair"], int(place["numa"][MAX_GROUPS]), cores_per_proc, num_cores, place["misc_late"])
+        u = f[50 + g]
+        groups.append({"cores": expand_batch(f[g], f[4 + g], u, cores_per_proc, num_cores, f[56 + g]),
+                       "helpers": expand_batch(f[8 + g], f[12 + g], u, cores_per_proc, num_cores, f[60 + g]),
+                       "gpus": list(f[18 + 8 * g:18 + 8 * g + gpus_per_group[g]])})
+    misc = expand_batch(f[16], f[17], f[50 + MAX_GROUPS], cores_per_proc, num_cores, f[64])
     return {"groups": groups, "misc": misc}
 
 
