@@ -212,3 +212,58 @@ def test_claim_on_a_counter_outside_the_tracked_range_keeps_the_class():
     fresh = pack.Packer()
     fresh.pack_node_into(nd, one, 0)
     assert fresh.caps[int(one.detail[0]["nic_cls"][u][k])] == pk.caps[int(table.detail[i]["nic_cls"][u][k])] != 0.0
+
+
+def test_records_unpacked_in_one_pass_equal_the_field_by_field_reading():
+    """pack.unpack_placements / unpack_mappings / unpack_big_mappings (one struct pass over the array) against the records read
+    field by field, and expand_placement on both forms; expand_batch against the bit-by-bit walk it replaced (pair and late
+    masks, bits up to 63)."""
+    rng = np.random.default_rng(11)
+    n = 64
+    places = np.zeros(n, pack.PLACEMENT)
+    raw = places.view(np.uint8).reshape(n, -1)
+    raw[:] = rng.integers(0, 256, size=raw.shape, dtype=np.uint8)
+    for f in ("proc_take", "proc_pair", "help_take", "help_pair", "proc_late", "help_late"):
+        places[f] &= rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64) >> np.uint64(20)      # (sparse masks: a few cores per batch)
+    places["numa"] = rng.integers(0, 2, size=(n, 5))
+    rows = pack.unpack_placements(places)
+    assert len(rows) == n
+    for i in range(n):
+        r = rows[i]
+        assert list(r[0:4]) == places[i]["proc_take"].tolist() and list(r[4:8]) == places[i]["proc_pair"].tolist()
+        assert list(r[8:12]) == places[i]["help_take"].tolist() and list(r[12:16]) == places[i]["help_pair"].tolist()
+        assert r[16] == int(places[i]["misc_take"]) and r[17] == int(places[i]["misc_pair"])
+        assert list(r[18:50]) == places[i]["gpu"].reshape(-1).tolist() and list(r[50:55]) == places[i]["numa"].tolist()
+        assert r[55] == int(places[i]["status"])
+        assert list(r[56:60]) == places[i]["proc_late"].tolist() and list(r[60:64]) == places[i]["help_late"].tolist() and r[64] == int(places[i]["misc_late"])
+        G = int(rng.integers(1, 5))
+        gp = [int(x) for x in rng.integers(0, 3, size=G)]
+        assert pack.expand_placement(places[i], G, 64, 128, gp) == pack.expand_placement(r, G, 64, 128, gp)
+
+    def walk(take, pair, numa, cpp, num_cores, late):            # the reference's order, bit by bit
+        out = []
+        for b in range(64):
+            if take >> b & 1:
+                out.append(numa * cpp + b)
+                if pair >> b & 1:
+                    out.append(numa * cpp + b + num_cores)
+        for b in range(64):
+            if late >> b & 1:
+                out.append(numa * cpp + b + num_cores)
+        return out
+    for _ in range(200):
+        take, pair, late = (int(x) for x in rng.integers(0, 2**63, size=3, dtype=np.uint64) & rng.integers(0, 2**63, size=3, dtype=np.uint64))
+        take |= 1 << 63 if rng.random() < 0.1 else 0
+        numa = int(rng.integers(0, 2))
+        assert pack.expand_batch(take, pair, numa, 64, 128, late) == walk(take, pair, numa, 64, 128, late)
+
+    maps = np.zeros(n, pack.MAPPING)
+    maps.view(np.int8).reshape(n, -1)[:] = rng.integers(-1, 8, size=(n, pack.MAPPING.itemsize))
+    for i, (gpu, cpu, nn, ni, valid) in enumerate(pack.unpack_mappings(maps)):
+        assert list(gpu) == maps[i]["gpu"].tolist() and list(cpu) == maps[i]["cpu"].tolist() and list(nn) == maps[i]["nic_numa"].tolist()
+        assert list(ni) == maps[i]["nic_idx"].tolist() and valid == int(maps[i]["valid"])
+    big = np.zeros(n, pack.BIG_MAPPING)
+    big.view(np.int8).reshape(n, -1)[:] = rng.integers(-1, 8, size=(n, pack.BIG_MAPPING.itemsize))
+    for i, (gpu, cpu, nn, ni, valid) in enumerate(pack.unpack_big_mappings(big)):
+        assert list(gpu) == big[i]["gpu"].tolist() and list(cpu) == big[i]["cpu"].tolist() and list(nn) == big[i]["nic_numa"].tolist()
+        assert list(ni) == big[i]["nic_idx"].tolist() and valid == int(big[i]["valid"])
