@@ -164,6 +164,7 @@ struct nhdfit_ctx {
     hipStream_t stream = nullptr;        // = pipe[0].stream: uploads, deltas, commits, mode B, single finds
     hipStream_t s_red = nullptr;         // the all-reduce of sharded runs, overlapping the next step launch
     bool side_streams_used = true;       // something was enqueued on a pipe other than the first, or on s_red, since sync_all last waited for them
+    bool known_idle = false;             // no HIP call of this context since its streams were last seen idle (sync_all; a single-launch find's polled word)
     bool dual = tune_env("NHDFIT_ONE_PIPE") == nullptr;   // tuning aid: NHDFIT_ONE_PIPE=1 keeps every step on pipe 0
     uint64_t n_enq = 0;                  // steps enqueued since the last stage_requests (step k runs on pipe k % 2)
     int last_pipe = 0;                   // the pipe of the most recent step (nhdfit_fetch reads its results)
@@ -310,6 +311,7 @@ int fail(nhdfit_ctx* c, int code, const char* fmt, ...) {
 
 #define HIPCHK(c, expr)                                                                         \
     do {                                                                                        \
+        (c)->known_idle = false;          /* (whatever it is, it may put work on a stream) */   \
         hipError_t e_ = (expr);                                                                 \
         if (e_ != hipSuccess) return fail((c), NHDFIT_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
@@ -362,6 +364,7 @@ int sync_all(nhdfit_ctx* c) {
         if (&p == &c->pipe[0] || c->side_streams_used) HIPCHK(c, wait_stream(p.stream));
     if (c->side_streams_used) HIPCHK(c, wait_stream(c->s_red));
     c->side_streams_used = false;
+    c->known_idle = true;
     return NHDFIT_OK;
 }
 
@@ -791,9 +794,14 @@ int stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, bool defer
         fprintf(stderr, "[nhdfit]   stage P=%u %s %.1f us\n", P, what, std::chrono::duration<double, std::micro>(t1 - t_prev).count());
         t_prev = t1;
     };
+    // (a single-launch find that saw its word left the streams idle, and nothing has been asked of the runtime since: asking the first
+    // stream would only make it reap that launch now - ~12 us of every batch call)
+    const bool idle = c->known_idle && c->ev_pending == 0;
     HIPCHK(c, hipSetDevice(c->dev));
-    { int rc_ = sync_all(c); if (rc_) return rc_; }
-    { int rc_ = drain_events(c); if (rc_) return rc_; }
+    if (!idle) {
+        { int rc_ = sync_all(c); if (rc_) return rc_; }
+        { int rc_ = drain_events(c); if (rc_) return rc_; }
+    }
     lap("streams idle, events read");
     for (Pipe& p : c->pipe) p.n_dig = p.n_fit = p.n_shaped = p.n_chosen = p.n_finished = 0;
     c->n_enq = 0;
@@ -1730,6 +1738,7 @@ int find_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     c->stats.nodes = c->n; c->stats.nsig = c->nsig; c->stats.ncls = c->ncls; c->stats.lds_bytes = c->lds_bytes;
     c->stats.batch_finds++;
     c->P = 0; c->n_items = 0;                                   // nothing stays staged for nhdfit_enqueue_step / nhdfit_fetch
+    c->known_idle = true;                                       // (the word came behind everything this call put on the stream)
     (void)chunks;
     return NHDFIT_OK;
 }
