@@ -8,9 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "nhdfit.hip")
 WIRE = os.path.join(HERE, "csrc", "wire_digest.cpp")          # host-only translation unit (libconfig reader)
-DEPS = [SRC, WIRE, os.path.join(HERE, "csrc", "fit_core.h"), os.path.join(HERE, "csrc", "winner_map.h"),
-        os.path.join(HERE, "csrc", "seq_core.h"), os.path.join(HERE, "csrc", "set_states.h"), os.path.join(HERE, "csrc", "commit_core.h"), os.path.join(ROOT, "include", "nhdfit.h")] + \
-       [os.path.join(HERE, "csrc", f) for f in ("step_digest.h", "step_fit.h", "step_map.h", "step_kernel.h", "seq_kernel.h", "seq2_kernel.h", "wide_core.h", "wide_kernel.h", "big_kernel.h", "dict_stream.h")]
+DEPS = [SRC, WIRE, os.path.join(ROOT, "include", "nhdfit.h")] + \
+       sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h"))   # every header nhdfit.hip may include
 LIB = os.path.join(HERE, "libnhdfit.so")
 TUNING_LIB = os.path.join(HERE, "libnhdfit_tuning.so")   # -DNHDFIT_TUNING: environment knobs + ablation switches, for tools/ only
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
