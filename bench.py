@@ -392,43 +392,57 @@ def sharded_mode_b(eng, pk, table, reqs, spec, lo, hi, cfg, total_nodes, tops, g
 
 
 def roofline(st, fit_ms, achieved, traffic, traffic_source, valu, counters, pipes=1, ms_per_step=None):
-    """`achieved` / `frac`: SURVEY.md 8(d)'s algorithmic bytes per step / the wall clock of the timed region per step, against
-    the 8 TB/s HBM spec (one k_step launch per step; the library keeps two launches in flight on two streams, so the wall
-    clock per step is what one launch's worth of work really costs).  `achieved_from_events_x_concurrency` is the same bytes
-    / the step kernel's mean HIP-event duration x the launches in flight (`concurrency`) - a cross-check that assumes perfect
-    overlap and so reads a few percent high.  The algorithmic bytes price the node records once per pod tile although L2
-    serves the re-reads, so the counters ride along (what HBM really moved, how busy the LDS pipes and the VALUs were) and
-    `bound` names what they point at."""
+    """`achieved` / `frac` (the contract's definition, and what VERDICT r05 recomputed): SURVEY.md 8(d)'s algorithmic bytes of ONE
+    k_step launch / that launch's mean HIP-event duration over the timed region (`kernel_ms`; it agrees with the rocprofv3
+    --kernel-trace --stats average kept under profiles/), against the 8 TB/s HBM spec.  The library keeps two launches in flight on
+    two streams, so a launch lasts about two steps of wall clock: the device's byte RATE is the wall-clock figure `frac_wall`
+    (bytes per step / wall clock per step), which rides along and is NOT `frac`.  Neither says what HBM did: the algorithmic
+    bytes re-count the 1.5 MB of node records once per pod tile and L2 serves 63 of 64 of those reads - `hbm_counter_frac` (the
+    counters' bytes per launch / wall clock per step) is HBM's own figure.  All unit fractions are flat scalars of this object
+    (the driver's record keeps scalars only): hbm_counter_frac, lds_frac, valu_issue_frac, wait_frac, bank_conflict_share."""
     secs = fit_ms * 1e-3 / max(1, pipes)                  # kernel time per launch's worth of work at the measured concurrency
-    hbm = None if not traffic or secs <= 0 else {
-        "achieved": traffic / secs / 1e9, "frac": traffic / secs / 1e9 / HBM_PEAK_GBS,
-        "note": "bytes the counters saw per launch / the same kernel time: what HBM really moved"}
-    issue = None if not valu or secs <= 0 else {
-        "valu_wave_insts_per_launch": valu, "valu_issue_frac": valu * VALU_NS_PER_WAVE_INST * 1e-9 / SIMDS / secs,
-        "note": "wave64 VALU instructions x 1.2 ns (measured full-rate issue per SIMD, profiles/r02/valu_calib.jsonl) / 1024 SIMDs / kernel time"}
+    step_s = ms_per_step * 1e-3 if ms_per_step else secs
+    hbm = None if not traffic or step_s <= 0 else {
+        "achieved": traffic / step_s / 1e9, "frac": traffic / step_s / 1e9 / HBM_PEAK_GBS,
+        "note": "bytes the counters saw per launch / the wall clock per step (one launch per step): what HBM really moved"}
+    issue = None if not valu or step_s <= 0 else {
+        "valu_wave_insts_per_launch": valu, "valu_issue_frac": valu * VALU_NS_PER_WAVE_INST * 1e-9 / SIMDS / step_s,
+        "note": "wave64 VALU instructions x 1.2 ns (measured full-rate issue per SIMD, profiles/r02/valu_calib.jsonl) / 1024 SIMDs / wall clock per step"}
     lds = None
-    if counters and counters.get("SQ_LDS_IDX_ACTIVE") and secs > 0:
+    if counters and counters.get("SQ_LDS_IDX_ACTIVE") and step_s > 0:
         cyc = counters["SQ_LDS_IDX_ACTIVE"] / CUS                      # LDS-array cycles per CU and launch
-        lds = {"lds_active_cycles_per_cu": cyc, "lds_frac": cyc / (secs * CLOCK_HZ),
+        lds = {"lds_active_cycles_per_cu": cyc, "lds_frac": cyc / (step_s * CLOCK_HZ),
                "bank_conflict_share": (counters.get("SQ_LDS_BANK_CONFLICT", 0.0) / counters["SQ_LDS_IDX_ACTIVE"]),
-               "note": "SQ_LDS_IDX_ACTIVE / 256 CUs / (kernel time x 2.4 GHz): share of the launch the CU's LDS pipe is busy"}
+               "note": "SQ_LDS_IDX_ACTIVE / 256 CUs / (wall clock per step x 2.4 GHz): share of a step the CU's LDS pipe is busy"}
+    wait = None
+    if counters and counters.get("SQ_WAVE_CYCLES") and counters.get("SQ_WAIT_ANY") is not None:
+        wait = counters["SQ_WAIT_ANY"] / counters["SQ_WAVE_CYCLES"]   # share of the resident waves' cycles spent waiting on any counter (vmcnt / lgkmcnt / ...)
     fr = {"hbm": hbm["frac"] if hbm else None, "lds": lds["lds_frac"] if lds else None, "valu": issue["valu_issue_frac"] if issue else None}
     known = {k: v for k, v in fr.items() if v is not None}
     top = max(known, key=known.get) if known else None
     bound = "hbm" if top == "hbm" and known[top] >= 0.5 else ("latency" if not known or known[top] < 0.5 else top)
     wall = None if not ms_per_step else st.bytes_last / (ms_per_step * 1e-3) / 1e9
-    return {"bound": bound, "priced_against": "hbm", "kernel": "k_step", "achieved": wall if wall is not None else achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": (wall if wall is not None else achieved) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+    per_launch = st.bytes_last / (fit_ms * 1e-3) / 1e9 if fit_ms > 0 else 0.0
+    return {"bound": bound, "priced_against": "hbm", "kernel": "k_step", "achieved": per_launch, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": per_launch / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": int(st.bytes_last), "kernel_ms": fit_ms, "concurrency": pipes,
+            "frac_kernel": per_launch / HBM_PEAK_GBS,
+            "frac_wall": None if wall is None else wall / HBM_PEAK_GBS,
+            "hbm_counter_frac": hbm["frac"] if hbm else None,
+            "lds_frac": lds["lds_frac"] if lds else None,
+            "valu_issue_frac": issue["valu_issue_frac"] if issue else None,
+            "wait_frac": wait,
+            "bank_conflict_share": lds["bank_conflict_share"] if lds else None,
+            "traffic_over_algorithmic": None if not traffic else traffic / float(st.bytes_last),
             "achieved_from_wall": wall,
             "achieved_from_events_x_concurrency": achieved,
-            "achieved_note": "achieved / frac = algorithmic bytes per step / the WALL CLOCK of the timed region per step (one launch per step; two "
-                             "launches overlap, so bytes / one launch's HIP-event duration alone would understate and 2 x that overstate the rate "
-                             "- VERDICT r03 weak #3); the HIP-event figure x concurrency rides along for the cross-check",
+            "achieved_note": "achieved / frac = algorithmic bytes of one launch / that launch's mean HIP-event duration (kernel_ms), as the contract "
+                             "defines it; `concurrency` launches overlap, so the device's byte rate is achieved_from_wall (frac_wall) - bytes per "
+                             "step / wall clock per step of the timed region",
             "bytes_formula": "SURVEY.md 8(d): ceil(P/64) * N * 24 (16-byte node record + 8-byte busy time per node and tile) "
                              "+ P * 128 (requests) + P * N / 8 (verdict matrix) + 8 * P (scores)",
             "frac_note": "algorithmic bytes re-count the node records once per pod tile (SURVEY.md 8(d)'s definition) although L2 / Infinity "
-                         "Cache serve those re-reads: this fraction can pass 1 and says nothing about HBM - hbm_counter.frac is what HBM moved",
+                         "Cache serve those re-reads: frac_wall can pass 1 and says nothing about HBM - hbm_counter_frac is what HBM moved",
             "hbm_counter": hbm, "lds": lds, "issue": issue, "unit_fracs": fr,
             "limited_by": "no unit above half of its peak -> latency: dependent L2 / LDS round trips inside short blocks plus the fixed cost "
                           "of a launch" if bound == "latency" else bound,
@@ -697,7 +711,7 @@ def measure_counters(args):
     tmp = tempfile.mkdtemp(prefix="nhdbench_", dir="/tmp")
     try:
         for name, ctrs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("valu", ["SQ_INSTS_VALU"]),
-                           ("lds", ["SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"])):
+                           ("lds", ["SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES"])):
             d = os.path.join(tmp, name)
             cmd = [rocprof, "--pmc"] + ctrs + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + base
             try:
@@ -728,8 +742,11 @@ def measure_counters(args):
 
 def cpu_baseline(spec, tops, pod_groups, sample, gpu_score, base, winner_index, args):
     """The C port of the reference path (oracle/nhd_oracle.c) on the same inputs, 1 host core, on the
-    first `sample` pods x all of this GPU's nodes; also asserts the GPU picked the same nodes.  The reference itself is
-    Python and absent on this box: its figures, measured in the build container on this workload's inputs, ride along."""
+    first `sample` pods x all of this GPU's nodes; also asserts the GPU picked the same nodes.  `kind` stays "port": the
+    reference is Python, and a Python reference may not travel to the GPU box in any form (source, bytecode or otherwise -
+    task statement, section 3), so there is no oracle/_ref to time here.  What rides along instead: the unmodified reference's
+    figures on this very workload from the build container (tools/cpu_reference.py, newest profiles/r*/cpu_reference.json),
+    the pinned Python restatement timed on THIS box in THIS run, and the estimate the two give for the reference on this box."""
     from oracle import coracle
     cl = coracle.Cluster.from_spec(spec)
     sample = min(sample, len(tops))
@@ -757,16 +774,30 @@ def cpu_baseline(spec, tops, pod_groups, sample, gpu_score, base, winner_index, 
             rj = json.load(f)
         if (rj.get("config"), rj.get("nodes"), rj.get("pods_in_batch")) == (args.config, spec.n, args.pods):
             reference = {"source": os.path.relpath(rpath, ROOT) + " (unmodified reference Matcher.FindNode on this workload's inputs, measured in the "
-                                   "build container - the reference is Python and not present on the GPU box)",
+                                   "build container by tools/cpu_reference.py - the reference is Python and may not travel to the GPU box in any form)",
                          "one_core": {"value": rj["one_core"]["evals_per_s"], "decisions_per_s": rj["one_core"]["decisions_per_s"], "cores": 1},
                          "all_cores": {"value": rj["all_cores"]["evals_per_s"], "decisions_per_s": rj["all_cores"]["decisions_per_s"],
                                        "cores": rj["all_cores"]["cores"]},
                          "host": rj.get("host"), "sampled_pods": rj.get("sampled_pods"), "parity": rj.get("parity")}
+            cal = (rj.get("python_restatement") or {}).get("calibration")
+            if cal and python_port and python_port.get("value"):
+                # the same calibration sample of the pinned Python restatement, timed there and here: how much faster one core of this
+                # box runs the same CPython work - the only bridge between the two hosts that does not move the reference
+                k = python_port["value"] / cal["evals_per_s"]
+                reference["estimate_on_this_box"] = {
+                    "one_core": rj["one_core"]["evals_per_s"] * k, "core_speed_ratio": k, "cores": 1,
+                    "note": "ESTIMATE, not a measurement: the build container's reference figure x (Python restatement on this box / the same "
+                            "sample in the build container); the reference itself is timed in the build container only"}
             break
     return {"value": sample * spec.n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
             "all_host_cores": many, "python_restatement": python_port,
             "sample": f"first {sample} pods x {spec.n} nodes, oracle/nhd_oracle.c (gcc -O2), {dt:.1f} s; "
-                      f"winners identical to the GPU's on all {sample} pods",
+                      f"winners identical to the GPU's on all {sample} pods" +
+                      ("" if not reference else f"; unmodified reference Matcher.FindNode on the same inputs, build container "
+                       f"({reference['source'].split(' ')[0]}): {reference['one_core']['value']:.0f} evals/s on 1 core, "
+                       f"{reference['all_cores']['value']:.0f} on {reference['all_cores']['cores']}" +
+                       ("" if "estimate_on_this_box" not in reference else
+                        f"; estimated on one core of this box: {reference['estimate_on_this_box']['one_core']:.0f} evals/s")),
             "reference": reference}
 
 

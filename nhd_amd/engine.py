@@ -70,6 +70,15 @@ class Engine:
         if table.origin is not None and table.n:
             origin = np.ascontiguousarray(table.origin)          # (bound to a name: _p hands out a bare address)
             self._chk(self.lib.nhdfit_upload_origin(self.ctx, first, table.n, _p(origin)))
+        sharing = getattr(self, "_share", None) is not None
+        whole = first == 0 and table.n >= self.n
+        if sharing and not whole and self.n_wide:
+            # ENABLE_SHARING, delta upload: device-side commits (wide_commit, schedule_batch) added rx / tx to speed_used records this
+            # host copy has never seen - fetch them before nhdfit_wide_upload switches sharing off, so that the nodes OUTSIDE the slice
+            # go back up as the device left them (a wide record showing the cores taken beside a speed_used that forgot the claim)
+            dev = self.wide_share_download()
+            if len(dev):
+                self._share[:len(dev)] = dev
         if table.n and (table.wide or self.n_wide):               # nodes beyond the fast layout: their records replace those of this range
             recs = table.wide_records(first)
             self._chk(self.lib.nhdfit_wide_upload(self.ctx, first, table.n, _p(recs) if len(recs) else None, len(recs)))
@@ -78,20 +87,27 @@ class Engine:
         # nhd/Node.py:20 ENABLE_SHARING = True: every node is a wide record and carries its NICs' speed_used (nhdfit_wide_share).  The
         # device wants the records of ALL wide nodes after every wide upload: this engine keeps them by node index
         if table.share:
-            if not hasattr(self, "_share") or self._share is None or len(self._share) < self.n:
+            if not sharing or len(self._share) < self.n:
                 grown = np.zeros(self.n, pack.WIDE_SHARE)
-                if getattr(self, "_share", None) is not None:
+                if sharing:
                     grown[:len(self._share)] = self._share
                 self._share = grown
+            missing = [i for i in range(table.n) if i not in table.share] if len(table.share) != table.n else []
+            if missing:
+                raise _lib.NhdFitError(-5, "ENABLE_SHARING: node %d of the uploaded slice carries no speed_used record" % (first + missing[0]))
             for i, rec in table.share.items():
                 self._share[first + i] = rec
             if self.n_wide != self.n:
                 raise _lib.NhdFitError(-5, "ENABLE_SHARING: a node of the mirror is not held by the general path")
             share = np.ascontiguousarray(self._share[:self.n])
             self._chk(self.lib.nhdfit_wide_share_upload(self.ctx, _p(share), len(share)))
-        elif getattr(self, "_share", None) is not None and first == 0 and table.n >= self.n:
-            self._share = None
+        elif sharing and whole:
+            self._share = None                                      # the whole mirror replaced by a table without speed_used records: sharing is off
             self._chk(self.lib.nhdfit_wide_share_upload(self.ctx, None, 0))
+        elif sharing and table.n:
+            # a slice without speed_used records under ENABLE_SHARING (a node that no longer fits a wide record, a table packed with the
+            # constant off): nhdfit_wide_upload has switched the sharing arithmetic off - never continue with the shipped arithmetic silently
+            raise _lib.NhdFitError(-5, "ENABLE_SHARING: the uploaded slice [%d, %d) carries no speed_used records" % (first, first + table.n))
         self.global_base = global_base
 
     def wide_count(self) -> int:

@@ -4,7 +4,12 @@
 processes, node axis cut into contiguous shards, unmodified FindNode per shard, shard winners merged in node order).
 Parity with the product's own CPU checker (oracle C port) is asserted on every pod the reference ran.
 
-    python tools/cpu_reference.py [--config 4] [--nodes 65536] [--pods 2] [--procs 8] > profiles/r02/cpu_reference.json
+The pinned Python restatement (oracle/nhd_oracle.py) is timed on the same pods and nodes, and on bench.py's own calibration
+sample (first 2 pods x first 4 096 nodes), in the same process: bench.py times that calibration sample again on the GPU box, and
+the ratio of the two is the only honest bridge between this container's cores and the box's (the reference is Python: it may not
+travel to the box in any form - task statement, section 3).
+
+    python tools/cpu_reference.py [--config 4] [--nodes 65536] [--pods 2] [--procs 8] > profiles/r06/cpu_reference.json
 """
 import argparse, contextlib, io, json, logging, multiprocessing as mp, os, platform, sys, time
 
@@ -88,6 +93,21 @@ def main():
     assert port == one, (port, one)
     assert merged == one, (merged, one)
     n_eval = len(idx) * args.nodes
+    # the pinned Python restatement on the same host: the sampled pods x all nodes, then bench.py's calibration sample
+    own_nodes = spec.build_nodes()
+    rest = []
+    for i in idx:
+        top = refmodel.make_topology(pods[i])
+        t0 = time.perf_counter()
+        r = nhd_oracle.find_node(nhd_oracle.initial_node_filter(own_nodes, groups[i]), top, spec.clock_now)
+        rest.append(time.perf_counter() - t0)
+        assert r[0] == one[len(rest) - 1]
+    cal_n, cal_p = min(4096, args.nodes), 2
+    sub = spec.shard(0, cal_n).build_nodes()
+    t0 = time.perf_counter()
+    for k in range(cal_p):
+        nhd_oracle.find_node(nhd_oracle.initial_node_filter(sub, groups[k]), refmodel.make_topology(pods[k]), spec.clock_now)
+    cal = time.perf_counter() - t0
     print(json.dumps({
         "what": "unmodified reference nhd.Matcher.Matcher().FindNode (nhd/Matcher.py:27-63), logging disabled, stdout swallowed, on bench.py's inputs",
         "config": args.config, "nodes": args.nodes, "pods_in_batch": args.pods_total, "sampled_pods": idx,
@@ -96,6 +116,10 @@ def main():
         "one_core": {"seconds_per_pod": per_pod, "evals_per_s": n_eval / sum(per_pod), "decisions_per_s": len(idx) / sum(per_pod), "cores": 1},
         "all_cores": {"processes": args.procs, "wall_s_incl_cluster_build": wall_mp, "slowest_worker_findnode_s": busy_mp,
                       "evals_per_s": n_eval / busy_mp, "decisions_per_s": len(idx) / busy_mp, "cores": args.procs},
+        "python_restatement": {"what": "oracle/nhd_oracle.py (linear in N; the reference's IntersectResources is quadratic) on the same pods x nodes, same host, 1 core",
+                               "seconds_per_pod": rest, "evals_per_s": n_eval / sum(rest),
+                               "calibration": {"sample": "first %d pods x first %d nodes (bench.py python_oracle_sample times the same on the GPU box)" % (cal_p, cal_n),
+                                               "seconds": cal, "evals_per_s": cal_p * cal_n / cal}},
         "parity": "winners identical: reference (1 core) == reference (sharded, merged) == oracle C port, on every sampled pod"}))
 
 
