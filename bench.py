@@ -224,6 +224,7 @@ def main():
         out["other_configs"] = other_configs(args, local_rank)
         out["deltas"] = delta_rate(eng, table)
         out["big_pod_find"] = big_pod_find(eng, pk, pods, pod_groups, tops, reqs, now, n_total)
+        out["sched_loop"] = sched_loop(args.config, local_rank)
         out["score_only"] = score_only(eng, reqs, now, args.pods, n_total)     # last: it changes the context's outputs
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not inner:
         out["cpu_baseline"] = cpu_baseline(spec, tops, pod_groups, args.cpu_sample_pods, score, lo, winner_index, args)
@@ -534,6 +535,58 @@ def big_pod_find(eng, pk, pods, pod_groups, tops, reqs, now, n_total, calls=12):
                            "against": "the table-driven pass on the same (ordinary) pods digested both ways: score words and mappings"}}
     except Exception as e:  # noqa: BLE001 - an extra must not cost the run its line
         return {"error": f"{type(e).__name__}: {e}"}
+
+
+def sched_loop(cfg, device, n=16384, P=1024):
+    """Row f4 as a number of the run: what a scheduler gets THROUGH the drop-in class (nhd_amd.matcher.HipMatcher, attached to
+    its node dict - Python above the C-ABI included), in placement decisions per second with every winner committed before the
+    next pod is matched (nhd/NHDScheduler.py:249-353, 425-437): (1) pod by pod - FindNodes(nodes, [top], pod_groups=[groups])
+    (the kernel applies InitialNodeFilter) + CommitPlacement (nhdfit_commit on the mirror, physical ids expanded); (2) pod by
+    pod the reference's way - the scheduler builds the filtered dict first (InitialNodeFilter's O(N) Python loop per pod), then
+    FindNode(filtered, top) + CommitPlacement; (3) the pending list as ONE ScheduleBatch (decided and committed on the device,
+    physical ids of every pod expanded).  Node objects: workload.refmodel stand-ins built from the same NFD labels; the
+    reference's own bookkeeping on its Node objects (SetPhysicalIdsFromMapping in Python) is the scheduler's cost and not timed
+    here - tools/time_sched_loop.py times the loop with a stand-in for it (profiles/r06).  All three must make the same
+    decisions and produce the same ids: asserted.  Never raises: an error is reported in place."""
+    try:
+        from nhd_amd.matcher import HipMatcher
+        from workload import refmodel, synth
+        spec = synth.make_cluster(cfg, n_nodes=n)
+        pods, groups = synth.make_pods(cfg, n_pods=P)
+        tops = [refmodel.make_topology(s) for s in pods]
+        now = spec.clock_now
+        res = {}
+        for leg in ("batched", "pod_by_pod_kernel_filter", "pod_by_pod_filtered_dict"):
+            nodes = spec.build_nodes()
+            m = HipMatcher(device=device, clock=lambda: now)
+            m.attach(nodes)
+            if leg == "pod_by_pod_filtered_dict":
+                want = [set(g) for g in groups]
+            t0 = time.perf_counter()
+            if leg == "batched":
+                got = m.ScheduleBatch(nodes, tops, pod_groups=groups, now=now, apply=True)
+                ids = list(m.last_placements)
+            else:
+                got, ids = [], []
+                for k, top in enumerate(tops):
+                    if leg == "pod_by_pod_kernel_filter":
+                        r = m.FindNodes(nodes, [top], pod_groups=[groups[k]])[0]
+                    else:       # nhd/NHDScheduler.py:235-247: keep node iff its groups meet the pod's and it is active
+                        filt = {nm: nd for nm, nd in nodes.items() if nd.active and not want[k].isdisjoint(nd.groups)}
+                        r = m.FindNode(filt, top)
+                    got.append(r)
+                    ids.append(m.CommitPlacement(r[0], top, r[1], busy_time=now) if r[0] is not None else None)
+            dt = time.perf_counter() - t0
+            res[leg] = (dt, got, ids)
+            m.engine.close()
+        same = all(res[leg][1] == res["batched"][1] and res[leg][2] == res["batched"][2] for leg in res)
+        out = {"nodes": n, "pending_pods": P, "config": cfg, "placed": sum(r[0] is not None for r in res["batched"][1]), "identical_decisions_and_ids": bool(same),
+               "call": "HipMatcher attached to the scheduler's node dict; every winner committed on the device mirror before the next pod is matched"}
+        for leg, (dt, _, _) in res.items():
+            out[leg] = {"pods_per_s": P / dt, "us_per_pod": dt / P * 1e6}
+        return out
+    except Exception as e:  # noqa: BLE001 - an extra must not cost the run its line
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def pack_mod():

@@ -1326,8 +1326,24 @@ int flush_pipeline(nhdfit_ctx* c) {
                 a.m[a.nsteps++] = make_map_args(c, p, b);
             }
             c->side_streams_used = true;
+            const bool drain_prof = tune_env("NHDFIT_DRAIN_PROF") != nullptr;      // tuning aid: where a drain launch's time goes
+            if (drain_prof) {
+                HIPCHK(c, c->role_clock.reserve(16));
+                unsigned long long init[16] = {0};
+                init[7] = ~0ull;
+                HIPCHK(c, hipMemcpyAsync(c->role_clock.p, init, sizeof init, hipMemcpyHostToDevice, p.stream));
+                a.clk = c->role_clock.p;
+            }
             hipLaunchKernelGGL(k_map_tiles, dim3(a.nsteps * tiles), dim3(256), map_tile_lds_bytes<256>(), p.stream, a);
             HIPCHK(c, hipGetLastError());
+            if (drain_prof) {
+                unsigned long long t[16];
+                HIPCHK(c, wait_stream(p.stream));
+                HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[nhdfit] drain of %u step(s) x %u tiles: staged +%.2f, NIC bits / masks / key +%.2f, shapes de-duplicated +%.2f, state machine +%.2f, "
+                                "generic shapes +%.2f, finish +%.2f us after a block's start (latest block each); first block start to last block end %.2f us\n",
+                        a.nsteps, tiles, t[0] * 0.01, t[1] * 0.01, t[2] * 0.01, t[3] * 0.01, t[4] * 0.01, t[5] * 0.01, (t[6] - t[7]) * 0.01);
+            }
             p.n_finished += a.nsteps;
         }
         p.n_shaped = p.n_chosen = p.n_finished;
@@ -2240,8 +2256,16 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     // GPU-less pod (the multiset of their commits), one bit per pod; the optional tables go in after those.
     const uint32_t n_gpu_less = c->tn_n;
     const uint32_t hash_slots = decide_hash_slots(n_gpu_less);
-    const size_t dyn_base = 2 * lds_slice((size_t)chunks * 8) + lds_slice((size_t)hash_slots * 4) + lds_slice((size_t)((P + 31) / 32) * 4);
-    bool fast = !c->seq_general && dyn_base <= 64 * 1024 && c->n > 0 && P < (1u << 26);
+    // (the two node bit maps may stop short of the mirror - DecideArgs::span: config 5's whole cluster is 4 096 chunks, 64 KB on their own;
+    // they then cover what the 64 KB leave, at least 512 chunks, and a decision past them sends the batch to the general kernel)
+    const size_t dyn_fixed = lds_slice((size_t)hash_slots * 4) + lds_slice((size_t)((P + 31) / 32) * 4);
+    uint32_t span = chunks;
+    if (2 * lds_slice((size_t)chunks * 8) + dyn_fixed > 64 * 1024)
+        span = dyn_fixed + 2 * 512 * 8 <= 64 * 1024 ? (uint32_t)((64 * 1024 - dyn_fixed) / 16) & ~15u : 0u;
+    static const uint32_t force_span = tune_env("NHDFIT_SEQ_SPAN") ? (uint32_t)atoi(tune_env("NHDFIT_SEQ_SPAN")) : 0u;   // tuning aid (tests of the fallback)
+    if (force_span && force_span < span) span = force_span;
+    const size_t dyn_base = 2 * lds_slice((size_t)span * 8) + dyn_fixed;
+    bool fast = !c->seq_general && span > 0 && c->n > 0 && P < (1u << 26);
     if (fast) {
         queue_len = P * 4u;                                     // a commit per pod + up to three patch items per commit of a GPU-less pod
         HIPCHK(c, c->seq_queue.reserve(queue_len));
@@ -2257,6 +2281,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         memset(&qa, 0, sizeof qa);
         qa.list_n = list_dev; qa.n_n = n_n; qa.list_g = list_dev + n_n; qa.n_g = n_g; qa.ent_n = c->seq_ent.p; qa.ent_g = c->seq_ent.p + n_n; qa.queue_len = queue_len; qa.ncls = c->ncls;
         qa.hash_slots = hash_slots;
+        qa.span = span;
         qa.dbg = tune_env("NHDFIT_SEQ_SKIP") ? (uint32_t)atoi(tune_env("NHDFIT_SEQ_SKIP")) : 0u;
         qa.s = sa; qa.queue = c->seq_queue.p; qa.ctrl = c->seq_ctrl.p; qa.mat = c->seq_mat.p; qa.flags = c->seq_flags.p;
         size_t dyn = dyn_base;

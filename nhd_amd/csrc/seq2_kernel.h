@@ -34,6 +34,9 @@ struct DecideArgs {
     uint32_t queue_len;          // entries of `queue`
     uint32_t ncls;               // NIC capacity classes of the dictionary
     uint32_t hash_slots;         // block 0's multiset of GPU-less commits (decide_hash_slots)
+    uint32_t span;               // chunks block 0's two node bit maps cover (<= s.chunks).  Shorter than the mirror (config 5's whole cluster: 4 096
+                                 // chunks = 2 x 32 KB of LDS on their own): a decision on a node past the span ends the pass with flags[3] and the
+                                 // host falls back on the general kernel - first fit fills a cluster from the front, a batch seldom gets that far
     uint32_t dbg;                // tuning aid (NHDFIT_SEQ_SKIP, tuning build; results are wrong with it): 1 no first-touch copy, 2 no commit, 4 no result / node stores
 };
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
@@ -643,8 +646,9 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
 
     // ---- block 0: the decision engine ------------------------------------------------------------------------------------
     uint8_t* dynp = s_dyn;
-    uint64_t* s_taken = carve<uint64_t>(dynp, a.chunks);                  // nodes that received a pod of this batch (busy: gone for pods with GPUs)
-    uint64_t* s_tgpu = carve<uint64_t>(dynp, a.chunks);                   // ... a pod with GPUs
+    const uint32_t span = q.span;                                         // the bit maps' reach in chunks (<= a.chunks): no node past it is ever taken
+    uint64_t* s_taken = carve<uint64_t>(dynp, span);                      // nodes that received a pod of this batch (busy: gone for pods with GPUs)
+    uint64_t* s_tgpu = carve<uint64_t>(dynp, span);                       // ... a pod with GPUs
     uint32_t* s_hash = carve<uint32_t>(dynp, q.hash_slots);               // one entry per GPU-less pod retired: its node
     uint32_t* s_isn = carve<uint32_t>(dynp, (a.P + 31) / 32);             // pods without GPUs
     const uint32_t hmask = q.hash_slots - 1u;
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     if (tid < 64) { s_ctag[tid] = kNoNode; s_cver[tid] = 0; }
     if (tid < kSpecWaves) { s_post[tid] = 0; s_verd[tid] = 0; s_examv[tid] = kNoNode; s_pende[tid] = 0xFFFFFFFFu; }
     if (tid < 32) s_cnt[tid] = 0;
-    for (uint32_t k = tid; k < a.chunks; k += 64 * kDecideWaves) { s_taken[k] = 0; s_tgpu[k] = 0; }
+    for (uint32_t k = tid; k < span; k += 64 * kDecideWaves) { s_taken[k] = 0; s_tgpu[k] = 0; }
     for (uint32_t k = tid; k < q.hash_slots; k += 64 * kDecideWaves) s_hash[k] = kNoNode;
     for (uint32_t k = tid; k < (a.P + 31) / 32; k += 64 * kDecideWaves) s_isn[k] = 0;
     if (q.lds_sigs) {
@@ -700,7 +704,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 uint64_t x = w[k];
                 if (c < a.chunks) {
                     if (mode == 1) x &= a.nogpu[c];
-                    else if (mode == 3) x &= ~s_taken[c];
+                    else if (mode == 3) x &= c < span ? ~s_taken[c] : ~0ull;
                     else if (mode == 4) x &= ~a.nogpu[c];
                 } else x = 0;
                 if (c == from_chunk) x &= ~0ull << from_bit;
@@ -716,7 +720,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     // decisions made on node v so far (wave-uniform): the sequencer's two structures
     auto hash_of = [&](uint32_t v) { return (v * 2654435761u) >> 7; };
     auto decisions_on = [&](uint32_t v) -> uint32_t {
-        uint32_t d = (uint32_t)(__hip_atomic_load(&s_tgpu[v >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (v & 63)) & 1u;
+        uint32_t d = (v >> 6) < span ? (uint32_t)(__hip_atomic_load(&s_tgpu[v >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (v & 63)) & 1u : 0u;
         for (uint32_t h = hash_of(v);; h += 64) {
             const uint32_t key = __hip_atomic_load(&s_hash[(h + lane) & hmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const uint64_t eq = __ballot(key == v), em = __ballot(key == kNoNode);
@@ -786,7 +790,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     uint32_t wb = t.from[i] >> 6;
                     if (t.from[i] != kNoNode) {
                         const uint32_t c = wb + lane;
-                        uint64_t w = t.w[i] & (c < a.chunks ? ~s_taken[c] : 0ull);
+                        uint64_t w = t.w[i] & (c < a.chunks ? (c < span ? ~s_taken[c] : ~0ull) : 0ull);
                         if (lane == 0) w &= ~0ull << (t.from[i] & 63u);
                         if (__ballot(w != 0)) { s_win[slot][lane] = w; have = 2; }
                         else if (wb + 64u < a.chunks && scan_window(s_win[slot], t.pos[i], 3u, wb + 64u, 0, wb)) have = 2;
@@ -1076,6 +1080,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     unsigned long long t_ready = 0, t_gpu = 0, t_post = 0, t_retire = 0, t_last = wall_clock64();   // tuning aid, 100 MHz ticks (ctrl[9..12])
     auto lap = [&](unsigned long long& acc) { const unsigned long long t = wall_clock64(); acc += t - t_last; t_last = t; };
     auto take = [&](uint32_t v, bool gpu_pod) {
+        if ((v >> 6) >= span) { give_up(); return; }                          // past the bit maps' reach (wave-uniform): the general kernel decides this batch
         if (lane == 0) {
             atomicOr(reinterpret_cast<unsigned long long*>(&s_taken[v >> 6]), 1ull << (v & 63));
             if (gpu_pod) atomicOr(reinterpret_cast<unsigned long long*>(&s_tgpu[v >> 6]), 1ull << (v & 63));
@@ -1100,7 +1105,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             bool placed = false;
             while (have == 2 && !placed) {
                 const uint32_t c = wbase + lane;
-                const uint64_t w = s_win[slot][lane] & (c < a.chunks ? ~s_taken[c] : 0ull);
+                const uint64_t w = s_win[slot][lane] & (c < a.chunks ? (c < span ? ~s_taken[c] : ~0ull) : 0ull);
                 const uint64_t any = __ballot(w != 0);
                 if (!any) {
                     const uint32_t nb = wbase + 64;
@@ -1134,7 +1139,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 bool retire = true;
                 if (v != kNoNode) {
                     // decisions on v so far, and where the next one goes in the multiset
-                    uint32_t d = (uint32_t)(s_tgpu[v >> 6] >> (v & 63)) & 1u, at = 0;
+                    uint32_t d = (v >> 6) < span ? (uint32_t)(s_tgpu[v >> 6] >> (v & 63)) & 1u : 0u, at = 0;
                     for (uint32_t h = hash_of(v);; h += 64) {
                         const uint32_t key = s_hash[(h + lane) & hmask];
                         const uint64_t eq = __ballot(key == v), em = __ballot(key == kNoNode);

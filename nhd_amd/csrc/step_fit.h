@@ -2,7 +2,14 @@
 // Device code of libnhdfit.so; included by nhdfit.hip inside its anonymous namespace, in this order: step_digest.h,
 // step_fit.h, step_map.h, step_kernel.h, seq_kernel.h (one translation unit: the roles are fused into one kernel).
 // gfx950 only.
-struct FitItem { uint32_t tile, wcls, c_begin, c_end; };       // one block of the fit role: chunks [c_begin, c_end) of a tile
+struct FitItem { uint32_t tile, wcls, c_begin, c_end; };
+#ifndef NHDFIT_FIT_TRACK_SKIP
+#define NHDFIT_FIT_TRACK_SKIP 1     // once every pod of the tile has its winners of a wavefront's run, the winner test of a chunk is one scalar branch
+#endif
+#ifndef NHDFIT_FIT_SWP
+#define NHDFIT_FIT_SWP 3            // bit 0: software-pipelined chunk loop for the W = 2 pair form, bit 1: for W = 4 (A/B builds: -DNHDFIT_FIT_SWP=n;
+                                    // profiles/r06/fit_swp_ab.log: steady step 14.94 -> 14.34 us with both, 14.59 with the first alone)
+#endif       // one block of the fit role: chunks [c_begin, c_end) of a tile
 #ifdef NHDFIT_TUNING
 constexpr bool kTuning = true;        // ablation switches (FitArgs::dbg_skip) are compiled into the tuning build only
 #else
@@ -161,6 +168,47 @@ __device__ __forceinline__ uint64_t sweep_pair_c(const uint8_t* lds, uint32_t a_
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Address of a node's C row (piece 0): row ((smt * D + min(c0, D - 1)) * D + min(c1, D - 1)) of 16 bytes behind off_c.  Every factor
+// is below 2^24: v_min_u32 and v_mad_u32_u24 (full rate) instead of compare + select and the quarter-rate 64-bit multiply-add the
+// plain expression compiles to (round 6).
+__device__ __forceinline__ uint32_t pair_row_addr(uint32_t rec_w, uint32_t pD, uint32_t off_c) {
+    const uint32_t cw = rec_w >> 16, c0 = cw & 127u, c1 = (cw >> 7) & 127u, top = pD - 1u;
+    const uint32_t r0 = ((0u - (cw >> 14)) & pD) + (c0 < top ? c0 : top);        // (smt is 0 or 1)
+    return off_c + ((__umul24(r0, pD) + (c1 < top ? c1 : top)) << 4);
+}
+
+// One chunk's rows in flight for the software-pipelined sweep (pair form): everything the verdict word of a node needs from LDS.
+template <int W>
+struct PairRows { uint4 cp[W / 2], x0[W / 2], x1[W / 2]; uint2 gx, hp; };
+template <int W>
+__device__ __forceinline__ PairRows<W> fetch_pair_rows(const uint8_t* lds, const uint4 rv, uint32_t pD, uint32_t off_c, uint32_t c_plane,
+                                                       uint32_t hot_hp, uint32_t hp_last) {
+    PairRows<W> r;
+    const uint32_t a_x0 = (rv.y & 0xFFFFu) << 3, a_x1 = (rv.y >> 16) << 3, a_gx = (rv.z & 0xFFFFu) << 3;
+    const uint32_t hp = (rv.z >> 16) & 1023u;
+    const uint32_t a_hp = hot_hp + (hp < hp_last ? hp : hp_last) * 8;
+    const uint32_t a_c = pair_row_addr(rv.w, pD, off_c);
+#pragma unroll
+    for (int q = 0; q < W / 2; ++q) {
+        r.cp[q] = lds16(lds, a_c + q * c_plane);
+        r.x0[q] = lds16(lds, a_x0 + q * 16);
+        r.x1[q] = lds16(lds, a_x1 + q * 16);
+    }
+    r.gx = lds8(lds, a_gx);
+    r.hp = lds8(lds, a_hp);
+    return r;
+}
+template <int W>
+__device__ __forceinline__ uint64_t pair_rows_word(const PairRows<W>& r) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int q = 0; q < W / 2; ++q) {
+        lo |= __builtin_amdgcn_bitop3_b32(r.cp[q].x, r.x0[q].x, r.x1[q].x, 0x80) | __builtin_amdgcn_bitop3_b32(r.cp[q].z, r.x0[q].z, r.x1[q].z, 0x80);
+        hi |= __builtin_amdgcn_bitop3_b32(r.cp[q].y, r.x0[q].y, r.x1[q].y, 0x80) | __builtin_amdgcn_bitop3_b32(r.cp[q].w, r.x0[q].w, r.x1[q].w, 0x80);
+    }
+    return ((uint64_t)(hi & r.gx.y & r.hp.y) << 32) | (lo & r.gx.x & r.hp.x);
+}
+
 // The P x N pass.  Block = chunks [c_begin, c_end) of one pod tile: the hot section of the tile's table image is
 // staged in LDS, every wavefront sweeps a contiguous run of 64-node chunks (lane = node: one 16-byte record and
 // the busy time per node), writes the node-major verdict word and tracks the tile's first-fit winners.
@@ -172,9 +220,13 @@ __device__ __forceinline__ uint64_t sweep_pair_c(const uint8_t* lds, uint32_t a_
 // transposed (lane = pod) and scored.
 // PAIR: 0 = six row fetches per pair of assignments; 1 = C tabulated in LDS (three).
 // The lanes of a chunk work in the records' order (NodeRec::hp names the node's position in the chunk, fit_core.h "lane order").
-template <int BLOCK, int W, bool SPILL, int PAIR = 0>
+// SWP (pair form only): the chunk loop software-pipelined - the NEXT chunk's row fetches are in the LDS queue while this chunk's words are
+// combined, stored and tracked, the record after that is on its way from L2 (round 6; the form of round 2 was bound by an LDS pipe that
+// spent half of its cycles on bank conflicts - they are gone since round 5).
+template <int BLOCK, int W, bool SPILL, int PAIR = 0, bool SWP = false>
 __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_from, const FitItem it, uint8_t* lds) {
     static_assert(PAIR == 0 || (!SPILL && W <= 4), "pair tables: narrow tiles, whole hot section staged");
+    static_assert(!SWP || PAIR == 1, "the pipelined loop is the pair form's");
     constexpr int NW = BLOCK / 64;
     const uint32_t dbg = kTuning ? a.dbg_skip : 0u;
     // the argument block may live behind a pointer (k_step_p): what the chunk loop uses is read once, here
@@ -253,6 +305,59 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
     const size_t npad = (size_t)a.chunks * 64;
     // the next chunk's record and busy time are requested before this chunk is worked on: a wavefront's chunks are
     // one dependent chain of L2 round trips otherwise
+    if constexpr (SWP) {
+        // Two register sets that swap roles every chunk (the loop is unrolled by two: rotating ONE set through copies would make every
+        // iteration wait for the loads it has just issued).  At the top of a step for chunk c: rows(c) are in the LDS queue or back (qa),
+        // record(c) is back (ra / ba), record(c + 1) is on its way (rb / bb).  The step requests record(c + 2) into the registers of
+        // record(c) - whose address fields were consumed by the row fetch one step ago; position, GPU-less flag and busy time are
+        // copied out first -, fetches rows(c + 1), then combines / stores / tracks chunk c.  Past the run's end the last chunk's record
+        // is requested again (harmless).
+        const uint32_t c_stop = c_last - 1u;
+        auto rec_of = [&](uint32_t c) { return *reinterpret_cast<const uint4*>(recs + (c < c_stop ? c : c_stop) * 64 + lane); };
+        auto bt_of = [&](uint32_t c) { return bts[(c < c_stop ? c : c_stop) * 64 + lane]; };
+        auto step = [&](const uint32_t c, const PairRows<W>& qa, uint4& ra, double& ba, PairRows<W>& qb, const uint4& rb) {
+            const uint32_t pos = ra.z >> 26;
+            const bool nogpu = (ra.w & kRecNoGpu) != 0;
+            const bool busy = ba >= busy_from;                                  // Node.IsBusy, nhd/Node.py:847-850
+            ra = rec_of(c + 2);
+            ba = bt_of(c + 2);
+            qb = fetch_pair_rows<W>(lds, rb, pD, off_c, c_plane, hot_hp, hp_last);
+            const uint64_t okm = pair_rows_word<W>(qa);
+            uint32_t wlo = (uint32_t)okm, whi = (uint32_t)(okm >> 32);
+            if (busy) { wlo &= ~(uint32_t)m_need; whi &= ~(uint32_t)(m_need >> 32); }      // Matcher.py:107-111
+            if (cand) {
+                const uint64_t cw = cand[c];
+                if (!(cw >> pos & 1)) wlo = whi = 0;
+            }
+            if (nm) nm[(size_t)tile * npad + c * 64 + pos] = ((uint64_t)whi << 32) | wlo;
+            const uint32_t nlo = (uint32_t)need_any | (nogpu ? (uint32_t)need_pref : 0u);
+            const uint32_t nhi = (uint32_t)(need_any >> 32) | (nogpu ? (uint32_t)(need_pref >> 32) : 0u);
+            if (NHDFIT_FIT_TRACK_SKIP && !(need_any | need_pref)) return;      // every pod of the tile has its winner of this run: nothing left to track (wave-uniform)
+            if (__ballot(((wlo & nlo) | (whi & nhi)) != 0)) {
+                wlo = (uint32_t)__builtin_amdgcn_ds_permute((int)(pos << 2), (int)wlo);
+                whi = (uint32_t)__builtin_amdgcn_ds_permute((int)(pos << 2), (int)whi);
+                const uint64_t nogpu_mask = __ballot(__builtin_amdgcn_ds_permute((int)(pos << 2), nogpu ? 1 : 0) != 0);
+                transpose64(wlo, whi);
+                const uint64_t word = ((uint64_t)whi << 32) | wlo;
+                const uint64_t pref = my_pod_needs_gpu ? 0ull : word & nogpu_mask;
+                if (word && best_any == ~0u) best_any = c * 64 + (uint32_t)__builtin_ctzll(word);
+                if (pref && best_pref == ~0u) best_pref = c * 64 + (uint32_t)__builtin_ctzll(pref);
+                need_any &= ~__ballot(word != 0);
+                need_pref &= ~__ballot(pref != 0);
+            }
+        };
+        if (c_first < c_last) {
+            uint4 r0 = rv, r1 = rec_of(c_first + 1);
+            double b0 = bt, b1 = bt_of(c_first + 1);
+            PairRows<W> q0 = fetch_pair_rows<W>(lds, r0, pD, off_c, c_plane, hot_hp, hp_last), q1;
+            uint32_t c = c_first;
+            for (; c + 1 < c_last; c += 2) {
+                step(c, q0, r0, b0, q1, r1);
+                step(c + 1, q1, r1, b1, q0, r0);
+            }
+            if (c < c_last) step(c, q0, r0, b0, q1, r1);
+        }
+    } else
     for (uint32_t c = c_first; c < c_last; ++c) {
         const uint32_t i = c * 64 + lane;
         uint4 rv_next = rv;
@@ -275,9 +380,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
         else if constexpr (PAIR == 0)
             okm = (dbg & 1) ? ((uint64_t)rv.y << 32 | rv.x) : sweep_assignments<W>(hot, a_w0, a_w1, a_x0, a_x1);
         else {
-            const uint32_t cw = rv.w >> 16, c0 = cw & 127u, c1 = (cw >> 7) & 127u;
-            const uint32_t a_c = off_c + (((cw >> 14) * pD + (c0 < pD ? c0 : pD - 1)) * pD + (c1 < pD ? c1 : pD - 1)) * 16;
-            okm = sweep_pair_c<W>(lds, a_c, c_plane, a_x0, a_x1);
+            okm = sweep_pair_c<W>(lds, pair_row_addr(rv.w, pD, off_c), c_plane, a_x0, a_x1);
         }
         const uint2 gx = (dbg & 8) ? make_uint2(rv.z, rv.w) : lds8(hot, a_gx), hpw = (dbg & 8) ? make_uint2(~0u, ~0u) : lds8(hot, a_hp);
         const bool busy = bt >= busy_from;                                  // Node.IsBusy, nhd/Node.py:847-850
@@ -292,7 +395,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
         // (3) does this chunk change any pod's winner?
         const uint32_t nlo = (uint32_t)need_any | (nogpu ? (uint32_t)need_pref : 0u);
         const uint32_t nhi = (uint32_t)(need_any >> 32) | (nogpu ? (uint32_t)(need_pref >> 32) : 0u);
-        if (!(dbg & 2) && __ballot(((wlo & nlo) | (whi & nhi)) != 0)) {
+        if (!(dbg & 2) && (!NHDFIT_FIT_TRACK_SKIP || (need_any | need_pref)) && __ballot(((wlo & nlo) | (whi & nhi)) != 0)) {
             // back to node order first (rare path): lane p receives the words of the lane that worked on node c * 64 + p
             wlo = (uint32_t)__builtin_amdgcn_ds_permute((int)(pos << 2), (int)wlo);
             whi = (uint32_t)__builtin_amdgcn_ds_permute((int)(pos << 2), (int)whi);
@@ -345,8 +448,8 @@ __device__ __forceinline__ void role_fit(const FitArgs& a, const double busy_fro
     it.c_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_end);
     if constexpr (!SPILL) {                          // narrow tiles whose pair table fits the launch's LDS (refresh_layouts)
         if (it.wcls <= 1 && a.pair_D[it.wcls]) {
-            if (it.wcls == 0) role_fit_w<BLOCK, 2, false, 1>(a, busy_from, it, lds);
-            else role_fit_w<BLOCK, 4, false, 1>(a, busy_from, it, lds);
+            if (it.wcls == 0) role_fit_w<BLOCK, 2, false, 1, (NHDFIT_FIT_SWP & 1) != 0>(a, busy_from, it, lds);
+            else role_fit_w<BLOCK, 4, false, 1, (NHDFIT_FIT_SWP & 2) != 0>(a, busy_from, it, lds);
             return;
         }
     }

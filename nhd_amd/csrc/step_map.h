@@ -305,7 +305,10 @@ __device__ __forceinline__ void role_finish(const MapArgs& a, const ShapeArgs& h
 // `tile`: which tile of the staged batch (k_find: its only one; k_map_tiles: any).
 template <int THREADS, bool LONE = false>
 __device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& h, uint32_t wcls, uint8_t* lds, const LoneMasks* lone = nullptr,
-                                             uint32_t tile = 0) {
+                                             uint32_t tile = 0, unsigned long long* clk = nullptr) {
+    // tuning aid (k_map_tiles, NHDFIT_DRAIN_PROF): the latest time after the block's start at which any block passed phase k -> clk[k]
+    const unsigned long long t_blk = kTuning && clk ? (unsigned long long)wall_clock64() : 0ull;
+    auto lap = [&](int k) { if (kTuning && clk && threadIdx.x == 0) atomicMax(&clk[k], (unsigned long long)wall_clock64() - t_blk); };
     static_assert(THREADS / 4 == kTile, "the pods of the tile are one wavefront");
     const uint32_t pod0 = tile * kTile;
     // The set-layout state machine of the three-group shapes is ~40 DEPENDENT look-ups per shape: against global memory that is
@@ -324,6 +327,7 @@ __device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& 
         lst = SetStates{l_info, l_next, l_asc, h.st.n};                   // (stage_winners' barriers below order the copies)
     }
     const MapStage st = stage_winners<THREADS>(a, pod0, lds);
+    lap(0);
     const uint32_t j = threadIdx.x;
     if (j < (uint32_t)kTile) {
         const uint32_t lane = j;
@@ -352,6 +356,7 @@ __device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& 
                     key = shape_key((int)rq.n_groups, w.U, sg, sc, codes);
             }
         }
+        lap(1);
         unsigned long long todo = __ballot(key != 0ull), mine = 0;
         uint32_t nd = 0;
         while (todo) {                                                    // distinct shapes: lane nd keeps the nd-th
@@ -362,6 +367,7 @@ __device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& 
             todo &= ~__ballot(key == k);
             ++nd;
         }
+        lap(2);
         uint32_t res = 0;                                                 // (2) the set model per distinct shape
         bool generic = false;
         if (lane < nd) {
@@ -371,6 +377,7 @@ __device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& 
             else
                 generic = true;
         }
+        lap(3);
         unsigned long long gtodo = __ballot(generic);
         while (gtodo) {
             const int jj = __builtin_ctzll(gtodo);
@@ -390,11 +397,13 @@ __device__ __forceinline__ void map_one_tile(const MapArgs& a, const ShapeArgs& 
             r = (uint32_t)__shfl((int)r, 0, 64);
             if ((int)lane == jj) res = r;
         }
+        lap(4);
         const uint32_t got = (uint32_t)__shfl((int)res, slot >= 0 ? slot : 0, 64);      // (3) first valid NIC choice under the chosen tuples
         if (live && slot != -1) {
             const uint32_t rr = slot >= 0 ? got : (uint32_t)(-2 - slot);
             if (rr >> 8 & 1) finish_mapping(rq, staged_state(st, j), (rr >> 4) & 7u, (int)(rr & 15u), m);
         }
+        lap(5);
     }
     __syncthreads();
     const uint32_t livep = pod0 < a.P ? (a.P - pod0 < (uint32_t)kTile ? a.P - pod0 : (uint32_t)kTile) : 0u;
@@ -415,10 +424,13 @@ struct DrainArgs {
     uint32_t nsteps, tiles;
     MapArgs m[kDrainSteps];
     ShapeArgs h;                      // its static tables only (asc, choose_tab, st); the per-step shape buffers are not used
+    unsigned long long* clk;          // tuning aid (NHDFIT_DRAIN_PROF): [0..5] latest time after a block's start at which a phase was passed, [6] the launch's span
 };
 __global__ __launch_bounds__(256) void k_map_tiles(DrainArgs a) {
     extern __shared__ __align__(16) uint8_t lds_drain[];
     const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / a.tiles)), tile = blockIdx.x - s * a.tiles;
     const MapArgs& m = a.m[s < (uint32_t)kDrainSteps ? s : 0];
-    map_one_tile<256>(m, a.h, m.tile_wcls[tile], lds_drain, nullptr, tile);
+    const unsigned long long t0 = kTuning && a.clk ? (unsigned long long)wall_clock64() : 0ull;
+    map_one_tile<256>(m, a.h, m.tile_wcls[tile], lds_drain, nullptr, tile, kTuning ? a.clk : nullptr);
+    if (kTuning && a.clk && threadIdx.x == 0) { atomicMin(&a.clk[7], t0); atomicMax(&a.clk[6], (unsigned long long)wall_clock64()); }
 }

@@ -263,13 +263,13 @@ class HipMatcher:
     def _on_commit(self, node, mapping, top) -> bool:
         """After the reference's own SetPhysicalIdsFromMapping succeeded on an attached node: the same commit on the
         device mirror, checked against what the reference just wrote into `top`.  True = the mirror is current."""
-        if self._attached is None or node.name not in self._index or node.name in self._dirty_strict or self._off_planes(node.name):
+        if self._attached is None or node.name not in self._index or self._waits_for_repack(node.name) or self._off_planes(node.name):
             self._batch_ids.pop(node.name, None)
             return False
         pending = self._batch_ids.get(node.name)
         if not pending and self._deltas:
             self._flush_deltas()                               # releases queued before this commit reach the device first
-            if node.name in self._dirty_strict:
+            if self._waits_for_repack(node.name):
                 return False
         from_batch = bool(pending)
         if pending:                                            # ScheduleBatch(apply=True) committed this placement on the device already
@@ -316,7 +316,7 @@ class HipMatcher:
     def _on_topology(self, node, name, top) -> bool:
         """After the reference's RemoveResourcesFromTopology / AddResourcesFromTopology ran on an attached node: the same
         change as a delta record for nhdfit_apply_deltas (sent with the next flush).  True = no re-pack needed."""
-        if self._attached is None or node.name not in self._index or node.name in self._dirty_strict or self._off_planes(node.name):
+        if self._attached is None or node.name not in self._index or self._waits_for_repack(node.name) or self._off_planes(node.name):
             return False
         try:
             op = pack.DELTA_TAKE if name == "RemoveResourcesFromTopology" else pack.DELTA_GIVE
@@ -326,7 +326,7 @@ class HipMatcher:
         return True
 
     def _on_queued_scalar(self, node, what: str) -> bool:
-        if self._attached is None or node.name not in self._index or node.name in self._dirty_strict or self._off_planes(node.name):
+        if self._attached is None or node.name not in self._index or self._waits_for_repack(node.name) or self._off_planes(node.name):
             return False
         self._deltas.append(self.packer.delta_scalar(self._index[node.name], node, what))
         return True
@@ -336,8 +336,7 @@ class HipMatcher:
         state without a signature) is re-packed from its object like any other dirty node."""
         if not self._deltas:
             return
-        strict = self._dirty_strict
-        q = [d for d in self._deltas if self._names[int(d["node"])] not in strict]
+        q = [d for d in self._deltas if not self._waits_for_repack(self._names[int(d["node"])])]
         self._deltas = []
         if not q:
             return
@@ -347,7 +346,7 @@ class HipMatcher:
         for d, st in zip(q, status):
             if st != pack.DELTA_OK:
                 name = self._names[int(d["node"])]
-                if name not in self._dirty_strict:
+                if not self._waits_for_repack(name):
                     self.delta_stats["repacked"] += 1
                 self._mark(self._attached[name], "delta-status")
 
@@ -355,11 +354,16 @@ class HipMatcher:
         self._dirty[node.name] = node
         self._reasons.setdefault(node.name, set()).add(reason)
 
+    def _waits_for_repack(self, name: str) -> bool:
+        """The node waits for a re-pack: its pending change is more than writes to scalar fields (those travel as deltas of their
+        own and commute with commits and releases).  Asked per node: every commit of a pending list asks it, and a set over ALL
+        dirty nodes per question made the scheduler's loop quadratic in the list's length (round 6: 512 pods, 109 k look-ups)."""
+        return name in self._dirty and (not self._reasons.get(name, {""}) <= self._SCALAR_REASONS or self._off_planes(name))
+
     @property
     def _dirty_strict(self):
-        """Nodes that wait for a re-pack: their pending change is more than writes to scalar fields (those travel as deltas
-        of their own and commute with commits and releases)."""
-        return {nm for nm in self._dirty if not self._reasons.get(nm, {""}) <= self._SCALAR_REASONS or self._off_planes(nm)}
+        """All such nodes (diagnostics and tests; the hot paths ask _waits_for_repack)."""
+        return {nm for nm in self._dirty if self._waits_for_repack(nm)}
 
     def mark_dirty(self, name: str) -> None:
         if self._attached is not None and name in self._attached:

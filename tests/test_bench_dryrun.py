@@ -69,6 +69,13 @@ def test_bench_json_contract(tmp_path):
     par = out["mode_b"]["parity"]
     assert par["identical"] and par["pods_checked"] == 96 and out["mode_b"]["commits_that_would_raise"] == 0
     assert out["repeats"]["n"] == 5 and out["cpu_baseline"]["python_restatement"]["value"] > 0
+    sl = out["sched_loop"]                                    # row f4 through the drop-in class: three ways to serve a pending list, same decisions and ids
+    assert "error" not in sl, sl
+    assert sl["identical_decisions_and_ids"] and sl["placed"] > 0 and sl["batched"]["pods_per_s"] > 0 and sl["pod_by_pod_kernel_filter"]["pods_per_s"] > 0
+    rf = out["roofline"]                                      # flat scalars (the driver's record keeps scalars only)
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["frac"] == rf["frac_kernel"] and "frac_wall" in rf
+    for key in ("hbm_counter_frac", "lds_frac", "valu_issue_frac", "wait_frac", "bank_conflict_share"):
+        assert key in rf, key
     big = out["big_pod_find"]                                 # pods beyond the table pass: the leg runs, its in-run parity holds
     assert "error" not in big and big["parity"]["identical"] and big["parity"]["pods"] > 0 and big["calls"] > 0
 
@@ -142,3 +149,27 @@ def test_bench_strong_scaling_shape(tmp_path):
     out = json.loads([ln for ln in outs[0][0].splitlines() if ln.strip()][0])
     assert out["scaling"] == "strong" and out["n_gpus"] == 2
     assert out["config"]["nodes_total"] == 1500 and out["config"]["nodes_per_gpu"] == 750
+
+
+_FOUR_SCRIPT = _RANK_SCRIPT.replace('"--gpus", "2"', '"--gpus", "4"').replace('"--nodes-per-gpu", "512", "--pods", "40"', '"--config", "4", "--total-nodes", "1200", "--pods", "48", "--no-extras"')
+
+
+def test_bench_four_ranks_strong_shape(tmp_path):
+    """`bench.py --gpus 4 --config 4 --total-nodes N` - BASELINE config 4's own multi-GPU shape - at FOUR ranks on the host twin
+    (the first 8-GPU box must meet no untested rank count): one JSON line from rank 0, strong scaling,
+    the node axis cut four ways, every pod placed somewhere."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "four.py"
+    script.write_text(_FOUR_SCRIPT.format(root=ROOT, bench=os.path.join(ROOT, "bench.py")))
+    procs = []
+    for rank in range(4):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all(not o[0].strip() for o in outs[1:])
+    out = json.loads([ln for ln in outs[0][0].splitlines() if ln.strip()][0])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 4 and out["config"]["nodes_total"] == 1200 and out["config"]["nodes_per_gpu"] == 300
+    assert out["placed_pods"] > 0

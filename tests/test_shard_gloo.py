@@ -26,8 +26,11 @@ def _free_port():
     return port
 
 
-def _problem(cfg, n, P):
+def _problem(cfg, n, P, world=0):
     spec = synth.make_cluster(cfg, n_nodes=n)
+    if world == 4:                                   # four ranks: the second shard holds no node a pod can take (every one under maintenance) -
+        lo, hi = shard.shard_bounds(n, world, 1)     # the ring must carry its pods THROUGH a rank that places nothing
+        spec.maintenance[lo:hi] = True
     pods, groups = synth.make_pods(cfg, n_pods=P)
     tops = [refmodel.make_topology(s) for s in pods]
     return spec, tops, groups
@@ -70,7 +73,7 @@ def test_two_rank_sharding_equals_single_shard(tmp_path, cfg, n, P):
 def _worker_mode_b(rank, world, port, cfg, n, P, out_dir, chunk=512):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    spec, tops, groups = _problem(cfg, n, P)
+    spec, tops, groups = _problem(cfg, n, P, world)
     lo, hi = shard.shard_bounds(n, world, rank)
     sub = spec.shard(lo, hi)
     pk = pack.Packer()
@@ -94,7 +97,7 @@ def _worker_mode_b(rank, world, port, cfg, n, P, out_dir, chunk=512):
 # (clusters small enough for the pods to spill into the later shards - first-fit fills shard 0 first: 130 / 70, 92 / 8 / 0, 79 / 42 / 39
 #  pods per shard; with the 600-node clusters this list used to hold, every pod stayed in shard 0 and only empty lists travelled)
 @pytest.mark.parametrize("cfg,n,P,world,chunk", [(4, 256, 200, 2, 512), (5, 256, 100, 3, 512), (4, 192, 160, 3, 512), (2, 128, 160, 2, 512),
-                                                  (4, 256, 200, 2, 48), (5, 256, 100, 3, 37), (4, 192, 160, 3, 16)])
+                                                  (4, 256, 200, 2, 48), (5, 256, 100, 3, 37), (4, 192, 160, 3, 16), (4, 256, 230, 4, 64)])
 def test_mode_b_one_process_per_shard_equals_the_scheduler_loop(tmp_path, cfg, n, P, world, chunk):
     """nhd_amd.sharding.schedule_batch_sharded under gloo (host twin per shard; the product's ring over workload.dist.TorchTransport
     instead of RcclTransport): every rank ends up with the decisions, mappings and physical ids the oracle's one-by-one loop over
@@ -103,7 +106,7 @@ def test_mode_b_one_process_per_shard_equals_the_scheduler_loop(tmp_path, cfg, n
     from oracle import nhd_oracle as O
     port = _free_port()
     mp.spawn(_worker_mode_b, args=(world, port, cfg, n, P, str(tmp_path), chunk), nprocs=world, join=True)
-    spec, tops, groups = _problem(cfg, n, P)
+    spec, tops, groups = _problem(cfg, n, P, world)
     nl = spec.build_nodes()
     names = list(nl)
     ids = []
@@ -126,6 +129,9 @@ def test_mode_b_one_process_per_shard_equals_the_scheduler_loop(tmp_path, cfg, n
     assert (want_node >= 0).sum() >= 20
     lo1 = shard.shard_bounds(n, world, 1)[0]
     assert (want_node >= lo1).sum() >= 5, "the case must send pods past the first shard"
+    if world == 4:
+        lo1, hi1 = shard.shard_bounds(n, world, 1)
+        assert ((want_node >= lo1) & (want_node < hi1)).sum() == 0 and (want_node >= hi1).sum() >= 5, "pods must pass through the empty shard"
 
 
 def test_order_preserving_score_encoding():
