@@ -527,9 +527,27 @@ NHD_HD uint64_t node_word_cold(const uint8_t* img, const Layout& L, const NodeId
 // ColdView: the four layout words that addressing needs (kernel arguments carry these instead of whole Layouts).
 struct ColdView { uint32_t off_r0, off_r1, row, W; };
 NHD_HD ColdView cold_view(const Layout& L) { return ColdView{L.off_r0, L.off_r1, L.row, L.W}; }
+// (every word of both rows is requested before the first is looked at: with the row width as a run-time loop bound and a branch per
+//  assignment the 2 W loads were W dependent round trips to L2 - 8 us of a drain launch's 34 for a three-group tile, round 6)
+template <uint32_t W>
+NHD_HD uint32_t nic_assignment_bits_w(const uint8_t* img, uint32_t o0, uint32_t o1, uint32_t col) {
+    uint64_t x[W];
+#pragma unroll
+    for (uint32_t p = 0; p < W; ++p) x[p] = ld64(img, o0 + p * 8) & ld64(img, o1 + p * 8);
+    uint32_t bits = 0;
+#pragma unroll
+    for (uint32_t p = 0; p < W; ++p) bits |= (uint32_t)(x[p] >> col & 1) << p;
+    return bits;
+}
 NHD_HD uint32_t nic_assignment_bits(const uint8_t* img, const ColdView& L, uint32_t col, bool pci, const nhdfit_plane3& q3) {
     const uint32_t o0 = L.off_r0 + (pci ? q3.sig_pci[0] : q3.sig_numa[0]) * L.row;
     const uint32_t o1 = L.off_r1 + (pci ? q3.sig_pci[1] : q3.sig_numa[1]) * L.row;
+    switch (L.W) {
+        case 2: return nic_assignment_bits_w<2>(img, o0, o1, col);
+        case 4: return nic_assignment_bits_w<4>(img, o0, o1, col);
+        case 8: return nic_assignment_bits_w<8>(img, o0, o1, col);
+        default: break;
+    }
     uint32_t bits = 0;
     for (uint32_t p = 0; p < L.W; ++p)
         if ((ld64(img, o0 + p * 8) & ld64(img, o1 + p * 8)) >> col & 1) bits |= 1u << p;

@@ -1027,7 +1027,18 @@ int build_items(nhdfit_ctx* c, uint32_t nw, bool batch_find = false) {
             // 8, 16 or 32 blocks per tile by its cost when one launch has the chip to itself; with two pipes the other launch's
             // blocks fill the gaps, and fewer, longer fit blocks (less staging, fewer tails) win: 8 per tile (-3 %, profiles/r03)
             const bool two_pipes = c->dual && !c->split && !c->role_kernels;
-            const uint32_t k = force_k ? force_k : batch_find ? 2u : two_pipes ? 1u : nb <= 11 ? 1u : nb <= 23 ? 2u : 4u;
+            static const uint32_t force_k8 = tune_env("NHDFIT_XCD_K8") ? (uint32_t)atoi(tune_env("NHDFIT_XCD_K8")) : 0u;   // tuning aid: the widest tiles only
+            const uint32_t k = force_k8 && w >= 2 ? force_k8 : force_k ? force_k : batch_find ? 2u : two_pipes ? 1u : nb <= 11 ? 1u : nb <= 23 ? 2u : 4u;
+            // tuning aid (NHDFIT_FIT_HALF = mask of row-width classes): FOUR blocks for a tile of such a class, a quarter of the node axis each -
+            // half as many stagings and pair-table derivations per tile, twice the chunks per wavefront.  Two such tiles share eight
+            // consecutive blocks (quarter q of the first on XCD q, of the second on XCD 4 + q); an odd one out gets its eight.
+            static const uint32_t half_mask = tune_env("NHDFIT_FIT_HALF") ? (uint32_t)atoi(tune_env("NHDFIT_FIT_HALF")) : 0u;
+            const bool next_same = t + 1 < tiles && c->h_tile_wcls[t + 1] == w;
+            if (!batch_find && k == 1 && (half_mask >> w & 1u) && (items.size() % 8 == 4 || next_same)) {
+                for (uint32_t q = 0; q < 4; ++q)
+                    items.push_back(FitItem{t, w, (uint32_t)((uint64_t)chunks * q / 4), (uint32_t)((uint64_t)chunks * (q + 1) / 4)});
+                continue;
+            }
             for (uint32_t j = 0; j < 8 * k; ++j) {
                 const uint32_t r = (j % 8) * k + j / 8;                     // range r of 8k: the (j / 8)-th piece of eighth j % 8
                 const uint32_t lo = (uint32_t)((uint64_t)chunks * r / (8 * k)), hi = (uint32_t)((uint64_t)chunks * (r + 1) / (8 * k));
@@ -1103,6 +1114,7 @@ void fill_fit_args(nhdfit_ctx* c, Pipe& p, int bf, double now, FitArgs& f, bool 
     f.score = p.score[bf].p;
     f.items = c->items.p;
     f.dbg_skip = tune_env("NHDFIT_FIT_SKIP") ? (uint32_t)atoi(tune_env("NHDFIT_FIT_SKIP")) : 0;
+    f.clk = nullptr;
 }
 
 // One launch of the step kernel with every role that has work (see k_step).  `with_fit`: the fit role for step
@@ -1191,12 +1203,13 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
 
     // HIP-event timing is sampled (every 8th fit launch; every digest-only launch)
     if (with_fit && (int64_t)p.n_fit == c->role_step) {
-        HIPCHK(c, c->role_clock.reserve(10));
-        unsigned long long init[10];
+        HIPCHK(c, c->role_clock.reserve(32));
+        unsigned long long init[32] = {0};
         for (int k = 0; k < 5; ++k) { init[2 * k] = ~0ull; init[2 * k + 1] = 0; }
         HIPCHK(c, hipMemcpyAsync(c->role_clock.p, init, sizeof init, hipMemcpyHostToDevice, p.stream));
         HIPCHK(c, wait_stream(p.stream));
         a.role_clock = c->role_clock.p;
+        a.fit.clk = c->role_clock.p + 16;                  // per-block phases of the fit role (FitArgs::clk)
     }
     const bool timed = (with_fit && (p.n_fit < 2 || (p.n_fit & 7) == 0)) || (!with_fit && with_digest);
     if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc) return rc; }
@@ -1240,9 +1253,15 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
         c->ev_kind[c->ev_pending++] = with_fit ? 0 : 1;
     }
     if (a.role_clock) {
-        unsigned long long t[10];
+        unsigned long long t[32];
         HIPCHK(c, wait_stream(p.stream));
         HIPCHK(c, hipMemcpy(t, c->role_clock.p, sizeof t, hipMemcpyDeviceToHost));
+        if (t[24]) {
+            const double nb = (double)t[24];
+            fprintf(stderr, "[nhdfit] step %lld fit blocks (%llu): mean / latest after the block's start - staged %.2f / %.2f, pair table %.2f / %.2f, sweep done %.2f / %.2f, "
+                            "scores out %.2f / %.2f us\n", (long long)c->role_step, t[24], t[16] * 0.01 / nb, t[17] * 0.01, t[18] * 0.01 / nb, t[19] * 0.01,
+                    t[20] * 0.01 / nb, t[21] * 0.01, t[22] * 0.01 / nb, t[23] * 0.01);
+        }
         unsigned long long first = ~0ull;
         for (int k = 0; k < 5; ++k) first = t[2 * k] < first ? t[2 * k] : first;
         static const char* names[5] = {"choose", "shapes", "finish", "digest", "fit"};
@@ -2290,9 +2309,12 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         if (dyn + sig_bytes <= 96 * 1024) { qa.lds_sigs = 1; dyn += sig_bytes; }
         if (c->use_set_states && c->st_n && dyn + st_bytes <= 96 * 1024) { qa.lds_states = 1; dyn += st_bytes; }
         if (c->use_choose_tab && dyn + lds_slice(kChooseEntries) <= 112 * 1024) { qa.lds_choose = 1; dyn += lds_slice(kChooseEntries); }
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_decide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));   // (static: ~45 KB of the 160)
+        bool any_g4 = false;                                    // (four-group pods: the instantiation that carries the generic set model)
+        for (uint32_t i = 0; i < P && !any_g4; ++i) any_g4 = reqs[i].n_groups > 3;
+        HIPCHK(c, hipFuncSetAttribute(any_g4 ? (const void*)k_decide<true> : (const void*)k_decide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));   // (static: ~45 KB of the 160)
         static const uint32_t workers = tune_env("NHDFIT_SEQ_WORKERS") ? (uint32_t)atoi(tune_env("NHDFIT_SEQ_WORKERS")) : (uint32_t)kWorkerBlocks;   // tuning aid
-        hipLaunchKernelGGL(k_decide, dim3(1 + (workers ? workers : 1u)), dim3(64 * kDecideWaves), dyn, sm, qa);
+        if (any_g4) hipLaunchKernelGGL(k_decide<true>, dim3(1 + (workers ? workers : 1u)), dim3(64 * kDecideWaves), dyn, sm, qa);
+        else hipLaunchKernelGGL(k_decide<false>, dim3(1 + (workers ? workers : 1u)), dim3(64 * kDecideWaves), dyn, sm, qa);
         HIPCHK(c, hipGetLastError());
         uint32_t flags[4] = {0, 0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(flags, c->seq_flags.p, sizeof flags, hipMemcpyDeviceToHost, sm));

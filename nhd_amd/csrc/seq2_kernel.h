@@ -505,6 +505,9 @@ __global__ __launch_bounds__(256) void k_decide_prep(const uint32_t* __restrict_
     out[j] = make_uint4(e, pos, sc ? (uint32_t)(NHDFIT_SCORE_INDEX(sc) - global_base) : kNoNode, (uint32_t)(sc >> 63));
 }
 
+// G4: the batch holds pods of four processing groups (their mapping is the generic set model's: scratch arrays).  The host launches
+// k_decide<false> for every other batch - no private segment to speak of, 10 KB per lane otherwise.
+template <bool G4>
 __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     const SeqArgs& a = q.s;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
             nhdfit_mapping mp = nhdfit_mapping{};
             const uint32_t tile = pos >> 6;
             const uint32_t bits = nic_assignment_bits_wave(a.tabs + (size_t)tile * a.pitch, s_L[a.tile_wcls[tile]], pos & 63, rq.map_type == NHDFIT_MAP_PCI, st.p3, lane);
-            const bool ok = map_on_state_wave(rq, st, dd, s_caps, bits, a.mt, lane, mp);
+            const bool ok = map_on_state_wave<G4>(rq, st, dd, s_caps, bits, a.mt, lane, mp);
             __builtin_amdgcn_wave_barrier();
             if (!(kTuning && (q.dbg & 1))) note_first_touch(a, v, st, dd, lane, true);
             __builtin_amdgcn_wave_barrier();
@@ -974,7 +977,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                     const uint32_t bits = nic_tab ? (s_snic[sp][pci ? st.p3.sig_pci[0] : st.p3.sig_numa[0]] & 0xFFFFu) & (s_snic[sp][pci ? st.p3.sig_pci[1] : st.p3.sig_numa[1]] >> 16)
                                                   : nic_assignment_bits_wave(img, L, pos & 63, pci, st.p3, lane);
                     lap(9);
-                    ok = map_on_state_wave(rq, st, dd, s_caps, bits, mt, lane, mp);
+                    ok = map_on_state_wave<G4>(rq, st, dd, s_caps, bits, mt, lane, mp);
                 }
                 __builtin_amdgcn_wave_barrier();
                 lap(2);

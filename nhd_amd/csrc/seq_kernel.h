@@ -156,13 +156,17 @@ __device__ __noinline__ uint32_t choose_model_cold(int G, int U, uint32_t sg, ui
     return choose_result_word(ok, gcode, ccode);
 }
 // map_on_state (seq_core.h) with the parallel pieces; every lane returns the same mapping
+// G4 = false: the caller knows that no pod of its batch has four processing groups - the generic set model (10 KB of private memory per
+// lane, reserved for every wavefront of a kernel that merely CONTAINS the call) is not compiled in (k_decide<false>, round 6)
+template <bool G4 = true>
 __device__ __forceinline__ bool map_on_state_wave(const nhdfit_req& r, const NodeState& s, const nhdfit_detail& d, const double* caps, uint32_t nic_bits,
                                                   const MapTables& t, uint32_t lane, nhdfit_mapping& m) {
     const WinnerState w = state_view(s, d, caps);
     const int G = (int)r.n_groups, U = w.U;
     m = nhdfit_mapping{};
     const uint32_t codes = nic_codes_from_table_bits(nic_bits, G, U);
-    if (G > 3) {                                                          // (copies: nothing the hot path keeps in registers has its address taken)
+    if constexpr (!G4) { if (G > 3) return false; }
+    if constexpr (G4) if (G > 3) {                                        // (copies: nothing the hot path keeps in registers has its address taken)
         WinnerState wc = w;
         nhdfit_mapping tmp = nhdfit_mapping{};
         const bool ok = map_generic_cold(&r, &wc, codes, &tmp);

@@ -42,6 +42,8 @@ struct FitArgs {
     uint32_t hot_wc1[2];             // where the second socket's CPU records start in the hot section
     uint32_t fc_dim;
     uint32_t dbg_skip;          // tuning aid (NHDFIT_FIT_SKIP): 1 no table sweep, 2 no winner tracking, 4 constant record, 8 no predicate rows
+    unsigned long long* clk;    // tuning aid (NHDFIT_FIT_PHASES): per fit block, summed and latest - [0/1] staged, [2/3] pair table derived, [4/5] sweep done,
+                                // [6/7] scores out (10 ns ticks after the block's start), [8] blocks
 };
 
 // One step of the 64 x 64 bit-matrix transpose across a wavefront: exchange S x S sub-blocks between
@@ -229,6 +231,14 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
     static_assert(!SWP || PAIR == 1, "the pipelined loop is the pair form's");
     constexpr int NW = BLOCK / 64;
     const uint32_t dbg = kTuning ? a.dbg_skip : 0u;
+    const unsigned long long t_blk = kTuning && a.clk ? (unsigned long long)wall_clock64() : 0ull;
+    auto phase = [&](int k) {                                      // tuning aid (FitArgs::clk): time since the block entered the role, summed and latest
+        if (kTuning && a.clk && threadIdx.x == 0) {
+            const unsigned long long d = (unsigned long long)wall_clock64() - t_blk;
+            atomicAdd(&a.clk[2 * k], d);
+            atomicMax(&a.clk[2 * k + 1], d);
+        }
+    };
     // the argument block may live behind a pointer (k_step_p): what the chunk loop uses is read once, here
     const uint64_t* __restrict__ cand = a.cand;
     uint64_t* __restrict__ nm = a.nm;
@@ -261,6 +271,8 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
     {   // stage the hot section of the tile's table image in LDS (16 B per lane, fully coalesced)
         const uint4* src = reinterpret_cast<const uint4*>(hot_global);
         uint4* dst = reinterpret_cast<uint4*>(hot);
+        // (a plain loop: load - wait - store per 8 KB.  Four loads in flight per thread were measured in round 6: staged 2.2 -> 1.8 us per
+        //  block, but the step 14.05 -> 14.2-14.3 us - the blocks then reach their pair-table derivation together)
         if (!(dbg & 16)) for (uint32_t i = threadIdx.x; i < staged / 16; i += BLOCK) dst[i] = src[i];
         if (spill) {                                                                 // the HP rows go right behind the prefix
             const uint4* hsrc = reinterpret_cast<const uint4*>(hot_global + a.hot_hp[WC]);
@@ -268,7 +280,12 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
         }
     }
     __syncthreads();
-    // pair table behind the winner scratch: C[2][D][D] as W / 2 planes of 16-byte pieces (fit_core.h "pair rows")
+    phase(0);
+    // pair table behind the winner scratch: C[2][D][D] as W / 2 planes of 16-byte pieces (fit_core.h "pair rows").  Derived by every
+    // block of the tile for itself: ONE derivation per tile in the digest role with the fit blocks copying the table from L2 was built
+    // and measured twice in round 6 (plain copy loop; four loads in flight per thread) - the copy (37 KB per four-assignment block)
+    // costs ~4 us from L2 with both launches' blocks on the chip, more than the derivation it replaces: step 14.4 -> 16.4 us
+    // (profiles/r06/pair_table_in_digest_*withdrawn.log)
     const uint32_t pD = PAIR ? a.pair_D[WC & 1] : 0u;
     const uint32_t off_c = (uint32_t)lds_slice(hot_bytes) + NW * 64 * (uint32_t)sizeof(unsigned long long), c_plane = 2 * pD * pD * 16;
     if constexpr (PAIR != 0) {
@@ -292,6 +309,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
         }
         __syncthreads();
     }
+    phase(1);
 
     // lane-as-pod view of the tile's 64 request headers -> class masks of the tile (scalar registers)
     const bool my_pod_live = pod0 + lane < a.P;
@@ -411,6 +429,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
         rv = rv_next;
         bt = bt_next;
     }
+    phase(2);
     unsigned long long best = 0;
     if (best_pref != ~0u) best = score_of(true, a.global_base + best_pref);
     else if (best_any != ~0u) best = score_of(false, a.global_base + best_any);
@@ -423,6 +442,8 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
         for (int w = 1; w < NW; ++w) m = s_best[w][lane] > m ? s_best[w][lane] : m;
         if (m) atomicMax(&a.score[pod0 + lane], m);
     }
+    phase(3);
+    if (kTuning && a.clk && threadIdx.x == 0) atomicAdd(&a.clk[8], 1ull);
 }
 
 // (the same for a work item computed by the caller: the single-launch find, k_find)

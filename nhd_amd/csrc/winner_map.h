@@ -604,19 +604,35 @@ NHD_HD uint32_t choose_from_table(const uint8_t* table, int G, uint32_t sg_mask,
 NHD_HD void candidate_masks(const nhdfit_req& r, const WinnerState& w, uint32_t& sg_mask, uint32_t& sc_mask) {
     const int G = (int)r.n_groups, U = w.U;
     const uint32_t nG = ipow(U, G), nC = ipow(U, G + 1);
+    // The groups' demands are read ONCE into registers (groups past G count zero): on the device the request sits in LDS or global
+    // memory, and the (code, group) loops below used to re-read a field per iteration - ~90 dependent round trips for a three-group
+    // pod, 11 of a drain launch's 34 us (round 6, profiles/r06/drain_phases.log).
+    uint32_t gp[kMaxG], cd[kMaxG];
+#pragma unroll
+    for (int g = 0; g < kMaxG; ++g) {
+        gp[g] = g < G ? (uint32_t)r.gpus[g] : 0u;
+        cd[g] = g < G ? (uint32_t)(w.smt ? r.cpu_smt[g] : r.cpu_nosmt[g]) : 0u;
+    }
+    const uint32_t misc = w.smt ? r.misc_smt : r.misc_nosmt;
+    const uint32_t fg0 = (uint32_t)w.free_g[0], fg1 = (uint32_t)w.free_g[1], fc0 = (uint32_t)w.free_c[0], fc1 = (uint32_t)w.free_c[1];
     sg_mask = sc_mask = 0;
     for (uint32_t code = 0; code < nG; ++code) {
-        uint32_t t0 = 0, t1 = 0;
-        for (int g = 0; g < G; ++g) { if (tup_digit(code, G, U, g)) t1 += r.gpus[g]; else t0 += r.gpus[g]; }
-        if (t0 <= (uint32_t)w.free_g[0] && t1 <= (uint32_t)w.free_g[1]) sg_mask |= 1u << code;
+        uint32_t t1 = 0, all = 0;
+#pragma unroll
+        for (int g = 0; g < kMaxG; ++g) {                  // tup_digit(code, G, U, g) = bit G - 1 - g of the code
+            all += gp[g];
+            if (g < G && (code >> (G - 1 - g) & 1u)) t1 += gp[g];
+        }
+        if (all - t1 <= fg0 && t1 <= fg1) sg_mask |= 1u << code;
     }
     for (uint32_t code = 0; code < nC; ++code) {
-        uint32_t t0 = 0, t1 = 0;
-        for (int g = 0; g <= G; ++g) {
-            const uint32_t d = g < G ? (w.smt ? r.cpu_smt[g] : r.cpu_nosmt[g]) : (w.smt ? r.misc_smt : r.misc_nosmt);
-            if (tup_digit(code, G + 1, U, g)) t1 += d; else t0 += d;
+        uint32_t t1 = (code & 1u) ? misc : 0u, all = misc;     // the misc cores are the tuple's last digit: bit 0
+#pragma unroll
+        for (int g = 0; g < kMaxG; ++g) {                  // tup_digit(code, G + 1, U, g) = bit G - g
+            all += cd[g];
+            if (g < G && (code >> (G - g) & 1u)) t1 += cd[g];
         }
-        if (t0 <= (uint32_t)w.free_c[0] && t1 <= (uint32_t)w.free_c[1]) sc_mask |= 1u << code;
+        if (all - t1 <= fc0 && t1 <= fc1) sc_mask |= 1u << code;
     }
 }
 

@@ -80,7 +80,9 @@ def schedule_batch_sharded(engine, reqs: np.ndarray, now: float, packer, nogpu_w
     with torch.distributed.isend from inside this package).  The results meet in ONE `transport.allreduce_sum_u8` of a byte
     buffer - every pod is placed by at most one rank, all others contribute zeros.  `transport`: see RcclTransport (default:
     the engine's own communicator).  `nogpu_words`: this shard's nodes without a GPU installed, one bit per node ([chunks]
-    uint64 words).  apply=False restores this rank's shard afterwards."""
+    uint64 words).  apply=False restores this rank's shard afterwards.  Pods placed on nodes beyond the fast layout (wide nodes: 3-4
+    sockets, more than 64 cores per socket) come back with `places[pod]["status"] == COMMIT_WIDE`; their placement records are in
+    `engine.last_wide_places[pod]` on every rank afterwards."""
     from . import pack as _pack
     if transport is None:
         transport = RcclTransport(engine)
@@ -95,6 +97,13 @@ def schedule_batch_sharded(engine, reqs: np.ndarray, now: float, packer, nogpu_w
     wants_gpu = reqs["gpus"].sum(axis=1) > 0
     saved = None if apply or engine.n == 0 else engine.download(0, engine.n)
     touched = None
+    # does ANY shard hold nodes beyond the fast layout?  Agreed on collectively before the first tick (one byte through the results'
+    # all-reduce): the ranks must size the final exchange alike
+    flag = np.array([1 if getattr(engine, "n_wide", 0) else 0], np.uint8)
+    if world > 1:
+        transport.allreduce_sum_u8(flag)
+    carry_wide = bool(flag[0])
+    wide = np.zeros(P if carry_wide else 0, _pack.WIDE_PLACEMENT)      # per pod: the wide placement record of the rank that placed it (zeros: none)
     mask_nogpu = np.ascontiguousarray(nogpu_words, dtype=np.uint64)
     slices = [np.arange(a, min(P, a + chunk), dtype=np.int64) for a in range(0, P, chunk)]
     S = len(slices)
@@ -107,12 +116,12 @@ def schedule_batch_sharded(engine, reqs: np.ndarray, now: float, packer, nogpu_w
         if len(pods) == 0 or engine.n == 0 or (mask is not None and not mask.any()):
             return pods
         nd, mp_, pl, st = engine.schedule_batch(reqs[pods], now, packer, cand=mask, apply=True)
-        if (st == _pack.COMMIT_WIDE).any():
-            # a pod landed on a node beyond the fast layout: its physical ids live in the owning rank's wide placement records
-            # (Engine.last_wide_places), which this function does not carry to the other ranks - refuse rather than hand every
-            # rank an empty placement
-            raise NotImplementedError("schedule_batch_sharded: a pod was placed on a wide node (3-4 sockets / more than 64 cores per socket); "
-                                      "such shards take HipMatcher(devices=[...]).ScheduleBatch, which returns their placement records")
+        if carry_wide and (pl["status"] == _pack.COMMIT_WIDE).any():           # (a placement's own status field says so, as in HipMatcher._run_checked)
+            # pods that landed on nodes beyond the fast layout: their physical ids are the owning rank's wide placement records
+            # (Engine.last_wide_places, keyed by the position in THIS pass's batch) - kept by the caller's pod index and carried to
+            # every rank with the results' all-reduce (round 5 raised here, in the middle of the lock-step ring)
+            for k, wp in getattr(engine, "last_wide_places", {}).items():
+                wide[int(pods[int(k)])] = wp
         got = nd >= 0
         idx = pods[got]
         node1[idx], maps[idx], places[idx], status[idx] = nd[got] + 1, mp_[got], pl[got], st[got]
@@ -150,14 +159,19 @@ def schedule_batch_sharded(engine, reqs: np.ndarray, now: float, packer, nogpu_w
     # every pod was placed by at most one rank: the element-wise sum of the ranks' (zero-initialised) results is the result
     if world > 1:
         parts = [node1.view(np.uint8), maps.view(np.uint8).reshape(-1), places.view(np.uint8).reshape(-1), status.view(np.uint8)]
+        if carry_wide:
+            parts.append(wide.view(np.uint8).reshape(-1))
         flat = np.ascontiguousarray(np.concatenate(parts))
         transport.allreduce_sum_u8(flat)
         at = 0
-        for arr in (node1, maps, places, status):
+        for arr in (node1, maps, places, status) + ((wide,) if carry_wide else ()):
             nbytes = arr.nbytes
             arr.view(np.uint8).reshape(-1)[:] = flat[at:at + nbytes]
             at += nbytes
     if saved is not None and touched is not None:
         a, b = touched
         engine.upload(saved.slice(a, b), global_base=engine.global_base, first=a, capacity=engine.n)
+    # the placements on wide nodes, by the caller's pod index, on EVERY rank - as Engine.schedule_batch leaves them on one
+    # (pack.expand_wide_placement turns one into the physical ids; its `node` field is the owner's LOCAL index)
+    engine.last_wide_places = {int(i): wide[i].copy() for i in np.flatnonzero(places["status"] == _pack.COMMIT_WIDE)} if carry_wide else {}
     return node1 - 1, maps, places, status

@@ -37,3 +37,7 @@ def test_step_kernel_uses_no_scratch_to_speak_of(tmp_path):
     for k, v in usage.items():
         if "k_find" in k or "k_map_tiles" in k:
             assert v.get("ScratchSize", 0) <= 64, (k, v)
+    # mode B's decision engine for batches without four-group pods (every BASELINE shape): no private segment to speak of - the generic set
+    # model's scratch arrays (10 KB per lane) belong to the other instantiation only
+    lean = [v for k, v in usage.items() if "k_decideILb0E" in k]
+    assert len(lean) == 1 and lean[0]["ScratchSize"] <= 64, lean

@@ -134,6 +134,90 @@ def test_mode_b_one_process_per_shard_equals_the_scheduler_loop(tmp_path, cfg, n
         assert ((want_node >= lo1) & (want_node < hi1)).sum() == 0 and (want_node >= hi1).sum() >= 5, "pods must pass through the empty shard"
 
 
+def _worker_mode_b_wide(rank, world, port, seed, n, P, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import util
+    nl = util.mixed_cluster(seed, n, occupancy=0.15)
+    names = list(nl)
+    rng = np.random.default_rng(seed)
+    specs = []
+    for _ in range(P):
+        sp = util.random_pod_spec(rng)
+        sp["misc_smt"] = True
+        sp["map_type"] = "NUMA" if sp["map_type"] == "NONE" else sp["map_type"]
+        specs.append(sp)
+    tops = [refmodel.make_topology(sp) for sp in specs]
+    lo, hi = shard.shard_bounds(n, world, rank)
+    sub = {nm: nl[nm] for nm in names[lo:hi]}
+    pk = pack.Packer()
+    whole = pk.pack_nodes(nl)                             # (one dictionary for every rank: the whole cluster is packed, the shard uploaded)
+    reqs = pk.digest_many(tops)
+    pk.close_signatures()
+    eng = harness.HarnessEngine(0)
+    eng.set_dictionary(pk)
+    eng.upload(whole.slice(lo, hi), global_base=lo)
+    bits = np.zeros(((hi - lo + 63) // 64) * 64, np.uint8)
+    bits[:hi - lo] = [len(nd.gpus) == 0 for nd in sub.values()]
+    nogpu = np.packbits(bits, bitorder="little").view(np.uint64).copy()
+    node, maps, places, status = shard.schedule_batch_sharded(eng, reqs, util.CLOCK, pk, nogpu, dist_util.TorchTransport(dist), apply=True, chunk=24)
+    ids = []
+    for i in range(P):
+        if node[i] < 0:
+            ids.append(None)
+            continue
+        nd = nl[names[int(node[i])]]
+        G = int(reqs[i]["n_groups"])
+        gpus = [int(reqs[i]["gpus"][g]) for g in range(G)]
+        cpp = int(nd.cores_per_proc)
+        if int(places[i]["status"]) == pack.COMMIT_WIDE:
+            ids.append(pack.expand_wide_placement(eng.last_wide_places[i], G, cpp, cpp * int(nd.sockets), gpus))
+        else:
+            ids.append(pack.expand_placement(places[i], G, cpp, cpp * int(nd.sockets), gpus))
+    import json
+    with open(os.path.join(out_dir, f"wide{rank}.json"), "w") as f:
+        json.dump({"node": node.tolist(), "ids": ids, "wide": int((places["status"] == pack.COMMIT_WIDE).sum())}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mode_b_sharded_carries_placements_on_wide_nodes(tmp_path):
+    """A cluster that mixes ordinary nodes with nodes beyond the fast layout (3-4 sockets, more than 64 cores per socket), cut over two
+    ranks: schedule_batch_sharded used to raise on the one rank whose shard placed a pod on a wide node - in the middle of the
+    lock-step ring (ADVICE r05 / VERDICT r05 item 8).  The wide placement records now travel with the results: node and physical ids
+    of every pod, on every rank, against the oracle's loop over the whole cluster."""
+    import json
+    from oracle import nhd_oracle as O
+    from tests import util
+    seed, n, P = 61003, 30, 60
+    port = _free_port()
+    mp.spawn(_worker_mode_b_wide, args=(2, port, seed, n, P, str(tmp_path)), nprocs=2, join=True)
+    nl = util.mixed_cluster(seed, n, occupancy=0.15)
+    names = list(nl)
+    rng = np.random.default_rng(seed)
+    specs = []
+    for _ in range(P):
+        sp = util.random_pod_spec(rng)
+        sp["misc_smt"] = True
+        sp["map_type"] = "NUMA" if sp["map_type"] == "NONE" else sp["map_type"]
+        specs.append(sp)
+    tops = [refmodel.make_topology(sp) for sp in specs]
+    want_node, want_ids = [], []
+    for top in tops:
+        res = O.find_node(nl, top, util.CLOCK)
+        rec = {}
+        if res[0] is not None:
+            O.commit(nl[res[0]], top, res[1], util.CLOCK, rec)
+        want_node.append(-1 if res[0] is None else names.index(res[0]))
+        want_ids.append(rec if res[0] is not None else None)
+    for rank in range(2):
+        with open(tmp_path / f"wide{rank}.json") as f:
+            got = json.load(f)
+        assert got["node"] == want_node, rank
+        assert got["ids"] == want_ids, rank
+        assert got["wide"] >= 2, "the case must place pods on wide nodes"
+
+
 def test_order_preserving_score_encoding():
     rng = np.random.default_rng(0)
     s = rng.integers(0, 2 ** 64, size=1000, dtype=np.uint64)
