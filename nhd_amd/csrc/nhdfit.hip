@@ -256,6 +256,7 @@ struct nhdfit_ctx {
     // single-launch find (k_find, step_kernel.h): the fine-grained host block the launch reads the requests from and stores
     // its results into, the launch's counters, the sequence number of the last call, and what the device's candidate mask holds
     FindHost* find_host = nullptr;
+    CommitHost* commit_host = nullptr; uint32_t commit_seq = 0;      // nhdfit_commit's result block (fine-grained host memory, polled)
     DevBuf<uint32_t> find_sync;
     DevBuf<unsigned long long> find_red;   // sharded single-launch find: the tile's scores on their way through the all-reduce
     uint32_t find_seq = 0;
@@ -422,6 +423,8 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
             if (e == hipSuccess) e = hipEventCreate(&x);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->find_host, sizeof(FindHost), hipHostMallocCoherent);
     if (e == hipSuccess) memset(c->find_host, 0, sizeof(FindHost));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->commit_host, sizeof(CommitHost), hipHostMallocCoherent);
+    if (e == hipSuccess) memset(c->commit_host, 0, sizeof(CommitHost));
     if (e == hipSuccess) e = c->find_sync.reserve(8);                  // [0..2] counters of k_find / k_find1, [4..5] k_find1's 64-bit score word
     if (e == hipSuccess) e = hipMemsetAsync(c->find_sync.p, 0, 8 * sizeof(uint32_t), c->stream);
     if (e == hipSuccess) e = c->xkeys.reserve(kXSlots);
@@ -474,6 +477,8 @@ void nhdfit_destroy(nhdfit_ctx* c) {
     c->big_reqs.release(); c->big_score.release(); c->big_maps.release(); c->big_flags.release(); c->big_place.release();
     c->big_cand.release(); c->big_scratch.release();
     if (c->find_host) (void)hipHostFree(c->find_host);
+    if (c->commit_host) (void)hipHostFree(c->commit_host);
+    c->commit_host = nullptr;
     if (c->findn_host) (void)hipHostFree(c->findn_host);
     c->findn_host = nullptr; c->findn_cap = 0; c->findn_sync.release();
     c->find_host = nullptr; c->find_sync.release(); c->find_red.release();
@@ -2399,15 +2404,27 @@ int nhdfit_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_req* req, const nhd
     // the commit writes the planes: steps in flight on EITHER pipe (their fit roles, digests running ahead, pending mapping
     // phases) read them - wait for both, as every other writer of the mirror does (nhdfit_upload_nodes)
     { int rc_ = sync_all(c); if (rc_) return rc_; }
-    HIPCHK(c, c->seq_place.reserve(1));
+    if (!c->commit_host) return fail(c, NHDFIT_E_STATE, "no host block for the commit's result");
     CommitArgs ca;
     memset(&ca, 0, sizeof ca);
     ca.p0 = c->p0.p; ca.p1 = c->p1.p; ca.p2 = c->p2.p; ca.p3 = c->p3.p; ca.p4 = c->p4.p; ca.det = c->det.p;
-    ca.node = node; ca.req = *req; ca.map = *map; ca.busy_time = busy_time; ca.sigs = sig_table(c); ca.out = c->seq_place.p;
+    ca.node = node; ca.req = *req; ca.map = *map; ca.busy_time = busy_time; ca.sigs = sig_table(c);
+    const uint32_t seq = ++c->commit_seq ? c->commit_seq : ++c->commit_seq;                 // (never 0: the block's resting value)
+    ca.host = c->commit_host; ca.seq = seq;
+    const auto t_launch = std::chrono::steady_clock::now();
     hipLaunchKernelGGL(k_commit, dim3(1), dim3(64), 0, c->stream, ca);       // (both pipes are idle: sync_all above)
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(place_out, c->seq_place.p, sizeof(nhdfit_placement), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, wait_stream(c->stream));
+    // the placement arrives in the fine-grained host block behind the sequence number: poll it (a launch that takes longer than
+    // half a millisecond - it cannot, short of a fault - is waited for on its stream)
+    for (uint32_t spins = 1; __atomic_load_n(&c->commit_host->flag, __ATOMIC_ACQUIRE) != seq; ++spins) {
+        if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t_launch > std::chrono::microseconds(500)) {
+            HIPCHK(c, wait_stream(c->stream));
+            if (__atomic_load_n(&c->commit_host->flag, __ATOMIC_ACQUIRE) != seq) return fail(c, NHDFIT_E_HIP, "the commit kernel ended without publishing its placement");
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    *place_out = c->commit_host->place;
     if (c->rec_lo == c->rec_hi) { c->rec_lo = node; c->rec_hi = node + 1; }
     else { c->rec_lo = std::min(c->rec_lo, node); c->rec_hi = std::max(c->rec_hi, node + 1); }
     return NHDFIT_OK;

@@ -170,6 +170,19 @@ __device__ __forceinline__ uint64_t sweep_pair_c(const uint8_t* lds, uint32_t a_
     return ((uint64_t)hi << 32) | lo;
 }
 
+// The verdict matrix is written once per step and never read back by the launch: NHDFIT_NM_NT = 1 marks the store non-temporal
+// (streaming: 33.5 MB per step that need not displace the node records in L2 nor wait for the launch's end to leave it).
+#ifndef NHDFIT_NM_NT
+#define NHDFIT_NM_NT 1
+#endif
+__device__ __forceinline__ void verdict_store(uint64_t* p, uint64_t v) {
+#if NHDFIT_NM_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // Address of a node's C row (piece 0): row ((smt * D + min(c0, D - 1)) * D + min(c1, D - 1)) of 16 bytes behind off_c.  Every factor
 // is below 2^24: v_min_u32 and v_mad_u32_u24 (full rate) instead of compare + select and the quarter-rate 64-bit multiply-add the
 // plain expression compiles to (round 6).
@@ -347,7 +360,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
                 const uint64_t cw = cand[c];
                 if (!(cw >> pos & 1)) wlo = whi = 0;
             }
-            if (nm) nm[(size_t)tile * npad + c * 64 + pos] = ((uint64_t)whi << 32) | wlo;
+            if (nm) verdict_store(&nm[(size_t)tile * npad + c * 64 + pos], ((uint64_t)whi << 32) | wlo);
             const uint32_t nlo = (uint32_t)need_any | (nogpu ? (uint32_t)need_pref : 0u);
             const uint32_t nhi = (uint32_t)(need_any >> 32) | (nogpu ? (uint32_t)(need_pref >> 32) : 0u);
             if (NHDFIT_FIT_TRACK_SKIP && !(need_any | need_pref)) return;      // every pod of the tile has its winner of this run: nothing left to track (wave-uniform)
@@ -408,7 +421,7 @@ __device__ __forceinline__ void role_fit_w(const FitArgs& a, const double busy_f
             const uint64_t cw = cand[c];
             if (!(cw >> pos & 1)) wlo = whi = 0;
         }
-        if (nm) nm[(size_t)tile * npad + c * 64 + pos] = ((uint64_t)whi << 32) | wlo;      // (the chunk's 512 bytes, whatever the lane order)
+        if (nm) verdict_store(&nm[(size_t)tile * npad + c * 64 + pos], ((uint64_t)whi << 32) | wlo);      // (the chunk's 512 bytes, whatever the lane order)
 
         // (3) does this chunk change any pod's winner?
         const uint32_t nlo = (uint32_t)need_any | (nogpu ? (uint32_t)need_pref : 0u);

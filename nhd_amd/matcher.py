@@ -221,7 +221,8 @@ class HipMatcher:
         bt = float(node.busy_time if busy_time is None and node is not None else busy_time)
         if pack.needs_general_path(top):                                                # a pod with 5..8 processing groups (or beyond the hugepage table): the general path's commit step
             return self._commit_big(i, node, self.packer.digest_big(top), self._mapping_record(mapping, big=True), bt)
-        req = self.packer.digest(top)
+        cached = getattr(self, "_digest_cache", None)                 # the record FindNode made of this very topology a moment ago (the scheduler
+        req = cached[1] if cached is not None and cached[0] is top else self.packer.digest(top)   # commits what it has just matched, nhd/NHDScheduler.py:277-304)
         if self._table is not None and self._table.wide and i in self._table.wide:      # a wide node: the general path's commit step
             place = self.engine.wide_commit(i, req, self._mapping_record(mapping), bt)
             G = int(req["n_groups"])
@@ -617,6 +618,8 @@ class HipMatcher:
         if reqs is None:
             beyond: List[Tuple[int, str]] = []
             reqs = self.packer.digest_many(tops, pod_groups, unsupported=beyond)
+            if n_pods == 1 and not beyond:
+                self._digest_cache = (tops[0], reqs[0])     # CommitPlacement of the same topology object does not digest it again
             for i, why in beyond:
                 self.logger.error("pod %d of the call cannot be expressed as a request record and is answered (None,): %s", i, why)
         elif pod_groups is not None:                       # requests digested from config texts: InitialNodeFilter in the kernel
