@@ -2403,14 +2403,17 @@ int nhdfit_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_req* req, const nhd
     HIPCHK(c, hipSetDevice(c->dev));
     // the commit writes the planes: steps in flight on EITHER pipe (their fit roles, digests running ahead, pending mapping
     // phases) read them - wait for both, as every other writer of the mirror does (nhdfit_upload_nodes)
-    { int rc_ = sync_all(c); if (rc_) return rc_; }
+    // ... unless nothing can be in flight anywhere but on this very stream: no batch is staged (the single-launch finds leave none) and
+    // the other pipes' streams and the reduce stream have carried nothing since they were last waited for - then stream order is all
+    // the commit needs (the scheduler's pod-at-a-time loop: asking the stream whether the find's launch has retired cost ~10 us per pod)
+    if (c->P || c->side_streams_used) { int rc_ = sync_all(c); if (rc_) return rc_; }
     if (!c->commit_host) return fail(c, NHDFIT_E_STATE, "no host block for the commit's result");
     CommitArgs ca;
     memset(&ca, 0, sizeof ca);
     ca.p0 = c->p0.p; ca.p1 = c->p1.p; ca.p2 = c->p2.p; ca.p3 = c->p3.p; ca.p4 = c->p4.p; ca.det = c->det.p;
     ca.node = node; ca.req = *req; ca.map = *map; ca.busy_time = busy_time; ca.sigs = sig_table(c);
     const uint32_t seq = ++c->commit_seq ? c->commit_seq : ++c->commit_seq;                 // (never 0: the block's resting value)
-    ca.host = c->commit_host; ca.seq = seq;
+    ca.host = c->commit_host; ca.seq = seq; ca.ncls = c->ncls;
     const auto t_launch = std::chrono::steady_clock::now();
     hipLaunchKernelGGL(k_commit, dim3(1), dim3(64), 0, c->stream, ca);       // (both pipes are idle: sync_all above)
     HIPCHK(c, hipGetLastError());

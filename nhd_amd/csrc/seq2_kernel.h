@@ -1174,3 +1174,82 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         __hip_atomic_store(&q.ctrl[1], (n_items < q.queue_len ? n_items : q.queue_len) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the workers leave once the queue is drained
     }
 }
+
+// ---- the commit step for one placement (nhdfit_commit) --------------------------------------------------------------------------
+// One wavefront: the node's five planes and its detail record are copied to LDS by sixteen lanes at once, the commit runs in its
+// wavefront form (commit_node_wave above: a batch of cores is one ballot, not a loop over bits - the form mode B's workers run, held
+// to the scalar form on emulated lanes, tests/test_wave_commit_emulation.py), the new state goes back by the same lanes and the
+// placement record crosses the link as 64 four-byte stores behind ONE wait (round 6: the scalar form on one lane took 12.2 us per
+// launch, profiles/r06 - a third of a pod's share of the scheduler's pod-at-a-time loop, nhd/NHDScheduler.py:289-304).  A commit the
+// reference would raise on (nhd/Node.py:700-704 and the IndexError paths behind it) is rare and takes the scalar form, whose partial
+// state is the documented one.
+__global__ __launch_bounds__(64) void k_commit(CommitArgs a) {
+    __shared__ NodeState s_st;
+    __shared__ nhdfit_detail s_dd;
+    __shared__ nhdfit_placement s_pl;
+    const uint32_t lane = threadIdx.x;
+    {
+        uint32_t* st = reinterpret_cast<uint32_t*>(&s_st);
+        if (lane < 5) {
+            const uint4 q = lane == 0 ? *reinterpret_cast<const uint4*>(a.p0 + a.node) : lane == 1 ? *reinterpret_cast<const uint4*>(a.p1 + a.node) :
+                            lane == 2 ? *reinterpret_cast<const uint4*>(a.p2 + a.node) : lane == 3 ? *reinterpret_cast<const uint4*>(a.p3 + a.node) :
+                                        *reinterpret_cast<const uint4*>(a.p4 + a.node);
+            st[lane * 4 + 0] = q.x; st[lane * 4 + 1] = q.y; st[lane * 4 + 2] = q.z; st[lane * 4 + 3] = q.w;
+        }
+        if (lane >= 8 && lane < 8 + sizeof(nhdfit_detail) / 16) {
+            const uint4 q = reinterpret_cast<const uint4*>(a.det + a.node)[lane - 8];
+            uint32_t* dd = reinterpret_cast<uint32_t*>(&s_dd) + (lane - 8) * 4;
+            dd[0] = q.x; dd[1] = q.y; dd[2] = q.z; dd[3] = q.w;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    auto publish = [&]() {                                         // the record in LDS -> the host block, the call's sequence number behind it
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&a.host->place)[lane] = reinterpret_cast<const uint32_t*>(&s_pl)[lane];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(&a.host->flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    bool nic_missing = false;
+    for (uint32_t g = 0; g < a.req.n_groups; ++g)                  // GetNicObjFromIndex returns None: IndexError before anything
+        nic_missing |= (uint32_t)a.map.nic_idx[g] >= s_dd.nic_cnt[a.map.nic_numa[g] & 1];   // of that group is touched (nhd/Node.py:700-704);
+    if (nic_missing) {                                             // the mirror is left alone
+        if (lane < sizeof(nhdfit_placement) / 4) reinterpret_cast<uint32_t*>(&s_pl)[lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) s_pl.status = kCommitWouldRaise;
+        publish();
+        return;
+    }
+    const int status = commit_node_wave(s_st, s_dd, a.req, a.map, a.busy_time, a.sigs, a.ncls, s_pl, lane);
+    if (status == kCommitWouldRaise) {                             // (every lane holds the same status)
+        if (lane == 0) {
+            NodeState s;
+            s.p0 = a.p0[a.node]; s.p1 = a.p1[a.node]; s.p2 = a.p2[a.node]; s.p3 = a.p3[a.node]; s.p4 = a.p4[a.node];
+            nhdfit_detail d = a.det[a.node];
+            nhdfit_placement pl;
+            memset(&pl, 0, sizeof pl);
+            commit_node(s, d, a.req, a.map, a.busy_time, a.sigs, pl);
+            s_st = s; s_dd = d; s_pl = pl;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    {
+        const uint32_t* st = reinterpret_cast<const uint32_t*>(&s_st);
+        if (lane < 5) {
+            const uint4 q = make_uint4(st[lane * 4], st[lane * 4 + 1], st[lane * 4 + 2], st[lane * 4 + 3]);
+            if (lane == 0) *reinterpret_cast<uint4*>(a.p0 + a.node) = q;
+            else if (lane == 1) *reinterpret_cast<uint4*>(a.p1 + a.node) = q;
+            else if (lane == 2) *reinterpret_cast<uint4*>(a.p2 + a.node) = q;
+            else if (lane == 3) *reinterpret_cast<uint4*>(a.p3 + a.node) = q;
+            else *reinterpret_cast<uint4*>(a.p4 + a.node) = q;
+        }
+        if (lane >= 8 && lane < 8 + sizeof(nhdfit_detail) / 16) {
+            const uint32_t* dd = reinterpret_cast<const uint32_t*>(&s_dd) + (lane - 8) * 4;
+            reinterpret_cast<uint4*>(a.det + a.node)[lane - 8] = make_uint4(dd[0], dd[1], dd[2], dd[3]);
+        }
+    }
+    publish();
+}

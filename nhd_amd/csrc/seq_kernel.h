@@ -569,27 +569,11 @@ struct CommitHost { uint32_t flag; uint32_t pad[3]; nhdfit_placement place; };
 struct CommitArgs {
     nhdfit_plane0* p0; nhdfit_plane1* p1; nhdfit_plane2* p2; nhdfit_plane3* p3; nhdfit_plane4* p4; nhdfit_detail* det;
     uint32_t node; nhdfit_req req; nhdfit_mapping map; double busy_time; SigTable sigs; CommitHost* host; uint32_t seq;
+    uint32_t ncls;                 // capacity classes of the dictionary (the wavefront form's signature keys)
 };
 __device__ __forceinline__ void commit_publish(CommitHost* h, const nhdfit_placement& pl, uint32_t seq) {
     h->place = pl;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&h->flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ __launch_bounds__(64) void k_commit(CommitArgs a) {
-    if (threadIdx.x != 0) return;
-    NodeState s;
-    s.p0 = a.p0[a.node]; s.p1 = a.p1[a.node]; s.p2 = a.p2[a.node]; s.p3 = a.p3[a.node]; s.p4 = a.p4[a.node];
-    nhdfit_detail d = a.det[a.node];
-    nhdfit_placement pl;
-    memset(&pl, 0, sizeof pl);
-    for (uint32_t g = 0; g < a.req.n_groups; ++g)                  // GetNicObjFromIndex returns None: IndexError before anything
-        if ((uint32_t)a.map.nic_idx[g] >= d.nic_cnt[a.map.nic_numa[g] & 1]) {   // of that group is touched (nhd/Node.py:700-704);
-            pl.status = kCommitWouldRaise;                         // the mirror is left alone
-            commit_publish(a.host, pl, a.seq);
-            return;
-        }
-    commit_node(s, d, a.req, a.map, a.busy_time, a.sigs, pl);
-    a.p0[a.node] = s.p0; a.p1[a.node] = s.p1; a.p2[a.node] = s.p2; a.p3[a.node] = s.p3; a.p4[a.node] = s.p4;
-    a.det[a.node] = d;
-    commit_publish(a.host, pl, a.seq);
-}
+// (k_commit itself: seq2_kernel.h, behind the wavefront form of the commit step)

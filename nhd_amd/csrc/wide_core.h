@@ -194,16 +194,18 @@ NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const R& r, const WideCap
             if (numa[g] == u) order[cnt++] = g;
     for (uint32_t g = 0; g < G; ++g)
         if (n.nic_cnt[numa[g]] == 0) return false;             // a NUMA node without NICs hosts no group (quirk Q3)
-    // The reference looks for a negative remainder on EVERY NIC of the node, picked or not (`any(x < 0 for y in nic_ttls ...)`,
-    // Matcher.py:267).  The shipped capacities are never negative; under ENABLE_SHARING a NIC carrying more than its capacity
-    // (speed_used above speed * 0.9) makes every combination fail: the node offers no NIC candidates at all.
-    if (caps.sh)
-        for (uint32_t u = 0; u < U; ++u)
-            for (uint32_t k = 0; k < n.nic_cnt[u]; ++k)
-                if (caps.free_of(n, u, k, 0) < 0 || caps.free_of(n, u, k, 1) < 0) return false;
     bool prune = true;
     for (uint32_t g = 0; g < G; ++g)
         if (!(r.rx[g] >= 0) || !(r.tx[g] >= 0)) prune = false;
+    // The reference looks for a negative remainder on EVERY NIC of the node, picked or not, AFTER the combination's demands were
+    // subtracted (`any(x < 0 for y in nic_ttls ...)`, Matcher.py:262-267).  The shipped capacities are never negative; under
+    // ENABLE_SHARING a NIC carrying more than its capacity (speed_used above speed * 0.9) makes every combination of non-negative
+    // demands fail: the node offers no NIC candidates at all.  A negative (or NaN) demand can lift such a NIC back above zero - those
+    // requests take the enumeration as the reference writes it, with the check over all NICs behind every combination.
+    if (caps.sh && prune)
+        for (uint32_t u = 0; u < U; ++u)
+            for (uint32_t k = 0; k < n.nic_cnt[u]; ++k)
+                if (caps.free_of(n, u, k, 0) < 0 || caps.free_of(n, u, k, 1) < 0) return false;
     // groups order[0..pos] assigned: does the NIC of the newest one still hold, and its switch?
     auto nic_holds = [&](uint32_t upto, uint32_t u, uint32_t k) {
         double rx = caps.free_of(n, u, k, 0), tx = caps.free_of(n, u, k, 1);
@@ -266,6 +268,9 @@ NHD_HD bool wide_nic_choice(const nhdfit_wide_node& n, const R& r, const WideCap
             const uint32_t g = order[q];
             ok = nic_holds(G - 1, numa[g], pick[g]) && (!pci || switch_holds(G - 1, n.nic_sw[numa[g]][pick[g]]));
         }
+        if (caps.sh)                                           // ... and no NIC of the node, picked or not, is left below zero (Matcher.py:267)
+            for (uint32_t u = 0; u < U && ok; ++u)
+                for (uint32_t k = 0; k < n.nic_cnt[u] && ok; ++k) ok = nic_holds(G - 1, u, k);
         if (ok) { for (uint32_t q = 0; q < G; ++q) nic_idx[q] = (int8_t)pick[q]; return true; }
         int pos = (int)G - 1;
         while (pos >= 0) {

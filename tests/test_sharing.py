@@ -132,3 +132,38 @@ def test_oracle_with_its_switch_flipped_equals_the_reference_with_its_constant_f
         assert placed >= 3
     finally:
         ref.node_mod.ENABLE_SHARING = False
+
+
+def _odd_traffic(rng):
+    s = _traffic(rng, 3)
+    for g in s["groups"]:
+        g["rx"] = float(rng.choice([-60, -30, -5, 0, 10, 25]))
+        g["tx"] = float(rng.choice([-90, -10, 0, 5, 12.25]))
+    return s
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_negative_demands_meet_oversubscribed_nics_as_in_the_reference(sharing, seed):
+    """the reference looks for negative remainders AFTER the combination's demands were subtracted (nhd/Matcher.py:262-267),
+    so a negative demand can lift a NIC that carries more than its capacity back above zero - and a NIC nobody picks still rules the
+    combination out.  Host build against the oracle; in the build container the oracle against the reference with its constant flipped."""
+    rng = np.random.default_rng(9400 + seed)
+    descs = util.random_cluster_desc(9400 + seed, 8, occupancy=0.05)
+    for d in descs:
+        d["nic_speed_used"] = [[float(rng.choice([0, 10, 47.5, 95.0], p=[0.4, 0.2, 0.2, 0.2])), float(rng.choice([0, 5, 89.5, 120.0], p=[0.4, 0.2, 0.2, 0.2]))]
+                               for _ in d["nic_pods_used"]]
+    specs = [_odd_traffic(rng) for _ in range(30)]
+    tops = [refmodel.make_topology(s) for s in specs]
+    nl = util.build_cluster(descs)
+    want = [as_jsonable(O.find_node(nl, t, util.CLOCK)) for t in tops]
+    got = _host(util.CLOCK).FindNodes(nl, tops)
+    assert [as_jsonable(r) for r in got] == want
+    if ref_loader.available():
+        ref = ref_loader.load()
+        ref_loader.VirtualClock(util.CLOCK).install()
+        ref.node_mod.ENABLE_SHARING = True
+        try:
+            rnl = util.build_cluster(descs, ref)
+            assert [as_jsonable(ref_loader.find_node(rnl, refmodel.make_topology(s, ref))) for s in specs] == want
+        finally:
+            ref.node_mod.ENABLE_SHARING = False

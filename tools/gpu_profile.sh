@@ -19,4 +19,8 @@ for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   if [ -n "${QUICK:-}" ] && [ $i -ne 1 ] && [ $i -ne 3 ] && [ $i -ne 4 ]; then continue; fi
   timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/pmc$i -o p -- $BENCH > $OUT/pmc$i.log 2>&1
 done
-find $OUT -name "*.csv" | head -20
+# the summaries stay, the per-dispatch tables go: gpurun copies back at most 64 MiB
+python $ROOT/tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+find $OUT -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} $OUT/kernel_stats.csv
+find $OUT \( -name "*kernel_trace.csv" -o -name "*counter_collection.csv" -o -name "*agent_info.csv" \) -delete
+du -sh $OUT
