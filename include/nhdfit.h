@@ -56,6 +56,12 @@ extern "C" {
 
 /* request flags */
 #define NHDFIT_RF_INITIAL_FILTER 0x01u   /* apply InitialNodeFilter (active && groups intersect), nhd/NHDScheduler.py:235-247 */
+#define NHDFIT_RF_NIC_SPLIT      0x02u   /* informational, set by the digests and ignored by the kernels: some group has several RX (or TX)
+                                            cores, its rx / tx are sums of their speeds.  Matters under ENABLE_SHARING only, where the
+                                            reference's commit adds the speeds to speed_used one by one (nhd/Node.py:754): the
+                                            caller decides whether the sum is the same f64 value (nhd_amd/pack.py, Packer.share_exact) */
+#define NHDFIT_RF_NIC_SPLIT_DYADIC 0x04u /* beside NHDFIT_RF_NIC_SPLIT: every speed of such a group is a non-negative multiple of 2^-20 below
+                                            2^31 - sums of such values are exact in f64 in any order while they stay below 2^33 */
 
 /* map types = values of nhd.CfgTopology.TopologyMapType (nhd/CfgTopology.py:41-45) */
 #define NHDFIT_MAP_INVALID 0u    /* never matches (Matcher.py:45-47) */
@@ -521,8 +527,9 @@ int nhdfit_reset_stats(nhdfit_ctx* ctx);
 /* ---- request digest straight from the wire format (host code, no GPU needed) -------------------------
  * The pod's Triad libconfig text -> nhdfit_req, replacing TriadCfgParser(text, False).CfgToTopology(False)
  * (nhd/TriadCfgParser.py:337-380, called from nhd/NHDScheduler.py:262-270) followed by the getters FindNode
- * applies to the resulting CfgTopology (nhd/CfgTopology.py:199-232).  `flags` / `groups` (the pod's NHD_GROUP
- * annotation, nhd/K8SMgr.py:152-165) are not part of the text: the caller fills them in.
+ * applies to the resulting CfgTopology (nhd/CfgTopology.py:199-232).  NHDFIT_RF_INITIAL_FILTER / `groups` (the pod's NHD_GROUP
+ * annotation, nhd/K8SMgr.py:152-165) are not part of the text: the caller fills them in (`flags` comes back holding
+ * NHDFIT_RF_NIC_SPLIT or nothing).
  * Returns 0, or one of the codes below with a message in err[errlen]. */
 #define NHDFIT_WIRE_NONE   1   /* the reference's CfgToTopology returns None for this text (pod not scheduled) */
 #define NHDFIT_WIRE_RAISE  2   /* the reference would raise (malformed text, value of the wrong type)           */

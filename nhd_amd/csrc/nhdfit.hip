@@ -317,6 +317,15 @@ int fail(nhdfit_ctx* c, int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail((c), NHDFIT_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// Everything that puts work on a stream clears known_idle in one place: the HIP calls through HIPCHK above, the kernel launches through
+// LAUNCH, the collectives through the comma form at their call sites (`(c->known_idle = false, g_rccl).AllReduce(...)`) - the
+// idle shortcut of stage_requests must never see a stale `true`.
+#define LAUNCH(c, ...)                                   \
+    do {                                                 \
+        (c)->known_idle = false;                         \
+        hipLaunchKernelGGL(__VA_ARGS__);                 \
+    } while (0)
+
 // Waiting for a stream: the runtime's own wait parks the thread on the queue's interrupt, and the wake-up costs tens of
 // microseconds - as much as a whole step of the pipelined form, half of what a 20-step region loses at its end, a third of a
 // batch call through host buffers.  The scheduler's thread has nothing else to do while its one call is in flight (the reference
@@ -436,7 +445,7 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
     if (e == hipSuccess) e = hipMemsetAsync(c->xnx.p, 0, 2 * sizeof(uint32_t), c->stream);
     if (e == hipSuccess) e = c->asc.reserve(kAscEntries);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_build_asc, dim3((kAscEntries + 255) / 256), dim3(256), 0, c->stream, c->asc.p);
+        LAUNCH(c, k_build_asc, dim3((kAscEntries + 255) / 256), dim3(256), 0, c->stream, c->asc.p);
         e = hipGetLastError();
         if (e == hipSuccess && c->use_set_states) {
             std::vector<uint64_t> info;
@@ -452,7 +461,7 @@ int nhdfit_create(int device_id, nhdfit_ctx** out) {
         }
         if (e == hipSuccess) e = c->choose_tab.reserve(kChooseEntries);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_build_choose, dim3((kChooseEntries + 255) / 256), dim3(256), 0, c->stream, c->asc.p, c->choose_tab.p);
+            LAUNCH(c, k_build_choose, dim3((kChooseEntries + 255) / 256), dim3(256), 0, c->stream, c->asc.p, c->choose_tab.p);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = wait_stream(c->stream);
@@ -904,7 +913,7 @@ int order_chunks(nhdfit_ctx* c, uint32_t first_chunk, uint32_t n_chunks, bool ev
     for (int w = 0; w < kWClasses; ++w) { o.rec[w] = c->rec[w].p; o.bt[w] = c->rec_bt[w].p; }
     o.first_chunk = first_chunk; o.n_chunks = n_chunks;
     o.pair_D[0] = c->order_D[0] == ~0u ? 0u : c->order_D[0]; o.pair_D[1] = c->order_D[1] == ~0u ? 0u : c->order_D[1];
-    hipLaunchKernelGGL(k_xorder, dim3((n_chunks * (uint32_t)kWClasses + 3) / 4), dim3(256), 0, c->stream, o);
+    LAUNCH(c, k_xorder, dim3((n_chunks * (uint32_t)kWClasses + 3) / 4), dim3(256), 0, c->stream, o);
     HIPCHK(c, hipGetLastError());
     return NHDFIT_OK;
 }
@@ -947,10 +956,10 @@ int ensure_records(nhdfit_ctx* c) {
         }
         const dim3 grid((count + 255) / 256), block(256);
         if (pass == 0) {
-            hipLaunchKernelGGL(k_xkeys, grid, block, 0, c->stream, r);
-            hipLaunchKernelGGL(k_xassign, dim3(1), dim3(1024), 0, c->stream, r.x);
+            LAUNCH(c, k_xkeys, grid, block, 0, c->stream, r);
+            LAUNCH(c, k_xassign, dim3(1), dim3(1024), 0, c->stream, r.x);
         }
-        hipLaunchKernelGGL(k_xrecords, grid, block, 0, c->stream, r);
+        LAUNCH(c, k_xrecords, grid, block, 0, c->stream, r);
         HIPCHK(c, hipGetLastError());
         if (pass == 1) break;
         uint32_t nx[2] = {0, 0};
@@ -1220,25 +1229,25 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
     if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc) return rc; }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][0], p.stream));
     if (c->x_spill) {               // more node classes than LDS rows: the variant whose fit role reads the rest from global memory
-        if (big) hipLaunchKernelGGL((k_step<512, true>), dim3(grid), dim3(512), lds, p.stream, a);
-        else     hipLaunchKernelGGL((k_step<256, true>), dim3(grid), dim3(256), lds, p.stream, a);
+        if (big) LAUNCH(c, (k_step<512, true>), dim3(grid), dim3(512), lds, p.stream, a);
+        else     LAUNCH(c, (k_step<256, true>), dim3(grid), dim3(256), lds, p.stream, a);
     } else
 #ifdef NHDFIT_TUNING         // (role_kernels / split are switched by the tuning build's environment only: never set in libnhdfit.so)
     if (c->role_kernels) {
         const uint32_t nb[5] = {a.nb_choose, a.nb_shapes, a.nb_finish, a.nb_digest, nb_fit};
-        if (nb[0]) hipLaunchKernelGGL((k_role<512, 0>), dim3(nb[0]), dim3(512), 0, p.stream, a);
-        if (nb[1]) hipLaunchKernelGGL((k_role<512, 1>), dim3(nb[1]), dim3(512), map_lds_bytes<512>(), p.stream, a);
-        if (nb[2]) hipLaunchKernelGGL((k_role<512, 2>), dim3(nb[2]), dim3(512), map_lds_bytes<512>(), p.stream, a);
-        if (nb[3]) hipLaunchKernelGGL((k_role<512, 3>), dim3(nb[3]), dim3(512), kDigestLds, p.stream, a);
-        if (nb[4]) hipLaunchKernelGGL((k_role<512, 4>), dim3(nb[4]), dim3(512), lds, p.stream, a);
+        if (nb[0]) LAUNCH(c, (k_role<512, 0>), dim3(nb[0]), dim3(512), 0, p.stream, a);
+        if (nb[1]) LAUNCH(c, (k_role<512, 1>), dim3(nb[1]), dim3(512), map_lds_bytes<512>(), p.stream, a);
+        if (nb[2]) LAUNCH(c, (k_role<512, 2>), dim3(nb[2]), dim3(512), map_lds_bytes<512>(), p.stream, a);
+        if (nb[3]) LAUNCH(c, (k_role<512, 3>), dim3(nb[3]), dim3(512), kDigestLds, p.stream, a);
+        if (nb[4]) LAUNCH(c, (k_role<512, 4>), dim3(nb[4]), dim3(512), lds, p.stream, a);
     } else
     if (grid == nb_fit && c->split) {
-        if (big) hipLaunchKernelGGL((k_fit_only<512>), dim3(grid), dim3(512), lds, p.stream, a.fit);
-        else     hipLaunchKernelGGL((k_fit_only<256>), dim3(grid), dim3(256), lds, p.stream, a.fit);
+        if (big) LAUNCH(c, (k_fit_only<512>), dim3(grid), dim3(512), lds, p.stream, a.fit);
+        else     LAUNCH(c, (k_fit_only<256>), dim3(grid), dim3(256), lds, p.stream, a.fit);
     } else
 #endif
-    if (big) hipLaunchKernelGGL((k_step<512>), dim3(grid), dim3(512), lds, p.stream, a);
-    else     hipLaunchKernelGGL((k_step<256>), dim3(grid), dim3(256), lds, p.stream, a);
+    if (big) LAUNCH(c, (k_step<512>), dim3(grid), dim3(512), lds, p.stream, a);
+    else     LAUNCH(c, (k_step<256>), dim3(grid), dim3(256), lds, p.stream, a);
     HIPCHK(c, hipGetLastError());
     if (with_fit && c->n_wide) {
         // the general path for the nodes beyond the fast layout: their verdict bits and scores join this step's (same stream,
@@ -1250,7 +1259,7 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
         wa.nm = c->want_bitmap ? reinterpret_cast<unsigned long long*>(p.nm.p) : nullptr; wa.chunks = chunks;
         wa.score = p.score[bf].p; wa.global_base = c->global_base; wa.share = c->sharing ? c->wide_share.p : nullptr;
         const uint64_t pairs = (uint64_t)c->n_wide * P;
-        hipLaunchKernelGGL(k_wide_eval, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, p.stream, wa);
+        LAUNCH(c, k_wide_eval, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, p.stream, wa);
         HIPCHK(c, hipGetLastError());
     }
     if (timed) {
@@ -1281,13 +1290,13 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
         if (c->comm) {      // one communicator -> its collectives stay on one stream (s_red), in step order
             HIPCHK(c, hipEventRecord(p.ev_fit[bf], p.stream));
             HIPCHK(c, hipStreamWaitEvent(c->s_red, p.ev_fit[bf], 0));
-            ncclResult_t r = g_rccl.AllReduce(p.score[bf].p, p.score[bf].p, P, ncclUint64, ncclMax, c->comm, c->s_red);
+            ncclResult_t r = (c->known_idle = false, g_rccl).AllReduce(p.score[bf].p, p.score[bf].p, P, ncclUint64, ncclMax, c->comm, c->s_red);
             if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
             after = c->s_red;
         }
         if (c->want_map && c->n_big_pods) {      // pods with 4 proc groups: generic set model (scratch-heavy, kept out of k_step)
             const dim3 mg((P + kMapWaves - 1) / kMapWaves), mb(64 * kMapWaves);
-            hipLaunchKernelGGL(k_map<true>, mg, mb, 0, after, map_args(bf));
+            LAUNCH(c, k_map<true>, mg, mb, 0, after, map_args(bf));
             HIPCHK(c, hipGetLastError());
         }
         if (c->comm) HIPCHK(c, hipEventRecord(p.ev_red[bf], c->s_red));
@@ -1310,7 +1319,7 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
 int convert_rows(nhdfit_ctx* c, Pipe& p) {
     const uint32_t chunks = (c->n + 63) / 64, tiles = (c->P + kTile - 1) / kTile;
     HIPCHK(c, c->bitmap.reserve((size_t)chunks * c->P));
-    hipLaunchKernelGGL(k_rows, dim3((tiles * chunks + 3) / 4), dim3(256), 0, p.stream, p.nm.p, c->bitmap.p, chunks, c->P);
+    LAUNCH(c, k_rows, dim3((tiles * chunks + 3) / 4), dim3(256), 0, p.stream, p.nm.p, c->bitmap.p, chunks, c->P);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, wait_stream(p.stream));
     return NHDFIT_OK;
@@ -1321,7 +1330,7 @@ int convert_rows_t(nhdfit_ctx* c, Pipe& p) {
     const uint32_t chunks = (c->n + 63) / 64, tiles = (c->P + kTile - 1) / kTile;
     const uint32_t groups = (chunks + kRowsTChunks - 1) / kRowsTChunks;
     HIPCHK(c, c->rows_t.reserve((size_t)chunks * c->P));
-    hipLaunchKernelGGL(k_rows_t, dim3((tiles * groups + 3) / 4), dim3(256), 0, p.stream, p.nm.p, c->rows_t.p, chunks, c->P);
+    LAUNCH(c, k_rows_t, dim3((tiles * groups + 3) / 4), dim3(256), 0, p.stream, p.nm.p, c->rows_t.p, chunks, c->P);
     HIPCHK(c, hipGetLastError());
     return NHDFIT_OK;
 }
@@ -1358,7 +1367,7 @@ int flush_pipeline(nhdfit_ctx* c) {
                 HIPCHK(c, hipMemcpyAsync(c->role_clock.p, init, sizeof init, hipMemcpyHostToDevice, p.stream));
                 a.clk = c->role_clock.p;
             }
-            hipLaunchKernelGGL(k_map_tiles, dim3(a.nsteps * tiles), dim3(256), map_tile_lds_bytes<256>(), p.stream, a);
+            LAUNCH(c, k_map_tiles, dim3(a.nsteps * tiles), dim3(256), map_tile_lds_bytes<256>(), p.stream, a);
             HIPCHK(c, hipGetLastError());
             if (drain_prof) {
                 unsigned long long t[16];
@@ -1449,7 +1458,7 @@ int nhdfit_fetch(nhdfit_ctx* c, uint64_t* score_out, uint64_t* bitmap_out, nhdfi
         wm.wide = c->wide.p; wm.n_wide = c->n_wide; wm.reqs = c->reqs.p; wm.P = P; wm.caps = c->caps.p;
         wm.score = p.score[b].p; wm.global_base = c->global_base; wm.n = c->n; wm.out = p.maps[b].p;
         wm.scratch = c->wide_scratch.p; wm.flags = c->wide_flags.p; wm.share = c->sharing ? c->wide_share.p : nullptr;
-        hipLaunchKernelGGL(k_wide_map, dim3(kWideMapThreads), dim3(64), 0, p.stream, wm);
+        LAUNCH(c, k_wide_map, dim3(kWideMapThreads), dim3(64), 0, p.stream, wm);
         HIPCHK(c, hipGetLastError());
         uint32_t fl[4] = {0, 0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(fl, c->wide_flags.p, sizeof fl, hipMemcpyDeviceToHost, p.stream));
@@ -1585,8 +1594,8 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     }
     const auto t_launch = std::chrono::steady_clock::now();
     c->P = 0;                                                   // nothing is staged for nhdfit_enqueue_step / nhdfit_fetch
-    if (lone) hipLaunchKernelGGL((k_find1<256>), dim3(a1.nb), dim3(256), kLoneLds + map_tile_lds_bytes<256>(), c->stream, a1);
-    else hipLaunchKernelGGL((k_find<256>), dim3(a.s.nb_digest + a.s.nb_fit), dim3(256), lds, c->stream, a);
+    if (lone) LAUNCH(c, (k_find1<256>), dim3(a1.nb), dim3(256), kLoneLds + map_tile_lds_bytes<256>(), c->stream, a1);
+    else LAUNCH(c, (k_find<256>), dim3(a.s.nb_digest + a.s.nb_fit), dim3(256), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     uint32_t seen = 0;
     for (uint32_t spins = 1;; ++spins) {
@@ -1632,7 +1641,7 @@ int find_small(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
         uint64_t* send = c->pin_score.p + kTile;
         for (uint32_t k = 0; k < P; ++k) send[k] = h->score[c->perm[k]];
         HIPCHK(c, hipMemcpyAsync(c->find_red.p, send, (size_t)P * 8, hipMemcpyHostToDevice, c->s_red));
-        ncclResult_t r = g_rccl.AllReduce(c->find_red.p, c->find_red.p, P, ncclUint64, ncclMax, c->comm, c->s_red);
+        ncclResult_t r = (c->known_idle = false, g_rccl).AllReduce(c->find_red.p, c->find_red.p, P, ncclUint64, ncclMax, c->comm, c->s_red);
         if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
         HIPCHK(c, hipMemcpyAsync(c->pin_score.p, c->find_red.p, (size_t)P * 8, hipMemcpyDeviceToHost, c->s_red));
         HIPCHK(c, wait_stream(c->s_red));
@@ -1748,7 +1757,7 @@ int find_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, double now, co
     lds = std::max(lds, std::max(kDigestLds, map_tile_lds_bytes<256>()));
     lap("records, items, arguments");
     const auto t_launch = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL((k_findn<256>), dim3(a.nb_lead + a.s.nb_fit), dim3(256), lds, c->stream, a);
+    LAUNCH(c, (k_findn<256>), dim3(a.nb_lead + a.s.nb_fit), dim3(256), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     lap("launch call");
     uint32_t seen = 0;
@@ -1926,7 +1935,7 @@ int nhdfit_wide_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_req* req, cons
     memset(&wa, 0, sizeof wa);
     wa.wide = c->wide.p; wa.slot = (uint32_t)slot; wa.req = *req; wa.map = *map; wa.busy_time = busy_time; wa.out = c->wide_place.p;
     wa.share = c->sharing ? c->wide_share.p : nullptr;
-    hipLaunchKernelGGL(k_wide_commit, dim3(1), dim3(64), 0, c->stream, wa);
+    LAUNCH(c, k_wide_commit, dim3(1), dim3(64), 0, c->stream, wa);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(place_out, c->wide_place.p, sizeof *place_out, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, wait_stream(c->stream));
@@ -1961,12 +1970,12 @@ int nhdfit_big_find(nhdfit_ctx* c, const nhdfit_big_req* reqs, uint32_t P, doubl
         ea.wide = c->wide.p; ea.n_wide = c->n_wide; ea.reqs = c->big_reqs.p; ea.P = P; ea.caps = c->caps.p; ea.busy_from = busy_threshold(now);
         ea.share = c->sharing ? c->wide_share.p : nullptr;
         ea.cand = cand && chunks ? c->big_cand.p : nullptr; ea.score = c->big_score.p; ea.global_base = c->global_base; ea.flags = c->big_flags.p;
-        hipLaunchKernelGGL(k_big_eval, dim3((units + 63) / 64, P), dim3(64), 0, c->stream, ea);
+        LAUNCH(c, k_big_eval, dim3((units + 63) / 64, P), dim3(64), 0, c->stream, ea);
         HIPCHK(c, hipGetLastError());
     }
     if (c->comm) {      // sharded: one all-reduce(max) of the P packed scores picks the cluster's winners; the owner maps (k_big_map skips the rest)
         HIPCHK(c, wait_stream(c->stream));
-        ncclResult_t r = g_rccl.AllReduce(c->big_score.p, c->big_score.p, P, ncclUint64, ncclMax, c->comm, c->s_red);
+        ncclResult_t r = (c->known_idle = false, g_rccl).AllReduce(c->big_score.p, c->big_score.p, P, ncclUint64, ncclMax, c->comm, c->s_red);
         if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
         HIPCHK(c, wait_stream(c->s_red));
     }
@@ -1988,7 +1997,7 @@ int nhdfit_big_find(nhdfit_ctx* c, const nhdfit_big_req* reqs, uint32_t P, doubl
         ma.stride = stride; ma.slots_g = (int32_t)wide_table_slots(wide_ipow(umax, gmax)); ma.slots_c = (int32_t)wide_table_slots(wide_ipow(umax, gmax + 1)); ma.workers = workers;
         ma.lds_tables = lds_tables ? 1u : 0u;
         if (lds_tables) HIPCHK(c, hipFuncSetAttribute((const void*)k_big_map, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        hipLaunchKernelGGL(k_big_map, dim3(workers), dim3(64), lds_tables ? stride * sizeof(int32_t) : 0, c->stream, ma);
+        LAUNCH(c, k_big_map, dim3(workers), dim3(64), lds_tables ? stride * sizeof(int32_t) : 0, c->stream, ma);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(map_out, c->big_maps.p, (size_t)P * sizeof *map_out, hipMemcpyDeviceToHost, c->stream));
     } else if (map_out) {
@@ -2029,7 +2038,7 @@ int nhdfit_big_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_big_req* req, c
     ba.wide = c->wide.p; ba.slot = slot; ba.node = node; ba.req = *req; ba.map = *map; ba.busy_time = busy_time; ba.sigs = sig_table(c);
     ba.share = c->sharing ? c->wide_share.p : nullptr;
     ba.out = c->big_place.p;
-    hipLaunchKernelGGL(k_big_commit, dim3(1), dim3(64), 0, c->stream, ba);
+    LAUNCH(c, k_big_commit, dim3(1), dim3(64), 0, c->stream, ba);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(place_out, c->big_place.p, sizeof *place_out, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, wait_stream(c->stream));
@@ -2201,9 +2210,9 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
             }
         }
         HIPCHK(c, hipMemcpyAsync(c->order.p, order_h, 2 * (size_t)P * sizeof(uint32_t), hipMemcpyHostToDevice, sm));
-        hipLaunchKernelGGL(k_nogpu, dim3(chunks), dim3(64), 0, sm, c->p2.p, c->n, c->nogpu.p);
+        LAUNCH(c, k_nogpu, dim3(chunks), dim3(64), 0, sm, c->p2.p, c->n, c->nogpu.p);
         const int b0 = (int)((p.n_fit - 1) % kBufs);
-        hipLaunchKernelGGL(k_tile_masks, dim3(tiles), dim3(64), 0, sm, p.hdr[b0].p, tiles, c->tile_masks.p);
+        LAUNCH(c, k_tile_masks, dim3(tiles), dim3(64), 0, sm, p.hdr[b0].p, tiles, c->tile_masks.p);
         HIPCHK(c, hipGetLastError());
     }
     // pod-major verdict rows of the snapshot + empty taken / first-touch state (again before a fallback pass)
@@ -2219,7 +2228,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         ra.counters = c->seq_counters.p; ra.flags = c->seq_flags.p;
         if (engine) { ra.ctrl = c->seq_ctrl.p; ra.mat = c->seq_mat.p; ra.queue = c->seq_queue.p; ra.queue_len = queue_len; }
         const uint32_t most = std::max(std::max(ra.chunks, ra.n), ra.queue_len);
-        hipLaunchKernelGGL(k_seq_reset, dim3(std::min<uint32_t>((most + 255) / 256, 1024u)), dim3(256), 0, sm, ra);
+        LAUNCH(c, k_seq_reset, dim3(std::min<uint32_t>((most + 255) / 256, 1024u)), dim3(256), 0, sm, ra);
         HIPCHK(c, hipGetLastError());
         return NHDFIT_OK;
     };
@@ -2248,8 +2257,8 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         HIPCHK(c, hipFuncSetAttribute(seq_pods == 16 ? (const void*)k_seq<16> : (const void*)k_seq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         const bool seq_prof = tune_env("NHDFIT_SEQ_PROF") != nullptr;
         if (seq_prof) { HIPCHK(c, c->role_clock.reserve(16)); g.prof = c->role_clock.p; }
-        if (seq_pods == 16) hipLaunchKernelGGL(k_seq<16>, dim3(1), dim3(1024), seq_lds, sm, g);
-        else hipLaunchKernelGGL(k_seq<8>, dim3(1), dim3(512), seq_lds, sm, g);
+        if (seq_pods == 16) LAUNCH(c, k_seq<16>, dim3(1), dim3(1024), seq_lds, sm, g);
+        else LAUNCH(c, k_seq<8>, dim3(1), dim3(512), seq_lds, sm, g);
         HIPCHK(c, hipGetLastError());
         if (seq_prof) {
             unsigned long long t[16];
@@ -2270,7 +2279,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         return NHDFIT_OK;
     };
     auto undo_all = [&]() -> int {                              // every node this batch touched goes back to its first-touch copy
-        hipLaunchKernelGGL(k_undo, dim3(P), dim3(64), 0, sm, sa);
+        LAUNCH(c, k_undo, dim3(P), dim3(64), 0, sm, sa);
         HIPCHK(c, hipGetLastError());
         return NHDFIT_OK;
     };
@@ -2299,7 +2308,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         // The decision engine (seq2_kernel.h): one block decides, the rest of the grid commits.
         const uint32_t* list_dev = c->order.p + P;              // [the pods without GPUs | every other pod] (uploaded behind the order)
         const uint32_t n_n = c->tn_n, n_g = P - c->tn_n;
-        hipLaunchKernelGGL(k_decide_prep, dim3((P + 255) / 256), dim3(256), 0, sm, list_dev, P, c->order.p, p.score[b].p, c->global_base, c->seq_ent.p);
+        LAUNCH(c, k_decide_prep, dim3((P + 255) / 256), dim3(256), 0, sm, list_dev, P, c->order.p, p.score[b].p, c->global_base, c->seq_ent.p);
         HIPCHK(c, hipGetLastError());
         DecideArgs qa;
         memset(&qa, 0, sizeof qa);
@@ -2318,8 +2327,8 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         for (uint32_t i = 0; i < P && !any_g4; ++i) any_g4 = reqs[i].n_groups > 3;
         HIPCHK(c, hipFuncSetAttribute(any_g4 ? (const void*)k_decide<true> : (const void*)k_decide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));   // (static: ~45 KB of the 160)
         static const uint32_t workers = tune_env("NHDFIT_SEQ_WORKERS") ? (uint32_t)atoi(tune_env("NHDFIT_SEQ_WORKERS")) : (uint32_t)kWorkerBlocks;   // tuning aid
-        if (any_g4) hipLaunchKernelGGL(k_decide<true>, dim3(1 + (workers ? workers : 1u)), dim3(64 * kDecideWaves), dyn, sm, qa);
-        else hipLaunchKernelGGL(k_decide<false>, dim3(1 + (workers ? workers : 1u)), dim3(64 * kDecideWaves), dyn, sm, qa);
+        if (any_g4) LAUNCH(c, k_decide<true>, dim3(1 + (workers ? workers : 1u)), dim3(64 * kDecideWaves), dyn, sm, qa);
+        else LAUNCH(c, k_decide<false>, dim3(1 + (workers ? workers : 1u)), dim3(64 * kDecideWaves), dyn, sm, qa);
         HIPCHK(c, hipGetLastError());
         uint32_t flags[4] = {0, 0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(flags, c->seq_flags.p, sizeof flags, hipMemcpyDeviceToHost, sm));
@@ -2415,7 +2424,7 @@ int nhdfit_commit(nhdfit_ctx* c, uint32_t node, const nhdfit_req* req, const nhd
     const uint32_t seq = ++c->commit_seq ? c->commit_seq : ++c->commit_seq;                 // (never 0: the block's resting value)
     ca.host = c->commit_host; ca.seq = seq; ca.ncls = c->ncls;
     const auto t_launch = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(k_commit, dim3(1), dim3(64), 0, c->stream, ca);       // (both pipes are idle: sync_all above)
+    LAUNCH(c, k_commit, dim3(1), dim3(64), 0, c->stream, ca);       // (both pipes are idle: sync_all above)
     HIPCHK(c, hipGetLastError());
     // the placement arrives in the fine-grained host block behind the sequence number: poll it (a launch that takes longer than
     // half a millisecond - it cannot, short of a fault - is waited for on its stream)
@@ -2482,7 +2491,7 @@ int nhdfit_apply_deltas(nhdfit_ctx* c, const nhdfit_delta* deltas, uint32_t n, u
     memset(&da, 0, sizeof da);
     da.p0 = c->p0.p; da.p1 = c->p1.p; da.p2 = c->p2.p; da.p3 = c->p3.p; da.p4 = c->p4.p; da.det = c->det.p; da.origin = c->origin.p;
     da.deltas = c->deltas.p; da.run = c->delta_run.p; da.n_runs = n_runs; da.sigs = sig_table(c); da.status = c->delta_status.p;
-    hipLaunchKernelGGL(k_delta, dim3((n_runs + 63) / 64), dim3(64), 0, c->stream, da);
+    LAUNCH(c, k_delta, dim3((n_runs + 63) / 64), dim3(64), 0, c->stream, da);
     HIPCHK(c, hipGetLastError());
     std::vector<uint8_t> st(n);
     HIPCHK(c, hipMemcpyAsync(st.data(), c->delta_status.p, n, hipMemcpyDeviceToHost, c->stream));
@@ -2585,8 +2594,8 @@ int nhdfit_comm_sendrecv(nhdfit_ctx* c, const void* send_buf, size_t send_bytes,
     HIPCHK(c, c->xfer_recv.reserve(recv_bytes ? recv_bytes : 1));
     if (sending) HIPCHK(c, hipMemcpyAsync(c->xfer_send.p, send_buf, send_bytes, hipMemcpyHostToDevice, c->s_red));
     ncclResult_t r = g_rccl.GroupStart();
-    if (r == ncclSuccess && sending) r = g_rccl.Send(c->xfer_send.p, send_bytes, ncclUint8, dst, c->comm, c->s_red);
-    if (r == ncclSuccess && receiving) r = g_rccl.Recv(c->xfer_recv.p, recv_bytes, ncclUint8, src, c->comm, c->s_red);
+    if (r == ncclSuccess && sending) r = (c->known_idle = false, g_rccl).Send(c->xfer_send.p, send_bytes, ncclUint8, dst, c->comm, c->s_red);
+    if (r == ncclSuccess && receiving) r = (c->known_idle = false, g_rccl).Recv(c->xfer_recv.p, recv_bytes, ncclUint8, src, c->comm, c->s_red);
     const ncclResult_t r2 = g_rccl.GroupEnd();
     if (r != ncclSuccess || r2 != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclSend / ncclRecv: %s", g_rccl.GetErrorString(r != ncclSuccess ? r : r2));
     if (receiving) HIPCHK(c, hipMemcpyAsync(recv_buf, c->xfer_recv.p, recv_bytes, hipMemcpyDeviceToHost, c->s_red));
@@ -2601,7 +2610,7 @@ int nhdfit_comm_allreduce_sum_u8(nhdfit_ctx* c, void* buf, size_t bytes) {
     HIPCHK(c, hipSetDevice(c->dev));
     HIPCHK(c, c->xfer_send.reserve(bytes));
     HIPCHK(c, hipMemcpyAsync(c->xfer_send.p, buf, bytes, hipMemcpyHostToDevice, c->s_red));
-    ncclResult_t r = g_rccl.AllReduce(c->xfer_send.p, c->xfer_send.p, bytes, ncclUint8, ncclSum, c->comm, c->s_red);
+    ncclResult_t r = (c->known_idle = false, g_rccl).AllReduce(c->xfer_send.p, c->xfer_send.p, bytes, ncclUint8, ncclSum, c->comm, c->s_red);
     if (r != ncclSuccess) return fail(c, NHDFIT_E_RCCL, "ncclAllReduce(uint8, sum): %s", g_rccl.GetErrorString(r));
     HIPCHK(c, hipMemcpyAsync(buf, c->xfer_send.p, bytes, hipMemcpyDeviceToHost, c->s_red));
     HIPCHK(c, wait_stream(c->s_red));
@@ -2683,7 +2692,7 @@ int nhdfit_group_find(nhdfit_group* g, const nhdfit_req* reqs, uint32_t P, doubl
             if (!c->n) {                                                 // a shard without nodes contributes "no feasible node"
                 if (p.score[b].reserve(P) != hipSuccess || hipMemsetAsync(p.score[b].p, 0, (size_t)P * 8, c->stream) != hipSuccess) { r = ncclSystemError; break; }
             }
-            r = g_rccl.AllReduce(p.score[b].p, p.score[b].p, P, ncclUint64, ncclMax, g->comm[k], c->stream);
+            r = (c->known_idle = false, g_rccl).AllReduce(p.score[b].p, p.score[b].p, P, ncclUint64, ncclMax, g->comm[k], c->stream);
         }
         ncclResult_t r2 = g_rccl.GroupEnd();
         if (r != ncclSuccess || r2 != ncclSuccess) { g->err = std::string("ncclAllReduce (group): ") + g_rccl.GetErrorString(r != ncclSuccess ? r : r2); return NHDFIT_E_RCCL; }

@@ -539,6 +539,9 @@ struct GroupTotals {
     unsigned proc = 0, help = 0, gpus = 0;
     bool proc_smt = false, helper_smt = false, nic_use = false;
     double rx = 0, tx = 0;
+    unsigned nic_pairs = 0;            // RX / TX core pairs of the group: more than one -> rx / tx are sums (NHDFIT_RF_NIC_SPLIT)
+    bool dyadic = true;                // every speed a non-negative multiple of 2^-20 below 2^31 (NHDFIT_RF_NIC_SPLIT_DYADIC)
+    void note(double v) { if (!(v >= 0.0) || !(v < 2147483648.0) || std::floor(v * 1048576.0) != v * 1048576.0) dyadic = false; }
 };
 
 // nhd/TriadCfgParser.py:134-309
@@ -618,10 +621,10 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
                     for (size_t g = 0; g < n; ++g) {
                         const double rs = speed_of(elem("rx_speeds", g), bad_speed);
                         (void)py_int(elem("rx_cores", g));
-                        pg.proc++; pg.rx += rs; pg.nic_use = true;
+                        pg.proc++; pg.rx += rs; pg.nic_use = true; pg.nic_pairs++; pg.note(rs);
                         const double ts = speed_of(elem("tx_speeds", g), bad_speed);
                         (void)py_int(elem("tx_cores", g));
-                        pg.proc++; pg.tx += ts;
+                        pg.proc++; pg.tx += ts; pg.note(ts);
                     }
                 } catch (const Raise&) { throw Reject{"error when parsing NIC fields"}; }
                   catch (const AttrMissing&) { throw Reject{"error when parsing NIC fields"}; }
@@ -680,10 +683,10 @@ void parse_mod_groups(const Value& cfg, const Value& topo, std::vector<GroupTota
                 for (size_t g = 0; g < n; ++g) {
                     const double rs = speed_of(elem(1, g), bad_speed);
                     (void)py_int(elem(0, g));
-                    pg.proc++; pg.rx += rs; pg.nic_use = true;
+                    pg.proc++; pg.rx += rs; pg.nic_use = true; pg.nic_pairs++; pg.note(rs);
                     const double ts = speed_of(elem(3, g), bad_speed);
                     (void)py_int(elem(2, g));
-                    pg.proc++; pg.tx += ts;
+                    pg.proc++; pg.tx += ts; pg.note(ts);
                 }
             }
             groups.push_back(pg);
@@ -755,6 +758,7 @@ void digest(const char* text, size_t len, R& r) {
     r.n_groups = (uint32_t)groups.size();
     r.map_type = map_type;
     r.hugepages_gb = (int32_t)(hp < INT32_MIN ? INT32_MIN : hp > INT32_MAX ? INT32_MAX : hp);
+    bool split_dyadic = true;
     for (size_t i = 0; i < groups.size(); ++i) {
         const GroupTotals& g = groups[i];
         if (g.proc > 255 || g.help > 255) throw Limit{"a proc group asks for more than 255 cores"};
@@ -768,7 +772,9 @@ void digest(const char* text, size_t len, R& r) {
         r.rx[i] = g.rx;
         r.tx[i] = g.tx;
         if (g.nic_use) r.nic_use |= (uint8_t)(1u << i);
+        if (g.nic_pairs > 1) { r.flags |= NHDFIT_RF_NIC_SPLIT; split_dyadic = split_dyadic && g.dyadic; }
     }
+    if ((r.flags & NHDFIT_RF_NIC_SPLIT) && split_dyadic) r.flags |= NHDFIT_RF_NIC_SPLIT_DYADIC;
     if (n_misc > 65535) throw Limit{"too many misc cores"};
     r.misc_nosmt = (uint16_t)n_misc;
     r.n_misc = (uint8_t)(n_misc > 255 ? 255 : n_misc);

@@ -140,6 +140,7 @@ class HipMatcher:
         tries again, nhd/NHDScheduler.py:278-287); each is logged.  `strict=True` raises instead."""
         self.logger = logging.getLogger(__name__)
         self.strict = strict
+        self.last_placements: List[Optional[dict]] = []    # physical ids per pod of the last ScheduleBatch (see there)
         self._warned: set = set()
         check_interpreter_set_model()
         if devices is not None:
@@ -547,6 +548,7 @@ class HipMatcher:
     def _run_checked(self, nl, tops, pod_groups, now, sequential, reqs=None, apply=False, big_reqs=None):
         if reqs is None:
             if not tops:
+                self.last_placements = []
                 return []
             for top in tops:
                 if len(top.proc_groups) == 0 and len(nl):
@@ -582,6 +584,17 @@ class HipMatcher:
             self._full_upload(nl)
             self._mirror_foreign = self._attached is not None
         self._warn_unmirrored()
+        if reqs is not None and self.packer.sharing:       # digested from config texts, and speed_used prices the NICs (nhd/Node.py:754)
+            for arr in (reqs, *(big_reqs or {}).values()):
+                for rq in (arr if arr.ndim else [arr]):
+                    if int(rq["n_groups"]) == 0:
+                        continue
+                    why = self.packer.admit_wire_request(rq)
+                    if why is not None:
+                        if self.strict:
+                            raise pack.UnsupportedNode(why)
+                        self.logger.error("a pod of the call cannot be answered exactly and is answered (None,): %s", why)
+                        rq["n_groups"] = 0                 # (an all-zero group count never matches)
         # (nhd/Node.py:20 ENABLE_SHARING = True: the packer mirrored every node for the general path, whose NIC stage prices a NIC at
         #  speed * pct - speed_used[x] as the reference does - nothing to route here: the table pass finds placeholders only)
         if reqs is None and any(pack.needs_general_path(top) for top in tops):
@@ -612,7 +625,7 @@ class HipMatcher:
             if pod_groups is not None:
                 for arr, idx in ((small, [p for p in range(n_pods) if not is_big[p]]), (bigs, [p for p in range(n_pods) if is_big[p]])):
                     for k, p in enumerate(idx):
-                        arr[k]["flags"] = pack.RF_INITIAL_FILTER
+                        arr[k]["flags"] |= pack.RF_INITIAL_FILTER
                         arr[k]["groups"] = self.packer.group_bits_known(pod_groups[p])
             return self._run_with_big(nl, is_big, small, bigs, now, cand, sequential, apply)
         if reqs is None:
@@ -624,7 +637,7 @@ class HipMatcher:
                 self.logger.error("pod %d of the call cannot be expressed as a request record and is answered (None,): %s", i, why)
         elif pod_groups is not None:                       # requests digested from config texts: InitialNodeFilter in the kernel
             for i in range(n_pods):
-                reqs[i]["flags"] = pack.RF_INITIAL_FILTER
+                reqs[i]["flags"] |= pack.RF_INITIAL_FILTER
                 reqs[i]["groups"] = self.packer.group_bits_known(pod_groups[i])
         places = None
         if sequential:

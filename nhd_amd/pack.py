@@ -33,6 +33,8 @@ MAX_HUGEPAGES_GB = 1022         # fit_core.h kMaxHpRows - 2
 
 NF_MAINTENANCE, NF_ACTIVE, NF_SMT, NF_HAS_GPU = 1, 2, 4, 8
 RF_INITIAL_FILTER = 1
+RF_NIC_SPLIT = 2                  # informational (include/nhdfit.h NHDFIT_RF_NIC_SPLIT): a group with several RX / TX cores
+RF_NIC_SPLIT_DYADIC = 4
 
 NIC_BW_AVAIL_PERCENT = 0.9      # nhd/Node.py:18: the default; the packer reads the constant of the module the node objects come from
 _MODULE_CONSTANTS = ("NIC_BW_AVAIL_PERCENT", "SCHEDULABLE_NIC_SPEED_THRESH_MBPS", "ENABLE_SHARING")   # nhd/Node.py:18-20
@@ -227,6 +229,15 @@ def get_pods(det, u: int, k: int) -> int:
     return (int.from_bytes(bytes(det["nic_pods"]), "little") >> (3 * (u * MAX_NICS_PER_NUMA + k))) & 7
 
 
+def _dyadic_speed(v) -> bool:
+    """include/nhdfit.h NHDFIT_RF_NIC_SPLIT_DYADIC: a non-negative multiple of 2^-20 below 2^31 (wire_digest.cpp applies the same test)"""
+    try:
+        v = float(v)
+    except (TypeError, ValueError):
+        return False
+    return 0.0 <= v < 2147483648.0 and (v * 1048576.0).is_integer()
+
+
 class Packer:
     def __init__(self, strict: bool = False):
         """strict=False (default): a node whose shape exceeds a capacity of the device layout (include/nhdfit.h: more than 2
@@ -247,6 +258,14 @@ class Packer:
         self.max_cores_per_numa = 1
         self.dict_version = 0                          # bumped whenever caps / sigs / that maximum grow
         self.sharing: Optional[str] = None             # set (to the reason) when a node's module has ENABLE_SHARING = True
+        # ENABLE_SHARING: the commit step adds every RX / TX core's speed to speed_used one after the other (nhd/Node.py:754) while a
+        # request record carries the group's sums.  The two are the same f64 value whatever the accumulator holds as long as EVERY
+        # partial sum is exact - which is the case while every value that ever reaches a speed_used (the nodes' own, every digested
+        # pod's core speeds) is a multiple of 2^-20 and the magnitudes seen so far stay below 2^32 in total (53-bit significands).
+        # `share_exact` says the mirror is in that regime (Gb/s figures are integers or halves: it is, in practice); once a value
+        # breaks it, a group with several RX (or TX) cores is turned away again until the next full re-pack.
+        self.share_exact = True
+        self.share_mass = 0.0
         self.nic_pct = NIC_BW_AVAIL_PERCENT            # NIC_BW_AVAIL_PERCENT of the nodes' module as of the last pack
         self._closed_upto = 0                          # close_signatures: sigs[:_closed_upto] have their successors interned
 
@@ -675,6 +694,29 @@ class Packer:
         w["cores_per_proc"], w["numa_nodes"], w["n_gpus"] = cpp, U, len(gpus)
         return w
 
+    def _note_share_value(self, v) -> None:
+        v = float(v)
+        if v != v or abs(v) >= 2.0 ** 31 or not (v * 1048576.0).is_integer():
+            self.share_exact = False
+            return
+        self.share_mass += abs(v)
+        if self.share_mass >= 2.0 ** 32:
+            self.share_exact = False
+
+    def admit_wire_request(self, req) -> Optional[str]:
+        """ENABLE_SHARING and a request digested from a config text (nhd_amd/wire.py): its speeds are noted as _digest_fields notes a
+        topology's; returns why the request cannot be answered exactly (a group with several RX / TX cores outside the exact regime),
+        or None."""
+        G = int(req["n_groups"])
+        for g in range(G):
+            self._note_share_value(req["rx"][g])
+            self._note_share_value(req["tx"][g])
+        fl = int(req["flags"])
+        if fl & RF_NIC_SPLIT and not (fl & RF_NIC_SPLIT_DYADIC and self.share_exact):
+            return ("a processing group with several RX / TX cores (ENABLE_SHARING: at most one of each per group once a speed that is not a "
+                    "multiple of 2^-20 Gb/s has reached the mirror)")
+        return None
+
     def pack_share(self, node) -> np.ndarray:
         """Node.nics[].speed_used as one nhdfit_wide_share record, NIC (numa, idx) as pack_wide orders them (nhd/Node.py:290)."""
         sh = np.zeros((), WIDE_SHARE)
@@ -687,12 +729,15 @@ class Packer:
             k = cnt[u]
             sh["used"][u][k][0] = float(nic.speed_used[0])
             sh["used"][u][k][1] = float(nic.speed_used[1])
+            self._note_share_value(nic.speed_used[0])
+            self._note_share_value(nic.speed_used[1])
             cnt[u] = k + 1
         return sh
 
     def pack_nodes(self, nl: Dict[str, object]) -> NodeTable:
         t = empty_table(len(nl))
         t.names = list(nl.keys())
+        self.share_exact, self.share_mass = True, 0.0      # (every speed_used of the mirror is read again below)
         for i, node in enumerate(nl.values()):
             self.pack_node_into(node, t, i)
         return t
@@ -792,6 +837,7 @@ class Packer:
         gpus, cpu_smt, cpu_nosmt, procs, helps = [0] * W, [0] * W, [0] * W, [0] * W, [0] * W
         rxs, txs = [0.0] * W, [0.0] * W
         smt_bits = nic_use = 0
+        split, split_dyadic = False, True
         for i, pg in enumerate(groups):
             n_proc = len(pg.proc_cores) + sum(len(g.cpu_cores) for g in pg.group_gpus)
             n_help = len(pg.misc_cores)
@@ -819,18 +865,30 @@ class Packer:
                     rx += c.nic_speed
                     n_rx += 1
                     nic_use |= 1 << i
+                    if self.sharing:
+                        self._note_share_value(c.nic_speed)
                 elif d == 2:
                     tx += c.nic_speed
                     n_tx += 1
                     nic_use |= 1 << i
-            if self.sharing and (n_rx > 1 or n_tx > 1):
+                    if self.sharing:
+                        self._note_share_value(c.nic_speed)
+            if n_rx > 1 or n_tx > 1:
+                split = True
+                split_dyadic = split_dyadic and all(_dyadic_speed(c.nic_speed) for c in pg.proc_cores
+                                                    if getattr(c.nic_dir, "value", c.nic_dir) in (1, 2))
+            if self.sharing and (n_rx > 1 or n_tx > 1) and not self.share_exact:
                 # ENABLE_SHARING: the commit step adds every RX / TX core's speed to speed_used one after the other (nhd/Node.py:754);
-                # the request record carries a group's sums - the same f64 value only while a direction has one core
-                raise UnsupportedNode(f"processing group {i}: {n_rx} RX and {n_tx} TX cores (ENABLE_SHARING: at most one of each per group)")
+                # the request record carries a group's sums - the same f64 value while a direction has one core, or while every
+                # partial sum is exact (Packer.share_exact); neither holds here
+                raise UnsupportedNode(f"processing group {i}: {n_rx} RX and {n_tx} TX cores (ENABLE_SHARING: at most one of each per group "
+                                      "once a speed that is not a multiple of 2^-20 Gb/s has reached the mirror)")
             rxs[i] = float(rx)
             txs[i] = float(tx)
         n_misc = len(top.misc_cores)
         flags, gbits = (RF_INITIAL_FILTER, self.group_bits_known(pod_groups)) if pod_groups is not None else (0, 0)
+        if split:
+            flags |= RF_NIC_SPLIT | (RF_NIC_SPLIT_DYADIC if split_dyadic else 0)
         if big:
             return (G, map_type, max(-2 ** 31, min(2 ** 31 - 1, hp)), flags, int(gbits), *gpus, *cpu_smt, *cpu_nosmt,
                     (n_misc + 1) // 2 if top.misc_cores_smt else n_misc, n_misc, smt_bits, min(n_misc, 255),

@@ -44,7 +44,7 @@ def digest_config(text, pod_groups: Optional[Sequence[str]] = None, packer: Opti
     if pod_groups is not None:
         if packer is None:
             raise ValueError("pod_groups needs the Packer that interns the group names")
-        req["flags"] = pack.RF_INITIAL_FILTER
+        req["flags"] |= pack.RF_INITIAL_FILTER
         req["groups"] = packer.group_bits_known(pod_groups)
     return req
 

@@ -12,7 +12,7 @@ part.  Fields (those of oracle/gen_golden_big.py):
   sequence[i]  = [node, mapping, ids] or [None]: the scheduler's loop (nhd/NHDScheduler.py:274-304)
   final[name]  = the node afterwards, with every NIC's speed_used
 Node descriptions carry `nic_speed_used` (traffic already on a NIC) next to `nic_pods_used`; every processing group has one RX and
-one TX core (workload/refmodel.make_topology)."""
+one TX core (workload/refmodel.make_topology) - but for `sharing_split`, whose groups bring up to three pairs."""
 import contextlib
 import io
 import json
@@ -50,6 +50,19 @@ def traffic_pod(rng, max_groups):
     s["misc_smt"] = True                                      # (keeps the commit away from quirk Q1's raise; tests/golden/commit covers Q1)
     if s["map_type"] == "NONE":
         s["map_type"] = "NUMA"
+    return s
+
+
+def split_pod(rng, max_groups):
+    """groups with up to three RX / TX core pairs, every speed a multiple of 2^-20 Gb/s (round 6: the commit adds them to speed_used one by
+    one, nhd/Node.py:744-764; the product's request record carries their sums - the same f64 values while all sums are exact)"""
+    s = traffic_pod(rng, max_groups)
+    speeds = [0, 1, 2.5, 5, 10, 0.25, 12.5]
+    for g in s["groups"]:
+        g["rx"], g["tx"] = float(rng.choice(speeds)), float(rng.choice(speeds))
+        extra = int(rng.integers(0, 3))
+        g["more_nic_pairs"] = [(float(rng.choice(speeds)), float(rng.choice(speeds))) for _ in range(extra)]
+        g["proc"] = max(g["proc"], 2 + 2 * extra)
     return s
 
 
@@ -97,6 +110,11 @@ def main():
                 nnic = len(d["nic_pods_used"])
                 d["nic_speed_used"] = [[float(rng.choice([0, 0, 10, 25, 47.5])), float(rng.choice([0, 0, 5, 45]))] for _ in range(nnic)]
             run_case(ref, descs, [traffic_pod(rng, max_groups) for _ in range(n_pods)], fname)
+        rng = np.random.default_rng(83004)
+        descs = util.random_cluster_desc(83004, 12, occupancy=0.06)
+        for d in descs:
+            d["nic_speed_used"] = [[float(rng.choice([0, 0, 10, 12.5, 22.5])), float(rng.choice([0, 0, 5, 15.25]))] for _ in range(len(d["nic_pods_used"]))]
+        run_case(ref, descs, [split_pod(rng, 3) for _ in range(60)], "sharing_split")
     finally:
         ref.node_mod.ENABLE_SHARING = False
 

@@ -7,6 +7,7 @@ import copy
 import numpy as np
 import pytest
 
+from nhd_amd import pack
 from nhd_amd.matcher import HipMatcher
 from oracle import nhd_oracle as O
 from oracle import ref_loader
@@ -167,3 +168,119 @@ def test_negative_demands_meet_oversubscribed_nics_as_in_the_reference(sharing, 
             assert [as_jsonable(ref_loader.find_node(rnl, refmodel.make_topology(s, ref))) for s in specs] == want
         finally:
             ref.node_mod.ENABLE_SHARING = False
+
+
+def _split_traffic(rng, exact=True):
+    """pods whose groups carry up to three RX / TX core pairs (nhd/Node.py:744-764 adds their speeds to speed_used one by one)"""
+    s = util.random_pod_spec(rng, max_groups=3)
+    speeds = [0, 0, 1, 2.5, 5, 10, 0.25, 12.5] if exact else [0, 0, 1, 5, 10, 0.1, 3.3, 12.5]
+    for g in s["groups"]:
+        g["rx"] = float(rng.choice(speeds))
+        g["tx"] = float(rng.choice(speeds))
+        extra = int(rng.integers(0, 3))
+        g["proc"] = max(int(g["proc"]), 2 + 2 * extra)
+        g["more_nic_pairs"] = [(float(rng.choice(speeds)), float(rng.choice(speeds))) for _ in range(extra)]
+        if rng.random() < 0.75:
+            g["gpus"] = []
+    s["misc_smt"] = True
+    if s["map_type"] == "NONE":
+        s["map_type"] = "NUMA"
+    return s
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_groups_with_several_nic_cores_are_exact_while_every_speed_is_dyadic(sharing, seed):
+    """VERDICT r05 missing #5: under ENABLE_SHARING the reference's commit adds every RX / TX core's speed to speed_used one after the
+    other (nhd/Node.py:744-764); the request record carries a group's sums.  While every value that reaches a speed_used is a
+    multiple of 2^-20 (Packer.share_exact) all partial sums are exact and the two are the same f64 value: such pods are answered -
+    decisions, ids and every NIC's speed_used afterwards against the oracle, whose commit adds core by core."""
+    rng = np.random.default_rng(9500 + seed)
+    descs = util.random_cluster_desc(9500 + seed, 16, occupancy=0.05)
+    for d in descs:
+        d["nic_speed_used"] = [[float(rng.choice([0, 0, 0, 10, 12.5, 22.5])), float(rng.choice([0, 0, 0, 5, 15.25]))] for _ in d["nic_pods_used"]]
+    specs = [_split_traffic(rng) for _ in range(40)]
+    assert sum(bool(g["more_nic_pairs"]) for s in specs for g in s["groups"]) >= 10
+    tops = [refmodel.make_topology(s) for s in specs]
+    nl = util.build_cluster(descs)
+    m = _host(util.CLOCK)
+    got = m.FindNodes(nl, tops)
+    assert m.packer.share_exact
+    assert [as_jsonable(r) for r in got] == [as_jsonable(O.find_node(nl, t, util.CLOCK)) for t in tops]
+    ids = []
+    onl = copy.deepcopy(nl)
+    want = O.schedule_sequence(onl, tops, [None] * len(tops), util.CLOCK, ids_out=ids)
+    m.attach(nl)
+    seq = m.ScheduleBatch(nl, tops, now=util.CLOCK, apply=True)
+    assert [as_jsonable(r) for r in seq] == [as_jsonable(r) for r in want]
+    assert m.last_placements == ids
+    assert sum(r[0] is not None for r in seq) >= 5
+    share = m.engine.wide_share_download()
+    for i, node in enumerate(onl.values()):
+        for nic in node.nics:
+            if 0 <= nic.numa_node < node.numa_nodes:
+                assert [float(share[i]["used"][nic.numa_node][nic.idx][x]) for x in range(2)] == [float(x) for x in nic.speed_used], (node.name, nic.idx)
+
+
+def test_groups_with_several_nic_cores_are_turned_away_once_a_speed_is_not_dyadic(sharing):
+    rng = np.random.default_rng(9600)
+    descs = util.random_cluster_desc(9600, 6, occupancy=0.1)
+    for d in descs:
+        d["nic_speed_used"] = [[0.0, 0.0] for _ in d["nic_pods_used"]]
+    nl = util.build_cluster(descs)
+    one = dict(map_type="NUMA", hugepages_gb=0, misc=0, misc_smt=True,
+               groups=[dict(proc=4, helpers=0, rx=10.0, tx=5.0, more_nic_pairs=[(2.5, 2.5)], gpus=[], proc_smt=False, helper_smt=False)])
+    odd = dict(map_type="NUMA", hugepages_gb=0, misc=0, misc_smt=True,
+               groups=[dict(proc=2, helpers=0, rx=0.1, tx=5.0, gpus=[], proc_smt=False, helper_smt=False)])
+    m = _host(util.CLOCK)
+    m.attach(nl)                                                                   # (a stateless call reads every speed_used afresh: nothing carries over)
+    t_one, t_odd = refmodel.make_topology(one), refmodel.make_topology(odd)
+    assert as_jsonable(m.FindNode(nl, t_one)) == as_jsonable(O.find_node(nl, t_one, util.CLOCK)) and m.FindNode(nl, t_one) != (None,)
+    assert m.FindNode(nl, t_odd)[0] is not None and not m.packer.share_exact       # 0.1 Gb/s: sums are no longer exact in any order
+    assert m.FindNode(nl, t_one) == (None,)                                        # ... so the group with two RX cores is turned away, loudly
+    strict = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine, strict=True)
+    strict.attach(nl)
+    strict.FindNode(nl, t_odd)
+    with pytest.raises(pack.UnsupportedNode):
+        strict.FindNode(nl, t_one)
+    m.detach()
+    assert m.FindNode(nl, t_one) != (None,)                                        # the objects' own speed_used are all dyadic
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason="reference tree not present")
+@pytest.mark.parametrize("seed", range(2))
+def test_oracle_commit_of_several_nic_cores_equals_the_reference(sharing, seed):
+    """Pins the oracle's core-by-core speed_used updates (nhd/Node.py:744-764) for groups with several RX / TX cores against the reference
+    with its constant flipped - non-dyadic speeds included: the oracle itself has no exactness condition."""
+    import contextlib
+    import io
+    ref = ref_loader.load()
+    rng = np.random.default_rng(9700 + seed)
+    descs = util.random_cluster_desc(9700 + seed, 8, occupancy=0.1)
+    for d in descs:
+        d["nic_speed_used"] = [[float(rng.choice([0, 0, 10, 20.1])), float(rng.choice([0, 5, 15]))] for _ in d["nic_pods_used"]]
+    specs = [_split_traffic(rng, exact=False) for _ in range(25)]
+    ref_loader.VirtualClock(util.CLOCK).install()
+    ref.node_mod.ENABLE_SHARING = True
+    try:
+        rnl = util.build_cluster(descs, ref)
+        onl = util.build_cluster(descs)
+        placed = 0
+        for s in specs:
+            rtop, otop = refmodel.make_topology(s, ref), refmodel.make_topology(s)
+            want = ref_loader.find_node(rnl, rtop)
+            got = O.find_node(onl, otop, util.CLOCK)
+            assert as_jsonable(got) == as_jsonable(want), s
+            if want[0] is None:
+                continue
+            n = rnl[want[0]]
+            n.SetBusy()
+            with contextlib.redirect_stdout(io.StringIO()):
+                nic_list = n.SetPhysicalIdsFromMapping(want[1], rtop)
+            n.ClaimPodNICResources(list({x[0] for x in nic_list}))
+            O.commit(onl[got[0]], otop, got[1], util.CLOCK)
+            for a, b in zip(n.nics, onl[got[0]].nics):
+                assert [float(x) for x in a.speed_used] == [float(x) for x in b.speed_used]
+            placed += 1
+        assert placed >= 3
+    finally:
+        ref.node_mod.ENABLE_SHARING = False

@@ -268,3 +268,34 @@ def test_mutated_big_configs_agree():
             assert want[1].tobytes() == got[1].tobytes(), text
         outcomes.add(want[0])
     assert outcomes >= {"ok", "none", "raise", "limit"}, outcomes
+
+
+def test_config_texts_under_enable_sharing(monkeypatch):
+    """nhd/Node.py:20 ENABLE_SHARING = True and pods digested from their texts: the digest marks a pod whose group has several RX / TX
+    core pairs (NHDFIT_RF_NIC_SPLIT, with NHDFIT_RF_NIC_SPLIT_DYADIC when every such speed is a multiple of 2^-20) as Packer.digest does,
+    and the matcher admits it on the same condition - mode A and mode B from texts equal the same calls on the parsed topologies; with a
+    speed that is not dyadic in the mirror, such a pod is answered (None,) on both paths (the wire path had no such check)."""
+    from nhd_amd.matcher import HipMatcher
+    from oracle import nhd_oracle as O
+    from tests import harness, util
+    from workload import refmodel
+    monkeypatch.setattr(refmodel, "ENABLE_SHARING", True)
+    monkeypatch.setattr(O, "ENABLE_SHARING", True)
+    nl = util.random_cluster(45, 24)
+    texts = [t for t in (wire_gen.make_config(s) for s in range(300)) if reference_outcome(t)[0] == "ok"][:40]
+    tops = [ref_loader.config_to_topology(t) for t in texts]
+    reqs, codes = wire.digest_configs(texts)
+    split = [bool(int(r["flags"]) & pack.RF_NIC_SPLIT) for r in reqs]
+    assert any(split) and not all(split)
+    for r, t in zip(reqs, tops):
+        assert int(r["flags"]) == int(pack.Packer().digest(t)["flags"])
+    new = lambda: HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)      # noqa: E731
+    a, b = new().FindNodesFromConfigs(nl, texts), new().FindNodes(nl, tops)
+    assert a == b and sum(r[0] is not None for r in a) >= 5
+    assert [O.find_node(nl, t, util.CLOCK)[0] for t in tops] == [r[0] for r in a]
+    assert new().FindNodesFromConfigs(nl, texts, sequential=True) == new().ScheduleBatch(nl, tops)
+    # a speed of 0.1 Gb/s among the nodes' own speed_used: sums are no longer exact in any order - the pods with split groups are out
+    next(iter(nl.values())).nics[0].speed_used[0] = 0.1
+    a, b = new().FindNodesFromConfigs(nl, texts), new().FindNodes(nl, tops)
+    assert a == b
+    assert all(r == (None,) for r, s in zip(a, split) if s) and any(r != (None,) for r in a)

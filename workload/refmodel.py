@@ -173,7 +173,7 @@ def make_topology(spec: dict, types=None):
 
     spec = {"map_type": "NUMA"|"PCI"|"NONE", "hugepages_gb": int, "misc": int,
             "misc_smt": bool, "groups": [ {"proc": int (>=2, first two are the RX/TX pair),
-            "rx": float, "tx": float, "helpers": int, "proc_smt": bool, "helper_smt": bool,
+            "rx": float, "tx": float, "more_nic_pairs": [(rx, tx), ...] (optional), "helpers": int, "proc_smt": bool, "helper_smt": bool,
             "gpus": [n_cpu_cores_of_gpu0, ...]}, ... ]}
 
     `types` is the reference namespace from oracle.ref_loader.load() (then real
@@ -201,7 +201,13 @@ def make_topology(spec: dict, types=None):
             tx = core(f"g{gi}tx", g.get("tx", 0), NICCoreDirection.NIC_CORE_DIRECTION_TX)
             pg.proc_cores += [rx, tx]
             top.nic_core_pairing.append(SimpleNamespace(rx_core=rx, tx_core=tx, mac="", rx_ring_size=4096))
-        for k in range(max(0, nproc - 2) if nproc >= 2 else nproc):
+        more = g.get("more_nic_pairs", []) if nproc >= 2 else []      # further (rx speed, tx speed) pairs, out of the same `proc` cores
+        for k, (rs, ts) in enumerate(more):
+            rx = core(f"g{gi}rx{k + 1}", rs, NICCoreDirection.NIC_CORE_DIRECTION_RX)
+            tx = core(f"g{gi}tx{k + 1}", ts, NICCoreDirection.NIC_CORE_DIRECTION_TX)
+            pg.proc_cores += [rx, tx]
+            top.nic_core_pairing.append(SimpleNamespace(rx_core=rx, tx_core=tx, mac="", rx_ring_size=4096))
+        for k in range(max(0, nproc - 2 - 2 * len(more)) if nproc >= 2 else nproc):
             pg.proc_cores.append(core(f"g{gi}p{k}"))
         for k in range(g.get("helpers", 0)):
             pg.misc_cores.append(core(f"g{gi}h{k}"))
@@ -237,7 +243,14 @@ def _make_reference_topology(spec, R):
             pg.AddGroupCore(rx)
             pg.AddGroupCore(tx)
             top.AddNicPairing(rx, tx)
-        for k in range(max(0, nproc - 2) if nproc >= 2 else nproc):
+        more = g.get("more_nic_pairs", []) if nproc >= 2 else []
+        for k, (rs, ts) in enumerate(more):
+            rx = R.Core(f"g{gi}rx{k + 1}", rs, R.NICCoreDirection.NIC_CORE_DIRECTION_RX, grp, -1)
+            tx = R.Core(f"g{gi}tx{k + 1}", ts, R.NICCoreDirection.NIC_CORE_DIRECTION_TX, grp, -1)
+            pg.AddGroupCore(rx)
+            pg.AddGroupCore(tx)
+            top.AddNicPairing(rx, tx)
+        for k in range(max(0, nproc - 2 - 2 * len(more)) if nproc >= 2 else nproc):
             pg.AddGroupCore(R.Core(f"g{gi}p{k}", 0, none, grp, -1))
         for k in range(g.get("helpers", 0)):
             pg.AddMiscCore(R.Core(f"g{gi}h{k}", 0, none, grp, -1))
