@@ -164,6 +164,7 @@ struct nhdfit_ctx {
     hipStream_t stream = nullptr;        // = pipe[0].stream: uploads, deltas, commits, mode B, single finds
     hipStream_t s_red = nullptr;         // the all-reduce of sharded runs, overlapping the next step launch
     bool side_streams_used = true;       // something was enqueued on a pipe other than the first, or on s_red, since sync_all last waited for them
+    double enq_us = 0, enq_launch_us = 0, enq_events_us = 0; uint64_t enq_n = 0;   // tuning aid (NHDFIT_ENQ_PROF): host time of nhdfit_enqueue_step, of the launch calls, of the event records
     bool known_idle = false;             // no HIP call of this context since its streams were last seen idle (sync_all; a single-launch find's polled word)
     bool dual = tune_env("NHDFIT_ONE_PIPE") == nullptr;   // tuning aid: NHDFIT_ONE_PIPE=1 keeps every step on pipe 0
     uint64_t n_enq = 0;                  // steps enqueued since the last stage_requests (step k runs on pipe k % 2)
@@ -724,7 +725,10 @@ int refresh_layouts(nhdfit_ctx* c) {
     // the launch's dynamic LDS is one size for all of its blocks).
     c->pair_D[0] = c->pair_D[1] = 0;
     if (c->pair_rows && !spill) {
-        const uint32_t budget = (uint32_t)(kLdsPerCu / 3) & ~1023u;
+#ifndef NHDFIT_LDS_BLOCKS
+#define NHDFIT_LDS_BLOCKS 3
+#endif
+        const uint32_t budget = (uint32_t)(kLdsPerCu / NHDFIT_LDS_BLOCKS) & ~1023u;
         for (uint32_t w = 0; w < 2 && w <= c->max_wcls; ++w) {
             const Layout& L = c->L[w];
             const uint32_t D = pair_dim(c->max_demand[w], L.fc_dim);
@@ -1227,7 +1231,11 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
     }
     const bool timed = (with_fit && (p.n_fit < 2 || (p.n_fit & 7) == 0)) || (!with_fit && with_digest);
     if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc) return rc; }
+    static const bool enq_prof = tune_env("NHDFIT_ENQ_PROF") != nullptr;
+    const auto t_ev0 = enq_prof ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][0], p.stream));
+    const auto t_l0 = enq_prof ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+    if (enq_prof) c->enq_events_us += std::chrono::duration<double, std::micro>(t_l0 - t_ev0).count();
     if (c->x_spill) {               // more node classes than LDS rows: the variant whose fit role reads the rest from global memory
         if (big) LAUNCH(c, (k_step<512, true>), dim3(grid), dim3(512), lds, p.stream, a);
         else     LAUNCH(c, (k_step<256, true>), dim3(grid), dim3(256), lds, p.stream, a);
@@ -1249,6 +1257,7 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
     if (big) LAUNCH(c, (k_step<512>), dim3(grid), dim3(512), lds, p.stream, a);
     else     LAUNCH(c, (k_step<256>), dim3(grid), dim3(256), lds, p.stream, a);
     HIPCHK(c, hipGetLastError());
+    if (enq_prof) c->enq_launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_l0).count();
     if (with_fit && c->n_wide) {
         // the general path for the nodes beyond the fast layout: their verdict bits and scores join this step's (same stream,
         // behind the fit role; in front of the all-reduce of a sharded run and of every mapping phase)
@@ -1263,8 +1272,10 @@ int launch_step(nhdfit_ctx* c, Pipe& p, bool with_fit, bool with_digest, double 
         HIPCHK(c, hipGetLastError());
     }
     if (timed) {
+        const auto t_e1 = enq_prof ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         HIPCHK(c, hipEventRecord(c->ev[c->ev_pending][1], p.stream));
         c->ev_kind[c->ev_pending++] = with_fit ? 0 : 1;
+        if (enq_prof) c->enq_events_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_e1).count();
     }
     if (a.role_clock) {
         unsigned long long t[32];
@@ -1386,8 +1397,21 @@ int flush_pipeline(nhdfit_ctx* c) {
 
 }  // namespace
 
+static int enqueue_step(nhdfit_ctx* c, double now);
 int nhdfit_enqueue_step(nhdfit_ctx* c, double now) {
     if (!c) return NHDFIT_E_INVAL;
+    static const bool enq_prof = tune_env("NHDFIT_ENQ_PROF") != nullptr;
+    if (!enq_prof) return enqueue_step(c, now);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = enqueue_step(c, now);
+    c->enq_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (++c->enq_n % 1000 == 0) {
+        fprintf(stderr, "[nhdfit] 1000 enqueues: %.2f us each on the host, %.2f in the launch calls, %.2f in event records\n", c->enq_us / 1000, c->enq_launch_us / 1000, c->enq_events_us / 1000);
+        c->enq_us = c->enq_launch_us = c->enq_events_us = 0;
+    }
+    return rc;
+}
+static int enqueue_step(nhdfit_ctx* c, double now) {
     if (!c->P) return fail(c, NHDFIT_E_STATE, "stage requests first");
     if (!c->n) return fail(c, NHDFIT_E_STATE, "no nodes uploaded");
     HIPCHK(c, hipSetDevice(c->dev));

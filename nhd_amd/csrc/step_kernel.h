@@ -285,8 +285,11 @@ __device__ __forceinline__ void step_body(const StepArgs& a, const double busy_f
 
 // The step launch.  (The ~3 KB argument block travels by value: a device-resident copy behind a pointer was measured in
 // round 3 - no gain, the scalar loads through the pointer cost what the kernarg fetch saved: 236 spilled SGPRs against 19.)
+#ifndef NHDFIT_STEP_WAVES
+#define NHDFIT_STEP_WAVES 6          // wavefronts per SIMD the 512-thread form is compiled for (A/B builds: 8 = four blocks per CU, <= 64 VGPRs)
+#endif
 template <int BLOCK, bool SPILL = false>
-__global__ __launch_bounds__(BLOCK, SPILL ? (BLOCK == 512 ? 4 : 5) : (BLOCK == 512 ? 6 : 7)) void k_step(StepArgs a) {   // SPILL: two blocks per CU (LDS)   // 512 threads = 2 waves per SIMD: 3 blocks per CU either way
+__global__ __launch_bounds__(BLOCK, SPILL ? (BLOCK == 512 ? 4 : 5) : (BLOCK == 512 ? NHDFIT_STEP_WAVES : 7)) void k_step(StepArgs a) {   // SPILL: two blocks per CU (LDS)   // 512 threads = 2 waves per SIMD: 3 blocks per CU either way
     extern __shared__ __align__(16) uint8_t lds[];
     step_body<BLOCK, SPILL>(a, a.fit.busy_from, lds);
 }
