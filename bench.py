@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (HBM traffic of the step kernel)")
     ap.add_argument("--no-extras", action="store_true", help="skip the mode-B and end-to-end legs after the timed region")
+    ap.add_argument("--settle-ms", type=float, default=30.0, help="how long the device is kept busy with the benchmarked step in front of the headline region")
     ap.add_argument("--no-settle", action="store_true", help="time the W + K steps as the first GPU work of the process only (no clock settling in front of the headline region)")
     args = ap.parse_args()
 
@@ -140,7 +141,7 @@ def main():
     settled = 0
     if not os.environ.get("NHD_BENCH_INNER") and not args.no_settle:
         cold = timed_region()
-        settled = settle(eng, now, fixed_steps=2500 if world > 1 else 0)
+        settled = settle(eng, now, settle_ms=args.settle_ms, fixed_steps=2500 if world > 1 else 0)
     dt = timed_region()
     if dist is not None:
         import torch
