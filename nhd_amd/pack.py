@@ -261,11 +261,12 @@ class Packer:
         # ENABLE_SHARING: the commit step adds every RX / TX core's speed to speed_used one after the other (nhd/Node.py:754) while a
         # request record carries the group's sums.  The two are the same f64 value whatever the accumulator holds as long as EVERY
         # partial sum is exact - which is the case while every value that ever reaches a speed_used (the nodes' own, every digested
-        # pod's core speeds) is a multiple of 2^-20 and the magnitudes seen so far stay below 2^32 in total (53-bit significands).
-        # `share_exact` says the mirror is in that regime (Gb/s figures are integers or halves: it is, in practice); once a value
-        # breaks it, a group with several RX (or TX) cores is turned away again until the next full re-pack.
+        # pod's core speeds) is a non-negative multiple of 2^-20 below 2^31: a NIC's speed_used then never leaves [0, 2^32) - a pod is
+        # only committed where its demands still fit under speed * 0.9 (nhd/Matcher.py:262-267; a NIC already above its capacity
+        # takes its whole node out) - and sums of such values below 2^33 are exact (53-bit significands).  `share_exact` says the
+        # mirror is in that regime (Gb/s figures are integers or halves: it is, in practice); once a value breaks it, a group with
+        # several RX (or TX) cores is turned away again until the next full re-pack.
         self.share_exact = True
-        self.share_mass = 0.0
         self.nic_pct = NIC_BW_AVAIL_PERCENT            # NIC_BW_AVAIL_PERCENT of the nodes' module as of the last pack
         self._closed_upto = 0                          # close_signatures: sigs[:_closed_upto] have their successors interned
 
@@ -695,12 +696,7 @@ class Packer:
         return w
 
     def _note_share_value(self, v) -> None:
-        v = float(v)
-        if v != v or abs(v) >= 2.0 ** 31 or not (v * 1048576.0).is_integer():
-            self.share_exact = False
-            return
-        self.share_mass += abs(v)
-        if self.share_mass >= 2.0 ** 32:
+        if not _dyadic_speed(v):
             self.share_exact = False
 
     def admit_wire_request(self, req) -> Optional[str]:
@@ -737,7 +733,7 @@ class Packer:
     def pack_nodes(self, nl: Dict[str, object]) -> NodeTable:
         t = empty_table(len(nl))
         t.names = list(nl.keys())
-        self.share_exact, self.share_mass = True, 0.0      # (every speed_used of the mirror is read again below)
+        self.share_exact = True                            # (every speed_used of the mirror is read again below)
         for i, node in enumerate(nl.values()):
             self.pack_node_into(node, t, i)
         return t
