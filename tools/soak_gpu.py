@@ -16,14 +16,44 @@ from tests import util
 from workload import refmodel
 
 n_seeds = int(sys.argv[1])
-first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+first = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 1000
+sharing = "--sharing" in sys.argv          # nhd/Node.py:20 flipped: every node on the general path, NICs priced by speed_used; groups with up to three RX / TX pairs
+if sharing:
+    refmodel.ENABLE_SHARING = True
+    O.ENABLE_SHARING = True
+
+
+def share_pod(rng):
+    s = util.random_pod_spec(rng, max_groups=3)
+    speeds = [0, 0, 1, 2.5, 5, 10, 0.25, 12.5]
+    for g in s["groups"]:
+        g["rx"], g["tx"] = float(rng.choice(speeds)), float(rng.choice(speeds))
+        extra = int(rng.integers(0, 3))
+        g["proc"] = max(int(g["proc"]), 2 + 2 * extra)
+        g["more_nic_pairs"] = [(float(rng.choice(speeds)), float(rng.choice(speeds))) for _ in range(extra)]
+        if rng.random() < 0.75:
+            g["gpus"] = []
+    s["misc_smt"] = True
+    if s["map_type"] == "NONE":
+        s["map_type"] = "NUMA"
+    return s
+
+
+def cluster(seed, n, occupancy=None):
+    if not sharing:
+        return util.random_cluster(seed, n) if occupancy is None else util.random_cluster(seed, n, occupancy=occupancy)
+    rng = np.random.default_rng(seed)
+    descs = util.random_cluster_desc(seed, n, occupancy=0.05 if occupancy is None else occupancy)
+    for d in descs:
+        d["nic_speed_used"] = [[float(rng.choice([0, 0, 0, 10, 12.5, 22.5, 95.0])), float(rng.choice([0, 0, 0, 5, 15.25]))] for _ in d["nic_pods_used"]]
+    return util.build_cluster(descs)
 t0 = time.time()
 bad = 0
 raised = 0
 for seed in range(first, first + n_seeds):
     rng = np.random.default_rng(seed)
-    nl = util.random_cluster(31000 + seed, int(rng.integers(20, 200)))
-    specs = [util.random_pod_spec(rng, max_groups=4 if seed % 4 == 0 else 3) for _ in range(30)]
+    nl = cluster(31000 + seed, int(rng.integers(20, 200)) if not sharing else int(rng.integers(6, 40)))
+    specs = [share_pod(rng) if sharing else util.random_pod_spec(rng, max_groups=4 if seed % 4 == 0 else 3) for _ in range(30)]
     tops = [refmodel.make_topology(s) for s in specs]
     m = HipMatcher(clock=lambda: util.CLOCK)
     got = m.FindNodes(nl, tops)
@@ -33,11 +63,11 @@ for seed in range(first, first + n_seeds):
     m.engine.close()
     # the scheduler's loop with commits: batched on the device, then pod by pod
     n2 = int(rng.integers(10, 80))
-    nl2 = util.random_cluster(71000 + seed, n2, occupancy=0.15); ref_nl = util.random_cluster(71000 + seed, n2, occupancy=0.15)
-    nl3 = util.random_cluster(71000 + seed, n2, occupancy=0.15)
+    nl2 = cluster(71000 + seed, n2, occupancy=0.15); ref_nl = cluster(71000 + seed, n2, occupancy=0.15)
+    nl3 = cluster(71000 + seed, n2, occupancy=0.15)
     specs = []
     for _ in range(60):
-        s = util.random_pod_spec(rng)
+        s = share_pod(rng) if sharing else util.random_pod_spec(rng)
         if seed % 3:
             s["misc_smt"] = True                   # (every third seed keeps quirk Q1's raise in play: the loop then stops where the reference would)
         if s["map_type"] == "NONE": s["map_type"] = "NUMA"
@@ -65,6 +95,8 @@ for seed in range(first, first + n_seeds):
         ids3.append(mp.CommitPlacement(r[0], top, r[1], busy_time=util.CLOCK) if r[0] is not None else None)
     if [D.as_jsonable(x) for x in res3] != [D.as_jsonable(w) for w in want] or ids3 != ids:
         bad += 1; print("POD-BY-POD MISMATCH seed", seed)
+    if sharing and mb.engine.wide_share_download().tobytes() != mp.engine.wide_share_download().tobytes():
+        bad += 1; print("SPEED_USED MISMATCH seed", seed)
     a, b = mb.engine.download(), mp.engine.download()
     for f in ("p0", "p1", "p2", "p3", "p4", "detail"):
         if getattr(a, f).tobytes() != getattr(b, f).tobytes():
