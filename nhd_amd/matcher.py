@@ -224,6 +224,10 @@ class HipMatcher:
             return self._commit_big(i, node, self.packer.digest_big(top), self._mapping_record(mapping, big=True), bt)
         cached = getattr(self, "_digest_cache", None)                 # the record FindNode made of this very topology a moment ago (the scheduler
         req = cached[1] if cached is not None and cached[0] is top else self.packer.digest(top)   # commits what it has just matched, nhd/NHDScheduler.py:277-304)
+        if self.packer.sharing and int(req["flags"]) & pack.RF_NIC_SPLIT and not self.packer.share_exact:
+            # (the cached record was admitted when every speed in the mirror was still a multiple of 2^-20; one that is not arrived since)
+            raise pack.UnsupportedNode("a processing group with several RX / TX cores (ENABLE_SHARING), and the mirror's speeds are no longer all "
+                                       "multiples of 2^-20 Gb/s: the commit's sum would not be the reference's core-by-core accumulation")
         if self._table is not None and self._table.wide and i in self._table.wide:      # a wide node: the general path's commit step
             place = self.engine.wide_commit(i, req, self._mapping_record(mapping), bt)
             G = int(req["n_groups"])

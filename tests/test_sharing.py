@@ -284,3 +284,32 @@ def test_oracle_commit_of_several_nic_cores_equals_the_reference(sharing, seed):
         assert placed >= 3
     finally:
         ref.node_mod.ENABLE_SHARING = False
+
+
+def test_commit_of_a_cached_split_request_is_refused_once_the_regime_is_left(sharing):
+    """CommitPlacement reuses the record FindNode digested a moment ago; under ENABLE_SHARING a record with several RX / TX cores per
+    group is only good while the mirror's speeds are all dyadic - a value that is not, arriving between the find and the commit,
+    makes the commit refuse instead of adding a sum the reference would have accumulated core by core."""
+    descs = util.random_cluster_desc(9800, 6, occupancy=0.05)
+    for d in descs:
+        d["nic_speed_used"] = [[0.0, 0.0] for _ in d["nic_pods_used"]]
+    nl = util.build_cluster(descs)
+    m = _host(util.CLOCK)
+    m.attach(nl)
+    split = refmodel.make_topology(dict(map_type="NUMA", hugepages_gb=0, misc=0, misc_smt=True,
+                                        groups=[dict(proc=4, helpers=0, rx=10.0, tx=5.0, more_nic_pairs=[(2.5, 2.5)], gpus=[], proc_smt=False, helper_smt=False)]))
+    odd = refmodel.make_topology(dict(map_type="NUMA", hugepages_gb=0, misc=0, misc_smt=True,
+                                      groups=[dict(proc=2, helpers=0, rx=0.1, tx=5.0, gpus=[], proc_smt=False, helper_smt=False)]))
+    r = m.FindNode(nl, split)
+    assert r[0] is not None
+    ids = m.CommitPlacement(r[0], split, r[1], busy_time=util.CLOCK)                # inside the regime: committed, ids as the oracle's
+    rec = {}
+    onl = util.build_cluster(descs)
+    O.commit(onl[r[0]], split, r[1], util.CLOCK, rec)
+    assert ids == rec
+    r2 = m.FindNode(nl, split)
+    assert r2[0] is not None
+    m.FindNodes(nl, [odd, odd])                                                     # (two pods: the one-pod cache keeps the split record)
+    assert not m.packer.share_exact
+    with pytest.raises(pack.UnsupportedNode):
+        m.CommitPlacement(r2[0], split, r2[1], busy_time=util.CLOCK)
