@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (HBM traffic of the step kernel)")
     ap.add_argument("--no-extras", action="store_true", help="skip the mode-B and end-to-end legs after the timed region")
     ap.add_argument("--settle-ms", type=float, default=30.0, help="how long the device is kept busy with the benchmarked step in front of the headline region")
+    ap.add_argument("--settle-regions", type=int, default=0, help="experiment: untimed W + K regions (each closed by a sync) at the end of the settling phase")
     ap.add_argument("--no-settle", action="store_true", help="time the W + K steps as the first GPU work of the process only (no clock settling in front of the headline region)")
     args = ap.parse_args()
 
@@ -142,6 +143,11 @@ def main():
     if not os.environ.get("NHD_BENCH_INNER") and not args.no_settle:
         cold = timed_region()
         settled = settle(eng, now, settle_ms=args.settle_ms, fixed_steps=2500 if world > 1 else 0)
+        for _ in range(args.settle_regions):
+            for _ in range(args.warmup + args.steps):
+                eng.enqueue(now)
+            eng.sync()
+            settled += args.warmup + args.steps
     dt = timed_region()
     if dist is not None:
         import torch
