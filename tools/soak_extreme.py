@@ -147,6 +147,10 @@ def states_agree(nodes, m):
     return True
 
 
+DEVICE = "--device" in sys.argv          # the same checks through the C-ABI on the GPU (the sharded parts need three devices: host twin only)
+EF = {} if DEVICE else {"engine_factory": harness.HarnessEngine}
+
+
 def main():
     n_seeds = int(sys.argv[1])
     first = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 0
@@ -172,7 +176,7 @@ def main():
         specs = [edge_pod(rng, max_groups) for _ in range(16)]
         tops = [refmodel.make_topology(s) for s in specs]
         pgs = [list(rng.choice(NAMES, size=int(rng.integers(1, 4)), replace=False)) if rng.random() < 0.3 else None for _ in specs]
-        m = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)
+        m = HipMatcher(clock=lambda: util.CLOCK, **EF)
         m.attach(nl)
         unmirrored += len(m.unmirrored)
         live = {k: v for k, v in nl.items() if k not in m.unmirrored}      # (a node no record holds never matches: a documented deviation)
@@ -191,8 +195,8 @@ def main():
                 if norm(rwant) != norm(want):
                     bad += 1
                     print("FIND oracle != REFERENCE seed", seed, "pod", p, s, norm(want), norm(rwant), flush=True)
-        if seed % 4 == 1:                                   # the same through a mirror sharded over three host-twin shards (engine.GroupEngine)
-            ms = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine, devices=[0, 1, 2])
+        if seed % 4 == 1 and not DEVICE:                    # the same through a mirror sharded over three host-twin shards (engine.GroupEngine)
+            ms = HipMatcher(clock=lambda: util.CLOCK, devices=[0, 1, 2], **EF)
             ms.attach(util.build_cluster(descs))
             gs = ms.FindNodes(ms._attached, tops)
             if [norm(x) for x in gs] != [norm(x) for x in got]:
@@ -215,7 +219,7 @@ def main():
             if s["map_type"] not in ("NUMA", "PCI"):
                 s["map_type"] = "NUMA"
         tops = [refmodel.make_topology(s) for s in specs]
-        mb = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine)
+        mb = HipMatcher(clock=lambda: util.CLOCK, **EF)
         mb.attach(nl_b)
         live_o = {k: v for k, v in nl_o.items() if k not in mb.unmirrored}
         try:
@@ -236,9 +240,9 @@ def main():
             want.append(r)
             ids.append(rec if r[0] is not None else None)
         k = len(want)
-        if seed % 4 == 1:
+        if seed % 4 == 1 and not DEVICE:
             nl_s = util.build_cluster(descs)
-            ms = HipMatcher(clock=lambda: util.CLOCK, engine_factory=harness.HarnessEngine, devices=[0, 1, 2])
+            ms = HipMatcher(clock=lambda: util.CLOCK, devices=[0, 1, 2], **EF)
             ms.attach(nl_s)
             rs = ms.ScheduleBatch(nl_s, tops, now=util.CLOCK)
             if [norm(x) for x in rs[:k]] != [norm(w) for w in want] or ms.last_placements[:k] != ids:
@@ -264,7 +268,7 @@ def main():
                 s["misc_smt"] = True
             tops = [refmodel.make_topology(s) for s in specs[:P] + fresh_specs]
             grps = [["default"] + list(rng.choice(NAMES, size=2, replace=False)) for _ in tops]
-            md = HipMatcher(clock=clock, engine_factory=harness.HarnessEngine)
+            md = HipMatcher(clock=clock, **EF)
             md.attach(nodes)
             try:
                 binds = sched_standin.check_pending_pods_batched(nodes, md, tops[:P], grps[:P], now=clock.t)
