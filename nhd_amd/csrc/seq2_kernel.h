@@ -1080,8 +1080,11 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     // ---- wavefront 0: the sequencer - every pod, in the caller's order ------------------------------------------------------
     __builtin_amdgcn_s_setprio(3);
     uint32_t n_tn_done = 0, c_redo = 0;
-    unsigned long long t_ready = 0, t_gpu = 0, t_post = 0, t_retire = 0, t_last = wall_clock64();   // tuning aid, 100 MHz ticks (ctrl[9..12])
-    auto lap = [&](unsigned long long& acc) { const unsigned long long t = wall_clock64(); acc += t - t_last; t_last = t; };
+    // tuning aid, 100 MHz ticks (ctrl[9..12]).  In the tuning build ONLY (round 6): a read of the real-time counter is a scalar memory
+    // instruction, and the wait for it (lgkmcnt) is a wait for every LDS operation in flight as well - two to four of them per pod sat on
+    // the sequencer's chain in the shipped library for nobody to read
+    unsigned long long t_ready = 0, t_gpu = 0, t_post = 0, t_retire = 0, t_last = kTuning ? (unsigned long long)wall_clock64() : 0ull;
+    auto lap = [&](unsigned long long& acc) { if (kTuning) { const unsigned long long t = wall_clock64(); acc += t - t_last; t_last = t; } };
     auto take = [&](uint32_t v, bool gpu_pod) {
         if ((v >> 6) >= span) { give_up(); return; }                          // past the bit maps' reach (wave-uniform): the general kernel decides this batch
         if (lane == 0) {
