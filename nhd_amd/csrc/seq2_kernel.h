@@ -1085,6 +1085,8 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
     // the sequencer's chain in the shipped library for nobody to read
     unsigned long long t_ready = 0, t_gpu = 0, t_post = 0, t_retire = 0, t_last = kTuning ? (unsigned long long)wall_clock64() : 0ull;
     auto lap = [&](unsigned long long& acc) { if (kTuning) { const unsigned long long t = wall_clock64(); acc += t - t_last; t_last = t; } };
+    unsigned long long t_sub[4] = {0, 0, 0, 0}, t_sub_last = 0;      // tuning aid: the path of a pod with GPUs, finer (ctrl[28..30]): window + pick, take, push
+    auto sub = [&](int k) { if (kTuning) { const unsigned long long t = wall_clock64(); if (k == 0) t_sub[0] += t - t_last; else t_sub[k] += t - t_sub_last; t_sub_last = t; } };
     auto take = [&](uint32_t v, bool gpu_pod) {
         if ((v >> 6) >= span) { give_up(); return; }                          // past the bit maps' reach (wave-uniform): the general kernel decides this batch
         if (lane == 0) {
@@ -1122,8 +1124,11 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, l);
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), l);
                 const uint32_t v = (wbase + (uint32_t)l) * 64u + (uint32_t)__builtin_ctzll(((uint64_t)hi << 32) | lo);
+                sub(0);
                 take(v, true);
+                sub(1);
                 push(kItemValid | ((unsigned long long)mine << 32) | v);
+                sub(2);
                 placed = true;
             }
             if (!placed) not_placed(mine);
@@ -1172,6 +1177,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         q.ctrl[4] = s_cnt[0]; q.ctrl[5] = s_cnt[1]; q.ctrl[6] = s_cnt[2]; q.ctrl[7] = s_cnt[3]; q.ctrl[8] = s_cnt[4]; q.ctrl[14] = s_cnt[5]; q.ctrl[15] = c_redo;
         q.ctrl[9] = (uint32_t)t_ready; q.ctrl[10] = (uint32_t)t_gpu; q.ctrl[11] = (uint32_t)t_post; q.ctrl[12] = (uint32_t)t_retire;
         if (kTuning) for (int k = 0; k < 16; ++k) q.ctrl[16 + k] = s_cnt[8 + k];
+        if (kTuning) for (int k = 0; k < 3; ++k) q.ctrl[28 + k] = (uint32_t)t_sub[k];      // (t_acc[12..14] of the speculators are not in use)
         wg_store(&s_done, n_pods);                                        // the fetchers run out
         const uint32_t n_items = wg_load(&s_nitems);
         __hip_atomic_store(&q.ctrl[1], (n_items < q.queue_len ? n_items : q.queue_len) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the workers leave once the queue is drained
