@@ -431,7 +431,9 @@ def roofline(st, fit_ms, achieved, traffic, traffic_source, valu, counters, pipe
     bound = "hbm" if top == "hbm" and known[top] >= 0.5 else ("latency" if not known or known[top] < 0.5 else top)
     wall = None if not ms_per_step else st.bytes_last / (ms_per_step * 1e-3) / 1e9
     per_launch = st.bytes_last / (fit_ms * 1e-3) / 1e9 if fit_ms > 0 else 0.0
-    return {"bound": bound, "priced_against": "hbm", "kernel": "k_step", "achieved": per_launch, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # `bound` names the roofline the kernel is priced against - the contract offers "hbm" | "mfma", and this is byte / integer work with no
+    # matrix arithmetic; which unit actually limits the launch (none above half of its peak: latency) is `limiter` / `limited_by`
+    return {"bound": "hbm", "limiter": bound, "priced_against": "hbm", "kernel": "k_step", "achieved": per_launch, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": per_launch / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": int(st.bytes_last), "kernel_ms": fit_ms, "concurrency": pipes,
             "frac_kernel": per_launch / HBM_PEAK_GBS,

@@ -2322,7 +2322,19 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
     static const uint32_t force_span = tune_env("NHDFIT_SEQ_SPAN") ? (uint32_t)atoi(tune_env("NHDFIT_SEQ_SPAN")) : 0u;   // tuning aid (tests of the fallback)
     if (force_span && force_span < span) span = force_span;
     const size_t dyn_base = 2 * lds_slice((size_t)span * 8) + dyn_fixed;
-    bool fast = !c->seq_general && span > 0 && c->n > 0 && P < (1u << 26);
+    bool any_g4 = false;                                        // (four-group pods: the instantiation that carries the generic set model)
+    for (uint32_t i = 0; i < P && !any_g4; ++i) any_g4 = reqs[i].n_groups > 3;
+    // What the block may ask for is the CU's 160 KB less the kernel's own static LDS (read from the code object: it moves with every edit
+    // of seq2_kernel.h - the optional tables were once admitted against fixed marks that assumed 45 KB of it and a batch whose tables all
+    // fitted those marks was refused by hipFuncSetAttribute, found by tools/soak_mode_b_gpu.py).
+    static size_t decide_static[2] = {0, 0};
+    if (!decide_static[any_g4]) {
+        hipFuncAttributes fa;
+        HIPCHK(c, hipFuncGetAttributes(&fa, any_g4 ? (const void*)k_decide<true> : (const void*)k_decide<false>));
+        decide_static[any_g4] = fa.sharedSizeBytes ? fa.sharedSizeBytes : 1;
+    }
+    const size_t dyn_room = decide_static[any_g4] < 160 * 1024 ? 160 * 1024 - decide_static[any_g4] : 0;
+    bool fast = !c->seq_general && span > 0 && c->n > 0 && P < (1u << 26) && dyn_base <= dyn_room;
     if (fast) {
         queue_len = P * 4u;                                     // a commit per pod + up to three patch items per commit of a GPU-less pod
         HIPCHK(c, c->seq_queue.reserve(queue_len));
@@ -2344,12 +2356,11 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
         size_t dyn = dyn_base;
         const size_t sig_bytes = lds_slice(((size_t)c->sig_mask + 1) * 8) + lds_slice(((size_t)c->sig_mask + 1) * 4);
         const size_t st_bytes = lds_slice((size_t)c->st_n * 8) + lds_slice((size_t)c->st_n * 32) + lds_slice(256 * 4);
-        if (dyn + sig_bytes <= 96 * 1024) { qa.lds_sigs = 1; dyn += sig_bytes; }
-        if (c->use_set_states && c->st_n && dyn + st_bytes <= 96 * 1024) { qa.lds_states = 1; dyn += st_bytes; }
-        if (c->use_choose_tab && dyn + lds_slice(kChooseEntries) <= 112 * 1024) { qa.lds_choose = 1; dyn += lds_slice(kChooseEntries); }
-        bool any_g4 = false;                                    // (four-group pods: the instantiation that carries the generic set model)
-        for (uint32_t i = 0; i < P && !any_g4; ++i) any_g4 = reqs[i].n_groups > 3;
-        HIPCHK(c, hipFuncSetAttribute(any_g4 ? (const void*)k_decide<true> : (const void*)k_decide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));   // (static: ~45 KB of the 160)
+        const size_t room96 = dyn_room < 96 * 1024 ? dyn_room : 96 * 1024, room112 = dyn_room < 112 * 1024 ? dyn_room : 112 * 1024;
+        if (dyn + sig_bytes <= room96) { qa.lds_sigs = 1; dyn += sig_bytes; }
+        if (c->use_set_states && c->st_n && dyn + st_bytes <= room96) { qa.lds_states = 1; dyn += st_bytes; }
+        if (c->use_choose_tab && dyn + lds_slice(kChooseEntries) <= room112) { qa.lds_choose = 1; dyn += lds_slice(kChooseEntries); }
+        HIPCHK(c, hipFuncSetAttribute(any_g4 ? (const void*)k_decide<true> : (const void*)k_decide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         static const uint32_t workers = tune_env("NHDFIT_SEQ_WORKERS") ? (uint32_t)atoi(tune_env("NHDFIT_SEQ_WORKERS")) : (uint32_t)kWorkerBlocks;   // tuning aid
         if (any_g4) LAUNCH(c, k_decide<true>, dim3(1 + (workers ? workers : 1u)), dim3(64 * kDecideWaves), dyn, sm, qa);
         else LAUNCH(c, k_decide<false>, dim3(1 + (workers ? workers : 1u)), dim3(64 * kDecideWaves), dyn, sm, qa);

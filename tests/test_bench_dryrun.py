@@ -64,7 +64,7 @@ def test_bench_json_contract(tmp_path):
     assert out["mode_b"]["decisions_per_s"] > 0 and out["mode_b"]["placed"] > 0       # decisions under commit semantics
     assert out["end_to_end"]["evals_per_s"] > 0 and out["single_find"]["ms_per_call_median"] > 0
     assert out["score_only"]["evals_per_s"] > 0 and out["deltas"]["mirror_restored"] and out["deltas"]["deltas_per_s"] > 0
-    assert out["roofline"]["bound"] in ("hbm", "lds", "valu", "latency") and out["roofline"]["priced_against"] == "hbm"
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["limiter"] in ("hbm", "lds", "valu", "latency") and out["roofline"]["priced_against"] == "hbm"
     assert "limited_by" in out["roofline"] and "traffic_source" in out["roofline"]
     par = out["mode_b"]["parity"]
     assert par["identical"] and par["pods_checked"] == 96 and out["mode_b"]["commits_that_would_raise"] == 0
