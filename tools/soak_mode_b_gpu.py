@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Soak of mode B's decision engine on the device (`python tools/soak_mode_b_gpu.py <seeds> [first]` on a GPU box): BASELINE configs 2..5
-drawn with other seeds at random sizes (500..24 000 nodes, 100..3 000 pods) through nhdfit_schedule_batch(apply) against the independent
+drawn with other seeds at random sizes (500..24 000 nodes, 100..3 000 pods; every fourth seed a SMALL cluster of 20..400 nodes that fills
+up long before the pods run out; every fifth seed with nine nodes in ten under maintenance, so that the decision engine's windows run dry;
+every third seed decides the batch once without applying it first - the undo path - and then for good) through nhdfit_schedule_batch(apply) against the independent
 oracle (oracle/seq_oracle.py: C scan + C commit, Python set-order mapping) - node, mapping and physical ids of every pod, the mirror of
 every node that received one (tests/test_gpu_parity.mode_b_against_seq_oracle).  A batch in which the oracle meets a commit the
 reference raises on is cut in front of that pod."""
@@ -21,7 +23,12 @@ for seed in range(first, first + n_seeds):
     cfg = int(rng.choice([2, 3, 4, 5]))
     n = int(rng.integers(500, 24000))
     P = int(rng.integers(100, 3000))
+    if seed % 4 == 1:
+        n = int(rng.integers(20, 400))
     spec = synth.make_cluster(cfg, n_nodes=n, seed=7000 + seed)
+    if seed % 5 == 2:
+        keep = rng.random(n) < 0.1
+        spec.maintenance[:] = ~keep
     pods, groups = synth.make_pods(cfg, n_pods=P, seed=7000 + seed)
     tops = [refmodel.make_topology(s) for s in pods]
     # where would the reference raise?  (the oracle alone, on its own copy)
@@ -40,8 +47,12 @@ for seed in range(first, first + n_seeds):
     eng.set_dictionary(pk)
     eng.upload(table)
     try:
+        if seed % 3 == 0:                                    # decided, undone (apply=False), then decided again below: the mirror must be back where it was
+            dry = eng.schedule_batch(reqs, spec.clock_now, pk, apply=False)
         placed, distinct = mode_b_against_seq_oracle(spec, pods, groups, eng, pk, reqs, tops, spec.clock_now)
         pods_total += len(tops); placed_total += placed
+        if seed % 3 == 0:
+            assert placed == int((np.asarray(dry[0]) >= 0).sum()), "the dry run placed another number of pods"
     except AssertionError as e:
         bad += 1
         print("MISMATCH seed", seed, "config", cfg, "nodes", n, "pods", len(tops), str(e)[:300], flush=True)
