@@ -2376,6 +2376,7 @@ int nhdfit_schedule_batch(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, dou
                     ctl[1] ? ctl[1] - 1 : 0, ctl[4], ctl[5], ctl[6], ctl[7], ctl[8], ctl[14], ctl[15]);
             fprintf(stderr, "[nhdfit] k_decide sequencer: waiting for fetchers %.2f ms, pods with GPUs %.2f ms, GPU-less pods: waiting for their speculators %.2f ms, "
                             "validation %.2f ms\n", ctl[9] * 1e-5, ctl[10] * 1e-5, ctl[11] * 1e-5, ctl[12] * 1e-5);
+            fprintf(stderr, "[nhdfit] k_decide fetcher 0: waiting for list entries / windows %.2f ms, for the ring %.2f ms, issue + park %.2f ms\n", ctl[2] * 1e-5, ctl[3] * 1e-5, ctl[13] * 1e-5);
             fprintf(stderr, "[nhdfit] k_decide sequencer, a pod with GPUs: window + pick %.2f ms, take %.2f ms, queue entry %.2f ms\n", ctl[28] * 1e-5, ctl[29] * 1e-5, ctl[30] * 1e-5);
             fprintf(stderr, "[nhdfit] k_decide speculators, finer: candidate pick %.2f ms, pre-checks %.2f ms, NIC bits %.2f ms, (mapping = verification), before post %.2f ms, "
                             "post + first-touch + result %.2f ms, (summary = stage 1)\n", ctl[23] * 1e-5, ctl[24] * 1e-5, ctl[25] * 1e-5, ctl[26] * 1e-5, ctl[27] * 1e-5);

@@ -762,10 +762,15 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
         constexpr uint32_t kFetchChunk = NHDFIT_FETCH_CHUNK;
         static_assert(kFetchChunk <= 64 && kFetchChunk % (2 * kFetchBatch) == 0, "two batches of eight in flight per chunk");
         struct Batch { uint32_t e[kFetchBatch], pos[kFetchBatch], from[kFetchBatch]; uint64_t w[kFetchBatch]; };
+        // tuning aid (ctrl[2], [3], [13]; 100 MHz ticks): the fetcher's time by what it waits for - [2] list entries and the first windows of a chunk
+        // (global round trips nothing else covers), [3] the ring (the sequencer has to leave a slot), [13] everything else (issue + park)
+        unsigned long long f_acc[3] = {0, 0, 0}, f_last = kTuning ? (unsigned long long)wall_clock64() : 0ull;
+        auto flap = [&](int k) { if (kTuning) { const unsigned long long t = wall_clock64(); f_acc[k] += t - f_last; f_last = t; } };
         for (uint32_t j0 = fid * kFetchChunk; j0 < q.n_g; j0 += kFetchWaves * kFetchChunk) {
             const uint32_t cnt = q.n_g - j0 < kFetchChunk ? q.n_g - j0 : kFetchChunk;
             uint4 ent = make_uint4(0, 0, kNoNode, 0);
             if (lane < cnt) ent = q.ent_g[j0 + lane];
+            if (kTuning) { flap(2); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); flap(0); }
             // entries k0 .. k0 + 7: their first windows requested (one load instruction each, all in flight together)
             auto issue = [&](uint32_t k0, Batch& t) {
 #pragma unroll
@@ -785,10 +790,12 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 for (uint32_t i = 0; i < kFetchBatch; ++i) {
                     if (k0 + i >= cnt) break;
                     const uint32_t e = t.e[i], slot = e % kDecideRing;
+                    flap(2);
                     for (uint32_t spin = 0; e >= wg_load(&s_done) + kDecideRing; ++spin) {
                         if (spin > kSpinLimit || wg_load(&s_abort)) return false;
                         __builtin_amdgcn_s_sleep(2);
                     }
+                    flap(1);
                     int32_t have = 0;
                     uint32_t wb = t.from[i] >> 6;
                     if (t.from[i] != kNoNode) {
@@ -813,6 +820,7 @@ __global__ __launch_bounds__(64 * kDecideWaves) void k_decide(DecideArgs q) {
                 if (k0 + kFetchBatch < cnt && !park(k0 + kFetchBatch, bb)) return;
             }
         }
+        if (kTuning && lane == 0 && fid == 0) { flap(2); q.ctrl[2] = (uint32_t)f_acc[0]; q.ctrl[3] = (uint32_t)f_acc[1]; q.ctrl[13] = (uint32_t)f_acc[2]; }
         return;
     }
 
