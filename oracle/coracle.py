@@ -173,6 +173,10 @@ class Cluster:
 
     def find(self, pods, now, want_feas=True, threads=1):
         L = lib()
+        try:                                                 # never more threads than this process may run on (a container's CPU set)
+            threads = max(1, min(int(threads), len(os.sched_getaffinity(0))))
+        except (AttributeError, OSError):
+            threads = max(1, int(threads))
         os.environ["OMP_NUM_THREADS"] = str(threads)
         try:
             ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))

@@ -37,16 +37,32 @@ from . import nhd_oracle as O
 _proto_done = False
 
 
+def scan_threads() -> int:
+    """Threads for the first-feasible scan: it hands out 256-node blocks in ascending order and stops at the first hit, so a handful is
+    all it can use - a parallel region over every core of a 256-core host costs more to start than the scan itself - and never more
+    than this process may run on."""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    return int(max(1, min(16, usable)))
+
+
+def set_scan_threads():
+    """(Re)set the OpenMP thread count for the scan.  Called at the start of every sequence, not once per process: coracle.find(threads=N)
+    sets the count for the whole library, and a sequence that follows a 256-thread snapshot find in the same process would otherwise
+    open a 256-thread parallel region twice per pod (found when a new test put such a find in front of the mode-B tests: 8 x slower)."""
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(scan_threads())
+    except OSError:
+        pass
+
+
 def _lib():
     global _proto_done
     L = coracle.lib()
     if not _proto_done:
-        # the scan hands out 256-node blocks in ascending order and stops at the first hit: a handful of threads is all it can
-        # use; a parallel region over every core of a 256-core host costs more to start than the scan itself
-        try:
-            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(min(16, os.cpu_count() or 1)))
-        except OSError:
-            pass
+        set_scan_threads()
         L.oracle_first_feasible.restype = ctypes.c_int64
         L.oracle_first_feasible.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
         L.oracle_commit.restype = ctypes.c_int
@@ -132,6 +148,8 @@ def schedule_sequence(sc: SeqCluster, tops, pod_groups, now: float, stop_at_rais
     physical ids or None per pod, n_defined): pods [0, n_defined) are decided under defined reference behaviour; the first
     pod whose commit the reference would raise on ends the sequence (its unwind path is itself broken)."""
     pods = sc.c.pods_from_tops(tops, pod_groups)
+    _lib()
+    set_scan_threads()
     winners: List[int] = []
     maps: List[Optional[dict]] = []
     ids_all: List[Optional[dict]] = []
