@@ -390,7 +390,10 @@ struct alignas(16) NodeRec {
     uint16_t w0, w1, x0, x1;          // WC records of socket 0 / 1, X rows of NUMA 0 / 1   (offset / 8)
     uint16_t gx;                      // GX row (offset / 8)
     uint16_t hp;                      // bits 0..9: HP row INDEX (clamped to the batch's rows in the kernel); bits 10..15: the node's position in its chunk
-    uint16_t flags;                   // kRecNoGpu
+    uint16_t flags;                   // bit 0: kRecNoGpu; bits 1..15 (round 6): the node's row of the pair table C for the dimension the records were
+                                      // last written for (pair_c_row; 0 = not written for any) - the pipelined sweep reads its C row's address
+                                      // with one AND and one shift instead of ten instructions of min / multiply-add on `cc`, when the launch's
+                                      // dimension is that one (FitArgs::crow_ok); `cc` stays what every other reader uses
     uint16_t cc;                      // free physical cores socket 0 | socket 1 << 7 | SMT << 14
 };
 static_assert(sizeof(NodeRec) == 16, "one 16-byte load per node");
@@ -399,7 +402,8 @@ constexpr uint16_t kRecNoGpu = 1;
 NHD_HD uint32_t rec_hp(const NodeRec& r) { return r.hp & 1023u; }
 NHD_HD uint32_t rec_pos(const NodeRec& r) { return r.hp >> 10; }
 
-NHD_HD NodeRec make_record(const NodeIdx& n, uint32_t x0, uint32_t x1, const Layout& L, uint32_t pos) {
+NHD_HD uint32_t pair_c_row(uint32_t cc, uint32_t D);
+NHD_HD NodeRec make_record(const NodeIdx& n, uint32_t x0, uint32_t x1, const Layout& L, uint32_t pos, uint32_t crow_D = 0) {
     NodeRec r;
     r.w0 = (uint16_t)((L.hot_wc0 + n.w0 * L.wc_stride) >> 3);
     r.w1 = (uint16_t)((L.hot_wc1 + n.w1 * L.wc_stride) >> 3);
@@ -410,6 +414,7 @@ NHD_HD NodeRec make_record(const NodeIdx& n, uint32_t x0, uint32_t x1, const Lay
     r.flags = (uint16_t)(n.nogpu ? kRecNoGpu : 0);
     const uint32_t smt = n.w0 >= L.fc_dim ? 1u : 0u;                       // node_index: w = smt * fc_dim + free cores
     r.cc = (uint16_t)((n.w0 - smt * L.fc_dim) | (n.w1 - smt * L.fc_dim) << 7 | smt << 14);
+    if (crow_D) r.flags = (uint16_t)(r.flags | pair_c_row(r.cc, crow_D) << 1);           // (2 D^2 <= 2 * 65^2 rows: 14 bits)
     return r;
 }
 NHD_HD NodeRec dead_record(const Layout& L, uint32_t pos) {      // lanes past the end of the mirror: GX row 0 = never

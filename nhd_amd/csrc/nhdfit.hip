@@ -210,6 +210,8 @@ struct nhdfit_ctx {
     // tiles of that width, and what refresh_layouts makes of it - table dimension D (0: off)
     uint32_t max_demand[2] = {0, 0};
     uint32_t pair_D[2] = {0, 0};
+    uint32_t crow_D[2] = {0, 0};          // pair-table dimensions the records' C rows (NodeRec::flags) are written for; crow_stale: a staged
+    bool crow_stale = false;              // batch of more than a tile asks for others - k_xcrow rewrites them in front of its first step
     bool pair_rows = !(tune_env("NHDFIT_PAIR") && atoi(tune_env("NHDFIT_PAIR")) == 0);   // tuning aid: NHDFIT_PAIR=0 keeps the six-fetch sweep
 
     // requests / results
@@ -892,6 +894,9 @@ int stage_requests(nhdfit_ctx* c, const nhdfit_req* reqs, uint32_t P, bool defer
     // a node's C row depends on the pair table's dimension: a batch that changes it has the chunks' records dealt to the lanes again
     // (ensure_records, in front of the batch's first step) - a full tile and more only: smaller batches are latency, not throughput
     if (P > (uint32_t)kTile && (c->pair_D[0] != c->order_D[0] || c->pair_D[1] != c->order_D[1])) c->ord_all = true;
+    // ... and so does the row itself, which the records carry ready-made (NodeRec::flags): rewritten likewise (k_xcrow); a smaller batch
+    // of another dimension sweeps six rows per pair of assignments meanwhile (FitArgs::crow_ok = 0)
+    if (P > (uint32_t)kTile && (c->pair_D[0] != c->crow_D[0] || c->pair_D[1] != c->crow_D[1])) c->crow_stale = true;
     return NHDFIT_OK;
 }
 }  // namespace
@@ -929,17 +934,31 @@ int ensure_records(nhdfit_ctx* c) {
     const uint32_t all_chunks = (c->n + 63) / 64;
     // dealing the records to the lanes pays where the fit role is more than a launch: from 128 chunks on
     const bool deal = c->lane_order && all_chunks >= 128;
+    // the C rows the records carry, for the staged batch's pair-table dimensions: every record's flags word (unless all records are
+    // about to be written anyway) - in front of whatever else rewrites records, which then writes for the new dimensions too
+    const bool crow = c->crow_stale;
+    if (crow) { c->crow_D[0] = c->pair_D[0]; c->crow_D[1] = c->pair_D[1]; c->crow_stale = false; }
+    auto rewrite_crows = [&]() -> int {
+        if (!c->n || c->rec_all || !c->rec[0].p || !c->rec[1].p) return NHDFIT_OK;
+        CrowArgs k;
+        k.rec[0] = c->rec[0].p; k.rec[1] = c->rec[1].p; k.npad = (c->n + 63) & ~63u; k.D[0] = c->crow_D[0]; k.D[1] = c->crow_D[1];
+        LAUNCH(c, k_xcrow, dim3((k.npad + 255) / 256), dim3(256), 0, c->stream, k);
+        HIPCHK(c, hipGetLastError());
+        return NHDFIT_OK;
+    };
     if (!c->rec_all && c->rec_lo == c->rec_hi) {
-        if (c->ord_all && c->n && deal) {                       // the records stand, a staged batch changed the pair table's dimension
+        if (c->n && (crow || (c->ord_all && deal))) {           // the records stand, a staged batch changed the pair table's dimension
             { int rc_ = sync_all(c); if (rc_) return rc_; }     // (steps in flight read the records)
             c->staged_gen++;
-            { int rc_ = order_chunks(c, 0, all_chunks, true); if (rc_) return rc_; }
+            if (crow) { int rc_ = rewrite_crows(); if (rc_) return rc_; }
+            if (c->ord_all && deal) { int rc_ = order_chunks(c, 0, all_chunks, true); if (rc_) return rc_; }
         }
         c->ord_all = false;
         return NHDFIT_OK;
     }
     c->staged_gen++;                                            // (its kernels run on pipe 0's stream)
     if (!c->n) { c->rec_all = false; c->rec_lo = c->rec_hi = 0; c->ord_all = false; return NHDFIT_OK; }
+    if (crow) { { int rc_ = sync_all(c); if (rc_) return rc_; } { int rc_ = rewrite_crows(); if (rc_) return rc_; } }
     const uint32_t npad = (c->n + 63) & ~63u;
     uint32_t dealt_first = 0, dealt_count = 0;
     for (int pass = 0; pass < 2; ++pass) {
@@ -958,6 +977,7 @@ int ensure_records(nhdfit_ctx* c) {
             r.rec[w] = c->rec[w].p;
             r.bt[w] = c->rec_bt[w].p;
         }
+        r.crow_D[0] = c->crow_D[0]; r.crow_D[1] = c->crow_D[1];
         const dim3 grid((count + 255) / 256), block(256);
         if (pass == 0) {
             LAUNCH(c, k_xkeys, grid, block, 0, c->stream, r);
@@ -1118,6 +1138,7 @@ void fill_digest_args(nhdfit_ctx* c, Pipe& p, int b, uint32_t wc_parts, uint32_t
 void fill_fit_args(nhdfit_ctx* c, Pipe& p, int bf, double now, FitArgs& f, bool pair = false) {
     for (int w = 0; w < 2; ++w) {
         f.pair_D[w] = pair ? c->pair_D[w] : 0u;
+        f.crow_ok[w] = pair && c->pair_D[w] != 0u && c->crow_D[w] == c->pair_D[w] && !c->crow_stale ? 1u : 0u;
         f.hot_wc1[w] = c->L[w].hot_wc1;
     }
     f.fc_dim = c->max_cores + 1;

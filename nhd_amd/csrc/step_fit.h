@@ -6,6 +6,11 @@ struct FitItem { uint32_t tile, wcls, c_begin, c_end; };
 #ifndef NHDFIT_FIT_TRACK_SKIP
 #define NHDFIT_FIT_TRACK_SKIP 1     // once every pod of the tile has its winners of a wavefront's run, the winner test of a chunk is one scalar branch
 #endif
+#ifndef NHDFIT_FIT_CROW
+#define NHDFIT_FIT_CROW 1           // the pipelined loop takes the C row's address from the record (NodeRec::flags); a launch whose records were written
+                                    // for another pair-table dimension (FitArgs::crow_ok = 0) sweeps six rows instead.  NOT a further instantiation of the
+                                    // loop: with four pipelined loops instead of two the register allocation of k_step spilled in the three-group tiles' loop
+#endif
 #ifndef NHDFIT_FIT_SWP
 #define NHDFIT_FIT_SWP 3            // bit 0: software-pipelined chunk loop for the W = 2 pair form, bit 1: for W = 4 (A/B builds: -DNHDFIT_FIT_SWP=n;
                                     // profiles/r06/fit_swp_ab.log: steady step 14.94 -> 14.34 us with both, 14.59 with the first alone)
@@ -40,6 +45,8 @@ struct FitArgs {
     // the winner scratch (W / 2 planes of 16-byte pieces).  Set for W = 2 and 4 only.
     uint32_t pair_D[2];
     uint32_t hot_wc1[2];             // where the second socket's CPU records start in the hot section
+    uint32_t crow_ok[2];             // the records' flags hold the C row for exactly pair_D (NodeRec::flags): the pipelined sweep takes the address from
+                                     // there; 0 (a small batch behind a larger one of another dimension): that width sweeps six rows this launch
     uint32_t fc_dim;
     uint32_t dbg_skip;          // tuning aid (NHDFIT_FIT_SKIP): 1 no table sweep, 2 no winner tracking, 4 constant record, 8 no predicate rows
     unsigned long long* clk;    // tuning aid (NHDFIT_FIT_PHASES): per fit block, summed and latest - [0/1] staged, [2/3] pair table derived, [4/5] sweep done,
@@ -202,7 +209,7 @@ __device__ __forceinline__ PairRows<W> fetch_pair_rows(const uint8_t* lds, const
     const uint32_t a_x0 = (rv.y & 0xFFFFu) << 3, a_x1 = (rv.y >> 16) << 3, a_gx = (rv.z & 0xFFFFu) << 3;
     const uint32_t hp = (rv.z >> 16) & 1023u;
     const uint32_t a_hp = hot_hp + (hp < hp_last ? hp : hp_last) * 8;
-    const uint32_t a_c = pair_row_addr(rv.w, pD, off_c);
+    const uint32_t a_c = NHDFIT_FIT_CROW ? off_c + ((rv.w & 0xFFFEu) << 3) : pair_row_addr(rv.w, pD, off_c);   // (row << 1 in the flags half, 16 bytes a row)
 #pragma unroll
     for (int q = 0; q < W / 2; ++q) {
         r.cp[q] = lds16(lds, a_c + q * c_plane);
@@ -481,7 +488,7 @@ __device__ __forceinline__ void role_fit(const FitArgs& a, const double busy_fro
     it.c_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_begin);
     it.c_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.c_end);
     if constexpr (!SPILL) {                          // narrow tiles whose pair table fits the launch's LDS (refresh_layouts)
-        if (it.wcls <= 1 && a.pair_D[it.wcls]) {
+        if (it.wcls <= 1 && a.pair_D[it.wcls] && (!NHDFIT_FIT_CROW || !((NHDFIT_FIT_SWP >> it.wcls) & 1) || a.crow_ok[it.wcls])) {
             if (it.wcls == 0) role_fit_w<BLOCK, 2, false, 1, (NHDFIT_FIT_SWP & 1) != 0>(a, busy_from, it, lds);
             else role_fit_w<BLOCK, 4, false, 1, (NHDFIT_FIT_SWP & 2) != 0>(a, busy_from, it, lds);
             return;

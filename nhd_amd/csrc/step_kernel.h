@@ -59,6 +59,7 @@ struct RecArgs {
     Layout L[kWClasses];
     NodeRec* rec[kWClasses];
     double* bt[kWClasses];                      // busy times beside the records, same order
+    uint32_t crow_D[2];                         // pair-table dimension the records' C rows are written for (NodeRec::flags), per narrow row width
 };
 __device__ __forceinline__ uint32_t xhash(uint64_t k) {
     k ^= k >> 33; k *= 0xFF51AFD7ED558CCDull; k ^= k >> 29;
@@ -111,7 +112,18 @@ __global__ __launch_bounds__(256) void k_xrecords(RecArgs a) {      // (first / 
     const nhdfit_plane3 q3 = a.p3[i];
     const uint32_t x0 = a.x.id[xslot_find(a.x, xkey(0, n.f0, q3.sig_numa[0], q3.sig_pci[0]))];
     const uint32_t x1 = a.x.id[xslot_find(a.x, xkey(1, n.f1, q3.sig_numa[1], q3.sig_pci[1]))];
-    for (int w = 0; w < kWClasses; ++w) { a.rec[w][i] = make_record(n, x0, x1, a.L[w], i & 63u); a.bt[w][i] = q4.busy_time; }
+    for (int w = 0; w < kWClasses; ++w) { a.rec[w][i] = make_record(n, x0, x1, a.L[w], i & 63u, w < 2 ? a.crow_D[w] : 0u); a.bt[w][i] = q4.busy_time; }
+}
+// the records' C rows for another pair-table dimension (a staged batch changed it): the flags word of every record of the two narrow widths
+struct CrowArgs { NodeRec* rec[2]; uint32_t npad; uint32_t D[2]; };
+__global__ __launch_bounds__(256) void k_xcrow(CrowArgs a) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.npad) return;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        NodeRec* r = a.rec[w] + i;
+        r->flags = (uint16_t)((r->flags & kRecNoGpu) | (a.D[w] ? pair_c_row(r->cc, a.D[w]) << 1 : 0u));
+    }
 }
 
 // ---- lane order of a chunk (fit_core.h NodeRec "LANE ORDER") ----------------------------------------------------------------

@@ -142,7 +142,9 @@ int hh_find(const nhdfit_plane0* p0, const nhdfit_plane1* p1, const nhdfit_plane
                 const uint32_t i = c * 64 + l;
                 const bool busy = p4[i].busy_time >= busy_from;
                 if (busy != ((now - p4[i].busy_time) < kMinBusySecs)) ++mismatches;      // the threshold form of IsBusy
-                const NodeRec rec = make_record(nidx[i], x0[i], x1[i], L, l);
+                const NodeRec rec = make_record(nidx[i], x0[i], x1[i], L, l, pair_D);
+                // the C row the record carries ready-made (NodeRec::flags, round 6) is the row the free-core counts name, and the flag beside it is intact
+                if ((uint32_t)(rec.flags >> 1) != pair_c_row(rec.cc, pair_D) || (bool)(rec.flags & kRecNoGpu) != (bool)nidx[i].nogpu) ++mismatches;
                 fm[l] = node_word_hot(img.data() + L.off_hot, L, rec, busy, m_need);
                 if (fm[l] != node_word_cold(img.data(), L, nidx[i], p3[i], busy, m_need, m_pci)) ++mismatches;
                 if (fm[l] != node_word_pair(img.data() + L.off_hot, L, rec, pair_D, busy, m_need)) ++mismatches;
