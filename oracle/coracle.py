@@ -46,6 +46,31 @@ def lib():
     return _lib
 
 
+def usable_cpus() -> int:
+    """CPUs this process may really use: its affinity set, cut down by a cgroup CPU quota if there is one (a container on a 256-core
+    host may be allowed a few cores' worth of time; OpenMP teams sized by os.cpu_count() then spend their time spinning)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts and parts[0] != "max":
+                    n = min(n, max(1, -(-int(parts[0]) // int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, -(-quota // int(f2.read().split()[0]))))
+            break
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+    return max(1, n)
+
+
 class GroupIds:
     def __init__(self):
         self.ids = {}
@@ -173,10 +198,7 @@ class Cluster:
 
     def find(self, pods, now, want_feas=True, threads=1):
         L = lib()
-        try:                                                 # never more threads than this process may run on (a container's CPU set)
-            threads = max(1, min(int(threads), len(os.sched_getaffinity(0))))
-        except (AttributeError, OSError):
-            threads = max(1, int(threads))
+        threads = max(1, min(int(threads), usable_cpus()))   # never more threads than this process may run on (CPU set, cgroup quota)
         os.environ["OMP_NUM_THREADS"] = str(threads)
         try:
             ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))

@@ -41,11 +41,7 @@ def scan_threads() -> int:
     """Threads for the first-feasible scan: it hands out 256-node blocks in ascending order and stops at the first hit, so a handful is
     all it can use - a parallel region over every core of a 256-core host costs more to start than the scan itself - and never more
     than this process may run on."""
-    try:
-        usable = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        usable = os.cpu_count() or 1
-    return int(max(1, min(16, usable)))
+    return int(max(1, min(16, coracle.usable_cpus())))
 
 
 def set_scan_threads():
