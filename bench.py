@@ -756,7 +756,7 @@ def mode_b_parity(spec, tops, pod_groups, now, reqs, node, maps, places, status)
     return {"identical": True, "pods_checked": n_def, "pods": len(tops), "defined_prefix": n_def,
             "checked": "node, NUMA mapping, NIC choice and physical core / GPU ids of every pod",
             "oracle": "oracle/seq_oracle.py (C scan + C commit over flat records, Python set-order mapping of the winner), "
-                      f"{secs:.1f} s on {os.cpu_count()} host cores",
+                      f"{secs:.1f} s on {coracle.usable_cpus()} host cores",
             "note": "pods past defined_prefix follow a commit the reference itself raises on (none in this batch)" if n_def < len(tops) else
                     "the reference raises on no commit of this batch: the whole batch is defined"}
 
@@ -820,7 +820,7 @@ def cpu_baseline(spec, tops, pod_groups, sample, gpu_score, base, winner_index, 
     if not np.array_equal(gpu_winner, winner):
         raise SystemExit("PARITY FAILURE: GPU winners differ from the CPU port on the sampled pods")
     # the same sample on every host core (OpenMP over pods), for scale: the primary figure stays the 1-core one
-    ncores = os.cpu_count() or 1
+    ncores = coracle.usable_cpus()                        # the cores this process may really use (CPU set, cgroup quota): the count the record states
     many = None
     if ncores > 1:
         t0 = time.perf_counter()
